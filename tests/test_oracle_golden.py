@@ -1,0 +1,119 @@
+"""Pin the CPU oracle (oracle/cvig_fov_oracle.py) to outputs of the reference itself
+(tests/golden/*.npz, produced by tests/golden/gen_golden.py from /root/reference)."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import cvig_fov_oracle as O
+from witw_amd import synth
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def _tw(weights):
+    return {k: (torch.from_numpy(w), torch.from_numpy(b)) for k, (w, b) in weights.items()}
+
+
+def test_polar_transform_bit_exact(golden_dir):
+    g = _load(golden_dir, 'polar.npz')
+    img = torch.from_numpy(synth.normalized_images(int(g['seed']), int(g['stream']), (3, 256, 256)))
+    out = O.polar_transform(img)
+    assert out.shape == (3, 128, 512) and out.dtype == torch.float32
+    np.testing.assert_array_equal(out[:, ::8, :].numpy(), g['polar_rows'])
+    assert out.double().sum().item() == float(g['polar_sum'])
+    assert out.double().abs().sum().item() == float(g['polar_abs_sum'])
+    # the two samples whose clipped taps have all-zero weights (reference behaviour, kept)
+    for (y, x), v in zip(g['zero_taps'], g['zero_vals']):
+        np.testing.assert_array_equal(out[:, y, x].numpy(), v)
+        assert np.all(v == 0)
+
+
+def test_normalization_bit_exact(golden_dir):
+    g = _load(golden_dir, 'normalize.npz')
+    raw5 = torch.from_numpy(g['raw5'])
+    np.testing.assert_array_equal(O.image_normalization(raw5[:3]).numpy(), g['norm3'])
+    np.testing.assert_array_equal(O.image_normalization_semantic(raw5).numpy(), g['norm5'])
+
+
+def test_encoder_eval_matches_reference(golden_dir):
+    g = _load(golden_dir, 'encoder.npz')
+    seed = int(g['seed'])
+    w = _tw(synth.fov_dsm_weights(seed))
+    x360 = torch.from_numpy(synth.normalized_images(seed, 10, (2, 3, 128, 512)))
+    x70 = torch.from_numpy(synth.normalized_images(seed, 11, (2, 3, 128, 99)))
+    with torch.no_grad():
+        for circ in (False, True):
+            e360 = O.fov_dsm_forward(x360, w, circ).numpy()
+            e70 = O.fov_dsm_forward(x70, w, circ).numpy()
+            assert e360.shape == (2, 16, 4, 64) and e70.shape == (2, 16, 4, 12)
+            np.testing.assert_allclose(e360, g['embed360_circ%d' % circ], rtol=0, atol=1e-6)
+            np.testing.assert_allclose(e70, g['embed70_circ%d' % circ], rtol=0, atol=1e-6)
+
+
+def test_encoder_train_mode_injected_dropout(golden_dir):
+    g = _load(golden_dir, 'encoder.npz')
+    seed = int(g['seed'])
+    w = _tw(synth.fov_dsm_weights(seed))
+    x360 = torch.from_numpy(synth.normalized_images(seed, 10, (2, 3, 128, 512)))
+    scales = {i: torch.from_numpy(g['drop_scale_%d' % i]) for i in (17, 19, 21)}
+    assert all(0 < (s == 0).float().mean() < 0.5 for s in scales.values())
+    with torch.no_grad():
+        e = O.fov_dsm_forward(x360, w, True, dropout_scales=scales).numpy()
+    np.testing.assert_allclose(e, g['embed360_circ1_train'], rtol=0, atol=1e-6)
+
+
+def test_encoder_semantic(golden_dir):
+    g = _load(golden_dir, 'encoder_semantic.npz')
+    seed = int(g['seed'])
+    w = _tw(synth.fov_dsm_weights(seed, in_channels=5))
+    x5 = torch.from_numpy(synth.normalized_images(seed, 12, (1, 5, 128, 512)))
+    with torch.no_grad():
+        e = O.fov_dsm_forward(x5, w, True).numpy()
+    np.testing.assert_allclose(e, g['embed5_circ1'], rtol=0, atol=1e-6)
+    assert 'model.features.0.layer.weight' in set(g['trainable'])  # layer 0 unfrozen, cvig_semantic.py:308
+
+
+def test_matching_and_loss(golden_dir):
+    g = _load(golden_dir, 'matching.npz')
+    seed = int(g['seed'])
+    for tag in 'abcde':
+        bo, bs, we = (int(v) for v in g['%s_shape' % tag])
+        ov = torch.from_numpy(synth.embeddings(seed, 100 + ord(tag), (bo, 16, 4, 64))).requires_grad_(True)
+        su = torch.from_numpy(synth.embeddings(seed, 200 + ord(tag), (bs, 16, 4, we))).requires_grad_(True)
+        ori, dist = O.match(ov, su)
+        assert ori.dtype == torch.int64
+        np.testing.assert_array_equal(ori.numpy(), g['%s_orientation' % tag])
+        np.testing.assert_allclose(dist.detach().numpy(), g['%s_distance' % tag], rtol=0, atol=2e-6)
+        ori_f, dist_f = O.match_fused(ov.detach(), su.detach())
+        np.testing.assert_array_equal(ori_f.numpy(), g['%s_orientation' % tag])
+        np.testing.assert_allclose(dist_f.numpy(), g['%s_distance' % tag], rtol=0, atol=2e-6)
+        if tag == 'c':
+            np.testing.assert_array_equal(O.crop_overhead(ov.detach(), ori, we).numpy(), g['c_crop'])
+        if bo == bs:
+            loss = O.triplet_loss(dist)
+            loss.backward()
+            np.testing.assert_allclose(loss.item(), float(g['%s_loss' % tag]), rtol=1e-6)
+            np.testing.assert_allclose(ov.grad.numpy(), g['%s_grad_ov' % tag], rtol=0, atol=1e-6)
+            np.testing.assert_allclose(su.grad.numpy(), g['%s_grad_su' % tag], rtol=0, atol=1e-6)
+    dm = torch.from_numpy(g['loss_in'])
+    assert O.triplet_loss(dm).item() == float(g['loss_a10'])
+    assert O.triplet_loss(dm, alpha=3.).item() == float(g['loss_a3'])
+
+
+def test_ranking(golden_dir):
+    g = _load(golden_dir, 'ranking.npz')
+    seed = int(g['seed'])
+    for tag in ('r360', 'r70'):
+        n, we = (int(v) for v in g['%s_n_we' % tag])
+        ov = torch.from_numpy(synth.embeddings(seed, 400 + we, (n, 16, 4, 64)))
+        noise = torch.from_numpy(synth.embeddings(seed, 500 + we, (n, 16, 4, we)))
+        shifts = g['%s_shifts' % tag]
+        su = torch.stack([torch.roll(ov[i], -int(shifts[i]), dims=2)[:, :, :we] for i in range(n)]) + 1.5 * noise
+        r = O.ranks(ov, su)
+        np.testing.assert_array_equal(r, g['%s_ranks' % tag])
+        t = O.recall_table(r)
+        np.testing.assert_allclose([t['top_1'], t['top_5'], t['top_10'], t['top_1pct'], t['mean'], t['median']],
+                                   g['%s_table' % tag])

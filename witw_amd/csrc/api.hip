@@ -1,0 +1,43 @@
+// C-ABI plumbing shared by every entry point: thread-local error text, version, device probe.
+#include "common.h"
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+
+void witw_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" {
+
+const char* witw_last_error(void) { return g_err; }
+
+int witw_version(void) { return 100; }  // 0.1.0
+
+// 0 when device `dev` exists and is a gfx950 part; the message says what was found otherwise.
+int witw_device_check(int dev) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        witw_set_error("no HIP device visible");
+        return WITW_ERR_NODEVICE;
+    }
+    if (dev < 0 || dev >= n) {
+        witw_set_error("device %d out of range (%d visible)", dev, n);
+        return WITW_ERR_INVALID;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+        witw_set_error("hipGetDeviceProperties failed");
+        return WITW_ERR_NODEVICE;
+    }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        witw_set_error("device %d is %s; this library carries gfx950 code only", dev, prop.gcnArchName);
+        return WITW_ERR_NODEVICE;
+    }
+    return WITW_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,39 @@
+// Shared helpers for the WITW gfx950 kernels (HIP, CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Error convention of the C ABI (include/witw_hip.h): 0 = ok, negative = error,
+// message retrievable through witw_last_error() (thread-local).
+enum {
+    WITW_OK = 0,
+    WITW_ERR_INVALID = -1,   // bad argument / unsupported shape
+    WITW_ERR_LAUNCH = -2,    // HIP launch failure
+    WITW_ERR_NODEVICE = -3,  // no gfx950 device
+};
+
+void witw_set_error(const char* fmt, ...);
+
+#define WITW_CHECK_ARG(cond, ...)                \
+    do {                                         \
+        if (!(cond)) {                           \
+            witw_set_error(__VA_ARGS__);         \
+            return WITW_ERR_INVALID;             \
+        }                                        \
+    } while (0)
+
+#define WITW_CHECK_LAUNCH(what)                                            \
+    do {                                                                   \
+        hipError_t e_ = hipGetLastError();                                 \
+        if (e_ != hipSuccess) {                                            \
+            witw_set_error("%s: %s", what, hipGetErrorString(e_));         \
+            return WITW_ERR_LAUNCH;                                        \
+        }                                                                  \
+    } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

@@ -1,0 +1,369 @@
+// 3x3 convolution, NHWC fp32, implicit GEMM on v_mfma_f32_32x32x2_f32 (gfx950).
+//
+// Replaces, for the FOV_DSM encoder of the reference (model/cvig_fov.py:256-294):
+//   torch.nn.Conv2d(k=3, pad=1, stride (1,1)|(2,1)) [+ HorizCircPadding :212-231]
+//   [+ AddDropout :234-245] [+ ReLU] [+ MaxPool2d(2,2)]
+// as ONE kernel per conv layer: padding is a halo-load policy (zero rows, zero or
+// wrapped columns), bias / dropout-scale / ReLU / 2x2 max-pool live in the epilogue.
+//
+// Tiling (per 256-thread workgroup = 4 waves, one per SIMD):
+//   output tile  TH x TW = 4 x 64 conv-output pixels  (8 MFMA M-tiles of 32 columns)
+//   x TN output channels (64 or 128)                  (2 or 4 MFMA N-tiles of 32)
+//   K loop over input channels in chunks of 8 (two "quads" of 4 channels); per chunk
+//   the (TH-1)*SH+3 x 66 input halo tile and the 9x8xTN weight slab are staged in LDS
+//   (double buffered, register-staged one chunk ahead of the MFMAs).
+// LDS images are quad-planar ([quad][row][col] of float4 / [tap][quad][n] of float4)
+// so every ds_read_b128 of a wave covers 2 x 512 contiguous bytes (conflict free) and
+// yields the operands of 4 MFMA k-steps: MFMA step j takes channel j of quad 0 from
+// lanes 0-31 and channel j of quad 1 from lanes 32-63 (A and B agree on that order).
+#include "common.h"
+
+namespace {
+
+constexpr int TH = 4;
+constexpr int TW = 64;
+constexpr int IW = TW + 2;
+constexpr int NTHREADS = 256;
+
+struct ConvArgs {
+    const float* x;         // [B,H,W,Cin] NHWC, Cin % 8 == 0
+    const float* wpk;       // packed: [n_tile][cin/8][tap][quad][TN][4]
+    const float* bias;      // [n_tiles*TN] (zero padded)
+    const float* dropmask;  // [B,Cout] scale (0 or 1/(1-p)) or nullptr
+    float* y;               // NHWC [B,Hy,Wy,Cout] or NCHW [B,Cout,Hy,Wy]
+    int B, H, W, Cin, Cout;
+    int Ho, Wo;             // conv output size (before pooling)
+    int tiles_x, tiles_y;
+    int circ, relu, out_nchw;
+};
+
+template <int TN, int SH, bool POOL>
+__global__ __launch_bounds__(NTHREADS) void conv3x3_nhwc_f32_kernel(ConvArgs p) {
+    constexpr int IH = (TH - 1) * SH + 3;
+    constexpr int IN_F4 = 2 * IH * IW;          // float4 slots of one input stage
+    constexpr int W_F4 = 9 * 2 * TN;            // float4 slots of one weight stage
+    constexpr int STAGE_F4 = IN_F4 + W_F4;
+    constexpr int NIN = (IN_F4 + NTHREADS - 1) / NTHREADS;
+    constexpr int NWT = (W_F4 + NTHREADS - 1) / NTHREADS;
+    constexpr int WGM = (TN == 128) ? 2 : 4;    // waves along M
+    constexpr int WM = 8 / WGM;                 // M-tiles per wave
+    constexpr int WN = 2;                       // N-tiles per wave (64 channels)
+
+    __shared__ f32x4 smem[2 * STAGE_F4];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int l31 = lane & 31;
+    const int hq = lane >> 5;
+
+    // ---- block -> (n tile, image, spatial tile); n tile slowest so that the blocks in
+    // flight share one weight slab (L2 resident) while input tiles stream.
+    int bid = blockIdx.x;
+    const int tiles_img = p.tiles_x * p.tiles_y;
+    const int per_n = p.B * tiles_img;
+    const int ntile = bid / per_n;
+    bid -= ntile * per_n;
+    const int b = bid / tiles_img;
+    bid -= b * tiles_img;
+    const int ty = bid / p.tiles_x;
+    const int tx = bid - ty * p.tiles_x;
+    const int oy0 = ty * TH;
+    const int ox0 = tx * TW;
+    const int n0 = ntile * TN;
+    const int nkc = p.Cin >> 3;
+
+    // ---- per-thread staging descriptors (constant over the K loop)
+    const float* gin[NIN];
+    bool gok[NIN];
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) {
+        const int s = tid + i * NTHREADS;
+        const int pix = s >> 1, q = s & 1;
+        const int r = pix / IW, c = pix - r * IW;
+        const int gr = oy0 * SH - 1 + r;
+        int gc = ox0 - 1 + c;
+        bool ok = (s < IN_F4) && gr >= 0 && gr < p.H;
+        if (p.circ) {
+            gc %= p.W;
+            if (gc < 0) gc += p.W;
+        } else {
+            ok = ok && gc >= 0 && gc < p.W;
+        }
+        gok[i] = ok;
+        const size_t off = ok ? ((size_t)((size_t)b * p.H + gr) * p.W + gc) * p.Cin + q * 4 : 0;
+        gin[i] = p.x + off;
+    }
+    const f32x4* gw = reinterpret_cast<const f32x4*>(p.wpk) + (size_t)ntile * nkc * W_F4 + tid;
+
+    f32x4 rin[NIN], rw[NWT];
+    auto load_stage = [&](int kc) {
+#pragma unroll
+        for (int i = 0; i < NIN; ++i) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (gok[i]) v = *reinterpret_cast<const f32x4*>(gin[i] + (size_t)kc * 8);
+            rin[i] = v;
+        }
+        const f32x4* w = gw + (size_t)kc * W_F4;
+#pragma unroll
+        for (int i = 0; i < NWT; ++i) {
+            if (NWT * NTHREADS == W_F4 || tid + i * NTHREADS < W_F4) rw[i] = w[i * NTHREADS];
+        }
+    };
+    auto store_stage = [&](int buf) {
+        f32x4* in_s = smem + buf * STAGE_F4;
+        f32x4* w_s = in_s + IN_F4;
+#pragma unroll
+        for (int i = 0; i < NIN; ++i) {
+            const int s = tid + i * NTHREADS;
+            if (NIN * NTHREADS == IN_F4 || s < IN_F4) in_s[(s & 1) * (IH * IW) + (s >> 1)] = rin[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NWT; ++i) {
+            const int s = tid + i * NTHREADS;
+            if (NWT * NTHREADS == W_F4 || s < W_F4) w_s[s] = rw[i];
+        }
+    };
+
+    // ---- wave -> M-tiles / N-tiles
+    const int wm = (WGM == 2) ? (wave >> 1) : wave;
+    const int wn = (WGM == 2) ? (wave & 1) : 0;
+    int trow[WM], tcol[WM];  // tile row in [0,TH), tile column base in {0,32}
+#pragma unroll
+    for (int mt = 0; mt < WM; ++mt) {
+        if (WGM == 2) {
+            trow[mt] = 2 * wm + (mt >> 1);
+            tcol[mt] = 32 * (mt & 1);
+        } else {
+            trow[mt] = 2 * (wm >> 1) + mt;
+            tcol[mt] = 32 * (wm & 1);
+        }
+    }
+    int abase[WM];
+#pragma unroll
+    for (int mt = 0; mt < WM; ++mt) abase[mt] = hq * (IH * IW) + trow[mt] * SH * IW + tcol[mt] + l31;
+    const int wbase = hq * TN + wn * 64 + l31;
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < WN; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    load_stage(0);
+    store_stage(0);
+    __syncthreads();
+
+    for (int kc = 0; kc < nkc; ++kc) {
+        const int cur = kc & 1;
+        if (kc + 1 < nkc) load_stage(kc + 1);
+        const f32x4* in_s = smem + cur * STAGE_F4;
+        const f32x4* w_s = in_s + IN_F4;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int kh = tap / 3, kw = tap - kh * 3;
+            f32x4 a[WM], bq[WN];
+#pragma unroll
+            for (int mt = 0; mt < WM; ++mt) a[mt] = in_s[abase[mt] + kh * IW + kw];
+#pragma unroll
+            for (int nt = 0; nt < WN; ++nt) bq[nt] = w_s[tap * 2 * TN + wbase + nt * 32];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < WN; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][j], bq[nt][j], acc[mt][nt], 0, 0, 0);
+        }
+        if (kc + 1 < nkc) store_stage(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias, dropout scale, ReLU, optional 2x2 max pool, store
+    float bv[WN], dm[WN];
+    int nch[WN];
+#pragma unroll
+    for (int nt = 0; nt < WN; ++nt) {
+        nch[nt] = n0 + wn * 64 + nt * 32 + l31;
+        bv[nt] = p.bias[nch[nt]];
+        dm[nt] = 1.f;
+        if (p.dropmask != nullptr && nch[nt] < p.Cout) dm[nt] = p.dropmask[(size_t)b * p.Cout + nch[nt]];
+    }
+    const int Hy = POOL ? (p.Ho >> 1) : p.Ho;
+    const int Wy = POOL ? (p.Wo >> 1) : p.Wo;
+
+    auto emit = [&](float v, int nt, int yy, int xx) {
+        v = (v + bv[nt]) * dm[nt];
+        if (p.relu) v = fmaxf(v, 0.f);
+        if (yy < Hy && xx < Wy && nch[nt] < p.Cout) {
+            size_t o;
+            if (p.out_nchw)
+                o = (((size_t)b * p.Cout + nch[nt]) * Hy + yy) * Wy + xx;
+            else
+                o = (((size_t)b * Hy + yy) * Wy + xx) * p.Cout + nch[nt];
+            p.y[o] = v;
+        }
+    };
+
+    if (!POOL) {
+#pragma unroll
+        for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < WN; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = (r & 3) + 8 * (r >> 2) + 4 * hq;
+                    emit(acc[mt][nt][r], nt, oy0 + trow[mt], ox0 + tcol[mt] + m);
+                }
+    } else {
+        // rows (2a, 2a+1) of one column half sit in M-tiles (mtA, mtB) of this wave
+#pragma unroll
+        for (int pr = 0; pr < WM / 2; ++pr) {
+            const int mtA = (WGM == 2) ? (pr & 1) : 0;       // WGM==2: tiles {0,1}=row0 halves, {2,3}=row1
+            const int mtB = (WGM == 2) ? (2 + (pr & 1)) : 1;
+#pragma unroll
+            for (int nt = 0; nt < WN; ++nt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const float v0 = fmaxf(acc[mtA][nt][4 * g + 2 * e], acc[mtA][nt][4 * g + 2 * e + 1]);
+                        const float v1 = fmaxf(acc[mtB][nt][4 * g + 2 * e], acc[mtB][nt][4 * g + 2 * e + 1]);
+                        const int yy = (oy0 + trow[mtA]) >> 1;
+                        const int xx = ((ox0 + tcol[mtA]) >> 1) + 4 * g + 2 * hq + e;
+                        emit(fmaxf(v0, v1), nt, yy, xx);
+                    }
+        }
+    }
+}
+
+// One thread per packed float4: wpk[nt][kc][tap][q][n][0..3] <- w[cout][cin][kh][kw]
+// (torch KCRS). transpose_flip!=0 builds the dgrad filter instead: roles of cin/cout
+// swapped and taps rotated by 180 degrees (w'[ci][co][kh][kw] = w[co][ci][2-kh][2-kw]).
+__global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wpk, int Cout, int Cin,
+                                    int n_tiles, int nkc, int TN, int transpose_flip, int src_cout, int src_cin) {
+    const size_t total = (size_t)n_tiles * nkc * 9 * 2 * TN;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    size_t t = idx;
+    const int n = t % TN; t /= TN;
+    const int q = t % 2; t /= 2;
+    const int tap = t % 9; t /= 9;
+    const int kc = t % nkc; t /= nkc;
+    const int nt = (int)t;
+    const int kh = tap / 3, kw = tap % 3;
+    const int co = nt * TN + n;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int ci = kc * 8 + q * 4 + j;
+        if (co < Cout && ci < Cin) {
+            if (!transpose_flip)
+                v[j] = w[(((size_t)co * src_cin + ci) * 3 + kh) * 3 + kw];
+            else
+                v[j] = w[(((size_t)ci * src_cin + co) * 3 + (2 - kh)) * 3 + (2 - kw)];
+        }
+    }
+    reinterpret_cast<f32x4*>(wpk)[idx] = v;
+}
+
+// NCHW [B,C,H,W] -> NHWC8 [B,H,W,8], channels >= C zero filled (C <= 8).
+__global__ void nchw_to_nhwc8_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int C, int H, int W) {
+    const size_t npix = (size_t)B * H * W;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= npix) return;
+    const size_t hw = (size_t)H * W;
+    const size_t b = idx / hw, r = idx - b * hw;
+    float v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) v[c] = (c < C) ? x[(b * C + c) * hw + r] : 0.f;
+    f32x4* o = reinterpret_cast<f32x4*>(y + idx * 8);
+    o[0] = f32x4{v[0], v[1], v[2], v[3]};
+    o[1] = f32x4{v[4], v[5], v[6], v[7]};
+}
+
+template <int TN, int SH, bool POOL>
+int launch_conv(const ConvArgs& a, hipStream_t st) {
+    const int n_tiles = cdiv(a.Cout, TN);
+    const long long grid = (long long)n_tiles * a.B * a.tiles_x * a.tiles_y;
+    if (grid <= 0 || grid > 0x7fffffffLL) {
+        witw_set_error("conv3x3: grid %lld out of range", grid);
+        return WITW_ERR_INVALID;
+    }
+    hipLaunchKernelGGL((conv3x3_nhwc_f32_kernel<TN, SH, POOL>), dim3((unsigned)grid), dim3(NTHREADS), 0, st, a);
+    WITW_CHECK_LAUNCH("conv3x3_nhwc_f32");
+    return WITW_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int witw_conv3x3_tile_n(int cout) { return cout >= 128 ? 128 : 64; }
+
+long long witw_conv3x3_packed_floats(int cout, int cin) {
+    if (cout <= 0 || cin <= 0) return -1;
+    const int TN = witw_conv3x3_tile_n(cout);
+    const long long n_tiles = cdiv(cout, TN), nkc = cdiv(cin, 8);
+    return n_tiles * nkc * 9 * 2 * TN * 4;
+}
+
+int witw_conv3x3_bias_floats(int cout) {
+    const int TN = witw_conv3x3_tile_n(cout);
+    return cdiv(cout, TN) * TN;
+}
+
+int witw_conv3x3_pack_weights(const float* w_kcrs, float* wpk, int cout, int cin, int transpose_flip, void* stream) {
+    WITW_CHECK_ARG(w_kcrs && wpk, "pack_weights: null pointer");
+    WITW_CHECK_ARG(cout > 0 && cin > 0, "pack_weights: bad shape cout=%d cin=%d", cout, cin);
+    const int TN = witw_conv3x3_tile_n(cout);
+    const int n_tiles = cdiv(cout, TN), nkc = cdiv(cin, 8);
+    const size_t total = (size_t)n_tiles * nkc * 9 * 2 * TN;
+    // in transpose_flip mode (cout,cin) describe the PACKED filter; the source tensor is [cin][cout][3][3]
+    const int src_cin = transpose_flip ? cout : cin;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       w_kcrs, wpk, cout, cin, n_tiles, nkc, TN, transpose_flip, cout, src_cin);
+    WITW_CHECK_LAUNCH("pack_weights");
+    return WITW_OK;
+}
+
+int witw_nchw_to_nhwc8(const float* x, float* y, int B, int C, int H, int W, void* stream) {
+    WITW_CHECK_ARG(x && y, "nchw_to_nhwc8: null pointer");
+    WITW_CHECK_ARG(B > 0 && C > 0 && C <= 8 && H > 0 && W > 0, "nchw_to_nhwc8: bad shape B=%d C=%d H=%d W=%d", B, C, H, W);
+    const size_t npix = (size_t)B * H * W;
+    hipLaunchKernelGGL(nchw_to_nhwc8_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y,
+                       B, C, H, W);
+    WITW_CHECK_LAUNCH("nchw_to_nhwc8");
+    return WITW_OK;
+}
+
+int witw_conv3x3_fwd(const float* x, const float* wpk, const float* bias, const float* dropmask, float* y, int B, int H,
+                     int W, int Cin, int Cout, int stride_h, int pad_circular, int relu, int pool, int out_nchw,
+                     void* stream) {
+    WITW_CHECK_ARG(x && wpk && bias && y, "conv3x3_fwd: null pointer");
+    WITW_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cout > 0, "conv3x3_fwd: bad shape B=%d H=%d W=%d Cout=%d", B, H, W, Cout);
+    WITW_CHECK_ARG(Cin > 0 && (Cin % 8) == 0, "conv3x3_fwd: Cin=%d must be a positive multiple of 8", Cin);
+    WITW_CHECK_ARG(stride_h == 1 || stride_h == 2, "conv3x3_fwd: stride_h=%d unsupported", stride_h);
+    WITW_CHECK_ARG(!(pool && stride_h == 2), "conv3x3_fwd: pool with stride 2 unsupported");
+    WITW_CHECK_ARG(!(pool && out_nchw), "conv3x3_fwd: pool with NCHW output unsupported");
+    ConvArgs a;
+    a.x = x; a.wpk = wpk; a.bias = bias; a.dropmask = dropmask; a.y = y;
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+    a.Ho = (H + 2 - 3) / stride_h + 1;
+    a.Wo = W;
+    a.tiles_x = cdiv(a.Wo, TW);
+    a.tiles_y = cdiv(a.Ho, TH);
+    a.circ = pad_circular; a.relu = relu; a.out_nchw = out_nchw;
+    hipStream_t st = (hipStream_t)stream;
+    const int TN = witw_conv3x3_tile_n(Cout);
+    if (TN == 128) {
+        if (stride_h == 2) return launch_conv<128, 2, false>(a, st);
+        return pool ? launch_conv<128, 1, true>(a, st) : launch_conv<128, 1, false>(a, st);
+    }
+    if (stride_h == 2) return launch_conv<64, 2, false>(a, st);
+    return pool ? launch_conv<64, 1, true>(a, st) : launch_conv<64, 1, false>(a, st);
+}
+
+}  // extern "C"
