@@ -235,11 +235,11 @@ def main():
 
     # ---- A12 ranking loop body (model/cvig_fov.py:543-558), planted matches
     res = {'seed': SEED}
-    for (tag, n, we) in [('r360', 24, 64), ('r70', 24, 12)]:
+    for (tag, n, we, nf) in [('r360', 24, 64, 20.0), ('r70', 24, 12, 8.0)]:
         ov = torch.from_numpy(synth.embeddings(SEED, 400 + we, (n, 16, 4, 64)))
         noise = torch.from_numpy(synth.embeddings(SEED, 500 + we, (n, 16, 4, we)))
         shifts = (np.arange(n) * 7) % 64
-        su = torch.stack([torch.roll(ov[i], -int(shifts[i]), dims=2)[:, :, :we] for i in range(n)]) + 1.5 * noise
+        su = torch.stack([torch.roll(ov[i], -int(shifts[i]), dims=2)[:, :, :we] for i in range(n)]) + nf * noise
         count = n
         ranks = np.zeros([count], dtype=int)
         dmat = np.zeros((n, n), dtype=np.float32)
@@ -253,6 +253,8 @@ def main():
             dmat[:, idx] = distances.numpy()
             omat[:, idx] = ori.squeeze(1).numpy()
         res['%s_n_we' % tag] = np.array([n, we])
+        res['%s_noise' % tag] = np.float32(nf)
+        assert 1 < ranks.max() and (ranks == 1).sum() >= 3, ranks
         res['%s_shifts' % tag] = shifts
         res['%s_ranks' % tag] = ranks
         res['%s_dist' % tag] = dmat

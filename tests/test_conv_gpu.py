@@ -1,0 +1,110 @@
+"""GPU parity of the HIP conv3x3 / encoder against the CPU oracle and the reference goldens."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cvig_fov_oracle as O
+from witw_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4  # north_star: embeddings within 1e-4 fp32
+
+
+def _rand(seed, shape, scale=1.0):
+    g = np.random.Generator(np.random.Philox(key=[seed, 7]))
+    return (g.standard_normal(shape, dtype=np.float32) * np.float32(scale)).astype(np.float32)
+
+
+CASES = [
+    # B, H, W, Cin, Cout, stride_h, circ, relu, pool, nchw, drop
+    (2, 8, 64, 8, 64, 1, False, True, False, False, False),
+    (2, 8, 64, 8, 64, 1, True, True, True, False, False),
+    (1, 12, 99, 16, 64, 1, False, True, True, False, False),     # ragged width, floor pooling
+    (1, 12, 99, 16, 64, 1, True, False, False, False, False),
+    (2, 16, 64, 64, 128, 1, True, True, False, False, True),     # TN=128, dropout scale
+    (2, 16, 64, 32, 128, 1, False, True, True, False, False),    # TN=128 pooled
+    (1, 16, 24, 64, 256, 2, True, True, False, False, False),    # stride (2,1), narrow
+    (2, 8, 64, 64, 64, 2, False, True, False, False, False),
+    (2, 4, 64, 64, 16, 1, True, False, False, True, False),      # last layer: Cout=16, NCHW out
+    (1, 5, 130, 8, 64, 1, True, True, False, False, False),      # odd sizes, two column tiles
+    (1, 4, 12, 24, 200, 1, True, True, False, False, False),     # Cout not a tile multiple
+]
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_conv3x3_matches_oracle(case):
+    from witw_amd import ops
+    B, H, W, Cin, Cout, sh, circ, relu, pool, nchw, drop = case
+    x = _rand(1, (B, Cin, H, W))
+    w = _rand(2, (Cout, Cin, 3, 3), scale=(2.0 / (9 * Cin)) ** 0.5)
+    b = _rand(3, (Cout,), scale=0.1)
+    scale = synth.dropout_scales(5, 0, B, Cout) if drop else None
+    ref = O.conv3x3(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(b), sh, circ)
+    if drop:
+        ref = ref * torch.from_numpy(scale)[:, :, None, None]
+    if relu:
+        ref = torch.relu(ref)
+    if pool:
+        ref = torch.nn.functional.max_pool2d(ref, 2, 2)
+    dev = torch.device('cuda:0')
+    xd = torch.from_numpy(x).to(dev).permute(0, 2, 3, 1).contiguous()
+    pk = ops.PackedConv(torch.from_numpy(w).to(dev), torch.from_numpy(b).to(dev))
+    y = ops.conv3x3_fwd(xd, pk, stride_h=sh, circular=circ, relu=relu, pool=pool, out_nchw=nchw,
+                        drop_scale=None if scale is None else torch.from_numpy(scale).to(dev))
+    y = y.cpu() if nchw else y.cpu().permute(0, 3, 1, 2)
+    assert y.shape == ref.shape
+    np.testing.assert_allclose(y.numpy(), ref.numpy(), rtol=1e-5, atol=2e-5)
+
+
+def test_nchw_to_nhwc8():
+    from witw_amd import ops
+    x = torch.from_numpy(_rand(4, (2, 5, 7, 13))).cuda()
+    y = ops.nchw_to_nhwc8(x).cpu()
+    assert y.shape == (2, 7, 13, 8)
+    np.testing.assert_array_equal(y[..., :5].numpy(), x.cpu().permute(0, 2, 3, 1).numpy())
+    assert torch.all(y[..., 5:] == 0)
+
+
+def test_encoder_matches_reference_goldens(golden_dir):
+    from witw_amd import cvig_fov
+    g = np.load(os.path.join(golden_dir, 'encoder.npz'))
+    seed = int(g['seed'])
+    w = synth.fov_dsm_weights(seed)
+    x360 = torch.from_numpy(synth.normalized_images(seed, 10, (2, 3, 128, 512))).cuda()
+    x70 = torch.from_numpy(synth.normalized_images(seed, 11, (2, 3, 128, 99))).cuda()
+    for circ in (False, True):
+        enc = cvig_fov.FOV_DSM(circ_padding=circ, weights=w).cuda().eval()
+        with torch.no_grad():
+            e360 = enc(x360).cpu().numpy()
+            e70 = enc(x70).cpu().numpy()
+        assert e360.shape == (2, 16, 4, 64) and e70.shape == (2, 16, 4, 12)
+        np.testing.assert_allclose(e360, g['embed360_circ%d' % circ], rtol=0, atol=TOL)
+        np.testing.assert_allclose(e70, g['embed70_circ%d' % circ], rtol=0, atol=TOL)
+    # train mode with the reference's captured Dropout2d masks injected
+    enc.train()
+    scales = {i: torch.from_numpy(g['drop_scale_%d' % i]).cuda() for i in (17, 19, 21)}
+    with torch.no_grad():
+        e = enc(x360, dropout_scales=scales).cpu().numpy()
+    np.testing.assert_allclose(e, g['embed360_circ1_train'], rtol=0, atol=TOL)
+
+
+def test_encoder_state_dict_keys_match_reference(golden_dir):
+    from witw_amd import cvig_fov
+    g = np.load(os.path.join(golden_dir, 'encoder.npz'))
+    for circ, name in ((False, 'keys_surface'), (True, 'keys_overhead')):
+        enc = cvig_fov.FOV_DSM(circ_padding=circ)
+        ref_keys = {k for k in g[name] if not k.startswith('model.classifier')}
+        assert set(enc.state_dict().keys()) == ref_keys
+    enc = cvig_fov.FOV_DSM(circ_padding=False)
+    ref_train = [k for k in g['trainable_surface'] if not k.startswith('model.classifier')]
+    assert sorted(n for n, p in enc.named_parameters() if p.requires_grad) == ref_train
+
+
+def test_cpu_tensor_is_refused():
+    from witw_amd import _lib, cvig_fov
+    enc = cvig_fov.FOV_DSM()
+    with pytest.raises(_lib.WitwError):
+        enc(torch.zeros(1, 3, 128, 512))

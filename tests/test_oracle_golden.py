@@ -111,7 +111,7 @@ def test_ranking(golden_dir):
         ov = torch.from_numpy(synth.embeddings(seed, 400 + we, (n, 16, 4, 64)))
         noise = torch.from_numpy(synth.embeddings(seed, 500 + we, (n, 16, 4, we)))
         shifts = g['%s_shifts' % tag]
-        su = torch.stack([torch.roll(ov[i], -int(shifts[i]), dims=2)[:, :, :we] for i in range(n)]) + 1.5 * noise
+        su = torch.stack([torch.roll(ov[i], -int(shifts[i]), dims=2)[:, :, :we] for i in range(n)]) + float(g['%s_noise' % tag]) * noise
         r = O.ranks(ov, su)
         np.testing.assert_array_equal(r, g['%s_ranks' % tag])
         t = O.recall_table(r)

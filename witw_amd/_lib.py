@@ -1,0 +1,56 @@
+"""ctypes binding of libwitw_hip.so — the C-ABI boundary declared in include/witw_hip.h.
+
+There is no CPU fallback: if the library is missing it is built (hipcc) and if that fails, or a
+call returns an error code, an exception is raised.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_longlong, c_void_p
+
+from . import build as _build
+
+_LIB = None
+
+# name -> (restype, argtypes); mirrors include/witw_hip.h one-to-one
+SIGNATURES = {
+    'witw_last_error': (c_char_p, []),
+    'witw_version': (c_int, []),
+    'witw_device_check': (c_int, [c_int]),
+    'witw_conv3x3_tile_n': (c_int, [c_int]),
+    'witw_conv3x3_packed_floats': (c_longlong, [c_int, c_int]),
+    'witw_conv3x3_bias_floats': (c_int, [c_int]),
+    'witw_conv3x3_pack_weights': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    'witw_nchw_to_nhwc8': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'witw_conv3x3_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),
+}
+
+
+class WitwError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return _build.LIB
+
+
+def load():
+    """Load (building first if the .so is absent or stale) and type every entry point."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = _build.LIB
+    if not os.path.exists(path) or (os.path.isdir(_build.CSRC) and _build.stale() and os.path.exists(_build.HIPCC)):
+        _build.build(verbose=False)
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().witw_last_error()
+        raise WitwError('%s failed (%d): %s' % (what, rc, msg.decode() if msg else ''))
