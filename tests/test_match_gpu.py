@@ -1,0 +1,147 @@
+"""GPU parity of matching / loss / ranking / data-path kernels against reference goldens and the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cvig_fov_oracle as O
+from witw_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _g(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def test_match_matches_reference_goldens(golden_dir):
+    from witw_amd import cvig_fov
+    g = _g(golden_dir, 'matching.npz')
+    seed = int(g['seed'])
+    for tag in 'abcde':
+        bo, bs, we = (int(v) for v in g['%s_shape' % tag])
+        ov = torch.from_numpy(synth.embeddings(seed, 100 + ord(tag), (bo, 16, 4, 64))).cuda()
+        su = torch.from_numpy(synth.embeddings(seed, 200 + ord(tag), (bs, 16, 4, we))).cuda()
+        ori, dist = cvig_fov.match(ov, su)
+        assert ori.dtype == torch.int64 and ori.shape == (bo, bs)
+        np.testing.assert_array_equal(ori.cpu().numpy(), g['%s_orientation' % tag])      # bit-exact indices
+        np.testing.assert_allclose(dist.cpu().numpy(), g['%s_distance' % tag], rtol=0, atol=1e-5)
+        # the reference's three-call form through the compatibility entry points
+        ori2 = cvig_fov.correlation(ov, su)
+        crop = cvig_fov.crop_overhead(ov, ori2, we)
+        d2 = cvig_fov.l2_distance(crop, su)
+        np.testing.assert_array_equal(ori2.cpu().numpy(), g['%s_orientation' % tag])
+        np.testing.assert_allclose(d2.cpu().numpy(), g['%s_distance' % tag], rtol=0, atol=1e-5)
+        if tag == 'c':
+            np.testing.assert_array_equal(crop.cpu().numpy(), g['c_crop'])
+        if bo == bs:
+            loss = cvig_fov.triplet_loss(dist)
+            np.testing.assert_allclose(loss.item(), float(g['%s_loss' % tag]), rtol=1e-5)
+
+
+def test_match_tie_break_first_index():
+    """torch.argmax returns the first maximal index; periodic overhead rows tie exactly."""
+    from witw_amd import cvig_fov
+    base = synth.embeddings(3, 1, (3, 16, 4, 16))
+    ov = np.tile(base, (1, 1, 1, 4))                      # period 16 -> shifts s, s+16, s+32, s+48 tie
+    su = np.ascontiguousarray(np.roll(ov, -5, axis=3)[:, :, :, :32])
+    ori = cvig_fov.correlation(torch.from_numpy(ov).cuda(), torch.from_numpy(su).cuda()).cpu()
+    ref = O.correlation(torch.from_numpy(ov), torch.from_numpy(su))
+    assert torch.equal(torch.diagonal(ori), torch.full((3,), 5, dtype=torch.int64))
+    assert torch.equal(torch.diagonal(ref), torch.full((3,), 5, dtype=torch.int64))
+
+
+@pytest.mark.parametrize('shape', [(1, 1, 64), (130, 257, 64), (3, 200, 1), (70, 5, 63)])
+def test_match_ragged_shapes_vs_oracle(shape):
+    from witw_amd import cvig_fov
+    bo, bs, we = shape
+    ov = torch.from_numpy(synth.embeddings(11, bo, (bo, 16, 4, 64)))
+    su = torch.from_numpy(synth.embeddings(12, bs, (bs, 16, 4, we)))
+    ori_r, dist_r = O.match_fused(ov, su)
+    sc = O.correlation_scores(ov.double(), su.double())
+    top2 = sc.topk(2, -1).values
+    safe = (top2[..., 0] - top2[..., 1]) > 1e-3            # compare indices away from argmax near-ties
+    ori, dist = cvig_fov.match(ov.cuda(), su.cuda())
+    ori, dist = ori.cpu(), dist.cpu()
+    assert torch.equal(ori[safe], ori_r[safe])
+    np.testing.assert_allclose(dist[safe].numpy(), dist_r[safe].numpy(), rtol=0, atol=1e-5)
+    assert safe.float().mean() > 0.95
+
+
+def test_triplet_loss_fwd_bwd(golden_dir):
+    from witw_amd import cvig_fov
+    g = _g(golden_dir, 'matching.npz')
+    dm = torch.from_numpy(g['loss_in'])
+    assert abs(cvig_fov.triplet_loss(dm.cuda()).item() - float(g['loss_a10'])) < 1e-6
+    assert abs(cvig_fov.triplet_loss(dm.cuda(), alpha=3.).item() - float(g['loss_a3'])) < 1e-6
+    for B in (2, 7, 300):
+        d = torch.from_numpy(synth.embeddings(5, B, (B, B))).abs().clamp(max=3.9)
+        dr = d.clone().requires_grad_(True)
+        lr = O.triplet_loss(dr)
+        lr.backward()
+        dg = d.cuda().requires_grad_(True)
+        lg = cvig_fov.triplet_loss(dg)
+        (lg * 1.0).backward()
+        np.testing.assert_allclose(lg.item(), lr.item(), rtol=2e-6)
+        np.testing.assert_allclose(dg.grad.cpu().numpy(), dr.grad.numpy(), rtol=1e-4, atol=1e-8)
+    with pytest.raises(Exception):
+        cvig_fov.triplet_loss(torch.zeros(1, 1).cuda())
+
+
+def test_ranking_matches_reference_goldens(golden_dir):
+    from witw_amd import cvig_fov
+    g = _g(golden_dir, 'ranking.npz')
+    seed = int(g['seed'])
+    for tag in ('r360', 'r70'):
+        n, we = (int(v) for v in g['%s_n_we' % tag])
+        ov = torch.from_numpy(synth.embeddings(seed, 400 + we, (n, 16, 4, 64)))
+        noise = torch.from_numpy(synth.embeddings(seed, 500 + we, (n, 16, 4, we)))
+        shifts = g['%s_shifts' % tag]
+        su = torch.stack([torch.roll(ov[i], -int(shifts[i]), dims=2)[:, :, :we] for i in range(n)]) \
+            + float(g['%s_noise' % tag]) * noise
+        r = cvig_fov.ranks(ov.cuda(), su.contiguous().cuda())
+        np.testing.assert_array_equal(r, g['%s_ranks' % tag])                         # bit-exact ranks
+        ori, dist = cvig_fov.match(ov.cuda(), su.contiguous().cuda())
+        np.testing.assert_array_equal(ori.cpu().numpy(), g['%s_ori' % tag])
+        np.testing.assert_allclose(dist.cpu().numpy(), g['%s_dist' % tag], rtol=0, atol=1e-5)
+        t = cvig_fov.recall_table(r)
+        np.testing.assert_allclose([t['top_1'], t['top_5'], t['top_10'], t['top_1pct'], t['mean'], t['median']],
+                                   g['%s_table' % tag])
+
+
+def test_polar_transform_bit_exact(golden_dir):
+    from witw_amd import cvig_fov
+    g = _g(golden_dir, 'polar.npz')
+    img = torch.from_numpy(synth.normalized_images(int(g['seed']), int(g['stream']), (3, 256, 256)))
+    out = cvig_fov.PolarTransform()({'overhead': img.cuda()})['polar'].cpu()
+    assert out.shape == (3, 128, 512)
+    np.testing.assert_array_equal(out[:, ::8, :].numpy(), g['polar_rows'])
+    assert out.double().sum().item() == float(g['polar_sum'])
+    assert out.double().abs().sum().item() == float(g['polar_abs_sum'])
+    batched = cvig_fov.PolarTransform()({'overhead': torch.stack([img, img * 2]).cuda()})['polar'].cpu()
+    np.testing.assert_array_equal(batched[0].numpy(), out.numpy())
+    np.testing.assert_array_equal(batched[1].numpy(), O.polar_transform(img * 2).numpy())
+
+
+def test_normalization_bit_exact(golden_dir):
+    from witw_amd import cvig_fov
+    g = _g(golden_dir, 'normalize.npz')
+    raw5 = torch.from_numpy(g['raw5'])
+    d = cvig_fov.ImageNormalization()({'surface': raw5[:3].cuda(), 'overhead': raw5[:3].cuda()})
+    np.testing.assert_array_equal(d['surface'].cpu().numpy(), g['norm3'])
+    d5 = cvig_fov.ImageNormalization(O.SEM_MEAN, O.SEM_STD, n_div255=3)({'surface': raw5.cuda(), 'overhead': raw5.cuda()})
+    np.testing.assert_array_equal(d5['overhead'].cpu().numpy(), g['norm5'])
+
+
+@pytest.mark.parametrize('fov,panorama', [(360, False), (70, False), (70, True), (360, True)])
+def test_resize_vs_oracle(fov, panorama):
+    from witw_amd import cvig_fov
+    s = torch.from_numpy(synth.images_u8(7, 1, (3, 224, 224)))
+    o = torch.from_numpy(synth.images_u8(7, 2, (3, 512, 512)))
+    rs, ro = O.resize_pair(s, o, fov=fov, panorama=panorama, start=470)
+    t = cvig_fov.Resize('cvusa' if panorama else 'witw', fov)
+    d = t({'surface': s.cuda(), 'overhead': o.cuda()}, start=470)
+    assert d['surface'].shape == rs.shape and d['overhead'].shape == (3, 256, 256)
+    np.testing.assert_allclose(d['surface'].cpu().numpy(), rs.numpy(), rtol=0, atol=2e-4)   # values up to 255
+    np.testing.assert_allclose(d['overhead'].cpu().numpy(), ro.numpy(), rtol=0, atol=2e-4)

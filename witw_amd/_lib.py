@@ -22,6 +22,16 @@ SIGNATURES = {
     'witw_conv3x3_pack_weights': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'witw_nchw_to_nhwc8': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'witw_conv3x3_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),
+    'witw_match_workspace_floats': (c_longlong, [c_int, c_int]),
+    'witw_match_fwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'witw_crop_overhead': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    'witw_l2_distance': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    'witw_rank_count': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    'witw_triplet_loss_fwd': (c_int, [c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p]),
+    'witw_triplet_loss_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p]),
+    'witw_resize_bilinear_normalize': (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p, c_void_p, c_int, c_void_p]),
+    'witw_normalize': (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p, c_void_p, c_int, c_void_p]),
+    'witw_polar_transform': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]),
 }
 
 

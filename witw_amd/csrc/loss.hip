@@ -1,0 +1,97 @@
+// Soft-margin triplet loss over the B x B distance matrix (gfx950).
+//
+// Reference: triplet_loss, model/cvig_fov.py:366-382:
+//   loss = ( sum_ij log(1+exp(a*(d_jj - d_ij))) + sum_ij log(1+exp(a*(d_ii - d_ij))) ) / (2B(B-1))
+// (both sums over the FULL matrix, diagonal included; naive log(1+exp) kept).
+// All reductions run in a fixed order (per-row / per-column partials, then one block) so the
+// result is bitwise reproducible run to run.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float block_sum_256(float v, float* sh) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// blocks [0,B): row i  -> ws[i]      = sum_j softplus(a*(d_ii - d_ij)), ws[2B+i] = sum_j sigmoid(.)
+// blocks [B,2B): col j -> ws[B+j]    = sum_i softplus(a*(d_jj - d_ij)), ws[3B+j] = sum_i sigmoid(.)
+__global__ __launch_bounds__(256) void triplet_partials_kernel(const float* __restrict__ D, float* __restrict__ ws, int B,
+                                                                float alpha) {
+    __shared__ float sh[4];
+    const bool is_col = blockIdx.x >= (unsigned)B;
+    const int m = is_col ? blockIdx.x - B : blockIdx.x;
+    const float dm = D[(size_t)m * B + m];
+    float sp = 0.f, sg = 0.f;
+    for (int t = threadIdx.x; t < B; t += 256) {
+        const float d = is_col ? D[(size_t)t * B + m] : D[(size_t)m * B + t];
+        const float x = alpha * (dm - d);
+        sp += logf(1.f + expf(x));
+        sg += 1.f / (1.f + expf(-x));
+    }
+    const float tsp = block_sum_256(sp, sh);
+    const float tsg = block_sum_256(sg, sh);
+    if (threadIdx.x == 0) {
+        ws[(is_col ? B : 0) + m] = tsp;
+        ws[(is_col ? 3 * B : 2 * B) + m] = tsg;
+    }
+}
+
+__global__ __launch_bounds__(256) void triplet_finish_kernel(const float* __restrict__ ws, float* __restrict__ loss, int B,
+                                                              float norm) {
+    __shared__ float sh[4];
+    float a = 0.f, b = 0.f;
+    for (int t = threadIdx.x; t < B; t += 256) {
+        a += ws[B + t];   // surface -> overhead term (column partials), reference :377
+        b += ws[t];       // overhead -> surface term (row partials), reference :378
+    }
+    const float ta = block_sum_256(a, sh);
+    const float tb = block_sum_256(b, sh);
+    if (threadIdx.x == 0) loss[0] = (ta + tb) / norm;
+}
+
+// dL/dD_ij = g*(a/norm) * ( -sig(a(d_jj-d_ij)) - sig(a(d_ii-d_ij)) + [i==j]*(colsig_j + rowsig_i) )
+__global__ void triplet_bwd_kernel(const float* __restrict__ D, const float* __restrict__ ws,
+                                   const float* __restrict__ gloss, float* __restrict__ gD, int B, float alpha,
+                                   float norm) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)B * B) return;
+    const int i = idx / B, j = idx - (size_t)i * B;
+    const float d = D[idx];
+    const float x1 = alpha * (D[(size_t)j * B + j] - d);
+    const float x2 = alpha * (D[(size_t)i * B + i] - d);
+    float g = -(1.f / (1.f + expf(-x1))) - (1.f / (1.f + expf(-x2)));
+    if (i == j) g += ws[3 * B + j] + ws[2 * B + i];
+    gD[idx] = g * (gloss[0] * alpha / norm);
+}
+
+}  // namespace
+
+extern "C" {
+
+int witw_triplet_loss_fwd(const float* distance, int B, float alpha, float* loss, float* workspace, void* stream) {
+    WITW_CHECK_ARG(distance && loss && workspace, "triplet_loss_fwd: null pointer");
+    WITW_CHECK_ARG(B >= 2, "triplet_loss_fwd: batch %d < 2 (the reference divides by 2B(B-1))", B);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(triplet_partials_kernel, dim3(2 * B), dim3(256), 0, st, distance, workspace, B, alpha);
+    hipLaunchKernelGGL(triplet_finish_kernel, dim3(1), dim3(256), 0, st, workspace, loss, B, 2.f * B * (B - 1));
+    WITW_CHECK_LAUNCH("triplet_loss_fwd");
+    return WITW_OK;
+}
+
+int witw_triplet_loss_bwd(const float* distance, const float* workspace, const float* grad_loss, float* grad_distance, int B,
+                          float alpha, void* stream) {
+    WITW_CHECK_ARG(distance && workspace && grad_loss && grad_distance, "triplet_loss_bwd: null pointer");
+    WITW_CHECK_ARG(B >= 2, "triplet_loss_bwd: batch %d < 2", B);
+    const size_t total = (size_t)B * B;
+    hipLaunchKernelGGL(triplet_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, distance,
+                       workspace, grad_loss, grad_distance, B, alpha, 2.f * B * (B - 1));
+    WITW_CHECK_LAUNCH("triplet_loss_bwd");
+    return WITW_OK;
+}
+
+}  // extern "C"

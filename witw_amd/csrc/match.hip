@@ -1,0 +1,324 @@
+// Fused orientation search + chord distance (gfx950, fp32 MFMA).
+//
+// Replaces the reference's correlation -> crop_overhead -> l2_distance chain
+// (model/cvig_fov.py:297-363, called at :450-453 and :547-549) WITHOUT materialising the
+// [Bo,Bs,C,H,We] crop tensor (268 MB at B=128, 17 GB at B=1024):
+//   score[o,s,shift] = sum_{ch,k<We} ov[o,ch,(k+shift)%64] * su[s,ch,k]        (ch = c*4+h, 64 rows)
+//   orientation[o,s] = argmax_shift score   (first index on ties, as torch.argmax)
+//   distance[o,s]    = 2*(1 - score_max / (|window(o,orientation)| * |su[s]|))
+// As a GEMM per overhead image: M = surfaces, N = 64 shifts, K = 64*We. The surface tile is the
+// A operand (LDS rows of stride 65 floats -> conflict-free ds_read_b32), the overhead row,
+// stored twice back to back so that (k+shift) never wraps, is the B operand read at consecutive
+// addresses by the 32 lanes of a shift tile. Accumulators hold [surface rows][shift lanes]; the
+// arg-max over shifts is a 5-step wavefront butterfly per accumulator register.
+#include "common.h"
+
+namespace {
+
+constexpr int MS = 128;        // surfaces per block (4 M-tiles)
+constexpr int SUS = 65;        // LDS row stride of the surface tile (floats)
+constexpr int NT = 256;
+
+struct MatchArgs {
+    const float* ov;     // [Bo,64,64]
+    const float* su;     // [Bs,64,We]
+    const float* wn;     // [Bo,64] window norms per shift
+    const float* sn;     // [Bs]    surface norms
+    long long* orientation;  // [Bo,Bs] or null
+    float* distance;         // [Bo,Bs] or null
+    float* score;            // [Bo,Bs] or null (max correlation)
+    int Bo, Bs, We;
+};
+
+// OPW = overhead images per wave (1 or 2); a block covers 2*OPW overheads x 128 surfaces.
+template <int OPW>
+__global__ __launch_bounds__(NT) void match_kernel(MatchArgs p) {
+    constexpr int MO = 2 * OPW;
+    constexpr int SU_F = MS * SUS;       // floats per surface stage
+    constexpr int OV_F = MO * 128;       // floats per overhead stage
+    __shared__ float smem[2 * (SU_F + OV_F)];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hk = lane >> 5;
+    const int s0 = blockIdx.x * MS;
+    const int o0 = blockIdx.y * MO;
+    const int We = p.We;
+    const int Wp = (We + 1) & ~1;        // K per row padded to the MFMA k-step of 2
+    const int wm = wave >> 1;            // surface half: rows [64*wm, 64*wm+64)
+    const int wo = wave & 1;             // overhead group: local overheads [OPW*wo, OPW*wo+OPW)
+
+    // staging roles: lane <-> k within a row, (wave + 4*i) <-> surface row
+    const bool kin = lane < We;
+    float rsu[32];
+    float rov = 0.f;
+    const int ovo = tid >> 6, ovw = tid & 63;   // overhead staging: thread -> (local overhead, column)
+    auto load_stage = [&](int r) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const int s = s0 + wave + 4 * i;
+            float v = 0.f;
+            if (kin && s < p.Bs) v = p.su[((size_t)s * 64 + r) * We + lane];
+            rsu[i] = v;
+        }
+        rov = 0.f;
+        if (ovo < MO && o0 + ovo < p.Bo) rov = p.ov[((size_t)(o0 + ovo) * 64 + r) * 64 + ovw];
+    };
+    auto store_stage = [&](int buf) {
+        float* su_s = smem + buf * (SU_F + OV_F);
+        float* ov_s = su_s + SU_F;
+        if (lane < Wp) {
+#pragma unroll
+            for (int i = 0; i < 32; ++i) su_s[(wave + 4 * i) * SUS + lane] = rsu[i];
+        }
+        if (ovo < MO) {
+            ov_s[ovo * 128 + ovw] = rov;
+            ov_s[ovo * 128 + 64 + ovw] = rov;
+        }
+    };
+
+    f32x16 acc[2][OPW][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < OPW; ++b)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][c][r] = 0.f;
+
+    load_stage(0);
+    store_stage(0);
+    __syncthreads();
+
+    const int arow0 = (64 * wm + l31) * SUS + hk;
+    const int arow1 = arow0 + 32 * SUS;
+    const int bcol = OPW * wo * 128 + l31 + hk;
+    for (int r = 0; r < 64; ++r) {
+        const int cur = r & 1;
+        if (r + 1 < 64) load_stage(r + 1);
+        const float* su_s = smem + cur * (SU_F + OV_F);
+        const float* ov_s = su_s + SU_F;
+#pragma unroll 4
+        for (int k = 0; k < Wp; k += 2) {
+            const float a0 = su_s[arow0 + k];
+            const float a1 = su_s[arow1 + k];
+            float b[OPW][2];
+#pragma unroll
+            for (int o = 0; o < OPW; ++o) {
+                b[o][0] = ov_s[bcol + o * 128 + k];
+                b[o][1] = ov_s[bcol + o * 128 + k + 32];
+            }
+#pragma unroll
+            for (int o = 0; o < OPW; ++o)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    acc[0][o][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b[o][n], acc[0][o][n], 0, 0, 0);
+                    acc[1][o][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b[o][n], acc[1][o][n], 0, 0, 0);
+                }
+        }
+        if (r + 1 < 64) store_stage(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: arg-max over the 64 shifts (2 N-tiles x 32 lanes), first index wins ties
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int o = 0; o < OPW; ++o) {
+            const int og = o0 + OPW * wo + o;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[mt][o][0][r];
+                int idx = l31;
+                const float v1 = acc[mt][o][1][r];
+                if (v1 > v) { v = v1; idx = 32 + l31; }
+#pragma unroll
+                for (int d = 1; d < 32; d <<= 1) {
+                    const float vo = __shfl_xor(v, d, 64);
+                    const int io = __shfl_xor(idx, d, 64);
+                    if (vo > v || (vo == v && io < idx)) { v = vo; idx = io; }
+                }
+                const int srow = s0 + 64 * wm + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hk;
+                if (l31 == r && og < p.Bo && srow < p.Bs) {
+                    const size_t off = (size_t)og * p.Bs + srow;
+                    if (p.orientation) p.orientation[off] = idx;
+                    if (p.score) p.score[off] = v;
+                    if (p.distance) p.distance[off] = 2.f * (1.f - v / (p.wn[(size_t)og * 64 + idx] * p.sn[srow]));
+                }
+            }
+        }
+}
+
+// wn[o][shift] = sqrt(sum_{ch} sum_{k<We} ov[o][ch][(k+shift)%64]^2): the L2 norm of the window
+// that crop_overhead would cut at that shift (model/cvig_fov.py:335-341,350-351).
+__global__ __launch_bounds__(256) void window_norm_kernel(const float* __restrict__ ov, float* __restrict__ wn, int We) {
+    __shared__ float part[4][64];
+    __shared__ float col[64];
+    const int o = blockIdx.x, t = threadIdx.x, w = t & 63, g = t >> 6;
+    const float* base = ov + (size_t)o * 4096;
+    float s = 0.f;
+    for (int ch = g * 16; ch < g * 16 + 16; ++ch) {
+        const float v = base[ch * 64 + w];
+        s += v * v;
+    }
+    part[g][w] = s;
+    __syncthreads();
+    if (t < 64) col[t] = (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
+    __syncthreads();
+    if (t < 64) {
+        float acc = 0.f;
+        for (int k = 0; k < We; ++k) acc += col[(t + k) & 63];
+        wn[(size_t)o * 64 + t] = sqrtf(acc);
+    }
+}
+
+// sn[s] = |su[s]|_2 over all 64*We elements (model/cvig_fov.py:356-357).
+__global__ __launch_bounds__(256) void row_norm_kernel(const float* __restrict__ x, float* __restrict__ out, int n) {
+    __shared__ float part[4];
+    const float* base = x + (size_t)blockIdx.x * n;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float v = base[i];
+        s += v * v;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = sqrtf((part[0] + part[1]) + (part[2] + part[3]));
+}
+
+// crop_overhead as a materialising gather (model/cvig_fov.py:318-343); compatibility entry for
+// callers that index the crop (tools/heatmap/heatmap.py:173, TensorBoard dumps). One thread per
+// output element, k fastest.
+__global__ void crop_overhead_kernel(const float* __restrict__ ov, const long long* __restrict__ ori,
+                                     float* __restrict__ out, int Bo, int Bs, int We, size_t total) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int k = idx % We;
+    size_t t = idx / We;
+    const int ch = t % 64;
+    t /= 64;
+    const int s = t % Bs;
+    const int o = (int)(t / Bs);
+    const int sh = (int)ori[(size_t)o * Bs + s];
+    out[idx] = ov[((size_t)o * 64 + ch) * 64 + ((k + sh) & 63)];
+}
+
+// l2_distance on a materialised crop (model/cvig_fov.py:346-363): one block per (o,s).
+__global__ __launch_bounds__(256) void l2_distance_kernel(const float* __restrict__ crop, const float* __restrict__ su,
+                                                           float* __restrict__ dist, int Bs, int n) {
+    __shared__ float part[3][4];
+    const int s = blockIdx.x % Bs;
+    const float* a = crop + (size_t)blockIdx.x * n;
+    const float* b = su + (size_t)s * n;
+    float aa = 0.f, bb = 0.f, ab = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float x = a[i], y = b[i];
+        aa += x * x;
+        bb += y * y;
+        ab += x * y;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        aa += __shfl_xor(aa, d, 64);
+        bb += __shfl_xor(bb, d, 64);
+        ab += __shfl_xor(ab, d, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        part[0][threadIdx.x >> 6] = aa;
+        part[1][threadIdx.x >> 6] = bb;
+        part[2][threadIdx.x >> 6] = ab;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float na = sqrtf((part[0][0] + part[0][1]) + (part[0][2] + part[0][3]));
+        const float nb = sqrtf((part[1][0] + part[1][1]) + (part[1][2] + part[1][3]));
+        const float dot = (part[2][0] + part[2][1]) + (part[2][2] + part[2][3]);
+        dist[blockIdx.x] = 2.f * (1.f - dot / (na * nb));
+    }
+}
+
+// rank[q] = #{o : D[o][q] <= D[true(q)][q]}  (model/cvig_fov.py:550-552); true(q) = q + true_offset.
+// grid (ceil(Bs/256), chunks of gallery rows); integer atomics -> order independent, exact.
+__global__ __launch_bounds__(256) void rank_count_kernel(const float* __restrict__ D, int* __restrict__ ranks, int Bo, int Bs,
+                                                         int true_offset, int rows_per_block) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= Bs) return;
+    const int t = q + true_offset;
+    if (t < 0 || t >= Bo) return;
+    const float dt = D[(size_t)t * Bs + q];
+    const int r0 = blockIdx.y * rows_per_block;
+    const int r1 = min(Bo, r0 + rows_per_block);
+    int c = 0;
+    for (int o = r0; o < r1; ++o) c += (D[(size_t)o * Bs + q] <= dt) ? 1 : 0;
+    if (c) atomicAdd(&ranks[q], c);
+}
+
+}  // namespace
+
+extern "C" {
+
+long long witw_match_workspace_floats(int Bo, int Bs) { return (long long)Bo * 64 + Bs; }
+
+int witw_match_fwd(const float* ov, const float* su, int Bo, int Bs, int We, long long* orientation, float* distance,
+                   float* score, float* workspace, void* stream) {
+    WITW_CHECK_ARG(ov && su && workspace, "match_fwd: null pointer");
+    WITW_CHECK_ARG(Bo > 0 && Bs > 0, "match_fwd: empty batch Bo=%d Bs=%d", Bo, Bs);
+    WITW_CHECK_ARG(We >= 1 && We <= 64, "match_fwd: surface embedding width %d outside [1,64]", We);
+    hipStream_t st = (hipStream_t)stream;
+    float* wn = workspace;
+    float* sn = workspace + (size_t)Bo * 64;
+    hipLaunchKernelGGL(window_norm_kernel, dim3(Bo), dim3(256), 0, st, ov, wn, We);
+    hipLaunchKernelGGL(row_norm_kernel, dim3(Bs), dim3(256), 0, st, su, sn, 64 * We);
+    MatchArgs a;
+    a.ov = ov; a.su = su; a.wn = wn; a.sn = sn;
+    a.orientation = orientation; a.distance = distance; a.score = score;
+    a.Bo = Bo; a.Bs = Bs; a.We = We;
+    const int gx = cdiv(Bs, MS);
+    // small problems: 2 overheads per block (more blocks); large: 4 per block (less staging per FLOP)
+    if ((long long)gx * cdiv(Bo, 4) >= 512) {
+        hipLaunchKernelGGL((match_kernel<2>), dim3(gx, cdiv(Bo, 4)), dim3(NT), 0, st, a);
+    } else {
+        hipLaunchKernelGGL((match_kernel<1>), dim3(gx, cdiv(Bo, 2)), dim3(NT), 0, st, a);
+    }
+    WITW_CHECK_LAUNCH("match_fwd");
+    return WITW_OK;
+}
+
+int witw_crop_overhead(const float* ov, const long long* orientation, float* out, int Bo, int Bs, int We, void* stream) {
+    WITW_CHECK_ARG(ov && orientation && out, "crop_overhead: null pointer");
+    WITW_CHECK_ARG(Bo > 0 && Bs > 0 && We >= 1 && We <= 64, "crop_overhead: bad shape Bo=%d Bs=%d We=%d", Bo, Bs, We);
+    const size_t total = (size_t)Bo * Bs * 64 * We;
+    WITW_CHECK_ARG((total + 255) / 256 <= 0x7fffffffULL, "crop_overhead: output too large");
+    hipLaunchKernelGGL(crop_overhead_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ov,
+                       orientation, out, Bo, Bs, We, total);
+    WITW_CHECK_LAUNCH("crop_overhead");
+    return WITW_OK;
+}
+
+int witw_l2_distance(const float* cropped, const float* su, float* distance, int Bo, int Bs, int n, void* stream) {
+    WITW_CHECK_ARG(cropped && su && distance, "l2_distance: null pointer");
+    WITW_CHECK_ARG(Bo > 0 && Bs > 0 && n > 0, "l2_distance: bad shape Bo=%d Bs=%d n=%d", Bo, Bs, n);
+    WITW_CHECK_ARG((long long)Bo * Bs <= 0x7fffffffLL, "l2_distance: too many pairs");
+    hipLaunchKernelGGL(l2_distance_kernel, dim3(Bo * Bs), dim3(256), 0, (hipStream_t)stream, cropped, su, distance, Bs, n);
+    WITW_CHECK_LAUNCH("l2_distance");
+    return WITW_OK;
+}
+
+int witw_rank_count(const float* distance, int* ranks, int Bo, int Bs, int true_offset, void* stream) {
+    WITW_CHECK_ARG(distance && ranks, "rank_count: null pointer");
+    WITW_CHECK_ARG(Bo > 0 && Bs > 0, "rank_count: bad shape Bo=%d Bs=%d", Bo, Bs);
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(ranks, 0, sizeof(int) * (size_t)Bs, st) != hipSuccess) {
+        witw_set_error("rank_count: memset failed");
+        return WITW_ERR_LAUNCH;
+    }
+    const int rows = 512;
+    hipLaunchKernelGGL(rank_count_kernel, dim3(cdiv(Bs, 256), cdiv(Bo, rows)), dim3(256), 0, st, distance, ranks, Bo, Bs,
+                       true_offset, rows);
+    WITW_CHECK_LAUNCH("rank_count");
+    return WITW_OK;
+}
+
+}  // extern "C"

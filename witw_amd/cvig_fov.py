@@ -135,3 +135,136 @@ class FOV_DSM(torch.nn.Module):
             h = ops.conv3x3_fwd(h, self._pack(idx), stride_h=sh, circular=self.circ_padding, relu=relu, pool=pool,
                                 out_nchw=(idx == last), drop_scale=scale)
         return h
+
+
+# ----------------------------------------------------------------------------- transforms
+def _batched(t):
+    return (t.unsqueeze(0), True) if t.dim() == 3 else (t, False)
+
+
+def _to_device(t):
+    if not t.is_cuda:
+        if device.type != 'cuda':
+            raise _lib.WitwError('no gfx950 device: the WITW transforms run on the GPU only')
+        t = t.to(device)
+    return t.contiguous()
+
+
+class Resize(object):
+    """model/cvig_fov.py:100-134 on the GPU. Accepts per-sample CHW or batched NCHW tensors in
+    the data dict. `start` fixes the random FoV crop offset (reference draws torch.randint, :121)."""
+
+    def __init__(self, dataset, fov=360, random_orientation=True):
+        self.fov = fov
+        self.surface_width = int(self.fov / 360 * Globals.surface_width_max)
+        self.panorama = Globals.path_formats[dataset]['panorama']
+        self.random_orientation = random_orientation
+
+    def __call__(self, data, start=None):
+        s, squeeze = _batched(_to_device(data['surface']))
+        if self.panorama:
+            s = ops.resize_bilinear(s, (Globals.surface_height_max, Globals.surface_width_max))
+            if start is None:
+                start = int(torch.randint(0, Globals.surface_width_max, ())) if self.random_orientation else 0
+            end = start + self.surface_width
+            if end < Globals.surface_width_max:
+                s = s[:, :, :, start:end]
+            else:
+                s = torch.cat((s[:, :, :, start:], s[:, :, :, :end - Globals.surface_width_max]), dim=3)
+            s = s.contiguous()
+        else:
+            s = ops.resize_bilinear(s, (Globals.surface_height_max, self.surface_width))
+        o, _ = _batched(_to_device(data['overhead']))
+        o = ops.resize_bilinear(o, (Globals.overhead_size, Globals.overhead_size))
+        data['surface'] = s.squeeze(0) if squeeze else s
+        data['overhead'] = o.squeeze(0) if squeeze else o
+        return data
+
+
+class ImageNormalization(object):
+    """model/cvig_fov.py:137-149."""
+
+    def __init__(self, mean=None, std=None, n_div255=None):
+        self.keys = ['surface', 'overhead']
+        self.mean = Globals.img_mean if mean is None else mean
+        self.std = Globals.img_std if std is None else std
+        self.n_div255 = n_div255
+
+    def __call__(self, data):
+        for key in self.keys:
+            t, squeeze = _batched(_to_device(data[key]))
+            t = ops.normalize(t, self.mean, self.std, self.n_div255)
+            data[key] = t.squeeze(0) if squeeze else t
+        return data
+
+
+class PolarTransform(object):
+    """model/cvig_fov.py:186-209."""
+
+    def __call__(self, data):
+        t, squeeze = _batched(_to_device(data['overhead']))
+        p = ops.polar_transform(t, Globals.surface_height_max, Globals.surface_width_max)
+        data['polar'] = p.squeeze(0) if squeeze else p
+        return data
+
+
+# ----------------------------------------------------------------------------- matching + loss
+def correlation(overhead_embed, surface_embed):
+    """model/cvig_fov.py:297-315 -> int64 [Bo,Bs]."""
+    return ops.match_fwd(overhead_embed.contiguous(), surface_embed.contiguous())[0]
+
+
+def crop_overhead(overhead_embed, orientation, surface_width):
+    """model/cvig_fov.py:318-343 (materialising; the drivers use match() instead)."""
+    return ops.crop_overhead(overhead_embed.contiguous(), orientation.contiguous(), surface_width)
+
+
+def l2_distance(overhead_cropped, surface_embed):
+    """model/cvig_fov.py:346-363."""
+    return ops.l2_distance(overhead_cropped.contiguous(), surface_embed.contiguous())
+
+
+def match(overhead_embed, surface_embed):
+    """correlation -> crop_overhead -> l2_distance fused (no crop tensor): (orientation, distance)."""
+    return ops.match_fwd(overhead_embed.contiguous(), surface_embed.contiguous())
+
+
+class _TripletLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, distances, alpha):
+        d = distances.contiguous()
+        loss, ws = ops.triplet_loss_fwd(d, alpha)
+        ctx.save_for_backward(d, ws)
+        ctx.alpha = alpha
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, grad):
+        d, ws = ctx.saved_tensors
+        return ops.triplet_loss_bwd(d, ws, grad.contiguous(), ctx.alpha), None
+
+
+def triplet_loss(distances, alpha=10.):
+    """model/cvig_fov.py:366-382."""
+    return _TripletLoss.apply(distances, float(alpha))
+
+
+def ranks(overhead_embed, surface_embed):
+    """Ranking loop of test() (model/cvig_fov.py:543-552) for all queries at once: int64 [N] on
+    the host, rank = #{gallery : d <= d_true} with gallery index == query index."""
+    _, dist = match(overhead_embed, surface_embed)
+    return ops.rank_count(dist, 0).cpu().numpy().astype('int64')
+
+
+def recall_table(ranks_arr):
+    """model/cvig_fov.py:553-558."""
+    import numpy as np
+    count = len(ranks_arr)
+    return {
+        'top_1': np.sum(ranks_arr <= 1) / count * 100,
+        'top_5': np.sum(ranks_arr <= 5) / count * 100,
+        'top_10': np.sum(ranks_arr <= 10) / count * 100,
+        'top_1pct': np.sum(ranks_arr * 100 <= count) / count * 100,
+        'mean': float(np.mean(ranks_arr)),
+        'median': float(np.median(ranks_arr)),
+    }

@@ -77,3 +77,173 @@ def conv3x3_fwd(x_nhwc, packed, stride_h=1, circular=False, relu=True, pool=Fals
                                     y.data_ptr(), B, H, W, C, packed.cout, stride_h, int(circular), int(relu),
                                     int(pool), int(out_nchw), _stream()), 'witw_conv3x3_fwd')
     return y
+
+
+# ----------------------------------------------------------------------------- matching
+def match_fwd(overhead_embed, surface_embed, want_score=False):
+    """Fused correlation -> argmax -> window norm -> chord distance (no crop tensor).
+    overhead_embed [Bo,16,4,64], surface_embed [Bs,16,4,We] -> (orientation int64 [Bo,Bs],
+    distance f32 [Bo,Bs][, max score f32 [Bo,Bs]])."""
+    lib = _lib.load()
+    ov = _dev_f32(overhead_embed, 'overhead_embed')
+    su = _dev_f32(surface_embed, 'surface_embed')
+    if ov.dim() != 4 or su.dim() != 4 or ov.shape[1] * ov.shape[2] != 64 or ov.shape[3] != 64:
+        raise _lib.WitwError('match_fwd: overhead embedding must be [Bo,16,4,64], got %s' % (tuple(ov.shape),))
+    if su.shape[1] != ov.shape[1] or su.shape[2] != ov.shape[2]:
+        raise _lib.WitwError('match_fwd: surface embedding %s does not match overhead %s' % (tuple(su.shape), tuple(ov.shape)))
+    Bo, Bs, We = ov.shape[0], su.shape[0], su.shape[3]
+    ori = torch.empty((Bo, Bs), dtype=torch.int64, device=ov.device)
+    dist = torch.empty((Bo, Bs), dtype=torch.float32, device=ov.device)
+    score = torch.empty((Bo, Bs), dtype=torch.float32, device=ov.device) if want_score else None
+    ws = torch.empty(lib.witw_match_workspace_floats(Bo, Bs), dtype=torch.float32, device=ov.device)
+    _lib.check(lib.witw_match_fwd(ov.data_ptr(), su.data_ptr(), Bo, Bs, We, ori.data_ptr(), dist.data_ptr(), _p(score),
+                                  ws.data_ptr(), _stream()), 'witw_match_fwd')
+    return (ori, dist, score) if want_score else (ori, dist)
+
+
+def crop_overhead(overhead_embed, orientation, surface_width):
+    lib = _lib.load()
+    ov = _dev_f32(overhead_embed, 'overhead_embed')
+    if not (orientation.is_cuda and orientation.dtype == torch.int64 and orientation.is_contiguous()):
+        raise _lib.WitwError('crop_overhead: orientation must be a contiguous int64 GPU tensor')
+    Bo, Bs = orientation.shape
+    c, h, w = ov.shape[1:]
+    if c * h != 64 or w != 64:
+        raise _lib.WitwError('crop_overhead: overhead embedding must be [Bo,16,4,64]')
+    out = torch.empty((Bo, Bs, c, h, surface_width), dtype=torch.float32, device=ov.device)
+    _lib.check(lib.witw_crop_overhead(ov.data_ptr(), orientation.data_ptr(), out.data_ptr(), Bo, Bs, surface_width,
+                                      _stream()), 'witw_crop_overhead')
+    return out
+
+
+def l2_distance(overhead_cropped, surface_embed):
+    lib = _lib.load()
+    cr = _dev_f32(overhead_cropped, 'overhead_cropped')
+    su = _dev_f32(surface_embed, 'surface_embed')
+    Bo, Bs = cr.shape[:2]
+    n = su[0].numel()
+    if cr[0, 0].numel() != n or su.shape[0] != Bs:
+        raise _lib.WitwError('l2_distance: shapes %s vs %s do not match' % (tuple(cr.shape), tuple(su.shape)))
+    dist = torch.empty((Bo, Bs), dtype=torch.float32, device=cr.device)
+    _lib.check(lib.witw_l2_distance(cr.data_ptr(), su.data_ptr(), dist.data_ptr(), Bo, Bs, n, _stream()), 'witw_l2_distance')
+    return dist
+
+
+def rank_count(distance, true_offset=0):
+    """ranks[q] = #{o : D[o,q] <= D[q+true_offset, q]} as int32 [Bs]."""
+    lib = _lib.load()
+    d = _dev_f32(distance, 'distance')
+    Bo, Bs = d.shape
+    ranks = torch.empty((Bs,), dtype=torch.int32, device=d.device)
+    _lib.check(lib.witw_rank_count(d.data_ptr(), ranks.data_ptr(), Bo, Bs, true_offset, _stream()), 'witw_rank_count')
+    return ranks
+
+
+def triplet_loss_fwd(distance, alpha=10.):
+    """-> (loss [1] f32, workspace [4B] holding the row/column partials for the backward)."""
+    lib = _lib.load()
+    d = _dev_f32(distance, 'distance')
+    if d.dim() != 2 or d.shape[0] != d.shape[1]:
+        raise _lib.WitwError('triplet_loss: distance matrix must be square, got %s' % (tuple(d.shape),))
+    B = d.shape[0]
+    loss = torch.empty((1,), dtype=torch.float32, device=d.device)
+    ws = torch.empty((4 * B,), dtype=torch.float32, device=d.device)
+    _lib.check(lib.witw_triplet_loss_fwd(d.data_ptr(), B, float(alpha), loss.data_ptr(), ws.data_ptr(), _stream()),
+               'witw_triplet_loss_fwd')
+    return loss, ws
+
+
+def triplet_loss_bwd(distance, ws, grad_loss, alpha=10.):
+    lib = _lib.load()
+    d = _dev_f32(distance, 'distance')
+    g = _dev_f32(grad_loss.reshape(1).contiguous(), 'grad_loss')
+    B = d.shape[0]
+    gd = torch.empty_like(d)
+    _lib.check(lib.witw_triplet_loss_bwd(d.data_ptr(), ws.data_ptr(), g.data_ptr(), gd.data_ptr(), B, float(alpha),
+                                         _stream()), 'witw_triplet_loss_bwd')
+    return gd
+
+
+# ----------------------------------------------------------------------------- data path
+def _host_floats(vals):
+    import ctypes
+    arr = (ctypes.c_float * len(vals))(*[float(v) for v in vals])
+    return arr
+
+
+def resize_bilinear(x, size, mean=None, std=None, n_div255=None):
+    """[B,C,Hi,Wi] -> [B,C,Ho,Wo] bilinear (align_corners=False, no antialias), optionally fused
+    with (x/255 - mean)/std."""
+    import ctypes
+    lib = _lib.load()
+    x = _dev_f32(x, 'x')
+    B, C, Hi, Wi = x.shape
+    Ho, Wo = size
+    y = torch.empty((B, C, Ho, Wo), dtype=torch.float32, device=x.device)
+    m = s = None
+    if mean is not None:
+        m, s = _host_floats(mean), _host_floats(std)
+    nd = C if n_div255 is None else n_div255
+    _lib.check(lib.witw_resize_bilinear_normalize(x.data_ptr(), y.data_ptr(), B, C, Hi, Wi, Ho, Wo,
+                                                  ctypes.cast(m, ctypes.c_void_p) if m is not None else None,
+                                                  ctypes.cast(s, ctypes.c_void_p) if s is not None else None, nd, _stream()),
+               'witw_resize_bilinear_normalize')
+    return y
+
+
+def normalize(x, mean, std, n_div255=None):
+    import ctypes
+    lib = _lib.load()
+    x = _dev_f32(x, 'x')
+    B, C, H, W = x.shape
+    y = torch.empty_like(x)
+    m, s = _host_floats(mean), _host_floats(std)
+    nd = C if n_div255 is None else n_div255
+    _lib.check(lib.witw_normalize(x.data_ptr(), y.data_ptr(), B, C, H, W, ctypes.cast(m, ctypes.c_void_p),
+                                  ctypes.cast(s, ctypes.c_void_p), nd, _stream()), 'witw_normalize')
+    return y
+
+
+_POLAR_LUT = {}
+
+
+def polar_lut(device, size=256, h_s=128, w_s=512):
+    """Constant sampling table of PolarTransform, built on the host in fp64 exactly as
+    model/cvig_fov.py:197-201 (grid) and :163-181 (clip-before-weights bilinear taps), then
+    rounded to fp32 weights like torch.FloatTensor(...) does."""
+    import math
+    import numpy as np
+    key = (str(device), size, h_s, w_s)
+    if key in _POLAR_LUT:
+        return _POLAR_LUT[key]
+    xx, yy = np.meshgrid(range(w_s), range(h_s))
+    y = (size / 2) + (size / 2) * (h_s - 1 - yy) / h_s * np.cos(2 * math.pi * xx / w_s)
+    x = (size / 2) - (size / 2) * (h_s - 1 - yy) / h_s * np.sin(2 * math.pi * xx / w_s)
+    x0 = np.floor(x).astype(int)
+    x1 = x0 + 1
+    y0 = np.floor(y).astype(int)
+    y1 = y0 + 1
+    x0 = np.clip(x0, 0, size - 1)
+    x1 = np.clip(x1, 0, size - 1)
+    y0 = np.clip(y0, 0, size - 1)
+    y1 = np.clip(y1, 0, size - 1)
+    wts = np.stack([(x1 - x) * (y1 - y), (x1 - x) * (y - y0), (x - x0) * (y1 - y), (x - x0) * (y - y0)], -1)
+    taps = np.stack([y0 * size + x0, y1 * size + x0, y0 * size + x1, y1 * size + x1], -1)
+    lut = (torch.from_numpy(taps.reshape(-1, 4).astype(np.int32)).to(device),
+           torch.from_numpy(wts.reshape(-1, 4).astype(np.float32)).to(device))
+    _POLAR_LUT[key] = lut
+    return lut
+
+
+def polar_transform(x, h_s=128, w_s=512):
+    """[B,C,S,S] -> [B,C,128,512] (PolarTransform, model/cvig_fov.py:186-209)."""
+    lib = _lib.load()
+    x = _dev_f32(x, 'x')
+    B, C, S, S2 = x.shape
+    if S != S2:
+        raise _lib.WitwError('polar_transform: overhead image must be square')
+    taps, wts = polar_lut(x.device, S, h_s, w_s)
+    y = torch.empty((B, C, h_s, w_s), dtype=torch.float32, device=x.device)
+    _lib.check(lib.witw_polar_transform(x.data_ptr(), taps.data_ptr(), wts.data_ptr(), y.data_ptr(), B, C, S, h_s, w_s,
+                                        _stream()), 'witw_polar_transform')
+    return y
