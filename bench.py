@@ -1,0 +1,201 @@
+#!/usr/bin/env python
+"""Headline benchmark: image-pairs/sec of the cvig_fov embedding + similarity hot path.
+
+    python bench.py [--gpus N --steps K --warmup W]        (N>1: launched by torch.distributed.run)
+
+One step = one pass of the hot path over one synthetic batch that is already resident in HBM:
+  raw ground 3x224x224 + raw overhead 3x512x512 (uint8-valued fp32)
+    -> Resize + ImageNormalization + PolarTransform            (A1-A3, model/cvig_fov.py:100-209)
+    -> surface / overhead FOV_DSM encoders, eval mode, fp32     (A4-A6, :248-294)
+    -> [N>1] all-gather of both embedding sets over RCCL        (global negatives)
+    -> fused correlation/argmax/crop/chord distance + soft-margin triplet loss over the GLOBAL
+       batch, rank counts for the local queries                 (A7-A10, A12, :297-382, :543-552)
+Per-GPU batch is fixed (weak scaling); value = global pairs / max-over-ranks step time.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 MFMA
+DOMINANT = (128, 1, False)     # conv3x3_nhwc_f32_kernel<128,1,false>: layers 5,10,12,17,19,21
+
+
+def make_inputs(cvig_fov, ops, synth, batch, fov, seed, device):
+    """Synthetic raw pairs with planted matches: the overhead is uint8 noise; its ground
+    image is the polar view of that overhead, rolled by a seeded shift, plus noise, at raw size."""
+    ov_raw = torch.from_numpy(synth.images_u8(seed, 1, (batch, 3, 512, 512))).to(device)
+    ws = int(fov / 360 * 512)
+    small = ops.resize_bilinear(ov_raw, (256, 256))
+    polar = ops.polar_transform(small)                                   # [B,3,128,512], 0..255 scale
+    g = np.random.Generator(np.random.Philox(key=[seed, 77]))
+    shifts = g.integers(0, 512, size=batch)
+    rolled = torch.stack([torch.roll(polar[i], -int(shifts[i]), dims=2)[:, :, :ws] for i in range(batch)])
+    noise = torch.from_numpy(synth.images_u8(seed, 2, (batch, 3, 128, ws))).to(device)
+    ground = (0.7 * rolled + 0.3 * noise).contiguous()
+    ground_raw = ops.resize_bilinear(ground, (224, 224)).round().clamp(0, 255).contiguous()
+    return ground_raw, ov_raw
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--batch', type=int, default=128, help='pairs per GPU (BASELINE.json configs[1]: bs=128)')
+    ap.add_argument('--fov', type=int, default=360)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-pairs', type=int, default=8)
+    a = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit('bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d' % (a.gpus, a.gpus))
+    torch.cuda.set_device(local)
+    device = torch.device('cuda', local)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=device)
+
+    from witw_amd import _lib, cvig_fov, ops, synth, parallel
+    _lib.check(_lib.load().witw_device_check(local), 'witw_device_check')
+
+    B = a.batch
+    seed = 1234
+    wts = synth.fov_dsm_weights(seed)
+    surface_encoder = cvig_fov.FOV_DSM(circ_padding=False, weights=wts).to(device).eval()
+    overhead_encoder = cvig_fov.FOV_DSM(circ_padding=True, weights=wts).to(device).eval()
+    ground_raw, ov_raw = make_inputs(cvig_fov, ops, synth, B, a.fov, seed + rank, device)
+    ws = int(a.fov / 360 * 512)
+    mean, std = cvig_fov.Globals.img_mean, cvig_fov.Globals.img_std
+
+    def step():
+        with torch.no_grad():
+            surface = ops.resize_bilinear(ground_raw, (128, ws), mean, std)
+            overhead = ops.resize_bilinear(ov_raw, (256, 256), mean, std)
+            polar = ops.polar_transform(overhead)
+            su = surface_encoder(surface)
+            ov = overhead_encoder(polar)
+            su_all, ov_all = parallel.all_gather_embeddings(su, ov)
+            ori, d = cvig_fov.match(ov_all, su_all)
+            loss = cvig_fov.triplet_loss(d)
+            ranks = ops.rank_count(d[:, rank * B:(rank + 1) * B].contiguous(), rank * B) if world > 1 \
+                else ops.rank_count(d, 0)
+        return loss, ranks, ori
+
+    for _ in range(a.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ops.PROFILE = []
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss, ranks, ori = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof, ops.PROFILE = ops.PROFILE, None
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        rk = [torch.empty_like(ranks) for _ in range(world)]
+        dist.all_gather(rk, ranks)
+        ranks = torch.cat(rk)
+    ranks_h = ranks.cpu().numpy().astype(np.int64)
+    pairs = B * world * a.steps
+    value = pairs / dt
+
+    # ---- live roofline of the dominant kernel (HIP events on the launch stream, timed region only)
+    dom = [(fl, e0.elapsed_time(e1)) for (v, fl, e0, e1) in prof if v == DOMINANT]
+    allc = [(fl, e0.elapsed_time(e1)) for (v, fl, e0, e1) in prof]
+    dom_fl = sum(f for f, _ in dom) / max(1, len(dom))
+    dom_ms = sum(m for _, m in dom) / max(1, len(dom))
+    achieved = dom_fl / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+    conv_tf = sum(f for f, _ in allc) / (sum(m for _, m in allc) * 1e-3) / 1e12 if allc else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get('conv3x3_nhwc_f32_kernel<128,1,false>_bytes_per_launch_B%d' % B)
+        except Exception:
+            traffic = None
+
+    out = {
+        'metric': 'image-pairs/sec (embedding+similarity)', 'value': round(value, 2), 'unit': 'pairs/s',
+        'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 3),
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'cvig_fov fov=%d eval: resize+normalize+polar -> 2x FOV_DSM (VGG16[:23]+3 conv) -> '
+                               'fused match + soft-margin triplet loss + rank counts' % a.fov,
+                   'pairs_per_gpu': B, 'global_batch': B * world, 'ground_raw': '3x224x224', 'overhead_raw': '3x512x512',
+                   'parallelism': 'dp%d (embedding all-gather, global-batch loss)' % world},
+        'recall': {'top1_pct': float(np.mean(ranks_h <= 1) * 100), 'top5_pct': float(np.mean(ranks_h <= 5) * 100),
+                   'N': int(len(ranks_h))},
+        'loss': float(loss.item()),
+        'roofline': {'bound': 'mfma', 'kernel': 'conv3x3_nhwc_f32_kernel<128,1,false>', 'achieved': round(achieved, 2),
+                     'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                     'traffic': traffic, 'launches': len(dom), 'avg_launch_ms': round(dom_ms, 4),
+                     'avg_launch_gflop': round(dom_fl / 1e9, 2), 'all_conv_launches_tflops': round(conv_tf, 2)},
+    }
+
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(a, ground_raw, ov_raw, wts, ws, step)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(a, ground_raw, ov_raw, wts, ws, gpu_step):
+    """The oracle (CPU restatement of the reference, kind 'port') timed on this host on a bounded
+    sample of the same workload, plus a parity check of the GPU step against it on that sample."""
+    from oracle import cvig_fov_oracle as O
+    n = min(a.cpu_pairs, ground_raw.shape[0])
+    g = ground_raw[:n].cpu()
+    o = ov_raw[:n].cpu()
+    w = {k: (torch.from_numpy(v[0]), torch.from_numpy(v[1])) for k, v in wts.items()}
+    threads = torch.get_num_threads()
+
+    def cpu_step():
+        with torch.no_grad():
+            su_in, ov_in = [], []
+            for i in range(n):
+                s, ov = O.resize_pair(g[i], o[i], fov=a.fov, panorama=False)
+                su_in.append(O.image_normalization(s))
+                ov_in.append(O.polar_transform(O.image_normalization(ov)))
+            su = O.fov_dsm_forward(torch.stack(su_in), w, False)
+            ov = O.fov_dsm_forward(torch.stack(ov_in), w, True)
+            ori, d = O.match(ov, su)
+            loss = O.triplet_loss(d)
+            ranks = (d <= torch.diagonal(d)[None, :]).sum(0)
+        return su, ov, ori, d, loss, ranks
+
+    cpu_step()
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        su, ov, ori, d, loss, ranks = cpu_step()
+        times.append(time.perf_counter() - t0)
+    med = sorted(times)[1]
+    return {'value': round(n / med, 3), 'unit': 'pairs/s', 'cores': threads, 'kind': 'port',
+            'sample': '%d pairs of the same synthetic batch, full step (transforms+encoders+match+loss+ranks), '
+                      'median of 3 after 1 warm-up, torch %s CPU ops' % (n, torch.__version__)}
+
+
+if __name__ == '__main__':
+    main()

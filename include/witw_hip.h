@@ -1,0 +1,86 @@
+/* libwitw_hip.so — C ABI of the MI355X (gfx950) hot path of IQTLabs/WITW.
+ *
+ * The reference exposes no FFI: its boundary is the Python surface of model/cvig_fov.py
+ * (SURVEY.md §8b). Each entry point below replaces the stock-PyTorch op(s) behind one of those
+ * Python functions; witw_amd/_lib.py binds them with ctypes and witw_amd/cvig_fov.py keeps the
+ * reference's names on top (INTEGRATION.md shows the stub a reference maintainer would add).
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller unless a
+ *    comment says HOST; the library never allocates or frees;
+ *  - fp32 everywhere (indices: int64 orientation, int32 ranks); tensors are contiguous;
+ *  - every launcher is asynchronous on `stream` (a hipStream_t passed as void*, NULL = default
+ *    stream), never synchronises, is re-entrant across streams;
+ *  - return 0 on success, <0 on error (-1 invalid argument, -2 launch failure, -3 no gfx950
+ *    device); the message is thread-local text from witw_last_error();
+ *  - one process per GPU; the code object is gfx950 only.
+ */
+#ifndef WITW_HIP_H
+#define WITW_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* witw_last_error(void);
+int witw_version(void);               /* major*10000 + minor*100 + patch */
+int witw_device_check(int device);    /* 0 iff `device` is a gfx950 part */
+
+/* ---- FOV_DSM encoder: Conv2d(3x3,pad 1) [+HorizCircPadding] [+Dropout2d] [+ReLU] [+MaxPool2d(2)]
+ *      reference: model/cvig_fov.py:212-231 (padding), :234-245 (dropout), :256-294 (layer stack).
+ * Activations are NHWC with the channel count padded to a multiple of 8. */
+
+/* output-channel tile the kernel will use for `cout` (64 or 128) */
+int witw_conv3x3_tile_n(int cout);
+/* number of floats of the packed filter / of the zero-padded bias for a (cout, cin) layer */
+long long witw_conv3x3_packed_floats(int cout, int cin);
+int witw_conv3x3_bias_floats(int cout);
+/* w_kcrs: torch layout [cout][cin][3][3]. transpose_flip=1 packs the data-gradient filter instead
+ * (source layout [cin][cout][3][3], taps rotated 180 degrees). */
+int witw_conv3x3_pack_weights(const float* w_kcrs, float* wpk, int cout, int cin, int transpose_flip, void* stream);
+/* NCHW [B,C,H,W] (C<=8) -> NHWC8 [B,H,W,8], zero-filled channels; replaces the implicit layout of
+ * the first Conv2d call (model/cvig_fov.py:293). */
+int witw_nchw_to_nhwc8(const float* x, float* y, int B, int C, int H, int W, void* stream);
+/* x [B,H,W,Cin] (Cin%8==0) -> y NHWC [B,Hy,Wy,Cout] (or NCHW [B,Cout,Hy,Wy] if out_nchw).
+ * stride_h in {1,2} (stride_w = 1); pad_circular: wrap columns (HorizCircPadding) else zero pad;
+ * dropmask: NULL or [B,Cout] Dropout2d scales applied before the ReLU; pool: fused MaxPool2d(2,2).
+ * bias: witw_conv3x3_bias_floats(Cout) floats. */
+int witw_conv3x3_fwd(const float* x, const float* wpk, const float* bias, const float* dropmask, float* y, int B, int H,
+                     int W, int Cin, int Cout, int stride_h, int pad_circular, int relu, int pool, int out_nchw,
+                     void* stream);
+
+/* ---- matching: correlation (:297-315) + crop_overhead (:318-343) + l2_distance (:346-363) fused.
+ * ov [Bo,16,4,64], su [Bs,16,4,We] (NCHW embeddings). Outputs [Bo,Bs]; any of them may be NULL.
+ * workspace: witw_match_workspace_floats(Bo,Bs) floats (window norms + surface norms). */
+long long witw_match_workspace_floats(int Bo, int Bs);
+int witw_match_fwd(const float* ov, const float* su, int Bo, int Bs, int We, long long* orientation, float* distance,
+                   float* score, float* workspace, void* stream);
+/* compatibility entries with the reference's materialising semantics */
+int witw_crop_overhead(const float* ov, const long long* orientation, float* out /*[Bo,Bs,16,4,We]*/, int Bo, int Bs,
+                       int We, void* stream);
+int witw_l2_distance(const float* cropped /*[Bo,Bs,n]*/, const float* su /*[Bs,n]*/, float* distance, int Bo, int Bs, int n,
+                     void* stream);
+/* ranks[q] = #{o : D[o][q] <= D[q+true_offset][q]} — the loop body of test(), model/cvig_fov.py:550-552 */
+int witw_rank_count(const float* distance /*[Bo,Bs]*/, int* ranks /*[Bs]*/, int Bo, int Bs, int true_offset, void* stream);
+
+/* ---- triplet_loss, model/cvig_fov.py:366-382. workspace: 4*B floats, filled by fwd, read by bwd. */
+int witw_triplet_loss_fwd(const float* distance /*[B,B]*/, int B, float alpha, float* loss /*[1]*/, float* workspace,
+                          void* stream);
+int witw_triplet_loss_bwd(const float* distance, const float* workspace, const float* grad_loss /*[1]*/,
+                          float* grad_distance /*[B,B]*/, int B, float alpha, void* stream);
+
+/* ---- data path: Resize (:100-134), ImageNormalization (:137-149; semantic: cvig_semantic.py:167-176),
+ *      PolarTransform (:156-209). NCHW fp32. mean/stdv: HOST arrays of C floats (NULL = resize only). */
+int witw_resize_bilinear_normalize(const float* x, float* y, int B, int C, int Hi, int Wi, int Ho, int Wo,
+                                   const float* mean, const float* stdv, int n_div255, void* stream);
+int witw_normalize(const float* x, float* y, int B, int C, int H, int W, const float* mean, const float* stdv, int n_div255,
+                   void* stream);
+/* taps: int32 [Ho*Wo][4] flat offsets into a size*size plane; wts: fp32 [Ho*Wo][4]; both DEVICE tables
+ * built on the host in fp64 exactly as model/cvig_fov.py:163-181,197-201. */
+int witw_polar_transform(const float* x, const int* taps, const float* wts, float* y, int B, int C, int size, int Ho, int Wo,
+                         void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WITW_HIP_H */

@@ -1,0 +1,72 @@
+"""CPU-side checks of the C-ABI boundary: the library builds/loads without a GPU and exports exactly the
+symbols include/witw_hip.h declares; argument validation fails loudly; nothing in the product imports the oracle."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, 'include', 'witw_hip.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(witw_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from witw_amd import _lib
+    lib = _lib.load()
+    names = _declared()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), 'libwitw_hip.so lacks %s declared in include/witw_hip.h' % n
+    assert sorted(_lib.SIGNATURES) == names, 'ctypes SIGNATURES and the header disagree'
+    exported = subprocess.check_output(['nm', '-D', '--defined-only', _lib.lib_path()]).decode()
+    exported = sorted(set(re.findall(r' T (witw_[a-z0-9_]+)', exported)))
+    assert exported == names, 'exported symbols and header differ: %s' % (set(exported) ^ set(names))
+
+
+def test_header_compiles_as_c():
+    subprocess.check_call(['gcc', '-std=c99', '-Wall', '-Werror', '-fsyntax-only', '-x', 'c',
+                           os.path.join(ROOT, 'include', 'witw_hip.h')])
+
+
+def test_version_and_argument_errors_without_gpu():
+    from witw_amd import _lib
+    lib = _lib.load()
+    assert lib.witw_version() >= 100
+    assert lib.witw_conv3x3_tile_n(64) == 64 and lib.witw_conv3x3_tile_n(512) == 128
+    assert lib.witw_conv3x3_packed_floats(64, 3) == 1 * 1 * 9 * 2 * 64 * 4
+    assert lib.witw_conv3x3_bias_floats(16) == 64
+    # invalid arguments are rejected before any launch, with a message
+    rc = lib.witw_conv3x3_fwd(None, None, None, None, None, 1, 1, 1, 8, 8, 1, 0, 0, 0, 0, None)
+    assert rc == -1 and b'null' in lib.witw_last_error()
+    rc = lib.witw_match_fwd(1, 1, 4, 4, 65, None, None, None, 1, None)
+    assert rc == -1 and b'width' in lib.witw_last_error()
+    rc = lib.witw_triplet_loss_fwd(1, 1, 10.0, 1, 1, None)
+    assert rc == -1 and b'batch' in lib.witw_last_error()
+    with pytest.raises(_lib.WitwError):
+        _lib.check(rc, 'witw_triplet_loss_fwd')
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, 'witw_amd')
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith('.py'):
+                txt = open(os.path.join(dp, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', txt, flags=re.M), f
+                assert '/root/reference' not in txt, f
+
+
+def test_product_refuses_cpu_tensors():
+    import torch
+    from witw_amd import _lib, cvig_fov, ops
+    with pytest.raises(_lib.WitwError):
+        ops.match_fwd(torch.zeros(2, 16, 4, 64), torch.zeros(2, 16, 4, 64))
+    with pytest.raises(_lib.WitwError):
+        cvig_fov.FOV_DSM()(torch.zeros(1, 3, 128, 512))
+    with pytest.raises(_lib.WitwError):
+        ops.polar_transform(torch.zeros(1, 3, 256, 256))

@@ -48,6 +48,10 @@ def load():
     global _LIB
     if _LIB is not None:
         return _LIB
+    # torch ships its own libamdhip64.so (same SONAME as /opt/rocm's). It must be mapped BEFORE this
+    # library so that both share ONE HIP runtime (streams and device pointers are exchanged); a
+    # second runtime in the process fails with "no ROCm-capable device is detected".
+    import torch  # noqa: F401
     path = _build.LIB
     if not os.path.exists(path) or (os.path.isdir(_build.CSRC) and _build.stale() and os.path.exists(_build.HIPCC)):
         _build.build(verbose=False)

@@ -20,8 +20,9 @@ int witw_version(void) { return 100; }  // 0.1.0
 // 0 when device `dev` exists and is a gfx950 part; the message says what was found otherwise.
 int witw_device_check(int dev) {
     int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
-        witw_set_error("no HIP device visible");
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        witw_set_error("no HIP device visible (hipGetDeviceCount: %s, count %d)", hipGetErrorString(e), n);
         return WITW_ERR_NODEVICE;
     }
     if (dev < 0 || dev >= n) {

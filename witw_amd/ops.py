@@ -8,6 +8,11 @@ import torch
 from . import _lib
 
 
+# When set to a list, every conv3x3 launch is bracketed by HIP events on the launch stream and
+# (variant, algorithmic FLOPs, start, end) is appended (bench.py's live roofline measurement).
+PROFILE = None
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -73,9 +78,17 @@ def conv3x3_fwd(x_nhwc, packed, stride_h=1, circular=False, relu=True, pool=Fals
         drop_scale = _dev_f32(drop_scale, 'drop_scale')
         if tuple(drop_scale.shape) != (B, packed.cout):
             raise _lib.WitwError('drop_scale must be [B,Cout]')
+    prof = PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     _lib.check(lib.witw_conv3x3_fwd(x.data_ptr(), packed.wpk.data_ptr(), packed.bias.data_ptr(), _p(drop_scale),
                                     y.data_ptr(), B, H, W, C, packed.cout, stride_h, int(circular), int(relu),
                                     int(pool), int(out_nchw), _stream()), 'witw_conv3x3_fwd')
+    if prof is not None:
+        e1.record()
+        variant = (lib.witw_conv3x3_tile_n(packed.cout), stride_h, bool(pool))
+        prof.append((variant, 2.0 * packed.cin * packed.cout * 9 * Ho * W * B, e0, e1))
     return y
 
 
