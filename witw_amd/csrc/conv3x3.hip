@@ -25,6 +25,10 @@ constexpr int TW = 64;
 constexpr int IW = TW + 2;
 constexpr int NTHREADS = 256;
 
+// Source of every padded (out-of-image) halo slot: loading zeros from memory keeps the staging
+// path free of selects, which the compiler would otherwise pin right behind each load (vmcnt(0)).
+__device__ const f32x4 g_zero_f4[1] = {{0.f, 0.f, 0.f, 0.f}};
+
 struct ConvArgs {
     const float* x;         // [B,H,W,Cin] NHWC, Cin % 8 == 0
     const float* wpk;       // packed: [n_tile][cin/8][tap][quad][TN][4]
@@ -35,6 +39,9 @@ struct ConvArgs {
     int Ho, Wo;             // conv output size (before pooling)
     int tiles_x, tiles_y;
     int circ, relu, out_nchw;
+#ifdef WITW_STAMPS
+    unsigned long long* stamps;   // diagnostic build only (tools/conv_stamps.cpp)
+#endif
 };
 
 template <int TN, int SH, bool POOL>
@@ -49,7 +56,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_nhwc_f32_kernel(ConvArgs p) 
     constexpr int WM = 8 / WGM;                 // M-tiles per wave
     constexpr int WN = 2;                       // N-tiles per wave (64 channels)
 
-    __shared__ f32x4 smem[2 * STAGE_F4];
+    __shared__ f32x4 smem[2 * STAGE_F4 + 1];   // +1: dummy slot that absorbs out-of-tile staging stores
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -75,7 +82,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_nhwc_f32_kernel(ConvArgs p) 
 
     // ---- per-thread staging descriptors (constant over the K loop)
     const float* gin[NIN];
-    bool gok[NIN];
+    int gstep[NIN];   // floats to advance per K chunk (0 for padded slots, which stay on the zero source)
 #pragma unroll
     for (int i = 0; i < NIN; ++i) {
         const int s = tid + i * NTHREADS;
@@ -90,24 +97,23 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_nhwc_f32_kernel(ConvArgs p) 
         } else {
             ok = ok && gc >= 0 && gc < p.W;
         }
-        gok[i] = ok;
-        const size_t off = ok ? ((size_t)((size_t)b * p.H + gr) * p.W + gc) * p.Cin + q * 4 : 0;
-        gin[i] = p.x + off;
+        gstep[i] = ok ? 8 : 0;
+        gin[i] = ok ? p.x + (((size_t)((size_t)b * p.H + gr) * p.W + gc) * p.Cin + q * 4)
+                    : reinterpret_cast<const float*>(g_zero_f4);
     }
     const f32x4* gw = reinterpret_cast<const f32x4*>(p.wpk) + (size_t)ntile * nkc * W_F4 + tid;
 
+    // Staging is branch-free so that the whole K-chunk body is ONE scheduling region: loads of
+    // padded slots load from a zero source, out-of-tile slots are sent to the dummy LDS slot.
     f32x4 rin[NIN], rw[NWT];
     auto load_stage = [&](int kc) {
 #pragma unroll
-        for (int i = 0; i < NIN; ++i) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (gok[i]) v = *reinterpret_cast<const f32x4*>(gin[i] + (size_t)kc * 8);
-            rin[i] = v;
-        }
+        for (int i = 0; i < NIN; ++i) rin[i] = *reinterpret_cast<const f32x4*>(gin[i] + (size_t)kc * gstep[i]);
         const f32x4* w = gw + (size_t)kc * W_F4;
 #pragma unroll
         for (int i = 0; i < NWT; ++i) {
-            if (NWT * NTHREADS == W_F4 || tid + i * NTHREADS < W_F4) rw[i] = w[i * NTHREADS];
+            const int s = tid + i * NTHREADS;
+            rw[i] = w[(NWT * NTHREADS == W_F4 || s < W_F4) ? i * NTHREADS : 0];
         }
     };
     auto store_stage = [&](int buf) {
@@ -116,12 +122,14 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_nhwc_f32_kernel(ConvArgs p) 
 #pragma unroll
         for (int i = 0; i < NIN; ++i) {
             const int s = tid + i * NTHREADS;
-            if (NIN * NTHREADS == IN_F4 || s < IN_F4) in_s[(s & 1) * (IH * IW) + (s >> 1)] = rin[i];
+            f32x4* dst = (NIN * NTHREADS == IN_F4 || s < IN_F4) ? in_s + (s & 1) * (IH * IW) + (s >> 1) : smem + 2 * STAGE_F4;
+            *dst = rin[i];
         }
 #pragma unroll
         for (int i = 0; i < NWT; ++i) {
             const int s = tid + i * NTHREADS;
-            if (NWT * NTHREADS == W_F4 || s < W_F4) w_s[s] = rw[i];
+            f32x4* dst = (NWT * NTHREADS == W_F4 || s < W_F4) ? w_s + s : smem + 2 * STAGE_F4;
+            *dst = rw[i];
         }
     };
 
@@ -152,35 +160,116 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_nhwc_f32_kernel(ConvArgs p) 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
+    // ---- main loop. Per K chunk: 9 taps x 4 k-steps x (WM x WN) MFMAs. The operand fragments of
+    // tap t+1 are read from LDS BEFORE the MFMAs of tap t are issued (two register sets), the
+    // next chunk's global loads are issued at the top of the chunk and written to the other LDS
+    // buffer after tap 4, and the chunk's single barrier sits in front of tap 8 so that the
+    // first fragments of the next chunk are fetched behind tap 8's MFMAs: the matrix pipe only
+    // idles for the barrier skew.
+    f32x4 fa[2][WM], fb[2][WN];
+    auto read_frags = [&](int set, const f32x4* in_s, const f32x4* w_s, int tap) {
+        const int kh = tap / 3, kw = tap - kh * 3;
+#pragma unroll
+        for (int mt = 0; mt < WM; ++mt) fa[set][mt] = in_s[abase[mt] + kh * IW + kw];
+#pragma unroll
+        for (int nt = 0; nt < WN; ++nt) fb[set][nt] = w_s[tap * 2 * TN + wbase + nt * 32];
+    };
+    auto mfma_tap = [&](int set) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < WN; ++nt)
+                    acc[mt][nt] =
+                        __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][mt][j], fb[set][nt][j], acc[mt][nt], 0, 0, 0);
+    };
+
+#ifdef WITW_STAMPS
+    unsigned long long t_stamp[6];
+    int n_stamp = 0;
+#define STAMP() do { if (n_stamp < 6) t_stamp[n_stamp++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP() do { } while (0)
+#endif
+    STAMP();
     load_stage(0);
     store_stage(0);
     __syncthreads();
+    read_frags(0, smem, smem + IN_F4, 0);
+    STAMP();
+
+    // Issue-order recipe for one tap (LLVM sched groups: 0x8 MFMA, 0x20 VMEM read, 0x100 DS read,
+    // 0x200 DS write): every LDS / global instruction is issued alone between MFMAs so that it
+    // hides in the shadow of a 64-cycle v_mfma_f32_32x32x2_f32 instead of stalling the pipe.
+    constexpr int MPT = 4 * WM * WN;   // MFMAs per tap
+    constexpr int RPT = WM + WN;       // fragment reads per tap
+#define SG_PLAIN_TAP()                                                  \
+    do {                                                                \
+        _Pragma("unroll") for (int i_ = 0; i_ < RPT; ++i_) {            \
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);          \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);          \
+        }                                                               \
+        _Pragma("unroll") for (int i_ = 0; i_ < MPT - 2 * RPT; ++i_)    \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          \
+    } while (0)
+#define SG_HEAVY_TAP(MASK, NX)                                          \
+    do {                                                                \
+        _Pragma("unroll") for (int i_ = 0; i_ < RPT; ++i_) {            \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);          \
+        }                                                               \
+        _Pragma("unroll") for (int i_ = 0; i_ < (NX); ++i_) {           \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          \
+            __builtin_amdgcn_sched_group_barrier(MASK, 1, 0);           \
+        }                                                               \
+        _Pragma("unroll") for (int i_ = 0; i_ < MPT - RPT - (NX); ++i_) \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          \
+    } while (0)
+    static_assert(MPT - RPT - (NIN + NWT) >= 0, "tap too short to hide the staging instructions");
 
     for (int kc = 0; kc < nkc; ++kc) {
         const int cur = kc & 1;
-        if (kc + 1 < nkc) load_stage(kc + 1);
+        const int kn = (kc + 1 < nkc) ? kc + 1 : kc;   // last chunk restages itself (never read)
         const f32x4* in_s = smem + cur * STAGE_F4;
         const f32x4* w_s = in_s + IN_F4;
+        const f32x4* in_n = smem + (cur ^ 1) * STAGE_F4;
+        // tap 0 (+ global loads of the next chunk)
+        read_frags(1, in_s, w_s, 1);
+        load_stage(kn);
+        mfma_tap(0);
+        SG_HEAVY_TAP(0x020, NIN + NWT);
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int kh = tap / 3, kw = tap - kh * 3;
-            f32x4 a[WM], bq[WN];
-#pragma unroll
-            for (int mt = 0; mt < WM; ++mt) a[mt] = in_s[abase[mt] + kh * IW + kw];
-#pragma unroll
-            for (int nt = 0; nt < WN; ++nt) bq[nt] = w_s[tap * 2 * TN + wbase + nt * 32];
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int mt = 0; mt < WM; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < WN; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][j], bq[nt][j], acc[mt][nt], 0, 0, 0);
+        for (int tap = 1; tap < 4; ++tap) {
+            read_frags((tap + 1) & 1, in_s, w_s, tap + 1);
+            mfma_tap(tap & 1);
+            SG_PLAIN_TAP();
         }
-        if (kc + 1 < nkc) store_stage(cur ^ 1);
+        // tap 4 (+ LDS writes of the next chunk)
+        read_frags(1, in_s, w_s, 5);
+        store_stage(cur ^ 1);
+        mfma_tap(0);
+        SG_HEAVY_TAP(0x200, NIN + NWT);
+#pragma unroll
+        for (int tap = 5; tap < 8; ++tap) {
+            read_frags((tap + 1) & 1, in_s, w_s, tap + 1);
+            mfma_tap(tap & 1);
+            SG_PLAIN_TAP();
+        }
         __syncthreads();
+        // tap 8, behind which the first fragments of the next chunk arrive
+        read_frags(1, in_n, in_n + IN_F4, 0);
+        mfma_tap(0);
+        SG_PLAIN_TAP();
+#pragma unroll
+        for (int mt = 0; mt < WM; ++mt) fa[0][mt] = fa[1][mt];
+#pragma unroll
+        for (int nt = 0; nt < WN; ++nt) fb[0][nt] = fb[1][nt];
     }
+#undef SG_PLAIN_TAP
+#undef SG_HEAVY_TAP
 
+    STAMP();
     // ---- epilogue: bias, dropout scale, ReLU, optional 2x2 max pool, store
     float bv[WN], dm[WN];
     int nch[WN];
@@ -237,6 +326,15 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_nhwc_f32_kernel(ConvArgs p) 
                     }
         }
     }
+#ifdef WITW_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP();
+    if (lane == 0 && p.stamps != nullptr) {
+        unsigned long long* o = p.stamps + ((size_t)blockIdx.x * 4 + wave) * 8;
+        for (int i = 0; i < n_stamp; ++i) o[i] = t_stamp[i];
+        o[7] = n_stamp;
+    }
+#endif
 }
 
 // One thread per packed float4: wpk[nt][kc][tap][q][n][0..3] <- w[cout][cin][kh][kw]
@@ -299,6 +397,10 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
 
 }  // namespace
 
+#ifdef WITW_STAMPS
+unsigned long long* witw_conv_stamps_ptr = nullptr;
+#endif
+
 extern "C" {
 
 int witw_conv3x3_tile_n(int cout) { return cout >= 128 ? 128 : 64; }
@@ -356,6 +458,9 @@ int witw_conv3x3_fwd(const float* x, const float* wpk, const float* bias, const 
     a.tiles_x = cdiv(a.Wo, TW);
     a.tiles_y = cdiv(a.Ho, TH);
     a.circ = pad_circular; a.relu = relu; a.out_nchw = out_nchw;
+#ifdef WITW_STAMPS
+    a.stamps = witw_conv_stamps_ptr;
+#endif
     hipStream_t st = (hipStream_t)stream;
     const int TN = witw_conv3x3_tile_n(Cout);
     if (TN == 128) {
