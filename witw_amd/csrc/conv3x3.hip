@@ -296,7 +296,35 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_nhwc_f32_kernel(ConvArgs p) 
         }
     };
 
-    if (!POOL) {
+    if (!POOL && !p.out_nchw && (p.Cout & 3) == 0) {
+        // Wide NHWC store: one M-tile (32 pixels x this wave's 64 channels) at a time is transposed
+        // through a wave-private 8 KB LDS slab (the staging buffers are dead: every useful fragment
+        // read precedes the loop's last barrier) and leaves as 16-byte stores, 4 pixels x 256 B per
+        // wave-instruction, instead of 4-byte stores straight from the accumulator layout.
+        float* slab = reinterpret_cast<float*>(smem) + wave * (32 * 64);
+        const int prow = lane >> 4, pc4 = (lane & 15) * 4;   // read-back role: pixel row in a group of 4, channel quad
+#pragma unroll
+        for (int mt = 0; mt < WM; ++mt) {
+#pragma unroll
+            for (int nt = 0; nt < WN; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = (acc[mt][nt][r] + bv[nt]) * dm[nt];
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    slab[((r & 3) + 8 * (r >> 2) + 4 * hq) * 64 + nt * 32 + l31] = v;
+                }
+            const int yy = oy0 + trow[mt];
+            const int nbase = n0 + wn * 64 + pc4;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const int m = g * 4 + prow;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(slab + m * 64 + pc4);
+                const int xx = ox0 + tcol[mt] + m;
+                if (yy < Hy && xx < Wy && nbase < p.Cout)
+                    *reinterpret_cast<f32x4*>(p.y + (((size_t)b * Hy + yy) * Wy + xx) * p.Cout + nbase) = v;
+            }
+        }
+    } else if (!POOL) {
 #pragma unroll
         for (int mt = 0; mt < WM; ++mt)
 #pragma unroll
