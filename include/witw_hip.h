@@ -49,12 +49,36 @@ int witw_conv3x3_fwd(const float* x, const float* wpk, const float* bias, const 
                      int W, int Cin, int Cout, int stride_h, int pad_circular, int relu, int pool, int out_nchw,
                      void* stream);
 
+/* Extended form used by the backward pass: `gate` (NULL or a tensor shaped like y) zeroes outputs where
+ * gate <= 0 (ReLU backward), dilate_h=1 reads the input as zero-interleaved rows (row 2i = physical row i,
+ * H is the dilated height) — the data gradient of a stride-(2,1) conv is then this same kernel on the
+ * transpose_flip filter. autograd of torch.nn.Conv2d at model/cvig_fov.py:460. */
+int witw_conv3x3_fwd_ex(const float* x, const float* wpk, const float* bias, const float* dropmask, const float* gate,
+                        float* y, int B, int H, int W, int Cin, int Cout, int stride_h, int pad_circular, int relu, int pool,
+                        int out_nchw, int dilate_h, void* stream);
+/* NCHW [B,C,H,W] -> NHWC [B,H,W,Cpad] with zero-filled extra channels (embedding gradients). */
+int witw_nchw_to_nhwc(const float* x, float* y, int B, int C, int H, int W, int Cpad, void* stream);
+/* Weight / bias gradient of one conv layer. x: the layer's NHWC input [B,H,W,Cin], dz: gradient at its output
+ * [B,Ho,W,Cout] NHWC (ReLU / dropout gates already applied). dw: torch layout [Cout][cin_real][3][3];
+ * db: [Cout] or NULL; accumulate != 0 adds into dw/db. workspace: witw_conv3x3_wgrad_workspace_floats(). */
+int witw_conv3x3_wgrad_splits(int B, int Ho, int Wo, int Cin, int Cout);
+long long witw_conv3x3_wgrad_workspace_floats(int B, int H, int W, int Cin, int Cout, int stride_h);
+int witw_conv3x3_wgrad(const float* x, const float* dz, float* dw, float* db, float* workspace, int B, int H, int W, int Cin,
+                       int cin_real, int Cout, int stride_h, int pad_circular, int accumulate, void* stream);
+/* torch.optim.Adam step (no weight decay / amsgrad), optimizer of model/cvig_fov.py:416-418. step counts from 1. */
+int witw_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr, float beta1,
+                   float beta2, float eps, int step, void* stream);
+
 /* ---- matching: correlation (:297-315) + crop_overhead (:318-343) + l2_distance (:346-363) fused.
  * ov [Bo,16,4,64], su [Bs,16,4,We] (NCHW embeddings). Outputs [Bo,Bs]; any of them may be NULL.
  * workspace: witw_match_workspace_floats(Bo,Bs) floats (window norms + surface norms). */
 long long witw_match_workspace_floats(int Bo, int Bs);
 int witw_match_fwd(const float* ov, const float* su, int Bo, int Bs, int We, long long* orientation, float* distance,
                    float* score, float* workspace, void* stream);
+/* backward of witw_match_fwd (orientation is a constant of the graph): grad_distance [Bo,Bs] ->
+ * grad_ov [Bo,16,4,64] and/or grad_su [Bs,16,4,We]; orientation/score/workspace as left by the forward. */
+int witw_match_bwd(const float* ov, const float* su, const long long* orientation, const float* score, const float* workspace,
+                   const float* grad_distance, float* grad_ov, float* grad_su, int Bo, int Bs, int We, void* stream);
 /* compatibility entries with the reference's materialising semantics */
 int witw_crop_overhead(const float* ov, const long long* orientation, float* out /*[Bo,Bs,16,4,We]*/, int Bo, int Bs,
                        int We, void* stream);

@@ -251,3 +251,36 @@ def recall_table(ranks_arr):
         'mean': float(np.mean(ranks_arr)),
         'median': float(np.median(ranks_arr)),
     }
+
+
+# ----------------------------------------------------------------------------- training step
+TRAINABLE = (17, 19, 21, 23, 25, 27)   # model/cvig_fov.py:275-278
+
+
+def train_step(surface, overhead, w_surface, w_overhead, drop_surface=None, drop_overhead=None, lr=1.E-5,
+               adam_state=None):
+    """One iteration of the loop body model/cvig_fov.py:444-461 with torch autograd on the CPU:
+    forward (train mode, injected Dropout2d scales) -> correlation/crop/l2_distance -> triplet_loss ->
+    backward -> Adam(lr) step over the trainable layers. w_*: {idx: (w, b)} torch tensors (updated in place).
+    Returns (loss, orientation, distance, grads {('s'|'o', idx): (dw, db)})."""
+    leaves = {}
+    for tag, w in (('s', w_surface), ('o', w_overhead)):
+        for idx in TRAINABLE:
+            for t in w[idx]:
+                t.requires_grad_(True)
+                t.grad = None
+            leaves[(tag, idx)] = w[idx]
+    s_emb = fov_dsm_forward(surface, w_surface, False, dropout_scales=drop_surface)
+    o_emb = fov_dsm_forward(overhead, w_overhead, True, dropout_scales=drop_overhead)
+    ori, dist = match(o_emb, s_emb)
+    loss = triplet_loss(dist)
+    loss.backward()
+    grads = {k: (v[0].grad.clone(), v[1].grad.clone()) for k, v in leaves.items()}
+    params = [t for v in leaves.values() for t in v]
+    opt = torch.optim.Adam(params, lr=lr)
+    if adam_state is not None:
+        opt.load_state_dict(adam_state)
+    opt.step()
+    for t in params:
+        t.requires_grad_(False)
+    return loss.detach(), ori, dist.detach(), grads

@@ -269,5 +269,68 @@ def main():
             print('  %-28s %8d bytes' % (f, os.path.getsize(os.path.join(HERE, f))))
 
 
-if __name__ == '__main__':
+if __name__ == '__main__' and '--trainstep' not in sys.argv:
     main()
+
+
+def gen_trainstep():
+    """One iteration of the reference's training loop body (model/cvig_fov.py:444-461) on a tiny batch,
+    Dropout2d masks captured, then one torch.optim.Adam step (lr as :418). Stores the loss, per-parameter
+    gradient norms and strided samples of gradients and of updated parameters."""
+    fov, sem, base = import_reference()
+    fov.device = torch.device('cpu')
+    weights = synth.fov_dsm_weights(SEED + 1)
+    B, ws = 3, 96      # fov 67.5 deg -> int(67.5/360*512) = 96 -> embedding width 12
+    xs = torch.from_numpy(synth.normalized_images(SEED, 20, (B, 3, 128, ws)))
+    xo = torch.from_numpy(synth.normalized_images(SEED, 21, (B, 3, 128, 512)))
+    se = build_ref_encoder(fov, False, weights).train()
+    oe = build_ref_encoder(fov, True, weights).train()
+    captured = {}
+
+    def mk_hook(tag, i):
+        def hook(m, inp, outp):
+            xi, xo_ = inp[0].detach(), outp.detach()
+            b, c = xi.shape[:2]
+            fi = xi.reshape(b, c, -1)
+            pos = fi.abs().argmax(-1, keepdim=True)
+            sc = (xo_.reshape(b, c, -1).gather(2, pos) / fi.gather(2, pos)).squeeze(-1).numpy()
+            captured[(tag, i)] = np.where(np.abs(sc) < 1e-6, 0.0, 1.25).astype(np.float32)
+        return hook
+    for tag, e in (('s', se), ('o', oe)):
+        for i in (17, 19, 21):
+            e.model.features[i].postlayer.register_forward_hook(mk_hook(tag, i))
+    params = [p for p in list(se.parameters()) + list(oe.parameters())]
+    opt = torch.optim.Adam(params, lr=1.E-5)
+    torch.manual_seed(77)
+    s_emb = se(xs)
+    o_emb = oe(xo)
+    ori = fov.correlation(o_emb, s_emb)
+    crop = fov.crop_overhead(o_emb, ori, s_emb.shape[3])
+    dist = fov.l2_distance(crop, s_emb)
+    loss = fov.triplet_loss(dist)
+    opt.zero_grad()
+    loss.backward()
+    res = {'seed': SEED, 'B': B, 'ws': ws, 'loss': loss.detach().numpy(), 'orientation': ori.numpy(),
+           'distance': dist.detach().numpy()}
+    for (tag, i), v in captured.items():
+        res['drop_%s_%d' % (tag, i)] = v
+    named = [('s.' + n, p) for n, p in se.named_parameters()] + [('o.' + n, p) for n, p in oe.named_parameters()]
+    names = []
+    for n, p in named:
+        if p.grad is None or 'classifier' in n:
+            continue
+        names.append(n)
+        g = p.grad.detach().reshape(-1)
+        res['gnorm:' + n] = np.float64(g.double().norm().item())
+        res['gsamp:' + n] = g[::max(1, g.numel() // 257)].numpy()
+    opt.step()
+    for n, p in named:
+        if n in names:
+            res['psamp:' + n] = p.detach().reshape(-1)[::max(1, p.numel() // 257)].numpy()
+    res['names'] = np.array(names)
+    np.savez(os.path.join(HERE, 'trainstep.npz'), **res)
+    print('trainstep.npz: loss %.6f, %d trainable tensors' % (loss.item(), len(names)))
+
+
+if __name__ == '__main__' and '--trainstep' in sys.argv:
+    gen_trainstep()

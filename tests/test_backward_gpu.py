@@ -1,0 +1,165 @@
+"""GPU parity of the backward kernels (wgrad, dgrad, match backward, Adam) and of a whole training step."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import cvig_fov_oracle as O
+from witw_amd import synth
+from tests.test_trainstep_golden import load_case, ref_key, sample
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(seed, shape, scale=1.0):
+    g = np.random.Generator(np.random.Philox(key=[seed, 9]))
+    return torch.from_numpy((g.standard_normal(shape, dtype=np.float32) * np.float32(scale)).astype(np.float32))
+
+
+def _nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+CASES = [  # B, H, W, Cin, Cout, stride_h, circ
+    (2, 16, 64, 64, 128, 1, True),
+    (2, 16, 64, 64, 128, 1, False),
+    (3, 8, 12, 256, 64, 2, True),
+    (2, 7, 24, 64, 64, 2, False),       # odd height under stride 2
+    (2, 4, 64, 64, 16, 1, True),        # layer-27 shape (Cout 16)
+    (1, 5, 130, 8, 72, 1, True),        # three column segments, ragged channel tiles
+]
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_wgrad_and_dgrad_match_autograd(case):
+    from witw_amd import ops
+    B, H, W, Cin, Cout, sh, circ = case
+    x = _rand(1, (B, Cin, H, W)).requires_grad_(True)
+    w = _rand(2, (Cout, Cin, 3, 3), 0.05).requires_grad_(True)
+    b = _rand(3, (Cout,), 0.1).requires_grad_(True)
+    y = O.conv3x3(x, w, b, sh, circ)
+    gy = _rand(4, tuple(y.shape))
+    y.backward(gy)
+    dev = torch.device('cuda:0')
+    xd, gyd = _nhwc(x.detach()).to(dev), _nhwc(gy).to(dev)
+    dw, db = ops.conv3x3_wgrad(xd, gyd, Cin, stride_h=sh, circular=circ)
+    scale = max(1.0, float(w.grad.abs().max()))
+    np.testing.assert_allclose(dw.cpu().numpy(), w.grad.numpy(), rtol=0, atol=2e-5 * scale)
+    np.testing.assert_allclose(db.cpu().numpy(), b.grad.numpy(), rtol=0, atol=2e-5 * max(1.0, float(b.grad.abs().max())))
+    # data gradient = the forward kernel on the transposed, tap-rotated filter (+ zero-interleaved rows for stride 2)
+    if Cout % 8 == 0:
+        pt = ops.PackedConv(w.detach().to(dev), None, transpose_flip=True)
+        dx = ops.conv3x3_fwd(gyd, pt, stride_h=1, circular=circ, relu=False, dilate_h=(sh == 2),
+                             out_h=H if sh == 2 else None)
+        assert dx.shape == (B, H, W, Cin)
+        np.testing.assert_allclose(dx.cpu().permute(0, 3, 1, 2).numpy(), x.grad.numpy(), rtol=0,
+                                   atol=2e-5 * max(1.0, float(x.grad.abs().max())))
+
+
+def test_dgrad_gate_and_dropout_scale():
+    from witw_amd import ops
+    B, H, W, C = 2, 8, 64, 64
+    dev = torch.device('cuda:0')
+    gy = _rand(5, (B, H, W, C)).to(dev)
+    w = _rand(6, (C, C, 3, 3), 0.05).to(dev)
+    gate = _rand(7, (B, H, W, C)).to(dev)
+    scale = torch.from_numpy(synth.dropout_scales(8, 0, B, C)).to(dev)
+    pt = ops.PackedConv(w, None, transpose_flip=True)
+    plain = ops.conv3x3_fwd(gy, pt, relu=False, circular=True)
+    gated = ops.conv3x3_fwd(gy, pt, relu=False, circular=True, drop_scale=scale, gate=gate)
+    ref = plain * scale[:, None, None, :] * (gate > 0).float()
+    np.testing.assert_allclose(gated.cpu().numpy(), ref.cpu().numpy(), rtol=0, atol=1e-6)
+
+
+def test_match_backward_matches_reference_goldens(golden_dir):
+    from witw_amd import cvig_fov
+    g = np.load(os.path.join(golden_dir, 'matching.npz'))
+    seed = int(g['seed'])
+    for tag in 'ade':
+        bo, bs, we = (int(v) for v in g['%s_shape' % tag])
+        ov = torch.from_numpy(synth.embeddings(seed, 100 + ord(tag), (bo, 16, 4, 64))).cuda().requires_grad_(True)
+        su = torch.from_numpy(synth.embeddings(seed, 200 + ord(tag), (bs, 16, 4, we))).cuda().requires_grad_(True)
+        ori, dist = cvig_fov.match(ov, su)
+        loss = cvig_fov.triplet_loss(dist)
+        loss.backward()
+        np.testing.assert_allclose(loss.item(), float(g['%s_loss' % tag]), rtol=1e-5)
+        np.testing.assert_allclose(ov.grad.cpu().numpy(), g['%s_grad_ov' % tag], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(su.grad.cpu().numpy(), g['%s_grad_su' % tag], rtol=0, atol=2e-6)
+
+
+def test_match_backward_rectangular_vs_oracle():
+    from witw_amd import cvig_fov
+    ov = torch.from_numpy(synth.embeddings(21, 1, (37, 16, 4, 64)))
+    su = torch.from_numpy(synth.embeddings(22, 1, (29, 16, 4, 33)))
+    gd = _rand(23, (37, 29))
+    ovr, sur = ov.clone().requires_grad_(True), su.clone().requires_grad_(True)
+    _, d = O.match(ovr, sur)
+    (d * gd).sum().backward()
+    ovg, sug = ov.cuda().requires_grad_(True), su.cuda().requires_grad_(True)
+    _, dg = cvig_fov.match(ovg, sug)
+    (dg * gd.cuda()).sum().backward()
+    np.testing.assert_allclose(ovg.grad.cpu().numpy(), ovr.grad.numpy(), rtol=0, atol=5e-6)
+    np.testing.assert_allclose(sug.grad.cpu().numpy(), sur.grad.numpy(), rtol=0, atol=5e-6)
+
+
+def test_adam_matches_torch():
+    from witw_amd import cvig_fov
+    p0, g1, g2 = _rand(31, (1000,)), _rand(32, (1000,), 0.01), _rand(33, (1000,), 0.01)
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pr], lr=1e-5)
+    pg = torch.nn.Parameter(p0.clone().cuda())
+    mine = cvig_fov.Adam([pg], lr=1e-5)
+    for gr in (g1, g2, g1):
+        pr.grad = gr.clone()
+        opt.step()
+        pg.grad = gr.clone().cuda()
+        mine.step()
+    np.testing.assert_allclose(pg.detach().cpu().numpy(), pr.detach().numpy(), rtol=0, atol=1e-7)
+    assert (pr.detach() - p0).abs().max() > 1e-5
+
+
+def test_training_step_matches_reference_golden(golden_dir):
+    """model/cvig_fov.py:444-461 on the GPU: loss, orientation, every trainable gradient and the
+    parameters after one Adam step against the reference's own run."""
+    from witw_amd import cvig_fov
+    g, xs, xo, w, drops = load_case(golden_dir)
+    dev = torch.device('cuda:0')
+    se = cvig_fov.FOV_DSM(False, weights=w).to(dev).train()
+    oe = cvig_fov.FOV_DSM(True, weights=w).to(dev).train()
+    opt = cvig_fov.Adam(list(se.parameters()) + list(oe.parameters()), lr=1.E-5)
+    s_emb = se(xs.to(dev), dropout_scales={k: v.to(dev) for k, v in drops['s'].items()})
+    o_emb = oe(xo.to(dev), dropout_scales={k: v.to(dev) for k, v in drops['o'].items()})
+    ori, dist = cvig_fov.match(o_emb, s_emb)
+    loss = cvig_fov.triplet_loss(dist)
+    opt.zero_grad()
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), float(g['loss']), rtol=0, atol=1e-4)
+    np.testing.assert_array_equal(ori.cpu().numpy(), g['orientation'])
+    np.testing.assert_allclose(dist.detach().cpu().numpy(), g['distance'], rtol=0, atol=1e-4)
+    named = {('s.' + n): p for n, p in se.named_parameters()}
+    named.update({('o.' + n): p for n, p in oe.named_parameters()})
+    # Gradients upstream of a ReLU are only piecewise continuous: one activation within rounding of 0
+    # flips its gate between the CPU and GPU forward and moves one channel's gradient by that pixel's
+    # share (this tiny batch has 3x16x12 pixels per channel), and everything upstream of it slightly.
+    # Hence a norm-wise 1e-2 bound everywhere and rounding-level agreement below the last gated layer.
+    for name in g['names']:
+        p = named[str(name)]
+        ref = g['gsamp:' + str(name)]
+        got = sample(p.grad.detach().cpu()).numpy()
+        gn = float(g['gnorm:' + str(name)])
+        assert abs(p.grad.detach().double().norm().item() - gn) <= 1e-2 * gn + 1e-9, name
+        assert np.linalg.norm(got - ref) <= 1e-2 * np.linalg.norm(ref) + 1e-9, name
+        # layers whose gradient does not pass through a flipped gate in this fixture agree to rounding
+        if any(('features.%d' % i) in str(name) for i in (23, 25, 27)):
+            assert np.linalg.norm(got - ref) <= 2e-5 * np.linalg.norm(ref), name
+    assert all(p.grad is None for n, p in named.items() if str(n) not in set(g['names']))   # frozen layers
+    opt.step()
+    for name in g['names']:
+        np.testing.assert_allclose(sample(named[str(name)].detach().cpu()).numpy(), g['psamp:' + str(name)], rtol=0,
+                                   atol=2.5e-5)   # one Adam step moves each weight by <= lr = 1e-5
+    # packed-weight caches must notice the update
+    with torch.no_grad():
+        e2 = se.eval()(xs.to(dev))
+    assert float((e2 - s_emb.detach()).abs().max()) > 0

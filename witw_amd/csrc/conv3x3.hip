@@ -34,11 +34,13 @@ struct ConvArgs {
     const float* wpk;       // packed: [n_tile][cin/8][tap][quad][TN][4]
     const float* bias;      // [n_tiles*TN] (zero padded)
     const float* dropmask;  // [B,Cout] scale (0 or 1/(1-p)) or nullptr
+    const float* gate;      // nullptr, or a tensor shaped like y: outputs where gate <= 0 are zeroed (ReLU backward)
     float* y;               // NHWC [B,Hy,Wy,Cout] or NCHW [B,Cout,Hy,Wy]
     int B, H, W, Cin, Cout;
     int Ho, Wo;             // conv output size (before pooling)
     int tiles_x, tiles_y;
     int circ, relu, out_nchw;
+    int dil_h;              // 1: input rows are zero-interleaved (row 2i = physical row i): dgrad of a stride-(2,1) conv
 #ifdef WITW_STAMPS
     unsigned long long* stamps;   // diagnostic build only (tools/conv_stamps.cpp)
 #endif
@@ -91,6 +93,12 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_nhwc_f32_kernel(ConvArgs p) 
         const int gr = oy0 * SH - 1 + r;
         int gc = ox0 - 1 + c;
         bool ok = (s < IN_F4) && gr >= 0 && gr < p.H;
+        int grp = gr, Hp = p.H;       // physical row / physical height
+        if (p.dil_h) {
+            ok = ok && (gr & 1) == 0;
+            grp = gr >> 1;
+            Hp = (p.H - 1) / 2 + 1;
+        }
         if (p.circ) {
             gc %= p.W;
             if (gc < 0) gc += p.W;
@@ -98,7 +106,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_nhwc_f32_kernel(ConvArgs p) 
             ok = ok && gc >= 0 && gc < p.W;
         }
         gstep[i] = ok ? 8 : 0;
-        gin[i] = ok ? p.x + (((size_t)((size_t)b * p.H + gr) * p.W + gc) * p.Cin + q * 4)
+        gin[i] = ok ? p.x + (((size_t)((size_t)b * Hp + grp) * p.W + gc) * p.Cin + q * 4)
                     : reinterpret_cast<const float*>(g_zero_f4);
     }
     const f32x4* gw = reinterpret_cast<const f32x4*>(p.wpk) + (size_t)ntile * nkc * W_F4 + tid;
@@ -292,6 +300,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_nhwc_f32_kernel(ConvArgs p) 
                 o = (((size_t)b * p.Cout + nch[nt]) * Hy + yy) * Wy + xx;
             else
                 o = (((size_t)b * Hy + yy) * Wy + xx) * p.Cout + nch[nt];
+            if (p.gate != nullptr && !(p.gate[o] > 0.f)) v = 0.f;
             p.y[o] = v;
         }
     };
@@ -320,8 +329,16 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_nhwc_f32_kernel(ConvArgs p) 
                 const int m = g * 4 + prow;
                 const f32x4 v = *reinterpret_cast<const f32x4*>(slab + m * 64 + pc4);
                 const int xx = ox0 + tcol[mt] + m;
-                if (yy < Hy && xx < Wy && nbase < p.Cout)
-                    *reinterpret_cast<f32x4*>(p.y + (((size_t)b * Hy + yy) * Wy + xx) * p.Cout + nbase) = v;
+                if (yy < Hy && xx < Wy && nbase < p.Cout) {
+                    const size_t o = (((size_t)b * Hy + yy) * Wy + xx) * p.Cout + nbase;
+                    f32x4 w = v;
+                    if (p.gate != nullptr) {
+                        const f32x4 gt = *reinterpret_cast<const f32x4*>(p.gate + o);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) w[e] = gt[e] > 0.f ? v[e] : 0.f;
+                    }
+                    *reinterpret_cast<f32x4*>(p.y + o) = w;
+                }
             }
         }
     } else if (!POOL) {
@@ -410,6 +427,16 @@ __global__ void nchw_to_nhwc8_kernel(const float* __restrict__ x, float* __restr
     o[1] = f32x4{v[4], v[5], v[6], v[7]};
 }
 
+// NCHW [B,C,H,W] -> NHWC [B,H,W,Cp] (Cp >= C, extra channels zero) and back; small tensors (embedding grads).
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int Cp, size_t hw, size_t total) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = idx % Cp;
+    const size_t t = idx / Cp;
+    const size_t b = t / hw, r = t - b * hw;
+    y[idx] = (c < C) ? x[(b * C + c) * hw + r] : 0.f;
+}
+
 template <int TN, int SH, bool POOL>
 int launch_conv(const ConvArgs& a, hipStream_t st) {
     const int n_tiles = cdiv(a.Cout, TN);
@@ -469,23 +496,35 @@ int witw_nchw_to_nhwc8(const float* x, float* y, int B, int C, int H, int W, voi
     return WITW_OK;
 }
 
-int witw_conv3x3_fwd(const float* x, const float* wpk, const float* bias, const float* dropmask, float* y, int B, int H,
-                     int W, int Cin, int Cout, int stride_h, int pad_circular, int relu, int pool, int out_nchw,
-                     void* stream) {
+int witw_nchw_to_nhwc(const float* x, float* y, int B, int C, int H, int W, int Cpad, void* stream) {
+    WITW_CHECK_ARG(x && y, "nchw_to_nhwc: null pointer");
+    WITW_CHECK_ARG(B > 0 && C > 0 && H > 0 && W > 0 && Cpad >= C, "nchw_to_nhwc: bad shape");
+    const size_t total = (size_t)B * H * W * Cpad;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, C,
+                       Cpad, (size_t)H * W, total);
+    WITW_CHECK_LAUNCH("nchw_to_nhwc");
+    return WITW_OK;
+}
+
+int witw_conv3x3_fwd_ex(const float* x, const float* wpk, const float* bias, const float* dropmask, const float* gate,
+                        float* y, int B, int H, int W, int Cin, int Cout, int stride_h, int pad_circular, int relu, int pool,
+                        int out_nchw, int dilate_h, void* stream) {
     WITW_CHECK_ARG(x && wpk && bias && y, "conv3x3_fwd: null pointer");
     WITW_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cout > 0, "conv3x3_fwd: bad shape B=%d H=%d W=%d Cout=%d", B, H, W, Cout);
     WITW_CHECK_ARG(Cin > 0 && (Cin % 8) == 0, "conv3x3_fwd: Cin=%d must be a positive multiple of 8", Cin);
     WITW_CHECK_ARG(stride_h == 1 || stride_h == 2, "conv3x3_fwd: stride_h=%d unsupported", stride_h);
     WITW_CHECK_ARG(!(pool && stride_h == 2), "conv3x3_fwd: pool with stride 2 unsupported");
     WITW_CHECK_ARG(!(pool && out_nchw), "conv3x3_fwd: pool with NCHW output unsupported");
+    WITW_CHECK_ARG(!(pool && gate), "conv3x3_fwd: pool with gate unsupported");
+    WITW_CHECK_ARG(!(dilate_h && stride_h == 2), "conv3x3_fwd: dilated input with stride 2 unsupported");
     ConvArgs a;
-    a.x = x; a.wpk = wpk; a.bias = bias; a.dropmask = dropmask; a.y = y;
+    a.x = x; a.wpk = wpk; a.bias = bias; a.dropmask = dropmask; a.gate = gate; a.y = y;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
     a.Ho = (H + 2 - 3) / stride_h + 1;
     a.Wo = W;
     a.tiles_x = cdiv(a.Wo, TW);
     a.tiles_y = cdiv(a.Ho, TH);
-    a.circ = pad_circular; a.relu = relu; a.out_nchw = out_nchw;
+    a.circ = pad_circular; a.relu = relu; a.out_nchw = out_nchw; a.dil_h = dilate_h;
 #ifdef WITW_STAMPS
     a.stamps = witw_conv_stamps_ptr;
 #endif
@@ -497,6 +536,13 @@ int witw_conv3x3_fwd(const float* x, const float* wpk, const float* bias, const 
     }
     if (stride_h == 2) return launch_conv<64, 2, false>(a, st);
     return pool ? launch_conv<64, 1, true>(a, st) : launch_conv<64, 1, false>(a, st);
+}
+
+int witw_conv3x3_fwd(const float* x, const float* wpk, const float* bias, const float* dropmask, float* y, int B, int H,
+                     int W, int Cin, int Cout, int stride_h, int pad_circular, int relu, int pool, int out_nchw,
+                     void* stream) {
+    return witw_conv3x3_fwd_ex(x, wpk, bias, dropmask, nullptr, y, B, H, W, Cin, Cout, stride_h, pad_circular, relu, pool,
+                               out_nchw, 0, stream);
 }
 
 }  // extern "C"

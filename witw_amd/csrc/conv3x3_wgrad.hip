@@ -1,0 +1,285 @@
+// Weight gradient of the 3x3 convolution (gfx950, fp32 MFMA) + bias gradient + Adam.
+//
+// Backward of the trainable FOV_DSM layers (reference: autograd through torch.nn.Conv2d in
+// model/cvig_fov.py:447-460; trainable set :275-278): with dZ the gradient at the conv output
+// (after the ReLU / Dropout2d gates),
+//   dW[co][ci][kh][kw] = sum_{b,h,w} dZ[b,h,w,co] * Xpad[b, h*SH+kh-1, w+kw-1, ci]
+// is 9 GEMMs (one per tap) with M = ci, N = co, K = output pixels, sharing the dZ operand. A
+// workgroup owns a 64(ci) x 64(co) tile of ALL 9 taps (9 accumulator tiles per wave) and walks a
+// contiguous range of K chunks (one chunk = up to 64 pixels of one output row): the 3 x 66 input
+// halo rows and the dZ row are staged in LDS in their natural NHWC order ([pixel][channel]), so
+// that MFMA lanes (= consecutive channels) read consecutive LDS words. Staging uses buffer
+// loads whose descriptor is built per row from scalars: padded rows get a zero-length
+// descriptor, padded columns an out-of-range offset (both return 0), so there is no per-load
+// VALU work next to the f32 MFMAs. Split-K partials go to a workspace and are summed in a
+// fixed order by the reduce kernel (bitwise reproducible), which also writes torch's KCRS layout.
+#include "common.h"
+
+namespace {
+
+constexpr int WT = 256;
+constexpr int XCOLS = 66;                     // 64 pixels + 2 halo columns
+constexpr int X_F = 3 * XCOLS * 64;           // floats of the input tile [3][66][64]
+constexpr int DZ_F = 64 * 64;                 // floats of the dZ tile   [64][64]
+constexpr int XROW_F4 = XCOLS * 16;           // float4 slots per halo row
+constexpr int XLD = (XROW_F4 + WT - 1) / WT;  // loads per thread per halo row (5)
+constexpr unsigned OOR = 0xfffffff0u;         // buffer offset that is out of range for any descriptor
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct WgradArgs {
+    const float* x;    // [B,H,W,Cin]   NHWC
+    const float* dz;   // [B,Ho,Wo,Cout] NHWC
+    float* ws;         // [splits][9][Cin][Cout]
+    int B, H, W, Cin, Cout, Ho, Wo;
+    int SH, circ;
+    int nseg;          // column segments of 64 per output row
+    int chunks;        // B*Ho*nseg
+    int cps;           // chunks per split
+};
+
+__global__ __launch_bounds__(WT, 2) void conv3x3_wgrad_kernel(WgradArgs p) {
+    __shared__ float smem[X_F + DZ_F];
+    float* x_s = smem;
+    float* dz_s = smem + X_F;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hk = lane >> 5;
+    const int ci0 = blockIdx.x * 64, co0 = blockIdx.y * 64, split = blockIdx.z;
+    const int c_begin = split * p.cps;
+    const int c_end = min(p.chunks, c_begin + p.cps);
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int mci = (wave & 1) * 32 + l31;    // this lane's ci within the tile (A operand row)
+    const int nco = (wave >> 1) * 32 + l31;   // this lane's co within the tile (B operand column)
+    const unsigned xrow_bytes = (unsigned)p.W * p.Cin * 4u;
+    const unsigned zrow_bytes = (unsigned)p.Wo * p.Cout * 4u;
+
+    int cur_seg = -1;
+    unsigned xoff[XLD], zoff[4];
+    for (int c = c_begin; c < c_end; ++c) {
+        const int seg = c % p.nseg;
+        const int bh = c / p.nseg;
+        const int h = bh % p.Ho, b = bh / p.Ho;
+        const int w0 = seg * 64;
+        if (seg != cur_seg) {   // uniform; once per block when the row fits one segment
+            cur_seg = seg;
+#pragma unroll
+            for (int i = 0; i < XLD; ++i) {
+                const int s = tid + i * WT;
+                const int col = s >> 4, q = s & 15;
+                int gc = w0 - 1 + col;
+                bool ok = s < XROW_F4 && (ci0 + 4 * q) < p.Cin;
+                if (p.circ) {
+                    gc %= p.W;
+                    if (gc < 0) gc += p.W;
+                } else {
+                    ok = ok && gc >= 0 && gc < p.W;
+                }
+                xoff[i] = ok ? ((unsigned)gc * p.Cin + ci0 + 4 * q) * 4u : OOR;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int s = tid + i * WT;
+                const int px = s >> 4, q = s & 15;
+                const bool ok = (w0 + px) < p.Wo && (co0 + 4 * q) < p.Cout;
+                zoff[i] = ok ? ((unsigned)(w0 + px) * p.Cout + co0 + 4 * q) * 4u : OOR;
+            }
+        }
+        // ---- stage: 3 halo rows of X and one row of dZ
+        u32x4 rx[3][XLD], rz[4];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int gr = h * p.SH - 1 + r;
+            const bool rok = gr >= 0 && gr < p.H;
+            const float* base = p.x + ((size_t)b * p.H + (rok ? gr : 0)) * p.W * p.Cin;
+            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, rok ? xrow_bytes : 0u, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < XLD; ++i) rx[r][i] = __builtin_amdgcn_raw_buffer_load_b128(rs, xoff[i], 0, 0);
+        }
+        {
+            const float* base = p.dz + ((size_t)b * p.Ho + h) * p.Wo * p.Cout;
+            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, zrow_bytes, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rz[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, zoff[i], 0, 0);
+        }
+        __syncthreads();   // previous chunk's fragment reads are done
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int i = 0; i < XLD; ++i) {
+                const int s = tid + i * WT;
+                if (XLD * WT == XROW_F4 || s < XROW_F4)
+                    reinterpret_cast<u32x4*>(x_s)[r * XROW_F4 + s] = rx[r][i];
+            }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) reinterpret_cast<u32x4*>(dz_s)[tid + i * WT] = rz[i];
+        __syncthreads();
+
+        // ---- 9 taps x ceil(npix/2) k-steps; lanes 0-31 take pixel 2k, lanes 32-63 pixel 2k+1
+        const int npix = min(64, p.Wo - w0);
+        const int ksteps = (npix + 1) >> 1;
+        const float* ap = x_s + (hk + 0) * 64 + mci;
+        const float* bp = dz_s + hk * 64 + nco;
+#pragma unroll 2
+        for (int k = 0; k < ksteps; ++k) {
+            const float bv = bp[k * 128];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int kh = t / 3, kw = t - kh * 3;
+                const float av = ap[(kh * XCOLS + kw) * 64 + k * 128];
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- partial tile -> workspace [split][tap][ci][co]
+    float* out = p.ws + (size_t)split * 9 * p.Cin * p.Cout;
+    const int co = co0 + nco;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ci = ci0 + (wave & 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hk;
+            if (ci < p.Cin && co < p.Cout) out[((size_t)t * p.Cin + ci) * p.Cout + co] = acc[t][r];
+        }
+}
+
+// dW[co][ci][kh][kw] (+)= sum_split ws[split][tap][ci][co]; one thread per (tap, ci, co), co fastest.
+__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Cin, int Cout, int splits,
+                                    int accumulate, int cin_real) {
+    const size_t n = (size_t)9 * Cin * Cout;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const int co = idx % Cout;
+    const size_t t = idx / Cout;
+    const int ci = t % Cin;
+    const int tap = (int)(t / Cin);
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += ws[(size_t)k * n + idx];
+    if (ci >= cin_real) return;   // zero-padded input channels have no weight
+    float* d = dw + ((size_t)co * cin_real + ci) * 9 + tap;
+    *d = accumulate ? (*d + s) : s;
+}
+
+// db[co] (+)= sum over all pixels of dZ[.., co]; grid = Cout/64 blocks (x) ; fixed-order two-level sum.
+__global__ __launch_bounds__(256) void bias_grad_partial_kernel(const float* __restrict__ dz, float* __restrict__ part,
+                                                                 size_t npix, int Cout, int rows_per_block) {
+    // thread -> (channel = tid % 64 + 64*blockIdx.x, pixel phase = tid / 64)
+    const int co = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int ph = threadIdx.x >> 6;
+    const size_t p0 = (size_t)blockIdx.y * rows_per_block;
+    const size_t p1 = min(npix, p0 + rows_per_block);
+    float s = 0.f;
+    if (co < Cout)
+        for (size_t px = p0 + ph; px < p1; px += 4) s += dz[px * Cout + co];
+    __shared__ float sh[4][64];
+    sh[ph][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (threadIdx.x < 64 && co < Cout)
+        part[(size_t)blockIdx.y * Cout + co] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+}
+
+__global__ void bias_grad_finish_kernel(const float* __restrict__ part, float* __restrict__ db, int Cout, int nparts,
+                                        int accumulate) {
+    const int co = blockIdx.x * blockDim.x + threadIdx.x;
+    if (co >= Cout) return;
+    float s = 0.f;
+    for (int k = 0; k < nparts; ++k) s += part[(size_t)k * Cout + co];
+    db[co] = accumulate ? db[co] + s : s;
+}
+
+// torch.optim.Adam (no weight decay, no amsgrad) as pinned by the reference (torch==1.8.1,
+// model/requirements.txt:1; optimizer built at model/cvig_fov.py:416-418 with lr=1e-5):
+//   m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g*g ; p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            size_t n, float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i];
+    const float mi = m[i] * b1 + gi * (1.f - b1);
+    const float vi = v[i] * b2 + (gi * gi) * (1.f - b2);
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = p[i] + (-(lr / bc1)) * (mi / denom);
+}
+
+}  // namespace
+
+extern "C" {
+
+// number of K splits the launcher will use and the workspace it needs (floats)
+int witw_conv3x3_wgrad_splits(int B, int Ho, int Wo, int Cin, int Cout) {
+    const int tiles = cdiv(Cin, 64) * cdiv(Cout, 64);
+    const int chunks = B * Ho * cdiv(Wo, 64);
+    int splits = cdiv(1024, tiles);           // aim at ~1024 workgroups (2 per CU x 256 CUs x 2 rounds)
+    if (splits > chunks) splits = chunks;
+    if (splits < 1) splits = 1;
+    return splits;
+}
+
+long long witw_conv3x3_wgrad_workspace_floats(int B, int H, int W, int Cin, int Cout, int stride_h) {
+    const int Ho = (H + 2 - 3) / stride_h + 1;
+    const long long splits = witw_conv3x3_wgrad_splits(B, Ho, W, Cin, Cout);
+    const long long bias_parts = cdiv((long long)B * Ho * W > 0 ? B * Ho * W : 1, 4096);
+    return splits * 9 * Cin * Cout + bias_parts * Cout;
+}
+
+// x [B,H,W,Cin] NHWC (the conv's input), dz [B,Ho,W,Cout] NHWC (gradient at its output),
+// dw [Cout][cin_real][3][3] (torch layout; Cin is the NHWC-padded channel count of x, cin_real <= Cin),
+// db [Cout] or NULL. accumulate != 0 adds to dw/db instead of overwriting.
+int witw_conv3x3_wgrad(const float* x, const float* dz, float* dw, float* db, float* workspace, int B, int H, int W, int Cin,
+                       int cin_real, int Cout, int stride_h, int pad_circular, int accumulate, void* stream) {
+    WITW_CHECK_ARG(x && dz && dw && workspace, "conv3x3_wgrad: null pointer");
+    WITW_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv3x3_wgrad: bad shape");
+    WITW_CHECK_ARG((Cin % 4) == 0 && (Cout % 4) == 0, "conv3x3_wgrad: Cin=%d and Cout=%d must be multiples of 4", Cin, Cout);
+    WITW_CHECK_ARG(cin_real > 0 && cin_real <= Cin, "conv3x3_wgrad: cin_real=%d outside (0,%d]", cin_real, Cin);
+    WITW_CHECK_ARG(stride_h == 1 || stride_h == 2, "conv3x3_wgrad: stride_h=%d unsupported", stride_h);
+    WITW_CHECK_ARG((size_t)W * Cin * 4 < 0xfffffff0ull && (size_t)W * Cout * 4 < 0xfffffff0ull, "conv3x3_wgrad: row too large");
+    hipStream_t st = (hipStream_t)stream;
+    WgradArgs a;
+    a.x = x; a.dz = dz; a.ws = workspace;
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+    a.Ho = (H + 2 - 3) / stride_h + 1;
+    a.Wo = W;
+    a.SH = stride_h; a.circ = pad_circular;
+    a.nseg = cdiv(a.Wo, 64);
+    a.chunks = B * a.Ho * a.nseg;
+    const int splits = witw_conv3x3_wgrad_splits(B, a.Ho, a.Wo, Cin, Cout);
+    a.cps = cdiv(a.chunks, splits);
+    hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3(cdiv(Cin, 64), cdiv(Cout, 64), splits), dim3(WT), 0, st, a);
+    WITW_CHECK_LAUNCH("conv3x3_wgrad");
+    const size_t n = (size_t)9 * Cin * Cout;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, workspace, dw, Cin, Cout,
+                       splits, accumulate, cin_real);
+    WITW_CHECK_LAUNCH("wgrad_reduce");
+    if (db != nullptr) {
+        float* part = workspace + (size_t)splits * n;
+        const size_t npix = (size_t)B * a.Ho * a.Wo;
+        const int nparts = (int)((npix + 4095) / 4096);
+        hipLaunchKernelGGL(bias_grad_partial_kernel, dim3(cdiv(Cout, 64), nparts), dim3(256), 0, st, dz, part, npix, Cout, 4096);
+        hipLaunchKernelGGL(bias_grad_finish_kernel, dim3(cdiv(Cout, 256)), dim3(256), 0, st, part, db, Cout, nparts, accumulate);
+        WITW_CHECK_LAUNCH("bias_grad");
+    }
+    return WITW_OK;
+}
+
+int witw_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr, float beta1,
+                   float beta2, float eps, int step, void* stream) {
+    WITW_CHECK_ARG(param && grad && exp_avg && exp_avg_sq, "adam_step: null pointer");
+    WITW_CHECK_ARG(n > 0 && step >= 1, "adam_step: bad n=%lld or step=%d", n, step);
+    const double bc1 = 1.0 - pow((double)beta1, step);
+    const double bc2 = 1.0 - pow((double)beta2, step);
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
+                       exp_avg_sq, (size_t)n, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2));
+    WITW_CHECK_LAUNCH("adam_step");
+    return WITW_OK;
+}
+
+}  // extern "C"

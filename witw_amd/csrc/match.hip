@@ -255,6 +255,118 @@ __global__ __launch_bounds__(256) void rank_count_kernel(const float* __restrict
     if (c) atomicAdd(&ranks[q], c);
 }
 
+
+// ---- backward of the fused match (autograd of correlation->crop->l2_distance, reference
+// model/cvig_fov.py:450-453; the arg-max orientation is a constant of the graph, as in torch):
+//   d = 2*(1 - c/(wn*sn)),  c = <window, su>,  wn = |window|, sn = |su|
+//   dd/dsu[k]     = -2*( window[k]/(wn*sn) - c*su[k]/(wn*sn^3) )
+//   dd/dwindow[k] = -2*( su[k]/(wn*sn)     - c*window[k]/(wn^3*sn) )
+// grad_su: one block per surface s, loops over overheads; grad_ov: one block per overhead o,
+// loops over surfaces and scatters through the rotation. fp32 VALU (Bo*Bs*E MACs, 1/64 of forward).
+__global__ __launch_bounds__(256) void match_bwd_su_kernel(const float* __restrict__ ov, const float* __restrict__ su,
+                                                            const long long* __restrict__ ori, const float* __restrict__ score,
+                                                            const float* __restrict__ wn, const float* __restrict__ sn,
+                                                            const float* __restrict__ gD, float* __restrict__ gsu, int Bo,
+                                                            int Bs, int We) {
+    __shared__ float coef[256];
+    __shared__ int rot[256];
+    __shared__ float part[4];
+    const int s = blockIdx.x, tid = threadIdx.x;
+    const int E = 64 * We;
+    const float sns = sn[s];
+    int ch[16], kk[16];
+    float acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int e = tid + 256 * i;
+        ch[i] = e / We;
+        kk[i] = e - ch[i] * We;
+        acc[i] = 0.f;
+    }
+    float self = 0.f;   // sum_o gD*2c/(wn*sn^3), accumulated by thread 0..255 over its o's then reduced
+    for (int o0 = 0; o0 < Bo; o0 += 256) {
+        const int o = o0 + tid;
+        __syncthreads();
+        if (o < Bo) {
+            const size_t off = (size_t)o * Bs + s;
+            const int t = (int)ori[off];
+            const float w = wn[(size_t)o * 64 + t];
+            const float g = gD[off];
+            coef[tid] = g * (-2.f / (w * sns));
+            rot[tid] = t;
+            self += g * (2.f * score[off] / (w * sns * sns * sns));
+        }
+        __syncthreads();
+        const int n = min(256, Bo - o0);
+        for (int j = 0; j < n; ++j) {
+            const float a = coef[j];
+            const int t = rot[j];
+            const float* row = ov + (size_t)(o0 + j) * 4096;
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (tid + 256 * i < E) acc[i] += a * row[ch[i] * 64 + ((kk[i] + t) & 63)];
+        }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) self += __shfl_xor(self, d, 64);
+    __syncthreads();
+    if ((tid & 63) == 0) part[tid >> 6] = self;
+    __syncthreads();
+    const float selfsum = (part[0] + part[1]) + (part[2] + part[3]);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int e = tid + 256 * i;
+        if (e < E) gsu[(size_t)s * E + e] = acc[i] + su[(size_t)s * E + e] * selfsum;
+    }
+}
+
+__global__ __launch_bounds__(256) void match_bwd_ov_kernel(const float* __restrict__ ov, const float* __restrict__ su,
+                                                            const long long* __restrict__ ori, const float* __restrict__ score,
+                                                            const float* __restrict__ wn, const float* __restrict__ sn,
+                                                            const float* __restrict__ gD, float* __restrict__ gov, int Bo,
+                                                            int Bs, int We) {
+    __shared__ float coef[256];
+    __shared__ float coef2[256];
+    __shared__ int rot[256];
+    const int o = blockIdx.x, tid = threadIdx.x;
+    const int w = tid & 63, cg = tid >> 6;   // element (ch = cg + 4*i, w)
+    float acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    float beta = 0.f;                        // sum_s gD*2c/(wn^3*sn) over surfaces whose window covers column w
+    for (int s0 = 0; s0 < Bs; s0 += 256) {
+        const int s = s0 + tid;
+        __syncthreads();
+        if (s < Bs) {
+            const size_t off = (size_t)o * Bs + s;
+            const int t = (int)ori[off];
+            const float wv = wn[(size_t)o * 64 + t];
+            const float g = gD[off];
+            const float sv = sn[s];
+            coef[tid] = g * (-2.f / (wv * sv));
+            coef2[tid] = g * (2.f * score[off] / (wv * wv * wv * sv));
+            rot[tid] = t;
+        }
+        __syncthreads();
+        const int n = min(256, Bs - s0);
+        for (int j = 0; j < n; ++j) {
+            const int k = (w - rot[j]) & 63;
+            if (k < We) {
+                const float a = coef[j];
+                beta += coef2[j];
+                const float* base = su + (size_t)(s0 + j) * 64 * We + k;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] += a * base[(cg + 4 * i) * We];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const size_t e = (size_t)o * 4096 + (cg + 4 * i) * 64 + w;
+        gov[e] = acc[i] + ov[e] * beta;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -283,6 +395,26 @@ int witw_match_fwd(const float* ov, const float* su, int Bo, int Bs, int We, lon
         hipLaunchKernelGGL((match_kernel<1>), dim3(gx, cdiv(Bo, 2)), dim3(NT), 0, st, a);
     }
     WITW_CHECK_LAUNCH("match_fwd");
+    return WITW_OK;
+}
+
+// grad_distance [Bo,Bs] -> grad_ov [Bo,16,4,64], grad_su [Bs,16,4,We]. orientation / score / workspace are
+// the outputs of witw_match_fwd on the same (ov, su) (workspace must not have been overwritten).
+int witw_match_bwd(const float* ov, const float* su, const long long* orientation, const float* score, const float* workspace,
+                   const float* grad_distance, float* grad_ov, float* grad_su, int Bo, int Bs, int We, void* stream) {
+    WITW_CHECK_ARG(ov && su && orientation && score && workspace && grad_distance, "match_bwd: null pointer");
+    WITW_CHECK_ARG(grad_ov || grad_su, "match_bwd: no output requested");
+    WITW_CHECK_ARG(Bo > 0 && Bs > 0 && We >= 1 && We <= 64, "match_bwd: bad shape Bo=%d Bs=%d We=%d", Bo, Bs, We);
+    hipStream_t st = (hipStream_t)stream;
+    const float* wn = workspace;
+    const float* sn = workspace + (size_t)Bo * 64;
+    if (grad_su)
+        hipLaunchKernelGGL(match_bwd_su_kernel, dim3(Bs), dim3(256), 0, st, ov, su, orientation, score, wn, sn, grad_distance,
+                           grad_su, Bo, Bs, We);
+    if (grad_ov)
+        hipLaunchKernelGGL(match_bwd_ov_kernel, dim3(Bo), dim3(256), 0, st, ov, su, orientation, score, wn, sn, grad_distance,
+                           grad_ov, Bo, Bs, We);
+    WITW_CHECK_LAUNCH("match_bwd");
     return WITW_OK;
 }
 

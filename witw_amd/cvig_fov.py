@@ -108,33 +108,108 @@ class FOV_DSM(torch.nn.Module):
 
     def _pack(self, idx):
         conv = _conv_of(self.model.features[idx])
-        key = (conv.weight.data_ptr(), conv.weight._version, conv.bias._version)
+        key = (conv.weight.data_ptr(), conv.weight._version, conv.bias._version, getattr(conv.weight, '_witw_version', 0),
+               getattr(conv.bias, '_witw_version', 0))
         hit = self._packed.get(idx)
         if hit is None or hit[0] != key:
             hit = (key, ops.PackedConv(conv.weight, conv.bias))
             self._packed[idx] = hit
         return hit[1]
 
+    def _pack_t(self, idx):
+        """dgrad filter (transpose + 180-degree tap rotation) of layer idx."""
+        conv = _conv_of(self.model.features[idx])
+        key = (conv.weight.data_ptr(), conv.weight._version, getattr(conv.weight, '_witw_version', 0))
+        hit = self._packed.get(('t', idx))
+        if hit is None or hit[0] != key:
+            hit = (key, ops.PackedConv(conv.weight, None, transpose_flip=True))
+            self._packed[('t', idx)] = hit
+        return hit[1]
+
+    def _draw_scales(self, x, dropout_scales):
+        scales = {}
+        for (idx, sh, relu, pool, drop) in self.layer_specs:
+            if drop and self.training:
+                if dropout_scales is not None:
+                    scales[idx] = dropout_scales[idx].contiguous()
+                else:   # Dropout2d(p=0.2): whole channels, scale 1/(1-p) (reference :241,288)
+                    conv = _conv_of(self.model.features[idx])
+                    keep = torch.rand((x.shape[0], conv.out_channels), device=x.device) >= 0.2
+                    scales[idx] = keep.float() / 0.8
+        return scales
+
+    def _run(self, x, scales, keep_from=None):
+        """Layer stack; returns (embedding NCHW, {idx: NHWC output} for idx >= keep_from, input of keep_from)."""
+        h = ops.nchw_to_nhwc8(x.contiguous())
+        last = self.layer_specs[-1][0]
+        kept, first_in = {}, None
+        for (idx, sh, relu, pool, drop) in self.layer_specs:
+            if keep_from is not None and idx == keep_from:
+                first_in = h
+            h = ops.conv3x3_fwd(h, self._pack(idx), stride_h=sh, circular=self.circ_padding, relu=relu, pool=pool,
+                                out_nchw=(idx == last), drop_scale=scales.get(idx))
+            if keep_from is not None and idx >= keep_from:
+                kept[idx] = h
+        return h, kept, first_in
+
+    def trainable_convs(self):
+        return [(idx, _conv_of(self.model.features[idx])) for (idx, *_r) in self.layer_specs
+                if _conv_of(self.model.features[idx]).weight.requires_grad]
+
     def forward(self, x, dropout_scales=None):
         """x [B,C,128,W] NCHW fp32 on the GPU -> [B,16,4,W/8] NCHW (reference :292-294).
         In train() mode Dropout2d scales are drawn per call unless `dropout_scales`
-        ({17|19|21: [B,C]}) injects them."""
+        ({17|19|21: [B,C]}) injects them. With grad enabled the call is recorded for autograd
+        (weight / bias gradients of the trainable layers, computed by the HIP backward kernels)."""
         if not x.is_cuda:
             raise _lib.WitwError('FOV_DSM.forward needs a GPU tensor (no CPU fallback)')
-        h = ops.nchw_to_nhwc8(x.contiguous())
-        last = self.layer_specs[-1][0]
-        for (idx, sh, relu, pool, drop) in self.layer_specs:
-            scale = None
-            if drop and self.training:
-                if dropout_scales is not None:
-                    scale = dropout_scales[idx]
-                else:
-                    conv = _conv_of(self.model.features[idx])
-                    keep = torch.rand((x.shape[0], conv.out_channels), device=x.device) >= 0.2
-                    scale = keep.float() / 0.8
-            h = ops.conv3x3_fwd(h, self._pack(idx), stride_h=sh, circular=self.circ_padding, relu=relu, pool=pool,
-                                out_nchw=(idx == last), drop_scale=scale)
-        return h
+        scales = self._draw_scales(x, dropout_scales)
+        tr = self.trainable_convs()
+        if torch.is_grad_enabled() and tr:
+            if tr[0][0] != synth.TRAINABLE_FROM or self.in_channels != 3:
+                raise _lib.WitwError('backward is implemented for the cvig_fov trainable set (layers >= 17) only')
+            params = []
+            for _i, c in tr:
+                params += [c.weight, c.bias]
+            return _EncoderFn.apply(x, self, scales, *params)
+        return self._run(x, scales)[0]
+
+
+class _EncoderFn(torch.autograd.Function):
+    """autograd node of one FOV_DSM call: forward = the 13 fused conv launches; backward = per
+    trainable layer one wgrad launch and one dgrad launch (the forward kernel on the transposed,
+    tap-rotated filter with the ReLU / Dropout2d gate fused into its epilogue)."""
+
+    @staticmethod
+    def forward(ctx, x, enc, scales, *params):
+        out, kept, first_in = enc._run(x, scales, keep_from=synth.TRAINABLE_FROM)
+        ctx.enc, ctx.scales, ctx.kept, ctx.first_in = enc, scales, kept, first_in
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        enc, scales, kept = ctx.enc, ctx.scales, ctx.kept
+        specs = [sp for sp in enc.layer_specs if sp[0] >= synth.TRAINABLE_FROM]
+        circ = enc.circ_padding
+        last = specs[-1][0]
+        cout_last = _conv_of(enc.model.features[last]).out_channels
+        dz = ops.nchw_to_nhwc(grad_out.contiguous(), (cout_last + 7) // 8 * 8)   # layer 27 has no ReLU
+        grads = {}
+        for n in range(len(specs) - 1, -1, -1):
+            idx, sh, relu, pool, drop = specs[n]
+            x_in = ctx.first_in if n == 0 else kept[specs[n - 1][0]]
+            conv = _conv_of(enc.model.features[idx])
+            grads[idx] = ops.conv3x3_wgrad(x_in, dz, conv.in_channels, stride_h=sh, circular=circ)
+            if n > 0:   # gradient at the previous layer's conv output: dgrad, gated by its ReLU and dropout
+                pidx = specs[n - 1][0]
+                dz = ops.conv3x3_fwd(dz, enc._pack_t(idx), stride_h=1, circular=circ, relu=False, pool=False,
+                                     drop_scale=scales.get(pidx), gate=kept[pidx], dilate_h=(sh == 2),
+                                     out_h=x_in.shape[1] if sh == 2 else None)
+        ctx.kept = ctx.first_in = None
+        flat = []
+        for (idx, *_r) in specs:
+            flat += [grads[idx][0], grads[idx][1]]
+        return (None, None, None) + tuple(flat)
 
 
 # ----------------------------------------------------------------------------- transforms
@@ -224,9 +299,57 @@ def l2_distance(overhead_cropped, surface_embed):
     return ops.l2_distance(overhead_cropped.contiguous(), surface_embed.contiguous())
 
 
+class _MatchFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, overhead_embed, surface_embed):
+        ov, su = overhead_embed.contiguous(), surface_embed.contiguous()
+        ori, dist, score, ws = ops.match_fwd(ov, su, want_score=True, want_workspace=True)
+        ctx.save_for_backward(ov, su, ori, score, ws)
+        ctx.mark_non_differentiable(ori)
+        return ori, dist
+
+    @staticmethod
+    def backward(ctx, _g_ori, g_dist):
+        ov, su, ori, score, ws = ctx.saved_tensors
+        gov, gsu = ops.match_bwd(ov, su, ori, score, ws, g_dist.contiguous(), ctx.needs_input_grad[0],
+                                 ctx.needs_input_grad[1])
+        return gov, gsu
+
+
 def match(overhead_embed, surface_embed):
-    """correlation -> crop_overhead -> l2_distance fused (no crop tensor): (orientation, distance)."""
+    """correlation -> crop_overhead -> l2_distance fused (no crop tensor): (orientation, distance).
+    Differentiable w.r.t. both embeddings (the arg-max orientation is a constant, as in the reference)."""
+    if torch.is_grad_enabled() and (overhead_embed.requires_grad or surface_embed.requires_grad):
+        return _MatchFn.apply(overhead_embed, surface_embed)
     return ops.match_fwd(overhead_embed.contiguous(), surface_embed.contiguous())
+
+
+class Adam(object):
+    """torch.optim.Adam(params, lr) as used at model/cvig_fov.py:416-418 (defaults betas=(0.9,0.999),
+    eps=1e-8, no weight decay), one fused HIP launch per parameter. Parameters that never receive a
+    gradient (the frozen layers) are skipped, as torch does."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        self.params = [p for p in params]
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.state = {}
+
+    def zero_grad(self):
+        for p in self.params:
+            p.grad = None
+
+    def step(self):
+        for p in self.params:
+            if p.grad is None:
+                continue
+            st = self.state.get(p)
+            if st is None:
+                st = self.state[p] = {'step': 0, 'exp_avg': torch.zeros_like(p), 'exp_avg_sq': torch.zeros_like(p)}
+            st['step'] += 1
+            with torch.no_grad():
+                ops.adam_step(p.data, p.grad.contiguous(), st['exp_avg'], st['exp_avg_sq'], st['step'], self.lr,
+                              self.betas[0], self.betas[1], self.eps)
+                p._witw_version = getattr(p, '_witw_version', 0) + 1   # packed-weight caches key on this
 
 
 class _TripletLoss(torch.autograd.Function):

@@ -63,13 +63,27 @@ def nchw_to_nhwc8(x):
     return y
 
 
-def conv3x3_fwd(x_nhwc, packed, stride_h=1, circular=False, relu=True, pool=False, out_nchw=False, drop_scale=None):
+def nchw_to_nhwc(x, cpad):
+    lib = _lib.load()
+    x = _dev_f32(x, 'x')
+    B, C, H, W = x.shape
+    y = torch.empty((B, H, W, cpad), dtype=torch.float32, device=x.device)
+    _lib.check(lib.witw_nchw_to_nhwc(x.data_ptr(), y.data_ptr(), B, C, H, W, cpad, _stream()), 'witw_nchw_to_nhwc')
+    return y
+
+
+def conv3x3_fwd(x_nhwc, packed, stride_h=1, circular=False, relu=True, pool=False, out_nchw=False, drop_scale=None,
+                gate=None, dilate_h=False, out_h=None):
     """x_nhwc [B,H,W,Cin_pad] -> NHWC [B,Hy,Wy,Cout] (or NCHW [B,Cout,Hy,Wy])."""
     lib = _lib.load()
     x = _dev_f32(x_nhwc, 'x')
     B, H, W, C = x.shape
     if C != packed.cin_pad:
         raise _lib.WitwError('conv3x3_fwd: input has %d channels, packed weights expect %d' % (C, packed.cin_pad))
+    if dilate_h:
+        if out_h is None or (out_h - 1) // 2 + 1 != H:
+            raise _lib.WitwError('conv3x3_fwd: dilate_h needs out_h with (out_h-1)//2+1 == %d physical rows' % H)
+        H = out_h          # logical (zero-interleaved) height
     Ho = (H + 2 - 3) // stride_h + 1
     Hy, Wy = (Ho // 2, W // 2) if pool else (Ho, W)
     shape = (B, packed.cout, Hy, Wy) if out_nchw else (B, Hy, Wy, packed.cout)
@@ -82,9 +96,14 @@ def conv3x3_fwd(x_nhwc, packed, stride_h=1, circular=False, relu=True, pool=Fals
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _lib.check(lib.witw_conv3x3_fwd(x.data_ptr(), packed.wpk.data_ptr(), packed.bias.data_ptr(), _p(drop_scale),
-                                    y.data_ptr(), B, H, W, C, packed.cout, stride_h, int(circular), int(relu),
-                                    int(pool), int(out_nchw), _stream()), 'witw_conv3x3_fwd')
+    if gate is not None:
+        gate = _dev_f32(gate, 'gate')
+        if tuple(gate.shape) != shape:
+            raise _lib.WitwError('gate must have the output shape %s, got %s' % (shape, tuple(gate.shape)))
+    _lib.check(lib.witw_conv3x3_fwd_ex(x.data_ptr(), packed.wpk.data_ptr(), packed.bias.data_ptr(), _p(drop_scale),
+                                       _p(gate), y.data_ptr(), B, H, W, C, packed.cout, stride_h, int(circular),
+                                       int(relu), int(pool), int(out_nchw), int(bool(dilate_h)), _stream()),
+               'witw_conv3x3_fwd_ex')
     if prof is not None:
         e1.record()
         variant = (lib.witw_conv3x3_tile_n(packed.cout), stride_h, bool(pool))
@@ -92,8 +111,50 @@ def conv3x3_fwd(x_nhwc, packed, stride_h=1, circular=False, relu=True, pool=Fals
     return y
 
 
+def conv3x3_wgrad(x_nhwc, dz_nhwc, cin_real, stride_h=1, circular=False, want_bias=True):
+    """-> (dW [Cout,cin_real,3,3], db [Cout] or None) for one conv layer."""
+    lib = _lib.load()
+    x = _dev_f32(x_nhwc, 'x')
+    dz = _dev_f32(dz_nhwc, 'dz')
+    B, H, W, Cin = x.shape
+    Ho = (H + 2 - 3) // stride_h + 1
+    Cout = dz.shape[3]
+    if tuple(dz.shape[:3]) != (B, Ho, W):
+        raise _lib.WitwError('conv3x3_wgrad: dz %s does not match x %s (stride %d)' % (tuple(dz.shape), tuple(x.shape), stride_h))
+    dw = torch.empty((Cout, cin_real, 3, 3), dtype=torch.float32, device=x.device)
+    db = torch.empty((Cout,), dtype=torch.float32, device=x.device) if want_bias else None
+    ws = torch.empty(lib.witw_conv3x3_wgrad_workspace_floats(B, H, W, Cin, Cout, stride_h), dtype=torch.float32,
+                     device=x.device)
+    _lib.check(lib.witw_conv3x3_wgrad(x.data_ptr(), dz.data_ptr(), dw.data_ptr(), _p(db), ws.data_ptr(), B, H, W, Cin,
+                                      cin_real, Cout, stride_h, int(circular), 0, _stream()), 'witw_conv3x3_wgrad')
+    return dw, db
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8):
+    lib = _lib.load()
+    for t, n in ((param, 'param'), (grad, 'grad'), (exp_avg, 'exp_avg'), (exp_avg_sq, 'exp_avg_sq')):
+        _dev_f32(t, n)
+    _lib.check(lib.witw_adam_step(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
+                                  param.numel(), float(lr), float(beta1), float(beta2), float(eps), int(step), _stream()),
+               'witw_adam_step')
+
+
 # ----------------------------------------------------------------------------- matching
-def match_fwd(overhead_embed, surface_embed, want_score=False):
+def match_bwd(overhead_embed, surface_embed, orientation, score, workspace, grad_distance, need_ov=True, need_su=True):
+    lib = _lib.load()
+    ov = _dev_f32(overhead_embed, 'overhead_embed')
+    su = _dev_f32(surface_embed, 'surface_embed')
+    gd = _dev_f32(grad_distance, 'grad_distance')
+    Bo, Bs, We = ov.shape[0], su.shape[0], su.shape[3]
+    gov = torch.empty_like(ov) if need_ov else None
+    gsu = torch.empty_like(su) if need_su else None
+    _lib.check(lib.witw_match_bwd(ov.data_ptr(), su.data_ptr(), orientation.data_ptr(), score.data_ptr(),
+                                  workspace.data_ptr(), gd.data_ptr(), _p(gov), _p(gsu), Bo, Bs, We, _stream()),
+               'witw_match_bwd')
+    return gov, gsu
+
+
+def match_fwd(overhead_embed, surface_embed, want_score=False, want_workspace=False):
     """Fused correlation -> argmax -> window norm -> chord distance (no crop tensor).
     overhead_embed [Bo,16,4,64], surface_embed [Bs,16,4,We] -> (orientation int64 [Bo,Bs],
     distance f32 [Bo,Bs][, max score f32 [Bo,Bs]])."""
@@ -111,6 +172,8 @@ def match_fwd(overhead_embed, surface_embed, want_score=False):
     ws = torch.empty(lib.witw_match_workspace_floats(Bo, Bs), dtype=torch.float32, device=ov.device)
     _lib.check(lib.witw_match_fwd(ov.data_ptr(), su.data_ptr(), Bo, Bs, We, ori.data_ptr(), dist.data_ptr(), _p(score),
                                   ws.data_ptr(), _stream()), 'witw_match_fwd')
+    if want_workspace:
+        return ori, dist, score, ws
     return (ori, dist, score) if want_score else (ori, dist)
 
 
