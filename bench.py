@@ -53,6 +53,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--batch', type=int, default=128, help='pairs per GPU (BASELINE.json configs[1]: bs=128)')
     ap.add_argument('--fov', type=int, default=360)
+    ap.add_argument('--mode', choices=['infer', 'train'], default='infer',
+                    help='infer (headline): embedding + similarity; train: the full step of model/cvig_fov.py:444-461')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-pairs', type=int, default=8)
     a = ap.parse_args()
@@ -75,13 +77,38 @@ def main():
     B = a.batch
     seed = 1234
     wts = synth.fov_dsm_weights(seed)
-    surface_encoder = cvig_fov.FOV_DSM(circ_padding=False, weights=wts).to(device).eval()
-    overhead_encoder = cvig_fov.FOV_DSM(circ_padding=True, weights=wts).to(device).eval()
+    surface_encoder = cvig_fov.FOV_DSM(circ_padding=False, weights=wts).to(device)
+    overhead_encoder = cvig_fov.FOV_DSM(circ_padding=True, weights=wts).to(device)
+    train = a.mode == 'train'
+    surface_encoder.train(train)
+    overhead_encoder.train(train)
+    all_params = list(surface_encoder.parameters()) + list(overhead_encoder.parameters())
+    optimizer = cvig_fov.Adam(all_params, lr=1.E-5) if train else None
     ground_raw, ov_raw = make_inputs(cvig_fov, ops, synth, B, a.fov, seed + rank, device)
     ws = int(a.fov / 360 * 512)
     mean, std = cvig_fov.Globals.img_mean, cvig_fov.Globals.img_std
 
-    def step():
+    def train_step():
+        with torch.no_grad():
+            surface = ops.resize_bilinear(ground_raw, (128, ws), mean, std)
+            overhead = ops.resize_bilinear(ov_raw, (256, 256), mean, std)
+            polar = ops.polar_transform(overhead)
+        su = surface_encoder(surface)
+        ov = overhead_encoder(polar)
+        su_all, ov_all = parallel.all_gather_embeddings(su, ov)
+        ori, d = cvig_fov.match(ov_all, su_all)
+        loss = cvig_fov.triplet_loss(d)
+        optimizer.zero_grad()
+        loss.backward()
+        parallel.all_reduce_grads(all_params)
+        optimizer.step()
+        with torch.no_grad():
+            dd = d.detach()
+            ranks = ops.rank_count(dd[:, rank * B:(rank + 1) * B].contiguous(), rank * B) if world > 1 \
+                else ops.rank_count(dd, 0)
+        return loss.detach(), ranks, ori
+
+    def infer_step():
         with torch.no_grad():
             surface = ops.resize_bilinear(ground_raw, (128, ws), mean, std)
             overhead = ops.resize_bilinear(ov_raw, (256, 256), mean, std)
@@ -95,6 +122,7 @@ def main():
                 else ops.rank_count(d, 0)
         return loss, ranks, ori
 
+    step = train_step if train else infer_step
     for _ in range(a.warmup):
         step()
     if world > 1:
@@ -137,11 +165,13 @@ def main():
             traffic = None
 
     out = {
-        'metric': 'image-pairs/sec (embedding+similarity)', 'value': round(value, 2), 'unit': 'pairs/s',
+        'metric': 'image-pairs/sec (embedding+similarity)' if not train else 'image-pairs/sec (training step)', 'value': round(value, 2), 'unit': 'pairs/s',
         'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 3),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': 'cvig_fov fov=%d eval: resize+normalize+polar -> 2x FOV_DSM (VGG16[:23]+3 conv) -> '
-                               'fused match + soft-margin triplet loss + rank counts' % a.fov,
+        'config': {'workload': ('cvig_fov fov=%d eval: resize+normalize+polar -> 2x FOV_DSM (VGG16[:23]+3 conv) -> '
+                                'fused match + soft-margin triplet loss + rank counts' % a.fov) if not train else
+                               ('cvig_fov fov=%d TRAIN step: resize+normalize+polar -> 2x FOV_DSM fwd (Dropout2d) -> match + '
+                                'triplet loss -> backward (dgrad L19-27, wgrad L17-27) -> grad all-reduce -> Adam' % a.fov),
                    'pairs_per_gpu': B, 'global_batch': B * world, 'ground_raw': '3x224x224', 'overhead_raw': '3x512x512',
                    'parallelism': 'dp%d (embedding all-gather, global-batch loss)' % world},
         'recall': {'top1_pct': float(np.mean(ranks_h <= 1) * 100), 'top5_pct': float(np.mean(ranks_h <= 5) * 100),
@@ -153,7 +183,7 @@ def main():
                      'avg_launch_gflop': round(dom_fl / 1e9, 2), 'all_conv_launches_tflops': round(conv_tf, 2)},
     }
 
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and not train:
         out['cpu_baseline'] = cpu_baseline(a, ground_raw, ov_raw, wts, ws, step)
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -87,6 +87,9 @@ int witw_l2_distance(const float* cropped /*[Bo,Bs,n]*/, const float* su /*[Bs,n
 /* ranks[q] = #{o : D[o][q] <= D[q+true_offset][q]} — the loop body of test(), model/cvig_fov.py:550-552 */
 int witw_rank_count(const float* distance /*[Bo,Bs]*/, int* ranks /*[Bs]*/, int Bo, int Bs, int true_offset, void* stream);
 
+/* sharded-gallery form: ranks[q] = #{o in this shard : D[o][q] <= threshold[q]} (threshold = true match's distance) */
+int witw_rank_count_thresh(const float* distance, const float* threshold, int* ranks, int Bo, int Bs, void* stream);
+
 /* ---- triplet_loss, model/cvig_fov.py:366-382. workspace: 4*B floats, filled by fwd, read by bwd. */
 int witw_triplet_loss_fwd(const float* distance /*[B,B]*/, int B, float alpha, float* loss /*[1]*/, float* workspace,
                           void* stream);

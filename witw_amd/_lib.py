@@ -35,6 +35,7 @@ SIGNATURES = {
     'witw_crop_overhead': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'witw_l2_distance': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'witw_rank_count': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    'witw_rank_count_thresh': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     'witw_triplet_loss_fwd': (c_int, [c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     'witw_triplet_loss_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p]),
     'witw_resize_bilinear_normalize': (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p, c_void_p, c_int, c_void_p]),

@@ -185,6 +185,27 @@ __global__ __launch_bounds__(256) void bias_grad_partial_kernel(const float* __r
         part[(size_t)blockIdx.y * Cout + co] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
 }
 
+// Wide variant for Cout with 256 % (Cout/4) == 0: thread -> (channel quad, pixel phase), float4 loads
+// (a wave reads 1 KB contiguous), fixed-order combination of the phases through LDS.
+__global__ __launch_bounds__(256) void bias_grad_partial_wide_kernel(const float* __restrict__ dz, float* __restrict__ part,
+                                                                      size_t npix, int Cout, int rows_per_block) {
+    __shared__ f32x4 sh[256];
+    const int Q = Cout >> 2;                 // channel quads
+    const int phases = 256 / Q;
+    const int q = threadIdx.x % Q, ph = threadIdx.x / Q;
+    const size_t p0 = (size_t)blockIdx.x * rows_per_block;
+    const size_t p1 = min(npix, p0 + rows_per_block);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (size_t px = p0 + ph; px < p1; px += phases) s += *reinterpret_cast<const f32x4*>(dz + px * Cout + 4 * q);
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < Q) {
+        f32x4 t = sh[threadIdx.x];
+        for (int k = 1; k < phases; ++k) t += sh[k * Q + threadIdx.x];
+        *reinterpret_cast<f32x4*>(part + (size_t)blockIdx.x * Cout + 4 * threadIdx.x) = t;
+    }
+}
+
 __global__ void bias_grad_finish_kernel(const float* __restrict__ part, float* __restrict__ db, int Cout, int nparts,
                                         int accumulate) {
     const int co = blockIdx.x * blockDim.x + threadIdx.x;
@@ -212,6 +233,13 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 
 }  // namespace
 
+// pixels summed by one bias-gradient workgroup: ~512 workgroups, at least 64 pixels each
+static int bias_rows_per_block(size_t npix) {
+    size_t r = (npix + 511) / 512;
+    if (r < 64) r = 64;
+    return (int)r;
+}
+
 extern "C" {
 
 // number of K splits the launcher will use and the workspace it needs (floats)
@@ -227,7 +255,8 @@ int witw_conv3x3_wgrad_splits(int B, int Ho, int Wo, int Cin, int Cout) {
 long long witw_conv3x3_wgrad_workspace_floats(int B, int H, int W, int Cin, int Cout, int stride_h) {
     const int Ho = (H + 2 - 3) / stride_h + 1;
     const long long splits = witw_conv3x3_wgrad_splits(B, Ho, W, Cin, Cout);
-    const long long bias_parts = cdiv((long long)B * Ho * W > 0 ? B * Ho * W : 1, 4096);
+    const size_t npix = (size_t)B * Ho * W;
+    const long long bias_parts = (long long)((npix + bias_rows_per_block(npix) - 1) / bias_rows_per_block(npix));
     return splits * 9 * Cin * Cout + bias_parts * Cout;
 }
 
@@ -262,8 +291,13 @@ int witw_conv3x3_wgrad(const float* x, const float* dz, float* dw, float* db, fl
     if (db != nullptr) {
         float* part = workspace + (size_t)splits * n;
         const size_t npix = (size_t)B * a.Ho * a.Wo;
-        const int nparts = (int)((npix + 4095) / 4096);
-        hipLaunchKernelGGL(bias_grad_partial_kernel, dim3(cdiv(Cout, 64), nparts), dim3(256), 0, st, dz, part, npix, Cout, 4096);
+        const int rows = bias_rows_per_block(npix);
+        const int nparts = (int)((npix + rows - 1) / rows);
+        if ((Cout & 3) == 0 && Cout >= 16 && (256 % (Cout >> 2)) == 0)
+            hipLaunchKernelGGL(bias_grad_partial_wide_kernel, dim3(nparts), dim3(256), 0, st, dz, part, npix, Cout, rows);
+        else
+            hipLaunchKernelGGL(bias_grad_partial_kernel, dim3(cdiv(Cout, 64), nparts), dim3(256), 0, st, dz, part, npix, Cout,
+                               rows);
         hipLaunchKernelGGL(bias_grad_finish_kernel, dim3(cdiv(Cout, 256)), dim3(256), 0, st, part, db, Cout, nparts, accumulate);
         WITW_CHECK_LAUNCH("bias_grad");
     }

@@ -367,6 +367,20 @@ __global__ __launch_bounds__(256) void match_bwd_ov_kernel(const float* __restri
     }
 }
 
+// Sharded-gallery form: count against an explicit per-query threshold (the true match's distance,
+// produced by whichever rank owns that gallery row).
+__global__ __launch_bounds__(256) void rank_count_thresh_kernel(const float* __restrict__ D, const float* __restrict__ thr,
+                                                                int* __restrict__ ranks, int Bo, int Bs, int rows_per_block) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= Bs) return;
+    const float dt = thr[q];
+    const int r0 = blockIdx.y * rows_per_block;
+    const int r1 = min(Bo, r0 + rows_per_block);
+    int c = 0;
+    for (int o = r0; o < r1; ++o) c += (D[(size_t)o * Bs + q] <= dt) ? 1 : 0;
+    if (c) atomicAdd(&ranks[q], c);
+}
+
 }  // namespace
 
 extern "C" {
@@ -450,6 +464,21 @@ int witw_rank_count(const float* distance, int* ranks, int Bo, int Bs, int true_
     hipLaunchKernelGGL(rank_count_kernel, dim3(cdiv(Bs, 256), cdiv(Bo, rows)), dim3(256), 0, st, distance, ranks, Bo, Bs,
                        true_offset, rows);
     WITW_CHECK_LAUNCH("rank_count");
+    return WITW_OK;
+}
+
+int witw_rank_count_thresh(const float* distance, const float* threshold, int* ranks, int Bo, int Bs, void* stream) {
+    WITW_CHECK_ARG(distance && threshold && ranks, "rank_count_thresh: null pointer");
+    WITW_CHECK_ARG(Bo > 0 && Bs > 0, "rank_count_thresh: bad shape Bo=%d Bs=%d", Bo, Bs);
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(ranks, 0, sizeof(int) * (size_t)Bs, st) != hipSuccess) {
+        witw_set_error("rank_count_thresh: memset failed");
+        return WITW_ERR_LAUNCH;
+    }
+    const int rows = 512;
+    hipLaunchKernelGGL(rank_count_thresh_kernel, dim3(cdiv(Bs, 256), cdiv(Bo, rows)), dim3(256), 0, st, distance, threshold,
+                       ranks, Bo, Bs, rows);
+    WITW_CHECK_LAUNCH("rank_count_thresh");
     return WITW_OK;
 }
 

@@ -379,6 +379,31 @@ def ranks(overhead_embed, surface_embed):
     return ops.rank_count(dist, 0).cpu().numpy().astype('int64')
 
 
+def sharded_ranks(overhead_shard, surface_all, shard_begin, query_chunk=4096, _match=None, _count=None):
+    """Ranking with the GALLERY sharded by rows across ranks: this rank holds
+    overhead_shard = gallery rows [shard_begin, shard_begin+n); queries (replicated) match gallery row
+    == query index. The owner of each true row publishes its distance (all-reduce of a vector that is
+    zero elsewhere), every rank counts d <= d_true over its shard, counts are summed. Returns int64 [N]
+    on the host, identical on every rank and identical to ranks() on one GPU."""
+    from . import parallel
+    _match = _match or ops.match_fwd                 # injectable so the collective algebra is testable on CPU/gloo
+    _count = _count or ops.rank_count_thresh
+    n_q = surface_all.shape[0]
+    n_g = overhead_shard.shape[0]
+    out = torch.zeros((n_q,), dtype=torch.int32, device=surface_all.device)
+    for q0 in range(0, n_q, query_chunk):
+        q1 = min(n_q, q0 + query_chunk)
+        _, dist = _match(overhead_shard.contiguous(), surface_all[q0:q1].contiguous())   # [n_g, q]
+        qi = torch.arange(q0, q1, device=dist.device)
+        own = (qi >= shard_begin) & (qi < shard_begin + n_g)
+        row = (qi - shard_begin).clamp(0, n_g - 1)
+        d_true = torch.where(own, dist[row, qi - q0], torch.zeros_like(dist[0]))
+        parallel.all_reduce_sum_(d_true)
+        out[q0:q1] = _count(dist, d_true.contiguous())
+    parallel.all_reduce_sum_(out)
+    return out.cpu().numpy().astype('int64')
+
+
 def recall_table(ranks_arr):
     """model/cvig_fov.py:553-558."""
     import numpy as np

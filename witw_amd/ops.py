@@ -215,6 +215,20 @@ def rank_count(distance, true_offset=0):
     return ranks
 
 
+def rank_count_thresh(distance, threshold):
+    """ranks[q] = #{o : D[o,q] <= threshold[q]} over the rows present (one gallery shard)."""
+    lib = _lib.load()
+    d = _dev_f32(distance, 'distance')
+    t = _dev_f32(threshold, 'threshold')
+    Bo, Bs = d.shape
+    if t.numel() != Bs:
+        raise _lib.WitwError('rank_count_thresh: threshold must have one entry per query')
+    ranks = torch.empty((Bs,), dtype=torch.int32, device=d.device)
+    _lib.check(lib.witw_rank_count_thresh(d.data_ptr(), t.data_ptr(), ranks.data_ptr(), Bo, Bs, _stream()),
+               'witw_rank_count_thresh')
+    return ranks
+
+
 def triplet_loss_fwd(distance, alpha=10.):
     """-> (loss [1] f32, workspace [4B] holding the row/column partials for the backward)."""
     lib = _lib.load()

@@ -3,8 +3,15 @@
 The encoder has no BatchNorm, so samples are independent and the minibatch shards across ranks
 (SURVEY.md §8e). The loss couples the GLOBAL batch (nn.DataParallel semantics of the reference,
 model/cvig_baseline.py:339-343; normaliser 2B(B-1) with B = global batch, model/cvig_fov.py:380):
-embeddings are all-gathered (2 MiB per rank per side at B=128) and every rank evaluates the
-match + loss over the global batch.
+  1. both embedding sets are all-gathered (2 MiB per rank per side at 128 pairs/rank),
+  2. every rank evaluates match + loss over the global batch, so the gradient w.r.t. its LOCAL
+     embeddings is complete without a further exchange (it is the local slice of the global
+     embedding gradient),
+  3. weight gradients (57.9 MB for both encoders) are summed with one all-reduce over a flat bucket.
+Retrieval (gallery >> queries) shards the gallery rows instead: rank counts are summed with an
+all-reduce of int32[queries].
+
+Everything here is backend-agnostic host logic (tested on CPU with gloo, world_size 2).
 """
 import torch
 import torch.distributed as dist
@@ -18,18 +25,76 @@ def rank():
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
-def all_gather_embeddings(surface_embed, overhead_embed):
-    """[b,16,4,We],[b,16,4,64] per rank -> global [B,...] tensors in rank order (one fused
-    collective for both sides when their shapes agree, two otherwise)."""
+def _all_gather_cat(t):
     n = world()
-    if n == 1:
+    t = t.contiguous()
+    out = torch.empty((n * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    if dist.get_backend() == 'gloo':
+        dist.all_gather(list(out.chunk(n, 0)), t)
+    else:
+        dist.all_gather_into_tensor(out, t)
+    return out
+
+
+class _AllGather(torch.autograd.Function):
+    """cat over ranks; backward keeps the local slice (each rank holds the full global loss)."""
+
+    @staticmethod
+    def forward(ctx, t):
+        ctx.b = t.shape[0]
+        return _all_gather_cat(t)
+
+    @staticmethod
+    def backward(ctx, g):
+        r = rank()
+        return g[r * ctx.b:(r + 1) * ctx.b].contiguous()
+
+
+def all_gather_embeddings(surface_embed, overhead_embed):
+    """[b,16,4,We],[b,16,4,64] per rank -> global [B,...] tensors in rank order. Differentiable."""
+    if world() == 1:
         return surface_embed, overhead_embed
-    su = surface_embed.contiguous()
-    ov = overhead_embed.contiguous()
-    su_all = torch.empty((n * su.shape[0],) + tuple(su.shape[1:]), dtype=su.dtype, device=su.device)
-    ov_all = torch.empty((n * ov.shape[0],) + tuple(ov.shape[1:]), dtype=ov.dtype, device=ov.device)
-    h1 = dist.all_gather_into_tensor(su_all, su, async_op=True)
-    h2 = dist.all_gather_into_tensor(ov_all, ov, async_op=True)
-    h1.wait()
-    h2.wait()
-    return su_all, ov_all
+    if torch.is_grad_enabled() and (surface_embed.requires_grad or overhead_embed.requires_grad):
+        return _AllGather.apply(surface_embed), _AllGather.apply(overhead_embed)
+    return _all_gather_cat(surface_embed), _all_gather_cat(overhead_embed)
+
+
+def all_reduce_grads(params):
+    """SUM (not mean: the loss is already normalised by the global batch) of every existing .grad
+    through ONE flat bucket; parameters without a gradient (frozen layers) are skipped on all ranks
+    alike. Returns the number of floats reduced."""
+    grads = [p.grad for p in params if p.grad is not None]
+    if world() == 1 or not grads:
+        return sum(g.numel() for g in grads)
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    off = 0
+    for g in grads:
+        n = g.numel()
+        g.copy_(flat[off:off + n].view_as(g))
+        off += n
+    return off
+
+
+def broadcast_parameters(modules, src=0):
+    """Make every rank start from rank `src`'s weights."""
+    if world() == 1:
+        return
+    for m in modules:
+        for t in list(m.parameters()) + list(m.buffers()):
+            dist.broadcast(t.data, src)
+
+
+def shard_range(n, r=None, n_ranks=None):
+    """Contiguous [begin, end) share of n items for rank r (first n % ranks shares are one longer)."""
+    r = rank() if r is None else r
+    n_ranks = world() if n_ranks is None else n_ranks
+    q, rem = divmod(n, n_ranks)
+    begin = r * q + min(r, rem)
+    return begin, begin + q + (1 if r < rem else 0)
+
+
+def all_reduce_sum_(t):
+    if world() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
