@@ -1,0 +1,85 @@
+"""End-to-end drivers on a tiny synthetic dataset written to disk: ImagePairDataset -> GPU transforms ->
+train() (1 epoch) -> checkpoint with the reference's names/keys -> test() recall table; heat-map scoring."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cvig_fov_oracle as O
+from witw_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _write_dataset(root, n):
+    from PIL import Image
+    rows = []
+    for i in range(n):
+        ov = synth.images_u8(50, i, (64, 64, 3)).astype(np.uint8)
+        su = synth.images_u8(51, i, (48, 80, 3)).astype(np.uint8)
+        Image.fromarray(ov).save(os.path.join(root, 'ov_%d.png' % i))
+        Image.fromarray(su).save(os.path.join(root, 'su_%d.png' % i))
+        rows.append('ov_%d.png,su_%d.png' % (i, i))           # cvusa format: overhead,surface, no header
+    with open(os.path.join(root, 'pairs.csv'), 'w') as f:
+        f.write('\n'.join(rows) + '\n')
+    return os.path.join(root, 'pairs.csv')
+
+
+def test_dataset_and_gpu_preprocess_match_oracle(tmp_path):
+    from witw_amd import cvig_fov
+    csv = _write_dataset(str(tmp_path), 3)
+    ds = cvig_fov.ImagePairDataset('cvusa', csv)
+    assert len(ds) == 3
+    s = ds[1]
+    assert s['surface'].shape == (3, 48, 80) and s['overhead'].shape == (3, 64, 64) and s['surface'].dtype == torch.float32
+    prep = cvig_fov.GpuPreprocess('cvusa', fov=70, random_orientation=False)
+    out = prep(cvig_fov.collate_raw([ds[0], ds[1]]))
+    assert out['surface'].shape == (2, 3, 128, 99) and out['polar'].shape == (2, 3, 128, 512)
+    rs, ro = O.resize_pair(ds[1]['surface'], ds[1]['overhead'], fov=70, panorama=True, start=0)
+    np.testing.assert_allclose(out['surface'][1].cpu().numpy(), O.image_normalization(rs).numpy(), atol=2e-5)
+    np.testing.assert_allclose(out['polar'][1].cpu().numpy(), O.polar_transform(O.image_normalization(ro)).numpy(), atol=2e-5)
+
+
+def test_train_then_test_drivers(tmp_path, monkeypatch, capsys):
+    from witw_amd import cvig_fov
+    csv = _write_dataset(str(tmp_path), 6)
+    monkeypatch.chdir(tmp_path)
+    best = cvig_fov.train(dataset='cvusa', fov=70, val_quantity=2, batch_size=2, num_workers=0, num_epochs=1, csv_path=csv)
+    assert best is not None and np.isfinite(best)
+    for side in ('surface', 'overhead'):
+        sd = torch.load(os.path.join('weights', 'fov_70_%s_best.pth' % side))
+        assert any(k.endswith('features.27.weight') or k.endswith('features.27.layer.weight') for k in sd)
+    table = cvig_fov.test(dataset='cvusa', fov=70, batch_size=4, num_workers=0, csv_path=csv)
+    out = capsys.readouterr().out
+    assert 'Top  1:' in out and 'Locations: 6' in out and 'new best' in out
+    assert 0 <= table['top_1'] <= 100 and 1 <= table['median'] <= 6
+
+
+def test_sweep_scores_matches_heatmap_formula():
+    from witw_amd import cvig_fov
+    ov = torch.from_numpy(synth.embeddings(60, 1, (9, 16, 4, 64)))
+    su = torch.from_numpy(synth.embeddings(60, 2, (1, 16, 4, 12)))
+    ori_r, d_r = O.match(ov, su)
+    o, d, sc = cvig_fov.sweep_scores(ov.cuda(), su.cuda())
+    np.testing.assert_array_equal(o.cpu().numpy(), (ori_r.squeeze() * 360 / 64 - 180).numpy())
+    np.testing.assert_allclose(d.cpu().numpy(), d_r.squeeze().numpy(), atol=1e-5)
+    np.testing.assert_allclose(sc.cpu().numpy(), torch.exp(10. * (1. - d_r.squeeze())).numpy(), rtol=2e-4)
+
+
+def test_sharded_ranks_single_rank_equals_ranks():
+    from witw_amd import cvig_fov
+    n, we = 40, 12
+    ov = torch.from_numpy(synth.embeddings(61, 1, (n, 16, 4, 64)))
+    su = torch.stack([torch.roll(ov[i], -int(i % 64), dims=2)[:, :, :we] for i in range(n)]) \
+        + 7.0 * torch.from_numpy(synth.embeddings(61, 2, (n, 16, 4, we)))
+    a = cvig_fov.ranks(ov.cuda(), su.contiguous().cuda())
+    b = cvig_fov.sharded_ranks(ov.cuda(), su.contiguous().cuda(), 0, query_chunk=16)
+    np.testing.assert_array_equal(a, b)
+    assert a.max() > 1
+    # two half-gallery shards evaluated one after the other add up to the same counts
+    from witw_amd import ops
+    _, dist = cvig_fov.match(ov.cuda(), su.contiguous().cuda())
+    thr = torch.diagonal(dist).contiguous()
+    c = ops.rank_count_thresh(dist[:17].contiguous(), thr) + ops.rank_count_thresh(dist[17:].contiguous(), thr)
+    np.testing.assert_array_equal(c.cpu().numpy().astype('int64'), a)

@@ -416,3 +416,214 @@ def recall_table(ranks_arr):
         'mean': float(np.mean(ranks_arr)),
         'median': float(np.median(ranks_arr)),
     }
+
+
+# ----------------------------------------------------------------------------- dataset + drivers
+class ImagePairDataset(torch.utils.data.Dataset):
+    """model/cvig_fov.py:54-97: pairs of images (one surface, one overhead) from a CSV. Returns CPU
+    float32 CHW tensors {'idx','surface','overhead'}; `transform` (if any) is applied per sample — the
+    drivers pass none here and run Resize/ImageNormalization/PolarTransform batched on the GPU instead
+    (DataLoader worker processes must not touch the device)."""
+
+    def __init__(self, dataset, csv_path, base_path=None, transform=None):
+        import os
+        import pandas as pd
+        self.csv_path = csv_path
+        self.base_path = base_path if base_path is not None else os.path.dirname(csv_path)
+        self.transform = transform
+        path_format = Globals.path_formats[dataset]
+        file_paths = pd.read_csv(self.csv_path, header=path_format['header'], names=path_format['path_names'],
+                                 usecols=path_format['path_columns'])
+        self.file_paths = file_paths.map(
+            lambda x: os.path.join(self.base_path, x) if isinstance(x, str) and len(x) > 0 and x[0] != '/' else x)
+
+    def __len__(self):
+        return len(self.file_paths)
+
+    @staticmethod
+    def _read(path):
+        import numpy as np
+        from PIL import Image
+        a = np.asarray(Image.open(path))
+        if a.ndim == 2:
+            a = a[:, :, None]
+        return torch.from_numpy(a.astype(np.float32).transpose((2, 0, 1)).copy())
+
+    def __getitem__(self, idx):
+        data = {'idx': idx, 'surface': self._read(self.file_paths.iloc[idx]['surface']),
+                'overhead': self._read(self.file_paths.iloc[idx]['overhead'])}
+        if self.transform is not None:
+            data = self.transform(data)
+        return data
+
+
+def collate_raw(samples):
+    """Raw images differ in size: keep them as lists; GpuPreprocess batches them on the device."""
+    return {'idx': [s['idx'] for s in samples], 'surface': [s['surface'] for s in samples],
+            'overhead': [s['overhead'] for s in samples]}
+
+
+class GpuPreprocess(object):
+    """Compose[Resize, ImageNormalization, PolarTransform] (model/cvig_fov.py:393-397) over a batch of raw
+    images, on the GPU: -> {'surface' [B,3,128,Ws], 'overhead' [B,3,256,256], 'polar' [B,3,128,512]}."""
+
+    def __init__(self, dataset, fov=360, random_orientation=True):
+        self.resize = Resize(dataset, fov, random_orientation)
+        self.norm = ImageNormalization()
+        self.polar = PolarTransform()
+
+    def __call__(self, batch):
+        s, o = [], []
+        for su, ov in zip(batch['surface'], batch['overhead']):
+            d = self.resize({'surface': su[:3], 'overhead': ov[:3]})
+            s.append(d['surface'])
+            o.append(d['overhead'])
+        data = {'idx': batch['idx'], 'surface': torch.stack(s), 'overhead': torch.stack(o)}
+        return self.polar(self.norm(data))
+
+
+class _NullWriter(object):
+    def add_scalar(self, *a, **k):
+        pass
+
+    add_text = add_embedding = add_scalar
+
+
+def _writer(path):
+    try:
+        from torch.utils.tensorboard import SummaryWriter
+        return SummaryWriter(path)
+    except Exception:
+        return _NullWriter()
+
+
+def load_reference_state_dict(encoder, state):
+    """Load a checkpoint written by the reference (model/cvig_fov.py:485-486): same keys, plus the unused
+    VGG classifier tensors (model.classifier.*), which are dropped."""
+    state = {k: v for k, v in state.items() if not k.startswith('model.classifier')}
+    return encoder.load_state_dict(state, strict=True)
+
+
+def train(dataset='cvusa', fov=360, val_quantity=1000, batch_size=64, num_workers=12, num_epochs=999999, csv_path=None,
+          seed=0):
+    """model/cvig_fov.py:385-487 on the HIP kernels (same flow, checkpoint names and prints)."""
+    import pathlib
+    import time
+    from datetime import datetime
+    pathlib.Path('./weights').mkdir(parents=True, exist_ok=True)
+    writer = _writer('runs/{}/train/{}/{}'.format(dataset, fov, datetime.now().strftime("%Y%m%d-%H%M%S")))
+    csv_path = csv_path or Globals.dataset_paths[dataset]['train']
+    prep = GpuPreprocess(dataset, fov)
+    trainval_set = ImagePairDataset(dataset=dataset, csv_path=csv_path)
+    train_set, val_set = torch.utils.data.random_split(trainval_set, [len(trainval_set) - val_quantity, val_quantity])
+    train_loader = torch.utils.data.DataLoader(train_set, batch_size=batch_size, shuffle=True, drop_last=True,
+                                               num_workers=num_workers, collate_fn=collate_raw)
+    val_loader = torch.utils.data.DataLoader(val_set, batch_size=batch_size, shuffle=False, drop_last=False,
+                                             num_workers=num_workers, collate_fn=collate_raw)
+    surface_encoder = FOV_DSM(circ_padding=False, seed=seed).to(device)
+    overhead_encoder = FOV_DSM(circ_padding=True, seed=seed).to(device)
+    loss_func = triplet_loss
+    all_params = list(surface_encoder.parameters()) + list(overhead_encoder.parameters())
+    optimizer = Adam(all_params, lr=1.E-5)
+
+    best_loss = None
+    for epoch in range(num_epochs):
+        print('Epoch %d, %s' % (epoch + 1, time.ctime(time.time())))
+        for phase in ['train', 'val']:
+            running_count = 0
+            running_loss = 0.
+            loader = train_loader if phase == 'train' else val_loader
+            surface_encoder.train(phase == 'train')
+            overhead_encoder.train(phase == 'train')
+            for batch, raw in enumerate(loader):
+                data = prep(raw)
+                surface = data['surface']
+                overhead = data['polar']
+                with torch.set_grad_enabled(phase == 'train'):
+                    surface_embed = surface_encoder(surface)
+                    overhead_embed = overhead_encoder(overhead)
+                    orientation_estimate, distance = match(overhead_embed, surface_embed)
+                    loss = loss_func(distance)
+                    if phase == 'train':
+                        optimizer.zero_grad()
+                        loss.backward()
+                        optimizer.step()
+                count = surface_embed.size(0)
+                running_count += count
+                running_loss += loss.item() * count
+                print('epoch = {} {}, iter = {}, count = {}, loss = {:.4f}'.format(epoch + 1, phase, batch, running_count,
+                                                                                 loss.item()))
+                writer.add_scalar('{} loss'.format(phase), running_loss / running_count, epoch * len(loader) + batch)
+            print('  %5s: avg loss = %f' % (phase, running_loss / max(1, running_count)))
+        if running_count and (best_loss is None or running_loss / running_count < best_loss):
+            print('-------> new best')
+            best_loss = running_loss / running_count
+            torch.save(surface_encoder.state_dict(), './weights/fov_{}_surface_best.pth'.format(int(fov)))
+            torch.save(overhead_encoder.state_dict(), './weights/fov_{}_overhead_best.pth'.format(int(fov)))
+            writer.add_text('best_loss', 'new best loss: {}, epoch: {}'.format(best_loss, epoch + 1), epoch)
+    return best_loss
+
+
+def test(dataset='cvusa', fov=360, batch_size=64, num_workers=8, csv_path=None):
+    """model/cvig_fov.py:490-575: embed the test set, rank every query against the whole gallery (all
+    queries at once on the GPU instead of the O(N) Python loop), print the recall table."""
+    from datetime import datetime
+    writer = _writer('runs/{}/test/{}/{}'.format(dataset, fov, datetime.now().strftime("%Y%m%d-%H%M%S")))
+    csv_path = csv_path or Globals.dataset_paths[dataset]['test']
+    prep = GpuPreprocess(dataset, fov)
+    test_set = ImagePairDataset(dataset=dataset, csv_path=csv_path)
+    test_loader = torch.utils.data.DataLoader(test_set, batch_size=batch_size, shuffle=False, drop_last=False,
+                                              num_workers=num_workers, collate_fn=collate_raw)
+    surface_encoder = FOV_DSM(circ_padding=False).to(device)
+    overhead_encoder = FOV_DSM(circ_padding=True).to(device)
+    load_reference_state_dict(surface_encoder, torch.load('./weights/fov_{}_surface_best.pth'.format(int(fov))))
+    load_reference_state_dict(overhead_encoder, torch.load('./weights/fov_{}_overhead_best.pth'.format(int(fov))))
+    surface_encoder.eval()
+    overhead_encoder.eval()
+    su_parts, ov_parts = [], []
+    for raw in test_loader:
+        data = prep(raw)
+        with torch.no_grad():
+            su_parts.append(surface_encoder(data['surface']))
+            ov_parts.append(overhead_encoder(data['polar']))
+    surface_embed = torch.cat(su_parts, dim=0)
+    overhead_embed = torch.cat(ov_parts, dim=0)
+    rk = ranks(overhead_embed, surface_embed)
+    t = recall_table(rk)
+    count = len(rk)
+    lines = ['Top  1: {:.2f}%'.format(t['top_1']), 'Top  5: {:.2f}%'.format(t['top_5']), 'Top 10: {:.2f}%'.format(t['top_10']),
+             'Top 1%: {:.2f}%'.format(t['top_1pct']), 'Avg. Rank: {:.2f}'.format(t['mean']),
+             'Med. Rank: {:.2f}'.format(t['median']), 'Locations: {}'.format(count)]
+    for tag, line in zip(['top_1', 'top_5', 'top_10', 'top_1%', 'avg_rank', 'med_rank', 'locations'], lines):
+        print(line)
+        writer.add_text(tag, line)
+    return t
+
+
+def sweep_scores(overhead_embed, surface_embed, output_width_max=64):
+    """The scoring block of tools/heatmap/heatmap.py:172-178 (one photo against N satellite tiles):
+    -> (orientation in degrees, dissimilarity, score = exp(10*(1-d))), each [N] (or [N,Bs])."""
+    ori, dist = match(overhead_embed, surface_embed)
+    orientations = torch.squeeze(ori) * 360 / output_width_max - 180
+    distances = torch.squeeze(dist)
+    return orientations, distances, torch.exp(10. * (1. - distances))
+
+
+def main(argv=None):
+    """CLI of model/cvig_fov.py:580-601."""
+    import argparse
+    parser = argparse.ArgumentParser()
+    parser.add_argument('--mode', default='train', choices=['train', 'test'], help='Run mode. [Default = train]')
+    parser.add_argument('--dataset', default='cvusa', choices=['cvusa', 'witw'], help='Dataset to use. [Default = cvusa]')
+    parser.add_argument('--fov', type=int, default=360, choices=range(6, 361), metavar='{6-360}',
+                        help='The field of view for cropping street level images. [Default = 360]')
+    args = parser.parse_args(argv)
+    print(args)
+    if args.mode == 'train':
+        train(dataset=args.dataset, fov=args.fov)
+    elif args.mode == 'test':
+        test(dataset=args.dataset, fov=args.fov)
+
+
+if __name__ == '__main__':
+    main()
