@@ -52,10 +52,13 @@ int witw_conv3x3_fwd(const float* x, const float* wpk, const float* bias, const 
 /* Extended form used by the backward pass: `gate` (NULL or a tensor shaped like y) zeroes outputs where
  * gate <= 0 (ReLU backward), dilate_h=1 reads the input as zero-interleaved rows (row 2i = physical row i,
  * H is the dilated height) — the data gradient of a stride-(2,1) conv is then this same kernel on the
- * transpose_flip filter. autograd of torch.nn.Conv2d at model/cvig_fov.py:460. */
+ * transpose_flip filter (autograd of torch.nn.Conv2d at model/cvig_fov.py:460). relu: 0 none, 1 ReLU,
+ * 2 LeakyReLU(lrelu_slope); post_scale/post_shift (NULL or [Cout]): per-channel affine after the activation
+ * (eval-mode BatchNorm2d of model/cvig_baseline.py:267-275). */
 int witw_conv3x3_fwd_ex(const float* x, const float* wpk, const float* bias, const float* dropmask, const float* gate,
-                        float* y, int B, int H, int W, int Cin, int Cout, int stride_h, int pad_circular, int relu, int pool,
-                        int out_nchw, int dilate_h, void* stream);
+                        const float* post_scale, const float* post_shift, float* y, int B, int H, int W, int Cin, int Cout,
+                        int stride_h, int pad_circular, int relu, float lrelu_slope, int pool, int out_nchw, int dilate_h,
+                        void* stream);
 /* NCHW [B,C,H,W] -> NHWC [B,H,W,Cpad] with zero-filled extra channels (embedding gradients). */
 int witw_nchw_to_nhwc(const float* x, float* y, int B, int C, int H, int W, int Cpad, void* stream);
 /* Weight / bias gradient of one conv layer. x: the layer's NHWC input [B,H,W,Cin], dz: gradient at its output
@@ -95,6 +98,23 @@ int witw_triplet_loss_fwd(const float* distance /*[B,B]*/, int B, float alpha, f
                           void* stream);
 int witw_triplet_loss_bwd(const float* distance, const float* workspace, const float* grad_loss /*[1]*/,
                           float* grad_distance /*[B,B]*/, int B, float alpha, void* stream);
+
+/* ---- cvig_baseline (model/cvig_baseline.py). Conv2d(k=4,s=2,p=0) = the 3x3 kernel above on the
+ * space-to-depth(2) image with a filter whose first tap row/column is zero. */
+/* x NHWC [B,Hp,Wp,C] (NCHW if in_nchw) with valid region HxW -> NHWC [B,ceil(H/2),ceil(W/2),Cpad], channel
+ * (dy*2+dx)*C+c; normalize=1 applies x/255, -1+2x (:265-266). */
+int witw_space_to_depth2(const float* x, float* y, int B, int Hp, int Wp, int H, int W, int C, int Cpad, int in_nchw,
+                         int normalize, void* stream);
+/* f[b,col0+c] = (mean relu(x)^p)^(1/p) over the valid HxW region (:276-282); f has row length ldf. */
+int witw_gem_pool(const float* x, float* f, int B, int Hp, int Wp, int H, int W, int C, int ldf, int col0, float p,
+                  void* stream);
+/* f[b,:] /= sqrt(|f[b,:]|_2) in place (:284) */
+int witw_embed_normalize(float* f, int B, int n, void* stream);
+/* D[i][j] = |a_i - b_j|^2 (or its square root: Euclidean ranking distance of :457-458) */
+int witw_pairwise_sqdist(const float* a, const float* b, float* D, int Na, int Nb, int n, int take_sqrt, void* stream);
+/* exhaustive_minibatch_triplet_loss (:286-315) from D[i][j] = |embed1_i - embed2_j|^2; workspace B floats */
+int witw_exhaustive_triplet_loss(const float* D, int B, int soft_margin, float alpha, float margin, float* loss,
+                                 float* workspace, void* stream);
 
 /* ---- data path: Resize (:100-134), ImageNormalization (:137-149; semantic: cvig_semantic.py:167-176),
  *      PolarTransform (:156-209). NCHW fp32. mean/stdv: HOST arrays of C floats (NULL = resize only). */

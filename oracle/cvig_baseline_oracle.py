@@ -1,0 +1,47 @@
+"""CPU oracle for the cvig_baseline hot path — TEST INFRASTRUCTURE ONLY (see cvig_fov_oracle.py header).
+Restates model/cvig_baseline.py's encoder (eval mode), loss and ranking in plain CPU torch ops; pinned to the
+reference through tests/golden/baseline.npz (tests/test_oracle_golden.py)."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def encoder_forward(x, params, p=3.):
+    """SurfaceEncoder.forward, model/cvig_baseline.py:264-279, eval-mode BatchNorm.
+    params: list of 7 dicts {w,b,gamma,beta,mean,var}."""
+    x = x / 255.
+    x = -1. + 2. * x
+    feats = []
+    for i, q in enumerate(params):
+        x = F.conv2d(x, q['w'], q['b'], stride=2, padding=0)
+        x = F.leaky_relu(x, 0.2)
+        x = F.batch_norm(x, q['mean'], q['var'], q['gamma'], q['beta'], training=False, momentum=0.1, eps=1e-5)
+        if i >= 4:
+            feats.append(torch.pow(torch.mean(torch.pow(F.relu(x), p), [2, 3]), 1. / p))
+    f = torch.cat(feats, 1)
+    return f / torch.unsqueeze(torch.pow(torch.linalg.norm(f, dim=1), 0.5), 1)
+
+
+def exhaustive_minibatch_triplet_loss(embed1, embed2, soft_margin=False, alpha=10., margin=1.):
+    """model/cvig_baseline.py:286-315."""
+    loss = torch.tensor(0.)
+    bsz = embed1.size(0)
+    for (a, p) in [(embed1, embed2), (embed2, embed1)]:
+        for shift in range(1, bsz):
+            n = torch.roll(p, shift, dims=0)
+            ap = torch.sum((p - a) ** 2, dim=1)
+            an = torch.sum((n - a) ** 2, dim=1)
+            this = torch.log(1. + torch.exp(alpha * (ap - an))) if soft_margin else F.relu(ap - an + margin)
+            loss = loss + torch.sum(this)
+    return loss / (2 * bsz * (bsz - 1))
+
+
+def ranks(overhead_embed, surface_embed):
+    """model/cvig_baseline.py:454-460."""
+    count = surface_embed.size(0)
+    out = np.zeros([count], dtype=np.int64)
+    for idx in range(count):
+        q = torch.unsqueeze(surface_embed[idx, :], 0)
+        d = torch.pow(torch.sum(torch.pow(overhead_embed - q, 2), dim=1), 0.5)
+        out[idx] = torch.sum(torch.le(d, d[idx])).item()
+    return out

@@ -269,7 +269,7 @@ def main():
             print('  %-28s %8d bytes' % (f, os.path.getsize(os.path.join(HERE, f))))
 
 
-if __name__ == '__main__' and '--trainstep' not in sys.argv:
+if __name__ == '__main__' and '--trainstep' not in sys.argv and '--baseline' not in sys.argv:
     main()
 
 
@@ -334,3 +334,49 @@ def gen_trainstep():
 
 if __name__ == '__main__' and '--trainstep' in sys.argv:
     gen_trainstep()
+
+
+def gen_baseline():
+    """cvig_baseline goldens: encoder eval forward (500x500 surface / 512x512 overhead, SURVEY C1 shapes),
+    exhaustive minibatch triplet loss (hard and soft margin) and the Euclidean ranking loop body."""
+    fov, sem, base = import_reference()
+    res = {'seed': SEED}
+    for tag, cls, hw, stream in (('surface', base.SurfaceEncoder, 500, 30), ('overhead', base.OverheadEncoder, 512, 31)):
+        enc = cls()
+        prm = synth.baseline_params(SEED + (0 if tag == 'surface' else 1))
+        with torch.no_grad():
+            for i, q in enumerate(prm, 1):
+                getattr(enc, 'conv%d' % i).weight.copy_(torch.from_numpy(q['w']))
+                getattr(enc, 'conv%d' % i).bias.copy_(torch.from_numpy(q['b']))
+                bn = getattr(enc, 'bn%d' % i)
+                bn.weight.copy_(torch.from_numpy(q['gamma']))
+                bn.bias.copy_(torch.from_numpy(q['beta']))
+                bn.running_mean.copy_(torch.from_numpy(q['mean']))
+                bn.running_var.copy_(torch.from_numpy(q['var']))
+        enc.eval()
+        x = torch.from_numpy(synth.images_u8(SEED, stream, (2, 3, hw, hw)))
+        with torch.no_grad():
+            res['embed_' + tag] = enc(x).numpy()
+        res['keys_' + tag] = np.array(sorted(enc.state_dict().keys()))
+    e1 = torch.from_numpy(synth.embeddings(SEED, 600, (5, 1536))) * 0.018
+    e2 = e1 + torch.from_numpy(synth.embeddings(SEED, 601, (5, 1536))) * 0.02
+    res['loss_hard'] = base.exhaustive_minibatch_triplet_loss(e1, e2).numpy()
+    res['loss_soft'] = base.exhaustive_minibatch_triplet_loss(e1, e2, soft_margin=True).numpy()
+    res['loss_hard_m03'] = base.exhaustive_minibatch_triplet_loss(e1 * 0.55, e2 * 0.55, margin=0.3).numpy()
+    res['loss_soft_a2'] = base.exhaustive_minibatch_triplet_loss(e1, e2, soft_margin=True, alpha=2.).numpy()
+    n = 14
+    ov = torch.from_numpy(synth.embeddings(SEED, 602, (n, 1536)))
+    su = ov + 14.0 * torch.from_numpy(synth.embeddings(SEED, 603, (n, 1536)))
+    ranks = np.zeros([n], dtype=int)
+    for idx in range(n):
+        q = torch.unsqueeze(su[idx, :], 0)
+        d = torch.pow(torch.sum(torch.pow(ov - q, 2), dim=1), 0.5)
+        ranks[idx] = torch.sum(torch.le(d, d[idx])).item()
+    res['ranks'] = ranks
+    assert ranks.max() > 1 and float(res['loss_hard']) > 0 and float(res['loss_hard_m03']) > 0
+    np.savez(os.path.join(HERE, 'baseline.npz'), **res)
+    print('baseline.npz written; ranks', ranks, 'losses', res['loss_hard'], res['loss_soft'])
+
+
+if __name__ == '__main__' and '--baseline' in sys.argv:
+    gen_baseline()

@@ -108,3 +108,19 @@ def test_cpu_tensor_is_refused():
     enc = cvig_fov.FOV_DSM()
     with pytest.raises(_lib.WitwError):
         enc(torch.zeros(1, 3, 128, 512))
+
+
+def test_semantic_encoder_matches_reference_golden(golden_dir):
+    from witw_amd import cvig_semantic
+    g = np.load(os.path.join(golden_dir, 'encoder_semantic.npz'))
+    seed = int(g['seed'])
+    w5 = synth.fov_dsm_weights(seed, in_channels=5)
+    x5 = torch.from_numpy(synth.normalized_images(seed, 12, (1, 5, 128, 512))).cuda()
+    enc = cvig_semantic.FOV_DSM(circ_padding=True, weights=w5).cuda().eval()
+    with torch.no_grad():
+        e = enc(x5).cpu().numpy()
+    np.testing.assert_allclose(e, g['embed5_circ1'], rtol=0, atol=TOL)
+    ref_train = sorted(k for k in g['trainable'] if not k.startswith('model.classifier'))
+    assert sorted(n for n, p in enc.named_parameters() if p.requires_grad) == ref_train
+    with pytest.raises(Exception):       # backward through layers 0-16 is not built: fail loudly, never silently
+        enc.train()(x5)

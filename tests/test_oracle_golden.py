@@ -117,3 +117,28 @@ def test_ranking(golden_dir):
         t = O.recall_table(r)
         np.testing.assert_allclose([t['top_1'], t['top_5'], t['top_10'], t['top_1pct'], t['mean'], t['median']],
                                    g['%s_table' % tag])
+
+
+def _baseline_params(seed):
+    return [{k: torch.from_numpy(v) for k, v in q.items()} for q in synth.baseline_params(seed)]
+
+
+def test_baseline_oracle_matches_reference(golden_dir):
+    from oracle import cvig_baseline_oracle as OB
+    g = _load(golden_dir, 'baseline.npz')
+    seed = int(g['seed'])
+    for tag, hw, stream, off in (('surface', 500, 30, 0), ('overhead', 512, 31, 1)):
+        x = torch.from_numpy(synth.images_u8(seed, stream, (2, 3, hw, hw)))
+        with torch.no_grad():
+            e = OB.encoder_forward(x, _baseline_params(seed + off)).numpy()
+        assert e.shape == (2, 1536)
+        np.testing.assert_allclose(e, g['embed_' + tag], rtol=0, atol=1e-6)
+    e1 = torch.from_numpy(synth.embeddings(seed, 600, (5, 1536))) * 0.018
+    e2 = e1 + torch.from_numpy(synth.embeddings(seed, 601, (5, 1536))) * 0.02
+    assert OB.exhaustive_minibatch_triplet_loss(e1, e2).item() == float(g['loss_hard'])
+    assert OB.exhaustive_minibatch_triplet_loss(e1, e2, soft_margin=True).item() == float(g['loss_soft'])
+    assert OB.exhaustive_minibatch_triplet_loss(e1 * 0.55, e2 * 0.55, margin=0.3).item() == float(g['loss_hard_m03'])
+    assert OB.exhaustive_minibatch_triplet_loss(e1, e2, soft_margin=True, alpha=2.).item() == float(g['loss_soft_a2'])
+    ov = torch.from_numpy(synth.embeddings(seed, 602, (14, 1536)))
+    su = ov + 14.0 * torch.from_numpy(synth.embeddings(seed, 603, (14, 1536)))
+    np.testing.assert_array_equal(OB.ranks(ov, su), g['ranks'])

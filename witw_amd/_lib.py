@@ -22,13 +22,18 @@ SIGNATURES = {
     'witw_conv3x3_pack_weights': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'witw_nchw_to_nhwc8': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'witw_conv3x3_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),
-    'witw_conv3x3_fwd_ex': (c_int, [c_void_p] * 6 + [c_int] * 11 + [c_void_p]),
+    'witw_conv3x3_fwd_ex': (c_int, [c_void_p] * 8 + [c_int] * 8 + [c_float] + [c_int] * 3 + [c_void_p]),
     'witw_nchw_to_nhwc': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'witw_conv3x3_wgrad_splits': (c_int, [c_int] * 5),
     'witw_conv3x3_wgrad_workspace_floats': (c_longlong, [c_int] * 6),
     'witw_conv3x3_wgrad': (c_int, [c_void_p] * 5 + [c_int] * 9 + [c_void_p]),
     'witw_adam_step': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_float, c_float, c_float, c_float, c_int,
                                c_void_p]),
+    'witw_space_to_depth2': (c_int, [c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]),
+    'witw_gem_pool': (c_int, [c_void_p, c_void_p] + [c_int] * 8 + [c_float, c_void_p]),
+    'witw_embed_normalize': (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    'witw_pairwise_sqdist': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'witw_exhaustive_triplet_loss': (c_int, [c_void_p, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     'witw_match_bwd': (c_int, [c_void_p] * 8 + [c_int] * 3 + [c_void_p]),
     'witw_match_workspace_floats': (c_longlong, [c_int, c_int]),
     'witw_match_fwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -34,6 +34,9 @@ struct ConvArgs {
     const float* wpk;       // packed: [n_tile][cin/8][tap][quad][TN][4]
     const float* bias;      // [n_tiles*TN] (zero padded)
     const float* dropmask;  // [B,Cout] scale (0 or 1/(1-p)) or nullptr
+    const float* post_scale;  // nullptr, or per-channel scale/shift applied AFTER the activation (folded BatchNorm)
+    const float* post_shift;
+    float lrelu;            // negative slope when relu == 2 (LeakyReLU)
     const float* gate;      // nullptr, or a tensor shaped like y: outputs where gate <= 0 are zeroed (ReLU backward)
     float* y;               // NHWC [B,Hy,Wy,Cout] or NCHW [B,Cout,Hy,Wy]
     int B, H, W, Cin, Cout;
@@ -279,7 +282,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_nhwc_f32_kernel(ConvArgs p) 
 
     STAMP();
     // ---- epilogue: bias, dropout scale, ReLU, optional 2x2 max pool, store
-    float bv[WN], dm[WN];
+    float bv[WN], dm[WN], ps[WN], pt[WN];
     int nch[WN];
 #pragma unroll
     for (int nt = 0; nt < WN; ++nt) {
@@ -287,13 +290,26 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_nhwc_f32_kernel(ConvArgs p) 
         bv[nt] = p.bias[nch[nt]];
         dm[nt] = 1.f;
         if (p.dropmask != nullptr && nch[nt] < p.Cout) dm[nt] = p.dropmask[(size_t)b * p.Cout + nch[nt]];
+        ps[nt] = 1.f;
+        pt[nt] = 0.f;
+        if (p.post_scale != nullptr && nch[nt] < p.Cout) {
+            ps[nt] = p.post_scale[nch[nt]];
+            pt[nt] = p.post_shift[nch[nt]];
+        }
     }
+    // conv + bias -> Dropout2d scale -> activation -> per-channel affine
+    auto fin = [&](float v, int nt) {
+        v = (v + bv[nt]) * dm[nt];
+        if (p.relu == 1) v = fmaxf(v, 0.f);
+        else if (p.relu == 2) v = v > 0.f ? v : v * p.lrelu;
+        if (p.post_scale != nullptr) v = v * ps[nt] + pt[nt];
+        return v;
+    };
     const int Hy = POOL ? (p.Ho >> 1) : p.Ho;
     const int Wy = POOL ? (p.Wo >> 1) : p.Wo;
 
     auto emit = [&](float v, int nt, int yy, int xx) {
-        v = (v + bv[nt]) * dm[nt];
-        if (p.relu) v = fmaxf(v, 0.f);
+        v = fin(v, nt);
         if (yy < Hy && xx < Wy && nch[nt] < p.Cout) {
             size_t o;
             if (p.out_nchw)
@@ -318,8 +334,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_nhwc_f32_kernel(ConvArgs p) 
             for (int nt = 0; nt < WN; ++nt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    float v = (acc[mt][nt][r] + bv[nt]) * dm[nt];
-                    if (p.relu) v = fmaxf(v, 0.f);
+                    const float v = fin(acc[mt][nt][r], nt);
                     slab[((r & 3) + 8 * (r >> 2) + 4 * hq) * 64 + nt * 32 + l31] = v;
                 }
             const int yy = oy0 + trow[mt];
@@ -507,8 +522,9 @@ int witw_nchw_to_nhwc(const float* x, float* y, int B, int C, int H, int W, int 
 }
 
 int witw_conv3x3_fwd_ex(const float* x, const float* wpk, const float* bias, const float* dropmask, const float* gate,
-                        float* y, int B, int H, int W, int Cin, int Cout, int stride_h, int pad_circular, int relu, int pool,
-                        int out_nchw, int dilate_h, void* stream) {
+                        const float* post_scale, const float* post_shift, float* y, int B, int H, int W, int Cin, int Cout,
+                        int stride_h, int pad_circular, int relu, float lrelu_slope, int pool, int out_nchw, int dilate_h,
+                        void* stream) {
     WITW_CHECK_ARG(x && wpk && bias && y, "conv3x3_fwd: null pointer");
     WITW_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cout > 0, "conv3x3_fwd: bad shape B=%d H=%d W=%d Cout=%d", B, H, W, Cout);
     WITW_CHECK_ARG(Cin > 0 && (Cin % 8) == 0, "conv3x3_fwd: Cin=%d must be a positive multiple of 8", Cin);
@@ -517,8 +533,12 @@ int witw_conv3x3_fwd_ex(const float* x, const float* wpk, const float* bias, con
     WITW_CHECK_ARG(!(pool && out_nchw), "conv3x3_fwd: pool with NCHW output unsupported");
     WITW_CHECK_ARG(!(pool && gate), "conv3x3_fwd: pool with gate unsupported");
     WITW_CHECK_ARG(!(dilate_h && stride_h == 2), "conv3x3_fwd: dilated input with stride 2 unsupported");
+    WITW_CHECK_ARG(relu >= 0 && relu <= 2, "conv3x3_fwd: activation %d unknown (0 none, 1 ReLU, 2 LeakyReLU)", relu);
+    WITW_CHECK_ARG((post_scale == nullptr) == (post_shift == nullptr), "conv3x3_fwd: post_scale and post_shift go together");
+    WITW_CHECK_ARG(!(pool && relu == 2) && !(pool && post_scale), "conv3x3_fwd: pool needs a monotone epilogue (ReLU only)");
     ConvArgs a;
     a.x = x; a.wpk = wpk; a.bias = bias; a.dropmask = dropmask; a.gate = gate; a.y = y;
+    a.post_scale = post_scale; a.post_shift = post_shift; a.lrelu = lrelu_slope;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
     a.Ho = (H + 2 - 3) / stride_h + 1;
     a.Wo = W;
@@ -541,8 +561,8 @@ int witw_conv3x3_fwd_ex(const float* x, const float* wpk, const float* bias, con
 int witw_conv3x3_fwd(const float* x, const float* wpk, const float* bias, const float* dropmask, float* y, int B, int H,
                      int W, int Cin, int Cout, int stride_h, int pad_circular, int relu, int pool, int out_nchw,
                      void* stream) {
-    return witw_conv3x3_fwd_ex(x, wpk, bias, dropmask, nullptr, y, B, H, W, Cin, Cout, stride_h, pad_circular, relu, pool,
-                               out_nchw, 0, stream);
+    return witw_conv3x3_fwd_ex(x, wpk, bias, dropmask, nullptr, nullptr, nullptr, y, B, H, W, Cin, Cout, stride_h,
+                               pad_circular, relu ? 1 : 0, 0.f, pool, out_nchw, 0, stream);
 }
 
 }  // extern "C"

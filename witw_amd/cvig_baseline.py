@@ -1,0 +1,159 @@
+#!/usr/bin/env python
+"""MI355X-native drop-in for the hot path of the reference's model/cvig_baseline.py (Liu & Li CVPR'19-style
+baseline): 7 x [Conv2d(4,2,0) -> LeakyReLU(0.2) -> BatchNorm2d] encoders with GeM-like
+multi-scale pooling, exhaustive minibatch triplet loss on squared Euclidean distances, Euclidean ranking.
+Inference (eval-mode BatchNorm) runs on the HIP kernels; train-mode BatchNorm / backward are not built and raise.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _lib, ops
+from .cvig_fov import recall_table  # noqa: F401  (same table, model/cvig_baseline.py:461-466)
+
+device = torch.device('cuda:0' if torch.cuda.is_available() else 'cpu')   # model/cvig_baseline.py:20
+device_parallel = False
+device_ids = None
+
+
+class Globals:
+    """model/cvig_baseline.py:24-48"""
+    dataset_paths = {
+        'cvusa': {'train': './data/train-19zl.csv', 'test': './data/val-19zl.csv'},
+        'witw': {'train': './data2/train.csv', 'test': './data2/test.csv'},
+    }
+    path_formats = {
+        'cvusa': {'path_columns': [0, 1], 'path_names': ['overhead', 'surface'], 'header': None, 'panorama': True},
+        'witw': {'path_columns': [15, 16], 'path_names': ['surface', 'overhead'], 'header': 0, 'panorama': False},
+    }
+
+
+def horizontal_shift(img, shift, unit='pixels'):
+    """model/cvig_baseline.py:97-113 (host-side glue: a roll)."""
+    u = unit.lower()
+    if u in ['pixels', 'pixel', 'p']:
+        pix_shift = -round(shift)
+    elif u in ['fraction', 'fractions', 'f']:
+        pix_shift = -round(shift * img.size(-1))
+    elif u in ['degrees', 'degree', 'd']:
+        pix_shift = -round(shift * img.size(-1) / 360.)
+    elif u in ['radians', 'radian', 'r']:
+        pix_shift = -round(shift * img.size(-1) / (2 * math.pi))
+    else:
+        raise Exception('! Invalid unit in horizontal_shift()')
+    return torch.roll(img, pix_shift, dims=-1)
+
+
+def quantized_rotation(img, factor):
+    """model/cvig_baseline.py:116-128."""
+    if factor % 4 == 1:
+        img = img.transpose(-2, -1).flip(-1)
+    elif factor % 4 == 2:
+        img = img.flip(-2).flip(-1)
+    elif factor % 4 == 3:
+        img = img.transpose(-2, -1).flip(-2)
+    return img
+
+
+class SurfaceResize(object):
+    """model/cvig_baseline.py:208-225 on the GPU."""
+
+    def __init__(self, dataset):
+        self.dataset = dataset
+
+    def __call__(self, data):
+        s = data['surface']
+        if self.dataset == 'cvusa':
+            data['surface'] = torch.repeat_interleave(s, 2, dim=-2)
+        elif self.dataset == 'witw':
+            x = s.to(device) if not s.is_cuda else s
+            squeeze = x.dim() == 3
+            x = ops.resize_bilinear((x.unsqueeze(0) if squeeze else x).contiguous(), (500, 500))
+            data['surface'] = x.squeeze(0) if squeeze else x
+        else:
+            raise Exception('! Invalid dataset type in ' + type(self).__name__ + '().')
+        return data
+
+
+class SurfaceEncoder(nn.Module):
+    """model/cvig_baseline.py:228-279; parameters live in nn.Conv2d / nn.BatchNorm2d children named
+    conv1..7 / bn1..7 (same state-dict keys), the forward runs on the HIP kernels."""
+
+    def __init__(self, orientation=False, bands=3, p=3.):
+        super().__init__()
+        self.orientation, self.bands, self.p = orientation, bands, p
+        self.inputs = self.bands + 2 * self.orientation
+        widths = [self.inputs, 64, 128, 256, 512, 512, 512, 512]
+        for i in range(1, 8):
+            conv = nn.Conv2d(widths[i - 1], widths[i], kernel_size=4, stride=2, padding=0)
+            bn = nn.BatchNorm2d(widths[i], momentum=0.1, affine=True, track_running_stats=True)
+            torch.nn.init.normal_(conv.weight, mean=0.0, std=0.02)     # :255-262
+            torch.nn.init.normal_(conv.bias, mean=0.0, std=0.02)
+            torch.nn.init.normal_(bn.weight, mean=1.0, std=0.02)
+            torch.nn.init.normal_(bn.bias, mean=0.0, std=0.02)
+            setattr(self, 'conv%d' % i, conv)
+            setattr(self, 'bn%d' % i, bn)
+        self._packed = {}
+
+    def _layer(self, i):
+        conv, bn = getattr(self, 'conv%d' % i), getattr(self, 'bn%d' % i)
+        key = (conv.weight._version, conv.bias._version, bn.weight._version, bn.bias._version, bn.running_mean._version,
+               bn.running_var._version, conv.weight.data_ptr())
+        hit = self._packed.get(i)
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                w = conv.weight                                     # [co, ci, 4, 4]
+                co, ci = w.shape[:2]
+                cpad = (4 * ci + 7) // 8 * 8
+                # 4x4/s2 filter -> 3x3 filter over space-to-depth channels (dy*2+dx)*ci+c; tap (kh,kw) in
+                # {1,2}^2 holds W[:, :, 2(kh-1)+dy, 2(kw-1)+dx], row/column 0 of taps stay zero
+                k3 = torch.zeros((co, cpad, 3, 3), dtype=torch.float32, device=w.device)
+                for a in range(2):
+                    for b in range(2):
+                        blk = w[:, :, 2 * a:2 * a + 2, 2 * b:2 * b + 2]                 # [co,ci,dy,dx]
+                        k3[:, :4 * ci, a + 1, b + 1] = blk.permute(0, 2, 3, 1).reshape(co, 4 * ci)
+                packed = ops.PackedConv(k3, conv.bias)
+                scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)               # eval-mode BatchNorm2d
+                shift = bn.bias - bn.running_mean * scale
+            hit = (key, packed, scale.contiguous(), shift.contiguous(), cpad)
+            self._packed[i] = hit
+        return hit[1:]
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise _lib.WitwError('SurfaceEncoder.forward needs a GPU tensor (no CPU fallback)')
+        if self.training:
+            raise _lib.WitwError('cvig_baseline: train-mode BatchNorm / backward are not built; call .eval()')
+        B, _c, H, W = x.shape
+        if min(H, W) < 382:
+            raise _lib.WitwError('cvig_baseline encoder needs sides >= 382 px, got %dx%d' % (H, W))
+        with torch.no_grad():
+            h = ops.space_to_depth2(x.contiguous(), in_nchw=True, normalize=True, cpad=self._layer(1)[3])   # :265-266
+            f = torch.empty((B, 1536), dtype=torch.float32, device=x.device)
+            vh, vw = H, W
+            for i in range(1, 8):
+                packed, scale, shift, _cp = self._layer(i)
+                vh, vw = (vh - 4) // 2 + 1, (vw - 4) // 2 + 1
+                y = ops.conv3x3_fwd(h, packed, relu=False, lrelu_slope=0.2, post_scale=scale, post_shift=shift)
+                if i >= 5:
+                    ops.gem_pool(y, (vh, vw), f, 512 * (i - 5), self.p)                                      # :276-282
+                if i < 7:
+                    h = ops.space_to_depth2(y, valid_hw=(vh, vw), cpad=self._layer(i + 1)[3])
+            return ops.embed_normalize_(f)                                                                 # :283-284
+
+
+class OverheadEncoder(SurfaceEncoder):
+    pass
+
+
+def exhaustive_minibatch_triplet_loss(embed1, embed2, soft_margin=False, alpha=10., margin=1.):
+    """model/cvig_baseline.py:286-315 (forward value; all valid (a,p,n) combinations of the minibatch)."""
+    D = ops.pairwise_sqdist(embed1.contiguous(), embed2.contiguous())
+    return ops.exhaustive_triplet_loss(D, soft_margin, alpha, margin)
+
+
+def ranks(overhead_embed, surface_embed):
+    """model/cvig_baseline.py:454-460: Euclidean distances, rank = #{gallery : d <= d_true}."""
+    D = ops.pairwise_sqdist(overhead_embed.contiguous(), surface_embed.contiguous(), take_sqrt=True)   # [gallery, query]
+    return ops.rank_count(D, 0).cpu().numpy().astype('int64')

@@ -73,7 +73,7 @@ def nchw_to_nhwc(x, cpad):
 
 
 def conv3x3_fwd(x_nhwc, packed, stride_h=1, circular=False, relu=True, pool=False, out_nchw=False, drop_scale=None,
-                gate=None, dilate_h=False, out_h=None):
+                gate=None, dilate_h=False, out_h=None, lrelu_slope=None, post_scale=None, post_shift=None):
     """x_nhwc [B,H,W,Cin_pad] -> NHWC [B,Hy,Wy,Cout] (or NCHW [B,Cout,Hy,Wy])."""
     lib = _lib.load()
     x = _dev_f32(x_nhwc, 'x')
@@ -100,14 +100,20 @@ def conv3x3_fwd(x_nhwc, packed, stride_h=1, circular=False, relu=True, pool=Fals
         gate = _dev_f32(gate, 'gate')
         if tuple(gate.shape) != shape:
             raise _lib.WitwError('gate must have the output shape %s, got %s' % (shape, tuple(gate.shape)))
+    act = 2 if lrelu_slope is not None else int(bool(relu))
+    if post_scale is not None:
+        post_scale, post_shift = _dev_f32(post_scale, 'post_scale'), _dev_f32(post_shift, 'post_shift')
+        if post_scale.numel() != packed.cout or post_shift.numel() != packed.cout:
+            raise _lib.WitwError('post_scale/post_shift must have Cout entries')
     _lib.check(lib.witw_conv3x3_fwd_ex(x.data_ptr(), packed.wpk.data_ptr(), packed.bias.data_ptr(), _p(drop_scale),
-                                       _p(gate), y.data_ptr(), B, H, W, C, packed.cout, stride_h, int(circular),
-                                       int(relu), int(pool), int(out_nchw), int(bool(dilate_h)), _stream()),
-               'witw_conv3x3_fwd_ex')
+                                       _p(gate), _p(post_scale), _p(post_shift), y.data_ptr(), B, H, W, C, packed.cout,
+                                       stride_h, int(circular), act, float(lrelu_slope or 0.), int(pool), int(out_nchw),
+                                       int(bool(dilate_h)), _stream()), 'witw_conv3x3_fwd_ex')
     if prof is not None:
         e1.record()
         variant = (lib.witw_conv3x3_tile_n(packed.cout), stride_h, bool(pool))
         prof.append((variant, 2.0 * packed.cin * packed.cout * 9 * Ho * W * B, e0, e1))
+
     return y
 
 
@@ -337,3 +343,58 @@ def polar_transform(x, h_s=128, w_s=512):
     _lib.check(lib.witw_polar_transform(x.data_ptr(), taps.data_ptr(), wts.data_ptr(), y.data_ptr(), B, C, S, h_s, w_s,
                                         _stream()), 'witw_polar_transform')
     return y
+
+
+# ----------------------------------------------------------------------------- cvig_baseline pieces
+def space_to_depth2(x, valid_hw=None, cpad=None, in_nchw=False, normalize=False):
+    lib = _lib.load()
+    x = _dev_f32(x, 'x')
+    if in_nchw:
+        B, C, Hp, Wp = x.shape
+    else:
+        B, Hp, Wp, C = x.shape
+    H, W = valid_hw if valid_hw is not None else (Hp, Wp)
+    cpad = cpad or (4 * C + 7) // 8 * 8
+    y = torch.empty((B, (H + 1) // 2, (W + 1) // 2, cpad), dtype=torch.float32, device=x.device)
+    _lib.check(lib.witw_space_to_depth2(x.data_ptr(), y.data_ptr(), B, Hp, Wp, H, W, C, cpad, int(in_nchw), int(normalize),
+                                        _stream()), 'witw_space_to_depth2')
+    return y
+
+
+def gem_pool(x_nhwc, valid_hw, out, col0, p=3.):
+    lib = _lib.load()
+    x = _dev_f32(x_nhwc, 'x')
+    B, Hp, Wp, C = x.shape
+    H, W = valid_hw
+    _lib.check(lib.witw_gem_pool(x.data_ptr(), out.data_ptr(), B, Hp, Wp, H, W, C, out.shape[1], col0, float(p), _stream()),
+               'witw_gem_pool')
+    return out
+
+
+def embed_normalize_(f):
+    lib = _lib.load()
+    f = _dev_f32(f, 'f')
+    _lib.check(lib.witw_embed_normalize(f.data_ptr(), f.shape[0], f.shape[1], _stream()), 'witw_embed_normalize')
+    return f
+
+
+def pairwise_sqdist(a, b, take_sqrt=False):
+    lib = _lib.load()
+    a, b = _dev_f32(a, 'a'), _dev_f32(b, 'b')
+    if a.dim() != 2 or b.dim() != 2 or a.shape[1] != b.shape[1]:
+        raise _lib.WitwError('pairwise_sqdist: need [Na,n] and [Nb,n]')
+    D = torch.empty((a.shape[0], b.shape[0]), dtype=torch.float32, device=a.device)
+    _lib.check(lib.witw_pairwise_sqdist(a.data_ptr(), b.data_ptr(), D.data_ptr(), a.shape[0], b.shape[0], a.shape[1],
+                                        int(take_sqrt), _stream()), 'witw_pairwise_sqdist')
+    return D
+
+
+def exhaustive_triplet_loss(D, soft_margin=False, alpha=10., margin=1.):
+    lib = _lib.load()
+    D = _dev_f32(D, 'D')
+    B = D.shape[0]
+    loss = torch.empty((1,), dtype=torch.float32, device=D.device)
+    ws = torch.empty((B,), dtype=torch.float32, device=D.device)
+    _lib.check(lib.witw_exhaustive_triplet_loss(D.data_ptr(), B, int(soft_margin), float(alpha), float(margin),
+                                                loss.data_ptr(), ws.data_ptr(), _stream()), 'witw_exhaustive_triplet_loss')
+    return loss.reshape(())

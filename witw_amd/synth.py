@@ -83,3 +83,25 @@ def dropout_scales(seed, stream, batch, channels, p=0.2):
     g = _rng(seed, 4000 + stream)
     keep = g.random((batch, channels)) >= p
     return (keep.astype(np.float32) / np.float32(1.0 - p)).astype(np.float32)
+
+
+BASELINE_WIDTHS = [3, 64, 128, 256, 512, 512, 512, 512]   # model/cvig_baseline.py:240-253
+
+
+def baseline_params(seed, bands=3):
+    """7 x {w [co,ci,4,4], b, gamma, beta, mean, var} for SurfaceEncoder/OverheadEncoder: the reference's
+    init distributions (model/cvig_baseline.py:255-262) plus non-trivial BatchNorm running statistics."""
+    out = []
+    widths = [bands] + BASELINE_WIDTHS[1:]
+    for i in range(7):
+        g = _rng(seed, 5000 + i)
+        ci, co = widths[i], widths[i + 1]
+        out.append({
+            'w': (g.standard_normal((co, ci, 4, 4), dtype=np.float32) * np.float32(0.02)).astype(np.float32),
+            'b': (g.standard_normal((co,), dtype=np.float32) * np.float32(0.02)).astype(np.float32),
+            'gamma': (np.float32(1.0) + g.standard_normal((co,), dtype=np.float32) * np.float32(0.02)).astype(np.float32),
+            'beta': (g.standard_normal((co,), dtype=np.float32) * np.float32(0.02)).astype(np.float32),
+            'mean': (g.standard_normal((co,), dtype=np.float32) * np.float32(0.05)).astype(np.float32),
+            'var': (np.float32(0.05) + g.random((co,), dtype=np.float32) * np.float32(0.2)).astype(np.float32),
+        })
+    return out
