@@ -7,9 +7,10 @@ One step = one pass of the hot path over one synthetic batch that is already res
   raw ground 3x224x224 + raw overhead 3x512x512 (uint8-valued fp32)
     -> Resize + ImageNormalization + PolarTransform            (A1-A3, model/cvig_fov.py:100-209)
     -> surface / overhead FOV_DSM encoders, eval mode, fp32     (A4-A6, :248-294)
-    -> [N>1] all-gather of both embedding sets over RCCL        (global negatives)
-    -> fused correlation/argmax/crop/chord distance + soft-margin triplet loss over the GLOBAL
-       batch, rank counts for the local queries                 (A7-A10, A12, :297-382, :543-552)
+    -> [N>1] all-gather of the overhead embeddings over RCCL    (global negatives)
+    -> fused correlation/argmax/crop/chord distance of ALL overheads vs the local surfaces, global-batch
+       soft-margin triplet loss (diagonal all-gather + scalar all-reduce), rank counts for the local
+       queries                                                  (A7-A10, A12, :297-382, :543-552)
 Per-GPU batch is fixed (weak scaling); value = global pairs / max-over-ranks step time.
 Prints ONE JSON line on rank 0.
 """
@@ -115,11 +116,8 @@ def main():
             polar = ops.polar_transform(overhead)
             su = surface_encoder(surface)
             ov = overhead_encoder(polar)
-            su_all, ov_all = parallel.all_gather_embeddings(su, ov)
-            ori, d = cvig_fov.match(ov_all, su_all)
-            loss = cvig_fov.triplet_loss(d)
-            ranks = ops.rank_count(d[:, rank * B:(rank + 1) * B].contiguous(), rank * B) if world > 1 \
-                else ops.rank_count(d, 0)
+            ov_all = parallel._all_gather_cat(ov) if world > 1 else ov     # global gallery; surfaces stay local
+            loss, ranks, ori, d = cvig_fov.evaluate_global_batch(ov_all, su, rank * B)
         return loss, ranks, ori
 
     step = train_step if train else infer_step
@@ -173,7 +171,7 @@ def main():
                                ('cvig_fov fov=%d TRAIN step: resize+normalize+polar -> 2x FOV_DSM fwd (Dropout2d) -> match + '
                                 'triplet loss -> backward (dgrad L19-27, wgrad L17-27) -> grad all-reduce -> Adam' % a.fov),
                    'pairs_per_gpu': B, 'global_batch': B * world, 'ground_raw': '3x224x224', 'overhead_raw': '3x512x512',
-                   'parallelism': 'dp%d (embedding all-gather, global-batch loss)' % world},
+                   'parallelism': 'dp%d (overhead-embedding all-gather, global-batch loss from column slabs)' % world},
         'recall': {'top1_pct': float(np.mean(ranks_h <= 1) * 100), 'top5_pct': float(np.mean(ranks_h <= 5) * 100),
                    'N': int(len(ranks_h))},
         'loss': float(loss.item()),

@@ -96,6 +96,10 @@ int witw_rank_count_thresh(const float* distance, const float* threshold, int* r
 /* ---- triplet_loss, model/cvig_fov.py:366-382. workspace: 4*B floats, filled by fwd, read by bwd. */
 int witw_triplet_loss_fwd(const float* distance /*[B,B]*/, int B, float alpha, float* loss /*[1]*/, float* workspace,
                           void* stream);
+/* sharded global batch: un-normalised partial over the column slab D[Bo][Bs] (surfaces col0..col0+Bs of the global
+ * batch), diag[Bo] = global diagonal; sum over ranks / (2*Bo*(Bo-1)) = the loss. workspace: Bo floats. */
+int witw_triplet_loss_slab_fwd(const float* distance, const float* diag, int Bo, int Bs, int col0, float alpha, float* partial,
+                               float* workspace, void* stream);
 int witw_triplet_loss_bwd(const float* distance, const float* workspace, const float* grad_loss /*[1]*/,
                           float* grad_distance /*[B,B]*/, int B, float alpha, void* stream);
 

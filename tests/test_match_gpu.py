@@ -145,3 +145,24 @@ def test_resize_vs_oracle(fov, panorama):
     assert d['surface'].shape == rs.shape and d['overhead'].shape == (3, 256, 256)
     np.testing.assert_allclose(d['surface'].cpu().numpy(), rs.numpy(), rtol=0, atol=2e-4)   # values up to 255
     np.testing.assert_allclose(d['overhead'].cpu().numpy(), ro.numpy(), rtol=0, atol=2e-4)
+
+
+def test_global_batch_slab_evaluation_equals_full():
+    """Column-slab evaluation (what each rank does at N>1) summed over slabs == the single-GPU result."""
+    from witw_amd import cvig_fov, ops
+    B, we = 24, 12
+    ov = torch.from_numpy(synth.embeddings(71, 1, (B, 16, 4, 64))).cuda()
+    su = torch.from_numpy(synth.embeddings(71, 2, (B, 16, 4, we))).cuda()
+    ori, dist = cvig_fov.match(ov, su)
+    loss = cvig_fov.triplet_loss(dist)
+    ranks = ops.rank_count(dist, 0)
+    diag = dist.diagonal().contiguous()
+    total = 0.0
+    for col0 in (0, 8, 16):
+        slab = dist[:, col0:col0 + 8].contiguous()
+        total += ops.triplet_loss_slab_fwd(slab, diag, col0).item()
+        np.testing.assert_array_equal(ops.rank_count(slab, col0).cpu().numpy(), ranks[col0:col0 + 8].cpu().numpy())
+    np.testing.assert_allclose(total / (2. * B * (B - 1)), loss.item(), rtol=1e-5)
+    l1, r1, o1, d1 = cvig_fov.evaluate_global_batch(ov, su, 0)          # world size 1: slab == everything
+    np.testing.assert_allclose(l1.item(), loss.item(), rtol=1e-5)
+    np.testing.assert_array_equal(r1.cpu().numpy(), ranks.cpu().numpy())

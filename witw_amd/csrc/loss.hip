@@ -69,6 +69,31 @@ __global__ void triplet_bwd_kernel(const float* __restrict__ D, const float* __r
     gD[idx] = g * (gloss[0] * alpha / norm);
 }
 
+// Column-slab form for the sharded global batch: this rank holds D[:, col0:col0+Bs] (all overheads x its
+// own surfaces) and the full diagonal. part[i] = sum_j softplus(a(d_{c,c} - d_ij)) + softplus(a(d_ii - d_ij)), c = col0+j.
+__global__ __launch_bounds__(256) void triplet_slab_partials_kernel(const float* __restrict__ D, const float* __restrict__ diag,
+                                                                     float* __restrict__ part, int Bs, int col0, float alpha) {
+    __shared__ float sh[4];
+    const int i = blockIdx.x;
+    const float dii = diag[i];
+    float s = 0.f;
+    for (int j = threadIdx.x; j < Bs; j += 256) {
+        const float d = D[(size_t)i * Bs + j];
+        s += logf(1.f + expf(alpha * (diag[col0 + j] - d)));
+        s += logf(1.f + expf(alpha * (dii - d)));
+    }
+    const float t = block_sum_256(s, sh);
+    if (threadIdx.x == 0) part[i] = t;
+}
+
+__global__ __launch_bounds__(256) void sum_parts_kernel(const float* __restrict__ part, float* __restrict__ out, int n) {
+    __shared__ float sh[4];
+    float s = 0.f;
+    for (int t = threadIdx.x; t < n; t += 256) s += part[t];
+    const float tot = block_sum_256(s, sh);
+    if (threadIdx.x == 0) out[0] = tot;
+}
+
 }  // namespace
 
 extern "C" {
@@ -80,6 +105,21 @@ int witw_triplet_loss_fwd(const float* distance, int B, float alpha, float* loss
     hipLaunchKernelGGL(triplet_partials_kernel, dim3(2 * B), dim3(256), 0, st, distance, workspace, B, alpha);
     hipLaunchKernelGGL(triplet_finish_kernel, dim3(1), dim3(256), 0, st, workspace, loss, B, 2.f * B * (B - 1));
     WITW_CHECK_LAUNCH("triplet_loss_fwd");
+    return WITW_OK;
+}
+
+// Un-normalised partial of the loss over a column slab D[Bo][Bs] = distances of all Bo overheads to the
+// surfaces [col0, col0+Bs) of the global batch; diag[Bo] = the global diagonal. The caller sums the partials of
+// all ranks and divides by 2*Bo*(Bo-1). workspace: Bo floats.
+int witw_triplet_loss_slab_fwd(const float* distance, const float* diag, int Bo, int Bs, int col0, float alpha, float* partial,
+                               float* workspace, void* stream) {
+    WITW_CHECK_ARG(distance && diag && partial && workspace, "triplet_loss_slab_fwd: null pointer");
+    WITW_CHECK_ARG(Bo >= 2 && Bs >= 1 && col0 >= 0 && col0 + Bs <= Bo, "triplet_loss_slab_fwd: bad slab Bo=%d Bs=%d col0=%d", Bo, Bs,
+                   col0);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(triplet_slab_partials_kernel, dim3(Bo), dim3(256), 0, st, distance, diag, workspace, Bs, col0, alpha);
+    hipLaunchKernelGGL(sum_parts_kernel, dim3(1), dim3(256), 0, st, workspace, partial, Bo);
+    WITW_CHECK_LAUNCH("triplet_loss_slab_fwd");
     return WITW_OK;
 }
 

@@ -404,6 +404,23 @@ def sharded_ranks(overhead_shard, surface_all, shard_begin, query_chunk=4096, _m
     return out.cpu().numpy().astype('int64')
 
 
+def evaluate_global_batch(overhead_all, surface_local, col0, alpha=10.):
+    """Inference-time similarity for a minibatch sharded over ranks (no gradients): this rank matches ALL
+    overhead embeddings of the global batch against its OWN surfaces (column slab [B, b]), which is all that
+    the rank counts of its queries and its share of the global-batch loss need; the only exchanges are the
+    diagonal (B floats) and the loss partial. -> (loss scalar tensor, ranks int32 [b], orientation [B,b], distance [B,b])."""
+    from . import parallel
+    ori, dist = ops.match_fwd(overhead_all.contiguous(), surface_local.contiguous())
+    b = surface_local.shape[0]
+    B = overhead_all.shape[0]
+    diag_local = dist[col0:col0 + b].diagonal().contiguous()
+    diag = parallel._all_gather_cat(diag_local) if parallel.world() > 1 else diag_local
+    part = ops.triplet_loss_slab_fwd(dist, diag, col0, alpha)
+    parallel.all_reduce_sum_(part)
+    loss = part / (2. * B * (B - 1))
+    return loss.reshape(()), ops.rank_count(dist, col0), ori, dist
+
+
 def recall_table(ranks_arr):
     """model/cvig_fov.py:553-558."""
     import numpy as np

@@ -249,6 +249,21 @@ def triplet_loss_fwd(distance, alpha=10.):
     return loss, ws
 
 
+def triplet_loss_slab_fwd(distance_slab, diag, col0, alpha=10.):
+    """Un-normalised loss partial over this rank's column slab [Bo,Bs] (see witw_triplet_loss_slab_fwd)."""
+    lib = _lib.load()
+    d = _dev_f32(distance_slab, 'distance_slab')
+    g = _dev_f32(diag, 'diag')
+    Bo, Bs = d.shape
+    if g.numel() != Bo:
+        raise _lib.WitwError('triplet_loss_slab: diag must have one entry per overhead')
+    out = torch.empty((1,), dtype=torch.float32, device=d.device)
+    ws = torch.empty((Bo,), dtype=torch.float32, device=d.device)
+    _lib.check(lib.witw_triplet_loss_slab_fwd(d.data_ptr(), g.data_ptr(), Bo, Bs, col0, float(alpha), out.data_ptr(),
+                                              ws.data_ptr(), _stream()), 'witw_triplet_loss_slab_fwd')
+    return out
+
+
 def triplet_loss_bwd(distance, ws, grad_loss, alpha=10.):
     lib = _lib.load()
     d = _dev_f32(distance, 'distance')
