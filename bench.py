@@ -57,6 +57,8 @@ def main():
     ap.add_argument('--mode', choices=['infer', 'train'], default='infer',
                     help='infer (headline): embedding + similarity; train: the full step of model/cvig_fov.py:444-461')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL); gloo only for 1-GPU self-tests')
+    ap.add_argument('--single-device', action='store_true', help='self-test: put every rank on cuda:0')
     ap.add_argument('--cpu-pairs', type=int, default=8)
     a = ap.parse_args()
 
@@ -66,11 +68,16 @@ def main():
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             sys.exit('bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d' % (a.gpus, a.gpus))
+    if a.single_device:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=device)
+        if a.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)
+        else:
+            dist.init_process_group(a.backend)
 
     from witw_amd import _lib, cvig_fov, ops, synth, parallel
     _lib.check(_lib.load().witw_device_check(local), 'witw_device_check')

@@ -30,7 +30,9 @@ def _all_gather_cat(t):
     t = t.contiguous()
     out = torch.empty((n * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
     if dist.get_backend() == 'gloo':
-        dist.all_gather(list(out.chunk(n, 0)), t)
+        parts = [torch.empty_like(t) for _ in range(n)]
+        dist.all_gather(parts, t)
+        torch.cat(parts, 0, out=out)
     else:
         dist.all_gather_into_tensor(out, t)
     return out
