@@ -90,6 +90,10 @@ int witw_l2_distance(const float* cropped /*[Bo,Bs,n]*/, const float* su /*[Bs,n
 /* ranks[q] = #{o : D[o][q] <= D[q+true_offset][q]} — the loop body of test(), model/cvig_fov.py:550-552 */
 int witw_rank_count(const float* distance /*[Bo,Bs]*/, int* ranks /*[Bs]*/, int Bo, int Bs, int true_offset, void* stream);
 
+/* k smallest distances of every query column of D[Bo][Bs], ordered by (distance, gallery index): values [Bs][k],
+ * indices [Bs][k] (+row_offset: global row number of this shard's first row; -1 pads when Bo < k). 1 <= k <= 32. */
+int witw_topk_smallest(const float* distance, float* values, long long* indices, int Bo, int Bs, int k, long long row_offset,
+                       void* stream);
 /* sharded-gallery form: ranks[q] = #{o in this shard : D[o][q] <= threshold[q]} (threshold = true match's distance) */
 int witw_rank_count_thresh(const float* distance, const float* threshold, int* ranks, int Bo, int Bs, void* stream);
 

@@ -166,3 +166,44 @@ def test_global_batch_slab_evaluation_equals_full():
     l1, r1, o1, d1 = cvig_fov.evaluate_global_batch(ov, su, 0)          # world size 1: slab == everything
     np.testing.assert_allclose(l1.item(), loss.item(), rtol=1e-5)
     np.testing.assert_array_equal(r1.cpu().numpy(), ranks.cpu().numpy())
+
+
+@pytest.mark.parametrize('shape', [(1000, 70, 5), (37, 300, 10), (5, 3, 8), (4096, 130, 32), (300, 64, 1)])
+def test_topk_smallest_bit_exact(shape):
+    from witw_amd import ops
+    bo, bs, k = shape
+    g = np.random.Generator(np.random.Philox(key=[bo, bs]))
+    d = g.integers(0, 50, size=(bo, bs)).astype(np.float32) / 8          # many exact ties
+    vals, idx = ops.topk_smallest(torch.from_numpy(d).cuda(), k)
+    order = np.lexsort((np.broadcast_to(np.arange(bo)[:, None], d.shape), d), axis=0)   # (distance, index) ascending
+    kk = min(k, bo)
+    np.testing.assert_array_equal(idx.cpu().numpy()[:, :kk], order[:kk].T)
+    np.testing.assert_array_equal(vals.cpu().numpy()[:, :kk], np.take_along_axis(d, order[:kk], 0).T)
+    if bo < k:
+        assert np.all(idx.cpu().numpy()[:, bo:] == -1)
+
+
+def test_retrieve_topk_matches_oracle_and_shards():
+    from witw_amd import cvig_fov, ops
+    n, we, k = 60, 12, 5
+    ov = torch.from_numpy(synth.embeddings(81, 1, (n, 16, 4, 64)))
+    su = torch.stack([torch.roll(ov[i], -int(i % 64), dims=2)[:, :, :we] for i in range(n)]) \
+        + 5.0 * torch.from_numpy(synth.embeddings(81, 2, (n, 16, 4, we)))
+    _, d_ref = O.match_fused(ov, su)
+    v, i = cvig_fov.retrieve_topk(ov.cuda(), su.contiguous().cuda(), k=k, query_chunk=25)
+    ref_i = torch.argsort(d_ref, dim=0, stable=True)[:k].t()
+    gaps = torch.sort(d_ref, dim=0).values
+    safe = (gaps[1:k + 1] - gaps[:k]).min(0).values > 1e-5           # queries whose top-(k+1) is free of near-ties
+    assert safe.float().mean() > 0.9
+    assert torch.equal(i.cpu()[safe], ref_i[safe])
+    np.testing.assert_allclose(v.cpu().numpy(), torch.sort(d_ref, dim=0).values[:k].t().numpy(), atol=1e-5)
+    # two shards merged by hand == unsharded
+    _, dist = cvig_fov.match(ov.cuda(), su.contiguous().cuda())
+    v1, i1 = ops.topk_smallest(dist[:23].contiguous(), k, 0)
+    v2, i2 = ops.topk_smallest(dist[23:].contiguous(), k, 23)
+    cv = torch.cat((v1.t(), v2.t())).contiguous()
+    ci = torch.cat((i1.t(), i2.t()))
+    order = torch.argsort(ci, dim=0, stable=True)
+    vm, pm = ops.topk_smallest(torch.gather(cv, 0, order).contiguous(), k)
+    im = torch.gather(torch.gather(ci, 0, order).t(), 1, pm)
+    assert torch.equal(im, i) and torch.equal(vm, v)

@@ -483,3 +483,91 @@ int witw_rank_count_thresh(const float* distance, const float* threshold, int* r
 }
 
 }  // extern "C"
+
+// ---- top-k smallest distances per query (retrieval indices, BASELINE config C5 / north_star "top-k").
+// D is [Bo][Bs] (gallery rows x queries). A block covers 64 consecutive queries (lanes -> coalesced 256-B
+// row reads) and its 4 waves split the gallery rows; every thread keeps a sorted K-list in registers, the 4
+// lists of a query are merged through LDS. Order: (distance, gallery index) ascending, so ties resolve to the
+// lower index and the result is deterministic and independent of the launch shape.
+namespace {
+
+template <int K>
+__global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ D, float* __restrict__ vals,
+                                                   long long* __restrict__ idx, int Bo, int Bs, int k, long long row_offset) {
+    __shared__ float sv[4][K][64];
+    __shared__ int si[4][K][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = blockIdx.x * 64 + lane;
+    float bv[K];
+    int bi[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        bv[j] = __builtin_inff();
+        bi[j] = 0x7fffffff;
+    }
+    if (q < Bs) {
+        for (int o = wave; o < Bo; o += 4) {
+            float d = D[(size_t)o * Bs + q];
+            if (d != d) d = __builtin_inff();          // NaN sorts last
+            if (d < bv[K - 1] || (d == bv[K - 1] && o < bi[K - 1])) {
+                float cv = d;
+                int ci = o;
+#pragma unroll
+                for (int j = 0; j < K; ++j) {          // insertion into the sorted list
+                    const bool lt = cv < bv[j] || (cv == bv[j] && ci < bi[j]);
+                    const float tv = lt ? bv[j] : cv;
+                    const int ti = lt ? bi[j] : ci;
+                    bv[j] = lt ? cv : bv[j];
+                    bi[j] = lt ? ci : bi[j];
+                    cv = tv;
+                    ci = ti;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        sv[wave][j][lane] = bv[j];
+        si[wave][j][lane] = bi[j];
+    }
+    __syncthreads();
+    if (wave == 0 && q < Bs) {                        // 4-way merge of sorted lists, one query per lane
+        int h[4] = {0, 0, 0, 0};
+        for (int out = 0; out < k; ++out) {
+            int best = -1;
+            float v = __builtin_inff();
+            int ix = 0x7fffffff;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                if (h[w] < K) {
+                    const float cv = sv[w][h[w]][lane];
+                    const int ci = si[w][h[w]][lane];
+                    if (best < 0 || cv < v || (cv == v && ci < ix)) { best = w; v = cv; ix = ci; }
+                }
+            }
+#pragma unroll
+            for (int w = 0; w < 4; ++w) h[w] += (w == best) ? 1 : 0;
+            vals[(size_t)q * k + out] = v;
+            idx[(size_t)q * k + out] = (ix == 0x7fffffff) ? -1 : (long long)ix + row_offset;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int witw_topk_smallest(const float* distance, float* values, long long* indices, int Bo, int Bs, int k,
+                                  long long row_offset, void* stream) {
+    WITW_CHECK_ARG(distance && values && indices, "topk_smallest: null pointer");
+    WITW_CHECK_ARG(Bo > 0 && Bs > 0, "topk_smallest: bad shape Bo=%d Bs=%d", Bo, Bs);
+    WITW_CHECK_ARG(k >= 1 && k <= 32, "topk_smallest: k=%d outside [1,32]", k);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(cdiv(Bs, 64));
+    if (k <= 8)
+        hipLaunchKernelGGL((topk_kernel<8>), grid, dim3(256), 0, st, distance, values, indices, Bo, Bs, k, row_offset);
+    else if (k <= 16)
+        hipLaunchKernelGGL((topk_kernel<16>), grid, dim3(256), 0, st, distance, values, indices, Bo, Bs, k, row_offset);
+    else
+        hipLaunchKernelGGL((topk_kernel<32>), grid, dim3(256), 0, st, distance, values, indices, Bo, Bs, k, row_offset);
+    WITW_CHECK_LAUNCH("topk_smallest");
+    return WITW_OK;
+}

@@ -404,6 +404,38 @@ def sharded_ranks(overhead_shard, surface_all, shard_begin, query_chunk=4096, _m
     return out.cpu().numpy().astype('int64')
 
 
+def retrieve_topk(overhead_shard, surface_all, k=10, shard_begin=0, query_chunk=4096):
+    """Top-k retrieval (BASELINE config C5): for every query the k nearest gallery rows by the fused
+    orientation-search chord distance, ordered by (distance, gallery index). With the gallery sharded over
+    ranks each rank ranks its shard, the [N,k] candidate lists are all-gathered and merged by the same kernel.
+    -> (distances f32 [N,k], gallery indices int64 [N,k]) on the device, identical on every rank."""
+    from . import parallel
+    n_q = surface_all.shape[0]
+    vals, idxs = [], []
+    for q0 in range(0, n_q, query_chunk):
+        q1 = min(n_q, q0 + query_chunk)
+        _, dist = ops.match_fwd(overhead_shard.contiguous(), surface_all[q0:q1].contiguous())
+        v, i = ops.topk_smallest(dist, k, shard_begin)
+        vals.append(v)
+        idxs.append(i)
+    v, i = torch.cat(vals), torch.cat(idxs)
+    if parallel.world() > 1:
+        w = parallel.world()
+        v_all = parallel._all_gather_cat(v.unsqueeze(0))            # [w, N, k]
+        i_all = parallel._all_gather_cat(i.unsqueeze(0))
+        cand_v = v_all.permute(0, 2, 1).reshape(w * k, n_q).contiguous()   # candidates as a [w*k, N] "distance matrix"
+        cand_i = i_all.permute(0, 2, 1).reshape(w * k, n_q)
+        cand_v = torch.where(cand_i < 0, torch.full_like(cand_v, float('inf')), cand_v)
+        # merge on (distance, global index): order candidate rows by global index first so that the kernel's
+        # row-number tie-break equals the gallery-index tie-break
+        order = torch.argsort(torch.where(cand_i < 0, torch.full_like(cand_i, 2 ** 62), cand_i), dim=0, stable=True)
+        cand_v = torch.gather(cand_v, 0, order).contiguous()
+        cand_i = torch.gather(cand_i, 0, order)
+        v, pos = ops.topk_smallest(cand_v, k)
+        i = torch.gather(cand_i.t(), 1, pos.clamp(min=0))
+    return v, i
+
+
 def evaluate_global_batch(overhead_all, surface_local, col0, alpha=10.):
     """Inference-time similarity for a minibatch sharded over ranks (no gradients): this rank matches ALL
     overhead embeddings of the global batch against its OWN surfaces (column slab [B, b]), which is all that

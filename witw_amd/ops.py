@@ -221,6 +221,19 @@ def rank_count(distance, true_offset=0):
     return ranks
 
 
+def topk_smallest(distance, k, row_offset=0):
+    """Per query column of D [Bo,Bs]: the k smallest distances and their gallery rows, (distance, index) ascending.
+    -> (values f32 [Bs,k], indices int64 [Bs,k])."""
+    lib = _lib.load()
+    d = _dev_f32(distance, 'distance')
+    Bo, Bs = d.shape
+    vals = torch.empty((Bs, k), dtype=torch.float32, device=d.device)
+    idx = torch.empty((Bs, k), dtype=torch.int64, device=d.device)
+    _lib.check(lib.witw_topk_smallest(d.data_ptr(), vals.data_ptr(), idx.data_ptr(), Bo, Bs, int(k), int(row_offset),
+                                      _stream()), 'witw_topk_smallest')
+    return vals, idx
+
+
 def rank_count_thresh(distance, threshold):
     """ranks[q] = #{o : D[o,q] <= threshold[q]} over the rows present (one gallery shard)."""
     lib = _lib.load()
