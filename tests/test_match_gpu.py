@@ -52,7 +52,7 @@ def test_match_tie_break_first_index():
     assert torch.equal(torch.diagonal(ref), torch.full((3,), 5, dtype=torch.int64))
 
 
-@pytest.mark.parametrize('shape', [(1, 1, 64), (130, 257, 64), (3, 200, 1), (70, 5, 63)])
+@pytest.mark.parametrize('shape', [(1, 1, 64), (130, 257, 64), (3, 200, 1), (70, 5, 63), (1101, 130, 64), (1030, 129, 63)])
 def test_match_ragged_shapes_vs_oracle(shape):
     from witw_amd import cvig_fov
     bo, bs, we = shape

@@ -149,6 +149,169 @@ __global__ __launch_bounds__(NT) void match_kernel(MatchArgs p) {
         }
 }
 
+
+// ---- pipelined variant for full-width surfaces (We in {63,64}: 32 MFMA k-steps per embedding row), the
+// retrieval shape (BASELINE config C5). Same tiling as match_kernel<2> (4 overheads x 128 surfaces per
+// workgroup) but: staging uses buffer loads (row offset in a scalar, out-of-range rows/columns read 0: no
+// per-load VALU next to the f32 MFMAs), the 32 k-steps are fully unrolled with the operands of step k+1
+// read during step k, every LDS / global instruction is issued alone between two MFMAs
+// (sched_group_barrier), and the per-row barrier sits in front of the last k-step so the next row's first
+// operands arrive behind it.
+typedef unsigned int u32x1;
+
+__global__ __launch_bounds__(NT, 2) void match_kernel_w64(MatchArgs p) {
+    constexpr int OPW = 2, MO = 4, KS = 32;
+    constexpr int SU_F = MS * SUS;
+    constexpr int OV_F = MO * 128;
+    constexpr unsigned OOR = 0x80000000u;
+    __shared__ float smem[2 * (SU_F + OV_F)];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hk = lane >> 5;
+    const int s0 = blockIdx.x * MS;
+    const int o0 = blockIdx.y * MO;
+    const int We = p.We;
+    const int wm = wave >> 1, wo = wave & 1;
+
+    // staging: lane <-> k within a row, (wave + 4*i) <-> surface row; offsets relative to the tile's first row
+    const int rows_here = min(MS, p.Bs - s0);
+    const unsigned su_bytes = (unsigned)rows_here * 64u * We * 4u;
+    __amdgpu_buffer_rsrc_t su_rs =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(p.su + (size_t)s0 * 64 * We), 0, su_bytes, 0x00020000);
+    const int ov_here = min(MO, p.Bo - o0);
+    __amdgpu_buffer_rsrc_t ov_rs =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(p.ov + (size_t)o0 * 4096), 0, (unsigned)ov_here * 4096u * 4u, 0x00020000);
+    unsigned suoff[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const int row = wave + 4 * i;
+        suoff[i] = (lane < We && row < rows_here) ? ((unsigned)row * 64u * We + lane) * 4u : OOR;
+    }
+    const int ovo = tid >> 6, ovw = tid & 63;
+    const unsigned ovoff = (ovo < ov_here) ? ((unsigned)ovo * 4096u + ovw) * 4u : OOR;
+
+    float rsu[32];
+    float rov;
+    auto load_stage = [&](int r) {
+        const unsigned srow = (unsigned)r * We * 4u;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) rsu[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(su_rs, suoff[i], srow, 0));
+        rov = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ov_rs, ovoff, (unsigned)r * 256u, 0));
+    };
+    auto store_stage = [&](int buf) {
+        float* su_s = smem + buf * (SU_F + OV_F);
+        float* ov_s = su_s + SU_F;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) su_s[(wave + 4 * i) * SUS + lane] = rsu[i];
+        ov_s[ovo * 128 + ovw] = rov;
+        ov_s[ovo * 128 + 64 + ovw] = rov;
+    };
+
+    f32x16 acc[2][OPW][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < OPW; ++b)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][c][r] = 0.f;
+
+    const int arow0 = (64 * wm + l31) * SUS + hk;
+    const int arow1 = arow0 + 32 * SUS;
+    const int bcol = OPW * wo * 128 + l31 + hk;
+    float fa[2][2], fb[2][OPW][2];
+    auto read_frags = [&](int set, const float* su_s, const float* ov_s, int k) {
+        fa[set][0] = su_s[arow0 + 2 * k];
+        fa[set][1] = su_s[arow1 + 2 * k];
+#pragma unroll
+        for (int o = 0; o < OPW; ++o) {
+            fb[set][o][0] = ov_s[bcol + o * 128 + 2 * k];
+            fb[set][o][1] = ov_s[bcol + o * 128 + 2 * k + 32];
+        }
+    };
+    auto mfma_step = [&](int set) {
+#pragma unroll
+        for (int o = 0; o < OPW; ++o)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                acc[0][o][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][0], fb[set][o][n], acc[0][o][n], 0, 0, 0);
+                acc[1][o][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][1], fb[set][o][n], acc[1][o][n], 0, 0, 0);
+            }
+    };
+
+    load_stage(0);
+    store_stage(0);
+    __syncthreads();
+    read_frags(0, smem, smem + SU_F, 0);
+
+    for (int r = 0; r < 64; ++r) {
+        const int cur = r & 1;
+        const int rn = (r + 1 < 64) ? r + 1 : r;      // the last row restages itself (never read)
+        const float* su_s = smem + cur * (SU_F + OV_F);
+        const float* ov_s = su_s + SU_F;
+        const float* su_n = smem + (cur ^ 1) * (SU_F + OV_F);
+        load_stage(rn);
+#pragma unroll
+        for (int k = 0; k < KS - 1; ++k) {
+            read_frags((k + 1) & 1, su_s, ov_s, k + 1);
+            if (k == 17) store_stage(cur ^ 1);
+            mfma_step(k & 1);
+            // 8 MFMAs per k-step: 6 operand reads + (k < 17: 2 global loads | k == 17: the 34 LDS writes)
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            if (k < 17) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            } else {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            }
+        }
+        __syncthreads();
+        read_frags(0, su_n, su_n + SU_F, 0);
+        mfma_step(1);                                 // k-step 31 (set (KS-1)&1 == 1)
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+    }
+
+    // ---- epilogue: identical to match_kernel
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int o = 0; o < OPW; ++o) {
+            const int og = o0 + OPW * wo + o;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[mt][o][0][r];
+                int idx = l31;
+                const float v1 = acc[mt][o][1][r];
+                if (v1 > v) { v = v1; idx = 32 + l31; }
+#pragma unroll
+                for (int d = 1; d < 32; d <<= 1) {
+                    const float vo = __shfl_xor(v, d, 64);
+                    const int io = __shfl_xor(idx, d, 64);
+                    if (vo > v || (vo == v && io < idx)) { v = vo; idx = io; }
+                }
+                const int srow = s0 + 64 * wm + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hk;
+                if (l31 == r && og < p.Bo && srow < p.Bs) {
+                    const size_t off = (size_t)og * p.Bs + srow;
+                    if (p.orientation) p.orientation[off] = idx;
+                    if (p.score) p.score[off] = v;
+                    if (p.distance) p.distance[off] = 2.f * (1.f - v / (p.wn[(size_t)og * 64 + idx] * p.sn[srow]));
+                }
+            }
+        }
+}
+
 // wn[o][shift] = sqrt(sum_{ch} sum_{k<We} ov[o][ch][(k+shift)%64]^2): the L2 norm of the window
 // that crop_overhead would cut at that shift (model/cvig_fov.py:335-341,350-351).
 __global__ __launch_bounds__(256) void window_norm_kernel(const float* __restrict__ ov, float* __restrict__ wn, int We) {
@@ -403,7 +566,9 @@ int witw_match_fwd(const float* ov, const float* su, int Bo, int Bs, int We, lon
     a.Bo = Bo; a.Bs = Bs; a.We = We;
     const int gx = cdiv(Bs, MS);
     // small problems: 2 overheads per block (more blocks); large: 4 per block (less staging per FLOP)
-    if ((long long)gx * cdiv(Bo, 4) >= 512) {
+    if ((long long)gx * cdiv(Bo, 4) >= 256 && We >= 63) {
+        hipLaunchKernelGGL(match_kernel_w64, dim3(gx, cdiv(Bo, 4)), dim3(NT), 0, st, a);
+    } else if ((long long)gx * cdiv(Bo, 4) >= 512) {
         hipLaunchKernelGGL((match_kernel<2>), dim3(gx, cdiv(Bo, 4)), dim3(NT), 0, st, a);
     } else {
         hipLaunchKernelGGL((match_kernel<1>), dim3(gx, cdiv(Bo, 2)), dim3(NT), 0, st, a);
