@@ -85,9 +85,19 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_nhwc_f32_kernel(ConvArgs p) 
     const int n0 = ntile * TN;
     const int nkc = p.Cin >> 3;
 
-    // ---- per-thread staging descriptors (constant over the K loop)
-    const float* gin[NIN];
-    int gstep[NIN];   // floats to advance per K chunk (0 for padded slots, which stay on the zero source)
+    // ---- staging through buffer loads: one descriptor per image / per weight tile built from scalars, the
+    // per-thread byte offset is fixed for the whole K loop and the K-chunk advance rides in the scalar
+    // offset, so a load costs no VALU instruction next to the f32 MFMAs. Padded halo slots (rows outside the
+    // image, zero-padded columns) carry an out-of-range offset and read 0.
+    constexpr unsigned OOR = 0x80000000u;
+    const int Hp = p.dil_h ? (p.H - 1) / 2 + 1 : p.H;          // physical rows of the input
+    const size_t img_floats = (size_t)Hp * p.W * p.Cin;
+    __amdgpu_buffer_rsrc_t in_rs =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)b * img_floats), 0, (unsigned)(img_floats * 4), 0x00020000);
+    const unsigned wtile_bytes = (unsigned)nkc * W_F4 * 16u;
+    __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(reinterpret_cast<const f32x4*>(p.wpk) + (size_t)ntile * nkc * W_F4), 0, wtile_bytes, 0x00020000);
+    unsigned gin[NIN];
 #pragma unroll
     for (int i = 0; i < NIN; ++i) {
         const int s = tid + i * NTHREADS;
@@ -96,11 +106,10 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_nhwc_f32_kernel(ConvArgs p) 
         const int gr = oy0 * SH - 1 + r;
         int gc = ox0 - 1 + c;
         bool ok = (s < IN_F4) && gr >= 0 && gr < p.H;
-        int grp = gr, Hp = p.H;       // physical row / physical height
+        int grp = gr;                 // physical row
         if (p.dil_h) {
             ok = ok && (gr & 1) == 0;
             grp = gr >> 1;
-            Hp = (p.H - 1) / 2 + 1;
         }
         if (p.circ) {
             gc %= p.W;
@@ -108,24 +117,21 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_nhwc_f32_kernel(ConvArgs p) 
         } else {
             ok = ok && gc >= 0 && gc < p.W;
         }
-        gstep[i] = ok ? 8 : 0;
-        gin[i] = ok ? p.x + (((size_t)((size_t)b * Hp + grp) * p.W + gc) * p.Cin + q * 4)
-                    : reinterpret_cast<const float*>(g_zero_f4);
+        gin[i] = ok ? (unsigned)((((size_t)grp * p.W + gc) * p.Cin + q * 4) * 4) : OOR;
     }
-    const f32x4* gw = reinterpret_cast<const f32x4*>(p.wpk) + (size_t)ntile * nkc * W_F4 + tid;
+    const unsigned gwoff = (unsigned)tid * 16u;
 
-    // Staging is branch-free so that the whole K-chunk body is ONE scheduling region: loads of
-    // padded slots load from a zero source, out-of-tile slots are sent to the dummy LDS slot.
+    // Staging is branch-free so that the whole K-chunk body is ONE scheduling region; out-of-tile
+    // slots are sent to the dummy LDS slot.
     f32x4 rin[NIN], rw[NWT];
     auto load_stage = [&](int kc) {
 #pragma unroll
-        for (int i = 0; i < NIN; ++i) rin[i] = *reinterpret_cast<const f32x4*>(gin[i] + (size_t)kc * gstep[i]);
-        const f32x4* w = gw + (size_t)kc * W_F4;
+        for (int i = 0; i < NIN; ++i)
+            rin[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rs, gin[i], (unsigned)kc * 32u, 0));
+        const unsigned wbase = (unsigned)kc * W_F4 * 16u;
 #pragma unroll
-        for (int i = 0; i < NWT; ++i) {
-            const int s = tid + i * NTHREADS;
-            rw[i] = w[(NWT * NTHREADS == W_F4 || s < W_F4) ? i * NTHREADS : 0];
-        }
+        for (int i = 0; i < NWT; ++i)   // slots past the slab read past the tile (still inside wpk or range-checked to 0)
+            rw[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rs, gwoff, wbase + (unsigned)i * 4096u, 0));
     };
     auto store_stage = [&](int buf) {
         f32x4* in_s = smem + buf * STAGE_F4;
@@ -247,7 +253,9 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_nhwc_f32_kernel(ConvArgs p) 
         const f32x4* in_n = smem + (cur ^ 1) * STAGE_F4;
         // tap 0 (+ global loads of the next chunk)
         read_frags(1, in_s, w_s, 1);
+#ifndef WITW_DIAG_NOSTAGE
         load_stage(kn);
+#endif
         mfma_tap(0);
         SG_HEAVY_TAP(0x020, NIN + NWT);
 #pragma unroll
@@ -258,7 +266,9 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_nhwc_f32_kernel(ConvArgs p) 
         }
         // tap 4 (+ LDS writes of the next chunk)
         read_frags(1, in_s, w_s, 5);
+#ifndef WITW_DIAG_NOSTAGE
         store_stage(cur ^ 1);
+#endif
         mfma_tap(0);
         SG_HEAVY_TAP(0x200, NIN + NWT);
 #pragma unroll
@@ -267,7 +277,9 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_nhwc_f32_kernel(ConvArgs p) 
             mfma_tap(tap & 1);
             SG_PLAIN_TAP();
         }
+#ifndef WITW_DIAG_NOBARRIER
         __syncthreads();
+#endif
         // tap 8, behind which the first fragments of the next chunk arrive
         read_frags(1, in_n, in_n + IN_F4, 0);
         mfma_tap(0);
