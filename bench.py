@@ -28,7 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 MFMA
-DOMINANT = (128, 1, False)     # conv3x3_nhwc_f32_kernel<128,1,false>: layers 5,10,12,17,19,21
+DOMINANT = (128, 1, False, 8)  # conv3x3_nhwc_f32_kernel<128,1,false,8>: layers 5,10,12,17,19,21 at B=128
 
 
 def make_inputs(cvig_fov, ops, synth, batch, fov, seed, device):
@@ -165,7 +165,7 @@ def main():
     tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get('conv3x3_nhwc_f32_kernel<128,1,false>_bytes_per_launch_B%d' % B)
+            traffic = json.load(open(tpath)).get('conv3x3_nhwc_f32_kernel<128,1,false,8>_bytes_per_launch_B%d' % B)
         except Exception:
             traffic = None
 
@@ -182,7 +182,7 @@ def main():
         'recall': {'top1_pct': float(np.mean(ranks_h <= 1) * 100), 'top5_pct': float(np.mean(ranks_h <= 5) * 100),
                    'N': int(len(ranks_h))},
         'loss': float(loss.item()),
-        'roofline': {'bound': 'mfma', 'kernel': 'conv3x3_nhwc_f32_kernel<128,1,false>', 'achieved': round(achieved, 2),
+        'roofline': {'bound': 'mfma', 'kernel': 'conv3x3_nhwc_f32_kernel<128,1,false,8>', 'achieved': round(achieved, 2),
                      'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
                      'traffic': traffic, 'launches': len(dom), 'avg_launch_ms': round(dom_ms, 4),
                      'avg_launch_gflop': round(dom_fl / 1e9, 2), 'all_conv_launches_tflops': round(conv_tf, 2)},

@@ -32,6 +32,9 @@ int witw_device_check(int device);    /* 0 iff `device` is a gfx950 part */
 
 /* output-channel tile the kernel will use for `cout` (64 or 128) */
 int witw_conv3x3_tile_n(int cout);
+/* waves per workgroup (4 or 8) chosen for a layer shape; with tile_n, stride and pool it names the kernel
+ * instantiation conv3x3_nhwc_f32_kernel<tile_n,stride_h,pool,waves> seen in profiles */
+int witw_conv3x3_workgroup_waves(int B, int H, int W, int Cout, int stride_h);
 /* number of floats of the packed filter / of the zero-padded bias for a (cout, cin) layer */
 long long witw_conv3x3_packed_floats(int cout, int cin);
 int witw_conv3x3_bias_floats(int cout);

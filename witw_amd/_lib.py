@@ -17,6 +17,7 @@ SIGNATURES = {
     'witw_version': (c_int, []),
     'witw_device_check': (c_int, [c_int]),
     'witw_conv3x3_tile_n': (c_int, [c_int]),
+    'witw_conv3x3_workgroup_waves': (c_int, [c_int] * 5),
     'witw_conv3x3_packed_floats': (c_longlong, [c_int, c_int]),
     'witw_conv3x3_bias_floats': (c_int, [c_int]),
     'witw_conv3x3_pack_weights': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

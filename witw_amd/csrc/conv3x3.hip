@@ -6,8 +6,8 @@
 // as ONE kernel per conv layer: padding is a halo-load policy (zero rows, zero or
 // wrapped columns), bias / dropout-scale / ReLU / 2x2 max-pool live in the epilogue.
 //
-// Tiling (per 256-thread workgroup = 4 waves, one per SIMD):
-//   output tile  TH x TW = 4 x 64 conv-output pixels  (8 MFMA M-tiles of 32 columns)
+// Tiling (per workgroup of NW = 4 or 8 waves; 8 = two waves per SIMD sharing one weight slab):
+//   output tile  TH x TW = NW x 64 conv-output pixels  (2*NW MFMA M-tiles of 32 columns)
 //   x TN output channels (64 or 128)                  (2 or 4 MFMA N-tiles of 32)
 //   K loop over input channels in chunks of 8 (two "quads" of 4 channels); per chunk
 //   the (TH-1)*SH+3 x 66 input halo tile and the 9x8xTN weight slab are staged in LDS
@@ -17,13 +17,12 @@
 // yields the operands of 4 MFMA k-steps: MFMA step j takes channel j of quad 0 from
 // lanes 0-31 and channel j of quad 1 from lanes 32-63 (A and B agree on that order).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
-constexpr int TH = 4;
 constexpr int TW = 64;
 constexpr int IW = TW + 2;
-constexpr int NTHREADS = 256;
 
 // Source of every padded (out-of-image) halo slot: loading zeros from memory keeps the staging
 // path free of selects, which the compiler would otherwise pin right behind each load (vmcnt(0)).
@@ -43,22 +42,28 @@ struct ConvArgs {
     int Ho, Wo;             // conv output size (before pooling)
     int tiles_x, tiles_y;
     int circ, relu, out_nchw;
+    int force_nw;           // 0 = choose, 4 / 8 = force the workgroup shape (tuning aid)
     int dil_h;              // 1: input rows are zero-interleaved (row 2i = physical row i): dgrad of a stride-(2,1) conv
 #ifdef WITW_STAMPS
     unsigned long long* stamps;   // diagnostic build only (tools/conv_stamps.cpp)
 #endif
 };
 
-template <int TN, int SH, bool POOL>
-__global__ __launch_bounds__(NTHREADS) void conv3x3_nhwc_f32_kernel(ConvArgs p) {
+// NW = waves per workgroup (4: 4x64-pixel tile, one wave per SIMD; 8: 8x64-pixel tile, two waves per SIMD
+// sharing one weight slab: 40 % less staging and half the barriers per MFMA, used when the layer is tall
+// and the grid large enough).
+template <int TN, int SH, bool POOL, int NW>
+__global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_f32_kernel(ConvArgs p) {
+    constexpr int TH = NW;
+    constexpr int NTHREADS = 64 * NW;
     constexpr int IH = (TH - 1) * SH + 3;
     constexpr int IN_F4 = 2 * IH * IW;          // float4 slots of one input stage
     constexpr int W_F4 = 9 * 2 * TN;            // float4 slots of one weight stage
     constexpr int STAGE_F4 = IN_F4 + W_F4;
     constexpr int NIN = (IN_F4 + NTHREADS - 1) / NTHREADS;
     constexpr int NWT = (W_F4 + NTHREADS - 1) / NTHREADS;
-    constexpr int WGM = (TN == 128) ? 2 : 4;    // waves along M
-    constexpr int WM = 8 / WGM;                 // M-tiles per wave
+    constexpr int WGM = (TN == 128) ? NW / 2 : NW;   // waves along M
+    constexpr int WM = (2 * TH) / WGM;               // M-tiles per wave (4 at TN=128, 2 at TN=64)
     constexpr int WN = 2;                       // N-tiles per wave (64 channels)
 
     __shared__ f32x4 smem[2 * STAGE_F4 + 1];   // +1: dummy slot that absorbs out-of-tile staging stores
@@ -131,7 +136,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_nhwc_f32_kernel(ConvArgs p) 
         const unsigned wbase = (unsigned)kc * W_F4 * 16u;
 #pragma unroll
         for (int i = 0; i < NWT; ++i)   // slots past the slab read past the tile (still inside wpk or range-checked to 0)
-            rw[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rs, gwoff, wbase + (unsigned)i * 4096u, 0));
+            rw[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rs, gwoff, wbase + (unsigned)i * (NTHREADS * 16u), 0));
     };
     auto store_stage = [&](int buf) {
         f32x4* in_s = smem + buf * STAGE_F4;
@@ -151,12 +156,12 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_nhwc_f32_kernel(ConvArgs p) 
     };
 
     // ---- wave -> M-tiles / N-tiles
-    const int wm = (WGM == 2) ? (wave >> 1) : wave;
-    const int wn = (WGM == 2) ? (wave & 1) : 0;
+    const int wm = (TN == 128) ? (wave >> 1) : wave;
+    const int wn = (TN == 128) ? (wave & 1) : 0;
     int trow[WM], tcol[WM];  // tile row in [0,TH), tile column base in {0,32}
 #pragma unroll
     for (int mt = 0; mt < WM; ++mt) {
-        if (WGM == 2) {
+        if (TN == 128) {
             trow[mt] = 2 * wm + (mt >> 1);
             tcol[mt] = 32 * (mt & 1);
         } else {
@@ -382,8 +387,8 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_nhwc_f32_kernel(ConvArgs p) 
         // rows (2a, 2a+1) of one column half sit in M-tiles (mtA, mtB) of this wave
 #pragma unroll
         for (int pr = 0; pr < WM / 2; ++pr) {
-            const int mtA = (WGM == 2) ? (pr & 1) : 0;       // WGM==2: tiles {0,1}=row0 halves, {2,3}=row1
-            const int mtB = (WGM == 2) ? (2 + (pr & 1)) : 1;
+            const int mtA = (TN == 128) ? (pr & 1) : 0;       // TN==128: tiles {0,1}=row0 halves, {2,3}=row1
+            const int mtB = (TN == 128) ? (2 + (pr & 1)) : 1;
 #pragma unroll
             for (int nt = 0; nt < WN; ++nt)
 #pragma unroll
@@ -464,17 +469,37 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, float* __restri
     y[idx] = (c < C) ? x[(b * C + c) * hw + r] : 0.f;
 }
 
-template <int TN, int SH, bool POOL>
-int launch_conv(const ConvArgs& a, hipStream_t st) {
+template <int TN, int SH, bool POOL, int NW>
+int launch_conv_nw(ConvArgs a, hipStream_t st) {
+    a.tiles_y = cdiv(a.Ho, NW);
     const int n_tiles = cdiv(a.Cout, TN);
     const long long grid = (long long)n_tiles * a.B * a.tiles_x * a.tiles_y;
     if (grid <= 0 || grid > 0x7fffffffLL) {
         witw_set_error("conv3x3: grid %lld out of range", grid);
         return WITW_ERR_INVALID;
     }
-    hipLaunchKernelGGL((conv3x3_nhwc_f32_kernel<TN, SH, POOL>), dim3((unsigned)grid), dim3(NTHREADS), 0, st, a);
+    hipLaunchKernelGGL((conv3x3_nhwc_f32_kernel<TN, SH, POOL, NW>), dim3((unsigned)grid), dim3(64 * NW), 0, st, a);
     WITW_CHECK_LAUNCH("conv3x3_nhwc_f32");
     return WITW_OK;
+}
+
+// 8-wave workgroups (8-row tiles) when no rows are wasted and >= 2 workgroups per CU remain
+int choose_waves(int B, int Ho, int Wo, int Cout, int force_nw) {
+    const int TN = (Cout >= 128) ? 128 : 64;
+    const long long big = (long long)cdiv(Cout, TN) * B * cdiv(Wo, TW) * cdiv(Ho, 8);
+    if (force_nw == 4) return 4;
+    return (force_nw == 8 || ((Ho % 8) == 0 && big >= 512)) ? 8 : 4;
+}
+
+int env_force_nw() {
+    const char* e = getenv("WITW_CONV_NW");   // tuning aid: force the workgroup shape
+    return e ? atoi(e) : 0;
+}
+
+template <int TN, int SH, bool POOL>
+int launch_conv(const ConvArgs& a, hipStream_t st) {
+    if (choose_waves(a.B, a.Ho, a.Wo, a.Cout, a.force_nw) == 8) return launch_conv_nw<TN, SH, POOL, 8>(a, st);
+    return launch_conv_nw<TN, SH, POOL, 4>(a, st);
 }
 
 }  // namespace
@@ -486,6 +511,13 @@ unsigned long long* witw_conv_stamps_ptr = nullptr;
 extern "C" {
 
 int witw_conv3x3_tile_n(int cout) { return cout >= 128 ? 128 : 64; }
+
+// waves per workgroup (4 or 8) the launcher picks for a layer: names the kernel instantiation
+// conv3x3_nhwc_f32_kernel<tile_n, stride_h, pool, waves> that a profile will show
+int witw_conv3x3_workgroup_waves(int B, int H, int W, int Cout, int stride_h) {
+    if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (stride_h != 1 && stride_h != 2)) return -1;
+    return choose_waves(B, (H + 2 - 3) / stride_h + 1, W, Cout, env_force_nw());
+}
 
 long long witw_conv3x3_packed_floats(int cout, int cin) {
     if (cout <= 0 || cin <= 0) return -1;
@@ -555,7 +587,8 @@ int witw_conv3x3_fwd_ex(const float* x, const float* wpk, const float* bias, con
     a.Ho = (H + 2 - 3) / stride_h + 1;
     a.Wo = W;
     a.tiles_x = cdiv(a.Wo, TW);
-    a.tiles_y = cdiv(a.Ho, TH);
+    a.tiles_y = 0;   // set by the launcher for the chosen tile height
+    a.force_nw = env_force_nw();
     a.circ = pad_circular; a.relu = relu; a.out_nchw = out_nchw; a.dil_h = dilate_h;
 #ifdef WITW_STAMPS
     a.stamps = witw_conv_stamps_ptr;

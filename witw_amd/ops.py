@@ -111,7 +111,8 @@ def conv3x3_fwd(x_nhwc, packed, stride_h=1, circular=False, relu=True, pool=Fals
                                        int(bool(dilate_h)), _stream()), 'witw_conv3x3_fwd_ex')
     if prof is not None:
         e1.record()
-        variant = (lib.witw_conv3x3_tile_n(packed.cout), stride_h, bool(pool))
+        variant = (lib.witw_conv3x3_tile_n(packed.cout), stride_h, bool(pool),
+                   lib.witw_conv3x3_workgroup_waves(B, H, W, packed.cout, stride_h))
         prof.append((variant, 2.0 * packed.cin * packed.cout * 9 * Ho * W * B, e0, e1))
 
     return y
