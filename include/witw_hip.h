@@ -59,9 +59,13 @@ int witw_conv3x3_fwd(const float* x, const float* wpk, const float* bias, const 
  * 2 LeakyReLU(lrelu_slope); post_scale/post_shift (NULL or [Cout]): per-channel affine after the activation
  * (eval-mode BatchNorm2d of model/cvig_baseline.py:267-275). */
 int witw_conv3x3_fwd_ex(const float* x, const float* wpk, const float* bias, const float* dropmask, const float* gate,
-                        const float* post_scale, const float* post_shift, float* y, int B, int H, int W, int Cin, int Cout,
-                        int stride_h, int pad_circular, int relu, float lrelu_slope, int pool, int out_nchw, int dilate_h,
-                        void* stream);
+                        const float* post_scale, const float* post_shift, float* y, unsigned char* pool_code, int B, int H,
+                        int W, int Cin, int Cout, int stride_h, int pad_circular, int relu, float lrelu_slope, int pool,
+                        int out_nchw, int dilate_h, void* stream);
+/* backward of the fused MaxPool2d(2,2): pool_code (written by the forward when non-NULL: first arg-max position
+ * dy*2+dx in torch's scan order) routes dy [B,Hp,Wp,C] into dx [B,H,W,C] (H>=2Hp, W>=2Wp). */
+int witw_maxpool2x2_bwd(const float* dy, const unsigned char* pool_code, float* dx, int B, int Hp, int Wp, int H, int W,
+                        int C, void* stream);
 /* NCHW [B,C,H,W] -> NHWC [B,H,W,Cpad] with zero-filled extra channels (embedding gradients). */
 int witw_nchw_to_nhwc(const float* x, float* y, int B, int C, int H, int W, int Cpad, void* stream);
 /* Weight / bias gradient of one conv layer. x: the layer's NHWC input [B,H,W,Cin], dz: gradient at its output

@@ -163,3 +163,68 @@ def test_training_step_matches_reference_golden(golden_dir):
     with torch.no_grad():
         e2 = se.eval()(xs.to(dev))
     assert float((e2 - s_emb.detach()).abs().max()) > 0
+
+
+def test_maxpool_backward_and_codes():
+    """Fused conv+pool forward records torch's arg-max positions; the scatter kernel reproduces autograd."""
+    from witw_amd import ops
+    B, H, W, Cin, Cout = 2, 10, 70, 8, 64
+    x = _rand(41, (B, Cin, H, W))
+    w = _rand(42, (Cout, Cin, 3, 3), 0.2).requires_grad_(False)
+    b = _rand(43, (Cout,), 0.1)
+    xr = x.clone().requires_grad_(True)
+    z = O.conv3x3(xr, w, b, 1, True)
+    pooled = F.max_pool2d(torch.relu(z), 2, 2)
+    gy = _rand(44, tuple(pooled.shape))
+    z.retain_grad()                      # gradient at the conv output, i.e. through max-pool AND ReLU
+    pooled.backward(gy)
+    dev = torch.device('cuda:0')
+    pk = ops.PackedConv(w.to(dev), b.to(dev))
+    y, code = ops.conv3x3_fwd(_nhwc(x).to(dev), pk, circular=True, relu=True, pool=True, want_pool_code=True)
+    np.testing.assert_allclose(y.cpu().permute(0, 3, 1, 2).numpy(), pooled.detach().numpy(), atol=2e-5)
+    gated = _nhwc(gy).to(dev) * (y > 0).float()
+    dpre = ops.maxpool2x2_bwd(gated.contiguous(), code, (H, W)).cpu().permute(0, 3, 1, 2)
+    np.testing.assert_allclose(dpre.numpy(), z.grad.numpy(), atol=1e-6)
+
+
+def test_semantic_training_step_vs_oracle_autograd():
+    """cvig_semantic: layer 0 trains, so the backward runs through all 13 layers and the 3 fused max-pools."""
+    from witw_amd import cvig_semantic, cvig_fov
+    seed = 321
+    w5 = synth.fov_dsm_weights(seed, in_channels=5)
+    B = 2
+    xs = torch.from_numpy(synth.normalized_images(seed, 1, (B, 5, 128, 64)))     # narrow inputs keep the CPU side quick
+    xo = torch.from_numpy(synth.normalized_images(seed, 2, (B, 5, 128, 512)))
+    drops = {t: {i: torch.from_numpy(synth.dropout_scales(seed, 10 * k + i, B, 512)) for i in (17, 19, 21)}
+             for k, t in enumerate('so')}
+    # oracle (CPU autograd) with layer 0 trainable as well
+    leaves = {}
+    ws_, wo_ = ({k: (torch.from_numpy(a.copy()), torch.from_numpy(c.copy())) for k, (a, c) in w5.items()} for _ in range(2))
+    for tag, wd in (('s', ws_), ('o', wo_)):
+        for idx in (0,) + O.TRAINABLE:
+            for t in wd[idx]:
+                t.requires_grad_(True)
+            leaves[(tag, idx)] = wd[idx]
+    s_emb = O.fov_dsm_forward(xs, ws_, False, dropout_scales=drops['s'])
+    o_emb = O.fov_dsm_forward(xo, wo_, True, dropout_scales=drops['o'])
+    ori_r, dist_r = O.match(o_emb, s_emb)
+    loss_r = O.triplet_loss(dist_r)
+    loss_r.backward()
+    dev = torch.device('cuda:0')
+    se = cvig_semantic.FOV_DSM(False, weights=w5).to(dev).train()
+    oe = cvig_semantic.FOV_DSM(True, weights=w5).to(dev).train()
+    se_out = se(xs.to(dev), dropout_scales={k: v.to(dev) for k, v in drops['s'].items()})
+    oe_out = oe(xo.to(dev), dropout_scales={k: v.to(dev) for k, v in drops['o'].items()})
+    ori, dist = cvig_fov.match(oe_out, se_out)
+    loss = cvig_fov.triplet_loss(dist)
+    loss.backward()
+    assert abs(loss.item() - loss_r.item()) < 1e-4
+    assert torch.equal(ori.cpu(), ori_r)
+    for tag, enc in (('s', se), ('o', oe)):
+        for idx, conv in enc.trainable_convs():
+            for k, prm in ((0, conv.weight), (1, conv.bias)):
+                ref = leaves[(tag, idx)][k].grad
+                got = prm.grad.cpu()
+                rel = (got - ref).norm() / ref.norm()
+                assert rel < 2e-2, (tag, idx, k, float(rel))       # ReLU / max-pool kinks: see the cvig_fov test
+    assert sorted(i for i, _c in se.trainable_convs()) == [0, 17, 19, 21, 23, 25, 27]

@@ -122,5 +122,3 @@ def test_semantic_encoder_matches_reference_golden(golden_dir):
     np.testing.assert_allclose(e, g['embed5_circ1'], rtol=0, atol=TOL)
     ref_train = sorted(k for k in g['trainable'] if not k.startswith('model.classifier'))
     assert sorted(n for n, p in enc.named_parameters() if p.requires_grad) == ref_train
-    with pytest.raises(Exception):       # backward through layers 0-16 is not built: fail loudly, never silently
-        enc.train()(x5)

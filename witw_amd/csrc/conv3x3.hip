@@ -36,6 +36,7 @@ struct ConvArgs {
     const float* post_scale;  // nullptr, or per-channel scale/shift applied AFTER the activation (folded BatchNorm)
     const float* post_shift;
     float lrelu;            // negative slope when relu == 2 (LeakyReLU)
+    unsigned char* pool_code;  // nullptr, or [B,Hy,Wy,Cout] argmax position (dy*2+dx) of the fused 2x2 max pool
     const float* gate;      // nullptr, or a tensor shaped like y: outputs where gate <= 0 are zeroed (ReLU backward)
     float* y;               // NHWC [B,Hy,Wy,Cout] or NCHW [B,Cout,Hy,Wy]
     int B, H, W, Cin, Cout;
@@ -395,11 +396,19 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_f32_kernel(ConvArgs p) {
                 for (int g = 0; g < 4; ++g)
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
-                        const float v0 = fmaxf(acc[mtA][nt][4 * g + 2 * e], acc[mtA][nt][4 * g + 2 * e + 1]);
-                        const float v1 = fmaxf(acc[mtB][nt][4 * g + 2 * e], acc[mtB][nt][4 * g + 2 * e + 1]);
+                        const float a00 = acc[mtA][nt][4 * g + 2 * e], a01 = acc[mtA][nt][4 * g + 2 * e + 1];
+                        const float a10 = acc[mtB][nt][4 * g + 2 * e], a11 = acc[mtB][nt][4 * g + 2 * e + 1];
+                        const float v0 = fmaxf(a00, a01);
+                        const float v1 = fmaxf(a10, a11);
                         const int yy = (oy0 + trow[mtA]) >> 1;
                         const int xx = ((ox0 + tcol[mtA]) >> 1) + 4 * g + 2 * hq + e;
                         emit(fmaxf(v0, v1), nt, yy, xx);
+                        if (p.pool_code != nullptr && yy < Hy && xx < Wy && nch[nt] < p.Cout) {
+                            // first position attaining the max, scan order (0,0),(0,1),(1,0),(1,1) as torch's max_pool2d
+                            const float m = fmaxf(v0, v1);
+                            const int code = (a00 == m) ? 0 : (a01 == m) ? 1 : (a10 == m) ? 2 : 3;
+                            p.pool_code[(((size_t)b * Hy + yy) * Wy + xx) * p.Cout + nch[nt]] = (unsigned char)code;
+                        }
                     }
         }
     }
@@ -566,9 +575,9 @@ int witw_nchw_to_nhwc(const float* x, float* y, int B, int C, int H, int W, int 
 }
 
 int witw_conv3x3_fwd_ex(const float* x, const float* wpk, const float* bias, const float* dropmask, const float* gate,
-                        const float* post_scale, const float* post_shift, float* y, int B, int H, int W, int Cin, int Cout,
-                        int stride_h, int pad_circular, int relu, float lrelu_slope, int pool, int out_nchw, int dilate_h,
-                        void* stream) {
+                        const float* post_scale, const float* post_shift, float* y, unsigned char* pool_code, int B, int H,
+                        int W, int Cin, int Cout, int stride_h, int pad_circular, int relu, float lrelu_slope, int pool,
+                        int out_nchw, int dilate_h, void* stream) {
     WITW_CHECK_ARG(x && wpk && bias && y, "conv3x3_fwd: null pointer");
     WITW_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cout > 0, "conv3x3_fwd: bad shape B=%d H=%d W=%d Cout=%d", B, H, W, Cout);
     WITW_CHECK_ARG(Cin > 0 && (Cin % 8) == 0, "conv3x3_fwd: Cin=%d must be a positive multiple of 8", Cin);
@@ -583,6 +592,7 @@ int witw_conv3x3_fwd_ex(const float* x, const float* wpk, const float* bias, con
     ConvArgs a;
     a.x = x; a.wpk = wpk; a.bias = bias; a.dropmask = dropmask; a.gate = gate; a.y = y;
     a.post_scale = post_scale; a.post_shift = post_shift; a.lrelu = lrelu_slope;
+    a.pool_code = pool ? pool_code : nullptr;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
     a.Ho = (H + 2 - 3) / stride_h + 1;
     a.Wo = W;
@@ -606,7 +616,7 @@ int witw_conv3x3_fwd_ex(const float* x, const float* wpk, const float* bias, con
 int witw_conv3x3_fwd(const float* x, const float* wpk, const float* bias, const float* dropmask, float* y, int B, int H,
                      int W, int Cin, int Cout, int stride_h, int pad_circular, int relu, int pool, int out_nchw,
                      void* stream) {
-    return witw_conv3x3_fwd_ex(x, wpk, bias, dropmask, nullptr, nullptr, nullptr, y, B, H, W, Cin, Cout, stride_h,
+    return witw_conv3x3_fwd_ex(x, wpk, bias, dropmask, nullptr, nullptr, nullptr, y, nullptr, B, H, W, Cin, Cout, stride_h,
                                pad_circular, relu ? 1 : 0, 0.f, pool, out_nchw, 0, stream);
 }
 

@@ -215,6 +215,26 @@ __global__ void bias_grad_finish_kernel(const float* __restrict__ part, float* _
     db[co] = accumulate ? db[co] + s : s;
 }
 
+// Backward of the fused MaxPool2d(2,2): dy [B,Hp,Wp,C] (gradient at the pooled output, ReLU gate already
+// applied) is routed to the position recorded by the forward (code = dy*2+dx); dx is [B,H,W,C] with H >= 2Hp,
+// W >= 2Wp (a dropped odd row/column gets 0). One thread per pooled element and channel quad.
+__global__ void maxpool2x2_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ code,
+                                      float* __restrict__ dx, int Hp, int Wp, int H, int W, int C, size_t total) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = idx % C;
+    size_t t = idx / C;
+    const int w = t % Wp;
+    t /= Wp;
+    const int h = t % Hp;
+    const size_t b = t / Hp;
+    const float g = dy[idx];
+    const int k = code[idx];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        dx[((b * H + 2 * h + (q >> 1)) * W + 2 * w + (q & 1)) * C + c] = (q == k) ? g : 0.f;
+}
+
 // torch.optim.Adam (no weight decay, no amsgrad) as pinned by the reference (torch==1.8.1,
 // model/requirements.txt:1; optimizer built at model/cvig_fov.py:416-418 with lr=1e-5):
 //   m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g*g ; p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
@@ -301,6 +321,23 @@ int witw_conv3x3_wgrad(const float* x, const float* dz, float* dw, float* db, fl
         hipLaunchKernelGGL(bias_grad_finish_kernel, dim3(cdiv(Cout, 256)), dim3(256), 0, st, part, db, Cout, nparts, accumulate);
         WITW_CHECK_LAUNCH("bias_grad");
     }
+    return WITW_OK;
+}
+
+int witw_maxpool2x2_bwd(const float* dy, const unsigned char* code, float* dx, int B, int Hp, int Wp, int H, int W, int C,
+                        void* stream) {
+    WITW_CHECK_ARG(dy && code && dx, "maxpool2x2_bwd: null pointer");
+    WITW_CHECK_ARG(B > 0 && Hp > 0 && Wp > 0 && C > 0 && H >= 2 * Hp && W >= 2 * Wp, "maxpool2x2_bwd: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    if ((H > 2 * Hp || W > 2 * Wp) &&
+        hipMemsetAsync(dx, 0, sizeof(float) * (size_t)B * H * W * C, st) != hipSuccess) {   // dropped odd row / column
+        witw_set_error("maxpool2x2_bwd: memset failed");
+        return WITW_ERR_LAUNCH;
+    }
+    const size_t total = (size_t)B * Hp * Wp * C;
+    hipLaunchKernelGGL(maxpool2x2_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dy, code, dx, Hp, Wp, H, W,
+                       C, total);
+    WITW_CHECK_LAUNCH("maxpool2x2_bwd");
     return WITW_OK;
 }
 

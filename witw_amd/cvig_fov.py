@@ -139,18 +139,20 @@ class FOV_DSM(torch.nn.Module):
         return scales
 
     def _run(self, x, scales, keep_from=None):
-        """Layer stack; returns (embedding NCHW, {idx: NHWC output} for idx >= keep_from, input of keep_from)."""
+        """Layer stack. Returns (embedding NCHW, kept) where kept[idx] = (layer input NHWC, layer output NHWC,
+        max-pool arg-max codes or None) for every layer idx >= keep_from (what the backward needs)."""
         h = ops.nchw_to_nhwc8(x.contiguous())
         last = self.layer_specs[-1][0]
-        kept, first_in = {}, None
+        kept = {}
         for (idx, sh, relu, pool, drop) in self.layer_specs:
-            if keep_from is not None and idx == keep_from:
-                first_in = h
-            h = ops.conv3x3_fwd(h, self._pack(idx), stride_h=sh, circular=self.circ_padding, relu=relu, pool=pool,
-                                out_nchw=(idx == last), drop_scale=scales.get(idx))
-            if keep_from is not None and idx >= keep_from:
-                kept[idx] = h
-        return h, kept, first_in
+            keep = keep_from is not None and idx >= keep_from
+            out = ops.conv3x3_fwd(h, self._pack(idx), stride_h=sh, circular=self.circ_padding, relu=relu, pool=pool,
+                                  out_nchw=(idx == last), drop_scale=scales.get(idx), want_pool_code=(keep and pool))
+            y, code = out if (keep and pool) else (out, None)
+            if keep:
+                kept[idx] = (h, y, code)
+            h = y
+        return h, kept
 
     def trainable_convs(self):
         return [(idx, _conv_of(self.model.features[idx])) for (idx, *_r) in self.layer_specs
@@ -166,8 +168,6 @@ class FOV_DSM(torch.nn.Module):
         scales = self._draw_scales(x, dropout_scales)
         tr = self.trainable_convs()
         if torch.is_grad_enabled() and tr:
-            if tr[0][0] != synth.TRAINABLE_FROM or self.in_channels != 3:
-                raise _lib.WitwError('backward is implemented for the cvig_fov trainable set (layers >= 17) only')
             params = []
             for _i, c in tr:
                 params += [c.weight, c.bias]
@@ -176,20 +176,23 @@ class FOV_DSM(torch.nn.Module):
 
 
 class _EncoderFn(torch.autograd.Function):
-    """autograd node of one FOV_DSM call: forward = the 13 fused conv launches; backward = per
-    trainable layer one wgrad launch and one dgrad launch (the forward kernel on the transposed,
-    tap-rotated filter with the ReLU / Dropout2d gate fused into its epilogue)."""
+    """autograd node of one FOV_DSM call: forward = the 13 fused conv launches; backward walks the layers from
+    27 down to the first trainable one: per trainable layer one wgrad launch, per layer one dgrad launch (the
+    forward kernel on the transposed, tap-rotated filter with the previous layer's ReLU / Dropout2d gate fused
+    into its epilogue, zero-interleaved rows for the stride-(2,1) layers) and, behind a fused max-pool, the
+    arg-max scatter. cvig_fov stops at layer 17; cvig_semantic (layer 0 trainable) goes all the way down."""
 
     @staticmethod
     def forward(ctx, x, enc, scales, *params):
-        out, kept, first_in = enc._run(x, scales, keep_from=synth.TRAINABLE_FROM)
-        ctx.enc, ctx.scales, ctx.kept, ctx.first_in = enc, scales, kept, first_in
+        first = min(i for i, _c in enc.trainable_convs())
+        out, kept = enc._run(x, scales, keep_from=first)
+        ctx.enc, ctx.scales, ctx.kept, ctx.first = enc, scales, kept, first
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         enc, scales, kept = ctx.enc, ctx.scales, ctx.kept
-        specs = [sp for sp in enc.layer_specs if sp[0] >= synth.TRAINABLE_FROM]
+        specs = [sp for sp in enc.layer_specs if sp[0] >= ctx.first]
         circ = enc.circ_padding
         last = specs[-1][0]
         cout_last = _conv_of(enc.model.features[last]).out_channels
@@ -197,17 +200,20 @@ class _EncoderFn(torch.autograd.Function):
         grads = {}
         for n in range(len(specs) - 1, -1, -1):
             idx, sh, relu, pool, drop = specs[n]
-            x_in = ctx.first_in if n == 0 else kept[specs[n - 1][0]]
+            x_in = kept[idx][0]
             conv = _conv_of(enc.model.features[idx])
-            grads[idx] = ops.conv3x3_wgrad(x_in, dz, conv.in_channels, stride_h=sh, circular=circ)
-            if n > 0:   # gradient at the previous layer's conv output: dgrad, gated by its ReLU and dropout
-                pidx = specs[n - 1][0]
-                dz = ops.conv3x3_fwd(dz, enc._pack_t(idx), stride_h=1, circular=circ, relu=False, pool=False,
-                                     drop_scale=scales.get(pidx), gate=kept[pidx], dilate_h=(sh == 2),
+            if conv.weight.requires_grad:
+                grads[idx] = ops.conv3x3_wgrad(x_in, dz, conv.in_channels, stride_h=sh, circular=circ)
+            if n > 0:   # gradient at the previous layer's conv output
+                pidx, _psh, _prelu, ppool, _pdrop = specs[n - 1]
+                p_in, p_out, p_code = kept[pidx]
+                dy = ops.conv3x3_fwd(dz, enc._pack_t(idx), stride_h=1, circular=circ, relu=False, pool=False,
+                                     drop_scale=scales.get(pidx), gate=p_out, dilate_h=(sh == 2),
                                      out_h=x_in.shape[1] if sh == 2 else None)
-        ctx.kept = ctx.first_in = None
+                dz = ops.maxpool2x2_bwd(dy, p_code, (p_in.shape[1], p_in.shape[2])) if ppool else dy
+        ctx.kept = None
         flat = []
-        for (idx, *_r) in specs:
+        for (idx, _c) in enc.trainable_convs():
             flat += [grads[idx][0], grads[idx][1]]
         return (None, None, None) + tuple(flat)
 

@@ -5,8 +5,8 @@ inputs (RGB + 2 semantic channels). Differences from cvig_fov (reference diff, S
   * ImageNormalization divides only channels 0-2 by 255 (:172-176);
   * FOV_DSM's first conv is Conv2d(5,64) and is trainable (:301-309).
 Everything else (matching, loss, ranking, transforms) is shared with witw_amd.cvig_fov.
-Forward/eval run on the HIP kernels; the backward through layers 0-16 (needed because layer 0 trains) is not
-built yet and raises.
+Forward and backward run on the HIP kernels; because layer 0 trains, the backward walks all 13 layers
+(dgrad through the frozen VGG layers, arg-max scatter behind the three fused max-pools, layer-0 wgrad).
 """
 import torch
 

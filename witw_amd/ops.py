@@ -73,7 +73,8 @@ def nchw_to_nhwc(x, cpad):
 
 
 def conv3x3_fwd(x_nhwc, packed, stride_h=1, circular=False, relu=True, pool=False, out_nchw=False, drop_scale=None,
-                gate=None, dilate_h=False, out_h=None, lrelu_slope=None, post_scale=None, post_shift=None):
+                gate=None, dilate_h=False, out_h=None, lrelu_slope=None, post_scale=None, post_shift=None,
+                want_pool_code=False):
     """x_nhwc [B,H,W,Cin_pad] -> NHWC [B,Hy,Wy,Cout] (or NCHW [B,Cout,Hy,Wy])."""
     lib = _lib.load()
     x = _dev_f32(x_nhwc, 'x')
@@ -105,8 +106,9 @@ def conv3x3_fwd(x_nhwc, packed, stride_h=1, circular=False, relu=True, pool=Fals
         post_scale, post_shift = _dev_f32(post_scale, 'post_scale'), _dev_f32(post_shift, 'post_shift')
         if post_scale.numel() != packed.cout or post_shift.numel() != packed.cout:
             raise _lib.WitwError('post_scale/post_shift must have Cout entries')
+    code = torch.empty(shape, dtype=torch.uint8, device=x.device) if (pool and want_pool_code) else None
     _lib.check(lib.witw_conv3x3_fwd_ex(x.data_ptr(), packed.wpk.data_ptr(), packed.bias.data_ptr(), _p(drop_scale),
-                                       _p(gate), _p(post_scale), _p(post_shift), y.data_ptr(), B, H, W, C, packed.cout,
+                                       _p(gate), _p(post_scale), _p(post_shift), y.data_ptr(), _p(code), B, H, W, C, packed.cout,
                                        stride_h, int(circular), act, float(lrelu_slope or 0.), int(pool), int(out_nchw),
                                        int(bool(dilate_h)), _stream()), 'witw_conv3x3_fwd_ex')
     if prof is not None:
@@ -114,8 +116,21 @@ def conv3x3_fwd(x_nhwc, packed, stride_h=1, circular=False, relu=True, pool=Fals
         variant = (lib.witw_conv3x3_tile_n(packed.cout), stride_h, bool(pool),
                    lib.witw_conv3x3_workgroup_waves(B, H, W, packed.cout, stride_h))
         prof.append((variant, 2.0 * packed.cin * packed.cout * 9 * Ho * W * B, e0, e1))
-
+    if want_pool_code:
+        return y, code
     return y
+
+
+def maxpool2x2_bwd(dy, code, out_hw):
+    """dy/code [B,Hp,Wp,C] -> dx [B,H,W,C] (gradient routed to the recorded arg-max position)."""
+    lib = _lib.load()
+    dy = _dev_f32(dy, 'dy')
+    B, Hp, Wp, C = dy.shape
+    H, W = out_hw
+    dx = torch.empty((B, H, W, C), dtype=torch.float32, device=dy.device)
+    _lib.check(lib.witw_maxpool2x2_bwd(dy.data_ptr(), code.data_ptr(), dx.data_ptr(), B, Hp, Wp, H, W, C, _stream()),
+               'witw_maxpool2x2_bwd')
+    return dx
 
 
 def conv3x3_wgrad(x_nhwc, dz_nhwc, cin_real, stride_h=1, circular=False, want_bias=True):
