@@ -114,6 +114,15 @@ int witw_triplet_loss_slab_fwd(const float* distance, const float* diag, int Bo,
 int witw_triplet_loss_bwd(const float* distance, const float* workspace, const float* grad_loss /*[1]*/,
                           float* grad_distance /*[B,B]*/, int B, float alpha, void* stream);
 
+/* ---- bf16 inference path of the encoder (BASELINE config "cvig_semantic ... bf16 MFMA"): bf16 NHWC activations
+ * (channels padded to 16) and packed bf16 filters, fp32 accumulate on v_mfma_f32_32x32x16_bf16, fp32 bias;
+ * the last layer writes the fp32 NCHW embedding (out_nchw_f32). Pointers typed void* carry bf16 data. */
+long long witw_conv3x3_bf16_packed_elems(int cout, int cin);
+int witw_conv3x3_bf16_pack_weights(const float* w_kcrs, void* wpk_bf16, int cout, int cin, void* stream);
+int witw_nchw_f32_to_nhwc_bf16(const float* x, void* y_bf16, int B, int C, int H, int W, int Cpad, void* stream);
+int witw_conv3x3_bf16_fwd(const void* x_bf16, const void* wpk_bf16, const float* bias, void* y, int B, int H, int W, int Cin,
+                          int Cout, int stride_h, int pad_circular, int relu, int pool, int out_nchw_f32, void* stream);
+
 /* ---- cvig_baseline (model/cvig_baseline.py). Conv2d(k=4,s=2,p=0) = the 3x3 kernel above on the
  * space-to-depth(2) image with a filter whose first tap row/column is zero. */
 /* x NHWC [B,Hp,Wp,C] (NCHW if in_nchw) with valid region HxW -> NHWC [B,ceil(H/2),ceil(W/2),Cpad], channel

@@ -284,3 +284,24 @@ def train_step(surface, overhead, w_surface, w_overhead, drop_surface=None, drop
     for t in params:
         t.requires_grad_(False)
     return loss.detach(), ori, dist.detach(), grads
+
+
+def fov_dsm_forward_bf16_emulated(x, weights, circ_padding):
+    """What the bf16 MFMA path computes, emulated on the CPU: inputs, filters and every stored activation are
+    rounded to bfloat16 (round-to-nearest-even), products/accumulation/bias/ReLU/max-pool in fp32, the last
+    layer's output stays fp32. (No reference counterpart: the reference has no reduced-precision path; this
+    pins the GPU kernel to 'the fp32 algorithm of model/cvig_fov.py:292-294 with bf16 storage'.)"""
+    def r(t):
+        return t.bfloat16().float()
+    x = r(x)
+    last = FOV_LAYERS[-1][0]
+    for (idx, sh, relu, pool, drop) in FOV_LAYERS:
+        w, b = weights[idx]
+        x = conv3x3(x, r(w), b, sh, circ_padding)
+        if relu:
+            x = F.relu(x)
+        if pool:
+            x = F.max_pool2d(x, 2, 2)
+        if idx != last:
+            x = r(x)
+    return x

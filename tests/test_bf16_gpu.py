@@ -1,0 +1,72 @@
+"""bf16 MFMA inference path (BASELINE config 'cvig_semantic ... bf16 MFMA'): parity with a CPU emulation of
+'fp32 algorithm + bf16 storage' and the accuracy cost against the fp32 reference goldens.
+
+Tolerances (stated, as bf16 cannot meet the fp32 1e-4): against the bf16-storage emulation the embeddings agree
+to 1e-2 of their norm (fp32 summation order moves a few intermediate activations across a bf16 rounding
+boundary); against the reference's fp32 embeddings the bf16 path is within 5e-2 of the norm."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cvig_fov_oracle as O
+from witw_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return float(np.linalg.norm(a - b) / np.linalg.norm(b))
+
+
+@pytest.mark.parametrize('case', [(2, 8, 64, 16, 64, 1, True, True, False), (1, 16, 64, 64, 128, 1, False, True, True),
+                                  (2, 16, 24, 32, 256, 2, True, True, False), (1, 12, 99, 16, 64, 1, True, True, True),
+                                  (2, 4, 64, 64, 16, 1, True, False, False)])
+def test_conv3x3_bf16_vs_emulation(case):
+    from witw_amd import ops
+    B, H, W, Cin, Cout, sh, circ, relu, pool = case
+    g = np.random.Generator(np.random.Philox(key=[7, Cin + Cout]))
+    x = torch.from_numpy(g.standard_normal((B, Cin, H, W), dtype=np.float32)).bfloat16().float()
+    w = torch.from_numpy((g.standard_normal((Cout, Cin, 3, 3), dtype=np.float32) * (2.0 / (9 * Cin)) ** 0.5)).float()
+    b = torch.from_numpy(g.standard_normal((Cout,), dtype=np.float32) * 0.1)
+    ref = O.conv3x3(x, w.bfloat16().float(), b, sh, circ)
+    if relu:
+        ref = torch.relu(ref)
+    if pool:
+        ref = torch.nn.functional.max_pool2d(ref, 2, 2)
+    dev = torch.device('cuda:0')
+    xd = x.to(dev).permute(0, 2, 3, 1).contiguous().bfloat16()
+    pk = ops.PackedConvBf16(w.to(dev), b.to(dev))
+    last = Cout % 16 != 0 or Cout == 16
+    y = ops.conv3x3_bf16_fwd(xd, pk, stride_h=sh, circular=circ, relu=relu, pool=pool, out_nchw_f32=last)
+    if last:
+        np.testing.assert_allclose(y.cpu().numpy(), ref.numpy(), rtol=0, atol=2e-5)           # fp32 out: exact products
+    else:
+        got = y.float().cpu().permute(0, 3, 1, 2)
+        np.testing.assert_allclose(got.numpy(), ref.bfloat16().float().numpy(), rtol=2 ** -7, atol=1e-6)  # <= 1 bf16 ulp
+
+
+def test_encoder_bf16_vs_emulation_and_fp32_goldens(golden_dir):
+    from witw_amd import cvig_fov, cvig_semantic
+    g = np.load(os.path.join(golden_dir, 'encoder.npz'))
+    seed = int(g['seed'])
+    w = synth.fov_dsm_weights(seed)
+    wt = {k: (torch.from_numpy(a), torch.from_numpy(b)) for k, (a, b) in w.items()}
+    x360 = torch.from_numpy(synth.normalized_images(seed, 10, (2, 3, 128, 512)))
+    for circ in (False, True):
+        enc = cvig_fov.FOV_DSM(circ_padding=circ, weights=w).cuda().eval()
+        e = enc.forward_bf16(x360.cuda()).cpu().numpy()
+        assert e.shape == (2, 16, 4, 64) and e.dtype == np.float32
+        with torch.no_grad():
+            emu = O.fov_dsm_forward_bf16_emulated(x360, wt, circ).numpy()
+        assert _rel(e, emu) < 1e-2, _rel(e, emu)
+        assert _rel(e, g['embed360_circ%d' % circ]) < 5e-2
+    # 5-channel semantic variant on the same kernels
+    gs = np.load(os.path.join(golden_dir, 'encoder_semantic.npz'))
+    w5 = synth.fov_dsm_weights(seed, in_channels=5)
+    x5 = torch.from_numpy(synth.normalized_images(seed, 12, (1, 5, 128, 512)))
+    e5 = cvig_semantic.FOV_DSM(circ_padding=True, weights=w5).cuda().eval().forward_bf16(x5.cuda()).cpu().numpy()
+    assert _rel(e5, gs['embed5_circ1']) < 5e-2
+    with pytest.raises(Exception):
+        enc.train().forward_bf16(x360.cuda())

@@ -1,0 +1,388 @@
+// 3x3 convolution, NHWC bf16 operands / fp32 accumulate, implicit GEMM on v_mfma_f32_32x32x16_bf16 (gfx950).
+//
+// The bf16 inference path of the FOV_DSM encoder (BASELINE config "cvig_semantic.py semantic-branch variant,
+// bf16 MFMA": reference layers model/cvig_semantic.py:275-325 = model/cvig_fov.py:256-294 with a 5-channel
+// first conv). Same structure as the fp32 kernel (conv3x3.hip): NW x 64-pixel output tile x TN channels per
+// workgroup, halo tile + weight slab double buffered in LDS as 16-byte slots in [group][row][col] /
+// [tap][group][n] order, padding as a load policy (range-checked buffer loads), bias / ReLU / 2x2 max-pool in
+// the epilogue. What changes with the data type:
+//   * a 16-byte slot holds 8 bf16 channels; lanes 0-31 read channel group 0 and lanes 32-63 group 1 of a
+//     16-channel K chunk, which is exactly one v_mfma_f32_32x32x16_bf16 operand pair (A[row][k=8h+j],
+//     B[k=8h+j][col]) per ds_read_b128 — one MFMA (32 cycles) per fragment pair instead of four 64-cycle ones,
+//     so the kernel is bound by operand delivery (LDS / L2), not by the matrix pipe;
+//   * activations are stored bf16 (round-to-nearest-even, v_cvt_pk_bf16_f32), channel count padded to 16;
+//     the last layer writes the fp32 NCHW embedding.
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TW = 64;
+constexpr int IW = TW + 2;
+
+struct ConvBfArgs {
+    const unsigned short* x;   // [B,H,W,Cin] NHWC bf16, Cin % 16 == 0
+    const unsigned short* wpk; // packed bf16: [n_tile][cin/16][tap][group][TN][8]
+    const float* bias;         // [n_tiles*TN] fp32 (zero padded)
+    void* y;                   // NHWC bf16 [B,Hy,Wy,Cout] or fp32 NCHW [B,Cout,Hy,Wy]
+    int B, H, W, Cin, Cout;
+    int Ho, Wo;
+    int tiles_x, tiles_y;
+    int circ, relu, out_nchw_f32;
+};
+
+template <int TN, int SH, bool POOL, int NW>
+__global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_bf16_kernel(ConvBfArgs p) {
+    constexpr int TH = NW;
+    constexpr int NTHREADS = 64 * NW;
+    constexpr int IH = (TH - 1) * SH + 3;
+    constexpr int IN_S = 2 * IH * IW;           // 16-B slots of one input stage (2 channel groups)
+    constexpr int W_S = 9 * 2 * TN;             // 16-B slots of one weight stage
+    constexpr int STAGE_S = IN_S + W_S;
+    constexpr int NIN = (IN_S + NTHREADS - 1) / NTHREADS;
+    constexpr int NWT = (W_S + NTHREADS - 1) / NTHREADS;
+    constexpr int WGM = (TN == 128) ? NW / 2 : NW;
+    constexpr int WM = (2 * TH) / WGM;
+    constexpr int WN = 2;
+    constexpr unsigned OOR = 0x80000000u;
+
+    __shared__ u32x4 smem[2 * STAGE_S + 1];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hq = lane >> 5;
+
+    int bid = blockIdx.x;
+    const int tiles_img = p.tiles_x * p.tiles_y;
+    const int per_n = p.B * tiles_img;
+    const int ntile = bid / per_n;
+    bid -= ntile * per_n;
+    const int b = bid / tiles_img;
+    bid -= b * tiles_img;
+    const int ty = bid / p.tiles_x;
+    const int tx = bid - ty * p.tiles_x;
+    const int oy0 = ty * TH, ox0 = tx * TW, n0 = ntile * TN;
+    const int nkc = p.Cin >> 4;
+
+    // ---- staging descriptors: per-image / per-weight-tile buffer resources, fixed per-thread byte offsets,
+    // K-chunk advance in the scalar offset (32 B per pixel per chunk)
+    const size_t img_elems = (size_t)p.H * p.W * p.Cin;
+    __amdgpu_buffer_rsrc_t in_rs =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)b * img_elems), 0, (unsigned)(img_elems * 2), 0x00020000);
+    __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(reinterpret_cast<const u32x4*>(p.wpk) + (size_t)ntile * nkc * W_S), 0, (unsigned)nkc * W_S * 16u, 0x00020000);
+    unsigned gin[NIN];
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) {
+        const int s = tid + i * NTHREADS;
+        const int pix = s >> 1, q = s & 1;
+        const int r = pix / IW, c = pix - r * IW;
+        const int gr = oy0 * SH - 1 + r;
+        int gc = ox0 - 1 + c;
+        bool ok = (s < IN_S) && gr >= 0 && gr < p.H;
+        if (p.circ) {
+            gc %= p.W;
+            if (gc < 0) gc += p.W;
+        } else {
+            ok = ok && gc >= 0 && gc < p.W;
+        }
+        gin[i] = ok ? (unsigned)((((size_t)gr * p.W + gc) * p.Cin + q * 8) * 2) : OOR;
+    }
+    const unsigned gwoff = (unsigned)tid * 16u;
+
+    u32x4 rin[NIN], rw[NWT];
+    auto load_stage = [&](int kc) {
+#pragma unroll
+        for (int i = 0; i < NIN; ++i) rin[i] = __builtin_amdgcn_raw_buffer_load_b128(in_rs, gin[i], (unsigned)kc * 32u, 0);
+        const unsigned wbase = (unsigned)kc * W_S * 16u;
+#pragma unroll
+        for (int i = 0; i < NWT; ++i) rw[i] = __builtin_amdgcn_raw_buffer_load_b128(w_rs, gwoff, wbase + (unsigned)i * (NTHREADS * 16u), 0);
+    };
+    auto store_stage = [&](int buf) {
+        u32x4* in_s = smem + buf * STAGE_S;
+        u32x4* w_s = in_s + IN_S;
+#pragma unroll
+        for (int i = 0; i < NIN; ++i) {
+            const int s = tid + i * NTHREADS;
+            u32x4* dst = (NIN * NTHREADS == IN_S || s < IN_S) ? in_s + (s & 1) * (IH * IW) + (s >> 1) : smem + 2 * STAGE_S;
+            *dst = rin[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NWT; ++i) {
+            const int s = tid + i * NTHREADS;
+            u32x4* dst = (NWT * NTHREADS == W_S || s < W_S) ? w_s + s : smem + 2 * STAGE_S;
+            *dst = rw[i];
+        }
+    };
+
+    const int wm = (TN == 128) ? (wave >> 1) : wave;
+    const int wn = (TN == 128) ? (wave & 1) : 0;
+    int trow[WM], tcol[WM];
+#pragma unroll
+    for (int mt = 0; mt < WM; ++mt) {
+        if (TN == 128) {
+            trow[mt] = 2 * wm + (mt >> 1);
+            tcol[mt] = 32 * (mt & 1);
+        } else {
+            trow[mt] = 2 * (wm >> 1) + mt;
+            tcol[mt] = 32 * (wm & 1);
+        }
+    }
+    int abase[WM];
+#pragma unroll
+    for (int mt = 0; mt < WM; ++mt) abase[mt] = hq * (IH * IW) + trow[mt] * SH * IW + tcol[mt] + l31;
+    const int wbase = hq * TN + wn * 64 + l31;
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < WN; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    u32x4 fa[2][WM], fb[2][WN];
+    auto read_frags = [&](int set, const u32x4* in_s, const u32x4* w_s, int tap) {
+        const int kh = tap / 3, kw = tap - kh * 3;
+#pragma unroll
+        for (int mt = 0; mt < WM; ++mt) fa[set][mt] = in_s[abase[mt] + kh * IW + kw];
+#pragma unroll
+        for (int nt = 0; nt < WN; ++nt) fb[set][nt] = w_s[tap * 2 * TN + wbase + nt * 32];
+    };
+    auto mfma_tap = [&](int set) {
+#pragma unroll
+        for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < WN; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[set][mt]),
+                                                                     __builtin_bit_cast(bf16x8, fb[set][nt]), acc[mt][nt], 0, 0, 0);
+    };
+
+    load_stage(0);
+    store_stage(0);
+    __syncthreads();
+    read_frags(0, smem, smem + IN_S, 0);
+
+    for (int kc = 0; kc < nkc; ++kc) {
+        const int cur = kc & 1;
+        const int kn = (kc + 1 < nkc) ? kc + 1 : kc;
+        const u32x4* in_s = smem + cur * STAGE_S;
+        const u32x4* w_s = in_s + IN_S;
+        const u32x4* in_n = smem + (cur ^ 1) * STAGE_S;
+        load_stage(kn);
+#pragma unroll
+        for (int tap = 0; tap < 8; ++tap) {
+            read_frags((tap + 1) & 1, in_s, w_s, tap + 1);
+            if (tap == 5) store_stage(cur ^ 1);
+            mfma_tap(tap & 1);
+        }
+        __syncthreads();
+        read_frags(1, in_n, in_n + IN_S, 0);
+        mfma_tap(0);
+#pragma unroll
+        for (int mt = 0; mt < WM; ++mt) fa[0][mt] = fa[1][mt];
+#pragma unroll
+        for (int nt = 0; nt < WN; ++nt) fb[0][nt] = fb[1][nt];
+    }
+
+    // ---- epilogue
+    float bv[WN];
+    int nch[WN];
+#pragma unroll
+    for (int nt = 0; nt < WN; ++nt) {
+        nch[nt] = n0 + wn * 64 + nt * 32 + l31;
+        bv[nt] = p.bias[nch[nt]];
+    }
+    auto fin = [&](float v, int nt) {
+        v = v + bv[nt];
+        if (p.relu) v = fmaxf(v, 0.f);
+        return v;
+    };
+    const int Hy = POOL ? (p.Ho >> 1) : p.Ho;
+    const int Wy = POOL ? (p.Wo >> 1) : p.Wo;
+    auto emit = [&](float v, int nt, int yy, int xx) {
+        v = fin(v, nt);
+        if (yy < Hy && xx < Wy && nch[nt] < p.Cout) {
+            if (p.out_nchw_f32)
+                reinterpret_cast<float*>(p.y)[(((size_t)b * p.Cout + nch[nt]) * Hy + yy) * Wy + xx] = v;
+            else
+                reinterpret_cast<__bf16*>(p.y)[(((size_t)b * Hy + yy) * Wy + xx) * p.Cout + nch[nt]] = (__bf16)v;
+        }
+    };
+
+    if (!POOL && !p.out_nchw_f32 && (p.Cout & 7) == 0) {
+        // wide store: fp32 tile -> wave-private LDS slab -> 8 channels (16 B of bf16) per lane
+        float* slab = reinterpret_cast<float*>(smem) + wave * (32 * 64);
+        const int prow = lane >> 3, pc8 = (lane & 7) * 8;   // read-back role: pixel row in a group of 8, channel octet
+#pragma unroll
+        for (int mt = 0; mt < WM; ++mt) {
+#pragma unroll
+            for (int nt = 0; nt < WN; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    slab[((r & 3) + 8 * (r >> 2) + 4 * hq) * 64 + nt * 32 + l31] = fin(acc[mt][nt][r], nt);
+            const int yy = oy0 + trow[mt];
+            const int nbase = n0 + wn * 64 + pc8;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int m = g * 8 + prow;
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(slab + m * 64 + pc8);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(slab + m * 64 + pc8 + 4);
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o[e] = (__bf16)v0[e];
+                    o[4 + e] = (__bf16)v1[e];
+                }
+                const int xx = ox0 + tcol[mt] + m;
+                if (yy < Hy && xx < Wy && nbase < p.Cout)
+                    *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p.y) + (((size_t)b * Hy + yy) * Wy + xx) * p.Cout + nbase) = o;
+            }
+        }
+    } else if (!POOL) {
+#pragma unroll
+        for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < WN; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = (r & 3) + 8 * (r >> 2) + 4 * hq;
+                    emit(acc[mt][nt][r], nt, oy0 + trow[mt], ox0 + tcol[mt] + m);
+                }
+    } else {
+#pragma unroll
+        for (int pr = 0; pr < WM / 2; ++pr) {
+            const int mtA = (TN == 128) ? (pr & 1) : 0;
+            const int mtB = (TN == 128) ? (2 + (pr & 1)) : 1;
+#pragma unroll
+            for (int nt = 0; nt < WN; ++nt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const float v0 = fmaxf(acc[mtA][nt][4 * g + 2 * e], acc[mtA][nt][4 * g + 2 * e + 1]);
+                        const float v1 = fmaxf(acc[mtB][nt][4 * g + 2 * e], acc[mtB][nt][4 * g + 2 * e + 1]);
+                        const int yy = (oy0 + trow[mtA]) >> 1;
+                        const int xx = ((ox0 + tcol[mtA]) >> 1) + 4 * g + 2 * hq + e;
+                        emit(fmaxf(v0, v1), nt, yy, xx);
+                    }
+        }
+    }
+}
+
+// wpk[nt][kc][tap][g][n][0..7] (bf16) <- w[cout][cin][kh][kw] (fp32, torch KCRS); one thread per 16-B slot
+__global__ void pack_weights_bf16_kernel(const float* __restrict__ w, unsigned short* __restrict__ wpk, int Cout, int Cin,
+                                         int n_tiles, int nkc, int TN) {
+    const size_t total = (size_t)n_tiles * nkc * 9 * 2 * TN;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    size_t t = idx;
+    const int n = t % TN; t /= TN;
+    const int g = t % 2; t /= 2;
+    const int tap = t % 9; t /= 9;
+    const int kc = t % nkc; t /= nkc;
+    const int nt = (int)t;
+    const int kh = tap / 3, kw = tap % 3;
+    const int co = nt * TN + n;
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int ci = kc * 16 + g * 8 + j;
+        const float f = (co < Cout && ci < Cin) ? w[(((size_t)co * Cin + ci) * 3 + kh) * 3 + kw] : 0.f;
+        v[j] = (__bf16)f;
+    }
+    reinterpret_cast<bf16x8*>(wpk)[idx] = v;
+}
+
+// NCHW fp32 [B,C,H,W] -> NHWC bf16 [B,H,W,Cp] (Cp % 16 == 0, extra channels zero)
+__global__ void nchw_f32_to_nhwc_bf16_kernel(const float* __restrict__ x, __bf16* __restrict__ y, int C, int Cp, size_t hw,
+                                             size_t total) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = idx % Cp;
+    const size_t t = idx / Cp;
+    const size_t b = t / hw, r = t - b * hw;
+    y[idx] = (__bf16)((c < C) ? x[(b * C + c) * hw + r] : 0.f);
+}
+
+template <int TN, int SH, bool POOL, int NW>
+int launch_bf_nw(ConvBfArgs a, hipStream_t st) {
+    a.tiles_y = cdiv(a.Ho, NW);
+    const long long grid = (long long)cdiv(a.Cout, TN) * a.B * a.tiles_x * a.tiles_y;
+    if (grid <= 0 || grid > 0x7fffffffLL) {
+        witw_set_error("conv3x3_bf16: grid %lld out of range", grid);
+        return WITW_ERR_INVALID;
+    }
+    hipLaunchKernelGGL((conv3x3_nhwc_bf16_kernel<TN, SH, POOL, NW>), dim3((unsigned)grid), dim3(64 * NW), 0, st, a);
+    WITW_CHECK_LAUNCH("conv3x3_nhwc_bf16");
+    return WITW_OK;
+}
+
+template <int TN, int SH, bool POOL>
+int launch_bf(const ConvBfArgs& a, hipStream_t st) {
+    const long long big = (long long)cdiv(a.Cout, TN) * a.B * a.tiles_x * cdiv(a.Ho, 8);
+    if ((a.Ho % 8) == 0 && big >= 512) return launch_bf_nw<TN, SH, POOL, 8>(a, st);
+    return launch_bf_nw<TN, SH, POOL, 4>(a, st);
+}
+
+}  // namespace
+
+extern "C" {
+
+long long witw_conv3x3_bf16_packed_elems(int cout, int cin) {
+    if (cout <= 0 || cin <= 0) return -1;
+    const int TN = cout >= 128 ? 128 : 64;
+    return (long long)cdiv(cout, TN) * cdiv(cin, 16) * 9 * 2 * TN * 8;
+}
+
+int witw_conv3x3_bf16_pack_weights(const float* w_kcrs, void* wpk_bf16, int cout, int cin, void* stream) {
+    WITW_CHECK_ARG(w_kcrs && wpk_bf16, "bf16 pack_weights: null pointer");
+    WITW_CHECK_ARG(cout > 0 && cin > 0, "bf16 pack_weights: bad shape");
+    const int TN = cout >= 128 ? 128 : 64;
+    const int n_tiles = cdiv(cout, TN), nkc = cdiv(cin, 16);
+    const size_t total = (size_t)n_tiles * nkc * 9 * 2 * TN;
+    hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_kcrs,
+                       (unsigned short*)wpk_bf16, cout, cin, n_tiles, nkc, TN);
+    WITW_CHECK_LAUNCH("bf16 pack_weights");
+    return WITW_OK;
+}
+
+int witw_nchw_f32_to_nhwc_bf16(const float* x, void* y_bf16, int B, int C, int H, int W, int Cpad, void* stream) {
+    WITW_CHECK_ARG(x && y_bf16, "nchw_f32_to_nhwc_bf16: null pointer");
+    WITW_CHECK_ARG(B > 0 && C > 0 && H > 0 && W > 0 && Cpad >= C && (Cpad % 16) == 0, "nchw_f32_to_nhwc_bf16: bad shape");
+    const size_t total = (size_t)B * H * W * Cpad;
+    hipLaunchKernelGGL(nchw_f32_to_nhwc_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       (__bf16*)y_bf16, C, Cpad, (size_t)H * W, total);
+    WITW_CHECK_LAUNCH("nchw_f32_to_nhwc_bf16");
+    return WITW_OK;
+}
+
+// x NHWC bf16 [B,H,W,Cin] (Cin%16==0) -> y NHWC bf16 [B,Hy,Wy,Cout] (or fp32 NCHW [B,Cout,Hy,Wy] if out_nchw_f32).
+int witw_conv3x3_bf16_fwd(const void* x_bf16, const void* wpk_bf16, const float* bias, void* y, int B, int H, int W, int Cin,
+                          int Cout, int stride_h, int pad_circular, int relu, int pool, int out_nchw_f32, void* stream) {
+    WITW_CHECK_ARG(x_bf16 && wpk_bf16 && bias && y, "conv3x3_bf16_fwd: null pointer");
+    WITW_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cout > 0, "conv3x3_bf16_fwd: bad shape");
+    WITW_CHECK_ARG(Cin > 0 && (Cin % 16) == 0, "conv3x3_bf16_fwd: Cin=%d must be a positive multiple of 16", Cin);
+    WITW_CHECK_ARG(stride_h == 1 || stride_h == 2, "conv3x3_bf16_fwd: stride_h=%d unsupported", stride_h);
+    WITW_CHECK_ARG(!(pool && stride_h == 2) && !(pool && out_nchw_f32), "conv3x3_bf16_fwd: unsupported pool combination");
+    WITW_CHECK_ARG((size_t)H * W * Cin * 2 < 0x80000000ull, "conv3x3_bf16_fwd: image too large for one buffer descriptor");
+    ConvBfArgs a;
+    a.x = (const unsigned short*)x_bf16; a.wpk = (const unsigned short*)wpk_bf16; a.bias = bias; a.y = y;
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+    a.Ho = (H + 2 - 3) / stride_h + 1;
+    a.Wo = W;
+    a.tiles_x = cdiv(a.Wo, TW);
+    a.tiles_y = 0;
+    a.circ = pad_circular; a.relu = relu; a.out_nchw_f32 = out_nchw_f32;
+    hipStream_t st = (hipStream_t)stream;
+    if (Cout >= 128) {
+        if (stride_h == 2) return launch_bf<128, 2, false>(a, st);
+        return pool ? launch_bf<128, 1, true>(a, st) : launch_bf<128, 1, false>(a, st);
+    }
+    if (stride_h == 2) return launch_bf<64, 2, false>(a, st);
+    return pool ? launch_bf<64, 1, true>(a, st) : launch_bf<64, 1, false>(a, st);
+}
+
+}  // extern "C"

@@ -154,6 +154,32 @@ class FOV_DSM(torch.nn.Module):
             h = y
         return h, kept
 
+    def _pack_bf16(self, idx):
+        conv = _conv_of(self.model.features[idx])
+        key = (conv.weight.data_ptr(), conv.weight._version, conv.bias._version, getattr(conv.weight, '_witw_version', 0),
+               getattr(conv.bias, '_witw_version', 0))
+        hit = self._packed.get(('bf16', idx))
+        if hit is None or hit[0] != key:
+            hit = (key, ops.PackedConvBf16(conv.weight, conv.bias))
+            self._packed[('bf16', idx)] = hit
+        return hit[1]
+
+    def forward_bf16(self, x):
+        """Inference on the bf16 MFMA kernels (bf16 activations and filters, fp32 accumulate, fp32 embedding
+        out): the 'bf16 MFMA' configuration of BASELINE.json. Not bit-comparable with the fp32 path — see
+        tests/test_bf16_gpu.py for the stated tolerance. Eval only."""
+        if not x.is_cuda:
+            raise _lib.WitwError('FOV_DSM.forward_bf16 needs a GPU tensor (no CPU fallback)')
+        if self.training:
+            raise _lib.WitwError('forward_bf16 is an inference path; call .eval()')
+        with torch.no_grad():
+            h = ops.nchw_to_nhwc_bf16(x.contiguous(), 16)
+            last = self.layer_specs[-1][0]
+            for (idx, sh, relu, pool, drop) in self.layer_specs:
+                h = ops.conv3x3_bf16_fwd(h, self._pack_bf16(idx), stride_h=sh, circular=self.circ_padding, relu=relu,
+                                         pool=pool, out_nchw_f32=(idx == last))
+        return h
+
     def trainable_convs(self):
         return [(idx, _conv_of(self.model.features[idx])) for (idx, *_r) in self.layer_specs
                 if _conv_of(self.model.features[idx]).weight.requires_grad]

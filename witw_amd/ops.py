@@ -442,3 +442,59 @@ def exhaustive_triplet_loss(D, soft_margin=False, alpha=10., margin=1.):
     _lib.check(lib.witw_exhaustive_triplet_loss(D.data_ptr(), B, int(soft_margin), float(alpha), float(margin),
                                                 loss.data_ptr(), ws.data_ptr(), _stream()), 'witw_exhaustive_triplet_loss')
     return loss.reshape(())
+
+
+# ----------------------------------------------------------------------------- bf16 inference path
+class PackedConvBf16:
+    """bf16 filter packing of one 3x3 conv for the bf16 MFMA kernel + fp32 bias padded to the channel tile."""
+
+    def __init__(self, weight, bias):
+        lib = _lib.load()
+        w = _dev_f32(weight.detach(), 'weight')
+        self.cout, self.cin = w.shape[0], w.shape[1]
+        self.cin_pad = (self.cin + 15) // 16 * 16
+        self.wpk = torch.empty(lib.witw_conv3x3_bf16_packed_elems(self.cout, self.cin), dtype=torch.bfloat16, device=w.device)
+        _lib.check(lib.witw_conv3x3_bf16_pack_weights(w.data_ptr(), self.wpk.data_ptr(), self.cout, self.cin, _stream()),
+                   'witw_conv3x3_bf16_pack_weights')
+        self.bias = torch.zeros(lib.witw_conv3x3_bias_floats(self.cout), dtype=torch.float32, device=w.device)
+        if bias is not None:
+            self.bias[:self.cout].copy_(bias.detach())
+
+
+def nchw_to_nhwc_bf16(x, cpad=16):
+    lib = _lib.load()
+    x = _dev_f32(x, 'x')
+    B, C, H, W = x.shape
+    y = torch.empty((B, H, W, cpad), dtype=torch.bfloat16, device=x.device)
+    _lib.check(lib.witw_nchw_f32_to_nhwc_bf16(x.data_ptr(), y.data_ptr(), B, C, H, W, cpad, _stream()),
+               'witw_nchw_f32_to_nhwc_bf16')
+    return y
+
+
+def conv3x3_bf16_fwd(x_nhwc, packed, stride_h=1, circular=False, relu=True, pool=False, out_nchw_f32=False):
+    lib = _lib.load()
+    if not (x_nhwc.is_cuda and x_nhwc.dtype == torch.bfloat16 and x_nhwc.is_contiguous()):
+        raise _lib.WitwError('conv3x3_bf16_fwd: x must be a contiguous bfloat16 GPU tensor')
+    B, H, W, C = x_nhwc.shape
+    if C != packed.cin_pad:
+        raise _lib.WitwError('conv3x3_bf16_fwd: input has %d channels, packed weights expect %d' % (C, packed.cin_pad))
+    Ho = (H + 2 - 3) // stride_h + 1
+    Hy, Wy = (Ho // 2, W // 2) if pool else (Ho, W)
+    if out_nchw_f32:
+        y = torch.empty((B, packed.cout, Hy, Wy), dtype=torch.float32, device=x_nhwc.device)
+    else:
+        if packed.cout % 16:
+            raise _lib.WitwError('conv3x3_bf16_fwd: a bf16 NHWC output needs Cout %% 16 == 0 (next layer\'s K chunk)')
+        y = torch.empty((B, Hy, Wy, packed.cout), dtype=torch.bfloat16, device=x_nhwc.device)
+    prof = PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.check(lib.witw_conv3x3_bf16_fwd(x_nhwc.data_ptr(), packed.wpk.data_ptr(), packed.bias.data_ptr(), y.data_ptr(), B, H,
+                                         W, C, packed.cout, stride_h, int(circular), int(relu), int(pool), int(out_nchw_f32),
+                                         _stream()), 'witw_conv3x3_bf16_fwd')
+    if prof is not None:
+        e1.record()
+        prof.append((('bf16', lib.witw_conv3x3_tile_n(packed.cout), stride_h, bool(pool)),
+                     2.0 * packed.cin * packed.cout * 9 * Ho * W * B, e0, e1))
+    return y
