@@ -28,6 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 MFMA
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # same table, dense bf16 MFMA (no sparsity)
 DOMINANT = (128, 1, False, 8)  # conv3x3_nhwc_f32_kernel<128,1,false,8>: layers 5,10,12,17,19,21 at B=128
 
 
@@ -56,6 +57,8 @@ def main():
     ap.add_argument('--fov', type=int, default=360)
     ap.add_argument('--mode', choices=['infer', 'train'], default='infer',
                     help='infer (headline): embedding + similarity; train: the full step of model/cvig_fov.py:444-461')
+    ap.add_argument('--precision', choices=['fp32', 'bf16'], default='fp32',
+                    help='fp32 (headline, BASELINE configs[1]) or the bf16 MFMA inference path (configs[3] arithmetic)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL); gloo only for 1-GPU self-tests')
     ap.add_argument('--single-device', action='store_true', help='self-test: put every rank on cuda:0')
@@ -88,6 +91,9 @@ def main():
     surface_encoder = cvig_fov.FOV_DSM(circ_padding=False, weights=wts).to(device)
     overhead_encoder = cvig_fov.FOV_DSM(circ_padding=True, weights=wts).to(device)
     train = a.mode == 'train'
+    bf16 = a.precision == 'bf16'
+    if bf16 and train:
+        sys.exit('the bf16 path is inference only')
     surface_encoder.train(train)
     overhead_encoder.train(train)
     all_params = list(surface_encoder.parameters()) + list(overhead_encoder.parameters())
@@ -121,8 +127,8 @@ def main():
             surface = ops.resize_bilinear(ground_raw, (128, ws), mean, std)
             overhead = ops.resize_bilinear(ov_raw, (256, 256), mean, std)
             polar = ops.polar_transform(overhead)
-            su = surface_encoder(surface)
-            ov = overhead_encoder(polar)
+            su = surface_encoder.forward_bf16(surface) if bf16 else surface_encoder(surface)
+            ov = overhead_encoder.forward_bf16(polar) if bf16 else overhead_encoder(polar)
             ov_all = parallel._all_gather_cat(ov) if world > 1 else ov     # global gallery; surfaces stay local
             loss, ranks, ori, d = cvig_fov.evaluate_global_batch(ov_all, su, rank * B)
         return loss, ranks, ori
@@ -155,7 +161,10 @@ def main():
     value = pairs / dt
 
     # ---- live roofline of the dominant kernel (HIP events on the launch stream, timed region only)
-    dom = [(fl, e0.elapsed_time(e1)) for (v, fl, e0, e1) in prof if v == DOMINANT]
+    dominant = ('bf16', 128, 1, False) if bf16 else DOMINANT
+    peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
+    kname = 'conv3x3_nhwc_bf16_kernel<128,1,false,8>' if bf16 else 'conv3x3_nhwc_f32_kernel<128,1,false,8>'
+    dom = [(fl, e0.elapsed_time(e1)) for (v, fl, e0, e1) in prof if v == dominant]
     allc = [(fl, e0.elapsed_time(e1)) for (v, fl, e0, e1) in prof]
     dom_fl = sum(f for f, _ in dom) / max(1, len(dom))
     dom_ms = sum(m for _, m in dom) / max(1, len(dom))
@@ -165,16 +174,16 @@ def main():
     tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get('conv3x3_nhwc_f32_kernel<128,1,false,8>_bytes_per_launch_B%d' % B)
+            traffic = json.load(open(tpath)).get('%s_bytes_per_launch_B%d' % (kname, B))
         except Exception:
             traffic = None
 
     out = {
         'metric': 'image-pairs/sec (embedding+similarity)' if not train else 'image-pairs/sec (training step)', 'value': round(value, 2), 'unit': 'pairs/s',
         'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 3),
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': ('cvig_fov fov=%d eval: resize+normalize+polar -> 2x FOV_DSM (VGG16[:23]+3 conv) -> '
-                                'fused match + soft-margin triplet loss + rank counts' % a.fov) if not train else
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16' if bf16 else 'f32', 'data': 'synthetic',
+        'config': {'workload': ('cvig_fov fov=%d eval%s: resize+normalize+polar -> 2x FOV_DSM (VGG16[:23]+3 conv) -> '
+                                'fused match + soft-margin triplet loss + rank counts' % (a.fov, ' [bf16 MFMA encoders, fp32 accumulate; matching fp32]' if bf16 else '')) if not train else
                                ('cvig_fov fov=%d TRAIN step: resize+normalize+polar -> 2x FOV_DSM fwd (Dropout2d) -> match + '
                                 'triplet loss -> backward (dgrad L19-27, wgrad L17-27) -> grad all-reduce -> Adam' % a.fov),
                    'pairs_per_gpu': B, 'global_batch': B * world, 'ground_raw': '3x224x224', 'overhead_raw': '3x512x512',
@@ -182,13 +191,13 @@ def main():
         'recall': {'top1_pct': float(np.mean(ranks_h <= 1) * 100), 'top5_pct': float(np.mean(ranks_h <= 5) * 100),
                    'N': int(len(ranks_h))},
         'loss': float(loss.item()),
-        'roofline': {'bound': 'mfma', 'kernel': 'conv3x3_nhwc_f32_kernel<128,1,false,8>', 'achieved': round(achieved, 2),
-                     'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+        'roofline': {'bound': 'mfma', 'kernel': kname, 'achieved': round(achieved, 2),
+                     'peak': peak, 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
                      'traffic': traffic, 'launches': len(dom), 'avg_launch_ms': round(dom_ms, 4),
                      'avg_launch_gflop': round(dom_fl / 1e9, 2), 'all_conv_launches_tflops': round(conv_tf, 2)},
     }
 
-    if rank == 0 and world == 1 and not a.no_cpu_baseline and not train:
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and not train and not bf16:
         out['cpu_baseline'] = cpu_baseline(a, ground_raw, ov_raw, wts, ws, step)
     if rank == 0:
         print(json.dumps(out), flush=True)
