@@ -27,8 +27,22 @@ def stale():
 
 
 def build(force=False, verbose=True):
+    """Compile and link; serialised across processes with a file lock (N ranks may import at once)."""
     if not force and not stale():
         return LIB
+    import fcntl
+    os.makedirs(os.path.join(HERE, 'build'), exist_ok=True)
+    with open(os.path.join(HERE, 'build', '.lock'), 'w') as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not stale():      # another process built it while we waited
+                return LIB
+            return _build_locked(verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(verbose):
     objs = []
     procs = []
     os.makedirs(os.path.join(HERE, 'build'), exist_ok=True)
@@ -42,10 +56,12 @@ def build(force=False, verbose=True):
     for cmd, p in procs:
         if p.wait() != 0:
             raise RuntimeError('hipcc failed: ' + ' '.join(cmd))
-    cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+    tmp = LIB + '.tmp.%d' % os.getpid()
+    cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', tmp] + objs
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.check_call(cmd)
+    os.replace(tmp, LIB)                       # atomic: a concurrent dlopen never sees a half-written file
     return LIB
 
 
