@@ -1,0 +1,104 @@
+"""Size-independent properties at BASELINE.json's full sizes (B = 128 pairs, fov 360; the oracle is too slow
+there): equivariances and invariances the reference's algorithm guarantees exactly or to rounding."""
+import numpy as np
+import pytest
+import torch
+
+from witw_amd import synth
+
+pytestmark = pytest.mark.gpu
+B = 128
+
+
+@pytest.fixture(scope='module')
+def encoders():
+    from witw_amd import cvig_fov
+    w = synth.fov_dsm_weights(11)
+    dev = torch.device('cuda:0')
+    return (cvig_fov.FOV_DSM(False, weights=w).to(dev).eval(), cvig_fov.FOV_DSM(True, weights=w).to(dev).eval())
+
+
+@pytest.fixture(scope='module')
+def batch():
+    x = torch.from_numpy(synth.normalized_images(12, 0, (B, 3, 128, 512)))
+    return x.cuda()
+
+
+def test_circular_encoder_is_shift_equivariant(encoders, batch):
+    """HorizCircPadding (model/cvig_fov.py:212-231) + three 2x2 pools: rolling the polar image by 8k columns
+    rolls the overhead embedding by k columns — exactly (same products, same order)."""
+    _s, ov_enc = encoders
+    with torch.no_grad():
+        e0 = ov_enc(batch)
+        e1 = ov_enc(torch.roll(batch, shifts=8 * 5, dims=3).contiguous())
+    assert e0.shape == (B, 16, 4, 64)
+    assert torch.equal(torch.roll(e0, shifts=5, dims=3), e1)
+
+
+def test_batch_composition_does_not_change_an_embedding(encoders, batch):
+    """No BatchNorm in FOV_DSM: sample i's embedding is the same in a batch of 128 (8-wave workgroups) and
+    alone (4-wave workgroups); the K order per output is identical, so the match is exact."""
+    s_enc, ov_enc = encoders
+    with torch.no_grad():
+        for enc in (s_enc, ov_enc):
+            full = enc(batch)
+            for i in (0, 77, 127):
+                assert torch.equal(enc(batch[i:i + 1].contiguous())[0], full[i])
+
+
+def test_match_orientation_tracks_a_rolled_gallery(encoders, batch):
+    """correlation (:297-315): rolling an overhead embedding by -s columns moves every arg-max by -s (mod 64)
+    and leaves the chord distance unchanged (same window, same products)."""
+    from witw_amd import ops
+    s_enc, ov_enc = encoders
+    with torch.no_grad():
+        su, ov = s_enc(batch), ov_enc(batch)
+        ori0, d0, s0 = ops.match_fwd(ov, su, want_score=True)
+        ori1, d1, s1 = ops.match_fwd(torch.roll(ov, shifts=-9, dims=3).contiguous(), su, want_score=True)
+    assert ori0.shape == (B, B)
+    assert torch.equal(s0, s1)                                   # the maximal correlation is bit-identical
+    same = ((ori0 - 9) % 64) == ori1
+    # the only admissible difference: two shifts tie EXACTLY and the first-index rule picks the other one
+    assert same.float().mean() > 0.999
+    np.testing.assert_allclose(d1[same].cpu().numpy(), d0[same].cpu().numpy(), rtol=0, atol=2e-6)
+
+
+def test_ranks_invariants_full_batch(encoders, batch):
+    from witw_amd import cvig_fov, ops
+    s_enc, ov_enc = encoders
+    with torch.no_grad():
+        su, ov = s_enc(batch), ov_enc(batch)
+        _, d = cvig_fov.match(ov, su)
+        r = ops.rank_count(d, 0).cpu().numpy()
+        loss, r2, _o, _d = cvig_fov.evaluate_global_batch(ov, su, 0)
+    assert r.min() >= 1 and r.max() <= B                      # the true match always counts itself
+    dn = d.cpu().numpy()
+    np.testing.assert_array_equal(r, (dn <= np.diag(dn)[None, :]).sum(0))
+    np.testing.assert_array_equal(r2.cpu().numpy(), r)
+    v, i = ops.topk_smallest(d, 5)
+    assert torch.all(v[:, 1:] >= v[:, :-1])                   # sorted
+    np.testing.assert_array_equal(i[:, 0].cpu().numpy(), dn.argmin(0))
+    assert abs(loss.item() - cvig_fov.triplet_loss(d).item()) < 1e-6
+
+
+def test_training_reduces_the_loss():
+    """A few Adam steps of the full train loop body (model/cvig_fov.py:444-461) on one fixed batch lower the loss."""
+    from witw_amd import cvig_fov
+    dev = torch.device('cuda:0')
+    w = synth.fov_dsm_weights(13)
+    se = cvig_fov.FOV_DSM(False, weights=w).to(dev).train()
+    oe = cvig_fov.FOV_DSM(True, weights=w).to(dev).train()
+    opt = cvig_fov.Adam(list(se.parameters()) + list(oe.parameters()), lr=1e-4)
+    xo = torch.from_numpy(synth.normalized_images(14, 0, (16, 3, 128, 512))).to(dev)
+    xs = (xo + 0.3 * torch.from_numpy(synth.normalized_images(14, 1, (16, 3, 128, 512))).to(dev)).contiguous()
+    drops = {i: torch.full((16, 512), 1.0, device=dev) for i in (17, 19, 21)}      # dropout off: deterministic
+    losses = []
+    for _ in range(8):
+        _, d = cvig_fov.match(oe(xo, dropout_scales=drops), se(xs, dropout_scales=drops))
+        loss = cvig_fov.triplet_loss(d)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert all(np.isfinite(losses))
+    assert losses[-1] < losses[0] - 1e-3, losses
