@@ -384,6 +384,44 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_f32_kernel(ConvArgs p) {
                     const int m = (r & 3) + 8 * (r >> 2) + 4 * hq;
                     emit(acc[mt][nt][r], nt, oy0 + trow[mt], ox0 + tcol[mt] + m);
                 }
+    } else if ((p.Cout & 3) == 0 && p.gate == nullptr) {
+        // Fused 2x2 max-pool, wide store: rows (2a, 2a+1) of one column half sit in M-tiles (mtA, mtB) of this
+        // wave; the 16 pooled pixels x 64 channels of the pair go through the wave-private LDS slab and leave
+        // as 16-byte stores (4 pooled pixels x 256 B per wave-instruction).
+        float* slab = reinterpret_cast<float*>(smem) + wave * (32 * 64);
+        const int prow = lane >> 4, pc4 = (lane & 15) * 4;
+#pragma unroll
+        for (int pr = 0; pr < WM / 2; ++pr) {
+            const int mtA = (TN == 128) ? (pr & 1) : 0;       // TN==128: tiles {0,1}=row0 halves, {2,3}=row1
+            const int mtB = (TN == 128) ? (2 + (pr & 1)) : 1;
+            const int yy = (oy0 + trow[mtA]) >> 1;
+            const int xb = (ox0 + tcol[mtA]) >> 1;
+#pragma unroll
+            for (int nt = 0; nt < WN; ++nt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const float a00 = acc[mtA][nt][4 * g + 2 * e], a01 = acc[mtA][nt][4 * g + 2 * e + 1];
+                        const float a10 = acc[mtB][nt][4 * g + 2 * e], a11 = acc[mtB][nt][4 * g + 2 * e + 1];
+                        const float m = fmaxf(fmaxf(a00, a01), fmaxf(a10, a11));
+                        const int pc = 4 * g + 2 * hq + e;
+                        slab[pc * 64 + nt * 32 + l31] = fin(m, nt);
+                        if (p.pool_code != nullptr && yy < Hy && xb + pc < Wy && nch[nt] < p.Cout) {
+                            // first position attaining the max, scan order (0,0),(0,1),(1,0),(1,1) as torch's max_pool2d
+                            const int code = (a00 == m) ? 0 : (a01 == m) ? 1 : (a10 == m) ? 2 : 3;
+                            p.pool_code[(((size_t)b * Hy + yy) * Wy + xb + pc) * p.Cout + nch[nt]] = (unsigned char)code;
+                        }
+                    }
+            const int nbase = n0 + wn * 64 + pc4;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int pc = g * 4 + prow;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(slab + pc * 64 + pc4);
+                if (yy < Hy && xb + pc < Wy && nbase < p.Cout)
+                    *reinterpret_cast<f32x4*>(p.y + (((size_t)b * Hy + yy) * Wy + xb + pc) * p.Cout + nbase) = v;
+            }
+        }
     } else {
         // rows (2a, 2a+1) of one column half sit in M-tiles (mtA, mtB) of this wave
 #pragma unroll

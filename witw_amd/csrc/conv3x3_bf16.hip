@@ -251,6 +251,43 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_bf16_kernel(ConvBfArgs p
                     const int m = (r & 3) + 8 * (r >> 2) + 4 * hq;
                     emit(acc[mt][nt][r], nt, oy0 + trow[mt], ox0 + tcol[mt] + m);
                 }
+    } else if ((p.Cout & 7) == 0) {
+        // fused 2x2 max-pool, wide store through the wave-private slab: 16 pooled pixels x 64 channels per
+        // M-tile pair leave as 16-byte stores of 8 bf16 channels
+        float* slab = reinterpret_cast<float*>(smem) + wave * (32 * 64);
+        const int prow = lane >> 3, pc8 = (lane & 7) * 8;
+#pragma unroll
+        for (int pr = 0; pr < WM / 2; ++pr) {
+            const int mtA = (TN == 128) ? (pr & 1) : 0;
+            const int mtB = (TN == 128) ? (2 + (pr & 1)) : 1;
+            const int yy = (oy0 + trow[mtA]) >> 1;
+            const int xb = (ox0 + tcol[mtA]) >> 1;
+#pragma unroll
+            for (int nt = 0; nt < WN; ++nt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const float v0 = fmaxf(acc[mtA][nt][4 * g + 2 * e], acc[mtA][nt][4 * g + 2 * e + 1]);
+                        const float v1 = fmaxf(acc[mtB][nt][4 * g + 2 * e], acc[mtB][nt][4 * g + 2 * e + 1]);
+                        slab[(4 * g + 2 * hq + e) * 64 + nt * 32 + l31] = fin(fmaxf(v0, v1), nt);
+                    }
+            const int nbase = n0 + wn * 64 + pc8;
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int pc = g * 8 + prow;
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(slab + pc * 64 + pc8);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(slab + pc * 64 + pc8 + 4);
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o[e] = (__bf16)v0[e];
+                    o[4 + e] = (__bf16)v1[e];
+                }
+                if (yy < Hy && xb + pc < Wy && nbase < p.Cout)
+                    *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p.y) + (((size_t)b * Hy + yy) * Wy + xb + pc) * p.Cout + nbase) = o;
+            }
+        }
     } else {
 #pragma unroll
         for (int pr = 0; pr < WM / 2; ++pr) {
