@@ -52,6 +52,13 @@ int witw_conv3x3_fwd(const float* x, const float* wpk, const float* bias, const 
                      int W, int Cin, int Cout, int stride_h, int pad_circular, int relu, int pool, int out_nchw,
                      void* stream);
 
+/* First layer fast path: Conv2d(C<=4 -> 64, 3x3, pad 1)+ReLU straight from the NCHW fp32 image (features[0..1],
+ * model/cvig_fov.py:256-260): wf = witw_conv3x3_first_pack(w [64][C][3][3]) (2560 floats; round_bf16 rounds the
+ * filter to bf16), y = NHWC [B,H,W,64] fp32, or bf16 with bf16-rounded operands when out_bf16. */
+int witw_conv3x3_first_pack(const float* w, float* wf, int C, int round_bf16, void* stream);
+int witw_conv3x3_first_fwd(const float* x, const float* wf, const float* bias, void* y, int B, int C, int H, int W,
+                           int pad_circular, int relu, int out_bf16, void* stream);
+
 /* Extended form used by the backward pass: `gate` (NULL or a tensor shaped like y) zeroes outputs where
  * gate <= 0 (ReLU backward), dilate_h=1 reads the input as zero-interleaved rows (row 2i = physical row i,
  * H is the dilated height) — the data gradient of a stride-(2,1) conv is then this same kernel on the

@@ -122,3 +122,23 @@ def test_semantic_encoder_matches_reference_golden(golden_dir):
     np.testing.assert_allclose(e, g['embed5_circ1'], rtol=0, atol=TOL)
     ref_train = sorted(k for k in g['trainable'] if not k.startswith('model.classifier'))
     assert sorted(n for n, p in enc.named_parameters() if p.requires_grad) == ref_train
+
+
+@pytest.mark.parametrize('shape', [(2, 3, 16, 64, True), (1, 3, 13, 99, False), (2, 4, 8, 130, True), (1, 1, 9, 40, False)])
+def test_first_layer_fast_path_matches_oracle(shape):
+    from witw_amd import ops
+    B, C, H, W, circ = shape
+    x = _rand(11, (B, C, H, W))
+    w = _rand(12, (64, C, 3, 3), scale=(2.0 / (9 * C)) ** 0.5)
+    b = _rand(13, (64,), scale=0.1)
+    ref = torch.relu(O.conv3x3(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(b), 1, circ))
+    dev = torch.device('cuda:0')
+    pk = ops.PackedFirstConv(torch.from_numpy(w).to(dev), torch.from_numpy(b).to(dev))
+    y = ops.conv3x3_first_fwd(torch.from_numpy(x).to(dev), pk, circular=circ).cpu().permute(0, 3, 1, 2)
+    np.testing.assert_allclose(y.numpy(), ref.numpy(), rtol=1e-5, atol=2e-5)
+    pkb = ops.PackedFirstConv(torch.from_numpy(w).to(dev), torch.from_numpy(b).to(dev), bf16=True)
+    yb = ops.conv3x3_first_fwd(torch.from_numpy(x).to(dev), pkb, circular=circ)
+    assert yb.dtype == torch.bfloat16
+    refb = torch.relu(O.conv3x3(torch.from_numpy(x).bfloat16().float(), torch.from_numpy(w).bfloat16().float(),
+                                torch.from_numpy(b), 1, circ)).bfloat16().float()
+    np.testing.assert_allclose(yb.float().cpu().permute(0, 3, 1, 2).numpy(), refb.numpy(), rtol=2 ** -7, atol=1e-6)

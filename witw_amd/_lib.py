@@ -31,6 +31,8 @@ SIGNATURES = {
     'witw_conv3x3_wgrad': (c_int, [c_void_p] * 5 + [c_int] * 9 + [c_void_p]),
     'witw_adam_step': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_float, c_float, c_float, c_float, c_int,
                                c_void_p]),
+    'witw_conv3x3_first_pack': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    'witw_conv3x3_first_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
     'witw_conv3x3_bf16_packed_elems': (c_longlong, [c_int, c_int]),
     'witw_conv3x3_bf16_pack_weights': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     'witw_nchw_f32_to_nhwc_bf16': (c_int, [c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]),

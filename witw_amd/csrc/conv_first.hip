@@ -1,0 +1,191 @@
+// First encoder layer: Conv2d(C<=4 -> 64, 3x3, pad 1) + ReLU straight from the NCHW fp32 image (gfx950).
+//
+// Reference: features[0..1] of the VGG16 trunk (model/cvig_fov.py:256-260) fed by the Dataset's CHW tensors
+// (:90-91). K = 27 is too short for the generic implicit-GEMM kernel, whose 8-channel K chunks would spend
+// 72 MFMA k-steps on 27 products and which needs an NHWC8 copy of the input first. Here the two lane halves
+// of v_mfma_f32_32x32x2_f32 take two different TAPS of the same pixel's (r,g,b,0) float4 instead of two
+// channel groups, so a tile costs 5 tap-pairs x 3 channels = 15 k-steps (20 for 4 channels); the halo tile is gathered from the
+// three NCHW planes directly. The layer is bound by its output stream (64 channels per pixel), which leaves
+// through the same LDS-transposed 16-byte stores as the generic kernel, in fp32 or bf16.
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int FT = 512;            // threads: 8 waves, 8 rows x 64 columns x 64 channels per workgroup
+constexpr int FIW = 66, FIH = 10;
+
+struct FirstArgs {
+    const float* x;      // NCHW [B,C,H,W]
+    const float* wf;     // packed [5 tap pairs][2][64][4]
+    const float* bias;   // [64]
+    void* y;             // NHWC [B,H,W,64] fp32 or bf16
+    int B, C, H, W;
+    int tiles_x, tiles_y;
+    int circ, relu, out_bf16;
+};
+
+__global__ __launch_bounds__(FT, 2) void conv3x3_first_kernel(FirstArgs p) {
+    __shared__ f32x4 smem[4096];                 // 64 KB: [0,660) input tile, [704,1344) weights; slabs alias all of it
+    f32x4* in_s = smem;
+    f32x4* w_s = smem + 704;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hq = lane >> 5;
+    int bid = blockIdx.x;
+    const int tiles_img = p.tiles_x * p.tiles_y;
+    const int b = bid / tiles_img;
+    bid -= b * tiles_img;
+    const int ty = bid / p.tiles_x, tx = bid - ty * p.tiles_x;
+    const int oy0 = ty * 8, ox0 = tx * 64;
+    const size_t plane = (size_t)p.H * p.W;
+
+    for (int s = tid; s < FIH * FIW; s += FT) {
+        const int r = s / FIW, c = s - r * FIW;
+        const int gr = oy0 - 1 + r;
+        int gc = ox0 - 1 + c;
+        bool ok = gr >= 0 && gr < p.H;
+        if (p.circ) {
+            gc %= p.W;
+            if (gc < 0) gc += p.W;
+        } else {
+            ok = ok && gc >= 0 && gc < p.W;
+        }
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (ok) {
+            const float* src = p.x + (size_t)b * p.C * plane + (size_t)gr * p.W + gc;
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch)
+                if (ch < p.C) v[ch] = p.out_bf16 ? (float)(__bf16)src[ch * plane] : src[ch * plane];
+        }
+        in_s[s] = v;
+    }
+    for (int s = tid; s < 640; s += FT) w_s[s] = reinterpret_cast<const f32x4*>(p.wf)[s];
+    __syncthreads();
+
+    // wave -> 2 M-tiles (rows 2*(wave>>1), +1; column half wave&1) x 2 N-tiles
+    const int row0 = 2 * (wave >> 1), col0 = 32 * (wave & 1);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int tapA = 2 * i, tapB = (2 * i + 1 < 9) ? 2 * i + 1 : 0;     // tap 9 does not exist: zero weights
+        const int offA = (tapA / 3) * FIW + tapA % 3, offB = (tapB / 3) * FIW + tapB % 3;
+        const int off = hq ? offB : offA;
+        f32x4 av[2], bw[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) av[mt] = in_s[(row0 + mt) * FIW + col0 + l31 + off];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) bw[nt] = w_s[(i * 2 + hq) * 64 + nt * 32 + l31];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (j == 3 && p.C < 4) break;       // RGB: the 4th channel of every slot is zero (uniform branch)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt][j], bw[nt][j], acc[mt][nt], 0, 0, 0);
+        }
+    }
+    __syncthreads();     // every wave is done with the input / weight images before the slabs overwrite them
+
+    float bv[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) bv[nt] = p.bias[nt * 32 + l31];
+    float* slab = reinterpret_cast<float*>(smem) + wave * (32 * 64);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[mt][nt][r] + bv[nt];
+                if (p.relu) v = fmaxf(v, 0.f);
+                slab[((r & 3) + 8 * (r >> 2) + 4 * hq) * 64 + nt * 32 + l31] = v;
+            }
+        const int yy = oy0 + row0 + mt;
+        if (!p.out_bf16) {
+            const int prow = lane >> 4, pc4 = (lane & 15) * 4;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const int m = g * 4 + prow;
+                const int xx = ox0 + col0 + m;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(slab + m * 64 + pc4);
+                if (yy < p.H && xx < p.W)
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.y) + (((size_t)b * p.H + yy) * p.W + xx) * 64 + pc4) = v;
+            }
+        } else {
+            const int prow = lane >> 3, pc8 = (lane & 7) * 8;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int m = g * 8 + prow;
+                const int xx = ox0 + col0 + m;
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(slab + m * 64 + pc8);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(slab + m * 64 + pc8 + 4);
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o[e] = (__bf16)v0[e];
+                    o[4 + e] = (__bf16)v1[e];
+                }
+                if (yy < p.H && xx < p.W)
+                    *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p.y) + (((size_t)b * p.H + yy) * p.W + xx) * 64 + pc8) = o;
+            }
+        }
+    }
+}
+
+// wf[i][h][n][0..3] = (w[n][0][tap], w[n][1][tap], w[n][2][tap], w[n][3][tap]) with tap = 2i+h (zeros for tap 9
+// and for channels >= C); round_bf16 != 0 rounds the weights to bf16 first (the bf16 path's filters).
+__global__ void pack_first_kernel(const float* __restrict__ w, float* __restrict__ wf, int C, int round_bf16) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 640) return;
+    const int n = idx % 64, h = (idx / 64) % 2, i = idx / 128;
+    const int tap = 2 * i + h;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (tap < 9)
+        for (int ch = 0; ch < C && ch < 4; ++ch) {
+            float f = w[((size_t)n * C + ch) * 9 + tap];
+            if (round_bf16) f = (float)(__bf16)f;
+            v[ch] = f;
+        }
+    reinterpret_cast<f32x4*>(wf)[idx] = v;
+}
+
+}  // namespace
+
+extern "C" {
+
+// w: torch layout [64][C][3][3], C <= 4 -> wf: 2560 floats
+int witw_conv3x3_first_pack(const float* w, float* wf, int C, int round_bf16, void* stream) {
+    WITW_CHECK_ARG(w && wf, "conv3x3_first_pack: null pointer");
+    WITW_CHECK_ARG(C >= 1 && C <= 4, "conv3x3_first_pack: C=%d outside [1,4]", C);
+    hipLaunchKernelGGL(pack_first_kernel, dim3(3), dim3(256), 0, (hipStream_t)stream, w, wf, C, round_bf16);
+    WITW_CHECK_LAUNCH("conv3x3_first_pack");
+    return WITW_OK;
+}
+
+// x NCHW fp32 [B,C,H,W] (C <= 4) -> y NHWC [B,H,W,64] (fp32, or bf16 if out_bf16; with out_bf16 the INPUT is
+// rounded to bf16 on load so that the arithmetic equals the bf16 path's: bf16 operands, fp32 accumulate).
+int witw_conv3x3_first_fwd(const float* x, const float* wf, const float* bias, void* y, int B, int C, int H, int W,
+                           int pad_circular, int relu, int out_bf16, void* stream) {
+    WITW_CHECK_ARG(x && wf && bias && y, "conv3x3_first_fwd: null pointer");
+    WITW_CHECK_ARG(B > 0 && C >= 1 && C <= 4 && H > 0 && W > 0, "conv3x3_first_fwd: bad shape B=%d C=%d H=%d W=%d", B, C, H, W);
+    FirstArgs a;
+    a.x = x; a.wf = wf; a.bias = bias; a.y = y;
+    a.B = B; a.C = C; a.H = H; a.W = W;
+    a.tiles_x = cdiv(W, 64); a.tiles_y = cdiv(H, 8);
+    a.circ = pad_circular; a.relu = relu; a.out_bf16 = out_bf16;
+    const long long grid = (long long)B * a.tiles_x * a.tiles_y;
+    WITW_CHECK_ARG(grid <= 0x7fffffffLL, "conv3x3_first_fwd: grid too large");
+    hipLaunchKernelGGL(conv3x3_first_kernel, dim3((unsigned)grid), dim3(FT), 0, (hipStream_t)stream, a);
+    WITW_CHECK_LAUNCH("conv3x3_first_fwd");
+    return WITW_OK;
+}
+
+}  // extern "C"

@@ -141,10 +141,14 @@ class FOV_DSM(torch.nn.Module):
     def _run(self, x, scales, keep_from=None):
         """Layer stack. Returns (embedding NCHW, kept) where kept[idx] = (layer input NHWC, layer output NHWC,
         max-pool arg-max codes or None) for every layer idx >= keep_from (what the backward needs)."""
-        h = ops.nchw_to_nhwc8(x.contiguous())
+        fast0 = self.in_channels <= 4 and (keep_from is None or keep_from > 0)
+        h = x.contiguous() if fast0 else ops.nchw_to_nhwc8(x.contiguous())
         last = self.layer_specs[-1][0]
         kept = {}
         for (idx, sh, relu, pool, drop) in self.layer_specs:
+            if idx == 0 and fast0:     # C<=4 -> 64 straight from NCHW (layer 0 is frozen: nothing to keep)
+                h = ops.conv3x3_first_fwd(h, self._pack_first(False), circular=self.circ_padding, relu=relu)
+                continue
             keep = keep_from is not None and idx >= keep_from
             out = ops.conv3x3_fwd(h, self._pack(idx), stride_h=sh, circular=self.circ_padding, relu=relu, pool=pool,
                                   out_nchw=(idx == last), drop_scale=scales.get(idx), want_pool_code=(keep and pool))
@@ -153,6 +157,16 @@ class FOV_DSM(torch.nn.Module):
                 kept[idx] = (h, y, code)
             h = y
         return h, kept
+
+    def _pack_first(self, bf16):
+        conv = _conv_of(self.model.features[0])
+        key = (conv.weight.data_ptr(), conv.weight._version, conv.bias._version, getattr(conv.weight, '_witw_version', 0),
+               getattr(conv.bias, '_witw_version', 0))
+        hit = self._packed.get(('first', bf16))
+        if hit is None or hit[0] != key:
+            hit = (key, ops.PackedFirstConv(conv.weight, conv.bias, bf16=bf16))
+            self._packed[('first', bf16)] = hit
+        return hit[1]
 
     def _pack_bf16(self, idx):
         conv = _conv_of(self.model.features[idx])
@@ -173,9 +187,13 @@ class FOV_DSM(torch.nn.Module):
         if self.training:
             raise _lib.WitwError('forward_bf16 is an inference path; call .eval()')
         with torch.no_grad():
-            h = ops.nchw_to_nhwc_bf16(x.contiguous(), 16)
+            fast0 = self.in_channels <= 4
+            h = x.contiguous() if fast0 else ops.nchw_to_nhwc_bf16(x.contiguous(), 16)
             last = self.layer_specs[-1][0]
             for (idx, sh, relu, pool, drop) in self.layer_specs:
+                if idx == 0 and fast0:
+                    h = ops.conv3x3_first_fwd(h, self._pack_first(True), circular=self.circ_padding, relu=relu)
+                    continue
                 h = ops.conv3x3_bf16_fwd(h, self._pack_bf16(idx), stride_h=sh, circular=self.circ_padding, relu=relu,
                                          pool=pool, out_nchw_f32=(idx == last))
         return h

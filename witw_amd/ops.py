@@ -54,6 +54,41 @@ class PackedConv:
             self.bias[:cout].copy_(bias.detach())
 
 
+class PackedFirstConv:
+    """Filter of the first layer (C<=4 -> 64) packed for witw_conv3x3_first_fwd; bf16=True rounds it to bf16."""
+
+    def __init__(self, weight, bias, bf16=False):
+        lib = _lib.load()
+        w = _dev_f32(weight.detach(), 'weight')
+        if w.shape[0] != 64 or w.shape[1] > 4:
+            raise _lib.WitwError('PackedFirstConv: expects a [64, C<=4, 3, 3] filter')
+        self.cin, self.bf16 = w.shape[1], bool(bf16)
+        self.wf = torch.empty(2560, dtype=torch.float32, device=w.device)
+        _lib.check(lib.witw_conv3x3_first_pack(w.data_ptr(), self.wf.data_ptr(), self.cin, int(self.bf16), _stream()),
+                   'witw_conv3x3_first_pack')
+        self.bias = bias.detach().to(torch.float32).contiguous().clone()
+
+
+def conv3x3_first_fwd(x_nchw, packed, circular=False, relu=True):
+    """x NCHW fp32 [B,C<=4,H,W] -> NHWC [B,H,W,64] (fp32, or bf16 when packed.bf16)."""
+    lib = _lib.load()
+    x = _dev_f32(x_nchw, 'x')
+    B, C, H, W = x.shape
+    if C != packed.cin:
+        raise _lib.WitwError('conv3x3_first_fwd: input has %d channels, filter expects %d' % (C, packed.cin))
+    y = torch.empty((B, H, W, 64), dtype=torch.bfloat16 if packed.bf16 else torch.float32, device=x.device)
+    prof = PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.check(lib.witw_conv3x3_first_fwd(x.data_ptr(), packed.wf.data_ptr(), packed.bias.data_ptr(), y.data_ptr(), B, C, H, W,
+                                          int(circular), int(relu), int(packed.bf16), _stream()), 'witw_conv3x3_first_fwd')
+    if prof is not None:
+        e1.record()
+        prof.append((('first', packed.bf16), 2.0 * C * 64 * 9 * H * W * B, e0, e1))
+    return y
+
+
 def nchw_to_nhwc8(x):
     lib = _lib.load()
     x = _dev_f32(x, 'x')
