@@ -253,9 +253,10 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 
 }  // namespace
 
-// pixels summed by one bias-gradient workgroup: ~512 workgroups, at least 64 pixels each
+// pixels summed by one bias-gradient workgroup: ~128 workgroups (the finish kernel walks the partials
+// serially per channel), at least 64 pixels each
 static int bias_rows_per_block(size_t npix) {
-    size_t r = (npix + 511) / 512;
+    size_t r = (npix + 127) / 128;
     if (r < 64) r = 64;
     return (int)r;
 }
