@@ -133,12 +133,13 @@ int witw_conv3x3_bf16_fwd(const void* x_bf16, const void* wpk_bf16, const float*
 /* ---- cvig_baseline (model/cvig_baseline.py). Conv2d(k=4,s=2,p=0) = the 3x3 kernel above on the
  * space-to-depth(2) image with a filter whose first tap row/column is zero. */
 /* x NHWC [B,Hp,Wp,C] (NCHW if in_nchw) with valid region HxW -> NHWC [B,ceil(H/2),ceil(W/2),Cpad], channel
- * (dy*2+dx)*C+c; normalize=1 applies x/255, -1+2x (:265-266). */
+ * (dy*2+dx)*C+c; normalize=1 applies x/255, -1+2x (:265-266); scale/shift (NULL or [C]): per-channel affine of a
+ * train-mode BatchNorm applied on the fly (also accepted by witw_gem_pool). */
 int witw_space_to_depth2(const float* x, float* y, int B, int Hp, int Wp, int H, int W, int C, int Cpad, int in_nchw,
-                         int normalize, void* stream);
+                         int normalize, const float* scale, const float* shift, void* stream);
 /* f[b,col0+c] = (mean relu(x)^p)^(1/p) over the valid HxW region (:276-282); f has row length ldf. */
 int witw_gem_pool(const float* x, float* f, int B, int Hp, int Wp, int H, int W, int C, int ldf, int col0, float p,
-                  void* stream);
+                  const float* scale, const float* shift, void* stream);
 /* f[b,:] /= sqrt(|f[b,:]|_2) in place (:284) */
 int witw_embed_normalize(float* f, int B, int n, void* stream);
 /* D[i][j] = |a_i - b_j|^2 (or its square root: Euclidean ranking distance of :457-458) */
@@ -146,6 +147,30 @@ int witw_pairwise_sqdist(const float* a, const float* b, float* D, int Na, int N
 /* exhaustive_minibatch_triplet_loss (:286-315) from D[i][j] = |embed1_i - embed2_j|^2; workspace B floats */
 int witw_exhaustive_triplet_loss(const float* D, int B, int soft_margin, float alpha, float margin, float* loss,
                                  float* workspace, void* stream);
+
+/* training mode of cvig_baseline (BatchNorm2d batch statistics, autograd of :267-315) */
+long long witw_bn_workspace_floats(int B, int H, int W, int C);
+/* batch mean / biased variance over the valid HxW region of a [B,Hp,Wp,C] tensor -> mean, invstd, and the affine
+ * y = a*scale + shift; running_mean/var (may be NULL) are updated with `momentum` and the unbiased variance. */
+int witw_bn_train_stats(const float* a, int B, int Hp, int Wp, int H, int W, int C, const float* gamma, const float* beta,
+                        float eps, float momentum, float* mean, float* invstd, float* scale, float* shift, float* running_mean,
+                        float* running_var, float* workspace, void* stream);
+/* backward of y = BatchNorm_train(LeakyReLU(z)): a = LeakyReLU(z) as saved, dy at y -> dz (0 outside the valid region),
+ * dgamma, dbeta. */
+int witw_bn_lrelu_bwd(const float* a, const float* dy, float* dz, float* dgamma, float* dbeta, const float* mean,
+                      const float* invstd, const float* gamma, int B, int Hp, int Wp, int H, int W, int C, float slope,
+                      float* workspace, void* stream);
+/* inverse of witw_space_to_depth2 for gradients: g [B,ceil(H/2),ceil(W/2),Cpad] -> dx [B,Hp,Wp,C] (+ add, may be NULL) */
+int witw_depth_to_space2(const float* g, const float* add, float* dx, int B, int Hp, int Wp, int H, int W, int C, int Cpad,
+                         void* stream);
+int witw_gem_pool_bwd(const float* a, const float* scale, const float* shift, const float* f, const float* df, float* dy, int B,
+                      int Hp, int Wp, int H, int W, int C, int ldf, int col0, float p, int accumulate, void* stream);
+/* g: un-normalised feature [B,n], df: gradient at g/sqrt(|g|) -> dg */
+int witw_embed_normalize_bwd(const float* g, const float* df, float* dg, int B, int n, void* stream);
+/* backward of witw_pairwise_sqdist + witw_exhaustive_triplet_loss; workspace B*B floats */
+int witw_exhaustive_triplet_loss_bwd(const float* e1, const float* e2, const float* D, const float* grad_loss, float* de1,
+                                     float* de2, int B, int n, int soft_margin, float alpha, float margin, float* workspace,
+                                     void* stream);
 
 /* ---- data path: Resize (:100-134), ImageNormalization (:137-149; semantic: cvig_semantic.py:167-176),
  *      PolarTransform (:156-209). NCHW fp32. mean/stdv: HOST arrays of C floats (NULL = resize only). */

@@ -6,8 +6,9 @@ import torch
 import torch.nn.functional as F
 
 
-def encoder_forward(x, params, p=3.):
-    """SurfaceEncoder.forward, model/cvig_baseline.py:264-279, eval-mode BatchNorm.
+def encoder_forward(x, params, p=3., train=False):
+    """SurfaceEncoder.forward, model/cvig_baseline.py:264-279. eval-mode BatchNorm by default; train=True uses batch
+    statistics and updates params[i]['mean'/'var'] in place (momentum 0.1), as nn.BatchNorm2d does under .train().
     params: list of 7 dicts {w,b,gamma,beta,mean,var}."""
     x = x / 255.
     x = -1. + 2. * x
@@ -15,7 +16,7 @@ def encoder_forward(x, params, p=3.):
     for i, q in enumerate(params):
         x = F.conv2d(x, q['w'], q['b'], stride=2, padding=0)
         x = F.leaky_relu(x, 0.2)
-        x = F.batch_norm(x, q['mean'], q['var'], q['gamma'], q['beta'], training=False, momentum=0.1, eps=1e-5)
+        x = F.batch_norm(x, q['mean'], q['var'], q['gamma'], q['beta'], training=train, momentum=0.1, eps=1e-5)
         if i >= 4:
             feats.append(torch.pow(torch.mean(torch.pow(F.relu(x), p), [2, 3]), 1. / p))
     f = torch.cat(feats, 1)

@@ -269,7 +269,7 @@ def main():
             print('  %-28s %8d bytes' % (f, os.path.getsize(os.path.join(HERE, f))))
 
 
-if __name__ == '__main__' and '--trainstep' not in sys.argv and '--baseline' not in sys.argv:
+if __name__ == '__main__' and not any(a in sys.argv for a in ('--trainstep', '--baseline', '--baseline-train')):
     main()
 
 
@@ -380,3 +380,56 @@ def gen_baseline():
 
 if __name__ == '__main__' and '--baseline' in sys.argv:
     gen_baseline()
+
+
+def gen_baseline_train():
+    """One iteration of the reference's cvig_baseline training loop body (model/cvig_baseline.py:373-387): train-mode
+    encoders (BatchNorm batch statistics), exhaustive_minibatch_triplet_loss, backward, Adam(lr=1e-3) step."""
+    fov, sem, base = import_reference()
+    B = 3
+    encs = {}
+    for tag, cls, hw, stream, off in (('surface', base.SurfaceEncoder, 400, 40, 0), ('overhead', base.OverheadEncoder, 416, 41, 1)):
+        enc = cls()
+        prm = synth.baseline_params(SEED + 10 + off)
+        with torch.no_grad():
+            for i, q in enumerate(prm, 1):
+                getattr(enc, 'conv%d' % i).weight.copy_(torch.from_numpy(q['w']))
+                getattr(enc, 'conv%d' % i).bias.copy_(torch.from_numpy(q['b']))
+                bn = getattr(enc, 'bn%d' % i)
+                bn.weight.copy_(torch.from_numpy(q['gamma']))
+                bn.bias.copy_(torch.from_numpy(q['beta']))
+                bn.running_mean.copy_(torch.from_numpy(q['mean']))
+                bn.running_var.copy_(torch.from_numpy(q['var']))
+        encs[tag] = (enc.train(), torch.from_numpy(synth.images_u8(SEED, stream, (B, 3, hw, hw))))
+    params = list(encs['surface'][0].parameters()) + list(encs['overhead'][0].parameters())
+    opt = torch.optim.Adam(params)                                   # default lr 1e-3, :349
+    s_emb = encs['surface'][0](encs['surface'][1])
+    o_emb = encs['overhead'][0](encs['overhead'][1])
+    loss = base.exhaustive_minibatch_triplet_loss(s_emb, o_emb)
+    opt.zero_grad()
+    loss.backward()
+    res = {'seed': SEED, 'B': B, 'loss': loss.detach().numpy(), 'embed_surface': s_emb.detach().numpy(),
+           'embed_overhead': o_emb.detach().numpy()}
+    names = []
+    for tag in ('surface', 'overhead'):
+        for n, p in encs[tag][0].named_parameters():
+            key = '%s.%s' % (tag, n)
+            names.append(key)
+            gflat = p.grad.reshape(-1)
+            res['gnorm:' + key] = np.float64(gflat.double().norm().item())
+            res['gsamp:' + key] = gflat[::max(1, gflat.numel() // 129)].numpy()
+    opt.step()
+    for tag in ('surface', 'overhead'):
+        for n, p in encs[tag][0].named_parameters():
+            res['psamp:%s.%s' % (tag, n)] = p.detach().reshape(-1)[::max(1, p.numel() // 129)].numpy()
+        for n, bbuf in encs[tag][0].named_buffers():
+            if 'num_batches' not in n:
+                res['buf:%s.%s' % (tag, n)] = bbuf.detach().numpy()
+    res['names'] = np.array(names)
+    assert float(loss) > 0
+    np.savez(os.path.join(HERE, 'baseline_train.npz'), **res)
+    print('baseline_train.npz written; loss', float(loss))
+
+
+if __name__ == '__main__' and '--baseline-train' in sys.argv:
+    gen_baseline_train()

@@ -142,3 +142,39 @@ def test_baseline_oracle_matches_reference(golden_dir):
     ov = torch.from_numpy(synth.embeddings(seed, 602, (14, 1536)))
     su = ov + 14.0 * torch.from_numpy(synth.embeddings(seed, 603, (14, 1536)))
     np.testing.assert_array_equal(OB.ranks(ov, su), g['ranks'])
+
+
+def _baseline_train_case(golden_dir):
+    g = _load(golden_dir, 'baseline_train.npz')
+    seed, B = int(g['seed']), int(g['B'])
+    xs = torch.from_numpy(synth.images_u8(seed, 40, (B, 3, 400, 400)))
+    xo = torch.from_numpy(synth.images_u8(seed, 41, (B, 3, 416, 416)))
+    return g, xs, xo, seed
+
+
+def test_baseline_oracle_train_step_matches_reference(golden_dir):
+    """Oracle train-mode forward + torch autograd + Adam against the reference's loop body (BatchNorm batch statistics)."""
+    from oracle import cvig_baseline_oracle as OB
+    g, xs, xo, seed = _baseline_train_case(golden_dir)
+    ps, po = _baseline_params(seed + 10), _baseline_params(seed + 11)
+    leaves = []
+    for prm in (ps, po):
+        for q in prm:
+            for k in ('w', 'b', 'gamma', 'beta'):
+                q[k].requires_grad_(True)
+                leaves.append(q[k])
+    es = OB.encoder_forward(xs, ps, train=True)
+    eo = OB.encoder_forward(xo, po, train=True)
+    loss = OB.exhaustive_minibatch_triplet_loss(es, eo)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), float(g['loss']), rtol=1e-6)
+    np.testing.assert_allclose(es.detach().numpy(), g['embed_surface'], atol=1e-6)
+    key = {'w': 'conv%d.weight', 'b': 'conv%d.bias', 'gamma': 'bn%d.weight', 'beta': 'bn%d.bias'}
+    for tag, prm in (('surface', ps), ('overhead', po)):
+        for i, q in enumerate(prm, 1):
+            for k, pat in key.items():
+                name = '%s.%s' % (tag, pat % i)
+                gr = q[k].grad.reshape(-1)
+                np.testing.assert_allclose(gr.double().norm().item(), float(g['gnorm:' + name]), rtol=1e-4)
+            np.testing.assert_allclose(q['mean'].numpy(), g['buf:%s.bn%d.running_mean' % (tag, i)], atol=1e-6)
+            np.testing.assert_allclose(q['var'].numpy(), g['buf:%s.bn%d.running_var' % (tag, i)], rtol=1e-5, atol=1e-7)

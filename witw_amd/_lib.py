@@ -37,8 +37,15 @@ SIGNATURES = {
     'witw_conv3x3_bf16_pack_weights': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     'witw_nchw_f32_to_nhwc_bf16': (c_int, [c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]),
     'witw_conv3x3_bf16_fwd': (c_int, [c_void_p] * 4 + [c_int] * 10 + [c_void_p]),
-    'witw_space_to_depth2': (c_int, [c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]),
-    'witw_gem_pool': (c_int, [c_void_p, c_void_p] + [c_int] * 8 + [c_float, c_void_p]),
+    'witw_space_to_depth2': (c_int, [c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p, c_void_p]),
+    'witw_gem_pool': (c_int, [c_void_p, c_void_p] + [c_int] * 8 + [c_float, c_void_p, c_void_p, c_void_p]),
+    'witw_bn_workspace_floats': (c_longlong, [c_int] * 4),
+    'witw_bn_train_stats': (c_int, [c_void_p] + [c_int] * 6 + [c_void_p, c_void_p, c_float, c_float] + [c_void_p] * 8),
+    'witw_bn_lrelu_bwd': (c_int, [c_void_p] * 8 + [c_int] * 6 + [c_float, c_void_p, c_void_p]),
+    'witw_depth_to_space2': (c_int, [c_void_p] * 3 + [c_int] * 7 + [c_void_p]),
+    'witw_gem_pool_bwd': (c_int, [c_void_p] * 6 + [c_int] * 8 + [c_float, c_int, c_void_p]),
+    'witw_embed_normalize_bwd': (c_int, [c_void_p] * 3 + [c_int, c_int, c_void_p]),
+    'witw_exhaustive_triplet_loss_bwd': (c_int, [c_void_p] * 6 + [c_int] * 3 + [c_float, c_float, c_void_p, c_void_p]),
     'witw_embed_normalize': (c_int, [c_void_p, c_int, c_int, c_void_p]),
     'witw_pairwise_sqdist': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'witw_exhaustive_triplet_loss': (c_int, [c_void_p, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p]),

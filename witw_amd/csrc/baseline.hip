@@ -15,7 +15,8 @@ namespace {
 // x: NHWC [B,Hp,Wp,C] (or NCHW [B,C,Hp,Wp] if in_nchw) of which rows < H, cols < W are valid.
 // y: NHWC [B,ceil(H/2),ceil(W/2),Cp], y[b,h2,w2,(dy*2+dx)*C+c] = f(x[b,2h2+dy,2w2+dx,c]); zero elsewhere.
 __global__ void space_to_depth2_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int Hp, int Wp, int H, int W,
-                                       int C, int Cp, int in_nchw, int normalize, size_t total) {
+                                       int C, int Cp, int in_nchw, int normalize, size_t total,
+                                       const float* __restrict__ scale, const float* __restrict__ shift) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     const int H2 = (H + 1) >> 1, W2 = (W + 1) >> 1;
@@ -35,6 +36,7 @@ __global__ void space_to_depth2_kernel(const float* __restrict__ x, float* __res
                 v = v / 255.f;
                 v = -1.f + 2.f * v;
             }
+            if (scale != nullptr) v = v * scale[c] + shift[c];     // train-mode BatchNorm of the producer layer
         }
     }
     y[idx] = v;
@@ -42,15 +44,16 @@ __global__ void space_to_depth2_kernel(const float* __restrict__ x, float* __res
 
 // f[b, col0 + c] = (mean_{h<H,w<W} relu(x[b,h,w,c])^p)^(1/p); x NHWC [B,Hp,Wp,C]; one thread per (b,c).
 __global__ void gem_pool_kernel(const float* __restrict__ x, float* __restrict__ f, int B, int Hp, int Wp, int H, int W, int C,
-                                int ldf, int col0, float p) {
+                                int ldf, int col0, float p, const float* __restrict__ scale, const float* __restrict__ shift) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= B * C) return;
     const int c = idx % C, b = idx / C;
     float s = 0.f;
     for (int h = 0; h < H; ++h)
         for (int w = 0; w < W; ++w) {
-            const float v = fmaxf(x[(((size_t)b * Hp + h) * Wp + w) * C + c], 0.f);
-            s += powf(v, p);
+            float v = x[(((size_t)b * Hp + h) * Wp + w) * C + c];
+            if (scale != nullptr) v = v * scale[c] + shift[c];
+            s += powf(fmaxf(v, 0.f), p);
         }
     f[(size_t)b * ldf + col0 + c] = powf(s / (float)(H * W), 1.f / p);
 }
@@ -123,28 +126,250 @@ __global__ __launch_bounds__(256) void sum_finish_kernel(const float* __restrict
     if (threadIdx.x == 0) out[0] = ((sh[0] + sh[1]) + (sh[2] + sh[3])) / norm;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Training-mode pieces (model/cvig_baseline.py:267-284 under .train(), autograd of :286-315): batch statistics of
+// BatchNorm2d, its backward fused with the LeakyReLU backward, GeM / normalisation / loss backward, depth-to-space.
+
+// per-channel partial sums over the valid region: part[blk][0][c] = sum a, part[blk][1][c] = sum a^2
+// (bwd form: a2 != nullptr -> sum g and sum g*xhat with xhat = (a - mean[c]) * invstd[c], g = second tensor)
+__global__ __launch_bounds__(256) void channel_sums_kernel(const float* __restrict__ a, const float* __restrict__ g,
+                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                            float* __restrict__ part, int Hp, int Wp, int H, int W, int C,
+                                                            size_t npix, int rows_per_block) {
+    __shared__ float sh[2][4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
+    const size_t p0 = (size_t)blockIdx.y * rows_per_block, p1 = min(npix, p0 + (size_t)rows_per_block);
+    float s0 = 0.f, s1 = 0.f;
+    if (c < C) {
+        const float mu = g ? mean[c] : 0.f, is = g ? invstd[c] : 0.f;
+        for (size_t px = p0 + ph; px < p1; px += 4) {      // px enumerates VALID pixels (b, h<H, w<W)
+            const size_t w = px % W, t = px / W, h = t % H, b = t / H;
+            const size_t off = ((b * Hp + h) * Wp + w) * C + c;
+            const float v = a[off];
+            if (g) {
+                const float gv = g[off];
+                s0 += gv;
+                s1 += gv * ((v - mu) * is);
+            } else {
+                s0 += v;
+                s1 += v * v;
+            }
+        }
+    }
+    sh[0][ph][threadIdx.x & 63] = s0;
+    sh[1][ph][threadIdx.x & 63] = s1;
+    __syncthreads();
+    if (threadIdx.x < 64 && c < C) {
+        const int l = threadIdx.x;
+        part[((size_t)blockIdx.y * 2 + 0) * C + c] = (sh[0][0][l] + sh[0][1][l]) + (sh[0][2][l] + sh[0][3][l]);
+        part[((size_t)blockIdx.y * 2 + 1) * C + c] = (sh[1][0][l] + sh[1][1][l]) + (sh[1][2][l] + sh[1][3][l]);
+    }
+}
+
+// BatchNorm2d training statistics: mean / biased var -> scale = gamma*invstd, shift = beta - mean*scale, and the
+// running-stat update running = (1-m)*running + m*stat (unbiased variance), torch semantics.
+__global__ void bn_stats_finish_kernel(const float* __restrict__ part, int nparts, int C, float n, const float* __restrict__ gamma,
+                                       const float* __restrict__ beta, float eps, float momentum, float* __restrict__ mean,
+                                       float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift,
+                                       float* __restrict__ running_mean, float* __restrict__ running_var) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s0 = 0.f, s1 = 0.f;
+    for (int k = 0; k < nparts; ++k) {
+        s0 += part[((size_t)k * 2 + 0) * C + c];
+        s1 += part[((size_t)k * 2 + 1) * C + c];
+    }
+    const float mu = s0 / n;
+    const float var = fmaxf(s1 / n - mu * mu, 0.f);
+    const float is = 1.f / sqrtf(var + eps);
+    mean[c] = mu;
+    invstd[c] = is;
+    scale[c] = gamma[c] * is;
+    shift[c] = beta[c] - mu * gamma[c] * is;
+    if (running_mean != nullptr) {
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (var * n / (n - 1.f));
+    }
+}
+
+// sums[0][c] = sum dy, sums[1][c] = sum dy*xhat  (+ writes dgamma = sums[1], dbeta = sums[0])
+__global__ void bn_bwd_finish_kernel(const float* __restrict__ part, int nparts, int C, float* __restrict__ sums,
+                                     float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s0 = 0.f, s1 = 0.f;
+    for (int k = 0; k < nparts; ++k) {
+        s0 += part[((size_t)k * 2 + 0) * C + c];
+        s1 += part[((size_t)k * 2 + 1) * C + c];
+    }
+    sums[c] = s0;
+    sums[C + c] = s1;
+    dbeta[c] = s0;
+    dgamma[c] = s1;
+}
+
+// dz = lrelu'(a) * gamma*invstd * (dy - sum_dy/n - xhat*sum_dyxhat/n) on the valid region, 0 elsewhere.
+__global__ void bn_lrelu_bwd_apply_kernel(const float* __restrict__ a, const float* __restrict__ dy, float* __restrict__ dz,
+                                          const float* __restrict__ mean, const float* __restrict__ invstd,
+                                          const float* __restrict__ gamma, const float* __restrict__ sums, int Hp, int Wp, int H,
+                                          int W, int C, float n, float slope, size_t total) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = idx % C;
+    size_t t = idx / C;
+    const int w = t % Wp;
+    t /= Wp;
+    const int h = t % Hp;
+    float out = 0.f;
+    if (h < H && w < W) {
+        const float av = a[idx];
+        const float xh = (av - mean[c]) * invstd[c];
+        const float da = gamma[c] * invstd[c] * (dy[idx] - sums[c] / n - xh * sums[C + c] / n);
+        out = av > 0.f ? da : da * slope;
+    }
+    dz[idx] = out;
+}
+
+// depth-to-space(2) of the s2d-layout gradient: dx[b,h,w,c] = g[b,h/2,w/2,((h&1)*2+(w&1))*C+c] (+ add[b,h,w,c]) on
+// the valid region of a [B,Hp,Wp,C] tensor, 0 elsewhere.
+__global__ void depth_to_space2_kernel(const float* __restrict__ g, const float* __restrict__ add, float* __restrict__ dx, int Hp,
+                                       int Wp, int H, int W, int C, int Cp, size_t total) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = idx % C;
+    size_t t = idx / C;
+    const int w = t % Wp;
+    t /= Wp;
+    const int h = t % Hp;
+    const size_t b = t / Hp;
+    float v = 0.f;
+    if (h < H && w < W) {
+        const int H2 = (H + 1) >> 1, W2 = (W + 1) >> 1;
+        v = g[((b * H2 + (h >> 1)) * W2 + (w >> 1)) * Cp + ((h & 1) * 2 + (w & 1)) * C + c];
+        if (add != nullptr) v += add[idx];
+    }
+    dx[idx] = v;
+}
+
+// GeM backward: dy[b,h,w,c] (+)= df[b,col0+c] * m^(1/p-1) * relu(y)^(p-1) / N, y = a*scale+shift, m = f^p.
+__global__ void gem_pool_bwd_kernel(const float* __restrict__ a, const float* __restrict__ scale, const float* __restrict__ shift,
+                                    const float* __restrict__ f, const float* __restrict__ df, float* __restrict__ dy, int Hp,
+                                    int Wp, int H, int W, int C, int ldf, int col0, float p, int accumulate, size_t total) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = idx % C;
+    size_t t = idx / C;
+    const int w = t % Wp;
+    t /= Wp;
+    const int h = t % Hp;
+    const size_t b = t / Hp;
+    float out = 0.f;
+    if (h < H && w < W) {
+        const float y = fmaxf(a[idx] * scale[c] + shift[c], 0.f);
+        const float fv = f[b * ldf + col0 + c];              // = m^(1/p)
+        if (y > 0.f && fv > 0.f) out = df[b * ldf + col0 + c] * powf(fv, 1.f - p) * powf(y, p - 1.f) / (float)(H * W);
+    }
+    dy[idx] = accumulate ? dy[idx] + out : out;
+}
+
+// f = g / |g|^(1/2)  ->  dg = df/|g|^(1/2) - 0.5 * (g.df) * g / |g|^(5/2); one block per row. f and df given, g = f*|g|^(1/2)
+// is recovered from the saved norm.
+__global__ __launch_bounds__(256) void embed_normalize_bwd_kernel(const float* __restrict__ g, const float* __restrict__ df,
+                                                                   float* __restrict__ dg, int n) {
+    __shared__ float part[2][4];
+    const float* gr = g + (size_t)blockIdx.x * n;
+    const float* dr = df + (size_t)blockIdx.x * n;
+    float s0 = 0.f, s1 = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        s0 += gr[i] * gr[i];
+        s1 += gr[i] * dr[i];
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        s0 += __shfl_xor(s0, d, 64);
+        s1 += __shfl_xor(s1, d, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        part[0][threadIdx.x >> 6] = s0;
+        part[1][threadIdx.x >> 6] = s1;
+    }
+    __syncthreads();
+    const float nn = (part[0][0] + part[0][1]) + (part[0][2] + part[0][3]);     // |g|^2
+    const float gd = (part[1][0] + part[1][1]) + (part[1][2] + part[1][3]);
+    const float nrm = sqrtf(nn);
+    const float c0 = 1.f / sqrtf(nrm), c1 = 0.5f * gd / (nrm * nrm * sqrtf(nrm));
+    for (int i = threadIdx.x; i < n; i += 256) dg[(size_t)blockIdx.x * n + i] = dr[i] * c0 - c1 * gr[i];
+}
+
+__device__ __forceinline__ float trip_d(float x, int soft, float alpha, float margin) {
+    return soft ? alpha / (1.f + expf(-alpha * x)) : ((x + margin > 0.f) ? 1.f : 0.f);
+}
+
+// G = dL/dD for the exhaustive loss; one block per row a (diagonal entry gathers the row and column terms).
+__global__ __launch_bounds__(256) void exhaustive_bwd_kernel(const float* __restrict__ D, const float* __restrict__ gloss,
+                                                              float* __restrict__ G, int B, int soft, float alpha, float margin) {
+    __shared__ float sh[4];
+    const int a = blockIdx.x;
+    const float daa = D[(size_t)a * B + a];
+    const float sc = gloss[0] / (2.f * B * (B - 1));
+    float diag = 0.f;
+    for (int j = threadIdx.x; j < B; j += 256) {
+        if (j == a) continue;
+        const float dab = D[(size_t)a * B + j];
+        const float t1 = trip_d(daa - dab, soft, alpha, margin);                       // anchor a in embed1, negative j
+        const float t2 = trip_d(D[(size_t)j * B + j] - dab, soft, alpha, margin);      // anchor j in embed2
+        G[(size_t)a * B + j] = -(t1 + t2) * sc;
+        diag += t1 + trip_d(daa - D[(size_t)j * B + a], soft, alpha, margin);
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) diag += __shfl_xor(diag, d, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = diag;
+    __syncthreads();
+    if (threadIdx.x == 0) G[(size_t)a * B + a] = ((sh[0] + sh[1]) + (sh[2] + sh[3])) * sc;
+}
+
+// D[a][b] = |e1_a - e2_b|^2: de1[a] = 2 * sum_b G[a][b] (e1_a - e2_b)   (side 0)
+//                            de2[b] = 2 * sum_a G[a][b] (e2_b - e1_a)   (side 1); one block per output row.
+__global__ __launch_bounds__(256) void sqdist_bwd_kernel(const float* __restrict__ e1, const float* __restrict__ e2,
+                                                          const float* __restrict__ G, float* __restrict__ out, int B, int n,
+                                                          int side) {
+    const int r = blockIdx.x;
+    const float* self = (side == 0 ? e1 : e2) + (size_t)r * n;
+    const float* other = side == 0 ? e2 : e1;
+    for (int k = threadIdx.x; k < n; k += 256) {
+        float s = 0.f;
+        const float sv = self[k];
+        for (int q = 0; q < B; ++q) {
+            const float gq = side == 0 ? G[(size_t)r * B + q] : G[(size_t)q * B + r];
+            s += gq * (sv - other[(size_t)q * n + k]);
+        }
+        out[(size_t)r * n + k] = 2.f * s;
+    }
+}
+
 }  // namespace
 
 extern "C" {
 
 int witw_space_to_depth2(const float* x, float* y, int B, int Hp, int Wp, int H, int W, int C, int Cpad, int in_nchw,
-                         int normalize, void* stream) {
+                         int normalize, const float* scale, const float* shift, void* stream) {
     WITW_CHECK_ARG(x && y, "space_to_depth2: null pointer");
     WITW_CHECK_ARG(B > 0 && C > 0 && H > 0 && W > 0 && H <= Hp && W <= Wp && Cpad >= 4 * C, "space_to_depth2: bad shape");
     const size_t total = (size_t)B * ((H + 1) / 2) * ((W + 1) / 2) * Cpad;
     WITW_CHECK_ARG((total + 255) / 256 <= 0x7fffffffULL, "space_to_depth2: tensor too large");
     hipLaunchKernelGGL(space_to_depth2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, B,
-                       Hp, Wp, H, W, C, Cpad, in_nchw, normalize, total);
+                       Hp, Wp, H, W, C, Cpad, in_nchw, normalize, total, scale, shift);
     WITW_CHECK_LAUNCH("space_to_depth2");
     return WITW_OK;
 }
 
 int witw_gem_pool(const float* x, float* f, int B, int Hp, int Wp, int H, int W, int C, int ldf, int col0, float p,
-                  void* stream) {
+                  const float* scale, const float* shift, void* stream) {
     WITW_CHECK_ARG(x && f, "gem_pool: null pointer");
     WITW_CHECK_ARG(B > 0 && C > 0 && H > 0 && W > 0 && H <= Hp && W <= Wp && col0 >= 0 && col0 + C <= ldf, "gem_pool: bad shape");
     hipLaunchKernelGGL(gem_pool_kernel, dim3(cdiv(B * C, 256)), dim3(256), 0, (hipStream_t)stream, x, f, B, Hp, Wp, H, W, C, ldf,
-                       col0, p);
+                       col0, p, scale, shift);
     WITW_CHECK_LAUNCH("gem_pool");
     return WITW_OK;
 }
@@ -174,6 +399,101 @@ int witw_exhaustive_triplet_loss(const float* D, int B, int soft_margin, float a
     hipLaunchKernelGGL(exhaustive_partials_kernel, dim3(B), dim3(256), 0, st, D, workspace, B, soft_margin, alpha, margin);
     hipLaunchKernelGGL(sum_finish_kernel, dim3(1), dim3(256), 0, st, workspace, loss, B, 2.f * B * (B - 1));
     WITW_CHECK_LAUNCH("exhaustive_triplet_loss");
+    return WITW_OK;
+}
+
+// ---- training-mode entry points of cvig_baseline
+static int bl_rows(size_t npix) {
+    size_t r = (npix + 127) / 128;
+    return (int)(r < 64 ? 64 : r);
+}
+
+long long witw_bn_workspace_floats(int B, int H, int W, int C) {
+    const size_t npix = (size_t)B * H * W;
+    const int rows = bl_rows(npix);
+    return (long long)((npix + rows - 1) / rows) * 2 * C + 2 * C;
+}
+
+// Batch statistics of BatchNorm2d over the valid region of a [B,Hp,Wp,C] tensor -> mean, invstd, and the affine
+// (scale, shift) with y = a*scale + shift; running stats updated in place when non-NULL (momentum, unbiased var).
+int witw_bn_train_stats(const float* a, int B, int Hp, int Wp, int H, int W, int C, const float* gamma, const float* beta,
+                        float eps, float momentum, float* mean, float* invstd, float* scale, float* shift, float* running_mean,
+                        float* running_var, float* workspace, void* stream) {
+    WITW_CHECK_ARG(a && gamma && beta && mean && invstd && scale && shift && workspace, "bn_train_stats: null pointer");
+    WITW_CHECK_ARG(B > 0 && C > 0 && H > 0 && W > 0 && H <= Hp && W <= Wp, "bn_train_stats: bad shape");
+    WITW_CHECK_ARG((size_t)B * H * W > 1, "bn_train_stats: needs more than one value per channel");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t npix = (size_t)B * H * W;
+    const int rows = bl_rows(npix), nparts = (int)((npix + rows - 1) / rows);
+    hipLaunchKernelGGL(channel_sums_kernel, dim3(cdiv(C, 64), nparts), dim3(256), 0, st, a, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, workspace, Hp, Wp, H, W, C, npix, rows);
+    hipLaunchKernelGGL(bn_stats_finish_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, workspace, nparts, C, (float)npix, gamma, beta,
+                       eps, momentum, mean, invstd, scale, shift, running_mean, running_var);
+    WITW_CHECK_LAUNCH("bn_train_stats");
+    return WITW_OK;
+}
+
+// Backward of y = BN_train(lrelu(z)) w.r.t. z, gamma, beta: a = lrelu(z) (saved), dy = gradient at y.
+int witw_bn_lrelu_bwd(const float* a, const float* dy, float* dz, float* dgamma, float* dbeta, const float* mean,
+                      const float* invstd, const float* gamma, int B, int Hp, int Wp, int H, int W, int C, float slope,
+                      float* workspace, void* stream) {
+    WITW_CHECK_ARG(a && dy && dz && dgamma && dbeta && mean && invstd && gamma && workspace, "bn_lrelu_bwd: null pointer");
+    WITW_CHECK_ARG(B > 0 && C > 0 && H > 0 && W > 0 && H <= Hp && W <= Wp, "bn_lrelu_bwd: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t npix = (size_t)B * H * W;
+    const int rows = bl_rows(npix), nparts = (int)((npix + rows - 1) / rows);
+    float* sums = workspace + (size_t)nparts * 2 * C;
+    hipLaunchKernelGGL(channel_sums_kernel, dim3(cdiv(C, 64), nparts), dim3(256), 0, st, a, dy, mean, invstd, workspace, Hp, Wp, H, W,
+                       C, npix, rows);
+    hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, workspace, nparts, C, sums, dgamma, dbeta);
+    const size_t total = (size_t)B * Hp * Wp * C;
+    hipLaunchKernelGGL(bn_lrelu_bwd_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a, dy, dz, mean, invstd,
+                       gamma, sums, Hp, Wp, H, W, C, (float)npix, slope, total);
+    WITW_CHECK_LAUNCH("bn_lrelu_bwd");
+    return WITW_OK;
+}
+
+int witw_depth_to_space2(const float* g, const float* add, float* dx, int B, int Hp, int Wp, int H, int W, int C, int Cpad,
+                         void* stream) {
+    WITW_CHECK_ARG(g && dx, "depth_to_space2: null pointer");
+    WITW_CHECK_ARG(B > 0 && C > 0 && H > 0 && W > 0 && H <= Hp && W <= Wp && Cpad >= 4 * C, "depth_to_space2: bad shape");
+    const size_t total = (size_t)B * Hp * Wp * C;
+    hipLaunchKernelGGL(depth_to_space2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, add, dx,
+                       Hp, Wp, H, W, C, Cpad, total);
+    WITW_CHECK_LAUNCH("depth_to_space2");
+    return WITW_OK;
+}
+
+int witw_gem_pool_bwd(const float* a, const float* scale, const float* shift, const float* f, const float* df, float* dy, int B,
+                      int Hp, int Wp, int H, int W, int C, int ldf, int col0, float p, int accumulate, void* stream) {
+    WITW_CHECK_ARG(a && scale && shift && f && df && dy, "gem_pool_bwd: null pointer");
+    WITW_CHECK_ARG(B > 0 && C > 0 && H > 0 && W > 0 && H <= Hp && W <= Wp, "gem_pool_bwd: bad shape");
+    const size_t total = (size_t)B * Hp * Wp * C;
+    hipLaunchKernelGGL(gem_pool_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, scale, shift,
+                       f, df, dy, Hp, Wp, H, W, C, ldf, col0, p, accumulate, total);
+    WITW_CHECK_LAUNCH("gem_pool_bwd");
+    return WITW_OK;
+}
+
+// g: the un-normalised concat feature [B,n]; df: gradient at f = g/|g|^(1/2); dg out.
+int witw_embed_normalize_bwd(const float* g, const float* df, float* dg, int B, int n, void* stream) {
+    WITW_CHECK_ARG(g && df && dg && B > 0 && n > 0, "embed_normalize_bwd: bad argument");
+    hipLaunchKernelGGL(embed_normalize_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, g, df, dg, n);
+    WITW_CHECK_LAUNCH("embed_normalize_bwd");
+    return WITW_OK;
+}
+
+// backward of witw_pairwise_sqdist + witw_exhaustive_triplet_loss: grad_loss [1] -> de1, de2 [B,n]; workspace B*B floats.
+int witw_exhaustive_triplet_loss_bwd(const float* e1, const float* e2, const float* D, const float* grad_loss, float* de1,
+                                     float* de2, int B, int n, int soft_margin, float alpha, float margin, float* workspace,
+                                     void* stream) {
+    WITW_CHECK_ARG(e1 && e2 && D && grad_loss && de1 && de2 && workspace, "exhaustive_triplet_loss_bwd: null pointer");
+    WITW_CHECK_ARG(B >= 2 && n > 0, "exhaustive_triplet_loss_bwd: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(exhaustive_bwd_kernel, dim3(B), dim3(256), 0, st, D, grad_loss, workspace, B, soft_margin, alpha, margin);
+    hipLaunchKernelGGL(sqdist_bwd_kernel, dim3(B), dim3(256), 0, st, e1, e2, workspace, de1, B, n, 0);
+    hipLaunchKernelGGL(sqdist_bwd_kernel, dim3(B), dim3(256), 0, st, e1, e2, workspace, de2, B, n, 1);
+    WITW_CHECK_LAUNCH("exhaustive_triplet_loss_bwd");
     return WITW_OK;
 }
 

@@ -2,7 +2,8 @@
 """MI355X-native drop-in for the hot path of the reference's model/cvig_baseline.py (Liu & Li CVPR'19-style
 baseline): 7 x [Conv2d(4,2,0) -> LeakyReLU(0.2) -> BatchNorm2d] encoders with GeM-like
 multi-scale pooling, exhaustive minibatch triplet loss on squared Euclidean distances, Euclidean ranking.
-Inference (eval-mode BatchNorm) runs on the HIP kernels; train-mode BatchNorm / backward are not built and raise.
+Inference (BatchNorm running statistics folded into the conv epilogue) and training (batch statistics, full backward
+through BatchNorm / LeakyReLU / the 4x4 convolutions / GeM pooling / the exhaustive loss) run on the HIP kernels.
 """
 import math
 
@@ -116,18 +117,29 @@ class SurfaceEncoder(nn.Module):
                 packed = ops.PackedConv(k3, conv.bias)
                 scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)               # eval-mode BatchNorm2d
                 shift = bn.bias - bn.running_mean * scale
-            hit = (key, packed, scale.contiguous(), shift.contiguous(), cpad)
+            hit = (key, packed, scale.contiguous(), shift.contiguous(), cpad, k3)
             self._packed[i] = hit
-        return hit[1:]
+        return hit[1:5]
+
+    def _layer_k3(self, i):
+        self._layer(i)
+        return self._packed[i][5]
+
+    def train_params(self):
+        out = []
+        for i in range(1, 8):
+            conv, bn = getattr(self, 'conv%d' % i), getattr(self, 'bn%d' % i)
+            out += [conv.weight, conv.bias, bn.weight, bn.bias]
+        return out
 
     def forward(self, x):
         if not x.is_cuda:
             raise _lib.WitwError('SurfaceEncoder.forward needs a GPU tensor (no CPU fallback)')
-        if self.training:
-            raise _lib.WitwError('cvig_baseline: train-mode BatchNorm / backward are not built; call .eval()')
         B, _c, H, W = x.shape
         if min(H, W) < 382:
             raise _lib.WitwError('cvig_baseline encoder needs sides >= 382 px, got %dx%d' % (H, W))
+        if self.training:
+            return _BaselineEncoderFn.apply(x, self, *self.train_params())
         with torch.no_grad():
             h = ops.space_to_depth2(x.contiguous(), in_nchw=True, normalize=True, cpad=self._layer(1)[3])   # :265-266
             f = torch.empty((B, 1536), dtype=torch.float32, device=x.device)
@@ -147,8 +159,85 @@ class OverheadEncoder(SurfaceEncoder):
     pass
 
 
+class _BaselineEncoderFn(torch.autograd.Function):
+    """Train-mode forward (BatchNorm2d batch statistics, running-stat update) and backward of one encoder call."""
+
+    @staticmethod
+    def forward(ctx, x, enc, *params):
+        B, _c, H, W = x.shape
+        with torch.no_grad():
+            h = ops.space_to_depth2(x.contiguous(), in_nchw=True, normalize=True, cpad=enc._layer(1)[3])
+            g = torch.empty((B, 1536), dtype=torch.float32, device=x.device)
+            vh, vw = H, W
+            saved = []
+            for i in range(1, 8):
+                packed, _es, _et, _cp = enc._layer(i)
+                bn = getattr(enc, 'bn%d' % i)
+                vh, vw = (vh - 4) // 2 + 1, (vw - 4) // 2 + 1
+                a = ops.conv3x3_fwd(h, packed, relu=False, lrelu_slope=0.2)                  # LeakyReLU(conv), :267-275
+                mean, invstd, scale, shift = ops.bn_train_stats(a, (vh, vw), bn.weight, bn.bias, bn.running_mean,
+                                                                bn.running_var, bn.eps, bn.momentum)
+                bn.num_batches_tracked += 1
+                saved.append((h, a, (vh, vw), mean, invstd, scale, shift))
+                if i >= 5:
+                    ops.gem_pool(a, (vh, vw), g, 512 * (i - 5), enc.p, scale, shift)
+                if i < 7:
+                    h = ops.space_to_depth2(a, valid_hw=(vh, vw), cpad=enc._layer(i + 1)[3], scale=scale, shift=shift)
+            f = ops.embed_normalize_(g.clone())
+        ctx.enc, ctx.saved, ctx.g = enc, saved, g
+        return f
+
+    @staticmethod
+    def backward(ctx, df):
+        enc, saved, g = ctx.enc, ctx.saved, ctx.g
+        dg = ops.embed_normalize_bwd(g, df.contiguous())
+        grads = [None] * 28
+        dx_s2d = None
+        for i in range(7, 0, -1):
+            h, a, valid, mean, invstd, scale, shift = saved[i - 1]
+            conv, bn = getattr(enc, 'conv%d' % i), getattr(enc, 'bn%d' % i)
+            if i == 7:
+                dy = ops.gem_pool_bwd(a, scale, shift, g, dg, valid, 1024, enc.p)
+            else:
+                dy = ops.depth_to_space2(dx_s2d, a, valid)
+                if i >= 5:
+                    ops.gem_pool_bwd(a, scale, shift, g, dg, valid, 512 * (i - 5), enc.p, out=dy)
+            dz, dgamma, dbeta = ops.bn_lrelu_bwd(a, dy, valid, mean, invstd, bn.weight, 0.2)
+            k3 = enc._layer_k3(i)
+            dk3, dbias = ops.conv3x3_wgrad(h, dz, k3.shape[1], stride_h=1, circular=False)
+            co, ci = conv.weight.shape[:2]
+            dw = torch.empty_like(conv.weight)
+            for ta in range(2):
+                for tb in range(2):     # tap (ta+1, tb+1) of the 3x3 filter holds W[:, :, 2ta+dy, 2tb+dx] as channel (dy,dx,c)
+                    blk = dk3[:, :4 * ci, ta + 1, tb + 1].reshape(co, 2, 2, ci).permute(0, 3, 1, 2)
+                    dw[:, :, 2 * ta:2 * ta + 2, 2 * tb:2 * tb + 2] = blk
+            grads[4 * (i - 1):4 * i] = [dw, dbias, dgamma, dbeta]
+            if i > 1:
+                dx_s2d = ops.conv3x3_fwd(dz, ops.PackedConv(k3, None, transpose_flip=True), relu=False)
+        ctx.saved = ctx.g = None
+        return (None, None) + tuple(grads)
+
+
+class _ExhaustiveLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, e1, e2, soft_margin, alpha, margin):
+        e1, e2 = e1.contiguous(), e2.contiguous()
+        D = ops.pairwise_sqdist(e1, e2)
+        ctx.save_for_backward(e1, e2, D)
+        ctx.cfg = (soft_margin, alpha, margin)
+        return ops.exhaustive_triplet_loss(D, soft_margin, alpha, margin)
+
+    @staticmethod
+    def backward(ctx, gl):
+        e1, e2, D = ctx.saved_tensors
+        de1, de2 = ops.exhaustive_triplet_loss_bwd(e1, e2, D, gl.contiguous(), *ctx.cfg)
+        return de1, de2, None, None, None
+
+
 def exhaustive_minibatch_triplet_loss(embed1, embed2, soft_margin=False, alpha=10., margin=1.):
-    """model/cvig_baseline.py:286-315 (forward value; all valid (a,p,n) combinations of the minibatch)."""
+    """model/cvig_baseline.py:286-315 (all valid (a,p,n) combinations of the minibatch); differentiable."""
+    if torch.is_grad_enabled() and (embed1.requires_grad or embed2.requires_grad):
+        return _ExhaustiveLossFn.apply(embed1, embed2, bool(soft_margin), float(alpha), float(margin))
     D = ops.pairwise_sqdist(embed1.contiguous(), embed2.contiguous())
     return ops.exhaustive_triplet_loss(D, soft_margin, alpha, margin)
 

@@ -425,7 +425,7 @@ def polar_transform(x, h_s=128, w_s=512):
 
 
 # ----------------------------------------------------------------------------- cvig_baseline pieces
-def space_to_depth2(x, valid_hw=None, cpad=None, in_nchw=False, normalize=False):
+def space_to_depth2(x, valid_hw=None, cpad=None, in_nchw=False, normalize=False, scale=None, shift=None):
     lib = _lib.load()
     x = _dev_f32(x, 'x')
     if in_nchw:
@@ -436,17 +436,17 @@ def space_to_depth2(x, valid_hw=None, cpad=None, in_nchw=False, normalize=False)
     cpad = cpad or (4 * C + 7) // 8 * 8
     y = torch.empty((B, (H + 1) // 2, (W + 1) // 2, cpad), dtype=torch.float32, device=x.device)
     _lib.check(lib.witw_space_to_depth2(x.data_ptr(), y.data_ptr(), B, Hp, Wp, H, W, C, cpad, int(in_nchw), int(normalize),
-                                        _stream()), 'witw_space_to_depth2')
+                                        _p(scale), _p(shift), _stream()), 'witw_space_to_depth2')
     return y
 
 
-def gem_pool(x_nhwc, valid_hw, out, col0, p=3.):
+def gem_pool(x_nhwc, valid_hw, out, col0, p=3., scale=None, shift=None):
     lib = _lib.load()
     x = _dev_f32(x_nhwc, 'x')
     B, Hp, Wp, C = x.shape
     H, W = valid_hw
-    _lib.check(lib.witw_gem_pool(x.data_ptr(), out.data_ptr(), B, Hp, Wp, H, W, C, out.shape[1], col0, float(p), _stream()),
-               'witw_gem_pool')
+    _lib.check(lib.witw_gem_pool(x.data_ptr(), out.data_ptr(), B, Hp, Wp, H, W, C, out.shape[1], col0, float(p), _p(scale),
+                                 _p(shift), _stream()), 'witw_gem_pool')
     return out
 
 
@@ -533,3 +533,79 @@ def conv3x3_bf16_fwd(x_nhwc, packed, stride_h=1, circular=False, relu=True, pool
         prof.append((('bf16', lib.witw_conv3x3_tile_n(packed.cout), stride_h, bool(pool)),
                      2.0 * packed.cin * packed.cout * 9 * Ho * W * B, e0, e1))
     return y
+
+
+def bn_train_stats(a, valid_hw, gamma, beta, running_mean=None, running_var=None, eps=1e-5, momentum=0.1):
+    """Batch statistics of BatchNorm2d over the valid region of a NHWC tensor -> (mean, invstd, scale, shift)."""
+    lib = _lib.load()
+    a = _dev_f32(a, 'a')
+    B, Hp, Wp, C = a.shape
+    H, W = valid_hw
+    out = [torch.empty((C,), dtype=torch.float32, device=a.device) for _ in range(4)]
+    ws = torch.empty(lib.witw_bn_workspace_floats(B, H, W, C), dtype=torch.float32, device=a.device)
+    _lib.check(lib.witw_bn_train_stats(a.data_ptr(), B, Hp, Wp, H, W, C, gamma.data_ptr(), beta.data_ptr(), float(eps),
+                                       float(momentum), out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(),
+                                       out[3].data_ptr(), _p(running_mean), _p(running_var), ws.data_ptr(), _stream()),
+               'witw_bn_train_stats')
+    return out
+
+
+def bn_lrelu_bwd(a, dy, valid_hw, mean, invstd, gamma, slope=0.2):
+    """-> (dz, dgamma, dbeta) for y = BatchNorm_train(LeakyReLU(z)), a = LeakyReLU(z)."""
+    lib = _lib.load()
+    a, dy = _dev_f32(a, 'a'), _dev_f32(dy, 'dy')
+    B, Hp, Wp, C = a.shape
+    H, W = valid_hw
+    dz = torch.empty_like(a)
+    dg = torch.empty((C,), dtype=torch.float32, device=a.device)
+    db = torch.empty((C,), dtype=torch.float32, device=a.device)
+    ws = torch.empty(lib.witw_bn_workspace_floats(B, H, W, C), dtype=torch.float32, device=a.device)
+    _lib.check(lib.witw_bn_lrelu_bwd(a.data_ptr(), dy.data_ptr(), dz.data_ptr(), dg.data_ptr(), db.data_ptr(), mean.data_ptr(),
+                                     invstd.data_ptr(), gamma.data_ptr(), B, Hp, Wp, H, W, C, float(slope), ws.data_ptr(),
+                                     _stream()), 'witw_bn_lrelu_bwd')
+    return dz, dg, db
+
+
+def depth_to_space2(g, like, valid_hw, add=None):
+    lib = _lib.load()
+    g = _dev_f32(g, 'g')
+    B, Hp, Wp, C = like.shape
+    H, W = valid_hw
+    dx = torch.empty((B, Hp, Wp, C), dtype=torch.float32, device=g.device)
+    _lib.check(lib.witw_depth_to_space2(g.data_ptr(), _p(add), dx.data_ptr(), B, Hp, Wp, H, W, C, g.shape[3], _stream()),
+               'witw_depth_to_space2')
+    return dx
+
+
+def gem_pool_bwd(a, scale, shift, f, df, valid_hw, col0, p=3., out=None):
+    lib = _lib.load()
+    a = _dev_f32(a, 'a')
+    B, Hp, Wp, C = a.shape
+    H, W = valid_hw
+    acc = out is not None
+    dy = out if acc else torch.empty_like(a)
+    _lib.check(lib.witw_gem_pool_bwd(a.data_ptr(), scale.data_ptr(), shift.data_ptr(), f.data_ptr(), df.data_ptr(), dy.data_ptr(),
+                                     B, Hp, Wp, H, W, C, f.shape[1], col0, float(p), int(acc), _stream()), 'witw_gem_pool_bwd')
+    return dy
+
+
+def embed_normalize_bwd(g, df):
+    lib = _lib.load()
+    g, df = _dev_f32(g, 'g'), _dev_f32(df, 'df')
+    dg = torch.empty_like(g)
+    _lib.check(lib.witw_embed_normalize_bwd(g.data_ptr(), df.data_ptr(), dg.data_ptr(), g.shape[0], g.shape[1], _stream()),
+               'witw_embed_normalize_bwd')
+    return dg
+
+
+def exhaustive_triplet_loss_bwd(e1, e2, D, grad_loss, soft_margin=False, alpha=10., margin=1.):
+    lib = _lib.load()
+    e1, e2, D = _dev_f32(e1, 'e1'), _dev_f32(e2, 'e2'), _dev_f32(D, 'D')
+    gl = _dev_f32(grad_loss.reshape(1).contiguous(), 'grad_loss')
+    B, n = e1.shape
+    de1, de2 = torch.empty_like(e1), torch.empty_like(e2)
+    ws = torch.empty((B * B,), dtype=torch.float32, device=e1.device)
+    _lib.check(lib.witw_exhaustive_triplet_loss_bwd(e1.data_ptr(), e2.data_ptr(), D.data_ptr(), gl.data_ptr(), de1.data_ptr(),
+                                                    de2.data_ptr(), B, n, int(soft_margin), float(alpha), float(margin),
+                                                    ws.data_ptr(), _stream()), 'witw_exhaustive_triplet_loss_bwd')
+    return de1, de2
