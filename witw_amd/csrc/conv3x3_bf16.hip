@@ -177,6 +177,15 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_bf16_kernel(ConvBfArgs p
             read_frags((tap + 1) & 1, in_s, w_s, tap + 1);
             if (tap == 5) store_stage(cur ^ 1);
             mfma_tap(tap & 1);
+            if (tap != 0 && tap != 5) {     // plain taps: one fragment read per MFMA (staging taps are left to the scheduler)
+#pragma unroll
+                for (int i = 0; i < WM + WN; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < WM * WN - (WM + WN); ++i) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            }
         }
         __syncthreads();
         read_frags(1, in_n, in_n + IN_S, 0);
