@@ -21,8 +21,7 @@
 
 namespace {
 
-constexpr int TW = 64;
-constexpr int IW = TW + 2;
+constexpr int TW_WIDE = 64;
 
 // Source of every padded (out-of-image) halo slot: loading zeros from memory keeps the staging
 // path free of selects, which the compiler would otherwise pin right behind each load (vmcnt(0)).
@@ -44,6 +43,7 @@ struct ConvArgs {
     int tiles_x, tiles_y;
     int circ, relu, out_nchw;
     int force_nw;           // 0 = choose, 4 / 8 = force the workgroup shape (tuning aid)
+    int force_geo;          // -1 = choose, 0 / 1 = force the wide / narrow tile geometry
     int dil_h;              // 1: input rows are zero-interleaved (row 2i = physical row i): dgrad of a stride-(2,1) conv
 #ifdef WITW_STAMPS
     unsigned long long* stamps;   // diagnostic build only (tools/conv_stamps.cpp)
@@ -53,9 +53,14 @@ struct ConvArgs {
 // NW = waves per workgroup (4: 4x64-pixel tile, one wave per SIMD; 8: 8x64-pixel tile, two waves per SIMD
 // sharing one weight slab: 40 % less staging and half the barriers per MFMA, used when the layer is tall
 // and the grid large enough).
-template <int TN, int SH, bool POOL, int NW>
+// GEO = shape of one MFMA M-tile (32 output pixels): 0 = 1 row x 32 columns, workgroup tile NW rows x 64 columns
+// (wide maps); 1 = 2 rows x 16 columns, workgroup tile 4*NW rows x 16 columns (maps up to 32 columns wide, e.g. the
+// fov-70 ground branch whose widths are 24 and 12 in the deep layers: a 64-column tile would idle 63-81 % of it).
+template <int TN, int SH, bool POOL, int NW, int GEO>
 __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_f32_kernel(ConvArgs p) {
-    constexpr int TH = NW;
+    constexpr int TH = GEO ? 4 * NW : NW;
+    constexpr int TW = GEO ? 16 : 64;
+    constexpr int IW = TW + 2;
     constexpr int NTHREADS = 64 * NW;
     constexpr int IH = (TH - 1) * SH + 3;
     constexpr int IN_F4 = 2 * IH * IW;          // float4 slots of one input stage
@@ -64,7 +69,7 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_f32_kernel(ConvArgs p) {
     constexpr int NIN = (IN_F4 + NTHREADS - 1) / NTHREADS;
     constexpr int NWT = (W_F4 + NTHREADS - 1) / NTHREADS;
     constexpr int WGM = (TN == 128) ? NW / 2 : NW;   // waves along M
-    constexpr int WM = (2 * TH) / WGM;               // M-tiles per wave (4 at TN=128, 2 at TN=64)
+    constexpr int WM = (2 * NW) / WGM;               // M-tiles per wave (2*NW per workgroup): 4 at TN=128, 2 at TN=64
     constexpr int WN = 2;                       // N-tiles per wave (64 channels)
 
     __shared__ f32x4 smem[2 * STAGE_F4 + 1];   // +1: dummy slot that absorbs out-of-tile staging stores
@@ -159,10 +164,13 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_f32_kernel(ConvArgs p) {
     // ---- wave -> M-tiles / N-tiles
     const int wm = (TN == 128) ? (wave >> 1) : wave;
     const int wn = (TN == 128) ? (wave & 1) : 0;
-    int trow[WM], tcol[WM];  // tile row in [0,TH), tile column base in {0,32}
+    int trow[WM], tcol[WM];  // first tile row / column of each M-tile of this wave
 #pragma unroll
     for (int mt = 0; mt < WM; ++mt) {
-        if (TN == 128) {
+        if (GEO) {                       // M-tile t covers tile rows 2t, 2t+1 and all 16 columns
+            trow[mt] = 2 * ((TN == 128 ? 4 : 2) * wm + mt);
+            tcol[mt] = 0;
+        } else if (TN == 128) {
             trow[mt] = 2 * wm + (mt >> 1);
             tcol[mt] = 32 * (mt & 1);
         } else {
@@ -170,9 +178,12 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_f32_kernel(ConvArgs p) {
             tcol[mt] = 32 * (wm & 1);
         }
     }
+    // pixel m (0..31) of an M-tile -> (row, column) offset inside it
+    auto m_row = [](int m) { return GEO ? (m >> 4) : 0; };
+    auto m_col = [](int m) { return GEO ? (m & 15) : m; };
     int abase[WM];
 #pragma unroll
-    for (int mt = 0; mt < WM; ++mt) abase[mt] = hq * (IH * IW) + trow[mt] * SH * IW + tcol[mt] + l31;
+    for (int mt = 0; mt < WM; ++mt) abase[mt] = hq * (IH * IW) + (trow[mt] + m_row(l31)) * SH * IW + tcol[mt] + m_col(l31);
     const int wbase = hq * TN + wn * 64 + l31;
 
     f32x16 acc[WM][WN];
@@ -355,13 +366,13 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_f32_kernel(ConvArgs p) {
                     const float v = fin(acc[mt][nt][r], nt);
                     slab[((r & 3) + 8 * (r >> 2) + 4 * hq) * 64 + nt * 32 + l31] = v;
                 }
-            const int yy = oy0 + trow[mt];
             const int nbase = n0 + wn * 64 + pc4;
 #pragma unroll
             for (int g = 0; g < 8; ++g) {
                 const int m = g * 4 + prow;
                 const f32x4 v = *reinterpret_cast<const f32x4*>(slab + m * 64 + pc4);
-                const int xx = ox0 + tcol[mt] + m;
+                const int yy = oy0 + trow[mt] + m_row(m);
+                const int xx = ox0 + tcol[mt] + m_col(m);
                 if (yy < Hy && xx < Wy && nbase < p.Cout) {
                     const size_t o = (((size_t)b * Hy + yy) * Wy + xx) * p.Cout + nbase;
                     f32x4 w = v;
@@ -382,8 +393,29 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_f32_kernel(ConvArgs p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = (r & 3) + 8 * (r >> 2) + 4 * hq;
-                    emit(acc[mt][nt][r], nt, oy0 + trow[mt], ox0 + tcol[mt] + m);
+                    emit(acc[mt][nt][r], nt, oy0 + trow[mt] + m_row(m), ox0 + tcol[mt] + m_col(m));
                 }
+    } else if (GEO) {
+        // Narrow geometry: both rows of a pooling window sit in ONE M-tile (registers r and r+8), its two columns in
+        // registers r and r+1: 8 pooled pixels (1 row x 8 columns) per M-tile, all in-lane.
+#pragma unroll
+        for (int mt = 0; mt < WM; ++mt) {
+            const int yy = (oy0 + trow[mt]) >> 1;
+#pragma unroll
+            for (int nt = 0; nt < WN; ++nt)
+#pragma unroll
+                for (int r = 0; r < 8; r += 2) {
+                    const float a00 = acc[mt][nt][r], a01 = acc[mt][nt][r + 1];
+                    const float a10 = acc[mt][nt][r + 8], a11 = acc[mt][nt][r + 9];
+                    const float m = fmaxf(fmaxf(a00, a01), fmaxf(a10, a11));
+                    const int xx = (ox0 >> 1) + (((r & 3) >> 1) | (hq << 1) | (((r >> 2) & 1) << 2));
+                    emit(m, nt, yy, xx);
+                    if (p.pool_code != nullptr && yy < Hy && xx < Wy && nch[nt] < p.Cout) {
+                        const int code = (a00 == m) ? 0 : (a01 == m) ? 1 : (a10 == m) ? 2 : 3;
+                        p.pool_code[(((size_t)b * Hy + yy) * Wy + xx) * p.Cout + nch[nt]] = (unsigned char)code;
+                    }
+                }
+        }
     } else if ((p.Cout & 3) == 0 && p.gate == nullptr) {
         // Fused 2x2 max-pool, wide store: rows (2a, 2a+1) of one column half sit in M-tiles (mtA, mtB) of this
         // wave; the 16 pooled pixels x 64 channels of the pair go through the wave-private LDS slab and leave
@@ -516,16 +548,17 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, float* __restri
     y[idx] = (c < C) ? x[(b * C + c) * hw + r] : 0.f;
 }
 
-template <int TN, int SH, bool POOL, int NW>
+template <int TN, int SH, bool POOL, int NW, int GEO>
 int launch_conv_nw(ConvArgs a, hipStream_t st) {
-    a.tiles_y = cdiv(a.Ho, NW);
+    a.tiles_y = cdiv(a.Ho, GEO ? 4 * NW : NW);
+    a.tiles_x = cdiv(a.Wo, GEO ? 16 : 64);
     const int n_tiles = cdiv(a.Cout, TN);
     const long long grid = (long long)n_tiles * a.B * a.tiles_x * a.tiles_y;
     if (grid <= 0 || grid > 0x7fffffffLL) {
         witw_set_error("conv3x3: grid %lld out of range", grid);
         return WITW_ERR_INVALID;
     }
-    hipLaunchKernelGGL((conv3x3_nhwc_f32_kernel<TN, SH, POOL, NW>), dim3((unsigned)grid), dim3(64 * NW), 0, st, a);
+    hipLaunchKernelGGL((conv3x3_nhwc_f32_kernel<TN, SH, POOL, NW, GEO>), dim3((unsigned)grid), dim3(64 * NW), 0, st, a);
     WITW_CHECK_LAUNCH("conv3x3_nhwc_f32");
     return WITW_OK;
 }
@@ -533,20 +566,26 @@ int launch_conv_nw(ConvArgs a, hipStream_t st) {
 // 8-wave workgroups (8-row tiles) when no rows are wasted and >= 2 workgroups per CU remain
 int choose_waves(int B, int Ho, int Wo, int Cout, int force_nw) {
     const int TN = (Cout >= 128) ? 128 : 64;
-    const long long big = (long long)cdiv(Cout, TN) * B * cdiv(Wo, TW) * cdiv(Ho, 8);
+    const long long big = (long long)cdiv(Cout, TN) * B * cdiv(Wo, TW_WIDE) * cdiv(Ho, 8);
     if (force_nw == 4) return 4;
     return (force_nw == 8 || ((Ho % 8) == 0 && big >= 512)) ? 8 : 4;
 }
 
-int env_force_nw() {
-    const char* e = getenv("WITW_CONV_NW");   // tuning aid: force the workgroup shape
-    return e ? atoi(e) : 0;
+// narrow geometry (2x16-pixel M-tiles, 16-column workgroup tiles) for maps of at most 32 columns
+bool choose_narrow(int Wo, int force_geo) { return force_geo == 1 || (force_geo != 0 && Wo <= 32); }
+
+int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);      // tuning / test aids: WITW_CONV_NW in {4,8}, WITW_CONV_GEO in {0,1}
+    return e ? atoi(e) : dflt;
 }
 
 template <int TN, int SH, bool POOL>
 int launch_conv(const ConvArgs& a, hipStream_t st) {
-    if (choose_waves(a.B, a.Ho, a.Wo, a.Cout, a.force_nw) == 8) return launch_conv_nw<TN, SH, POOL, 8>(a, st);
-    return launch_conv_nw<TN, SH, POOL, 4>(a, st);
+#ifndef WITW_NO_NARROW
+    if (choose_narrow(a.Wo, a.force_geo)) return launch_conv_nw<TN, SH, POOL, 4, 1>(a, st);
+#endif
+    if (choose_waves(a.B, a.Ho, a.Wo, a.Cout, a.force_nw) == 8) return launch_conv_nw<TN, SH, POOL, 8, 0>(a, st);
+    return launch_conv_nw<TN, SH, POOL, 4, 0>(a, st);
 }
 
 }  // namespace
@@ -563,7 +602,8 @@ int witw_conv3x3_tile_n(int cout) { return cout >= 128 ? 128 : 64; }
 // conv3x3_nhwc_f32_kernel<tile_n, stride_h, pool, waves> that a profile will show
 int witw_conv3x3_workgroup_waves(int B, int H, int W, int Cout, int stride_h) {
     if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (stride_h != 1 && stride_h != 2)) return -1;
-    return choose_waves(B, (H + 2 - 3) / stride_h + 1, W, Cout, env_force_nw());
+    if (choose_narrow(W, env_int("WITW_CONV_GEO", -1))) return 4;
+    return choose_waves(B, (H + 2 - 3) / stride_h + 1, W, Cout, env_int("WITW_CONV_NW", 0));
 }
 
 long long witw_conv3x3_packed_floats(int cout, int cin) {
@@ -634,9 +674,10 @@ int witw_conv3x3_fwd_ex(const float* x, const float* wpk, const float* bias, con
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
     a.Ho = (H + 2 - 3) / stride_h + 1;
     a.Wo = W;
-    a.tiles_x = cdiv(a.Wo, TW);
+    a.tiles_x = 0;
     a.tiles_y = 0;   // set by the launcher for the chosen tile height
-    a.force_nw = env_force_nw();
+    a.force_nw = env_int("WITW_CONV_NW", 0);
+    a.force_geo = env_int("WITW_CONV_GEO", -1);
     a.circ = pad_circular; a.relu = relu; a.out_nchw = out_nchw; a.dil_h = dilate_h;
 #ifdef WITW_STAMPS
     a.stamps = witw_conv_stamps_ptr;
