@@ -182,6 +182,10 @@ int witw_normalize(const float* x, float* y, int B, int C, int H, int W, const f
  * built on the host in fp64 exactly as model/cvig_fov.py:163-181,197-201. */
 int witw_polar_transform(const float* x, const int* taps, const float* wts, float* y, int B, int C, int size, int Ho, int Wo,
                          void* stream);
+/* SyncedRotation's overhead rotation (model/cvig_baseline.py:142: torchvision.transforms.functional.rotate on a float
+ * CHW tensor = nearest-neighbour affine grid sample, zero fill, same size). x,y [B,C,H,W] fp32, y != x; theta DEVICE
+ * fp32 [B][3][2]: per image the inverse rotation matrix divided by (W/2, H/2), row k = (x, y, 1) coefficient. */
+int witw_rotate_nearest(const float* x, const float* theta, float* y, int B, int C, int H, int W, void* stream);
 
 #ifdef __cplusplus
 }

@@ -46,3 +46,26 @@ def ranks(overhead_embed, surface_embed):
         d = torch.pow(torch.sum(torch.pow(overhead_embed - q, 2), dim=1), 0.5)
         out[idx] = torch.sum(torch.le(d, d[idx])).item()
     return out
+
+
+def rotate(img, angle):
+    """torchvision==0.9.1 transforms.functional.rotate(img, angle) for a float tensor [..,C,H,W] with the defaults
+    the reference uses (model/cvig_baseline.py:142: nearest, expand=False, centre, no fill) — restated from
+    torchvision 0.9.1's published functional.py / functional_tensor.py (_get_inverse_affine_matrix,
+    _gen_affine_grid, _apply_grid_transform); torchvision is not installed here, so this restatement is
+    PARITY-UNPINNED (no reference test holds vectors for it)."""
+    import math
+    squeeze = img.dim() == 3
+    x = img.unsqueeze(0) if squeeze else img
+    h, w = x.shape[-2], x.shape[-1]
+    rot = math.radians(-angle)
+    matrix = [math.cos(rot), math.sin(rot), 0.0, -math.sin(rot), math.cos(rot), 0.0]
+    theta = torch.tensor(matrix, dtype=torch.float32).reshape(1, 2, 3)
+    base = torch.empty(1, h, w, 3, dtype=torch.float32)
+    base[..., 0].copy_(torch.linspace(-w * 0.5 + 0.5, w * 0.5 + 0.5 - 1, steps=w))
+    base[..., 1].copy_(torch.linspace(-h * 0.5 + 0.5, h * 0.5 + 0.5 - 1, steps=h).unsqueeze_(-1))
+    base[..., 2].fill_(1)
+    rescaled = theta.transpose(1, 2) / torch.tensor([0.5 * w, 0.5 * h], dtype=torch.float32)
+    grid = base.view(1, h * w, 3).bmm(rescaled).view(1, h, w, 2).expand(x.shape[0], h, w, 2)
+    y = F.grid_sample(x, grid, mode='nearest', padding_mode='zeros', align_corners=False)
+    return y.squeeze(0) if squeeze else y

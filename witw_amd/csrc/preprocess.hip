@@ -4,6 +4,8 @@
 //   ImageNormalization  model/cvig_fov.py:137-149  ((x/255 - mean)/std; semantic variant
 //                       model/cvig_semantic.py:172-176 divides only channels 0-2 by 255)
 //   PolarTransform      model/cvig_fov.py:186-209 + bilinear_interpolate :156-183
+//   SyncedRotation      model/cvig_baseline.py:131-144 (torchvision F.rotate on a float CHW tensor = affine grid +
+//                       grid_sample(nearest, zeros, align_corners=False) under torchvision 0.9.1)
 // Compiled with -ffp-contract=off so products and sums round exactly like the reference's
 // separate elementwise torch ops (polar: wa*Ia + wb*Ib + wc*Ic + wd*Id, left to right).
 #include "common.h"
@@ -78,6 +80,32 @@ __global__ void polar_kernel(const float* __restrict__ x, const int4* __restrict
     }
 }
 
+// theta: per image the 2x3 inverse rotation matrix ALREADY divided by (0.5*W, 0.5*H) as torchvision's
+// _gen_affine_grid does, laid out [b][k][j] (k = x,y,1 row; j = output coordinate): gx = x*t00 + y*t10 + t20.
+// Base grid = half-integer pixel centres (linspace(-W/2+.5, W/2-.5, W): step exactly 1); un-normalisation
+// and rounding follow ATen's grid_sampler (align_corners=False, nearbyint, zero outside).
+__global__ void rotate_nearest_kernel(const float* __restrict__ x, const float* __restrict__ theta, float* __restrict__ y,
+                                      int B, int C, int H, int W) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)B * H * W) return;
+    const int ox = idx % W;
+    size_t t = idx / W;
+    const int oy = t % H;
+    const int b = (int)(t / H);
+    const float* th = theta + (size_t)b * 6;
+    const float xg = (float)ox + (0.5f - 0.5f * (float)W), yg = (float)oy + (0.5f - 0.5f * (float)H);
+    const float gx = __fmaf_rn(yg, th[2], xg * th[0]) + th[4];
+    const float gy = __fmaf_rn(yg, th[3], xg * th[1]) + th[5];
+    const float fx = ((gx + 1.f) * (float)W - 1.f) / 2.f, fy = ((gy + 1.f) * (float)H - 1.f) / 2.f;
+    const float rx = nearbyintf(fx), ry = nearbyintf(fy);
+    const bool ok = rx >= 0.f && rx <= (float)(W - 1) && ry >= 0.f && ry <= (float)(H - 1);
+    const size_t src = ok ? (size_t)(int)ry * W + (int)rx : 0;
+    for (int c = 0; c < C; ++c) {
+        const size_t plane = ((size_t)b * C + c) * H * W;
+        y[plane + (size_t)oy * W + ox] = ok ? x[plane + src] : 0.f;
+    }
+}
+
 int fill_norm(NormArgs& na, int C, const float* mean, const float* stdv, int n_div255) {
     na.enabled = (mean != nullptr && stdv != nullptr);
     na.n_div255 = n_div255;
@@ -129,6 +157,17 @@ int witw_polar_transform(const float* x, const int* taps, const float* wts, floa
     hipLaunchKernelGGL(polar_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
                        (const int4*)taps, (const float4*)wts, y, B, C, size * size, Ho * Wo);
     WITW_CHECK_LAUNCH("polar_transform");
+    return WITW_OK;
+}
+
+// x, y: [B,C,H,W] fp32 (y != x); theta: DEVICE [B,2,3]^T rescaled matrices, see rotate_nearest_kernel.
+int witw_rotate_nearest(const float* x, const float* theta, float* y, int B, int C, int H, int W, void* stream) {
+    WITW_CHECK_ARG(x && theta && y && x != y, "rotate_nearest: null or aliased pointer");
+    WITW_CHECK_ARG(B > 0 && C > 0 && H > 0 && W > 0, "rotate_nearest: bad shape B=%d C=%d H=%d W=%d", B, C, H, W);
+    const size_t total = (size_t)B * H * W;
+    hipLaunchKernelGGL(rotate_nearest_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       theta, y, B, C, H, W);
+    WITW_CHECK_LAUNCH("rotate_nearest");
     return WITW_OK;
 }
 

@@ -11,7 +11,8 @@ import torch
 import torch.nn as nn
 
 from . import _lib, ops
-from .cvig_fov import recall_table  # noqa: F401  (same table, model/cvig_baseline.py:461-466)
+from . import cvig_fov as _fov
+from .cvig_fov import Adam, recall_table  # noqa: F401  (same table, model/cvig_baseline.py:461-466)
 
 device = torch.device('cuda:0' if torch.cuda.is_available() else 'cpu')   # model/cvig_baseline.py:20
 device_parallel = False
@@ -57,6 +58,74 @@ def quantized_rotation(img, factor):
     return img
 
 
+class ImagePairDataset(_fov.ImagePairDataset):
+    """model/cvig_baseline.py:51-94: {'surface','overhead'} CPU float32 CHW tensors (no 'idx')."""
+    _with_idx = False
+
+    @classmethod
+    def _globals(cls):
+        return Globals
+
+
+def _on_device(t):
+    if not t.is_cuda:
+        if device.type != 'cuda':
+            raise _lib.WitwError('no gfx950 device: the WITW transforms run on the GPU only')
+        t = t.to(device)
+    return t
+
+
+class SyncedRotation(object):
+    """model/cvig_baseline.py:130-144: rotate the overhead image by a random angle; a panoramic surface image is
+    rolled by the same angle. `angle` can be injected (tests)."""
+
+    def __init__(self, dataset):
+        self.dataset = dataset
+
+    def __call__(self, data, angle=None):
+        if angle is None:
+            angle = torch.rand(()).item() * 360.
+        if Globals.path_formats[self.dataset]['panorama']:
+            data['surface'] = horizontal_shift(data['surface'], angle, unit='degrees')
+        o = _on_device(data['overhead'])
+        squeeze = o.dim() == 3
+        o = ops.rotate_nearest(o.unsqueeze(0) if squeeze else o, [angle] * (1 if squeeze else o.shape[0]))
+        data['overhead'] = o.squeeze(0) if squeeze else o
+        return data
+
+
+class QuantizedSyncedRotation(object):
+    """model/cvig_baseline.py:147-160: multiples of 90 degrees (exact transposes / flips)."""
+
+    def __init__(self, dataset):
+        self.dataset = dataset
+
+    def __call__(self, data, factor=None):
+        if factor is None:
+            factor = torch.randint(4, ()).item()
+        if Globals.path_formats[self.dataset]['panorama']:
+            data['surface'] = horizontal_shift(data['surface'], factor * 90, unit='degrees')
+        data['overhead'] = quantized_rotation(data['overhead'], factor)
+        return data
+
+
+class GpuPreprocess(object):
+    """Compose[SyncedRotation, SurfaceResize] (model/cvig_baseline.py:324-328) over a batch of raw images, on the
+    GPU: -> {'surface' [B,3,Hs,Ws], 'overhead' [B,3,Ho,Wo]} (values stay 0..255, the encoders rescale)."""
+
+    def __init__(self, dataset):
+        self.rotation = SyncedRotation(dataset)
+        self.resize = SurfaceResize(dataset)
+
+    def __call__(self, batch):
+        s, o = [], []
+        for su, ov in zip(batch['surface'], batch['overhead']):
+            d = self.resize(self.rotation({'surface': _on_device(su[:3]), 'overhead': ov[:3]}))
+            s.append(d['surface'])
+            o.append(d['overhead'])
+        return {'surface': torch.stack(s), 'overhead': torch.stack(o)}
+
+
 class SurfaceResize(object):
     """model/cvig_baseline.py:208-225 on the GPU."""
 
@@ -99,8 +168,10 @@ class SurfaceEncoder(nn.Module):
 
     def _layer(self, i):
         conv, bn = getattr(self, 'conv%d' % i), getattr(self, 'bn%d' % i)
-        key = (conv.weight._version, conv.bias._version, bn.weight._version, bn.bias._version, bn.running_mean._version,
-               bn.running_var._version, conv.weight.data_ptr())
+        # torch's version counters see in-place torch ops; the C-ABI Adam bumps _witw_version instead
+        key = tuple(t._version for t in (conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var)) + \
+            tuple(getattr(t, '_witw_version', 0) for t in (conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var)) + \
+            (conv.weight.data_ptr(),)
         hit = self._packed.get(i)
         if hit is None or hit[0] != key:
             with torch.no_grad():
@@ -178,6 +249,8 @@ class _BaselineEncoderFn(torch.autograd.Function):
                 mean, invstd, scale, shift = ops.bn_train_stats(a, (vh, vw), bn.weight, bn.bias, bn.running_mean,
                                                                 bn.running_var, bn.eps, bn.momentum)
                 bn.num_batches_tracked += 1
+                for t in (bn.running_mean, bn.running_var):      # updated through the C-ABI: invalidate the eval fold
+                    t._witw_version = getattr(t, '_witw_version', 0) + 1
                 saved.append((h, a, (vh, vw), mean, invstd, scale, shift))
                 if i >= 5:
                     ops.gem_pool(a, (vh, vw), g, 512 * (i - 5), enc.p, scale, shift)
@@ -246,3 +319,106 @@ def ranks(overhead_embed, surface_embed):
     """model/cvig_baseline.py:454-460: Euclidean distances, rank = #{gallery : d <= d_true}."""
     D = ops.pairwise_sqdist(overhead_embed.contiguous(), surface_embed.contiguous(), take_sqrt=True)   # [gallery, query]
     return ops.rank_count(D, 0).cpu().numpy().astype('int64')
+
+
+# ----------------------------------------------------------------------------- drivers
+def train(dataset='cvusa', val_quantity=1000, batch_size=16, num_workers=4, num_epochs=999999, csv_path=None):
+    """model/cvig_baseline.py:318-404 on the HIP kernels: same flow, prints and checkpoint names; Adam with torch's
+    defaults (lr 1e-3) over every encoder parameter. Single GPU: the reference's optional nn.DataParallel (:338-342)
+    would change the BatchNorm statistics per replica and is not reproduced."""
+    import pathlib
+    import time
+    pathlib.Path('./weights').mkdir(parents=True, exist_ok=True)
+    csv_path = csv_path or Globals.dataset_paths[dataset]['train']
+    prep = GpuPreprocess(dataset)
+    trainval_set = ImagePairDataset(dataset=dataset, csv_path=csv_path)
+    train_set, val_set = torch.utils.data.random_split(trainval_set, [len(trainval_set) - val_quantity, val_quantity])
+    train_loader = torch.utils.data.DataLoader(train_set, batch_size=batch_size, shuffle=True, drop_last=True,
+                                               num_workers=num_workers, collate_fn=_fov.collate_raw)
+    val_loader = torch.utils.data.DataLoader(val_set, batch_size=batch_size, shuffle=False, drop_last=False,
+                                             num_workers=num_workers, collate_fn=_fov.collate_raw)
+    surface_encoder = SurfaceEncoder().to(device)
+    overhead_encoder = OverheadEncoder().to(device)
+    loss_func = exhaustive_minibatch_triplet_loss
+    optimizer = Adam(list(surface_encoder.parameters()) + list(overhead_encoder.parameters()))
+
+    best_loss = None
+    for epoch in range(num_epochs):
+        print('Epoch %d, %s' % (epoch + 1, time.ctime(time.time())))
+        for phase in ['train', 'val']:
+            running_count = 0
+            running_loss = 0.
+            loader = train_loader if phase == 'train' else val_loader
+            surface_encoder.train(phase == 'train')
+            overhead_encoder.train(phase == 'train')
+            for batch, raw in enumerate(loader):
+                data = prep(raw)
+                with torch.set_grad_enabled(phase == 'train'):
+                    surface_embed = surface_encoder(data['surface'])
+                    overhead_embed = overhead_encoder(data['overhead'])
+                    loss = loss_func(surface_embed, overhead_embed)
+                    if phase == 'train':
+                        optimizer.zero_grad()
+                        loss.backward()
+                        optimizer.step()
+                count = surface_embed.size(0)
+                running_count += count
+                running_loss += loss.item() * count
+                print('epoch = {} {}, iter = {}, count = {}, loss = {:.4f}'.format(epoch + 1, phase, batch, running_count,
+                                                                                 loss.item()))
+            print('  %5s: avg loss = %f' % (phase, running_loss / max(1, running_count)))
+        if running_count and (best_loss is None or running_loss / running_count < best_loss):
+            print('-------> new best')
+            best_loss = running_loss / running_count
+            torch.save(surface_encoder.state_dict(), './weights/surface_best.pth')
+            torch.save(overhead_encoder.state_dict(), './weights/overhead_best.pth')
+    return best_loss
+
+
+def test(dataset='cvusa', batch_size=16, num_workers=4, csv_path=None):
+    """model/cvig_baseline.py:405-475: embed the test set (SyncedRotation stays on, as in the reference :410-414),
+    rank every query against the whole gallery on the GPU, print the recall table."""
+    csv_path = csv_path or Globals.dataset_paths[dataset]['test']
+    prep = GpuPreprocess(dataset)
+    test_set = ImagePairDataset(dataset=dataset, csv_path=csv_path)
+    test_loader = torch.utils.data.DataLoader(test_set, batch_size=batch_size, shuffle=False, drop_last=False,
+                                              num_workers=num_workers, collate_fn=_fov.collate_raw)
+    surface_encoder = SurfaceEncoder().to(device)
+    overhead_encoder = OverheadEncoder().to(device)
+    surface_encoder.load_state_dict(torch.load('./weights/surface_best.pth', map_location='cpu'))
+    overhead_encoder.load_state_dict(torch.load('./weights/overhead_best.pth', map_location='cpu'))
+    surface_encoder.eval()
+    overhead_encoder.eval()
+    su_parts, ov_parts = [], []
+    for raw in test_loader:
+        data = prep(raw)
+        with torch.no_grad():
+            su_parts.append(surface_encoder(data['surface']))
+            ov_parts.append(overhead_encoder(data['overhead']))
+    rk = ranks(torch.cat(ov_parts, dim=0), torch.cat(su_parts, dim=0))
+    t = recall_table(rk)
+    print('Top  1: {:.2f}%'.format(t['top_1']))
+    print('Top  5: {:.2f}%'.format(t['top_5']))
+    print('Top 10: {:.2f}%'.format(t['top_10']))
+    print('Top 1%: {:.2f}%'.format(t['top_1pct']))
+    print('Avg. Rank: {:.2f}'.format(t['mean']))
+    print('Med. Rank: {:.2f}'.format(t['median']))
+    print('Locations: {}'.format(len(rk)))
+    return t
+
+
+def main(argv=None):
+    """CLI of model/cvig_baseline.py:478-492."""
+    import argparse
+    parser = argparse.ArgumentParser()
+    parser.add_argument('--mode', default='train', choices=['train', 'test'], help='Run mode. [Default = train]')
+    parser.add_argument('--dataset', default='cvusa', choices=['cvusa', 'witw'], help='Dataset to use. [Default = cvusa]')
+    args = parser.parse_args(argv)
+    if args.mode == 'train':
+        train(dataset=args.dataset)
+    elif args.mode == 'test':
+        test(dataset=args.dataset)
+
+
+if __name__ == '__main__':
+    main()

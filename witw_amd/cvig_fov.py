@@ -524,13 +524,19 @@ class ImagePairDataset(torch.utils.data.Dataset):
     drivers pass none here and run Resize/ImageNormalization/PolarTransform batched on the GPU instead
     (DataLoader worker processes must not touch the device)."""
 
+    _with_idx = True
+
+    @classmethod
+    def _globals(cls):
+        return Globals
+
     def __init__(self, dataset, csv_path, base_path=None, transform=None):
         import os
         import pandas as pd
         self.csv_path = csv_path
         self.base_path = base_path if base_path is not None else os.path.dirname(csv_path)
         self.transform = transform
-        path_format = Globals.path_formats[dataset]
+        path_format = self._globals().path_formats[dataset]
         file_paths = pd.read_csv(self.csv_path, header=path_format['header'], names=path_format['path_names'],
                                  usecols=path_format['path_columns'])
         self.file_paths = file_paths.map(
@@ -549,8 +555,10 @@ class ImagePairDataset(torch.utils.data.Dataset):
         return torch.from_numpy(a.astype(np.float32).transpose((2, 0, 1)).copy())
 
     def __getitem__(self, idx):
-        data = {'idx': idx, 'surface': self._read(self.file_paths.iloc[idx]['surface']),
+        data = {'surface': self._read(self.file_paths.iloc[idx]['surface']),
                 'overhead': self._read(self.file_paths.iloc[idx]['overhead'])}
+        if self._with_idx:
+            data = dict(idx=idx, **data)
         if self.transform is not None:
             data = self.transform(data)
         return data
@@ -558,26 +566,32 @@ class ImagePairDataset(torch.utils.data.Dataset):
 
 def collate_raw(samples):
     """Raw images differ in size: keep them as lists; GpuPreprocess batches them on the device."""
-    return {'idx': [s['idx'] for s in samples], 'surface': [s['surface'] for s in samples],
-            'overhead': [s['overhead'] for s in samples]}
+    out = {'surface': [s['surface'] for s in samples], 'overhead': [s['overhead'] for s in samples]}
+    if samples and 'idx' in samples[0]:
+        out['idx'] = [s['idx'] for s in samples]
+    return out
 
 
 class GpuPreprocess(object):
     """Compose[Resize, ImageNormalization, PolarTransform] (model/cvig_fov.py:393-397) over a batch of raw
     images, on the GPU: -> {'surface' [B,3,128,Ws], 'overhead' [B,3,256,256], 'polar' [B,3,128,512]}."""
 
+    channels = 3
+    normalization = None      # class used for the normalisation step (cvig_semantic overrides both)
+
     def __init__(self, dataset, fov=360, random_orientation=True):
         self.resize = Resize(dataset, fov, random_orientation)
-        self.norm = ImageNormalization()
+        self.norm = (self.normalization or ImageNormalization)()
         self.polar = PolarTransform()
 
     def __call__(self, batch):
         s, o = [], []
+        c = self.channels
         for su, ov in zip(batch['surface'], batch['overhead']):
-            d = self.resize({'surface': su[:3], 'overhead': ov[:3]})
+            d = self.resize({'surface': su[:c], 'overhead': ov[:c]})
             s.append(d['surface'])
             o.append(d['overhead'])
-        data = {'idx': batch['idx'], 'surface': torch.stack(s), 'overhead': torch.stack(o)}
+        data = {'idx': batch.get('idx'), 'surface': torch.stack(s), 'overhead': torch.stack(o)}
         return self.polar(self.norm(data))
 
 
@@ -599,16 +613,37 @@ def _writer(path):
 def load_reference_state_dict(encoder, state):
     """Load a checkpoint written by the reference (model/cvig_fov.py:485-486): same keys, plus the unused
     VGG classifier tensors (model.classifier.*), which are dropped."""
+    encoder._reference_classifier = {k: v for k, v in state.items() if k.startswith('model.classifier')} or None
     state = {k: v for k, v in state.items() if not k.startswith('model.classifier')}
     return encoder.load_state_dict(state, strict=True)
 
 
+def save_reference_state_dict(encoder, path):
+    """Write a checkpoint the reference's `load_state_dict` accepts (model/cvig_fov.py:511-512, strict): this
+    encoder's tensors plus the VGG classifier tensors the reference carries along — the ones a previous
+    load_reference_state_dict saw, else zeros of the VGG16 shapes (they never reach the forward, :258)."""
+    state = dict(encoder.state_dict())
+    extra = getattr(encoder, '_reference_classifier', None)
+    if extra is None:
+        shapes = {0: (4096, 25088), 3: (4096, 4096), 6: (1000, 4096)}
+        extra = {}
+        for i, (o, n) in shapes.items():
+            extra['model.classifier.%d.weight' % i] = torch.zeros((o, n))
+            extra['model.classifier.%d.bias' % i] = torch.zeros((o,))
+    state.update(extra)
+    torch.save(state, path)
+
+
 def train(dataset='cvusa', fov=360, val_quantity=1000, batch_size=64, num_workers=12, num_epochs=999999, csv_path=None,
-          seed=0):
-    """model/cvig_fov.py:385-487 on the HIP kernels (same flow, checkpoint names and prints)."""
+          seed=0, _mod=None):
+    """model/cvig_fov.py:385-487 on the HIP kernels (same flow, checkpoint names and prints). `_mod` is the
+    module whose Globals / FOV_DSM / ImagePairDataset / GpuPreprocess are used (cvig_semantic passes itself)."""
     import pathlib
+    import sys
     import time
     from datetime import datetime
+    m = _mod or sys.modules[__name__]
+    Globals, FOV_DSM, ImagePairDataset, GpuPreprocess, device = m.Globals, m.FOV_DSM, m.ImagePairDataset, m.GpuPreprocess, m.device
     pathlib.Path('./weights').mkdir(parents=True, exist_ok=True)
     writer = _writer('runs/{}/train/{}/{}'.format(dataset, fov, datetime.now().strftime("%Y%m%d-%H%M%S")))
     csv_path = csv_path or Globals.dataset_paths[dataset]['train']
@@ -663,10 +698,13 @@ def train(dataset='cvusa', fov=360, val_quantity=1000, batch_size=64, num_worker
     return best_loss
 
 
-def test(dataset='cvusa', fov=360, batch_size=64, num_workers=8, csv_path=None):
+def test(dataset='cvusa', fov=360, batch_size=64, num_workers=8, csv_path=None, _mod=None):
     """model/cvig_fov.py:490-575: embed the test set, rank every query against the whole gallery (all
     queries at once on the GPU instead of the O(N) Python loop), print the recall table."""
+    import sys
     from datetime import datetime
+    m = _mod or sys.modules[__name__]
+    Globals, FOV_DSM, ImagePairDataset, GpuPreprocess, device = m.Globals, m.FOV_DSM, m.ImagePairDataset, m.GpuPreprocess, m.device
     writer = _writer('runs/{}/test/{}/{}'.format(dataset, fov, datetime.now().strftime("%Y%m%d-%H%M%S")))
     csv_path = csv_path or Globals.dataset_paths[dataset]['test']
     prep = GpuPreprocess(dataset, fov)

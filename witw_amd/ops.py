@@ -424,6 +424,34 @@ def polar_transform(x, h_s=128, w_s=512):
     return y
 
 
+def rotation_theta(angles_deg, H, W):
+    """Host side of torchvision 0.9.1's F.rotate for tensors: inverse matrix of a rotation by `angle` about the
+    image centre (_get_inverse_affine_matrix with centre 0, angle -> -angle), as fp32, divided by (W/2, H/2)
+    (_gen_affine_grid). -> CPU fp32 [B,3,2] (row k = coefficient of x, y, 1)."""
+    import math
+    out = torch.empty((len(angles_deg), 3, 2), dtype=torch.float32)
+    half = torch.tensor([0.5 * W, 0.5 * H], dtype=torch.float32)
+    for i, a in enumerate(angles_deg):
+        rot = math.radians(-float(a))
+        m = torch.tensor([[math.cos(rot), math.sin(rot), 0.0], [-math.sin(rot), math.cos(rot), 0.0]], dtype=torch.float32)
+        out[i] = m.t() / half
+    return out
+
+
+def rotate_nearest(x, angles_deg):
+    """x [B,C,H,W] fp32 on the GPU rotated counter-clockwise by angles_deg[b] degrees about the centre, nearest
+    neighbour, zero fill, same size (model/cvig_baseline.py:142)."""
+    lib = _lib.load()
+    assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+    x = x.contiguous()
+    B, C, H, W = x.shape
+    theta = rotation_theta(angles_deg, H, W).to(x.device)
+    y = torch.empty_like(x)
+    _lib.check(lib.witw_rotate_nearest(x.data_ptr(), theta.data_ptr(), y.data_ptr(), B, C, H, W, _stream()),
+               'witw_rotate_nearest')
+    return y
+
+
 # ----------------------------------------------------------------------------- cvig_baseline pieces
 def space_to_depth2(x, valid_hw=None, cpad=None, in_nchw=False, normalize=False, scale=None, shift=None):
     lib = _lib.load()
