@@ -55,8 +55,12 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--batch', type=int, default=128, help='pairs per GPU (BASELINE.json configs[1]: bs=128)')
     ap.add_argument('--fov', type=int, default=360)
-    ap.add_argument('--mode', choices=['infer', 'train'], default='infer',
-                    help='infer (headline): embedding + similarity; train: the full step of model/cvig_fov.py:444-461')
+    ap.add_argument('--mode', choices=['infer', 'train', 'retrieval'], default='infer',
+                    help='infer (headline): embedding + similarity; train: the full step of model/cvig_fov.py:444-461; '
+                         'retrieval: BASELINE config 5, --gallery rows per GPU x --queries, ranks + top-k')
+    ap.add_argument('--gallery', type=int, default=125000, help='retrieval: gallery rows PER GPU (1M / 8)')
+    ap.add_argument('--queries', type=int, default=10000, help='retrieval: ground queries (replicated)')
+    ap.add_argument('--topk', type=int, default=10)
     ap.add_argument('--precision', choices=['fp32', 'bf16'], default='fp32',
                     help='fp32 (headline, BASELINE configs[1]) or the bf16 MFMA inference path (configs[3] arithmetic)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -84,6 +88,9 @@ def main():
 
     from witw_amd import _lib, cvig_fov, ops, synth, parallel
     _lib.check(_lib.load().witw_device_check(local), 'witw_device_check')
+
+    if a.mode == 'retrieval':
+        return retrieval(a, rank, world, device, cvig_fov, ops)
 
     B = a.batch
     seed = 1234
@@ -165,7 +172,7 @@ def main():
     peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
     kname = 'conv3x3_nhwc_bf16_kernel<128,1,false,8>' if bf16 else 'conv3x3_nhwc_f32_kernel<128,1,false,8,0>'
     dom = [(fl, e0.elapsed_time(e1)) for (v, fl, e0, e1) in prof if v == dominant]
-    allc = [(fl, e0.elapsed_time(e1)) for (v, fl, e0, e1) in prof]
+    allc = [(fl, e0.elapsed_time(e1)) for (v, fl, e0, e1) in prof if v[0] != 'match']
     dom_fl = sum(f for f, _ in dom) / max(1, len(dom))
     dom_ms = sum(m for _, m in dom) / max(1, len(dom))
     achieved = dom_fl / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
@@ -199,6 +206,78 @@ def main():
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline and not train and not bf16:
         out['cpu_baseline'] = cpu_baseline(a, ground_raw, ov_raw, wts, ws, step)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def retrieval(a, rank, world, device, cvig_fov, ops):
+    """BASELINE config 5 (gallery retrieval): every rank holds --gallery overhead embeddings [16,4,64] (weak
+    scaling: 8 x 125k = 1M rows), the --queries ground embeddings are replicated; one step = fused orientation
+    search + chord distance of every (gallery row, query) pair (524,288 FLOP each at fov 360), rank counts
+    against the true match and the k nearest rows, merged over ranks (A7-A9, A12; model/cvig_fov.py:543-552)."""
+    G, Q, k = a.gallery, a.queries, a.topk
+    we = int(a.fov / 360 * 512) // 8
+    gen = torch.Generator(device=device)
+    gen.manual_seed(4321 + rank)
+    gallery = torch.randn((G, 16, 4, 64), generator=gen, device=device)
+    # query q = gallery row q (global numbering, rank-major) rolled by a per-query shift, cropped to the FoV, plus noise
+    queries = torch.zeros((Q, 16, 4, we), device=device)
+    lo, hi = rank * G, min(Q, (rank + 1) * G)
+    if hi > lo:
+        shifts = torch.randint(0, 64, (hi - lo,), generator=gen, device=device)
+        col = (torch.arange(we, device=device)[None, :] + shifts[:, None]) % 64                      # [n, we]
+        rows = gallery[lo - rank * G:hi - rank * G]
+        queries[lo:hi] = torch.gather(rows, 3, col[:, None, None, :].expand(-1, 16, 4, -1)) \
+            + 10.0 * torch.randn((hi - lo, 16, 4, we), generator=gen, device=device)
+    if world > 1:
+        dist.all_reduce(queries)
+
+    def step():
+        return cvig_fov.retrieve(gallery, queries, k=k, shard_begin=rank * G)
+
+    for _ in range(a.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ops.PROFILE = []
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        ranks_h, vals, idx = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof, ops.PROFILE = ops.PROFILE, None
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    m = [(fl, e0.elapsed_time(e1)) for (v, fl, e0, e1) in prof if v[0] == 'match']
+    m_fl = sum(f for f, _ in m) / max(1, len(m))
+    m_ms = sum(t for _, t in m) / max(1, len(m))
+    achieved = m_fl / (m_ms * 1e-3) / 1e12 if m_ms > 0 else 0.0
+    top1_hit = float((idx[:, 0].cpu().numpy() == np.arange(Q)).mean() * 100)
+    out = {
+        'metric': 'query-gallery pairs/sec (orientation search + distance + rank + top-%d)' % k,
+        'value': round(float(G) * world * Q * a.steps / dt, 1), 'unit': 'pairs/s', 'n_gpus': world, 'steps': a.steps,
+        'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'gallery retrieval: %d overhead embeddings per GPU (%d total) x %d ground queries, fov=%d, '
+                               'ranks + top-%d' % (G, G * world, Q, a.fov, k),
+                   'parallelism': 'gallery rows sharded over %d rank(s); all-reduce of true distances and rank counts, '
+                                  'all-gather + merge of top-k candidates' % world},
+        'queries_per_sec': round(Q * a.steps / dt, 1),
+        'recall': {'top1_pct': float(np.mean(ranks_h <= 1) * 100), 'top5_pct': float(np.mean(ranks_h <= 5) * 100),
+                   'top10_pct': float(np.mean(ranks_h <= 10) * 100), 'N': int(G * world), 'topk_first_is_true_pct': top1_hit},
+        'roofline': {'bound': 'mfma', 'kernel': 'witw_match_fwd launch (match_kernel_w64 + 2 norm kernels)',
+                     'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                     'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None, 'launches': len(m),
+                     'avg_launch_ms': round(m_ms, 3), 'avg_launch_gflop': round(m_fl / 1e9, 1)},
+    }
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -381,7 +381,7 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_f32_kernel(ConvArgs p) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) w[e] = gt[e] > 0.f ? v[e] : 0.f;
                     }
-                    *reinterpret_cast<f32x4*>(p.y + o) = w;
+                    __builtin_nontemporal_store(w, reinterpret_cast<f32x4*>(p.y + o));
                 }
             }
         }
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_f32_kernel(ConvArgs p) {
                 const int pc = g * 4 + prow;
                 const f32x4 v = *reinterpret_cast<const f32x4*>(slab + pc * 64 + pc4);
                 if (yy < Hy && xb + pc < Wy && nbase < p.Cout)
-                    *reinterpret_cast<f32x4*>(p.y + (((size_t)b * Hy + yy) * Wy + xb + pc) * p.Cout + nbase) = v;
+                    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p.y + (((size_t)b * Hy + yy) * Wy + xb + pc) * p.Cout + nbase));
             }
         }
     } else {

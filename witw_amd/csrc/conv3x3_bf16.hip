@@ -247,7 +247,7 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_bf16_kernel(ConvBfArgs p
                 }
                 const int xx = ox0 + tcol[mt] + m;
                 if (yy < Hy && xx < Wy && nbase < p.Cout)
-                    *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p.y) + (((size_t)b * Hy + yy) * Wy + xx) * p.Cout + nbase) = o;
+                    __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p.y) + (((size_t)b * Hy + yy) * Wy + xx) * p.Cout + nbase));
             }
         }
     } else if (!POOL) {
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_bf16_kernel(ConvBfArgs p
                     o[4 + e] = (__bf16)v1[e];
                 }
                 if (yy < Hy && xb + pc < Wy && nbase < p.Cout)
-                    *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p.y) + (((size_t)b * Hy + yy) * Wy + xb + pc) * p.Cout + nbase) = o;
+                    __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p.y) + (((size_t)b * Hy + yy) * Wy + xb + pc) * p.Cout + nbase));
             }
         }
     } else {

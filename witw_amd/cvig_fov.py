@@ -470,20 +470,55 @@ def retrieve_topk(overhead_shard, surface_all, k=10, shard_begin=0, query_chunk=
         idxs.append(i)
     v, i = torch.cat(vals), torch.cat(idxs)
     if parallel.world() > 1:
-        w = parallel.world()
-        v_all = parallel._all_gather_cat(v.unsqueeze(0))            # [w, N, k]
-        i_all = parallel._all_gather_cat(i.unsqueeze(0))
-        cand_v = v_all.permute(0, 2, 1).reshape(w * k, n_q).contiguous()   # candidates as a [w*k, N] "distance matrix"
-        cand_i = i_all.permute(0, 2, 1).reshape(w * k, n_q)
-        cand_v = torch.where(cand_i < 0, torch.full_like(cand_v, float('inf')), cand_v)
-        # merge on (distance, global index): order candidate rows by global index first so that the kernel's
-        # row-number tie-break equals the gallery-index tie-break
-        order = torch.argsort(torch.where(cand_i < 0, torch.full_like(cand_i, 2 ** 62), cand_i), dim=0, stable=True)
-        cand_v = torch.gather(cand_v, 0, order).contiguous()
-        cand_i = torch.gather(cand_i, 0, order)
-        v, pos = ops.topk_smallest(cand_v, k)
-        i = torch.gather(cand_i.t(), 1, pos.clamp(min=0))
+        v, i = _merge_topk(v, i, k)
     return v, i
+
+
+def _merge_topk(v, i, k):
+    """All-gather per-shard [N,k] candidate lists and merge them on (distance, global gallery index)."""
+    from . import parallel
+    w = parallel.world()
+    n_q = v.shape[0]
+    v_all = parallel._all_gather_cat(v.unsqueeze(0))            # [w, N, k]
+    i_all = parallel._all_gather_cat(i.unsqueeze(0))
+    cand_v = v_all.permute(0, 2, 1).reshape(w * k, n_q).contiguous()   # candidates as a [w*k, N] "distance matrix"
+    cand_i = i_all.permute(0, 2, 1).reshape(w * k, n_q)
+    cand_v = torch.where(cand_i < 0, torch.full_like(cand_v, float('inf')), cand_v)
+    # order candidate rows by global index first so that the kernel's row-number tie-break equals the
+    # gallery-index tie-break
+    order = torch.argsort(torch.where(cand_i < 0, torch.full_like(cand_i, 2 ** 62), cand_i), dim=0, stable=True)
+    cand_v = torch.gather(cand_v, 0, order).contiguous()
+    cand_i = torch.gather(cand_i, 0, order)
+    v, pos = ops.topk_smallest(cand_v, k)
+    return v, torch.gather(cand_i.t(), 1, pos.clamp(min=0))
+
+
+def retrieve(overhead_shard, surface_all, k=10, shard_begin=0, query_chunk=4096):
+    """sharded_ranks + retrieve_topk from ONE matching pass per query chunk (config C5: the pass is
+    2*64*E FLOP per (gallery row, query) and dominates). -> (ranks int64 [N] on the host, distances f32 [N,k],
+    gallery indices int64 [N,k] on the device), identical on every rank."""
+    from . import parallel
+    n_q, n_g = surface_all.shape[0], overhead_shard.shape[0]
+    counts = torch.zeros((n_q,), dtype=torch.int32, device=surface_all.device)
+    vals, idxs = [], []
+    gallery = overhead_shard.contiguous()
+    for q0 in range(0, n_q, query_chunk):
+        q1 = min(n_q, q0 + query_chunk)
+        _, dist = ops.match_fwd(gallery, surface_all[q0:q1].contiguous())            # [n_g, q]
+        qi = torch.arange(q0, q1, device=dist.device)
+        own = (qi >= shard_begin) & (qi < shard_begin + n_g)
+        row = (qi - shard_begin).clamp(0, n_g - 1)
+        d_true = torch.where(own, dist[row, qi - q0], torch.zeros_like(dist[0]))
+        parallel.all_reduce_sum_(d_true)
+        counts[q0:q1] = ops.rank_count_thresh(dist, d_true.contiguous())
+        v, i = ops.topk_smallest(dist, k, shard_begin)
+        vals.append(v)
+        idxs.append(i)
+    parallel.all_reduce_sum_(counts)
+    v, i = torch.cat(vals), torch.cat(idxs)
+    if parallel.world() > 1:
+        v, i = _merge_topk(v, i, k)
+    return counts.cpu().numpy().astype('int64'), v, i
 
 
 def evaluate_global_batch(overhead_all, surface_local, col0, alpha=10.):

@@ -227,8 +227,15 @@ def match_fwd(overhead_embed, surface_embed, want_score=False, want_workspace=Fa
     dist = torch.empty((Bo, Bs), dtype=torch.float32, device=ov.device)
     score = torch.empty((Bo, Bs), dtype=torch.float32, device=ov.device) if want_score else None
     ws = torch.empty(lib.witw_match_workspace_floats(Bo, Bs), dtype=torch.float32, device=ov.device)
+    prof = PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     _lib.check(lib.witw_match_fwd(ov.data_ptr(), su.data_ptr(), Bo, Bs, We, ori.data_ptr(), dist.data_ptr(), _p(score),
                                   ws.data_ptr(), _stream()), 'witw_match_fwd')
+    if prof is not None:      # the launch = two small norm kernels + the match kernel
+        e1.record()
+        prof.append((('match', We), 2.0 * 64 * (64 * We) * Bo * Bs, e0, e1))
     if want_workspace:
         return ori, dist, score, ws
     return (ori, dist, score) if want_score else (ori, dist)
