@@ -1,0 +1,46 @@
+#!/usr/bin/env python
+"""profiles/traffic.json from two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE, collected separately as
+MI355X_MICROARCH.md prescribes) over `bench.py --steps 2 --warmup 1 --no-cpu-baseline`.
+
+    python tools/make_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> [batch] > profiles/traffic.json
+"""
+import csv
+import json
+import sys
+from collections import defaultdict
+
+
+def per_kernel(path, counter):
+    acc = defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r['Counter_Name'] != counter:
+            continue
+        k = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0]
+        acc[k].append(float(r['Counter_Value']))
+    return {k: (len(v), sum(v) / len(v)) for k, v in acc.items()}
+
+
+def main():
+    fetch, write = per_kernel(sys.argv[1], 'FETCH_SIZE'), per_kernel(sys.argv[2], 'WRITE_SIZE')
+    batch = int(sys.argv[3]) if len(sys.argv) > 3 else 128
+    out = {'_note': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes over `bench.py --steps 2 --warmup 1 '
+                    '--no-cpu-baseline` (B=%d, fov 360); bytes = (2*FETCH_SIZE + WRITE_SIZE) KB * 1024: gfx950 FETCH_SIZE reports '
+                    'half the bytes of 16-B/lane coalesced reads (MI355X_MICROARCH.md, HBM section); averaged over the launches '
+                    'of each kernel; FETCH_SIZE counts L2 misses served by the fabric (Infinity Cache hits included)' % batch}
+    kernels = {}
+    for k in sorted(fetch, key=lambda k: -fetch[k][0] * fetch[k][1]):
+        if k not in write or 'at::' in k or 'rocclr' in k:
+            continue
+        n, f = fetch[k]
+        w = write[k][1]
+        kernels[k] = {'launches': n, 'FETCH_SIZE_KB_avg': round(f, 1), 'WRITE_SIZE_KB_avg': round(w, 1),
+                      'hbm_bytes_per_launch_corrected': int((2 * f + w) * 1024)}
+        compact = k.replace(' ', '')
+        if compact.startswith('conv3x3_nhwc_f32_kernel<128,1,false,8') or compact.startswith('conv3x3_nhwc_bf16_kernel<128,1,false,8'):
+            out['%s_bytes_per_launch_B%d' % (compact, batch)] = kernels[k]['hbm_bytes_per_launch_corrected']
+    out['kernels'] = kernels
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == '__main__':
+    main()

@@ -84,8 +84,8 @@ def load():
     # library so that both share ONE HIP runtime (streams and device pointers are exchanged); a
     # second runtime in the process fails with "no ROCm-capable device is detected".
     import torch  # noqa: F401
-    path = _build.LIB
-    if not os.path.exists(path) or (os.path.isdir(_build.CSRC) and _build.stale() and os.path.exists(_build.HIPCC)):
+    path = os.environ.get('WITW_LIB') or _build.LIB      # WITW_LIB: an alternative build of the same ABI (A/B timing)
+    if path == _build.LIB and (not os.path.exists(path) or (os.path.isdir(_build.CSRC) and _build.stale() and os.path.exists(_build.HIPCC))):
         _build.build(verbose=False)
     lib = ctypes.CDLL(path)
     for name, (res, args) in SIGNATURES.items():

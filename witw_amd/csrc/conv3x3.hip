@@ -41,6 +41,7 @@ struct ConvArgs {
     int B, H, W, Cin, Cout;
     int Ho, Wo;             // conv output size (before pooling)
     int tiles_x, tiles_y;
+    int n_tiles, sp_total, sp_per_xcd, xcd_map;   // workgroup -> tile mapping, see the kernel
     int circ, relu, out_nchw;
     int force_nw;           // 0 = choose, 4 / 8 = force the workgroup shape (tuning aid)
     int force_geo;          // -1 = choose, 0 / 1 = force the wide / narrow tile geometry
@@ -80,17 +81,26 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_f32_kernel(ConvArgs p) {
     const int l31 = lane & 31;
     const int hq = lane >> 5;
 
-    // ---- block -> (n tile, image, spatial tile); n tile slowest so that the blocks in
-    // flight share one weight slab (L2 resident) while input tiles stream.
-    int bid = blockIdx.x;
+    // ---- block -> (n tile, image, spatial tile). Workgroups go to the 8 XCDs round-robin (block i -> XCD i % 8), each
+    // with its own L2. XCD x takes the contiguous range [x*sp_per_xcd, (x+1)*sp_per_xcd) of spatial tiles and runs
+    // the n tiles of one spatial tile back to back: the halo tile is fetched over the fabric once instead of once per
+    // n tile, vertically adjacent tiles share their halo rows in L2, and the (small) weight chunks of all n tiles stay
+    // L2 resident. The grid is padded to 8 * sp_per_xcd * n_tiles; surplus workgroups leave here.
+    int ntile, sp;
+    if (p.xcd_map) {
+        const int g = blockIdx.x >> 3;
+        ntile = g % p.n_tiles;
+        sp = (blockIdx.x & 7) * p.sp_per_xcd + g / p.n_tiles;
+        if (sp >= p.sp_total) return;
+    } else {        // n tile slowest: the workgroups in flight share one weight slab
+        ntile = blockIdx.x / p.sp_total;
+        sp = blockIdx.x - ntile * p.sp_total;
+    }
     const int tiles_img = p.tiles_x * p.tiles_y;
-    const int per_n = p.B * tiles_img;
-    const int ntile = bid / per_n;
-    bid -= ntile * per_n;
-    const int b = bid / tiles_img;
-    bid -= b * tiles_img;
-    const int ty = bid / p.tiles_x;
-    const int tx = bid - ty * p.tiles_x;
+    const int b = sp / tiles_img;
+    sp -= b * tiles_img;
+    const int ty = sp / p.tiles_x;
+    const int tx = sp - ty * p.tiles_x;
     const int oy0 = ty * TH;
     const int ox0 = tx * TW;
     const int n0 = ntile * TN;
@@ -552,12 +562,15 @@ template <int TN, int SH, bool POOL, int NW, int GEO>
 int launch_conv_nw(ConvArgs a, hipStream_t st) {
     a.tiles_y = cdiv(a.Ho, GEO ? 4 * NW : NW);
     a.tiles_x = cdiv(a.Wo, GEO ? 16 : 64);
-    const int n_tiles = cdiv(a.Cout, TN);
-    const long long grid = (long long)n_tiles * a.B * a.tiles_x * a.tiles_y;
-    if (grid <= 0 || grid > 0x7fffffffLL) {
+    const long long sp_total = (long long)a.B * a.tiles_x * a.tiles_y;
+    a.n_tiles = cdiv(a.Cout, TN);
+    a.sp_per_xcd = (int)((sp_total + 7) / 8);
+    const long long grid = a.xcd_map ? 8LL * a.sp_per_xcd * a.n_tiles : sp_total * a.n_tiles;
+    if (grid <= 0 || grid > 0x7fffffffLL || sp_total > 0x7fffffffLL) {
         witw_set_error("conv3x3: grid %lld out of range", grid);
         return WITW_ERR_INVALID;
     }
+    a.sp_total = (int)sp_total;
     hipLaunchKernelGGL((conv3x3_nhwc_f32_kernel<TN, SH, POOL, NW, GEO>), dim3((unsigned)grid), dim3(64 * NW), 0, st, a);
     WITW_CHECK_LAUNCH("conv3x3_nhwc_f32");
     return WITW_OK;
@@ -678,6 +691,7 @@ int witw_conv3x3_fwd_ex(const float* x, const float* wpk, const float* bias, con
     a.tiles_y = 0;   // set by the launcher for the chosen tile height
     a.force_nw = env_int("WITW_CONV_NW", 0);
     a.force_geo = env_int("WITW_CONV_GEO", -1);
+    a.xcd_map = env_int("WITW_CONV_XCD", 1) != 0;      // 0: plain n-tile-major order (A/B timing)
     a.circ = pad_circular; a.relu = relu; a.out_nchw = out_nchw; a.dil_h = dilate_h;
 #ifdef WITW_STAMPS
     a.stamps = witw_conv_stamps_ptr;

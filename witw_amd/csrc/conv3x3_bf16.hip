@@ -22,6 +22,43 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int TW = 64;
 constexpr int IW = TW + 2;
 
+// Staging mode: 0 = global -> VGPR -> ds_write for both images; 1 = weight slab by LDS-DMA (buffer_load ... lds:
+// the packed slab is already the LDS image, 1 KB contiguous per wave instruction); 2 = input tile by LDS-DMA too.
+#ifndef WITW_BF_DMA
+#define WITW_BF_DMA 1
+#endif
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// Raw buffer descriptor (base, stride 0, byte count, the flag word __builtin_amdgcn_make_buffer_rsrc is given elsewhere
+// in this file) as four SGPRs for the hand-issued LDS-DMA loads.
+__device__ __forceinline__ i32x4 raw_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)base;
+    i32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    r[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)((a >> 32) & 0xffffu));
+    r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+    r[3] = 0x00020000;
+    return r;
+}
+
+// One wave instruction of LDS-DMA: lane l moves 16 B from rs[voff_l + soff] to LDS byte address lds_addr + 16*l
+// (out-of-range lanes store zeros). Issued as inline assembly ON PURPOSE: for the builtin form the compiler puts a
+// vmcnt wait in front of every later ds_read (it cannot tell the stage being read from the stage being filled), which
+// serialises the pipeline; here the wave drains vmcnt itself once per K chunk (stage_wait) before the barrier.
+__device__ __forceinline__ void dma16(i32x4 rs, unsigned lds_addr, unsigned voff, unsigned soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :
+                 : "s"(lds_addr), "v"(voff), "s"(rs), "s"(soff)
+                 : "memory");      // m0 is a scratch register for the compiler too: it re-sets it right before each of its own uses
+#endif
+}
+
+__device__ __forceinline__ unsigned lds_address(const void* p) {
+    return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)p;
+}
+
 struct ConvBfArgs {
     const unsigned short* x;   // [B,H,W,Cin] NHWC bf16, Cin % 16 == 0
     const unsigned short* wpk; // packed bf16: [n_tile][cin/16][tap][group][TN][8]
@@ -31,6 +68,7 @@ struct ConvBfArgs {
     int Ho, Wo;
     int tiles_x, tiles_y;
     int circ, relu, out_nchw_f32;
+    int n_tiles, sp_total, sp_per_xcd, xcd_map;
 };
 
 template <int TN, int SH, bool POOL, int NW>
@@ -39,30 +77,48 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_bf16_kernel(ConvBfArgs p
     constexpr int NTHREADS = 64 * NW;
     constexpr int IH = (TH - 1) * SH + 3;
     constexpr int IN_S = 2 * IH * IW;           // 16-B slots of one input stage (2 channel groups)
-    constexpr int W_S = 9 * 2 * TN;             // 16-B slots of one weight stage
-    constexpr int STAGE_S = IN_S + W_S;
+    constexpr int IN_P = (IN_S + 63) / 64 * 64;  // ... padded to whole 64-slot wave instructions (LDS-DMA granule)
+    constexpr int W_S = 9 * 2 * TN;             // 16-B slots of one weight stage (a multiple of 64)
+    constexpr int STAGE_S = IN_P + W_S;
     constexpr int NIN = (IN_S + NTHREADS - 1) / NTHREADS;
     constexpr int NWT = (W_S + NTHREADS - 1) / NTHREADS;
+    constexpr int NIN_D = (IN_P / 64 + NW - 1) / NW;     // LDS-DMA wave instructions per wave and stage
+    constexpr int NWT_D = (W_S / 64 + NW - 1) / NW;
     constexpr int WGM = (TN == 128) ? NW / 2 : NW;
     constexpr int WM = (2 * TH) / WGM;
     constexpr int WN = 2;
     constexpr unsigned OOR = 0x80000000u;
+    static_assert(W_S % 64 == 0, "weight stage must be whole wave instructions");
+    static_assert(STAGE_S * 16 >= (NW / 2) * 32 * 64 * 4, "a stage must hold the epilogue slabs of half the waves");
 
-    __shared__ u32x4 smem[2 * STAGE_S + 1];
+    // two separately declared stages: the compiler can then tell the fragment reads of one stage from the LDS-DMA
+    // writes into the other (distinct objects -> no vmcnt wait in front of every ds_read); stageB's extra slot takes
+    // the masked-off register-path stores
+    __shared__ u32x4 stageA[STAGE_S];
+    __shared__ u32x4 stageB[STAGE_S + 1];
+    u32x4* const dummy_slot = stageB + STAGE_S;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave) & (NW - 1);      // the mask tells the compiler the range
     const int l31 = lane & 31, hq = lane >> 5;
 
-    int bid = blockIdx.x;
+    // block -> (n tile, spatial tile): XCD-aware order, see conv3x3.hip (block i runs on XCD i % 8)
+    int ntile, sp;
+    if (p.xcd_map) {
+        const int g = blockIdx.x >> 3;
+        ntile = g % p.n_tiles;
+        sp = (blockIdx.x & 7) * p.sp_per_xcd + g / p.n_tiles;
+        if (sp >= p.sp_total) return;
+    } else {
+        ntile = blockIdx.x / p.sp_total;
+        sp = blockIdx.x - ntile * p.sp_total;
+    }
     const int tiles_img = p.tiles_x * p.tiles_y;
-    const int per_n = p.B * tiles_img;
-    const int ntile = bid / per_n;
-    bid -= ntile * per_n;
-    const int b = bid / tiles_img;
-    bid -= b * tiles_img;
-    const int ty = bid / p.tiles_x;
-    const int tx = bid - ty * p.tiles_x;
+    const int b = sp / tiles_img;
+    sp -= b * tiles_img;
+    const int ty = sp / p.tiles_x;
+    const int tx = sp - ty * p.tiles_x;
     const int oy0 = ty * TH, ox0 = tx * TW, n0 = ntile * TN;
     const int nkc = p.Cin >> 4;
 
@@ -73,48 +129,104 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_bf16_kernel(ConvBfArgs p
         __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)b * img_elems), 0, (unsigned)(img_elems * 2), 0x00020000);
     __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(reinterpret_cast<const u32x4*>(p.wpk) + (size_t)ntile * nkc * W_S), 0, (unsigned)nkc * W_S * 16u, 0x00020000);
-    unsigned gin[NIN];
-#pragma unroll
-    for (int i = 0; i < NIN; ++i) {
-        const int s = tid + i * NTHREADS;
-        const int pix = s >> 1, q = s & 1;
+#if WITW_BF_DMA >= 1
+    const i32x4 w_rd = raw_rsrc(reinterpret_cast<const u32x4*>(p.wpk) + (size_t)ntile * nkc * W_S, (unsigned)nkc * W_S * 16u);
+#endif
+#if WITW_BF_DMA >= 2
+    const i32x4 in_rd = raw_rsrc(p.x + (size_t)b * img_elems, (unsigned)(img_elems * 2));
+#endif
+    // byte offset of halo-tile slot (pixel pix, channel group q) in the image, or OOR (loads return zero: padding)
+    auto in_offset = [&](bool in_range, int pix, int q) -> unsigned {
         const int r = pix / IW, c = pix - r * IW;
         const int gr = oy0 * SH - 1 + r;
         int gc = ox0 - 1 + c;
-        bool ok = (s < IN_S) && gr >= 0 && gr < p.H;
+        bool ok = in_range && gr >= 0 && gr < p.H;
         if (p.circ) {
             gc %= p.W;
             if (gc < 0) gc += p.W;
         } else {
             ok = ok && gc >= 0 && gc < p.W;
         }
-        gin[i] = ok ? (unsigned)((((size_t)gr * p.W + gc) * p.Cin + q * 8) * 2) : OOR;
+        return ok ? (unsigned)((((size_t)gr * p.W + gc) * p.Cin + q * 8) * 2) : OOR;
+    };
+#if WITW_BF_DMA >= 2
+    unsigned gin[NIN_D];        // DMA: slot s = instr * 64 + lane IS the LDS position [group][pixel]
+#pragma unroll
+    for (int i = 0; i < NIN_D; ++i) {
+        const int s = (wave + NW * i) * 64 + lane;
+        const int q = s / (IH * IW);
+        gin[i] = in_offset(s < IN_S, s - q * (IH * IW), q);
     }
+#else
+    unsigned gin[NIN];          // registers: slot s -> pixel s/2, group s%2 (a pixel's 32 B load as one segment)
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) {
+        const int s = tid + i * NTHREADS;
+        gin[i] = in_offset(s < IN_S, s >> 1, s & 1);
+    }
+    u32x4 rin[NIN];
+#endif
+#if WITW_BF_DMA < 1
+    u32x4 rw[NWT];
+#endif
     const unsigned gwoff = (unsigned)tid * 16u;
+    const unsigned lane16 = (unsigned)lane * 16u;
 
-    u32x4 rin[NIN], rw[NWT];
-    auto load_stage = [&](int kc) {
+    // start moving K chunk kc toward LDS stage `buf`
+    auto stage_issue = [&](int kc, u32x4* in_s) {
+        u32x4* w_s = in_s + IN_P;
+        (void)in_s; (void)w_s;
+#if WITW_BF_DMA >= 1
+        const unsigned in_lds = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_address(in_s));
+#endif
+#if WITW_BF_DMA >= 2
+#pragma unroll
+        for (int i = 0; i < NIN_D; ++i) {
+            const int j = wave_u + NW * i;
+            if (NIN_D * NW == IN_P / 64 || j < IN_P / 64) dma16(in_rd, in_lds + (unsigned)j * 1024u, gin[i], (unsigned)kc * 32u);
+        }
+#else
 #pragma unroll
         for (int i = 0; i < NIN; ++i) rin[i] = __builtin_amdgcn_raw_buffer_load_b128(in_rs, gin[i], (unsigned)kc * 32u, 0);
+#endif
         const unsigned wbase = (unsigned)kc * W_S * 16u;
+#if WITW_BF_DMA >= 1
+#pragma unroll
+        for (int i = 0; i < NWT_D; ++i) {
+            const int j = wave_u + NW * i;
+            if (NWT_D * NW == W_S / 64 || j < W_S / 64) dma16(w_rd, in_lds + (unsigned)(IN_P + j * 64) * 16u, lane16, wbase + (unsigned)j * 1024u);
+        }
+#else
 #pragma unroll
         for (int i = 0; i < NWT; ++i) rw[i] = __builtin_amdgcn_raw_buffer_load_b128(w_rs, gwoff, wbase + (unsigned)i * (NTHREADS * 16u), 0);
+#endif
     };
-    auto store_stage = [&](int buf) {
-        u32x4* in_s = smem + buf * STAGE_S;
-        u32x4* w_s = in_s + IN_S;
+    // register-staged images: VGPR -> LDS
+    auto stage_commit = [&](u32x4* in_s) {
+        u32x4* w_s = in_s + IN_P;
+        (void)in_s; (void)w_s;
+#if WITW_BF_DMA < 2
 #pragma unroll
         for (int i = 0; i < NIN; ++i) {
             const int s = tid + i * NTHREADS;
-            u32x4* dst = (NIN * NTHREADS == IN_S || s < IN_S) ? in_s + (s & 1) * (IH * IW) + (s >> 1) : smem + 2 * STAGE_S;
+            u32x4* dst = (NIN * NTHREADS == IN_S || s < IN_S) ? in_s + (s & 1) * (IH * IW) + (s >> 1) : dummy_slot;
             *dst = rin[i];
         }
+#endif
+#if WITW_BF_DMA < 1
 #pragma unroll
         for (int i = 0; i < NWT; ++i) {
             const int s = tid + i * NTHREADS;
-            u32x4* dst = (NWT * NTHREADS == W_S || s < W_S) ? w_s + s : smem + 2 * STAGE_S;
+            u32x4* dst = (NWT * NTHREADS == W_S || s < W_S) ? w_s + s : dummy_slot;
             *dst = rw[i];
         }
+#endif
+    };
+    // LDS-DMA data has landed once this wave's vector-memory counter drains (then the workgroup barrier publishes it)
+    auto stage_wait = [&]() {
+#if WITW_BF_DMA >= 1
+        __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0), expcnt / lgkmcnt untouched
+#endif
     };
 
     const int wm = (TN == 128) ? (wave >> 1) : wave;
@@ -160,22 +272,25 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_bf16_kernel(ConvBfArgs p
                                                                      __builtin_bit_cast(bf16x8, fb[set][nt]), acc[mt][nt], 0, 0, 0);
     };
 
-    load_stage(0);
-    store_stage(0);
+    stage_issue(0, stageA);
+    stage_commit(stageA);
+    stage_wait();
     __syncthreads();
-    read_frags(0, smem, smem + IN_S, 0);
+    read_frags(0, stageA, stageA + IN_P, 0);
 
-    for (int kc = 0; kc < nkc; ++kc) {
-        const int cur = kc & 1;
+    // one K chunk: 9 taps of MFMAs out of stage `in_s` while chunk kc+1 moves into stage `in_n`
+    auto chunk = [&](const u32x4* in_s, u32x4* in_n, int kc) {
         const int kn = (kc + 1 < nkc) ? kc + 1 : kc;
-        const u32x4* in_s = smem + cur * STAGE_S;
-        const u32x4* w_s = in_s + IN_S;
-        const u32x4* in_n = smem + (cur ^ 1) * STAGE_S;
-        load_stage(kn);
+        const u32x4* w_s = in_s + IN_P;
+#ifndef WITW_DIAG_NOSTAGE
+        stage_issue(kn, in_n);
+#endif
 #pragma unroll
         for (int tap = 0; tap < 8; ++tap) {
             read_frags((tap + 1) & 1, in_s, w_s, tap + 1);
-            if (tap == 5) store_stage(cur ^ 1);
+#ifndef WITW_DIAG_NOSTAGE
+            if (tap == 5) stage_commit(in_n);
+#endif
             mfma_tap(tap & 1);
             if (tap != 0 && tap != 5) {     // plain taps: one fragment read per MFMA (staging taps are left to the scheduler)
 #pragma unroll
@@ -187,14 +302,24 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_bf16_kernel(ConvBfArgs p
                 for (int i = 0; i < WM * WN - (WM + WN); ++i) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             }
         }
+#ifndef WITW_DIAG_NOSTAGE
+        stage_wait();
+#endif
+#ifndef WITW_DIAG_NOBARRIER
         __syncthreads();
-        read_frags(1, in_n, in_n + IN_S, 0);
+#endif
+        read_frags(1, in_n, in_n + IN_P, 0);
         mfma_tap(0);
 #pragma unroll
         for (int mt = 0; mt < WM; ++mt) fa[0][mt] = fa[1][mt];
 #pragma unroll
         for (int nt = 0; nt < WN; ++nt) fb[0][nt] = fb[1][nt];
+    };
+    for (int kc = 0; kc < nkc; kc += 2) {
+        chunk(stageA, stageB, kc);
+        if (kc + 1 < nkc) chunk(stageB, stageA, kc + 1);
     }
+    __syncthreads();      // the slabs below reuse the stages
 
     // ---- epilogue
     float bv[WN];
@@ -223,7 +348,7 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_bf16_kernel(ConvBfArgs p
 
     if (!POOL && !p.out_nchw_f32 && (p.Cout & 7) == 0) {
         // wide store: fp32 tile -> wave-private LDS slab -> 8 channels (16 B of bf16) per lane
-        float* slab = reinterpret_cast<float*>(smem) + wave * (32 * 64);
+        float* slab = reinterpret_cast<float*>((wave & 1) ? stageB : stageA) + (wave >> 1) * (32 * 64);
         const int prow = lane >> 3, pc8 = (lane & 7) * 8;   // read-back role: pixel row in a group of 8, channel octet
 #pragma unroll
         for (int mt = 0; mt < WM; ++mt) {
@@ -263,7 +388,7 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_bf16_kernel(ConvBfArgs p
     } else if ((p.Cout & 7) == 0) {
         // fused 2x2 max-pool, wide store through the wave-private slab: 16 pooled pixels x 64 channels per
         // M-tile pair leave as 16-byte stores of 8 bf16 channels
-        float* slab = reinterpret_cast<float*>(smem) + wave * (32 * 64);
+        float* slab = reinterpret_cast<float*>((wave & 1) ? stageB : stageA) + (wave >> 1) * (32 * 64);
         const int prow = lane >> 3, pc8 = (lane & 7) * 8;
 #pragma unroll
         for (int pr = 0; pr < WM / 2; ++pr) {
@@ -356,11 +481,15 @@ __global__ void nchw_f32_to_nhwc_bf16_kernel(const float* __restrict__ x, __bf16
 template <int TN, int SH, bool POOL, int NW>
 int launch_bf_nw(ConvBfArgs a, hipStream_t st) {
     a.tiles_y = cdiv(a.Ho, NW);
-    const long long grid = (long long)cdiv(a.Cout, TN) * a.B * a.tiles_x * a.tiles_y;
-    if (grid <= 0 || grid > 0x7fffffffLL) {
+    const long long sp_total = (long long)a.B * a.tiles_x * a.tiles_y;
+    a.n_tiles = cdiv(a.Cout, TN);
+    a.sp_per_xcd = (int)((sp_total + 7) / 8);
+    const long long grid = a.xcd_map ? 8LL * a.sp_per_xcd * a.n_tiles : sp_total * a.n_tiles;
+    if (grid <= 0 || grid > 0x7fffffffLL || sp_total > 0x7fffffffLL) {
         witw_set_error("conv3x3_bf16: grid %lld out of range", grid);
         return WITW_ERR_INVALID;
     }
+    a.sp_total = (int)sp_total;
     hipLaunchKernelGGL((conv3x3_nhwc_bf16_kernel<TN, SH, POOL, NW>), dim3((unsigned)grid), dim3(64 * NW), 0, st, a);
     WITW_CHECK_LAUNCH("conv3x3_nhwc_bf16");
     return WITW_OK;
@@ -422,6 +551,8 @@ int witw_conv3x3_bf16_fwd(const void* x_bf16, const void* wpk_bf16, const float*
     a.tiles_x = cdiv(a.Wo, TW);
     a.tiles_y = 0;
     a.circ = pad_circular; a.relu = relu; a.out_nchw_f32 = out_nchw_f32;
+    const char* e = getenv("WITW_CONV_XCD");
+    a.xcd_map = e ? atoi(e) != 0 : 1;
     hipStream_t st = (hipStream_t)stream;
     if (Cout >= 128) {
         if (stride_h == 2) return launch_bf<128, 2, false>(a, st);
