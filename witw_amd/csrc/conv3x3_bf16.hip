@@ -22,10 +22,13 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int TW = 64;
 constexpr int IW = TW + 2;
 
-// Staging mode: 0 = global -> VGPR -> ds_write for both images; 1 = weight slab by LDS-DMA (buffer_load ... lds:
+// Staging mode: 1 = input tile global -> VGPR -> ds_write, weight slab by LDS-DMA (buffer_load ... lds:
 // the packed slab is already the LDS image, 1 KB contiguous per wave instruction); 2 = input tile by LDS-DMA too.
 #ifndef WITW_BF_DMA
 #define WITW_BF_DMA 1
+#endif
+#ifndef WITW_BF_SPREAD
+#define WITW_BF_SPREAD 5        // taps over which the staging pieces of a chunk are issued (1 = all at tap 0)
 #endif
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -69,6 +72,9 @@ struct ConvBfArgs {
     int tiles_x, tiles_y;
     int circ, relu, out_nchw_f32;
     int n_tiles, sp_total, sp_per_xcd, xcd_map;
+#ifdef WITW_BF_STAMPS
+    unsigned long long* stamps;   // diagnostic build only (tools/bf16_stamps.cpp): per wave {loop, vmcnt wait, barrier wait} ticks
+#endif
 };
 
 template <int TN, int SH, bool POOL, int NW>
@@ -81,7 +87,6 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_bf16_kernel(ConvBfArgs p
     constexpr int W_S = 9 * 2 * TN;             // 16-B slots of one weight stage (a multiple of 64)
     constexpr int STAGE_S = IN_P + W_S;
     constexpr int NIN = (IN_S + NTHREADS - 1) / NTHREADS;
-    constexpr int NWT = (W_S + NTHREADS - 1) / NTHREADS;
     constexpr int NIN_D = (IN_P / 64 + NW - 1) / NW;     // LDS-DMA wave instructions per wave and stage
     constexpr int NWT_D = (W_S / 64 + NW - 1) / NW;
     constexpr int WGM = (TN == 128) ? NW / 2 : NW;
@@ -98,6 +103,10 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_bf16_kernel(ConvBfArgs p
     __shared__ u32x4 stageB[STAGE_S + 1];
     u32x4* const dummy_slot = stageB + STAGE_S;
 
+#ifdef WITW_BF_STAMPS
+    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+    const unsigned long long r_start = __builtin_amdgcn_s_memrealtime();
+#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave) & (NW - 1);      // the mask tells the compiler the range
@@ -127,11 +136,7 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_bf16_kernel(ConvBfArgs p
     const size_t img_elems = (size_t)p.H * p.W * p.Cin;
     __amdgpu_buffer_rsrc_t in_rs =
         __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)b * img_elems), 0, (unsigned)(img_elems * 2), 0x00020000);
-    __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(reinterpret_cast<const u32x4*>(p.wpk) + (size_t)ntile * nkc * W_S), 0, (unsigned)nkc * W_S * 16u, 0x00020000);
-#if WITW_BF_DMA >= 1
     const i32x4 w_rd = raw_rsrc(reinterpret_cast<const u32x4*>(p.wpk) + (size_t)ntile * nkc * W_S, (unsigned)nkc * W_S * 16u);
-#endif
 #if WITW_BF_DMA >= 2
     const i32x4 in_rd = raw_rsrc(p.x + (size_t)b * img_elems, (unsigned)(img_elems * 2));
 #endif
@@ -166,67 +171,61 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_bf16_kernel(ConvBfArgs p
     }
     u32x4 rin[NIN];
 #endif
-#if WITW_BF_DMA < 1
-    u32x4 rw[NWT];
-#endif
-    const unsigned gwoff = (unsigned)tid * 16u;
     const unsigned lane16 = (unsigned)lane * 16u;
 
-    // start moving K chunk kc toward LDS stage `buf`
-    auto stage_issue = [&](int kc, u32x4* in_s) {
-        u32x4* w_s = in_s + IN_P;
-        (void)in_s; (void)w_s;
-#if WITW_BF_DMA >= 1
-        const unsigned in_lds = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_address(in_s));
+#ifdef WITW_DIAG_NOIN
+    constexpr bool DIAG_IN = false;     // diagnostic builds: stage the input tile / the weight slab only once (wrong results)
+#else
+    constexpr bool DIAG_IN = true;
 #endif
+#ifdef WITW_DIAG_NOW
+    constexpr bool DIAG_W = false;
+#else
+    constexpr bool DIAG_W = true;
+#endif
+    bool first_stage = true;
+    // Staging of one K chunk is cut into PIECES wave instructions per wave (input pieces first: they come over the
+    // fabric, the weight pieces are L2 hits). piece p of chunk kc -> LDS stage in_s:
 #if WITW_BF_DMA >= 2
-#pragma unroll
-        for (int i = 0; i < NIN_D; ++i) {
-            const int j = wave_u + NW * i;
-            if (NIN_D * NW == IN_P / 64 || j < IN_P / 64) dma16(in_rd, in_lds + (unsigned)j * 1024u, gin[i], (unsigned)kc * 32u);
-        }
+    constexpr int P_IN = NIN_D;
 #else
-#pragma unroll
-        for (int i = 0; i < NIN; ++i) rin[i] = __builtin_amdgcn_raw_buffer_load_b128(in_rs, gin[i], (unsigned)kc * 32u, 0);
+    constexpr int P_IN = NIN;
 #endif
-        const unsigned wbase = (unsigned)kc * W_S * 16u;
-#if WITW_BF_DMA >= 1
-#pragma unroll
-        for (int i = 0; i < NWT_D; ++i) {
-            const int j = wave_u + NW * i;
-            if (NWT_D * NW == W_S / 64 || j < W_S / 64) dma16(w_rd, in_lds + (unsigned)(IN_P + j * 64) * 16u, lane16, wbase + (unsigned)j * 1024u);
-        }
+    constexpr int PIECES = P_IN + NWT_D;
+    auto stage_piece = [&](int kc, u32x4* in_s, int pc) {
+        const unsigned in_lds = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_address(in_s));
+        if (pc < P_IN) {
+            if (DIAG_IN || first_stage) {
+#if WITW_BF_DMA >= 2
+                const int j = wave_u + NW * pc;
+                if (NIN_D * NW == IN_P / 64 || j < IN_P / 64) dma16(in_rd, in_lds + (unsigned)j * 1024u, gin[pc], (unsigned)kc * 32u);
 #else
-#pragma unroll
-        for (int i = 0; i < NWT; ++i) rw[i] = __builtin_amdgcn_raw_buffer_load_b128(w_rs, gwoff, wbase + (unsigned)i * (NTHREADS * 16u), 0);
+                rin[pc] = __builtin_amdgcn_raw_buffer_load_b128(in_rs, gin[pc], (unsigned)kc * 32u, 0);
 #endif
+            }
+        } else if (DIAG_W || first_stage) {
+            const int j = wave_u + NW * (pc - P_IN);
+            if (NWT_D * NW == W_S / 64 || j < W_S / 64)
+                dma16(w_rd, in_lds + (unsigned)(IN_P + j * 64) * 16u, lane16, (unsigned)kc * W_S * 16u + (unsigned)j * 1024u);
+        }
     };
-    // register-staged images: VGPR -> LDS
+    // register-staged input tile: VGPR -> LDS
     auto stage_commit = [&](u32x4* in_s) {
-        u32x4* w_s = in_s + IN_P;
-        (void)in_s; (void)w_s;
+        (void)in_s;
 #if WITW_BF_DMA < 2
+        if (DIAG_IN || first_stage) {
 #pragma unroll
-        for (int i = 0; i < NIN; ++i) {
-            const int s = tid + i * NTHREADS;
-            u32x4* dst = (NIN * NTHREADS == IN_S || s < IN_S) ? in_s + (s & 1) * (IH * IW) + (s >> 1) : dummy_slot;
-            *dst = rin[i];
-        }
-#endif
-#if WITW_BF_DMA < 1
-#pragma unroll
-        for (int i = 0; i < NWT; ++i) {
-            const int s = tid + i * NTHREADS;
-            u32x4* dst = (NWT * NTHREADS == W_S || s < W_S) ? w_s + s : dummy_slot;
-            *dst = rw[i];
+            for (int i = 0; i < NIN; ++i) {
+                const int s = tid + i * NTHREADS;
+                u32x4* dst = (NIN * NTHREADS == IN_S || s < IN_S) ? in_s + (s & 1) * (IH * IW) + (s >> 1) : dummy_slot;
+                *dst = rin[i];
+            }
         }
 #endif
     };
     // LDS-DMA data has landed once this wave's vector-memory counter drains (then the workgroup barrier publishes it)
     auto stage_wait = [&]() {
-#if WITW_BF_DMA >= 1
         __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0), expcnt / lgkmcnt untouched
-#endif
     };
 
     const int wm = (TN == 128) ? (wave >> 1) : wave;
@@ -272,27 +271,35 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_bf16_kernel(ConvBfArgs p
                                                                      __builtin_bit_cast(bf16x8, fb[set][nt]), acc[mt][nt], 0, 0, 0);
     };
 
-    stage_issue(0, stageA);
+#pragma unroll
+    for (int pc = 0; pc < PIECES; ++pc) stage_piece(0, stageA, pc);
     stage_commit(stageA);
     stage_wait();
+    first_stage = false;
     __syncthreads();
     read_frags(0, stageA, stageA + IN_P, 0);
 
+#ifdef WITW_BF_STAMPS
+    unsigned long long t_vm = 0, t_bar = 0;
+    const unsigned long long t_loop0 = __builtin_amdgcn_s_memtime();
+#endif
     // one K chunk: 9 taps of MFMAs out of stage `in_s` while chunk kc+1 moves into stage `in_n`
     auto chunk = [&](const u32x4* in_s, u32x4* in_n, int kc) {
         const int kn = (kc + 1 < nkc) ? kc + 1 : kc;
         const u32x4* w_s = in_s + IN_P;
-#ifndef WITW_DIAG_NOSTAGE
-        stage_issue(kn, in_n);
-#endif
 #pragma unroll
         for (int tap = 0; tap < 8; ++tap) {
             read_frags((tap + 1) & 1, in_s, w_s, tap + 1);
 #ifndef WITW_DIAG_NOSTAGE
-            if (tap == 5) stage_commit(in_n);
+            // the pieces of the next chunk leave over taps 0..SPREAD-1, a few per tap (each costs the wave issue time
+            // that the partner wave's MFMAs cover), the rest of the chunk is landing time before the barrier
+#pragma unroll
+            for (int pc = 0; pc < PIECES; ++pc)
+                if (pc * WITW_BF_SPREAD / PIECES == tap) stage_piece(kn, in_n, pc);
+            if (tap == 6) stage_commit(in_n);
 #endif
             mfma_tap(tap & 1);
-            if (tap != 0 && tap != 5) {     // plain taps: one fragment read per MFMA (staging taps are left to the scheduler)
+            if (tap != 0 && tap != 6) {     // one fragment read per MFMA (tap 0 / the commit tap are left to the scheduler)
 #pragma unroll
                 for (int i = 0; i < WM + WN; ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -302,11 +309,22 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_bf16_kernel(ConvBfArgs p
                 for (int i = 0; i < WM * WN - (WM + WN); ++i) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             }
         }
+#ifdef WITW_BF_STAMPS
+        const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
+#endif
 #ifndef WITW_DIAG_NOSTAGE
         stage_wait();
 #endif
+#ifdef WITW_BF_STAMPS
+        const unsigned long long ts1 = __builtin_amdgcn_s_memtime();
+#endif
 #ifndef WITW_DIAG_NOBARRIER
         __syncthreads();
+#endif
+#ifdef WITW_BF_STAMPS
+        const unsigned long long ts2 = __builtin_amdgcn_s_memtime();
+        t_vm += ts1 - ts0;
+        t_bar += ts2 - ts1;
 #endif
         read_frags(1, in_n, in_n + IN_P, 0);
         mfma_tap(0);
@@ -319,6 +337,9 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_bf16_kernel(ConvBfArgs p
         chunk(stageA, stageB, kc);
         if (kc + 1 < nkc) chunk(stageB, stageA, kc + 1);
     }
+#ifdef WITW_BF_STAMPS
+    const unsigned long long t_loop1 = __builtin_amdgcn_s_memtime();
+#endif
     __syncthreads();      // the slabs below reuse the stages
 
     // ---- epilogue
@@ -441,6 +462,20 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_bf16_kernel(ConvBfArgs p
                     }
         }
     }
+#ifdef WITW_BF_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0 && p.stamps != nullptr) {
+        unsigned long long* o = p.stamps + ((size_t)blockIdx.x * NW + wave) * 8;
+        o[0] = t_loop1 - t_loop0;
+        o[1] = t_vm;
+        o[2] = t_bar;
+        o[3] = 1;
+        o[4] = t_loop0 - t_start;
+        o[5] = __builtin_amdgcn_s_memtime() - t_loop1;
+        o[6] = __builtin_amdgcn_s_memtime() - t_start;
+        o[7] = __builtin_amdgcn_s_memrealtime() - r_start;     // 100 MHz ticks
+    }
+#endif
 }
 
 // wpk[nt][kc][tap][g][n][0..7] (bf16) <- w[cout][cin][kh][kw] (fp32, torch KCRS); one thread per 16-B slot
@@ -504,6 +539,10 @@ int launch_bf(const ConvBfArgs& a, hipStream_t st) {
 
 }  // namespace
 
+#ifdef WITW_BF_STAMPS
+unsigned long long* witw_bf16_stamps_ptr = nullptr;
+#endif
+
 extern "C" {
 
 long long witw_conv3x3_bf16_packed_elems(int cout, int cin) {
@@ -551,6 +590,9 @@ int witw_conv3x3_bf16_fwd(const void* x_bf16, const void* wpk_bf16, const float*
     a.tiles_x = cdiv(a.Wo, TW);
     a.tiles_y = 0;
     a.circ = pad_circular; a.relu = relu; a.out_nchw_f32 = out_nchw_f32;
+#ifdef WITW_BF_STAMPS
+    a.stamps = witw_bf16_stamps_ptr;
+#endif
     const char* e = getenv("WITW_CONV_XCD");
     a.xcd_map = e ? atoi(e) != 0 : 1;
     hipStream_t st = (hipStream_t)stream;
