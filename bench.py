@@ -198,6 +198,9 @@ def main():
         'recall': {'top1_pct': float(np.mean(ranks_h <= 1) * 100), 'top5_pct': float(np.mean(ranks_h <= 5) * 100),
                    'N': int(len(ranks_h))},
         'loss': float(loss.item()),
+        **({'recall_note': 'train mode: the two encoders draw independent Dropout2d masks (reference :287-288) on random-init '
+                           'weights, so the in-step recall is near chance; the eval-mode recall is the inference bench line'}
+           if train else {}),
         'roofline': {'bound': 'mfma', 'kernel': kname, 'achieved': round(achieved, 2),
                      'peak': peak, 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
                      'traffic': traffic, 'launches': len(dom), 'avg_launch_ms': round(dom_ms, 4),
