@@ -23,9 +23,10 @@ int main(int argc, char** argv) {
     hipMemcpy(wpk, hw.data(), nw * 4, hipMemcpyHostToDevice);
     hipMemset(bias, 0, witw_conv3x3_bias_floats(Cout) * 4);
     int TN = witw_conv3x3_tile_n(Cout);
-    long long nblk = (long long)((Cout + TN - 1) / TN) * B * ((W + 63) / 64) * ((H + 3) / 4);
-    hipMalloc(&witw_conv_stamps_ptr, nblk * 4 * 8 * 8);
-    hipMemset(witw_conv_stamps_ptr, 0, nblk * 4 * 8 * 8);
+    const int NWV = 8;      // waves per workgroup upper bound; grid upper bound incl. the XCD padding
+    long long nblk = (long long)((Cout + TN - 1) / TN) * (8LL * (((long long)B * ((W + 15) / 16) * ((H + 3) / 4) + 7) / 8)) + 64;
+    hipMalloc(&witw_conv_stamps_ptr, nblk * NWV * 8 * 8);
+    hipMemset(witw_conv_stamps_ptr, 0, nblk * NWV * 8 * 8);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int it = 0; it < 3; ++it) {
         hipEventRecord(e0, 0);
@@ -35,13 +36,14 @@ int main(int argc, char** argv) {
         double fl = 2.0 * Cin * Cout * 9 * H * W * B;
         printf("rc=%d  %.3f ms  %.1f TF/s\n", rc, ms, fl / ms / 1e9);
     }
-    std::vector<unsigned long long> st(nblk * 4 * 8);
+    std::vector<unsigned long long> st(nblk * NWV * 8);
     hipMemcpy(st.data(), witw_conv_stamps_ptr, st.size() * 8, hipMemcpyDeviceToHost);
-    std::vector<double> pro, loop, epi, tot;
+    std::vector<double> pro, loop, epi, tot, clk;
     unsigned long long tmin = ~0ull, tmax = 0;
-    for (long long b = 0; b < nblk * 4; ++b) {
+    for (long long b = 0; b < nblk * NWV; ++b) {
         unsigned long long* o = &st[b * 8];
         if (o[7] < 4) continue;
+        if (o[6]) clk.push_back((double)(o[3] - o[0]) / (double)o[6] * 0.1);
         pro.push_back((double)(o[1] - o[0])); loop.push_back((double)(o[2] - o[1])); epi.push_back((double)(o[3] - o[2]));
         tot.push_back((double)(o[3] - o[0]));
         tmin = std::min(tmin, o[0]); tmax = std::max(tmax, o[3]);
@@ -49,6 +51,8 @@ int main(int argc, char** argv) {
     auto med = [](std::vector<double>& v) { std::sort(v.begin(), v.end()); return v.empty() ? 0.0 : v[v.size() / 2]; };
     printf("waves=%zu  median cycles(memtime ticks): prologue %.0f  kloop %.0f  epilogue %.0f  total %.0f   span %.0f\n",
            pro.size(), med(pro), med(loop), med(epi), med(tot), (double)(tmax - tmin));
+    printf("in-kernel shader clock (s_memtime / s_memrealtime): median %.3f GHz -> fp32 MFMA peak at that clock %.1f TF/s\n", med(clk),
+           157.3 * med(clk) / 2.4);
     int nkc = Cin / 8;
     printf("kloop per chunk %.0f ticks; ideal MFMA per chunk %d cycles\n", med(loop) / nkc, (TN == 128 ? 288 : 144) * 64);
     return 0;

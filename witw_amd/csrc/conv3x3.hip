@@ -233,6 +233,7 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_f32_kernel(ConvArgs p) {
     unsigned long long t_stamp[6];
     int n_stamp = 0;
 #define STAMP() do { if (n_stamp < 6) t_stamp[n_stamp++] = __builtin_amdgcn_s_memtime(); } while (0)
+    const unsigned long long r_stamp0 = __builtin_amdgcn_s_memrealtime();
 #else
 #define STAMP() do { } while (0)
 #endif
@@ -496,8 +497,9 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_f32_kernel(ConvArgs p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     STAMP();
     if (lane == 0 && p.stamps != nullptr) {
-        unsigned long long* o = p.stamps + ((size_t)blockIdx.x * 4 + wave) * 8;
+        unsigned long long* o = p.stamps + ((size_t)blockIdx.x * NW + wave) * 8;
         for (int i = 0; i < n_stamp; ++i) o[i] = t_stamp[i];
+        o[6] = __builtin_amdgcn_s_memrealtime() - r_stamp0;      // 100 MHz ticks over the same span as o[3] - o[0]
         o[7] = n_stamp;
     }
 #endif
