@@ -207,3 +207,23 @@ def test_retrieve_topk_matches_oracle_and_shards():
     vm, pm = ops.topk_smallest(torch.gather(cv, 0, order).contiguous(), k)
     im = torch.gather(torch.gather(ci, 0, order).t(), 1, pm)
     assert torch.equal(im, i) and torch.equal(vm, v)
+
+
+@pytest.mark.parametrize('we', [1, 7, 12, 16, 17, 24, 32, 33, 48, 62])
+def test_narrow_surface_pipelined_kernel_is_bit_identical(we, monkeypatch):
+    """Retrieval-sized problems with surfaces narrower than 63 columns take match_kernel_rows (several embedding
+    rows per LDS stage, zero-padded columns). Zero columns add exact zeros, so scores, orientations and distances
+    must equal the generic kernel's bit for bit; a sample of queries is also checked against the oracle."""
+    from witw_amd import ops
+    bo, bs = 130, 1030                                   # ragged on both sides of the 4 x 128 workgroup tile
+    ov = torch.from_numpy(synth.embeddings(80 + we, 1, (bo, 16, 4, 64))).cuda()
+    su = torch.from_numpy(synth.embeddings(80 + we, 2, (bs, 16, 4, we))).cuda()
+    ori, dist, score = ops.match_fwd(ov, su, want_score=True)
+    monkeypatch.setenv('WITW_MATCH_GENERIC', '1')
+    ori_g, dist_g, score_g = ops.match_fwd(ov, su, want_score=True)
+    monkeypatch.delenv('WITW_MATCH_GENERIC')
+    assert torch.equal(score, score_g) and torch.equal(ori, ori_g) and torch.equal(dist, dist_g)
+    sel = [0, 1, 127, 128, 1029]
+    o_ref, d_ref = O.match(ov.cpu(), su[sel].cpu())
+    np.testing.assert_array_equal(ori[:, sel].cpu().numpy(), o_ref.numpy())
+    np.testing.assert_allclose(dist[:, sel].cpu().numpy(), d_ref.numpy(), atol=2e-5)

@@ -312,6 +312,173 @@ __global__ __launch_bounds__(NT, 2) void match_kernel_w64(MatchArgs p) {
         }
 }
 
+// ---- narrower surfaces (We < 63: fov < 355): the same pipelined loop as match_kernel_w64, but one LDS stage holds
+// R = 4 (We <= 16), 2 (We <= 32) or 1 (We <= 62) embedding rows side by side, each zero-padded to WP = 64/R columns, so that a
+// stage is again 32 full k-steps (a stage per row would be 6 k-steps and a barrier at We = 12). K index of a
+// stage = rr*WP + k; the B operand of (rr, k) is overhead row rr at column k + shift, overhead rows are stored
+// 64 + WP floats long (the window never wraps). Zero columns add exact zeros: scores are bit-identical to the
+// other kernels.
+template <int R>
+__global__ __launch_bounds__(NT, 2) void match_kernel_rows(MatchArgs p) {
+    constexpr int OPW = 2, MO = 4, KS = 32, WP = 64 / R, OVS = 64 + WP;
+    constexpr int SU_F = MS * SUS;
+    constexpr int OV_F = MO * R * OVS;
+    constexpr unsigned OOR = 0x80000000u;
+    __shared__ float smem[2 * (SU_F + OV_F)];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hk = lane >> 5;
+    const int s0 = blockIdx.x * MS;
+    const int o0 = blockIdx.y * MO;
+    const int We = p.We;
+    const int wm = wave >> 1, wo = wave & 1;
+
+    // staging: lane <-> (row rr = lane / WP of the stage, column k = lane % WP), (wave + 4*i) <-> surface
+    const int rows_here = min(MS, p.Bs - s0);
+    __amdgpu_buffer_rsrc_t su_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.su + (size_t)s0 * 64 * We), 0,
+                                                                    (unsigned)rows_here * 64u * We * 4u, 0x00020000);
+    const int ov_here = min(MO, p.Bo - o0);
+    __amdgpu_buffer_rsrc_t ov_rs =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(p.ov + (size_t)o0 * 4096), 0, (unsigned)ov_here * 4096u * 4u, 0x00020000);
+    const int lrr = lane / WP, lk = lane % WP;
+    unsigned suoff[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const int row = wave + 4 * i;
+        suoff[i] = (lk < We && row < rows_here) ? ((unsigned)row * 64u * We + lrr * We + lk) * 4u : OOR;
+    }
+    // overhead staging: R passes, thread -> (local overhead tid/64, column tid%64), pass <-> row rr
+    const int ovo = tid >> 6, ovw = tid & 63;
+    const unsigned ovoff = (ovo < ov_here) ? ((unsigned)ovo * 4096u + ovw) * 4u : OOR;
+
+    float rsu[32];
+    float rov[R];
+    auto load_stage = [&](int st) {
+        const unsigned srow = (unsigned)st * R * We * 4u;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) rsu[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(su_rs, suoff[i], srow, 0));
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr)
+            rov[rr] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ov_rs, ovoff, (unsigned)(st * R + rr) * 256u, 0));
+    };
+    auto store_stage = [&](int buf) {
+        float* su_s = smem + buf * (SU_F + OV_F);
+        float* ov_s = su_s + SU_F;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) su_s[(wave + 4 * i) * SUS + lane] = rsu[i];
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            ov_s[(ovo * R + rr) * OVS + ovw] = rov[rr];
+            if (ovw < WP) ov_s[(ovo * R + rr) * OVS + 64 + ovw] = rov[rr];
+        }
+    };
+
+    f32x16 acc[2][OPW][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < OPW; ++b)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][c][r] = 0.f;
+
+    const int arow0 = (64 * wm + l31) * SUS + hk;
+    const int arow1 = arow0 + 32 * SUS;
+    const int bcol = OPW * wo * R * OVS + l31 + hk;
+    float fa[2][2], fb[2][OPW][2];
+    auto read_frags = [&](int set, const float* su_s, const float* ov_s, int k) {
+        const int rr = (2 * k) / WP, kk = (2 * k) % WP;       // compile-time after unrolling
+        fa[set][0] = su_s[arow0 + 2 * k];
+        fa[set][1] = su_s[arow1 + 2 * k];
+#pragma unroll
+        for (int o = 0; o < OPW; ++o) {
+            fb[set][o][0] = ov_s[bcol + (o * R + rr) * OVS + kk];
+            fb[set][o][1] = ov_s[bcol + (o * R + rr) * OVS + kk + 32];
+        }
+    };
+    auto mfma_step = [&](int set) {
+#pragma unroll
+        for (int o = 0; o < OPW; ++o)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                acc[0][o][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][0], fb[set][o][n], acc[0][o][n], 0, 0, 0);
+                acc[1][o][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][1], fb[set][o][n], acc[1][o][n], 0, 0, 0);
+            }
+    };
+
+    constexpr int NS = 64 / R;
+    load_stage(0);
+    store_stage(0);
+    __syncthreads();
+    read_frags(0, smem, smem + SU_F, 0);
+
+    for (int st = 0; st < NS; ++st) {
+        const int cur = st & 1;
+        const int sn = (st + 1 < NS) ? st + 1 : st;      // the last stage restages itself (never read)
+        const float* su_s = smem + cur * (SU_F + OV_F);
+        const float* ov_s = su_s + SU_F;
+        const float* su_n = smem + (cur ^ 1) * (SU_F + OV_F);
+        load_stage(sn);
+#pragma unroll
+        for (int k = 0; k < KS - 1; ++k) {
+            read_frags((k + 1) & 1, su_s, ov_s, k + 1);
+            if (k == 17) store_stage(cur ^ 1);
+            mfma_step(k & 1);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            if (k < 17) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            } else {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            }
+        }
+        __syncthreads();
+        read_frags(0, su_n, su_n + SU_F, 0);
+        mfma_step(1);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+    }
+
+    // ---- epilogue: identical to match_kernel
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int o = 0; o < OPW; ++o) {
+            const int og = o0 + OPW * wo + o;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[mt][o][0][r];
+                int idx = l31;
+                const float v1 = acc[mt][o][1][r];
+                if (v1 > v) { v = v1; idx = 32 + l31; }
+#pragma unroll
+                for (int d = 1; d < 32; d <<= 1) {
+                    const float vo = __shfl_xor(v, d, 64);
+                    const int io = __shfl_xor(idx, d, 64);
+                    if (vo > v || (vo == v && io < idx)) { v = vo; idx = io; }
+                }
+                const int srow = s0 + 64 * wm + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hk;
+                if (l31 == r && og < p.Bo && srow < p.Bs) {
+                    const size_t off = (size_t)og * p.Bs + srow;
+                    if (p.orientation) p.orientation[off] = idx;
+                    if (p.score) p.score[off] = v;
+                    if (p.distance) p.distance[off] = 2.f * (1.f - v / (p.wn[(size_t)og * 64 + idx] * p.sn[srow]));
+                }
+            }
+        }
+}
+
 // wn[o][shift] = sqrt(sum_{ch} sum_{k<We} ov[o][ch][(k+shift)%64]^2): the L2 norm of the window
 // that crop_overhead would cut at that shift (model/cvig_fov.py:335-341,350-351).
 __global__ __launch_bounds__(256) void window_norm_kernel(const float* __restrict__ ov, float* __restrict__ wn, int We) {
@@ -566,8 +733,16 @@ int witw_match_fwd(const float* ov, const float* su, int Bo, int Bs, int We, lon
     a.Bo = Bo; a.Bs = Bs; a.We = We;
     const int gx = cdiv(Bs, MS);
     // small problems: 2 overheads per block (more blocks); large: 4 per block (less staging per FLOP)
-    if ((long long)gx * cdiv(Bo, 4) >= 256 && We >= 63) {
+    const char* force = getenv("WITW_MATCH_GENERIC");       // A/B aid: 1 = never use the pipelined kernels
+    const bool pipelined = (long long)gx * cdiv(Bo, 4) >= 256 && !(force && atoi(force) != 0);
+    if (pipelined && We >= 63) {
         hipLaunchKernelGGL(match_kernel_w64, dim3(gx, cdiv(Bo, 4)), dim3(NT), 0, st, a);
+    } else if (pipelined && We <= 16) {
+        hipLaunchKernelGGL((match_kernel_rows<4>), dim3(gx, cdiv(Bo, 4)), dim3(NT), 0, st, a);
+    } else if (pipelined && We <= 32) {
+        hipLaunchKernelGGL((match_kernel_rows<2>), dim3(gx, cdiv(Bo, 4)), dim3(NT), 0, st, a);
+    } else if (pipelined) {      // 33..62 columns: one row per stage, zero-padded to 64
+        hipLaunchKernelGGL((match_kernel_rows<1>), dim3(gx, cdiv(Bo, 4)), dim3(NT), 0, st, a);
     } else if ((long long)gx * cdiv(Bo, 4) >= 512) {
         hipLaunchKernelGGL((match_kernel<2>), dim3(gx, cdiv(Bo, 4)), dim3(NT), 0, st, a);
     } else {
