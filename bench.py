@@ -116,17 +116,13 @@ def main():
             polar = ops.polar_transform(overhead)
         su = surface_encoder(surface)
         ov = overhead_encoder(polar)
-        su_all, ov_all = parallel.all_gather_embeddings(su, ov)
-        ori, d = cvig_fov.match(ov_all, su_all)
-        loss = cvig_fov.triplet_loss(d)
+        loss, ori, d = cvig_fov.sharded_match_loss(ov, su)       # global-batch loss from this rank's [B_global, B] slab
         optimizer.zero_grad()
         loss.backward()
         parallel.all_reduce_grads(all_params)
         optimizer.step()
         with torch.no_grad():
-            dd = d.detach()
-            ranks = ops.rank_count(dd[:, rank * B:(rank + 1) * B].contiguous(), rank * B) if world > 1 \
-                else ops.rank_count(dd, 0)
+            ranks = ops.rank_count(d, rank * B)
         return loss.detach(), ranks, ori
 
     def infer_step():

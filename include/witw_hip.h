@@ -118,6 +118,14 @@ int witw_triplet_loss_fwd(const float* distance /*[B,B]*/, int B, float alpha, f
  * batch), diag[Bo] = global diagonal; sum over ranks / (2*Bo*(Bo-1)) = the loss. workspace: Bo floats. */
 int witw_triplet_loss_slab_fwd(const float* distance, const float* diag, int Bo, int Bs, int col0, float alpha, float* partial,
                                float* workspace, void* stream);
+/* Backward of the sharded global-batch loss (the gradient of model/cvig_fov.py:366-382 restricted to one rank's column slab):
+ * step 1 -> rowsig[Bo] = sum over THIS rank's surfaces of sigmoid(alpha*(d_ii - d_ij)) (the caller all-reduces it) and
+ * colsig[Bs] = sum over all overheads of sigmoid(alpha*(d_cc - d_ij)), c = col0 + j (complete);
+ * step 2 -> grad_distance[Bo,Bs] for the device scalar grad_loss of the global loss (normaliser 2*Bo*(Bo-1)). */
+int witw_triplet_loss_slab_sig(const float* distance, const float* diag, int Bo, int Bs, int col0, float alpha, float* rowsig,
+                               float* colsig, void* stream);
+int witw_triplet_loss_slab_bwd(const float* distance, const float* diag, const float* rowsig, const float* colsig,
+                               const float* grad_loss, float* grad_distance, int Bo, int Bs, int col0, float alpha, void* stream);
 int witw_triplet_loss_bwd(const float* distance, const float* workspace, const float* grad_loss /*[1]*/,
                           float* grad_distance /*[B,B]*/, int B, float alpha, void* stream);
 

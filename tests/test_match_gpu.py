@@ -227,3 +227,29 @@ def test_narrow_surface_pipelined_kernel_is_bit_identical(we, monkeypatch):
     o_ref, d_ref = O.match(ov.cpu(), su[sel].cpu())
     np.testing.assert_array_equal(ori[:, sel].cpu().numpy(), o_ref.numpy())
     np.testing.assert_allclose(dist[:, sel].cpu().numpy(), d_ref.numpy(), atol=2e-5)
+
+
+def test_sharded_loss_slab_kernels_equal_full_matrix_gradient():
+    """witw_triplet_loss_slab_fwd/_sig/_bwd on the two column slabs of a [B,B] distance matrix (the all-reduces done by
+    hand) reproduce witw_triplet_loss_fwd/bwd on the whole matrix: same loss, same dL/dD, column block by column block."""
+    from witw_amd import ops
+    B, b = 70, 35
+    g = np.random.Generator(np.random.Philox(key=[90, 1]))
+    D = torch.from_numpy((g.random((B, B), dtype=np.float32) * 1.5 + 0.2)).cuda()
+    loss_full, ws = ops.triplet_loss_fwd(D, 10.)
+    one = torch.ones((1,), device='cuda')
+    g_full = ops.triplet_loss_bwd(D, ws, one, 10.)
+    diag = D.diagonal().contiguous()
+    slabs = [D[:, r * b:(r + 1) * b].contiguous() for r in range(2)]
+    parts = [ops.triplet_loss_slab_fwd(slabs[r], diag, r * b, 10.) for r in range(2)]
+    loss = (parts[0] + parts[1]) / (2. * B * (B - 1))
+    np.testing.assert_allclose(loss.item(), loss_full.item(), rtol=2e-6)
+    sig = [ops.triplet_loss_slab_sig(slabs[r], diag, r * b, 10.) for r in range(2)]
+    rowsig = sig[0][0] + sig[1][0]                          # the all-reduce
+    for r in range(2):
+        g_slab = ops.triplet_loss_slab_bwd(slabs[r], diag, rowsig, sig[r][1], one, r * b, 10.)
+        np.testing.assert_allclose(g_slab.cpu().numpy(), g_full[:, r * b:(r + 1) * b].cpu().numpy(), rtol=2e-5, atol=1e-9)
+    # and against CPU autograd of the reference formula
+    Dc = D.cpu().double().requires_grad_(True)
+    O.triplet_loss(Dc).backward()
+    np.testing.assert_allclose(g_full.cpu().numpy(), Dc.grad.float().numpy(), rtol=1e-4, atol=1e-8)

@@ -102,6 +102,95 @@ def test_global_batch_gradients_and_sharded_ranks_world2():
         np.testing.assert_array_equal(r, ranks_ref)
 
 
+class _CpuKernels(object):
+    """The op set of cvig_fov.sharded_match_loss restated in CPU torch ops (oracle match; the slab formulas of
+    witw_amd/csrc/loss.hip), so that the collective algebra runs under gloo without a GPU."""
+
+    @staticmethod
+    def match_fwd(ov, su, want_score=False, want_workspace=False):
+        ori, dist = O.match(ov.detach(), su.detach())
+        return ori, dist, torch.zeros_like(dist), torch.zeros(1)
+
+    @staticmethod
+    def match_bwd(ov, su, ori, score, ws, g_dist, need_ov=True, need_su=True):
+        with torch.enable_grad():               # autograd.Function.backward runs with grad mode off
+            ov = ov.detach().requires_grad_(True)
+            su = su.detach().requires_grad_(True)
+            _, d = O.match(ov, su)
+            d.backward(g_dist)
+        return ov.grad, su.grad
+
+    @staticmethod
+    def triplet_loss_slab_fwd(dist, diag, col0, alpha):
+        b = dist.shape[1]
+        t = torch.log(1 + torch.exp(alpha * (diag[col0:col0 + b][None, :] - dist))) + \
+            torch.log(1 + torch.exp(alpha * (diag[:, None] - dist)))
+        return t.sum().reshape(1)
+
+    @staticmethod
+    def triplet_loss_slab_sig(dist, diag, col0, alpha):
+        b = dist.shape[1]
+        rowsig = torch.sigmoid(alpha * (diag[:, None] - dist)).sum(1)
+        colsig = torch.sigmoid(alpha * (diag[col0:col0 + b][None, :] - dist)).sum(0)
+        return rowsig, colsig
+
+    @staticmethod
+    def triplet_loss_slab_bwd(dist, diag, rowsig, colsig, g_loss, col0, alpha):
+        B, b = dist.shape
+        g = -torch.sigmoid(alpha * (diag[col0:col0 + b][None, :] - dist)) - torch.sigmoid(alpha * (diag[:, None] - dist))
+        idx = torch.arange(b)
+        g[col0 + idx, idx] += colsig + rowsig[col0:col0 + b]
+        return g * (g_loss * alpha / (2. * B * (B - 1)))
+
+
+def _worker_sharded(rank, world, port, we, out_q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from witw_amd import cvig_fov, parallel
+        torch.set_num_threads(2)
+        B = 6
+        xs = torch.from_numpy(synth.embeddings(3, 1, (B, 24)))
+        xo = torch.from_numpy(synth.embeddings(3, 2, (B, 24)))
+        b0, b1 = parallel.shard_range(B)
+        su_enc, ov_enc = _toy_encoders(we)
+        su = su_enc(xs[b0:b1]).view(-1, 16, 4, we)
+        ov = ov_enc(xo[b0:b1]).view(-1, 16, 4, 64)
+        loss, ori, d = cvig_fov.sharded_match_loss(ov, su, _kernels=_CpuKernels)
+        assert tuple(d.shape) == (B, b1 - b0) and tuple(ori.shape) == (B, b1 - b0)
+        loss.backward()
+        params = list(su_enc.parameters()) + list(ov_enc.parameters())
+        parallel.all_reduce_grads(params)
+        out_q.put((rank, loss.item(), [p.grad.clone() for p in params]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_match_loss_world2_equals_full_batch():
+    """The column-sharded global-batch loss (one [B,b] slab per rank, reduce-scatter of the overhead-embedding gradients)
+    gives the loss and the weight gradients of the single-process full-batch computation."""
+    we = 12
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_sharded, args=(r, 2, port, we, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    B = 6
+    xs = torch.from_numpy(synth.embeddings(3, 1, (B, 24)))
+    xo = torch.from_numpy(synth.embeddings(3, 2, (B, 24)))
+    loss_ref, grads_ref = _full_reference(xs, xo, we)
+    for (_rank, loss, grads) in res:
+        assert abs(loss - loss_ref) < 1e-6
+        for g, gr in zip(grads, grads_ref):
+            np.testing.assert_allclose(g.numpy(), gr.numpy(), rtol=1e-4, atol=1e-7)
+
+
 def test_shard_range_partitions():
     from witw_amd import parallel
     for n in (1, 7, 8, 1000003):

@@ -59,6 +59,8 @@ SIGNATURES = {
     'witw_rank_count_thresh': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     'witw_triplet_loss_fwd': (c_int, [c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     'witw_triplet_loss_slab_fwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
+    'witw_triplet_loss_slab_sig': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
+    'witw_triplet_loss_slab_bwd': (c_int, [c_void_p] * 6 + [c_int, c_int, c_int, c_float, c_void_p]),
     'witw_triplet_loss_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p]),
     'witw_resize_bilinear_normalize': (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p, c_void_p, c_int, c_void_p]),
     'witw_normalize': (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p, c_void_p, c_int, c_void_p]),

@@ -86,6 +86,41 @@ __global__ __launch_bounds__(256) void triplet_slab_partials_kernel(const float*
     if (threadIdx.x == 0) part[i] = t;
 }
 
+// Sigmoid sums of a column slab (backward of the sharded loss):
+// blocks [0,Bo): rowsig[i] = sum_{j in slab} sig(a(d_ii - d_ij));  blocks [Bo,Bo+Bs): colsig[j] = sum_i sig(a(d_cc - d_ij)), c = col0+j
+__global__ __launch_bounds__(256) void triplet_slab_sig_kernel(const float* __restrict__ D, const float* __restrict__ diag,
+                                                                float* __restrict__ rowsig, float* __restrict__ colsig, int Bo, int Bs,
+                                                                int col0, float alpha) {
+    __shared__ float sh[4];
+    const bool is_col = blockIdx.x >= (unsigned)Bo;
+    const int m = is_col ? blockIdx.x - Bo : blockIdx.x;
+    const float dm = is_col ? diag[col0 + m] : diag[m];
+    const int n = is_col ? Bo : Bs;
+    float sg = 0.f;
+    for (int t = threadIdx.x; t < n; t += 256) {
+        const float d = is_col ? D[(size_t)t * Bs + m] : D[(size_t)m * Bs + t];
+        sg += 1.f / (1.f + expf(-alpha * (dm - d)));
+    }
+    const float tot = block_sum_256(sg, sh);
+    if (threadIdx.x == 0) (is_col ? colsig : rowsig)[m] = tot;
+}
+
+// dL/dD_ij over the slab: g*(a/norm) * ( -sig(a(d_cc-d_ij)) - sig(a(d_ii-d_ij)) + [i==c]*(colsig_j + rowsig_i) ), c = col0+j,
+// rowsig = the row sums over ALL surfaces (summed over the ranks by the caller)
+__global__ void triplet_slab_bwd_kernel(const float* __restrict__ D, const float* __restrict__ diag, const float* __restrict__ rowsig,
+                                        const float* __restrict__ colsig, const float* __restrict__ gloss, float* __restrict__ gD,
+                                        int Bo, int Bs, int col0, float alpha, float norm) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)Bo * Bs) return;
+    const int i = idx / Bs, j = idx - (size_t)i * Bs;
+    const float d = D[idx];
+    const float x1 = alpha * (diag[col0 + j] - d);
+    const float x2 = alpha * (diag[i] - d);
+    float g = -(1.f / (1.f + expf(-x1))) - (1.f / (1.f + expf(-x2)));
+    if (i == col0 + j) g += colsig[j] + rowsig[i];
+    gD[idx] = g * (gloss[0] * alpha / norm);
+}
+
 __global__ __launch_bounds__(256) void sum_parts_kernel(const float* __restrict__ part, float* __restrict__ out, int n) {
     __shared__ float sh[4];
     float s = 0.f;
@@ -120,6 +155,32 @@ int witw_triplet_loss_slab_fwd(const float* distance, const float* diag, int Bo,
     hipLaunchKernelGGL(triplet_slab_partials_kernel, dim3(Bo), dim3(256), 0, st, distance, diag, workspace, Bs, col0, alpha);
     hipLaunchKernelGGL(sum_parts_kernel, dim3(1), dim3(256), 0, st, workspace, partial, Bo);
     WITW_CHECK_LAUNCH("triplet_loss_slab_fwd");
+    return WITW_OK;
+}
+
+// Backward of the sharded loss, step 1: rowsig[Bo] (partial: this rank's surfaces only — all-reduce it over the
+// ranks) and colsig[Bs] (complete) of the slab, see witw_triplet_loss_slab_fwd for the arguments.
+int witw_triplet_loss_slab_sig(const float* distance, const float* diag, int Bo, int Bs, int col0, float alpha, float* rowsig,
+                               float* colsig, void* stream) {
+    WITW_CHECK_ARG(distance && diag && rowsig && colsig, "triplet_loss_slab_sig: null pointer");
+    WITW_CHECK_ARG(Bo >= 2 && Bs >= 1 && col0 >= 0 && col0 + Bs <= Bo, "triplet_loss_slab_sig: bad slab Bo=%d Bs=%d col0=%d", Bo, Bs,
+                   col0);
+    hipLaunchKernelGGL(triplet_slab_sig_kernel, dim3(Bo + Bs), dim3(256), 0, (hipStream_t)stream, distance, diag, rowsig, colsig, Bo,
+                       Bs, col0, alpha);
+    WITW_CHECK_LAUNCH("triplet_loss_slab_sig");
+    return WITW_OK;
+}
+
+// Step 2: grad_distance[Bo,Bs] of the slab for grad_loss (device scalar) of the GLOBAL loss; rowsig = the summed row sums.
+int witw_triplet_loss_slab_bwd(const float* distance, const float* diag, const float* rowsig, const float* colsig,
+                               const float* grad_loss, float* grad_distance, int Bo, int Bs, int col0, float alpha, void* stream) {
+    WITW_CHECK_ARG(distance && diag && rowsig && colsig && grad_loss && grad_distance, "triplet_loss_slab_bwd: null pointer");
+    WITW_CHECK_ARG(Bo >= 2 && Bs >= 1 && col0 >= 0 && col0 + Bs <= Bo, "triplet_loss_slab_bwd: bad slab Bo=%d Bs=%d col0=%d", Bo, Bs,
+                   col0);
+    const size_t total = (size_t)Bo * Bs;
+    hipLaunchKernelGGL(triplet_slab_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, distance, diag,
+                       rowsig, colsig, grad_loss, grad_distance, Bo, Bs, col0, alpha, 2.f * Bo * (Bo - 1));
+    WITW_CHECK_LAUNCH("triplet_loss_slab_bwd");
     return WITW_OK;
 }
 

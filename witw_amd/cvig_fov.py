@@ -521,6 +521,54 @@ def retrieve(overhead_shard, surface_all, k=10, shard_begin=0, query_chunk=4096)
     return counts.cpu().numpy().astype('int64'), v, i
 
 
+class _ShardedMatchLossFn(torch.autograd.Function):
+    """Global-batch match + soft-margin triplet loss with the distance matrix sharded by COLUMNS over the ranks:
+    rank r evaluates all B overheads against its own b surfaces ([B,b] slab; the full [B,B] matrix is never built on
+    one GPU). Exchanges: forward = all-gather of the overhead embeddings and of the diagonal (B floats), all-reduce
+    of the loss partial; backward = all-reduce of the row sigmoid sums (B floats) and a reduce-scatter of the
+    overhead-embedding gradients (every rank holds the part that flows through ITS surfaces). The surface gradients
+    are complete locally. Same value and gradients as match + triplet_loss on the gathered batch."""
+
+    @staticmethod
+    def forward(ctx, overhead_local, surface_local, alpha, k):
+        from . import parallel
+        b = surface_local.shape[0]
+        col0 = parallel.rank() * b
+        ov_all = parallel._all_gather_cat(overhead_local.contiguous())
+        su = surface_local.contiguous()
+        ori, dist, score, ws = k.match_fwd(ov_all, su, want_score=True, want_workspace=True)
+        B = ov_all.shape[0]
+        diag = parallel._all_gather_cat(dist[col0:col0 + b].diagonal().contiguous())
+        part = k.triplet_loss_slab_fwd(dist, diag, col0, alpha)
+        parallel.all_reduce_sum_(part)
+        ctx.save_for_backward(ov_all, su, ori, score, ws, dist, diag)
+        ctx.cfg = (col0, b, float(alpha), k)
+        ctx.mark_non_differentiable(ori, dist)
+        return (part / (2. * B * (B - 1))).reshape(()), ori, dist
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_ori, _g_dist):
+        from . import parallel
+        ov_all, su, ori, score, ws, dist, diag = ctx.saved_tensors
+        col0, b, alpha, k = ctx.cfg
+        rowsig, colsig = k.triplet_loss_slab_sig(dist, diag, col0, alpha)
+        parallel.all_reduce_sum_(rowsig)
+        g_dist = k.triplet_loss_slab_bwd(dist, diag, rowsig, colsig, g_loss.contiguous(), col0, alpha)
+        gov_all, gsu = k.match_bwd(ov_all, su, ori, score, ws, g_dist, True, True)
+        return parallel.reduce_scatter_rows(gov_all, b), gsu, None, None
+
+
+def sharded_match_loss(overhead_local, surface_local, alpha=10., _kernels=None):
+    """(loss, orientation [B,b], distance [B,b]) of the GLOBAL batch from this rank's b pairs; every rank must call it
+    with the same b. On one rank it is match + triplet_loss. `_kernels` swaps the op set (CPU tests of the
+    collective algebra)."""
+    from . import parallel
+    if parallel.world() == 1 and _kernels is None:
+        ori, dist = match(overhead_local, surface_local)
+        return triplet_loss(dist, alpha), ori, dist.detach()
+    return _ShardedMatchLossFn.apply(overhead_local, surface_local, float(alpha), _kernels or ops)
+
+
 def evaluate_global_batch(overhead_all, surface_local, col0, alpha=10.):
     """Inference-time similarity for a minibatch sharded over ranks (no gradients): this rank matches ALL
     overhead embeddings of the global batch against its OWN surfaces (column slab [B, b]), which is all that

@@ -335,6 +335,32 @@ def triplet_loss_slab_fwd(distance_slab, diag, col0, alpha=10.):
     return out
 
 
+def triplet_loss_slab_sig(distance_slab, diag, col0, alpha=10.):
+    """-> (rowsig [Bo] partial over this slab's surfaces, colsig [Bs]) for the sharded loss backward."""
+    lib = _lib.load()
+    d = _dev_f32(distance_slab, 'distance_slab')
+    g = _dev_f32(diag, 'diag')
+    Bo, Bs = d.shape
+    rowsig = torch.empty((Bo,), dtype=torch.float32, device=d.device)
+    colsig = torch.empty((Bs,), dtype=torch.float32, device=d.device)
+    _lib.check(lib.witw_triplet_loss_slab_sig(d.data_ptr(), g.data_ptr(), Bo, Bs, col0, float(alpha), rowsig.data_ptr(),
+                                              colsig.data_ptr(), _stream()), 'witw_triplet_loss_slab_sig')
+    return rowsig, colsig
+
+
+def triplet_loss_slab_bwd(distance_slab, diag, rowsig, colsig, grad_loss, col0, alpha=10.):
+    """Gradient of the GLOBAL loss w.r.t. this rank's distance slab [Bo,Bs]; rowsig must be summed over the ranks."""
+    lib = _lib.load()
+    d = _dev_f32(distance_slab, 'distance_slab')
+    Bo, Bs = d.shape
+    gd = torch.empty_like(d)
+    gl = _dev_f32(grad_loss.reshape(1), 'grad_loss')
+    _lib.check(lib.witw_triplet_loss_slab_bwd(d.data_ptr(), _dev_f32(diag, 'diag').data_ptr(), _dev_f32(rowsig, 'rowsig').data_ptr(),
+                                              _dev_f32(colsig, 'colsig').data_ptr(), gl.data_ptr(), gd.data_ptr(), Bo, Bs, col0,
+                                              float(alpha), _stream()), 'witw_triplet_loss_slab_bwd')
+    return gd
+
+
 def triplet_loss_bwd(distance, ws, grad_loss, alpha=10.):
     lib = _lib.load()
     d = _dev_f32(distance, 'distance')

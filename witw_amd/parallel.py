@@ -3,10 +3,12 @@
 The encoder has no BatchNorm, so samples are independent and the minibatch shards across ranks
 (SURVEY.md §8e). The loss couples the GLOBAL batch (nn.DataParallel semantics of the reference,
 model/cvig_baseline.py:339-343; normaliser 2B(B-1) with B = global batch, model/cvig_fov.py:380):
-  1. both embedding sets are all-gathered (2 MiB per rank per side at 128 pairs/rank),
-  2. every rank evaluates match + loss over the global batch, so the gradient w.r.t. its LOCAL
-     embeddings is complete without a further exchange (it is the local slice of the global
-     embedding gradient),
+  1. the overhead embeddings are all-gathered (2 MiB per rank at 128 pairs/rank),
+  2. every rank evaluates match + loss for its column slab [B_global, b_local] (cvig_fov.sharded_match_loss);
+     the diagonal, the loss partial and the row sigmoid sums are exchanged (B floats each), the
+     overhead-embedding gradients are reduce-scattered to their owners (reduce_scatter_rows);
+     all_gather_embeddings keeps the simpler replicated form (every rank evaluates the full matrix, backward
+     = local slice),
   3. weight gradients (57.9 MB for both encoders) are summed with one all-reduce over a flat bucket.
 Retrieval (gallery >> queries) shards the gallery rows instead: rank counts are summed with an
 all-reduce of int32[queries].
@@ -76,6 +78,20 @@ def all_reduce_grads(params):
         g.copy_(flat[off:off + n].view_as(g))
         off += n
     return off
+
+
+def reduce_scatter_rows(t, rows):
+    """SUM t [world*rows, ...] over the ranks and keep this rank's block of `rows` rows."""
+    if world() == 1:
+        return t
+    t = t.contiguous()
+    r = rank()
+    if dist.get_backend() == 'gloo':
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t[r * rows:(r + 1) * rows].contiguous()
+    out = torch.empty((rows,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    dist.reduce_scatter_tensor(out, t, op=dist.ReduceOp.SUM)
+    return out
 
 
 def broadcast_parameters(modules, src=0):
