@@ -67,3 +67,45 @@ def test_sharded_match_loss_two_ranks_one_gpu(we):
         assert abs(loss - loss_full) <= 2e-6 * max(1.0, abs(loss_full)), (rank, loss, loss_full)
         assert ori_equal and dd == 0.0                       # same kernel on a column subset: bit-identical slab
         assert dgo <= 1e-5 * go + 1e-9 and dgs <= 1e-5 * gs + 1e-9, (rank, dgo, go, dgs, gs)
+
+
+def _train_worker(rank, world, port, root, out_q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ['LOCAL_RANK'] = '0'                      # both ranks share the one GPU of the test box
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from witw_amd import cvig_fov
+        os.chdir(root)
+        best = cvig_fov.train(dataset='cvusa', fov=70, val_quantity=4, batch_size=2, num_workers=0, num_epochs=2,
+                              csv_path=os.path.join(root, 'pairs.csv'), seed=3)
+        out_q.put((rank, best))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_train_driver_two_ranks(tmp_path):
+    """cvig_fov.train under torch.distributed (2 ranks): DistributedSampler shards, column-sharded global-batch loss,
+    gradient all-reduce; both ranks report the same validation loss and only rank 0 writes the checkpoints."""
+    from PIL import Image
+    root = str(tmp_path)
+    rows = []
+    for i in range(12):
+        Image.fromarray(synth.images_u8(96, i, (64, 64, 3)).astype(np.uint8)).save(os.path.join(root, 'ov_%d.png' % i))
+        Image.fromarray(synth.images_u8(97, i, (48, 80, 3)).astype(np.uint8)).save(os.path.join(root, 'su_%d.png' % i))
+        rows.append('ov_%d.png,su_%d.png' % (i, i))
+    with open(os.path.join(root, 'pairs.csv'), 'w') as f:
+        f.write('\n'.join(rows) + '\n')
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, root, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0][1] is not None and np.isfinite(res[0][1]) and res[0][1] == res[1][1]
+    sd = torch.load(os.path.join(root, 'weights', 'fov_70_surface_best.pth'))
+    assert 'model.features.27.weight' in sd

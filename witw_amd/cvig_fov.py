@@ -31,7 +31,16 @@ class Globals:
     }
 
 
-device = torch.device('cuda:0' if torch.cuda.is_available() else 'cpu')  # model/cvig_fov.py:578
+def _default_device():
+    # model/cvig_fov.py:578 uses cuda:0; under torch.distributed.run every process takes the GPU of its LOCAL_RANK
+    import os
+    if not torch.cuda.is_available():
+        return torch.device('cpu')
+    n = torch.cuda.device_count()
+    return torch.device('cuda:%d' % (int(os.environ.get('LOCAL_RANK', '0')) % max(1, n)))
+
+
+device = _default_device()
 
 
 class HorizCircPadding(torch.nn.Module):
@@ -727,25 +736,42 @@ def train(dataset='cvusa', fov=360, val_quantity=1000, batch_size=64, num_worker
     from datetime import datetime
     m = _mod or sys.modules[__name__]
     Globals, FOV_DSM, ImagePairDataset, GpuPreprocess, device = m.Globals, m.FOV_DSM, m.ImagePairDataset, m.GpuPreprocess, m.device
+    from . import parallel
+    world, rank = parallel.world(), parallel.rank()
+    if device.type == 'cuda':
+        torch.cuda.set_device(device)
     pathlib.Path('./weights').mkdir(parents=True, exist_ok=True)
-    writer = _writer('runs/{}/train/{}/{}'.format(dataset, fov, datetime.now().strftime("%Y%m%d-%H%M%S")))
+    writer = _writer('runs/{}/train/{}/{}'.format(dataset, fov, datetime.now().strftime("%Y%m%d-%H%M%S"))) if rank == 0 \
+        else _NullWriter()
     csv_path = csv_path or Globals.dataset_paths[dataset]['train']
     prep = GpuPreprocess(dataset, fov)
     trainval_set = ImagePairDataset(dataset=dataset, csv_path=csv_path)
-    train_set, val_set = torch.utils.data.random_split(trainval_set, [len(trainval_set) - val_quantity, val_quantity])
-    train_loader = torch.utils.data.DataLoader(train_set, batch_size=batch_size, shuffle=True, drop_last=True,
-                                               num_workers=num_workers, collate_fn=collate_raw)
+    split_gen = torch.Generator().manual_seed(seed) if world > 1 else None      # every rank must draw the same split
+    train_set, val_set = torch.utils.data.random_split(trainval_set, [len(trainval_set) - val_quantity, val_quantity],
+                                                       generator=split_gen)
+    # batch_size is per process; with N ranks (python -m torch.distributed.run ... ) the global batch is N * batch_size,
+    # every rank reads its own shard of each epoch and the loss still couples the whole global batch
+    train_sampler = torch.utils.data.distributed.DistributedSampler(train_set, shuffle=True, drop_last=True) if world > 1 else None
+    val_sampler = torch.utils.data.distributed.DistributedSampler(val_set, shuffle=False) if world > 1 else None
+    train_loader = torch.utils.data.DataLoader(train_set, batch_size=batch_size, shuffle=(world == 1), drop_last=True,
+                                               sampler=train_sampler, num_workers=num_workers, collate_fn=collate_raw)
     val_loader = torch.utils.data.DataLoader(val_set, batch_size=batch_size, shuffle=False, drop_last=False,
-                                             num_workers=num_workers, collate_fn=collate_raw)
+                                             sampler=val_sampler, num_workers=num_workers, collate_fn=collate_raw)
     surface_encoder = FOV_DSM(circ_padding=False, seed=seed).to(device)
     overhead_encoder = FOV_DSM(circ_padding=True, seed=seed).to(device)
-    loss_func = triplet_loss
+    parallel.broadcast_parameters([surface_encoder, overhead_encoder])
     all_params = list(surface_encoder.parameters()) + list(overhead_encoder.parameters())
     optimizer = Adam(all_params, lr=1.E-5)
 
+    def say(*a):
+        if rank == 0:
+            print(*a)
+
     best_loss = None
     for epoch in range(num_epochs):
-        print('Epoch %d, %s' % (epoch + 1, time.ctime(time.time())))
+        say('Epoch %d, %s' % (epoch + 1, time.ctime(time.time())))
+        if train_sampler is not None:
+            train_sampler.set_epoch(epoch)
         for phase in ['train', 'val']:
             running_count = 0
             running_loss = 0.
@@ -759,24 +785,26 @@ def train(dataset='cvusa', fov=360, val_quantity=1000, batch_size=64, num_worker
                 with torch.set_grad_enabled(phase == 'train'):
                     surface_embed = surface_encoder(surface)
                     overhead_embed = overhead_encoder(overhead)
-                    orientation_estimate, distance = match(overhead_embed, surface_embed)
-                    loss = loss_func(distance)
+                    # correlation -> crop_overhead -> l2_distance -> triplet_loss (:450-454) over the GLOBAL batch
+                    loss, orientation_estimate, distance = sharded_match_loss(overhead_embed, surface_embed)
                     if phase == 'train':
                         optimizer.zero_grad()
                         loss.backward()
+                        parallel.all_reduce_grads(all_params)
                         optimizer.step()
-                count = surface_embed.size(0)
+                count = surface_embed.size(0) * world
                 running_count += count
                 running_loss += loss.item() * count
-                print('epoch = {} {}, iter = {}, count = {}, loss = {:.4f}'.format(epoch + 1, phase, batch, running_count,
-                                                                                 loss.item()))
+                say('epoch = {} {}, iter = {}, count = {}, loss = {:.4f}'.format(epoch + 1, phase, batch, running_count,
+                                                                                loss.item()))
                 writer.add_scalar('{} loss'.format(phase), running_loss / running_count, epoch * len(loader) + batch)
-            print('  %5s: avg loss = %f' % (phase, running_loss / max(1, running_count)))
+            say('  %5s: avg loss = %f' % (phase, running_loss / max(1, running_count)))
         if running_count and (best_loss is None or running_loss / running_count < best_loss):
-            print('-------> new best')
+            say('-------> new best')
             best_loss = running_loss / running_count
-            torch.save(surface_encoder.state_dict(), './weights/fov_{}_surface_best.pth'.format(int(fov)))
-            torch.save(overhead_encoder.state_dict(), './weights/fov_{}_overhead_best.pth'.format(int(fov)))
+            if rank == 0:
+                torch.save(surface_encoder.state_dict(), './weights/fov_{}_surface_best.pth'.format(int(fov)))
+                torch.save(overhead_encoder.state_dict(), './weights/fov_{}_overhead_best.pth'.format(int(fov)))
             writer.add_text('best_loss', 'new best loss: {}, epoch: {}'.format(best_loss, epoch + 1), epoch)
     return best_loss
 
@@ -839,10 +867,23 @@ def main(argv=None):
                         help='The field of view for cropping street level images. [Default = 360]')
     args = parser.parse_args(argv)
     print(args)
+    init_distributed()
     if args.mode == 'train':
         train(dataset=args.dataset, fov=args.fov)
     elif args.mode == 'test':
         test(dataset=args.dataset, fov=args.fov)
+
+
+def init_distributed(backend='nccl'):
+    """Under `python -m torch.distributed.run --nproc-per-node N -m witw_amd.cvig_fov ...`: one process per GPU over RCCL
+    (backend name 'nccl'); a plain `python` launch stays single-process like the reference."""
+    import os
+    import torch.distributed as dist
+    if int(os.environ.get('WORLD_SIZE', '1')) > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if device.type == 'cuda':
+            torch.cuda.set_device(device)
+        dist.init_process_group(backend, device_id=device if backend == 'nccl' else None)
 
 
 if __name__ == '__main__':

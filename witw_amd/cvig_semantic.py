@@ -113,6 +113,7 @@ def main(argv=None):
                         help='The field of view for cropping street level images. [Default = 360]')
     args = parser.parse_args(argv)
     print(args)
+    _fov.init_distributed()
     if args.mode == 'train':
         train(dataset=args.dataset, fov=args.fov)
     elif args.mode == 'test':
