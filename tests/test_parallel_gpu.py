@@ -79,7 +79,9 @@ def _train_worker(rank, world, port, root, out_q):
         os.chdir(root)
         best = cvig_fov.train(dataset='cvusa', fov=70, val_quantity=4, batch_size=2, num_workers=0, num_epochs=2,
                               csv_path=os.path.join(root, 'pairs.csv'), seed=3)
-        out_q.put((rank, best))
+        cvig_fov.Globals.test_random_orientation = False
+        table = cvig_fov.test(dataset='cvusa', fov=70, batch_size=4, num_workers=0, csv_path=os.path.join(root, 'pairs.csv'))
+        out_q.put((rank, best, table))
     finally:
         dist.destroy_process_group()
 
@@ -102,10 +104,22 @@ def test_train_driver_two_ranks(tmp_path):
     procs = [ctx.Process(target=_train_worker, args=(r, 2, port, root, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=300) for _ in procs])
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
     assert res[0][1] is not None and np.isfinite(res[0][1]) and res[0][1] == res[1][1]
     sd = torch.load(os.path.join(root, 'weights', 'fov_70_surface_best.pth'))
     assert 'model.features.27.weight' in sd
+    # test() with the gallery sharded over the two ranks equals the single-process table on the same checkpoint
+    assert res[0][2] == res[1][2]
+    from witw_amd import cvig_fov
+    cwd = os.getcwd()
+    os.chdir(root)
+    cvig_fov.Globals.test_random_orientation = False
+    try:
+        single = cvig_fov.test(dataset='cvusa', fov=70, batch_size=4, num_workers=0, csv_path=os.path.join(root, 'pairs.csv'))
+    finally:
+        os.chdir(cwd)
+        del cvig_fov.Globals.test_random_orientation
+    assert single == res[0][2]

@@ -816,11 +816,21 @@ def test(dataset='cvusa', fov=360, batch_size=64, num_workers=8, csv_path=None, 
     from datetime import datetime
     m = _mod or sys.modules[__name__]
     Globals, FOV_DSM, ImagePairDataset, GpuPreprocess, device = m.Globals, m.FOV_DSM, m.ImagePairDataset, m.GpuPreprocess, m.device
-    writer = _writer('runs/{}/test/{}/{}'.format(dataset, fov, datetime.now().strftime("%Y%m%d-%H%M%S")))
+    from . import parallel
+    world, rank = parallel.world(), parallel.rank()
+    if device.type == 'cuda':
+        torch.cuda.set_device(device)
+    writer = _writer('runs/{}/test/{}/{}'.format(dataset, fov, datetime.now().strftime("%Y%m%d-%H%M%S"))) if rank == 0 \
+        else _NullWriter()
     csv_path = csv_path or Globals.dataset_paths[dataset]['test']
-    prep = GpuPreprocess(dataset, fov)
+    # the reference crops test panoramas at a random orientation too (:495-499); Globals.test_random_orientation = False
+    # makes the evaluation repeatable
+    prep = GpuPreprocess(dataset, fov, getattr(Globals, 'test_random_orientation', True))
     test_set = ImagePairDataset(dataset=dataset, csv_path=csv_path)
-    test_loader = torch.utils.data.DataLoader(test_set, batch_size=batch_size, shuffle=False, drop_last=False,
+    # under torch.distributed every rank embeds a contiguous shard of the test set and keeps its gallery rows
+    shard_begin, shard_end = parallel.shard_range(len(test_set))
+    shard = torch.utils.data.Subset(test_set, range(shard_begin, shard_end)) if world > 1 else test_set
+    test_loader = torch.utils.data.DataLoader(shard, batch_size=batch_size, shuffle=False, drop_last=False,
                                               num_workers=num_workers, collate_fn=collate_raw)
     surface_encoder = FOV_DSM(circ_padding=False).to(device)
     overhead_encoder = FOV_DSM(circ_padding=True).to(device)
@@ -836,9 +846,14 @@ def test(dataset='cvusa', fov=360, batch_size=64, num_workers=8, csv_path=None, 
             ov_parts.append(overhead_encoder(data['polar']))
     surface_embed = torch.cat(su_parts, dim=0)
     overhead_embed = torch.cat(ov_parts, dim=0)
-    rk = ranks(overhead_embed, surface_embed)
+    if world > 1:       # queries replicated, gallery rows stay sharded (SURVEY §8e retrieval partitioning)
+        rk = sharded_ranks(overhead_embed, parallel.all_gather_ragged(surface_embed), shard_begin)
+    else:
+        rk = ranks(overhead_embed, surface_embed)
     t = recall_table(rk)
     count = len(rk)
+    if rank != 0:
+        return t
     lines = ['Top  1: {:.2f}%'.format(t['top_1']), 'Top  5: {:.2f}%'.format(t['top_5']), 'Top 10: {:.2f}%'.format(t['top_10']),
              'Top 1%: {:.2f}%'.format(t['top_1pct']), 'Avg. Rank: {:.2f}'.format(t['mean']),
              'Med. Rank: {:.2f}'.format(t['median']), 'Locations: {}'.format(count)]

@@ -80,6 +80,19 @@ def all_reduce_grads(params):
     return off
 
 
+def all_gather_ragged(t):
+    """cat over ranks of tensors whose first dimension differs from rank to rank (shard_range splits)."""
+    if world() == 1:
+        return t
+    n = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
+    sizes = _all_gather_cat(n).tolist()
+    m = max(sizes)
+    pad = torch.zeros((m,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    pad[:t.shape[0]] = t
+    allp = _all_gather_cat(pad)
+    return torch.cat([allp[i * m:i * m + k] for i, k in enumerate(sizes)], dim=0)
+
+
 def reduce_scatter_rows(t, rows):
     """SUM t [world*rows, ...] over the ranks and keep this rank's block of `rows` rows."""
     if world() == 1:
