@@ -67,7 +67,7 @@ def _worker(rank, world, port, we, out_q):
         g0, g1 = parallel.shard_range(N)
         r = cvig_fov.sharded_ranks(gal[g0:g1], qry, g0, query_chunk=4, _match=O.match,
                                    _count=lambda dd, thr: (dd <= thr[None, :]).sum(0).to(torch.int32))
-        out_q.put((rank, loss.item(), [p.grad.clone() for p in params], r))
+        out_q.put((rank, loss.item(), [p.grad.numpy().copy() for p in params], np.asarray(r)))   # numpy: no shared-memory handles that die with the sender
     finally:
         dist.destroy_process_group()
 
@@ -91,7 +91,7 @@ def test_global_batch_gradients_and_sharded_ranks_world2():
     for (_rank, loss, grads, _r) in res:
         assert abs(loss - loss_ref) < 1e-6
         for g, gr in zip(grads, grads_ref):
-            np.testing.assert_allclose(g.numpy(), gr.numpy(), rtol=1e-4, atol=1e-7)
+            np.testing.assert_allclose(np.asarray(g), gr.numpy(), rtol=1e-4, atol=1e-7)
     N = 10
     gal = torch.from_numpy(synth.embeddings(4, 1, (N, 16, 4, 64)))
     qry = torch.stack([torch.roll(gal[i], -3 * i, dims=2)[:, :, :we] for i in range(N)]) \
@@ -162,7 +162,7 @@ def _worker_sharded(rank, world, port, we, out_q):
         loss.backward()
         params = list(su_enc.parameters()) + list(ov_enc.parameters())
         parallel.all_reduce_grads(params)
-        out_q.put((rank, loss.item(), [p.grad.clone() for p in params]))
+        out_q.put((rank, loss.item(), [p.grad.numpy().copy() for p in params]))
     finally:
         dist.destroy_process_group()
 
@@ -188,7 +188,7 @@ def test_sharded_match_loss_world2_equals_full_batch():
     for (_rank, loss, grads) in res:
         assert abs(loss - loss_ref) < 1e-6
         for g, gr in zip(grads, grads_ref):
-            np.testing.assert_allclose(g.numpy(), gr.numpy(), rtol=1e-4, atol=1e-7)
+            np.testing.assert_allclose(np.asarray(g), gr.numpy(), rtol=1e-4, atol=1e-7)
 
 
 def test_shard_range_partitions():
