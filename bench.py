@@ -32,20 +32,27 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # same table, dense bf16 MFMA (no sparsity)
 DOMINANT = (128, 1, False, 8)  # conv3x3_nhwc_f32_kernel<128,1,false,8,0>: layers 5,10,12,17,19,21 at B=128
 
 
-def make_inputs(cvig_fov, ops, synth, batch, fov, seed, device):
+def make_inputs(cvig_fov, ops, synth, batch, fov, seed, device, channels=3):
     """Synthetic raw pairs with planted matches: the overhead is uint8 noise; its ground
-    image is the polar view of that overhead, rolled by a seeded shift, plus noise, at raw size."""
-    ov_raw = torch.from_numpy(synth.images_u8(seed, 1, (batch, 3, 512, 512))).to(device)
+    image is the polar view of that overhead, rolled by a seeded shift, plus noise, at raw size.
+    channels=5 (cvig_semantic): bands 3,4 are the semantic channels, uniform in [0,1] (they are not divided
+    by 255, model/cvig_semantic.py:172-176)."""
+    ov_raw = torch.from_numpy(synth.images_u8(seed, 1, (batch, channels, 512, 512))).to(device)
+    if channels > 3:
+        ov_raw[:, 3:] /= 255.0
     ws = int(fov / 360 * 512)
     small = ops.resize_bilinear(ov_raw, (256, 256))
     polar = ops.polar_transform(small)                                   # [B,3,128,512], 0..255 scale
     g = np.random.Generator(np.random.Philox(key=[seed, 77]))
     shifts = g.integers(0, 512, size=batch)
     rolled = torch.stack([torch.roll(polar[i], -int(shifts[i]), dims=2)[:, :, :ws] for i in range(batch)])
-    noise = torch.from_numpy(synth.images_u8(seed, 2, (batch, 3, 128, ws))).to(device)
+    noise = torch.from_numpy(synth.images_u8(seed, 2, (batch, channels, 128, ws))).to(device)
+    if channels > 3:
+        noise[:, 3:] /= 255.0
     ground = (0.7 * rolled + 0.3 * noise).contiguous()
-    ground_raw = ops.resize_bilinear(ground, (224, 224)).round().clamp(0, 255).contiguous()
-    return ground_raw, ov_raw
+    ground_raw = ops.resize_bilinear(ground, (224, 224))
+    ground_raw[:, :3] = ground_raw[:, :3].round().clamp(0, 255)
+    return ground_raw.contiguous(), ov_raw
 
 
 def main():
@@ -63,6 +70,9 @@ def main():
     ap.add_argument('--topk', type=int, default=10)
     ap.add_argument('--precision', choices=['fp32', 'bf16'], default='fp32',
                     help='fp32 (headline, BASELINE configs[1]) or the bf16 MFMA inference path (configs[3] arithmetic)')
+    ap.add_argument('--model', choices=['fov', 'semantic'], default='fov',
+                    help='fov = cvig_fov (3-channel, BASELINE configs[1]); semantic = cvig_semantic (5-channel first conv, '
+                         'configs[3]: run it with --precision bf16)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL); gloo only for 1-GPU self-tests')
     ap.add_argument('--single-device', action='store_true', help='self-test: put every rank on cuda:0')
@@ -94,25 +104,34 @@ def main():
 
     B = a.batch
     seed = 1234
-    wts = synth.fov_dsm_weights(seed)
-    surface_encoder = cvig_fov.FOV_DSM(circ_padding=False, weights=wts).to(device)
-    overhead_encoder = cvig_fov.FOV_DSM(circ_padding=True, weights=wts).to(device)
+    semantic = a.model == 'semantic'
+    channels = 5 if semantic else 3
+    if semantic:
+        from witw_amd import cvig_semantic as model_mod
+    else:
+        model_mod = cvig_fov
+    wts = synth.fov_dsm_weights(seed, in_channels=channels)
+    surface_encoder = model_mod.FOV_DSM(circ_padding=False, weights=wts).to(device)
+    overhead_encoder = model_mod.FOV_DSM(circ_padding=True, weights=wts).to(device)
     train = a.mode == 'train'
     bf16 = a.precision == 'bf16'
     if bf16 and train:
-        sys.exit('the bf16 path is inference only')
+        if semantic:
+            sys.exit('bf16 training of cvig_semantic (backward through the fused max-pools) is not implemented')
+        surface_encoder.precision = overhead_encoder.precision = 'bf16'     # mixed-precision step, fp32 master weights
     surface_encoder.train(train)
     overhead_encoder.train(train)
     all_params = list(surface_encoder.parameters()) + list(overhead_encoder.parameters())
     optimizer = cvig_fov.Adam(all_params, lr=1.E-5) if train else None
-    ground_raw, ov_raw = make_inputs(cvig_fov, ops, synth, B, a.fov, seed + rank, device)
+    ground_raw, ov_raw = make_inputs(cvig_fov, ops, synth, B, a.fov, seed + rank, device, channels)
     ws = int(a.fov / 360 * 512)
-    mean, std = cvig_fov.Globals.img_mean, cvig_fov.Globals.img_std
+    mean, std = model_mod.Globals.img_mean, model_mod.Globals.img_std
+    ndiv = 3 if semantic else None      # only the RGB bands are /255 (model/cvig_semantic.py:172-176)
 
     def train_step():
         with torch.no_grad():
-            surface = ops.resize_bilinear(ground_raw, (128, ws), mean, std)
-            overhead = ops.resize_bilinear(ov_raw, (256, 256), mean, std)
+            surface = ops.resize_bilinear(ground_raw, (128, ws), mean, std, ndiv)
+            overhead = ops.resize_bilinear(ov_raw, (256, 256), mean, std, ndiv)
             polar = ops.polar_transform(overhead)
         su = surface_encoder(surface)
         ov = overhead_encoder(polar)
@@ -127,8 +146,8 @@ def main():
 
     def infer_step():
         with torch.no_grad():
-            surface = ops.resize_bilinear(ground_raw, (128, ws), mean, std)
-            overhead = ops.resize_bilinear(ov_raw, (256, 256), mean, std)
+            surface = ops.resize_bilinear(ground_raw, (128, ws), mean, std, ndiv)
+            overhead = ops.resize_bilinear(ov_raw, (256, 256), mean, std, ndiv)
             polar = ops.polar_transform(overhead)
             su = surface_encoder.forward_bf16(surface) if bf16 else surface_encoder(surface)
             ov = overhead_encoder.forward_bf16(polar) if bf16 else overhead_encoder(polar)
@@ -168,7 +187,8 @@ def main():
     peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
     kname = 'conv3x3_nhwc_bf16_kernel<128,1,false,8>' if bf16 else 'conv3x3_nhwc_f32_kernel<128,1,false,8,0>'
     dom = [(fl, e0.elapsed_time(e1)) for (v, fl, e0, e1) in prof if v == dominant]
-    allc = [(fl, e0.elapsed_time(e1)) for (v, fl, e0, e1) in prof if v[0] != 'match']
+    allc = [(fl, e0.elapsed_time(e1)) for (v, fl, e0, e1) in prof if v[0] not in ('match', 'wgrad_bf16')]
+    wg = [(fl, e0.elapsed_time(e1)) for (v, fl, e0, e1) in prof if v[0] == 'wgrad_bf16']
     dom_fl = sum(f for f, _ in dom) / max(1, len(dom))
     dom_ms = sum(m for _, m in dom) / max(1, len(dom))
     achieved = dom_fl / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
@@ -181,15 +201,19 @@ def main():
         except Exception:
             traffic = None
 
+    mname = 'cvig_semantic (5-channel)' if semantic else 'cvig_fov'
     out = {
         'metric': 'image-pairs/sec (embedding+similarity)' if not train else 'image-pairs/sec (training step)', 'value': round(value, 2), 'unit': 'pairs/s',
         'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 3),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16' if bf16 else 'f32', 'data': 'synthetic',
-        'config': {'workload': ('cvig_fov fov=%d eval%s: resize+normalize+polar -> 2x FOV_DSM (VGG16[:23]+3 conv) -> '
-                                'fused match + soft-margin triplet loss + rank counts' % (a.fov, ' [bf16 MFMA encoders, fp32 accumulate; matching fp32]' if bf16 else '')) if not train else
-                               ('cvig_fov fov=%d TRAIN step: resize+normalize+polar -> 2x FOV_DSM fwd (Dropout2d) -> match + '
-                                'triplet loss -> backward (dgrad L19-27, wgrad L17-27) -> grad all-reduce -> Adam' % a.fov),
-                   'pairs_per_gpu': B, 'global_batch': B * world, 'ground_raw': '3x224x224', 'overhead_raw': '3x512x512',
+        'config': {'workload': ('%s fov=%d eval%s: resize+normalize+polar -> 2x FOV_DSM (VGG16[:23]+3 conv) -> '
+                                'fused match + soft-margin triplet loss + rank counts' % (mname, a.fov, ' [bf16 MFMA encoders, fp32 accumulate; matching fp32]' if bf16 else '')) if not train else
+                               ('%s fov=%d TRAIN step: resize+normalize+polar -> 2x FOV_DSM fwd (Dropout2d) -> match + '
+                                'triplet loss -> backward (%s) -> grad all-reduce -> Adam'
+                                % (mname + (' [bf16 MFMA fwd/dgrad/wgrad, fp32 accumulate + master weights]' if bf16 else ''), a.fov,
+                                   'dgrad L2-27, max-pool scatter, wgrad L0 + L17-27' if semantic else 'dgrad L19-27, wgrad L17-27')),
+                   'pairs_per_gpu': B, 'global_batch': B * world, 'ground_raw': '%dx224x224' % channels,
+                   'overhead_raw': '%dx512x512' % channels,
                    'parallelism': 'dp%d (overhead-embedding all-gather, global-batch loss from column slabs)' % world},
         'recall': {'top1_pct': float(np.mean(ranks_h <= 1) * 100), 'top5_pct': float(np.mean(ranks_h <= 5) * 100),
                    'N': int(len(ranks_h))},
@@ -200,11 +224,13 @@ def main():
         'roofline': {'bound': 'mfma', 'kernel': kname, 'achieved': round(achieved, 2),
                      'peak': peak, 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
                      'traffic': traffic, 'launches': len(dom), 'avg_launch_ms': round(dom_ms, 4),
-                     'avg_launch_gflop': round(dom_fl / 1e9, 2), 'all_conv_launches_tflops': round(conv_tf, 2)},
+                     'avg_launch_gflop': round(dom_fl / 1e9, 2), 'all_conv_launches_tflops': round(conv_tf, 2),
+                     **({'wgrad_bf16_tflops_incl_layout_passes': round(sum(f for f, _ in wg) / (sum(m for _, m in wg) * 1e-3) / 1e12, 2)}
+                        if wg else {})},
     }
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline and not train and not bf16:
-        out['cpu_baseline'] = cpu_baseline(a, ground_raw, ov_raw, wts, ws, step)
+        out['cpu_baseline'] = cpu_baseline(a, ground_raw, ov_raw, wts, ws, step, semantic)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -283,7 +309,7 @@ def retrieval(a, rank, world, device, cvig_fov, ops):
         dist.destroy_process_group()
 
 
-def cpu_baseline(a, ground_raw, ov_raw, wts, ws, gpu_step):
+def cpu_baseline(a, ground_raw, ov_raw, wts, ws, gpu_step, semantic=False):
     """The oracle (CPU restatement of the reference, kind 'port') timed on this host on a bounded
     sample of the same workload, plus a parity check of the GPU step against it on that sample."""
     from oracle import cvig_fov_oracle as O
@@ -292,14 +318,15 @@ def cpu_baseline(a, ground_raw, ov_raw, wts, ws, gpu_step):
     o = ov_raw[:n].cpu()
     w = {k: (torch.from_numpy(v[0]), torch.from_numpy(v[1])) for k, v in wts.items()}
     threads = torch.get_num_threads()
+    norm = O.image_normalization_semantic if semantic else O.image_normalization
 
     def cpu_step():
         with torch.no_grad():
             su_in, ov_in = [], []
             for i in range(n):
                 s, ov = O.resize_pair(g[i], o[i], fov=a.fov, panorama=False)
-                su_in.append(O.image_normalization(s))
-                ov_in.append(O.polar_transform(O.image_normalization(ov)))
+                su_in.append(norm(s))
+                ov_in.append(O.polar_transform(norm(ov)))
             su = O.fov_dsm_forward(torch.stack(su_in), w, False)
             ov = O.fov_dsm_forward(torch.stack(ov_in), w, True)
             ori, d = O.match(ov, su)

@@ -1,0 +1,174 @@
+"""Mixed-precision (bf16 MFMA) training step of the FOV_DSM encoder: FOV_DSM.precision = 'bf16'.
+
+The reference trains in fp32 only (model/cvig_fov.py:439-465), so the bf16 step has no reference golden; it is pinned
+  * kernel by kernel against CPU autograd on bf16-representable operands (products of bf16 values are exact in fp32,
+    so the weight gradient must agree to fp32 summation order: 2e-5 of the largest entry; bf16 activation gradients
+    to one bf16 ulp),
+  * end to end against the fp32 HIP path, which itself is pinned to the reference's training-loop golden
+    (tests/test_backward_gpu.py): loss within 2e-2 relative, every trainable gradient within 8e-2 of its norm,
+  * and by the loss going down under Adam.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cvig_fov_oracle as O
+from witw_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand_bf16(stream, shape, scale=1.0):
+    """fp32 tensor whose values are exactly representable in bf16."""
+    g = np.random.Generator(np.random.Philox(key=[4242, stream]))
+    return (torch.from_numpy(g.standard_normal(shape, dtype=np.float32)) * scale).bfloat16().float()
+
+
+def _nhwc_bf16(t, dev):
+    return t.permute(0, 2, 3, 1).contiguous().to(dev).bfloat16()
+
+
+WGRAD_CASES = [  # B, H, W, Cin, Cout, stride_h, circ
+    (16, 16, 64, 64, 128, 1, True),
+    (10, 6, 12, 64, 16, 1, True),        # ragged image octet, ragged column segment (fov-70 width), Cout 16
+    (8, 8, 24, 72, 64, 2, False),        # stride (2,1), second ci tile mostly out of range
+    (3, 7, 20, 16, 256, 2, True),        # odd height under stride 2, two co tiles
+    (9, 5, 9, 128, 64, 1, False),        # odd width
+]
+
+
+@pytest.mark.parametrize('case', WGRAD_CASES)
+def test_wgrad_bf16_matches_autograd(case):
+    from witw_amd import ops
+    B, H, W, Cin, Cout, sh, circ = case
+    x = _rand_bf16(1, (B, Cin, H, W))
+    w = torch.zeros((Cout, Cin, 3, 3), requires_grad=True)
+    b = torch.zeros((Cout,), requires_grad=True)
+    y = O.conv3x3(x, w, b, sh, circ)
+    gy = _rand_bf16(2, tuple(y.shape))
+    y.backward(gy)
+    dev = torch.device('cuda:0')
+    xd, gyd = _nhwc_bf16(x, dev), _nhwc_bf16(gy, dev)
+    oct_ = ops.nhwc_bf16_to_octet(xd)
+    assert oct_.shape == ((B + 7) // 8, H, W, Cin, 8)
+    back = oct_.permute(0, 4, 1, 2, 3).reshape(-1, H, W, Cin)          # [B8*8,H,W,C]
+    assert torch.equal(back[:B], xd) and float(back[B:].float().abs().max() if back.shape[0] > B else 0.) == 0.
+    dw, db = ops.conv3x3_wgrad_bf16(xd, gyd, Cin, stride_h=sh, circular=circ)
+    assert dw.dtype == torch.float32 and dw.shape == (Cout, Cin, 3, 3)
+    np.testing.assert_allclose(dw.cpu().numpy(), w.grad.numpy(), rtol=0, atol=2e-5 * max(1.0, float(w.grad.abs().max())))
+    np.testing.assert_allclose(db.cpu().numpy(), b.grad.numpy(), rtol=0, atol=2e-5 * max(1.0, float(b.grad.abs().max())))
+    # bitwise reproducible (fixed-order split-K reduction)
+    dw2, db2 = ops.conv3x3_wgrad_bf16(xd, gyd, Cin, stride_h=sh, circular=circ)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
+
+
+DGRAD_CASES = [  # B, H (layer input rows), W, Cin, Cout, stride_h, circ
+    (2, 16, 64, 64, 128, 1, True),
+    (2, 8, 12, 256, 64, 2, True),
+    (3, 7, 24, 64, 64, 2, False),
+    (2, 4, 64, 64, 16, 1, False),
+]
+
+
+@pytest.mark.parametrize('case', DGRAD_CASES)
+def test_dgrad_bf16_gate_dropout_dilation(case):
+    """The bf16 forward kernel on the transposed, tap-rotated filter = data gradient; Dropout2d scale and the ReLU gate
+    of the previous layer in the epilogue; zero-interleaved rows for the stride-(2,1) layers."""
+    from witw_amd import ops
+    B, H, W, Cin, Cout, sh, circ = case
+    x = _rand_bf16(3, (B, Cin, H, W)).requires_grad_(True)
+    w = _rand_bf16(4, (Cout, Cin, 3, 3), 0.05)
+    y = O.conv3x3(x, w, torch.zeros(Cout), sh, circ)
+    gy = _rand_bf16(5, tuple(y.shape))
+    y.backward(gy)
+    dev = torch.device('cuda:0')
+    gate = _rand_bf16(6, (B, Cin, H, W))
+    scale = torch.from_numpy(synth.dropout_scales(8, 0, B, Cin))
+    ref = x.grad * scale[:, :, None, None] * (gate > 0).float()
+    pt = ops.PackedConvBf16(w.to(dev), None, transpose_flip=True)
+    cpad = (Cout + 15) // 16 * 16
+    gyd = torch.zeros((B, y.shape[2], W, cpad), dtype=torch.bfloat16, device=dev)
+    gyd[..., :Cout] = _nhwc_bf16(gy, dev)
+    dx = ops.conv3x3_bf16_fwd(gyd, pt, stride_h=1, circular=circ, relu=False, drop_scale=scale.to(dev),
+                              gate=_nhwc_bf16(gate, dev), dilate_h=(sh == 2), out_h=H if sh == 2 else None)
+    assert dx.shape == (B, H, W, Cin) and dx.dtype == torch.bfloat16
+    got = dx.float().cpu().permute(0, 3, 1, 2).numpy()
+    np.testing.assert_allclose(got, ref.bfloat16().float().numpy(), rtol=2 ** -7, atol=2e-5 * float(ref.abs().max()))
+
+
+def _encoders(precision, w, dev):
+    from witw_amd import cvig_fov
+    se = cvig_fov.FOV_DSM(False, weights=w).to(dev).train()
+    oe = cvig_fov.FOV_DSM(True, weights=w).to(dev).train()
+    se.precision = oe.precision = precision
+    return se, oe
+
+
+@pytest.mark.parametrize('ws', [512, 96])
+def test_bf16_training_step_vs_fp32_path(ws):
+    from witw_amd import cvig_fov
+    dev = torch.device('cuda:0')
+    B, seed = 12, 31
+    w = synth.fov_dsm_weights(seed)
+    xo = torch.from_numpy(synth.normalized_images(seed, 1, (B, 3, 128, 512))).to(dev)
+    xs = (xo[..., :ws] + 0.3 * torch.from_numpy(synth.normalized_images(seed, 2, (B, 3, 128, ws))).to(dev)).contiguous()
+    drops = {t: {i: torch.from_numpy(synth.dropout_scales(seed, 10 * k + i, B, 512)).to(dev) for i in (17, 19, 21)}
+             for k, t in enumerate('so')}
+    out = {}
+    for prec in ('fp32', 'bf16'):
+        se, oe = _encoders(prec, w, dev)
+        s_emb = se(xs, dropout_scales=drops['s'])
+        o_emb = oe(xo, dropout_scales=drops['o'])
+        assert s_emb.dtype == torch.float32 and s_emb.shape == (B, 16, 4, ws // 8)
+        ori, dist = cvig_fov.match(o_emb, s_emb)
+        loss = cvig_fov.triplet_loss(dist)
+        loss.backward()
+        grads = {('s.' + n): p.grad for n, p in se.named_parameters() if p.grad is not None}
+        grads.update({('o.' + n): p.grad for n, p in oe.named_parameters() if p.grad is not None})
+        out[prec] = (loss.item(), s_emb.detach(), o_emb.detach(), grads)
+    l32, s32, o32, g32 = out['fp32']
+    l16, s16, o16, g16 = out['bf16']
+    assert abs(l16 - l32) <= 2e-2 * abs(l32), (l16, l32)
+    for a, b in ((s16, s32), (o16, o32)):
+        assert float((a - b).norm() / b.norm()) < 5e-2
+    assert set(g16) == set(g32) and len(g16) == 24
+    worst = 0.0
+    for name, g in g32.items():
+        assert g16[name].dtype == torch.float32 and g16[name].shape == g.shape
+        rel = float((g16[name] - g).norm() / (g.norm() + 1e-30))
+        worst = max(worst, rel)
+        assert rel < 8e-2, (name, rel)
+    print('bf16 vs fp32 training step (ws=%d): loss %.6f vs %.6f, worst gradient deviation %.3e of its norm' % (ws, l16, l32, worst))
+
+
+def test_bf16_training_reduces_the_loss():
+    from witw_amd import cvig_fov
+    dev = torch.device('cuda:0')
+    w = synth.fov_dsm_weights(13)
+    se, oe = _encoders('bf16', w, dev)
+    opt = cvig_fov.Adam(list(se.parameters()) + list(oe.parameters()), lr=1e-4)
+    xo = torch.from_numpy(synth.normalized_images(14, 0, (16, 3, 128, 512))).to(dev)
+    xs = (xo + 0.3 * torch.from_numpy(synth.normalized_images(14, 1, (16, 3, 128, 512))).to(dev)).contiguous()
+    drops = {i: torch.full((16, 512), 1.0, device=dev) for i in (17, 19, 21)}      # dropout off: deterministic
+    losses = []
+    for _ in range(8):
+        _, d = cvig_fov.match(oe(xo, dropout_scales=drops), se(xs, dropout_scales=drops))
+        loss = cvig_fov.triplet_loss(d)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert all(np.isfinite(losses))
+    assert losses[-1] < losses[0] - 1e-3, losses
+    # master weights stay fp32 and the packed bf16 filters follow them
+    assert all(p.dtype == torch.float32 for p in se.parameters())
+
+
+def test_bf16_training_through_a_pool_is_refused():
+    from witw_amd import cvig_semantic, _lib
+    dev = torch.device('cuda:0')
+    enc = cvig_semantic.FOV_DSM(True, weights=synth.fov_dsm_weights(3, in_channels=5)).to(dev).train()
+    enc.precision = 'bf16'
+    x = torch.from_numpy(synth.normalized_images(3, 1, (1, 5, 128, 512))).to(dev)
+    with pytest.raises(_lib.WitwError):
+        enc(x)

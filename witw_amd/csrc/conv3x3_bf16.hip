@@ -72,6 +72,9 @@ struct ConvBfArgs {
     int tiles_x, tiles_y;
     int circ, relu, out_nchw_f32;
     int n_tiles, sp_total, sp_per_xcd, xcd_map;
+    const float* dropmask;       // nullptr, or [B,Cout] Dropout2d scale applied to conv + bias before the ReLU
+    const unsigned short* gate;  // nullptr, or a bf16 tensor shaped like y: outputs where gate <= 0 are zeroed (ReLU backward)
+    int dil_h;                   // 1: input rows are zero-interleaved (logical row 2i = physical row i): dgrad of a stride-(2,1) conv
 #ifdef WITW_BF_STAMPS
     unsigned long long* stamps;   // diagnostic build only (tools/bf16_stamps.cpp): per wave {loop, vmcnt wait, barrier wait} ticks
 #endif
@@ -133,7 +136,8 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_bf16_kernel(ConvBfArgs p
 
     // ---- staging descriptors: per-image / per-weight-tile buffer resources, fixed per-thread byte offsets,
     // K-chunk advance in the scalar offset (32 B per pixel per chunk)
-    const size_t img_elems = (size_t)p.H * p.W * p.Cin;
+    const int Hp = p.dil_h ? (p.H - 1) / 2 + 1 : p.H;      // physical rows of the input
+    const size_t img_elems = (size_t)Hp * p.W * p.Cin;
     __amdgpu_buffer_rsrc_t in_rs =
         __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)b * img_elems), 0, (unsigned)(img_elems * 2), 0x00020000);
     const i32x4 w_rd = raw_rsrc(reinterpret_cast<const u32x4*>(p.wpk) + (size_t)ntile * nkc * W_S, (unsigned)nkc * W_S * 16u);
@@ -143,9 +147,13 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_bf16_kernel(ConvBfArgs p
     // byte offset of halo-tile slot (pixel pix, channel group q) in the image, or OOR (loads return zero: padding)
     auto in_offset = [&](bool in_range, int pix, int q) -> unsigned {
         const int r = pix / IW, c = pix - r * IW;
-        const int gr = oy0 * SH - 1 + r;
+        int gr = oy0 * SH - 1 + r;
         int gc = ox0 - 1 + c;
         bool ok = in_range && gr >= 0 && gr < p.H;
+        if (p.dil_h) {
+            ok = ok && !(gr & 1);
+            gr >>= 1;
+        }
         if (p.circ) {
             gc %= p.W;
             if (gc < 0) gc += p.W;
@@ -343,27 +351,34 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_bf16_kernel(ConvBfArgs p
     __syncthreads();      // the slabs below reuse the stages
 
     // ---- epilogue
-    float bv[WN];
+    float bv[WN], dm[WN];
     int nch[WN];
 #pragma unroll
     for (int nt = 0; nt < WN; ++nt) {
         nch[nt] = n0 + wn * 64 + nt * 32 + l31;
         bv[nt] = p.bias[nch[nt]];
+        dm[nt] = 1.f;
+        if (p.dropmask != nullptr && nch[nt] < p.Cout) dm[nt] = p.dropmask[(size_t)b * p.Cout + nch[nt]];
     }
+    // conv + bias -> Dropout2d scale -> ReLU (the order of the fp32 kernel, model/cvig_fov.py:287-288)
     auto fin = [&](float v, int nt) {
-        v = v + bv[nt];
+        v = (v + bv[nt]) * dm[nt];
         if (p.relu) v = fmaxf(v, 0.f);
         return v;
     };
+    auto gate_open = [](unsigned short g) { return (g & 0x7fffu) != 0 && !(g & 0x8000u); };   // bf16 value > 0
     const int Hy = POOL ? (p.Ho >> 1) : p.Ho;
     const int Wy = POOL ? (p.Wo >> 1) : p.Wo;
     auto emit = [&](float v, int nt, int yy, int xx) {
         v = fin(v, nt);
         if (yy < Hy && xx < Wy && nch[nt] < p.Cout) {
-            if (p.out_nchw_f32)
+            if (p.out_nchw_f32) {
                 reinterpret_cast<float*>(p.y)[(((size_t)b * p.Cout + nch[nt]) * Hy + yy) * Wy + xx] = v;
-            else
-                reinterpret_cast<__bf16*>(p.y)[(((size_t)b * Hy + yy) * Wy + xx) * p.Cout + nch[nt]] = (__bf16)v;
+            } else {
+                const size_t o = (((size_t)b * Hy + yy) * Wy + xx) * p.Cout + nch[nt];
+                if (p.gate != nullptr && !gate_open(p.gate[o])) v = 0.f;
+                reinterpret_cast<__bf16*>(p.y)[o] = (__bf16)v;
+            }
         }
     };
 
@@ -392,8 +407,17 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_bf16_kernel(ConvBfArgs p
                     o[4 + e] = (__bf16)v1[e];
                 }
                 const int xx = ox0 + tcol[mt] + m;
-                if (yy < Hy && xx < Wy && nbase < p.Cout)
-                    __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p.y) + (((size_t)b * Hy + yy) * Wy + xx) * p.Cout + nbase));
+                if (yy < Hy && xx < Wy && nbase < p.Cout) {
+                    const size_t off = (((size_t)b * Hy + yy) * Wy + xx) * p.Cout + nbase;
+                    if (p.gate != nullptr) {
+                        typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+                        const u16x8 gt = *reinterpret_cast<const u16x8*>(p.gate + off);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            if (!gate_open(gt[e])) o[e] = (__bf16)0.f;
+                    }
+                    __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p.y) + off));
+                }
             }
         }
     } else if (!POOL) {
@@ -574,9 +598,15 @@ int witw_nchw_f32_to_nhwc_bf16(const float* x, void* y_bf16, int B, int C, int H
 }
 
 // x NHWC bf16 [B,H,W,Cin] (Cin%16==0) -> y NHWC bf16 [B,Hy,Wy,Cout] (or fp32 NCHW [B,Cout,Hy,Wy] if out_nchw_f32).
-int witw_conv3x3_bf16_fwd(const void* x_bf16, const void* wpk_bf16, const float* bias, void* y, int B, int H, int W, int Cin,
-                          int Cout, int stride_h, int pad_circular, int relu, int pool, int out_nchw_f32, void* stream) {
+// Training form: dropmask [B,Cout] fp32 (Dropout2d scale before the ReLU), gate = bf16 tensor shaped like y (outputs where
+// gate <= 0 are zeroed: the ReLU backward of a dgrad launch), dilate_h = x holds (H-1)/2+1 physical rows that stand for H
+// zero-interleaved rows (dgrad of a stride-(2,1) layer). H is the LOGICAL input height.
+int witw_conv3x3_bf16_fwd_ex(const void* x_bf16, const void* wpk_bf16, const float* bias, const float* dropmask,
+                             const void* gate_bf16, void* y, int B, int H, int W, int Cin, int Cout, int stride_h,
+                             int pad_circular, int relu, int pool, int out_nchw_f32, int dilate_h, void* stream) {
     WITW_CHECK_ARG(x_bf16 && wpk_bf16 && bias && y, "conv3x3_bf16_fwd: null pointer");
+    WITW_CHECK_ARG(!(gate_bf16 && (pool || out_nchw_f32)), "conv3x3_bf16_fwd: gate with pool / NCHW output unsupported");
+    WITW_CHECK_ARG(!(dilate_h && stride_h == 2), "conv3x3_bf16_fwd: dilated input with stride 2 unsupported");
     WITW_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cout > 0, "conv3x3_bf16_fwd: bad shape");
     WITW_CHECK_ARG(Cin > 0 && (Cin % 16) == 0, "conv3x3_bf16_fwd: Cin=%d must be a positive multiple of 16", Cin);
     WITW_CHECK_ARG(stride_h == 1 || stride_h == 2, "conv3x3_bf16_fwd: stride_h=%d unsupported", stride_h);
@@ -590,6 +620,7 @@ int witw_conv3x3_bf16_fwd(const void* x_bf16, const void* wpk_bf16, const float*
     a.tiles_x = cdiv(a.Wo, TW);
     a.tiles_y = 0;
     a.circ = pad_circular; a.relu = relu; a.out_nchw_f32 = out_nchw_f32;
+    a.dropmask = dropmask; a.gate = (const unsigned short*)gate_bf16; a.dil_h = dilate_h ? 1 : 0;
 #ifdef WITW_BF_STAMPS
     a.stamps = witw_bf16_stamps_ptr;
 #endif
@@ -602,6 +633,12 @@ int witw_conv3x3_bf16_fwd(const void* x_bf16, const void* wpk_bf16, const float*
     }
     if (stride_h == 2) return launch_bf<64, 2, false>(a, st);
     return pool ? launch_bf<64, 1, true>(a, st) : launch_bf<64, 1, false>(a, st);
+}
+
+int witw_conv3x3_bf16_fwd(const void* x_bf16, const void* wpk_bf16, const float* bias, void* y, int B, int H, int W, int Cin,
+                          int Cout, int stride_h, int pad_circular, int relu, int pool, int out_nchw_f32, void* stream) {
+    return witw_conv3x3_bf16_fwd_ex(x_bf16, wpk_bf16, bias, nullptr, nullptr, y, B, H, W, Cin, Cout, stride_h, pad_circular, relu,
+                                    pool, out_nchw_f32, 0, stream);
 }
 
 }  // extern "C"

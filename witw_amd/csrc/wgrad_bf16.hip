@@ -1,0 +1,389 @@
+// Weight gradient of the 3x3 convolution on v_mfma_f32_32x32x16_bf16 (gfx950): the mixed-precision training
+// step of the FOV_DSM encoder (bf16 operands, fp32 accumulate, fp32 gradients out).
+//
+// Reference semantics: autograd through torch.nn.Conv2d in the training loop of model/cvig_fov.py:447-460
+// (trainable layers :275-278; model/cvig_semantic.py:301-309 adds layer 0), i.e.
+//   dW[co][ci][kh][kw] = sum_{b,h,w} dZ[b,h,w,co] * Xpad[b, h*SH+kh-1, w+kw-1, ci]
+// with dZ the gradient at the conv output. The contraction runs over (image, pixel); a bf16 MFMA lane needs
+// EIGHT consecutive k values of its row/column, which in NHWC (channels innermost) are 8 far-apart pixels.
+// Instead of transposing through LDS, both operands are re-laid out once per layer (an HBM-bound pass over
+// tensors of at most a few 100 MB) into the BATCH-OCTET layout
+//   [B/8][H][W][C][8 images]   (16 bytes per (pixel, channel) slot)
+// so that the 8 k values of a lane are the 8 images of one octet at ONE pixel: a filter tap is then a pure
+// pixel offset of the X operand, every operand fragment is one conflict-free ds_read_b128, and the two lane
+// halves of the MFMA (k = 0-7 / 8-15) take two horizontally adjacent pixels.
+//
+// Workgroup = 8 waves (two per SIMD), tile 64 (ci) x 128 (co) of ALL 9 taps: wave (wm, wn) owns 32 ci x 32 co = 9
+// accumulator tiles (144 registers; 18 tiles per wave do not fit the 256 accumulator registers). One K chunk = one image octet x R output rows x 8 output columns: the (R-1)*SH+3 halo rows x 10 columns
+// of X and the R x 8 pixels of dZ move into LDS by LDS-DMA (buffer_load ... lds: a (pixel, 64 channels) run is
+// 1 KB contiguous in both HBM and LDS; padding = out-of-range offsets, which store zeros), double buffered.
+// Split-K partials go to a workspace and are summed in a fixed order (bitwise reproducible).
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int WB_P = 8;                 // output columns per chunk
+constexpr int WB_XC = WB_P + 2;         // halo columns
+constexpr int WB_TM = 64, WB_TN = 128;  // ci x co tile of a workgroup
+constexpr unsigned OOR = 0x80000000u;
+
+__device__ __forceinline__ i32x4 raw_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)base;
+    i32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    r[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)((a >> 32) & 0xffffu));
+    r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+    r[3] = 0x00020000;
+    return r;
+}
+
+// one wave instruction of LDS-DMA: lane l moves 16 B from rs[voff_l + soff] to LDS byte lds_addr + 16*l
+// (out-of-range lanes store zeros); see conv3x3_bf16.hip for why this is inline assembly
+__device__ __forceinline__ void dma16(i32x4 rs, unsigned lds_addr, unsigned voff, unsigned soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :
+                 : "s"(lds_addr), "v"(voff), "s"(rs), "s"(soff)
+                 : "memory");
+#endif
+}
+
+__device__ __forceinline__ unsigned lds_address(const void* p) {
+    return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)p;
+}
+
+struct WgradBfArgs {
+    const unsigned short* x;    // [B8][H][W][Cin][8]   bf16, batch-octet layout
+    const unsigned short* dz;   // [B8][Ho][Wo][Cout][8]
+    float* ws;                  // [splits][9][Cin][Cout]
+    int B8, H, W, Cin, Cout, Ho, Wo;
+    int circ;
+    int nseg;                   // column segments of WB_P per output row
+    int nrg;                    // row groups of R per image octet
+    int chunks;                 // B8 * nrg * nseg
+    int cps;                    // chunks per split
+};
+
+template <int SH, int R>
+__global__ __launch_bounds__(512) void conv3x3_wgrad_bf16_kernel(WgradBfArgs p) {
+    constexpr int NW = 8;
+    constexpr int XR = (R - 1) * SH + 3;              // halo rows
+    constexpr int NXI = XR * WB_XC;                   // X DMA instructions per stage (one per halo pixel: 64 ci slots)
+    constexpr int NZI = R * WB_P * 2;                 // dZ DMA instructions per stage (one per pixel and co half)
+    constexpr int X_S = NXI * 64;                     // 16-B slots
+    constexpr int Z_S = NZI * 64;
+    constexpr int STAGE_S = X_S + Z_S;
+    static_assert(2 * STAGE_S * 16 <= 160 * 1024, "two stages must fit the LDS");
+    __shared__ u32x4 stageA[STAGE_S];
+    __shared__ u32x4 stageB[STAGE_S];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6) & (NW - 1);
+    const int l31 = lane & 31, kg = lane >> 5;
+    const int wm = wave_u & 1, wn = wave_u >> 1;
+    const int ci0 = blockIdx.x * WB_TM, co0 = blockIdx.y * WB_TN, split = blockIdx.z;
+    const int c_begin = split * p.cps;
+    const int c_end = min(p.chunks, c_begin + p.cps);
+
+    const i32x4 x_rs = raw_rsrc(p.x, (unsigned)((size_t)p.B8 * p.H * p.W * p.Cin * 16u));
+    const i32x4 z_rs = raw_rsrc(p.dz, (unsigned)((size_t)p.B8 * p.Ho * p.Wo * p.Cout * 16u));
+    const unsigned x_lane = (ci0 + lane < p.Cin) ? (unsigned)lane * 16u : OOR;
+    unsigned z_lane[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) z_lane[h] = (co0 + h * 64 + lane < p.Cout) ? (unsigned)lane * 16u : OOR;
+
+    // chunk c -> stage s: this wave's share of the DMA instructions
+    auto stage = [&](int c, u32x4* s) {
+        const unsigned lds = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_address(s));
+        const int seg = c % p.nseg;
+        const int t = c / p.nseg;
+        const int rg = t % p.nrg, b8 = t / p.nrg;
+        const int h0 = rg * R, w0 = seg * WB_P;
+#pragma unroll
+        for (int i = 0; i < (NXI + NW - 1) / NW; ++i) {
+            const int j = wave_u + NW * i;
+            if (NXI % NW == 0 || j < NXI) {
+                const int r = j / WB_XC, cc = j - r * WB_XC;
+                const int gr = h0 * SH - 1 + r;
+                int gc = w0 - 1 + cc;
+                bool ok = gr >= 0 && gr < p.H;
+                if (p.circ) {               // only columns -1 and W wrap; columns past W pair with zero dZ pixels
+                    if (gc < 0) gc += p.W;
+                    else if (gc >= p.W) gc -= p.W;
+                }
+                ok = ok && gc >= 0 && gc < p.W;
+                const unsigned soff = ok ? (unsigned)(((((size_t)b8 * p.H + gr) * p.W + gc) * p.Cin + ci0) * 16u) : 0u;
+                dma16(x_rs, lds + (unsigned)j * 1024u, ok ? x_lane : OOR, soff);
+            }
+        }
+        static_assert(NZI % NW == 0, "dZ instructions split evenly over the waves");
+#pragma unroll
+        for (int i = 0; i < NZI / NW; ++i) {
+            const int j = wave_u + NW * i;
+            const int half = j & 1, pp = j >> 1;
+            const int rr = pp / WB_P, px = pp - rr * WB_P;
+            const int h = h0 + rr, w = w0 + px;
+            const bool ok = h < p.Ho && w < p.Wo;
+            const unsigned soff = ok ? (unsigned)(((((size_t)b8 * p.Ho + h) * p.Wo + w) * p.Cout + co0 + half * 64) * 16u) : 0u;
+            dma16(z_rs, lds + (unsigned)(X_S + j * 64) * 16u, ok ? z_lane[half] : OOR, soff);
+        }
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int abase = kg * 64 + wm * 32 + l31;               // X slot of (tile pixel 0 + kg, this lane's ci)
+    const int bbase = X_S + kg * 128 + wn * 32 + l31;        // dZ slot of (pixel 0 + kg, this lane's co)
+
+    // all MFMAs of one staged chunk: R rows x 4 pixel pairs (k-steps) x 9 taps; the fragments of k-step i+1 are
+    // read while the 9 MFMAs of k-step i run
+    constexpr int KS = R * WB_P / 2;
+    static_assert(KS % 2 == 0, "k-steps are processed in pairs");
+    u32x4 fa[2][9], fb[2];
+    auto read_frags = [&](int set, const u32x4* s, int ks) {
+        const int rr = ks / (WB_P / 2), kp = ks % (WB_P / 2);
+        const u32x4* ap = s + abase + (rr * SH * WB_XC + 2 * kp) * 64;
+        fb[set] = s[bbase + (rr * WB_P + 2 * kp) * 128];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) fa[set][t] = ap[((t / 3) * WB_XC + (t % 3)) * 64];
+    };
+    auto mfma_step = [&](int set) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[set][t]),
+                                                             __builtin_bit_cast(bf16x8, fb[set]), acc[t], 0, 0, 0);
+    };
+    auto compute = [&](const u32x4* s) {
+        read_frags(0, s, 0);
+#pragma unroll 1
+        for (int ks = 0; ks < KS; ks += 2) {
+            read_frags(1, s, ks + 1);
+            mfma_step(0);
+            if (ks + 2 < KS) read_frags(0, s, ks + 2);
+            mfma_step(1);
+        }
+    };
+
+    if (c_begin < c_end) {
+        stage(c_begin, stageA);
+        __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): this wave's DMA has landed
+        __syncthreads();
+        for (int c = c_begin; c < c_end; c += 2) {
+            if (c + 1 < c_end) stage(c + 1, stageB);
+            compute(stageA);
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            __syncthreads();
+            if (c + 1 < c_end) {
+                if (c + 2 < c_end) stage(c + 2, stageA);
+                compute(stageB);
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+                __syncthreads();
+            }
+        }
+    }
+
+    // ---- partial tile -> workspace [split][tap][ci][co]
+    float* out = p.ws + (size_t)split * 9 * p.Cin * p.Cout;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int co = co0 + wn * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ci = ci0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+            if (ci < p.Cin && co < p.Cout) out[((size_t)t * p.Cin + ci) * p.Cout + co] = acc[t][r];
+        }
+    }
+}
+
+// dW[co][ci][kh][kw] (+)= sum_split ws[split][tap][ci][co]; one thread per (tap, ci, co), co fastest.
+__global__ void wgrad_bf16_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Cin, int Cout, int splits,
+                                         int accumulate, int cin_real) {
+    const size_t n = (size_t)9 * Cin * Cout;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const int co = idx % Cout;
+    const size_t t = idx / Cout;
+    const int ci = t % Cin;
+    const int tap = (int)(t / Cin);
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += ws[(size_t)k * n + idx];
+    if (ci >= cin_real) return;
+    float* d = dw + ((size_t)co * cin_real + ci) * 9 + tap;
+    *d = accumulate ? (*d + s) : s;
+}
+
+// NHWC bf16 [B][HW][C] -> batch-octet [ceil(B/8)][HW][C][8] (images past B are zeros). One thread per
+// (octet, pixel, channel octet): 8 loads of 16 B (8 channels of one image), an 8x8 transpose in registers,
+// 8 stores of 16 B (one channel, 8 images) = 128 contiguous bytes.
+__global__ void nhwc_to_octet_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ y, int B, size_t HW, int C,
+                                     size_t total) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int C8 = C >> 3;
+    const int c8 = idx % C8;
+    const size_t t = idx / C8;
+    const size_t pix = t % HW;
+    const size_t b8 = t / HW;
+    u16x8 in[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const size_t b = b8 * 8 + i;
+        if (b < (size_t)B)
+            in[i] = *reinterpret_cast<const u16x8*>(x + ((b * HW + pix) * C + (size_t)c8 * 8));
+        else
+            in[i] = (u16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    }
+    u16x8* out = reinterpret_cast<u16x8*>(y + (((b8 * HW + pix) * C + (size_t)c8 * 8) * 8));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        u16x8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = in[i][j];
+        out[j] = o;
+    }
+}
+
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short v) { return __uint_as_float((unsigned)v << 16); }
+
+// db partials from bf16 NHWC dZ: thread -> (channel octet q, pixel phase); fixed-order combination through LDS.
+__global__ __launch_bounds__(256) void bias_grad_partial_bf16_kernel(const unsigned short* __restrict__ dz, float* __restrict__ part,
+                                                                      size_t npix, int Cout, int rows_per_block) {
+    __shared__ float sh[256][9];
+    const int Q = Cout >> 3;
+    const int phases = 256 / Q;
+    const int q = threadIdx.x % Q, ph = threadIdx.x / Q;
+    const size_t p0 = (size_t)blockIdx.x * rows_per_block;
+    const size_t p1 = min(npix, p0 + rows_per_block);
+    float s[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = 0.f;
+    if (ph < phases)
+        for (size_t px = p0 + ph; px < p1; px += phases) {
+            const u16x8 v = *reinterpret_cast<const u16x8*>(dz + px * Cout + 8 * q);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[e] += bf16_bits_to_f32(v[e]);
+        }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sh[threadIdx.x][e] = s[e];
+    __syncthreads();
+    if (threadIdx.x < Q) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float t = sh[threadIdx.x][e];
+            for (int k = 1; k < phases; ++k) t += sh[k * Q + threadIdx.x][e];
+            part[(size_t)blockIdx.x * Cout + 8 * threadIdx.x + e] = t;
+        }
+    }
+}
+
+__global__ void bias_grad_finish_bf16_kernel(const float* __restrict__ part, float* __restrict__ db, int Cout, int nparts,
+                                             int accumulate) {
+    const int co = blockIdx.x * blockDim.x + threadIdx.x;
+    if (co >= Cout) return;
+    float s = 0.f;
+    for (int k = 0; k < nparts; ++k) s += part[(size_t)k * Cout + co];
+    db[co] = accumulate ? db[co] + s : s;
+}
+
+int bias_rows(size_t npix) {
+    size_t r = (npix + 127) / 128;
+    if (r < 64) r = 64;
+    return (int)r;
+}
+
+int wgrad_bf16_rows(int stride_h) { return stride_h == 2 ? 1 : 2; }
+
+int wgrad_bf16_splits(int B8, int Ho, int Wo, int Cin, int Cout, int stride_h) {
+    const int tiles = cdiv(Cin, WB_TM) * cdiv(Cout, WB_TN);
+    const int chunks = B8 * cdiv(Ho, wgrad_bf16_rows(stride_h)) * cdiv(Wo, WB_P);
+    int splits = cdiv(512, tiles);            // ~2 rounds of 256 one-per-CU workgroups
+    if (splits > chunks) splits = chunks;
+    if (splits < 1) splits = 1;
+    return splits;
+}
+
+}  // namespace
+
+extern "C" {
+
+long long witw_octet_elems(int B, int H, int W, int C) { return (long long)cdiv(B, 8) * 8 * H * W * C; }
+
+// x NHWC bf16 [B,H,W,C] (C % 8 == 0) -> y batch-octet bf16 [ceil(B/8)][H][W][C][8]
+int witw_nhwc_bf16_to_octet(const void* x_bf16, void* y_bf16, int B, int H, int W, int C, void* stream) {
+    WITW_CHECK_ARG(x_bf16 && y_bf16, "nhwc_bf16_to_octet: null pointer");
+    WITW_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && (C % 8) == 0, "nhwc_bf16_to_octet: bad shape (C=%d must be a multiple of 8)", C);
+    const size_t total = (size_t)cdiv(B, 8) * H * W * (C / 8);
+    hipLaunchKernelGGL(nhwc_to_octet_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)x_bf16, (unsigned short*)y_bf16, B, (size_t)H * W, C, total);
+    WITW_CHECK_LAUNCH("nhwc_bf16_to_octet");
+    return WITW_OK;
+}
+
+long long witw_conv3x3_wgrad_bf16_workspace_floats(int B, int H, int W, int Cin, int Cout, int stride_h) {
+    const int Ho = (H + 2 - 3) / stride_h + 1;
+    const long long splits = wgrad_bf16_splits(cdiv(B, 8), Ho, W, Cin, Cout, stride_h);
+    const size_t npix = (size_t)B * Ho * W;
+    const long long bias_parts = (long long)((npix + bias_rows(npix) - 1) / bias_rows(npix));
+    return splits * 9 * Cin * Cout + bias_parts * Cout;
+}
+
+// x_oct [B8][H][W][Cin][8], dz_oct [B8][Ho][W][Cout][8] (batch-octet bf16, witw_nhwc_bf16_to_octet), dz_nhwc = the
+// same gradient as NHWC bf16 [B,Ho,W,Cout] (bias gradient; may be NULL when db is NULL).
+// dw [Cout][cin_real][3][3] fp32 (torch layout), db [Cout] fp32 or NULL. accumulate != 0 adds instead of overwriting.
+int witw_conv3x3_wgrad_bf16(const void* x_oct, const void* dz_oct, const void* dz_nhwc, float* dw, float* db, float* workspace,
+                            int B, int H, int W, int Cin, int cin_real, int Cout, int stride_h, int pad_circular, int accumulate,
+                            void* stream) {
+    WITW_CHECK_ARG(x_oct && dz_oct && dw && workspace, "conv3x3_wgrad_bf16: null pointer");
+    WITW_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv3x3_wgrad_bf16: bad shape");
+    WITW_CHECK_ARG((Cin % 8) == 0 && (Cout % 8) == 0, "conv3x3_wgrad_bf16: Cin=%d and Cout=%d must be multiples of 8", Cin, Cout);
+    WITW_CHECK_ARG(cin_real > 0 && cin_real <= Cin, "conv3x3_wgrad_bf16: cin_real=%d outside (0,%d]", cin_real, Cin);
+    WITW_CHECK_ARG(stride_h == 1 || stride_h == 2, "conv3x3_wgrad_bf16: stride_h=%d unsupported", stride_h);
+    WITW_CHECK_ARG(!db || dz_nhwc, "conv3x3_wgrad_bf16: the bias gradient needs dz_nhwc");
+    WITW_CHECK_ARG(!db || (256 % (Cout / 8)) == 0, "conv3x3_wgrad_bf16: bias gradient needs Cout/8 to divide 256 (Cout=%d)", Cout);
+    const int B8 = cdiv(B, 8);
+    const int Ho = (H + 2 - 3) / stride_h + 1;
+    WITW_CHECK_ARG((size_t)B8 * H * W * Cin * 16 < 0x80000000ull && (size_t)B8 * Ho * W * Cout * 16 < 0x80000000ull,
+                   "conv3x3_wgrad_bf16: operand too large for one buffer descriptor");
+    hipStream_t st = (hipStream_t)stream;
+    WgradBfArgs a;
+    a.x = (const unsigned short*)x_oct; a.dz = (const unsigned short*)dz_oct; a.ws = workspace;
+    a.B8 = B8; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.Ho = Ho; a.Wo = W;
+    a.circ = pad_circular;
+    const int R = wgrad_bf16_rows(stride_h);
+    a.nseg = cdiv(a.Wo, WB_P);
+    a.nrg = cdiv(Ho, R);
+    a.chunks = B8 * a.nrg * a.nseg;
+    const int splits = wgrad_bf16_splits(B8, Ho, a.Wo, Cin, Cout, stride_h);
+    a.cps = cdiv(a.chunks, splits);
+    const dim3 grid(cdiv(Cin, WB_TM), cdiv(Cout, WB_TN), splits);
+    if (stride_h == 2)
+        hipLaunchKernelGGL((conv3x3_wgrad_bf16_kernel<2, 1>), grid, dim3(512), 0, st, a);
+    else
+        hipLaunchKernelGGL((conv3x3_wgrad_bf16_kernel<1, 2>), grid, dim3(512), 0, st, a);
+    WITW_CHECK_LAUNCH("conv3x3_wgrad_bf16");
+    const size_t n = (size_t)9 * Cin * Cout;
+    hipLaunchKernelGGL(wgrad_bf16_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, workspace, dw, Cin, Cout,
+                       splits, accumulate, cin_real);
+    WITW_CHECK_LAUNCH("wgrad_bf16_reduce");
+    if (db != nullptr) {
+        float* part = workspace + (size_t)splits * n;
+        const size_t npix = (size_t)B * Ho * W;
+        const int rows = bias_rows(npix);
+        const int nparts = (int)((npix + rows - 1) / rows);
+        hipLaunchKernelGGL(bias_grad_partial_bf16_kernel, dim3(nparts), dim3(256), 0, st, (const unsigned short*)dz_nhwc, part, npix,
+                           Cout, rows);
+        hipLaunchKernelGGL(bias_grad_finish_bf16_kernel, dim3(cdiv(Cout, 256)), dim3(256), 0, st, part, db, Cout, nparts, accumulate);
+        WITW_CHECK_LAUNCH("bias_grad_bf16");
+    }
+    return WITW_OK;
+}
+
+}  // extern "C"

@@ -83,6 +83,10 @@ class FOV_DSM(torch.nn.Module):
     weights with load_state_dict. The unused VGG classifier of the reference is not kept.
     """
     in_channels = 3
+    # 'fp32' = the reference's arithmetic on the fp32 MFMA kernels (parity path). 'bf16' = mixed precision on the bf16
+    # MFMA kernels: bf16 activations / filters / activation gradients, fp32 accumulate, fp32 weight gradients, master
+    # weights and Adam (BASELINE config "bf16 MFMA"; not bit-comparable, see tests/test_bf16_train_gpu.py).
+    precision = 'fp32'
 
     def __init__(self, circ_padding=False, weights=None, seed=0):
         super().__init__()
@@ -187,6 +191,38 @@ class FOV_DSM(torch.nn.Module):
             self._packed[('bf16', idx)] = hit
         return hit[1]
 
+    def _pack_t_bf16(self, idx):
+        """bf16 dgrad filter (transpose + 180-degree tap rotation) of layer idx."""
+        conv = _conv_of(self.model.features[idx])
+        key = (conv.weight.data_ptr(), conv.weight._version, getattr(conv.weight, '_witw_version', 0))
+        hit = self._packed.get(('t_bf16', idx))
+        if hit is None or hit[0] != key:
+            hit = (key, ops.PackedConvBf16(conv.weight, None, transpose_flip=True))
+            self._packed[('t_bf16', idx)] = hit
+        return hit[1]
+
+    def _run_bf16(self, x, scales, keep_from=None):
+        """The layer stack on the bf16 MFMA kernels (bf16 NHWC activations, fp32 accumulate, fp32 NCHW embedding).
+        Returns (embedding, kept) with kept[idx] = (layer input, layer output) bf16 NHWC for idx >= keep_from."""
+        fast0 = self.in_channels <= 4 and (keep_from is None or keep_from > 0)
+        h = x.contiguous() if fast0 else ops.nchw_to_nhwc_bf16(x.contiguous(), 16)
+        last = self.layer_specs[-1][0]
+        kept = {}
+        for (idx, sh, relu, pool, drop) in self.layer_specs:
+            if idx == 0 and fast0:
+                h = ops.conv3x3_first_fwd(h, self._pack_first(True), circular=self.circ_padding, relu=relu)
+                continue
+            keep = keep_from is not None and idx >= keep_from
+            if keep and pool:
+                raise _lib.WitwError('bf16 training through a fused max-pool (layer %d) is not implemented: '
+                                     'train this encoder with precision="fp32"' % idx)
+            y = ops.conv3x3_bf16_fwd(h, self._pack_bf16(idx), stride_h=sh, circular=self.circ_padding, relu=relu, pool=pool,
+                                     out_nchw_f32=(idx == last), drop_scale=scales.get(idx))
+            if keep:
+                kept[idx] = (h, y)
+            h = y
+        return h, kept
+
     def forward_bf16(self, x):
         """Inference on the bf16 MFMA kernels (bf16 activations and filters, fp32 accumulate, fp32 embedding
         out): the 'bf16 MFMA' configuration of BASELINE.json. Not bit-comparable with the fp32 path — see
@@ -224,7 +260,10 @@ class FOV_DSM(torch.nn.Module):
             params = []
             for _i, c in tr:
                 params += [c.weight, c.bias]
-            return _EncoderFn.apply(x, self, scales, *params)
+            fn = _EncoderFnBf16 if self.precision == 'bf16' else _EncoderFn
+            return fn.apply(x, self, scales, *params)
+        if self.precision == 'bf16':
+            return self._run_bf16(x, scales)[0]
         return self._run(x, scales)[0]
 
 
@@ -264,6 +303,50 @@ class _EncoderFn(torch.autograd.Function):
                                      drop_scale=scales.get(pidx), gate=p_out, dilate_h=(sh == 2),
                                      out_h=x_in.shape[1] if sh == 2 else None)
                 dz = ops.maxpool2x2_bwd(dy, p_code, (p_in.shape[1], p_in.shape[2])) if ppool else dy
+        ctx.kept = None
+        flat = []
+        for (idx, _c) in enc.trainable_convs():
+            flat += [grads[idx][0], grads[idx][1]]
+        return (None, None, None) + tuple(flat)
+
+
+class _EncoderFnBf16(torch.autograd.Function):
+    """_EncoderFn on the bf16 MFMA kernels (FOV_DSM.precision = 'bf16'): mixed-precision training step with bf16
+    activations / filters / activation gradients, fp32 accumulation, fp32 weight gradients (the fp32 master weights and
+    Adam are untouched). Per trainable layer one witw_conv3x3_wgrad_bf16 (operands re-laid out to the batch-octet
+    layout), per layer one dgrad launch = the bf16 forward kernel on the transposed, tap-rotated filter with the
+    ReLU / Dropout2d gate in its epilogue. No reference counterpart (the reference trains in fp32 only): parity is
+    stated against the fp32 HIP path in tests/test_bf16_train_gpu.py."""
+
+    @staticmethod
+    def forward(ctx, x, enc, scales, *params):
+        first = min(i for i, _c in enc.trainable_convs())
+        out, kept = enc._run_bf16(x, scales, keep_from=first)
+        ctx.enc, ctx.scales, ctx.kept, ctx.first = enc, scales, kept, first
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        enc, scales, kept = ctx.enc, ctx.scales, ctx.kept
+        specs = [sp for sp in enc.layer_specs if sp[0] >= ctx.first]
+        circ = enc.circ_padding
+        last = specs[-1][0]
+        cout_last = _conv_of(enc.model.features[last]).out_channels
+        dz = ops.nchw_to_nhwc_bf16(grad_out.contiguous(), (cout_last + 15) // 16 * 16)   # layer 27 has no ReLU
+        grads = {}
+        for n in range(len(specs) - 1, -1, -1):
+            idx, sh, relu, pool, drop = specs[n]
+            x_in = kept[idx][0]
+            conv = _conv_of(enc.model.features[idx])
+            if conv.weight.requires_grad:
+                dw, db = ops.conv3x3_wgrad_bf16(x_in, dz, conv.in_channels, stride_h=sh, circular=circ)
+                grads[idx] = (dw[:conv.out_channels].contiguous(), db[:conv.out_channels].contiguous())
+            if n > 0:   # gradient at the previous layer's conv output
+                pidx = specs[n - 1][0]
+                p_out = kept[pidx][1]
+                dz = ops.conv3x3_bf16_fwd(dz, enc._pack_t_bf16(idx), stride_h=1, circular=circ, relu=False, pool=False,
+                                          drop_scale=scales.get(pidx), gate=p_out, dilate_h=(sh == 2),
+                                          out_h=x_in.shape[1] if sh == 2 else None)
         ctx.kept = None
         flat = []
         for (idx, _c) in enc.trainable_convs():

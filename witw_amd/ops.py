@@ -544,9 +544,11 @@ def exhaustive_triplet_loss(D, soft_margin=False, alpha=10., margin=1.):
 class PackedConvBf16:
     """bf16 filter packing of one 3x3 conv for the bf16 MFMA kernel + fp32 bias padded to the channel tile."""
 
-    def __init__(self, weight, bias):
+    def __init__(self, weight, bias, transpose_flip=False):
         lib = _lib.load()
         w = _dev_f32(weight.detach(), 'weight')
+        if transpose_flip:      # dgrad filter: w_t[ci][co][kh][kw] = w[co][ci][2-kh][2-kw]
+            w = w.transpose(0, 1).flip(2, 3).contiguous()
         self.cout, self.cin = w.shape[0], w.shape[1]
         self.cin_pad = (self.cin + 15) // 16 * 16
         self.wpk = torch.empty(lib.witw_conv3x3_bf16_packed_elems(self.cout, self.cin), dtype=torch.bfloat16, device=w.device)
@@ -567,13 +569,21 @@ def nchw_to_nhwc_bf16(x, cpad=16):
     return y
 
 
-def conv3x3_bf16_fwd(x_nhwc, packed, stride_h=1, circular=False, relu=True, pool=False, out_nchw_f32=False):
+def conv3x3_bf16_fwd(x_nhwc, packed, stride_h=1, circular=False, relu=True, pool=False, out_nchw_f32=False, drop_scale=None,
+                     gate=None, dilate_h=False, out_h=None):
+    """x NHWC bf16 [B,H,W,Cin_pad] -> NHWC bf16 [B,Hy,Wy,Cout] (or the fp32 NCHW embedding). Training extras as in
+    conv3x3_fwd: drop_scale [B,Cout] fp32, gate = bf16 tensor shaped like the output (dgrad launches), dilate_h/out_h
+    = zero-interleaved input rows (dgrad of a stride-(2,1) layer)."""
     lib = _lib.load()
     if not (x_nhwc.is_cuda and x_nhwc.dtype == torch.bfloat16 and x_nhwc.is_contiguous()):
         raise _lib.WitwError('conv3x3_bf16_fwd: x must be a contiguous bfloat16 GPU tensor')
     B, H, W, C = x_nhwc.shape
     if C != packed.cin_pad:
         raise _lib.WitwError('conv3x3_bf16_fwd: input has %d channels, packed weights expect %d' % (C, packed.cin_pad))
+    if dilate_h:
+        if out_h is None or (out_h - 1) // 2 + 1 != H:
+            raise _lib.WitwError('conv3x3_bf16_fwd: dilate_h needs out_h with (out_h-1)//2+1 == %d physical rows' % H)
+        H = out_h          # logical (zero-interleaved) height
     Ho = (H + 2 - 3) // stride_h + 1
     Hy, Wy = (Ho // 2, W // 2) if pool else (Ho, W)
     if out_nchw_f32:
@@ -582,18 +592,70 @@ def conv3x3_bf16_fwd(x_nhwc, packed, stride_h=1, circular=False, relu=True, pool
         if packed.cout % 16:
             raise _lib.WitwError('conv3x3_bf16_fwd: a bf16 NHWC output needs Cout %% 16 == 0 (next layer\'s K chunk)')
         y = torch.empty((B, Hy, Wy, packed.cout), dtype=torch.bfloat16, device=x_nhwc.device)
+    if drop_scale is not None:
+        drop_scale = _dev_f32(drop_scale, 'drop_scale')
+        if tuple(drop_scale.shape) != (B, packed.cout):
+            raise _lib.WitwError('drop_scale must be [B,Cout]')
+    if gate is not None:
+        if not (gate.is_cuda and gate.dtype == torch.bfloat16 and gate.is_contiguous() and tuple(gate.shape) == tuple(y.shape)):
+            raise _lib.WitwError('gate must be a contiguous bfloat16 GPU tensor with the output shape %s' % (tuple(y.shape),))
     prof = PROFILE
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _lib.check(lib.witw_conv3x3_bf16_fwd(x_nhwc.data_ptr(), packed.wpk.data_ptr(), packed.bias.data_ptr(), y.data_ptr(), B, H,
-                                         W, C, packed.cout, stride_h, int(circular), int(relu), int(pool), int(out_nchw_f32),
-                                         _stream()), 'witw_conv3x3_bf16_fwd')
+    _lib.check(lib.witw_conv3x3_bf16_fwd_ex(x_nhwc.data_ptr(), packed.wpk.data_ptr(), packed.bias.data_ptr(), _p(drop_scale),
+                                            _p(gate), y.data_ptr(), B, H, W, C, packed.cout, stride_h, int(circular), int(relu),
+                                            int(pool), int(out_nchw_f32), int(bool(dilate_h)), _stream()),
+               'witw_conv3x3_bf16_fwd_ex')
     if prof is not None:
         e1.record()
         prof.append((('bf16', lib.witw_conv3x3_tile_n(packed.cout), stride_h, bool(pool)),
                      2.0 * packed.cin * packed.cout * 9 * Ho * W * B, e0, e1))
     return y
+
+
+def nhwc_bf16_to_octet(x):
+    """NHWC bf16 [B,H,W,C] -> batch-octet [ceil(B/8),H,W,C,8] (the operand layout of conv3x3_wgrad_bf16)."""
+    lib = _lib.load()
+    if not (x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous() and x.dim() == 4):
+        raise _lib.WitwError('nhwc_bf16_to_octet: x must be a contiguous bfloat16 NHWC GPU tensor')
+    B, H, W, C = x.shape
+    y = torch.empty(((B + 7) // 8, H, W, C, 8), dtype=torch.bfloat16, device=x.device)
+    _lib.check(lib.witw_nhwc_bf16_to_octet(x.data_ptr(), y.data_ptr(), B, H, W, C, _stream()), 'witw_nhwc_bf16_to_octet')
+    return y
+
+
+def conv3x3_wgrad_bf16(x_nhwc, dz_nhwc, cin_real, stride_h=1, circular=False, want_bias=True, x_oct=None):
+    """bf16 MFMA weight gradient of one conv layer: x_nhwc [B,H,W,Cin] (its input), dz_nhwc [B,Ho,W,Cout] (gradient at
+    its output), both bf16 NHWC -> (dW [Cout,cin_real,3,3] fp32, db [Cout] fp32 or None)."""
+    lib = _lib.load()
+    for t, n in ((x_nhwc, 'x'), (dz_nhwc, 'dz')):
+        if not (t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous()):
+            raise _lib.WitwError('conv3x3_wgrad_bf16: %s must be a contiguous bfloat16 GPU tensor' % n)
+    B, H, W, Cin = x_nhwc.shape
+    Ho = (H + 2 - 3) // stride_h + 1
+    Cout = dz_nhwc.shape[3]
+    if tuple(dz_nhwc.shape[:3]) != (B, Ho, W):
+        raise _lib.WitwError('conv3x3_wgrad_bf16: dz %s does not match x %s (stride %d)' % (tuple(dz_nhwc.shape),
+                                                                                          tuple(x_nhwc.shape), stride_h))
+    prof = PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    if x_oct is None:
+        x_oct = nhwc_bf16_to_octet(x_nhwc)
+    dz_oct = nhwc_bf16_to_octet(dz_nhwc)
+    dw = torch.empty((Cout, cin_real, 3, 3), dtype=torch.float32, device=x_nhwc.device)
+    db = torch.empty((Cout,), dtype=torch.float32, device=x_nhwc.device) if want_bias else None
+    ws = torch.empty(lib.witw_conv3x3_wgrad_bf16_workspace_floats(B, H, W, Cin, Cout, stride_h), dtype=torch.float32,
+                     device=x_nhwc.device)
+    _lib.check(lib.witw_conv3x3_wgrad_bf16(x_oct.data_ptr(), dz_oct.data_ptr(), dz_nhwc.data_ptr(), dw.data_ptr(), _p(db),
+                                           ws.data_ptr(), B, H, W, Cin, cin_real, Cout, stride_h, int(circular), 0, _stream()),
+               'witw_conv3x3_wgrad_bf16')
+    if prof is not None:
+        e1.record()
+        prof.append((('wgrad_bf16', stride_h), 2.0 * cin_real * Cout * 9 * Ho * W * B, e0, e1))
+    return dw, db
 
 
 def bn_train_stats(a, valid_hw, gamma, beta, running_mean=None, running_var=None, eps=1e-5, momentum=0.1):
