@@ -116,8 +116,6 @@ def main():
     train = a.mode == 'train'
     bf16 = a.precision == 'bf16'
     if bf16 and train:
-        if semantic:
-            sys.exit('bf16 training of cvig_semantic (backward through the fused max-pools) is not implemented')
         surface_encoder.precision = overhead_encoder.precision = 'bf16'     # mixed-precision step, fp32 master weights
     surface_encoder.train(train)
     overhead_encoder.train(train)

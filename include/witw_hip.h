@@ -144,21 +144,24 @@ int witw_conv3x3_bf16_fwd(const void* x_bf16, const void* wpk_bf16, const float*
  * witw_conv3x3_bf16_fwd_ex = witw_conv3x3_bf16_fwd plus: dropmask [B,Cout] fp32 (Dropout2d scale before the ReLU,
  * :287-288) or NULL; gate_bf16 = bf16 tensor shaped like y or NULL (outputs where gate <= 0 are zeroed: the ReLU
  * backward of a dgrad launch, which is this kernel on witw_conv3x3_bf16_pack_weights of the transposed, tap-rotated
- * filter); dilate_h = x holds (H-1)/2+1 physical rows standing for H zero-interleaved rows (dgrad of a stride-(2,1) layer). */
+ * filter); dilate_h = x holds (H-1)/2+1 physical rows standing for H zero-interleaved rows (dgrad of a stride-(2,1) layer);
+ * pool_code = NULL or uint8 [B,Hy,Wy,Cout]: arg-max position (dy*2+dx) of the fused max-pool, consumed by
+ * witw_maxpool2x2_bwd_bf16 (dy bf16 [B,Hp,Wp,C] -> dx bf16 [B,H,W,C]). */
 int witw_conv3x3_bf16_fwd_ex(const void* x_bf16, const void* wpk_bf16, const float* bias, const float* dropmask,
-                             const void* gate_bf16, void* y, int B, int H, int W, int Cin, int Cout, int stride_h,
-                             int pad_circular, int relu, int pool, int out_nchw_f32, int dilate_h, void* stream);
+                             const void* gate_bf16, void* y, unsigned char* pool_code, int B, int H, int W, int Cin, int Cout,
+                             int stride_h, int pad_circular, int relu, int pool, int out_nchw_f32, int dilate_h, void* stream);
+int witw_maxpool2x2_bwd_bf16(const void* dy_bf16, const unsigned char* code, void* dx_bf16, int B, int Hp, int Wp, int H, int W,
+                             int C, void* stream);
 /* Weight gradient on v_mfma_f32_32x32x16_bf16. Both operands in the batch-octet layout [ceil(B/8)][H][W][C][8 images]
  * (witw_nhwc_bf16_to_octet; witw_octet_elems = its element count): the 8 k values of an MFMA lane are 8 images at one
  * pixel, so a filter tap is a pixel offset and no transposition is needed. x_oct = the layer's input, dz_oct = the
- * gradient at its output, dz_nhwc = that gradient as NHWC bf16 (bias gradient; NULL with db NULL);
- * dw [Cout][cin_real][3][3] fp32, db [Cout] fp32 or NULL; workspace of witw_conv3x3_wgrad_bf16_workspace_floats floats. */
+ * gradient at its output; dw [Cout][cin_real][3][3] fp32, db [Cout] fp32 or NULL (summed inside the same kernel);
+ * workspace of witw_conv3x3_wgrad_bf16_workspace_floats floats. */
 long long witw_octet_elems(int B, int H, int W, int C);
 int witw_nhwc_bf16_to_octet(const void* x_bf16, void* y_bf16, int B, int H, int W, int C, void* stream);
 long long witw_conv3x3_wgrad_bf16_workspace_floats(int B, int H, int W, int Cin, int Cout, int stride_h);
-int witw_conv3x3_wgrad_bf16(const void* x_oct, const void* dz_oct, const void* dz_nhwc, float* dw, float* db, float* workspace,
-                            int B, int H, int W, int Cin, int cin_real, int Cout, int stride_h, int pad_circular, int accumulate,
-                            void* stream);
+int witw_conv3x3_wgrad_bf16(const void* x_oct, const void* dz_oct, float* dw, float* db, float* workspace, int B, int H, int W,
+                            int Cin, int cin_real, int Cout, int stride_h, int pad_circular, int accumulate, void* stream);
 
 /* ---- cvig_baseline (model/cvig_baseline.py). Conv2d(k=4,s=2,p=0) = the 3x3 kernel above on the
  * space-to-depth(2) image with a filter whose first tap row/column is zero. */

@@ -164,11 +164,64 @@ def test_bf16_training_reduces_the_loss():
     assert all(p.dtype == torch.float32 for p in se.parameters())
 
 
-def test_bf16_training_through_a_pool_is_refused():
-    from witw_amd import cvig_semantic, _lib
+def test_pool_codes_and_maxpool_backward_bf16():
+    """The fused max-pool of the bf16 kernel records torch's arg-max (first maximum in scan order) and
+    witw_maxpool2x2_bwd_bf16 routes the gradient there."""
+    from witw_amd import ops
+    B, H, W, Cin, Cout = 2, 8, 64, 16, 64
+    x = _rand_bf16(11, (B, Cin, H, W))
+    w = _rand_bf16(12, (Cout, Cin, 3, 3), 0.1)
+    b = _rand_bf16(13, (Cout,), 0.1)
+    pre = torch.relu(O.conv3x3(x, w, b, 1, True)).requires_grad_(True)
+    pooled = torch.nn.functional.max_pool2d(pre, 2, 2)
+    gy = _rand_bf16(14, tuple(pooled.shape))
+    pooled.backward(gy)
     dev = torch.device('cuda:0')
-    enc = cvig_semantic.FOV_DSM(True, weights=synth.fov_dsm_weights(3, in_channels=5)).to(dev).train()
-    enc.precision = 'bf16'
-    x = torch.from_numpy(synth.normalized_images(3, 1, (1, 5, 128, 512))).to(dev)
-    with pytest.raises(_lib.WitwError):
-        enc(x)
+    pk = ops.PackedConvBf16(w.to(dev), b.to(dev))
+    y, code = ops.conv3x3_bf16_fwd(_nhwc_bf16(x, dev), pk, circular=True, relu=True, pool=True, want_pool_code=True)
+    assert code.dtype == torch.uint8 and code.shape == y.shape == (B, H // 2, W // 2, Cout)
+    dx = ops.maxpool2x2_bwd_bf16(_nhwc_bf16(gy, dev), code, (H, W))
+    got = dx.float().cpu().permute(0, 3, 1, 2)
+    # where the four pre-activations are distinct the routing must equal torch's; exact ties (all four clipped to 0
+    # by the ReLU) may differ in position but carry the same gradient, so compare the 2x2 block sums too
+    blk = lambda t: torch.nn.functional.avg_pool2d(t, 2, 2) * 4
+    np.testing.assert_array_equal(blk(got).numpy(), blk(pre.grad).numpy())
+    distinct = (torch.nn.functional.max_pool2d(pre.detach(), 2, 2) > 0)
+    mask = distinct.repeat_interleave(2, 2).repeat_interleave(2, 3)
+    np.testing.assert_array_equal((got * mask).numpy(), (pre.grad * mask).numpy())
+
+
+def test_semantic_bf16_training_step_vs_fp32_path():
+    """cvig_semantic (layer 0 trainable): the bf16 backward walks all 13 layers (dgrad through the frozen VGG filters,
+    arg-max scatter behind the three fused max-pools, layer-0 wgrad with 5 of 16 padded input channels)."""
+    from witw_amd import cvig_fov, cvig_semantic
+    dev = torch.device('cuda:0')
+    B, seed = 8, 41
+    w = synth.fov_dsm_weights(seed, in_channels=5)
+    xo = torch.from_numpy(synth.normalized_images(seed, 1, (B, 5, 128, 512))).to(dev)
+    xs = (xo + 0.3 * torch.from_numpy(synth.normalized_images(seed, 2, (B, 5, 128, 512))).to(dev)).contiguous()
+    drops = {t: {i: torch.from_numpy(synth.dropout_scales(seed, 10 * k + i, B, 512)).to(dev) for i in (17, 19, 21)}
+             for k, t in enumerate('so')}
+    out = {}
+    for prec in ('fp32', 'bf16'):
+        se = cvig_semantic.FOV_DSM(False, weights=w).to(dev).train()
+        oe = cvig_semantic.FOV_DSM(True, weights=w).to(dev).train()
+        se.precision = oe.precision = prec
+        ori, dist = cvig_fov.match(oe(xo, dropout_scales=drops['o']), se(xs, dropout_scales=drops['s']))
+        loss = cvig_fov.triplet_loss(dist)
+        loss.backward()
+        grads = {('s.' + n): p.grad for n, p in se.named_parameters() if p.grad is not None}
+        grads.update({('o.' + n): p.grad for n, p in oe.named_parameters() if p.grad is not None})
+        out[prec] = (loss.item(), grads)
+    (l32, g32), (l16, g16) = out['fp32'], out['bf16']
+    assert abs(l16 - l32) <= 2e-2 * abs(l32), (l16, l32)
+    assert set(g16) == set(g32) and len(g16) == 28           # 7 trainable convs x (weight, bias) x 2 encoders
+    worst = ('', 0.0)
+    for name, g in g32.items():
+        assert g16[name].shape == g.shape
+        rel = float((g16[name] - g).norm() / (g.norm() + 1e-30))
+        if rel > worst[1]:
+            worst = (name, rel)
+        # layer 0 sits behind 12 bf16-rounded layers and three arg-max routings (near-ties route differently)
+        assert rel < (0.3 if 'features.0.' in name else 8e-2), (name, rel)
+    print('semantic bf16 vs fp32 step: loss %.6f vs %.6f, worst gradient deviation %.3e (%s)' % (l16, l32, worst[1], worst[0]))

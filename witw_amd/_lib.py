@@ -37,11 +37,12 @@ SIGNATURES = {
     'witw_conv3x3_bf16_pack_weights': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     'witw_nchw_f32_to_nhwc_bf16': (c_int, [c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]),
     'witw_conv3x3_bf16_fwd': (c_int, [c_void_p] * 4 + [c_int] * 10 + [c_void_p]),
-    'witw_conv3x3_bf16_fwd_ex': (c_int, [c_void_p] * 6 + [c_int] * 11 + [c_void_p]),
+    'witw_conv3x3_bf16_fwd_ex': (c_int, [c_void_p] * 7 + [c_int] * 11 + [c_void_p]),
+    'witw_maxpool2x2_bwd_bf16': (c_int, [c_void_p] * 3 + [c_int] * 6 + [c_void_p]),
     'witw_octet_elems': (c_longlong, [c_int] * 4),
     'witw_nhwc_bf16_to_octet': (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
     'witw_conv3x3_wgrad_bf16_workspace_floats': (c_longlong, [c_int] * 6),
-    'witw_conv3x3_wgrad_bf16': (c_int, [c_void_p] * 6 + [c_int] * 9 + [c_void_p]),
+    'witw_conv3x3_wgrad_bf16': (c_int, [c_void_p] * 5 + [c_int] * 9 + [c_void_p]),
     'witw_space_to_depth2': (c_int, [c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p, c_void_p]),
     'witw_gem_pool': (c_int, [c_void_p, c_void_p] + [c_int] * 8 + [c_float, c_void_p, c_void_p, c_void_p]),
     'witw_bn_workspace_floats': (c_longlong, [c_int] * 4),

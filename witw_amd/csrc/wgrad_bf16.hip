@@ -18,6 +18,9 @@
 // of X and the R x 8 pixels of dZ move into LDS by LDS-DMA (buffer_load ... lds: a (pixel, 64 channels) run is
 // 1 KB contiguous in both HBM and LDS; padding = out-of-range offsets, which store zeros), double buffered.
 // Split-K partials go to a workspace and are summed in a fixed order (bitwise reproducible).
+// The bias gradient db[co] = sum dZ rides along: the waves of the first ci tile that own ci rows 0-31 feed the dZ
+// fragment they hold anyway to two v_mfma_f32_16x16x32_bf16 against a constant 'ones in row 0' operand (+1/9 MFMA
+// time on 1/(Cin/64) of the workgroups) instead of a separate pass over dZ.
 #include "common.h"
 
 namespace {
@@ -61,6 +64,7 @@ struct WgradBfArgs {
     const unsigned short* x;    // [B8][H][W][Cin][8]   bf16, batch-octet layout
     const unsigned short* dz;   // [B8][Ho][Wo][Cout][8]
     float* ws;                  // [splits][9][Cin][Cout]
+    float* bias_part;           // nullptr, or [splits][Cout] partial bias gradients
     int B8, H, W, Cin, Cout, Ho, Wo;
     int circ;
     int nseg;                   // column segments of WB_P per output row
@@ -148,6 +152,17 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_bf16_kernel(WgradBfArgs p) 
     constexpr int KS = R * WB_P / 2;
     static_assert(KS % 2 == 0, "k-steps are processed in pairs");
     u32x4 fa[2][9], fb[2];
+    // bias gradient: the dZ fragment (lane l: co = l & 31, pixel = l >> 5, 8 images) read as the B operand of the
+    // 16x16x32 shape has k groups (l >> 4) = {co 0-15 px0, co 16-31 px0, co 0-15 px1, co 16-31 px1}; ones in row 0 of
+    // A on groups {0,2} / {1,3} sum the images and both pixels of co 0-15 / 16-31 into row 0 of the result
+    const bool do_bias = p.bias_part != nullptr && blockIdx.x == 0 && wm == 0;     // wave-uniform
+    f32x4 accb[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    u32x4 ones[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const unsigned v = ((lane & 15) == 0 && ((lane >> 4) & 1) == h) ? 0x3F803F80u : 0u;
+        ones[h] = (u32x4){v, v, v, v};
+    }
     auto read_frags = [&](int set, const u32x4* s, int ks) {
         const int rr = ks / (WB_P / 2), kp = ks % (WB_P / 2);
         const u32x4* ap = s + abase + (rr * SH * WB_XC + 2 * kp) * 64;
@@ -160,6 +175,12 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_bf16_kernel(WgradBfArgs p) 
         for (int t = 0; t < 9; ++t)
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[set][t]),
                                                              __builtin_bit_cast(bf16x8, fb[set]), acc[t], 0, 0, 0);
+        if (do_bias) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                accb[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ones[h]),
+                                                                  __builtin_bit_cast(bf16x8, fb[set]), accb[h], 0, 0, 0);
+        }
     };
     auto compute = [&](const u32x4* s) {
         read_frags(0, s, 0);
@@ -201,14 +222,31 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_bf16_kernel(WgradBfArgs p) 
             if (ci < p.Cin && co < p.Cout) out[((size_t)t * p.Cin + ci) * p.Cout + co] = acc[t][r];
         }
     }
+    if (do_bias && lane < 16) {          // row 0 of the 16x16 results: lanes 0-15, register 0
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int co = co0 + wn * 32 + h * 16 + lane;
+            if (co < p.Cout) p.bias_part[(size_t)split * p.Cout + co] = accb[h][0];
+        }
+    }
 }
 
 // dW[co][ci][kh][kw] (+)= sum_split ws[split][tap][ci][co]; one thread per (tap, ci, co), co fastest.
+// Threads past the weight elements sum the bias partials: db[co] (+)= sum_split bias_part[split][co].
 __global__ void wgrad_bf16_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Cin, int Cout, int splits,
-                                         int accumulate, int cin_real) {
+                                         int accumulate, int cin_real, const float* __restrict__ bias_part,
+                                         float* __restrict__ db) {
     const size_t n = (size_t)9 * Cin * Cout;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n) return;
+    if (idx >= n) {
+        const size_t co = idx - n;
+        if (db != nullptr && co < (size_t)Cout) {
+            float s = 0.f;
+            for (int k = 0; k < splits; ++k) s += bias_part[(size_t)k * Cout + co];
+            db[co] = accumulate ? db[co] + s : s;
+        }
+        return;
+    }
     const int co = idx % Cout;
     const size_t t = idx / Cout;
     const int ci = t % Cin;
@@ -251,60 +289,12 @@ __global__ void nhwc_to_octet_kernel(const unsigned short* __restrict__ x, unsig
     }
 }
 
-__device__ __forceinline__ float bf16_bits_to_f32(unsigned short v) { return __uint_as_float((unsigned)v << 16); }
-
-// db partials from bf16 NHWC dZ: thread -> (channel octet q, pixel phase); fixed-order combination through LDS.
-__global__ __launch_bounds__(256) void bias_grad_partial_bf16_kernel(const unsigned short* __restrict__ dz, float* __restrict__ part,
-                                                                      size_t npix, int Cout, int rows_per_block) {
-    __shared__ float sh[256][9];
-    const int Q = Cout >> 3;
-    const int phases = 256 / Q;
-    const int q = threadIdx.x % Q, ph = threadIdx.x / Q;
-    const size_t p0 = (size_t)blockIdx.x * rows_per_block;
-    const size_t p1 = min(npix, p0 + rows_per_block);
-    float s[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) s[e] = 0.f;
-    if (ph < phases)
-        for (size_t px = p0 + ph; px < p1; px += phases) {
-            const u16x8 v = *reinterpret_cast<const u16x8*>(dz + px * Cout + 8 * q);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) s[e] += bf16_bits_to_f32(v[e]);
-        }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) sh[threadIdx.x][e] = s[e];
-    __syncthreads();
-    if (threadIdx.x < Q) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float t = sh[threadIdx.x][e];
-            for (int k = 1; k < phases; ++k) t += sh[k * Q + threadIdx.x][e];
-            part[(size_t)blockIdx.x * Cout + 8 * threadIdx.x + e] = t;
-        }
-    }
-}
-
-__global__ void bias_grad_finish_bf16_kernel(const float* __restrict__ part, float* __restrict__ db, int Cout, int nparts,
-                                             int accumulate) {
-    const int co = blockIdx.x * blockDim.x + threadIdx.x;
-    if (co >= Cout) return;
-    float s = 0.f;
-    for (int k = 0; k < nparts; ++k) s += part[(size_t)k * Cout + co];
-    db[co] = accumulate ? db[co] + s : s;
-}
-
-int bias_rows(size_t npix) {
-    size_t r = (npix + 127) / 128;
-    if (r < 64) r = 64;
-    return (int)r;
-}
-
 int wgrad_bf16_rows(int stride_h) { return stride_h == 2 ? 1 : 2; }
 
 int wgrad_bf16_splits(int B8, int Ho, int Wo, int Cin, int Cout, int stride_h) {
     const int tiles = cdiv(Cin, WB_TM) * cdiv(Cout, WB_TN);
     const int chunks = B8 * cdiv(Ho, wgrad_bf16_rows(stride_h)) * cdiv(Wo, WB_P);
-    int splits = cdiv(512, tiles);            // ~2 rounds of 256 one-per-CU workgroups
+    int splits = cdiv(256, tiles);            // one workgroup per CU; every extra split costs a 36*Cin*Cout-byte partial
     if (splits > chunks) splits = chunks;
     if (splits < 1) splits = 1;
     return splits;
@@ -330,24 +320,18 @@ int witw_nhwc_bf16_to_octet(const void* x_bf16, void* y_bf16, int B, int H, int 
 long long witw_conv3x3_wgrad_bf16_workspace_floats(int B, int H, int W, int Cin, int Cout, int stride_h) {
     const int Ho = (H + 2 - 3) / stride_h + 1;
     const long long splits = wgrad_bf16_splits(cdiv(B, 8), Ho, W, Cin, Cout, stride_h);
-    const size_t npix = (size_t)B * Ho * W;
-    const long long bias_parts = (long long)((npix + bias_rows(npix) - 1) / bias_rows(npix));
-    return splits * 9 * Cin * Cout + bias_parts * Cout;
+    return splits * 9 * Cin * Cout + splits * Cout;
 }
 
-// x_oct [B8][H][W][Cin][8], dz_oct [B8][Ho][W][Cout][8] (batch-octet bf16, witw_nhwc_bf16_to_octet), dz_nhwc = the
-// same gradient as NHWC bf16 [B,Ho,W,Cout] (bias gradient; may be NULL when db is NULL).
+// x_oct [B8][H][W][Cin][8], dz_oct [B8][Ho][W][Cout][8] (batch-octet bf16, witw_nhwc_bf16_to_octet).
 // dw [Cout][cin_real][3][3] fp32 (torch layout), db [Cout] fp32 or NULL. accumulate != 0 adds instead of overwriting.
-int witw_conv3x3_wgrad_bf16(const void* x_oct, const void* dz_oct, const void* dz_nhwc, float* dw, float* db, float* workspace,
-                            int B, int H, int W, int Cin, int cin_real, int Cout, int stride_h, int pad_circular, int accumulate,
-                            void* stream) {
+int witw_conv3x3_wgrad_bf16(const void* x_oct, const void* dz_oct, float* dw, float* db, float* workspace, int B, int H, int W,
+                            int Cin, int cin_real, int Cout, int stride_h, int pad_circular, int accumulate, void* stream) {
     WITW_CHECK_ARG(x_oct && dz_oct && dw && workspace, "conv3x3_wgrad_bf16: null pointer");
     WITW_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv3x3_wgrad_bf16: bad shape");
     WITW_CHECK_ARG((Cin % 8) == 0 && (Cout % 8) == 0, "conv3x3_wgrad_bf16: Cin=%d and Cout=%d must be multiples of 8", Cin, Cout);
     WITW_CHECK_ARG(cin_real > 0 && cin_real <= Cin, "conv3x3_wgrad_bf16: cin_real=%d outside (0,%d]", cin_real, Cin);
     WITW_CHECK_ARG(stride_h == 1 || stride_h == 2, "conv3x3_wgrad_bf16: stride_h=%d unsupported", stride_h);
-    WITW_CHECK_ARG(!db || dz_nhwc, "conv3x3_wgrad_bf16: the bias gradient needs dz_nhwc");
-    WITW_CHECK_ARG(!db || (256 % (Cout / 8)) == 0, "conv3x3_wgrad_bf16: bias gradient needs Cout/8 to divide 256 (Cout=%d)", Cout);
     const int B8 = cdiv(B, 8);
     const int Ho = (H + 2 - 3) / stride_h + 1;
     WITW_CHECK_ARG((size_t)B8 * H * W * Cin * 16 < 0x80000000ull && (size_t)B8 * Ho * W * Cout * 16 < 0x80000000ull,
@@ -363,26 +347,18 @@ int witw_conv3x3_wgrad_bf16(const void* x_oct, const void* dz_oct, const void* d
     a.chunks = B8 * a.nrg * a.nseg;
     const int splits = wgrad_bf16_splits(B8, Ho, a.Wo, Cin, Cout, stride_h);
     a.cps = cdiv(a.chunks, splits);
+    const size_t n = (size_t)9 * Cin * Cout;
+    a.bias_part = db ? workspace + (size_t)splits * n : nullptr;
     const dim3 grid(cdiv(Cin, WB_TM), cdiv(Cout, WB_TN), splits);
     if (stride_h == 2)
         hipLaunchKernelGGL((conv3x3_wgrad_bf16_kernel<2, 1>), grid, dim3(512), 0, st, a);
     else
         hipLaunchKernelGGL((conv3x3_wgrad_bf16_kernel<1, 2>), grid, dim3(512), 0, st, a);
     WITW_CHECK_LAUNCH("conv3x3_wgrad_bf16");
-    const size_t n = (size_t)9 * Cin * Cout;
-    hipLaunchKernelGGL(wgrad_bf16_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, workspace, dw, Cin, Cout,
-                       splits, accumulate, cin_real);
+    // (a split whose chunk range came out empty has written zero partials)
+    hipLaunchKernelGGL(wgrad_bf16_reduce_kernel, dim3((unsigned)((n + Cout + 255) / 256)), dim3(256), 0, st, workspace, dw, Cin,
+                       Cout, splits, accumulate, cin_real, a.bias_part, db);
     WITW_CHECK_LAUNCH("wgrad_bf16_reduce");
-    if (db != nullptr) {
-        float* part = workspace + (size_t)splits * n;
-        const size_t npix = (size_t)B * Ho * W;
-        const int rows = bias_rows(npix);
-        const int nparts = (int)((npix + rows - 1) / rows);
-        hipLaunchKernelGGL(bias_grad_partial_bf16_kernel, dim3(nparts), dim3(256), 0, st, (const unsigned short*)dz_nhwc, part, npix,
-                           Cout, rows);
-        hipLaunchKernelGGL(bias_grad_finish_bf16_kernel, dim3(cdiv(Cout, 256)), dim3(256), 0, st, part, db, Cout, nparts, accumulate);
-        WITW_CHECK_LAUNCH("bias_grad_bf16");
-    }
     return WITW_OK;
 }
 

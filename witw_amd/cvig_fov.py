@@ -203,7 +203,8 @@ class FOV_DSM(torch.nn.Module):
 
     def _run_bf16(self, x, scales, keep_from=None):
         """The layer stack on the bf16 MFMA kernels (bf16 NHWC activations, fp32 accumulate, fp32 NCHW embedding).
-        Returns (embedding, kept) with kept[idx] = (layer input, layer output) bf16 NHWC for idx >= keep_from."""
+        Returns (embedding, kept) with kept[idx] = (layer input, layer output, max-pool arg-max codes or None) bf16 NHWC
+        for idx >= keep_from."""
         fast0 = self.in_channels <= 4 and (keep_from is None or keep_from > 0)
         h = x.contiguous() if fast0 else ops.nchw_to_nhwc_bf16(x.contiguous(), 16)
         last = self.layer_specs[-1][0]
@@ -213,13 +214,11 @@ class FOV_DSM(torch.nn.Module):
                 h = ops.conv3x3_first_fwd(h, self._pack_first(True), circular=self.circ_padding, relu=relu)
                 continue
             keep = keep_from is not None and idx >= keep_from
-            if keep and pool:
-                raise _lib.WitwError('bf16 training through a fused max-pool (layer %d) is not implemented: '
-                                     'train this encoder with precision="fp32"' % idx)
-            y = ops.conv3x3_bf16_fwd(h, self._pack_bf16(idx), stride_h=sh, circular=self.circ_padding, relu=relu, pool=pool,
-                                     out_nchw_f32=(idx == last), drop_scale=scales.get(idx))
+            out = ops.conv3x3_bf16_fwd(h, self._pack_bf16(idx), stride_h=sh, circular=self.circ_padding, relu=relu, pool=pool,
+                                       out_nchw_f32=(idx == last), drop_scale=scales.get(idx), want_pool_code=(keep and pool))
+            y, code = out if (keep and pool) else (out, None)
             if keep:
-                kept[idx] = (h, y)
+                kept[idx] = (h, y, code)
             h = y
         return h, kept
 
@@ -342,11 +341,12 @@ class _EncoderFnBf16(torch.autograd.Function):
                 dw, db = ops.conv3x3_wgrad_bf16(x_in, dz, conv.in_channels, stride_h=sh, circular=circ)
                 grads[idx] = (dw[:conv.out_channels].contiguous(), db[:conv.out_channels].contiguous())
             if n > 0:   # gradient at the previous layer's conv output
-                pidx = specs[n - 1][0]
-                p_out = kept[pidx][1]
-                dz = ops.conv3x3_bf16_fwd(dz, enc._pack_t_bf16(idx), stride_h=1, circular=circ, relu=False, pool=False,
+                pidx, _psh, _prelu, ppool, _pdrop = specs[n - 1]
+                p_in, p_out, p_code = kept[pidx]
+                dy = ops.conv3x3_bf16_fwd(dz, enc._pack_t_bf16(idx), stride_h=1, circular=circ, relu=False, pool=False,
                                           drop_scale=scales.get(pidx), gate=p_out, dilate_h=(sh == 2),
                                           out_h=x_in.shape[1] if sh == 2 else None)
+                dz = ops.maxpool2x2_bwd_bf16(dy, p_code, (p_in.shape[1], p_in.shape[2])) if ppool else dy
         ctx.kept = None
         flat = []
         for (idx, _c) in enc.trainable_convs():

@@ -570,7 +570,7 @@ def nchw_to_nhwc_bf16(x, cpad=16):
 
 
 def conv3x3_bf16_fwd(x_nhwc, packed, stride_h=1, circular=False, relu=True, pool=False, out_nchw_f32=False, drop_scale=None,
-                     gate=None, dilate_h=False, out_h=None):
+                     gate=None, dilate_h=False, out_h=None, want_pool_code=False):
     """x NHWC bf16 [B,H,W,Cin_pad] -> NHWC bf16 [B,Hy,Wy,Cout] (or the fp32 NCHW embedding). Training extras as in
     conv3x3_fwd: drop_scale [B,Cout] fp32, gate = bf16 tensor shaped like the output (dgrad launches), dilate_h/out_h
     = zero-interleaved input rows (dgrad of a stride-(2,1) layer)."""
@@ -603,15 +603,32 @@ def conv3x3_bf16_fwd(x_nhwc, packed, stride_h=1, circular=False, relu=True, pool
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
+    code = torch.empty(tuple(y.shape), dtype=torch.uint8, device=y.device) if (pool and want_pool_code) else None
     _lib.check(lib.witw_conv3x3_bf16_fwd_ex(x_nhwc.data_ptr(), packed.wpk.data_ptr(), packed.bias.data_ptr(), _p(drop_scale),
-                                            _p(gate), y.data_ptr(), B, H, W, C, packed.cout, stride_h, int(circular), int(relu),
-                                            int(pool), int(out_nchw_f32), int(bool(dilate_h)), _stream()),
+                                            _p(gate), y.data_ptr(), _p(code), B, H, W, C, packed.cout, stride_h, int(circular),
+                                            int(relu), int(pool), int(out_nchw_f32), int(bool(dilate_h)), _stream()),
                'witw_conv3x3_bf16_fwd_ex')
     if prof is not None:
         e1.record()
         prof.append((('bf16', lib.witw_conv3x3_tile_n(packed.cout), stride_h, bool(pool)),
                      2.0 * packed.cin * packed.cout * 9 * Ho * W * B, e0, e1))
+    if want_pool_code:
+        return y, code
     return y
+
+
+def maxpool2x2_bwd_bf16(dy, code, out_hw):
+    """dy (bf16) / code (uint8) [B,Hp,Wp,C] -> dx bf16 [B,H,W,C]: gradient routed to the recorded arg-max position."""
+    lib = _lib.load()
+    if not (dy.is_cuda and dy.dtype == torch.bfloat16 and dy.is_contiguous() and code.dtype == torch.uint8
+            and tuple(code.shape) == tuple(dy.shape)):
+        raise _lib.WitwError('maxpool2x2_bwd_bf16: dy must be contiguous bfloat16 on the GPU, code uint8 of the same shape')
+    B, Hp, Wp, C = dy.shape
+    H, W = out_hw
+    dx = torch.empty((B, H, W, C), dtype=torch.bfloat16, device=dy.device)
+    _lib.check(lib.witw_maxpool2x2_bwd_bf16(dy.data_ptr(), code.data_ptr(), dx.data_ptr(), B, Hp, Wp, H, W, C, _stream()),
+               'witw_maxpool2x2_bwd_bf16')
+    return dx
 
 
 def nhwc_bf16_to_octet(x):
@@ -649,7 +666,7 @@ def conv3x3_wgrad_bf16(x_nhwc, dz_nhwc, cin_real, stride_h=1, circular=False, wa
     db = torch.empty((Cout,), dtype=torch.float32, device=x_nhwc.device) if want_bias else None
     ws = torch.empty(lib.witw_conv3x3_wgrad_bf16_workspace_floats(B, H, W, Cin, Cout, stride_h), dtype=torch.float32,
                      device=x_nhwc.device)
-    _lib.check(lib.witw_conv3x3_wgrad_bf16(x_oct.data_ptr(), dz_oct.data_ptr(), dz_nhwc.data_ptr(), dw.data_ptr(), _p(db),
+    _lib.check(lib.witw_conv3x3_wgrad_bf16(x_oct.data_ptr(), dz_oct.data_ptr(), dw.data_ptr(), _p(db),
                                            ws.data_ptr(), B, H, W, Cin, cin_real, Cout, stride_h, int(circular), 0, _stream()),
                'witw_conv3x3_wgrad_bf16')
     if prof is not None:
