@@ -47,6 +47,25 @@ def test_conv3x3_bf16_vs_emulation(case):
         np.testing.assert_allclose(got.numpy(), ref.bfloat16().float().numpy(), rtol=2 ** -7, atol=1e-6)  # <= 1 bf16 ulp
 
 
+@pytest.mark.parametrize('case', [(2, 3, 16, 64, True), (1, 3, 13, 99, False), (2, 4, 8, 130, True), (1, 1, 9, 70, False)])
+def test_first_layer_bf16_vs_emulation(case):
+    """C<=4 -> 64 first layer on the bf16 MFMA (two taps of a pixel per operand): bf16-rounded image and filter,
+    fp32 accumulate, bf16 NHWC out -> within one bf16 ulp of the CPU emulation."""
+    from witw_amd import ops
+    B, C, H, W, circ = case
+    g = np.random.Generator(np.random.Philox(key=[9, C * 1000 + W]))
+    x = torch.from_numpy(g.standard_normal((B, C, H, W), dtype=np.float32))
+    w = torch.from_numpy(g.standard_normal((64, C, 3, 3), dtype=np.float32) * (2.0 / (9 * C)) ** 0.5)
+    b = torch.from_numpy(g.standard_normal((64,), dtype=np.float32) * 0.1)
+    ref = torch.relu(O.conv3x3(x.bfloat16().float(), w.bfloat16().float(), b, 1, circ))
+    dev = torch.device('cuda:0')
+    pk = ops.PackedFirstConv(w.to(dev), b.to(dev), bf16=True)
+    y = ops.conv3x3_first_fwd(x.to(dev), pk, circular=circ, relu=True)
+    assert y.dtype == torch.bfloat16 and y.shape == (B, H, W, 64)
+    got = y.float().cpu().permute(0, 3, 1, 2)
+    np.testing.assert_allclose(got.numpy(), ref.bfloat16().float().numpy(), rtol=2 ** -7, atol=1e-6)
+
+
 def test_encoder_bf16_vs_emulation_and_fp32_goldens(golden_dir):
     from witw_amd import cvig_fov, cvig_semantic
     g = np.load(os.path.join(golden_dir, 'encoder.npz'))

@@ -56,6 +56,21 @@ def test_train_then_test_drivers(tmp_path, monkeypatch, capsys):
     assert 0 <= table['top_1'] <= 100 and 1 <= table['median'] <= 6
 
 
+def test_train_then_test_drivers_bf16(tmp_path, monkeypatch, capsys):
+    """The same drivers with Globals.precision = 'bf16' (CLI --precision bf16): mixed-precision training step,
+    fp32 checkpoints under the reference's names, bf16 evaluation."""
+    from witw_amd import cvig_fov
+    csv = _write_dataset(str(tmp_path), 6)
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setattr(cvig_fov.Globals, 'precision', 'bf16')
+    best = cvig_fov.train(dataset='cvusa', fov=70, val_quantity=2, batch_size=2, num_workers=0, num_epochs=1, csv_path=csv)
+    assert best is not None and np.isfinite(best)
+    sd = torch.load(os.path.join('weights', 'fov_70_surface_best.pth'))
+    assert all(v.dtype == torch.float32 for v in sd.values())
+    table = cvig_fov.test(dataset='cvusa', fov=70, batch_size=4, num_workers=0, csv_path=csv)
+    assert 'Top  1:' in capsys.readouterr().out and 1 <= table['median'] <= 6
+
+
 def test_sweep_scores_matches_heatmap_formula():
     from witw_amd import cvig_fov
     ov = torch.from_numpy(synth.embeddings(60, 1, (9, 16, 4, 64)))

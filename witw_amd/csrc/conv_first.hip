@@ -140,6 +140,131 @@ __global__ __launch_bounds__(FT, 2) void conv3x3_first_kernel(FirstArgs p) {
     }
 }
 
+// bf16 form (the bf16 path's first layer: bf16-rounded operands, fp32 accumulate, bf16 NHWC out): with a pixel's
+// (r,g,b,0) held as four bf16 (8 bytes), one v_mfma_f32_32x32x16_bf16 operand = 8 k values = TWO taps of a pixel, so the
+// 9 taps take 3 MFMAs per tile (lane half h of MFMA i holds taps 4i+2h, 4i+2h+1; taps 9-11 do not exist: zeros)
+// instead of 15 fp32 k-steps of twice the cycles: the layer is then purely bound by its 64-channel output stream.
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(FT, 2) void conv3x3_first_bf16_kernel(FirstArgs p) {
+    __shared__ f32x4 smem[4096];                 // 64 KB: input tile (660 x 8 B), weights (384 x 16 B); slabs alias all of it
+    u32x2* in_s = reinterpret_cast<u32x2*>(smem);
+    u32x4v* w_s = reinterpret_cast<u32x4v*>(smem + 352);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hq = lane >> 5;
+    int bid = blockIdx.x;
+    const int tiles_img = p.tiles_x * p.tiles_y;
+    const int b = bid / tiles_img;
+    bid -= b * tiles_img;
+    const int ty = bid / p.tiles_x, tx = bid - ty * p.tiles_x;
+    const int oy0 = ty * 8, ox0 = tx * 64;
+    const size_t plane = (size_t)p.H * p.W;
+
+    for (int s = tid; s < FIH * FIW; s += FT) {
+        const int r = s / FIW, c = s - r * FIW;
+        const int gr = oy0 - 1 + r;
+        int gc = ox0 - 1 + c;
+        bool ok = gr >= 0 && gr < p.H;
+        if (p.circ) {
+            gc %= p.W;
+            if (gc < 0) gc += p.W;
+        } else {
+            ok = ok && gc >= 0 && gc < p.W;
+        }
+        __bf16 v[4] = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+        if (ok) {
+            const float* src = p.x + (size_t)b * p.C * plane + (size_t)gr * p.W + gc;
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch)
+                if (ch < p.C) v[ch] = (__bf16)src[ch * plane];
+        }
+        in_s[s] = __builtin_bit_cast(u32x2, v);
+    }
+    for (int s = tid; s < 384; s += FT) w_s[s] = reinterpret_cast<const u32x4v*>(p.wf)[s];
+    __syncthreads();
+
+    const int row0 = 2 * (wave >> 1), col0 = 32 * (wave & 1);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        // this lane's two taps of MFMA i; a tap past 8 reads tap 0's pixel and is zeroed
+        const int tA = 4 * i + 2 * hq, tB = tA + 1;
+        const int offA = (tA < 9) ? (tA / 3) * FIW + tA % 3 : 0;
+        const int offB = (tB < 9) ? (tB / 3) * FIW + tB % 3 : 0;
+        u32x4v bw[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) bw[nt] = w_s[(i * 2 + hq) * 64 + nt * 32 + l31];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int base = (row0 + mt) * FIW + col0 + l31;
+            u32x2 pa = in_s[base + offA], pb = in_s[base + offB];
+            if (tA >= 9) pa = (u32x2){0u, 0u};
+            if (tB >= 9) pb = (u32x2){0u, 0u};
+            const u32x4v av = {pa[0], pa[1], pb[0], pb[1]};
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bw[nt]),
+                                                                     acc[mt][nt], 0, 0, 0);
+        }
+    }
+    __syncthreads();     // every wave is done with the input / weight images before the slabs overwrite them
+
+    float bv[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) bv[nt] = p.bias[nt * 32 + l31];
+    float* slab = reinterpret_cast<float*>(smem) + wave * (32 * 64);
+    const int prow = lane >> 3, pc8 = (lane & 7) * 8;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[mt][nt][r] + bv[nt];
+                if (p.relu) v = fmaxf(v, 0.f);
+                slab[((r & 3) + 8 * (r >> 2) + 4 * hq) * 64 + nt * 32 + l31] = v;
+            }
+        const int yy = oy0 + row0 + mt;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int m = g * 8 + prow;
+            const int xx = ox0 + col0 + m;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(slab + m * 64 + pc8);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(slab + m * 64 + pc8 + 4);
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o[e] = (__bf16)v0[e];
+                o[4 + e] = (__bf16)v1[e];
+            }
+            if (yy < p.H && xx < p.W)
+                __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p.y) + (((size_t)b * p.H + yy) * p.W + xx) * 64 + pc8));
+        }
+    }
+}
+
+// bf16 filter image of conv3x3_first_bf16_kernel: slot [i][h][n] (16 B) = (w[n][0..3][tap 4i+2h], w[n][0..3][tap 4i+2h+1])
+// as bf16, zeros for taps >= 9 and channels >= C; 384 slots = 1536 floats of the 2560-float buffer.
+__global__ void pack_first_bf16_kernel(const float* __restrict__ w, unsigned short* __restrict__ wf, int C) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 384) return;
+    const int n = idx % 64, h = (idx / 64) % 2, i = idx / 128;
+    __bf16 v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int tap = 4 * i + 2 * h + (e >> 2), ch = e & 3;
+        v[e] = (__bf16)((tap < 9 && ch < C) ? w[((size_t)n * C + ch) * 9 + tap] : 0.f);
+    }
+    reinterpret_cast<bf16x8*>(wf)[idx] = __builtin_bit_cast(bf16x8, v);
+}
+
 // wf[i][h][n][0..3] = (w[n][0][tap], w[n][1][tap], w[n][2][tap], w[n][3][tap]) with tap = 2i+h (zeros for tap 9
 // and for channels >= C); round_bf16 != 0 rounds the weights to bf16 first (the bf16 path's filters).
 __global__ void pack_first_kernel(const float* __restrict__ w, float* __restrict__ wf, int C, int round_bf16) {
@@ -165,13 +290,17 @@ extern "C" {
 int witw_conv3x3_first_pack(const float* w, float* wf, int C, int round_bf16, void* stream) {
     WITW_CHECK_ARG(w && wf, "conv3x3_first_pack: null pointer");
     WITW_CHECK_ARG(C >= 1 && C <= 4, "conv3x3_first_pack: C=%d outside [1,4]", C);
-    hipLaunchKernelGGL(pack_first_kernel, dim3(3), dim3(256), 0, (hipStream_t)stream, w, wf, C, round_bf16);
+    if (round_bf16)     // the bf16 kernel's own filter image (see pack_first_bf16_kernel)
+        hipLaunchKernelGGL(pack_first_bf16_kernel, dim3(2), dim3(256), 0, (hipStream_t)stream, w, (unsigned short*)wf, C);
+    else
+        hipLaunchKernelGGL(pack_first_kernel, dim3(3), dim3(256), 0, (hipStream_t)stream, w, wf, C, round_bf16);
     WITW_CHECK_LAUNCH("conv3x3_first_pack");
     return WITW_OK;
 }
 
 // x NCHW fp32 [B,C,H,W] (C <= 4) -> y NHWC [B,H,W,64] (fp32, or bf16 if out_bf16; with out_bf16 the INPUT is
-// rounded to bf16 on load so that the arithmetic equals the bf16 path's: bf16 operands, fp32 accumulate).
+// rounded to bf16 on load so that the arithmetic equals the bf16 path's: bf16 operands, fp32 accumulate, and wf
+// must come from witw_conv3x3_first_pack(round_bf16 = 1), which writes the bf16 kernel's filter image).
 int witw_conv3x3_first_fwd(const float* x, const float* wf, const float* bias, void* y, int B, int C, int H, int W,
                            int pad_circular, int relu, int out_bf16, void* stream) {
     WITW_CHECK_ARG(x && wf && bias && y, "conv3x3_first_fwd: null pointer");
@@ -183,7 +312,10 @@ int witw_conv3x3_first_fwd(const float* x, const float* wf, const float* bias, v
     a.circ = pad_circular; a.relu = relu; a.out_bf16 = out_bf16;
     const long long grid = (long long)B * a.tiles_x * a.tiles_y;
     WITW_CHECK_ARG(grid <= 0x7fffffffLL, "conv3x3_first_fwd: grid too large");
-    hipLaunchKernelGGL(conv3x3_first_kernel, dim3((unsigned)grid), dim3(FT), 0, (hipStream_t)stream, a);
+    if (out_bf16)
+        hipLaunchKernelGGL(conv3x3_first_bf16_kernel, dim3((unsigned)grid), dim3(FT), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(conv3x3_first_kernel, dim3((unsigned)grid), dim3(FT), 0, (hipStream_t)stream, a);
     WITW_CHECK_LAUNCH("conv3x3_first_fwd");
     return WITW_OK;
 }

@@ -30,6 +30,10 @@ class Globals:
         'witw': {'path_columns': [15, 16], 'path_names': ['surface', 'overhead'], 'header': 0, 'panorama': False},
     }
 
+    # not in the reference: arithmetic of the encoders built by train() / test() / the CLI (`--precision`).
+    # 'fp32' = the reference's arithmetic (parity path); 'bf16' = bf16 MFMA operands, fp32 accumulate / weights / Adam.
+    precision = 'fp32'
+
 
 def _default_device():
     # model/cvig_fov.py:578 uses cuda:0; under torch.distributed.run every process takes the GPU of its LOCAL_RANK
@@ -842,6 +846,7 @@ def train(dataset='cvusa', fov=360, val_quantity=1000, batch_size=64, num_worker
                                              sampler=val_sampler, num_workers=num_workers, collate_fn=collate_raw)
     surface_encoder = FOV_DSM(circ_padding=False, seed=seed).to(device)
     overhead_encoder = FOV_DSM(circ_padding=True, seed=seed).to(device)
+    surface_encoder.precision = overhead_encoder.precision = Globals.precision
     parallel.broadcast_parameters([surface_encoder, overhead_encoder])
     all_params = list(surface_encoder.parameters()) + list(overhead_encoder.parameters())
     optimizer = Adam(all_params, lr=1.E-5)
@@ -917,6 +922,7 @@ def test(dataset='cvusa', fov=360, batch_size=64, num_workers=8, csv_path=None, 
                                               num_workers=num_workers, collate_fn=collate_raw)
     surface_encoder = FOV_DSM(circ_padding=False).to(device)
     overhead_encoder = FOV_DSM(circ_padding=True).to(device)
+    surface_encoder.precision = overhead_encoder.precision = Globals.precision
     load_reference_state_dict(surface_encoder, torch.load('./weights/fov_{}_surface_best.pth'.format(int(fov))))
     load_reference_state_dict(overhead_encoder, torch.load('./weights/fov_{}_overhead_best.pth'.format(int(fov))))
     surface_encoder.eval()
@@ -963,8 +969,11 @@ def main(argv=None):
     parser.add_argument('--dataset', default='cvusa', choices=['cvusa', 'witw'], help='Dataset to use. [Default = cvusa]')
     parser.add_argument('--fov', type=int, default=360, choices=range(6, 361), metavar='{6-360}',
                         help='The field of view for cropping street level images. [Default = 360]')
+    parser.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'],
+                        help='Encoder arithmetic (not in the reference): fp32, or bf16 MFMA mixed precision. [Default = fp32]')
     args = parser.parse_args(argv)
     print(args)
+    Globals.precision = args.precision
     init_distributed()
     if args.mode == 'train':
         train(dataset=args.dataset, fov=args.fov)

@@ -111,8 +111,11 @@ def main(argv=None):
     parser.add_argument('--dataset', default='cvusa', choices=['cvusa', 'witw'], help='Dataset to use. [Default = cvusa]')
     parser.add_argument('--fov', type=int, default=360, choices=range(6, 361), metavar='{6-360}',
                         help='The field of view for cropping street level images. [Default = 360]')
+    parser.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'],
+                        help='Encoder arithmetic (not in the reference): fp32, or bf16 MFMA mixed precision. [Default = fp32]')
     args = parser.parse_args(argv)
     print(args)
+    Globals.precision = args.precision
     _fov.init_distributed()
     if args.mode == 'train':
         train(dataset=args.dataset, fov=args.fov)
