@@ -195,7 +195,8 @@ def main():
     tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get('%s_bytes_per_launch_B%d' % (kname, B))
+            tag = ('_bf16_train' if bf16 else '_train') if train else ''     # train modes average forward + dgrad launches
+            traffic = json.load(open(tpath)).get('%s_bytes_per_launch_B%d%s' % (kname, B, tag))
         except Exception:
             traffic = None
 
