@@ -164,6 +164,20 @@ long long witw_conv3x3_wgrad_bf16_workspace_floats(int B, int H, int W, int Cin,
 int witw_conv3x3_wgrad_bf16(const void* x_oct, const void* dz_oct, float* dw, float* db, float* workspace, int B, int H, int W,
                             int Cin, int cin_real, int Cout, int stride_h, int pad_circular, int accumulate, void* stream);
 
+/* ---- 2x2 sub-window form of the 3x3 kernels: cvig_baseline's Conv2d(k=4,s=2,p=0) (model/cvig_baseline.py:236-252) is a
+ * 2x2 convolution over the space-to-depth(2) image, i.e. a 3x3 window whose first tap row/column are zero (dgrad: last
+ * row/column); these entries run only the 4 live taps (2.25x fewer MFMAs than witw_conv3x3_fwd_ex on the zero-filled
+ * 3x3 filter, same results). pack: taps {1,2}^2 of w [cout][cin][3][3] (transpose_flip: taps {0,1}^2 of the dgrad
+ * filter of the source [cin][cout][3][3]); fwd: tap_base = 1 with a forward-packed filter, 0 with a dgrad-packed one;
+ * wgrad: taps {1,2}^2 of dw, exact zeros elsewhere (workspace as witw_conv3x3_wgrad, stride 1). */
+long long witw_conv3x3_packed_floats_taps4(int cout, int cin);
+int witw_conv3x3_pack_weights_taps4(const float* w_kcrs, float* wpk, int cout, int cin, int transpose_flip, void* stream);
+int witw_conv3x3_fwd_taps4(const float* x, const float* wpk4, const float* bias, const float* gate, const float* post_scale,
+                           const float* post_shift, float* y, int B, int H, int W, int Cin, int Cout, int relu,
+                           float lrelu_slope, int tap_base, void* stream);
+int witw_conv3x3_wgrad_taps4(const float* x, const float* dz, float* dw, float* db, float* workspace, int B, int H, int W,
+                             int Cin, int cin_real, int Cout, int accumulate, void* stream);
+
 /* ---- cvig_baseline (model/cvig_baseline.py). Conv2d(k=4,s=2,p=0) = the 3x3 kernel above on the
  * space-to-depth(2) image with a filter whose first tap row/column is zero. */
 /* x NHWC [B,Hp,Wp,C] (NCHW if in_nchw) with valid region HxW -> NHWC [B,ceil(H/2),ceil(W/2),Cpad], channel

@@ -112,3 +112,34 @@ def test_baseline_training_step_matches_reference_golden(golden_dir):
         pv = named[str(name)].detach().reshape(-1).cpu()
         np.testing.assert_allclose(pv[::max(1, pv.numel() // 129)].numpy(), g['psamp:' + str(name)], rtol=0, atol=2.5e-3)
     print('worst sampled-gradient relative error', worst)
+
+
+@pytest.mark.parametrize('case', [(2, 20, 70, 24, 128, 4), (1, 64, 64, 16, 64, 8), (2, 9, 30, 64, 192, 4), (3, 16, 130, 8, 64, 4)])
+def test_taps4_kernels_equal_the_zero_filled_3x3_form(case):
+    """The 4-tap kernels (witw_conv3x3_fwd_taps4 / _wgrad_taps4) against the full 3x3 kernels on a filter whose first tap
+    row/column are zero: the zero taps only ever add exact zeros, so forward, dgrad and the live weight-gradient taps are
+    BIT-identical; the dead taps come back as exact zeros."""
+    import torch
+    from witw_amd import ops
+    B, H, W, Cin, Cout, _nw = case
+    g = np.random.Generator(np.random.Philox(key=[77, Cin + Cout]))
+    dev = torch.device('cuda:0')
+    x = torch.from_numpy(g.standard_normal((B, H, W, Cin), dtype=np.float32)).to(dev)
+    k3 = torch.from_numpy(g.standard_normal((Cout, Cin, 3, 3), dtype=np.float32) * 0.05)
+    k3[:, :, 0, :] = 0
+    k3[:, :, :, 0] = 0
+    k3 = k3.to(dev)
+    b = torch.from_numpy(g.standard_normal((Cout,), dtype=np.float32) * 0.1).to(dev)
+    full, live = ops.PackedConv(k3, b), ops.PackedConv(k3, b, taps4=True)
+    y9 = ops.conv3x3_fwd(x, full, relu=False, lrelu_slope=0.2)
+    y4 = ops.conv3x3_fwd(x, live, relu=False, lrelu_slope=0.2)
+    assert torch.equal(y9, y4)
+    dz = torch.from_numpy(g.standard_normal((B, H, W, Cout), dtype=np.float32)).to(dev)
+    if Cout % 8 == 0:
+        d9 = ops.conv3x3_fwd(dz, ops.PackedConv(k3, None, transpose_flip=True), relu=False)
+        d4 = ops.conv3x3_fwd(dz, ops.PackedConv(k3, None, transpose_flip=True, taps4=True), relu=False)
+        assert torch.equal(d9, d4)
+    w9, b9 = ops.conv3x3_wgrad(x, dz, Cin)
+    w4, b4 = ops.conv3x3_wgrad(x, dz, Cin, taps4=True)
+    assert torch.equal(w9[:, :, 1:, 1:], w4[:, :, 1:, 1:]) and torch.equal(b9, b4)
+    assert float(w4[:, :, 0, :].abs().max()) == 0.0 and float(w4[:, :, :, 0].abs().max()) == 0.0

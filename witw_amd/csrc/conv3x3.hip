@@ -46,6 +46,7 @@ struct ConvArgs {
     int force_nw;           // 0 = choose, 4 / 8 = force the workgroup shape (tuning aid)
     int force_geo;          // -1 = choose, 0 / 1 = force the wide / narrow tile geometry
     int dil_h;              // 1: input rows are zero-interleaved (row 2i = physical row i): dgrad of a stride-(2,1) conv
+    int tap_base;           // TAPS == 4 only: the 2x2 taps are (tap_base + {0,1}, tap_base + {0,1}) of the 3x3 window
 #ifdef WITW_STAMPS
     unsigned long long* stamps;   // diagnostic build only (tools/conv_stamps.cpp)
 #endif
@@ -57,15 +58,19 @@ struct ConvArgs {
 // GEO = shape of one MFMA M-tile (32 output pixels): 0 = 1 row x 32 columns, workgroup tile NW rows x 64 columns
 // (wide maps); 1 = 2 rows x 16 columns, workgroup tile 4*NW rows x 16 columns (maps up to 32 columns wide, e.g. the
 // fov-70 ground branch whose widths are 24 and 12 in the deep layers: a 64-column tile would idle 63-81 % of it).
-template <int TN, int SH, bool POOL, int NW, int GEO>
+// TAPS = 9: the full 3x3 window. TAPS = 4: a 2x2 sub-window of it (rows/columns tap_base + {0,1}): the cvig_baseline
+// Conv2d(k=4, s=2, p=0) (model/cvig_baseline.py:236-252) is a 2x2 convolution over the space-to-depth(2) image, i.e. the
+// 3x3 window whose first tap row and column are zero (dgrad: last row and column) — 4 of 9 taps carry all the work.
+template <int TN, int SH, bool POOL, int NW, int GEO, int TAPS = 9>
 __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_f32_kernel(ConvArgs p) {
+    static_assert(TAPS == 9 || TAPS == 4, "3x3 window or a 2x2 sub-window");
     constexpr int TH = GEO ? 4 * NW : NW;
     constexpr int TW = GEO ? 16 : 64;
     constexpr int IW = TW + 2;
     constexpr int NTHREADS = 64 * NW;
     constexpr int IH = (TH - 1) * SH + 3;
     constexpr int IN_F4 = 2 * IH * IW;          // float4 slots of one input stage
-    constexpr int W_F4 = 9 * 2 * TN;            // float4 slots of one weight stage
+    constexpr int W_F4 = TAPS * 2 * TN;         // float4 slots of one weight stage
     constexpr int STAGE_F4 = IN_F4 + W_F4;
     constexpr int NIN = (IN_F4 + NTHREADS - 1) / NTHREADS;
     constexpr int NWT = (W_F4 + NTHREADS - 1) / NTHREADS;
@@ -193,7 +198,8 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_f32_kernel(ConvArgs p) {
     auto m_col = [](int m) { return GEO ? (m & 15) : m; };
     int abase[WM];
 #pragma unroll
-    for (int mt = 0; mt < WM; ++mt) abase[mt] = hq * (IH * IW) + (trow[mt] + m_row(l31)) * SH * IW + tcol[mt] + m_col(l31);
+    for (int mt = 0; mt < WM; ++mt)
+        abase[mt] = hq * (IH * IW) + (trow[mt] + m_row(l31)) * SH * IW + tcol[mt] + m_col(l31) + (TAPS == 4 ? p.tap_base * (IW + 1) : 0);
     const int wbase = hq * TN + wn * 64 + l31;
 
     f32x16 acc[WM][WN];
@@ -212,7 +218,7 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_f32_kernel(ConvArgs p) {
     // idles for the barrier skew.
     f32x4 fa[2][WM], fb[2][WN];
     auto read_frags = [&](int set, const f32x4* in_s, const f32x4* w_s, int tap) {
-        const int kh = tap / 3, kw = tap - kh * 3;
+        const int kh = (TAPS == 4) ? (tap >> 1) : tap / 3, kw = (TAPS == 4) ? (tap & 1) : tap - kh * 3;
 #pragma unroll
         for (int mt = 0; mt < WM; ++mt) fa[set][mt] = in_s[abase[mt] + kh * IW + kw];
 #pragma unroll
@@ -273,49 +279,77 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_f32_kernel(ConvArgs p) {
     } while (0)
     static_assert(MPT - RPT - (NIN + NWT) >= 0, "tap too short to hide the staging instructions");
 
-    for (int kc = 0; kc < nkc; ++kc) {
-        const int cur = kc & 1;
-        const int kn = (kc + 1 < nkc) ? kc + 1 : kc;   // last chunk restages itself (never read)
-        const f32x4* in_s = smem + cur * STAGE_F4;
-        const f32x4* w_s = in_s + IN_F4;
-        const f32x4* in_n = smem + (cur ^ 1) * STAGE_F4;
-        // tap 0 (+ global loads of the next chunk)
-        read_frags(1, in_s, w_s, 1);
-#ifndef WITW_DIAG_NOSTAGE
-        load_stage(kn);
-#endif
-        mfma_tap(0);
-        SG_HEAVY_TAP(0x020, NIN + NWT);
-#pragma unroll
-        for (int tap = 1; tap < 4; ++tap) {
-            read_frags((tap + 1) & 1, in_s, w_s, tap + 1);
-            mfma_tap(tap & 1);
+    if constexpr (TAPS == 4) {
+        // 4 taps per chunk: global loads of the next chunk ride under tap 0, its LDS writes under tap 2, the chunk's
+        // barrier sits in front of tap 3, behind whose MFMAs the first fragments of the next chunk arrive. An even
+        // tap count keeps the fragment sets aligned from chunk to chunk (no register copy).
+        for (int kc = 0; kc < nkc; ++kc) {
+            const int cur = kc & 1;
+            const int kn = (kc + 1 < nkc) ? kc + 1 : kc;
+            const f32x4* in_s = smem + cur * STAGE_F4;
+            const f32x4* w_s = in_s + IN_F4;
+            const f32x4* in_n = smem + (cur ^ 1) * STAGE_F4;
+            read_frags(1, in_s, w_s, 1);
+            load_stage(kn);
+            mfma_tap(0);
+            SG_HEAVY_TAP(0x020, NIN + NWT);
+            read_frags(0, in_s, w_s, 2);
+            mfma_tap(1);
+            SG_PLAIN_TAP();
+            read_frags(1, in_s, w_s, 3);
+            store_stage(cur ^ 1);
+            mfma_tap(0);
+            SG_HEAVY_TAP(0x200, NIN + NWT);
+            __syncthreads();
+            read_frags(0, in_n, in_n + IN_F4, 0);
+            mfma_tap(1);
             SG_PLAIN_TAP();
         }
-        // tap 4 (+ LDS writes of the next chunk)
-        read_frags(1, in_s, w_s, 5);
+    } else {
+        for (int kc = 0; kc < nkc; ++kc) {
+            const int cur = kc & 1;
+            const int kn = (kc + 1 < nkc) ? kc + 1 : kc;   // last chunk restages itself (never read)
+            const f32x4* in_s = smem + cur * STAGE_F4;
+            const f32x4* w_s = in_s + IN_F4;
+            const f32x4* in_n = smem + (cur ^ 1) * STAGE_F4;
+            // tap 0 (+ global loads of the next chunk)
+            read_frags(1, in_s, w_s, 1);
 #ifndef WITW_DIAG_NOSTAGE
-        store_stage(cur ^ 1);
+            load_stage(kn);
 #endif
-        mfma_tap(0);
-        SG_HEAVY_TAP(0x200, NIN + NWT);
+            mfma_tap(0);
+            SG_HEAVY_TAP(0x020, NIN + NWT);
 #pragma unroll
-        for (int tap = 5; tap < 8; ++tap) {
-            read_frags((tap + 1) & 1, in_s, w_s, tap + 1);
-            mfma_tap(tap & 1);
-            SG_PLAIN_TAP();
-        }
+            for (int tap = 1; tap < 4; ++tap) {
+                read_frags((tap + 1) & 1, in_s, w_s, tap + 1);
+                mfma_tap(tap & 1);
+                SG_PLAIN_TAP();
+            }
+            // tap 4 (+ LDS writes of the next chunk)
+            read_frags(1, in_s, w_s, 5);
+#ifndef WITW_DIAG_NOSTAGE
+            store_stage(cur ^ 1);
+#endif
+            mfma_tap(0);
+            SG_HEAVY_TAP(0x200, NIN + NWT);
+#pragma unroll
+            for (int tap = 5; tap < 8; ++tap) {
+                read_frags((tap + 1) & 1, in_s, w_s, tap + 1);
+                mfma_tap(tap & 1);
+                SG_PLAIN_TAP();
+            }
 #ifndef WITW_DIAG_NOBARRIER
-        __syncthreads();
+            __syncthreads();
 #endif
-        // tap 8, behind which the first fragments of the next chunk arrive
-        read_frags(1, in_n, in_n + IN_F4, 0);
-        mfma_tap(0);
-        SG_PLAIN_TAP();
+            // tap 8, behind which the first fragments of the next chunk arrive
+            read_frags(1, in_n, in_n + IN_F4, 0);
+            mfma_tap(0);
+            SG_PLAIN_TAP();
 #pragma unroll
-        for (int mt = 0; mt < WM; ++mt) fa[0][mt] = fa[1][mt];
+            for (int mt = 0; mt < WM; ++mt) fa[0][mt] = fa[1][mt];
 #pragma unroll
-        for (int nt = 0; nt < WN; ++nt) fb[0][nt] = fb[1][nt];
+            for (int nt = 0; nt < WN; ++nt) fb[0][nt] = fb[1][nt];
+        }
     }
 #undef SG_PLAIN_TAP
 #undef SG_HEAVY_TAP
@@ -508,18 +542,20 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_f32_kernel(ConvArgs p) {
 // One thread per packed float4: wpk[nt][kc][tap][q][n][0..3] <- w[cout][cin][kh][kw]
 // (torch KCRS). transpose_flip!=0 builds the dgrad filter instead: roles of cin/cout
 // swapped and taps rotated by 180 degrees (w'[ci][co][kh][kw] = w[co][ci][2-kh][2-kw]).
+// taps = 9: all of the window; taps = 4: the 2x2 sub-window (tap_base + {0,1})^2 of the PACKED filter (TAPS = 4 kernels).
 __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wpk, int Cout, int Cin,
-                                    int n_tiles, int nkc, int TN, int transpose_flip, int src_cout, int src_cin) {
-    const size_t total = (size_t)n_tiles * nkc * 9 * 2 * TN;
+                                    int n_tiles, int nkc, int TN, int transpose_flip, int src_cout, int src_cin, int taps,
+                                    int tap_base) {
+    const size_t total = (size_t)n_tiles * nkc * taps * 2 * TN;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     size_t t = idx;
     const int n = t % TN; t /= TN;
     const int q = t % 2; t /= 2;
-    const int tap = t % 9; t /= 9;
+    const int tap = t % taps; t /= taps;
     const int kc = t % nkc; t /= nkc;
     const int nt = (int)t;
-    const int kh = tap / 3, kw = tap % 3;
+    const int kh = (taps == 4) ? tap_base + (tap >> 1) : tap / 3, kw = (taps == 4) ? tap_base + (tap & 1) : tap % 3;
     const int co = nt * TN + n;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -560,7 +596,7 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, float* __restri
     y[idx] = (c < C) ? x[(b * C + c) * hw + r] : 0.f;
 }
 
-template <int TN, int SH, bool POOL, int NW, int GEO>
+template <int TN, int SH, bool POOL, int NW, int GEO, int TAPS = 9>
 int launch_conv_nw(ConvArgs a, hipStream_t st) {
     a.tiles_y = cdiv(a.Ho, GEO ? 4 * NW : NW);
     a.tiles_x = cdiv(a.Wo, GEO ? 16 : 64);
@@ -573,7 +609,7 @@ int launch_conv_nw(ConvArgs a, hipStream_t st) {
         return WITW_ERR_INVALID;
     }
     a.sp_total = (int)sp_total;
-    hipLaunchKernelGGL((conv3x3_nhwc_f32_kernel<TN, SH, POOL, NW, GEO>), dim3((unsigned)grid), dim3(64 * NW), 0, st, a);
+    hipLaunchKernelGGL((conv3x3_nhwc_f32_kernel<TN, SH, POOL, NW, GEO, TAPS>), dim3((unsigned)grid), dim3(64 * NW), 0, st, a);
     WITW_CHECK_LAUNCH("conv3x3_nhwc_f32");
     return WITW_OK;
 }
@@ -601,6 +637,16 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
 #endif
     if (choose_waves(a.B, a.Ho, a.Wo, a.Cout, a.force_nw) == 8) return launch_conv_nw<TN, SH, POOL, 8, 0>(a, st);
     return launch_conv_nw<TN, SH, POOL, 4, 0>(a, st);
+}
+
+// 2x2 sub-window kernels (stride 1, no pool)
+template <int TN>
+int launch_conv_taps4(const ConvArgs& a, hipStream_t st) {
+#ifndef WITW_NO_NARROW
+    if (choose_narrow(a.Wo, a.force_geo)) return launch_conv_nw<TN, 1, false, 4, 1, 4>(a, st);
+#endif
+    if (choose_waves(a.B, a.Ho, a.Wo, a.Cout, a.force_nw) == 8) return launch_conv_nw<TN, 1, false, 8, 0, 4>(a, st);
+    return launch_conv_nw<TN, 1, false, 4, 0, 4>(a, st);
 }
 
 }  // namespace
@@ -642,9 +688,61 @@ int witw_conv3x3_pack_weights(const float* w_kcrs, float* wpk, int cout, int cin
     // in transpose_flip mode (cout,cin) describe the PACKED filter; the source tensor is [cin][cout][3][3]
     const int src_cin = transpose_flip ? cout : cin;
     hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       w_kcrs, wpk, cout, cin, n_tiles, nkc, TN, transpose_flip, cout, src_cin);
+                       w_kcrs, wpk, cout, cin, n_tiles, nkc, TN, transpose_flip, cout, src_cin, 9, 0);
     WITW_CHECK_LAUNCH("pack_weights");
     return WITW_OK;
+}
+
+// ---- 2x2 sub-window form (cvig_baseline's Conv2d(k=4,s=2) over the space-to-depth image, model/cvig_baseline.py:236-252)
+long long witw_conv3x3_packed_floats_taps4(int cout, int cin) {
+    if (cout <= 0 || cin <= 0) return -1;
+    const int TN = witw_conv3x3_tile_n(cout);
+    return (long long)cdiv(cout, TN) * cdiv(cin, 8) * 4 * 2 * TN * 4;
+}
+
+// Packs 4 of the 9 taps of a [cout][cin][3][3] filter: rows/columns {1,2} (transpose_flip = 0: the forward filter whose
+// first tap row/column are zero) or, with transpose_flip, rows/columns {0,1} of the transposed, 180-degree rotated filter
+// (its dgrad filter, source tensor [cin][cout][3][3] as in witw_conv3x3_pack_weights).
+int witw_conv3x3_pack_weights_taps4(const float* w_kcrs, float* wpk, int cout, int cin, int transpose_flip, void* stream) {
+    WITW_CHECK_ARG(w_kcrs && wpk, "pack_weights_taps4: null pointer");
+    WITW_CHECK_ARG(cout > 0 && cin > 0, "pack_weights_taps4: bad shape cout=%d cin=%d", cout, cin);
+    const int TN = witw_conv3x3_tile_n(cout);
+    const int n_tiles = cdiv(cout, TN), nkc = cdiv(cin, 8);
+    const size_t total = (size_t)n_tiles * nkc * 4 * 2 * TN;
+    const int src_cin = transpose_flip ? cout : cin;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       w_kcrs, wpk, cout, cin, n_tiles, nkc, TN, transpose_flip, cout, src_cin, 4, transpose_flip ? 0 : 1);
+    WITW_CHECK_LAUNCH("pack_weights_taps4");
+    return WITW_OK;
+}
+
+// y = act(conv over the 2x2 taps (tap_base + {0,1})^2 of the 3x3 window, zero padding 1) [* post_scale + post_shift],
+// gate as in witw_conv3x3_fwd_ex. tap_base = 1 with a forward-packed filter, 0 with a transpose_flip-packed one.
+int witw_conv3x3_fwd_taps4(const float* x, const float* wpk4, const float* bias, const float* gate, const float* post_scale,
+                           const float* post_shift, float* y, int B, int H, int W, int Cin, int Cout, int relu,
+                           float lrelu_slope, int tap_base, void* stream) {
+    WITW_CHECK_ARG(x && wpk4 && bias && y, "conv3x3_fwd_taps4: null pointer");
+    WITW_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cout > 0, "conv3x3_fwd_taps4: bad shape B=%d H=%d W=%d Cout=%d", B, H, W, Cout);
+    WITW_CHECK_ARG(Cin > 0 && (Cin % 8) == 0, "conv3x3_fwd_taps4: Cin=%d must be a positive multiple of 8", Cin);
+    WITW_CHECK_ARG(relu >= 0 && relu <= 2, "conv3x3_fwd_taps4: activation %d unknown (0 none, 1 ReLU, 2 LeakyReLU)", relu);
+    WITW_CHECK_ARG(tap_base == 0 || tap_base == 1, "conv3x3_fwd_taps4: tap_base=%d outside {0,1}", tap_base);
+    WITW_CHECK_ARG((post_scale == nullptr) == (post_shift == nullptr), "conv3x3_fwd_taps4: post_scale and post_shift go together");
+    ConvArgs a;
+    a.x = x; a.wpk = wpk4; a.bias = bias; a.dropmask = nullptr; a.gate = gate; a.y = y;
+    a.post_scale = post_scale; a.post_shift = post_shift; a.lrelu = lrelu_slope;
+    a.pool_code = nullptr;
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+    a.Ho = H; a.Wo = W;
+    a.tiles_x = 0; a.tiles_y = 0;
+    a.force_nw = env_int("WITW_CONV_NW", 0);
+    a.force_geo = env_int("WITW_CONV_GEO", -1);
+    a.xcd_map = env_int("WITW_CONV_XCD", 1) != 0;
+    a.circ = 0; a.relu = relu; a.out_nchw = 0; a.dil_h = 0; a.tap_base = tap_base;
+#ifdef WITW_STAMPS
+    a.stamps = witw_conv_stamps_ptr;
+#endif
+    hipStream_t st = (hipStream_t)stream;
+    return witw_conv3x3_tile_n(Cout) == 128 ? launch_conv_taps4<128>(a, st) : launch_conv_taps4<64>(a, st);
 }
 
 int witw_nchw_to_nhwc8(const float* x, float* y, int B, int C, int H, int W, void* stream) {
@@ -694,7 +792,7 @@ int witw_conv3x3_fwd_ex(const float* x, const float* wpk, const float* bias, con
     a.force_nw = env_int("WITW_CONV_NW", 0);
     a.force_geo = env_int("WITW_CONV_GEO", -1);
     a.xcd_map = env_int("WITW_CONV_XCD", 1) != 0;      // 0: plain n-tile-major order (A/B timing)
-    a.circ = pad_circular; a.relu = relu; a.out_nchw = out_nchw; a.dil_h = dilate_h;
+    a.circ = pad_circular; a.relu = relu; a.out_nchw = out_nchw; a.dil_h = dilate_h; a.tap_base = 0;
 #ifdef WITW_STAMPS
     a.stamps = witw_conv_stamps_ptr;
 #endif

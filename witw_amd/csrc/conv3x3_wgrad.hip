@@ -38,6 +38,9 @@ struct WgradArgs {
     int cps;           // chunks per split
 };
 
+// TAPS = 9: the full window. TAPS = 4: only the taps (kh, kw) in {1,2}^2 (cvig_baseline's Conv2d(k=4,s=2) as a 2x2
+// convolution over the space-to-depth image: the other five taps of its 3x3 form are structurally zero and get no gradient).
+template <int TAPS>
 __global__ __launch_bounds__(WT, 2) void conv3x3_wgrad_kernel(WgradArgs p) {
     __shared__ float smem[X_F + DZ_F];
     float* x_s = smem;
@@ -49,11 +52,12 @@ __global__ __launch_bounds__(WT, 2) void conv3x3_wgrad_kernel(WgradArgs p) {
     const int c_begin = split * p.cps;
     const int c_end = min(p.chunks, c_begin + p.cps);
 
-    f32x16 acc[9];
+    f32x16 acc[TAPS];
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < TAPS; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    constexpr int R0 = (TAPS == 4) ? 1 : 0;      // first halo row that is read
 
     const int mci = (wave & 1) * 32 + l31;    // this lane's ci within the tile (A operand row)
     const int nco = (wave >> 1) * 32 + l31;   // this lane's co within the tile (B operand column)
@@ -94,7 +98,7 @@ __global__ __launch_bounds__(WT, 2) void conv3x3_wgrad_kernel(WgradArgs p) {
         // ---- stage: 3 halo rows of X and one row of dZ
         u32x4 rx[3][XLD], rz[4];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
+        for (int r = R0; r < 3; ++r) {
             const int gr = h * p.SH - 1 + r;
             const bool rok = gr >= 0 && gr < p.H;
             const float* base = p.x + ((size_t)b * p.H + (rok ? gr : 0)) * p.W * p.Cin;
@@ -110,7 +114,7 @@ __global__ __launch_bounds__(WT, 2) void conv3x3_wgrad_kernel(WgradArgs p) {
         }
         __syncthreads();   // previous chunk's fragment reads are done
 #pragma unroll
-        for (int r = 0; r < 3; ++r)
+        for (int r = R0; r < 3; ++r)
 #pragma unroll
             for (int i = 0; i < XLD; ++i) {
                 const int s = tid + i * WT;
@@ -130,8 +134,8 @@ __global__ __launch_bounds__(WT, 2) void conv3x3_wgrad_kernel(WgradArgs p) {
         for (int k = 0; k < ksteps; ++k) {
             const float bv = bp[k * 128];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int kh = t / 3, kw = t - kh * 3;
+            for (int t = 0; t < TAPS; ++t) {
+                const int kh = (TAPS == 4) ? 1 + (t >> 1) : t / 3, kw = (TAPS == 4) ? 1 + (t & 1) : t - (t / 3) * 3;
                 const float av = ap[(kh * XCOLS + kw) * 64 + k * 128];
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
             }
@@ -139,10 +143,10 @@ __global__ __launch_bounds__(WT, 2) void conv3x3_wgrad_kernel(WgradArgs p) {
     }
 
     // ---- partial tile -> workspace [split][tap][ci][co]
-    float* out = p.ws + (size_t)split * 9 * p.Cin * p.Cout;
+    float* out = p.ws + (size_t)split * TAPS * p.Cin * p.Cout;
     const int co = co0 + nco;
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < TAPS; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int ci = ci0 + (wave & 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hk;
@@ -152,14 +156,15 @@ __global__ __launch_bounds__(WT, 2) void conv3x3_wgrad_kernel(WgradArgs p) {
 
 // dW[co][ci][kh][kw] (+)= sum_split ws[split][tap][ci][co]; one thread per (tap, ci, co), co fastest.
 __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Cin, int Cout, int splits,
-                                    int accumulate, int cin_real) {
-    const size_t n = (size_t)9 * Cin * Cout;
+                                    int accumulate, int cin_real, int taps) {
+    const size_t n = (size_t)taps * Cin * Cout;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
     const int co = idx % Cout;
     const size_t t = idx / Cout;
     const int ci = t % Cin;
-    const int tap = (int)(t / Cin);
+    int tap = (int)(t / Cin);
+    if (taps == 4) tap = (1 + (tap >> 1)) * 3 + 1 + (tap & 1);      // 2x2 sub-window -> its place in the 3x3 filter
     float s = 0.f;
     for (int k = 0; k < splits; ++k) s += ws[(size_t)k * n + idx];
     if (ci >= cin_real) return;   // zero-padded input channels have no weight
@@ -284,8 +289,8 @@ long long witw_conv3x3_wgrad_workspace_floats(int B, int H, int W, int Cin, int 
 // x [B,H,W,Cin] NHWC (the conv's input), dz [B,Ho,W,Cout] NHWC (gradient at its output),
 // dw [Cout][cin_real][3][3] (torch layout; Cin is the NHWC-padded channel count of x, cin_real <= Cin),
 // db [Cout] or NULL. accumulate != 0 adds to dw/db instead of overwriting.
-int witw_conv3x3_wgrad(const float* x, const float* dz, float* dw, float* db, float* workspace, int B, int H, int W, int Cin,
-                       int cin_real, int Cout, int stride_h, int pad_circular, int accumulate, void* stream) {
+static int wgrad_launch(const float* x, const float* dz, float* dw, float* db, float* workspace, int B, int H, int W, int Cin,
+                        int cin_real, int Cout, int stride_h, int pad_circular, int accumulate, int taps, void* stream) {
     WITW_CHECK_ARG(x && dz && dw && workspace, "conv3x3_wgrad: null pointer");
     WITW_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv3x3_wgrad: bad shape");
     WITW_CHECK_ARG((Cin % 4) == 0 && (Cout % 4) == 0, "conv3x3_wgrad: Cin=%d and Cout=%d must be multiples of 4", Cin, Cout);
@@ -303,14 +308,24 @@ int witw_conv3x3_wgrad(const float* x, const float* dz, float* dw, float* db, fl
     a.chunks = B * a.Ho * a.nseg;
     const int splits = witw_conv3x3_wgrad_splits(B, a.Ho, a.Wo, Cin, Cout);
     a.cps = cdiv(a.chunks, splits);
-    hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3(cdiv(Cin, 64), cdiv(Cout, 64), splits), dim3(WT), 0, st, a);
+    const dim3 grid(cdiv(Cin, 64), cdiv(Cout, 64), splits);
+    if (taps == 4) {
+        // the five taps outside the 2x2 sub-window get an exact zero gradient
+        if (!accumulate && hipMemsetAsync(dw, 0, sizeof(float) * (size_t)Cout * cin_real * 9, st) != hipSuccess) {
+            witw_set_error("conv3x3_wgrad_taps4: memset failed");
+            return WITW_ERR_LAUNCH;
+        }
+        hipLaunchKernelGGL(conv3x3_wgrad_kernel<4>, grid, dim3(WT), 0, st, a);
+    } else {
+        hipLaunchKernelGGL(conv3x3_wgrad_kernel<9>, grid, dim3(WT), 0, st, a);
+    }
     WITW_CHECK_LAUNCH("conv3x3_wgrad");
-    const size_t n = (size_t)9 * Cin * Cout;
+    const size_t n = (size_t)taps * Cin * Cout;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, workspace, dw, Cin, Cout,
-                       splits, accumulate, cin_real);
+                       splits, accumulate, cin_real, taps);
     WITW_CHECK_LAUNCH("wgrad_reduce");
     if (db != nullptr) {
-        float* part = workspace + (size_t)splits * n;
+        float* part = workspace + (size_t)splits * 9 * Cin * Cout;
         const size_t npix = (size_t)B * a.Ho * a.Wo;
         const int rows = bias_rows_per_block(npix);
         const int nparts = (int)((npix + rows - 1) / rows);
@@ -323,6 +338,19 @@ int witw_conv3x3_wgrad(const float* x, const float* dz, float* dw, float* db, fl
         WITW_CHECK_LAUNCH("bias_grad");
     }
     return WITW_OK;
+}
+
+int witw_conv3x3_wgrad(const float* x, const float* dz, float* dw, float* db, float* workspace, int B, int H, int W, int Cin,
+                       int cin_real, int Cout, int stride_h, int pad_circular, int accumulate, void* stream) {
+    return wgrad_launch(x, dz, dw, db, workspace, B, H, W, Cin, cin_real, Cout, stride_h, pad_circular, accumulate, 9, stream);
+}
+
+// Weight gradient of the 2x2 sub-window form (witw_conv3x3_fwd_taps4 with tap_base = 1, zero padding): only the taps
+// (kh, kw) in {1,2}^2 of dw [Cout][cin_real][3][3] are computed, the other five are set to exact zeros. Same workspace
+// as witw_conv3x3_wgrad (stride 1).
+int witw_conv3x3_wgrad_taps4(const float* x, const float* dz, float* dw, float* db, float* workspace, int B, int H, int W,
+                             int Cin, int cin_real, int Cout, int accumulate, void* stream) {
+    return wgrad_launch(x, dz, dw, db, workspace, B, H, W, Cin, cin_real, Cout, 1, 0, accumulate, 4, stream);
 }
 
 int witw_maxpool2x2_bwd(const float* dy, const unsigned char* code, float* dx, int B, int Hp, int Wp, int H, int W, int C,

@@ -185,7 +185,7 @@ class SurfaceEncoder(nn.Module):
                     for b in range(2):
                         blk = w[:, :, 2 * a:2 * a + 2, 2 * b:2 * b + 2]                 # [co,ci,dy,dx]
                         k3[:, :4 * ci, a + 1, b + 1] = blk.permute(0, 2, 3, 1).reshape(co, 4 * ci)
-                packed = ops.PackedConv(k3, conv.bias)
+                packed = ops.PackedConv(k3, conv.bias, taps4=True)      # only the 2x2 live taps are packed and multiplied
                 scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)               # eval-mode BatchNorm2d
                 shift = bn.bias - bn.running_mean * scale
             hit = (key, packed, scale.contiguous(), shift.contiguous(), cpad, k3)
@@ -277,7 +277,7 @@ class _BaselineEncoderFn(torch.autograd.Function):
                     ops.gem_pool_bwd(a, scale, shift, g, dg, valid, 512 * (i - 5), enc.p, out=dy)
             dz, dgamma, dbeta = ops.bn_lrelu_bwd(a, dy, valid, mean, invstd, bn.weight, 0.2)
             k3 = enc._layer_k3(i)
-            dk3, dbias = ops.conv3x3_wgrad(h, dz, k3.shape[1], stride_h=1, circular=False)
+            dk3, dbias = ops.conv3x3_wgrad(h, dz, k3.shape[1], stride_h=1, circular=False, taps4=True)
             co, ci = conv.weight.shape[:2]
             dw = torch.empty_like(conv.weight)
             for ta in range(2):
@@ -286,7 +286,7 @@ class _BaselineEncoderFn(torch.autograd.Function):
                     dw[:, :, 2 * ta:2 * ta + 2, 2 * tb:2 * tb + 2] = blk
             grads[4 * (i - 1):4 * i] = [dw, dbias, dgamma, dbeta]
             if i > 1:
-                dx_s2d = ops.conv3x3_fwd(dz, ops.PackedConv(k3, None, transpose_flip=True), relu=False)
+                dx_s2d = ops.conv3x3_fwd(dz, ops.PackedConv(k3, None, transpose_flip=True, taps4=True), relu=False)
         ctx.saved = ctx.g = None
         return (None, None) + tuple(grads)
 

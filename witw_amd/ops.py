@@ -33,9 +33,11 @@ def _p(t):
 
 class PackedConv:
     """Weights of one 3x3 conv packed for the MFMA kernel ([n_tile][cin/8][tap][quad][TN][4])
-    plus the zero-padded bias. `transpose_flip` packs the dgrad filter of the same weights."""
+    plus the zero-padded bias. `transpose_flip` packs the dgrad filter of the same weights. `taps4` packs only the
+    2x2 sub-window that is live in a filter whose first tap row/column are zero (cvig_baseline's 4x4/s2 convs over the
+    space-to-depth image; with transpose_flip: the dgrad filter, whose LAST row/column are zero) for the 4-tap kernels."""
 
-    def __init__(self, weight, bias, transpose_flip=False):
+    def __init__(self, weight, bias, transpose_flip=False, taps4=False):
         lib = _lib.load()
         w = _dev_f32(weight.detach(), 'weight')
         if transpose_flip:
@@ -44,10 +46,16 @@ class PackedConv:
             cout, cin = w.shape[0], w.shape[1]
         self.cout, self.cin = cout, cin
         self.cin_pad = (cin + 7) // 8 * 8
-        n = lib.witw_conv3x3_packed_floats(cout, cin)
-        self.wpk = torch.empty(n, dtype=torch.float32, device=w.device)
-        _lib.check(lib.witw_conv3x3_pack_weights(w.data_ptr(), self.wpk.data_ptr(), cout, cin, int(transpose_flip),
-                                                 _stream()), 'witw_conv3x3_pack_weights')
+        self.taps4 = bool(taps4)
+        self.tap_base = 0 if transpose_flip else 1
+        if taps4:
+            self.wpk = torch.empty(lib.witw_conv3x3_packed_floats_taps4(cout, cin), dtype=torch.float32, device=w.device)
+            _lib.check(lib.witw_conv3x3_pack_weights_taps4(w.data_ptr(), self.wpk.data_ptr(), cout, cin, int(transpose_flip),
+                                                           _stream()), 'witw_conv3x3_pack_weights_taps4')
+        else:
+            self.wpk = torch.empty(lib.witw_conv3x3_packed_floats(cout, cin), dtype=torch.float32, device=w.device)
+            _lib.check(lib.witw_conv3x3_pack_weights(w.data_ptr(), self.wpk.data_ptr(), cout, cin, int(transpose_flip),
+                                                     _stream()), 'witw_conv3x3_pack_weights')
         nb = lib.witw_conv3x3_bias_floats(cout)
         self.bias = torch.zeros(nb, dtype=torch.float32, device=w.device)
         if bias is not None and not transpose_flip:
@@ -142,15 +150,22 @@ def conv3x3_fwd(x_nhwc, packed, stride_h=1, circular=False, relu=True, pool=Fals
         if post_scale.numel() != packed.cout or post_shift.numel() != packed.cout:
             raise _lib.WitwError('post_scale/post_shift must have Cout entries')
     code = torch.empty(shape, dtype=torch.uint8, device=x.device) if (pool and want_pool_code) else None
-    _lib.check(lib.witw_conv3x3_fwd_ex(x.data_ptr(), packed.wpk.data_ptr(), packed.bias.data_ptr(), _p(drop_scale),
-                                       _p(gate), _p(post_scale), _p(post_shift), y.data_ptr(), _p(code), B, H, W, C, packed.cout,
-                                       stride_h, int(circular), act, float(lrelu_slope or 0.), int(pool), int(out_nchw),
-                                       int(bool(dilate_h)), _stream()), 'witw_conv3x3_fwd_ex')
+    if getattr(packed, 'taps4', False):
+        if stride_h != 1 or circular or pool or out_nchw or dilate_h or drop_scale is not None:
+            raise _lib.WitwError('conv3x3_fwd: a taps4-packed filter runs stride 1, zero padding, NHWC out, no pool / dropout')
+        _lib.check(lib.witw_conv3x3_fwd_taps4(x.data_ptr(), packed.wpk.data_ptr(), packed.bias.data_ptr(), _p(gate),
+                                              _p(post_scale), _p(post_shift), y.data_ptr(), B, H, W, C, packed.cout, act,
+                                              float(lrelu_slope or 0.), packed.tap_base, _stream()), 'witw_conv3x3_fwd_taps4')
+    else:
+        _lib.check(lib.witw_conv3x3_fwd_ex(x.data_ptr(), packed.wpk.data_ptr(), packed.bias.data_ptr(), _p(drop_scale),
+                                           _p(gate), _p(post_scale), _p(post_shift), y.data_ptr(), _p(code), B, H, W, C,
+                                           packed.cout, stride_h, int(circular), act, float(lrelu_slope or 0.), int(pool),
+                                           int(out_nchw), int(bool(dilate_h)), _stream()), 'witw_conv3x3_fwd_ex')
     if prof is not None:
         e1.record()
         variant = (lib.witw_conv3x3_tile_n(packed.cout), stride_h, bool(pool),
                    lib.witw_conv3x3_workgroup_waves(B, H, W, packed.cout, stride_h))
-        prof.append((variant, 2.0 * packed.cin * packed.cout * 9 * Ho * W * B, e0, e1))
+        prof.append((variant, 2.0 * packed.cin * packed.cout * (4 if getattr(packed, 'taps4', False) else 9) * Ho * W * B, e0, e1))
     if want_pool_code:
         return y, code
     return y
@@ -168,8 +183,9 @@ def maxpool2x2_bwd(dy, code, out_hw):
     return dx
 
 
-def conv3x3_wgrad(x_nhwc, dz_nhwc, cin_real, stride_h=1, circular=False, want_bias=True):
-    """-> (dW [Cout,cin_real,3,3], db [Cout] or None) for one conv layer."""
+def conv3x3_wgrad(x_nhwc, dz_nhwc, cin_real, stride_h=1, circular=False, want_bias=True, taps4=False):
+    """-> (dW [Cout,cin_real,3,3], db [Cout] or None) for one conv layer. taps4: only the taps {1,2}^2 are computed
+    (filters whose first tap row/column are structurally zero), the others come back as exact zeros."""
     lib = _lib.load()
     x = _dev_f32(x_nhwc, 'x')
     dz = _dev_f32(dz_nhwc, 'dz')
@@ -182,8 +198,14 @@ def conv3x3_wgrad(x_nhwc, dz_nhwc, cin_real, stride_h=1, circular=False, want_bi
     db = torch.empty((Cout,), dtype=torch.float32, device=x.device) if want_bias else None
     ws = torch.empty(lib.witw_conv3x3_wgrad_workspace_floats(B, H, W, Cin, Cout, stride_h), dtype=torch.float32,
                      device=x.device)
-    _lib.check(lib.witw_conv3x3_wgrad(x.data_ptr(), dz.data_ptr(), dw.data_ptr(), _p(db), ws.data_ptr(), B, H, W, Cin,
-                                      cin_real, Cout, stride_h, int(circular), 0, _stream()), 'witw_conv3x3_wgrad')
+    if taps4:
+        if stride_h != 1 or circular:
+            raise _lib.WitwError('conv3x3_wgrad: taps4 runs stride 1 with zero padding')
+        _lib.check(lib.witw_conv3x3_wgrad_taps4(x.data_ptr(), dz.data_ptr(), dw.data_ptr(), _p(db), ws.data_ptr(), B, H, W, Cin,
+                                                cin_real, Cout, 0, _stream()), 'witw_conv3x3_wgrad_taps4')
+    else:
+        _lib.check(lib.witw_conv3x3_wgrad(x.data_ptr(), dz.data_ptr(), dw.data_ptr(), _p(db), ws.data_ptr(), B, H, W, Cin,
+                                          cin_real, Cout, stride_h, int(circular), 0, _stream()), 'witw_conv3x3_wgrad')
     return dw, db
 
 
