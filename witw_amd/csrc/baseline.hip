@@ -167,6 +167,52 @@ __global__ __launch_bounds__(256) void channel_sums_kernel(const float* __restri
     }
 }
 
+// The same sums for channel counts with C % 4 == 0 and (C/4) | 256 (every layer of the reference's encoders): a block
+// owns whole image rows (b, h) so the inner loop has no index arithmetic, a thread owns one channel quad (16-byte loads,
+// a wave reads 1 KB contiguous) and every (256 / (C/4))-th pixel of the row; fixed-order combination through LDS.
+__global__ __launch_bounds__(256) void channel_sums_rows_kernel(const float* __restrict__ a, const float* __restrict__ g,
+                                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                 float* __restrict__ part, int Hp, int Wp, int H, int W, int C,
+                                                                 int nrows, int rows_per_block) {
+    __shared__ f32x4 sh[2][256];
+    const int Q = C >> 2, phases = 256 / Q;
+    const int q = threadIdx.x % Q, ph = threadIdx.x / Q;
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(nrows, r0 + rows_per_block);
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 mu = {0.f, 0.f, 0.f, 0.f}, is = {0.f, 0.f, 0.f, 0.f};
+    if (g) {
+        mu = *reinterpret_cast<const f32x4*>(mean + 4 * q);
+        is = *reinterpret_cast<const f32x4*>(invstd + 4 * q);
+    }
+    for (int r = r0; r < r1; ++r) {
+        const int b = r / H, h = r - b * H;
+        const size_t row = ((size_t)b * Hp + h) * Wp * C + 4 * q;
+        for (int w = ph; w < W; w += phases) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(a + row + (size_t)w * C);
+            if (g) {
+                const f32x4 gv = *reinterpret_cast<const f32x4*>(g + row + (size_t)w * C);
+                s0 += gv;
+                s1 += gv * ((v - mu) * is);
+            } else {
+                s0 += v;
+                s1 += v * v;
+            }
+        }
+    }
+    sh[0][threadIdx.x] = s0;
+    sh[1][threadIdx.x] = s1;
+    __syncthreads();
+    if (threadIdx.x < Q) {
+        f32x4 t0 = sh[0][threadIdx.x], t1 = sh[1][threadIdx.x];
+        for (int k = 1; k < phases; ++k) {
+            t0 += sh[0][k * Q + threadIdx.x];
+            t1 += sh[1][k * Q + threadIdx.x];
+        }
+        *reinterpret_cast<f32x4*>(part + ((size_t)blockIdx.x * 2 + 0) * C + 4 * threadIdx.x) = t0;
+        *reinterpret_cast<f32x4*>(part + ((size_t)blockIdx.x * 2 + 1) * C + 4 * threadIdx.x) = t1;
+    }
+}
+
 // BatchNorm2d training statistics: mean / biased var -> scale = gamma*invstd, shift = beta - mean*scale, and the
 // running-stat update running = (1-m)*running + m*stat (unbiased variance), torch semantics.
 __global__ void bn_stats_finish_kernel(const float* __restrict__ part, int nparts, int C, float n, const float* __restrict__ gamma,
@@ -408,10 +454,32 @@ static int bl_rows(size_t npix) {
     return (int)(r < 64 ? 64 : r);
 }
 
+// row-based sums (channel_sums_rows_kernel): image rows per block for ~1024 blocks, and whether C qualifies
+static int bl_rows_per_block(int nrows) { return cdiv(nrows, 1024); }
+static bool bl_wide(int C) { return (C % 4) == 0 && C >= 4 && C <= 1024 && (256 % (C / 4)) == 0; }
+
+// launches the partial sums; returns the number of partials written
+static int bl_launch_sums(const float* a, const float* g, const float* mean, const float* invstd, float* part, int B, int Hp,
+                          int Wp, int H, int W, int C, hipStream_t st) {
+    const size_t npix = (size_t)B * H * W;
+    if (bl_wide(C)) {
+        const int nrows = B * H, rpb = bl_rows_per_block(nrows), nparts = cdiv(nrows, rpb);
+        hipLaunchKernelGGL(channel_sums_rows_kernel, dim3(nparts), dim3(256), 0, st, a, g, mean, invstd, part, Hp, Wp, H, W, C,
+                           nrows, rpb);
+        return nparts;
+    }
+    const int rows = bl_rows(npix), nparts = (int)((npix + rows - 1) / rows);
+    hipLaunchKernelGGL(channel_sums_kernel, dim3(cdiv(C, 64), nparts), dim3(256), 0, st, a, g, mean, invstd, part, Hp, Wp, H, W, C,
+                       npix, rows);
+    return nparts;
+}
+
 long long witw_bn_workspace_floats(int B, int H, int W, int C) {
     const size_t npix = (size_t)B * H * W;
     const int rows = bl_rows(npix);
-    return (long long)((npix + rows - 1) / rows) * 2 * C + 2 * C;
+    long long nparts = (long long)((npix + rows - 1) / rows);
+    if (nparts < 1024) nparts = 1024;          // the row-based form writes at most 1024 partials
+    return nparts * 2 * C + 2 * C;
 }
 
 // Batch statistics of BatchNorm2d over the valid region of a [B,Hp,Wp,C] tensor -> mean, invstd, and the affine
@@ -424,9 +492,7 @@ int witw_bn_train_stats(const float* a, int B, int Hp, int Wp, int H, int W, int
     WITW_CHECK_ARG((size_t)B * H * W > 1, "bn_train_stats: needs more than one value per channel");
     hipStream_t st = (hipStream_t)stream;
     const size_t npix = (size_t)B * H * W;
-    const int rows = bl_rows(npix), nparts = (int)((npix + rows - 1) / rows);
-    hipLaunchKernelGGL(channel_sums_kernel, dim3(cdiv(C, 64), nparts), dim3(256), 0, st, a, (const float*)nullptr,
-                       (const float*)nullptr, (const float*)nullptr, workspace, Hp, Wp, H, W, C, npix, rows);
+    const int nparts = bl_launch_sums(a, nullptr, nullptr, nullptr, workspace, B, Hp, Wp, H, W, C, st);
     hipLaunchKernelGGL(bn_stats_finish_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, workspace, nparts, C, (float)npix, gamma, beta,
                        eps, momentum, mean, invstd, scale, shift, running_mean, running_var);
     WITW_CHECK_LAUNCH("bn_train_stats");
@@ -441,10 +507,8 @@ int witw_bn_lrelu_bwd(const float* a, const float* dy, float* dz, float* dgamma,
     WITW_CHECK_ARG(B > 0 && C > 0 && H > 0 && W > 0 && H <= Hp && W <= Wp, "bn_lrelu_bwd: bad shape");
     hipStream_t st = (hipStream_t)stream;
     const size_t npix = (size_t)B * H * W;
-    const int rows = bl_rows(npix), nparts = (int)((npix + rows - 1) / rows);
+    const int nparts = bl_launch_sums(a, dy, mean, invstd, workspace, B, Hp, Wp, H, W, C, st);
     float* sums = workspace + (size_t)nparts * 2 * C;
-    hipLaunchKernelGGL(channel_sums_kernel, dim3(cdiv(C, 64), nparts), dim3(256), 0, st, a, dy, mean, invstd, workspace, Hp, Wp, H, W,
-                       C, npix, rows);
     hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, workspace, nparts, C, sums, dgamma, dbeta);
     const size_t total = (size_t)B * Hp * Wp * C;
     hipLaunchKernelGGL(bn_lrelu_bwd_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a, dy, dz, mean, invstd,
