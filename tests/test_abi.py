@@ -49,6 +49,19 @@ def test_version_and_argument_errors_without_gpu():
     assert rc == -1 and b'batch' in lib.witw_last_error()
     with pytest.raises(_lib.WitwError):
         _lib.check(rc, 'witw_triplet_loss_fwd')
+    # the bf16 training and 4-tap entry points validate the same way
+    assert lib.witw_octet_elems(10, 2, 3, 8) == 16 * 2 * 3 * 8
+    assert lib.witw_conv3x3_packed_floats_taps4(64, 16) == 1 * 2 * 4 * 2 * 64 * 4
+    rc = lib.witw_conv3x3_bf16_fwd_ex(1, 1, 1, None, 1, 1, None, 1, 4, 4, 16, 64, 1, 0, 0, 1, 0, 0, None)
+    assert rc == -1 and b'gate' in lib.witw_last_error()
+    rc = lib.witw_conv3x3_wgrad_bf16(1, 1, 1, None, 1, 8, 4, 4, 12, 12, 64, 1, 0, 0, None)
+    assert rc == -1 and b'multiples of 8' in lib.witw_last_error()
+    rc = lib.witw_nhwc_bf16_to_octet(1, 1, 8, 4, 4, 12, None)
+    assert rc == -1 and b'multiple of 8' in lib.witw_last_error()
+    rc = lib.witw_conv3x3_fwd_taps4(1, 1, 1, None, None, None, 1, 1, 4, 4, 8, 64, 0, 0.0, 2, None)
+    assert rc == -1 and b'tap_base' in lib.witw_last_error()
+    rc = lib.witw_maxpool2x2_bwd_bf16(1, 1, 1, 1, 2, 2, 3, 4, 8, None)
+    assert rc == -1 and b'bad shape' in lib.witw_last_error()
 
 
 def test_product_never_imports_the_oracle():
@@ -70,3 +83,7 @@ def test_product_refuses_cpu_tensors():
         cvig_fov.FOV_DSM()(torch.zeros(1, 3, 128, 512))
     with pytest.raises(_lib.WitwError):
         ops.polar_transform(torch.zeros(1, 3, 256, 256))
+    with pytest.raises(_lib.WitwError):
+        ops.conv3x3_wgrad_bf16(torch.zeros(8, 4, 4, 16, dtype=torch.bfloat16), torch.zeros(8, 4, 4, 16, dtype=torch.bfloat16), 16)
+    with pytest.raises(_lib.WitwError):
+        ops.nhwc_bf16_to_octet(torch.zeros(8, 4, 4, 16, dtype=torch.bfloat16))
