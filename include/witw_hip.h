@@ -94,9 +94,13 @@ long long witw_match_workspace_floats(int Bo, int Bs);
 int witw_match_fwd(const float* ov, const float* su, int Bo, int Bs, int We, long long* orientation, float* distance,
                    float* score, float* workspace, void* stream);
 /* backward of witw_match_fwd (orientation is a constant of the graph): grad_distance [Bo,Bs] ->
- * grad_ov [Bo,16,4,64] and/or grad_su [Bs,16,4,We]; orientation/score/workspace as left by the forward. */
+ * grad_ov [Bo,16,4,64] and/or grad_su [Bs,16,4,We]; orientation/score/workspace as left by the forward. scratch: NULL,
+ * or witw_match_bwd_scratch_floats(Bo,Bs,We) floats that let the surface gradient split the overheads over several
+ * workgroups per surface (fixed-order sum; a batch of 128 surfaces alone leaves half the chip idle). */
+long long witw_match_bwd_scratch_floats(int Bo, int Bs, int We);
 int witw_match_bwd(const float* ov, const float* su, const long long* orientation, const float* score, const float* workspace,
-                   const float* grad_distance, float* grad_ov, float* grad_su, int Bo, int Bs, int We, void* stream);
+                   const float* grad_distance, float* grad_ov, float* grad_su, float* scratch, int Bo, int Bs, int We,
+                   void* stream);
 /* compatibility entries with the reference's materialising semantics */
 int witw_crop_overhead(const float* ov, const long long* orientation, float* out /*[Bo,Bs,16,4,We]*/, int Bo, int Bs,
                        int We, void* stream);

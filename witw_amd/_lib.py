@@ -59,7 +59,8 @@ SIGNATURES = {
     'witw_embed_normalize': (c_int, [c_void_p, c_int, c_int, c_void_p]),
     'witw_pairwise_sqdist': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'witw_exhaustive_triplet_loss': (c_int, [c_void_p, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p]),
-    'witw_match_bwd': (c_int, [c_void_p] * 8 + [c_int] * 3 + [c_void_p]),
+    'witw_match_bwd_scratch_floats': (c_longlong, [c_int, c_int, c_int]),
+    'witw_match_bwd': (c_int, [c_void_p] * 9 + [c_int] * 3 + [c_void_p]),
     'witw_match_workspace_floats': (c_longlong, [c_int, c_int]),
     'witw_match_fwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'witw_crop_overhead': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

@@ -30,31 +30,34 @@ struct MatchArgs {
     int Bo, Bs, We;
 };
 
-// OPW = overhead images per wave (1 or 2); a block covers 2*OPW overheads x 128 surfaces.
-template <int OPW>
+// OPW = overhead images per wave (1 or 2), MT = 32-surface M-tiles per wave (2, or 1 for batches too small to fill the
+// chip with 128-surface blocks); a block covers 2*OPW overheads x 64*MT surfaces.
+template <int OPW, int MT>
 __global__ __launch_bounds__(NT) void match_kernel(MatchArgs p) {
     constexpr int MO = 2 * OPW;
-    constexpr int SU_F = MS * SUS;       // floats per surface stage
+    constexpr int MSB = 64 * MT;         // surfaces per block
+    constexpr int SU_F = MSB * SUS;      // floats per surface stage
+    constexpr int RPW = MSB / 4;         // surface rows staged per wave
     constexpr int OV_F = MO * 128;       // floats per overhead stage
     __shared__ float smem[2 * (SU_F + OV_F)];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hk = lane >> 5;
-    const int s0 = blockIdx.x * MS;
+    const int s0 = blockIdx.x * MSB;
     const int o0 = blockIdx.y * MO;
     const int We = p.We;
     const int Wp = (We + 1) & ~1;        // K per row padded to the MFMA k-step of 2
-    const int wm = wave >> 1;            // surface half: rows [64*wm, 64*wm+64)
+    const int wm = wave >> 1;            // surface half: rows [32*MT*wm, 32*MT*(wm+1))
     const int wo = wave & 1;             // overhead group: local overheads [OPW*wo, OPW*wo+OPW)
 
     // staging roles: lane <-> k within a row, (wave + 4*i) <-> surface row
     const bool kin = lane < We;
-    float rsu[32];
+    float rsu[RPW];
     float rov = 0.f;
     const int ovo = tid >> 6, ovw = tid & 63;   // overhead staging: thread -> (local overhead, column)
     auto load_stage = [&](int r) {
 #pragma unroll
-        for (int i = 0; i < 32; ++i) {
+        for (int i = 0; i < RPW; ++i) {
             const int s = s0 + wave + 4 * i;
             float v = 0.f;
             if (kin && s < p.Bs) v = p.su[((size_t)s * 64 + r) * We + lane];
@@ -68,7 +71,7 @@ __global__ __launch_bounds__(NT) void match_kernel(MatchArgs p) {
         float* ov_s = su_s + SU_F;
         if (lane < Wp) {
 #pragma unroll
-            for (int i = 0; i < 32; ++i) su_s[(wave + 4 * i) * SUS + lane] = rsu[i];
+            for (int i = 0; i < RPW; ++i) su_s[(wave + 4 * i) * SUS + lane] = rsu[i];
         }
         if (ovo < MO) {
             ov_s[ovo * 128 + ovw] = rov;
@@ -76,9 +79,9 @@ __global__ __launch_bounds__(NT) void match_kernel(MatchArgs p) {
         }
     };
 
-    f32x16 acc[2][OPW][2];
+    f32x16 acc[MT][OPW][2];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < MT; ++a)
 #pragma unroll
         for (int b = 0; b < OPW; ++b)
 #pragma unroll
@@ -90,7 +93,7 @@ __global__ __launch_bounds__(NT) void match_kernel(MatchArgs p) {
     store_stage(0);
     __syncthreads();
 
-    const int arow0 = (64 * wm + l31) * SUS + hk;
+    const int arow0 = (32 * MT * wm + l31) * SUS + hk;
     const int arow1 = arow0 + 32 * SUS;
     const int bcol = OPW * wo * 128 + l31 + hk;
     for (int r = 0; r < 64; ++r) {
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(NT) void match_kernel(MatchArgs p) {
 #pragma unroll 4
         for (int k = 0; k < Wp; k += 2) {
             const float a0 = su_s[arow0 + k];
-            const float a1 = su_s[arow1 + k];
+            const float a1 = (MT == 2) ? su_s[arow1 + k] : 0.f;
             float b[OPW][2];
 #pragma unroll
             for (int o = 0; o < OPW; ++o) {
@@ -113,7 +116,7 @@ __global__ __launch_bounds__(NT) void match_kernel(MatchArgs p) {
 #pragma unroll
                 for (int n = 0; n < 2; ++n) {
                     acc[0][o][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b[o][n], acc[0][o][n], 0, 0, 0);
-                    acc[1][o][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b[o][n], acc[1][o][n], 0, 0, 0);
+                    if (MT == 2) acc[MT - 1][o][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b[o][n], acc[MT - 1][o][n], 0, 0, 0);
                 }
         }
         if (r + 1 < 64) store_stage(cur ^ 1);
@@ -122,7 +125,7 @@ __global__ __launch_bounds__(NT) void match_kernel(MatchArgs p) {
 
     // ---- epilogue: arg-max over the 64 shifts (2 N-tiles x 32 lanes), first index wins ties
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int o = 0; o < OPW; ++o) {
             const int og = o0 + OPW * wo + o;
@@ -138,7 +141,7 @@ __global__ __launch_bounds__(NT) void match_kernel(MatchArgs p) {
                     const int io = __shfl_xor(idx, d, 64);
                     if (vo > v || (vo == v && io < idx)) { v = vo; idx = io; }
                 }
-                const int srow = s0 + 64 * wm + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hk;
+                const int srow = s0 + 32 * MT * wm + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hk;
                 if (l31 == r && og < p.Bo && srow < p.Bs) {
                     const size_t off = (size_t)og * p.Bs + srow;
                     if (p.orientation) p.orientation[off] = idx;
@@ -597,12 +600,16 @@ __global__ __launch_bounds__(256) void match_bwd_su_kernel(const float* __restri
                                                             const long long* __restrict__ ori, const float* __restrict__ score,
                                                             const float* __restrict__ wn, const float* __restrict__ sn,
                                                             const float* __restrict__ gD, float* __restrict__ gsu, int Bo,
-                                                            int Bs, int We) {
+                                                            int Bs, int We, int o_per_split, float* __restrict__ scratch) {
+    // grid (Bs, splits): split y sums the overheads [y*o_per_split, (y+1)*o_per_split). With one split the result goes
+    // straight to gsu; otherwise partial sums [y][s][E] and the partial self terms [splits][Bs] behind them go to
+    // scratch and match_bwd_su_finish_kernel adds them in a fixed order (a small batch has too few surfaces to fill the chip).
     __shared__ float coef[256];
     __shared__ int rot[256];
     __shared__ float part[4];
     const int s = blockIdx.x, tid = threadIdx.x;
     const int E = 64 * We;
+    const int o_begin = blockIdx.y * o_per_split, o_end = min(Bo, o_begin + o_per_split);
     const float sns = sn[s];
     int ch[16], kk[16];
     float acc[16];
@@ -614,10 +621,10 @@ __global__ __launch_bounds__(256) void match_bwd_su_kernel(const float* __restri
         acc[i] = 0.f;
     }
     float self = 0.f;   // sum_o gD*2c/(wn*sn^3), accumulated by thread 0..255 over its o's then reduced
-    for (int o0 = 0; o0 < Bo; o0 += 256) {
+    for (int o0 = o_begin; o0 < o_end; o0 += 256) {
         const int o = o0 + tid;
         __syncthreads();
-        if (o < Bo) {
+        if (o < o_end) {
             const size_t off = (size_t)o * Bs + s;
             const int t = (int)ori[off];
             const float w = wn[(size_t)o * 64 + t];
@@ -627,7 +634,7 @@ __global__ __launch_bounds__(256) void match_bwd_su_kernel(const float* __restri
             self += g * (2.f * score[off] / (w * sns * sns * sns));
         }
         __syncthreads();
-        const int n = min(256, Bo - o0);
+        const int n = min(256, o_end - o0);
         for (int j = 0; j < n; ++j) {
             const float a = coef[j];
             const int t = rot[j];
@@ -643,11 +650,34 @@ __global__ __launch_bounds__(256) void match_bwd_su_kernel(const float* __restri
     if ((tid & 63) == 0) part[tid >> 6] = self;
     __syncthreads();
     const float selfsum = (part[0] + part[1]) + (part[2] + part[3]);
+    if (gridDim.y == 1) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int e = tid + 256 * i;
-        if (e < E) gsu[(size_t)s * E + e] = acc[i] + su[(size_t)s * E + e] * selfsum;
+        for (int i = 0; i < 16; ++i) {
+            const int e = tid + 256 * i;
+            if (e < E) gsu[(size_t)s * E + e] = acc[i] + su[(size_t)s * E + e] * selfsum;
+        }
+    } else {
+        float* dst = scratch + ((size_t)blockIdx.y * Bs + s) * E;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int e = tid + 256 * i;
+            if (e < E) dst[e] = acc[i];
+        }
+        if (tid == 0) scratch[(size_t)gridDim.y * Bs * E + (size_t)blockIdx.y * Bs + s] = selfsum;
     }
+}
+
+__global__ __launch_bounds__(256) void match_bwd_su_finish_kernel(const float* __restrict__ su, const float* __restrict__ scratch,
+                                                                   float* __restrict__ gsu, int Bs, int E, int splits) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)Bs * E) return;
+    const int s = (int)(idx / E);
+    float a = 0.f, self = 0.f;
+    for (int y = 0; y < splits; ++y) {
+        a += scratch[(size_t)y * Bs * E + idx];
+        self += scratch[(size_t)splits * Bs * E + (size_t)y * Bs + s];
+    }
+    gsu[idx] = a + su[idx] * self;
 }
 
 __global__ __launch_bounds__(256) void match_bwd_ov_kernel(const float* __restrict__ ov, const float* __restrict__ su,
@@ -744,9 +774,11 @@ int witw_match_fwd(const float* ov, const float* su, int Bo, int Bs, int We, lon
     } else if (pipelined) {      // 33..62 columns: one row per stage, zero-padded to 64
         hipLaunchKernelGGL((match_kernel_rows<1>), dim3(gx, cdiv(Bo, 4)), dim3(NT), 0, st, a);
     } else if ((long long)gx * cdiv(Bo, 4) >= 512) {
-        hipLaunchKernelGGL((match_kernel<2>), dim3(gx, cdiv(Bo, 4)), dim3(NT), 0, st, a);
-    } else {
-        hipLaunchKernelGGL((match_kernel<1>), dim3(gx, cdiv(Bo, 2)), dim3(NT), 0, st, a);
+        hipLaunchKernelGGL((match_kernel<2, 2>), dim3(gx, cdiv(Bo, 4)), dim3(NT), 0, st, a);
+    } else if ((long long)gx * cdiv(Bo, 2) >= 256) {
+        hipLaunchKernelGGL((match_kernel<1, 2>), dim3(gx, cdiv(Bo, 2)), dim3(NT), 0, st, a);
+    } else {        // a single minibatch (128 x 128): 64-surface blocks double the workgroup count
+        hipLaunchKernelGGL((match_kernel<1, 1>), dim3(cdiv(Bs, 64), cdiv(Bo, 2)), dim3(NT), 0, st, a);
     }
     WITW_CHECK_LAUNCH("match_fwd");
     return WITW_OK;
@@ -754,17 +786,41 @@ int witw_match_fwd(const float* ov, const float* su, int Bo, int Bs, int We, lon
 
 // grad_distance [Bo,Bs] -> grad_ov [Bo,16,4,64], grad_su [Bs,16,4,We]. orientation / score / workspace are
 // the outputs of witw_match_fwd on the same (ov, su) (workspace must not have been overwritten).
+// Overhead splits of the surface-gradient kernel: enough (surface, split) blocks to fill the chip when the batch has few
+// surfaces (one block per surface otherwise), at least 32 overheads per split.
+static int match_bwd_splits(int Bo, int Bs) {
+    int splits = cdiv(768, Bs);
+    if (splits > cdiv(Bo, 32)) splits = cdiv(Bo, 32);
+    return splits < 1 ? 1 : splits;
+}
+
+// floats of scratch witw_match_bwd wants for grad_su (0: none needed)
+long long witw_match_bwd_scratch_floats(int Bo, int Bs, int We) {
+    if (Bo <= 0 || Bs <= 0 || We < 1 || We > 64) return -1;
+    const int splits = match_bwd_splits(Bo, Bs);
+    return splits > 1 ? (long long)splits * Bs * (64 * We + 1) : 0;
+}
+
 int witw_match_bwd(const float* ov, const float* su, const long long* orientation, const float* score, const float* workspace,
-                   const float* grad_distance, float* grad_ov, float* grad_su, int Bo, int Bs, int We, void* stream) {
+                   const float* grad_distance, float* grad_ov, float* grad_su, float* scratch, int Bo, int Bs, int We,
+                   void* stream) {
     WITW_CHECK_ARG(ov && su && orientation && score && workspace && grad_distance, "match_bwd: null pointer");
     WITW_CHECK_ARG(grad_ov || grad_su, "match_bwd: no output requested");
     WITW_CHECK_ARG(Bo > 0 && Bs > 0 && We >= 1 && We <= 64, "match_bwd: bad shape Bo=%d Bs=%d We=%d", Bo, Bs, We);
     hipStream_t st = (hipStream_t)stream;
     const float* wn = workspace;
     const float* sn = workspace + (size_t)Bo * 64;
-    if (grad_su)
-        hipLaunchKernelGGL(match_bwd_su_kernel, dim3(Bs), dim3(256), 0, st, ov, su, orientation, score, wn, sn, grad_distance,
-                           grad_su, Bo, Bs, We);
+    if (grad_su) {
+        const int splits = scratch ? match_bwd_splits(Bo, Bs) : 1;      // without scratch: one block per surface
+        const int ops = cdiv(Bo, splits);
+        hipLaunchKernelGGL(match_bwd_su_kernel, dim3(Bs, splits), dim3(256), 0, st, ov, su, orientation, score, wn, sn,
+                           grad_distance, grad_su, Bo, Bs, We, ops, scratch);
+        if (splits > 1) {
+            const size_t n = (size_t)Bs * 64 * We;
+            hipLaunchKernelGGL(match_bwd_su_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, su, scratch, grad_su,
+                               Bs, 64 * We, splits);
+        }
+    }
     if (grad_ov)
         hipLaunchKernelGGL(match_bwd_ov_kernel, dim3(Bo), dim3(256), 0, st, ov, su, orientation, score, wn, sn, grad_distance,
                            grad_ov, Bo, Bs, We);

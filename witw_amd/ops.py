@@ -227,8 +227,10 @@ def match_bwd(overhead_embed, surface_embed, orientation, score, workspace, grad
     Bo, Bs, We = ov.shape[0], su.shape[0], su.shape[3]
     gov = torch.empty_like(ov) if need_ov else None
     gsu = torch.empty_like(su) if need_su else None
+    n_scratch = lib.witw_match_bwd_scratch_floats(Bo, Bs, We) if need_su else 0
+    scratch = torch.empty(n_scratch, dtype=torch.float32, device=ov.device) if n_scratch > 0 else None
     _lib.check(lib.witw_match_bwd(ov.data_ptr(), su.data_ptr(), orientation.data_ptr(), score.data_ptr(),
-                                  workspace.data_ptr(), gd.data_ptr(), _p(gov), _p(gsu), Bo, Bs, We, _stream()),
+                                  workspace.data_ptr(), gd.data_ptr(), _p(gov), _p(gsu), _p(scratch), Bo, Bs, We, _stream()),
                'witw_match_bwd')
     return gov, gsu
 
