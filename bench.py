@@ -193,7 +193,7 @@ def main():
     conv_tf = sum(f for f, _ in allc) / (sum(m for _, m in allc) * 1e-3) / 1e12 if allc else 0.0
     traffic = None
     tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
-    if os.path.exists(tpath):
+    if os.path.exists(tpath) and a.fov == 360:      # the PMC passes were taken at fov 360 (other widths change the launch mix)
         try:
             tag = ('_bf16_train' if bf16 else '_train') if train else ''     # train modes average forward + dgrad launches
             traffic = json.load(open(tpath)).get('%s_bytes_per_launch_B%d%s' % (kname, B, tag))
