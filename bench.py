@@ -340,7 +340,15 @@ def cpu_baseline(a, ground_raw, ov_raw, wts, ws, gpu_step, semantic=False):
         su, ov, ori, d, loss, ranks = cpu_step()
         times.append(time.perf_counter() - t0)
     med = sorted(times)[1]
-    return {'value': round(n / med, 3), 'unit': 'pairs/s', 'cores': threads, 'kind': 'port',
+    cpu_model = ''
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                cpu_model = line.split(':', 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {'value': round(n / med, 3), 'unit': 'pairs/s', 'cores': threads, 'kind': 'port', 'cpu': cpu_model,
             'sample': '%d pairs of the same synthetic batch, full step (transforms+encoders+match+loss+ranks), '
                       'median of 3 after 1 warm-up, torch %s CPU ops' % (n, torch.__version__)}
 
