@@ -34,6 +34,12 @@ python3 tools/make_traffic.py 128 infer:$O/pmc_fetch_infer/p_counter_collection.
   train:$O/pmc_fetch_train/p_counter_collection.csv:$O/pmc_write_train/p_counter_collection.csv \
   bf16:$O/pmc_fetch_bf16/p_counter_collection.csv:$O/pmc_write_bf16/p_counter_collection.csv \
   bf16_train:$O/pmc_fetch_bf16_train/p_counter_collection.csv:$O/pmc_write_bf16_train/p_counter_collection.csv > $O/traffic.json
+for m in "infer:" "train:--mode train" "bf16:--precision bf16" "bf16_train:--mode train --precision bf16"; do
+  tag=${m%%:*}; flags=${m#*:}
+  rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/pmc_mfma_$tag -o p --output-format csv -- python3 bench.py $flags --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_mfma_$tag.json 2> $O/pmc_mfma_$tag.log
+done
+python3 tools/make_mfma_util.py infer:$O/pmc_mfma_infer/p_counter_collection.csv train:$O/pmc_mfma_train/p_counter_collection.csv \
+  bf16:$O/pmc_mfma_bf16/p_counter_collection.csv bf16_train:$O/pmc_mfma_bf16_train/p_counter_collection.csv > $O/mfma_util.json
 # the big per-dispatch CSVs stay on the box; only summaries come back
 rm -f $O/pmc_*/p_counter_collection.csv $O/pmc_*/p_kernel_trace.csv $O/prof*/p_kernel_trace.csv
 ls -R $O | head -80

@@ -15,4 +15,5 @@ cp $O/prof_train/p_kernel_stats.csv profiles/${R}_train_kernel_stats.csv
 cp $O/prof_bf16/p_kernel_stats.csv profiles/${R}_bench_bf16_kernel_stats.csv
 cp $O/prof_bf16_train/p_kernel_stats.csv profiles/${R}_bf16_train_kernel_stats.csv
 cp $O/traffic.json profiles/traffic.json
+cp $O/mfma_util.json profiles/mfma_util.json
 ls profiles
