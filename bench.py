@@ -121,6 +121,7 @@ def main():
     overhead_encoder.train(train)
     all_params = list(surface_encoder.parameters()) + list(overhead_encoder.parameters())
     optimizer = cvig_fov.Adam(all_params, lr=1.E-5) if train else None
+    reducer = parallel.OverlappedGradReducer([surface_encoder, overhead_encoder]) if train else None
     ground_raw, ov_raw = make_inputs(cvig_fov, ops, synth, B, a.fov, seed + rank, device, channels)
     ws = int(a.fov / 360 * 512)
     mean, std = model_mod.Globals.img_mean, model_mod.Globals.img_std
@@ -135,8 +136,8 @@ def main():
         ov = overhead_encoder(polar)
         loss, ori, d = cvig_fov.sharded_match_loss(ov, su)       # global-batch loss from this rank's [B_global, B] slab
         optimizer.zero_grad()
-        loss.backward()
-        parallel.all_reduce_grads(all_params)
+        loss.backward()          # each encoder's gradient all-reduce starts as soon as its backward node has run
+        reducer.wait()
         optimizer.step()
         with torch.no_grad():
             ranks = ops.rank_count(d, rank * B)

@@ -155,13 +155,16 @@ def _worker_sharded(rank, world, port, we, out_q):
         xo = torch.from_numpy(synth.embeddings(3, 2, (B, 24)))
         b0, b1 = parallel.shard_range(B)
         su_enc, ov_enc = _toy_encoders(we)
+        reducer = parallel.OverlappedGradReducer([su_enc, ov_enc])     # per-encoder buckets launched from grad hooks
         su = su_enc(xs[b0:b1]).view(-1, 16, 4, we)
         ov = ov_enc(xo[b0:b1]).view(-1, 16, 4, 64)
         loss, ori, d = cvig_fov.sharded_match_loss(ov, su, _kernels=_CpuKernels)
         assert tuple(d.shape) == (B, b1 - b0) and tuple(ori.shape) == (B, b1 - b0)
         loss.backward()
         params = list(su_enc.parameters()) + list(ov_enc.parameters())
-        parallel.all_reduce_grads(params)
+        assert len(reducer.inflight) == 2                               # both all-reduces were started inside backward()
+        assert reducer.wait() == sum(p.numel() for p in params)
+        assert reducer.wait() == 0                                      # nothing left in flight
         out_q.put((rank, loss.item(), [p.grad.numpy().copy() for p in params]))
     finally:
         dist.destroy_process_group()

@@ -850,6 +850,7 @@ def train(dataset='cvusa', fov=360, val_quantity=1000, batch_size=64, num_worker
     parallel.broadcast_parameters([surface_encoder, overhead_encoder])
     all_params = list(surface_encoder.parameters()) + list(overhead_encoder.parameters())
     optimizer = Adam(all_params, lr=1.E-5)
+    reducer = parallel.OverlappedGradReducer([surface_encoder, overhead_encoder])
 
     def say(*a):
         if rank == 0:
@@ -877,8 +878,8 @@ def train(dataset='cvusa', fov=360, val_quantity=1000, batch_size=64, num_worker
                     loss, orientation_estimate, distance = sharded_match_loss(overhead_embed, surface_embed)
                     if phase == 'train':
                         optimizer.zero_grad()
-                        loss.backward()
-                        parallel.all_reduce_grads(all_params)
+                        loss.backward()          # per-encoder gradient all-reduce overlapped with the other encoder's backward
+                        reducer.wait()
                         optimizer.step()
                 count = surface_embed.size(0) * world
                 running_count += count

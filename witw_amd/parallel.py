@@ -80,6 +80,63 @@ def all_reduce_grads(params):
     return off
 
 
+class OverlappedGradReducer:
+    """Gradient all-reduce (SUM) overlapped with the backward: one flat bucket per module. The backward of an encoder
+    is ONE autograd node (cvig_fov._EncoderFn), so all of its weight gradients appear together; a post-accumulate-grad
+    hook launches that encoder's all-reduce asynchronously the moment its last gradient has landed, and RCCL moves
+    the 29 MB bucket over xGMI while the OTHER encoder's backward kernels run. wait() (before optimizer.step()) joins
+    the collectives, copies the sums back and launches buckets whose gradients never all arrived. With one rank it
+    does nothing. all_reduce_grads() is the same reduction without the overlap."""
+
+    def __init__(self, modules):
+        self.buckets = [[p for p in m.parameters() if p.requires_grad] for m in modules]
+        self.arrived = [0] * len(self.buckets)
+        self.inflight = {}
+        self._hooks = []
+        for bi, ps in enumerate(self.buckets):
+            for p in ps:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._hook(bi)))
+
+    def _hook(self, bi):
+        def fn(_p):
+            self.arrived[bi] += 1
+            if self.arrived[bi] == len(self.buckets[bi]):
+                self._launch(bi)
+        return fn
+
+    def _launch(self, bi):
+        if world() == 1 or bi in self.inflight:
+            return
+        grads = [p.grad for p in self.buckets[bi] if p.grad is not None]
+        if not grads:
+            return
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        self.inflight[bi] = (grads, flat, dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True))
+
+    def wait(self):
+        """-> number of floats reduced."""
+        for bi in range(len(self.buckets)):
+            if self.arrived[bi] > 0:    # a bucket some of whose gradients never came (unused parameters) goes now
+                self._launch(bi)
+        n = 0
+        for bi, (grads, flat, work) in sorted(self.inflight.items()):
+            work.wait()
+            off = 0
+            for g in grads:
+                k = g.numel()
+                g.copy_(flat[off:off + k].view_as(g))
+                off += k
+            n += off
+        self.inflight = {}
+        self.arrived = [0] * len(self.buckets)
+        return n
+
+    def close(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+
 def all_gather_ragged(t):
     """cat over ranks of tensors whose first dimension differs from rank to rank (shard_range splits)."""
     if world() == 1:
