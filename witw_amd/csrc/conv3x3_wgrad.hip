@@ -31,6 +31,7 @@ struct WgradArgs {
     const float* x;    // [B,H,W,Cin]   NHWC
     const float* dz;   // [B,Ho,Wo,Cout] NHWC
     float* ws;         // [splits][9][Cin][Cout]
+    float* bias_part;  // nullptr, or [splits][Cout]: partial bias gradients (sum of dZ), written by the first ci tile
     int B, H, W, Cin, Cout, Ho, Wo;
     int SH, circ;
     int nseg;          // column segments of 64 per output row
@@ -58,6 +59,10 @@ __global__ __launch_bounds__(WT, 2) void conv3x3_wgrad_kernel(WgradArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     constexpr int R0 = (TAPS == 4) ? 1 : 0;      // first halo row that is read
+    // bias gradient: the dZ operand every lane reads anyway is summed on the side (one VALU add per 9 MFMAs) by the
+    // waves of the first ci tile that own ci rows 0-31 — no separate pass over dZ
+    const bool do_bias = p.bias_part != nullptr && blockIdx.x == 0 && (wave & 1) == 0;
+    float bsum = 0.f;
 
     const int mci = (wave & 1) * 32 + l31;    // this lane's ci within the tile (A operand row)
     const int nco = (wave >> 1) * 32 + l31;   // this lane's co within the tile (B operand column)
@@ -133,6 +138,7 @@ __global__ __launch_bounds__(WT, 2) void conv3x3_wgrad_kernel(WgradArgs p) {
 #pragma unroll 2
         for (int k = 0; k < ksteps; ++k) {
             const float bv = bp[k * 128];
+            if (do_bias) bsum += bv;
 #pragma unroll
             for (int t = 0; t < TAPS; ++t) {
                 const int kh = (TAPS == 4) ? 1 + (t >> 1) : t / 3, kw = (TAPS == 4) ? 1 + (t & 1) : t - (t / 3) * 3;
@@ -152,14 +158,28 @@ __global__ __launch_bounds__(WT, 2) void conv3x3_wgrad_kernel(WgradArgs p) {
             const int ci = ci0 + (wave & 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hk;
             if (ci < p.Cin && co < p.Cout) out[((size_t)t * p.Cin + ci) * p.Cout + co] = acc[t][r];
         }
+    if (do_bias) {                       // lanes l and l+32 hold the even / odd pixels of the same co
+        bsum += __shfl_xor(bsum, 32, 64);
+        if (hk == 0 && co < p.Cout) p.bias_part[(size_t)split * p.Cout + co] = bsum;
+    }
 }
 
 // dW[co][ci][kh][kw] (+)= sum_split ws[split][tap][ci][co]; one thread per (tap, ci, co), co fastest.
+// Threads past the weight elements sum the bias partials: db[co] (+)= sum_split bias_part[split][co].
 __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Cin, int Cout, int splits,
-                                    int accumulate, int cin_real, int taps) {
+                                    int accumulate, int cin_real, int taps, const float* __restrict__ bias_part,
+                                    float* __restrict__ db) {
     const size_t n = (size_t)taps * Cin * Cout;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n) return;
+    if (idx >= n) {
+        const size_t co = idx - n;
+        if (db != nullptr && co < (size_t)Cout) {
+            float s = 0.f;
+            for (int k = 0; k < splits; ++k) s += bias_part[(size_t)k * Cout + co];
+            db[co] = accumulate ? db[co] + s : s;
+        }
+        return;
+    }
     const int co = idx % Cout;
     const size_t t = idx / Cout;
     const int ci = t % Cin;
@@ -170,54 +190,6 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
     if (ci >= cin_real) return;   // zero-padded input channels have no weight
     float* d = dw + ((size_t)co * cin_real + ci) * 9 + tap;
     *d = accumulate ? (*d + s) : s;
-}
-
-// db[co] (+)= sum over all pixels of dZ[.., co]; grid = Cout/64 blocks (x) ; fixed-order two-level sum.
-__global__ __launch_bounds__(256) void bias_grad_partial_kernel(const float* __restrict__ dz, float* __restrict__ part,
-                                                                 size_t npix, int Cout, int rows_per_block) {
-    // thread -> (channel = tid % 64 + 64*blockIdx.x, pixel phase = tid / 64)
-    const int co = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int ph = threadIdx.x >> 6;
-    const size_t p0 = (size_t)blockIdx.y * rows_per_block;
-    const size_t p1 = min(npix, p0 + rows_per_block);
-    float s = 0.f;
-    if (co < Cout)
-        for (size_t px = p0 + ph; px < p1; px += 4) s += dz[px * Cout + co];
-    __shared__ float sh[4][64];
-    sh[ph][threadIdx.x & 63] = s;
-    __syncthreads();
-    if (threadIdx.x < 64 && co < Cout)
-        part[(size_t)blockIdx.y * Cout + co] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
-}
-
-// Wide variant for Cout with 256 % (Cout/4) == 0: thread -> (channel quad, pixel phase), float4 loads
-// (a wave reads 1 KB contiguous), fixed-order combination of the phases through LDS.
-__global__ __launch_bounds__(256) void bias_grad_partial_wide_kernel(const float* __restrict__ dz, float* __restrict__ part,
-                                                                      size_t npix, int Cout, int rows_per_block) {
-    __shared__ f32x4 sh[256];
-    const int Q = Cout >> 2;                 // channel quads
-    const int phases = 256 / Q;
-    const int q = threadIdx.x % Q, ph = threadIdx.x / Q;
-    const size_t p0 = (size_t)blockIdx.x * rows_per_block;
-    const size_t p1 = min(npix, p0 + rows_per_block);
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    for (size_t px = p0 + ph; px < p1; px += phases) s += *reinterpret_cast<const f32x4*>(dz + px * Cout + 4 * q);
-    sh[threadIdx.x] = s;
-    __syncthreads();
-    if (threadIdx.x < Q) {
-        f32x4 t = sh[threadIdx.x];
-        for (int k = 1; k < phases; ++k) t += sh[k * Q + threadIdx.x];
-        *reinterpret_cast<f32x4*>(part + (size_t)blockIdx.x * Cout + 4 * threadIdx.x) = t;
-    }
-}
-
-__global__ void bias_grad_finish_kernel(const float* __restrict__ part, float* __restrict__ db, int Cout, int nparts,
-                                        int accumulate) {
-    const int co = blockIdx.x * blockDim.x + threadIdx.x;
-    if (co >= Cout) return;
-    float s = 0.f;
-    for (int k = 0; k < nparts; ++k) s += part[(size_t)k * Cout + co];
-    db[co] = accumulate ? db[co] + s : s;
 }
 
 // Backward of the fused MaxPool2d(2,2): dy [B,Hp,Wp,C] (gradient at the pooled output, ReLU gate already
@@ -258,14 +230,6 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 
 }  // namespace
 
-// pixels summed by one bias-gradient workgroup: ~128 workgroups (the finish kernel walks the partials
-// serially per channel), at least 64 pixels each
-static int bias_rows_per_block(size_t npix) {
-    size_t r = (npix + 127) / 128;
-    if (r < 64) r = 64;
-    return (int)r;
-}
-
 extern "C" {
 
 // number of K splits the launcher will use and the workspace it needs (floats)
@@ -281,9 +245,7 @@ int witw_conv3x3_wgrad_splits(int B, int Ho, int Wo, int Cin, int Cout) {
 long long witw_conv3x3_wgrad_workspace_floats(int B, int H, int W, int Cin, int Cout, int stride_h) {
     const int Ho = (H + 2 - 3) / stride_h + 1;
     const long long splits = witw_conv3x3_wgrad_splits(B, Ho, W, Cin, Cout);
-    const size_t npix = (size_t)B * Ho * W;
-    const long long bias_parts = (long long)((npix + bias_rows_per_block(npix) - 1) / bias_rows_per_block(npix));
-    return splits * 9 * Cin * Cout + bias_parts * Cout;
+    return splits * 9 * Cin * Cout + splits * Cout;
 }
 
 // x [B,H,W,Cin] NHWC (the conv's input), dz [B,Ho,W,Cout] NHWC (gradient at its output),
@@ -308,6 +270,7 @@ static int wgrad_launch(const float* x, const float* dz, float* dw, float* db, f
     a.chunks = B * a.Ho * a.nseg;
     const int splits = witw_conv3x3_wgrad_splits(B, a.Ho, a.Wo, Cin, Cout);
     a.cps = cdiv(a.chunks, splits);
+    a.bias_part = db ? workspace + (size_t)splits * 9 * Cin * Cout : nullptr;     // behind the weight partials
     const dim3 grid(cdiv(Cin, 64), cdiv(Cout, 64), splits);
     if (taps == 4) {
         // the five taps outside the 2x2 sub-window get an exact zero gradient
@@ -321,22 +284,9 @@ static int wgrad_launch(const float* x, const float* dz, float* dw, float* db, f
     }
     WITW_CHECK_LAUNCH("conv3x3_wgrad");
     const size_t n = (size_t)taps * Cin * Cout;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, workspace, dw, Cin, Cout,
-                       splits, accumulate, cin_real, taps);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + Cout + 255) / 256)), dim3(256), 0, st, workspace, dw, Cin, Cout,
+                       splits, accumulate, cin_real, taps, a.bias_part, db);
     WITW_CHECK_LAUNCH("wgrad_reduce");
-    if (db != nullptr) {
-        float* part = workspace + (size_t)splits * 9 * Cin * Cout;
-        const size_t npix = (size_t)B * a.Ho * a.Wo;
-        const int rows = bias_rows_per_block(npix);
-        const int nparts = (int)((npix + rows - 1) / rows);
-        if ((Cout & 3) == 0 && Cout >= 16 && (256 % (Cout >> 2)) == 0)
-            hipLaunchKernelGGL(bias_grad_partial_wide_kernel, dim3(nparts), dim3(256), 0, st, dz, part, npix, Cout, rows);
-        else
-            hipLaunchKernelGGL(bias_grad_partial_kernel, dim3(cdiv(Cout, 64), nparts), dim3(256), 0, st, dz, part, npix, Cout,
-                               rows);
-        hipLaunchKernelGGL(bias_grad_finish_kernel, dim3(cdiv(Cout, 256)), dim3(256), 0, st, part, db, Cout, nparts, accumulate);
-        WITW_CHECK_LAUNCH("bias_grad");
-    }
     return WITW_OK;
 }
 
