@@ -139,6 +139,8 @@ int witw_triplet_loss_bwd(const float* distance, const float* workspace, const f
  * the last layer writes the fp32 NCHW embedding (out_nchw_f32). Pointers typed void* carry bf16 data. */
 long long witw_conv3x3_bf16_packed_elems(int cout, int cin);
 int witw_conv3x3_bf16_pack_weights(const float* w_kcrs, void* wpk_bf16, int cout, int cin, void* stream);
+/* transpose_flip != 0: the dgrad filter of the source tensor [cin][cout][3][3] (cout, cin describe the packed filter) */
+int witw_conv3x3_bf16_pack_weights_ex(const float* w_kcrs, void* wpk_bf16, int cout, int cin, int transpose_flip, void* stream);
 int witw_nchw_f32_to_nhwc_bf16(const float* x, void* y_bf16, int B, int C, int H, int W, int Cpad, void* stream);
 int witw_conv3x3_bf16_fwd(const void* x_bf16, const void* wpk_bf16, const float* bias, void* y, int B, int H, int W, int Cin,
                           int Cout, int stride_h, int pad_circular, int relu, int pool, int out_nchw_f32, void* stream);

@@ -510,9 +510,11 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_bf16_kernel(ConvBfArgs p
 #endif
 }
 
-// wpk[nt][kc][tap][g][n][0..7] (bf16) <- w[cout][cin][kh][kw] (fp32, torch KCRS); one thread per 16-B slot
+// wpk[nt][kc][tap][g][n][0..7] (bf16) <- w[cout][cin][kh][kw] (fp32, torch KCRS); one thread per 16-B slot.
+// transpose_flip != 0 builds the dgrad filter instead: (Cout, Cin) describe the PACKED filter, the source tensor is
+// [Cin][Cout][3][3] and w'[co][ci][kh][kw] = w[ci][co][2-kh][2-kw].
 __global__ void pack_weights_bf16_kernel(const float* __restrict__ w, unsigned short* __restrict__ wpk, int Cout, int Cin,
-                                         int n_tiles, int nkc, int TN) {
+                                         int n_tiles, int nkc, int TN, int transpose_flip) {
     const size_t total = (size_t)n_tiles * nkc * 9 * 2 * TN;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
@@ -528,7 +530,10 @@ __global__ void pack_weights_bf16_kernel(const float* __restrict__ w, unsigned s
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int ci = kc * 16 + g * 8 + j;
-        const float f = (co < Cout && ci < Cin) ? w[(((size_t)co * Cin + ci) * 3 + kh) * 3 + kw] : 0.f;
+        float f = 0.f;
+        if (co < Cout && ci < Cin)
+            f = transpose_flip ? w[(((size_t)ci * Cout + co) * 3 + (2 - kh)) * 3 + (2 - kw)]
+                               : w[(((size_t)co * Cin + ci) * 3 + kh) * 3 + kw];
         v[j] = (__bf16)f;
     }
     reinterpret_cast<bf16x8*>(wpk)[idx] = v;
@@ -611,16 +616,20 @@ long long witw_conv3x3_bf16_packed_elems(int cout, int cin) {
     return (long long)cdiv(cout, TN) * cdiv(cin, 16) * 9 * 2 * TN * 8;
 }
 
-int witw_conv3x3_bf16_pack_weights(const float* w_kcrs, void* wpk_bf16, int cout, int cin, void* stream) {
+int witw_conv3x3_bf16_pack_weights_ex(const float* w_kcrs, void* wpk_bf16, int cout, int cin, int transpose_flip, void* stream) {
     WITW_CHECK_ARG(w_kcrs && wpk_bf16, "bf16 pack_weights: null pointer");
     WITW_CHECK_ARG(cout > 0 && cin > 0, "bf16 pack_weights: bad shape");
     const int TN = cout >= 128 ? 128 : 64;
     const int n_tiles = cdiv(cout, TN), nkc = cdiv(cin, 16);
     const size_t total = (size_t)n_tiles * nkc * 9 * 2 * TN;
     hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_kcrs,
-                       (unsigned short*)wpk_bf16, cout, cin, n_tiles, nkc, TN);
+                       (unsigned short*)wpk_bf16, cout, cin, n_tiles, nkc, TN, transpose_flip);
     WITW_CHECK_LAUNCH("bf16 pack_weights");
     return WITW_OK;
+}
+
+int witw_conv3x3_bf16_pack_weights(const float* w_kcrs, void* wpk_bf16, int cout, int cin, void* stream) {
+    return witw_conv3x3_bf16_pack_weights_ex(w_kcrs, wpk_bf16, cout, cin, 0, stream);
 }
 
 int witw_nchw_f32_to_nhwc_bf16(const float* x, void* y_bf16, int B, int C, int H, int W, int Cpad, void* stream) {

@@ -571,13 +571,12 @@ class PackedConvBf16:
     def __init__(self, weight, bias, transpose_flip=False):
         lib = _lib.load()
         w = _dev_f32(weight.detach(), 'weight')
-        if transpose_flip:      # dgrad filter: w_t[ci][co][kh][kw] = w[co][ci][2-kh][2-kw]
-            w = w.transpose(0, 1).flip(2, 3).contiguous()
-        self.cout, self.cin = w.shape[0], w.shape[1]
+        # transpose_flip: the dgrad filter w_t[ci][co][kh][kw] = w[co][ci][2-kh][2-kw], built by the pack kernel itself
+        self.cout, self.cin = (w.shape[1], w.shape[0]) if transpose_flip else (w.shape[0], w.shape[1])
         self.cin_pad = (self.cin + 15) // 16 * 16
         self.wpk = torch.empty(lib.witw_conv3x3_bf16_packed_elems(self.cout, self.cin), dtype=torch.bfloat16, device=w.device)
-        _lib.check(lib.witw_conv3x3_bf16_pack_weights(w.data_ptr(), self.wpk.data_ptr(), self.cout, self.cin, _stream()),
-                   'witw_conv3x3_bf16_pack_weights')
+        _lib.check(lib.witw_conv3x3_bf16_pack_weights_ex(w.data_ptr(), self.wpk.data_ptr(), self.cout, self.cin,
+                                                         int(bool(transpose_flip)), _stream()), 'witw_conv3x3_bf16_pack_weights_ex')
         self.bias = torch.zeros(lib.witw_conv3x3_bias_floats(self.cout), dtype=torch.float32, device=w.device)
         if bias is not None:
             self.bias[:self.cout].copy_(bias.detach())
