@@ -129,7 +129,7 @@ class FOV_DSM(torch.nn.Module):
                getattr(conv.bias, '_witw_version', 0))
         hit = self._packed.get(idx)
         if hit is None or hit[0] != key:
-            hit = (key, ops.PackedConv(conv.weight, conv.bias))
+            hit = (key, ops.PackedConv(conv.weight, conv.bias, reuse=hit[1] if hit else None))
             self._packed[idx] = hit
         return hit[1]
 
@@ -139,7 +139,7 @@ class FOV_DSM(torch.nn.Module):
         key = (conv.weight.data_ptr(), conv.weight._version, getattr(conv.weight, '_witw_version', 0))
         hit = self._packed.get(('t', idx))
         if hit is None or hit[0] != key:
-            hit = (key, ops.PackedConv(conv.weight, None, transpose_flip=True))
+            hit = (key, ops.PackedConv(conv.weight, None, transpose_flip=True, reuse=hit[1] if hit else None))
             self._packed[('t', idx)] = hit
         return hit[1]
 
@@ -191,7 +191,7 @@ class FOV_DSM(torch.nn.Module):
                getattr(conv.bias, '_witw_version', 0))
         hit = self._packed.get(('bf16', idx))
         if hit is None or hit[0] != key:
-            hit = (key, ops.PackedConvBf16(conv.weight, conv.bias))
+            hit = (key, ops.PackedConvBf16(conv.weight, conv.bias, reuse=hit[1] if hit else None))
             self._packed[('bf16', idx)] = hit
         return hit[1]
 
@@ -201,7 +201,7 @@ class FOV_DSM(torch.nn.Module):
         key = (conv.weight.data_ptr(), conv.weight._version, getattr(conv.weight, '_witw_version', 0))
         hit = self._packed.get(('t_bf16', idx))
         if hit is None or hit[0] != key:
-            hit = (key, ops.PackedConvBf16(conv.weight, None, transpose_flip=True))
+            hit = (key, ops.PackedConvBf16(conv.weight, None, transpose_flip=True, reuse=hit[1] if hit else None))
             self._packed[('t_bf16', idx)] = hit
         return hit[1]
 

@@ -37,7 +37,9 @@ class PackedConv:
     2x2 sub-window that is live in a filter whose first tap row/column are zero (cvig_baseline's 4x4/s2 convs over the
     space-to-depth image; with transpose_flip: the dgrad filter, whose LAST row/column are zero) for the 4-tap kernels."""
 
-    def __init__(self, weight, bias, transpose_flip=False, taps4=False):
+    def __init__(self, weight, bias, transpose_flip=False, taps4=False, reuse=None):
+        """reuse: a PackedConv of the same layer and mode whose device buffers are overwritten in place (re-packing
+        after an optimizer step without allocating or zero-filling; stream order keeps earlier launches safe)."""
         lib = _lib.load()
         w = _dev_f32(weight.detach(), 'weight')
         if transpose_flip:
@@ -48,16 +50,20 @@ class PackedConv:
         self.cin_pad = (cin + 7) // 8 * 8
         self.taps4 = bool(taps4)
         self.tap_base = 0 if transpose_flip else 1
+        n_pk = lib.witw_conv3x3_packed_floats_taps4(cout, cin) if taps4 else lib.witw_conv3x3_packed_floats(cout, cin)
+        if reuse is not None and not (reuse.wpk.numel() == n_pk and reuse.wpk.device == w.device and reuse.cout == cout
+                                      and reuse.taps4 == self.taps4):
+            reuse = None
         if taps4:
-            self.wpk = torch.empty(lib.witw_conv3x3_packed_floats_taps4(cout, cin), dtype=torch.float32, device=w.device)
+            self.wpk = reuse.wpk if reuse is not None else torch.empty(n_pk, dtype=torch.float32, device=w.device)
             _lib.check(lib.witw_conv3x3_pack_weights_taps4(w.data_ptr(), self.wpk.data_ptr(), cout, cin, int(transpose_flip),
                                                            _stream()), 'witw_conv3x3_pack_weights_taps4')
         else:
-            self.wpk = torch.empty(lib.witw_conv3x3_packed_floats(cout, cin), dtype=torch.float32, device=w.device)
+            self.wpk = reuse.wpk if reuse is not None else torch.empty(n_pk, dtype=torch.float32, device=w.device)
             _lib.check(lib.witw_conv3x3_pack_weights(w.data_ptr(), self.wpk.data_ptr(), cout, cin, int(transpose_flip),
                                                      _stream()), 'witw_conv3x3_pack_weights')
         nb = lib.witw_conv3x3_bias_floats(cout)
-        self.bias = torch.zeros(nb, dtype=torch.float32, device=w.device)
+        self.bias = reuse.bias if reuse is not None else torch.zeros(nb, dtype=torch.float32, device=w.device)
         if bias is not None and not transpose_flip:
             self.bias[:cout].copy_(bias.detach())
 
@@ -568,16 +574,20 @@ def exhaustive_triplet_loss(D, soft_margin=False, alpha=10., margin=1.):
 class PackedConvBf16:
     """bf16 filter packing of one 3x3 conv for the bf16 MFMA kernel + fp32 bias padded to the channel tile."""
 
-    def __init__(self, weight, bias, transpose_flip=False):
+    def __init__(self, weight, bias, transpose_flip=False, reuse=None):
         lib = _lib.load()
         w = _dev_f32(weight.detach(), 'weight')
         # transpose_flip: the dgrad filter w_t[ci][co][kh][kw] = w[co][ci][2-kh][2-kw], built by the pack kernel itself
         self.cout, self.cin = (w.shape[1], w.shape[0]) if transpose_flip else (w.shape[0], w.shape[1])
         self.cin_pad = (self.cin + 15) // 16 * 16
-        self.wpk = torch.empty(lib.witw_conv3x3_bf16_packed_elems(self.cout, self.cin), dtype=torch.bfloat16, device=w.device)
+        n_pk = lib.witw_conv3x3_bf16_packed_elems(self.cout, self.cin)
+        if reuse is not None and not (reuse.wpk.numel() == n_pk and reuse.wpk.device == w.device and reuse.cout == self.cout):
+            reuse = None
+        self.wpk = reuse.wpk if reuse is not None else torch.empty(n_pk, dtype=torch.bfloat16, device=w.device)
         _lib.check(lib.witw_conv3x3_bf16_pack_weights_ex(w.data_ptr(), self.wpk.data_ptr(), self.cout, self.cin,
                                                          int(bool(transpose_flip)), _stream()), 'witw_conv3x3_bf16_pack_weights_ex')
-        self.bias = torch.zeros(lib.witw_conv3x3_bias_floats(self.cout), dtype=torch.float32, device=w.device)
+        self.bias = reuse.bias if reuse is not None else \
+            torch.zeros(lib.witw_conv3x3_bias_floats(self.cout), dtype=torch.float32, device=w.device)
         if bias is not None:
             self.bias[:self.cout].copy_(bias.detach())
 
