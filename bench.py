@@ -73,6 +73,9 @@ def main():
     ap.add_argument('--model', choices=['fov', 'semantic'], default='fov',
                     help='fov = cvig_fov (3-channel, BASELINE configs[1]); semantic = cvig_semantic (5-channel first conv, '
                          'configs[3]: run it with --precision bf16)')
+    ap.add_argument('--graph', action='store_true',
+                    help='inference, one GPU: capture the whole step in a hipGraph (parallel.CapturedStep) and time replays; '
+                         'pays off where the step is launch-bound (small --batch, bf16)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL); gloo only for 1-GPU self-tests')
     ap.add_argument('--single-device', action='store_true', help='self-test: put every rank on cuda:0')
@@ -155,6 +158,19 @@ def main():
         return loss, ranks, ori
 
     step = train_step if train else infer_step
+    if a.graph:
+        if train or world > 1:
+            sys.exit('--graph captures the single-GPU inference step only (no collectives, no optimizer)')
+
+        def graph_body(g_raw, o_raw):
+            with torch.no_grad():
+                surface = ops.resize_bilinear(g_raw, (128, ws), mean, std, ndiv)
+                polar = ops.polar_transform(ops.resize_bilinear(o_raw, (256, 256), mean, std, ndiv))
+                su = surface_encoder.forward_bf16(surface) if bf16 else surface_encoder(surface)
+                ov = overhead_encoder.forward_bf16(polar) if bf16 else overhead_encoder(polar)
+                return cvig_fov.evaluate_global_batch(ov, su, 0)[:3]
+        captured = parallel.CapturedStep(graph_body, [ground_raw, ov_raw])
+        step = lambda: captured(ground_raw, ov_raw)      # noqa: E731  (input copy + one hipGraphLaunch)
     for _ in range(a.warmup):
         step()
     if world > 1:
@@ -214,7 +230,8 @@ def main():
                                    'dgrad L2-27, max-pool scatter, wgrad L0 + L17-27' if semantic else 'dgrad L19-27, wgrad L17-27')),
                    'pairs_per_gpu': B, 'global_batch': B * world, 'ground_raw': '%dx224x224' % channels,
                    'overhead_raw': '%dx512x512' % channels,
-                   'parallelism': 'dp%d (overhead-embedding all-gather, global-batch loss from column slabs)' % world},
+                   'parallelism': 'dp%d (overhead-embedding all-gather, global-batch loss from column slabs)' % world,
+                   **({'launch': 'whole step replayed as one hipGraph'} if a.graph else {})},
         'recall': {'top1_pct': float(np.mean(ranks_h <= 1) * 100), 'top5_pct': float(np.mean(ranks_h <= 5) * 100),
                    'N': int(len(ranks_h))},
         'loss': float(loss.item()),

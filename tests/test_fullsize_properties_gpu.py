@@ -102,3 +102,35 @@ def test_training_reduces_the_loss():
         losses.append(loss.item())
     assert all(np.isfinite(losses))
     assert losses[-1] < losses[0] - 1e-3, losses
+
+
+@pytest.mark.parametrize('bf16', [False, True])
+def test_step_replayed_as_a_hip_graph_equals_the_eager_step(bf16):
+    """parallel.CapturedStep: the whole inference step (transforms, both encoders, fused match, loss, rank counts) captured
+    in one hipGraph; replays on NEW inputs are bit-identical to the eager launches."""
+    from witw_amd import cvig_fov, ops, parallel
+    dev = torch.device('cuda:0')
+    w = synth.fov_dsm_weights(21)
+    se = cvig_fov.FOV_DSM(False, weights=w).to(dev).eval()
+    oe = cvig_fov.FOV_DSM(True, weights=w).to(dev).eval()
+    mean, std = cvig_fov.Globals.img_mean, cvig_fov.Globals.img_std
+
+    def body(g_raw, o_raw):
+        with torch.no_grad():
+            s = ops.resize_bilinear(g_raw, (128, 512), mean, std)
+            p = ops.polar_transform(ops.resize_bilinear(o_raw, (256, 256), mean, std))
+            su = se.forward_bf16(s) if bf16 else se(s)
+            ov = oe.forward_bf16(p) if bf16 else oe(p)
+            loss, ranks, ori, d = cvig_fov.evaluate_global_batch(ov, su, 0)
+            return loss, ranks, ori, d
+
+    def inputs(seed):
+        return (torch.from_numpy(synth.images_u8(seed, 1, (4, 3, 224, 224))).to(dev),
+                torch.from_numpy(synth.images_u8(seed, 2, (4, 3, 512, 512))).to(dev))
+    step = parallel.CapturedStep(body, inputs(5))
+    for seed in (6, 7):
+        x = inputs(seed)
+        got = [t.clone() for t in step(*x)]
+        ref = body(*x)
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b)

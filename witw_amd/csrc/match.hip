@@ -727,6 +727,13 @@ __global__ __launch_bounds__(256) void match_bwd_ov_kernel(const float* __restri
     }
 }
 
+// zero fill as a kernel (not hipMemsetAsync): a launch is captured faithfully when the step is recorded into a hipGraph
+// (parallel.CapturedStep); a memset node of this size replayed with stale contents on ROCm 7.2
+__global__ void zero_i32_kernel(int* __restrict__ p, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = 0;
+}
+
 // Sharded-gallery form: count against an explicit per-query threshold (the true match's distance,
 // produced by whichever rank owns that gallery row).
 __global__ __launch_bounds__(256) void rank_count_thresh_kernel(const float* __restrict__ D, const float* __restrict__ thr,
@@ -852,10 +859,7 @@ int witw_rank_count(const float* distance, int* ranks, int Bo, int Bs, int true_
     WITW_CHECK_ARG(distance && ranks, "rank_count: null pointer");
     WITW_CHECK_ARG(Bo > 0 && Bs > 0, "rank_count: bad shape Bo=%d Bs=%d", Bo, Bs);
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(ranks, 0, sizeof(int) * (size_t)Bs, st) != hipSuccess) {
-        witw_set_error("rank_count: memset failed");
-        return WITW_ERR_LAUNCH;
-    }
+    hipLaunchKernelGGL(zero_i32_kernel, dim3(cdiv(Bs, 256)), dim3(256), 0, st, ranks, Bs);
     const int rows = 512;
     hipLaunchKernelGGL(rank_count_kernel, dim3(cdiv(Bs, 256), cdiv(Bo, rows)), dim3(256), 0, st, distance, ranks, Bo, Bs,
                        true_offset, rows);
@@ -867,10 +871,7 @@ int witw_rank_count_thresh(const float* distance, const float* threshold, int* r
     WITW_CHECK_ARG(distance && threshold && ranks, "rank_count_thresh: null pointer");
     WITW_CHECK_ARG(Bo > 0 && Bs > 0, "rank_count_thresh: bad shape Bo=%d Bs=%d", Bo, Bs);
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(ranks, 0, sizeof(int) * (size_t)Bs, st) != hipSuccess) {
-        witw_set_error("rank_count_thresh: memset failed");
-        return WITW_ERR_LAUNCH;
-    }
+    hipLaunchKernelGGL(zero_i32_kernel, dim3(cdiv(Bs, 256)), dim3(256), 0, st, ranks, Bs);
     const int rows = 512;
     hipLaunchKernelGGL(rank_count_thresh_kernel, dim3(cdiv(Bs, 256), cdiv(Bo, rows)), dim3(256), 0, st, distance, threshold,
                        ranks, Bo, Bs, rows);

@@ -137,6 +137,35 @@ class OverlappedGradReducer:
         self._hooks = []
 
 
+class CapturedStep:
+    """A launch-bound step as ONE hipGraph launch. fn(*inputs) -> tensor or tuple of tensors must be a pure sequence
+    of device work on the current stream (the C-ABI launchers and torch allocations qualify; no host synchronisation,
+    no collectives, weights already packed). The step is run `warmup` times eagerly (caches, LUTs, allocator), then
+    captured with torch.cuda.CUDAGraph (hipStreamBeginCapture / hipGraphInstantiate on ROCm) on static copies of the
+    inputs; __call__ copies new inputs into those buffers and replays. At 8 pairs the bf16 inference step issues ~60
+    kernels of 5-30 us each and is bound by their launches; the graph removes that bound."""
+
+    def __init__(self, fn, example_inputs, warmup=2):
+        self.static_in = [t.clone() for t in example_inputs]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):               # capture needs a non-default stream; warm up on it too
+            for _ in range(warmup):
+                fn(*self.static_in)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            out = fn(*self.static_in)
+        self.static_out = out
+
+    def __call__(self, *inputs):
+        for dst, src in zip(self.static_in, inputs):
+            dst.copy_(src)
+        self.graph.replay()
+        return self.static_out
+
+
 def all_gather_ragged(t):
     """cat over ranks of tensors whose first dimension differs from rank to rank (shard_range splits)."""
     if world() == 1:
