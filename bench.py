@@ -29,7 +29,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 MFMA
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # same table, dense bf16 MFMA (no sparsity)
-DOMINANT = (128, 1, False, 8)  # conv3x3_nhwc_f32_kernel<128,1,false,8,0>: layers 5,10,12,17,19,21 at B=128
+DOMINANT = (128, 1, False, 8)  # conv3x3_nhwc_f32_kernel<128,1,false,8,0,9> (TN, SH, POOL, NW, GEO, TAPS): layers 5,10,12,17,19,21 at B=128
 
 
 def make_inputs(cvig_fov, ops, synth, batch, fov, seed, device, channels=3):
@@ -200,7 +200,7 @@ def main():
     # ---- live roofline of the dominant kernel (HIP events on the launch stream, timed region only)
     dominant = ('bf16', 128, 1, False) if bf16 else DOMINANT
     peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
-    kname = 'conv3x3_nhwc_bf16_kernel<128,1,false,8>' if bf16 else 'conv3x3_nhwc_f32_kernel<128,1,false,8,0>'
+    kname = 'conv3x3_nhwc_bf16_kernel<128,1,false,8>' if bf16 else 'conv3x3_nhwc_f32_kernel<128,1,false,8,0,9>'
     dom = [(fl, e0.elapsed_time(e1)) for (v, fl, e0, e1) in prof if v == dominant]
     allc = [(fl, e0.elapsed_time(e1)) for (v, fl, e0, e1) in prof if v[0] not in ('match', 'wgrad_bf16')]
     wg = [(fl, e0.elapsed_time(e1)) for (v, fl, e0, e1) in prof if v[0] == 'wgrad_bf16']
