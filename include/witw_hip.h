@@ -236,6 +236,10 @@ int witw_normalize(const float* x, float* y, int B, int C, int H, int W, const f
  * built on the host in fp64 exactly as model/cvig_fov.py:163-181,197-201. */
 int witw_polar_transform(const float* x, const int* taps, const float* wts, float* y, int B, int C, int size, int Ho, int Wo,
                          void* stream);
+/* bilinear_interpolate (model/cvig_fov.py:156-183) on arbitrary coordinates: the same 4-tap gather with a caller-built
+ * table; taps = flat offsets into a plane of plane_in elements, n_out samples per plane: y [B,C,n_out]. */
+int witw_bilinear_gather(const float* x, const int* taps, const float* wts, float* y, int B, int C, long long plane_in,
+                         long long n_out, void* stream);
 /* SyncedRotation's overhead rotation (model/cvig_baseline.py:142: torchvision.transforms.functional.rotate on a float
  * CHW tensor = nearest-neighbour affine grid sample, zero fill, same size). x,y [B,C,H,W] fp32, y != x; theta DEVICE
  * fp32 [B][3][2]: per image the inverse rotation matrix divided by (W/2, H/2), row k = (x, y, 1) coefficient. */

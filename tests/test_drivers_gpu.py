@@ -71,6 +71,46 @@ def test_train_then_test_drivers_bf16(tmp_path, monkeypatch, capsys):
     assert 'Top  1:' in capsys.readouterr().out and 1 <= table['median'] <= 6
 
 
+def test_projector_dump_inverse_normalize_and_bilinear_interpolate(tmp_path, monkeypatch):
+    """The reference's TensorBoard embedding-projector dump (model/cvig_fov.py:474-479, :534-540) with a recording
+    writer, inverse_normalize's verbatim semantics (:151-154) and bilinear_interpolate (:156-183) on free coordinates."""
+    from witw_amd import cvig_fov
+    calls = []
+
+    class Rec(object):
+        def add_scalar(self, *a, **k):
+            pass
+        add_text = add_scalar
+
+        def add_embedding(self, mat, metadata=None, metadata_header=None, label_img=None, global_step=None, tag=None):
+            calls.append((tuple(mat.shape), len(metadata), metadata_header, tuple(label_img.shape), global_step, tag))
+
+    monkeypatch.setattr(cvig_fov, '_writer', lambda path: Rec())
+    csv = _write_dataset(str(tmp_path), 6)
+    monkeypatch.chdir(tmp_path)
+    cvig_fov.train(dataset='cvusa', fov=70, val_quantity=2, batch_size=2, num_workers=0, num_epochs=1, csv_path=csv)
+    cvig_fov.test(dataset='cvusa', fov=70, batch_size=4, num_workers=0, csv_path=csv)
+    e = 16 * 4 * 12
+    assert calls[0] == ((4, e), 4, ['idx', 'type'], (4, 3, 128, 512), 1, 'val_embedding')
+    assert calls[1] == ((4, e), 4, ['idx', 'type'], (4, 3, 128, 512), 0, 'test_embedding')       # last test batch: 2 pairs
+    # inverse_normalize walks dim 0 like the reference
+    t = torch.ones(5, 3, 2, 2)
+    out = cvig_fov.inverse_normalize(t, [1., 2., 3.], [10., 20., 30.])
+    assert out is t and [float(t[i, 0, 0, 0]) for i in range(5)] == [11., 22., 33., 1., 1.]
+    # bilinear_interpolate vs the oracle's restatement on random coordinates (clipping before the weights)
+    g = np.random.Generator(np.random.Philox(key=[3, 3]))
+    im = torch.from_numpy(g.standard_normal((3, 17, 23), dtype=np.float32))
+    x = g.uniform(-2, 25, size=(7, 9))
+    y = g.uniform(-2, 19, size=(7, 9))
+    got = cvig_fov.bilinear_interpolate(im, x, y).cpu().numpy()
+    x0 = np.floor(x).astype(int); x1 = x0 + 1; y0 = np.floor(y).astype(int); y1 = y0 + 1
+    x0 = np.clip(x0, 0, 22); x1 = np.clip(x1, 0, 22); y0 = np.clip(y0, 0, 16); y1 = np.clip(y1, 0, 16)
+    f = lambda a: torch.from_numpy(a.astype(np.float32)).reshape(1, 7, 9)
+    ref = f((x1 - x) * (y1 - y)) * im[:, y0, x0] + f((x1 - x) * (y - y0)) * im[:, y1, x0] + \
+        f((x - x0) * (y1 - y)) * im[:, y0, x1] + f((x - x0) * (y - y0)) * im[:, y1, x1]
+    np.testing.assert_allclose(got, ref.numpy(), rtol=0, atol=1e-6)
+
+
 def test_sweep_scores_matches_heatmap_formula():
     from witw_amd import cvig_fov
     ov = torch.from_numpy(synth.embeddings(60, 1, (9, 16, 4, 64)))

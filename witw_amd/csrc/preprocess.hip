@@ -160,6 +160,20 @@ int witw_polar_transform(const float* x, const int* taps, const float* wts, floa
     return WITW_OK;
 }
 
+// The same 4-tap gather for any sampling table (bilinear_interpolate of the reference, model/cvig_fov.py:156-183, on
+// arbitrary coordinates): taps are flat offsets into a plane of plane_in elements, n_out output samples per plane.
+int witw_bilinear_gather(const float* x, const int* taps, const float* wts, float* y, int B, int C, long long plane_in,
+                         long long n_out, void* stream) {
+    WITW_CHECK_ARG(x && taps && wts && y, "bilinear_gather: null pointer");
+    WITW_CHECK_ARG(B > 0 && C > 0 && plane_in > 0 && plane_in <= 0x7fffffffLL && n_out > 0 && n_out <= 0x7fffffffLL,
+                   "bilinear_gather: bad shape");
+    const size_t total = (size_t)B * n_out;
+    hipLaunchKernelGGL(polar_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       (const int4*)taps, (const float4*)wts, y, B, C, (int)plane_in, (int)n_out);
+    WITW_CHECK_LAUNCH("bilinear_gather");
+    return WITW_OK;
+}
+
 // x, y: [B,C,H,W] fp32 (y != x); theta: DEVICE [B,2,3]^T rescaled matrices, see rotate_nearest_kernel.
 int witw_rotate_nearest(const float* x, const float* theta, float* y, int B, int C, int H, int W, void* stream) {
     WITW_CHECK_ARG(x && theta && y && x != y, "rotate_nearest: null or aliased pointer");

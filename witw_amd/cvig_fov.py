@@ -419,6 +419,20 @@ class ImageNormalization(object):
         return data
 
 
+def inverse_normalize(tensor, mean, std):
+    """model/cvig_fov.py:151-154, verbatim semantics: zip() walks the FIRST dimension of `tensor`, so on the [N,C,H,W] batch
+    the reference passes (:477, :536) slices 0..len(mean)-1 along N are rescaled in place, each as a whole — kept as is,
+    since the result only labels TensorBoard's embedding projector."""
+    for t, m, s in zip(tensor, mean, std):
+        t.mul_(s).add_(m)
+    return tensor
+
+
+def bilinear_interpolate(im, x, y):
+    """model/cvig_fov.py:156-183 on the GPU (ops.bilinear_interpolate): im [C,H,W], x / y coordinate arrays."""
+    return ops.bilinear_interpolate(_to_device(im), x, y)
+
+
 class PolarTransform(object):
     """model/cvig_fov.py:186-209."""
 
@@ -774,6 +788,28 @@ class GpuPreprocess(object):
         return self.polar(self.norm(data))
 
 
+def projector_dump(writer, surface, overhead, surface_embed, overhead_embed, global_step, tag, img_mean, img_std):
+    """The TensorBoard embedding-projector dump at the end of a validation epoch / of test() (model/cvig_fov.py:474-479,
+    :534-540): surface embeddings and the diagonal of the orientation-aligned overhead crops, labelled by the images of
+    the last batch. Nothing is computed for the null writer (tensorboard absent)."""
+    if isinstance(writer, _NullWriter):
+        return False
+    n = surface_embed.shape[0]
+    labels = [[i, 0] for i in range(n)] + [[i, 1] for i in range(overhead_embed.shape[0])]
+    label_header = ['idx', 'type']
+    original_images = inverse_normalize(
+        torch.cat((torch.nn.functional.pad(surface, (0, overhead.shape[-1] - surface.shape[-1])), overhead), dim=0),
+        mean=img_mean, std=img_std)
+    with torch.no_grad():
+        orientation = correlation(overhead_embed.detach(), surface_embed.detach())
+        cropped = crop_overhead(overhead_embed.detach(), orientation, surface_embed.shape[3])
+    cropped = cropped[range(n), range(n)]
+    writer.add_embedding(torch.cat((surface_embed.detach().reshape(n, -1), cropped.reshape(n, -1)), dim=0).cpu(),
+                         metadata=[[l, 0] for l in labels], metadata_header=label_header, label_img=original_images.cpu(),
+                         global_step=global_step, tag=tag)
+    return True
+
+
 class _NullWriter(object):
     def add_scalar(self, *a, **k):
         pass
@@ -888,6 +924,9 @@ def train(dataset='cvusa', fov=360, val_quantity=1000, batch_size=64, num_worker
                                                                                 loss.item()))
                 writer.add_scalar('{} loss'.format(phase), running_loss / running_count, epoch * len(loader) + batch)
             say('  %5s: avg loss = %f' % (phase, running_loss / max(1, running_count)))
+        if running_count and getattr(m, 'PROJECTOR_DUMP', True):      # last validation batch -> embedding projector (:474-479)
+            projector_dump(writer, surface, overhead, surface_embed, overhead_embed, epoch + 1, 'val_embedding',
+                           Globals.img_mean, Globals.img_std)
         if running_count and (best_loss is None or running_loss / running_count < best_loss):
             say('-------> new best')
             best_loss = running_loss / running_count
@@ -929,11 +968,15 @@ def test(dataset='cvusa', fov=360, batch_size=64, num_workers=8, csv_path=None, 
     surface_encoder.eval()
     overhead_encoder.eval()
     su_parts, ov_parts = [], []
+    data = None
     for raw in test_loader:
         data = prep(raw)
         with torch.no_grad():
             su_parts.append(surface_encoder(data['surface']))
             ov_parts.append(overhead_encoder(data['polar']))
+    if data is not None and getattr(m, 'PROJECTOR_DUMP', True):        # last batch -> embedding projector (:534-540)
+        projector_dump(writer, data['surface'], data['polar'], su_parts[-1], ov_parts[-1], 0, 'test_embedding',
+                       Globals.img_mean, Globals.img_std)
     surface_embed = torch.cat(su_parts, dim=0)
     overhead_embed = torch.cat(ov_parts, dim=0)
     if world > 1:       # queries replicated, gallery rows stay sharded (SURVEY §8e retrieval partitioning)

@@ -12,8 +12,10 @@ import torch
 
 from . import cvig_fov as _fov
 from . import synth
-from .cvig_fov import (Adam, PolarTransform, Resize, correlation, crop_overhead, l2_distance, match, ranks,  # noqa: F401
-                       recall_table, sweep_scores, triplet_loss)
+from .cvig_fov import (Adam, PolarTransform, Resize, bilinear_interpolate, correlation, crop_overhead,  # noqa: F401
+                       inverse_normalize, l2_distance, match, ranks, recall_table, sweep_scores, triplet_loss)
+
+PROJECTOR_DUMP = False      # the reference has the embedding-projector dump commented out here (model/cvig_semantic.py:508-510, :567-571)
 
 
 class Globals(_fov.Globals):

@@ -473,6 +473,40 @@ def polar_lut(device, size=256, h_s=128, w_s=512):
     return lut
 
 
+def bilinear_interpolate(im, x, y):
+    """bilinear_interpolate(im, x, y) of model/cvig_fov.py:156-183 for arbitrary sample coordinates: im [C,H,W] (or
+    [B,C,H,W]) on the GPU, x / y arrays of one shape (host, fp64 arithmetic as in the reference: indices clipped to the
+    image BEFORE the weights are formed, weights rounded to fp32) -> [C,*x.shape] (or [B,C,*x.shape])."""
+    import numpy as np
+    lib = _lib.load()
+    im = _dev_f32(im, 'im')
+    squeeze = im.dim() == 3
+    if squeeze:
+        im = im.unsqueeze(0)
+    B, C, H, W = im.shape
+    x = np.asarray(x.cpu() if torch.is_tensor(x) else x)
+    y = np.asarray(y.cpu() if torch.is_tensor(y) else y)
+    if x.shape != y.shape:
+        raise _lib.WitwError('bilinear_interpolate: x and y must have the same shape')
+    x0 = np.floor(x).astype(int)
+    x1 = x0 + 1
+    y0 = np.floor(y).astype(int)
+    y1 = y0 + 1
+    x0 = np.clip(x0, 0, W - 1)
+    x1 = np.clip(x1, 0, W - 1)
+    y0 = np.clip(y0, 0, H - 1)
+    y1 = np.clip(y1, 0, H - 1)
+    wts = np.stack([(x1 - x) * (y1 - y), (x1 - x) * (y - y0), (x - x0) * (y1 - y), (x - x0) * (y - y0)], -1)
+    taps = np.stack([y0 * W + x0, y1 * W + x0, y0 * W + x1, y1 * W + x1], -1)
+    t = torch.from_numpy(np.ascontiguousarray(taps.reshape(-1, 4).astype(np.int32))).to(im.device)
+    w = torch.from_numpy(np.ascontiguousarray(wts.reshape(-1, 4).astype(np.float32))).to(im.device)
+    n = t.shape[0]
+    out = torch.empty((B, C) + tuple(x.shape), dtype=torch.float32, device=im.device)
+    _lib.check(lib.witw_bilinear_gather(im.data_ptr(), t.data_ptr(), w.data_ptr(), out.data_ptr(), B, C, H * W, n, _stream()),
+               'witw_bilinear_gather')
+    return out.squeeze(0) if squeeze else out
+
+
 def polar_transform(x, h_s=128, w_s=512):
     """[B,C,S,S] -> [B,C,128,512] (PolarTransform, model/cvig_fov.py:186-209)."""
     lib = _lib.load()
