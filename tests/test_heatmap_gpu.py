@@ -55,3 +55,37 @@ def test_sweep_matches_oracle(tmp_path):
     np.testing.assert_array_equal(back['orientation'].to_numpy(), (ori.squeeze() * 360 / 64 - 180).numpy())
     np.testing.assert_allclose(back['dissimilarity'].to_numpy(), dist.squeeze().numpy(), atol=1e-4)
     np.testing.assert_allclose(back['score'].to_numpy(), torch.exp(10. * (1. - dist.squeeze())).numpy(), rtol=2e-3)
+
+
+@pytest.mark.gpu
+def test_reference_tool_classes_reproduce_the_batched_path(tmp_path):
+    """ImageDataset / TileDataset / ResizeSurface / ResizeOverhead / ImageNormalization / PolarTransform of the reference
+    tool (tools/heatmap/heatmap.py:35-110), composed per sample, give the tensors the batched sweep feeds the encoders."""
+    import torch
+    from PIL import Image
+    from witw_amd import cvig_fov, heatmap, ops
+    g = np.random.Generator(np.random.Philox(key=[12, 1]))
+    strip = g.integers(0, 256, size=(3, 90, 120)).astype(np.float32)
+    src = heatmap.ArrayTileSource(strip, 1000.0, 2000.0, 0.5)
+    _ce, _cn, windows = heatmap.tile_windows((1005.0, 1960.0, 1045.0, 1995.0), 20.0, 10.0)
+    compose = [heatmap.ResizeOverhead(), heatmap.ImageNormalization(), heatmap.PolarTransform()]
+    ds = heatmap.TileDataset(src, windows)
+    assert len(ds) == len(windows)
+    d = ds[3]
+    for t in compose:
+        d = t(d)
+    tiles = heatmap._cut_tiles(src.read_strip(cvig_fov.device), src, [windows[3]])
+    x = ops.resize_bilinear(tiles, (256, 256), cvig_fov.Globals.img_mean, cvig_fov.Globals.img_std)
+    ref = ops.polar_transform(x, 128, 512)[0]
+    np.testing.assert_allclose(d['polar'].cpu().numpy(), ref.cpu().numpy(), rtol=0, atol=2e-6)
+    # photo side
+    photo = g.integers(0, 256, size=(48, 80, 3)).astype(np.uint8)
+    path = str(tmp_path / 'photo.png')
+    Image.fromarray(photo).save(path)
+    s = heatmap.ImageDataset([path], transform=None)[0]
+    for t in (heatmap.ResizeSurface(70), heatmap.ImageNormalization()):
+        s = t(s)
+    ref_s = ops.resize_bilinear(torch.from_numpy(photo.astype(np.float32).transpose(2, 0, 1)).unsqueeze(0).to(cvig_fov.device).contiguous(),
+                                (128, 99), cvig_fov.Globals.img_mean, cvig_fov.Globals.img_std)[0]
+    assert s['image'].shape == (3, 128, 99)
+    np.testing.assert_allclose(s['image'].cpu().numpy(), ref_s.cpu().numpy(), rtol=0, atol=2e-6)

@@ -12,7 +12,8 @@ import torch
 
 from . import cvig_fov as _fov
 from . import synth
-from .cvig_fov import (Adam, PolarTransform, Resize, bilinear_interpolate, correlation, crop_overhead,  # noqa: F401
+from .cvig_fov import (AddDropout, Adam, HorizCircPadding, PolarTransform, Resize, bilinear_interpolate,  # noqa: F401
+                       correlation, crop_overhead,
                        inverse_normalize, l2_distance, match, ranks, recall_table, sweep_scores, triplet_loss)
 
 PROJECTOR_DUMP = False      # the reference has the embedding-projector dump commented out here (model/cvig_semantic.py:508-510, :567-571)

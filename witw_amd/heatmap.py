@@ -69,6 +69,89 @@ class GdalTileSource(ArrayTileSource):
         super().__init__(ds.ReadAsArray(), gt[0], gt[3], gt[1])
 
 
+# ---- the reference tool's dataset / transform classes (tools/heatmap/heatmap.py:35-110), same names and dict -> dict
+# protocol ({'image': CHW float tensor}); the transforms run on the GPU through the C-ABI ops. sweep() below does
+# not need them (it batches the same steps), they are here for code written against the reference tool.
+class ImageDataset(torch.utils.data.Dataset):
+    """tools/heatmap/heatmap.py:35-47: photos by path -> {'image': CHW fp32}."""
+
+    def __init__(self, paths, transform=None):
+        self.paths = paths
+        self.transform = transform
+
+    def __len__(self):
+        return len(self.paths)
+
+    def __getitem__(self, idx):
+        data = {'image': cvig.ImagePairDataset._read(self.paths[idx])}
+        if self.transform is not None:
+            data = self.transform(data)
+        return data
+
+
+class TileDataset(torch.utils.data.Dataset):
+    """tools/heatmap/heatmap.py:50-66 with a tile source (ArrayTileSource / GdalTileSource) in place of the
+    per-tile gdal.Translate call: window idx -> {'image': [C,h,w]} cut from the strip."""
+
+    def __init__(self, source, windows, transform=None):
+        self.source = source
+        self.windows = windows
+        self.transform = transform
+        self._strip = None
+
+    def __len__(self):
+        return len(self.windows)
+
+    def __getitem__(self, idx):
+        if self._strip is None:
+            self._strip = self.source.read_strip(cvig.device)
+        data = {'image': _cut_tiles(self._strip, self.source, [self.windows[idx]])[0]}
+        if self.transform is not None:
+            data = self.transform(data)
+        return data
+
+
+class ResizeSurface(object):
+    """tools/heatmap/heatmap.py:69-78."""
+
+    def __init__(self, fov=360):
+        self.fov = fov
+        self.surface_width = int(self.fov / 360 * Globals.surface_width_max)
+
+    def __call__(self, data):
+        x = data['image'].to(cvig.device).float().contiguous()
+        data['image'] = ops.resize_bilinear(x.unsqueeze(0), (Globals.surface_height_max, self.surface_width))[0]
+        return data
+
+
+class ResizeOverhead(object):
+    """tools/heatmap/heatmap.py:81-87."""
+
+    def __call__(self, data):
+        x = data['image'].to(cvig.device).float().contiguous()
+        data['image'] = ops.resize_bilinear(x.unsqueeze(0), (Globals.overhead_size, Globals.overhead_size))[0]
+        return data
+
+
+class ImageNormalization(object):
+    """tools/heatmap/heatmap.py:90-101 (the ImageNet statistics are hard-coded there too)."""
+
+    def __call__(self, data):
+        x = data['image'].to(cvig.device).float().contiguous()
+        data['image'] = ops.normalize(x.unsqueeze(0), [0.485, 0.456, 0.406], [0.229, 0.224, 0.225])[0]
+        return data
+
+
+class PolarTransform(object):
+    """tools/heatmap/heatmap.py:104-110: {'image'} -> cvig.PolarTransform's dict ({'overhead', 'polar'})."""
+
+    def __init__(self):
+        self.transform = cvig.PolarTransform()
+
+    def __call__(self, data):
+        return self.transform({'overhead': data['image']})
+
+
 def _cut_tiles(strip, source, windows):
     """[N,C,h,w] tile stack cut from the device-resident strip (zero outside the raster)."""
     C, H, W = strip.shape
