@@ -1,6 +1,6 @@
 import sys, time, torch
 sys.path.insert(0,'/root/repo')
-from witw_amd import cvig_fov, synth
+from witw_amd import cvig_fov
 B=1024
 ov=torch.randn(B,16,4,64,device='cuda',requires_grad=True); su=torch.randn(B,16,4,64,device='cuda',requires_grad=True)
 for it in range(3):

@@ -11,7 +11,7 @@ Forward and backward run on the HIP kernels; because layer 0 trains, the backwar
 import torch
 
 from . import cvig_fov as _fov
-from . import synth
+
 from .cvig_fov import (AddDropout, Adam, HorizCircPadding, PolarTransform, Resize, bilinear_interpolate,  # noqa: F401
                        correlation, crop_overhead,
                        inverse_normalize, l2_distance, match, ranks, recall_table, sweep_scores, triplet_loss)
