@@ -1,0 +1,186 @@
+#!/usr/bin/env python
+"""Randomised parity sweep of the HIP kernels against the CPU oracle (test infrastructure, like tests/): random layer
+shapes through the C ABI, compared with torch CPU ops in the reference's op order.
+
+    python tools/fuzz_parity.py [seconds] [seed]
+
+Covers: fp32 conv forward (stride, circular/zero padding, ReLU, fused pool, GEO / NW variants by shape), its dgrad
+form, fp32 wgrad (+ bias), the 4-tap forms, bf16 conv forward / wgrad, the fused match (orientation exact, distance
+1e-5) with ragged batch sizes and widths. Prints one line per failure and a summary; exit code 1 on any failure.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import cvig_fov_oracle as O  # noqa: E402
+from witw_amd import ops  # noqa: E402
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    rng = np.random.default_rng(seed)
+    dev = torch.device('cuda:0')
+    torch.manual_seed(seed)
+    t0 = time.time()
+    n, fails = 0, []
+
+    def check(name, cfg, got, ref, tol):
+        err = float((got - ref).abs().max())
+        scale = max(1.0, float(ref.abs().max()))
+        if not np.isfinite(err) or err > tol * scale:
+            fails.append((name, cfg, err, scale))
+            print('FAIL %s %s: max err %.3e (scale %.3e)' % (name, cfg, err, scale), flush=True)
+
+    while time.time() - t0 < budget:
+        n += 1
+        kind = rng.integers(0, 9)
+        B = int(rng.integers(1, 5))
+        H = int(rng.integers(1, 40))
+        W = int(rng.integers(1, 140))
+        cin = int(rng.choice([8, 16, 24, 64, 72, 128]))
+        cout = int(rng.choice([8, 16, 64, 72, 128, 136, 256]))
+        sh = int(rng.choice([1, 2]))
+        circ = bool(rng.integers(0, 2))
+        relu = bool(rng.integers(0, 2))
+        x = torch.randn(B, cin, H, W)
+        w = torch.randn(cout, cin, 3, 3) * (2.0 / (9 * cin)) ** 0.5
+        b = torch.randn(cout) * 0.1
+        cfg = (B, H, W, cin, cout, sh, circ, relu)
+        try:
+            if kind == 0:       # fp32 forward (+ pool)
+                pool = sh == 1 and H >= 2 and W >= 2 and bool(rng.integers(0, 2))
+                ref = O.conv3x3(x, w, b, sh, circ)
+                if relu:
+                    ref = torch.relu(ref)
+                if pool:
+                    ref = torch.nn.functional.max_pool2d(ref, 2, 2)
+                y = ops.conv3x3_fwd(nhwc(x).to(dev), ops.PackedConv(w.to(dev), b.to(dev)), stride_h=sh, circular=circ, relu=relu,
+                                    pool=pool)
+                check('conv_fwd' + ('_pool' if pool else ''), cfg, y.cpu().permute(0, 3, 1, 2), ref, 3e-5)
+            elif kind == 1:     # fp32 wgrad + dgrad
+                xr = x.clone().requires_grad_(True)
+                wr = w.clone().requires_grad_(True)
+                br = b.clone().requires_grad_(True)
+                yref = O.conv3x3(xr, wr, br, sh, circ)
+                gy = torch.randn_like(yref)
+                yref.backward(gy)
+                dw, db = ops.conv3x3_wgrad(nhwc(x).to(dev), nhwc(gy).to(dev), cin, stride_h=sh, circular=circ)
+                check('wgrad', cfg, dw.cpu(), wr.grad, 3e-5)
+                check('bgrad', cfg, db.cpu(), br.grad, 3e-5)
+                if cout % 8 == 0:
+                    dx = ops.conv3x3_fwd(nhwc(gy).to(dev), ops.PackedConv(w.to(dev), None, transpose_flip=True), relu=False,
+                                         circular=circ, dilate_h=(sh == 2), out_h=H if sh == 2 else None)
+                    check('dgrad', cfg, dx.cpu().permute(0, 3, 1, 2), xr.grad, 3e-5)
+            elif kind == 2:     # 4-tap forms vs the zero-filled 3x3 form
+                w4 = w.clone()
+                w4[:, :, 0, :] = 0
+                w4[:, :, :, 0] = 0
+                xd = nhwc(x).to(dev)
+                y9 = ops.conv3x3_fwd(xd, ops.PackedConv(w4.to(dev), b.to(dev)), relu=relu)
+                y4 = ops.conv3x3_fwd(xd, ops.PackedConv(w4.to(dev), b.to(dev), taps4=True), relu=relu)
+                if not torch.equal(y9, y4):
+                    check('taps4_fwd', cfg, y4.cpu(), y9.cpu(), 0.0)
+                gy = torch.randn(B, H, W, cout).to(dev)
+                a9, _ = ops.conv3x3_wgrad(xd, gy, cin)
+                a4, _ = ops.conv3x3_wgrad(xd, gy, cin, taps4=True)
+                if not torch.equal(a9[:, :, 1:, 1:], a4[:, :, 1:, 1:]):
+                    check('taps4_wgrad', cfg, a4[:, :, 1:, 1:].cpu(), a9[:, :, 1:, 1:].cpu(), 0.0)
+            elif kind == 3:     # bf16 forward vs emulation
+                cin16 = (cin + 15) // 16 * 16
+                x = torch.randn(B, cin16, H, W).bfloat16().float()
+                w = (torch.randn(cout, cin16, 3, 3) * (2.0 / (9 * cin16)) ** 0.5)
+                ref = O.conv3x3(x, w.bfloat16().float(), b, sh, circ)
+                if relu:
+                    ref = torch.relu(ref)
+                last = cout % 16 != 0
+                y = ops.conv3x3_bf16_fwd(nhwc(x).to(dev).bfloat16(), ops.PackedConvBf16(w.to(dev), b.to(dev)), stride_h=sh,
+                                         circular=circ, relu=relu, out_nchw_f32=last)
+                if last:
+                    check('bf16_fwd_f32out', cfg, y.cpu(), ref, 3e-5)
+                else:
+                    got = y.float().cpu().permute(0, 3, 1, 2)
+                    r16 = ref.bfloat16().float()
+                    bad = (got - r16).abs() > (2 ** -7) * r16.abs() + 1e-6
+                    if bool(bad.any()):
+                        check('bf16_fwd', cfg, got, r16, 2 ** -7)
+            elif kind == 4:     # bf16 wgrad on bf16-exact operands
+                cin8, cout8 = (cin + 7) // 8 * 8, (cout + 7) // 8 * 8
+                x = torch.randn(B, cin8, H, W).bfloat16().float()
+                wr = torch.zeros(cout8, cin8, 3, 3, requires_grad=True)
+                br = torch.zeros(cout8, requires_grad=True)
+                yref = O.conv3x3(x, wr, br, sh, circ)
+                gy = torch.randn_like(yref).bfloat16().float()
+                yref.backward(gy)
+                dw, db = ops.conv3x3_wgrad_bf16(nhwc(x).to(dev).bfloat16(), nhwc(gy).to(dev).bfloat16(), cin8, stride_h=sh,
+                                                circular=circ)
+                check('wgrad_bf16', (B, H, W, cin8, cout8, sh, circ), dw.cpu(), wr.grad, 3e-5)
+                check('bgrad_bf16', (B, H, W, cin8, cout8, sh, circ), db.cpu(), br.grad, 3e-5)
+            elif kind == 6:     # first layer (C <= 4 -> 64), fp32 and bf16 forms
+                c = int(rng.integers(1, 5))
+                x = torch.randn(B, c, H, W)
+                w = torch.randn(64, c, 3, 3) * (2.0 / (9 * c)) ** 0.5
+                b = torch.randn(64) * 0.1
+                ref = torch.relu(O.conv3x3(x, w, b, 1, circ))
+                y = ops.conv3x3_first_fwd(x.to(dev), ops.PackedFirstConv(w.to(dev), b.to(dev)), circular=circ, relu=True)
+                check('first_fwd', (B, c, H, W, circ), y.cpu().permute(0, 3, 1, 2), ref, 3e-5)
+                ref16 = torch.relu(O.conv3x3(x.bfloat16().float(), w.bfloat16().float(), b, 1, circ)).bfloat16().float()
+                y16 = ops.conv3x3_first_fwd(x.to(dev), ops.PackedFirstConv(w.to(dev), b.to(dev), bf16=True), circular=circ, relu=True)
+                got = y16.float().cpu().permute(0, 3, 1, 2)
+                if bool(((got - ref16).abs() > (2 ** -7) * ref16.abs() + 1e-6).any()):
+                    check('first_fwd_bf16', (B, c, H, W, circ), got, ref16, 2 ** -7)
+            elif kind == 7:     # resize + normalise, polar transform
+                c = int(rng.integers(1, 6))
+                hi, wi = int(rng.integers(2, 90)), int(rng.integers(2, 90))
+                ho, wo = int(rng.integers(1, 70)), int(rng.integers(1, 70))
+                img = torch.rand(B, c, hi, wi) * 255
+                ref = torch.stack([O.resize_bilinear(img[i], (ho, wo)) for i in range(B)])
+                y = ops.resize_bilinear(img.to(dev), (ho, wo))
+                check('resize', (B, c, hi, wi, ho, wo), y.cpu(), ref, 2e-5)
+                sq = torch.rand(B, c, 256, 256)
+                refp = torch.stack([O.polar_transform(sq[i]) for i in range(min(B, 2))])
+                yp = ops.polar_transform(sq[:min(B, 2)].to(dev))
+                if not torch.equal(yp.cpu(), refp):
+                    check('polar', (B, c), yp.cpu(), refp, 0.0)
+            elif kind == 8:     # loss and rank counts on a random distance matrix
+                nb = int(rng.integers(2, 200))
+                d = torch.rand(nb, nb) * 4
+                ref = O.triplet_loss(d)
+                got = ops.triplet_loss_fwd(d.to(dev))
+                got = got[0] if isinstance(got, (tuple, list)) else got
+                check('triplet_loss', (nb,), got.cpu().reshape(()), ref.reshape(()), 2e-6)
+                rk = ops.rank_count(d.to(dev))
+                ref_rk = (d <= torch.diagonal(d)[None, :]).sum(0).to(torch.int32)
+                if not torch.equal(rk.cpu(), ref_rk):
+                    fails.append(('rank_count', (nb,), 0, 0))
+                    print('FAIL rank_count', nb, flush=True)
+            else:               # fused match (kinds 5 and above the list)
+                bo, bs, we = int(rng.integers(1, 40)), int(rng.integers(1, 150)), int(rng.integers(1, 65))
+                ov = torch.randn(bo, 16, 4, 64)
+                su = torch.randn(bs, 16, 4, we)
+                ori_r, d_r = O.match(ov, su)
+                sc = O.correlation_scores(ov, su)
+                top2 = torch.topk(sc, min(2, sc.shape[-1]), dim=-1).values
+                clear = (top2[..., 0] - top2[..., -1]) > 1e-3 if sc.shape[-1] > 1 else torch.ones_like(ori_r, dtype=torch.bool)
+                ori, d = ops.match_fwd(ov.to(dev), su.to(dev))[:2]
+                if not torch.equal(ori.cpu()[clear], ori_r[clear]):
+                    fails.append(('match_ori', (bo, bs, we), 0, 0))
+                    print('FAIL match orientation', (bo, bs, we), flush=True)
+                check('match_dist', (bo, bs, we), d.cpu()[clear], d_r[clear], 2e-5)
+        except Exception as e:      # an error return from the C ABI on a legal shape is a failure too
+            fails.append(('exception', cfg, str(e)[:200], kind))
+            print('EXC kind %d %s: %s' % (kind, cfg, str(e)[:300]), flush=True)
+    print('fuzz_parity: %d cases in %.0f s, %d failures' % (n, time.time() - t0, len(fails)), flush=True)
+    sys.exit(1 if fails else 0)
+
+
+if __name__ == '__main__':
+    main()
