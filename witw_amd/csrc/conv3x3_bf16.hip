@@ -27,6 +27,10 @@ constexpr int IW = TW + 2;
 #ifndef WITW_BF_DMA
 #define WITW_BF_DMA 1
 #endif
+#ifndef WITW_BF_SWAP
+#define WITW_BF_SWAP 0          // A/B builds: 1 = MFMA operands swapped (lane = pixel, register quad = 4 consecutive channels), the
+#endif                          //     epilogue transposes through LDS with 8-byte writes (12 instead of 40 LDS instructions per M-tile).
+                                //     Parity-green, but measured SLOWER per tile (epilogue 9.1 k -> 11.9 k ticks)
 #ifndef WITW_BF_SPREAD
 #define WITW_BF_SPREAD 5        // taps over which the staging pieces of a chunk are issued (1 = all at tap 0)
 #endif
@@ -276,8 +280,13 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_bf16_kernel(ConvBfArgs p
         for (int mt = 0; mt < WM; ++mt)
 #pragma unroll
             for (int nt = 0; nt < WN; ++nt)
+#if WITW_BF_SWAP
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb[set][nt]),
+                                                                     __builtin_bit_cast(bf16x8, fa[set][mt]), acc[mt][nt], 0, 0, 0);
+#else
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[set][mt]),
                                                                      __builtin_bit_cast(bf16x8, fb[set][nt]), acc[mt][nt], 0, 0, 0);
+#endif
     };
 
 #pragma unroll
@@ -351,6 +360,178 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_bf16_kernel(ConvBfArgs p
 #endif
     __syncthreads();      // the slabs below reuse the stages
 
+#if WITW_BF_SWAP
+    // ---- epilogue, swapped-operand form. acc[mt][nt][r] = output of PIXEL m = l31 of M-tile mt, CHANNEL
+    // nt*32 + 8*(r>>2) + 4*hq + (r&3) of this wave's 64: a register quad holds 4 consecutive channels of one pixel, so
+    // the LDS transposition writes 8 bytes of bf16 per quad (8 ds_write_b64 per M-tile instead of 32 scalar writes) into
+    // a [pixel][64 channels] slab of 128-byte rows whose 16-byte chunks are XOR-swizzled with the pixel index (and the
+    // two 8-byte halves of a chunk swapped on odd pixel octets): writes spread over all banks, the read-back is
+    // 4 ds_read_b128 per M-tile (8 channels of a pixel per lane, halves swapped back at compile time) -> 16-byte stores.
+    {
+        const int cbase = n0 + wn * 64;                 // first channel of this wave
+        const int m = l31;
+        // the bias of this lane's 8 channel quads is fetched once, up front (32 registers; fetching it where a quad is
+        // finished put a global-load latency in front of every LDS write); the Dropout2d scale, present on three layers of
+        // a training forward only, is fetched per quad
+        f32x4 bv4[WN][4];
+#pragma unroll
+        for (int nt = 0; nt < WN; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bv4[nt][g] = *reinterpret_cast<const f32x4*>(p.bias + cbase + nt * 32 + 8 * g + 4 * hq);
+        f32x4 bq, dq = {1.f, 1.f, 1.f, 1.f};
+        auto load_quad = [&](int nt, int g) {
+            bq = bv4[nt][g];
+            if (p.dropmask != nullptr) {
+                const int c = cbase + nt * 32 + 8 * g + 4 * hq;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dq[j] = (c + j < p.Cout) ? p.dropmask[(size_t)b * p.Cout + c + j] : 1.f;
+            }
+        };
+        auto fin = [&](float v, int nt, int g, int j) {      // conv + bias -> Dropout2d scale -> ReLU, after load_quad(nt, g)
+            (void)nt; (void)g;
+            v = (v + bq[j]) * dq[j];
+            if (p.relu) v = fmaxf(v, 0.f);
+            return v;
+        };
+        auto gate_open = [](unsigned short g) { return (g & 0x7fffu) != 0 && !(g & 0x8000u); };   // bf16 value > 0
+        const int Hy = POOL ? (p.Ho >> 1) : p.Ho;
+        const int Wy = POOL ? (p.Wo >> 1) : p.Wo;
+        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+        typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+        constexpr int SLABB = 32 * 128;
+        char* const slab0 = reinterpret_cast<char*>((wave & 1) ? stageB : stageA) + (wave >> 1) * (2 * SLABB);
+        const int prow = lane >> 3, oct = lane & 7;
+        // byte offset of (pixel row q, channel chunk k = nt*4 + g, half hq) inside a slab
+        auto wr_off = [&](int q, int k) { return q * 128 + (((k ^ (q & 7)) << 4) | ((hq ^ ((q >> 3) & 1)) << 3)); };
+        // read-back of one slab row group: pixel rows gq*8 + prow, chunk `oct`; halves come back swapped on odd gq
+        auto rd_chunk = [&](const char* slab, int gq) {
+            const u16x8 v = *reinterpret_cast<const u16x8*>(slab + (gq * 8 + prow) * 128 + ((oct ^ prow) << 4));
+            return (gq & 1) ? (u16x8){v[4], v[5], v[6], v[7], v[0], v[1], v[2], v[3]} : v;
+        };
+        auto store8 = [&](u16x8 o, int yy, int xx) {
+            const int nbase = cbase + oct * 8;
+            if (yy < Hy && xx < Wy && nbase < p.Cout) {
+                const size_t off = (((size_t)b * Hy + yy) * Wy + xx) * p.Cout + nbase;
+                if (p.gate != nullptr) {
+                    const u16x8 gt = *reinterpret_cast<const u16x8*>(p.gate + off);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (!gate_open(gt[e])) o[e] = 0;
+                }
+                __builtin_nontemporal_store(o, reinterpret_cast<u16x8*>(reinterpret_cast<unsigned short*>(p.y) + off));
+            }
+        };
+        if (p.out_nchw_f32 || (p.Cout & 7) != 0) {
+            // fp32 NCHW embedding (last layer) or a ragged channel count: lanes are consecutive pixels of a row, so
+            // every register is a coalesced run along x
+            if (!POOL) {
+#pragma unroll
+                for (int mt = 0; mt < WM; ++mt) {
+                    const int yy = oy0 + trow[mt], xx = ox0 + tcol[mt] + m;
+#pragma unroll
+                    for (int nt = 0; nt < WN; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int g = r >> 2, j = r & 3;
+                            const int c = cbase + nt * 32 + 8 * g + 4 * hq + j;
+                            if (j == 0) load_quad(nt, g);
+                            float v = fin(acc[mt][nt][r], nt, g, j);
+                            if (yy < Hy && xx < Wy && c < p.Cout) {
+                                if (p.out_nchw_f32) {
+                                    reinterpret_cast<float*>(p.y)[(((size_t)b * p.Cout + c) * Hy + yy) * Wy + xx] = v;
+                                } else {
+                                    const size_t o = (((size_t)b * Hy + yy) * Wy + xx) * p.Cout + c;
+                                    if (p.gate != nullptr && !gate_open(p.gate[o])) v = 0.f;
+                                    reinterpret_cast<__bf16*>(p.y)[o] = (__bf16)v;
+                                }
+                            }
+                        }
+                }
+            } else {
+#pragma unroll
+                for (int pr = 0; pr < WM / 2; ++pr) {
+                    const int mtA = (TN == 128) ? (pr & 1) : 0;
+                    const int mtB = (TN == 128) ? (2 + (pr & 1)) : 1;
+                    const int yy = (oy0 + trow[mtA]) >> 1, xx = ((ox0 + tcol[mtA]) >> 1) + (m >> 1);
+#pragma unroll
+                    for (int nt = 0; nt < WN; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int g = r >> 2, j = r & 3;
+                            const int c = cbase + nt * 32 + 8 * g + 4 * hq + j;
+                            if (j == 0) load_quad(nt, g);
+                            float v = fmaxf(acc[mtA][nt][r], acc[mtB][nt][r]);
+                            v = fmaxf(v, __shfl_xor(v, 1, 64));
+                            v = fin(v, nt, g, j);
+                            if (!(m & 1) && yy < Hy && xx < Wy && c < p.Cout)
+                                reinterpret_cast<__bf16*>(p.y)[(((size_t)b * Hy + yy) * Wy + xx) * p.Cout + c] = (__bf16)v;
+                        }
+                }
+            }
+        } else if (!POOL) {
+            auto write_tile = [&](int mt, char* slab) {
+#pragma unroll
+                for (int nt = 0; nt < WN; ++nt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        bf16x4 q;
+                        load_quad(nt, g);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) q[j] = (__bf16)fin(acc[mt][nt][4 * g + j], nt, g, j);
+                        *reinterpret_cast<bf16x4*>(slab + wr_off(m, nt * 4 + g)) = q;
+                    }
+            };
+            write_tile(0, slab0);
+#pragma unroll
+            for (int mt = 0; mt < WM; ++mt) {
+                if (mt + 1 < WM) write_tile(mt + 1, slab0 + ((mt + 1) & 1) * SLABB);
+                const char* slab = slab0 + (mt & 1) * SLABB;
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq)
+                    store8(rd_chunk(slab, gq), oy0 + trow[mt], ox0 + tcol[mt] + gq * 8 + prow);
+            }
+        } else {
+            // fused 2x2 max-pool: vertical partner = the M-tile one row below (same lane), horizontal partner = the
+            // neighbouring lane; even lanes keep the pooled pixel m/2 (16 per M-tile pair)
+#pragma unroll
+            for (int pr = 0; pr < WM / 2; ++pr) {
+                const int mtA = (TN == 128) ? (pr & 1) : 0;
+                const int mtB = (TN == 128) ? (2 + (pr & 1)) : 1;
+                const int yy = (oy0 + trow[mtA]) >> 1;
+                const int xb = (ox0 + tcol[mtA]) >> 1;
+                const int pc = m >> 1;
+                char* slab = slab0 + (pr & 1) * SLABB;
+#pragma unroll
+                for (int nt = 0; nt < WN; ++nt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        bf16x4 q;
+                        unsigned code4 = 0;
+                        load_quad(nt, g);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float a00 = acc[mtA][nt][4 * g + j], a10 = acc[mtB][nt][4 * g + j];
+                            const float a01 = __shfl_xor(a00, 1, 64), a11 = __shfl_xor(a10, 1, 64);
+                            const float mx = fmaxf(fmaxf(a00, a01), fmaxf(a10, a11));
+                            q[j] = (__bf16)fin(mx, nt, g, j);
+                            // first position attaining the max, scan order (0,0),(0,1),(1,0),(1,1) as torch's max_pool2d
+                            const unsigned code = (a00 == mx) ? 0u : (a01 == mx) ? 1u : (a10 == mx) ? 2u : 3u;
+                            code4 |= code << (8 * j);
+                        }
+                        if (!(m & 1)) {
+                            *reinterpret_cast<bf16x4*>(slab + wr_off(pc, nt * 4 + g)) = q;
+                            const int c = cbase + nt * 32 + 8 * g + 4 * hq;
+                            if (p.pool_code != nullptr && yy < Hy && xb + pc < Wy && c < p.Cout)
+                                *reinterpret_cast<unsigned*>(p.pool_code + (((size_t)b * Hy + yy) * Wy + xb + pc) * p.Cout + c) = code4;
+                        }
+                    }
+#pragma unroll
+                for (int gq = 0; gq < 2; ++gq)
+                    store8(rd_chunk(slab, gq), yy, xb + gq * 8 + prow);
+            }
+        }
+    }
+#else
     // ---- epilogue
     float bv[WN], dm[WN];
     int nch[WN];
@@ -494,6 +675,7 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_bf16_kernel(ConvBfArgs p
                     }
         }
     }
+#endif      // WITW_BF_SWAP
 #ifdef WITW_BF_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0 && p.stamps != nullptr) {
