@@ -68,7 +68,7 @@ def main():
     ap.add_argument('--gallery', type=int, default=125000, help='retrieval: gallery rows PER GPU (1M / 8)')
     ap.add_argument('--queries', type=int, default=10000, help='retrieval: ground queries (replicated)')
     ap.add_argument('--topk', type=int, default=10)
-    ap.add_argument('--precision', choices=['fp32', 'bf16'], default='fp32',
+    ap.add_argument('--precision', choices=['fp32', 'bf16', 'fp16x3'], default='fp32',
                     help='fp32 (headline, BASELINE configs[1]) or the bf16 MFMA inference path (configs[3] arithmetic)')
     ap.add_argument('--model', choices=['fov', 'semantic'], default='fov',
                     help='fov = cvig_fov (3-channel, BASELINE configs[1]); semantic = cvig_semantic (5-channel first conv, '
@@ -118,6 +118,9 @@ def main():
     overhead_encoder = model_mod.FOV_DSM(circ_padding=True, weights=wts).to(device)
     train = a.mode == 'train'
     bf16 = a.precision == 'bf16'
+    f16x3 = a.precision == 'fp16x3'      # fp32-grade products as fp16 hi/lo triples on the fp16 MFMA (inference)
+    if f16x3 and train:
+        sys.exit('the fp16x3 path is inference only')
     if bf16 and train:
         surface_encoder.precision = overhead_encoder.precision = 'bf16'     # mixed-precision step, fp32 master weights
     surface_encoder.train(train)
@@ -151,8 +154,11 @@ def main():
             surface = ops.resize_bilinear(ground_raw, (128, ws), mean, std, ndiv)
             overhead = ops.resize_bilinear(ov_raw, (256, 256), mean, std, ndiv)
             polar = ops.polar_transform(overhead)
-            su = surface_encoder.forward_bf16(surface) if bf16 else surface_encoder(surface)
-            ov = overhead_encoder.forward_bf16(polar) if bf16 else overhead_encoder(polar)
+            if f16x3:
+                su, ov = surface_encoder.forward_f16x3(surface), overhead_encoder.forward_f16x3(polar)
+            else:
+                su = surface_encoder.forward_bf16(surface) if bf16 else surface_encoder(surface)
+                ov = overhead_encoder.forward_bf16(polar) if bf16 else overhead_encoder(polar)
             ov_all = parallel._all_gather_cat(ov) if world > 1 else ov     # global gallery; surfaces stay local
             loss, ranks, ori, d = cvig_fov.evaluate_global_batch(ov_all, su, rank * B)
         return loss, ranks, ori
@@ -198,9 +204,10 @@ def main():
     value = pairs / dt
 
     # ---- live roofline of the dominant kernel (HIP events on the launch stream, timed region only)
-    dominant = ('bf16', 128, 1, False) if bf16 else DOMINANT
+    dominant = ('bf16', 128, 1, False) if bf16 else ('f16x3', 128, 1, False) if f16x3 else DOMINANT
     peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
-    kname = 'conv3x3_nhwc_bf16_kernel<128,1,false,8>' if bf16 else 'conv3x3_nhwc_f32_kernel<128,1,false,8,0,9>'
+    kname = 'conv3x3_nhwc_bf16_kernel<128,1,false,8>' if bf16 else 'conv3x3_nhwc_f16x3_kernel<128,1,false,8>' if f16x3 else \
+        'conv3x3_nhwc_f32_kernel<128,1,false,8,0,9>'
     dom = [(fl, e0.elapsed_time(e1)) for (v, fl, e0, e1) in prof if v == dominant]
     allc = [(fl, e0.elapsed_time(e1)) for (v, fl, e0, e1) in prof if v[0] not in ('match', 'wgrad_bf16')]
     wg = [(fl, e0.elapsed_time(e1)) for (v, fl, e0, e1) in prof if v[0] == 'wgrad_bf16']
@@ -221,9 +228,11 @@ def main():
     out = {
         'metric': 'image-pairs/sec (embedding+similarity)' if not train else 'image-pairs/sec (training step)', 'value': round(value, 2), 'unit': 'pairs/s',
         'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 3),
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16' if bf16 else 'f32', 'data': 'synthetic',
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'bf16' if bf16 else 'f16x3 (fp16 hi+lo operands, 3 fp16 MFMAs per fp32-equivalent product, fp32 accumulate)' if f16x3 else 'f32',
+        'data': 'synthetic',
         'config': {'workload': ('%s fov=%d eval%s: resize+normalize+polar -> 2x FOV_DSM (VGG16[:23]+3 conv) -> '
-                                'fused match + soft-margin triplet loss + rank counts' % (mname, a.fov, ' [bf16 MFMA encoders, fp32 accumulate; matching fp32]' if bf16 else '')) if not train else
+                                'fused match + soft-margin triplet loss + rank counts' % (mname, a.fov, ' [bf16 MFMA encoders, fp32 accumulate; matching fp32]' if bf16 else ' [fp16x3 encoders: fp32-grade products on the fp16 MFMA; matching fp32]' if f16x3 else '')) if not train else
                                ('%s fov=%d TRAIN step: resize+normalize+polar -> 2x FOV_DSM fwd (Dropout2d) -> match + '
                                 'triplet loss -> backward (%s) -> grad all-reduce -> Adam'
                                 % (mname + (' [bf16 MFMA fwd/dgrad/wgrad, fp32 accumulate + master weights]' if bf16 else ''), a.fov,
@@ -246,7 +255,7 @@ def main():
                         if wg else {})},
     }
 
-    if rank == 0 and world == 1 and not a.no_cpu_baseline and not train and not bf16:
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and not train and not bf16 and not f16x3:
         out['cpu_baseline'] = cpu_baseline(a, ground_raw, ov_raw, wts, ws, step, semantic)
     if rank == 0:
         print(json.dumps(out), flush=True)

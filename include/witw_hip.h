@@ -145,6 +145,18 @@ int witw_nchw_f32_to_nhwc_bf16(const float* x, void* y_bf16, int B, int C, int H
 int witw_conv3x3_bf16_fwd(const void* x_bf16, const void* wpk_bf16, const float* bias, void* y, int B, int H, int W, int Cin,
                           int Cout, int stride_h, int pad_circular, int relu, int pool, int out_nchw_f32, void* stream);
 
+/* ---- fp32-grade inference on the fp16 MFMA ("fp16x3"): every value is carried as hi = fp16(x), lo = fp16(x - hi) and a
+ * product is hi*hi + lo*hi + hi*lo with fp32 accumulation (3 MFMAs of the 2.5 PF/s pipe per fp32-equivalent product; the
+ * encoder stays within 2e-5 of fp64, like the fp32 MFMA path, inside the reference goldens' 1e-4). Activations are NHWC
+ * "split-fp16": per pixel and 8 channels 16 B of hi then 16 B of lo ([B,H,W,C/8,2,8] fp16, 4 B per value). Same layer
+ * arguments as witw_conv3x3_bf16_fwd; the last layer writes the fp32 NCHW embedding (out_nchw_f32). */
+long long witw_conv3x3_f16x3_packed_elems(int cout, int cin);
+int witw_conv3x3_f16x3_pack_weights(const float* w_kcrs, void* wpk_f16, int cout, int cin, void* stream);
+int witw_nchw_f32_to_split_f16(const float* x, void* y_split, int B, int C, int H, int W, int Cpad, void* stream);
+int witw_split_f16_to_f32(const void* x_split, float* y /*[pixels][C]*/, long long pixels, int C, void* stream);
+int witw_conv3x3_f16x3_fwd(const void* x_split, const void* wpk_f16, const float* bias, void* y, int B, int H, int W, int Cin,
+                           int Cout, int stride_h, int pad_circular, int relu, int pool, int out_nchw_f32, void* stream);
+
 /* ---- bf16 (mixed-precision) TRAINING step of the encoder: the backward of the reference's training loop
  * (model/cvig_fov.py:447-460, autograd through torch.nn.Conv2d) with bf16 MFMA operands, fp32 accumulate, fp32
  * weight gradients / master weights / Adam.

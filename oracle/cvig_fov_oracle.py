@@ -305,3 +305,24 @@ def fov_dsm_forward_bf16_emulated(x, weights, circ_padding):
         if idx != last:
             x = r(x)
     return x
+
+
+def fov_dsm_forward_f16x3_emulated(x, weights, circ_padding):
+    """What the fp16x3 path computes, emulated on the CPU: every layer input and filter is split into hi = fp16(v) and
+    lo = fp16(v - hi) (fp16 subnormals kept, as the MI355X matrix core does) and the convolution is the sum of the
+    hi*hi, lo*hi and hi*lo convolutions in fp32; bias / ReLU / max-pool in fp32. (No reference counterpart; the path is
+    ALSO held directly to the reference goldens at the fp32 tolerance.)"""
+    def split(t):
+        hi = t.half().float()
+        return hi, (t - hi).half().float()
+    for (idx, sh, relu, pool, drop) in FOV_LAYERS:
+        w, b = weights[idx]
+        xh, xl = split(x)
+        wh, wl = split(w)
+        z = torch.zeros_like(b)
+        x = conv3x3(xh, wh, b, sh, circ_padding) + conv3x3(xl, wh, z, sh, circ_padding) + conv3x3(xh, wl, z, sh, circ_padding)
+        if relu:
+            x = F.relu(x)
+        if pool:
+            x = F.max_pool2d(x, 2, 2)
+    return x

@@ -246,6 +246,32 @@ class FOV_DSM(torch.nn.Module):
                                          pool=pool, out_nchw_f32=(idx == last))
         return h
 
+    def _pack_f16x3(self, idx):
+        conv = _conv_of(self.model.features[idx])
+        key = (conv.weight.data_ptr(), conv.weight._version, conv.bias._version, getattr(conv.weight, '_witw_version', 0),
+               getattr(conv.bias, '_witw_version', 0))
+        hit = self._packed.get(('f16x3', idx))
+        if hit is None or hit[0] != key:
+            hit = (key, ops.PackedConvF16x3(conv.weight, conv.bias))
+            self._packed[('f16x3', idx)] = hit
+        return hit[1]
+
+    def forward_f16x3(self, x):
+        """Inference with fp32-grade accuracy on the fp16 MFMA (csrc/conv3x3_f16x3.hip): every activation and filter
+        value is carried as fp16 hi + fp16 lo, products are hi*hi + lo*hi + hi*lo with fp32 accumulation. Held to the SAME
+        reference goldens and tolerance (1e-4) as the fp32 path (tests/test_f16x3_gpu.py). Eval only."""
+        if not x.is_cuda:
+            raise _lib.WitwError('FOV_DSM.forward_f16x3 needs a GPU tensor (no CPU fallback)')
+        if self.training:
+            raise _lib.WitwError('forward_f16x3 is an inference path; call .eval()')
+        with torch.no_grad():
+            h = ops.nchw_to_split_f16(x.contiguous(), 8)
+            last = self.layer_specs[-1][0]
+            for (idx, sh, relu, pool, drop) in self.layer_specs:
+                h = ops.conv3x3_f16x3_fwd(h, self._pack_f16x3(idx), stride_h=sh, circular=self.circ_padding, relu=relu,
+                                          pool=pool, out_nchw_f32=(idx == last))
+        return h
+
     def trainable_convs(self):
         return [(idx, _conv_of(self.model.features[idx])) for (idx, *_r) in self.layer_specs
                 if _conv_of(self.model.features[idx]).weight.requires_grad]

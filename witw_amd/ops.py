@@ -742,6 +742,74 @@ def conv3x3_wgrad_bf16(x_nhwc, dz_nhwc, cin_real, stride_h=1, circular=False, wa
     return dw, db
 
 
+# ----------------------------------------------------------------------------- fp16x3: fp32-grade inference on the fp16 MFMA
+class PackedConvF16x3:
+    """fp16 hi / lo filter packing of one 3x3 conv for the fp16x3 kernel (19 slots per 8-channel chunk) + fp32 bias."""
+
+    def __init__(self, weight, bias):
+        lib = _lib.load()
+        w = _dev_f32(weight.detach(), 'weight')
+        self.cout, self.cin = w.shape[0], w.shape[1]
+        self.cin_pad = (self.cin + 7) // 8 * 8
+        self.wpk = torch.empty(lib.witw_conv3x3_f16x3_packed_elems(self.cout, self.cin), dtype=torch.float16, device=w.device)
+        _lib.check(lib.witw_conv3x3_f16x3_pack_weights(w.data_ptr(), self.wpk.data_ptr(), self.cout, self.cin, _stream()),
+                   'witw_conv3x3_f16x3_pack_weights')
+        self.bias = torch.zeros(lib.witw_conv3x3_bias_floats(self.cout), dtype=torch.float32, device=w.device)
+        if bias is not None:
+            self.bias[:self.cout].copy_(bias.detach())
+
+
+def nchw_to_split_f16(x, cpad=8):
+    """NCHW fp32 -> split-fp16 NHWC [B,H,W,cpad/8,2,8] (hi plane, lo plane per 8 channels)."""
+    lib = _lib.load()
+    x = _dev_f32(x, 'x')
+    B, C, H, W = x.shape
+    y = torch.empty((B, H, W, cpad // 8, 2, 8), dtype=torch.float16, device=x.device)
+    _lib.check(lib.witw_nchw_f32_to_split_f16(x.data_ptr(), y.data_ptr(), B, C, H, W, cpad, _stream()), 'witw_nchw_f32_to_split_f16')
+    return y
+
+
+def split_f16_to_f32(x_split):
+    """split-fp16 NHWC [B,H,W,C/8,2,8] -> fp32 NHWC [B,H,W,C] (hi + lo)."""
+    lib = _lib.load()
+    B, H, W, C8 = x_split.shape[:4]
+    y = torch.empty((B, H, W, C8 * 8), dtype=torch.float32, device=x_split.device)
+    _lib.check(lib.witw_split_f16_to_f32(x_split.data_ptr(), y.data_ptr(), B * H * W, C8 * 8, _stream()), 'witw_split_f16_to_f32')
+    return y
+
+
+def conv3x3_f16x3_fwd(x_split, packed, stride_h=1, circular=False, relu=True, pool=False, out_nchw_f32=False):
+    """x split-fp16 NHWC [B,H,W,Cin/8,2,8] -> split-fp16 NHWC [B,Hy,Wy,Cout/8,2,8] (or the fp32 NCHW embedding)."""
+    lib = _lib.load()
+    if not (x_split.is_cuda and x_split.dtype == torch.float16 and x_split.is_contiguous() and x_split.dim() == 6
+            and tuple(x_split.shape[4:]) == (2, 8)):
+        raise _lib.WitwError('conv3x3_f16x3_fwd: x must be a contiguous float16 GPU tensor shaped [B,H,W,C/8,2,8]')
+    B, H, W, C8 = x_split.shape[:4]
+    C = C8 * 8
+    if C != packed.cin_pad:
+        raise _lib.WitwError('conv3x3_f16x3_fwd: input has %d channels, packed weights expect %d' % (C, packed.cin_pad))
+    Ho = (H + 2 - 3) // stride_h + 1
+    Hy, Wy = (Ho // 2, W // 2) if pool else (Ho, W)
+    if out_nchw_f32:
+        y = torch.empty((B, packed.cout, Hy, Wy), dtype=torch.float32, device=x_split.device)
+    else:
+        if packed.cout % 8:
+            raise _lib.WitwError('conv3x3_f16x3_fwd: a split-fp16 output needs Cout %% 8 == 0')
+        y = torch.empty((B, Hy, Wy, packed.cout // 8, 2, 8), dtype=torch.float16, device=x_split.device)
+    prof = PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.check(lib.witw_conv3x3_f16x3_fwd(x_split.data_ptr(), packed.wpk.data_ptr(), packed.bias.data_ptr(), y.data_ptr(), B, H, W,
+                                          C, packed.cout, stride_h, int(circular), int(relu), int(pool), int(out_nchw_f32),
+                                          _stream()), 'witw_conv3x3_f16x3_fwd')
+    if prof is not None:
+        e1.record()
+        prof.append((('f16x3', lib.witw_conv3x3_tile_n(packed.cout), stride_h, bool(pool)),
+                     2.0 * packed.cin * packed.cout * 9 * Ho * W * B, e0, e1))
+    return y
+
+
 def bn_train_stats(a, valid_hw, gamma, beta, running_mean=None, running_var=None, eps=1e-5, momentum=0.1):
     """Batch statistics of BatchNorm2d over the valid region of a NHWC tensor -> (mean, invstd, scale, shift)."""
     lib = _lib.load()
