@@ -205,7 +205,9 @@ def main():
 
     # ---- live roofline of the dominant kernel (HIP events on the launch stream, timed region only)
     dominant = ('bf16', 128, 1, False) if bf16 else ('f16x3', 128, 1, False) if f16x3 else DOMINANT
-    peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
+    # fp16x3 executes 28 fp16 MFMAs (K=16) per 16 input channels and 9 taps where a plain fp16 conv needs 9: its bound in
+    # fp32-equivalent FLOP/s is the dense fp16 MFMA peak x 9/28
+    peak = PEAK_BF16_MFMA_TFLOPS if bf16 else round(PEAK_BF16_MFMA_TFLOPS * 9 / 28, 1) if f16x3 else PEAK_F32_MFMA_TFLOPS
     kname = 'conv3x3_nhwc_bf16_kernel<128,1,false,8>' if bf16 else 'conv3x3_nhwc_f16x3_kernel<128,1,false,8>' if f16x3 else \
         'conv3x3_nhwc_f32_kernel<128,1,false,8,0,9>'
     dom = [(fl, e0.elapsed_time(e1)) for (v, fl, e0, e1) in prof if v == dominant]
@@ -252,7 +254,10 @@ def main():
                      'traffic': traffic, 'launches': len(dom), 'avg_launch_ms': round(dom_ms, 4),
                      'avg_launch_gflop': round(dom_fl / 1e9, 2), 'all_conv_launches_tflops': round(conv_tf, 2),
                      **({'wgrad_bf16_tflops_incl_layout_passes': round(sum(f for f, _ in wg) / (sum(m for _, m in wg) * 1e-3) / 1e12, 2)}
-                        if wg else {})},
+                        if wg else {}),
+                     **({'note': 'achieved = fp32-equivalent FLOP/s (2*Cin*Cout*9 per output); peak = dense fp16 MFMA peak x 9/28 '
+                                 '(the split arithmetic issues 28 MFMAs where a plain fp16 conv issues 9); the fp32 MFMA peak is 157.3'}
+                        if f16x3 else {})},
     }
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline and not train and not bf16 and not f16x3:

@@ -69,6 +69,10 @@ def test_train_then_test_drivers_bf16(tmp_path, monkeypatch, capsys):
     assert all(v.dtype == torch.float32 for v in sd.values())
     table = cvig_fov.test(dataset='cvusa', fov=70, batch_size=4, num_workers=0, csv_path=csv)
     assert 'Top  1:' in capsys.readouterr().out and 1 <= table['median'] <= 6
+    # evaluation on the fp16x3 arithmetic reads the same fp32 checkpoints
+    monkeypatch.setattr(cvig_fov.Globals, 'precision', 'fp16x3')
+    t3 = cvig_fov.test(dataset='cvusa', fov=70, batch_size=4, num_workers=0, csv_path=csv)
+    assert 1 <= t3['median'] <= 6
 
 
 def test_projector_dump_inverse_normalize_and_bilinear_interpolate(tmp_path, monkeypatch):

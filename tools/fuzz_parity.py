@@ -42,7 +42,7 @@ def main():
 
     while time.time() - t0 < budget:
         n += 1
-        kind = rng.integers(0, 9)
+        kind = rng.integers(0, 10)
         B = int(rng.integers(1, 5))
         H = int(rng.integers(1, 40))
         W = int(rng.integers(1, 140))
@@ -162,6 +162,24 @@ def main():
                 if not torch.equal(rk.cpu(), ref_rk):
                     fails.append(('rank_count', (nb,), 0, 0))
                     print('FAIL rank_count', nb, flush=True)
+            elif kind == 9:     # fp16x3 forward vs fp64
+                cin8 = (cin + 7) // 8 * 8
+                pool = sh == 1 and H >= 2 and W >= 2 and bool(rng.integers(0, 2))
+                x = torch.randn(B, cin8, H, W)
+                w = torch.randn(cout, cin8, 3, 3) * (2.0 / (9 * cin8)) ** 0.5
+                ref = O.conv3x3(x.double(), w.double(), b.double(), sh, circ)
+                if relu:
+                    ref = torch.relu(ref)
+                if pool:
+                    ref = torch.nn.functional.max_pool2d(ref, 2, 2)
+                last = cout % 8 != 0
+                y = ops.conv3x3_f16x3_fwd(ops.nchw_to_split_f16(x.to(dev), cin8), ops.PackedConvF16x3(w.to(dev), b.to(dev)),
+                                          stride_h=sh, circular=circ, relu=relu, pool=pool and not last, out_nchw_f32=last)
+                if last and pool:
+                    ref = O.conv3x3(x.double(), w.double(), b.double(), sh, circ)
+                    ref = torch.relu(ref) if relu else ref
+                got = y.cpu() if last else ops.split_f16_to_f32(y).cpu().permute(0, 3, 1, 2)
+                check('f16x3_fwd', (B, H, W, cin8, cout, sh, circ, relu, pool), got, ref.float(), 5e-6)
             else:               # fused match (kinds 5 and above the list)
                 bo, bs, we = int(rng.integers(1, 40)), int(rng.integers(1, 150)), int(rng.integers(1, 65))
                 ov = torch.randn(bo, 16, 4, 64)

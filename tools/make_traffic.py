@@ -12,7 +12,7 @@ import json
 import sys
 from collections import defaultdict
 
-DOMINANT = ('conv3x3_nhwc_f32_kernel<128,1,false,8', 'conv3x3_nhwc_bf16_kernel<128,1,false,8')
+DOMINANT = ('conv3x3_nhwc_f32_kernel<128,1,false,8', 'conv3x3_nhwc_bf16_kernel<128,1,false,8', 'conv3x3_nhwc_f16x3_kernel<128,1,false,8')
 
 
 def per_kernel(path, counter):
@@ -48,7 +48,7 @@ def main():
                           'hbm_bytes_per_launch_corrected': int((2 * f + w) * 1024)}
             compact = k.replace(' ', '')
             if compact.startswith(DOMINANT):
-                suffix = '' if tag in ('infer', 'bf16') else '_' + tag
+                suffix = '' if tag in ('infer', 'bf16', 'fp16x3') else '_' + tag
                 out['%s_bytes_per_launch_B%d%s' % (compact, batch, suffix)] = kernels[k]['hbm_bytes_per_launch_corrected']
         out['kernels_%s' % tag] = kernels
     print(json.dumps(out, indent=1))

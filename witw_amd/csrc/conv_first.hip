@@ -56,7 +56,7 @@ __global__ __launch_bounds__(FT, 2) void conv3x3_first_kernel(FirstArgs p) {
             const float* src = p.x + (size_t)b * p.C * plane + (size_t)gr * p.W + gc;
 #pragma unroll
             for (int ch = 0; ch < 4; ++ch)
-                if (ch < p.C) v[ch] = p.out_bf16 ? (float)(__bf16)src[ch * plane] : src[ch * plane];
+                if (ch < p.C) v[ch] = (p.out_bf16 == 1) ? (float)(__bf16)src[ch * plane] : src[ch * plane];
         }
         in_s[s] = v;
     }
@@ -118,6 +118,31 @@ __global__ __launch_bounds__(FT, 2) void conv3x3_first_kernel(FirstArgs p) {
                 const f32x4 v = *reinterpret_cast<const f32x4*>(slab + m * 64 + pc4);
                 if (yy < p.H && xx < p.W)
                     *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.y) + (((size_t)b * p.H + yy) * p.W + xx) * 64 + pc4) = v;
+            }
+        } else if (p.out_bf16 == 2) {
+            // split-fp16 output of the fp16x3 path (conv3x3_f16x3.hip): exact fp32 arithmetic here, then per pixel and 8
+            // channels 16 B of hi = fp16(v) followed by 16 B of lo = fp16(v - hi)
+            typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+            const int prow = lane >> 3, pc8 = (lane & 7) * 8;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int m = g * 8 + prow;
+                const int xx = ox0 + col0 + m;
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(slab + m * 64 + pc8);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(slab + m * 64 + pc8 + 4);
+                f16x8 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    hi[e] = (_Float16)v0[e];
+                    hi[4 + e] = (_Float16)v1[e];
+                    lo[e] = (_Float16)(v0[e] - (float)hi[e]);
+                    lo[4 + e] = (_Float16)(v1[e] - (float)hi[4 + e]);
+                }
+                if (yy < p.H && xx < p.W) {
+                    f16x8* dst = reinterpret_cast<f16x8*>(reinterpret_cast<_Float16*>(p.y) + ((((size_t)b * p.H + yy) * p.W + xx) * 64 + pc8) * 2);
+                    dst[0] = hi;
+                    dst[1] = lo;
+                }
             }
         } else {
             const int prow = lane >> 3, pc8 = (lane & 7) * 8;
@@ -300,7 +325,8 @@ int witw_conv3x3_first_pack(const float* w, float* wf, int C, int round_bf16, vo
 
 // x NCHW fp32 [B,C,H,W] (C <= 4) -> y NHWC [B,H,W,64] (fp32, or bf16 if out_bf16; with out_bf16 the INPUT is
 // rounded to bf16 on load so that the arithmetic equals the bf16 path's: bf16 operands, fp32 accumulate, and wf
-// must come from witw_conv3x3_first_pack(round_bf16 = 1), which writes the bf16 kernel's filter image).
+// must come from witw_conv3x3_first_pack(round_bf16 = 1), which writes the bf16 kernel's filter image). out_bf16 = 2: exact
+// fp32 arithmetic (wf packed with round_bf16 = 0) and a split-fp16 output [B,H,W,8,2,8] for the fp16x3 path.
 int witw_conv3x3_first_fwd(const float* x, const float* wf, const float* bias, void* y, int B, int C, int H, int W,
                            int pad_circular, int relu, int out_bf16, void* stream) {
     WITW_CHECK_ARG(x && wf && bias && y, "conv3x3_first_fwd: null pointer");
@@ -312,7 +338,7 @@ int witw_conv3x3_first_fwd(const float* x, const float* wf, const float* bias, v
     a.circ = pad_circular; a.relu = relu; a.out_bf16 = out_bf16;
     const long long grid = (long long)B * a.tiles_x * a.tiles_y;
     WITW_CHECK_ARG(grid <= 0x7fffffffLL, "conv3x3_first_fwd: grid too large");
-    if (out_bf16)
+    if (out_bf16 == 1)
         hipLaunchKernelGGL(conv3x3_first_bf16_kernel, dim3((unsigned)grid), dim3(FT), 0, (hipStream_t)stream, a);
     else
         hipLaunchKernelGGL(conv3x3_first_kernel, dim3((unsigned)grid), dim3(FT), 0, (hipStream_t)stream, a);

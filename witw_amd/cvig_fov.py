@@ -89,7 +89,8 @@ class FOV_DSM(torch.nn.Module):
     in_channels = 3
     # 'fp32' = the reference's arithmetic on the fp32 MFMA kernels (parity path). 'bf16' = mixed precision on the bf16
     # MFMA kernels: bf16 activations / filters / activation gradients, fp32 accumulate, fp32 weight gradients, master
-    # weights and Adam (BASELINE config "bf16 MFMA"; not bit-comparable, see tests/test_bf16_train_gpu.py).
+    # weights and Adam (BASELINE config "bf16 MFMA"; not bit-comparable, see tests/test_bf16_train_gpu.py). 'fp16x3' =
+    # evaluation with fp32-grade products from fp16 hi/lo pairs on the fp16 MFMA (forward_f16x3; same goldens, same 1e-4).
     precision = 'fp32'
 
     def __init__(self, circ_padding=False, weights=None, seed=0):
@@ -265,9 +266,13 @@ class FOV_DSM(torch.nn.Module):
         if self.training:
             raise _lib.WitwError('forward_f16x3 is an inference path; call .eval()')
         with torch.no_grad():
-            h = ops.nchw_to_split_f16(x.contiguous(), 8)
+            fast0 = self.in_channels <= 4
+            h = x.contiguous() if fast0 else ops.nchw_to_split_f16(x.contiguous(), 8)
             last = self.layer_specs[-1][0]
             for (idx, sh, relu, pool, drop) in self.layer_specs:
+                if idx == 0 and fast0:      # C<=4 -> 64 in exact fp32 straight from NCHW, output already split
+                    h = ops.conv3x3_first_fwd(h, self._pack_first(False), circular=self.circ_padding, relu=relu, split_f16=True)
+                    continue
                 h = ops.conv3x3_f16x3_fwd(h, self._pack_f16x3(idx), stride_h=sh, circular=self.circ_padding, relu=relu,
                                           pool=pool, out_nchw_f32=(idx == last))
         return h
@@ -289,8 +294,12 @@ class FOV_DSM(torch.nn.Module):
             params = []
             for _i, c in tr:
                 params += [c.weight, c.bias]
+            if self.precision == 'fp16x3':
+                raise _lib.WitwError("precision 'fp16x3' is an inference arithmetic; train with 'fp32' or 'bf16'")
             fn = _EncoderFnBf16 if self.precision == 'bf16' else _EncoderFn
             return fn.apply(x, self, scales, *params)
+        if self.precision == 'fp16x3' and not self.training:
+            return self.forward_f16x3(x)
         if self.precision == 'bf16':
             return self._run_bf16(x, scales)[0]
         return self._run(x, scales)[0]
@@ -1039,8 +1048,9 @@ def main(argv=None):
     parser.add_argument('--dataset', default='cvusa', choices=['cvusa', 'witw'], help='Dataset to use. [Default = cvusa]')
     parser.add_argument('--fov', type=int, default=360, choices=range(6, 361), metavar='{6-360}',
                         help='The field of view for cropping street level images. [Default = 360]')
-    parser.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'],
-                        help='Encoder arithmetic (not in the reference): fp32, or bf16 MFMA mixed precision. [Default = fp32]')
+    parser.add_argument('--precision', default='fp32', choices=['fp32', 'bf16', 'fp16x3'],
+                        help='Encoder arithmetic (not in the reference): fp32, bf16 MFMA mixed precision, or (test mode) fp16x3 = '
+                             'fp32-grade products on the fp16 MFMA. [Default = fp32]')
     args = parser.parse_args(argv)
     print(args)
     Globals.precision = args.precision

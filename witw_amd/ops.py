@@ -83,20 +83,27 @@ class PackedFirstConv:
         self.bias = bias.detach().to(torch.float32).contiguous().clone()
 
 
-def conv3x3_first_fwd(x_nchw, packed, circular=False, relu=True):
-    """x NCHW fp32 [B,C<=4,H,W] -> NHWC [B,H,W,64] (fp32, or bf16 when packed.bf16)."""
+def conv3x3_first_fwd(x_nchw, packed, circular=False, relu=True, split_f16=False):
+    """x NCHW fp32 [B,C<=4,H,W] -> NHWC [B,H,W,64] (fp32, or bf16 when packed.bf16, or split-fp16 [B,H,W,8,2,8] with
+    split_f16 and an fp32-packed filter)."""
     lib = _lib.load()
     x = _dev_f32(x_nchw, 'x')
     B, C, H, W = x.shape
     if C != packed.cin:
         raise _lib.WitwError('conv3x3_first_fwd: input has %d channels, filter expects %d' % (C, packed.cin))
-    y = torch.empty((B, H, W, 64), dtype=torch.bfloat16 if packed.bf16 else torch.float32, device=x.device)
+    if split_f16 and packed.bf16:
+        raise _lib.WitwError('conv3x3_first_fwd: split_f16 needs a filter packed with bf16=False')
+    if split_f16:
+        y = torch.empty((B, H, W, 8, 2, 8), dtype=torch.float16, device=x.device)
+    else:
+        y = torch.empty((B, H, W, 64), dtype=torch.bfloat16 if packed.bf16 else torch.float32, device=x.device)
     prof = PROFILE
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     _lib.check(lib.witw_conv3x3_first_fwd(x.data_ptr(), packed.wf.data_ptr(), packed.bias.data_ptr(), y.data_ptr(), B, C, H, W,
-                                          int(circular), int(relu), int(packed.bf16), _stream()), 'witw_conv3x3_first_fwd')
+                                          int(circular), int(relu), 2 if split_f16 else int(packed.bf16), _stream()),
+               'witw_conv3x3_first_fwd')
     if prof is not None:
         e1.record()
         prof.append((('first', packed.bf16), 2.0 * C * 64 * 9 * H * W * B, e0, e1))
