@@ -105,3 +105,33 @@ def test_f16x3_step_keeps_orientation_and_ranks_of_the_fp32_step():
     from witw_amd import ops
     r32, r16 = ops.rank_count(d32), ops.rank_count(d16)
     assert int((r32 != r16).sum()) <= 1, (r32, r16)
+
+
+def test_training_with_the_frozen_trunk_on_f16x3():
+    """precision 'fp16x3' under training: layers 0-14 (frozen) on the fp16x3 kernels, the trainable layers and the whole
+    backward on the exact-fp32 kernels. Loss within 1e-4 of the fp32 step, every gradient within 2e-3 of its norm."""
+    from witw_amd import cvig_fov
+    dev = torch.device('cuda:0')
+    B, seed = 8, 91
+    w = synth.fov_dsm_weights(seed)
+    xo = torch.from_numpy(synth.normalized_images(seed, 1, (B, 3, 128, 512))).to(dev)
+    xs = (xo + 0.3 * torch.from_numpy(synth.normalized_images(seed, 2, (B, 3, 128, 512))).to(dev)).contiguous()
+    drops = {t: {i: torch.from_numpy(synth.dropout_scales(seed, 10 * k + i, B, 512)).to(dev) for i in (17, 19, 21)}
+             for k, t in enumerate('so')}
+    out = {}
+    for prec in ('fp32', 'fp16x3'):
+        se = cvig_fov.FOV_DSM(False, weights=w).to(dev).train()
+        oe = cvig_fov.FOV_DSM(True, weights=w).to(dev).train()
+        se.precision = oe.precision = prec
+        _, dist = cvig_fov.match(oe(xo, dropout_scales=drops['o']), se(xs, dropout_scales=drops['s']))
+        loss = cvig_fov.triplet_loss(dist)
+        loss.backward()
+        grads = {('s.' + n): p.grad for n, p in se.named_parameters() if p.grad is not None}
+        grads.update({('o.' + n): p.grad for n, p in oe.named_parameters() if p.grad is not None})
+        out[prec] = (loss.item(), grads)
+    (l32, g32), (l3, g3) = out['fp32'], out['fp16x3']
+    assert abs(l3 - l32) <= 1e-4, (l3, l32)
+    assert set(g3) == set(g32) and len(g3) == 24
+    worst = max(float((g3[k] - g32[k]).norm() / (g32[k].norm() + 1e-30)) for k in g32)
+    assert worst < 2e-3, worst
+    print('fp16x3-trunk training step vs fp32: loss %.7f vs %.7f, worst gradient deviation %.2e of its norm' % (l3, l32, worst))

@@ -160,13 +160,25 @@ class FOV_DSM(torch.nn.Module):
         """Layer stack. Returns (embedding NCHW, kept) where kept[idx] = (layer input NHWC, layer output NHWC,
         max-pool arg-max codes or None) for every layer idx >= keep_from (what the backward needs)."""
         fast0 = self.in_channels <= 4 and (keep_from is None or keep_from > 0)
+        # precision 'fp16x3' under training: the frozen trunk (the layers below the first kept one, 65 % of the forward
+        # FLOPs, no dropout) runs on the fp16x3 kernels (fp32-grade products from fp16 hi/lo pairs); the layers the
+        # backward needs stay on the exact-fp32 kernels, fed by one split -> fp32 conversion of a small feature map
+        trunk3 = self.precision == 'fp16x3' and keep_from is not None and keep_from > 0 and fast0
         h = x.contiguous() if fast0 else ops.nchw_to_nhwc8(x.contiguous())
         last = self.layer_specs[-1][0]
         kept = {}
+        split = False           # h currently in the split-fp16 layout
         for (idx, sh, relu, pool, drop) in self.layer_specs:
             if idx == 0 and fast0:     # C<=4 -> 64 straight from NCHW (layer 0 is frozen: nothing to keep)
-                h = ops.conv3x3_first_fwd(h, self._pack_first(False), circular=self.circ_padding, relu=relu)
+                h = ops.conv3x3_first_fwd(h, self._pack_first(False), circular=self.circ_padding, relu=relu, split_f16=trunk3)
+                split = trunk3
                 continue
+            if trunk3 and idx < keep_from:
+                h = ops.conv3x3_f16x3_fwd(h, self._pack_f16x3(idx), stride_h=sh, circular=self.circ_padding, relu=relu, pool=pool)
+                continue
+            if split:
+                h = ops.split_f16_to_f32(h)
+                split = False
             keep = keep_from is not None and idx >= keep_from
             out = ops.conv3x3_fwd(h, self._pack(idx), stride_h=sh, circular=self.circ_padding, relu=relu, pool=pool,
                                   out_nchw=(idx == last), drop_scale=scales.get(idx), want_pool_code=(keep and pool))
@@ -294,8 +306,6 @@ class FOV_DSM(torch.nn.Module):
             params = []
             for _i, c in tr:
                 params += [c.weight, c.bias]
-            if self.precision == 'fp16x3':
-                raise _lib.WitwError("precision 'fp16x3' is an inference arithmetic; train with 'fp32' or 'bf16'")
             fn = _EncoderFnBf16 if self.precision == 'bf16' else _EncoderFn
             return fn.apply(x, self, scales, *params)
         if self.precision == 'fp16x3' and not self.training:
