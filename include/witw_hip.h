@@ -157,6 +157,12 @@ int witw_nchw_f32_to_split_f16(const float* x, void* y_split, int B, int C, int 
 int witw_split_f16_to_f32(const void* x_split, float* y /*[pixels][C]*/, long long pixels, int C, void* stream);
 int witw_conv3x3_f16x3_fwd(const void* x_split, const void* wpk_f16, const float* bias, void* y, int B, int H, int W, int Cin,
                            int Cout, int stride_h, int pad_circular, int relu, int pool, int out_nchw_f32, void* stream);
+/* training forms, as witw_conv3x3_bf16_fwd_ex / witw_conv3x3_bf16_pack_weights_ex: Dropout2d scale, ReLU gate (a split-fp16
+ * tensor shaped like y), zero-interleaved rows; transpose_flip packs the dgrad filter of the source [cin][cout][3][3] */
+int witw_conv3x3_f16x3_pack_weights_ex(const float* w_kcrs, void* wpk_f16, int cout, int cin, int transpose_flip, void* stream);
+int witw_conv3x3_f16x3_fwd_ex(const void* x_split, const void* wpk_f16, const float* bias, const float* dropmask,
+                              const void* gate_split, void* y, int B, int H, int W, int Cin, int Cout, int stride_h,
+                              int pad_circular, int relu, int pool, int out_nchw_f32, int dilate_h, void* stream);
 
 /* ---- bf16 (mixed-precision) TRAINING step of the encoder: the backward of the reference's training loop
  * (model/cvig_fov.py:447-460, autograd through torch.nn.Conv2d) with bf16 MFMA operands, fp32 accumulate, fp32

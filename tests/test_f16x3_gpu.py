@@ -107,9 +107,10 @@ def test_f16x3_step_keeps_orientation_and_ranks_of_the_fp32_step():
     assert int((r32 != r16).sum()) <= 1, (r32, r16)
 
 
-def test_training_with_the_frozen_trunk_on_f16x3():
-    """precision 'fp16x3' under training: layers 0-14 (frozen) on the fp16x3 kernels, the trainable layers and the whole
-    backward on the exact-fp32 kernels. Loss within 1e-4 of the fp32 step, every gradient within 2e-3 of its norm."""
+def test_training_step_on_f16x3():
+    """precision 'fp16x3' under training: forward (frozen trunk and trainable layers, Dropout2d) and dgrad on the fp16x3
+    kernels, weight gradients on the exact-fp32 wgrad kernel. Loss within 1e-4 of the fp32 step, every gradient within
+    2e-3 of its norm."""
     from witw_amd import cvig_fov
     dev = torch.device('cuda:0')
     B, seed = 8, 91
@@ -134,4 +135,4 @@ def test_training_with_the_frozen_trunk_on_f16x3():
     assert set(g3) == set(g32) and len(g3) == 24
     worst = max(float((g3[k] - g32[k]).norm() / (g32[k].norm() + 1e-30)) for k in g32)
     assert worst < 2e-3, worst
-    print('fp16x3-trunk training step vs fp32: loss %.7f vs %.7f, worst gradient deviation %.2e of its norm' % (l3, l32, worst))
+    print('fp16x3 training step vs fp32: loss %.7f vs %.7f, worst gradient deviation %.2e of its norm' % (l3, l32, worst))

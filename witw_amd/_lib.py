@@ -53,6 +53,8 @@ SIGNATURES = {
     'witw_nchw_f32_to_split_f16': (c_int, [c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]),
     'witw_split_f16_to_f32': (c_int, [c_void_p, c_void_p, c_longlong, c_int, c_void_p]),
     'witw_conv3x3_f16x3_fwd': (c_int, [c_void_p] * 4 + [c_int] * 10 + [c_void_p]),
+    'witw_conv3x3_f16x3_pack_weights_ex': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    'witw_conv3x3_f16x3_fwd_ex': (c_int, [c_void_p] * 6 + [c_int] * 11 + [c_void_p]),
     'witw_space_to_depth2': (c_int, [c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p, c_void_p]),
     'witw_gem_pool': (c_int, [c_void_p, c_void_p] + [c_int] * 8 + [c_float, c_void_p, c_void_p, c_void_p]),
     'witw_bn_workspace_floats': (c_longlong, [c_int] * 4),

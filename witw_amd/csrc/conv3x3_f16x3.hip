@@ -63,6 +63,9 @@ struct ConvHxArgs {
     int tiles_x, tiles_y;
     int circ, relu, out_nchw_f32;
     int n_tiles, sp_total, sp_per_xcd, xcd_map;
+    const float* dropmask;       // nullptr, or [B,Cout] Dropout2d scale applied to conv + bias before the ReLU
+    const unsigned short* gate;  // nullptr, or a split-fp16 tensor shaped like y: outputs where its value <= 0 are zeroed (ReLU backward)
+    int dil_h;                   // 1: input rows are zero-interleaved (logical row 2i = physical row i): dgrad of a stride-(2,1) conv
 };
 
 template <int TN, int SH, bool POOL, int NW>
@@ -114,7 +117,8 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_f16x3_kernel(ConvHxArgs 
 
     // ---- staging: per-image / per-weight-tile buffer resources, fixed per-thread byte offsets, K-chunk advance in the
     // scalar offset (32 B per pixel per chunk: 8 channels x (hi, lo))
-    const size_t img_halves = (size_t)p.H * p.W * p.Cin * 2;
+    const int Hp = p.dil_h ? (p.H - 1) / 2 + 1 : p.H;      // physical rows of the input
+    const size_t img_halves = (size_t)Hp * p.W * p.Cin * 2;
     __amdgpu_buffer_rsrc_t in_rs =
         __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)b * img_halves), 0, (unsigned)(img_halves * 2), 0x00020000);
     const i32x4 w_rd = raw_rsrc(reinterpret_cast<const u32x4*>(p.wpk) + (size_t)ntile * nkc * W_S, (unsigned)nkc * W_S * 16u);
@@ -124,9 +128,13 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_f16x3_kernel(ConvHxArgs 
         const int s = tid + i * NTHREADS;
         const int pix = s >> 1, q = s & 1;
         const int r = pix / IW, c = pix - r * IW;
-        const int gr = oy0 * SH - 1 + r;
+        int gr = oy0 * SH - 1 + r;
         int gc = ox0 - 1 + c;
         bool ok = s < IN_S && gr >= 0 && gr < p.H;
+        if (p.dil_h) {
+            ok = ok && !(gr & 1);
+            gr >>= 1;
+        }
         if (p.circ) {
             gc %= p.W;
             if (gc < 0) gc += p.W;
@@ -266,18 +274,24 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_f16x3_kernel(ConvHxArgs 
 
     // ---- epilogue: bias, ReLU, optional 2x2 max pool; the fp32 tile is transposed through a wave-private LDS slab and
     // leaves split into (hi, lo) fp16 as 2 x 16 B per lane (8 channels of a pixel), or as the fp32 NCHW embedding
-    float bv[WN];
+    float bv[WN], dm[WN];
     int nch[WN];
 #pragma unroll
     for (int nt = 0; nt < WN; ++nt) {
         nch[nt] = n0 + wn * 64 + nt * 32 + l31;
         bv[nt] = p.bias[nch[nt]];
+        dm[nt] = 1.f;
+        if (p.dropmask != nullptr && nch[nt] < p.Cout) dm[nt] = p.dropmask[(size_t)b * p.Cout + nch[nt]];
     }
+    // conv + bias -> Dropout2d scale -> ReLU (the order of the fp32 kernel, model/cvig_fov.py:287-288)
     auto fin = [&](float v, int nt) {
-        v = v + bv[nt];
+        v = (v + bv[nt]) * dm[nt];
         if (p.relu) v = fmaxf(v, 0.f);
         return v;
     };
+    // a split-fp16 value is > 0 iff its hi part is (lo only refines it; hi = 0 means the value itself was 0 or tiny positive:
+    // a saved ReLU output below the smallest fp16 subnormal counts as closed, like an exact zero)
+    auto gate_open = [](unsigned short g) { return (g & 0x7fffu) != 0 && !(g & 0x8000u); };
     const int Hy = POOL ? (p.Ho >> 1) : p.Ho;
     const int Wy = POOL ? (p.Wo >> 1) : p.Wo;
     _Float16* const yh = reinterpret_cast<_Float16*>(p.y);
@@ -290,6 +304,7 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_f16x3_kernel(ConvHxArgs 
                 reinterpret_cast<float*>(p.y)[(((size_t)b * p.Cout + nch[nt]) * Hy + yy) * Wy + xx] = v;
             } else {
                 const size_t o = split_off(((size_t)b * Hy + yy) * Wy + xx, nch[nt]);
+                if (p.gate != nullptr && !gate_open(p.gate[o])) v = 0.f;
                 const _Float16 hi = (_Float16)v;
                 yh[o] = hi;
                 yh[o + 8] = (_Float16)(v - (float)hi);
@@ -297,7 +312,16 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_f16x3_kernel(ConvHxArgs 
         }
     };
     // 8 channels (two float4) of one pixel -> 16 B hi + 16 B lo, adjacent
-    auto store_split8 = [&](const f32x4& v0, const f32x4& v1, size_t pix, int nbase) {
+    auto store_split8 = [&](f32x4 v0, f32x4 v1, size_t pix, int nbase) {
+        if (p.gate != nullptr) {
+            typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+            const u16x8 gt = *reinterpret_cast<const u16x8*>(p.gate + (pix * p.Cout + nbase) * 2);     // hi plane of the gate
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (!gate_open(gt[e])) v0[e] = 0.f;
+                if (!gate_open(gt[4 + e])) v1[e] = 0.f;
+            }
+        }
         f16x8 hi, lo;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -388,8 +412,10 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_f16x3_kernel(ConvHxArgs 
 
 // wpk[nt][kc][slot][n][0..7] (fp16) <- w[cout][cin][kh][kw] (fp32, torch KCRS); one thread per 16-B slot.
 // slot s < 9: hi part of tap s; slot 9 + 2i + h: lo part of tap 2i + h (zeros for tap 9), channels 8kc..8kc+7.
+// transpose_flip != 0: the dgrad filter: (Cout, Cin) describe the PACKED filter, the source is [Cin][Cout][3][3] and
+// w'[co][ci][kh][kw] = w[ci][co][2-kh][2-kw].
 __global__ void pack_weights_f16x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ wpk, int Cout, int Cin,
-                                          int n_tiles, int nkc, int TN) {
+                                          int n_tiles, int nkc, int TN, int transpose_flip) {
     const size_t total = (size_t)n_tiles * nkc * NSLOT * TN;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
@@ -406,7 +432,8 @@ __global__ void pack_weights_f16x3_kernel(const float* __restrict__ w, unsigned 
     for (int j = 0; j < 8; ++j) {
         const int ci = kc * 8 + j;
         float f = 0.f;
-        if (co < Cout && ci < Cin && tap < 9) f = w[((size_t)co * Cin + ci) * 9 + tap];
+        if (co < Cout && ci < Cin && tap < 9)
+            f = transpose_flip ? w[((size_t)ci * Cout + co) * 9 + (8 - tap)] : w[((size_t)co * Cin + ci) * 9 + tap];
         const _Float16 hi = (_Float16)f;
         v[j] = lo ? (_Float16)(f - (float)hi) : hi;
     }
@@ -480,16 +507,20 @@ long long witw_conv3x3_f16x3_packed_elems(int cout, int cin) {
     return (long long)cdiv(cout, TN) * cdiv(cin, 8) * NSLOT * TN * 8;
 }
 
-int witw_conv3x3_f16x3_pack_weights(const float* w_kcrs, void* wpk_f16, int cout, int cin, void* stream) {
+int witw_conv3x3_f16x3_pack_weights_ex(const float* w_kcrs, void* wpk_f16, int cout, int cin, int transpose_flip, void* stream) {
     WITW_CHECK_ARG(w_kcrs && wpk_f16, "f16x3 pack_weights: null pointer");
     WITW_CHECK_ARG(cout > 0 && cin > 0, "f16x3 pack_weights: bad shape");
     const int TN = cout >= 128 ? 128 : 64;
     const int n_tiles = cdiv(cout, TN), nkc = cdiv(cin, 8);
     const size_t total = (size_t)n_tiles * nkc * NSLOT * TN;
     hipLaunchKernelGGL(pack_weights_f16x3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_kcrs,
-                       (unsigned short*)wpk_f16, cout, cin, n_tiles, nkc, TN);
+                       (unsigned short*)wpk_f16, cout, cin, n_tiles, nkc, TN, transpose_flip);
     WITW_CHECK_LAUNCH("f16x3 pack_weights");
     return WITW_OK;
+}
+
+int witw_conv3x3_f16x3_pack_weights(const float* w_kcrs, void* wpk_f16, int cout, int cin, void* stream) {
+    return witw_conv3x3_f16x3_pack_weights_ex(w_kcrs, wpk_f16, cout, cin, 0, stream);
 }
 
 int witw_nchw_f32_to_split_f16(const float* x, void* y_split, int B, int C, int H, int W, int Cpad, void* stream) {
@@ -514,9 +545,15 @@ int witw_split_f16_to_f32(const void* x_split, float* y, long long pixels, int C
 
 // x split-fp16 NHWC [B,H,W,Cin/8,2,8] (Cin % 8 == 0) -> y split-fp16 NHWC [B,Hy,Wy,Cout/8,2,8] (Cout % 8 == 0) or the fp32 NCHW
 // embedding [B,Cout,Hy,Wy] (out_nchw_f32).
-int witw_conv3x3_f16x3_fwd(const void* x_split, const void* wpk_f16, const float* bias, void* y, int B, int H, int W, int Cin,
-                           int Cout, int stride_h, int pad_circular, int relu, int pool, int out_nchw_f32, void* stream) {
+// Training form (the trainable layers' forward and the dgrad launches of a backward): dropmask [B,Cout] fp32 (Dropout2d scale
+// before the ReLU), gate = split-fp16 tensor shaped like y (outputs where it is <= 0 are zeroed), dilate_h = x holds
+// (H-1)/2+1 physical rows standing for H zero-interleaved rows (dgrad of a stride-(2,1) layer; H is the logical height).
+int witw_conv3x3_f16x3_fwd_ex(const void* x_split, const void* wpk_f16, const float* bias, const float* dropmask,
+                              const void* gate_split, void* y, int B, int H, int W, int Cin, int Cout, int stride_h,
+                              int pad_circular, int relu, int pool, int out_nchw_f32, int dilate_h, void* stream) {
     WITW_CHECK_ARG(x_split && wpk_f16 && bias && y, "conv3x3_f16x3_fwd: null pointer");
+    WITW_CHECK_ARG(!(gate_split && (pool || out_nchw_f32)), "conv3x3_f16x3_fwd: gate with pool / NCHW output unsupported");
+    WITW_CHECK_ARG(!(dilate_h && stride_h == 2), "conv3x3_f16x3_fwd: dilated input with stride 2 unsupported");
     WITW_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cout > 0, "conv3x3_f16x3_fwd: bad shape");
     WITW_CHECK_ARG(Cin > 0 && (Cin % 8) == 0, "conv3x3_f16x3_fwd: Cin=%d must be a positive multiple of 8", Cin);
     WITW_CHECK_ARG(out_nchw_f32 || (Cout % 8) == 0, "conv3x3_f16x3_fwd: a split-fp16 output needs Cout %% 8 == 0 (Cout=%d)", Cout);
@@ -531,6 +568,7 @@ int witw_conv3x3_f16x3_fwd(const void* x_split, const void* wpk_f16, const float
     a.tiles_x = cdiv(a.Wo, TW);
     a.tiles_y = 0;
     a.circ = pad_circular; a.relu = relu; a.out_nchw_f32 = out_nchw_f32;
+    a.dropmask = dropmask; a.gate = (const unsigned short*)gate_split; a.dil_h = dilate_h ? 1 : 0;
     const char* e = getenv("WITW_CONV_XCD");
     a.xcd_map = e ? atoi(e) != 0 : 1;
     hipStream_t st = (hipStream_t)stream;
@@ -540,6 +578,12 @@ int witw_conv3x3_f16x3_fwd(const void* x_split, const void* wpk_f16, const float
     }
     if (stride_h == 2) return launch_hx<64, 2, false>(a, st);
     return pool ? launch_hx<64, 1, true>(a, st) : launch_hx<64, 1, false>(a, st);
+}
+
+int witw_conv3x3_f16x3_fwd(const void* x_split, const void* wpk_f16, const float* bias, void* y, int B, int H, int W, int Cin,
+                           int Cout, int stride_h, int pad_circular, int relu, int pool, int out_nchw_f32, void* stream) {
+    return witw_conv3x3_f16x3_fwd_ex(x_split, wpk_f16, bias, nullptr, nullptr, y, B, H, W, Cin, Cout, stride_h, pad_circular, relu,
+                                     pool, out_nchw_f32, 0, stream);
 }
 
 }  // extern "C"

@@ -160,25 +160,13 @@ class FOV_DSM(torch.nn.Module):
         """Layer stack. Returns (embedding NCHW, kept) where kept[idx] = (layer input NHWC, layer output NHWC,
         max-pool arg-max codes or None) for every layer idx >= keep_from (what the backward needs)."""
         fast0 = self.in_channels <= 4 and (keep_from is None or keep_from > 0)
-        # precision 'fp16x3' under training: the frozen trunk (the layers below the first kept one, 65 % of the forward
-        # FLOPs, no dropout) runs on the fp16x3 kernels (fp32-grade products from fp16 hi/lo pairs); the layers the
-        # backward needs stay on the exact-fp32 kernels, fed by one split -> fp32 conversion of a small feature map
-        trunk3 = self.precision == 'fp16x3' and keep_from is not None and keep_from > 0 and fast0
         h = x.contiguous() if fast0 else ops.nchw_to_nhwc8(x.contiguous())
         last = self.layer_specs[-1][0]
         kept = {}
-        split = False           # h currently in the split-fp16 layout
         for (idx, sh, relu, pool, drop) in self.layer_specs:
             if idx == 0 and fast0:     # C<=4 -> 64 straight from NCHW (layer 0 is frozen: nothing to keep)
-                h = ops.conv3x3_first_fwd(h, self._pack_first(False), circular=self.circ_padding, relu=relu, split_f16=trunk3)
-                split = trunk3
+                h = ops.conv3x3_first_fwd(h, self._pack_first(False), circular=self.circ_padding, relu=relu)
                 continue
-            if trunk3 and idx < keep_from:
-                h = ops.conv3x3_f16x3_fwd(h, self._pack_f16x3(idx), stride_h=sh, circular=self.circ_padding, relu=relu, pool=pool)
-                continue
-            if split:
-                h = ops.split_f16_to_f32(h)
-                split = False
             keep = keep_from is not None and idx >= keep_from
             out = ops.conv3x3_fwd(h, self._pack(idx), stride_h=sh, circular=self.circ_padding, relu=relu, pool=pool,
                                   out_nchw=(idx == last), drop_scale=scales.get(idx), want_pool_code=(keep and pool))
@@ -259,15 +247,38 @@ class FOV_DSM(torch.nn.Module):
                                          pool=pool, out_nchw_f32=(idx == last))
         return h
 
-    def _pack_f16x3(self, idx):
+    def _pack_f16x3(self, idx, transpose_flip=False):
         conv = _conv_of(self.model.features[idx])
         key = (conv.weight.data_ptr(), conv.weight._version, conv.bias._version, getattr(conv.weight, '_witw_version', 0),
                getattr(conv.bias, '_witw_version', 0))
-        hit = self._packed.get(('f16x3', idx))
+        slot = ('f16x3_t' if transpose_flip else 'f16x3', idx)
+        hit = self._packed.get(slot)
         if hit is None or hit[0] != key:
-            hit = (key, ops.PackedConvF16x3(conv.weight, conv.bias))
-            self._packed[('f16x3', idx)] = hit
+            hit = (key, ops.PackedConvF16x3(conv.weight, None if transpose_flip else conv.bias, transpose_flip=transpose_flip,
+                                            reuse=hit[1] if hit else None))
+            self._packed[slot] = hit
         return hit[1]
+
+    def _run_f16x3(self, x, scales, keep_from=None):
+        """The layer stack on the fp16x3 kernels (split-fp16 activations, fp32-grade products, fp32 NCHW embedding).
+        Returns (embedding, kept) with kept[idx] = (layer input, layer output) in the split layout for idx >= keep_from."""
+        fast0 = self.in_channels <= 4 and (keep_from is None or keep_from > 0)
+        h = x.contiguous() if fast0 else ops.nchw_to_split_f16(x.contiguous(), 8)
+        last = self.layer_specs[-1][0]
+        kept = {}
+        for (idx, sh, relu, pool, drop) in self.layer_specs:
+            if idx == 0 and fast0:      # C<=4 -> 64 in exact fp32 straight from NCHW, output already split
+                h = ops.conv3x3_first_fwd(h, self._pack_first(False), circular=self.circ_padding, relu=relu, split_f16=True)
+                continue
+            keep = keep_from is not None and idx >= keep_from
+            if keep and pool:
+                raise _lib.WitwError("precision 'fp16x3' cannot train through a fused max-pool (layer %d): use 'fp32' or 'bf16'" % idx)
+            y = ops.conv3x3_f16x3_fwd(h, self._pack_f16x3(idx), stride_h=sh, circular=self.circ_padding, relu=relu, pool=pool,
+                                      out_nchw_f32=(idx == last), drop_scale=scales.get(idx))
+            if keep:
+                kept[idx] = (h, y)
+            h = y
+        return h, kept
 
     def forward_f16x3(self, x):
         """Inference with fp32-grade accuracy on the fp16 MFMA (csrc/conv3x3_f16x3.hip): every activation and filter
@@ -278,16 +289,7 @@ class FOV_DSM(torch.nn.Module):
         if self.training:
             raise _lib.WitwError('forward_f16x3 is an inference path; call .eval()')
         with torch.no_grad():
-            fast0 = self.in_channels <= 4
-            h = x.contiguous() if fast0 else ops.nchw_to_split_f16(x.contiguous(), 8)
-            last = self.layer_specs[-1][0]
-            for (idx, sh, relu, pool, drop) in self.layer_specs:
-                if idx == 0 and fast0:      # C<=4 -> 64 in exact fp32 straight from NCHW, output already split
-                    h = ops.conv3x3_first_fwd(h, self._pack_first(False), circular=self.circ_padding, relu=relu, split_f16=True)
-                    continue
-                h = ops.conv3x3_f16x3_fwd(h, self._pack_f16x3(idx), stride_h=sh, circular=self.circ_padding, relu=relu,
-                                          pool=pool, out_nchw_f32=(idx == last))
-        return h
+            return self._run_f16x3(x, {})[0]
 
     def trainable_convs(self):
         return [(idx, _conv_of(self.model.features[idx])) for (idx, *_r) in self.layer_specs
@@ -306,7 +308,7 @@ class FOV_DSM(torch.nn.Module):
             params = []
             for _i, c in tr:
                 params += [c.weight, c.bias]
-            fn = _EncoderFnBf16 if self.precision == 'bf16' else _EncoderFn
+            fn = _EncoderFnBf16 if self.precision == 'bf16' else _EncoderFnF16x3 if self.precision == 'fp16x3' else _EncoderFn
             return fn.apply(x, self, scales, *params)
         if self.precision == 'fp16x3' and not self.training:
             return self.forward_f16x3(x)
@@ -351,6 +353,48 @@ class _EncoderFn(torch.autograd.Function):
                                      drop_scale=scales.get(pidx), gate=p_out, dilate_h=(sh == 2),
                                      out_h=x_in.shape[1] if sh == 2 else None)
                 dz = ops.maxpool2x2_bwd(dy, p_code, (p_in.shape[1], p_in.shape[2])) if ppool else dy
+        ctx.kept = None
+        flat = []
+        for (idx, _c) in enc.trainable_convs():
+            flat += [grads[idx][0], grads[idx][1]]
+        return (None, None, None) + tuple(flat)
+
+
+class _EncoderFnF16x3(torch.autograd.Function):
+    """_EncoderFn with fp32-grade products on the fp16 MFMA (FOV_DSM.precision = 'fp16x3'): the forward (frozen trunk and
+    trainable layers, Dropout2d scale in the epilogue) and every dgrad launch run on the fp16x3 kernels with split-fp16
+    activations and activation gradients; the weight gradients stay on the exact-fp32 wgrad kernel, fed by split -> fp32
+    conversions of the (small) saved activations and gradients. Parity: tests/test_f16x3_gpu.py against the fp32 path."""
+
+    @staticmethod
+    def forward(ctx, x, enc, scales, *params):
+        first = min(i for i, _c in enc.trainable_convs())
+        out, kept = enc._run_f16x3(x, scales, keep_from=first)
+        ctx.enc, ctx.scales, ctx.kept, ctx.first = enc, scales, kept, first
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        enc, scales, kept = ctx.enc, ctx.scales, ctx.kept
+        specs = [sp for sp in enc.layer_specs if sp[0] >= ctx.first]
+        circ = enc.circ_padding
+        last = specs[-1][0]
+        cout_last = _conv_of(enc.model.features[last]).out_channels
+        dz = ops.nchw_to_split_f16(grad_out.contiguous(), (cout_last + 7) // 8 * 8)      # layer 27 has no ReLU
+        grads = {}
+        for n in range(len(specs) - 1, -1, -1):
+            idx, sh, relu, pool, drop = specs[n]
+            x_in = kept[idx][0]
+            conv = _conv_of(enc.model.features[idx])
+            if conv.weight.requires_grad:
+                dw, db = ops.conv3x3_wgrad(ops.split_f16_to_f32(x_in), ops.split_f16_to_f32(dz), conv.in_channels, stride_h=sh,
+                                           circular=circ)
+                grads[idx] = (dw[:conv.out_channels].contiguous(), db[:conv.out_channels].contiguous())
+            if n > 0:   # gradient at the previous layer's conv output
+                pidx = specs[n - 1][0]
+                dz = ops.conv3x3_f16x3_fwd(dz, enc._pack_f16x3(idx, transpose_flip=True), stride_h=1, circular=circ, relu=False,
+                                           pool=False, drop_scale=scales.get(pidx), gate=kept[pidx][1], dilate_h=(sh == 2),
+                                           out_h=x_in.shape[1] if sh == 2 else None)
         ctx.kept = None
         flat = []
         for (idx, _c) in enc.trainable_convs():

@@ -751,17 +751,22 @@ def conv3x3_wgrad_bf16(x_nhwc, dz_nhwc, cin_real, stride_h=1, circular=False, wa
 
 # ----------------------------------------------------------------------------- fp16x3: fp32-grade inference on the fp16 MFMA
 class PackedConvF16x3:
-    """fp16 hi / lo filter packing of one 3x3 conv for the fp16x3 kernel (19 slots per 8-channel chunk) + fp32 bias."""
+    """fp16 hi / lo filter packing of one 3x3 conv for the fp16x3 kernel (19 slots per 8-channel chunk) + fp32 bias.
+    transpose_flip packs the dgrad filter; reuse = a previous packing of the same layer whose buffers are overwritten."""
 
-    def __init__(self, weight, bias):
+    def __init__(self, weight, bias, transpose_flip=False, reuse=None):
         lib = _lib.load()
         w = _dev_f32(weight.detach(), 'weight')
-        self.cout, self.cin = w.shape[0], w.shape[1]
+        self.cout, self.cin = (w.shape[1], w.shape[0]) if transpose_flip else (w.shape[0], w.shape[1])
         self.cin_pad = (self.cin + 7) // 8 * 8
-        self.wpk = torch.empty(lib.witw_conv3x3_f16x3_packed_elems(self.cout, self.cin), dtype=torch.float16, device=w.device)
-        _lib.check(lib.witw_conv3x3_f16x3_pack_weights(w.data_ptr(), self.wpk.data_ptr(), self.cout, self.cin, _stream()),
-                   'witw_conv3x3_f16x3_pack_weights')
-        self.bias = torch.zeros(lib.witw_conv3x3_bias_floats(self.cout), dtype=torch.float32, device=w.device)
+        n_pk = lib.witw_conv3x3_f16x3_packed_elems(self.cout, self.cin)
+        if reuse is not None and not (reuse.wpk.numel() == n_pk and reuse.wpk.device == w.device and reuse.cout == self.cout):
+            reuse = None
+        self.wpk = reuse.wpk if reuse is not None else torch.empty(n_pk, dtype=torch.float16, device=w.device)
+        _lib.check(lib.witw_conv3x3_f16x3_pack_weights_ex(w.data_ptr(), self.wpk.data_ptr(), self.cout, self.cin,
+                                                          int(bool(transpose_flip)), _stream()), 'witw_conv3x3_f16x3_pack_weights_ex')
+        self.bias = reuse.bias if reuse is not None else \
+            torch.zeros(lib.witw_conv3x3_bias_floats(self.cout), dtype=torch.float32, device=w.device)
         if bias is not None:
             self.bias[:self.cout].copy_(bias.detach())
 
@@ -785,16 +790,26 @@ def split_f16_to_f32(x_split):
     return y
 
 
-def conv3x3_f16x3_fwd(x_split, packed, stride_h=1, circular=False, relu=True, pool=False, out_nchw_f32=False):
-    """x split-fp16 NHWC [B,H,W,Cin/8,2,8] -> split-fp16 NHWC [B,Hy,Wy,Cout/8,2,8] (or the fp32 NCHW embedding)."""
+def _is_split(t):
+    return t.is_cuda and t.dtype == torch.float16 and t.is_contiguous() and t.dim() == 6 and tuple(t.shape[4:]) == (2, 8)
+
+
+def conv3x3_f16x3_fwd(x_split, packed, stride_h=1, circular=False, relu=True, pool=False, out_nchw_f32=False, drop_scale=None,
+                      gate=None, dilate_h=False, out_h=None):
+    """x split-fp16 NHWC [B,H,W,Cin/8,2,8] -> split-fp16 NHWC [B,Hy,Wy,Cout/8,2,8] (or the fp32 NCHW embedding). Training
+    extras as in conv3x3_bf16_fwd: drop_scale [B,Cout] fp32, gate = split-fp16 tensor shaped like the output, dilate_h /
+    out_h = zero-interleaved input rows (dgrad of a stride-(2,1) layer)."""
     lib = _lib.load()
-    if not (x_split.is_cuda and x_split.dtype == torch.float16 and x_split.is_contiguous() and x_split.dim() == 6
-            and tuple(x_split.shape[4:]) == (2, 8)):
+    if not _is_split(x_split):
         raise _lib.WitwError('conv3x3_f16x3_fwd: x must be a contiguous float16 GPU tensor shaped [B,H,W,C/8,2,8]')
     B, H, W, C8 = x_split.shape[:4]
     C = C8 * 8
     if C != packed.cin_pad:
         raise _lib.WitwError('conv3x3_f16x3_fwd: input has %d channels, packed weights expect %d' % (C, packed.cin_pad))
+    if dilate_h:
+        if out_h is None or (out_h - 1) // 2 + 1 != H:
+            raise _lib.WitwError('conv3x3_f16x3_fwd: dilate_h needs out_h with (out_h-1)//2+1 == %d physical rows' % H)
+        H = out_h
     Ho = (H + 2 - 3) // stride_h + 1
     Hy, Wy = (Ho // 2, W // 2) if pool else (Ho, W)
     if out_nchw_f32:
@@ -803,13 +818,20 @@ def conv3x3_f16x3_fwd(x_split, packed, stride_h=1, circular=False, relu=True, po
         if packed.cout % 8:
             raise _lib.WitwError('conv3x3_f16x3_fwd: a split-fp16 output needs Cout %% 8 == 0')
         y = torch.empty((B, Hy, Wy, packed.cout // 8, 2, 8), dtype=torch.float16, device=x_split.device)
+    if drop_scale is not None:
+        drop_scale = _dev_f32(drop_scale, 'drop_scale')
+        if tuple(drop_scale.shape) != (B, packed.cout):
+            raise _lib.WitwError('drop_scale must be [B,Cout]')
+    if gate is not None and not (_is_split(gate) and tuple(gate.shape) == tuple(y.shape)):
+        raise _lib.WitwError('gate must be a split-fp16 GPU tensor with the output shape %s' % (tuple(y.shape),))
     prof = PROFILE
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _lib.check(lib.witw_conv3x3_f16x3_fwd(x_split.data_ptr(), packed.wpk.data_ptr(), packed.bias.data_ptr(), y.data_ptr(), B, H, W,
-                                          C, packed.cout, stride_h, int(circular), int(relu), int(pool), int(out_nchw_f32),
-                                          _stream()), 'witw_conv3x3_f16x3_fwd')
+    _lib.check(lib.witw_conv3x3_f16x3_fwd_ex(x_split.data_ptr(), packed.wpk.data_ptr(), packed.bias.data_ptr(), _p(drop_scale),
+                                             _p(gate), y.data_ptr(), B, H, W, C, packed.cout, stride_h, int(circular), int(relu),
+                                             int(pool), int(out_nchw_f32), int(bool(dilate_h)), _stream()),
+               'witw_conv3x3_f16x3_fwd_ex')
     if prof is not None:
         e1.record()
         prof.append((('f16x3', lib.witw_conv3x3_tile_n(packed.cout), stride_h, bool(pool)),
