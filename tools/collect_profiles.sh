@@ -13,6 +13,7 @@ python3 bench.py --mode train > $O/bench_train.json 2> $O/bench_train.err
 python3 bench.py --precision bf16 > $O/bench_bf16.json 2> $O/bench_bf16.err
 python3 bench.py --precision fp16x3 > $O/bench_fp16x3.json 2> $O/bench_fp16x3.err
 python3 bench.py --precision fp16x3 --fov 70 > $O/bench_fp16x3_fov70.json 2> $O/bench_fp16x3_fov70.err
+python3 bench.py --precision fp16x3 --mode train > $O/bench_fp16x3_train.json 2> $O/bench_fp16x3_train.err
 python3 bench.py --mode train --precision bf16 > $O/bench_bf16_train.json 2> $O/bench_bf16_train.err
 python3 bench.py --model semantic --precision bf16 > $O/bench_semantic_bf16.json 2> $O/bench_semantic_bf16.err
 python3 bench.py --model semantic --mode train --precision bf16 > $O/bench_semantic_bf16_train.json 2> $O/bench_semantic_bf16_train.err
@@ -25,6 +26,7 @@ rocprofv3 --kernel-trace --stats -d $O/prof -o p --output-format csv -- python3 
 rocprofv3 --kernel-trace --stats -d $O/prof_train -o p --output-format csv -- python3 bench.py --mode train --steps 5 --warmup 2 > $O/train_under_rocprof.json 2> $O/prof_train.log
 rocprofv3 --kernel-trace --stats -d $O/prof_bf16 -o p --output-format csv -- python3 bench.py --precision bf16 --steps 5 --warmup 2 > $O/bf16_under_rocprof.json 2> $O/prof_bf16.log
 rocprofv3 --kernel-trace --stats -d $O/prof_fp16x3 -o p --output-format csv -- python3 bench.py --precision fp16x3 --steps 5 --warmup 2 > $O/fp16x3_under_rocprof.json 2> $O/prof_fp16x3.log
+rocprofv3 --kernel-trace --stats -d $O/prof_fp16x3_train -o p --output-format csv -- python3 bench.py --precision fp16x3 --mode train --steps 5 --warmup 2 > $O/fp16x3_train_under_rocprof.json 2> $O/prof_fp16x3_train.log
 rocprofv3 --kernel-trace --stats -d $O/prof_bf16_train -o p --output-format csv -- python3 bench.py --mode train --precision bf16 --steps 5 --warmup 2 > $O/bf16_train_under_rocprof.json 2> $O/prof_bf16_train.log
 echo stats done
 for m in "infer:" "train:--mode train" "bf16:--precision bf16" "bf16_train:--mode train --precision bf16" "fp16x3:--precision fp16x3"; do

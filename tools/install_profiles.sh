@@ -3,7 +3,7 @@
 set -eu
 R=${1:-r01}
 O=gpurun_out/final
-for m in "" _train _bf16 _bf16_train _fp16x3 _fp16x3_fov70 _semantic _semantic_train _semantic_bf16 _semantic_bf16_train _fov70 _retrieval; do
+for m in "" _train _bf16 _bf16_train _fp16x3 _fp16x3_fov70 _fp16x3_train _semantic _semantic_train _semantic_bf16 _semantic_bf16_train _fov70 _retrieval; do
   cp $O/bench$m.json profiles/${R}_bench$m.json
 done
 cp $O/bench_under_rocprof.json profiles/${R}_bench_under_rocprof.json
@@ -16,6 +16,7 @@ cp $O/prof_bf16/p_kernel_stats.csv profiles/${R}_bench_bf16_kernel_stats.csv
 cp $O/prof_bf16_train/p_kernel_stats.csv profiles/${R}_bf16_train_kernel_stats.csv
 cp $O/prof_fp16x3/p_kernel_stats.csv profiles/${R}_fp16x3_kernel_stats.csv
 cp $O/fp16x3_under_rocprof.json profiles/${R}_fp16x3_under_rocprof.json
+cp $O/prof_fp16x3_train/p_kernel_stats.csv profiles/${R}_fp16x3_train_kernel_stats.csv
 cp $O/traffic.json profiles/traffic.json
 cp $O/mfma_util.json profiles/mfma_util.json
 ls profiles
