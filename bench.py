@@ -213,7 +213,7 @@ def main():
     kname = 'conv3x3_nhwc_bf16_kernel<128,1,false,8>' if bf16 else 'conv3x3_nhwc_f16x3_kernel<128,1,false,8>' if f16x3 else \
         'conv3x3_nhwc_f32_kernel<128,1,false,8,0,9>'
     dom = [(fl, e0.elapsed_time(e1)) for (v, fl, e0, e1) in prof if v == dominant]
-    allc = [(fl, e0.elapsed_time(e1)) for (v, fl, e0, e1) in prof if v[0] not in ('match', 'wgrad_bf16')]
+    allc = [(fl, e0.elapsed_time(e1)) for (v, fl, e0, e1) in prof if v[0] not in ('match', 'wgrad_bf16', 'wgrad_f16x3')]
     wg = [(fl, e0.elapsed_time(e1)) for (v, fl, e0, e1) in prof if v[0] == 'wgrad_bf16']
     dom_fl = sum(f for f, _ in dom) / max(1, len(dom))
     dom_ms = sum(m for _, m in dom) / max(1, len(dom))

@@ -164,6 +164,16 @@ int witw_conv3x3_f16x3_fwd_ex(const void* x_split, const void* wpk_f16, const fl
                               const void* gate_split, void* y, int B, int H, int W, int Cin, int Cout, int stride_h,
                               int pad_circular, int relu, int pool, int out_nchw_f32, int dilate_h, void* stream);
 
+/* weight gradient of the fp16x3 training step (csrc/wgrad_f16x3.hip): operands in the batch-octet split layout
+ * [ceil(B/8)][H][W][C][2][8] fp16 (witw_split_f16_to_octet from split-fp16 NHWC), products hi*hi + lo*hi + hi*lo on the fp16
+ * MFMA; dz_split = the gradient as split-fp16 NHWC (bias gradient; NULL with db NULL); dw / db fp32. */
+long long witw_octet_split_elems(int B, int H, int W, int C);
+int witw_split_f16_to_octet(const void* x_split, void* y_oct, int B, int H, int W, int C, void* stream);
+long long witw_conv3x3_wgrad_f16x3_workspace_floats(int B, int H, int W, int Cin, int Cout, int stride_h);
+int witw_conv3x3_wgrad_f16x3(const void* x_oct, const void* dz_oct, const void* dz_split, float* dw, float* db, float* workspace,
+                             int B, int H, int W, int Cin, int cin_real, int Cout, int stride_h, int pad_circular, int accumulate,
+                             void* stream);
+
 /* ---- bf16 (mixed-precision) TRAINING step of the encoder: the backward of the reference's training loop
  * (model/cvig_fov.py:447-460, autograd through torch.nn.Conv2d) with bf16 MFMA operands, fp32 accumulate, fp32
  * weight gradients / master weights / Adam.

@@ -136,3 +136,28 @@ def test_training_step_on_f16x3():
     worst = max(float((g3[k] - g32[k]).norm() / (g32[k].norm() + 1e-30)) for k in g32)
     assert worst < 2e-3, worst
     print('fp16x3 training step vs fp32: loss %.7f vs %.7f, worst gradient deviation %.2e of its norm' % (l3, l32, worst))
+
+
+@pytest.mark.parametrize('case', [(16, 16, 64, 64, 128, 1, True), (10, 6, 12, 64, 16, 1, True), (8, 8, 24, 72, 64, 2, False),
+                                  (3, 7, 20, 16, 256, 2, True), (9, 5, 9, 128, 64, 1, False)])
+def test_wgrad_f16x3_matches_autograd(case):
+    """Weight gradient with split products vs CPU autograd in fp64 (operands random fp32: the split keeps 22 bits, the lo*lo
+    term is dropped): 3e-6 of the largest entry; bit-reproducible."""
+    from witw_amd import ops
+    B, H, W, Cin, Cout, sh, circ = case
+    g = np.random.Generator(np.random.Philox(key=[23, Cin + Cout]))
+    x = torch.from_numpy(g.standard_normal((B, Cin, H, W), dtype=np.float32))
+    w = torch.zeros((Cout, Cin, 3, 3), dtype=torch.float64, requires_grad=True)
+    b = torch.zeros((Cout,), dtype=torch.float64, requires_grad=True)
+    y = O.conv3x3(x.double(), w, b, sh, circ)
+    gy = torch.from_numpy(g.standard_normal(tuple(y.shape)).astype(np.float32))
+    y.backward(gy.double())
+    dev = torch.device('cuda:0')
+    xs, gs = ops.nchw_to_split_f16(x.to(dev), Cin), ops.nchw_to_split_f16(gy.to(dev), Cout)
+    oct_ = ops.split_f16_to_octet(xs)
+    assert oct_.shape == ((B + 7) // 8, H, W, Cin, 2, 8)
+    dw, db = ops.conv3x3_wgrad_f16x3(xs, gs, Cin, stride_h=sh, circular=circ)
+    np.testing.assert_allclose(dw.cpu().numpy(), w.grad.float().numpy(), rtol=0, atol=3e-6 * max(1.0, float(w.grad.abs().max())))
+    np.testing.assert_allclose(db.cpu().numpy(), b.grad.float().numpy(), rtol=0, atol=3e-6 * max(1.0, float(b.grad.abs().max())))
+    dw2, db2 = ops.conv3x3_wgrad_f16x3(xs, gs, Cin, stride_h=sh, circular=circ)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)

@@ -55,6 +55,10 @@ SIGNATURES = {
     'witw_conv3x3_f16x3_fwd': (c_int, [c_void_p] * 4 + [c_int] * 10 + [c_void_p]),
     'witw_conv3x3_f16x3_pack_weights_ex': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'witw_conv3x3_f16x3_fwd_ex': (c_int, [c_void_p] * 6 + [c_int] * 11 + [c_void_p]),
+    'witw_octet_split_elems': (c_longlong, [c_int] * 4),
+    'witw_split_f16_to_octet': (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
+    'witw_conv3x3_wgrad_f16x3_workspace_floats': (c_longlong, [c_int] * 6),
+    'witw_conv3x3_wgrad_f16x3': (c_int, [c_void_p] * 6 + [c_int] * 9 + [c_void_p]),
     'witw_space_to_depth2': (c_int, [c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p, c_void_p]),
     'witw_gem_pool': (c_int, [c_void_p, c_void_p] + [c_int] * 8 + [c_float, c_void_p, c_void_p, c_void_p]),
     'witw_bn_workspace_floats': (c_longlong, [c_int] * 4),

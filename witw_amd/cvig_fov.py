@@ -363,8 +363,8 @@ class _EncoderFn(torch.autograd.Function):
 class _EncoderFnF16x3(torch.autograd.Function):
     """_EncoderFn with fp32-grade products on the fp16 MFMA (FOV_DSM.precision = 'fp16x3'): the forward (frozen trunk and
     trainable layers, Dropout2d scale in the epilogue) and every dgrad launch run on the fp16x3 kernels with split-fp16
-    activations and activation gradients; the weight gradients stay on the exact-fp32 wgrad kernel, fed by split -> fp32
-    conversions of the (small) saved activations and gradients. Parity: tests/test_f16x3_gpu.py against the fp32 path."""
+    activations and activation gradients; the weight gradients come from witw_conv3x3_wgrad_f16x3 (the same split
+    products over the batch-octet layout), in fp32. Parity: tests/test_f16x3_gpu.py against the fp32 path."""
 
     @staticmethod
     def forward(ctx, x, enc, scales, *params):
@@ -387,8 +387,7 @@ class _EncoderFnF16x3(torch.autograd.Function):
             x_in = kept[idx][0]
             conv = _conv_of(enc.model.features[idx])
             if conv.weight.requires_grad:
-                dw, db = ops.conv3x3_wgrad(ops.split_f16_to_f32(x_in), ops.split_f16_to_f32(dz), conv.in_channels, stride_h=sh,
-                                           circular=circ)
+                dw, db = ops.conv3x3_wgrad_f16x3(x_in, dz, conv.in_channels, stride_h=sh, circular=circ)
                 grads[idx] = (dw[:conv.out_channels].contiguous(), db[:conv.out_channels].contiguous())
             if n > 0:   # gradient at the previous layer's conv output
                 pidx = specs[n - 1][0]

@@ -839,6 +839,47 @@ def conv3x3_f16x3_fwd(x_split, packed, stride_h=1, circular=False, relu=True, po
     return y
 
 
+def split_f16_to_octet(x_split):
+    """split-fp16 NHWC [B,H,W,C/8,2,8] -> batch-octet split [ceil(B/8),H,W,C,2,8] (operand layout of conv3x3_wgrad_f16x3)."""
+    lib = _lib.load()
+    if not _is_split(x_split):
+        raise _lib.WitwError('split_f16_to_octet: x must be a contiguous float16 GPU tensor shaped [B,H,W,C/8,2,8]')
+    B, H, W, C8 = x_split.shape[:4]
+    y = torch.empty(((B + 7) // 8, H, W, C8 * 8, 2, 8), dtype=torch.float16, device=x_split.device)
+    _lib.check(lib.witw_split_f16_to_octet(x_split.data_ptr(), y.data_ptr(), B, H, W, C8 * 8, _stream()), 'witw_split_f16_to_octet')
+    return y
+
+
+def conv3x3_wgrad_f16x3(x_split, dz_split, cin_real, stride_h=1, circular=False, want_bias=True):
+    """Weight gradient with fp32-grade products on the fp16 MFMA: x_split [B,H,W,Cin/8,2,8] (the layer's input), dz_split
+    [B,Ho,W,Cout/8,2,8] (gradient at its output) -> (dW [Cout,cin_real,3,3] fp32, db [Cout] fp32 or None)."""
+    lib = _lib.load()
+    if not (_is_split(x_split) and _is_split(dz_split)):
+        raise _lib.WitwError('conv3x3_wgrad_f16x3: operands must be contiguous float16 GPU tensors shaped [B,H,W,C/8,2,8]')
+    B, H, W, Ci8 = x_split.shape[:4]
+    Cin, Cout = Ci8 * 8, dz_split.shape[3] * 8
+    Ho = (H + 2 - 3) // stride_h + 1
+    if tuple(dz_split.shape[:3]) != (B, Ho, W):
+        raise _lib.WitwError('conv3x3_wgrad_f16x3: dz %s does not match x %s (stride %d)' % (tuple(dz_split.shape),
+                                                                                           tuple(x_split.shape), stride_h))
+    prof = PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    x_oct, dz_oct = split_f16_to_octet(x_split), split_f16_to_octet(dz_split)
+    dw = torch.empty((Cout, cin_real, 3, 3), dtype=torch.float32, device=x_split.device)
+    db = torch.empty((Cout,), dtype=torch.float32, device=x_split.device) if want_bias else None
+    ws = torch.empty(lib.witw_conv3x3_wgrad_f16x3_workspace_floats(B, H, W, Cin, Cout, stride_h), dtype=torch.float32,
+                     device=x_split.device)
+    _lib.check(lib.witw_conv3x3_wgrad_f16x3(x_oct.data_ptr(), dz_oct.data_ptr(), dz_split.data_ptr(), dw.data_ptr(), _p(db),
+                                            ws.data_ptr(), B, H, W, Cin, cin_real, Cout, stride_h, int(circular), 0, _stream()),
+               'witw_conv3x3_wgrad_f16x3')
+    if prof is not None:
+        e1.record()
+        prof.append((('wgrad_f16x3', stride_h), 2.0 * cin_real * Cout * 9 * Ho * W * B, e0, e1))
+    return dw, db
+
+
 def bn_train_stats(a, valid_hw, gamma, beta, running_mean=None, running_var=None, eps=1e-5, momentum=0.1):
     """Batch statistics of BatchNorm2d over the valid region of a NHWC tensor -> (mean, invstd, scale, shift)."""
     lib = _lib.load()
