@@ -124,7 +124,7 @@ def main():
     if f16x3 and train:
         if semantic:
             sys.exit('fp16x3 training through the fused max-pools of cvig_semantic is not implemented')
-        surface_encoder.precision = overhead_encoder.precision = 'fp16x3'   # forward + dgrad on fp16x3, wgrad exact fp32
+        surface_encoder.precision = overhead_encoder.precision = 'fp16x3'   # forward, dgrad and wgrad on fp16x3
     surface_encoder.train(train)
     overhead_encoder.train(train)
     all_params = list(surface_encoder.parameters()) + list(overhead_encoder.parameters())
@@ -233,7 +233,7 @@ def main():
         'metric': 'image-pairs/sec (embedding+similarity)' if not train else 'image-pairs/sec (training step)', 'value': round(value, 2), 'unit': 'pairs/s',
         'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 3),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'bf16' if bf16 else ('f16x3 forward + dgrad (fp16 hi+lo operands, fp32 accumulate), f32 wgrad' if train else
+        'dtype': 'bf16' if bf16 else ('f16x3 forward, dgrad, wgrad (fp16 hi+lo operands, fp32 accumulate; fp32 gradients and Adam)' if train else
                                      'f16x3 (fp16 hi+lo operands, 3 fp16 MFMAs per fp32-equivalent product, fp32 accumulate)') if f16x3 else 'f32',
         'data': 'synthetic',
         'config': {'workload': ('%s fov=%d eval%s: resize+normalize+polar -> 2x FOV_DSM (VGG16[:23]+3 conv) -> '
@@ -241,7 +241,7 @@ def main():
                                ('%s fov=%d TRAIN step: resize+normalize+polar -> 2x FOV_DSM fwd (Dropout2d) -> match + '
                                 'triplet loss -> backward (%s) -> grad all-reduce -> Adam'
                                 % (mname + (' [bf16 MFMA fwd/dgrad/wgrad, fp32 accumulate + master weights]' if bf16 else
-                                            ' [forward + dgrad on fp16x3 (fp32-grade products on the fp16 MFMA), wgrad / Adam exact fp32]' if f16x3 else ''), a.fov,
+                                            ' [forward, dgrad and wgrad on fp16x3 (fp32-grade products on the fp16 MFMA), fp32 gradients / Adam]' if f16x3 else ''), a.fov,
                                    'dgrad L2-27, max-pool scatter, wgrad L0 + L17-27' if semantic else 'dgrad L19-27, wgrad L17-27')),
                    'pairs_per_gpu': B, 'global_batch': B * world, 'ground_raw': '%dx224x224' % channels,
                    'overhead_raw': '%dx512x512' % channels,
