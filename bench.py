@@ -122,8 +122,6 @@ def main():
     if bf16 and train:
         surface_encoder.precision = overhead_encoder.precision = 'bf16'     # mixed-precision step, fp32 master weights
     if f16x3 and train:
-        if semantic:
-            sys.exit('fp16x3 training through the fused max-pools of cvig_semantic is not implemented')
         surface_encoder.precision = overhead_encoder.precision = 'fp16x3'   # forward, dgrad and wgrad on fp16x3
     surface_encoder.train(train)
     overhead_encoder.train(train)

@@ -66,6 +66,7 @@ struct ConvHxArgs {
     const float* dropmask;       // nullptr, or [B,Cout] Dropout2d scale applied to conv + bias before the ReLU
     const unsigned short* gate;  // nullptr, or a split-fp16 tensor shaped like y: outputs where its value <= 0 are zeroed (ReLU backward)
     int dil_h;                   // 1: input rows are zero-interleaved (logical row 2i = physical row i): dgrad of a stride-(2,1) conv
+    unsigned char* pool_code;    // nullptr, or [B,Hy,Wy,Cout] arg-max position (dy*2+dx) of the fused 2x2 max pool (Cout % 8 == 0)
 };
 
 template <int TN, int SH, bool POOL, int NW>
@@ -378,9 +379,16 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_f16x3_kernel(ConvHxArgs 
                 for (int g = 0; g < 4; ++g)
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
-                        const float v0 = fmaxf(acc[mtA][nt][4 * g + 2 * e], acc[mtA][nt][4 * g + 2 * e + 1]);
-                        const float v1 = fmaxf(acc[mtB][nt][4 * g + 2 * e], acc[mtB][nt][4 * g + 2 * e + 1]);
-                        slab[(4 * g + 2 * hq + e) * 64 + nt * 32 + l31] = fin(fmaxf(v0, v1), nt);
+                        const float a00 = acc[mtA][nt][4 * g + 2 * e], a01 = acc[mtA][nt][4 * g + 2 * e + 1];
+                        const float a10 = acc[mtB][nt][4 * g + 2 * e], a11 = acc[mtB][nt][4 * g + 2 * e + 1];
+                        const float m = fmaxf(fmaxf(a00, a01), fmaxf(a10, a11));
+                        const int pc = 4 * g + 2 * hq + e;
+                        slab[pc * 64 + nt * 32 + l31] = fin(m, nt);
+                        if (p.pool_code != nullptr && yy < Hy && xb + pc < Wy && nch[nt] < p.Cout) {
+                            // first position attaining the max, scan order (0,0),(0,1),(1,0),(1,1) as torch's max_pool2d
+                            const int code = (a00 == m) ? 0 : (a01 == m) ? 1 : (a10 == m) ? 2 : 3;
+                            p.pool_code[(((size_t)b * Hy + yy) * Wy + xb + pc) * p.Cout + nch[nt]] = (unsigned char)code;
+                        }
                     }
             const int nbase = n0 + wn * 64 + pc8;
 #pragma unroll
@@ -473,6 +481,40 @@ __global__ void split_to_f32_kernel(const unsigned short* __restrict__ x, float*
     y[idx] = (float)xh[o] + (float)xh[o + 8];
 }
 
+// Backward of the fused MaxPool2d(2,2) on split-fp16 tensors: dy [B,Hp,Wp,C/8,2,8] is routed (both planes) to the position
+// the forward recorded (code uint8 [B,Hp,Wp,C]); dx [B,H,W,C/8,2,8], H >= 2Hp, W >= 2Wp (a dropped odd row / column keeps its
+// zeros). One thread per pooled pixel and channel octet.
+__global__ void maxpool2x2_bwd_split_kernel(const unsigned short* __restrict__ dy, const unsigned char* __restrict__ code,
+                                            unsigned short* __restrict__ dx, int Hp, int Wp, int H, int W, int C, size_t total) {
+    typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+    typedef unsigned char u8x8 __attribute__((ext_vector_type(8)));
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int C8 = C >> 3;
+    const int c8 = idx % C8;
+    size_t t = idx / C8;
+    const int w = t % Wp;
+    t /= Wp;
+    const int h = t % Hp;
+    const size_t b = t / Hp;
+    const size_t pp = (b * Hp + h) * Wp + w;
+    const u16x8 ghi = *reinterpret_cast<const u16x8*>(dy + ((pp * C8 + c8) * 2) * 8);
+    const u16x8 glo = *reinterpret_cast<const u16x8*>(dy + ((pp * C8 + c8) * 2 + 1) * 8);
+    const u8x8 k = *reinterpret_cast<const u8x8*>(code + pp * C + (size_t)c8 * 8);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        u16x8 ohi, olo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            ohi[e] = (k[e] == q) ? ghi[e] : (unsigned short)0;
+            olo[e] = (k[e] == q) ? glo[e] : (unsigned short)0;
+        }
+        u16x8* dst = reinterpret_cast<u16x8*>(dx + ((((b * H + 2 * h + (q >> 1)) * W + 2 * w + (q & 1)) * C8 + c8) * 2) * 8);
+        dst[0] = ohi;
+        dst[1] = olo;
+    }
+}
+
 template <int TN, int SH, bool POOL, int NW>
 int launch_hx_nw(ConvHxArgs a, hipStream_t st) {
     a.tiles_y = cdiv(a.Ho, NW);
@@ -549,8 +591,9 @@ int witw_split_f16_to_f32(const void* x_split, float* y, long long pixels, int C
 // before the ReLU), gate = split-fp16 tensor shaped like y (outputs where it is <= 0 are zeroed), dilate_h = x holds
 // (H-1)/2+1 physical rows standing for H zero-interleaved rows (dgrad of a stride-(2,1) layer; H is the logical height).
 int witw_conv3x3_f16x3_fwd_ex(const void* x_split, const void* wpk_f16, const float* bias, const float* dropmask,
-                              const void* gate_split, void* y, int B, int H, int W, int Cin, int Cout, int stride_h,
-                              int pad_circular, int relu, int pool, int out_nchw_f32, int dilate_h, void* stream) {
+                              const void* gate_split, void* y, unsigned char* pool_code, int B, int H, int W, int Cin, int Cout,
+                              int stride_h, int pad_circular, int relu, int pool, int out_nchw_f32, int dilate_h, void* stream) {
+    WITW_CHECK_ARG(!pool_code || (pool && (Cout % 8) == 0), "conv3x3_f16x3_fwd: pool codes need pool=1 and Cout %% 8 == 0");
     WITW_CHECK_ARG(x_split && wpk_f16 && bias && y, "conv3x3_f16x3_fwd: null pointer");
     WITW_CHECK_ARG(!(gate_split && (pool || out_nchw_f32)), "conv3x3_f16x3_fwd: gate with pool / NCHW output unsupported");
     WITW_CHECK_ARG(!(dilate_h && stride_h == 2), "conv3x3_f16x3_fwd: dilated input with stride 2 unsupported");
@@ -569,6 +612,7 @@ int witw_conv3x3_f16x3_fwd_ex(const void* x_split, const void* wpk_f16, const fl
     a.tiles_y = 0;
     a.circ = pad_circular; a.relu = relu; a.out_nchw_f32 = out_nchw_f32;
     a.dropmask = dropmask; a.gate = (const unsigned short*)gate_split; a.dil_h = dilate_h ? 1 : 0;
+    a.pool_code = pool ? pool_code : nullptr;
     const char* e = getenv("WITW_CONV_XCD");
     a.xcd_map = e ? atoi(e) != 0 : 1;
     hipStream_t st = (hipStream_t)stream;
@@ -580,9 +624,25 @@ int witw_conv3x3_f16x3_fwd_ex(const void* x_split, const void* wpk_f16, const fl
     return pool ? launch_hx<64, 1, true>(a, st) : launch_hx<64, 1, false>(a, st);
 }
 
+int witw_maxpool2x2_bwd_split(const void* dy_split, const unsigned char* code, void* dx_split, int B, int Hp, int Wp, int H, int W,
+                              int C, void* stream) {
+    WITW_CHECK_ARG(dy_split && code && dx_split, "maxpool2x2_bwd_split: null pointer");
+    WITW_CHECK_ARG(B > 0 && Hp > 0 && Wp > 0 && C > 0 && (C % 8) == 0 && H >= 2 * Hp && W >= 2 * Wp, "maxpool2x2_bwd_split: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    if ((H > 2 * Hp || W > 2 * Wp) && hipMemsetAsync(dx_split, 0, 4 * (size_t)B * H * W * C, st) != hipSuccess) {
+        witw_set_error("maxpool2x2_bwd_split: memset failed");
+        return WITW_ERR_LAUNCH;
+    }
+    const size_t total = (size_t)B * Hp * Wp * (C / 8);
+    hipLaunchKernelGGL(maxpool2x2_bwd_split_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                       (const unsigned short*)dy_split, code, (unsigned short*)dx_split, Hp, Wp, H, W, C, total);
+    WITW_CHECK_LAUNCH("maxpool2x2_bwd_split");
+    return WITW_OK;
+}
+
 int witw_conv3x3_f16x3_fwd(const void* x_split, const void* wpk_f16, const float* bias, void* y, int B, int H, int W, int Cin,
                            int Cout, int stride_h, int pad_circular, int relu, int pool, int out_nchw_f32, void* stream) {
-    return witw_conv3x3_f16x3_fwd_ex(x_split, wpk_f16, bias, nullptr, nullptr, y, B, H, W, Cin, Cout, stride_h, pad_circular, relu,
+    return witw_conv3x3_f16x3_fwd_ex(x_split, wpk_f16, bias, nullptr, nullptr, y, nullptr, B, H, W, Cin, Cout, stride_h, pad_circular, relu,
                                      pool, out_nchw_f32, 0, stream);
 }
 

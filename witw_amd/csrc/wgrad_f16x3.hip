@@ -79,8 +79,9 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_f16x3_kernel(WgradHxArgs p)
     const int c_begin = split * p.cps;
     const int c_end = min(p.chunks, c_begin + p.cps);
 
-    const i32x4 x_rs = raw_rsrc(p.x, (unsigned)((size_t)p.B8 * p.H * p.W * p.Cin * 32u));
-    const i32x4 z_rs = raw_rsrc(p.dz, (unsigned)((size_t)p.B8 * p.Ho * p.Wo * p.Cout * 32u));
+    // one buffer descriptor per image octet (a layer-0 gradient of 128 images is 2.1 GB as a whole: past the 2 GB that
+    // keep the out-of-range offset 0x80000000 out of range)
+    const size_t x_oct_halves = (size_t)p.H * p.W * p.Cin * 16, z_oct_halves = (size_t)p.Ho * p.Wo * p.Cout * 16;
     // lane -> channel of the tile; its 16 B of one plane sit at channel*32 + plane*16 of the pixel's run
     const unsigned x_lane = (ci0 + lane < p.Cin) ? (unsigned)lane * 32u : OOR;
     const unsigned z_lane = (co0 + lane < p.Cout) ? (unsigned)lane * 32u : OOR;
@@ -92,6 +93,8 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_f16x3_kernel(WgradHxArgs p)
         const int t = c / p.nseg;
         const int h = t % p.Ho, b8 = t / p.Ho;
         const int w0 = seg * WH_P;
+        const i32x4 x_rs = raw_rsrc(p.x + (size_t)b8 * x_oct_halves, (unsigned)(x_oct_halves * 2));
+        const i32x4 z_rs = raw_rsrc(p.dz + (size_t)b8 * z_oct_halves, (unsigned)(z_oct_halves * 2));
 #pragma unroll
         for (int i = 0; i < (NXI + NW - 1) / NW; ++i) {
             const int j = wave_u + NW * i;
@@ -106,7 +109,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_f16x3_kernel(WgradHxArgs p)
                     else if (gc >= p.W) gc -= p.W;
                 }
                 ok = ok && gc >= 0 && gc < p.W;
-                const unsigned soff = ok ? (unsigned)(((((size_t)b8 * p.H + gr) * p.W + gc) * p.Cin + ci0) * 32u + plane * 16u) : 0u;
+                const unsigned soff = ok ? (unsigned)((((size_t)gr * p.W + gc) * p.Cin + ci0) * 32u + plane * 16u) : 0u;
                 dma16(x_rs, lds + (unsigned)j * 1024u, ok ? x_lane : OOR, soff);
             }
         }
@@ -117,7 +120,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_f16x3_kernel(WgradHxArgs p)
             const int plane = j & 1, px = j >> 1;
             const int w = w0 + px;
             const bool ok = w < p.Wo;
-            const unsigned soff = ok ? (unsigned)(((((size_t)b8 * p.Ho + h) * p.Wo + w) * p.Cout + co0) * 32u + plane * 16u) : 0u;
+            const unsigned soff = ok ? (unsigned)((((size_t)h * p.Wo + w) * p.Cout + co0) * 32u + plane * 16u) : 0u;
             dma16(z_rs, lds + (unsigned)(X_S + j * 64) * 16u, ok ? z_lane : OOR, soff);
         }
     };
@@ -334,8 +337,8 @@ int witw_conv3x3_wgrad_f16x3(const void* x_oct, const void* dz_oct, const void* 
     WITW_CHECK_ARG(!db || (256 % (Cout / 8)) == 0, "conv3x3_wgrad_f16x3: bias gradient needs Cout/8 to divide 256 (Cout=%d)", Cout);
     const int B8 = cdiv(B, 8);
     const int Ho = (H + 2 - 3) / stride_h + 1;
-    WITW_CHECK_ARG((size_t)B8 * H * W * Cin * 32 < 0x80000000ull && (size_t)B8 * Ho * W * Cout * 32 < 0x80000000ull,
-                   "conv3x3_wgrad_f16x3: operand too large for one buffer descriptor");
+    WITW_CHECK_ARG((size_t)H * W * Cin * 32 < 0x80000000ull && (size_t)Ho * W * Cout * 32 < 0x80000000ull,
+                   "conv3x3_wgrad_f16x3: one image octet of an operand exceeds a buffer descriptor");
     hipStream_t st = (hipStream_t)stream;
     WgradHxArgs a;
     a.x = (const unsigned short*)x_oct; a.dz = (const unsigned short*)dz_oct; a.ws = workspace;

@@ -261,7 +261,8 @@ class FOV_DSM(torch.nn.Module):
 
     def _run_f16x3(self, x, scales, keep_from=None):
         """The layer stack on the fp16x3 kernels (split-fp16 activations, fp32-grade products, fp32 NCHW embedding).
-        Returns (embedding, kept) with kept[idx] = (layer input, layer output) in the split layout for idx >= keep_from."""
+        Returns (embedding, kept) with kept[idx] = (layer input, layer output, max-pool arg-max codes or None) in the split
+        layout for idx >= keep_from."""
         fast0 = self.in_channels <= 4 and (keep_from is None or keep_from > 0)
         h = x.contiguous() if fast0 else ops.nchw_to_split_f16(x.contiguous(), 8)
         last = self.layer_specs[-1][0]
@@ -271,12 +272,11 @@ class FOV_DSM(torch.nn.Module):
                 h = ops.conv3x3_first_fwd(h, self._pack_first(False), circular=self.circ_padding, relu=relu, split_f16=True)
                 continue
             keep = keep_from is not None and idx >= keep_from
-            if keep and pool:
-                raise _lib.WitwError("precision 'fp16x3' cannot train through a fused max-pool (layer %d): use 'fp32' or 'bf16'" % idx)
-            y = ops.conv3x3_f16x3_fwd(h, self._pack_f16x3(idx), stride_h=sh, circular=self.circ_padding, relu=relu, pool=pool,
-                                      out_nchw_f32=(idx == last), drop_scale=scales.get(idx))
+            out = ops.conv3x3_f16x3_fwd(h, self._pack_f16x3(idx), stride_h=sh, circular=self.circ_padding, relu=relu, pool=pool,
+                                        out_nchw_f32=(idx == last), drop_scale=scales.get(idx), want_pool_code=(keep and pool))
+            y, code = out if (keep and pool) else (out, None)
             if keep:
-                kept[idx] = (h, y)
+                kept[idx] = (h, y, code)
             h = y
         return h, kept
 
@@ -390,10 +390,12 @@ class _EncoderFnF16x3(torch.autograd.Function):
                 dw, db = ops.conv3x3_wgrad_f16x3(x_in, dz, conv.in_channels, stride_h=sh, circular=circ)
                 grads[idx] = (dw[:conv.out_channels].contiguous(), db[:conv.out_channels].contiguous())
             if n > 0:   # gradient at the previous layer's conv output
-                pidx = specs[n - 1][0]
-                dz = ops.conv3x3_f16x3_fwd(dz, enc._pack_f16x3(idx, transpose_flip=True), stride_h=1, circular=circ, relu=False,
-                                           pool=False, drop_scale=scales.get(pidx), gate=kept[pidx][1], dilate_h=(sh == 2),
+                pidx, _psh, _prelu, ppool, _pdrop = specs[n - 1]
+                p_in, p_out, p_code = kept[pidx]
+                dy = ops.conv3x3_f16x3_fwd(dz, enc._pack_f16x3(idx, transpose_flip=True), stride_h=1, circular=circ, relu=False,
+                                           pool=False, drop_scale=scales.get(pidx), gate=p_out, dilate_h=(sh == 2),
                                            out_h=x_in.shape[1] if sh == 2 else None)
+                dz = ops.maxpool2x2_bwd_split(dy, p_code, (p_in.shape[1], p_in.shape[2])) if ppool else dy
         ctx.kept = None
         flat = []
         for (idx, _c) in enc.trainable_convs():

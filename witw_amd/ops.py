@@ -795,7 +795,7 @@ def _is_split(t):
 
 
 def conv3x3_f16x3_fwd(x_split, packed, stride_h=1, circular=False, relu=True, pool=False, out_nchw_f32=False, drop_scale=None,
-                      gate=None, dilate_h=False, out_h=None):
+                      gate=None, dilate_h=False, out_h=None, want_pool_code=False):
     """x split-fp16 NHWC [B,H,W,Cin/8,2,8] -> split-fp16 NHWC [B,Hy,Wy,Cout/8,2,8] (or the fp32 NCHW embedding). Training
     extras as in conv3x3_bf16_fwd: drop_scale [B,Cout] fp32, gate = split-fp16 tensor shaped like the output, dilate_h /
     out_h = zero-interleaved input rows (dgrad of a stride-(2,1) layer)."""
@@ -828,15 +828,31 @@ def conv3x3_f16x3_fwd(x_split, packed, stride_h=1, circular=False, relu=True, po
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
+    code = torch.empty((B, Hy, Wy, packed.cout), dtype=torch.uint8, device=y.device) if (pool and want_pool_code) else None
     _lib.check(lib.witw_conv3x3_f16x3_fwd_ex(x_split.data_ptr(), packed.wpk.data_ptr(), packed.bias.data_ptr(), _p(drop_scale),
-                                             _p(gate), y.data_ptr(), B, H, W, C, packed.cout, stride_h, int(circular), int(relu),
-                                             int(pool), int(out_nchw_f32), int(bool(dilate_h)), _stream()),
+                                             _p(gate), y.data_ptr(), _p(code), B, H, W, C, packed.cout, stride_h, int(circular),
+                                             int(relu), int(pool), int(out_nchw_f32), int(bool(dilate_h)), _stream()),
                'witw_conv3x3_f16x3_fwd_ex')
     if prof is not None:
         e1.record()
         prof.append((('f16x3', lib.witw_conv3x3_tile_n(packed.cout), stride_h, bool(pool)),
                      2.0 * packed.cin * packed.cout * 9 * Ho * W * B, e0, e1))
+    if want_pool_code:
+        return y, code
     return y
+
+
+def maxpool2x2_bwd_split(dy_split, code, out_hw):
+    """dy split-fp16 [B,Hp,Wp,C/8,2,8] + code uint8 [B,Hp,Wp,C] -> dx split-fp16 [B,H,W,C/8,2,8]."""
+    lib = _lib.load()
+    if not _is_split(dy_split) or code.dtype != torch.uint8:
+        raise _lib.WitwError('maxpool2x2_bwd_split: dy must be a split-fp16 tensor and code uint8')
+    B, Hp, Wp, C8 = dy_split.shape[:4]
+    H, W = out_hw
+    dx = torch.empty((B, H, W, C8, 2, 8), dtype=torch.float16, device=dy_split.device)
+    _lib.check(lib.witw_maxpool2x2_bwd_split(dy_split.data_ptr(), code.data_ptr(), dx.data_ptr(), B, Hp, Wp, H, W, C8 * 8, _stream()),
+               'witw_maxpool2x2_bwd_split')
+    return dx
 
 
 def split_f16_to_octet(x_split):
