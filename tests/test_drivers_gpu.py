@@ -75,6 +75,18 @@ def test_train_then_test_drivers_bf16(tmp_path, monkeypatch, capsys):
     assert 1 <= t3['median'] <= 6
 
 
+def test_train_driver_on_f16x3(tmp_path, monkeypatch):
+    """train() with Globals.precision = 'fp16x3': forward, dgrad and wgrad on the split-fp16 arithmetic, fp32 checkpoints."""
+    from witw_amd import cvig_fov
+    csv = _write_dataset(str(tmp_path), 6)
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setattr(cvig_fov.Globals, 'precision', 'fp16x3')
+    best = cvig_fov.train(dataset='cvusa', fov=70, val_quantity=2, batch_size=2, num_workers=0, num_epochs=1, csv_path=csv)
+    assert best is not None and np.isfinite(best)
+    sd = torch.load(os.path.join('weights', 'fov_70_overhead_best.pth'))
+    assert all(v.dtype == torch.float32 for v in sd.values())
+
+
 def test_projector_dump_inverse_normalize_and_bilinear_interpolate(tmp_path, monkeypatch):
     """The reference's TensorBoard embedding-projector dump (model/cvig_fov.py:474-479, :534-540) with a recording
     writer, inverse_normalize's verbatim semantics (:151-154) and bilinear_interpolate (:156-183) on free coordinates."""
