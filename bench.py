@@ -199,6 +199,8 @@ def main():
         rk = [torch.empty_like(ranks) for _ in range(world)]
         dist.all_gather(rk, ranks)
         ranks = torch.cat(rk)
+    if f16x3 and ops.f16x3_overflowed(device):
+        sys.exit('fp16x3: an activation left the fp16 range; the run is invalid')
     ranks_h = ranks.cpu().numpy().astype(np.int64)
     pairs = B * world * a.steps
     value = pairs / dt

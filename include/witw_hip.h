@@ -161,9 +161,11 @@ int witw_conv3x3_f16x3_fwd(const void* x_split, const void* wpk_f16, const float
  * tensor shaped like y), zero-interleaved rows; transpose_flip packs the dgrad filter of the source [cin][cout][3][3] */
 int witw_conv3x3_f16x3_pack_weights_ex(const float* w_kcrs, void* wpk_f16, int cout, int cin, int transpose_flip, void* stream);
 int witw_conv3x3_f16x3_fwd_ex(const void* x_split, const void* wpk_f16, const float* bias, const float* dropmask,
-                              const void* gate_split, void* y, unsigned char* pool_code, int B, int H, int W, int Cin, int Cout,
-                              int stride_h, int pad_circular, int relu, int pool, int out_nchw_f32, int dilate_h, void* stream);
-/* pool_code (uint8 [B,Hy,Wy,Cout]) as in witw_conv3x3_bf16_fwd_ex; its backward on split tensors: */
+                              const void* gate_split, void* y, unsigned char* pool_code, int* overflow_flag, int B, int H, int W,
+                              int Cin, int Cout, int stride_h, int pad_circular, int relu, int pool, int out_nchw_f32, int dilate_h,
+                              void* stream);
+/* pool_code (uint8 [B,Hy,Wy,Cout]) as in witw_conv3x3_bf16_fwd_ex; overflow_flag: NULL or a device int set to 1 when a
+ * split-fp16 output leaves the fp16 range (|v| > 65504 or NaN cannot be carried as hi + lo). The max-pool backward on split tensors: */
 int witw_maxpool2x2_bwd_split(const void* dy_split, const unsigned char* code, void* dx_split, int B, int Hp, int Wp, int H, int W,
                               int C, void* stream);
 

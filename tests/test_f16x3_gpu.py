@@ -196,3 +196,18 @@ def test_semantic_f16x3_training_step_vs_fp32_path():
         # layer 0 sits behind three arg-max routings: a near-tie that routes differently moves one pixel's gradient
         assert rel < (5e-2 if 'features.0.' in k else 5e-3), (k, rel)
     print('semantic fp16x3 vs fp32 step: loss %.7f vs %.7f, worst gradient deviation %.2e (%s)' % (l3, l32, worst[1], worst[0]))
+
+
+def test_f16x3_flags_values_beyond_the_fp16_range():
+    """|v| > 65504 cannot be carried as fp16 hi + lo: the kernel raises the device flag instead of passing infinities on."""
+    from witw_amd import ops
+    dev = torch.device('cuda:0')
+    ops.f16x3_overflowed(dev)           # clear
+    x = torch.ones(1, 8, 8, 64)
+    w = torch.zeros(64, 8, 3, 3)
+    w[:, :, 1, 1] = 1.0
+    pk = ops.PackedConvF16x3(w.to(dev), torch.zeros(64).to(dev))
+    ops.conv3x3_f16x3_fwd(ops.nchw_to_split_f16((x * 100.0).to(dev), 8), pk)                     # 8 * 100: fine
+    assert not ops.f16x3_overflowed(dev)
+    ops.conv3x3_f16x3_fwd(ops.nchw_to_split_f16((x * 2.0e4).to(dev), 8), pk)                     # 8 * 2e4 = 1.6e5 > 65504
+    assert ops.f16x3_overflowed(dev) and not ops.f16x3_overflowed(dev)

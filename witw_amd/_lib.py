@@ -54,7 +54,7 @@ SIGNATURES = {
     'witw_split_f16_to_f32': (c_int, [c_void_p, c_void_p, c_longlong, c_int, c_void_p]),
     'witw_conv3x3_f16x3_fwd': (c_int, [c_void_p] * 4 + [c_int] * 10 + [c_void_p]),
     'witw_conv3x3_f16x3_pack_weights_ex': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
-    'witw_conv3x3_f16x3_fwd_ex': (c_int, [c_void_p] * 7 + [c_int] * 11 + [c_void_p]),
+    'witw_conv3x3_f16x3_fwd_ex': (c_int, [c_void_p] * 8 + [c_int] * 11 + [c_void_p]),
     'witw_maxpool2x2_bwd_split': (c_int, [c_void_p] * 3 + [c_int] * 6 + [c_void_p]),
     'witw_octet_split_elems': (c_longlong, [c_int] * 4),
     'witw_split_f16_to_octet': (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),

@@ -67,6 +67,7 @@ struct ConvHxArgs {
     const unsigned short* gate;  // nullptr, or a split-fp16 tensor shaped like y: outputs where its value <= 0 are zeroed (ReLU backward)
     int dil_h;                   // 1: input rows are zero-interleaved (logical row 2i = physical row i): dgrad of a stride-(2,1) conv
     unsigned char* pool_code;    // nullptr, or [B,Hy,Wy,Cout] arg-max position (dy*2+dx) of the fused 2x2 max pool (Cout % 8 == 0)
+    int* overflow;               // nullptr, or a device flag set to 1 when an output leaves the fp16 range (|v| > 65504: its hi part is inf)
 };
 
 template <int TN, int SH, bool POOL, int NW>
@@ -298,6 +299,7 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_f16x3_kernel(ConvHxArgs 
     _Float16* const yh = reinterpret_cast<_Float16*>(p.y);
     // element (pixel index pix, channel c) of a split-fp16 tensor with C channels: hi at this offset, lo 8 halves further
     auto split_off = [&](size_t pix, int c) { return (pix * p.Cout + (size_t)(c & ~7)) * 2 + (c & 7); };
+    bool too_big_e = false;
     auto emit = [&](float v, int nt, int yy, int xx) {
         v = fin(v, nt);
         if (yy < Hy && xx < Wy && nch[nt] < p.Cout) {
@@ -306,6 +308,7 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_f16x3_kernel(ConvHxArgs 
             } else {
                 const size_t o = split_off(((size_t)b * Hy + yy) * Wy + xx, nch[nt]);
                 if (p.gate != nullptr && !gate_open(p.gate[o])) v = 0.f;
+                too_big_e = too_big_e || !(fabsf(v) <= 65504.f);
                 const _Float16 hi = (_Float16)v;
                 yh[o] = hi;
                 yh[o + 8] = (_Float16)(v - (float)hi);
@@ -313,7 +316,10 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_f16x3_kernel(ConvHxArgs 
         }
     };
     // 8 channels (two float4) of one pixel -> 16 B hi + 16 B lo, adjacent
+    bool too_big = false;       // some value of this lane left the fp16 range
     auto store_split8 = [&](f32x4 v0, f32x4 v1, size_t pix, int nbase) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) too_big = too_big || !(fabsf(v0[e]) <= 65504.f) || !(fabsf(v1[e]) <= 65504.f);
         if (p.gate != nullptr) {
             typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
             const u16x8 gt = *reinterpret_cast<const u16x8*>(p.gate + (pix * p.Cout + nbase) * 2);     // hi plane of the gate
@@ -416,6 +422,8 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_f16x3_kernel(ConvHxArgs 
                     }
         }
     }
+    // a value beyond the fp16 range (or a NaN) cannot be carried as hi + lo: raise the caller's flag instead of passing infinities on
+    if (p.overflow != nullptr && __any((too_big || too_big_e) ? 1 : 0) && lane == 0) atomicOr(p.overflow, 1);
 }
 
 // wpk[nt][kc][slot][n][0..7] (fp16) <- w[cout][cin][kh][kw] (fp32, torch KCRS); one thread per 16-B slot.
@@ -591,8 +599,9 @@ int witw_split_f16_to_f32(const void* x_split, float* y, long long pixels, int C
 // before the ReLU), gate = split-fp16 tensor shaped like y (outputs where it is <= 0 are zeroed), dilate_h = x holds
 // (H-1)/2+1 physical rows standing for H zero-interleaved rows (dgrad of a stride-(2,1) layer; H is the logical height).
 int witw_conv3x3_f16x3_fwd_ex(const void* x_split, const void* wpk_f16, const float* bias, const float* dropmask,
-                              const void* gate_split, void* y, unsigned char* pool_code, int B, int H, int W, int Cin, int Cout,
-                              int stride_h, int pad_circular, int relu, int pool, int out_nchw_f32, int dilate_h, void* stream) {
+                              const void* gate_split, void* y, unsigned char* pool_code, int* overflow_flag, int B, int H, int W,
+                              int Cin, int Cout, int stride_h, int pad_circular, int relu, int pool, int out_nchw_f32, int dilate_h,
+                              void* stream) {
     WITW_CHECK_ARG(!pool_code || (pool && (Cout % 8) == 0), "conv3x3_f16x3_fwd: pool codes need pool=1 and Cout %% 8 == 0");
     WITW_CHECK_ARG(x_split && wpk_f16 && bias && y, "conv3x3_f16x3_fwd: null pointer");
     WITW_CHECK_ARG(!(gate_split && (pool || out_nchw_f32)), "conv3x3_f16x3_fwd: gate with pool / NCHW output unsupported");
@@ -613,6 +622,7 @@ int witw_conv3x3_f16x3_fwd_ex(const void* x_split, const void* wpk_f16, const fl
     a.circ = pad_circular; a.relu = relu; a.out_nchw_f32 = out_nchw_f32;
     a.dropmask = dropmask; a.gate = (const unsigned short*)gate_split; a.dil_h = dilate_h ? 1 : 0;
     a.pool_code = pool ? pool_code : nullptr;
+    a.overflow = overflow_flag;
     const char* e = getenv("WITW_CONV_XCD");
     a.xcd_map = e ? atoi(e) != 0 : 1;
     hipStream_t st = (hipStream_t)stream;
@@ -642,7 +652,7 @@ int witw_maxpool2x2_bwd_split(const void* dy_split, const unsigned char* code, v
 
 int witw_conv3x3_f16x3_fwd(const void* x_split, const void* wpk_f16, const float* bias, void* y, int B, int H, int W, int Cin,
                            int Cout, int stride_h, int pad_circular, int relu, int pool, int out_nchw_f32, void* stream) {
-    return witw_conv3x3_f16x3_fwd_ex(x_split, wpk_f16, bias, nullptr, nullptr, y, nullptr, B, H, W, Cin, Cout, stride_h, pad_circular, relu,
+    return witw_conv3x3_f16x3_fwd_ex(x_split, wpk_f16, bias, nullptr, nullptr, y, nullptr, nullptr, B, H, W, Cin, Cout, stride_h, pad_circular, relu,
                                      pool, out_nchw_f32, 0, stream);
 }
 

@@ -1069,6 +1069,9 @@ def test(dataset='cvusa', fov=360, batch_size=64, num_workers=8, csv_path=None, 
                        Globals.img_mean, Globals.img_std)
     surface_embed = torch.cat(su_parts, dim=0)
     overhead_embed = torch.cat(ov_parts, dim=0)
+    if Globals.precision == 'fp16x3' and ops.f16x3_overflowed(surface_embed.device):
+        raise _lib.WitwError("an activation left the fp16 range (|v| > 65504) on the fp16x3 kernels: evaluate these weights with "
+                             "precision 'fp32'")
     if world > 1:       # queries replicated, gallery rows stay sharded (SURVEY §8e retrieval partitioning)
         rk = sharded_ranks(overhead_embed, parallel.all_gather_ragged(surface_embed), shard_begin)
     else:

@@ -790,6 +790,28 @@ def split_f16_to_f32(x_split):
     return y
 
 
+_F16X3_FLAGS = {}
+
+
+def _f16x3_flag(device):
+    """Per-device overflow flag of the fp16x3 kernels (set when an activation leaves the fp16 range)."""
+    key = (device.type, device.index)
+    if key not in _F16X3_FLAGS:
+        _F16X3_FLAGS[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return _F16X3_FLAGS[key]
+
+
+def f16x3_overflowed(device=None, reset=True):
+    """True if any fp16x3 conv since the last check produced a value beyond the fp16 range (|v| > 65504) or a NaN, which
+    the hi + lo representation cannot carry (synchronises: call it at the end of an evaluation, not per step)."""
+    device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+    flag = _f16x3_flag(device)
+    hit = bool(flag.item())
+    if hit and reset:
+        flag.zero_()
+    return hit
+
+
 def _is_split(t):
     return t.is_cuda and t.dtype == torch.float16 and t.is_contiguous() and t.dim() == 6 and tuple(t.shape[4:]) == (2, 8)
 
@@ -830,8 +852,9 @@ def conv3x3_f16x3_fwd(x_split, packed, stride_h=1, circular=False, relu=True, po
         e0.record()
     code = torch.empty((B, Hy, Wy, packed.cout), dtype=torch.uint8, device=y.device) if (pool and want_pool_code) else None
     _lib.check(lib.witw_conv3x3_f16x3_fwd_ex(x_split.data_ptr(), packed.wpk.data_ptr(), packed.bias.data_ptr(), _p(drop_scale),
-                                             _p(gate), y.data_ptr(), _p(code), B, H, W, C, packed.cout, stride_h, int(circular),
-                                             int(relu), int(pool), int(out_nchw_f32), int(bool(dilate_h)), _stream()),
+                                             _p(gate), y.data_ptr(), _p(code), _f16x3_flag(x_split.device).data_ptr(), B, H, W, C,
+                                             packed.cout, stride_h, int(circular), int(relu), int(pool), int(out_nchw_f32),
+                                             int(bool(dilate_h)), _stream()),
                'witw_conv3x3_f16x3_fwd_ex')
     if prof is not None:
         e1.record()
