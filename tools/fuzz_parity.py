@@ -6,7 +6,8 @@ shapes through the C ABI, compared with torch CPU ops in the reference's op orde
 
 Covers: fp32 conv forward (stride, circular/zero padding, ReLU, fused pool, GEO / NW variants by shape), its dgrad
 form, fp32 wgrad (+ bias), the 4-tap forms, bf16 conv forward / wgrad, the fused match (orientation exact, distance
-1e-5) with ragged batch sizes and widths. Prints one line per failure and a summary; exit code 1 on any failure.
+1e-5) with ragged batch sizes and widths, the fp16x3 conv forward / dgrad form (gate, Dropout2d scale, zero-interleaved
+rows) / wgrad against fp64. FUZZ_KINDS=10,11 restricts the sweep to the listed kinds. Prints one line per failure and a summary; exit code 1 on any failure.
 """
 import os
 import sys
@@ -42,7 +43,9 @@ def main():
 
     while time.time() - t0 < budget:
         n += 1
-        kind = rng.integers(0, 10)
+        kind = rng.integers(0, 12)
+        if os.environ.get('FUZZ_KINDS') and str(int(kind)) not in os.environ['FUZZ_KINDS'].split(','):
+            continue
         B = int(rng.integers(1, 5))
         H = int(rng.integers(1, 40))
         W = int(rng.integers(1, 140))
@@ -180,6 +183,42 @@ def main():
                     ref = torch.relu(ref) if relu else ref
                 got = y.cpu() if last else ops.split_f16_to_f32(y).cpu().permute(0, 3, 1, 2)
                 check('f16x3_fwd', (B, H, W, cin8, cout, sh, circ, relu, pool), got, ref.float(), 5e-6)
+            elif kind == 10:    # fp16x3 weight gradient vs fp64 autograd
+                cin8, cout8 = (cin + 7) // 8 * 8, (cout + 7) // 8 * 8
+                if 256 % (cout8 // 8):
+                    cout8 = 64
+                x = torch.randn(B, cin8, H, W)
+                wr = torch.zeros(cout8, cin8, 3, 3, dtype=torch.float64, requires_grad=True)
+                br = torch.zeros(cout8, dtype=torch.float64, requires_grad=True)
+                yref = O.conv3x3(x.double(), wr, br, sh, circ)
+                gy = torch.randn(tuple(yref.shape))
+                yref.backward(gy.double())
+                dw, db = ops.conv3x3_wgrad_f16x3(ops.nchw_to_split_f16(x.to(dev), cin8), ops.nchw_to_split_f16(gy.to(dev), cout8), cin8,
+                                                 stride_h=sh, circular=circ)
+                check('wgrad_f16x3', (B, H, W, cin8, cout8, sh, circ), dw.cpu(), wr.grad.float(), 4e-6)
+                check('bgrad_f16x3', (B, H, W, cin8, cout8, sh, circ), db.cpu(), br.grad.float(), 4e-6)
+            elif kind == 11:    # fp16x3 dgrad form: transposed filter, gate, dropout scale, zero-interleaved rows
+                cin8, cout8 = (cin + 7) // 8 * 8, (cout + 7) // 8 * 8
+                xr = torch.randn(B, cin8, H, W, dtype=torch.float64, requires_grad=True)
+                w = torch.randn(cout8, cin8, 3, 3) * 0.05
+                yref = O.conv3x3(xr, w.double(), torch.zeros(cout8, dtype=torch.float64), sh, circ)
+                gy = torch.randn(tuple(yref.shape))
+                yref.backward(gy.double())
+                gate = torch.randn(B, cin8, H, W)
+                scale = torch.rand(B, cin8) + 0.5
+                # the gate is a stored split-fp16 activation: open iff its fp16 hi part is > 0 (values under 2^-25 were stored as 0)
+                ref = xr.grad * scale[:, :, None, None].double() * (gate.half() > 0).double()
+                dx = ops.conv3x3_f16x3_fwd(ops.nchw_to_split_f16(gy.to(dev), cout8), ops.PackedConvF16x3(w.to(dev), None, transpose_flip=True),
+                                           stride_h=1, circular=circ, relu=False, drop_scale=scale.to(dev),
+                                           gate=ops.nchw_to_split_f16(gate.to(dev), cin8), dilate_h=(sh == 2), out_h=H if sh == 2 else None)
+                got = ops.split_f16_to_f32(dx).cpu().permute(0, 3, 1, 2)
+                check('dgrad_f16x3', (B, H, W, cin8, cout8, sh, circ), got, ref.float(), 5e-6)
+                if os.environ.get('FUZZ_DEBUG'):
+                    bad = ((got - ref.float()).abs() > 1e-3).nonzero()
+                    if len(bad):
+                        b0 = tuple(bad[0].tolist())
+                        print('   bad', len(bad), bad[:5].tolist(), 'got', float(got[b0]), 'ref', float(ref[b0]), 'gate', float(gate[b0]),
+                              'scale', float(scale[b0[0], b0[1]]), 'ungated', float(xr.grad[b0]), flush=True)
             else:               # fused match (kinds 5 and above the list)
                 bo, bs, we = int(rng.integers(1, 40)), int(rng.integers(1, 150)), int(rng.integers(1, 65))
                 ov = torch.randn(bo, 16, 4, 64)
