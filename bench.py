@@ -68,6 +68,9 @@ def main():
     ap.add_argument('--gallery', type=int, default=125000, help='retrieval: gallery rows PER GPU (1M / 8)')
     ap.add_argument('--queries', type=int, default=10000, help='retrieval: ground queries (replicated)')
     ap.add_argument('--topk', type=int, default=10)
+    ap.add_argument('--match', choices=['direct', 'dft'], default='direct',
+                    help="retrieval: 'dft' = orientation search through the 64-point row spectra (21k instead of 524k FLOP per "
+                         "pair, same fp32 MFMA; scores equal to fp32 rounding)")
     ap.add_argument('--precision', choices=['fp32', 'bf16', 'fp16x3'], default='fp32',
                     help='fp32 (headline, BASELINE configs[1]) or the bf16 MFMA inference path (configs[3] arithmetic)')
     ap.add_argument('--model', choices=['fov', 'semantic'], default='fov',
@@ -322,7 +325,7 @@ def retrieval(a, rank, world, device, cvig_fov, ops):
         dist.all_reduce(queries)
 
     def step():
-        return cvig_fov.retrieve(gallery, queries, k=k, shard_begin=rank * G)
+        return cvig_fov.retrieve(gallery, queries, k=k, shard_begin=rank * G, method=a.match)
 
     for _ in range(a.warmup):
         step()
@@ -343,7 +346,7 @@ def retrieval(a, rank, world, device, cvig_fov, ops):
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    m = [(fl, e0.elapsed_time(e1)) for (v, fl, e0, e1) in prof if v[0] == 'match']
+    m = [(fl, e0.elapsed_time(e1)) for (v, fl, e0, e1) in prof if v[0] in ('match', 'match_dft')]
     m_fl = sum(f for f, _ in m) / max(1, len(m))
     m_ms = sum(t for _, t in m) / max(1, len(m))
     achieved = m_fl / (m_ms * 1e-3) / 1e12 if m_ms > 0 else 0.0
@@ -355,12 +358,15 @@ def retrieval(a, rank, world, device, cvig_fov, ops):
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': 'gallery retrieval: %d overhead embeddings per GPU (%d total) x %d ground queries, fov=%d, '
                                'ranks + top-%d' % (G, G * world, Q, a.fov, k),
+                   'match': a.match,
                    'parallelism': 'gallery rows sharded over %d rank(s); all-reduce of true distances and rank counts, '
                                   'all-gather + merge of top-k candidates' % world},
         'queries_per_sec': round(Q * a.steps / dt, 1),
         'recall': {'top1_pct': float(np.mean(ranks_h <= 1) * 100), 'top5_pct': float(np.mean(ranks_h <= 5) * 100),
                    'top10_pct': float(np.mean(ranks_h <= 10) * 100), 'N': int(G * world), 'topk_first_is_true_pct': top1_hit},
-        'roofline': {'bound': 'mfma', 'kernel': 'witw_match_fwd launch (match_kernel_w64 + 2 norm kernels)',
+        'roofline': {'bound': 'mfma', 'kernel': 'witw_match_fwd_dft launch (match_dft_kernel + norm / table kernels), FLOP of the '
+                                                'spectral form: 21,120 per pair' if a.match == 'dft' else
+                                                'witw_match_fwd launch (match_kernel_w64 + 2 norm kernels)',
                      'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None, 'launches': len(m),
                      'avg_launch_ms': round(m_ms, 3), 'avg_launch_gflop': round(m_fl / 1e9, 1)},

@@ -94,6 +94,18 @@ int witw_adam_step(float* param, const float* grad, float* exp_avg, float* exp_a
 long long witw_match_workspace_floats(int Bo, int Bs);
 int witw_match_fwd(const float* ov, const float* su, int Bo, int Bs, int We, long long* orientation, float* distance,
                    float* score, float* workspace, void* stream);
+/* The same match through the row spectra (retrieval, BASELINE config 5: every gallery row against every query). The orientation
+ * search is a circular cross-correlation along the 64 columns: with the 64-point DFT of every (channel,row) line of both sides it
+ * costs 21k FLOP per pair instead of 524k. witw_match_spectrum: emb [B,64 lines,W] (overhead: W = 64; surface: W = We, zero-
+ * padded) -> spec [B,33,128] (witw_match_spectrum_floats(B) floats; fp64 transform rounded once to fp32). witw_match_fwd_dft:
+ * outputs as witw_match_fwd (first maximum wins); scores agree with the direct sum to fp32 rounding (1e-6 of |ov||su|), so
+ * orientations can differ from witw_match_fwd only between shifts whose scores tie to that accuracy.
+ * workspace: witw_match_dft_workspace_floats(Bo,Bs) floats. */
+long long witw_match_spectrum_floats(long long n_embeddings);
+int witw_match_spectrum(const float* emb, float* spec, int B, int W, void* stream);
+long long witw_match_dft_workspace_floats(int Bo, int Bs);
+int witw_match_fwd_dft(const float* ov, const float* su, const float* spec_ov, const float* spec_su, int Bo, int Bs, int We,
+                       long long* orientation, float* distance, float* score, float* workspace, void* stream);
 /* backward of witw_match_fwd (orientation is a constant of the graph): grad_distance [Bo,Bs] ->
  * grad_ov [Bo,16,4,64] and/or grad_su [Bs,16,4,We]; orientation/score/workspace as left by the forward. scratch: NULL,
  * or witw_match_bwd_scratch_floats(Bo,Bs,We) floats that let the surface gradient split the overheads over several

@@ -1,0 +1,309 @@
+// Orientation search + chord distance through the row spectra (gfx950, fp32 MFMA): the retrieval form of the fused match
+// (BASELINE config C5; model/cvig_fov.py:297-363, called at :547-549 for every (gallery row, query) pair).
+//
+// score[o,s,shift] = sum_{ch,k} ov[o,ch,(k+shift)%64] * su[s,ch,k] is a circular cross-correlation along the 64 columns, summed
+// over the 64 (channel,row) lines. With X_f = sum_k x[k] e^{-2 pi i f k/64} per line (su zero-padded to 64 columns):
+//   C_f[o,s]   = sum_ch OV_f[o,ch] * conj(SU_f[s,ch])                                  f = 0..32
+//   score[o,s,shift] = (1/64) [ C_0 + (-1)^shift C_32 + 2 sum_{f=1..31} (Re C_f cos(2 pi f shift/64) - Im C_f sin(..)) ]
+// 2*2*128*33 + 2*2*32*33 = 21k FLOP per pair instead of 2*64*4096 = 524k of the direct form (match.hip), both on the fp32 MFMA.
+//
+// Kernel: a workgroup = 32 surfaces x 32 overheads, 4 waves = 2 surface teams x {even, odd} frequencies. Per frequency slot
+//   GEMM 1 (32x32x2 f32 MFMA, K = 128 = 64 lines x {re,im}): rows = 16 surfaces x {Re C, Im C}, columns = 32 overheads. Rows are
+//          ordered so that accumulator register r of lanes 0-31 holds Re C[surface r] and of lanes 32-63 Im C[surface r] of the
+//          same (surface, overhead): exactly the A operand (32 overheads x K=2) of
+//   GEMM 2 (one 32x32x2 MFMA per surface and slot): [32 overheads x (Re,Im)] x [(cos,-sin) x 32 shifts], accumulated over the
+//          slots into 16 x f32x16 registers per wave (all 256 accumulation registers of the wave).
+// Even frequencies give E[shift], odd ones O[shift] for shift < 32; score[shift] = E + O, score[shift+32] = E - O. The two
+// waves of a team exchange E / O through LDS, every lane then scans the 64 shifts of two pairs (first maximum wins, as
+// torch.argmax) and writes orientation / score / distance like match.hip does.
+#include "common.h"
+
+namespace {
+
+constexpr int NSLOT = 33;              // frequency slots 0..32 ([P(64 lines) | Q(64 lines)] each; Q = 0 for slots 0 and 32)
+constexpr int SPEC = NSLOT * 128;      // floats per embedding spectrum
+constexpr int NSTEP = 17;              // step i: even waves slot 2i, odd waves slot 2i+1 (slot 33 reads zeros)
+constexpr int RSA = 132, QOFF = 66;    // surface rows in LDS: P at 0, Q at 66 (bank = 4*surface + 2*part + k: conflict-free)
+constexpr int RSB = 130;               // overhead rows in LDS: P at 0, Q at 64 (bank = 2*overhead + k)
+constexpr int A_F = 2 * 32 * RSA;      // [parity][32 surfaces]
+constexpr int B_F = 2 * 32 * RSB;      // [parity][32 overheads]
+constexpr int STAGE_F = A_F + B_F;     // 16768 floats
+constexpr int XCH = 256 * 33;          // exchange region: 256 pairs x 32 shifts, row stride 33
+constexpr int LDS_F = (2 * STAGE_F > 4 * XCH) ? 2 * STAGE_F : 4 * XCH;
+
+struct DftArgs {
+    const float* spec_ov;    // [Bo][33][128]
+    const float* spec_su;    // [Bs][33][128]
+    const float* dtab;       // [33][64]: lane (hk, shift) -> inverse-transform coefficient of (Re | Im) at that shift
+    const float* wn;         // [Bo,64] window norms per shift
+    const float* sn;         // [Bs]    surface norms
+    long long* orientation;  // [Bo,Bs] or null
+    float* distance;         // [Bo,Bs] or null
+    float* score;            // [Bo,Bs] or null
+    int Bo, Bs, nbx, nby;
+};
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void match_dft_kernel(DftArgs p) {
+    __shared__ float smem[LDS_F];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hk = lane >> 5;
+    const int team = wave >> 1, par = wave & 1;
+
+    // 16 x 16 tile windows: consecutive workgroups walk 16 overhead tiles of one surface tile, then the next surface tile, so
+    // the 256 resident workgroups share 16 + 16 tile spectra per slot (L2-resident while the slots advance together)
+    int bx, by;
+    {
+        const int per_group = 16 * p.nbx;
+        const int g = blockIdx.x / per_group, within = blockIdx.x - g * per_group;
+        const int rows = min(16, p.nby - 16 * g);
+        by = 16 * g + within % rows;
+        bx = within / rows;
+        if (bx >= p.nbx) return;        // never: within < rows * nbx for a full group; guards the ragged last group
+    }
+    const int s0 = bx * 32, o0 = by * 32;
+
+    // ---- staging roles: 128 rows (64 surface rows [parity][32], 64 overhead rows) x 32 float4 per step
+    const int l32 = tid & 31, rg = tid >> 5;
+    const float* src[16];
+    int dst[16];
+    bool live[16];
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int row = rg + 8 * it;
+        const int rp = (row >> 5) & 1, rl = row & 31;
+        if (row < 64) {
+            live[it] = s0 + rl < p.Bs;
+            src[it] = p.spec_su + ((size_t)(live[it] ? s0 + rl : 0) * NSLOT + rp) * 128 + 4 * l32;
+            dst[it] = (rp * 32 + rl) * RSA + (l32 < 16 ? 4 * l32 : QOFF + 4 * (l32 - 16));
+        } else {
+            live[it] = o0 + rl < p.Bo;
+            src[it] = p.spec_ov + ((size_t)(live[it] ? o0 + rl : 0) * NSLOT + rp) * 128 + 4 * l32;
+            dst[it] = A_F + (rp * 32 + rl) * RSB + 4 * l32;
+        }
+    }
+    f32x4 pre[16];
+    auto load_step = [&](int i) {
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int rp = ((rg + 8 * it) >> 5) & 1;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (live[it] && 2 * i + rp < NSLOT) v = *reinterpret_cast<const f32x4*>(src[it] + (size_t)i * 256);
+            pre[it] = v;
+        }
+    };
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    auto store_step = [&](int buf) {
+        float* st = smem + buf * STAGE_F;
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            f32x2 lo = {pre[it][0], pre[it][1]}, hi = {pre[it][2], pre[it][3]};
+            *reinterpret_cast<f32x2*>(st + dst[it]) = lo;
+            *reinterpret_cast<f32x2*>(st + dst[it] + 2) = hi;
+        }
+    };
+
+    // ---- operand roles. GEMM-1 row l31 = surface j, part (0: Re C, 1: Im C); row order j&3 + 4*part + 8*(j>>2)
+    const int j = (l31 & 3) + 4 * (l31 >> 3), part = (l31 >> 2) & 1;
+    //   K < 64 (lines x re of the overhead):  Re row reads P, Im row reads -Q;  K >= 64 (x im): Re row reads Q, Im row reads P
+    const int a_off1 = (par * 32 + team * 16 + j) * RSA + (part ? QOFF : 0) + hk;
+    const int a_off2 = (par * 32 + team * 16 + j) * RSA + (part ? 0 : QOFF) + hk;
+    const unsigned negm = part ? 0x80000000u : 0u;
+    const int b_off1 = A_F + (par * 32 + l31) * RSB + hk;
+    const int b_off2 = b_off1 + 64;
+
+    f32x16 acc2[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc2[r][q] = 0.f;
+
+    load_step(0);
+    store_step(0);
+    __syncthreads();
+
+    for (int i = 0; i < NSTEP; ++i) {
+        if (i + 1 < NSTEP) load_step(i + 1);
+        const int slot = 2 * i + par;
+        const float dval = slot < NSLOT ? p.dtab[slot * 64 + lane] : 0.f;
+        const float* st = smem + (i & 1) * STAGE_F;
+        f32x16 ca, cb;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { ca[q] = 0.f; cb[q] = 0.f; }
+#pragma unroll
+        for (int k = 0; k < 64; k += 2) {
+            const float a1 = __uint_as_float(__float_as_uint(st[a_off1 + k]) ^ negm);
+            const float b1 = st[b_off1 + k];
+            const float a2 = st[a_off2 + k];
+            const float b2 = st[b_off2 + k];
+            ca = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, ca, 0, 0, 0);
+            cb = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2, cb, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[r] + cb[r], dval, acc2[r], 0, 0, 0);
+        if (i + 1 < NSTEP) store_step((i + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue, two rounds of 8 surfaces per team: E and O tiles -> LDS [pair][shift], then 2 pairs per lane
+    float* xe = smem + team * (2 * XCH);       // this team's E region, O region behind it
+    float* mine = xe + par * XCH;
+    const int tl = par * 64 + lane;            // lane of the team (0..127)
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) {
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int o = (q & 3) + 8 * (q >> 2) + 4 * hk;
+                mine[(rr * 32 + o) * 33 + l31] = acc2[8 * rd + rr][q];
+            }
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int rl = tl & 7, o = (tl >> 3) + 16 * h;
+            const float* e = xe + (rl * 32 + o) * 33;
+            const float* od = e + XCH;
+            float vlo = -INFINITY, vhi = -INFINITY;
+            int ilo = 0, ihi = 32;
+#pragma unroll 8
+            for (int sft = 0; sft < 32; ++sft) {
+                const float ev = e[sft], ov = od[sft];
+                const float lo = ev + ov, hi = ev - ov;
+                if (lo > vlo) { vlo = lo; ilo = sft; }
+                if (hi > vhi) { vhi = hi; ihi = 32 + sft; }
+            }
+            const float v = vhi > vlo ? vhi : vlo;
+            const int idx = vhi > vlo ? ihi : ilo;
+            const int s = s0 + team * 16 + 8 * rd + rl, og = o0 + o;
+            if (s < p.Bs && og < p.Bo) {
+                const size_t off = (size_t)og * p.Bs + s;
+                if (p.orientation) p.orientation[off] = idx;
+                if (p.score) p.score[off] = v;
+                if (p.distance) p.distance[off] = 2.f * (1.f - v / (p.wn[(size_t)og * 64 + idx] * p.sn[s]));
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// spec[e][t][0..63] = Re X_t(line), [64..127] = Im X_t(line) (0 for t = 0, 32), X_t = sum_k x[line][k] e^{-2 pi i t k / 64}; fp64
+// accumulation, rounded once to fp32. One workgroup per embedding [64 lines][W columns], W <= 64.
+__global__ __launch_bounds__(256) void match_spectrum_kernel(const float* __restrict__ emb, float* __restrict__ spec, int W) {
+    __shared__ float xs[64 * 65];
+    __shared__ double cs[64], sn[64];
+    const int tid = threadIdx.x, line = tid & 63, tq = tid >> 6;
+    const float* x = emb + (size_t)blockIdx.x * 64 * W;
+    for (int i = tid; i < 64 * W; i += 256) xs[(i / W) * 65 + (i % W)] = x[i];
+    if (tid < 64) {
+        cs[tid] = cospi((double)tid / 32.0);
+        sn[tid] = sinpi((double)tid / 32.0);
+    }
+    __syncthreads();
+    float* out = spec + (size_t)blockIdx.x * SPEC;
+    for (int t = tq; t < NSLOT; t += 4) {
+        double pr = 0.0, pi = 0.0;
+        for (int k = 0; k < W; ++k) {
+            const int idx = (t * k) & 63;
+            const double xv = (double)xs[line * 65 + k];
+            pr += xv * cs[idx];
+            pi -= xv * sn[idx];
+        }
+        out[t * 128 + line] = (float)pr;
+        out[t * 128 + 64 + line] = (t == 0 || t == 32) ? 0.f : (float)pi;
+    }
+}
+
+// dtab[t][hk*32 + shift]: coefficient of Re C_t (hk = 0) / Im C_t (hk = 1) in score[shift], shift < 32
+__global__ void match_dft_table_kernel(float* __restrict__ dtab) {
+    const int t = blockIdx.x, lane = threadIdx.x, shift = lane & 31, hk = lane >> 5;
+    double v;
+    if (t == 0) v = hk ? 0.0 : 1.0 / 64.0;
+    else if (t == 32) v = hk ? 0.0 : ((shift & 1) ? -1.0 : 1.0) / 64.0;
+    else {
+        const double ang = (double)((t * shift) & 63) / 32.0;
+        v = hk ? -sinpi(ang) / 32.0 : cospi(ang) / 32.0;
+    }
+    dtab[t * 64 + lane] = (float)v;
+}
+
+// the two norm kernels of match.hip's launch, restated here (file-local there)
+__global__ __launch_bounds__(256) void dft_window_norm_kernel(const float* __restrict__ ov, float* __restrict__ wn, int We) {
+    __shared__ float part[4][64];
+    __shared__ float col[64];
+    const int o = blockIdx.x, t = threadIdx.x, w = t & 63, g = t >> 6;
+    const float* base = ov + (size_t)o * 4096;
+    float s = 0.f;
+    for (int ch = g * 16; ch < g * 16 + 16; ++ch) {
+        const float v = base[ch * 64 + w];
+        s += v * v;
+    }
+    part[g][w] = s;
+    __syncthreads();
+    if (t < 64) col[t] = (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
+    __syncthreads();
+    if (t < 64) {
+        float acc = 0.f;
+        for (int k = 0; k < We; ++k) acc += col[(t + k) & 63];
+        wn[(size_t)o * 64 + t] = sqrtf(acc);
+    }
+}
+
+__global__ __launch_bounds__(256) void dft_row_norm_kernel(const float* __restrict__ x, float* __restrict__ out, int n) {
+    __shared__ float part[4];
+    const float* base = x + (size_t)blockIdx.x * n;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float v = base[i];
+        s += v * v;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = sqrtf((part[0] + part[1]) + (part[2] + part[3]));
+}
+
+}  // namespace
+
+extern "C" {
+
+// floats of one embedding's row spectrum (33 slots x [64 re | 64 im])
+long long witw_match_spectrum_floats(long long n_embeddings) { return n_embeddings * (long long)SPEC; }
+
+// emb [B,64 lines,W] (an overhead embedding [B,16,4,64] or a surface embedding [B,16,4,We]) -> spec [B,33,128]
+int witw_match_spectrum(const float* emb, float* spec, int B, int W, void* stream) {
+    WITW_CHECK_ARG(emb && spec, "match_spectrum: null pointer");
+    WITW_CHECK_ARG(B > 0 && W >= 1 && W <= 64, "match_spectrum: bad shape B=%d W=%d", B, W);
+    hipLaunchKernelGGL(match_spectrum_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, emb, spec, W);
+    WITW_CHECK_LAUNCH("match_spectrum");
+    return WITW_OK;
+}
+
+long long witw_match_dft_workspace_floats(int Bo, int Bs) { return (long long)Bo * 64 + Bs + NSLOT * 64; }
+
+// Same outputs as witw_match_fwd (orientation / distance / score [Bo,Bs], any of them may be null) from the row spectra of the
+// two sides (witw_match_spectrum of ov with W = 64 and of su with W = We); ov / su themselves are read for the norms only.
+int witw_match_fwd_dft(const float* ov, const float* su, const float* spec_ov, const float* spec_su, int Bo, int Bs, int We,
+                       long long* orientation, float* distance, float* score, float* workspace, void* stream) {
+    WITW_CHECK_ARG(ov && su && spec_ov && spec_su && workspace, "match_fwd_dft: null pointer");
+    WITW_CHECK_ARG(Bo > 0 && Bs > 0, "match_fwd_dft: empty batch Bo=%d Bs=%d", Bo, Bs);
+    WITW_CHECK_ARG(We >= 1 && We <= 64, "match_fwd_dft: surface embedding width %d outside [1,64]", We);
+    hipStream_t st = (hipStream_t)stream;
+    float* wn = workspace;
+    float* sn = workspace + (size_t)Bo * 64;
+    float* dtab = sn + Bs;
+    hipLaunchKernelGGL(dft_window_norm_kernel, dim3(Bo), dim3(256), 0, st, ov, wn, We);
+    hipLaunchKernelGGL(dft_row_norm_kernel, dim3(Bs), dim3(256), 0, st, su, sn, 64 * We);
+    hipLaunchKernelGGL(match_dft_table_kernel, dim3(NSLOT), dim3(64), 0, st, dtab);
+    DftArgs a;
+    a.spec_ov = spec_ov; a.spec_su = spec_su; a.dtab = dtab; a.wn = wn; a.sn = sn;
+    a.orientation = orientation; a.distance = distance; a.score = score;
+    a.Bo = Bo; a.Bs = Bs; a.nbx = cdiv(Bs, 32); a.nby = cdiv(Bo, 32);
+    const long long blocks = (long long)a.nbx * a.nby;
+    WITW_CHECK_ARG(blocks <= 0x7fffffffLL, "match_fwd_dft: too many tiles");
+    hipLaunchKernelGGL(match_dft_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    WITW_CHECK_LAUNCH("match_fwd_dft");
+    return WITW_OK;
+}
+
+}  // extern "C"

@@ -693,7 +693,7 @@ def _merge_topk(v, i, k):
     return v, torch.gather(cand_i.t(), 1, pos.clamp(min=0))
 
 
-def retrieve(overhead_shard, surface_all, k=10, shard_begin=0, query_chunk=4096):
+def retrieve(overhead_shard, surface_all, k=10, shard_begin=0, query_chunk=4096, method='direct'):
     """sharded_ranks + retrieve_topk from ONE matching pass per query chunk (config C5: the pass is
     2*64*E FLOP per (gallery row, query) and dominates). -> (ranks int64 [N] on the host, distances f32 [N,k],
     gallery indices int64 [N,k] on the device), identical on every rank."""
@@ -702,9 +702,17 @@ def retrieve(overhead_shard, surface_all, k=10, shard_begin=0, query_chunk=4096)
     counts = torch.zeros((n_q,), dtype=torch.int32, device=surface_all.device)
     vals, idxs = [], []
     gallery = overhead_shard.contiguous()
+    if method not in ('direct', 'dft'):
+        raise ValueError("retrieve: method must be 'direct' or 'dft'")
+    # 'dft': the orientation search through the row spectra (ops.match_fwd_dft, 21k instead of 524k FLOP per pair); the
+    # gallery's spectra are computed once. Scores agree with the direct sum to fp32 rounding.
+    spec_g = ops.match_spectrum(gallery) if method == 'dft' else None
     for q0 in range(0, n_q, query_chunk):
         q1 = min(n_q, q0 + query_chunk)
-        _, dist = ops.match_fwd(gallery, surface_all[q0:q1].contiguous())            # [n_g, q]
+        if method == 'dft':
+            _, dist = ops.match_fwd_dft(gallery, surface_all[q0:q1].contiguous(), spec_ov=spec_g)
+        else:
+            _, dist = ops.match_fwd(gallery, surface_all[q0:q1].contiguous())            # [n_g, q]
         qi = torch.arange(q0, q1, device=dist.device)
         own = (qi >= shard_begin) & (qi < shard_begin + n_g)
         row = (qi - shard_begin).clamp(0, n_g - 1)
