@@ -23,13 +23,32 @@ namespace {
 constexpr int NSLOT = 33;              // frequency slots 0..32 ([P(64 lines) | Q(64 lines)] each; Q = 0 for slots 0 and 32)
 constexpr int SPEC = NSLOT * 128;      // floats per embedding spectrum
 constexpr int NSTEP = 17;              // step i: even waves slot 2i, odd waves slot 2i+1 (slot 33 reads zeros)
-constexpr int RSA = 132, QOFF = 66;    // surface rows in LDS: P at 0, Q at 66 (bank = 4*surface + 2*part + k: conflict-free)
-constexpr int RSB = 130;               // overhead rows in LDS: P at 0, Q at 64 (bank = 2*overhead + k)
+constexpr int RSA = 132, QOFF = 66;    // surface rows in LDS: P at 0, Q at 66 (ds_read_b64 banks 4*surface + 2*part + {0,1} of 64)
+constexpr int RSB = 130;               // overhead rows in LDS: P at 0, Q at 64 (banks 2*overhead + {0,1})
 constexpr int A_F = 2 * 32 * RSA;      // [parity][32 surfaces]
 constexpr int B_F = 2 * 32 * RSB;      // [parity][32 overheads]
 constexpr int STAGE_F = A_F + B_F;     // 16768 floats
 constexpr int XCH = 256 * 33;          // exchange region: 256 pairs x 32 shifts, row stride 33
 constexpr int LDS_F = (2 * STAGE_F > 4 * XCH) ? 2 * STAGE_F : 4 * XCH;
+
+__device__ __forceinline__ unsigned lds_address(const void* p) {
+    return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)p;
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// One ds_read_b64 (the compiler would fuse neighbouring ones into ds_read2_b64, which is banked like ds_read_b32: 2-way on
+// these rows). The results are ordered by lds_wait<N>() below, which also names them so that no MFMA moves above the wait.
+template <int OFF>
+__device__ __forceinline__ f32x2 lds_read64(unsigned addr) {
+    f32x2 v;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+template <int N>
+__device__ __forceinline__ void lds_wait(f32x2& a, f32x2& b, f32x2& c, f32x2& d) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
+}
 
 struct DftArgs {
     const float* spec_ov;    // [Bo][33][128]
@@ -62,54 +81,47 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     const int s0 = bx * 32, o0 = by * 32;
 
-    // ---- staging roles: 128 rows (64 surface rows [parity][32], 64 overhead rows) x 32 float4 per step
+    // ---- staging roles: 128 rows (64 surface rows [parity][32], 64 overhead rows) x 32 float4 per step. Rows past the batch
+    // re-read the last valid row (their outputs are never written), so the loads carry no predicate.
     const int l32 = tid & 31, rg = tid >> 5;
     const float* src[16];
     int dst[16];
-    bool live[16];
 #pragma unroll
     for (int it = 0; it < 16; ++it) {
         const int row = rg + 8 * it;
         const int rp = (row >> 5) & 1, rl = row & 31;
         if (row < 64) {
-            live[it] = s0 + rl < p.Bs;
-            src[it] = p.spec_su + ((size_t)(live[it] ? s0 + rl : 0) * NSLOT + rp) * 128 + 4 * l32;
+            src[it] = p.spec_su + (size_t)min(s0 + rl, p.Bs - 1) * SPEC + 4 * l32;
             dst[it] = (rp * 32 + rl) * RSA + (l32 < 16 ? 4 * l32 : QOFF + 4 * (l32 - 16));
         } else {
-            live[it] = o0 + rl < p.Bo;
-            src[it] = p.spec_ov + ((size_t)(live[it] ? o0 + rl : 0) * NSLOT + rp) * 128 + 4 * l32;
+            src[it] = p.spec_ov + (size_t)min(o0 + rl, p.Bo - 1) * SPEC + 4 * l32;
             dst[it] = A_F + (rp * 32 + rl) * RSB + 4 * l32;
         }
     }
     f32x4 pre[16];
-    auto load_step = [&](int i) {
-#pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            const int rp = ((rg + 8 * it) >> 5) & 1;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (live[it] && 2 * i + rp < NSLOT) v = *reinterpret_cast<const f32x4*>(src[it] + (size_t)i * 256);
-            pre[it] = v;
-        }
+    // slot of (step, parity), clamped: the odd waves' 17th slot does not exist (its inverse-transform coefficient is 0)
+    auto load_one = [&](int it, int step) {
+        const int rp = ((rg + 8 * it) >> 5) & 1;
+        pre[it] = *reinterpret_cast<const f32x4*>(src[it] + min(2 * step + rp, NSLOT - 1) * 128);
     };
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    auto store_step = [&](int buf) {
-        float* st = smem + buf * STAGE_F;
-#pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            f32x2 lo = {pre[it][0], pre[it][1]}, hi = {pre[it][2], pre[it][3]};
-            *reinterpret_cast<f32x2*>(st + dst[it]) = lo;
-            *reinterpret_cast<f32x2*>(st + dst[it] + 2) = hi;
-        }
+    auto store_one = [&](int it, float* st) {
+        f32x2 lo = {pre[it][0], pre[it][1]}, hi = {pre[it][2], pre[it][3]};
+        *reinterpret_cast<f32x2*>(st + dst[it]) = lo;
+        *reinterpret_cast<f32x2*>(st + dst[it] + 2) = hi;
     };
 
     // ---- operand roles. GEMM-1 row l31 = surface j, part (0: Re C, 1: Im C); row order j&3 + 4*part + 8*(j>>2)
     const int j = (l31 & 3) + 4 * (l31 >> 3), part = (l31 >> 2) & 1;
     //   K < 64 (lines x re of the overhead):  Re row reads P, Im row reads -Q;  K >= 64 (x im): Re row reads Q, Im row reads P
-    const int a_off1 = (par * 32 + team * 16 + j) * RSA + (part ? QOFF : 0) + hk;
-    const int a_off2 = (par * 32 + team * 16 + j) * RSA + (part ? 0 : QOFF) + hk;
+    const int a_off1 = (par * 32 + team * 16 + j) * RSA + (part ? QOFF : 0) + 2 * hk;
+    const int a_off2 = (par * 32 + team * 16 + j) * RSA + (part ? 0 : QOFF) + 2 * hk;
     const unsigned negm = part ? 0x80000000u : 0u;
-    const int b_off1 = A_F + (par * 32 + l31) * RSB + hk;
+    const int b_off1 = A_F + (par * 32 + l31) * RSB + 2 * hk;
     const int b_off2 = b_off1 + 64;
+    auto dcoef = [&](int step) {
+        const int slot = 2 * step + par;
+        return slot < NSLOT ? p.dtab[slot * 64 + lane] : 0.f;
+    };
 
     f32x16 acc2[16];
 #pragma unroll
@@ -117,30 +129,66 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc2[r][q] = 0.f;
 
-    load_step(0);
-    store_step(0);
+#pragma unroll
+    for (int it = 0; it < 16; ++it) load_one(it, 0);
+#pragma unroll
+    for (int it = 0; it < 16; ++it) store_one(it, smem);
+    float dval = dcoef(0);
     __syncthreads();
 
+    // step i: 64 GEMM-1 MFMAs, the 16 global loads of step i+1's rows spread one per two MFMAs of the first half (issued in a burst
+    // they hold the wave's issue port for ~1000 cycles); then the 16 GEMM-2 MFMAs with one LDS write of those rows behind each
     for (int i = 0; i < NSTEP; ++i) {
-        if (i + 1 < NSTEP) load_step(i + 1);
-        const int slot = 2 * i + par;
-        const float dval = slot < NSLOT ? p.dtab[slot * 64 + lane] : 0.f;
         const float* st = smem + (i & 1) * STAGE_F;
+        float* stn = smem + ((i + 1) & 1) * STAGE_F;
+        const int inext = min(i + 1, NSTEP - 1);
+        const float dnext = dcoef(inext);
         f32x16 ca, cb;
 #pragma unroll
         for (int q = 0; q < 16; ++q) { ca[q] = 0.f; cb[q] = 0.f; }
-#pragma unroll
-        for (int k = 0; k < 64; k += 2) {
-            const float a1 = __uint_as_float(__float_as_uint(st[a_off1 + k]) ^ negm);
-            const float b1 = st[b_off1 + k];
-            const float a2 = st[a_off2 + k];
-            const float b2 = st[b_off2 + k];
-            ca = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, ca, 0, 0, 0);
-            cb = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2, cb, 0, 0, 0);
+        // operands as ds_read_b64 (256 B/clk, 64 banks: conflict-free with these row strides; ds_read_b32 has 32 banks and
+        // would be 2-way): a lane holds k = 4u + 2hk and 4u + 2hk + 1 of its row, i.e. MFMA step 2u + e covers k = 4u + e
+        // (lanes 0-31) and 4u + 2 + e (lanes 32-63) -- the same K permutation on both operands. Reads run two groups ahead.
+        const unsigned sb = lds_address(st);
+        const unsigned xa1 = sb + 4u * a_off1, xb1 = sb + 4u * b_off1, xa2 = sb + 4u * a_off2, xb2 = sb + 4u * b_off2;
+        f32x2 qa1[3], qb1[3], qa2[3], qb2[3];
+#define WITW_DFT_FETCH(U)                                  \
+        {                                                  \
+            qa1[(U) % 3] = lds_read64<16 * (U)>(xa1);      \
+            qb1[(U) % 3] = lds_read64<16 * (U)>(xb1);      \
+            qa2[(U) % 3] = lds_read64<16 * (U)>(xa2);      \
+            qb2[(U) % 3] = lds_read64<16 * (U)>(xb2);      \
         }
+#define WITW_DFT_GROUP(U)                                                                                                      \
+        {                                                                                                                      \
+            constexpr int d = (U) % 3;                                                                                         \
+            if ((U) + 2 < 16) WITW_DFT_FETCH(((U) + 2) % 16)                                                                   \
+            if ((U) + 2 < 16) lds_wait<8>(qa1[d], qb1[d], qa2[d], qb2[d]);                                                     \
+            else if ((U) + 1 < 16) lds_wait<4>(qa1[d], qb1[d], qa2[d], qb2[d]);                                                \
+            else lds_wait<0>(qa1[d], qb1[d], qa2[d], qb2[d]);                                                                  \
+            ca = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(__float_as_uint(qa1[d][0]) ^ negm), qb1[d][0], ca, 0, 0, 0); \
+            if ((U) < 8) load_one(2 * ((U) % 8), inext);                                                                       \
+            cb = __builtin_amdgcn_mfma_f32_32x32x2f32(qa2[d][0], qb2[d][0], cb, 0, 0, 0);                                      \
+            ca = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(__float_as_uint(qa1[d][1]) ^ negm), qb1[d][1], ca, 0, 0, 0); \
+            if ((U) < 8) load_one(2 * ((U) % 8) + 1, inext);                                                                   \
+            cb = __builtin_amdgcn_mfma_f32_32x32x2f32(qa2[d][1], qb2[d][1], cb, 0, 0, 0);                                      \
+        }
+        WITW_DFT_FETCH(0)
+        WITW_DFT_FETCH(1)
+        WITW_DFT_GROUP(0) WITW_DFT_GROUP(1) WITW_DFT_GROUP(2) WITW_DFT_GROUP(3)
+        WITW_DFT_GROUP(4) WITW_DFT_GROUP(5) WITW_DFT_GROUP(6) WITW_DFT_GROUP(7)
+        WITW_DFT_GROUP(8) WITW_DFT_GROUP(9) WITW_DFT_GROUP(10) WITW_DFT_GROUP(11)
+        WITW_DFT_GROUP(12) WITW_DFT_GROUP(13) WITW_DFT_GROUP(14) WITW_DFT_GROUP(15)
+#undef WITW_DFT_GROUP
+#undef WITW_DFT_FETCH
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc2[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[r] + cb[r], dval, acc2[r], 0, 0, 0);
-        if (i + 1 < NSTEP) store_step((i + 1) & 1);
+        for (int r = 0; r < 16; ++r) {
+            acc2[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[r] + cb[r], dval, acc2[r], 0, 0, 0);
+            store_one(r, stn);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+        dval = dnext;
         __syncthreads();
     }
 
