@@ -36,6 +36,25 @@ __device__ __forceinline__ unsigned lds_address(const void* p) {
 }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ i32x4 raw_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)base;
+    i32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    r[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)((a >> 32) & 0xffffu));
+    r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+    r[3] = 0x00020000;
+    return r;
+}
+
+// global -> LDS, 4 B per lane, 256 contiguous LDS bytes per wave instruction at lds_addr (M0); out-of-range lanes write 0
+__device__ __forceinline__ void dma4(i32x4 rs, unsigned lds_addr, unsigned voff, unsigned soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
+                 :
+                 : "s"(lds_addr), "v"(voff), "s"(rs), "s"(soff)
+                 : "memory");
+}
 
 // One ds_read_b64 (the compiler would fuse neighbouring ones into ds_read2_b64, which is banked like ds_read_b32: 2-way on
 // these rows). The results are ordered by lds_wait<N>() below, which also names them so that no MFMA moves above the wait.
@@ -60,10 +79,14 @@ struct DftArgs {
     float* distance;         // [Bo,Bs] or null
     float* score;            // [Bo,Bs] or null
     int Bo, Bs, nbx, nby;
+    unsigned long long* stamps;      // null, or 64 slots per 4096th workgroup (WITW_DFT_STAMPS=1: in-kernel timeline)
 };
 
+// REC: the diagnostic instantiation that records the in-kernel timeline (costs registers: the product launch uses REC = false)
+template <bool REC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void match_dft_kernel(DftArgs p) {
     __shared__ float smem[LDS_F];
+    __shared__ float dt_s[(NSLOT + 1) * 64];      // inverse-transform coefficients; the extra slot (odd waves' 17th) is 0
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hk = lane >> 5;
     const int team = wave >> 1, par = wave & 1;
@@ -80,34 +103,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (bx >= p.nbx) return;        // never: within < rows * nbx for a full group; guards the ragged last group
     }
     const int s0 = bx * 32, o0 = by * 32;
+    const bool rec = REC && p.stamps && (blockIdx.x & 4095) == 2048 && tid == 0;
+    auto stamp = [&](int k) { if (rec) p.stamps[(blockIdx.x >> 12) * 64 + k] = __builtin_amdgcn_s_memrealtime(); };
+    stamp(0);
 
-    // ---- staging roles: 128 rows (64 surface rows [parity][32], 64 overhead rows) x 32 float4 per step. Rows past the batch
-    // re-read the last valid row (their outputs are never written), so the loads carry no predicate.
-    const int l32 = tid & 31, rg = tid >> 5;
-    const float* src[16];
-    int dst[16];
-#pragma unroll
-    for (int it = 0; it < 16; ++it) {
-        const int row = rg + 8 * it;
-        const int rp = (row >> 5) & 1, rl = row & 31;
-        if (row < 64) {
-            src[it] = p.spec_su + (size_t)min(s0 + rl, p.Bs - 1) * SPEC + 4 * l32;
-            dst[it] = (rp * 32 + rl) * RSA + (l32 < 16 ? 4 * l32 : QOFF + 4 * (l32 - 16));
-        } else {
-            src[it] = p.spec_ov + (size_t)min(o0 + rl, p.Bo - 1) * SPEC + 4 * l32;
-            dst[it] = A_F + (rp * 32 + rl) * RSB + 4 * l32;
-        }
-    }
-    f32x4 pre[16];
-    // slot of (step, parity), clamped: the odd waves' 17th slot does not exist (its inverse-transform coefficient is 0)
-    auto load_one = [&](int it, int step) {
-        const int rp = ((rg + 8 * it) >> 5) & 1;
-        pre[it] = *reinterpret_cast<const f32x4*>(src[it] + min(2 * step + rp, NSLOT - 1) * 128);
-    };
-    auto store_one = [&](int it, float* st) {
-        f32x2 lo = {pre[it][0], pre[it][1]}, hi = {pre[it][2], pre[it][3]};
-        *reinterpret_cast<f32x2*>(st + dst[it]) = lo;
-        *reinterpret_cast<f32x2*>(st + dst[it] + 2) = hi;
+    // ---- staging: LDS-DMA (buffer_load_dword ... lds: 64 lanes x 4 B = one 64-float P or Q segment of a row, written at an
+    // arbitrary LDS address, so the padded rows need no register transit and no ds_write). Wave w owns rows of one kind:
+    // w&1 = slot parity, w>>1 = 0 surfaces / 1 overheads; 32 rows x 2 segments per step. Rows past the batch and the odd
+    // waves' 17th slot fall outside the descriptor or read a neighbour's finite values whose coefficient is 0.
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int srp = wv & 1, is_ov = wv >> 1;
+    const int rows_here = is_ov ? min(32, p.Bo - o0) : min(32, p.Bs - s0);
+    const i32x4 rs = raw_rsrc(is_ov ? p.spec_ov + (size_t)o0 * SPEC : p.spec_su + (size_t)s0 * SPEC, (unsigned)rows_here * SPEC * 4u);
+    const unsigned row_bytes = is_ov ? RSB * 4u : RSA * 4u;         // LDS row stride of this wave's rows
+    const unsigned q_bytes = is_ov ? 64u * 4u : QOFF * 4u;          // where Q sits in the row
+    const unsigned region = (is_ov ? A_F + srp * 32 * RSB : srp * 32 * RSA) * 4u;
+    const unsigned lds0 = lds_address(smem);
+    const unsigned voff = lane * 4u;
+    auto dma_seg = [&](int n, int step, int buf) {      // n = 2 * row + half, compile-time after unrolling
+        const unsigned slot = (unsigned)(2 * step + srp);
+        const unsigned soff = (unsigned)(n >> 1) * (SPEC * 4u) + (unsigned)(n & 1) * 256u + slot * 512u;
+        const unsigned lds = lds0 + (unsigned)buf * (STAGE_F * 4u) + region + (unsigned)(n >> 1) * row_bytes + ((n & 1) ? q_bytes : 0u);
+        dma4(rs, lds, voff, soff);
     };
 
     // ---- operand roles. GEMM-1 row l31 = surface j, part (0: Re C, 1: Im C); row order j&3 + 4*part + 8*(j>>2)
@@ -118,10 +135,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const unsigned negm = part ? 0x80000000u : 0u;
     const int b_off1 = A_F + (par * 32 + l31) * RSB + 2 * hk;
     const int b_off2 = b_off1 + 64;
-    auto dcoef = [&](int step) {
-        const int slot = 2 * step + par;
-        return slot < NSLOT ? p.dtab[slot * 64 + lane] : 0.f;
-    };
+    for (int t = tid; t < (NSLOT + 1) * 64; t += 256) dt_s[t] = t < NSLOT * 64 ? p.dtab[t] : 0.f;
+    // a global load here would sit at the end of every step with its whole latency exposed (measured: ~4.6k cycles per step)
+    auto dcoef = [&](int step) { return dt_s[(2 * step + par) * 64 + lane]; };
 
     f32x16 acc2[16];
 #pragma unroll
@@ -130,19 +146,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int q = 0; q < 16; ++q) acc2[r][q] = 0.f;
 
 #pragma unroll
-    for (int it = 0; it < 16; ++it) load_one(it, 0);
-#pragma unroll
-    for (int it = 0; it < 16; ++it) store_one(it, smem);
-    float dval = dcoef(0);
+    for (int n = 0; n < 64; ++n) dma_seg(n, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    float dval = dcoef(0);
+    stamp(1);
 
-    // step i: 64 GEMM-1 MFMAs, the 16 global loads of step i+1's rows spread one per two MFMAs of the first half (issued in a burst
-    // they hold the wave's issue port for ~1000 cycles); then the 16 GEMM-2 MFMAs with one LDS write of those rows behind each
+    // step i: 64 GEMM-1 MFMAs with the 64 DMA segments of step i+1's rows issued four per MFMA group into the other stage
+    // (free since the barrier that ended step i-1), then the 16 GEMM-2 MFMAs; the DMAs land before the step's barrier
     for (int i = 0; i < NSTEP; ++i) {
         const float* st = smem + (i & 1) * STAGE_F;
-        float* stn = smem + ((i + 1) & 1) * STAGE_F;
+        const int bufn = (i + 1) & 1;
         const int inext = min(i + 1, NSTEP - 1);
-        const float dnext = dcoef(inext);
         f32x16 ca, cb;
 #pragma unroll
         for (int q = 0; q < 16; ++q) { ca[q] = 0.f; cb[q] = 0.f; }
@@ -167,10 +182,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             else if ((U) + 1 < 16) lds_wait<4>(qa1[d], qb1[d], qa2[d], qb2[d]);                                                \
             else lds_wait<0>(qa1[d], qb1[d], qa2[d], qb2[d]);                                                                  \
             ca = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(__float_as_uint(qa1[d][0]) ^ negm), qb1[d][0], ca, 0, 0, 0); \
-            if ((U) < 8) load_one(2 * ((U) % 8), inext);                                                                       \
+            dma_seg(4 * (U), inext, bufn); dma_seg(4 * (U) + 1, inext, bufn);                                                  \
             cb = __builtin_amdgcn_mfma_f32_32x32x2f32(qa2[d][0], qb2[d][0], cb, 0, 0, 0);                                      \
             ca = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(__float_as_uint(qa1[d][1]) ^ negm), qb1[d][1], ca, 0, 0, 0); \
-            if ((U) < 8) load_one(2 * ((U) % 8) + 1, inext);                                                                   \
+            dma_seg(4 * (U) + 2, inext, bufn); dma_seg(4 * (U) + 3, inext, bufn);                                              \
             cb = __builtin_amdgcn_mfma_f32_32x32x2f32(qa2[d][1], qb2[d][1], cb, 0, 0, 0);                                      \
         }
         WITW_DFT_FETCH(0)
@@ -181,15 +196,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         WITW_DFT_GROUP(12) WITW_DFT_GROUP(13) WITW_DFT_GROUP(14) WITW_DFT_GROUP(15)
 #undef WITW_DFT_GROUP
 #undef WITW_DFT_FETCH
+        stamp(2 + 3 * i);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            acc2[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[r] + cb[r], dval, acc2[r], 0, 0, 0);
-            store_one(r, stn);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-        }
-        dval = dnext;
+        for (int r = 0; r < 16; ++r) acc2[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[r] + cb[r], dval, acc2[r], 0, 0, 0);
+        dval = dcoef(inext);
+        stamp(3 + 3 * i);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        stamp(4 + 3 * i);
     }
 
     // ---- epilogue, two rounds of 8 surfaces per team: E and O tiles -> LDS [pair][shift], then 2 pairs per lane
@@ -203,13 +217,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int o = (q & 3) + 8 * (q >> 2) + 4 * hk;
-                mine[(rr * 32 + o) * 33 + l31] = acc2[8 * rd + rr][q];
+                mine[(o * 8 + rr) * 33 + l31] = acc2[8 * rd + rr][q];
             }
         __syncthreads();
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int rl = tl & 7, o = (tl >> 3) + 16 * h;
-            const float* e = xe + (rl * 32 + o) * 33;
+            const float* e = xe + (o * 8 + rl) * 33;       // pair index = team lane (+128): row stride 33 -> conflict-free
             const float* od = e + XCH;
             float vlo = -INFINITY, vhi = -INFINITY;
             int ilo = 0, ihi = 32;
@@ -232,6 +246,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
         __syncthreads();
     }
+    stamp(53);
 }
 
 // spec[e][t][0..63] = Re X_t(line), [64..127] = Im X_t(line) (0 for t = 0, 32), X_t = sum_k x[line][k] e^{-2 pi i t k / 64}; fp64
@@ -349,7 +364,30 @@ int witw_match_fwd_dft(const float* ov, const float* su, const float* spec_ov, c
     a.Bo = Bo; a.Bs = Bs; a.nbx = cdiv(Bs, 32); a.nby = cdiv(Bo, 32);
     const long long blocks = (long long)a.nbx * a.nby;
     WITW_CHECK_ARG(blocks <= 0x7fffffffLL, "match_fwd_dft: too many tiles");
-    hipLaunchKernelGGL(match_dft_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    // WITW_DFT_STAMPS=1 (diagnostic, synchronous): every 4096th workgroup records s_memrealtime around its phases; printed to stderr
+    a.stamps = nullptr;
+    const int nrec = (int)(blocks >> 12);
+    if (getenv("WITW_DFT_STAMPS") != nullptr && nrec > 0) {
+        if (hipMalloc((void**)&a.stamps, (size_t)nrec * 64 * 8) != hipSuccess) a.stamps = nullptr;
+        else (void)hipMemset(a.stamps, 0, (size_t)nrec * 64 * 8);
+    }
+    if (a.stamps) hipLaunchKernelGGL(match_dft_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(match_dft_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    if (a.stamps) {
+        (void)hipDeviceSynchronize();
+        unsigned long long* h = (unsigned long long*)malloc((size_t)nrec * 64 * 8);
+        (void)hipMemcpy(h, a.stamps, (size_t)nrec * 64 * 8, hipMemcpyDeviceToHost);
+        for (int b = 0; b < nrec && b < 4; ++b) {
+            const unsigned long long* t = h + (size_t)b * 64;
+            fprintf(stderr, "match_dft workgroup %d: prologue %.2f us; steps (gemm1, gemm2, barrier) us:", b * 4096 + 2048, (t[1] - t[0]) * 0.01);
+            for (int i = 0; i < 17; ++i)
+                fprintf(stderr, " [%.2f %.2f %.2f]", (t[2 + 3 * i] - (i ? t[1 + 3 * i] : t[1])) * 0.01, (t[3 + 3 * i] - t[2 + 3 * i]) * 0.01,
+                        (t[4 + 3 * i] - t[3 + 3 * i]) * 0.01);
+            fprintf(stderr, "; epilogue %.2f us; total %.2f us\n", (t[53] - t[52]) * 0.01, (t[53] - t[0]) * 0.01);
+        }
+        free(h);
+        (void)hipFree(a.stamps);
+    }
     WITW_CHECK_LAUNCH("match_fwd_dft");
     return WITW_OK;
 }
