@@ -654,7 +654,7 @@ def sharded_ranks(overhead_shard, surface_all, shard_begin, query_chunk=4096, _m
     return out.cpu().numpy().astype('int64')
 
 
-def retrieve_topk(overhead_shard, surface_all, k=10, shard_begin=0, query_chunk=4096):
+def retrieve_topk(overhead_shard, surface_all, k=10, shard_begin=0, query_chunk=4096, method='direct'):
     """Top-k retrieval (BASELINE config C5): for every query the k nearest gallery rows by the fused
     orientation-search chord distance, ordered by (distance, gallery index). With the gallery sharded over
     ranks each rank ranks its shard, the [N,k] candidate lists are all-gathered and merged by the same kernel.
@@ -662,9 +662,16 @@ def retrieve_topk(overhead_shard, surface_all, k=10, shard_begin=0, query_chunk=
     from . import parallel
     n_q = surface_all.shape[0]
     vals, idxs = [], []
+    if method not in ('direct', 'dft'):
+        raise ValueError("retrieve_topk: method must be 'direct' or 'dft'")
+    gallery = overhead_shard.contiguous()
+    spec_g = ops.match_spectrum(gallery) if method == 'dft' else None       # see retrieve()
     for q0 in range(0, n_q, query_chunk):
         q1 = min(n_q, q0 + query_chunk)
-        _, dist = ops.match_fwd(overhead_shard.contiguous(), surface_all[q0:q1].contiguous())
+        if method == 'dft':
+            _, dist = ops.match_fwd_dft(gallery, surface_all[q0:q1].contiguous(), spec_ov=spec_g)
+        else:
+            _, dist = ops.match_fwd(gallery, surface_all[q0:q1].contiguous())
         v, i = ops.topk_smallest(dist, k, shard_begin)
         vals.append(v)
         idxs.append(i)
