@@ -129,10 +129,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     // ---- operand roles. GEMM-1 row l31 = surface j, part (0: Re C, 1: Im C); row order j&3 + 4*part + 8*(j>>2)
     const int j = (l31 & 3) + 4 * (l31 >> 3), part = (l31 >> 2) & 1;
-    //   K < 64 (lines x re of the overhead):  Re row reads P, Im row reads -Q;  K >= 64 (x im): Re row reads Q, Im row reads P
+    //   K < 64 (lines x re of the overhead):  Re row reads P, Im row reads Q (sign below);  K >= 64 (x im): Re row reads Q, Im row reads P
     const int a_off1 = (par * 32 + team * 16 + j) * RSA + (part ? QOFF : 0) + 2 * hk;
     const int a_off2 = (par * 32 + team * 16 + j) * RSA + (part ? 0 : QOFF) + 2 * hk;
-    const unsigned negm = part ? 0x80000000u : 0u;
+    // the Im rows' minus sign (K < 64: -Q) is applied once per step: ca collects K < 64, cb K >= 64, and accumulator register r
+    // holds Re C in lanes 0-31 and Im C in lanes 32-63, so C = cb + sg * ca with sg = -1 in the upper half-wave
+    const float sg = hk ? -1.f : 1.f;
     const int b_off1 = A_F + (par * 32 + l31) * RSB + 2 * hk;
     const int b_off2 = b_off1 + 64;
     for (int t = tid; t < (NSLOT + 1) * 64; t += 256) dt_s[t] = t < NSLOT * 64 ? p.dtab[t] : 0.f;
@@ -181,10 +183,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if ((U) + 2 < 16) lds_wait<8>(qa1[d], qb1[d], qa2[d], qb2[d]);                                                     \
             else if ((U) + 1 < 16) lds_wait<4>(qa1[d], qb1[d], qa2[d], qb2[d]);                                                \
             else lds_wait<0>(qa1[d], qb1[d], qa2[d], qb2[d]);                                                                  \
-            ca = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(__float_as_uint(qa1[d][0]) ^ negm), qb1[d][0], ca, 0, 0, 0); \
+            ca = __builtin_amdgcn_mfma_f32_32x32x2f32(qa1[d][0], qb1[d][0], ca, 0, 0, 0);                                      \
             dma_seg(4 * (U), inext, bufn); dma_seg(4 * (U) + 1, inext, bufn);                                                  \
             cb = __builtin_amdgcn_mfma_f32_32x32x2f32(qa2[d][0], qb2[d][0], cb, 0, 0, 0);                                      \
-            ca = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(__float_as_uint(qa1[d][1]) ^ negm), qb1[d][1], ca, 0, 0, 0); \
+            ca = __builtin_amdgcn_mfma_f32_32x32x2f32(qa1[d][1], qb1[d][1], ca, 0, 0, 0);                                      \
             dma_seg(4 * (U) + 2, inext, bufn); dma_seg(4 * (U) + 3, inext, bufn);                                              \
             cb = __builtin_amdgcn_mfma_f32_32x32x2f32(qa2[d][1], qb2[d][1], cb, 0, 0, 0);                                      \
         }
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #undef WITW_DFT_FETCH
         stamp(2 + 3 * i);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc2[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[r] + cb[r], dval, acc2[r], 0, 0, 0);
+        for (int r = 0; r < 16; ++r) acc2[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(fmaf(ca[r], sg, cb[r]), dval, acc2[r], 0, 0, 0);
         dval = dcoef(inext);
         stamp(3 + 3 * i);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
