@@ -126,6 +126,11 @@ int witw_rank_count(const float* distance /*[Bo,Bs]*/, int* ranks /*[Bs]*/, int 
  * indices [Bs][k] (+row_offset: global row number of this shard's first row; -1 pads when Bo < k). 1 <= k <= 32. */
 int witw_topk_smallest(const float* distance, float* values, long long* indices, int Bo, int Bs, int k, long long row_offset,
                        void* stream);
+/* the same with the gallery rows split over workgroups (one workgroup column per 64 queries cannot fill the chip when the
+ * gallery is long): workspace = witw_topk_workspace_bytes(Bo,Bs,k) bytes (NULL or 0 bytes: single pass). Same result. */
+long long witw_topk_workspace_bytes(int Bo, int Bs, int k);
+int witw_topk_smallest_ws(const float* distance, float* values, long long* indices, int Bo, int Bs, int k, long long row_offset,
+                          void* workspace, void* stream);
 /* sharded-gallery form: ranks[q] = #{o in this shard : D[o][q] <= threshold[q]} (threshold = true match's distance) */
 int witw_rank_count_thresh(const float* distance, const float* threshold, int* ranks, int Bo, int Bs, void* stream);
 

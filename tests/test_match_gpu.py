@@ -168,7 +168,8 @@ def test_global_batch_slab_evaluation_equals_full():
     np.testing.assert_array_equal(r1.cpu().numpy(), ranks.cpu().numpy())
 
 
-@pytest.mark.parametrize('shape', [(1000, 70, 5), (37, 300, 10), (5, 3, 8), (4096, 130, 32), (300, 64, 1)])
+@pytest.mark.parametrize('shape', [(1000, 70, 5), (37, 300, 10), (5, 3, 8), (4096, 130, 32), (300, 64, 1), (20011, 200, 10),
+                                   (513, 64, 16), (70000, 65, 3)])
 def test_topk_smallest_bit_exact(shape):
     from witw_amd import ops
     bo, bs, k = shape
@@ -181,6 +182,16 @@ def test_topk_smallest_bit_exact(shape):
     np.testing.assert_array_equal(vals.cpu().numpy()[:, :kk], np.take_along_axis(d, order[:kk], 0).T)
     if bo < k:
         assert np.all(idx.cpu().numpy()[:, bo:] == -1)
+    # the single-pass entry (no workspace) and the row-split entry agree bit for bit, with a row offset and NaNs as well
+    from witw_amd import _lib
+    lib = _lib.load()
+    d[::7, ::3] = np.nan
+    dc = torch.from_numpy(d).cuda()
+    v0 = torch.empty((bs, k), dtype=torch.float32, device='cuda')
+    i0 = torch.empty((bs, k), dtype=torch.int64, device='cuda')
+    _lib.check(lib.witw_topk_smallest(dc.data_ptr(), v0.data_ptr(), i0.data_ptr(), bo, bs, k, 1000, None), 'witw_topk_smallest')
+    v1, i1 = ops.topk_smallest(dc, k, row_offset=1000)
+    assert torch.equal(i0, i1) and torch.equal(v0, v1)
 
 
 def test_retrieve_topk_matches_oracle_and_shards():

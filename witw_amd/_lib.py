@@ -85,6 +85,8 @@ SIGNATURES = {
     'witw_l2_distance': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'witw_rank_count': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'witw_topk_smallest': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_longlong, c_void_p]),
+    'witw_topk_workspace_bytes': (c_longlong, [c_int, c_int, c_int]),
+    'witw_topk_smallest_ws': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_longlong, c_void_p, c_void_p]),
     'witw_rank_count_thresh': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     'witw_triplet_loss_fwd': (c_int, [c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     'witw_triplet_loss_slab_fwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),

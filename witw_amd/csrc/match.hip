@@ -888,13 +888,18 @@ int witw_rank_count_thresh(const float* distance, const float* threshold, int* r
 // lower index and the result is deterministic and independent of the launch shape.
 namespace {
 
+// Gallery rows can be split over blockIdx.y (pv / pi non-null): a block then ranks rows [y*rps, (y+1)*rps) and leaves its k
+// candidates per query in the workspace, merged by topk_merge_kernel -- one block per 64 queries walking 125,000 rows alone is
+// 64 workgroups of dependent loads (16 ms per 125,000 x 4,096 launch; the matrix streams from HBM in 0.5 ms).
 template <int K>
 __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ D, float* __restrict__ vals,
-                                                   long long* __restrict__ idx, int Bo, int Bs, int k, long long row_offset) {
+                                                   long long* __restrict__ idx, int Bo, int Bs, int k, long long row_offset,
+                                                   int rps, float* __restrict__ pv, int* __restrict__ pi) {
     __shared__ float sv[4][K][64];
     __shared__ int si[4][K][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = blockIdx.x * 64 + lane;
+    const int r0 = blockIdx.y * rps, r1 = min(Bo, r0 + rps);
     float bv[K];
     int bi[K];
 #pragma unroll
@@ -902,25 +907,33 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ D, 
         bv[j] = __builtin_inff();
         bi[j] = 0x7fffffff;
     }
-    if (q < Bs) {
-        for (int o = wave; o < Bo; o += 4) {
-            float d = D[(size_t)o * Bs + q];
-            if (d != d) d = __builtin_inff();          // NaN sorts last
-            if (d < bv[K - 1] || (d == bv[K - 1] && o < bi[K - 1])) {
-                float cv = d;
-                int ci = o;
+    auto offer = [&](float d, int o) {
+        if (d != d) d = __builtin_inff();          // NaN sorts last
+        if (d < bv[K - 1] || (d == bv[K - 1] && o < bi[K - 1])) {
+            float cv = d;
+            int ci = o;
 #pragma unroll
-                for (int j = 0; j < K; ++j) {          // insertion into the sorted list
-                    const bool lt = cv < bv[j] || (cv == bv[j] && ci < bi[j]);
-                    const float tv = lt ? bv[j] : cv;
-                    const int ti = lt ? bi[j] : ci;
-                    bv[j] = lt ? cv : bv[j];
-                    bi[j] = lt ? ci : bi[j];
-                    cv = tv;
-                    ci = ti;
-                }
+            for (int j = 0; j < K; ++j) {          // insertion into the sorted list
+                const bool lt = cv < bv[j] || (cv == bv[j] && ci < bi[j]);
+                const float tv = lt ? bv[j] : cv;
+                const int ti = lt ? bi[j] : ci;
+                bv[j] = lt ? cv : bv[j];
+                bi[j] = lt ? ci : bi[j];
+                cv = tv;
+                ci = ti;
             }
         }
+    };
+    if (q < Bs) {
+        int o = r0 + wave;
+        for (; o + 28 < r1; o += 32) {             // eight independent loads in flight per thread
+            float d[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) d[u] = D[(size_t)(o + 4 * u) * Bs + q];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) offer(d[u], o + 4 * u);
+        }
+        for (; o < r1; o += 4) offer(D[(size_t)o * Bs + q], o);
     }
 #pragma unroll
     for (int j = 0; j < K; ++j) {
@@ -944,27 +957,103 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ D, 
             }
 #pragma unroll
             for (int w = 0; w < 4; ++w) h[w] += (w == best) ? 1 : 0;
-            vals[(size_t)q * k + out] = v;
-            idx[(size_t)q * k + out] = (ix == 0x7fffffff) ? -1 : (long long)ix + row_offset;
+            if (pv != nullptr) {
+                pv[((size_t)blockIdx.y * k + out) * Bs + q] = v;
+                pi[((size_t)blockIdx.y * k + out) * Bs + q] = ix;
+            } else {
+                vals[(size_t)q * k + out] = v;
+                idx[(size_t)q * k + out] = (ix == 0x7fffffff) ? -1 : (long long)ix + row_offset;
+            }
         }
     }
 }
 
+// splits x k sorted candidates per query -> the k best by (distance, row); one thread per query, coalesced candidate reads
+template <int K>
+__global__ __launch_bounds__(64) void topk_merge_kernel(const float* __restrict__ pv, const int* __restrict__ pi,
+                                                       float* __restrict__ vals, long long* __restrict__ idx, int Bs, int k,
+                                                       int splits, long long row_offset) {
+    const int q = blockIdx.x * 64 + threadIdx.x;
+    if (q >= Bs) return;
+    float bv[K];
+    int bi[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        bv[j] = __builtin_inff();
+        bi[j] = 0x7fffffff;
+    }
+    for (int c = 0; c < splits * k; ++c) {
+        float cv = pv[(size_t)c * Bs + q];
+        int ci = pi[(size_t)c * Bs + q];
+        if (cv < bv[K - 1] || (cv == bv[K - 1] && ci < bi[K - 1])) {
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                const bool lt = cv < bv[j] || (cv == bv[j] && ci < bi[j]);
+                const float tv = lt ? bv[j] : cv;
+                const int ti = lt ? bi[j] : ci;
+                bv[j] = lt ? cv : bv[j];
+                bi[j] = lt ? ci : bi[j];
+                cv = tv;
+                ci = ti;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+        if (j < k) {
+            vals[(size_t)q * k + j] = bv[j];
+            idx[(size_t)q * k + j] = (bi[j] == 0x7fffffff) ? -1 : (long long)bi[j] + row_offset;
+        }
+}
+
 }  // namespace
 
-extern "C" int witw_topk_smallest(const float* distance, float* values, long long* indices, int Bo, int Bs, int k,
-                                  long long row_offset, void* stream) {
+static int topk_splits(int Bo, int Bs) {
+    // enough (query tile, split) workgroups to fill the chip several times over, at least 512 rows per split
+    int s = cdiv(2048, cdiv(Bs, 64));
+    if (s > cdiv(Bo, 512)) s = cdiv(Bo, 512);
+    return s < 1 ? 1 : s;
+}
+
+template <int K>
+static void topk_launch(const float* D, float* values, long long* indices, int Bo, int Bs, int k, long long row_offset,
+                        void* workspace, hipStream_t st) {
+    const int splits = workspace ? topk_splits(Bo, Bs) : 1;
+    if (splits <= 1) {
+        hipLaunchKernelGGL((topk_kernel<K>), dim3(cdiv(Bs, 64)), dim3(256), 0, st, D, values, indices, Bo, Bs, k, row_offset, Bo,
+                           (float*)nullptr, (int*)nullptr);
+        return;
+    }
+    float* pv = (float*)workspace;
+    int* pi = (int*)(pv + (size_t)splits * k * Bs);
+    const int rps = cdiv(Bo, splits);
+    hipLaunchKernelGGL((topk_kernel<K>), dim3(cdiv(Bs, 64), splits), dim3(256), 0, st, D, values, indices, Bo, Bs, k, row_offset,
+                       rps, pv, pi);
+    hipLaunchKernelGGL((topk_merge_kernel<K>), dim3(cdiv(Bs, 64)), dim3(64), 0, st, pv, pi, values, indices, Bs, k, splits, row_offset);
+}
+
+// bytes of workspace that let witw_topk_smallest_ws split the gallery rows over workgroups (0: a single pass is used anyway)
+extern "C" long long witw_topk_workspace_bytes(int Bo, int Bs, int k) {
+    if (Bo <= 0 || Bs <= 0 || k < 1 || k > 32) return -1;
+    const int splits = topk_splits(Bo, Bs);
+    return splits > 1 ? (long long)splits * k * Bs * 8 : 0;
+}
+
+extern "C" int witw_topk_smallest_ws(const float* distance, float* values, long long* indices, int Bo, int Bs, int k,
+                                     long long row_offset, void* workspace, void* stream) {
     WITW_CHECK_ARG(distance && values && indices, "topk_smallest: null pointer");
     WITW_CHECK_ARG(Bo > 0 && Bs > 0, "topk_smallest: bad shape Bo=%d Bs=%d", Bo, Bs);
     WITW_CHECK_ARG(k >= 1 && k <= 32, "topk_smallest: k=%d outside [1,32]", k);
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid(cdiv(Bs, 64));
-    if (k <= 8)
-        hipLaunchKernelGGL((topk_kernel<8>), grid, dim3(256), 0, st, distance, values, indices, Bo, Bs, k, row_offset);
-    else if (k <= 16)
-        hipLaunchKernelGGL((topk_kernel<16>), grid, dim3(256), 0, st, distance, values, indices, Bo, Bs, k, row_offset);
-    else
-        hipLaunchKernelGGL((topk_kernel<32>), grid, dim3(256), 0, st, distance, values, indices, Bo, Bs, k, row_offset);
+    if (k <= 8) topk_launch<8>(distance, values, indices, Bo, Bs, k, row_offset, workspace, st);
+    else if (k <= 16) topk_launch<16>(distance, values, indices, Bo, Bs, k, row_offset, workspace, st);
+    else topk_launch<32>(distance, values, indices, Bo, Bs, k, row_offset, workspace, st);
     WITW_CHECK_LAUNCH("topk_smallest");
     return WITW_OK;
 }
+
+extern "C" int witw_topk_smallest(const float* distance, float* values, long long* indices, int Bo, int Bs, int k,
+                                  long long row_offset, void* stream) {
+    return witw_topk_smallest_ws(distance, values, indices, Bo, Bs, k, row_offset, nullptr, stream);
+}
+

@@ -368,8 +368,10 @@ def topk_smallest(distance, k, row_offset=0):
     Bo, Bs = d.shape
     vals = torch.empty((Bs, k), dtype=torch.float32, device=d.device)
     idx = torch.empty((Bs, k), dtype=torch.int64, device=d.device)
-    _lib.check(lib.witw_topk_smallest(d.data_ptr(), vals.data_ptr(), idx.data_ptr(), Bo, Bs, int(k), int(row_offset),
-                                      _stream()), 'witw_topk_smallest')
+    nws = lib.witw_topk_workspace_bytes(Bo, Bs, int(k))
+    ws = torch.empty((nws,), dtype=torch.uint8, device=d.device) if nws > 0 else None      # long galleries: rows split over workgroups
+    _lib.check(lib.witw_topk_smallest_ws(d.data_ptr(), vals.data_ptr(), idx.data_ptr(), Bo, Bs, int(k), int(row_offset), _p(ws),
+                                         _stream()), 'witw_topk_smallest_ws')
     return vals, idx
 
 
