@@ -23,11 +23,13 @@ namespace {
 constexpr int NSLOT = 33;              // frequency slots 0..32 ([P(64 lines) | Q(64 lines)] each; Q = 0 for slots 0 and 32)
 constexpr int SPEC = NSLOT * 128;      // floats per embedding spectrum
 constexpr int NSTEP = 17;              // step i: even waves slot 2i, odd waves slot 2i+1 (slot 33 reads zeros)
-constexpr int RSA = 132, QOFF = 66;    // surface rows in LDS: P at 0, Q at 66 (ds_read_b64 banks 4*surface + 2*part + {0,1} of 64)
-constexpr int RSB = 130;               // overhead rows in LDS: P at 0, Q at 64 (banks 2*overhead + {0,1})
-constexpr int A_F = 2 * 32 * RSA;      // [parity][32 surfaces]
-constexpr int B_F = 2 * 32 * RSB;      // [parity][32 overheads]
-constexpr int STAGE_F = A_F + B_F;     // 16768 floats
+// LDS rows: 128 floats [P 64 | Q 64], unpadded (a 16-byte LDS-DMA writes 1 KB = two whole rows contiguously), with the 16-byte
+// slots of each half XOR-swizzled by (row & 15): logical slot c of row r sits at slot c ^ (r & 15). ds_read_b64 of one k-group
+// by 32 rows then touches every bank pair twice (rows r and r+16, and a surface's P and Q halves): 2-way, 4 LDS cycles.
+constexpr int ROW_F = 128;
+constexpr int A_F = 2 * 32 * ROW_F;    // [parity][32 surfaces]
+constexpr int B_F = 2 * 32 * ROW_F;    // [parity][32 overheads]
+constexpr int STAGE_F = A_F + B_F;     // 16384 floats
 constexpr int XCH = 256 * 33;          // exchange region: 256 pairs x 32 shifts, row stride 33
 constexpr int LDS_F = (2 * STAGE_F > 4 * XCH) ? 2 * STAGE_F : 4 * XCH;
 
@@ -48,9 +50,9 @@ __device__ __forceinline__ i32x4 raw_rsrc(const void* base, unsigned bytes) {
     return r;
 }
 
-// global -> LDS, 4 B per lane, 256 contiguous LDS bytes per wave instruction at lds_addr (M0); out-of-range lanes write 0
-__device__ __forceinline__ void dma4(i32x4 rs, unsigned lds_addr, unsigned voff, unsigned soff) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
+// global -> LDS, 16 B per lane, 1 KB of contiguous LDS per wave instruction at lds_addr (M0); out-of-range lanes write 0
+__device__ __forceinline__ void dma16(i32x4 rs, unsigned lds_addr, unsigned voff, unsigned soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                  :
                  : "s"(lds_addr), "v"(voff), "s"(rs), "s"(soff)
                  : "memory");
@@ -85,7 +87,7 @@ struct DftArgs {
 // REC: the diagnostic instantiation that records the in-kernel timeline (costs registers: the product launch uses REC = false)
 template <bool REC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void match_dft_kernel(DftArgs p) {
-    __shared__ float smem[LDS_F];
+    __shared__ __attribute__((aligned(1024))) float smem[LDS_F];      // the read addresses XOR bits 4-7: stage bases stay 1 KB-aligned
     __shared__ float dt_s[(NSLOT + 1) * 64];      // inverse-transform coefficients; the extra slot (odd waves' 17th) is 0
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hk = lane >> 5;
@@ -107,36 +109,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto stamp = [&](int k) { if (rec) p.stamps[(blockIdx.x >> 12) * 64 + k] = __builtin_amdgcn_s_memrealtime(); };
     stamp(0);
 
-    // ---- staging: LDS-DMA (buffer_load_dword ... lds: 64 lanes x 4 B = one 64-float P or Q segment of a row, written at an
-    // arbitrary LDS address, so the padded rows need no register transit and no ds_write). Wave w owns rows of one kind:
-    // w&1 = slot parity, w>>1 = 0 surfaces / 1 overheads; 32 rows x 2 segments per step. Rows past the batch and the odd
-    // waves' 17th slot fall outside the descriptor or read a neighbour's finite values whose coefficient is 0.
+    // ---- staging: LDS-DMA, 16 B per lane: one instruction brings two whole rows (lanes 0-31 row 2n, lanes 32-63 row 2n+1)
+    // with no register transit and no ds_write; a lane fetches the 16-byte slot that belongs at its LDS position under the
+    // swizzle. Wave w owns the rows of one kind: w&1 = slot parity, w>>1 = 0 surfaces / 1 overheads; 16 instructions per
+    // step. Rows past the batch and the odd waves' 17th slot fall outside the descriptor (zeros) or read a neighbour's
+    // finite values whose coefficient is 0.
     const int wv = __builtin_amdgcn_readfirstlane(wave);
     const int srp = wv & 1, is_ov = wv >> 1;
     const int rows_here = is_ov ? min(32, p.Bo - o0) : min(32, p.Bs - s0);
     const i32x4 rs = raw_rsrc(is_ov ? p.spec_ov + (size_t)o0 * SPEC : p.spec_su + (size_t)s0 * SPEC, (unsigned)rows_here * SPEC * 4u);
-    const unsigned row_bytes = is_ov ? RSB * 4u : RSA * 4u;         // LDS row stride of this wave's rows
-    const unsigned q_bytes = is_ov ? 64u * 4u : QOFF * 4u;          // where Q sits in the row
-    const unsigned region = (is_ov ? A_F + srp * 32 * RSB : srp * 32 * RSA) * 4u;
+    const unsigned region = (is_ov ? A_F + srp * 32 * ROW_F : srp * 32 * ROW_F) * 4u;
     const unsigned lds0 = lds_address(smem);
-    const unsigned voff = lane * 4u;
-    auto dma_seg = [&](int n, int step, int buf) {      // n = 2 * row + half, compile-time after unrolling
+    // lane -> (row 2n + hi, physical slot l32): logical slot = l32 ^ ((2n + hi) & 15) = (l32 ^ hi) ^ (2n & 15)
+    const unsigned voff0 = (unsigned)hk * (SPEC * 4u) + (unsigned)(l31 ^ hk) * 16u;
+    auto dma_rows = [&](int n, int step, int buf) {      // n = row pair, compile-time after unrolling
         const unsigned slot = (unsigned)(2 * step + srp);
-        const unsigned soff = (unsigned)(n >> 1) * (SPEC * 4u) + (unsigned)(n & 1) * 256u + slot * 512u;
-        const unsigned lds = lds0 + (unsigned)buf * (STAGE_F * 4u) + region + (unsigned)(n >> 1) * row_bytes + ((n & 1) ? q_bytes : 0u);
-        dma4(rs, lds, voff, soff);
+        const unsigned soff = (unsigned)(2 * n) * (SPEC * 4u) + slot * 512u;
+        const unsigned lds = lds0 + (unsigned)buf * (STAGE_F * 4u) + region + (unsigned)n * 1024u;
+        dma16(rs, lds, voff0 ^ (unsigned)(((2 * n) & 15) << 4), soff);
     };
 
     // ---- operand roles. GEMM-1 row l31 = surface j, part (0: Re C, 1: Im C); row order j&3 + 4*part + 8*(j>>2)
     const int j = (l31 & 3) + 4 * (l31 >> 3), part = (l31 >> 2) & 1;
     //   K < 64 (lines x re of the overhead):  Re row reads P, Im row reads Q (sign below);  K >= 64 (x im): Re row reads Q, Im row reads P
-    const int a_off1 = (par * 32 + team * 16 + j) * RSA + (part ? QOFF : 0) + 2 * hk;
-    const int a_off2 = (par * 32 + team * 16 + j) * RSA + (part ? 0 : QOFF) + 2 * hk;
+    // byte offsets in a stage of k-group 0; k-group u is at offset ^ (u << 4) (the swizzle: slot u ^ (row & 15))
+    const unsigned a_row = (unsigned)(par * 32 + team * 16 + j) * 512u + 8u * hk + ((unsigned)j << 4);
+    const unsigned a_off1 = a_row + (part ? 256u : 0u);
+    const unsigned a_off2 = a_row + (part ? 0u : 256u);
     // the Im rows' minus sign (K < 64: -Q) is applied once per step: ca collects K < 64, cb K >= 64, and accumulator register r
     // holds Re C in lanes 0-31 and Im C in lanes 32-63, so C = cb + sg * ca with sg = -1 in the upper half-wave
     const float sg = hk ? -1.f : 1.f;
-    const int b_off1 = A_F + (par * 32 + l31) * RSB + 2 * hk;
-    const int b_off2 = b_off1 + 64;
+    const unsigned b_off1 = (unsigned)(A_F + (par * 32 + l31) * ROW_F) * 4u + 8u * hk + ((unsigned)(l31 & 15) << 4);     // Q: + 256
     for (int t = tid; t < (NSLOT + 1) * 64; t += 256) dt_s[t] = t < NSLOT * 64 ? p.dtab[t] : 0.f;
     // a global load here would sit at the end of every step with its whole latency exposed (measured: ~4.6k cycles per step)
     auto dcoef = [&](int step) { return dt_s[(2 * step + par) * 64 + lane]; };
@@ -148,13 +151,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int q = 0; q < 16; ++q) acc2[r][q] = 0.f;
 
 #pragma unroll
-    for (int n = 0; n < 64; ++n) dma_seg(n, 0, 0);
+    for (int n = 0; n < 16; ++n) dma_rows(n, 0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     float dval = dcoef(0);
     stamp(1);
 
-    // step i: 64 GEMM-1 MFMAs with the 64 DMA segments of step i+1's rows issued four per MFMA group into the other stage
+    // step i: 64 GEMM-1 MFMAs with the 16 DMA instructions of step i+1's rows issued one per MFMA group into the other stage
     // (free since the barrier that ended step i-1), then the 16 GEMM-2 MFMAs; the DMAs land before the step's barrier
     for (int i = 0; i < NSTEP; ++i) {
         const float* st = smem + (i & 1) * STAGE_F;
@@ -163,18 +166,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         f32x16 ca, cb;
 #pragma unroll
         for (int q = 0; q < 16; ++q) { ca[q] = 0.f; cb[q] = 0.f; }
-        // operands as ds_read_b64 (256 B/clk, 64 banks: conflict-free with these row strides; ds_read_b32 has 32 banks and
-        // would be 2-way): a lane holds k = 4u + 2hk and 4u + 2hk + 1 of its row, i.e. MFMA step 2u + e covers k = 4u + e
-        // (lanes 0-31) and 4u + 2 + e (lanes 32-63) -- the same K permutation on both operands. Reads run two groups ahead.
+        // operands as ds_read_b64: a lane holds k = 4u + 2hk and 4u + 2hk + 1 of its row, i.e. MFMA step 2u + e covers
+        // k = 4u + e (lanes 0-31) and 4u + 2 + e (lanes 32-63) -- the same K permutation on both operands. Reads run two
+        // groups ahead; the compiler would fuse neighbours into ds_read2_b64 (banked like ds_read_b32), hence the asm.
         const unsigned sb = lds_address(st);
-        const unsigned xa1 = sb + 4u * a_off1, xb1 = sb + 4u * b_off1, xa2 = sb + 4u * a_off2, xb2 = sb + 4u * b_off2;
+        const unsigned xa1 = sb + a_off1, xb1 = sb + b_off1, xa2 = sb + a_off2;
         f32x2 qa1[3], qb1[3], qa2[3], qb2[3];
-#define WITW_DFT_FETCH(U)                                  \
-        {                                                  \
-            qa1[(U) % 3] = lds_read64<16 * (U)>(xa1);      \
-            qb1[(U) % 3] = lds_read64<16 * (U)>(xb1);      \
-            qa2[(U) % 3] = lds_read64<16 * (U)>(xa2);      \
-            qb2[(U) % 3] = lds_read64<16 * (U)>(xb2);      \
+#define WITW_DFT_FETCH(U)                                              \
+        {                                                              \
+            qa1[(U) % 3] = lds_read64<0>(xa1 ^ (unsigned)((U) << 4));  \
+            const unsigned xb = xb1 ^ (unsigned)((U) << 4);            \
+            qb1[(U) % 3] = lds_read64<0>(xb);                          \
+            qa2[(U) % 3] = lds_read64<0>(xa2 ^ (unsigned)((U) << 4));  \
+            qb2[(U) % 3] = lds_read64<256>(xb);                        \
         }
 #define WITW_DFT_GROUP(U)                                                                                                      \
         {                                                                                                                      \
@@ -184,10 +188,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             else if ((U) + 1 < 16) lds_wait<4>(qa1[d], qb1[d], qa2[d], qb2[d]);                                                \
             else lds_wait<0>(qa1[d], qb1[d], qa2[d], qb2[d]);                                                                  \
             ca = __builtin_amdgcn_mfma_f32_32x32x2f32(qa1[d][0], qb1[d][0], ca, 0, 0, 0);                                      \
-            dma_seg(4 * (U), inext, bufn); dma_seg(4 * (U) + 1, inext, bufn);                                                  \
+            dma_rows((U), inext, bufn);                                                                                        \
             cb = __builtin_amdgcn_mfma_f32_32x32x2f32(qa2[d][0], qb2[d][0], cb, 0, 0, 0);                                      \
             ca = __builtin_amdgcn_mfma_f32_32x32x2f32(qa1[d][1], qb1[d][1], ca, 0, 0, 0);                                      \
-            dma_seg(4 * (U) + 2, inext, bufn); dma_seg(4 * (U) + 3, inext, bufn);                                              \
             cb = __builtin_amdgcn_mfma_f32_32x32x2f32(qa2[d][1], qb2[d][1], cb, 0, 0, 0);                                      \
         }
         WITW_DFT_FETCH(0)
