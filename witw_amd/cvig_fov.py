@@ -669,7 +669,7 @@ def retrieve_topk(overhead_shard, surface_all, k=10, shard_begin=0, query_chunk=
     for q0 in range(0, n_q, query_chunk):
         q1 = min(n_q, q0 + query_chunk)
         if method == 'dft':
-            _, dist = ops.match_fwd_dft(gallery, surface_all[q0:q1].contiguous(), spec_ov=spec_g)
+            _, dist = ops.match_fwd_dft(gallery, surface_all[q0:q1].contiguous(), spec_ov=spec_g, want_orientation=False)
         else:
             _, dist = ops.match_fwd(gallery, surface_all[q0:q1].contiguous())
         v, i = ops.topk_smallest(dist, k, shard_begin)
@@ -717,7 +717,7 @@ def retrieve(overhead_shard, surface_all, k=10, shard_begin=0, query_chunk=4096,
     for q0 in range(0, n_q, query_chunk):
         q1 = min(n_q, q0 + query_chunk)
         if method == 'dft':
-            _, dist = ops.match_fwd_dft(gallery, surface_all[q0:q1].contiguous(), spec_ov=spec_g)
+            _, dist = ops.match_fwd_dft(gallery, surface_all[q0:q1].contiguous(), spec_ov=spec_g, want_orientation=False)
         else:
             _, dist = ops.match_fwd(gallery, surface_all[q0:q1].contiguous())            # [n_g, q]
         qi = torch.arange(q0, q1, device=dist.device)

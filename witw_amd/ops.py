@@ -289,7 +289,7 @@ def match_spectrum(embed):
     return spec
 
 
-def match_fwd_dft(overhead_embed, surface_embed, spec_ov=None, spec_su=None, want_score=False):
+def match_fwd_dft(overhead_embed, surface_embed, spec_ov=None, spec_su=None, want_score=False, want_orientation=True):
     """match_fwd through the row spectra (21k FLOP per pair instead of 524k): same outputs; scores agree with the direct sum to
     fp32 rounding, so an orientation can differ only between shifts whose scores tie to ~1e-6. spec_ov / spec_su: cached
     match_spectrum of the two sides (the gallery's is computed once per retrieval)."""
@@ -306,7 +306,8 @@ def match_fwd_dft(overhead_embed, surface_embed, spec_ov=None, spec_su=None, wan
     for name, sp, n in (('spec_ov', spec_ov, Bo), ('spec_su', spec_su, Bs)):
         if not (sp.is_cuda and sp.dtype == torch.float32 and sp.is_contiguous() and tuple(sp.shape) == (n, 33, 128)):
             raise _lib.WitwError('match_fwd_dft: %s must be a contiguous float32 GPU tensor [%d,33,128]' % (name, n))
-    ori = torch.empty((Bo, Bs), dtype=torch.int64, device=ov.device)
+    # want_orientation=False (retrieval: only distances are ranked) skips the int64 matrix, two thirds of the output bytes
+    ori = torch.empty((Bo, Bs), dtype=torch.int64, device=ov.device) if want_orientation else None
     dist = torch.empty((Bo, Bs), dtype=torch.float32, device=ov.device)
     score = torch.empty((Bo, Bs), dtype=torch.float32, device=ov.device) if want_score else None
     ws = torch.empty(lib.witw_match_dft_workspace_floats(Bo, Bs), dtype=torch.float32, device=ov.device)
@@ -315,7 +316,7 @@ def match_fwd_dft(overhead_embed, surface_embed, spec_ov=None, spec_su=None, wan
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     _lib.check(lib.witw_match_fwd_dft(ov.data_ptr(), su.data_ptr(), spec_ov.data_ptr(), spec_su.data_ptr(), Bo, Bs, We,
-                                      ori.data_ptr(), dist.data_ptr(), _p(score), ws.data_ptr(), _stream()), 'witw_match_fwd_dft')
+                                      _p(ori), dist.data_ptr(), _p(score), ws.data_ptr(), _stream()), 'witw_match_fwd_dft')
     if prof is not None:      # FLOP of this form per pair: 33 slots x (2 rows x K=128 x 2 + 32 shifts x K=2 x 2) = 21,120
         e1.record()
         prof.append((('match_dft', We), 33.0 * (2 * 128 * 2 + 32 * 2 * 2) * Bo * Bs, e0, e1))
