@@ -296,10 +296,43 @@ def main():
             'ranks_differing_from_f32_step': int((r3[1] != ranks).sum().item()), 'overflow': bool(ops.f16x3_overflowed(device)),
             'note': 'operands carried as fp16 hi + lo, products hi*hi + lo*hi + hi*lo on v_mfma_f32_32x32x16_f16, fp32 accumulate; '
                     'held to the reference goldens at the same 1e-4 as the f32 kernels (tests/test_f16x3_gpu.py)'}
+    if world == 1 and not train and not bf16 and not f16x3 and not a.graph and not semantic and a.fov == 360 and not a.no_cpu_baseline:
+        out['config5_retrieval'] = retrieval_summary(device, cvig_fov, ops)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def retrieval_summary(device, cvig_fov, ops, G=125000, Q=10000, k=10):
+    """BASELINE config 5's per-GPU share (125,000 gallery rows x 10,000 queries, ranks + top-10) measured beside the headline
+    with the spectral orientation search: one warm-up and one timed pass (`--mode retrieval [--match dft]` is the full line,
+    the direct-sum pass takes 4.6 s)."""
+    gen = torch.Generator(device=device)
+    gen.manual_seed(4321)
+    gallery = torch.randn((G, 16, 4, 64), generator=gen, device=device)
+    shifts = torch.randint(0, 64, (Q,), generator=gen, device=device)
+    col = (torch.arange(64, device=device)[None, :] + shifts[:, None]) % 64
+    queries = torch.gather(gallery[:Q], 3, col[:, None, None, :].expand(-1, 16, 4, -1)) \
+        + 10.0 * torch.randn((Q, 16, 4, 64), generator=gen, device=device)
+    cvig_fov.retrieve(gallery, queries, k=k, method='dft')
+    torch.cuda.synchronize()
+    ops.PROFILE = []
+    t0 = time.perf_counter()
+    ranks_h, vals, idx = cvig_fov.retrieve(gallery, queries, k=k, method='dft')
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof, ops.PROFILE = ops.PROFILE, None
+    m = [(fl, e0.elapsed_time(e1)) for (v, fl, e0, e1) in prof if v[0] == 'match_dft']
+    tf = sum(f for f, _ in m) / (sum(t for _, t in m) * 1e-3) / 1e12 if m else 0.0
+    return {'workload': 'gallery retrieval: %d overhead embeddings x %d ground queries, fov=360, ranks + top-%d' % (G, Q, k),
+            'match': 'dft (witw_match_fwd_dft: orientation search through 64-point row spectra, 21,120 FLOP per pair)',
+            'value': round(float(G) * Q / dt, 1), 'unit': 'pairs/s', 'ms_per_step': round(dt * 1e3, 3),
+            'recall': {'top1_pct': float(np.mean(ranks_h <= 1) * 100), 'top10_pct': float(np.mean(ranks_h <= 10) * 100), 'N': G},
+            'match_kernel_tflops': round(tf, 2), 'match_kernel_frac_of_f32_mfma_peak': round(tf / PEAK_F32_MFMA_TFLOPS, 4),
+            'direct_sum_pairs_per_s_in_profiles_r01': 2.73e8,
+            'note': 'the direct-sum pass (witw_match_fwd, 524,288 FLOP per pair at 0.91 of the fp32 MFMA peak) is '
+                    'profiles/r01_bench_retrieval.json; same recall figures'}
 
 
 def retrieval(a, rank, world, device, cvig_fov, ops):
