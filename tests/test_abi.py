@@ -62,6 +62,20 @@ def test_version_and_argument_errors_without_gpu():
     assert rc == -1 and b'tap_base' in lib.witw_last_error()
     rc = lib.witw_maxpool2x2_bwd_bf16(1, 1, 1, 1, 2, 2, 3, 4, 8, None)
     assert rc == -1 and b'bad shape' in lib.witw_last_error()
+    # the spectral match and the row-split top-k
+    assert lib.witw_match_spectrum_floats(3) == 3 * 33 * 128
+    assert lib.witw_match_dft_workspace_floats(5, 7) == 5 * 64 + 7 + 33 * 64
+    rc = lib.witw_match_spectrum(1, 1, 4, 65, None)
+    assert rc == -1 and b'bad shape' in lib.witw_last_error()
+    rc = lib.witw_match_fwd_dft(1, 1, None, 1, 4, 4, 64, None, None, None, 1, None)
+    assert rc == -1 and b'null' in lib.witw_last_error()
+    rc = lib.witw_match_fwd_dft(1, 1, 1, 1, 4, 4, 0, None, None, None, 1, None)
+    assert rc == -1 and b'width' in lib.witw_last_error()
+    assert lib.witw_topk_workspace_bytes(100, 64, 10) == 0                 # short gallery: single pass
+    assert lib.witw_topk_workspace_bytes(125000, 4096, 10) == 32 * 10 * 4096 * 8
+    assert lib.witw_topk_workspace_bytes(10, 10, 33) == -1
+    rc = lib.witw_topk_smallest_ws(1, 1, 1, 100, 10, 40, 0, None, None)
+    assert rc == -1 and b'k=40' in lib.witw_last_error()
 
 
 def test_product_never_imports_the_oracle():

@@ -6,7 +6,7 @@ shapes through the C ABI, compared with torch CPU ops in the reference's op orde
 
 Covers: fp32 conv forward (stride, circular/zero padding, ReLU, fused pool, GEO / NW variants by shape), its dgrad
 form, fp32 wgrad (+ bias), the 4-tap forms, bf16 conv forward / wgrad, the fused match (orientation exact, distance
-1e-5) with ragged batch sizes and widths, the fp16x3 conv forward / dgrad form (gate, Dropout2d scale, zero-interleaved
+1e-5) with ragged batch sizes and widths (direct and spectral forms), the fp16x3 conv forward / dgrad form (gate, Dropout2d scale, zero-interleaved
 rows) / wgrad against fp64. FUZZ_KINDS=10,11 restricts the sweep to the listed kinds. Prints one line per failure and a summary; exit code 1 on any failure.
 """
 import os
@@ -43,7 +43,7 @@ def main():
 
     while time.time() - t0 < budget:
         n += 1
-        kind = rng.integers(0, 12)
+        kind = rng.integers(0, 14)
         if os.environ.get('FUZZ_KINDS') and str(int(kind)) not in os.environ['FUZZ_KINDS'].split(','):
             continue
         B = int(rng.integers(1, 5))
@@ -227,7 +227,8 @@ def main():
                 sc = O.correlation_scores(ov, su)
                 top2 = torch.topk(sc, min(2, sc.shape[-1]), dim=-1).values
                 clear = (top2[..., 0] - top2[..., -1]) > 1e-3 if sc.shape[-1] > 1 else torch.ones_like(ori_r, dtype=torch.bool)
-                ori, d = ops.match_fwd(ov.to(dev), su.to(dev))[:2]
+                spectral = bool(kind & 1)     # odd kinds: the spectral form (witw_match_fwd_dft), same checks
+                ori, d = (ops.match_fwd_dft if spectral else ops.match_fwd)(ov.to(dev), su.to(dev))[:2]
                 if not torch.equal(ori.cpu()[clear], ori_r[clear]):
                     fails.append(('match_ori', (bo, bs, we), 0, 0))
                     print('FAIL match orientation', (bo, bs, we), flush=True)
