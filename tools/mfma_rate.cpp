@@ -126,7 +126,61 @@ void run_mix(const char* name) {
     printf("%-28s %6.1f ns/MFMA/wave  (%.1f counter ticks)\n", name, ms * 1e6 / n, (double)h / n);
 }
 
+// the spectral match's register shape: 16 long-lived accumulators (256 registers, AGPRs) updated once per 'step' from two
+// short-lived ones that take 64 MFMAs per step
+template <int NT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void shape_kernel(float* out, unsigned long long* clk, int iters) {
+    f32x16 acc2[NT];
+    for (int c = 0; c < NT; ++c)
+        for (int q = 0; q < 16; ++q) acc2[c][q] = 0.f;
+    float a = threadIdx.x * 1e-3f, b = 1.0f + threadIdx.x * 1e-4f;
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (int i = 0; i < iters; ++i) {
+        f32x16 ca, cb;
+        for (int q = 0; q < 16; ++q) { ca[q] = 0.f; cb[q] = 0.f; }
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            ca = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, ca, 0, 0, 0);
+            cb = __builtin_amdgcn_mfma_f32_32x32x2f32(b, a, cb, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[r % NT] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[r] + cb[r], b, acc2[r % NT], 0, 0, 0);
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    float s = 0.f;
+    for (int c = 0; c < NT; ++c)
+        for (int q = 0; q < 16; ++q) s += acc2[c][q];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (threadIdx.x == 0 && blockIdx.x == 0) clk[0] = t1 - t0;
+}
+
+template <int NT>
+void run_shape(const char* name) {
+    float* out;
+    unsigned long long* clk;
+    hipMalloc((void**)&out, 256 * 256 * 4);
+    hipMalloc((void**)&clk, 8);
+    const int iters = 2000;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipLaunchKernelGGL(shape_kernel<NT>, dim3(256), dim3(256), 0, 0, out, clk, 10);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(shape_kernel<NT>, dim3(256), dim3(256), 0, 0, out, clk, iters);
+    hipEventRecord(e1);
+    hipDeviceSynchronize();
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    unsigned long long h;
+    hipMemcpy(&h, clk, 8, hipMemcpyDeviceToHost);
+    const double n = (double)iters * 80;
+    printf("%-28s %6.1f ns/MFMA/wave  (%.1f counter ticks)\n", name, ms * 1e6 / n, (double)h / n);
+}
+
 int main() {
+    run_shape<16>("shape: 2 + 16 accumulators");
+    run_shape<14>("shape: 2 + 14 accumulators");
+    run_shape<8>("shape: 2 + 8 accumulators");
     run_mix<0>("mix: MFMA only");
     run_mix<1>("mix: + ds_read_b64 each");
     run_mix<2>("mix: + LDS-DMA each");

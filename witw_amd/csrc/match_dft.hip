@@ -71,6 +71,18 @@ __device__ __forceinline__ void lds_wait(f32x2& a, f32x2& b, f32x2& c, f32x2& d)
     asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
 }
 
+// GEMM-1 MFMA with its accumulator pinned to VGPRs. The wave owns 16 x 16 long-lived accumulation registers (all 256 AGPRs);
+// left to the compiler the two short-lived GEMM-1 accumulators also go to AGPRs, 288 > 256, and one long-lived tile is shuttled
+// through v_accvgpr moves every step: 79 instead of 69 cycles per MFMA in tools/mfma_rate.cpp's model of this loop. Inline asm
+// is outside the compiler's hazard recogniser: the required wait states sit in mfma_settle() below.
+__device__ __forceinline__ void mfma_v(f32x16& acc, float a, float b) {
+    asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+// 16-pass XDL write -> VALU read of the result: 18 wait states (CDNA3 ISA, manually inserted wait states)
+__device__ __forceinline__ void mfma_settle(f32x16& x, f32x16& y) {
+    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(x), "+v"(y));
+}
+
 struct DftArgs {
     const float* spec_ov;    // [Bo][33][128]
     const float* spec_su;    // [Bs][33][128]
@@ -166,6 +178,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         f32x16 ca, cb;
 #pragma unroll
         for (int q = 0; q < 16; ++q) { ca[q] = 0.f; cb[q] = 0.f; }
+        asm volatile("s_nop 3" : "+v"(ca), "+v"(cb));      // VALU write -> XDL SrcC read
         // operands as ds_read_b64: a lane holds k = 4u + 2hk and 4u + 2hk + 1 of its row, i.e. MFMA step 2u + e covers
         // k = 4u + e (lanes 0-31) and 4u + 2 + e (lanes 32-63) -- the same K permutation on both operands. Reads run two
         // groups ahead; the compiler would fuse neighbours into ds_read2_b64 (banked like ds_read_b32), hence the asm.
@@ -187,11 +200,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if ((U) + 2 < 16) lds_wait<8>(qa1[d], qb1[d], qa2[d], qb2[d]);                                                     \
             else if ((U) + 1 < 16) lds_wait<4>(qa1[d], qb1[d], qa2[d], qb2[d]);                                                \
             else lds_wait<0>(qa1[d], qb1[d], qa2[d], qb2[d]);                                                                  \
-            ca = __builtin_amdgcn_mfma_f32_32x32x2f32(qa1[d][0], qb1[d][0], ca, 0, 0, 0);                                      \
+            mfma_v(ca, qa1[d][0], qb1[d][0]);                                                                                  \
             dma_rows((U), inext, bufn);                                                                                        \
-            cb = __builtin_amdgcn_mfma_f32_32x32x2f32(qa2[d][0], qb2[d][0], cb, 0, 0, 0);                                      \
-            ca = __builtin_amdgcn_mfma_f32_32x32x2f32(qa1[d][1], qb1[d][1], ca, 0, 0, 0);                                      \
-            cb = __builtin_amdgcn_mfma_f32_32x32x2f32(qa2[d][1], qb2[d][1], cb, 0, 0, 0);                                      \
+            mfma_v(cb, qa2[d][0], qb2[d][0]);                                                                                  \
+            mfma_v(ca, qa1[d][1], qb1[d][1]);                                                                                  \
+            mfma_v(cb, qa2[d][1], qb2[d][1]);                                                                                  \
         }
         WITW_DFT_FETCH(0)
         WITW_DFT_FETCH(1)
@@ -202,6 +215,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #undef WITW_DFT_GROUP
 #undef WITW_DFT_FETCH
         stamp(2 + 3 * i);
+        mfma_settle(ca, cb);
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc2[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(fmaf(ca[r], sg, cb[r]), dval, acc2[r], 0, 0, 0);
         dval = dcoef(inext);
