@@ -164,6 +164,46 @@ def correlation_scores(overhead_embed, surface_embed):
     return torch.squeeze(out, -2)
 
 
+def spectral_scores(overhead_embed, surface_embed):
+    """The algebra of witw_match_fwd_dft (witw_amd/csrc/match_dft.hip) restated in numpy fp64 -- test infrastructure for that
+    kernel, not a reference function: the scores of correlation_scores() through the 64-point DFT of every (channel,row) line.
+    Slots t = 0..32 hold [P | Q] = [Re X_t | Im X_t] per line (Q = 0 for t = 0, 32), X_t = sum_k x[k] e^{-2 pi i t k / 64};
+    per slot Re C = P_s.P_o + Q_s.Q_o and Im C = -Q_s.P_o + P_s.Q_o (the kernel's two K halves, the sign applied once);
+    even slots accumulate E[shift < 32], odd slots O[shift < 32] with the coefficient table of match_dft_table_kernel;
+    score[shift] = E + O, score[shift + 32] = E - O. -> float64 [Bo,Bs,64]."""
+    import numpy as np
+    ov = overhead_embed.numpy().astype(np.float64).reshape(overhead_embed.shape[0], 64, 64)
+    we = surface_embed.shape[3]
+    su = np.zeros((surface_embed.shape[0], 64, 64))
+    su[:, :, :we] = surface_embed.numpy().astype(np.float64).reshape(surface_embed.shape[0], 64, we)
+    k = np.arange(64)
+    t = np.arange(33)
+    ang = 2.0 * np.pi * ((t[:, None] * k[None, :]) % 64) / 64.0
+    cs, sn = np.cos(ang), np.sin(ang)                                  # [33,64]
+
+    def spectrum(x):                                                   # [B,64 lines,64] -> P, Q [B,33,64 lines]
+        p = np.einsum('blk,tk->btl', x, cs)
+        q = -np.einsum('blk,tk->btl', x, sn)
+        q[:, 0] = 0.0
+        q[:, 32] = 0.0
+        return p.astype(np.float32).astype(np.float64), q.astype(np.float32).astype(np.float64)      # rounded once to fp32
+
+    po, qo = spectrum(ov)
+    ps, qs = spectrum(su)
+    re = np.einsum('stl,otl->ost', ps, po) + np.einsum('stl,otl->ost', qs, qo)       # [Bo,Bs,33]
+    im = -np.einsum('stl,otl->ost', qs, po) + np.einsum('stl,otl->ost', ps, qo)
+    shift = np.arange(32)
+    a2 = 2.0 * np.pi * ((t[:, None] * shift[None, :]) % 64) / 64.0
+    d_re = np.cos(a2) / 32.0
+    d_im = -np.sin(a2) / 32.0
+    d_re[0], d_im[0] = 1.0 / 64.0, 0.0
+    d_re[32], d_im[32] = np.where(shift % 2 == 0, 1.0, -1.0) / 64.0, 0.0
+    contrib = re[..., None] * d_re[None, None] + im[..., None] * d_im[None, None]   # [Bo,Bs,33,32]
+    e = contrib[:, :, 0::2].sum(axis=2)
+    o = contrib[:, :, 1::2].sum(axis=2)
+    return np.concatenate([e + o, e - o], axis=2)
+
+
 def correlation(overhead_embed, surface_embed):
     """model/cvig_fov.py:297-315 -> int64 [Bo,Bs] (argmax, first index on ties)."""
     return torch.argmax(correlation_scores(overhead_embed, surface_embed), -1)
