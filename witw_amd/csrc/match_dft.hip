@@ -30,8 +30,8 @@ constexpr int ROW_F = 128;
 constexpr int A_F = 2 * 32 * ROW_F;    // [parity][32 surfaces]
 constexpr int B_F = 2 * 32 * ROW_F;    // [parity][32 overheads]
 constexpr int STAGE_F = A_F + B_F;     // 16384 floats
-constexpr int XCH = 256 * 33;          // exchange region: 256 pairs x 32 shifts, row stride 33
-constexpr int LDS_F = (2 * STAGE_F > 4 * XCH) ? 2 * STAGE_F : 4 * XCH;
+constexpr int XCH = 128 * 33;          // exchange region of an epilogue round: 128 pairs x 32 shifts, row stride 33
+constexpr int LDS_F = STAGE_F + ((STAGE_F > 4 * XCH) ? STAGE_F : 4 * XCH);      // stage 0 | stage 1 / the epilogue exchange
 
 __device__ __forceinline__ unsigned lds_address(const void* p) {
     return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)p;
@@ -105,21 +105,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int l31 = lane & 31, hk = lane >> 5;
     const int team = wave >> 1, par = wave & 1;
 
-    // 16 x 16 tile windows: consecutive workgroups walk 16 overhead tiles of one surface tile, then the next surface tile, so
-    // the 256 resident workgroups share 16 + 16 tile spectra per slot (L2-resident while the slots advance together)
-    int bx, by;
-    {
+    // Persistent workgroups (one per CU: the LDS admits one anyway): workgroup b ranks tiles b, b + gridDim.x, ... Tile numbering
+    // in 16 x 16 windows: consecutive tiles walk 16 overhead tiles of one surface tile, then the next surface tile, so the
+    // resident workgroups share 16 + 16 tile spectra per slot (L2-resident while the slots advance together).
+    const long long n_tiles = (long long)p.nbx * p.nby;
+    auto tile_origin = [&](long long tile, int& s0_, int& o0_) {
         const int per_group = 16 * p.nbx;
-        const int g = blockIdx.x / per_group, within = blockIdx.x - g * per_group;
+        const int g = (int)(tile / per_group), within = (int)(tile - (long long)g * per_group);
         const int rows = min(16, p.nby - 16 * g);
-        by = 16 * g + within % rows;
-        bx = within / rows;
-        if (bx >= p.nbx) return;        // never: within < rows * nbx for a full group; guards the ragged last group
-    }
-    const int s0 = bx * 32, o0 = by * 32;
-    const bool rec = REC && p.stamps && (blockIdx.x & 4095) == 2048 && tid == 0;
-    auto stamp = [&](int k) { if (rec) p.stamps[(blockIdx.x >> 12) * 64 + k] = __builtin_amdgcn_s_memrealtime(); };
-    stamp(0);
+        o0_ = (16 * g + within % rows) * 32;
+        s0_ = (within / rows) * 32;
+    };
 
     // ---- staging: LDS-DMA, 16 B per lane: one instruction brings two whole rows (lanes 0-31 row 2n, lanes 32-63 row 2n+1)
     // with no register transit and no ds_write; a lane fetches the 16-byte slot that belongs at its LDS position under the
@@ -128,12 +124,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // finite values whose coefficient is 0.
     const int wv = __builtin_amdgcn_readfirstlane(wave);
     const int srp = wv & 1, is_ov = wv >> 1;
-    const int rows_here = is_ov ? min(32, p.Bo - o0) : min(32, p.Bs - s0);
-    const i32x4 rs = raw_rsrc(is_ov ? p.spec_ov + (size_t)o0 * SPEC : p.spec_su + (size_t)s0 * SPEC, (unsigned)rows_here * SPEC * 4u);
     const unsigned region = (is_ov ? A_F + srp * 32 * ROW_F : srp * 32 * ROW_F) * 4u;
     const unsigned lds0 = lds_address(smem);
     // lane -> (row 2n + hi, physical slot l32): logical slot = l32 ^ ((2n + hi) & 15) = (l32 ^ hi) ^ (2n & 15)
     const unsigned voff0 = (unsigned)hk * (SPEC * 4u) + (unsigned)(l31 ^ hk) * 16u;
+    auto tile_rsrc = [&](int s0_, int o0_) {
+        const int rows_here = is_ov ? min(32, p.Bo - o0_) : min(32, p.Bs - s0_);
+        return raw_rsrc(is_ov ? p.spec_ov + (size_t)o0_ * SPEC : p.spec_su + (size_t)s0_ * SPEC, (unsigned)rows_here * SPEC * 4u);
+    };
+    i32x4 rs;
     auto dma_rows = [&](int n, int step, int buf) {      // n = row pair, compile-time after unrolling
         const unsigned slot = (unsigned)(2 * step + srp);
         const unsigned soff = (unsigned)(2 * n) * (SPEC * 4u) + slot * 512u;
@@ -156,14 +155,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // a global load here would sit at the end of every step with its whole latency exposed (measured: ~4.6k cycles per step)
     auto dcoef = [&](int step) { return dt_s[(2 * step + par) * 64 + lane]; };
 
+    int s0, o0;
+    tile_origin(blockIdx.x, s0, o0);
+    rs = tile_rsrc(s0, o0);
+#pragma unroll
+    for (int n = 0; n < 16; ++n) dma_rows(n, 0, 0);        // the first tile's first stage; later ones are issued in the epilogue
+
+    int iter = 0;
+#pragma clang loop unroll(disable)
+    for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, ++iter) {
+    const bool rec = REC && p.stamps && blockIdx.x < 4 && iter == 1 && tid == 0;      // a steady-state tile of the first workgroups
+    auto stamp = [&](int k) { if (rec) p.stamps[blockIdx.x * 64 + k] = __builtin_amdgcn_s_memrealtime(); };
+    stamp(0);
     f32x16 acc2[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r)
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc2[r][q] = 0.f;
-
-#pragma unroll
-    for (int n = 0; n < 16; ++n) dma_rows(n, 0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     float dval = dcoef(0);
@@ -171,6 +179,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     // step i: 64 GEMM-1 MFMAs with the 16 DMA instructions of step i+1's rows issued one per MFMA group into the other stage
     // (free since the barrier that ended step i-1), then the 16 GEMM-2 MFMAs; the DMAs land before the step's barrier
+#pragma clang loop unroll(disable)
     for (int i = 0; i < NSTEP; ++i) {
         const float* st = smem + (i & 1) * STAGE_F;
         const int bufn = (i + 1) & 1;
@@ -225,24 +234,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         stamp(4 + 3 * i);
     }
 
-    // ---- epilogue, two rounds of 8 surfaces per team: E and O tiles -> LDS [pair][shift], then 2 pairs per lane
-    float* xe = smem + team * (2 * XCH);       // this team's E region, O region behind it
+    // ---- the next tile's first stage goes into stage 0 (free since the last barrier) while this tile's epilogue runs in the
+    // area of stage 1 (the last step's redundant DMA into it has landed: vmcnt(0) before that barrier)
+    const int s0c = s0, o0c = o0;
+    if (tile + gridDim.x < n_tiles) {
+        tile_origin(tile + gridDim.x, s0, o0);
+        rs = tile_rsrc(s0, o0);
+#pragma unroll
+        for (int n = 0; n < 16; ++n) dma_rows(n, 0, 0);
+    }
+    // ---- epilogue, four rounds of 4 surfaces per team: E and O tiles -> LDS [pair][shift], then one pair per lane
+    float* xe = smem + STAGE_F + team * (2 * XCH);       // this team's E region, O region behind it
     float* mine = xe + par * XCH;
-    const int tl = par * 64 + lane;            // lane of the team (0..127)
+    const int tl = par * 64 + lane;            // lane of the team (0..127) = pair of the round: overhead tl >> 2, surface tl & 3
 #pragma unroll
-    for (int rd = 0; rd < 2; ++rd) {
+    for (int rd = 0; rd < 4; ++rd) {
 #pragma unroll
-        for (int rr = 0; rr < 8; ++rr)
+        for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int o = (q & 3) + 8 * (q >> 2) + 4 * hk;
-                mine[(o * 8 + rr) * 33 + l31] = acc2[8 * rd + rr][q];
+                mine[(o * 4 + rr) * 33 + l31] = acc2[4 * rd + rr][q];
             }
         __syncthreads();
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int rl = tl & 7, o = (tl >> 3) + 16 * h;
-            const float* e = xe + (o * 8 + rl) * 33;       // pair index = team lane (+128): row stride 33 -> conflict-free
+        {
+            const int rl = tl & 3, o = tl >> 2;
+            const float* e = xe + tl * 33;       // row stride 33 -> conflict-free
             const float* od = e + XCH;
             float vlo = -INFINITY, vhi = -INFINITY;
             int ilo = 0, ihi = 32;
@@ -255,7 +272,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
             const float v = vhi > vlo ? vhi : vlo;
             const int idx = vhi > vlo ? ihi : ilo;
-            const int s = s0 + team * 16 + 8 * rd + rl, og = o0 + o;
+            const int s = s0c + team * 16 + 4 * rd + rl, og = o0c + o;
             if (s < p.Bs && og < p.Bo) {
                 const size_t off = (size_t)og * p.Bs + s;
                 if (p.orientation) p.orientation[off] = idx;
@@ -266,6 +283,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         __syncthreads();
     }
     stamp(53);
+    }   // tiles
 }
 
 // spec[e][t][0..63] = Re X_t(line), [64..127] = Im X_t(line) (0 for t = 0, 32), X_t = sum_k x[line][k] e^{-2 pi i t k / 64}; fp64
@@ -381,24 +399,32 @@ int witw_match_fwd_dft(const float* ov, const float* su, const float* spec_ov, c
     a.spec_ov = spec_ov; a.spec_su = spec_su; a.dtab = dtab; a.wn = wn; a.sn = sn;
     a.orientation = orientation; a.distance = distance; a.score = score;
     a.Bo = Bo; a.Bs = Bs; a.nbx = cdiv(Bs, 32); a.nby = cdiv(Bo, 32);
-    const long long blocks = (long long)a.nbx * a.nby;
-    WITW_CHECK_ARG(blocks <= 0x7fffffffLL, "match_fwd_dft: too many tiles");
-    // WITW_DFT_STAMPS=1 (diagnostic, synchronous): every 4096th workgroup records s_memrealtime around its phases; printed to stderr
+    const long long tiles = (long long)a.nbx * a.nby;
+    static int n_cu = 0;        // persistent workgroups, one per CU
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+        if (n_cu <= 0) n_cu = 256;
+    }
+    const unsigned grid = (unsigned)(tiles < n_cu ? tiles : n_cu);
+    // WITW_DFT_STAMPS=1 (diagnostic, synchronous): the first workgroups record s_memrealtime around the phases of their second
+    // tile; printed to stderr
     a.stamps = nullptr;
-    const int nrec = (int)(blocks >> 12);
-    if (getenv("WITW_DFT_STAMPS") != nullptr && nrec > 0) {
+    const int nrec = 4;
+    if (getenv("WITW_DFT_STAMPS") != nullptr && tiles >= 2LL * grid) {
         if (hipMalloc((void**)&a.stamps, (size_t)nrec * 64 * 8) != hipSuccess) a.stamps = nullptr;
         else (void)hipMemset(a.stamps, 0, (size_t)nrec * 64 * 8);
     }
-    if (a.stamps) hipLaunchKernelGGL(match_dft_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(match_dft_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    if (a.stamps) hipLaunchKernelGGL(match_dft_kernel<true>, dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(match_dft_kernel<false>, dim3(grid), dim3(256), 0, st, a);
     if (a.stamps) {
         (void)hipDeviceSynchronize();
         unsigned long long* h = (unsigned long long*)malloc((size_t)nrec * 64 * 8);
         (void)hipMemcpy(h, a.stamps, (size_t)nrec * 64 * 8, hipMemcpyDeviceToHost);
         for (int b = 0; b < nrec && b < 4; ++b) {
             const unsigned long long* t = h + (size_t)b * 64;
-            fprintf(stderr, "match_dft workgroup %d: prologue %.2f us; steps (gemm1, gemm2, barrier) us:", b * 4096 + 2048, (t[1] - t[0]) * 0.01);
+            fprintf(stderr, "match_dft workgroup %d, second tile: first-stage wait %.2f us; steps (gemm1, gemm2, barrier) us:", b, (t[1] - t[0]) * 0.01);
             for (int i = 0; i < 17; ++i)
                 fprintf(stderr, " [%.2f %.2f %.2f]", (t[2 + 3 * i] - (i ? t[1 + 3 * i] : t[1])) * 0.01, (t[3 + 3 * i] - t[2 + 3 * i]) * 0.01,
                         (t[4 + 3 * i] - t[3 + 3 * i]) * 0.01);
