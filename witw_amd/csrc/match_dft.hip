@@ -7,7 +7,8 @@
 //   score[o,s,shift] = (1/64) [ C_0 + (-1)^shift C_32 + 2 sum_{f=1..31} (Re C_f cos(2 pi f shift/64) - Im C_f sin(..)) ]
 // 2*2*128*33 + 2*2*32*33 = 21k FLOP per pair instead of 2*64*4096 = 524k of the direct form (match.hip), both on the fp32 MFMA.
 //
-// Kernel: a workgroup = 32 surfaces x 32 overheads, 4 waves = 2 surface teams x {even, odd} frequencies. Per frequency slot
+// Kernel: persistent workgroups (one per CU), a tile = 32 surfaces x 32 overheads, 4 waves = 2 surface teams x {even, odd}
+// frequencies. Per frequency slot
 //   GEMM 1 (32x32x2 f32 MFMA, K = 128 = 64 lines x {re,im}): rows = 16 surfaces x {Re C, Im C}, columns = 32 overheads. Rows are
 //          ordered so that accumulator register r of lanes 0-31 holds Re C[surface r] and of lanes 32-63 Im C[surface r] of the
 //          same (surface, overhead): exactly the A operand (32 overheads x K=2) of
