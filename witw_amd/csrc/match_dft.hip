@@ -79,6 +79,10 @@ __device__ __forceinline__ void lds_wait(f32x2& a, f32x2& b, f32x2& c, f32x2& d)
 __device__ __forceinline__ void mfma_v(f32x16& acc, float a, float b) {
     asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 }
+// first MFMA of a chain: C = 0 as an inline constant instead of 16 zeroed registers
+__device__ __forceinline__ void mfma_v0(f32x16& acc, float a, float b) {
+    asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=v"(acc) : "v"(a), "v"(b));
+}
 // 16-pass XDL write -> VALU read of the result: 18 wait states (CDNA3 ISA, manually inserted wait states)
 __device__ __forceinline__ void mfma_settle(f32x16& x, f32x16& y) {
     asm volatile("s_nop 15\n\ts_nop 3" : "+v"(x), "+v"(y));
@@ -185,10 +189,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const float* st = smem + (i & 1) * STAGE_F;
         const int bufn = (i + 1) & 1;
         const int inext = min(i + 1, NSTEP - 1);
-        f32x16 ca, cb;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) { ca[q] = 0.f; cb[q] = 0.f; }
-        asm volatile("s_nop 3" : "+v"(ca), "+v"(cb));      // VALU write -> XDL SrcC read
+        f32x16 ca, cb;      // the first MFMA of each chain starts from C = 0
         // operands as ds_read_b64: a lane holds k = 4u + 2hk and 4u + 2hk + 1 of its row, i.e. MFMA step 2u + e covers
         // k = 4u + e (lanes 0-31) and 4u + 2 + e (lanes 32-63) -- the same K permutation on both operands. Reads run two
         // groups ahead; the compiler would fuse neighbours into ds_read2_b64 (banked like ds_read_b32), hence the asm.
@@ -210,9 +211,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if ((U) + 2 < 16) lds_wait<8>(qa1[d], qb1[d], qa2[d], qb2[d]);                                                     \
             else if ((U) + 1 < 16) lds_wait<4>(qa1[d], qb1[d], qa2[d], qb2[d]);                                                \
             else lds_wait<0>(qa1[d], qb1[d], qa2[d], qb2[d]);                                                                  \
-            mfma_v(ca, qa1[d][0], qb1[d][0]);                                                                                  \
+            if ((U) == 0) mfma_v0(ca, qa1[d][0], qb1[d][0]); else mfma_v(ca, qa1[d][0], qb1[d][0]);                            \
             dma_rows((U), inext, bufn);                                                                                        \
-            mfma_v(cb, qa2[d][0], qb2[d][0]);                                                                                  \
+            if ((U) == 0) mfma_v0(cb, qa2[d][0], qb2[d][0]); else mfma_v(cb, qa2[d][0], qb2[d][0]);                            \
             mfma_v(ca, qa1[d][1], qb1[d][1]);                                                                                  \
             mfma_v(cb, qa2[d][1], qb2[d][1]);                                                                                  \
         }
