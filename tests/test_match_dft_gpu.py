@@ -121,3 +121,19 @@ def test_dft_retrieve_equals_direct_retrieve():
         assert (near | ~diff).all()
     assert diff.mean() < 0.01
     assert (np.abs(r0 - r1) <= 1).all() and (r0 != r1).mean() < 0.01
+
+
+def test_evaluation_ranks_through_the_spectral_match():
+    """cvig_fov.sharded_ranks takes the matching pass as a callable: with ops.match_fwd_dft the evaluation ranks of test()
+    (model/cvig_fov.py:543-552) equal those of the direct kernel on structured pairs."""
+    from witw_amd import cvig_fov, ops
+    gen = torch.Generator(device='cuda')
+    gen.manual_seed(11)
+    n = 700
+    ov = torch.randn((n, 16, 4, 64), generator=gen, device='cuda')
+    shifts = torch.randint(0, 64, (n,), generator=gen, device='cuda')
+    col = (torch.arange(40, device='cuda')[None, :] + shifts[:, None]) % 64
+    su = torch.gather(ov, 3, col[:, None, None, :].expand(-1, 16, 4, -1)) + 3.0 * torch.randn((n, 16, 4, 40), generator=gen, device='cuda')
+    r_direct = cvig_fov.ranks(ov, su)
+    r_dft = cvig_fov.sharded_ranks(ov, su, 0, _match=ops.match_fwd_dft)
+    assert (np.abs(r_direct - r_dft) <= 1).all() and (r_direct != r_dft).mean() < 0.01
