@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Headline benchmark: image-pairs/sec of the cvig_fov embedding + similarity hot path.
 
-    python bench.py [--gpus N --steps K --warmup W]        (N>1: launched by torch.distributed.run)
+    python bench.py [--gpus N --steps K --warmup W]        (N>1 without a launcher: starts its own N ranks; under
+                                                            torch.distributed.run it is one of them)
 
 One step = one pass of the hot path over one synthetic batch that is already resident in HBM:
   raw ground 3x224x224 + raw overhead 3x512x512 (uint8-valued fp32)
@@ -55,6 +56,32 @@ def make_inputs(cvig_fov, ops, synth, batch, fov, seed, device, channels=3):
     return ground_raw.contiguous(), ov_raw
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU) through
+    torch.distributed.run and relay rank 0's JSON line. Runs BEFORE this process has made any GPU call, and the ranks are
+    children, not an exec of this process. -> exit status (0 only if every rank exited 0 and one JSON line came back)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # dmabuf IPC: RCCL's intra-node transport needs it on this driver
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in p.stdout.splitlines():
+        if ln.startswith('{') and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line, flush=True)
+    return p.returncode if p.returncode != 0 else (0 if line is not None else 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -80,6 +107,7 @@ def main():
                     help='inference, one GPU: capture the whole step in a hipGraph (parallel.CapturedStep) and time replays; '
                          'pays off where the step is launch-bound (small --batch, bf16)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-side-blocks', action='store_true', help='only the headline measurement (no blocks for the other BASELINE configs)')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL); gloo only for 1-GPU self-tests')
     ap.add_argument('--single-device', action='store_true', help='self-test: put every rank on cuda:0')
     ap.add_argument('--cpu-pairs', type=int, default=8)
@@ -88,9 +116,12 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if 'WORLD_SIZE' not in os.environ and a.gpus > 1:
+        # plain `python bench.py --gpus N` (the reference's multi-GPU construct is one command too, nn.DataParallel inside
+        # one python invocation, model/cvig_baseline.py:339-343): this process has not touched the GPU and never will
+        sys.exit(launch_ranks(a.gpus))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit('bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d' % (a.gpus, a.gpus))
+        sys.exit('bench.py --gpus %d was started with WORLD_SIZE=%d' % (a.gpus, world))
     if a.single_device:
         local = 0
     torch.cuda.set_device(local)
@@ -269,7 +300,7 @@ def main():
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline and not train and not bf16 and not f16x3:
         out['cpu_baseline'] = cpu_baseline(a, ground_raw, ov_raw, wts, ws, step, semantic)
-    if world == 1 and not train and not bf16 and not f16x3 and not a.graph:
+    if world == 1 and not train and not bf16 and not f16x3 and not a.graph and not a.no_side_blocks:
         # the same step with fp32-grade products from fp16 hi/lo pairs on the fp16 MFMA (--precision fp16x3), reported beside
         # the headline, never as `value`: same inputs, same weights, embeddings compared with the exact-fp32 kernels'
         def step3():
@@ -296,7 +327,7 @@ def main():
             'ranks_differing_from_f32_step': int((r3[1] != ranks).sum().item()), 'overflow': bool(ops.f16x3_overflowed(device)),
             'note': 'operands carried as fp16 hi + lo, products hi*hi + lo*hi + hi*lo on v_mfma_f32_32x32x16_f16, fp32 accumulate; '
                     'held to the reference goldens at the same 1e-4 as the f32 kernels (tests/test_f16x3_gpu.py)'}
-    if world == 1 and not train and not bf16 and not f16x3 and not a.graph and not semantic and a.fov == 360 and not a.no_cpu_baseline:
+    if world == 1 and not train and not bf16 and not f16x3 and not a.graph and not semantic and a.fov == 360 and not a.no_side_blocks:
         out['config5_retrieval'] = retrieval_summary(device, cvig_fov, ops)
     if rank == 0:
         print(json.dumps(out), flush=True)

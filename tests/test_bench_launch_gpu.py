@@ -1,0 +1,103 @@
+"""`python bench.py --gpus N` as the driver runs it (no launcher around it): the parent starts N rank processes before it
+has touched the GPU and relays rank 0's one JSON line. Rehearsed on the one GPU of the test box with two ranks sharing
+cuda:0 over gloo (`--backend gloo --single-device`); on an 8-GPU node the same command line runs one rank per GPU over RCCL.
+Also the two-rank cvig_semantic driver (every rank on its own LOCAL_RANK device; the ranks share one device object between
+the module-level transforms and the encoders)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from witw_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run_bench(*args, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + list(args), env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=timeout)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout                      # exactly ONE line on stdout
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_self_launched_infer():
+    one = _run_bench('--gpus', '1', '--steps', '1', '--warmup', '1', '--batch', '8', '--no-cpu-baseline', '--no-side-blocks')
+    two = _run_bench('--gpus', '2', '--backend', 'gloo', '--single-device', '--steps', '1', '--warmup', '1', '--batch', '8',
+                     '--no-cpu-baseline')
+    assert two['n_gpus'] == 2 and two['config']['global_batch'] == 16 and two['config']['pairs_per_gpu'] == 8
+    assert two['recall']['N'] == 16 and two['unit'] == 'pairs/s' and two['value'] > 0 and two['scaling'] == 'weak'
+    assert one['n_gpus'] == 1 and one['recall']['N'] == 8
+    assert np.isfinite(two['loss']) and two['roofline']['launches'] > 0
+
+
+def test_bench_two_ranks_self_launched_train_and_retrieval():
+    tr = _run_bench('--gpus', '2', '--backend', 'gloo', '--single-device', '--mode', 'train', '--steps', '1', '--warmup', '1',
+                    '--batch', '8')
+    assert tr['n_gpus'] == 2 and 'training step' in tr['metric'] and np.isfinite(tr['loss'])
+    rt = _run_bench('--gpus', '2', '--backend', 'gloo', '--single-device', '--mode', 'retrieval', '--gallery', '2000',
+                    '--queries', '100', '--steps', '1', '--warmup', '1')
+    assert rt['n_gpus'] == 2 and rt['recall']['N'] == 4000
+    one = _run_bench('--gpus', '1', '--mode', 'retrieval', '--gallery', '2000', '--queries', '100', '--steps', '1', '--warmup', '1')
+    # the planted match of every query is in rank 0's shard and is found from both layouts
+    assert rt['recall']['topk_first_is_true_pct'] == one['recall']['topk_first_is_true_pct'] == 100.0
+    rd = _run_bench('--gpus', '2', '--backend', 'gloo', '--single-device', '--mode', 'retrieval', '--match', 'dft', '--gallery',
+                    '2000', '--queries', '100', '--steps', '1', '--warmup', '1')
+    assert rd['recall'] == rt['recall']
+
+
+def test_bench_wrong_world_size_is_refused():
+    env = dict(os.environ, WORLD_SIZE='3', RANK='0', LOCAL_RANK='0')
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode != 0 and 'WORLD_SIZE' in p.stderr
+
+
+def _semantic_worker(rank, world, port, root, out_q):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ['LOCAL_RANK'] = '0'                      # both ranks share the one GPU of the test box
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from witw_amd import cvig_fov, cvig_semantic
+        assert cvig_semantic.device == cvig_fov.device          # ONE device per process for transforms, encoders, collectives
+        os.chdir(root)
+        csv = os.path.join(root, 'scenes.csv')
+        best = cvig_semantic.train(dataset='witw', fov=70, val_quantity=4, batch_size=2, num_workers=0, num_epochs=1, csv_path=csv,
+                                   seed=3)
+        cvig_semantic.Globals.test_random_orientation = False
+        table = cvig_semantic.test(dataset='witw', fov=70, batch_size=4, num_workers=0, csv_path=csv)
+        out_q.put((rank, best, table))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_semantic_driver_two_ranks(tmp_path):
+    import torch.multiprocessing as mp
+    from tests.test_drivers2_gpu import _write_semantic_dataset
+    from tests.test_parallel_gpu import _free_port
+    root = str(tmp_path)
+    _write_semantic_dataset(root, 12)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_semantic_worker, args=(r, 2, port, root, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0][1] is not None and np.isfinite(res[0][1]) and res[0][1] == res[1][1]
+    assert res[0][2] == res[1][2]
+    sd = torch.load(os.path.join(root, 'weights', 'fov_70_surface_best.pth'))
+    assert sd['model.features.0.weight'].shape == (64, 5, 3, 3)

@@ -1,0 +1,311 @@
+"""world_size-8 CPU (gloo) tests of the two multi-GPU partitionings at the sizes BASELINE.json names them at:
+
+* config 3 (cvig_fov bs=1024 global batch over 8 ranks, model/cvig_fov.py:444-455 under the DataParallel semantics of
+  model/cvig_baseline.py:339-343): `cvig_fov.sharded_match_loss` with B = 1024, b = 128, fov 360 (We = 64) -- loss and the
+  gradients w.r.t. every rank's own embeddings equal the single-process full-batch result;
+* config 5 (gallery retrieval, model/cvig_fov.py:545-552 over the whole gallery): `cvig_fov.retrieve` / `retrieve_topk` /
+  `_merge_topk` / `parallel.all_gather_ragged` with RAGGED gallery and query shards -- ranks, top-k distances and top-k gallery
+  indices bit-identical to the unsharded call, including exact ties that straddle shards and a rank that owns no rows.
+
+The HIP kernels are replaced by CPU restatements (the `_kernels=` hook), so what runs here is exactly the host logic and
+the collectives the 8-GPU job runs; the kernels themselves are held to the oracle by the -m gpu tests."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn.functional as F
+
+from oracle import cvig_fov_oracle as O
+from witw_amd import synth
+
+WORLD = 8
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def fused_match(ov, su):
+    """correlation -> crop_overhead -> l2_distance (model/cvig_fov.py:297-363) without the [Bo,Bs,16,4,We] crop tensor
+    (17 GB at B = 1024), in fp32 and differentiable: distance = 2 (1 - max score / (|window| |surface|)); checked against
+    the oracle's materialising form below."""
+    we, w = su.shape[3], ov.shape[3]
+    x = torch.cat((ov, ov[:, :, :, :we - 1]), dim=3) if we > 1 else ov
+    sc = F.conv2d(x, su).squeeze(-2)                                     # [Bo,Bs,64], the reference's own conv2d (:312)
+    ori = torch.argmax(sc.detach(), -1)
+    col = (ov * ov).sum(dim=(1, 2))
+    col2 = torch.cat((col, col[:, :we - 1]), dim=1) if we > 1 else col
+    win = col2.unfold(1, we, 1)[:, :w].sum(-1)                           # [Bo,64] window energy per shift
+    best = torch.gather(sc, 2, ori[:, :, None]).squeeze(-1)
+    wn = torch.gather(win, 1, ori).sqrt()
+    sn = su.reshape(su.shape[0], -1).norm(dim=1)
+    return ori, 2 * (1 - best / (wn * sn[None, :]))
+
+
+def test_fused_match_equals_the_oracle():
+    for we in (64, 12):
+        ov = torch.from_numpy(synth.embeddings(21, 1, (9, 16, 4, 64))).requires_grad_(True)
+        su = torch.from_numpy(synth.embeddings(21, 2, (7, 16, 4, we))).requires_grad_(True)
+        ori, d = fused_match(ov, su)
+        g = torch.from_numpy(synth.embeddings(21, 3, (9, 7)))
+        d.backward(g)
+        ov2, su2 = ov.detach().clone().requires_grad_(True), su.detach().clone().requires_grad_(True)
+        ori_r, d_r = O.match(ov2, su2)
+        d_r.backward(g)
+        assert torch.equal(ori, ori_r)
+        np.testing.assert_allclose(d.detach().numpy(), d_r.detach().numpy(), rtol=0, atol=2e-6)
+        np.testing.assert_allclose(ov.grad.numpy(), ov2.grad.numpy(), rtol=0, atol=2e-6 * float(ov2.grad.abs().max()) + 1e-9)
+        np.testing.assert_allclose(su.grad.numpy(), su2.grad.numpy(), rtol=0, atol=2e-6 * float(su2.grad.abs().max()) + 1e-9)
+
+
+class CpuKernels(object):
+    """The op set of cvig_fov.sharded_match_loss / retrieve restated in CPU torch ops (slab formulas of csrc/loss.hip,
+    selection rules of csrc/match.hip: NaN sorts last, ties broken by the smaller gallery index, missing candidates = -1)."""
+
+    @staticmethod
+    def match_fwd(ov, su, want_score=False, want_workspace=False):
+        with torch.no_grad():
+            ori, d = fused_match(ov, su)
+        if want_workspace:
+            return ori, d, torch.zeros(1), torch.zeros(1)
+        return ori, d
+
+    @staticmethod
+    def match_bwd(ov, su, ori, score, ws, g_dist, need_ov=True, need_su=True):
+        with torch.enable_grad():               # autograd.Function.backward runs with grad mode off
+            ov = ov.detach().requires_grad_(True)
+            su = su.detach().requires_grad_(True)
+            _, d = fused_match(ov, su)
+            d.backward(g_dist)
+        return ov.grad, su.grad
+
+    @staticmethod
+    def triplet_loss_slab_fwd(dist, diag, col0, alpha):
+        b = dist.shape[1]
+        t = torch.log(1 + torch.exp(alpha * (diag[col0:col0 + b][None, :] - dist))) + \
+            torch.log(1 + torch.exp(alpha * (diag[:, None] - dist)))
+        return t.double().sum().float().reshape(1)
+
+    @staticmethod
+    def triplet_loss_slab_sig(dist, diag, col0, alpha):
+        b = dist.shape[1]
+        rowsig = torch.sigmoid(alpha * (diag[:, None] - dist)).sum(1)
+        colsig = torch.sigmoid(alpha * (diag[col0:col0 + b][None, :] - dist)).sum(0)
+        return rowsig, colsig
+
+    @staticmethod
+    def triplet_loss_slab_bwd(dist, diag, rowsig, colsig, g_loss, col0, alpha):
+        B, b = dist.shape
+        g = -torch.sigmoid(alpha * (diag[col0:col0 + b][None, :] - dist)) - torch.sigmoid(alpha * (diag[:, None] - dist))
+        idx = torch.arange(b)
+        g[col0 + idx, idx] += colsig + rowsig[col0:col0 + b]
+        return g * (g_loss * alpha / (2. * B * (B - 1)))
+
+    @staticmethod
+    def rank_count_thresh(dist, thr):
+        return (dist <= thr[None, :]).sum(0).to(torch.int32)
+
+    @staticmethod
+    def topk_smallest(dist, k, row_offset=0):
+        d = torch.where(torch.isnan(dist), torch.full_like(dist, float('inf')), dist).numpy()
+        n_g, n_q = d.shape
+        rows = np.arange(n_g)
+        vals = np.full((n_q, k), np.inf, dtype=np.float32)
+        idx = np.full((n_q, k), -1, dtype=np.int64)
+        for q in range(n_q):
+            order = np.lexsort((rows, d[:, q]))[:k]
+            vals[q, :len(order)] = d[order, q]
+            idx[q, :len(order)] = order + row_offset
+        return torch.from_numpy(vals), torch.from_numpy(idx)
+
+
+class Fp64MatchKernels(CpuKernels):
+    """For the bit-identity test: distances from the oracle's float64 fused form rounded once to fp32, so that a pair's
+    distance does not depend on which other rows share its shard (an fp32 conv2d blocks by batch shape)."""
+
+    @staticmethod
+    def match_fwd(ov, su, want_score=False, want_workspace=False):
+        return O.match_fused(ov, su)
+
+
+# ----------------------------------------------------------------------------- config 3: B = 1024 over 8 ranks
+C3_B, C3_b, C3_WE = 1024, 128, 64
+
+
+def _c3_embeddings():
+    """Pre-generated embeddings with planted matches: surface i = overhead i rolled by 5 i columns + noise."""
+    ov = torch.from_numpy(synth.embeddings(31, 1, (C3_B, 16, 4, 64)))
+    noise = torch.from_numpy(synth.embeddings(31, 2, (C3_B, 16, 4, C3_WE)))
+    shift = (5 * torch.arange(C3_B)) % 64
+    col = (torch.arange(C3_WE)[None, :] + shift[:, None]) % 64
+    su = torch.gather(ov, 3, col[:, None, None, :].expand(-1, 16, 4, -1)) + 3.0 * noise
+    return ov, su.contiguous()
+
+
+def _c3_worker(rank, world, port, out_q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from witw_amd import cvig_fov
+        torch.set_num_threads(1)
+        ov, su = _c3_embeddings()
+        sl = slice(rank * C3_b, (rank + 1) * C3_b)
+        ov_l, su_l = ov[sl].clone().requires_grad_(True), su[sl].clone().requires_grad_(True)
+        loss, ori, d = cvig_fov.sharded_match_loss(ov_l, su_l, _kernels=CpuKernels)
+        assert tuple(d.shape) == (C3_B, C3_b) and tuple(ori.shape) == (C3_B, C3_b)
+        loss.backward()
+        out_q.put((rank, loss.item(), ov_l.grad.numpy().copy(), su_l.grad.numpy().copy(), ori.numpy().copy(), d.numpy().copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_config3_sharded_match_loss_1024_over_8_ranks():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_c3_worker, args=(r, WORLD, port, q)) for r in range(WORLD)]
+    for p in procs:
+        p.start()
+    # the single-process result while the ranks work: full [1024,1024] matrix -> triplet_loss -> autograd
+    torch.set_num_threads(2)
+    ov, su = _c3_embeddings()
+    ov.requires_grad_(True)
+    su.requires_grad_(True)
+    ori_f, d_f = fused_match(ov, su)
+    loss_f = O.triplet_loss(d_f)                 # model/cvig_fov.py:366-382, normaliser 2 B (B-1) with B = 1024
+    loss_f.backward()
+    res = sorted([q.get(timeout=900) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert (ori_f.diagonal() == (5 * torch.arange(C3_B)) % 64).float().mean() > 0.9     # the planted shifts are found
+    gov, gsu = ov.grad.numpy(), su.grad.numpy()
+    for (rank, loss, g_ov, g_su, ori, d) in res:
+        sl = slice(rank * C3_b, (rank + 1) * C3_b)
+        assert abs(loss - loss_f.item()) <= 2e-6 * abs(loss_f.item()), (rank, loss, loss_f.item())
+        np.testing.assert_array_equal(ori, ori_f[:, sl].numpy())
+        np.testing.assert_allclose(d, d_f.detach()[:, sl].numpy(), rtol=0, atol=2e-6)
+        # the overhead gradient of a rank's rows collects terms from ALL eight slabs (reduce-scatter); 1e-5 of its largest entry
+        np.testing.assert_allclose(g_ov, gov[sl], rtol=0, atol=1e-5 * float(np.abs(gov[sl]).max()))
+        np.testing.assert_allclose(g_su, gsu[sl], rtol=0, atol=1e-5 * float(np.abs(gsu[sl]).max()))
+
+
+# ----------------------------------------------------------------------------- config 5: sharded retrieval, ragged shards
+C5_G, C5_Q, C5_WE, C5_K = 1003, 203, 12, 10
+# gallery rows per rank: ragged on purpose, and rank 5 owns nothing
+C5_SPLIT = [130, 1, 257, 64, 200, 0, 301, 50]
+
+
+def _c5_data():
+    gal = torch.from_numpy(synth.embeddings(41, 1, (C5_G, 16, 4, 64)))
+    gal[700] = gal[3]          # exact duplicates in different shards: equal distances, the smaller gallery index must win
+    gal[999] = gal[3]
+    gal[131] = gal[130]        # duplicates across the rank 0 / rank 1 / rank 2 boundaries
+    gal[132] = gal[130]
+    noise = torch.from_numpy(synth.embeddings(41, 2, (C5_Q, 16, 4, C5_WE)))
+    qry = torch.stack([torch.roll(gal[i], -7 * i, dims=2)[:, :, :C5_WE] for i in range(C5_Q)]) + 2.0 * noise
+    return gal.contiguous(), qry.contiguous()
+
+
+def _c5_worker(rank, world, port, out_q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from witw_amd import cvig_fov, parallel
+        torch.set_num_threads(1)
+        gal, qry = _c5_data()
+        g0 = sum(C5_SPLIT[:rank])
+        g1 = g0 + C5_SPLIT[rank]
+        # the queries arrive sharded too (test() embeds a contiguous share per rank) and are replicated raggedly
+        q0, q1 = parallel.shard_range(C5_Q)
+        q_all = parallel.all_gather_ragged(qry[q0:q1].contiguous())
+        assert torch.equal(q_all, qry)
+        empty = parallel.all_gather_ragged(qry[:0].contiguous() if rank != 2 else qry[:3].contiguous())
+        assert torch.equal(empty, qry[:3])                       # ranks that contribute nothing
+        ranks, v, i = cvig_fov.retrieve(gal[g0:g1], q_all, k=C5_K, shard_begin=g0, query_chunk=64, _kernels=Fp64MatchKernels)
+        v2, i2 = cvig_fov.retrieve_topk(gal[g0:g1], q_all, k=C5_K, shard_begin=g0, query_chunk=50, _kernels=Fp64MatchKernels)
+        assert torch.equal(v, v2) and torch.equal(i, i2)
+        r2 = cvig_fov.sharded_ranks(gal[g0:g1], q_all, g0, query_chunk=64, _match=Fp64MatchKernels.match_fwd,
+                                    _count=Fp64MatchKernels.rank_count_thresh)
+        out_q.put((rank, np.asarray(ranks), v.numpy().copy(), i.numpy().copy(), np.asarray(r2)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_config5_sharded_retrieve_ragged_over_8_ranks():
+    assert sum(C5_SPLIT) == C5_G and len(C5_SPLIT) == WORLD
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_c5_worker, args=(r, WORLD, port, q)) for r in range(WORLD)]
+    for p in procs:
+        p.start()
+    from witw_amd import cvig_fov
+    gal, qry = _c5_data()
+    ranks_1, v_1, i_1 = cvig_fov.retrieve(gal, qry, k=C5_K, query_chunk=64, _kernels=Fp64MatchKernels)     # world 1
+    # the reference's own loop body (model/cvig_fov.py:545-552) on the same data
+    np.testing.assert_array_equal(ranks_1, O.ranks(gal, qry))
+    # top-k = the reference distances ordered by (distance, gallery index)
+    _, d_all = O.match_fused(gal, qry)
+    for qi in (0, 3, 130, 202):
+        order = np.lexsort((np.arange(C5_G), d_all[:, qi].numpy()))[:C5_K]
+        np.testing.assert_array_equal(i_1[qi].numpy(), order)
+    assert list(i_1[3, :3].numpy()) == [3, 700, 999] and v_1[3, 0] == v_1[3, 1] == v_1[3, 2]     # the planted tie, index order
+    assert list(i_1[130, :3].numpy()) == [130, 131, 132]
+    assert ranks_1[3] == 3 and ranks_1[130] == 3                  # ties counted pessimistically (d <= d_true)
+    res = sorted([q.get(timeout=600) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for (rank, ranks, v, i, r2) in res:
+        np.testing.assert_array_equal(ranks, ranks_1)
+        np.testing.assert_array_equal(i, i_1.numpy())
+        np.testing.assert_array_equal(v, v_1.numpy())
+        np.testing.assert_array_equal(r2, ranks_1)
+
+
+def _c5_small_worker(rank, world, port, out_q):
+    """More ranks than candidates: a 5-row gallery over 8 ranks, k = 10 > rows."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from witw_amd import cvig_fov, parallel
+        torch.set_num_threads(1)
+        gal, qry = _c5_data()
+        gal, qry = gal[:5], qry[:5]
+        g0, g1 = parallel.shard_range(5)
+        ranks, v, i = cvig_fov.retrieve(gal[g0:g1], qry, k=C5_K, shard_begin=g0, _kernels=Fp64MatchKernels)
+        out_q.put((rank, np.asarray(ranks), v.numpy().copy(), i.numpy().copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_config5_more_ranks_than_gallery_rows():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_c5_small_worker, args=(r, WORLD, port, q)) for r in range(WORLD)]
+    for p in procs:
+        p.start()
+    from witw_amd import cvig_fov
+    gal, qry = _c5_data()
+    ranks_1, v_1, i_1 = cvig_fov.retrieve(gal[:5], qry[:5], k=C5_K, _kernels=Fp64MatchKernels)
+    assert (i_1[:, 5:] == -1).all() and torch.isinf(v_1[:, 5:]).all() and (i_1[:, :5] >= 0).all()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for (rank, ranks, v, i) in res:
+        np.testing.assert_array_equal(ranks, ranks_1)
+        np.testing.assert_array_equal(i, i_1.numpy())
+        np.testing.assert_array_equal(v, v_1.numpy())

@@ -643,6 +643,9 @@ def sharded_ranks(overhead_shard, surface_all, shard_begin, query_chunk=4096, _m
     out = torch.zeros((n_q,), dtype=torch.int32, device=surface_all.device)
     for q0 in range(0, n_q, query_chunk):
         q1 = min(n_q, q0 + query_chunk)
+        if n_g == 0:         # a rank without gallery rows still takes part in the exchanges
+            parallel.all_reduce_sum_(torch.zeros((q1 - q0,), dtype=torch.float32, device=surface_all.device))
+            continue
         _, dist = _match(overhead_shard.contiguous(), surface_all[q0:q1].contiguous())   # [n_g, q]
         qi = torch.arange(q0, q1, device=dist.device)
         own = (qi >= shard_begin) & (qi < shard_begin + n_g)
@@ -654,36 +657,18 @@ def sharded_ranks(overhead_shard, surface_all, shard_begin, query_chunk=4096, _m
     return out.cpu().numpy().astype('int64')
 
 
-def retrieve_topk(overhead_shard, surface_all, k=10, shard_begin=0, query_chunk=4096, method='direct'):
+def retrieve_topk(overhead_shard, surface_all, k=10, shard_begin=0, query_chunk=4096, method='direct', _kernels=None):
     """Top-k retrieval (BASELINE config C5): for every query the k nearest gallery rows by the fused
     orientation-search chord distance, ordered by (distance, gallery index). With the gallery sharded over
     ranks each rank ranks its shard, the [N,k] candidate lists are all-gathered and merged by the same kernel.
     -> (distances f32 [N,k], gallery indices int64 [N,k]) on the device, identical on every rank."""
-    from . import parallel
-    n_q = surface_all.shape[0]
-    vals, idxs = [], []
-    if method not in ('direct', 'dft'):
-        raise ValueError("retrieve_topk: method must be 'direct' or 'dft'")
-    gallery = overhead_shard.contiguous()
-    spec_g = ops.match_spectrum(gallery) if method == 'dft' else None       # see retrieve()
-    for q0 in range(0, n_q, query_chunk):
-        q1 = min(n_q, q0 + query_chunk)
-        if method == 'dft':
-            _, dist = ops.match_fwd_dft(gallery, surface_all[q0:q1].contiguous(), spec_ov=spec_g, want_orientation=False)
-        else:
-            _, dist = ops.match_fwd(gallery, surface_all[q0:q1].contiguous())
-        v, i = ops.topk_smallest(dist, k, shard_begin)
-        vals.append(v)
-        idxs.append(i)
-    v, i = torch.cat(vals), torch.cat(idxs)
-    if parallel.world() > 1:
-        v, i = _merge_topk(v, i, k)
-    return v, i
+    return retrieve(overhead_shard, surface_all, k, shard_begin, query_chunk, method, _kernels, _want_ranks=False)[1:]
 
 
-def _merge_topk(v, i, k):
+def _merge_topk(v, i, k, _kernels=None):
     """All-gather per-shard [N,k] candidate lists and merge them on (distance, global gallery index)."""
     from . import parallel
+    kn = _kernels or ops
     w = parallel.world()
     n_q = v.shape[0]
     v_all = parallel._all_gather_cat(v.unsqueeze(0))            # [w, N, k]
@@ -696,15 +681,18 @@ def _merge_topk(v, i, k):
     order = torch.argsort(torch.where(cand_i < 0, torch.full_like(cand_i, 2 ** 62), cand_i), dim=0, stable=True)
     cand_v = torch.gather(cand_v, 0, order).contiguous()
     cand_i = torch.gather(cand_i, 0, order)
-    v, pos = ops.topk_smallest(cand_v, k)
+    v, pos = kn.topk_smallest(cand_v, k)
     return v, torch.gather(cand_i.t(), 1, pos.clamp(min=0))
 
 
-def retrieve(overhead_shard, surface_all, k=10, shard_begin=0, query_chunk=4096, method='direct'):
+def retrieve(overhead_shard, surface_all, k=10, shard_begin=0, query_chunk=4096, method='direct', _kernels=None,
+             _want_ranks=True):
     """sharded_ranks + retrieve_topk from ONE matching pass per query chunk (config C5: the pass is
     2*64*E FLOP per (gallery row, query) and dominates). -> (ranks int64 [N] on the host, distances f32 [N,k],
-    gallery indices int64 [N,k] on the device), identical on every rank."""
+    gallery indices int64 [N,k] on the device), identical on every rank. The gallery may be sharded raggedly (any
+    number of rows per rank, including none); `_kernels` swaps the op set (CPU tests of the collective algebra)."""
     from . import parallel
+    kn = _kernels or ops
     n_q, n_g = surface_all.shape[0], overhead_shard.shape[0]
     counts = torch.zeros((n_q,), dtype=torch.int32, device=surface_all.device)
     vals, idxs = [], []
@@ -713,27 +701,40 @@ def retrieve(overhead_shard, surface_all, k=10, shard_begin=0, query_chunk=4096,
         raise ValueError("retrieve: method must be 'direct' or 'dft'")
     # 'dft': the orientation search through the row spectra (ops.match_fwd_dft, 21k instead of 524k FLOP per pair); the
     # gallery's spectra are computed once. Scores agree with the direct sum to fp32 rounding.
-    spec_g = ops.match_spectrum(gallery) if method == 'dft' else None
+    spec_g = kn.match_spectrum(gallery) if method == 'dft' and n_g else None
     for q0 in range(0, n_q, query_chunk):
         q1 = min(n_q, q0 + query_chunk)
-        if method == 'dft':
-            _, dist = ops.match_fwd_dft(gallery, surface_all[q0:q1].contiguous(), spec_ov=spec_g, want_orientation=False)
+        nq = q1 - q0
+        if n_g == 0:        # a rank without gallery rows (more ranks than rows): nothing to match, empty candidate lists
+            dist = torch.empty((0, nq), dtype=torch.float32, device=surface_all.device)
+        elif method == 'dft':
+            _, dist = kn.match_fwd_dft(gallery, surface_all[q0:q1].contiguous(), spec_ov=spec_g, want_orientation=False)
         else:
-            _, dist = ops.match_fwd(gallery, surface_all[q0:q1].contiguous())            # [n_g, q]
-        qi = torch.arange(q0, q1, device=dist.device)
-        own = (qi >= shard_begin) & (qi < shard_begin + n_g)
-        row = (qi - shard_begin).clamp(0, n_g - 1)
-        d_true = torch.where(own, dist[row, qi - q0], torch.zeros_like(dist[0]))
-        parallel.all_reduce_sum_(d_true)
-        counts[q0:q1] = ops.rank_count_thresh(dist, d_true.contiguous())
-        v, i = ops.topk_smallest(dist, k, shard_begin)
+            _, dist = kn.match_fwd(gallery, surface_all[q0:q1].contiguous())            # [n_g, q]
+        if _want_ranks:
+            qi = torch.arange(q0, q1, device=dist.device)
+            own = (qi >= shard_begin) & (qi < shard_begin + n_g)
+            if n_g:
+                row = (qi - shard_begin).clamp(0, n_g - 1)
+                d_true = torch.where(own, dist[row, qi - q0], torch.zeros_like(dist[0]))
+            else:
+                d_true = torch.zeros((nq,), dtype=torch.float32, device=dist.device)
+            parallel.all_reduce_sum_(d_true)
+            if n_g:
+                counts[q0:q1] = kn.rank_count_thresh(dist, d_true.contiguous())
+        if n_g:
+            v, i = kn.topk_smallest(dist, k, shard_begin)
+        else:
+            v = torch.full((nq, k), float('inf'), dtype=torch.float32, device=dist.device)
+            i = torch.full((nq, k), -1, dtype=torch.int64, device=dist.device)
         vals.append(v)
         idxs.append(i)
-    parallel.all_reduce_sum_(counts)
+    if _want_ranks:
+        parallel.all_reduce_sum_(counts)
     v, i = torch.cat(vals), torch.cat(idxs)
     if parallel.world() > 1:
-        v, i = _merge_topk(v, i, k)
-    return counts.cpu().numpy().astype('int64'), v, i
+        v, i = _merge_topk(v, i, k, _kernels)
+    return (counts.cpu().numpy().astype('int64') if _want_ranks else None), v, i
 
 
 class _ShardedMatchLossFn(torch.autograd.Function):
@@ -877,15 +878,19 @@ class GpuPreprocess(object):
     channels = 3
     normalization = None      # class used for the normalisation step (cvig_semantic overrides both)
 
-    def __init__(self, dataset, fov=360, random_orientation=True):
+    def __init__(self, dataset, fov=360, random_orientation=True, device=None):
         self.resize = Resize(dataset, fov, random_orientation)
         self.norm = (self.normalization or ImageNormalization)()
         self.polar = PolarTransform()
+        self.device = device      # where host images go (train() / test() pass their module's `device`); None = cvig_fov.device
 
     def __call__(self, batch):
         s, o = [], []
         c = self.channels
+        dev = self.device
         for su, ov in zip(batch['surface'], batch['overhead']):
+            if dev is not None and not su.is_cuda:
+                su, ov = su.to(dev), ov.to(dev)
             d = self.resize({'surface': su[:c], 'overhead': ov[:c]})
             s.append(d['surface'])
             o.append(d['overhead'])
@@ -972,7 +977,7 @@ def train(dataset='cvusa', fov=360, val_quantity=1000, batch_size=64, num_worker
     writer = _writer('runs/{}/train/{}/{}'.format(dataset, fov, datetime.now().strftime("%Y%m%d-%H%M%S"))) if rank == 0 \
         else _NullWriter()
     csv_path = csv_path or Globals.dataset_paths[dataset]['train']
-    prep = GpuPreprocess(dataset, fov)
+    prep = GpuPreprocess(dataset, fov, device=device)
     trainval_set = ImagePairDataset(dataset=dataset, csv_path=csv_path)
     split_gen = torch.Generator().manual_seed(seed) if world > 1 else None      # every rank must draw the same split
     train_set, val_set = torch.utils.data.random_split(trainval_set, [len(trainval_set) - val_quantity, val_quantity],
@@ -1058,7 +1063,7 @@ def test(dataset='cvusa', fov=360, batch_size=64, num_workers=8, csv_path=None, 
     csv_path = csv_path or Globals.dataset_paths[dataset]['test']
     # the reference crops test panoramas at a random orientation too (:495-499); Globals.test_random_orientation = False
     # makes the evaluation repeatable
-    prep = GpuPreprocess(dataset, fov, getattr(Globals, 'test_random_orientation', True))
+    prep = GpuPreprocess(dataset, fov, getattr(Globals, 'test_random_orientation', True), device=device)
     test_set = ImagePairDataset(dataset=dataset, csv_path=csv_path)
     # under torch.distributed every rank embeds a contiguous shard of the test set and keeps its gallery rows
     shard_begin, shard_end = parallel.shard_range(len(test_set))

@@ -28,7 +28,7 @@ class Globals(_fov.Globals):
     }
 
 
-device = torch.device('cuda:0' if torch.cuda.is_available() else 'cpu')  # reference uses cuda:1 (:609)
+device = _fov.device      # the reference pins cuda:1 (:609); here ONE device per process, cuda:LOCAL_RANK, shared with cvig_fov's transforms
 
 
 class ImageNormalization(_fov.ImageNormalization):
