@@ -298,14 +298,15 @@ TRAINABLE = (17, 19, 21, 23, 25, 27)   # model/cvig_fov.py:275-278
 
 
 def train_step(surface, overhead, w_surface, w_overhead, drop_surface=None, drop_overhead=None, lr=1.E-5,
-               adam_state=None):
+               adam_state=None, trainable=None):
     """One iteration of the loop body model/cvig_fov.py:444-461 with torch autograd on the CPU:
     forward (train mode, injected Dropout2d scales) -> correlation/crop/l2_distance -> triplet_loss ->
     backward -> Adam(lr) step over the trainable layers. w_*: {idx: (w, b)} torch tensors (updated in place).
     Returns (loss, orientation, distance, grads {('s'|'o', idx): (dw, db)})."""
+    trainable = TRAINABLE if trainable is None else trainable      # cvig_semantic: (0,) + TRAINABLE (model/cvig_semantic.py:308)
     leaves = {}
     for tag, w in (('s', w_surface), ('o', w_overhead)):
-        for idx in TRAINABLE:
+        for idx in trainable:
             for t in w[idx]:
                 t.requires_grad_(True)
                 t.grad = None

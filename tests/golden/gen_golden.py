@@ -269,23 +269,47 @@ def main():
             print('  %-28s %8d bytes' % (f, os.path.getsize(os.path.join(HERE, f))))
 
 
-if __name__ == '__main__' and not any(a in sys.argv for a in ('--trainstep', '--baseline', '--baseline-train')):
+if __name__ == '__main__' and not any(a in sys.argv for a in ('--trainstep', '--trainstep-semantic', '--baseline', '--baseline-train')):
     main()
 
 
-def gen_trainstep():
-    """One iteration of the reference's training loop body (model/cvig_fov.py:444-461) on a tiny batch,
-    Dropout2d masks captured, then one torch.optim.Adam step (lr as :418). Stores the loss, per-parameter
-    gradient norms and strided samples of gradients and of updated parameters."""
-    fov, sem, base = import_reference()
-    fov.device = torch.device('cpu')
-    weights = synth.fov_dsm_weights(SEED + 1)
-    B, ws = 3, 96      # fov 67.5 deg -> int(67.5/360*512) = 96 -> embedding width 12
-    xs = torch.from_numpy(synth.normalized_images(SEED, 20, (B, 3, 128, ws)))
-    xo = torch.from_numpy(synth.normalized_images(SEED, 21, (B, 3, 128, 512)))
-    se = build_ref_encoder(fov, False, weights).train()
-    oe = build_ref_encoder(fov, True, weights).train()
-    captured = {}
+TAU = 1e-4      # |pre-activation| (or max-pool top-2 gap), relative to max(1, std of the layer), below which a ReLU gate (pool route) is listed as fragile
+
+
+def gate_records(res, tag, z_by_layer, pooled, dropped):
+    """For every ReLU of the reference whose gate shapes a gradient: per-(sample,channel) counts of open gates, and the
+    FRAGILE positions -- |pre-activation| < TAU -- with the side the reference took. For a ReLU followed by MaxPool2d (the
+    build fuses both into the conv epilogue and gates on the pooled value): the same on the window maximum, plus the arg-max
+    position (dy*2+dx) summed per (sample,channel) over the open windows and listed where the top-2 gap is < TAU."""
+    for idx, z in z_by_layer.items():
+        tau = TAU * max(1.0, float(z.std()))          # absolute 1e-4 at unit scale; the early VGG layers run at larger magnitudes
+        res['tau:%s:%d' % (tag, idx)] = np.float32(tau)
+        if idx in pooled:
+            b, c, h, w = z.shape
+            win = z[:, :, :h // 2 * 2, :w // 2 * 2].reshape(b, c, h // 2, 2, w // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(b, c, h // 2, w // 2, 4)
+            zmax, code = win.max(-1)            # first maximum wins, as MaxPool2d does
+            top2 = win.topk(2, -1).values
+            gap = top2[..., 0] - top2[..., 1]
+            gate = zmax > 0
+            res['pcsum:%s:%d' % (tag, idx)] = (code * gate).sum(dim=(2, 3)).numpy().astype(np.int64)
+            pf = torch.nonzero(((gap < tau) & gate).reshape(-1)).squeeze(1)
+            res['pfrag:%s:%d' % (tag, idx)] = pf.numpy().astype(np.int64)
+            res['pfragv:%s:%d' % (tag, idx)] = code.reshape(-1)[pf].numpy().astype(np.uint8)
+            z = zmax
+        gate = z > 0
+        res['gcount:%s:%d' % (tag, idx)] = gate.sum(dim=(2, 3)).numpy().astype(np.int32)
+        live = torch.ones_like(z, dtype=torch.bool)
+        if idx in dropped:          # channels Dropout2d zeroed are exact zeros with no gradient: not fragile
+            live = (torch.from_numpy(dropped[idx]) != 0)[:, :, None, None].expand_as(z)
+        fr = torch.nonzero(((z.abs() < tau) & live).reshape(-1)).squeeze(1)
+        res['gfrag:%s:%d' % (tag, idx)] = fr.numpy().astype(np.int64)
+        res['gfragv:%s:%d' % (tag, idx)] = gate.reshape(-1)[fr].numpy().astype(np.uint8)
+
+
+def run_reference_step(mod, se, oe, xs, xo, lr, relu_layers, pooled, nsamp):
+    """One iteration of the reference's training loop body (model/cvig_fov.py:444-461; cvig_semantic.py:475-492) with the
+    Dropout2d masks and the ReLU pre-activations captured, then one torch.optim.Adam step."""
+    captured, zs = {}, {'s': {}, 'o': {}}
 
     def mk_hook(tag, i):
         def hook(m, inp, outp):
@@ -296,44 +320,134 @@ def gen_trainstep():
             sc = (xo_.reshape(b, c, -1).gather(2, pos) / fi.gather(2, pos)).squeeze(-1).numpy()
             captured[(tag, i)] = np.where(np.abs(sc) < 1e-6, 0.0, 1.25).astype(np.float32)
         return hook
+
+    def mk_pre(tag, i):
+        def pre(m, inp):
+            zs[tag][i] = inp[0].detach().clone()        # the ReLU is in-place: copy its input first
+        return pre
     for tag, e in (('s', se), ('o', oe)):
         for i in (17, 19, 21):
             e.model.features[i].postlayer.register_forward_hook(mk_hook(tag, i))
+        for i in relu_layers:
+            assert isinstance(e.model.features[i + 1], nn.ReLU)
+            e.model.features[i + 1].register_forward_pre_hook(mk_pre(tag, i))
     params = [p for p in list(se.parameters()) + list(oe.parameters())]
-    opt = torch.optim.Adam(params, lr=1.E-5)
+    opt = torch.optim.Adam(params, lr=lr)
     torch.manual_seed(77)
     s_emb = se(xs)
     o_emb = oe(xo)
-    ori = fov.correlation(o_emb, s_emb)
-    crop = fov.crop_overhead(o_emb, ori, s_emb.shape[3])
-    dist = fov.l2_distance(crop, s_emb)
-    loss = fov.triplet_loss(dist)
+    ori = mod.correlation(o_emb, s_emb)
+    crop = mod.crop_overhead(o_emb, ori, s_emb.shape[3])
+    dist = mod.l2_distance(crop, s_emb)
+    loss = mod.triplet_loss(dist)
     opt.zero_grad()
     loss.backward()
-    res = {'seed': SEED, 'B': B, 'ws': ws, 'loss': loss.detach().numpy(), 'orientation': ori.numpy(),
-           'distance': dist.detach().numpy()}
+    res = {'loss': loss.detach().numpy(), 'orientation': ori.numpy(), 'distance': dist.detach().numpy(),
+           'embed_s': s_emb.detach().numpy(), 'embed_o': o_emb.detach().numpy(), 'tau': np.float32(TAU)}
+    sc = F.conv2d(torch.cat((o_emb, o_emb[:, :, :, :s_emb.shape[3] - 1]), 3), s_emb).squeeze(-2).detach()
+    top2 = sc.topk(2, -1).values
+    res['min_gap'] = np.float32((top2[..., 0] - top2[..., 1]).min().item())
+    bound = o_emb.detach().flatten(1).norm(dim=1)[:, None] * s_emb.detach().flatten(1).norm(dim=1)[None, :]
+    res['min_gap_rel'] = np.float32(((top2[..., 0] - top2[..., 1]) / bound).min().item())
+    assert res['min_gap_rel'] > 2e-5, res['min_gap_rel']        # orientations well clear of fp32 summation-order noise (~2e-6)
     for (tag, i), v in captured.items():
         res['drop_%s_%d' % (tag, i)] = v
+    for tag in 'so':
+        gate_records(res, tag, zs[tag], pooled, {i: captured[(tag, i)] for i in (17, 19, 21)})
     named = [('s.' + n, p) for n, p in se.named_parameters()] + [('o.' + n, p) for n, p in oe.named_parameters()]
     names = []
+    before = {}
     for n, p in named:
         if p.grad is None or 'classifier' in n:
             continue
         names.append(n)
         g = p.grad.detach().reshape(-1)
         res['gnorm:' + n] = np.float64(g.double().norm().item())
-        res['gsamp:' + n] = g[::max(1, g.numel() // 257)].numpy()
+        res['gsamp:' + n] = g[::max(1, g.numel() // nsamp)].numpy()
+        before[n] = p.detach().reshape(-1)[::max(1, p.numel() // nsamp)].clone()
     opt.step()
     for n, p in named:
         if n in names:
-            res['psamp:' + n] = p.detach().reshape(-1)[::max(1, p.numel() // 257)].numpy()
+            after = p.detach().reshape(-1)[::max(1, p.numel() // nsamp)]
+            res['psamp:' + n] = after.numpy()
+            res['dsamp:' + n] = (after - before[n]).numpy()      # what the Adam step moved (fp32 subtraction, as stored)
     res['names'] = np.array(names)
-    np.savez(os.path.join(HERE, 'trainstep.npz'), **res)
-    print('trainstep.npz: loss %.6f, %d trainable tensors' % (loss.item(), len(names)))
+    return res, loss
+
+
+def baseline_gate_records(res, tag, z_by_layer):
+    """LeakyReLU(0.2) gates of cvig_baseline (model/cvig_baseline.py:267-273; torch: derivative 1 where the conv output is
+    > 0, else 0.2): per-(sample,channel) counts of positive conv outputs and the fragile positions, as gate_records()."""
+    for i, z in z_by_layer.items():
+        tau = TAU * max(1.0, float(z.std()))
+        res['tau:%s:%d' % (tag, i)] = np.float32(tau)
+        gate = z > 0
+        res['gcount:%s:%d' % (tag, i)] = gate.sum(dim=(2, 3)).numpy().astype(np.int32)
+        fr = torch.nonzero((z.abs() < tau).reshape(-1)).squeeze(1)
+        res['gfrag:%s:%d' % (tag, i)] = fr.numpy().astype(np.int64)
+        res['gfragv:%s:%d' % (tag, i)] = gate.reshape(-1)[fr].numpy().astype(np.uint8)
+
+
+def gen_trainstep(out_name='trainstep.npz', B=3, ws=96, wseed=SEED + 1, streams=(20, 21)):
+    """The reference's cvig_fov training step on a tiny batch: loss, per-parameter gradient norms and strided samples of
+    gradients, of updated parameters and of the update itself, ReLU gate records of layers 17-25 (gate_records).
+    trainstep.npz: B=3, fov 67.5 (surface width 96 -> embedding width 12); trainstep360.npz: the config-2 geometry
+    (fov 360: surface width 512 -> embedding width 64), B=4."""
+    fov, sem, base = import_reference()
+    fov.device = torch.device('cpu')
+    weights = synth.fov_dsm_weights(wseed)
+    xs = torch.from_numpy(synth.normalized_images(SEED, streams[0], (B, 3, 128, ws)))
+    xo = torch.from_numpy(synth.normalized_images(SEED, streams[1], (B, 3, 128, 512)))
+    se = build_ref_encoder(fov, False, weights).train()
+    oe = build_ref_encoder(fov, True, weights).train()
+    res, loss = run_reference_step(fov, se, oe, xs, xo, 1.E-5, (17, 19, 21, 23, 25), (), 257)
+    res.update({'seed': SEED, 'B': B, 'ws': ws, 'wseed': wseed, 'streams': np.array(streams)})
+    np.savez_compressed(os.path.join(HERE, out_name), **res)
+    print('%s: loss %.6f, %d trainable tensors, min top-2 score gap %.3g, fragile gates %s' % (
+        out_name, loss.item(), len(res['names']), float(res['min_gap']),
+        {k: len(v) for k, v in res.items() if k.startswith('gfrag:')}))
+
+
+def gen_semantic_trainstep():
+    """The reference's cvig_semantic training step (model/cvig_semantic.py:475-492: 5-channel encoders, layer 0 trainable,
+    so the backward crosses all 13 convs and the 3 max-pools). B=2, surface 5x128x64, overhead 5x128x512."""
+    fov, sem, base = import_reference()
+    sem.device = torch.device('cpu')
+    seed = 321
+    w5 = synth.fov_dsm_weights(seed, in_channels=5)
+    w3 = synth.fov_dsm_weights(seed, in_channels=3)
+    B = 2
+    xs = torch.from_numpy(synth.normalized_images(seed, 1, (B, 5, 128, 64)))
+    xo = torch.from_numpy(synth.normalized_images(seed, 2, (B, 5, 128, 512)))
+    encs = []
+    for circ in (False, True):
+        torch.hub.load = lambda *a, **k: FakeVGG(w3)
+        e = sem.FOV_DSM(circ_padding=circ)
+        with torch.no_grad():
+            for i, (w, b) in w5.items():            # synth's 5-channel set defines every layer (layer 0: all 5 input channels)
+                c = conv_of(e.model.features[i])
+                assert tuple(c.weight.shape) == w.shape, (i, c.weight.shape, w.shape)
+                c.weight.copy_(torch.from_numpy(w))
+                c.bias.copy_(torch.from_numpy(b))
+        encs.append(e.train())
+    relu_layers = (0, 2, 5, 7, 10, 12, 14, 17, 19, 21, 23, 25)
+    res, loss = run_reference_step(sem, encs[0], encs[1], xs, xo, 1.E-5, relu_layers, (2, 7, 14), 257)
+    res.update({'seed': seed, 'B': B, 'ws': 64})
+    del res['embed_s'], res['embed_o']
+    np.savez_compressed(os.path.join(HERE, 'trainstep_semantic.npz'), **res)
+    print('trainstep_semantic.npz: loss %.6f, %d trainable tensors, fragile gates %s, fragile routes %s' % (
+        loss.item(), len(res['names']), {k: len(v) for k, v in res.items() if k.startswith('gfrag:')},
+        {k: len(v) for k, v in res.items() if k.startswith('pfrag:')}))
 
 
 if __name__ == '__main__' and '--trainstep' in sys.argv:
     gen_trainstep()
+    # streams picked so that no orientation sits on a near-tie: smallest top-2 score gap 4e-5 |ov||su| (fp32 summation
+    # orders differ by ~2e-6 |ov||su|; streams 22..27 give 1e-6..1e-5)
+    gen_trainstep('trainstep360.npz', B=4, ws=512, wseed=SEED + 2, streams=(28, 29))
+
+if __name__ == '__main__' and '--trainstep-semantic' in sys.argv:
+    gen_semantic_trainstep()
 
 
 def gen_baseline():
@@ -401,6 +515,14 @@ def gen_baseline_train():
                 bn.running_mean.copy_(torch.from_numpy(q['mean']))
                 bn.running_var.copy_(torch.from_numpy(q['var']))
         encs[tag] = (enc.train(), torch.from_numpy(synth.images_u8(SEED, stream, (B, 3, hw, hw))))
+    zs = {'surface': {}, 'overhead': {}}
+
+    def mk_pre(tag):
+        def pre(m, inp):                       # the one LeakyReLU module is called once per block, in order
+            zs[tag][len(zs[tag]) + 1] = inp[0].detach().clone()
+        return pre
+    for tag in zs:
+        encs[tag][0].activation.register_forward_pre_hook(mk_pre(tag))
     params = list(encs['surface'][0].parameters()) + list(encs['overhead'][0].parameters())
     opt = torch.optim.Adam(params)                                   # default lr 1e-3, :349
     s_emb = encs['surface'][0](encs['surface'][1])
@@ -410,7 +532,17 @@ def gen_baseline_train():
     loss.backward()
     res = {'seed': SEED, 'B': B, 'loss': loss.detach().numpy(), 'embed_surface': s_emb.detach().numpy(),
            'embed_overhead': o_emb.detach().numpy()}
+    for tag in zs:
+        assert sorted(zs[tag]) == list(range(1, 8))
+        baseline_gate_records(res, tag, zs[tag])
+    # the hinge terms relu(d_ap^2 - d_an^2 + margin) (:304-313) must not sit on their kink either
+    D = ((s_emb.detach()[:, None, :] - o_emb.detach()[None, :, :]) ** 2).sum(-1)
+    t1 = (D.diagonal()[:, None] - D + 1.0)[~torch.eye(B, dtype=torch.bool)]
+    t2 = (D.diagonal()[None, :] - D + 1.0)[~torch.eye(B, dtype=torch.bool)]
+    res['min_abs_hinge'] = np.float32(min(t1.abs().min().item(), t2.abs().min().item()))
+    assert res['min_abs_hinge'] > 1e-3, res['min_abs_hinge']
     names = []
+    before = {}
     for tag in ('surface', 'overhead'):
         for n, p in encs[tag][0].named_parameters():
             key = '%s.%s' % (tag, n)
@@ -418,17 +550,21 @@ def gen_baseline_train():
             gflat = p.grad.reshape(-1)
             res['gnorm:' + key] = np.float64(gflat.double().norm().item())
             res['gsamp:' + key] = gflat[::max(1, gflat.numel() // 129)].numpy()
+            before[key] = p.detach().reshape(-1)[::max(1, p.numel() // 129)].clone()
     opt.step()
     for tag in ('surface', 'overhead'):
         for n, p in encs[tag][0].named_parameters():
-            res['psamp:%s.%s' % (tag, n)] = p.detach().reshape(-1)[::max(1, p.numel() // 129)].numpy()
+            after = p.detach().reshape(-1)[::max(1, p.numel() // 129)]
+            res['psamp:%s.%s' % (tag, n)] = after.numpy()
+            res['dsamp:%s.%s' % (tag, n)] = (after - before['%s.%s' % (tag, n)]).numpy()
         for n, bbuf in encs[tag][0].named_buffers():
             if 'num_batches' not in n:
                 res['buf:%s.%s' % (tag, n)] = bbuf.detach().numpy()
     res['names'] = np.array(names)
     assert float(loss) > 0
-    np.savez(os.path.join(HERE, 'baseline_train.npz'), **res)
-    print('baseline_train.npz written; loss', float(loss))
+    np.savez_compressed(os.path.join(HERE, 'baseline_train.npz'), **res)
+    print('baseline_train.npz written; loss', float(loss), 'min |hinge argument|', float(res['min_abs_hinge']),
+          'fragile gates', {k: len(v) for k, v in res.items() if k.startswith('gfrag:')})
 
 
 if __name__ == '__main__' and '--baseline-train' in sys.argv:

@@ -8,7 +8,7 @@ import torch.nn.functional as F
 
 from oracle import cvig_fov_oracle as O
 from witw_amd import synth
-from tests.test_trainstep_golden import load_case, ref_key, sample
+from tests.test_trainstep_golden import check_adam_update, load_case, reconcile_gates, reconcile_routes, ref_key, sample
 
 pytestmark = pytest.mark.gpu
 
@@ -105,32 +105,67 @@ def test_match_backward_rectangular_vs_oracle():
 
 
 def test_adam_matches_torch():
+    """Three steps of torch.optim.Adam (model/cvig_fov.py:416-418 defaults) vs witw_adam_step: the accumulated UPDATE agrees to
+    1e-3 of lr per step (+ the fp32 spacing of the parameter), i.e. direction and length of every step, not just "close to
+    the start value"."""
     from witw_amd import cvig_fov
-    p0, g1, g2 = _rand(31, (1000,)), _rand(32, (1000,), 0.01), _rand(33, (1000,), 0.01)
+    lr = 1e-5
+    p0, g1, g2 = _rand(31, (1000,), 0.01), _rand(32, (1000,), 0.01), _rand(33, (1000,), 0.01)
+    g1[:10] = 0.0                                        # never-touched entries must not move
+    g2[:10] = 0.0
+    g1[10:20] *= 1e-6                                    # gradients comparable with eps = 1e-8
     pr = p0.clone().requires_grad_(True)
-    opt = torch.optim.Adam([pr], lr=1e-5)
+    opt = torch.optim.Adam([pr], lr=lr)
     pg = torch.nn.Parameter(p0.clone().cuda())
-    mine = cvig_fov.Adam([pg], lr=1e-5)
+    mine = cvig_fov.Adam([pg], lr=lr)
     for gr in (g1, g2, g1):
         pr.grad = gr.clone()
         opt.step()
         pg.grad = gr.clone().cuda()
         mine.step()
-    np.testing.assert_allclose(pg.detach().cpu().numpy(), pr.detach().numpy(), rtol=0, atol=1e-7)
-    assert (pr.detach() - p0).abs().max() > 1e-5
+    d_ref, d_got = pr.detach() - p0, pg.detach().cpu() - p0
+    tol = 3 * 1e-3 * lr + 2 * p0.abs() * 2.0 ** -23
+    assert bool(((d_got - d_ref).abs() <= tol).all()), float((d_got - d_ref).abs().max())
+    assert bool((d_got[:10] == 0).all()) and float(d_ref[20:].abs().min()) > 0.5 * lr
 
 
-def test_training_step_matches_reference_golden(golden_dir):
-    """model/cvig_fov.py:444-461 on the GPU: loss, orientation, every trainable gradient and the
-    parameters after one Adam step against the reference's own run."""
+def _gpu_gates(g, tag, enc, gates_out, layers=(17, 19, 21, 23, 25)):
+    """Reconcile the gates the GPU forward recorded (enc._last_kept) with the reference's (tests/test_trainstep_golden.py)
+    and put them where the backward reads them. -> number of fragile positions where the GPU forward fell on the other side."""
+    flips = 0
+    for idx in layers:
+        y = enc._last_kept[idx][1]                                    # layer output NHWC (post-ReLU)
+        gate, n = reconcile_gates(g, tag, idx, (y > 0).permute(0, 3, 1, 2).cpu())
+        flips += n
+        gates_out[idx] = gate.permute(0, 2, 3, 1).float().contiguous().to(y.device)
+    return flips
+
+
+@pytest.mark.parametrize('name', ['trainstep.npz', 'trainstep360.npz'])
+def test_training_step_matches_reference_golden(golden_dir, name):
+    """model/cvig_fov.py:444-461 on the GPU against the reference's own run (trainstep.npz: B=3, embedding width 12;
+    trainstep360.npz: the config-2 geometry, fov 360, embedding width 64, B=4): loss, orientation, distances, every
+    trainable gradient to 1e-4 of its norm, and the update one Adam step makes.
+    Gates: the GPU forward's ReLU gates may differ from the reference's ONLY at positions the golden lists as fragile
+    (|pre-activation| < 1e-4) -- reconcile_gates asserts that through the per-(sample,channel) open-gate counts -- and at no
+    more than a handful of those; the backward then runs with the reference's side taken at the fragile positions."""
     from witw_amd import cvig_fov
-    g, xs, xo, w, drops = load_case(golden_dir)
+    g, xs, xo, w, drops = load_case(golden_dir, name)
     dev = torch.device('cuda:0')
     se = cvig_fov.FOV_DSM(False, weights=w).to(dev).train()
     oe = cvig_fov.FOV_DSM(True, weights=w).to(dev).train()
+    se.keep_activations = oe.keep_activations = True
     opt = cvig_fov.Adam(list(se.parameters()) + list(oe.parameters()), lr=1.E-5)
-    s_emb = se(xs.to(dev), dropout_scales={k: v.to(dev) for k, v in drops['s'].items()})
-    o_emb = oe(xo.to(dev), dropout_scales={k: v.to(dev) for k, v in drops['o'].items()})
+    gates_s, gates_o = {}, {}
+    s_emb = se(xs.to(dev), dropout_scales={k: v.to(dev) for k, v in drops['s'].items()}, relu_gates=gates_s)
+    flips = _gpu_gates(g, 's', se, gates_s)
+    o_emb = oe(xo.to(dev), dropout_scales={k: v.to(dev) for k, v in drops['o'].items()}, relu_gates=gates_o)
+    flips += _gpu_gates(g, 'o', oe, gates_o)
+    n_fragile = sum(len(g[k]) for k in g.files if k.startswith('gfrag:'))
+    print('%s: GPU forward differs from the reference at %d of %d fragile gate positions' % (name, flips, n_fragile))
+    assert flips <= 12, flips
+    np.testing.assert_allclose(s_emb.detach().cpu().numpy(), g['embed_s'], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(o_emb.detach().cpu().numpy(), g['embed_o'], rtol=0, atol=1e-4)
     ori, dist = cvig_fov.match(o_emb, s_emb)
     loss = cvig_fov.triplet_loss(dist)
     opt.zero_grad()
@@ -140,29 +175,51 @@ def test_training_step_matches_reference_golden(golden_dir):
     np.testing.assert_allclose(dist.detach().cpu().numpy(), g['distance'], rtol=0, atol=1e-4)
     named = {('s.' + n): p for n, p in se.named_parameters()}
     named.update({('o.' + n): p for n, p in oe.named_parameters()})
-    # Gradients upstream of a ReLU are only piecewise continuous: one activation within rounding of 0
-    # flips its gate between the CPU and GPU forward and moves one channel's gradient by that pixel's
-    # share (this tiny batch has 3x16x12 pixels per channel), and everything upstream of it slightly.
-    # Hence a norm-wise 1e-2 bound everywhere and rounding-level agreement below the last gated layer.
-    for name in g['names']:
-        p = named[str(name)]
-        ref = g['gsamp:' + str(name)]
+    worst = 0.0
+    for nm in g['names']:
+        nm = str(nm)
+        p = named[nm]
+        ref = g['gsamp:' + nm]
         got = sample(p.grad.detach().cpu()).numpy()
-        gn = float(g['gnorm:' + str(name)])
-        assert abs(p.grad.detach().double().norm().item() - gn) <= 1e-2 * gn + 1e-9, name
-        assert np.linalg.norm(got - ref) <= 1e-2 * np.linalg.norm(ref) + 1e-9, name
-        # layers whose gradient does not pass through a flipped gate in this fixture agree to rounding
-        if any(('features.%d' % i) in str(name) for i in (23, 25, 27)):
-            assert np.linalg.norm(got - ref) <= 2e-5 * np.linalg.norm(ref), name
-    assert all(p.grad is None for n, p in named.items() if str(n) not in set(g['names']))   # frozen layers
+        gn = float(g['gnorm:' + nm])
+        assert abs(p.grad.detach().double().norm().item() - gn) <= 1e-4 * gn, nm
+        # the sample holds 1/stride of the entries: its share of the 1e-4 * norm budget is 1e-4 * its own norm
+        rel = np.linalg.norm(got - ref) / np.linalg.norm(ref)
+        worst = max(worst, rel)
+        assert rel <= 1e-4, (nm, rel)
+    print('%s: worst gradient deviation %.2e of its norm' % (name, worst))
+    assert all(p.grad is None for n, p in named.items() if str(n) not in set(str(v) for v in g['names']))   # frozen layers
+    before = {str(nm): named[str(nm)].detach().clone() for nm in g['names']}
     opt.step()
-    for name in g['names']:
-        np.testing.assert_allclose(sample(named[str(name)].detach().cpu()).numpy(), g['psamp:' + str(name)], rtol=0,
-                                   atol=2.5e-5)   # one Adam step moves each weight by <= lr = 1e-5
+    for nm in g['names']:
+        nm = str(nm)
+        check_adam_update(g, nm, before[nm].cpu(), named[nm].detach().cpu(), 1e-5, own_grad=named[nm].grad.detach().cpu())
     # packed-weight caches must notice the update
     with torch.no_grad():
         e2 = se.eval()(xs.to(dev))
     assert float((e2 - s_emb.detach()).abs().max()) > 0
+
+
+def test_training_step_without_gate_reconciliation_stays_close(golden_dir):
+    """The production path (the GPU forward's own gates): a gate that falls on the other side moves a gradient by that
+    pixel's share, so the bound here is the statement of that effect, not of kernel accuracy (which the test above holds to
+    1e-4): 1e-2 of the norm on the config-2 geometry fixture (observed 3e-3 with 6 gates on the other side)."""
+    from witw_amd import cvig_fov
+    g, xs, xo, w, drops = load_case(golden_dir, 'trainstep360.npz')
+    dev = torch.device('cuda:0')
+    se = cvig_fov.FOV_DSM(False, weights=w).to(dev).train()
+    oe = cvig_fov.FOV_DSM(True, weights=w).to(dev).train()
+    s_emb = se(xs.to(dev), dropout_scales={k: v.to(dev) for k, v in drops['s'].items()})
+    o_emb = oe(xo.to(dev), dropout_scales={k: v.to(dev) for k, v in drops['o'].items()})
+    ori, dist = cvig_fov.match(o_emb, s_emb)
+    cvig_fov.triplet_loss(dist).backward()
+    named = {('s.' + n): p for n, p in se.named_parameters()}
+    named.update({('o.' + n): p for n, p in oe.named_parameters()})
+    for nm in g['names']:
+        nm = str(nm)
+        got = sample(named[nm].grad.detach().cpu()).numpy()
+        ref = g['gsamp:' + nm]
+        assert np.linalg.norm(got - ref) <= 1e-2 * np.linalg.norm(ref), nm
 
 
 def test_maxpool_backward_and_codes():
@@ -187,44 +244,60 @@ def test_maxpool_backward_and_codes():
     np.testing.assert_allclose(dpre.numpy(), z.grad.numpy(), atol=1e-6)
 
 
-def test_semantic_training_step_vs_oracle_autograd():
-    """cvig_semantic: layer 0 trains, so the backward runs through all 13 layers and the 3 fused max-pools."""
+def test_semantic_training_step_matches_reference_golden(golden_dir):
+    """cvig_semantic (model/cvig_semantic.py:475-492): layer 0 trains, so the backward runs through all 13 layers and the 3
+    fused max-pools. Against the reference's own run (tests/golden/trainstep_semantic.npz): ReLU gates and max-pool routes
+    may differ from the reference's only at listed fragile positions (|pre-activation| or window top-2 gap < 1e-4); with
+    those reconciled every one of the 28 gradients is within 1e-4 of its norm, and the Adam update is the reference's."""
     from witw_amd import cvig_semantic, cvig_fov
-    seed = 321
+    g = np.load(os.path.join(golden_dir, 'trainstep_semantic.npz'))
+    seed, B = int(g['seed']), int(g['B'])
     w5 = synth.fov_dsm_weights(seed, in_channels=5)
-    B = 2
     xs = torch.from_numpy(synth.normalized_images(seed, 1, (B, 5, 128, 64)))     # narrow inputs keep the CPU side quick
     xo = torch.from_numpy(synth.normalized_images(seed, 2, (B, 5, 128, 512)))
-    drops = {t: {i: torch.from_numpy(synth.dropout_scales(seed, 10 * k + i, B, 512)) for i in (17, 19, 21)}
-             for k, t in enumerate('so')}
-    # oracle (CPU autograd) with layer 0 trainable as well
-    leaves = {}
-    ws_, wo_ = ({k: (torch.from_numpy(a.copy()), torch.from_numpy(c.copy())) for k, (a, c) in w5.items()} for _ in range(2))
-    for tag, wd in (('s', ws_), ('o', wo_)):
-        for idx in (0,) + O.TRAINABLE:
-            for t in wd[idx]:
-                t.requires_grad_(True)
-            leaves[(tag, idx)] = wd[idx]
-    s_emb = O.fov_dsm_forward(xs, ws_, False, dropout_scales=drops['s'])
-    o_emb = O.fov_dsm_forward(xo, wo_, True, dropout_scales=drops['o'])
-    ori_r, dist_r = O.match(o_emb, s_emb)
-    loss_r = O.triplet_loss(dist_r)
-    loss_r.backward()
+    drops = {t: {i: torch.from_numpy(g['drop_%s_%d' % (t, i)]) for i in (17, 19, 21)} for t in 'so'}
     dev = torch.device('cuda:0')
     se = cvig_semantic.FOV_DSM(False, weights=w5).to(dev).train()
     oe = cvig_semantic.FOV_DSM(True, weights=w5).to(dev).train()
-    se_out = se(xs.to(dev), dropout_scales={k: v.to(dev) for k, v in drops['s'].items()})
-    oe_out = oe(xo.to(dev), dropout_scales={k: v.to(dev) for k, v in drops['o'].items()})
-    ori, dist = cvig_fov.match(oe_out, se_out)
-    loss = cvig_fov.triplet_loss(dist)
-    loss.backward()
-    assert abs(loss.item() - loss_r.item()) < 1e-4
-    assert torch.equal(ori.cpu(), ori_r)
-    for tag, enc in (('s', se), ('o', oe)):
-        for idx, conv in enc.trainable_convs():
-            for k, prm in ((0, conv.weight), (1, conv.bias)):
-                ref = leaves[(tag, idx)][k].grad
-                got = prm.grad.cpu()
-                rel = (got - ref).norm() / ref.norm()
-                assert rel < 2e-2, (tag, idx, k, float(rel))       # ReLU / max-pool kinks: see the cvig_fov test
     assert sorted(i for i, _c in se.trainable_convs()) == [0, 17, 19, 21, 23, 25, 27]
+    opt = cvig_fov.Adam(list(se.parameters()) + list(oe.parameters()), lr=1.E-5)
+    relu_layers, pooled = (0, 2, 5, 7, 10, 12, 14, 17, 19, 21, 23, 25), (2, 7, 14)
+    outs, flips, rflips = {}, 0, 0
+    for tag, enc, x in (('s', se, xs), ('o', oe, xo)):
+        enc.keep_activations = True
+        gates, codes = {}, {}
+        outs[tag] = enc(x.to(dev), dropout_scales={k: v.to(dev) for k, v in drops[tag].items()}, relu_gates=gates, pool_codes=codes)
+        flips += _gpu_gates(g, tag, enc, gates, relu_layers)
+        for idx in pooled:
+            _h, y, code = enc._last_kept[idx]
+            gate = (gates[idx] > 0).permute(0, 3, 1, 2).cpu()
+            fixed, n = reconcile_routes(g, tag, idx, code.permute(0, 3, 1, 2).cpu(), gate)
+            rflips += n
+            codes[idx] = fixed.permute(0, 2, 3, 1).contiguous().to(dev)
+    print('semantic: GPU forward differs from the reference at %d fragile gates and %d fragile pool routes' % (flips, rflips))
+    assert flips <= 20 and rflips <= 10, (flips, rflips)
+    ori, dist = cvig_fov.match(outs['o'], outs['s'])
+    loss = cvig_fov.triplet_loss(dist)
+    opt.zero_grad()
+    loss.backward()
+    assert abs(loss.item() - float(g['loss'])) < 1e-4
+    np.testing.assert_array_equal(ori.cpu().numpy(), g['orientation'])
+    np.testing.assert_allclose(dist.detach().cpu().numpy(), g['distance'], rtol=0, atol=1e-4)
+    named = {('s.' + n): p for n, p in se.named_parameters()}
+    named.update({('o.' + n): p for n, p in oe.named_parameters()})
+    assert len(g['names']) == 28
+    worst = 0.0
+    for nm in g['names']:
+        nm = str(nm)
+        p = named[nm]
+        gn = float(g['gnorm:' + nm])
+        assert abs(p.grad.detach().double().norm().item() - gn) <= 1e-4 * gn, nm
+        ref = g['gsamp:' + nm]
+        rel = np.linalg.norm(sample(p.grad.detach().cpu()).numpy() - ref) / np.linalg.norm(ref)
+        worst = max(worst, rel)
+        assert rel <= 1e-4, (nm, rel)
+    print('semantic: worst gradient deviation %.2e of its norm' % worst)
+    before = {str(nm): named[str(nm)].detach().clone() for nm in g['names']}
+    opt.step()
+    for nm in g['names']:
+        check_adam_update(g, str(nm), before[str(nm)].cpu(), named[str(nm)].detach().cpu(), 1e-5, own_grad=named[str(nm)].grad.detach().cpu())

@@ -72,18 +72,49 @@ def test_baseline_loss_and_ranks(golden_dir):
                                rtol=1e-4)
 
 
+def _reconciled_lrelu_acts(g, tag, enc, out):
+    """LeakyReLU gates of the GPU forward (sign of the recorded activations) against the reference's: they may differ only at
+    positions the golden lists as fragile (tests/test_trainstep_golden.reconcile_gates); at those the reference's side is
+    taken by giving the activation the reference's sign (its magnitude is rounding-level there). -> positions flipped."""
+    from tests.test_trainstep_golden import reconcile_gates
+    flips = 0
+    for i in range(1, 8):
+        _h, a, (vh, vw), *_rest = enc._last_saved[i - 1]
+        gate = (a[:, :vh, :vw, :] > 0).permute(0, 3, 1, 2).cpu()
+        fixed, n = reconcile_gates(g, tag, i, gate)
+        flips += n
+        if n:
+            want = torch.zeros(a.shape, dtype=torch.bool, device=a.device)
+            want[:, :vh, :vw, :] = fixed.permute(0, 2, 3, 1).to(a.device)
+            inside = torch.zeros_like(want)
+            inside[:, :vh, :vw, :] = True
+            mag = a.abs()
+            out[i] = torch.where(inside & (want != (a > 0)), torch.where(want, mag + 1e-30, -mag), a).contiguous()
+    return flips
+
+
 def test_baseline_training_step_matches_reference_golden(golden_dir):
-    """model/cvig_baseline.py:373-387 on the GPU: train-mode encoders (BatchNorm batch statistics + running-stat
-    update), exhaustive triplet loss, backward through everything, Adam(lr=1e-3)."""
+    """model/cvig_baseline.py:373-387 on the GPU against the reference's own run: train-mode encoders (BatchNorm batch
+    statistics + running-stat update), exhaustive triplet loss, backward through everything, Adam(lr=1e-3).
+    LeakyReLU gates may differ from the reference's only at listed fragile positions (|conv output| < 1e-4 x max(1, std));
+    with the reference's side taken there all 56 gradients are within 1e-4 of their norm and the Adam update is the reference's."""
     from witw_amd import cvig_baseline, cvig_fov
+    from tests.test_trainstep_golden import check_adam_update
     g = np.load(os.path.join(golden_dir, 'baseline_train.npz'))
     seed, B = int(g['seed']), int(g['B'])
     xs = torch.from_numpy(synth.images_u8(seed, 40, (B, 3, 400, 400))).cuda()
     xo = torch.from_numpy(synth.images_u8(seed, 41, (B, 3, 416, 416))).cuda()
     se = _load_encoder(cvig_baseline.SurfaceEncoder, seed + 10).train()
     oe = _load_encoder(cvig_baseline.OverheadEncoder, seed + 11).train()
+    se.keep_activations = oe.keep_activations = True
     opt = cvig_fov.Adam(list(se.parameters()) + list(oe.parameters()), lr=1e-3)
-    es, eo = se(xs), oe(xo)
+    acts_s, acts_o = {}, {}
+    es = se(xs, lrelu_acts=acts_s)
+    flips = _reconciled_lrelu_acts(g, 'surface', se, acts_s)
+    eo = oe(xo, lrelu_acts=acts_o)
+    flips += _reconciled_lrelu_acts(g, 'overhead', oe, acts_o)
+    print('baseline: GPU forward differs from the reference at %d fragile LeakyReLU gates' % flips)
+    assert flips <= 40, flips
     loss = cvig_baseline.exhaustive_minibatch_triplet_loss(es, eo)
     opt.zero_grad()
     loss.backward()
@@ -94,24 +125,26 @@ def test_baseline_training_step_matches_reference_golden(golden_dir):
     named.update({('overhead.' + n): p for n, p in oe.named_parameters()})
     worst = 0.0
     for name in g['names']:
-        p = named[str(name)]
-        ref = g['gsamp:' + str(name)]
+        name = str(name)
+        p = named[name]
+        ref = g['gsamp:' + name]
         got = p.grad.detach().reshape(-1).cpu()
         got_s = got[::max(1, got.numel() // 129)].numpy()
-        gn = float(g['gnorm:' + str(name)])
-        assert abs(got.double().norm().item() - gn) <= 2e-2 * gn + 1e-9, name
+        gn = float(g['gnorm:' + name])
+        assert abs(got.double().norm().item() - gn) <= 1e-4 * gn + 1e-12, name
         rel = np.linalg.norm(got_s - ref) / (np.linalg.norm(ref) + 1e-30)
         worst = max(worst, rel)
-        assert rel < 5e-2, (name, rel)          # hinge / LeakyReLU kinks on a 3-sample batch; see the cvig_fov test
+        assert rel <= 1e-4, (name, rel)
+    print('baseline: worst gradient deviation %.2e of its norm' % worst)
     for tag, enc in (('surface', se), ('overhead', oe)):
         for n, bbuf in enc.named_buffers():
             if 'num_batches' not in n:
                 np.testing.assert_allclose(bbuf.cpu().numpy(), g['buf:%s.%s' % (tag, n)], rtol=1e-4, atol=1e-6)
+    before = {str(nm): named[str(nm)].detach().clone() for nm in g['names']}
     opt.step()
     for name in g['names']:
-        pv = named[str(name)].detach().reshape(-1).cpu()
-        np.testing.assert_allclose(pv[::max(1, pv.numel() // 129)].numpy(), g['psamp:' + str(name)], rtol=0, atol=2.5e-3)
-    print('worst sampled-gradient relative error', worst)
+        check_adam_update(g, str(name), before[str(name)].cpu(), named[str(name)].detach().cpu(), 1e-3, n=129,
+                          own_grad=named[str(name)].grad.detach().cpu(), min_cover=0.5)    # the last blocks' bias gradients are small
 
 
 @pytest.mark.parametrize('case', [(2, 20, 70, 24, 128, 4), (1, 64, 64, 16, 64, 8), (2, 9, 30, 64, 192, 4), (3, 16, 130, 8, 64, 4)])

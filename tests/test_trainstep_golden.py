@@ -1,4 +1,15 @@
-"""The oracle's training step against the reference's own loop body (tests/golden/trainstep.npz)."""
+"""The oracle's training step against the reference's own loop body (tests/golden/trainstep*.npz), and the helpers the GPU
+tests share: ReLU-gate reconciliation and the Adam-update check.
+
+Gate protocol. A gradient behind a ReLU is only piecewise continuous in the forward activations: where a pre-activation
+sits within rounding of zero, the CPU reference and another (equally exact) summation order can fall on different sides,
+and the gradient moves by that pixel's whole contribution. The goldens therefore carry, per gated layer, the reference's
+open-gate COUNT per (sample, channel) and the list of FRAGILE positions (|pre-activation| < tau = 1e-4 x max(1, std of that
+layer's pre-activations), the reference's
+side recorded). `reconcile_gates` takes an implementation's own gates, overrides them at the fragile positions with the
+reference's choice and requires the per-(sample,channel) counts to equal the reference's exactly -- i.e. the two forwards
+may disagree ONLY at listed fragile positions; it returns how many they did disagree at. With the reconciled gates in the
+backward every gradient must match the reference to 1e-4 of its norm (the north-star tolerance)."""
 import os
 
 import numpy as np
@@ -16,25 +27,83 @@ def ref_key(tag, idx, circ, kind):
     return '%s.model.features.%d%s.%s' % (tag, idx, mid, kind)
 
 
-def load_case(golden_dir):
-    g = np.load(os.path.join(golden_dir, 'trainstep.npz'))
+def load_case(golden_dir, name='trainstep.npz'):
+    g = np.load(os.path.join(golden_dir, name))
     seed, B, ws = int(g['seed']), int(g['B']), int(g['ws'])
-    xs = torch.from_numpy(synth.normalized_images(seed, 20, (B, 3, 128, ws)))
-    xo = torch.from_numpy(synth.normalized_images(seed, 21, (B, 3, 128, 512)))
-    w = synth.fov_dsm_weights(seed + 1)
+    st = [int(v) for v in g['streams']]
+    xs = torch.from_numpy(synth.normalized_images(seed, st[0], (B, 3, 128, ws)))
+    xo = torch.from_numpy(synth.normalized_images(seed, st[1], (B, 3, 128, 512)))
+    w = synth.fov_dsm_weights(int(g['wseed']))
     drops = {t: {i: torch.from_numpy(g['drop_%s_%d' % (t, i)]) for i in (17, 19, 21)} for t in 'so'}
     return g, xs, xo, w, drops
 
 
-def sample(t):
+def sample(t, n=257):
     t = t.reshape(-1)
-    return t[::max(1, t.numel() // 257)]
+    return t[::max(1, t.numel() // n)]
 
 
-def test_oracle_train_step_matches_reference(golden_dir):
-    g, xs, xo, w, drops = load_case(golden_dir)
+def reconcile_gates(g, tag, idx, gate_nchw):
+    """gate_nchw: bool [B,C,H,W], an implementation's open gates behind layer idx (for a fused max-pool: of the pooled map).
+    -> (gates with the reference's choice at the fragile positions, number of fragile positions where they differed).
+    Asserts that, after that, the per-(sample,channel) counts are the reference's."""
+    fr = torch.from_numpy(g['gfrag:%s:%d' % (tag, idx)])
+    fv = torch.from_numpy(g['gfragv:%s:%d' % (tag, idx)]).bool()
+    flat = gate_nchw.reshape(-1).clone()
+    flips = int((flat[fr] != fv).sum())
+    flat[fr] = fv
+    out = flat.view_as(gate_nchw)
+    cnt = out.sum(dim=(2, 3)).to(torch.int32)
+    ref = torch.from_numpy(g['gcount:%s:%d' % (tag, idx)])
+    bad = int((cnt != ref).sum())
+    assert bad == 0, 'layer %s:%d: %d (sample,channel) gate counts differ from the reference outside the fragile list' % (tag, idx, bad)
+    return out, flips
+
+
+def reconcile_routes(g, tag, idx, code_nchw, gate_nchw):
+    """The same for the arg-max position (dy*2+dx) of a fused 2x2 max-pool: fragile windows (top-2 gap < tau) take the
+    reference's position; the code sums over open windows must then equal the reference's per (sample,channel)."""
+    fr = torch.from_numpy(g['pfrag:%s:%d' % (tag, idx)])
+    fv = torch.from_numpy(g['pfragv:%s:%d' % (tag, idx)])
+    flat = code_nchw.reshape(-1).clone()
+    flips = int((flat[fr] != fv).sum())
+    flat[fr] = fv
+    out = flat.view_as(code_nchw)
+    csum = (out.long() * gate_nchw.long()).sum(dim=(2, 3))
+    bad = int((csum != torch.from_numpy(g['pcsum:%s:%d' % (tag, idx)])).sum())
+    assert bad == 0, 'layer %s:%d: %d (sample,channel) pool routes differ from the reference outside the fragile list' % (tag, idx, bad)
+    return out, flips
+
+
+def check_adam_update(g, name, p_before, p_after, lr, n=257, own_grad=None, min_cover=0.9):
+    """The parameter UPDATE of one Adam step against the reference's (`dsamp`, sampled like `gsamp`). First step:
+    delta = -lr * g / (|g| + eps), eps = 1e-8. Wherever the reference gradient is well above eps the update must agree to
+    1e-3 * lr (+ one fp32 spacing of the parameter, the resolution of a stored after-minus-before); where the reference
+    gradient is exactly zero (channels Dropout2d zeroed) nothing may move; the thin band in between (gradient comparable
+    with eps, so the update legitimately depends on the last digits of g) is only held to the step bound |delta| <= lr."""
+    gs = torch.from_numpy(g['gsamp:' + name])
+    d_ref = torch.from_numpy(g['dsamp:' + name])
+    before, after = sample(p_before, n), sample(p_after, n)
+    d = after - before
+    well = gs.abs() >= 1e-5          # 1000 x eps: the update there is -lr * sign(g) to 1e-3
+    zero = gs == 0
+    if own_grad is not None:      # an implementation whose own gradient is a rounding-level non-zero there may move (Adam: g / (|g| + eps))
+        zero = zero & (sample(own_grad, n) == 0)
+    ulp = torch.maximum(before.abs(), after.abs()) * 2.0 ** -23
+    err = (d - d_ref).abs()
+    assert bool((err[well] <= 1e-3 * lr + ulp[well]).all()), (name, float(err[well].max()), lr)
+    assert bool((d[zero] == 0).all()), name
+    assert bool((d.abs() <= lr * (1 + 1e-3) + ulp).all()), name
+    assert int(well.sum()) + int((gs == 0).sum()) >= min_cover * gs.numel(), (name, int(well.sum()), int(zero.sum()), gs.numel())
+    assert int(well.sum()) > 0 and bool((d[well].abs() > 0.99 * lr - ulp[well]).all()), name      # the step was really taken
+    return float(err[well].max())
+
+
+def _oracle_case(golden_dir, name):
+    g, xs, xo, w, drops = load_case(golden_dir, name)
     ws_ = {k: (torch.from_numpy(a.copy()), torch.from_numpy(b.copy())) for k, (a, b) in w.items()}
     wo_ = {k: (torch.from_numpy(a.copy()), torch.from_numpy(b.copy())) for k, (a, b) in w.items()}
+    before = {(t, i): (wd[i][0].clone(), wd[i][1].clone()) for t, wd in (('s', ws_), ('o', wo_)) for i in O.TRAINABLE}
     loss, ori, dist, grads = O.train_step(xs, xo, ws_, wo_, drops['s'], drops['o'], lr=1.E-5)
     np.testing.assert_allclose(loss.item(), float(g['loss']), rtol=1e-6)
     np.testing.assert_array_equal(ori.numpy(), g['orientation'])
@@ -48,3 +117,65 @@ def test_oracle_train_step_matches_reference(golden_dir):
                 np.testing.assert_allclose(gr.double().norm().item(), float(g['gnorm:' + name]), rtol=1e-5)
                 np.testing.assert_allclose(sample(gr).numpy(), g['gsamp:' + name], rtol=1e-4, atol=1e-9)
                 np.testing.assert_allclose(sample(wd[idx][k]).numpy(), g['psamp:' + name], rtol=0, atol=1e-7)
+                check_adam_update(g, name, before[(tag, idx)][k], wd[idx][k].detach(), 1e-5)
+    # the oracle's own gates: equal to the reference's everywhere except (possibly) at listed fragile positions
+    with torch.no_grad():
+        for tag, x, wd, circ in (('s', xs, ws_, False), ('o', xo, wo_, True)):
+            w0 = {k: (torch.from_numpy(a.copy()), torch.from_numpy(b.copy())) for k, (a, b) in w.items()}
+            _, acts = O.fov_dsm_forward(x, w0, circ, dropout_scales=drops[tag], return_activations=True)
+            for idx in (17, 19, 21, 23, 25):
+                _, flips = reconcile_gates(g, tag, idx, acts[idx] > 0)
+                assert flips <= 2, (tag, idx, flips)
+
+
+def test_oracle_train_step_matches_reference(golden_dir):
+    _oracle_case(golden_dir, 'trainstep.npz')
+
+
+def test_oracle_train_step_matches_reference_config2_geometry(golden_dir):
+    """fov 360: surface 128x512 -> embedding width 64 (the BASELINE config-2 shapes), B = 4."""
+    _oracle_case(golden_dir, 'trainstep360.npz')
+
+
+def test_oracle_semantic_train_step_matches_reference(golden_dir):
+    """cvig_semantic (5-channel, layer 0 trainable: gradients through all 13 convs and the 3 max-pools) against the
+    reference's own loop body, model/cvig_semantic.py:475-492."""
+    g = np.load(os.path.join(golden_dir, 'trainstep_semantic.npz'))
+    seed, B = int(g['seed']), int(g['B'])
+    w5 = synth.fov_dsm_weights(seed, in_channels=5)
+    xs = torch.from_numpy(synth.normalized_images(seed, 1, (B, 5, 128, 64)))
+    xo = torch.from_numpy(synth.normalized_images(seed, 2, (B, 5, 128, 512)))
+    drops = {t: {i: torch.from_numpy(g['drop_%s_%d' % (t, i)]) for i in (17, 19, 21)} for t in 'so'}
+    ws_, wo_ = ({k: (torch.from_numpy(a.copy()), torch.from_numpy(c.copy())) for k, (a, c) in w5.items()} for _ in range(2))
+    tr = (0,) + O.TRAINABLE
+    before = {(t, i): (wd[i][0].clone(), wd[i][1].clone()) for t, wd in (('s', ws_), ('o', wo_)) for i in tr}
+    loss, ori, dist, grads = O.train_step(xs, xo, ws_, wo_, drops['s'], drops['o'], lr=1.E-5, trainable=tr)
+    np.testing.assert_allclose(loss.item(), float(g['loss']), rtol=1e-6)
+    np.testing.assert_array_equal(ori.numpy(), g['orientation'])
+    assert len(g['names']) == 28
+    for tag, wd in (('s', ws_), ('o', wo_)):
+        for idx in tr:
+            for k, kind in ((0, 'weight'), (1, 'bias')):
+                name = ref_key(tag, idx, tag == 'o', kind)
+                gr = grads[(tag, idx)][k]
+                np.testing.assert_allclose(gr.double().norm().item(), float(g['gnorm:' + name]), rtol=1e-5)
+                np.testing.assert_allclose(sample(gr).numpy(), g['gsamp:' + name], rtol=1e-4, atol=1e-8)
+                check_adam_update(g, name, before[(tag, idx)][k], wd[idx][k].detach(), 1e-5)
+
+
+def test_adam_update_check_rejects_a_missing_or_reversed_step(golden_dir):
+    """The update check is not vacuous: an optimizer that does nothing, or steps the wrong way, fails it."""
+    import pytest
+    g, xs, xo, w, drops = load_case(golden_dir)
+    name = ref_key('s', 27, False, 'weight')
+    before = torch.from_numpy(w[27][0].copy())
+    full = torch.zeros_like(before).reshape(-1)
+    full[::max(1, full.numel() // 257)] = torch.from_numpy(g['dsamp:' + name])
+    good = before + full.view_as(before)
+    check_adam_update(g, name, before, good, 1e-5)
+    with pytest.raises(AssertionError):
+        check_adam_update(g, name, before, before.clone(), 1e-5)                   # no step
+    with pytest.raises(AssertionError):
+        check_adam_update(g, name, before, before - full.view_as(before), 1e-5)     # wrong direction
+    with pytest.raises(AssertionError):
+        check_adam_update(g, name, before, before + 1.01 * full.view_as(before), 1e-5)     # 1 % too long

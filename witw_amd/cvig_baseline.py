@@ -203,13 +203,18 @@ class SurfaceEncoder(nn.Module):
             out += [conv.weight, conv.bias, bn.weight, bn.bias]
         return out
 
-    def forward(self, x):
+    def forward(self, x, lrelu_acts=None):
+        """model/cvig_baseline.py:264-284. Parity hook (train mode): `lrelu_acts` {block i: NHWC tensor} replaces, in the
+        BACKWARD's LeakyReLU gate only, the activation this forward recorded (its sign is the gate); the dict is read when
+        the backward runs, so it may be filled after the forward (tests/test_baseline_gpu.py: a conv output within rounding of
+        zero can fall on the other side of the kink than it did on the CPU reference)."""
         if not x.is_cuda:
             raise _lib.WitwError('SurfaceEncoder.forward needs a GPU tensor (no CPU fallback)')
         B, _c, H, W = x.shape
         if min(H, W) < 382:
             raise _lib.WitwError('cvig_baseline encoder needs sides >= 382 px, got %dx%d' % (H, W))
         if self.training:
+            self._bwd_override = {} if lrelu_acts is None else lrelu_acts
             return _BaselineEncoderFn.apply(x, self, *self.train_params())
         with torch.no_grad():
             h = ops.space_to_depth2(x.contiguous(), in_nchw=True, normalize=True, cpad=self._layer(1)[3])   # :265-266
@@ -258,6 +263,9 @@ class _BaselineEncoderFn(torch.autograd.Function):
                     h = ops.space_to_depth2(a, valid_hw=(vh, vw), cpad=enc._layer(i + 1)[3], scale=scale, shift=shift)
             f = ops.embed_normalize_(g.clone())
         ctx.enc, ctx.saved, ctx.g = enc, saved, g
+        ctx.override = getattr(enc, '_bwd_override', {})
+        enc._bwd_override = {}
+        enc._last_saved = saved if getattr(enc, 'keep_activations', False) else None     # diagnostics / parity tests
         return f
 
     @staticmethod
@@ -275,7 +283,7 @@ class _BaselineEncoderFn(torch.autograd.Function):
                 dy = ops.depth_to_space2(dx_s2d, a, valid)
                 if i >= 5:
                     ops.gem_pool_bwd(a, scale, shift, g, dg, valid, 512 * (i - 5), enc.p, out=dy)
-            dz, dgamma, dbeta = ops.bn_lrelu_bwd(a, dy, valid, mean, invstd, bn.weight, 0.2)
+            dz, dgamma, dbeta = ops.bn_lrelu_bwd(ctx.override.get(i, a), dy, valid, mean, invstd, bn.weight, 0.2)
             k3 = enc._layer_k3(i)
             dk3, dbias = ops.conv3x3_wgrad(h, dz, k3.shape[1], stride_h=1, circular=False, taps4=True)
             co, ci = conv.weight.shape[:2]

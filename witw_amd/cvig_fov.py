@@ -295,11 +295,15 @@ class FOV_DSM(torch.nn.Module):
         return [(idx, _conv_of(self.model.features[idx])) for (idx, *_r) in self.layer_specs
                 if _conv_of(self.model.features[idx]).weight.requires_grad]
 
-    def forward(self, x, dropout_scales=None):
+    def forward(self, x, dropout_scales=None, relu_gates=None, pool_codes=None):
         """x [B,C,128,W] NCHW fp32 on the GPU -> [B,16,4,W/8] NCHW (reference :292-294).
         In train() mode Dropout2d scales are drawn per call unless `dropout_scales`
         ({17|19|21: [B,C]}) injects them. With grad enabled the call is recorded for autograd
-        (weight / bias gradients of the trainable layers, computed by the HIP backward kernels)."""
+        (weight / bias gradients of the trainable layers, computed by the HIP backward kernels).
+        Parity hooks, like dropout_scales: `relu_gates` {layer idx: NHWC float tensor, > 0 where the ReLU behind that
+        layer passes} and `pool_codes` {layer idx: uint8 arg-max codes of the fused max-pool} replace, in the BACKWARD only,
+        the gates / routes this forward would record itself -- a pre-activation within rounding of zero (or a tie inside a
+        pooling window) may fall the other way on the CPU reference, and the gradient is only piecewise continuous there."""
         if not x.is_cuda:
             raise _lib.WitwError('FOV_DSM.forward needs a GPU tensor (no CPU fallback)')
         scales = self._draw_scales(x, dropout_scales)
@@ -309,6 +313,8 @@ class FOV_DSM(torch.nn.Module):
             for _i, c in tr:
                 params += [c.weight, c.bias]
             fn = _EncoderFnBf16 if self.precision == 'bf16' else _EncoderFnF16x3 if self.precision == 'fp16x3' else _EncoderFn
+            # the dicts are read when the backward runs, so a caller may fill them between forward and backward
+            self._bwd_override = ({} if relu_gates is None else relu_gates, {} if pool_codes is None else pool_codes)
             return fn.apply(x, self, scales, *params)
         if self.precision == 'fp16x3' and not self.training:
             return self.forward_f16x3(x)
@@ -329,6 +335,9 @@ class _EncoderFn(torch.autograd.Function):
         first = min(i for i, _c in enc.trainable_convs())
         out, kept = enc._run(x, scales, keep_from=first)
         ctx.enc, ctx.scales, ctx.kept, ctx.first = enc, scales, kept, first
+        ctx.override = getattr(enc, '_bwd_override', ({}, {}))
+        enc._bwd_override = ({}, {})
+        enc._last_kept = kept if getattr(enc, 'keep_activations', False) else None      # diagnostics: gates of the last call
         return out
 
     @staticmethod
@@ -349,8 +358,10 @@ class _EncoderFn(torch.autograd.Function):
             if n > 0:   # gradient at the previous layer's conv output
                 pidx, _psh, _prelu, ppool, _pdrop = specs[n - 1]
                 p_in, p_out, p_code = kept[pidx]
+                p_gate = ctx.override[0].get(pidx, p_out)
+                p_code = ctx.override[1].get(pidx, p_code)
                 dy = ops.conv3x3_fwd(dz, enc._pack_t(idx), stride_h=1, circular=circ, relu=False, pool=False,
-                                     drop_scale=scales.get(pidx), gate=p_out, dilate_h=(sh == 2),
+                                     drop_scale=scales.get(pidx), gate=p_gate, dilate_h=(sh == 2),
                                      out_h=x_in.shape[1] if sh == 2 else None)
                 dz = ops.maxpool2x2_bwd(dy, p_code, (p_in.shape[1], p_in.shape[2])) if ppool else dy
         ctx.kept = None
