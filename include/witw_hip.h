@@ -106,6 +106,9 @@ int witw_match_spectrum(const float* emb, float* spec, int B, int W, void* strea
 long long witw_match_dft_workspace_floats(int Bo, int Bs);
 int witw_match_fwd_dft(const float* ov, const float* su, const float* spec_ov, const float* spec_su, int Bo, int Bs, int We,
                        long long* orientation, float* distance, float* score, float* workspace, void* stream);
+/* the same, also writing gap [Bo,Bs] = best score - runner-up score over the 64 shifts (distance of the arg-max from a tie) */
+int witw_match_fwd_dft_gap(const float* ov, const float* su, const float* spec_ov, const float* spec_su, int Bo, int Bs, int We,
+                           long long* orientation, float* distance, float* score, float* gap, float* workspace, void* stream);
 /* backward of witw_match_fwd (orientation is a constant of the graph): grad_distance [Bo,Bs] ->
  * grad_ov [Bo,16,4,64] and/or grad_su [Bs,16,4,We]; orientation/score/workspace as left by the forward. scratch: NULL,
  * or witw_match_bwd_scratch_floats(Bo,Bs,We) floats that let the surface gradient split the overheads over several
@@ -133,6 +136,18 @@ int witw_topk_smallest_ws(const float* distance, float* values, long long* indic
                           void* workspace, void* stream);
 /* sharded-gallery form: ranks[q] = #{o in this shard : D[o][q] <= threshold[q]} (threshold = true match's distance) */
 int witw_rank_count_thresh(const float* distance, const float* threshold, int* ranks, int Bo, int Bs, void* stream);
+
+/* Index-exact retrieval on top of the spectral pass (model/cvig_fov.py:547-552 ranks / top-k must not depend on which of two
+ * equally accurate fp32 summation orders produced a distance). witw_match_pairs: a LIST of n_pairs (overhead row pair_o[i],
+ * surface row pair_s[i]) pairs -> orientation / distance / score [n_pairs] (any may be NULL), bit-identical to the entries
+ * witw_match_fwd writes for those pairs (same MFMA accumulation chain, one wave per pair); wn [Bo,64] / sn [Bs] = the norms
+ * at the start of a witw_match_fwd / witw_match_fwd_dft workspace over the same ov / su (window norms, then surface norms).
+ * witw_rank_count_band: D [Bo,Bs] known to +-eps: counts[q] = #{o : D[o][q] < threshold[q] - eps}; the (o,q) inside the band
+ * |D - threshold| <= eps are appended to pair_o / pair_s (up to `capacity`), *n_pairs = how many there were in all. */
+int witw_match_pairs(const float* ov, const float* su, const float* wn, const float* sn, const int* pair_o, const int* pair_s,
+                     int n_pairs, int Bo, int Bs, int We, long long* orientation, float* distance, float* score, void* stream);
+int witw_rank_count_band(const float* distance, const float* threshold, float eps, int* counts, int* pair_o, int* pair_s,
+                         int* n_pairs, int capacity, int Bo, int Bs, void* stream);
 
 /* ---- triplet_loss, model/cvig_fov.py:366-382. workspace: 4*B floats, filled by fwd, read by bwd. */
 int witw_triplet_loss_fwd(const float* distance /*[B,B]*/, int B, float alpha, float* loss /*[1]*/, float* workspace,

@@ -309,3 +309,136 @@ def test_config5_more_ranks_than_gallery_rows():
         np.testing.assert_array_equal(ranks, ranks_1)
         np.testing.assert_array_equal(i, i_1.numpy())
         np.testing.assert_array_equal(v, v_1.numpy())
+
+
+# ----------------------------------------------------------------------------- index-exact spectral retrieval (host logic)
+class SpectralCpuKernels(Fp64MatchKernels):
+    """Stand-in for the spectral pass + exact re-scoring (ops.match_fwd_dft / match_pairs / rank_count_band): the "spectral"
+    distances are the exact ones plus a deterministic error of up to 0.9 DISTANCE_EPS, and on narrow surfaces the pass takes
+    the RUNNER-UP shift wherever the two best scores are closer than the score rounding -- the worst the real kernel may do.
+    The bounds are set a hundred times wider than the GPU's so that this small problem is full of undecided cases."""
+    DISTANCE_EPS = 1e-3
+    SCORE_ROUNDING = 2e-4
+
+    @staticmethod
+    def match_spectrum(emb):
+        return emb
+
+    @classmethod
+    def _exact(cls, ov, su):
+        we, w = su.shape[3], ov.shape[3]
+        sc = O.correlation_scores(ov.double(), su.double())                       # [Bo,Bs,64]
+        col = (ov.double() ** 2).sum(dim=(1, 2))
+        col2 = torch.cat((col, col[:, :we - 1]), dim=1) if we > 1 else col
+        win = col2.unfold(1, we, 1)[:, :w].sum(-1).sqrt()                        # [Bo,64]
+        sn = su.double().reshape(su.shape[0], -1).norm(dim=1)
+        return sc, win, sn
+
+    @classmethod
+    def match_fwd_dft(cls, ov, su, spec_ov=None, want_orientation=False, want_workspace=False, want_gap=False):
+        sc, win, sn = cls._exact(ov, su)
+        top = sc.topk(2, dim=-1)
+        ori = torch.argmax(O.correlation_scores(ov, su), -1)                     # the direct kernel's choice (fp32 scores)
+        best = torch.gather(sc, 2, ori[:, :, None]).squeeze(-1)
+        scale = ov.double().reshape(ov.shape[0], -1).norm(dim=1)[:, None] * sn[None, :]
+        gap = top.values[..., 0] - top.values[..., 1]
+        pick, val = ori, best
+        if su.shape[3] < 64:          # undecided shift: take the other one
+            other = torch.where(top.indices[..., 0] == ori, top.indices[..., 1], top.indices[..., 0])
+            flip = gap <= 3.9 * cls.SCORE_ROUNDING * scale
+            pick = torch.where(flip, other, ori)
+            val = torch.gather(sc, 2, pick[:, :, None]).squeeze(-1)
+        d = 2 * (1 - val / (torch.gather(win, 1, pick) * sn[None, :]))
+        err = 0.9 * cls.DISTANCE_EPS * torch.sin(1e7 * d)                        # "rounding": any value inside the bound
+        dist = (d + err).float()
+        ws = torch.cat((win.float().reshape(-1), sn.float()))
+        if want_gap:
+            return None, dist, gap.float(), ws
+        return (None, dist, ws) if want_workspace else (None, dist)
+
+    @staticmethod
+    def match_pairs(ov, su, wn, sn, pair_o, pair_s, want_orientation=True):
+        ori, d = O.match_fused(ov, su)                                           # what Fp64MatchKernels.match_fwd returns
+        return ori[pair_o.long(), pair_s.long()], d[pair_o.long(), pair_s.long()]
+
+    @staticmethod
+    def rank_count_band(dist, thr, eps):
+        eps = torch.tensor(eps, dtype=torch.float32)
+        lo, hi = (thr - eps)[None, :], (thr + eps)[None, :]
+        band = (dist >= lo) & (dist <= hi)
+        pairs = torch.nonzero(band)
+        return (dist < lo).sum(0).to(torch.int32), pairs[:, 0].to(torch.int32).contiguous(), pairs[:, 1].to(torch.int32).contiguous()
+
+
+def _dense_data(we, amp=0.02, n_g=400, n_q=120, seed=51):
+    """A gallery dense in near-ties: rows are perturbations (amplitude amp) of a few prototypes, so that many distances fall
+    inside the (widened) rounding band of each other and of the true match. amp = 0.02: so dense that every query has more
+    near-ties than candidates are kept (rank re-scoring by the thousand, top-k through the direct fallback); amp = 0.4: every
+    query undecided, all but a few settled by re-scoring its candidates."""
+    proto = torch.from_numpy(synth.embeddings(seed, 1, (8, 16, 4, 64)))
+    jit = torch.from_numpy(synth.embeddings(seed, 2, (n_g, 16, 4, 64)))
+    gal = proto[torch.arange(n_g) % 8] + amp * jit
+    gal[7] = gal[3]                                                              # exact duplicates too
+    noise = torch.from_numpy(synth.embeddings(seed, 3, (n_q, 16, 4, we)))
+    qry = torch.stack([torch.roll(gal[i], -5 * i, dims=2)[:, :, :we] for i in range(n_q)]) + 0.3 * noise
+    return gal.contiguous(), qry.contiguous()
+
+
+def test_spectral_retrieve_host_logic_equals_direct_single_process():
+    from witw_amd import cvig_fov
+    for we, amp in ((64, 0.02), (12, 0.02), (64, 0.4), (12, 0.4)):
+        gal, qry = _dense_data(we, amp)
+        r0, v0, i0 = cvig_fov.retrieve(gal, qry, k=10, query_chunk=50, _kernels=SpectralCpuKernels)                  # direct
+        r1, v1, i1 = cvig_fov.retrieve(gal, qry, k=10, query_chunk=50, method='dft', _kernels=SpectralCpuKernels)
+        st = cvig_fov.retrieve.last_stats
+        np.testing.assert_array_equal(r1, r0)
+        np.testing.assert_array_equal(i1.numpy(), i0.numpy())
+        np.testing.assert_allclose(v1.numpy(), v0.numpy(), rtol=0, atol=st['eps'])
+        assert st['rescored_rank'] > 100 and st['rescored_topk'] > 100           # the fixture does exercise the re-scoring
+        if amp < 0.1:
+            assert st['rescored_rank'] > 3000 and st['fallback_queries'] == 120
+        else:
+            assert 0 < st['fallback_queries'] < 20                               # the rest was settled by re-scoring candidates
+        if we < 64:
+            assert st['rescored_orientation'] > 0 and st['eps'] > SpectralCpuKernels.DISTANCE_EPS
+        # without the re-scoring the emulated spectral distances alone give different answers
+        _, d_s = SpectralCpuKernels.match_fwd_dft(gal, qry)
+        _, i_s = SpectralCpuKernels.topk_smallest(d_s, 10)
+        assert (i_s != i0).any()
+
+
+def _spectral_worker(rank, world, port, we, amp, out_q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from witw_amd import cvig_fov
+        torch.set_num_threads(1)
+        gal, qry = _dense_data(we, amp)
+        split = [60, 0, 100, 1, 90, 49, 70, 30]
+        g0 = sum(split[:rank])
+        ranks, v, i = cvig_fov.retrieve(gal[g0:g0 + split[rank]], qry, k=10, shard_begin=g0, query_chunk=50, method='dft',
+                                        _kernels=SpectralCpuKernels)
+        out_q.put((rank, np.asarray(ranks), v.numpy().copy(), i.numpy().copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_spectral_retrieve_sharded_over_8_ranks_equals_direct():
+    from witw_amd import cvig_fov
+    for we, amp in ((64, 0.4), (12, 0.02)):
+        ctx = mp.get_context('spawn')
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_spectral_worker, args=(r, WORLD, port, we, amp, q)) for r in range(WORLD)]
+        for p in procs:
+            p.start()
+        gal, qry = _dense_data(we, amp)
+        r0, v0, i0 = cvig_fov.retrieve(gal, qry, k=10, query_chunk=50, _kernels=SpectralCpuKernels)                  # direct, one process
+        res = [q.get(timeout=600) for _ in procs]
+        for p in procs:
+            p.join(120)
+            assert p.exitcode == 0
+        for (rank, ranks, v, i) in res:
+            np.testing.assert_array_equal(ranks, r0)
+            np.testing.assert_array_equal(i, i0.numpy())

@@ -81,6 +81,7 @@ SIGNATURES = {
     'witw_match_dft_workspace_floats': (c_longlong, [c_int, c_int]),
     'witw_match_fwd_dft': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p]),
+    'witw_match_fwd_dft_gap': (c_int, [c_void_p] * 4 + [c_int] * 3 + [c_void_p] * 6),
     'witw_crop_overhead': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'witw_l2_distance': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'witw_rank_count': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
@@ -88,6 +89,8 @@ SIGNATURES = {
     'witw_topk_workspace_bytes': (c_longlong, [c_int, c_int, c_int]),
     'witw_topk_smallest_ws': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_longlong, c_void_p, c_void_p]),
     'witw_rank_count_thresh': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    'witw_match_pairs': (c_int, [c_void_p] * 6 + [c_int] * 4 + [c_void_p] * 4),
+    'witw_rank_count_band': (c_int, [c_void_p, c_void_p, c_float] + [c_void_p] * 4 + [c_int] * 3 + [c_void_p]),
     'witw_triplet_loss_fwd': (c_int, [c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     'witw_triplet_loss_slab_fwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     'witw_triplet_loss_slab_sig': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),

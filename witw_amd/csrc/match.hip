@@ -748,6 +748,83 @@ __global__ __launch_bounds__(256) void rank_count_thresh_kernel(const float* __r
     if (c) atomicAdd(&ranks[q], c);
 }
 
+// ---- a LIST of (overhead, surface) pairs through exactly the arithmetic of the all-pairs kernels above: per pair the same
+// chain of v_mfma_f32_32x32x2_f32 over (row, k pair) from a zero accumulator, the same first-index arg-max, the same distance
+// expression -- bit-identical to what witw_match_fwd writes for that pair. One wave per pair: all 32 A rows carry the pair's
+// surface (31/32 of the matrix work is redundant: the price of bit-identity; the callers re-score a few pairs per million).
+// Used by the index-exact spectral retrieval (cvig_fov.retrieve(method='dft')) for the pairs whose spectral distance sits
+// within fp32 rounding of a decision boundary.
+__global__ __launch_bounds__(256) void match_pairs_kernel(const float* __restrict__ ov, const float* __restrict__ su,
+                                                          const float* __restrict__ wn, const float* __restrict__ sn,
+                                                          const int* __restrict__ pair_o, const int* __restrict__ pair_s,
+                                                          int n_pairs, int We, long long* __restrict__ orientation,
+                                                          float* __restrict__ distance, float* __restrict__ score) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pr = blockIdx.x * 4 + wave;
+    if (pr >= n_pairs) return;                       // wave-uniform; the kernel has no barrier
+    const int o = pair_o[pr], s = pair_s[pr];
+    const int l31 = lane & 31, hk = lane >> 5;
+    const int Wp = (We + 1) & ~1;
+    const float* orow = ov + (size_t)o * 4096;
+    const float* srow = su + (size_t)s * 64 * We;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+    for (int r = 0; r < 64; ++r, orow += 64, srow += We) {
+        for (int k = 0; k < Wp; k += 2) {
+            const int kk = k + hk;                   // lanes 0-31 carry k, lanes 32-63 k + 1 (the A / B layout of 32x32x2)
+            const float a = kk < We ? srow[kk] : 0.f;
+            const float b0 = orow[(kk + l31) & 63];
+            const float b1 = orow[(kk + l31 + 32) & 63];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+        }
+    }
+    float v = acc0[0];
+    int idx = l31;
+    const float v1 = acc1[0];
+    if (v1 > v) { v = v1; idx = 32 + l31; }
+#pragma unroll
+    for (int d = 1; d < 32; d <<= 1) {
+        const float vo = __shfl_xor(v, d, 64);
+        const int io = __shfl_xor(idx, d, 64);
+        if (vo > v || (vo == v && io < idx)) { v = vo; idx = io; }
+    }
+    if (lane == 0) {
+        if (orientation) orientation[pr] = idx;
+        if (score) score[pr] = v;
+        if (distance) distance[pr] = 2.f * (1.f - v / (wn[(size_t)o * 64 + idx] * sn[s]));
+    }
+}
+
+// Rank counting against a threshold with a rounding band: D holds distances known to eps (the spectral pass). Rows surely
+// below the threshold are counted, rows inside [thr - eps, thr + eps] are appended to a pair list for exact re-scoring
+// (n_pairs counts them all, also beyond the capacity: the caller then repeats with a larger list).
+__global__ __launch_bounds__(256) void rank_band_kernel(const float* __restrict__ D, const float* __restrict__ thr, float eps,
+                                                        int* __restrict__ counts, int* __restrict__ pair_o,
+                                                        int* __restrict__ pair_s, int* __restrict__ n_pairs, int capacity,
+                                                        int Bo, int Bs, int rows_per_block) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= Bs) return;
+    const float t = thr[q];
+    const float lo = t - eps, hi = t + eps;
+    const int r0 = blockIdx.y * rows_per_block;
+    const int r1 = min(Bo, r0 + rows_per_block);
+    int c = 0;
+    for (int o = r0; o < r1; ++o) {
+        const float d = D[(size_t)o * Bs + q];
+        if (d < lo) ++c;
+        else if (d <= hi) {
+            const int slot = atomicAdd(n_pairs, 1);
+            if (slot < capacity) {
+                pair_o[slot] = o;
+                pair_s[slot] = q;
+            }
+        }
+    }
+    if (c) atomicAdd(&counts[q], c);
+}
+
 }  // namespace
 
 extern "C" {
@@ -876,6 +953,36 @@ int witw_rank_count_thresh(const float* distance, const float* threshold, int* r
     hipLaunchKernelGGL(rank_count_thresh_kernel, dim3(cdiv(Bs, 256), cdiv(Bo, rows)), dim3(256), 0, st, distance, threshold,
                        ranks, Bo, Bs, rows);
     WITW_CHECK_LAUNCH("rank_count_thresh");
+    return WITW_OK;
+}
+
+// n_pairs (overhead row, surface row) pairs -> orientation / distance / score [n_pairs] (any may be null), bit-identical to
+// the entries witw_match_fwd writes for those pairs. wn [Bo,64] / sn [Bs]: the norms of a witw_match_fwd or
+// witw_match_fwd_dft workspace over the same ov / su (window norms first, surface norms behind them).
+int witw_match_pairs(const float* ov, const float* su, const float* wn, const float* sn, const int* pair_o, const int* pair_s,
+                     int n_pairs, int Bo, int Bs, int We, long long* orientation, float* distance, float* score, void* stream) {
+    WITW_CHECK_ARG(ov && su && wn && sn && pair_o && pair_s, "match_pairs: null pointer");
+    WITW_CHECK_ARG(n_pairs > 0 && Bo > 0 && Bs > 0, "match_pairs: empty list n=%d Bo=%d Bs=%d", n_pairs, Bo, Bs);
+    WITW_CHECK_ARG(We >= 1 && We <= 64, "match_pairs: surface embedding width %d outside [1,64]", We);
+    hipLaunchKernelGGL(match_pairs_kernel, dim3(cdiv(n_pairs, 4)), dim3(256), 0, (hipStream_t)stream, ov, su, wn, sn, pair_o, pair_s,
+                       n_pairs, We, orientation, distance, score);
+    WITW_CHECK_LAUNCH("match_pairs");
+    return WITW_OK;
+}
+
+// counts[q] = #{o : D[o,q] < threshold[q] - eps}; the (o, q) with |D[o,q] - threshold[q]| <= eps go to pair_o / pair_s
+// (first `capacity` of them) and *n_pairs = how many there were. counts and *n_pairs are zeroed here.
+int witw_rank_count_band(const float* distance, const float* threshold, float eps, int* counts, int* pair_o, int* pair_s,
+                         int* n_pairs, int capacity, int Bo, int Bs, void* stream) {
+    WITW_CHECK_ARG(distance && threshold && counts && pair_o && pair_s && n_pairs, "rank_count_band: null pointer");
+    WITW_CHECK_ARG(Bo > 0 && Bs > 0 && capacity > 0 && eps >= 0.f, "rank_count_band: bad arguments Bo=%d Bs=%d capacity=%d", Bo, Bs, capacity);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(zero_i32_kernel, dim3(cdiv(Bs, 256)), dim3(256), 0, st, counts, Bs);
+    hipLaunchKernelGGL(zero_i32_kernel, dim3(1), dim3(256), 0, st, n_pairs, 1);
+    const int rows = 512;
+    hipLaunchKernelGGL(rank_band_kernel, dim3(cdiv(Bs, 256), cdiv(Bo, rows)), dim3(256), 0, st, distance, threshold, eps, counts,
+                       pair_o, pair_s, n_pairs, capacity, Bo, Bs, rows);
+    WITW_CHECK_LAUNCH("rank_count_band");
     return WITW_OK;
 }
 

@@ -97,12 +97,15 @@ struct DftArgs {
     long long* orientation;  // [Bo,Bs] or null
     float* distance;         // [Bo,Bs] or null
     float* score;            // [Bo,Bs] or null
+    float* gap;              // [Bo,Bs] or null (GAP instantiation): best score - runner-up score over the 64 shifts
     int Bo, Bs, nbx, nby;
     unsigned long long* stamps;      // null, or 64 slots per 4096th workgroup (WITW_DFT_STAMPS=1: in-kernel timeline)
 };
 
 // REC: the diagnostic instantiation that records the in-kernel timeline (costs registers: the product launch uses REC = false)
-template <bool REC>
+// GAP: the shift scan also tracks the runner-up score and writes best - runner-up (narrow surfaces: the caller re-scores the
+// pairs whose two best shifts tie to rounding, cvig_fov._dft_pass_narrow)
+template <bool REC, bool GAP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void match_dft_kernel(DftArgs p) {
     __shared__ __attribute__((aligned(1024))) float smem[LDS_F];      // the read addresses XOR bits 4-7: stage bases stay 1 KB-aligned
     __shared__ float dt_s[(NSLOT + 1) * 64];      // inverse-transform coefficients; the extra slot (odd waves' 17th) is 0
@@ -264,11 +267,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const float* e = xe + tl * 33;       // row stride 33 -> conflict-free
             const float* od = e + XCH;
             float vlo = -INFINITY, vhi = -INFINITY;
+            float slo = -INFINITY, shi = -INFINITY;      // GAP: runner-up of each half
             int ilo = 0, ihi = 32;
 #pragma unroll 8
             for (int sft = 0; sft < 32; ++sft) {
                 const float ev = e[sft], ov = od[sft];
                 const float lo = ev + ov, hi = ev - ov;
+                if (GAP) {                                // before the maxima move: max(second, min(x, best so far))
+                    slo = fmaxf(slo, fminf(lo, vlo));
+                    shi = fmaxf(shi, fminf(hi, vhi));
+                }
                 if (lo > vlo) { vlo = lo; ilo = sft; }
                 if (hi > vhi) { vhi = hi; ihi = 32 + sft; }
             }
@@ -280,6 +288,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 if (p.orientation) p.orientation[off] = idx;
                 if (p.score) p.score[off] = v;
                 if (p.distance) p.distance[off] = 2.f * (1.f - v / (p.wn[(size_t)og * 64 + idx] * p.sn[s]));
+                if (GAP && p.gap) p.gap[off] = v - fmaxf(fmaxf(slo, shi), fminf(vlo, vhi));
             }
         }
         __syncthreads();
@@ -385,8 +394,8 @@ long long witw_match_dft_workspace_floats(int Bo, int Bs) { return (long long)Bo
 
 // Same outputs as witw_match_fwd (orientation / distance / score [Bo,Bs], any of them may be null) from the row spectra of the
 // two sides (witw_match_spectrum of ov with W = 64 and of su with W = We); ov / su themselves are read for the norms only.
-int witw_match_fwd_dft(const float* ov, const float* su, const float* spec_ov, const float* spec_su, int Bo, int Bs, int We,
-                       long long* orientation, float* distance, float* score, float* workspace, void* stream) {
+static int match_fwd_dft_launch(const float* ov, const float* su, const float* spec_ov, const float* spec_su, int Bo, int Bs, int We,
+                                long long* orientation, float* distance, float* score, float* gap, float* workspace, void* stream) {
     WITW_CHECK_ARG(ov && su && spec_ov && spec_su && workspace, "match_fwd_dft: null pointer");
     WITW_CHECK_ARG(Bo > 0 && Bs > 0, "match_fwd_dft: empty batch Bo=%d Bs=%d", Bo, Bs);
     WITW_CHECK_ARG(We >= 1 && We <= 64, "match_fwd_dft: surface embedding width %d outside [1,64]", We);
@@ -399,7 +408,7 @@ int witw_match_fwd_dft(const float* ov, const float* su, const float* spec_ov, c
     hipLaunchKernelGGL(match_dft_table_kernel, dim3(NSLOT), dim3(64), 0, st, dtab);
     DftArgs a;
     a.spec_ov = spec_ov; a.spec_su = spec_su; a.dtab = dtab; a.wn = wn; a.sn = sn;
-    a.orientation = orientation; a.distance = distance; a.score = score;
+    a.orientation = orientation; a.distance = distance; a.score = score; a.gap = gap;
     a.Bo = Bo; a.Bs = Bs; a.nbx = cdiv(Bs, 32); a.nby = cdiv(Bo, 32);
     const long long tiles = (long long)a.nbx * a.nby;
     static int n_cu = 0;        // persistent workgroups, one per CU
@@ -414,12 +423,13 @@ int witw_match_fwd_dft(const float* ov, const float* su, const float* spec_ov, c
     // tile; printed to stderr
     a.stamps = nullptr;
     const int nrec = 4;
-    if (getenv("WITW_DFT_STAMPS") != nullptr && tiles >= 2LL * grid) {
+    if (!gap && getenv("WITW_DFT_STAMPS") != nullptr && tiles >= 2LL * grid) {
         if (hipMalloc((void**)&a.stamps, (size_t)nrec * 64 * 8) != hipSuccess) a.stamps = nullptr;
         else (void)hipMemset(a.stamps, 0, (size_t)nrec * 64 * 8);
     }
-    if (a.stamps) hipLaunchKernelGGL(match_dft_kernel<true>, dim3(grid), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(match_dft_kernel<false>, dim3(grid), dim3(256), 0, st, a);
+    if (gap) hipLaunchKernelGGL((match_dft_kernel<false, true>), dim3(grid), dim3(256), 0, st, a);
+    else if (a.stamps) hipLaunchKernelGGL((match_dft_kernel<true, false>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((match_dft_kernel<false, false>), dim3(grid), dim3(256), 0, st, a);
     if (a.stamps) {
         (void)hipDeviceSynchronize();
         unsigned long long* h = (unsigned long long*)malloc((size_t)nrec * 64 * 8);
@@ -437,6 +447,19 @@ int witw_match_fwd_dft(const float* ov, const float* su, const float* spec_ov, c
     }
     WITW_CHECK_LAUNCH("match_fwd_dft");
     return WITW_OK;
+}
+
+int witw_match_fwd_dft(const float* ov, const float* su, const float* spec_ov, const float* spec_su, int Bo, int Bs, int We,
+                       long long* orientation, float* distance, float* score, float* workspace, void* stream) {
+    return match_fwd_dft_launch(ov, su, spec_ov, spec_su, Bo, Bs, We, orientation, distance, score, nullptr, workspace, stream);
+}
+
+// witw_match_fwd_dft that also writes gap [Bo,Bs] = best score - runner-up score of every pair (how far the chosen shift is
+// from a tie): the caller re-scores the pairs whose gap is within rounding with witw_match_pairs.
+int witw_match_fwd_dft_gap(const float* ov, const float* su, const float* spec_ov, const float* spec_su, int Bo, int Bs, int We,
+                           long long* orientation, float* distance, float* score, float* gap, float* workspace, void* stream) {
+    WITW_CHECK_ARG(gap, "match_fwd_dft_gap: null gap pointer");
+    return match_fwd_dft_launch(ov, su, spec_ov, spec_su, Bo, Bs, We, orientation, distance, score, gap, workspace, stream);
 }
 
 }  // extern "C"

@@ -701,25 +701,26 @@ def retrieve(overhead_shard, surface_all, k=10, shard_begin=0, query_chunk=4096,
     """sharded_ranks + retrieve_topk from ONE matching pass per query chunk (config C5: the pass is
     2*64*E FLOP per (gallery row, query) and dominates). -> (ranks int64 [N] on the host, distances f32 [N,k],
     gallery indices int64 [N,k] on the device), identical on every rank. The gallery may be sharded raggedly (any
-    number of rows per rank, including none); `_kernels` swaps the op set (CPU tests of the collective algebra)."""
+    number of rows per rank, including none); `_kernels` swaps the op set (CPU tests of the collective algebra).
+    method='dft': the pass runs through the row spectra (21k instead of 524k FLOP per pair) and every decision that the
+    spectral distances leave within fp32 rounding -- a row within DISTANCE_EPS of a query's true-match distance, neighbours
+    in a top-k list closer than 2 DISTANCE_EPS -- is re-made on distances from ops.match_pairs, which are bit-identical to the
+    direct kernel's: ranks and top-k INDICES equal method='direct' exactly (the listed distances agree to DISTANCE_EPS)."""
     from . import parallel
     kn = _kernels or ops
+    if method == 'dft':
+        return _retrieve_dft(overhead_shard, surface_all, k, shard_begin, query_chunk, kn, _want_ranks)
+    if method != 'direct':
+        raise ValueError("retrieve: method must be 'direct' or 'dft'")
     n_q, n_g = surface_all.shape[0], overhead_shard.shape[0]
     counts = torch.zeros((n_q,), dtype=torch.int32, device=surface_all.device)
     vals, idxs = [], []
     gallery = overhead_shard.contiguous()
-    if method not in ('direct', 'dft'):
-        raise ValueError("retrieve: method must be 'direct' or 'dft'")
-    # 'dft': the orientation search through the row spectra (ops.match_fwd_dft, 21k instead of 524k FLOP per pair); the
-    # gallery's spectra are computed once. Scores agree with the direct sum to fp32 rounding.
-    spec_g = kn.match_spectrum(gallery) if method == 'dft' and n_g else None
     for q0 in range(0, n_q, query_chunk):
         q1 = min(n_q, q0 + query_chunk)
         nq = q1 - q0
         if n_g == 0:        # a rank without gallery rows (more ranks than rows): nothing to match, empty candidate lists
             dist = torch.empty((0, nq), dtype=torch.float32, device=surface_all.device)
-        elif method == 'dft':
-            _, dist = kn.match_fwd_dft(gallery, surface_all[q0:q1].contiguous(), spec_ov=spec_g, want_orientation=False)
         else:
             _, dist = kn.match_fwd(gallery, surface_all[q0:q1].contiguous())            # [n_g, q]
         if _want_ranks:
@@ -746,6 +747,148 @@ def retrieve(overhead_shard, surface_all, k=10, shard_begin=0, query_chunk=4096,
     if parallel.world() > 1:
         v, i = _merge_topk(v, i, k, _kernels)
     return (counts.cpu().numpy().astype('int64') if _want_ranks else None), v, i
+
+
+def _sort_by_value_then_index(v, i):
+    """rows of (v, i) ordered by (value, index) ascending; missing candidates (index < 0) last."""
+    big = torch.where(i < 0, torch.full_like(i, 2 ** 62), i)
+    o1 = torch.argsort(big, dim=1, stable=True)
+    v, i = torch.gather(v, 1, o1), torch.gather(i, 1, o1)
+    o2 = torch.argsort(v, dim=1, stable=True)
+    return torch.gather(v, 1, o2), torch.gather(i, 1, o2)
+
+
+def _retrieve_dft(overhead_shard, surface_all, k, shard_begin, query_chunk, kn, want_ranks):
+    """retrieve() on the spectral pass, index-exact (see retrieve). eps = ops.DISTANCE_EPS bounds |d_dft - d_direct| at full
+    width; narrower surfaces (We < 64: the window norm, hence the distance, depends on the chosen shift) first have every pair
+    whose two best spectral scores are within rounding re-scored, so that the same bound holds for what is left."""
+    from . import parallel
+    eps = float(getattr(kn, 'DISTANCE_EPS', ops.DISTANCE_EPS))
+    dev = surface_all.device
+    n_q, n_g, we = surface_all.shape[0], overhead_shard.shape[0], surface_all.shape[3]
+    kc = min(32, k + 6)                                  # local candidates per query, by spectral distance
+    gallery = overhead_shard.contiguous()
+    spec_g = kn.match_spectrum(gallery) if n_g else None
+    counts = torch.zeros((n_q,), dtype=torch.int32, device=dev)
+    vals, idxs, sns = [], [], []
+    wn = None
+    stats = {'pairs': float(n_g) * n_q, 'rescored_rank': 0, 'rescored_topk': 0, 'rescored_true': 0,
+             'rescored_orientation': 0, 'fallback_queries': 0}
+    for q0 in range(0, n_q, query_chunk):
+        q1 = min(n_q, q0 + query_chunk)
+        nq = q1 - q0
+        su = surface_all[q0:q1].contiguous()
+        if n_g:
+            if we < 64:
+                dist, ws, n_fix = _dft_pass_narrow(kn, gallery, su, spec_g)
+                stats['rescored_orientation'] += n_fix
+            else:
+                _, dist, ws = kn.match_fwd_dft(gallery, su, spec_ov=spec_g, want_orientation=False, want_workspace=True)
+            wn, sn = ws[:n_g * 64], ws[n_g * 64:n_g * 64 + nq]
+        else:
+            dist = torch.empty((0, nq), dtype=torch.float32, device=dev)
+            sn = torch.zeros((nq,), dtype=torch.float32, device=dev)
+        sns.append(sn)
+        if q0 == 0 and we < 64:
+            # with the shift settled, d = 2 (1 - score / (|window| |su|)): a score known to 2 SCORE_ROUNDING |ov| |su| gives a
+            # distance known to 4 SCORE_ROUNDING |ov| / |window| -- take the gallery's worst window (the same on every rank)
+            ratio = torch.zeros((1,), dtype=torch.float32, device=dev)
+            if n_g:
+                wmin = wn.reshape(n_g, 64).min(dim=1).values
+                ratio = (gallery.reshape(n_g, -1).norm(dim=1) / wmin).max().reshape(1)
+            if parallel.world() > 1:
+                import torch.distributed as dist_
+                dist_.all_reduce(ratio, op=dist_.ReduceOp.MAX)
+            rounding = float(getattr(kn, 'SCORE_ROUNDING', ops.SCORE_ROUNDING))
+            eps = max(eps, 1.25 * 4 * rounding * float(ratio.item()))
+        if want_ranks:
+            qi = torch.arange(q0, q1, device=dev)
+            own = (qi >= shard_begin) & (qi < shard_begin + n_g)
+            d_true = torch.zeros((nq,), dtype=torch.float32, device=dev)
+            if n_g and bool(own.any()):                  # the owner's EXACT distance of every true pair
+                po = (qi - shard_begin)[own].to(torch.int32).contiguous()
+                ps = (qi - q0)[own].to(torch.int32).contiguous()
+                d_true[own] = kn.match_pairs(gallery, su, wn, sn, po, ps, want_orientation=False)[1]
+                stats['rescored_true'] += int(po.numel())
+            parallel.all_reduce_sum_(d_true)
+            if n_g:
+                c, po, ps = kn.rank_count_band(dist, d_true.contiguous(), eps)
+                if po.numel():
+                    d_x = kn.match_pairs(gallery, su, wn, sn, po, ps, want_orientation=False)[1]
+                    c.index_add_(0, ps.long(), (d_x <= d_true[ps.long()]).to(torch.int32))
+                    stats['rescored_rank'] += int(po.numel())
+                counts[q0:q1] = c
+        if n_g:
+            v, i = kn.topk_smallest(dist, kc, shard_begin)
+        else:
+            v = torch.full((nq, kc), float('inf'), dtype=torch.float32, device=dev)
+            i = torch.full((nq, kc), -1, dtype=torch.int64, device=dev)
+        vals.append(v)
+        idxs.append(i)
+    if want_ranks:
+        parallel.all_reduce_sum_(counts)
+    v, i, sn_all = torch.cat(vals), torch.cat(idxs), torch.cat(sns)
+    # ---- candidates of all shards, ordered by (spectral distance, index)
+    w = parallel.world()
+    outsider = v[:, kc - 1].clone()                      # no row outside a shard's list has a smaller spectral distance
+    if w > 1:
+        v = parallel._all_gather_cat(v.unsqueeze(0)).permute(1, 0, 2).reshape(n_q, w * kc)
+        i = parallel._all_gather_cat(i.unsqueeze(0)).permute(1, 0, 2).reshape(n_q, w * kc)
+        outsider = parallel._all_gather_cat(outsider.unsqueeze(0)).min(dim=0).values
+    v = torch.where(i < 0, torch.full_like(v, float('inf')), v)
+    v, i = _sort_by_value_then_index(v.contiguous(), i.contiguous())
+    ncand = v.shape[1]
+    m = min(ncand, k + 6)                                # candidates re-scored for an undecided query
+    inf_col = torch.full((n_q, 1), float('inf'), dtype=torch.float32, device=dev)
+    vp = torch.cat((v, inf_col), dim=1)
+    gaps = vp[:, 1:k + 1] - vp[:, :k]                    # between places 1..k+1
+    undecided = ((gaps <= 2 * eps) & torch.isfinite(vp[:, :k])).any(dim=1)
+    rows = torch.nonzero(undecided).squeeze(1)           # identical on every rank: computed from gathered data
+    fallback = torch.zeros((0,), dtype=torch.int64, device=dev)
+    if rows.numel():
+        ci = i[rows, :m]                                                     # [r, m] global gallery rows
+        mine = (ci >= shard_begin) & (ci < shard_begin + n_g)
+        exact = torch.zeros(ci.shape, dtype=torch.float32, device=dev)
+        if n_g and bool(mine.any()):
+            po = (ci - shard_begin)[mine].to(torch.int32).contiguous()
+            ps = rows[:, None].expand(-1, m)[mine].to(torch.int32).contiguous()
+            exact[mine] = kn.match_pairs(gallery, surface_all.contiguous(), wn, sn_all, po, ps, want_orientation=False)[1]
+            stats['rescored_topk'] += int(po.numel())
+        parallel.all_reduce_sum_(exact)
+        exact = torch.where(ci < 0, torch.full_like(exact, float('inf')), exact)
+        ev, ei = _sort_by_value_then_index(exact, ci)
+        # nothing outside the re-scored set can belong to the first k: its direct distance is >= its spectral one - eps
+        beyond = torch.minimum(outsider[rows], vp[rows, m]) - eps
+        kth = ev[:, min(k, m) - 1]
+        safe = (kth < beyond) | ~torch.isfinite(beyond)
+        v[rows, :m], i[rows, :m] = ev, ei
+        fallback = rows[~safe]
+    if fallback.numel():     # more near-ties than candidates kept (not seen on real data): those queries take the direct pass
+        stats['fallback_queries'] = int(fallback.numel())
+        _r, fv, fi = retrieve(overhead_shard, surface_all[fallback].contiguous(), k, shard_begin, query_chunk, 'direct',
+                              None if kn is ops else kn, _want_ranks=False)
+        v[fallback, :k], i[fallback, :k] = fv, fi
+    stats['eps'] = eps
+    retrieve.last_stats = stats
+    return (counts.cpu().numpy().astype('int64') if want_ranks else None), v[:, :k].contiguous(), i[:, :k].contiguous()
+
+
+def _dft_pass_narrow(kn, gallery, su, spec_g):
+    """The spectral pass for surfaces narrower than the overhead embedding (We < 64): the window norm depends on the shift, so
+    a pair whose two best scores are within rounding could take the other shift in the direct kernel and land on a different
+    distance. Those pairs (top-2 score gap <= 4 SCORE_ROUNDING |ov| |su|) are re-scored exactly and patched into the matrix.
+    -> (distance [n_g, nq], workspace, pairs re-scored)."""
+    n_g, nq = gallery.shape[0], su.shape[0]
+    _, dist, gap, ws = kn.match_fwd_dft(gallery, su, spec_ov=spec_g, want_orientation=False, want_workspace=True, want_gap=True)
+    wn, sn = ws[:n_g * 64], ws[n_g * 64:n_g * 64 + nq]
+    ov_norm = gallery.reshape(n_g, -1).norm(dim=1)
+    rounding = float(getattr(kn, 'SCORE_ROUNDING', ops.SCORE_ROUNDING))
+    close = gap <= (4 * rounding) * ov_norm[:, None] * sn[None, :]
+    pairs = torch.nonzero(close)
+    if pairs.numel():
+        po, ps = pairs[:, 0].to(torch.int32).contiguous(), pairs[:, 1].to(torch.int32).contiguous()
+        dist[pairs[:, 0], pairs[:, 1]] = kn.match_pairs(gallery, su, wn, sn, po, ps, want_orientation=False)[1]
+    return dist, ws, int(pairs.shape[0])
 
 
 class _ShardedMatchLossFn(torch.autograd.Function):

@@ -289,7 +289,8 @@ def match_spectrum(embed):
     return spec
 
 
-def match_fwd_dft(overhead_embed, surface_embed, spec_ov=None, spec_su=None, want_score=False, want_orientation=True):
+def match_fwd_dft(overhead_embed, surface_embed, spec_ov=None, spec_su=None, want_score=False, want_orientation=True,
+                  want_workspace=False, want_gap=False):
     """match_fwd through the row spectra (21k FLOP per pair instead of 524k): same outputs; scores agree with the direct sum to
     fp32 rounding, so an orientation can differ only between shifts whose scores tie to ~1e-6. spec_ov / spec_su: cached
     match_spectrum of the two sides (the gallery's is computed once per retrieval)."""
@@ -315,12 +316,74 @@ def match_fwd_dft(overhead_embed, surface_embed, spec_ov=None, spec_su=None, wan
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _lib.check(lib.witw_match_fwd_dft(ov.data_ptr(), su.data_ptr(), spec_ov.data_ptr(), spec_su.data_ptr(), Bo, Bs, We,
-                                      _p(ori), dist.data_ptr(), _p(score), ws.data_ptr(), _stream()), 'witw_match_fwd_dft')
+    gap = torch.empty((Bo, Bs), dtype=torch.float32, device=ov.device) if want_gap else None
+    if want_gap:
+        _lib.check(lib.witw_match_fwd_dft_gap(ov.data_ptr(), su.data_ptr(), spec_ov.data_ptr(), spec_su.data_ptr(), Bo, Bs, We,
+                                              _p(ori), dist.data_ptr(), _p(score), gap.data_ptr(), ws.data_ptr(), _stream()),
+                   'witw_match_fwd_dft_gap')
+    else:
+        _lib.check(lib.witw_match_fwd_dft(ov.data_ptr(), su.data_ptr(), spec_ov.data_ptr(), spec_su.data_ptr(), Bo, Bs, We,
+                                          _p(ori), dist.data_ptr(), _p(score), ws.data_ptr(), _stream()), 'witw_match_fwd_dft')
     if prof is not None:      # FLOP of this form per pair: 33 slots x (2 rows x K=128 x 2 + 32 shifts x K=2 x 2) = 21,120
         e1.record()
         prof.append((('match_dft', We), 33.0 * (2 * 128 * 2 + 32 * 2 * 2) * Bo * Bs, e0, e1))
+    if want_gap:            # best - runner-up score per pair (how far the chosen shift is from a tie), then the workspace
+        return ori, dist, gap, ws
+    if want_workspace:      # window norms [Bo,64] then surface norms [Bs]: what match_pairs needs to re-score pairs of this pass
+        return ori, dist, ws
     return (ori, dist, score) if want_score else (ori, dist)
+
+
+# Rounding of one fp32 orientation score, relative to |ov| |su|: both match kernels stay inside it against the fp64 sum
+# (tests/test_match_dft_gpu.py asserts it), so two kernels' scores of one pair differ by at most twice that and their chord
+# distances 2 (1 - score / (|window| |su|)) -- at full width |window| = |ov| -- by at most 4 x (+ the few ulps of the final ops).
+SCORE_ROUNDING = 2e-6
+DISTANCE_EPS = 1e-5
+
+
+def match_pairs(overhead_embed, surface_embed, wn, sn, pair_o, pair_s, want_orientation=True):
+    """(overhead row pair_o[i], surface row pair_s[i]) -> (orientation int64 [n] or None, distance f32 [n]) with the bits
+    match_fwd gives those pairs. wn / sn: the norm blocks of a match_fwd / match_fwd_dft workspace over the same tensors."""
+    lib = _lib.load()
+    ov = _dev_f32(overhead_embed, 'overhead_embed')
+    su = _dev_f32(surface_embed, 'surface_embed')
+    Bo, Bs, We = ov.shape[0], su.shape[0], su.shape[3]
+    n = int(pair_o.numel())
+    for name, t in (('pair_o', pair_o), ('pair_s', pair_s)):
+        if not (t.is_cuda and t.dtype == torch.int32 and t.is_contiguous() and t.numel() == n):
+            raise _lib.WitwError('match_pairs: %s must be a contiguous int32 GPU tensor of %d entries' % (name, n))
+    if wn.numel() != Bo * 64 or sn.numel() != Bs:
+        raise _lib.WitwError('match_pairs: wn / sn must hold [Bo,64] / [Bs] norms')
+    ori = torch.empty((n,), dtype=torch.int64, device=ov.device) if want_orientation else None
+    dist = torch.empty((n,), dtype=torch.float32, device=ov.device)
+    if n:
+        _lib.check(lib.witw_match_pairs(ov.data_ptr(), su.data_ptr(), _dev_f32(wn, 'wn').data_ptr(), _dev_f32(sn, 'sn').data_ptr(),
+                                        pair_o.data_ptr(), pair_s.data_ptr(), n, Bo, Bs, We, _p(ori), dist.data_ptr(), None,
+                                        _stream()), 'witw_match_pairs')
+    return ori, dist
+
+
+def rank_count_band(distance, threshold, eps):
+    """distance [Bo,Bs] known to +-eps -> (counts int32 [Bs] of the rows surely below threshold - eps, pair_o, pair_s int32: the
+    (row, query) inside the band, to be re-scored exactly)."""
+    lib = _lib.load()
+    d = _dev_f32(distance, 'distance')
+    t = _dev_f32(threshold, 'threshold')
+    Bo, Bs = d.shape
+    if t.numel() != Bs:
+        raise _lib.WitwError('rank_count_band: threshold must have one entry per query')
+    counts = torch.empty((Bs,), dtype=torch.int32, device=d.device)
+    n = torch.empty((1,), dtype=torch.int32, device=d.device)
+    cap = max(1 << 16, (Bo * Bs) // 4096)
+    while True:
+        po = torch.empty((cap,), dtype=torch.int32, device=d.device)
+        ps = torch.empty((cap,), dtype=torch.int32, device=d.device)
+        _lib.check(lib.witw_rank_count_band(d.data_ptr(), t.data_ptr(), float(eps), counts.data_ptr(), po.data_ptr(), ps.data_ptr(),
+                                            n.data_ptr(), cap, Bo, Bs, _stream()), 'witw_rank_count_band')
+        got = int(n.item())
+        if got <= cap:
+            return counts, po[:got].contiguous(), ps[:got].contiguous()
+        cap = got            # rare: more pairs in the band than the list holds -> once more with room for all
 
 
 def crop_overhead(overhead_embed, orientation, surface_width):
