@@ -13,9 +13,12 @@ One step = one pass of the hot path over one synthetic batch that is already res
        soft-margin triplet loss (diagonal all-gather + scalar all-reduce), rank counts for the local
        queries                                                  (A7-A10, A12, :297-382, :543-552)
 Per-GPU batch is fixed (weak scaling); value = global pairs / max-over-ranks step time.
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0. At N=1 the line also carries one compact block per other single-GPU BASELINE config
+(config 1 cvig_baseline, the config-2 training step, config 4 cvig_semantic on the bf16 MFMA, config 5 retrieval), each
+measured in this run with its dominant kernel's roofline; `--no-side-blocks` leaves them out.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -82,6 +85,234 @@ def launch_ranks(n):
     return p.returncode if p.returncode != 0 else (0 if line is not None else 1)
 
 
+def sha16(path):
+    try:
+        return hashlib.sha256(open(path, 'rb').read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
+def traffic_of(kname, batch, tag):
+    """HBM/fabric bytes per launch of the dominant kernel from the committed PMC passes (profiles/traffic.json: rocprofv3
+    --pmc FETCH_SIZE / WRITE_SIZE in separate runs, corrected as MI355X_MICROARCH.md prescribes). Counters cannot be read
+    inside a plain run, so the value is tied to the kernel SOURCES it was taken on: if those csrc files changed since, the
+    figure is withheld (null) and `stale` says so. -> (bytes or None, traffic_source dict)."""
+    tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
+    src = {'file': 'profiles/traffic.json', 'how': 'rocprofv3 --pmc FETCH_SIZE, --pmc WRITE_SIZE (separate passes), tools/make_traffic.py'}
+    try:
+        t = json.load(open(tpath))
+    except Exception:
+        return None, dict(src, stale=True, reason='no traffic.json')
+    recorded = t.get('_kernel_sources_sha16', {})
+    current = {f: sha16(os.path.join(ROOT, 'witw_amd', 'csrc', f)) for f in recorded}
+    stale = (not recorded) or any(current[f] != recorded[f] for f in recorded)
+    src.update(kernel_sources_sha16=recorded, stale=bool(stale), libwitw_hip_sha16=sha16(os.path.join(ROOT, 'witw_amd', 'libwitw_hip.so')))
+    if stale:
+        return None, src
+    return t.get('%s_bytes_per_launch_B%d%s' % (kname, batch, tag)), src
+
+
+class StepBench(object):
+    """One configuration of the cvig_fov / cvig_semantic step (model, mode, precision, batch, fov): builds the synthetic batch
+    and the two encoders, times K steps between barrier + synchronize pairs, and derives the live roofline of the dominant
+    kernel from HIP events recorded around every launch on the launch stream (ops.PROFILE)."""
+
+    def __init__(self, model, mode, precision, batch, fov, rank, world, device, graph=False):
+        from witw_amd import cvig_fov, ops, synth, parallel
+        self.cvig_fov, self.ops, self.synth, self.parallel = cvig_fov, ops, synth, parallel
+        self.model, self.mode, self.precision, self.B, self.fov = model, mode, precision, batch, fov
+        self.rank, self.world, self.device, self.graph = rank, world, device, graph
+        self.semantic = model == 'semantic'
+        self.channels = 5 if self.semantic else 3
+        if self.semantic:
+            from witw_amd import cvig_semantic as model_mod
+        else:
+            model_mod = cvig_fov
+        self.model_mod = model_mod
+        seed = 1234
+        self.train = mode == 'train'
+        self.bf16, self.f16x3 = precision == 'bf16', precision == 'fp16x3'
+        self.wts = synth.fov_dsm_weights(seed, in_channels=self.channels)
+        self.se = model_mod.FOV_DSM(circ_padding=False, weights=self.wts).to(device)
+        self.oe = model_mod.FOV_DSM(circ_padding=True, weights=self.wts).to(device)
+        if self.bf16 and self.train:
+            self.se.precision = self.oe.precision = 'bf16'        # mixed-precision step, fp32 master weights
+        if self.f16x3 and self.train:
+            self.se.precision = self.oe.precision = 'fp16x3'      # forward, dgrad and wgrad on fp16x3
+        self.se.train(self.train)
+        self.oe.train(self.train)
+        params = list(self.se.parameters()) + list(self.oe.parameters())
+        self.optimizer = cvig_fov.Adam(params, lr=1.E-5) if self.train else None
+        self.reducer = parallel.OverlappedGradReducer([self.se, self.oe]) if self.train else None
+        self.ground_raw, self.ov_raw = make_inputs(cvig_fov, ops, synth, batch, fov, seed + rank, device, self.channels)
+        self.ws = int(fov / 360 * 512)
+        self.mean, self.std = model_mod.Globals.img_mean, model_mod.Globals.img_std
+        self.ndiv = 3 if self.semantic else None      # only the RGB bands are /255 (model/cvig_semantic.py:172-176)
+        self.step = self.train_step if self.train else self.infer_step
+        if graph:
+            if self.train or world > 1:
+                sys.exit('--graph captures the single-GPU inference step only (no collectives, no optimizer)')
+            captured = parallel.CapturedStep(self.graph_body, [self.ground_raw, self.ov_raw])
+            self.step = lambda: captured(self.ground_raw, self.ov_raw)      # input copy + one hipGraphLaunch
+
+    def preprocess(self, g_raw, o_raw):
+        ops = self.ops
+        surface = ops.resize_bilinear(g_raw, (128, self.ws), self.mean, self.std, self.ndiv)
+        polar = ops.polar_transform(ops.resize_bilinear(o_raw, (256, 256), self.mean, self.std, self.ndiv))
+        return surface, polar
+
+    def embed(self, surface, polar, precision=None):
+        p = precision or self.precision
+        if p == 'fp16x3':
+            return self.se.forward_f16x3(surface), self.oe.forward_f16x3(polar)
+        if p == 'bf16':
+            return self.se.forward_bf16(surface), self.oe.forward_bf16(polar)
+        return self.se(surface), self.oe(polar)
+
+    def train_step(self):
+        with torch.no_grad():
+            surface, polar = self.preprocess(self.ground_raw, self.ov_raw)
+        su = self.se(surface)
+        ov = self.oe(polar)
+        loss, ori, d = self.cvig_fov.sharded_match_loss(ov, su)     # global-batch loss from this rank's [B_global, B] slab
+        self.optimizer.zero_grad()
+        loss.backward()          # each encoder's gradient all-reduce starts as soon as its backward node has run
+        self.reducer.wait()
+        self.optimizer.step()
+        with torch.no_grad():
+            ranks = self.ops.rank_count(d, self.rank * self.B)
+        return loss.detach(), ranks, ori
+
+    def infer_step(self):
+        with torch.no_grad():
+            surface, polar = self.preprocess(self.ground_raw, self.ov_raw)
+            su, ov = self.embed(surface, polar)
+            ov_all = self.parallel._all_gather_cat(ov) if self.world > 1 else ov     # global gallery; surfaces stay local
+            loss, ranks, ori, d = self.cvig_fov.evaluate_global_batch(ov_all, su, self.rank * self.B)
+        return loss, ranks, ori
+
+    def graph_body(self, g_raw, o_raw):
+        with torch.no_grad():
+            surface, polar = self.preprocess(g_raw, o_raw)
+            su, ov = self.embed(surface, polar)
+            return self.cvig_fov.evaluate_global_batch(ov, su, 0)[:3]
+
+    def run(self, steps, warmup):
+        ops, world, device = self.ops, self.world, self.device
+        for _ in range(warmup):
+            self.step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ops.PROFILE = []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss, ranks, ori = self.step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        prof, ops.PROFILE = ops.PROFILE, None
+        if world > 1:
+            t = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+            rk = [torch.empty_like(ranks) for _ in range(world)]
+            dist.all_gather(rk, ranks)
+            ranks = torch.cat(rk)
+        if self.f16x3 and ops.f16x3_overflowed(device):
+            sys.exit('fp16x3: an activation left the fp16 range; the run is invalid')
+        self.dt, self.steps, self.warmup = dt, steps, warmup
+        self.loss, self.ranks = loss, ranks
+        self.ranks_h = ranks.cpu().numpy().astype(np.int64)
+        self.value = self.B * world * steps / dt
+        self.ms = dt / steps * 1e3
+        self.roofline = self._roofline(prof)
+        return self
+
+    def _roofline(self, prof):
+        """Live roofline of the dominant kernel (HIP events on the launch stream, timed region only)."""
+        bf16, f16x3 = self.bf16, self.f16x3
+        dominant = ('bf16', 128, 1, False) if bf16 else ('f16x3', 128, 1, False) if f16x3 else DOMINANT
+        # fp16x3 executes 28 fp16 MFMAs (K=16) per 16 input channels and 9 taps where a plain fp16 conv needs 9: its bound in
+        # fp32-equivalent FLOP/s is the dense fp16 MFMA peak x 9/28
+        peak = PEAK_BF16_MFMA_TFLOPS if bf16 else round(PEAK_BF16_MFMA_TFLOPS * 9 / 28, 1) if f16x3 else PEAK_F32_MFMA_TFLOPS
+        kname = 'conv3x3_nhwc_bf16_kernel<128,1,false,8>' if bf16 else 'conv3x3_nhwc_f16x3_kernel<128,1,false,8>' if f16x3 else \
+            'conv3x3_nhwc_f32_kernel<128,1,false,8,0,9>'
+        dom = [(fl, e0.elapsed_time(e1)) for (v, fl, e0, e1) in prof if v == dominant]
+        allc = [(fl, e0.elapsed_time(e1)) for (v, fl, e0, e1) in prof if v[0] not in ('match', 'wgrad_bf16', 'wgrad_f16x3')]
+        wg = [(fl, e0.elapsed_time(e1)) for (v, fl, e0, e1) in prof if v[0] == 'wgrad_bf16']
+        dom_fl = sum(f for f, _ in dom) / max(1, len(dom))
+        dom_ms = sum(m for _, m in dom) / max(1, len(dom))
+        achieved = dom_fl / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+        conv_tf = sum(f for f, _ in allc) / (sum(m for _, m in allc) * 1e-3) / 1e12 if allc else 0.0
+        traffic, tsrc = None, None
+        if self.fov == 360:      # the PMC passes were taken at fov 360 (other widths change the launch mix)
+            tag = ('_bf16_train' if bf16 else '_train') if self.train else ''     # train modes average forward + dgrad launches
+            traffic, tsrc = traffic_of(kname, self.B, tag)
+        return {'bound': 'mfma', 'kernel': kname, 'achieved': round(achieved, 2),
+                'peak': peak, 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
+                'traffic': traffic, **({'traffic_source': tsrc} if tsrc else {}),
+                'launches': len(dom), 'avg_launch_ms': round(dom_ms, 4),
+                'avg_launch_gflop': round(dom_fl / 1e9, 2), 'all_conv_launches_tflops': round(conv_tf, 2),
+                **({'wgrad_bf16_tflops_incl_layout_passes': round(sum(f for f, _ in wg) / (sum(m for _, m in wg) * 1e-3) / 1e12, 2)}
+                   if wg else {}),
+                **({'note': 'achieved = fp32-equivalent FLOP/s (2*Cin*Cout*9 per output); peak = dense fp16 MFMA peak x 9/28 '
+                            '(the split arithmetic issues 28 MFMAs where a plain fp16 conv issues 9); the fp32 MFMA peak is 157.3'}
+                   if f16x3 else {})}
+
+    def dtype(self):
+        if self.bf16:
+            return 'bf16'
+        if self.f16x3:
+            return ('f16x3 forward, dgrad, wgrad (fp16 hi+lo operands, fp32 accumulate; fp32 gradients and Adam)' if self.train else
+                    'f16x3 (fp16 hi+lo operands, 3 fp16 MFMAs per fp32-equivalent product, fp32 accumulate)')
+        return 'f32'
+
+    def workload(self):
+        mname = 'cvig_semantic (5-channel)' if self.semantic else 'cvig_fov'
+        if not self.train:
+            return ('%s fov=%d eval%s: resize+normalize+polar -> 2x FOV_DSM (VGG16[:23]+3 conv) -> fused match + soft-margin '
+                    'triplet loss + rank counts' % (mname, self.fov, ' [bf16 MFMA encoders, fp32 accumulate; matching fp32]' if self.bf16 else
+                                                   ' [fp16x3 encoders: fp32-grade products on the fp16 MFMA; matching fp32]' if self.f16x3 else ''))
+        return ('%s fov=%d TRAIN step: resize+normalize+polar -> 2x FOV_DSM fwd (Dropout2d) -> match + triplet loss -> backward (%s) '
+                '-> grad all-reduce -> Adam' % (mname + (' [bf16 MFMA fwd/dgrad/wgrad, fp32 accumulate + master weights]' if self.bf16 else
+                                                         ' [forward, dgrad and wgrad on fp16x3 (fp32-grade products on the fp16 MFMA), fp32 gradients / Adam]'
+                                                         if self.f16x3 else ''), self.fov,
+                                                'dgrad L2-27, max-pool scatter, wgrad L0 + L17-27' if self.semantic else 'dgrad L19-27, wgrad L17-27'))
+
+    def line(self):
+        rk = self.ranks_h
+        return {
+            'metric': 'image-pairs/sec (embedding+similarity)' if not self.train else 'image-pairs/sec (training step)',
+            'value': round(self.value, 2), 'unit': 'pairs/s',
+            'n_gpus': self.world, 'steps': self.steps, 'warmup': self.warmup, 'ms_per_step': round(self.ms, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': self.dtype(), 'data': 'synthetic',
+            'config': {'workload': self.workload(), 'pairs_per_gpu': self.B, 'global_batch': self.B * self.world,
+                       'ground_raw': '%dx224x224' % self.channels, 'overhead_raw': '%dx512x512' % self.channels,
+                       'parallelism': 'dp%d (overhead-embedding all-gather, global-batch loss from column slabs)' % self.world,
+                       **({'launch': 'whole step replayed as one hipGraph'} if self.graph else {})},
+            'recall': {'top1_pct': float(np.mean(rk <= 1) * 100), 'top5_pct': float(np.mean(rk <= 5) * 100), 'N': int(len(rk))},
+            'loss': float(self.loss.item()),
+            **({'recall_note': 'train mode: the two encoders draw independent Dropout2d masks (reference :287-288) on random-init '
+                               'weights, so the in-step recall is near chance; the eval-mode recall is the inference bench line'}
+               if self.train else {}),
+            'roofline': self.roofline,
+        }
+
+    def block(self, baseline_config, parity):
+        """Compact form for a side block of the headline line."""
+        r = self.roofline
+        return {'baseline_config': baseline_config, 'workload': self.workload(), 'pairs_per_gpu': self.B,
+                'value': round(self.value, 2), 'unit': 'pairs/s', 'ms_per_step': round(self.ms, 3), 'steps': self.steps,
+                'dtype': self.dtype(), 'loss': float(self.loss.item()),
+                'recall': {'top1_pct': float(np.mean(self.ranks_h <= 1) * 100), 'top5_pct': float(np.mean(self.ranks_h <= 5) * 100)},
+                'roofline': {k: r[k] for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'launches', 'avg_launch_ms',
+                                               'all_conv_launches_tflops') if k in r},
+                'parity': parity}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -89,15 +320,16 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--batch', type=int, default=128, help='pairs per GPU (BASELINE.json configs[1]: bs=128)')
     ap.add_argument('--fov', type=int, default=360)
-    ap.add_argument('--mode', choices=['infer', 'train', 'retrieval'], default='infer',
+    ap.add_argument('--mode', choices=['infer', 'train', 'retrieval', 'baseline', 'e2e'], default='infer',
                     help='infer (headline): embedding + similarity; train: the full step of model/cvig_fov.py:444-461; '
-                         'retrieval: BASELINE config 5, --gallery rows per GPU x --queries, ranks + top-k')
+                         'retrieval: BASELINE config 5, --gallery rows per GPU x --queries, ranks + top-k; baseline: BASELINE '
+                         'config 1, cvig_baseline 32 pairs; e2e: disk -> embeddings through ImagePairDataset + DataLoader workers')
     ap.add_argument('--gallery', type=int, default=125000, help='retrieval: gallery rows PER GPU (1M / 8)')
     ap.add_argument('--queries', type=int, default=10000, help='retrieval: ground queries (replicated)')
     ap.add_argument('--topk', type=int, default=10)
     ap.add_argument('--match', choices=['direct', 'dft'], default='direct',
                     help="retrieval: 'dft' = orientation search through the 64-point row spectra (21k instead of 524k FLOP per "
-                         "pair, same fp32 MFMA; scores equal to fp32 rounding)")
+                         "pair, same fp32 MFMA) with every rounding-level decision re-made on exact distances")
     ap.add_argument('--precision', choices=['fp32', 'bf16', 'fp16x3'], default='fp32',
                     help='fp32 (headline, BASELINE configs[1]) or the bf16 MFMA inference path (configs[3] arithmetic)')
     ap.add_argument('--model', choices=['fov', 'semantic'], default='fov',
@@ -111,6 +343,8 @@ def main():
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL); gloo only for 1-GPU self-tests')
     ap.add_argument('--single-device', action='store_true', help='self-test: put every rank on cuda:0')
     ap.add_argument('--cpu-pairs', type=int, default=8)
+    ap.add_argument('--e2e-pairs', type=int, default=2048)
+    ap.add_argument('--workers', type=int, default=12, help='e2e: DataLoader workers (reference: 12, model/cvig_fov.py:402)')
     a = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -133,239 +367,227 @@ def main():
         else:
             dist.init_process_group(a.backend)
 
-    from witw_amd import _lib, cvig_fov, ops, synth, parallel
+    from witw_amd import _lib, cvig_fov, ops
     _lib.check(_lib.load().witw_device_check(local), 'witw_device_check')
 
     if a.mode == 'retrieval':
-        return retrieval(a, rank, world, device, cvig_fov, ops)
-
-    B = a.batch
-    seed = 1234
-    semantic = a.model == 'semantic'
-    channels = 5 if semantic else 3
-    if semantic:
-        from witw_amd import cvig_semantic as model_mod
+        out = retrieval(a, rank, world, device, cvig_fov, ops)
+    elif a.mode == 'baseline':
+        out = baseline_bench(a, device, full=not a.no_cpu_baseline)
+    elif a.mode == 'e2e':
+        out = e2e_bench(a, device)
     else:
-        model_mod = cvig_fov
-    wts = synth.fov_dsm_weights(seed, in_channels=channels)
-    surface_encoder = model_mod.FOV_DSM(circ_padding=False, weights=wts).to(device)
-    overhead_encoder = model_mod.FOV_DSM(circ_padding=True, weights=wts).to(device)
-    train = a.mode == 'train'
-    bf16 = a.precision == 'bf16'
-    f16x3 = a.precision == 'fp16x3'      # fp32-grade products as fp16 hi/lo triples on the fp16 MFMA (inference)
-    if bf16 and train:
-        surface_encoder.precision = overhead_encoder.precision = 'bf16'     # mixed-precision step, fp32 master weights
-    if f16x3 and train:
-        surface_encoder.precision = overhead_encoder.precision = 'fp16x3'   # forward, dgrad and wgrad on fp16x3
-    surface_encoder.train(train)
-    overhead_encoder.train(train)
-    all_params = list(surface_encoder.parameters()) + list(overhead_encoder.parameters())
-    optimizer = cvig_fov.Adam(all_params, lr=1.E-5) if train else None
-    reducer = parallel.OverlappedGradReducer([surface_encoder, overhead_encoder]) if train else None
-    ground_raw, ov_raw = make_inputs(cvig_fov, ops, synth, B, a.fov, seed + rank, device, channels)
-    ws = int(a.fov / 360 * 512)
-    mean, std = model_mod.Globals.img_mean, model_mod.Globals.img_std
-    ndiv = 3 if semantic else None      # only the RGB bands are /255 (model/cvig_semantic.py:172-176)
-
-    def train_step():
-        with torch.no_grad():
-            surface = ops.resize_bilinear(ground_raw, (128, ws), mean, std, ndiv)
-            overhead = ops.resize_bilinear(ov_raw, (256, 256), mean, std, ndiv)
-            polar = ops.polar_transform(overhead)
-        su = surface_encoder(surface)
-        ov = overhead_encoder(polar)
-        loss, ori, d = cvig_fov.sharded_match_loss(ov, su)       # global-batch loss from this rank's [B_global, B] slab
-        optimizer.zero_grad()
-        loss.backward()          # each encoder's gradient all-reduce starts as soon as its backward node has run
-        reducer.wait()
-        optimizer.step()
-        with torch.no_grad():
-            ranks = ops.rank_count(d, rank * B)
-        return loss.detach(), ranks, ori
-
-    def infer_step():
-        with torch.no_grad():
-            surface = ops.resize_bilinear(ground_raw, (128, ws), mean, std, ndiv)
-            overhead = ops.resize_bilinear(ov_raw, (256, 256), mean, std, ndiv)
-            polar = ops.polar_transform(overhead)
-            if f16x3:
-                su, ov = surface_encoder.forward_f16x3(surface), overhead_encoder.forward_f16x3(polar)
-            else:
-                su = surface_encoder.forward_bf16(surface) if bf16 else surface_encoder(surface)
-                ov = overhead_encoder.forward_bf16(polar) if bf16 else overhead_encoder(polar)
-            ov_all = parallel._all_gather_cat(ov) if world > 1 else ov     # global gallery; surfaces stay local
-            loss, ranks, ori, d = cvig_fov.evaluate_global_batch(ov_all, su, rank * B)
-        return loss, ranks, ori
-
-    step = train_step if train else infer_step
-    if a.graph:
-        if train or world > 1:
-            sys.exit('--graph captures the single-GPU inference step only (no collectives, no optimizer)')
-
-        def graph_body(g_raw, o_raw):
-            with torch.no_grad():
-                surface = ops.resize_bilinear(g_raw, (128, ws), mean, std, ndiv)
-                polar = ops.polar_transform(ops.resize_bilinear(o_raw, (256, 256), mean, std, ndiv))
-                su = surface_encoder.forward_bf16(surface) if bf16 else surface_encoder(surface)
-                ov = overhead_encoder.forward_bf16(polar) if bf16 else overhead_encoder(polar)
-                return cvig_fov.evaluate_global_batch(ov, su, 0)[:3]
-        captured = parallel.CapturedStep(graph_body, [ground_raw, ov_raw])
-        step = lambda: captured(ground_raw, ov_raw)      # noqa: E731  (input copy + one hipGraphLaunch)
-    for _ in range(a.warmup):
-        step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ops.PROFILE = []
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        loss, ranks, ori = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    prof, ops.PROFILE = ops.PROFILE, None
-    if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        rk = [torch.empty_like(ranks) for _ in range(world)]
-        dist.all_gather(rk, ranks)
-        ranks = torch.cat(rk)
-    if f16x3 and ops.f16x3_overflowed(device):
-        sys.exit('fp16x3: an activation left the fp16 range; the run is invalid')
-    ranks_h = ranks.cpu().numpy().astype(np.int64)
-    pairs = B * world * a.steps
-    value = pairs / dt
-
-    # ---- live roofline of the dominant kernel (HIP events on the launch stream, timed region only)
-    dominant = ('bf16', 128, 1, False) if bf16 else ('f16x3', 128, 1, False) if f16x3 else DOMINANT
-    # fp16x3 executes 28 fp16 MFMAs (K=16) per 16 input channels and 9 taps where a plain fp16 conv needs 9: its bound in
-    # fp32-equivalent FLOP/s is the dense fp16 MFMA peak x 9/28
-    peak = PEAK_BF16_MFMA_TFLOPS if bf16 else round(PEAK_BF16_MFMA_TFLOPS * 9 / 28, 1) if f16x3 else PEAK_F32_MFMA_TFLOPS
-    kname = 'conv3x3_nhwc_bf16_kernel<128,1,false,8>' if bf16 else 'conv3x3_nhwc_f16x3_kernel<128,1,false,8>' if f16x3 else \
-        'conv3x3_nhwc_f32_kernel<128,1,false,8,0,9>'
-    dom = [(fl, e0.elapsed_time(e1)) for (v, fl, e0, e1) in prof if v == dominant]
-    allc = [(fl, e0.elapsed_time(e1)) for (v, fl, e0, e1) in prof if v[0] not in ('match', 'wgrad_bf16', 'wgrad_f16x3')]
-    wg = [(fl, e0.elapsed_time(e1)) for (v, fl, e0, e1) in prof if v[0] == 'wgrad_bf16']
-    dom_fl = sum(f for f, _ in dom) / max(1, len(dom))
-    dom_ms = sum(m for _, m in dom) / max(1, len(dom))
-    achieved = dom_fl / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
-    conv_tf = sum(f for f, _ in allc) / (sum(m for _, m in allc) * 1e-3) / 1e12 if allc else 0.0
-    traffic = None
-    tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
-    if os.path.exists(tpath) and a.fov == 360:      # the PMC passes were taken at fov 360 (other widths change the launch mix)
-        try:
-            tag = ('_bf16_train' if bf16 else '_train') if train else ''     # train modes average forward + dgrad launches
-            traffic = json.load(open(tpath)).get('%s_bytes_per_launch_B%d%s' % (kname, B, tag))
-        except Exception:
-            traffic = None
-
-    mname = 'cvig_semantic (5-channel)' if semantic else 'cvig_fov'
-    out = {
-        'metric': 'image-pairs/sec (embedding+similarity)' if not train else 'image-pairs/sec (training step)', 'value': round(value, 2), 'unit': 'pairs/s',
-        'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 3),
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'bf16' if bf16 else ('f16x3 forward, dgrad, wgrad (fp16 hi+lo operands, fp32 accumulate; fp32 gradients and Adam)' if train else
-                                     'f16x3 (fp16 hi+lo operands, 3 fp16 MFMAs per fp32-equivalent product, fp32 accumulate)') if f16x3 else 'f32',
-        'data': 'synthetic',
-        'config': {'workload': ('%s fov=%d eval%s: resize+normalize+polar -> 2x FOV_DSM (VGG16[:23]+3 conv) -> '
-                                'fused match + soft-margin triplet loss + rank counts' % (mname, a.fov, ' [bf16 MFMA encoders, fp32 accumulate; matching fp32]' if bf16 else ' [fp16x3 encoders: fp32-grade products on the fp16 MFMA; matching fp32]' if f16x3 else '')) if not train else
-                               ('%s fov=%d TRAIN step: resize+normalize+polar -> 2x FOV_DSM fwd (Dropout2d) -> match + '
-                                'triplet loss -> backward (%s) -> grad all-reduce -> Adam'
-                                % (mname + (' [bf16 MFMA fwd/dgrad/wgrad, fp32 accumulate + master weights]' if bf16 else
-                                            ' [forward, dgrad and wgrad on fp16x3 (fp32-grade products on the fp16 MFMA), fp32 gradients / Adam]' if f16x3 else ''), a.fov,
-                                   'dgrad L2-27, max-pool scatter, wgrad L0 + L17-27' if semantic else 'dgrad L19-27, wgrad L17-27')),
-                   'pairs_per_gpu': B, 'global_batch': B * world, 'ground_raw': '%dx224x224' % channels,
-                   'overhead_raw': '%dx512x512' % channels,
-                   'parallelism': 'dp%d (overhead-embedding all-gather, global-batch loss from column slabs)' % world,
-                   **({'launch': 'whole step replayed as one hipGraph'} if a.graph else {})},
-        'recall': {'top1_pct': float(np.mean(ranks_h <= 1) * 100), 'top5_pct': float(np.mean(ranks_h <= 5) * 100),
-                   'N': int(len(ranks_h))},
-        'loss': float(loss.item()),
-        **({'recall_note': 'train mode: the two encoders draw independent Dropout2d masks (reference :287-288) on random-init '
-                           'weights, so the in-step recall is near chance; the eval-mode recall is the inference bench line'}
-           if train else {}),
-        'roofline': {'bound': 'mfma', 'kernel': kname, 'achieved': round(achieved, 2),
-                     'peak': peak, 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
-                     'traffic': traffic, 'launches': len(dom), 'avg_launch_ms': round(dom_ms, 4),
-                     'avg_launch_gflop': round(dom_fl / 1e9, 2), 'all_conv_launches_tflops': round(conv_tf, 2),
-                     **({'wgrad_bf16_tflops_incl_layout_passes': round(sum(f for f, _ in wg) / (sum(m for _, m in wg) * 1e-3) / 1e12, 2)}
-                        if wg else {}),
-                     **({'note': 'achieved = fp32-equivalent FLOP/s (2*Cin*Cout*9 per output); peak = dense fp16 MFMA peak x 9/28 '
-                                 '(the split arithmetic issues 28 MFMAs where a plain fp16 conv issues 9); the fp32 MFMA peak is 157.3'}
-                        if f16x3 else {})},
-    }
-
-    if rank == 0 and world == 1 and not a.no_cpu_baseline and not train and not bf16 and not f16x3:
-        out['cpu_baseline'] = cpu_baseline(a, ground_raw, ov_raw, wts, ws, step, semantic)
-    if world == 1 and not train and not bf16 and not f16x3 and not a.graph and not a.no_side_blocks:
-        # the same step with fp32-grade products from fp16 hi/lo pairs on the fp16 MFMA (--precision fp16x3), reported beside
-        # the headline, never as `value`: same inputs, same weights, embeddings compared with the exact-fp32 kernels'
-        def step3():
-            with torch.no_grad():
-                surface = ops.resize_bilinear(ground_raw, (128, ws), mean, std, ndiv)
-                polar = ops.polar_transform(ops.resize_bilinear(ov_raw, (256, 256), mean, std, ndiv))
-                su3, ov3 = surface_encoder.forward_f16x3(surface), overhead_encoder.forward_f16x3(polar)
-                return cvig_fov.evaluate_global_batch(ov3, su3, 0) + (su3, ov3, surface, polar)
-        for _ in range(2):
-            r3 = step3()
-        torch.cuda.synchronize()
-        t3 = time.perf_counter()
-        for _ in range(a.steps):
-            r3 = step3()
-        torch.cuda.synchronize()
-        dt3 = (time.perf_counter() - t3) / a.steps
-        with torch.no_grad():
-            su32, ov32 = surface_encoder(r3[6]), overhead_encoder(r3[7])
-        diff = max(float((r3[4] - su32).abs().max()), float((r3[5] - ov32).abs().max()))
-        out['fp32_grade_on_fp16_mfma'] = {
-            'precision': 'fp16x3', 'value': round(B / dt3, 2), 'unit': 'pairs/s', 'ms_per_step': round(dt3 * 1e3, 3),
-            'max_abs_embedding_diff_vs_f32_kernels': diff, 'loss': float(r3[0].item()),
-            'recall': {'top1_pct': float((r3[1] <= 1).float().mean().item() * 100), 'top5_pct': float((r3[1] <= 5).float().mean().item() * 100)},
-            'ranks_differing_from_f32_step': int((r3[1] != ranks).sum().item()), 'overflow': bool(ops.f16x3_overflowed(device)),
-            'note': 'operands carried as fp16 hi + lo, products hi*hi + lo*hi + hi*lo on v_mfma_f32_32x32x16_f16, fp32 accumulate; '
-                    'held to the reference goldens at the same 1e-4 as the f32 kernels (tests/test_f16x3_gpu.py)'}
-    if world == 1 and not train and not bf16 and not f16x3 and not a.graph and not semantic and a.fov == 360 and not a.no_side_blocks:
-        out['config5_retrieval'] = retrieval_summary(device, cvig_fov, ops)
+        out = step_line(a, rank, world, device, cvig_fov, ops)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
 
-def retrieval_summary(device, cvig_fov, ops, G=125000, Q=10000, k=10):
-    """BASELINE config 5's per-GPU share (125,000 gallery rows x 10,000 queries, ranks + top-10) measured beside the headline
-    with the spectral orientation search: one warm-up and one timed pass (`--mode retrieval [--match dft]` is the full line,
-    the direct-sum pass takes 4.6 s)."""
+def step_line(a, rank, world, device, cvig_fov, ops):
+    sb = StepBench(a.model, a.mode, a.precision, a.batch, a.fov, rank, world, device, a.graph).run(a.steps, a.warmup)
+    out = sb.line()
+    headline = world == 1 and a.mode == 'infer' and a.precision == 'fp32' and not a.graph
+    side = headline and not a.no_side_blocks and a.model == 'fov' and a.fov == 360 and a.batch == 128
+    if headline and not a.no_side_blocks:
+        out['fp32_grade_on_fp16_mfma'] = fp16x3_block(sb, a.steps)
+    cpu_args = (sb.ground_raw[:a.cpu_pairs].cpu(), sb.ov_raw[:a.cpu_pairs].cpu(), sb.wts, sb.semantic) if headline else None
+    if side:
+        del sb
+        torch.cuda.empty_cache()
+        k = max(2, min(a.steps, 5))
+        t = StepBench('fov', 'train', 'fp32', a.batch, a.fov, rank, world, device).run(k, 2)
+        out['train_step_fp32'] = t.block('configs[1] shape (cvig_fov bs=128, fp32), the training step of model/cvig_fov.py:444-461',
+                                         'every trainable gradient within 1e-4 of its norm of the reference run with reconciled ReLU gates, '
+                                         'Adam update within 1e-3 lr (tests/test_backward_gpu.py::test_training_step_matches_reference_golden)')
+        del t
+        torch.cuda.empty_cache()
+        s = StepBench('semantic', 'infer', 'bf16', a.batch, a.fov, rank, world, device).run(k, 2)
+        blk = s.block('configs[3]: cvig_semantic, bf16 MFMA, 1 GPU', None)
+        with torch.no_grad():       # accuracy of this very step against the exact-fp32 kernels on the same inputs
+            surface, polar = s.preprocess(s.ground_raw, s.ov_raw)
+            su_b, ov_b = s.embed(surface, polar)
+            su_f, ov_f = s.embed(surface, polar, 'fp32')
+            rel = max(float((su_b - su_f).norm() / su_f.norm()), float((ov_b - ov_f).norm() / ov_f.norm()))
+            _l, r32, _o, _d = cvig_fov.evaluate_global_batch(ov_f, su_f, 0)
+        blk['parity'] = {'embedding_rel_l2_vs_f32_kernels': rel, 'stated_tolerance': 5e-2,
+                         'top1_pct_f32_kernels': float((r32 <= 1).float().mean().item() * 100),
+                         'test': 'tests/test_bf16_gpu.py (vs CPU emulation of bf16 storage 1e-2, vs fp32 reference goldens 5e-2 of the norm)'}
+        out['config4_semantic_bf16'] = blk
+        del s, su_b, ov_b, su_f, ov_f, surface, polar
+        torch.cuda.empty_cache()
+        out['config1_baseline'] = baseline_bench(a, device, full=not a.no_cpu_baseline)
+        torch.cuda.empty_cache()
+        out['config5_retrieval'] = retrieval_block(device, cvig_fov, ops, 125000, 10000, 10, 'dft')
+        torch.cuda.empty_cache()
+        out['config5_retrieval_direct'] = retrieval_block(device, cvig_fov, ops, 125000, 1024, 10, 'direct')
+        torch.cuda.empty_cache()
+    if headline and rank == 0 and not a.no_cpu_baseline:      # last: nothing on the GPU waits behind the CPU leg
+        out['cpu_baseline'] = cpu_baseline(a, *cpu_args)
+    return out
+
+
+def fp16x3_block(sb, steps):
+    """The same step with fp32-grade products from fp16 hi/lo pairs on the fp16 MFMA (--precision fp16x3), reported beside the
+    headline, never as `value`: same inputs, same weights, embeddings compared with the exact-fp32 kernels'."""
+    ops, cvig_fov = sb.ops, sb.cvig_fov
+
+    def step3():
+        with torch.no_grad():
+            surface, polar = sb.preprocess(sb.ground_raw, sb.ov_raw)
+            su3, ov3 = sb.embed(surface, polar, 'fp16x3')
+            return cvig_fov.evaluate_global_batch(ov3, su3, 0) + (su3, ov3, surface, polar)
+    for _ in range(2):
+        r3 = step3()
+    torch.cuda.synchronize()
+    t3 = time.perf_counter()
+    for _ in range(steps):
+        r3 = step3()
+    torch.cuda.synchronize()
+    dt3 = (time.perf_counter() - t3) / steps
+    with torch.no_grad():
+        su32, ov32 = sb.se(r3[6]), sb.oe(r3[7])
+    diff = max(float((r3[4] - su32).abs().max()), float((r3[5] - ov32).abs().max()))
+    return {'precision': 'fp16x3', 'value': round(sb.B / dt3, 2), 'unit': 'pairs/s', 'ms_per_step': round(dt3 * 1e3, 3),
+            'max_abs_embedding_diff_vs_f32_kernels': diff, 'loss': float(r3[0].item()),
+            'recall': {'top1_pct': float((r3[1] <= 1).float().mean().item() * 100), 'top5_pct': float((r3[1] <= 5).float().mean().item() * 100)},
+            'ranks_differing_from_f32_step': int((r3[1] != sb.ranks).sum().item()), 'overflow': bool(ops.f16x3_overflowed(sb.device)),
+            'note': 'operands carried as fp16 hi + lo, products hi*hi + lo*hi + hi*lo on v_mfma_f32_32x32x16_f16, fp32 accumulate; '
+                    'held to the reference goldens at the same 1e-4 as the f32 kernels (tests/test_f16x3_gpu.py)'}
+
+
+def baseline_bench(a, device, full=True, B=32):
+    """BASELINE config 1: cvig_baseline, 32 pairs, ground 500x500 (SurfaceResize('witw'), model/cvig_baseline.py:219-221) /
+    overhead 512x512, eval step = 2 encoders (7 x [Conv2d(4,2) -> LeakyReLU -> BatchNorm2d], 3 GeM pools) -> exhaustive
+    minibatch triplet loss -> Euclidean rank counts (:228-315, :454-466). BASELINE calls this config CPU plumbing, so the
+    block carries its own cpu_baseline: the oracle on the same 32 pairs."""
+    from witw_amd import cvig_baseline as cb, ops, synth
+    seed = 4242
+    xs = torch.from_numpy(synth.images_u8(seed, 1, (B, 3, 500, 500))).to(device)
+    xo = torch.from_numpy(synth.images_u8(seed, 2, (B, 3, 512, 512))).to(device)
+    # planted matches: the ground image is the (resized) overhead plus noise, re-quantised to 0..255
+    xs = (torch.nn.functional.interpolate(xo, size=(500, 500), mode='bilinear', align_corners=False) * 0.7 + xs * 0.3).round().contiguous()
+    prm_s, prm_o = synth.baseline_params(seed), synth.baseline_params(seed + 1)
+    se, oe = cb.SurfaceEncoder().to(device).eval(), cb.OverheadEncoder().to(device).eval()
+    for enc, prm in ((se, prm_s), (oe, prm_o)):
+        with torch.no_grad():
+            for i, q in enumerate(prm, 1):
+                getattr(enc, 'conv%d' % i).weight.copy_(torch.from_numpy(q['w']))
+                getattr(enc, 'conv%d' % i).bias.copy_(torch.from_numpy(q['b']))
+                bn = getattr(enc, 'bn%d' % i)
+                bn.weight.copy_(torch.from_numpy(q['gamma']))
+                bn.bias.copy_(torch.from_numpy(q['beta']))
+                bn.running_mean.copy_(torch.from_numpy(q['mean']))
+                bn.running_var.copy_(torch.from_numpy(q['var']))
+
+    def step():
+        with torch.no_grad():
+            es, eo = se(xs), oe(xo)
+            loss = cb.exhaustive_minibatch_triplet_loss(es, eo)
+            D = ops.pairwise_sqdist(eo, es, take_sqrt=True)
+            return loss, ops.rank_count(D, 0), es, eo
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    ops.PROFILE = []
+    n = 10
+    t0 = time.perf_counter()
+    for _ in range(n):
+        loss, ranks, es, eo = step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / n * 1e3
+    prof, ops.PROFILE = ops.PROFILE, None
+    conv = [(fl, e0.elapsed_time(e1)) for (v, fl, e0, e1) in prof if v[0] not in ('match', 'match_dft')]
+    conv_ms = sum(m for _, m in conv)
+    tf = sum(f for f, _ in conv) / (conv_ms * 1e-3) / 1e12 if conv else 0.0
+    out = {'baseline_config': 'configs[0]: cvig_baseline, 32 pairs (BASELINE runs it CPU-only; here the same step on the GPU beside the CPU port)',
+           'metric': 'image-pairs/sec (embedding+similarity)',
+           'workload': 'cvig_baseline eval: 32 pairs, ground 3x500x500 + overhead 3x512x512 -> 2 encoders (7 conv4x4/2 + LeakyReLU + '
+                       'BatchNorm, 3 GeM pools) -> exhaustive triplet loss -> Euclidean ranks', 'pairs_per_gpu': B,
+           'value': round(B / ms * 1e3, 2), 'unit': 'pairs/s', 'ms_per_step': round(ms, 3), 'steps': n, 'dtype': 'f32', 'loss': float(loss.item()),
+           'n_gpus': 1, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'data': 'synthetic',
+           'recall': {'top1_pct': float((ranks <= 1).float().mean().item() * 100)},
+           'roofline': {'bound': 'mfma', 'kernel': 'conv3x3_nhwc_f32_kernel<...,TAPS=4> (Conv2d(4,2,0) as space-to-depth(2) + the 2x2 live taps), all 14 launches of a step',
+                        'achieved': round(tf, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tf / PEAK_F32_MFMA_TFLOPS, 4),
+                        'launches': len(conv), 'avg_launch_ms': round(conv_ms / max(1, len(conv)), 4),
+                        'note': 'algorithmic 2*Cin*Cout*16*Ho*Wo FLOP per launch; the conv launches take %.2f of the %.2f ms step' % (conv_ms / n, ms)}}
+    if full:
+        from oracle import cvig_baseline_oracle as OB
+        prm = [[dict((k, torch.from_numpy(np.asarray(v))) for k, v in q.items()) for q in p] for p in (prm_s, prm_o)]
+        xs_c, xo_c = xs.cpu(), xo.cpu()
+
+        def cpu_step():
+            with torch.no_grad():
+                es_r, eo_r = OB.encoder_forward(xs_c, prm[0]), OB.encoder_forward(xo_c, prm[1])
+                return es_r, eo_r, OB.exhaustive_minibatch_triplet_loss(es_r, eo_r), OB.ranks(eo_r, es_r)
+        cpu_step()
+        times = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            es_r, eo_r, loss_r, ranks_r = cpu_step()
+            times.append(time.perf_counter() - t0)
+        med = sorted(times)[1]
+        out['cpu_baseline'] = {'value': round(B / med, 3), 'unit': 'pairs/s', 'cores': torch.get_num_threads(), 'kind': 'port', 'cpu': cpu_model(),
+                               'sample': 'the same 32 pairs, full eval step, median of 3 after 1 warm-up, torch %s CPU ops' % torch.__version__}
+        out['parity'] = {'max_abs_embedding_diff_vs_oracle': max(float((es.cpu() - es_r).abs().max()), float((eo.cpu() - eo_r).abs().max())),
+                         'loss_abs_diff_vs_oracle': abs(float(loss.item()) - float(loss_r)),
+                         'ranks_equal_oracle': bool(np.array_equal(ranks.cpu().numpy().astype(np.int64), np.asarray(ranks_r).astype(np.int64))),
+                         'tolerance': 1e-4}
+    else:
+        out['parity'] = 'embeddings 1e-4 / ranks bit-exact vs the reference goldens (tests/test_baseline_gpu.py)'
+    return out
+
+
+def _retrieval_data(device, G, Q, we, rank=0):
+    """Gallery N(0,1) rows; query q = gallery row q (global numbering, rank-major) rolled by a per-query shift, cropped to the
+    FoV, plus noise (planted matches)."""
     gen = torch.Generator(device=device)
-    gen.manual_seed(4321)
+    gen.manual_seed(4321 + rank)
     gallery = torch.randn((G, 16, 4, 64), generator=gen, device=device)
-    shifts = torch.randint(0, 64, (Q,), generator=gen, device=device)
-    col = (torch.arange(64, device=device)[None, :] + shifts[:, None]) % 64
-    queries = torch.gather(gallery[:Q], 3, col[:, None, None, :].expand(-1, 16, 4, -1)) \
-        + 10.0 * torch.randn((Q, 16, 4, 64), generator=gen, device=device)
-    cvig_fov.retrieve(gallery, queries, k=k, method='dft')
+    queries = torch.zeros((Q, 16, 4, we), device=device)
+    lo, hi = rank * G, min(Q, (rank + 1) * G)
+    if hi > lo:
+        shifts = torch.randint(0, 64, (hi - lo,), generator=gen, device=device)
+        col = (torch.arange(we, device=device)[None, :] + shifts[:, None]) % 64                      # [n, we]
+        rows = gallery[lo - rank * G:hi - rank * G]
+        queries[lo:hi] = torch.gather(rows, 3, col[:, None, None, :].expand(-1, 16, 4, -1)) \
+            + 10.0 * torch.randn((hi - lo, 16, 4, we), generator=gen, device=device)
+    return gallery, queries
+
+
+def retrieval_block(device, cvig_fov, ops, G, Q, k, method):
+    """BASELINE config 5's per-GPU share (G gallery rows x Q queries, ranks + top-k) measured beside the headline: one warm-up
+    and one timed pass. 'dft': the spectral orientation search with the index-exact re-scoring; 'direct': the direct-sum
+    kernel (524,288 FLOP per pair) on a bounded number of queries so that the block stays under a second."""
+    gallery, queries = _retrieval_data(device, G, Q, 64)
+    cvig_fov.retrieve(gallery, queries, k=k, method=method)
     torch.cuda.synchronize()
     ops.PROFILE = []
     t0 = time.perf_counter()
-    ranks_h, vals, idx = cvig_fov.retrieve(gallery, queries, k=k, method='dft')
+    ranks_h, vals, idx = cvig_fov.retrieve(gallery, queries, k=k, method=method)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     prof, ops.PROFILE = ops.PROFILE, None
-    m = [(fl, e0.elapsed_time(e1)) for (v, fl, e0, e1) in prof if v[0] == 'match_dft']
+    kind = 'match_dft' if method == 'dft' else 'match'
+    m = [(fl, e0.elapsed_time(e1)) for (v, fl, e0, e1) in prof if v[0] == kind]
     tf = sum(f for f, _ in m) / (sum(t for _, t in m) * 1e-3) / 1e12 if m else 0.0
-    st = cvig_fov.retrieve.last_stats
-    return {'workload': 'gallery retrieval: %d overhead embeddings x %d ground queries, fov=360, ranks + top-%d' % (G, Q, k),
-            'match': 'dft (witw_match_fwd_dft: orientation search through 64-point row spectra, 21,120 FLOP per pair)',
-            'value': round(float(G) * Q / dt, 1), 'unit': 'pairs/s', 'ms_per_step': round(dt * 1e3, 3),
-            'recall': {'top1_pct': float(np.mean(ranks_h <= 1) * 100), 'top10_pct': float(np.mean(ranks_h <= 10) * 100), 'N': G},
-            'match_kernel_tflops': round(tf, 2), 'match_kernel_frac_of_f32_mfma_peak': round(tf / PEAK_F32_MFMA_TFLOPS, 4),
-            'index_exact': rescore_block(st),
-            'direct_sum_pairs_per_s_in_profiles_r01': 2.73e8,
-            'note': 'the direct-sum pass (witw_match_fwd, 524,288 FLOP per pair at 0.91 of the fp32 MFMA peak) is '
-                    'profiles/r01_bench_retrieval.json; same recall figures'}
+    out = {'baseline_config': 'configs[4] per-GPU share: gallery retrieval, 1M / 8 overhead embeddings per GPU',
+           'workload': 'gallery retrieval: %d overhead embeddings x %d ground queries, fov=360, ranks + top-%d' % (G, Q, k),
+           'match': 'dft (witw_match_fwd_dft: orientation search through 64-point row spectra, 21,120 FLOP per pair; rounding-level '
+                    'decisions re-made on witw_match_pairs distances)' if method == 'dft' else
+                    'direct (witw_match_fwd: 524,288 FLOP per pair)',
+           'value': round(float(G) * Q / dt, 1), 'unit': 'pairs/s', 'ms_per_step': round(dt * 1e3, 3), 'steps': 1, 'dtype': 'f32',
+           'recall': {'top1_pct': float(np.mean(ranks_h <= 1) * 100), 'top10_pct': float(np.mean(ranks_h <= 10) * 100), 'N': G},
+           'roofline': {'bound': 'mfma', 'kernel': 'match_dft_kernel (+ norm / table kernels of the launch)' if method == 'dft' else
+                        'match_kernel_w64 (+ 2 norm kernels of the launch)', 'achieved': round(tf, 2), 'peak': PEAK_F32_MFMA_TFLOPS,
+                        'unit': 'TFLOP/s', 'frac': round(tf / PEAK_F32_MFMA_TFLOPS, 4), 'launches': len(m),
+                        'avg_launch_ms': round(sum(t for _, t in m) / max(1, len(m)), 3),
+                        'flop_per_pair': 21120 if method == 'dft' else 524288}}
+    if method == 'dft':
+        out['index_exact'] = rescore_block(cvig_fov.retrieve.last_stats)
+    else:
+        out['parity'] = 'orientation / ranks bit-exact, distances 1e-5 vs the reference goldens (tests/test_match_gpu.py)'
+    return out
 
 
 def rescore_block(st):
@@ -384,18 +606,7 @@ def retrieval(a, rank, world, device, cvig_fov, ops):
     against the true match and the k nearest rows, merged over ranks (A7-A9, A12; model/cvig_fov.py:543-552)."""
     G, Q, k = a.gallery, a.queries, a.topk
     we = int(a.fov / 360 * 512) // 8
-    gen = torch.Generator(device=device)
-    gen.manual_seed(4321 + rank)
-    gallery = torch.randn((G, 16, 4, 64), generator=gen, device=device)
-    # query q = gallery row q (global numbering, rank-major) rolled by a per-query shift, cropped to the FoV, plus noise
-    queries = torch.zeros((Q, 16, 4, we), device=device)
-    lo, hi = rank * G, min(Q, (rank + 1) * G)
-    if hi > lo:
-        shifts = torch.randint(0, 64, (hi - lo,), generator=gen, device=device)
-        col = (torch.arange(we, device=device)[None, :] + shifts[:, None]) % 64                      # [n, we]
-        rows = gallery[lo - rank * G:hi - rank * G]
-        queries[lo:hi] = torch.gather(rows, 3, col[:, None, None, :].expand(-1, 16, 4, -1)) \
-            + 10.0 * torch.randn((hi - lo, 16, 4, we), generator=gen, device=device)
+    gallery, queries = _retrieval_data(device, G, Q, we, rank)
     if world > 1:
         dist.all_reduce(queries)
 
@@ -448,19 +659,24 @@ def retrieval(a, rank, world, device, cvig_fov, ops):
     }
     if a.match == 'dft':
         out['index_exact'] = rescore_block(cvig_fov.retrieve.last_stats)
-    if rank == 0:
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    return out
 
 
-def cpu_baseline(a, ground_raw, ov_raw, wts, ws, gpu_step, semantic=False):
+def cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return ''
+
+
+def cpu_baseline(a, g, o, wts, semantic):
     """The oracle (CPU restatement of the reference, kind 'port') timed on this host on a bounded
-    sample of the same workload, plus a parity check of the GPU step against it on that sample."""
+    sample of the same workload (the first --cpu-pairs pairs of the batch the GPU step ran on)."""
     from oracle import cvig_fov_oracle as O
-    n = min(a.cpu_pairs, ground_raw.shape[0])
-    g = ground_raw[:n].cpu()
-    o = ov_raw[:n].cpu()
+    n = g.shape[0]
     w = {k: (torch.from_numpy(v[0]), torch.from_numpy(v[1])) for k, v in wts.items()}
     threads = torch.get_num_threads()
     norm = O.image_normalization_semantic if semantic else O.image_normalization
@@ -483,20 +699,17 @@ def cpu_baseline(a, ground_raw, ov_raw, wts, ws, gpu_step, semantic=False):
     times = []
     for _ in range(3):
         t0 = time.perf_counter()
-        su, ov, ori, d, loss, ranks = cpu_step()
+        cpu_step()
         times.append(time.perf_counter() - t0)
     med = sorted(times)[1]
-    cpu_model = ''
-    try:
-        for line in open('/proc/cpuinfo'):
-            if line.startswith('model name'):
-                cpu_model = line.split(':', 1)[1].strip()
-                break
-    except OSError:
-        pass
-    return {'value': round(n / med, 3), 'unit': 'pairs/s', 'cores': threads, 'kind': 'port', 'cpu': cpu_model,
+    return {'value': round(n / med, 3), 'unit': 'pairs/s', 'cores': threads, 'kind': 'port', 'cpu': cpu_model(),
             'sample': '%d pairs of the same synthetic batch, full step (transforms+encoders+match+loss+ranks), '
                       'median of 3 after 1 warm-up, torch %s CPU ops' % (n, torch.__version__)}
+
+
+def e2e_bench(a, device):
+    from witw_amd import e2e
+    return e2e.bench(a, device)
 
 
 if __name__ == '__main__':

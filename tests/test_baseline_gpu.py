@@ -51,6 +51,21 @@ def test_baseline_odd_sizes_vs_oracle():
     np.testing.assert_allclose(enc(x.cuda()).cpu().numpy(), ref, rtol=0, atol=1e-4)
 
 
+@pytest.mark.parametrize('shape', [(4, 512, 512), (8, 512, 512), (5, 500, 500), (32, 512, 512)])
+def test_baseline_encoder_config1_batches_vs_oracle(shape):
+    """BASELINE config 1 shapes at batch sizes that pick the 8-wave workgroups (>= 4 images of 512 x 512): round 1 only ran 2
+    images here, and the 8-wave 64-channel 4-tap variant wrote two of its epilogue slabs past the end of the LDS buffer."""
+    from witw_amd import cvig_baseline
+    B, H, W = shape
+    enc = _load_encoder(cvig_baseline.OverheadEncoder, 4243)
+    prm = [{k: torch.from_numpy(v) for k, v in q.items()} for q in synth.baseline_params(4243)]
+    x = torch.from_numpy(synth.images_u8(9, B, (B, 3, H, W)))
+    with torch.no_grad():
+        ref = OB.encoder_forward(x, prm).numpy()
+    got = enc(x.cuda()).cpu().numpy()
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-4 * max(1.0, float(np.abs(ref).max())))
+
+
 def test_baseline_loss_and_ranks(golden_dir):
     from witw_amd import cvig_baseline
     g = np.load(os.path.join(golden_dir, 'baseline.npz'))
@@ -147,7 +162,8 @@ def test_baseline_training_step_matches_reference_golden(golden_dir):
                           own_grad=named[str(name)].grad.detach().cpu(), min_cover=0.5)    # the last blocks' bias gradients are small
 
 
-@pytest.mark.parametrize('case', [(2, 20, 70, 24, 128, 4), (1, 64, 64, 16, 64, 8), (2, 9, 30, 64, 192, 4), (3, 16, 130, 8, 64, 4)])
+@pytest.mark.parametrize('case', [(2, 20, 70, 24, 128, 4), (1, 64, 64, 16, 64, 8), (2, 9, 30, 64, 192, 4), (3, 16, 130, 8, 64, 4),
+                                  (4, 256, 256, 16, 64, 8)])      # the last: block 1 of a 512 x 512 batch of 4 (8 waves, 64-channel tile)
 def test_taps4_kernels_equal_the_zero_filled_3x3_form(case):
     """The 4-tap kernels (witw_conv3x3_fwd_taps4 / _wgrad_taps4) against the full 3x3 kernels on a filter whose first tap
     row/column are zero: the zero taps only ever add exact zeros, so forward, dgrad and the live weight-gradient taps are

@@ -78,7 +78,11 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_f32_kernel(ConvArgs p) {
     constexpr int WM = (2 * NW) / WGM;               // M-tiles per wave (2*NW per workgroup): 4 at TN=128, 2 at TN=64
     constexpr int WN = 2;                       // N-tiles per wave (64 channels)
 
-    __shared__ f32x4 smem[2 * STAGE_F4 + 1];   // +1: dummy slot that absorbs out-of-tile staging stores
+    // +1: dummy slot that absorbs out-of-tile staging stores. The epilogue re-uses the buffer as NW wave-private 8 KB slabs:
+    // with 4 taps and TN = 64 two stages are smaller than 8 slabs (58.6 KB < 64 KB), so the array is sized for both uses.
+    constexpr int SMEM_F4 = (2 * STAGE_F4 + 1 > NW * 512) ? 2 * STAGE_F4 + 1 : NW * 512;
+    __shared__ f32x4 smem[SMEM_F4];
+    static_assert(SMEM_F4 * 16 >= NW * 32 * 64 * 4, "the buffer must hold one epilogue slab per wave");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
