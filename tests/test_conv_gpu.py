@@ -91,6 +91,31 @@ def test_encoder_matches_reference_goldens(golden_dir):
     np.testing.assert_allclose(e, g['embed360_circ1_train'], rtol=0, atol=TOL)
 
 
+def test_encoder_from_vgg16_state_dict_matches_reference_goldens(golden_dir):
+    """The reference builds its encoders from a torchvision VGG16 (model/cvig_fov.py:256-261; the goldens: the same through a
+    VGG16-shaped module carrying synth's weights, tests/golden/gen_golden.py). The same weights handed over as a
+    torchvision-format state_dict (`features.{i}.*`) through FOV_DSM.from_vgg16_state_dict give the same embeddings."""
+    from witw_amd import cvig_fov
+    g = np.load(os.path.join(golden_dir, 'encoder.npz'))
+    seed = int(g['seed'])
+    w = synth.fov_dsm_weights(seed)
+    sd = {}
+    for idx in cvig_fov.VGG16_CONVS:
+        sd['features.%d.weight' % idx] = torch.from_numpy(w[idx][0].copy())
+        sd['features.%d.bias' % idx] = torch.from_numpy(w[idx][1].copy())
+    x360 = torch.from_numpy(synth.normalized_images(seed, 10, (2, 3, 128, 512))).cuda()
+    for circ in (False, True):
+        enc = cvig_fov.FOV_DSM.from_vgg16_state_dict(sd, circ_padding=circ)
+        with torch.no_grad():
+            for idx in (23, 25, 27):            # the goldens pin the randomly initialised head to synth's values
+                conv = cvig_fov._conv_of(enc.model.features[idx])
+                conv.weight.copy_(torch.from_numpy(w[idx][0]))
+                conv.bias.copy_(torch.from_numpy(w[idx][1]))
+        enc = enc.cuda().eval()
+        with torch.no_grad():
+            np.testing.assert_allclose(enc(x360).cpu().numpy(), g['embed360_circ%d' % circ], rtol=0, atol=TOL)
+
+
 def test_encoder_state_dict_keys_match_reference(golden_dir):
     from witw_amd import cvig_fov
     g = np.load(os.path.join(golden_dir, 'encoder.npz'))

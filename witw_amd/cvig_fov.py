@@ -30,6 +30,13 @@ class Globals:
         'witw': {'path_columns': [15, 16], 'path_names': ['surface', 'overhead'], 'header': 0, 'panorama': False},
     }
 
+    # not in the reference (which downloads them, :256): torchvision VGG16 weights for train() -- a path to a state_dict file
+    # with the keys `features.{i}.weight|bias` / `classifier.*` (torchvision.models.vgg16().state_dict()), or None = seeded
+    # synthetic weights (benchmarks / tests: there is no network here). CLI: --vgg16 PATH.
+    vgg16_weights = None
+    # train() writes checkpoints the reference's strict load_state_dict accepts (the unused VGG classifier keys included)
+    reference_checkpoints = True
+
     # not in the reference: arithmetic of the encoders built by train() / test() / the CLI (`--precision`).
     # 'fp32' = the reference's arithmetic (parity path); 'bf16' = bf16 MFMA operands, fp32 accumulate / weights / Adam.
     precision = 'fp32'
@@ -294,6 +301,12 @@ class FOV_DSM(torch.nn.Module):
     def trainable_convs(self):
         return [(idx, _conv_of(self.model.features[idx])) for (idx, *_r) in self.layer_specs
                 if _conv_of(self.model.features[idx]).weight.requires_grad]
+
+    @classmethod
+    def from_vgg16_state_dict(cls, state, circ_padding=False):
+        """The encoder the reference builds from the pretrained VGG16 (model/cvig_fov.py:256-290): `state` is a
+        torchvision-format VGG16 state_dict or a path to one (load_vgg16_state_dict)."""
+        return load_vgg16_state_dict(cls(circ_padding=circ_padding), state)
 
     def forward(self, x, dropout_scales=None, relu_gates=None, pool_codes=None):
         """x [B,C,128,W] NCHW fp32 on the GPU -> [B,16,4,W/8] NCHW (reference :292-294).
@@ -1097,20 +1110,64 @@ def load_reference_state_dict(encoder, state):
     return encoder.load_state_dict(state, strict=True)
 
 
+VGG16_CLASSIFIER_SHAPES = {0: (4096, 25088), 3: (4096, 4096), 6: (1000, 4096)}      # torchvision vgg16().classifier Linear layers
+
+
 def save_reference_state_dict(encoder, path):
     """Write a checkpoint the reference's `load_state_dict` accepts (model/cvig_fov.py:511-512, strict): this
-    encoder's tensors plus the VGG classifier tensors the reference carries along — the ones a previous
-    load_reference_state_dict saw, else zeros of the VGG16 shapes (they never reach the forward, :258)."""
-    state = dict(encoder.state_dict())
+    encoder's tensors plus the VGG classifier tensors the reference carries along (`self.model = model` keeps the whole
+    VGG, :290) -- the ones a previous load_reference_state_dict / load_vgg16_state_dict saw, else zeros of the VGG16 shapes
+    (they never reach the forward, :258). The zeros are stored as ONE element expanded to the shape (stride 0): the file
+    stays a few MB instead of 530 MB, and load_state_dict copies from it like from any tensor of that shape."""
+    state = {k: v.detach().cpu() for k, v in encoder.state_dict().items()}
     extra = getattr(encoder, '_reference_classifier', None)
     if extra is None:
-        shapes = {0: (4096, 25088), 3: (4096, 4096), 6: (1000, 4096)}
         extra = {}
-        for i, (o, n) in shapes.items():
-            extra['model.classifier.%d.weight' % i] = torch.zeros((o, n))
-            extra['model.classifier.%d.bias' % i] = torch.zeros((o,))
+        for i, (o, n) in VGG16_CLASSIFIER_SHAPES.items():
+            extra['model.classifier.%d.weight' % i] = torch.zeros((1, 1)).expand(o, n)
+            extra['model.classifier.%d.bias' % i] = torch.zeros((1,)).expand(o)
     state.update(extra)
     torch.save(state, path)
+
+
+VGG16_CONVS = (0, 2, 5, 7, 10, 12, 14, 17, 19, 21)     # conv indices of torchvision vgg16().features[:23] (cfg D)
+
+
+def load_vgg16_state_dict(encoder, state):
+    """What the reference's FOV_DSM.__init__ does with torch.hub's pretrained VGG16 (model/cvig_fov.py:256-272), from a
+    torchvision-format state_dict (or a path to one): `features.{i}.weight|bias` of the ten convs of features[:23] go to the
+    same-numbered layers (through the HorizCircPadding / AddDropout wrappers), the three extra convs 23 / 25 / 27 get
+    xavier_uniform weights and zero bias, `classifier.*` is remembered for save_reference_state_dict. cvig_semantic's
+    5-channel first conv (model/cvig_semantic.py:301-303): a freshly initialised Conv2d(5,64) whose first three input
+    channels take the VGG filter (its bias stays the fresh one, as in the reference)."""
+    if isinstance(state, (str, bytes)) or hasattr(state, '__fspath__'):
+        state = torch.load(state, map_location='cpu')
+    if any(k.startswith('model.features') for k in state):
+        raise _lib.WitwError('this is a cvig_fov checkpoint (model.features.*): use load_reference_state_dict')
+    with torch.no_grad():
+        for idx in VGG16_CONVS:
+            conv = _conv_of(encoder.model.features[idx])
+            w, b = state['features.%d.weight' % idx], state['features.%d.bias' % idx]
+            if idx == 0 and conv.in_channels != w.shape[1]:
+                fresh = torch.nn.Conv2d(conv.in_channels, conv.out_channels, kernel_size=3, stride=1, padding=1)
+                conv.weight.copy_(fresh.weight)
+                conv.bias.copy_(fresh.bias)
+                conv.weight[:, :w.shape[1]] = w.to(conv.weight.device)
+            else:
+                if tuple(w.shape) != tuple(conv.weight.shape):
+                    raise _lib.WitwError('features.%d.weight has shape %s, VGG16 layer %d is %s' % (idx, tuple(w.shape), idx,
+                                                                                             tuple(conv.weight.shape)))
+                conv.weight.copy_(w)
+                conv.bias.copy_(b)
+            for t in (conv.weight, conv.bias):
+                t._witw_version = getattr(t, '_witw_version', 0) + 1
+        for idx in (23, 25, 27):
+            conv = _conv_of(encoder.model.features[idx])
+            torch.nn.init.xavier_uniform_(conv.weight)
+            torch.nn.init.zeros_(conv.bias)
+    cls = {'model.' + k: v for k, v in state.items() if k.startswith('classifier.')}
+    encoder._reference_classifier = cls or None
+    return encoder
 
 
 def train(dataset='cvusa', fov=360, val_quantity=1000, batch_size=64, num_workers=12, num_epochs=999999, csv_path=None,
@@ -1144,8 +1201,12 @@ def train(dataset='cvusa', fov=360, val_quantity=1000, batch_size=64, num_worker
                                                sampler=train_sampler, num_workers=num_workers, collate_fn=collate_raw)
     val_loader = torch.utils.data.DataLoader(val_set, batch_size=batch_size, shuffle=False, drop_last=False,
                                              sampler=val_sampler, num_workers=num_workers, collate_fn=collate_raw)
-    surface_encoder = FOV_DSM(circ_padding=False, seed=seed).to(device)
-    overhead_encoder = FOV_DSM(circ_padding=True, seed=seed).to(device)
+    surface_encoder = FOV_DSM(circ_padding=False, seed=seed)
+    overhead_encoder = FOV_DSM(circ_padding=True, seed=seed)
+    if getattr(Globals, 'vgg16_weights', None):      # the reference's starting point (:256-272); else seeded synthetic weights
+        load_vgg16_state_dict(surface_encoder, Globals.vgg16_weights)
+        load_vgg16_state_dict(overhead_encoder, Globals.vgg16_weights)
+    surface_encoder, overhead_encoder = surface_encoder.to(device), overhead_encoder.to(device)
     surface_encoder.precision = overhead_encoder.precision = Globals.precision
     parallel.broadcast_parameters([surface_encoder, overhead_encoder])
     all_params = list(surface_encoder.parameters()) + list(overhead_encoder.parameters())
@@ -1195,8 +1256,12 @@ def train(dataset='cvusa', fov=360, val_quantity=1000, batch_size=64, num_worker
             say('-------> new best')
             best_loss = running_loss / running_count
             if rank == 0:
-                torch.save(surface_encoder.state_dict(), './weights/fov_{}_surface_best.pth'.format(int(fov)))
-                torch.save(overhead_encoder.state_dict(), './weights/fov_{}_overhead_best.pth'.format(int(fov)))
+                for enc, side in ((surface_encoder, 'surface'), (overhead_encoder, 'overhead')):
+                    path = './weights/fov_{}_{}_best.pth'.format(int(fov), side)
+                    if getattr(Globals, 'reference_checkpoints', True):      # the layout the reference's strict load expects (:511-512)
+                        save_reference_state_dict(enc, path)
+                    else:
+                        torch.save(enc.state_dict(), path)
             writer.add_text('best_loss', 'new best loss: {}, epoch: {}'.format(best_loss, epoch + 1), epoch)
     return best_loss
 
@@ -1283,9 +1348,13 @@ def main(argv=None):
     parser.add_argument('--precision', default='fp32', choices=['fp32', 'bf16', 'fp16x3'],
                         help='Encoder arithmetic (not in the reference): fp32, bf16 MFMA mixed precision, or (test mode) fp16x3 = '
                              'fp32-grade products on the fp16 MFMA. [Default = fp32]')
+    parser.add_argument('--vgg16', default=None, metavar='PATH',
+                        help='train mode: torchvision VGG16 state_dict file to start from (the reference downloads it through '
+                             'torch.hub). [Default = seeded synthetic weights]')
     args = parser.parse_args(argv)
     print(args)
     Globals.precision = args.precision
+    Globals.vgg16_weights = args.vgg16
     init_distributed()
     if args.mode == 'train':
         train(dataset=args.dataset, fov=args.fov)

@@ -13,7 +13,7 @@ import torch
 from . import cvig_fov as _fov
 
 from .cvig_fov import (AddDropout, Adam, HorizCircPadding, PolarTransform, Resize, bilinear_interpolate,  # noqa: F401
-                       correlation, crop_overhead,
+                       correlation, crop_overhead, load_reference_state_dict, load_vgg16_state_dict, save_reference_state_dict,
                        inverse_normalize, l2_distance, match, ranks, recall_table, sweep_scores, triplet_loss)
 
 PROJECTOR_DUMP = False      # the reference has the embedding-projector dump commented out here (model/cvig_semantic.py:508-510, :567-571)
@@ -116,9 +116,13 @@ def main(argv=None):
                         help='The field of view for cropping street level images. [Default = 360]')
     parser.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'],
                         help='Encoder arithmetic (not in the reference): fp32, or bf16 MFMA mixed precision. [Default = fp32]')
+    parser.add_argument('--vgg16', default=None, metavar='PATH',
+                        help='train mode: torchvision VGG16 state_dict file to start from (the RGB slice of the 5-channel first '
+                             'conv takes the VGG filter, model/cvig_semantic.py:301-303). [Default = seeded synthetic weights]')
     args = parser.parse_args(argv)
     print(args)
     Globals.precision = args.precision
+    Globals.vgg16_weights = args.vgg16
     _fov.init_distributed()
     if args.mode == 'train':
         train(dataset=args.dataset, fov=args.fov)
