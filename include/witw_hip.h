@@ -149,6 +149,12 @@ int witw_match_pairs(const float* ov, const float* su, const float* wn, const fl
 int witw_rank_count_band(const float* distance, const float* threshold, float eps, int* counts, int* pair_o, int* pair_s,
                          int* n_pairs, int capacity, int Bo, int Bs, void* stream);
 
+/* ---- Dropout2d masks (AddDropout, model/cvig_fov.py:234-245): out [n_layers][B][C] = 0 or 1/(1-p) per (sample, channel) from
+ * Philox4x32-10 keyed on `seed`, counter (sample*C + channel, layers[i] | encoder << 16, step, rank) -- reproducible from those
+ * numbers alone (the reference uses torch's global RNG stream). layers: HOST array of n_layers (<= 3) layer indices. */
+int witw_dropout2d_scales(float* out, unsigned long long seed, unsigned encoder, unsigned step, unsigned rank, const int* layers,
+                          int n_layers, int B, int C, float p, void* stream);
+
 /* ---- triplet_loss, model/cvig_fov.py:366-382. workspace: 4*B floats, filled by fwd, read by bwd. */
 int witw_triplet_loss_fwd(const float* distance /*[B,B]*/, int B, float alpha, float* loss /*[1]*/, float* workspace,
                           void* stream);

@@ -301,3 +301,93 @@ def test_semantic_training_step_matches_reference_golden(golden_dir):
     opt.step()
     for nm in g['names']:
         check_adam_update(g, str(nm), before[str(nm)].cpu(), named[str(nm)].detach().cpu(), 1e-5, own_grad=named[str(nm)].grad.detach().cpu())
+
+
+def _philox4x32_10_first(k0, k1, c0, c1, c2, c3):
+    """numpy restatement of csrc/loss.hip's generator (Salmon et al., SC'11): first output word."""
+    c = [np.asarray(v, dtype=np.uint64) for v in (c0, c1, c2, c3)]
+    k0, k1 = np.uint64(k0), np.uint64(k1)
+    m32 = np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0 = (np.uint64(0xD2511F53) * c[0]) & np.uint64(0xFFFFFFFFFFFFFFFF)
+        p1 = (np.uint64(0xCD9E8D57) * c[2]) & np.uint64(0xFFFFFFFFFFFFFFFF)
+        c = [((p1 >> np.uint64(32)) ^ c[1] ^ k0) & m32, p1 & m32, ((p0 >> np.uint64(32)) ^ c[3] ^ k1) & m32, p0 & m32]
+        k0 = (k0 + np.uint64(0x9E3779B9)) & m32
+        k1 = (k1 + np.uint64(0xBB67AE85)) & m32
+    return c[0]
+
+
+def test_dropout2d_scales_are_the_counter_based_stream():
+    """Dropout2d masks (model/cvig_fov.py:234-245) come from Philox4x32-10 keyed on (seed; sample*C+channel, layer | encoder<<16,
+    step, rank): bit-equal to the numpy restatement, a function of those numbers only, ~20 % dropped, scale 1/0.8."""
+    from witw_amd import ops, cvig_fov
+    seed, enc, step, rank, layers, B, C = 0x1234567890ABCDEF, 7, 5, 3, [17, 19, 21], 6, 512
+    got = ops.dropout2d_scales(seed, enc, step, rank, layers, B, C, 0.2, torch.device('cuda:0')).cpu().numpy()
+    e = np.arange(B * C, dtype=np.uint64)
+    for li, layer in enumerate(layers):
+        x = _philox4x32_10_first(seed & 0xFFFFFFFF, seed >> 32, e, np.uint64(layer | (enc << 16)), np.uint64(step), np.uint64(rank))
+        u = (x >> np.uint64(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+        ref = np.where(u >= np.float32(0.2), np.float32(1.0) / (np.float32(1.0) - np.float32(0.2)), np.float32(0.0)).reshape(B, C)
+        np.testing.assert_array_equal(got[li], ref)
+    assert 0.17 < (got == 0).mean() < 0.23 and set(np.unique(got)) == {np.float32(0.0), np.float32(1.25)}
+    other = ops.dropout2d_scales(seed, enc, step + 1, rank, layers, B, C, 0.2, torch.device('cuda:0')).cpu().numpy()
+    assert (other != got).mean() > 0.2
+    # the encoder draws a new mask every training call, the same sequence again after the same seed, and different ones per encoder
+    w = synth.fov_dsm_weights(3)
+    x = torch.from_numpy(synth.normalized_images(3, 1, (2, 3, 128, 64))).cuda()
+    torch.manual_seed(99)
+    a = cvig_fov.FOV_DSM(False, weights=w).cuda().train()
+    b = cvig_fov.FOV_DSM(False, weights=w).cuda().train()
+    with torch.no_grad():
+        a1, a2, b1 = a(x), a(x), b(x)
+    assert not torch.equal(a1, a2) and not torch.equal(a1, b1)
+    a._drop_step = 0
+    with torch.no_grad():
+        assert torch.equal(a(x), a1)
+
+
+def test_grad_bucket_gradients_are_written_in_place():
+    """parallel.GradBucket / OverlappedGradReducer: every trainable .grad is a view into one flat buffer, the HIP backward
+    writes the weight gradients straight into it (no torch.cat, no copy back: what the all-reduce sends IS the buffer), and
+    the values are those of the plain path bit for bit."""
+    from witw_amd import cvig_fov, parallel
+    w = synth.fov_dsm_weights(11)
+    x = torch.from_numpy(synth.normalized_images(11, 1, (2, 3, 128, 96))).cuda()
+    drops = {i: torch.from_numpy(synth.dropout_scales(11, i, 2, 512)).cuda() for i in (17, 19, 21)}
+
+    def run(with_bucket):
+        enc = cvig_fov.FOV_DSM(True, weights=w).cuda().train()
+        red = parallel.OverlappedGradReducer([enc]) if with_bucket else None
+        opt = cvig_fov.Adam(list(enc.parameters()), lr=1e-5)
+        opt.zero_grad()
+        out = enc(x, dropout_scales=drops)
+        (out * out).sum().backward()
+        return enc, red, opt
+    plain, _r, _o = run(False)
+    enc, red, opt = run(True)
+    bucket = enc._grad_bucket
+    n = 0
+    for (name, p), (_n2, q) in zip(enc.named_parameters(), plain.named_parameters()):
+        if not p.requires_grad:
+            assert p.grad is None
+            continue
+        assert p.grad.data_ptr() == bucket.flat.data_ptr() + 4 * n and p.grad is p._witw_grad_view
+        n += p.numel()
+        assert torch.equal(p.grad, q.grad), name
+    assert n == bucket.flat.numel() == 7236432 and not bucket.fresh and red.wait() == 0
+    # a second backward before zero_grad accumulates (through autograd, in place into the same views)
+    first = bucket.flat.clone()
+    out = enc(x, dropout_scales=drops)
+    (out * out).sum().backward()
+    assert torch.allclose(bucket.flat, 2 * first, rtol=1e-6, atol=0) and enc.model.features[27].layer.weight.grad.data_ptr() == \
+        enc.model.features[27].layer.weight._witw_grad_view.data_ptr()
+    opt.zero_grad()
+    assert float(bucket.flat.abs().max()) == 0.0 and bucket.fresh
+    out = enc(x, dropout_scales=drops)
+    (out * out).sum().backward()
+    assert torch.equal(bucket.flat, first)
+    before = enc.model.features[27].layer.weight.detach().clone()
+    opt.step()
+    assert float((enc.model.features[27].layer.weight.detach() - before).abs().max()) > 0
+    red.close()
+    assert not hasattr(enc, '_grad_bucket') and enc.model.features[27].layer.weight.grad is None

@@ -175,6 +175,7 @@ def test_config3_sharded_match_loss_1024_over_8_ranks():
     for p in procs:
         p.start()
     # the single-process result while the ranks work: full [1024,1024] matrix -> triplet_loss -> autograd
+    threads = torch.get_num_threads()
     torch.set_num_threads(2)
     ov, su = _c3_embeddings()
     ov.requires_grad_(True)
@@ -182,6 +183,7 @@ def test_config3_sharded_match_loss_1024_over_8_ranks():
     ori_f, d_f = fused_match(ov, su)
     loss_f = O.triplet_loss(d_f)                 # model/cvig_fov.py:366-382, normaliser 2 B (B-1) with B = 1024
     loss_f.backward()
+    torch.set_num_threads(threads)
     res = sorted([q.get(timeout=900) for _ in procs], key=lambda t: t[0])
     for p in procs:
         p.join(120)

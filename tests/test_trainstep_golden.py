@@ -115,7 +115,8 @@ def _oracle_case(golden_dir, name):
                 name = ref_key(tag, idx, tag == 'o', kind)
                 gr = grads[(tag, idx)][k]
                 np.testing.assert_allclose(gr.double().norm().item(), float(g['gnorm:' + name]), rtol=1e-5)
-                np.testing.assert_allclose(sample(gr).numpy(), g['gsamp:' + name], rtol=1e-4, atol=1e-9)
+                # (the CPU summation order moves with the thread count: a few 1e-8 on entries of 1e-4 next to ones of 1e-1)
+                np.testing.assert_allclose(sample(gr).numpy(), g['gsamp:' + name], rtol=1e-4, atol=1e-6 * float(np.abs(g['gsamp:' + name]).max()))
                 np.testing.assert_allclose(sample(wd[idx][k]).numpy(), g['psamp:' + name], rtol=0, atol=1e-7)
                 check_adam_update(g, name, before[(tag, idx)][k], wd[idx][k].detach(), 1e-5)
     # the oracle's own gates: equal to the reference's everywhere except (possibly) at listed fragile positions
@@ -159,7 +160,7 @@ def test_oracle_semantic_train_step_matches_reference(golden_dir):
                 name = ref_key(tag, idx, tag == 'o', kind)
                 gr = grads[(tag, idx)][k]
                 np.testing.assert_allclose(gr.double().norm().item(), float(g['gnorm:' + name]), rtol=1e-5)
-                np.testing.assert_allclose(sample(gr).numpy(), g['gsamp:' + name], rtol=1e-4, atol=1e-8)
+                np.testing.assert_allclose(sample(gr).numpy(), g['gsamp:' + name], rtol=1e-4, atol=1e-6 * float(np.abs(g['gsamp:' + name]).max()))
                 check_adam_update(g, name, before[(tag, idx)][k], wd[idx][k].detach(), 1e-5)
 
 

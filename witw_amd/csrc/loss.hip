@@ -196,3 +196,55 @@ int witw_triplet_loss_bwd(const float* distance, const float* workspace, const f
 }
 
 }  // extern "C"
+
+// ---- Dropout2d masks (model/cvig_fov.py:234-245, p = 0.2 behind convs 17 / 19 / 21): whole channels dropped per sample, the
+// kept ones scaled by 1/(1-p). The reference draws them from torch's global RNG stream; here a counter-based generator
+// (Philox4x32-10, Salmon et al. SC'11) keyed on the run's seed with the counter (sample*C + channel, layer | encoder << 16,
+// step, rank): a mask depends on nothing but those numbers, so an N-rank run is reproducible from (seed, rank, step) whatever
+// the launch order, and the backward can re-derive it.
+namespace {
+
+__device__ __forceinline__ unsigned philox4x32_10_first(unsigned k0, unsigned k1, unsigned c0, unsigned c1, unsigned c2, unsigned c3) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1;
+        const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return c0;
+}
+
+__global__ void dropout2d_scales_kernel(float* __restrict__ out, unsigned k0, unsigned k1, unsigned encoder, unsigned step,
+                                        unsigned rank, int l0, int l1, int l2, int n_layers, int BC, float p) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_layers * BC) return;
+    const int li = i / BC, e = i - li * BC;
+    const unsigned layer = (unsigned)(li == 0 ? l0 : li == 1 ? l1 : l2);
+    const unsigned x = philox4x32_10_first(k0, k1, (unsigned)e, layer | (encoder << 16), step, rank);
+    const float u = (float)(x >> 8) * (1.0f / 16777216.0f);       // 24 bits -> [0,1)
+    out[i] = u >= p ? 1.0f / (1.0f - p) : 0.0f;
+}
+
+}  // namespace
+
+extern "C" {
+
+// out [n_layers][B][C]: the Dropout2d scales of up to three layers of one encoder call in one launch.
+int witw_dropout2d_scales(float* out, unsigned long long seed, unsigned encoder, unsigned step, unsigned rank, const int* layers,
+                          int n_layers, int B, int C, float p, void* stream) {
+    WITW_CHECK_ARG(out && layers, "dropout2d_scales: null pointer");
+    WITW_CHECK_ARG(n_layers >= 1 && n_layers <= 3 && B > 0 && C > 0, "dropout2d_scales: bad shape layers=%d B=%d C=%d", n_layers, B, C);
+    WITW_CHECK_ARG(p >= 0.f && p < 1.f, "dropout2d_scales: p=%f outside [0,1)", (double)p);
+    WITW_CHECK_ARG(encoder < 65536u, "dropout2d_scales: encoder id %u too large", encoder);
+    const int total = n_layers * B * C;
+    hipLaunchKernelGGL(dropout2d_scales_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, out, (unsigned)seed,
+                       (unsigned)(seed >> 32), encoder, step, rank, layers[0], n_layers > 1 ? layers[1] : 0,
+                       n_layers > 2 ? layers[2] : 0, n_layers, B * C, p);
+    WITW_CHECK_LAUNCH("dropout2d_scales");
+    return WITW_OK;
+}
+
+}  // extern "C"

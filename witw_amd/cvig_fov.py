@@ -94,6 +94,8 @@ class FOV_DSM(torch.nn.Module):
     weights with load_state_dict. The unused VGG classifier of the reference is not kept.
     """
     in_channels = 3
+    _instances = 0            # encoders built so far: the id that keeps two encoders' Dropout2d masks independent
+    dropout_seed = None       # None: torch.initial_seed()
     # 'fp32' = the reference's arithmetic on the fp32 MFMA kernels (parity path). 'bf16' = mixed precision on the bf16
     # MFMA kernels: bf16 activations / filters / activation gradients, fp32 accumulate, fp32 weight gradients, master
     # weights and Adam (BASELINE config "bf16 MFMA"; not bit-comparable, see tests/test_bf16_train_gpu.py). 'fp16x3' =
@@ -130,6 +132,9 @@ class FOV_DSM(torch.nn.Module):
         self.model = _VGGShell(torch.nn.Sequential(*mods))
         self.circ_padding = circ_padding
         self._packed = {}
+        FOV_DSM._instances += 1
+        self._encoder_id = FOV_DSM._instances & 0xFFFF
+        self._drop_step = 0
 
     def _pack(self, idx):
         conv = _conv_of(self.model.features[idx])
@@ -152,16 +157,22 @@ class FOV_DSM(torch.nn.Module):
         return hit[1]
 
     def _draw_scales(self, x, dropout_scales):
-        scales = {}
-        for (idx, sh, relu, pool, drop) in self.layer_specs:
-            if drop and self.training:
-                if dropout_scales is not None:
-                    scales[idx] = dropout_scales[idx].contiguous()
-                else:   # Dropout2d(p=0.2): whole channels, scale 1/(1-p) (reference :241,288)
-                    conv = _conv_of(self.model.features[idx])
-                    keep = torch.rand((x.shape[0], conv.out_channels), device=x.device) >= 0.2
-                    scales[idx] = keep.float() / 0.8
-        return scales
+        """Dropout2d(p=0.2) scales of this call (whole channels, 1/(1-p) on the kept ones; reference :241,288): injected, or
+        drawn by the counter-based generator of csrc/loss.hip from (seed, encoder, step, rank, layer, sample, channel) in one
+        launch. seed = self.dropout_seed, else torch.initial_seed() (so torch.manual_seed still names the run); the step
+        counter advances per training call."""
+        layers = [idx for (idx, sh, relu, pool, drop) in self.layer_specs if drop]
+        if not self.training or not layers:
+            return {}
+        if dropout_scales is not None:
+            return {idx: dropout_scales[idx].contiguous() for idx in layers}
+        from . import parallel
+        seed = self.dropout_seed if self.dropout_seed is not None else torch.initial_seed()
+        ch = _conv_of(self.model.features[layers[0]]).out_channels
+        p = float(self.model.features[layers[0]].p)
+        sc = ops.dropout2d_scales(seed, self._encoder_id, self._drop_step, parallel.rank(), layers, x.shape[0], ch, p, x.device)
+        self._drop_step += 1
+        return {idx: sc[i] for i, idx in enumerate(layers)}
 
     def _run(self, x, scales, keep_from=None):
         """Layer stack. Returns (embedding NCHW, kept) where kept[idx] = (layer input NHWC, layer output NHWC,
@@ -362,12 +373,15 @@ class _EncoderFn(torch.autograd.Function):
         cout_last = _conv_of(enc.model.features[last]).out_channels
         dz = ops.nchw_to_nhwc(grad_out.contiguous(), (cout_last + 7) // 8 * 8)   # layer 27 has no ReLU
         grads = {}
+        bucket = getattr(enc, '_grad_bucket', None)      # parallel.GradBucket: the wgrad kernels write into its views
+        direct = bucket is not None and bucket.fresh
         for n in range(len(specs) - 1, -1, -1):
             idx, sh, relu, pool, drop = specs[n]
             x_in = kept[idx][0]
             conv = _conv_of(enc.model.features[idx])
             if conv.weight.requires_grad:
-                grads[idx] = ops.conv3x3_wgrad(x_in, dz, conv.in_channels, stride_h=sh, circular=circ)
+                out = (conv.weight._witw_grad_view, conv.bias._witw_grad_view) if direct else None
+                grads[idx] = ops.conv3x3_wgrad(x_in, dz, conv.in_channels, stride_h=sh, circular=circ, out=out)
             if n > 0:   # gradient at the previous layer's conv output
                 pidx, _psh, _prelu, ppool, _pdrop = specs[n - 1]
                 p_in, p_out, p_code = kept[pidx]
@@ -378,6 +392,9 @@ class _EncoderFn(torch.autograd.Function):
                                      out_h=x_in.shape[1] if sh == 2 else None)
                 dz = ops.maxpool2x2_bwd(dy, p_code, (p_in.shape[1], p_in.shape[2])) if ppool else dy
         ctx.kept = None
+        if direct:      # the gradients already sit in the parameters' .grad views: nothing for autograd to accumulate
+            bucket.notify()
+            return (None, None, None) + (None,) * (2 * len(enc.trainable_convs()))
         flat = []
         for (idx, _c) in enc.trainable_convs():
             flat += [grads[idx][0], grads[idx][1]]
@@ -609,8 +626,14 @@ class Adam(object):
         self.state = {}
 
     def zero_grad(self):
+        seen = set()
         for p in self.params:
-            p.grad = None
+            b = getattr(p, '_witw_bucket', None)      # parallel.GradBucket: .grad stays a view into the flat buffer
+            if b is None:
+                p.grad = None
+            elif id(b) not in seen:
+                seen.add(id(b))
+                b.zero()
 
     def step(self):
         for p in self.params:

@@ -196,9 +196,10 @@ def maxpool2x2_bwd(dy, code, out_hw):
     return dx
 
 
-def conv3x3_wgrad(x_nhwc, dz_nhwc, cin_real, stride_h=1, circular=False, want_bias=True, taps4=False):
+def conv3x3_wgrad(x_nhwc, dz_nhwc, cin_real, stride_h=1, circular=False, want_bias=True, taps4=False, out=None):
     """-> (dW [Cout,cin_real,3,3], db [Cout] or None) for one conv layer. taps4: only the taps {1,2}^2 are computed
-    (filters whose first tap row/column are structurally zero), the others come back as exact zeros."""
+    (filters whose first tap row/column are structurally zero), the others come back as exact zeros. out = (dW, db): write
+    into these contiguous tensors (the .grad views of a parallel.GradBucket) instead of fresh ones."""
     lib = _lib.load()
     x = _dev_f32(x_nhwc, 'x')
     dz = _dev_f32(dz_nhwc, 'dz')
@@ -207,8 +208,14 @@ def conv3x3_wgrad(x_nhwc, dz_nhwc, cin_real, stride_h=1, circular=False, want_bi
     Cout = dz.shape[3]
     if tuple(dz.shape[:3]) != (B, Ho, W):
         raise _lib.WitwError('conv3x3_wgrad: dz %s does not match x %s (stride %d)' % (tuple(dz.shape), tuple(x.shape), stride_h))
-    dw = torch.empty((Cout, cin_real, 3, 3), dtype=torch.float32, device=x.device)
-    db = torch.empty((Cout,), dtype=torch.float32, device=x.device) if want_bias else None
+    if out is not None:
+        dw, db = out
+        if not (dw.is_contiguous() and tuple(dw.shape) == (Cout, cin_real, 3, 3) and dw.dtype == torch.float32 and dw.is_cuda
+                and db is not None and db.is_contiguous() and db.numel() == Cout):
+            raise _lib.WitwError('conv3x3_wgrad: out must be contiguous float32 GPU tensors [%d,%d,3,3] and [%d]' % (Cout, cin_real, Cout))
+    else:
+        dw = torch.empty((Cout, cin_real, 3, 3), dtype=torch.float32, device=x.device)
+        db = torch.empty((Cout,), dtype=torch.float32, device=x.device) if want_bias else None
     ws = torch.empty(lib.witw_conv3x3_wgrad_workspace_floats(B, H, W, Cin, Cout, stride_h), dtype=torch.float32,
                      device=x.device)
     if taps4:
@@ -451,6 +458,18 @@ def rank_count_thresh(distance, threshold):
     _lib.check(lib.witw_rank_count_thresh(d.data_ptr(), t.data_ptr(), ranks.data_ptr(), Bo, Bs, _stream()),
                'witw_rank_count_thresh')
     return ranks
+
+
+def dropout2d_scales(seed, encoder, step, rank, layers, batch, channels, p, device):
+    """Dropout2d scales [len(layers), batch, channels] (0 or 1/(1-p)) from the counter-based generator of csrc/loss.hip."""
+    import ctypes
+    lib = _lib.load()
+    out = torch.empty((len(layers), batch, channels), dtype=torch.float32, device=device)
+    arr = (ctypes.c_int * len(layers))(*[int(v) for v in layers])
+    _lib.check(lib.witw_dropout2d_scales(out.data_ptr(), int(seed) & 0xFFFFFFFFFFFFFFFF, int(encoder), int(step) & 0xFFFFFFFF, int(rank),
+                                         ctypes.cast(arr, ctypes.c_void_p), len(layers), batch, channels, float(p), _stream()),
+               'witw_dropout2d_scales')
+    return out
 
 
 def triplet_loss_fwd(distance, alpha=10.):

@@ -80,38 +80,89 @@ def all_reduce_grads(params):
     return off
 
 
+class GradBucket:
+    """The gradients of one module in ONE persistent flat fp32 buffer: every trainable parameter's .grad is a view into it for
+    the life of the bucket, so the all-reduce runs on the buffer itself -- no torch.cat into a staging tensor, no copy back.
+    zero() (called through the optimizer's zero_grad) clears the buffer and marks it `fresh`; a backward that computes all of
+    the module's weight gradients itself (cvig_fov._EncoderFn) then WRITES them straight into the views and calls notify(),
+    any other backward goes through autograd, which accumulates into the views in place."""
+
+    def __init__(self, params, on_ready=None):
+        self.params = list(params)
+        dev = self.params[0].device if self.params else torch.device('cpu')
+        self.flat = torch.zeros(sum(p.numel() for p in self.params), dtype=torch.float32, device=dev)
+        self.views, off = [], 0
+        for p in self.params:
+            v = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+            self.views.append(v)
+            p.grad = v
+            p._witw_grad_view = v
+            p._witw_bucket = self
+        self.fresh = True
+        self.on_ready = on_ready
+
+    def zero(self):
+        self.flat.zero_()
+        for p, v in zip(self.params, self.views):
+            if p.grad is not v:
+                p.grad = v
+        self.fresh = True
+
+    def notify(self):
+        """All gradients of the bucket have been written in place (no autograd accumulation, hence no grad hooks)."""
+        self.fresh = False
+        if self.on_ready is not None:
+            self.on_ready()
+
+    def release(self):
+        for p in self.params:
+            p.grad = None
+            for a in ('_witw_grad_view', '_witw_bucket'):
+                if hasattr(p, a):
+                    delattr(p, a)
+
+
 class OverlappedGradReducer:
-    """Gradient all-reduce (SUM) overlapped with the backward: one flat bucket per module. The backward of an encoder
-    is ONE autograd node (cvig_fov._EncoderFn), so all of its weight gradients appear together; a post-accumulate-grad
-    hook launches that encoder's all-reduce asynchronously the moment its last gradient has landed, and RCCL moves
-    the 29 MB bucket over xGMI while the OTHER encoder's backward kernels run. wait() (before optimizer.step()) joins
-    the collectives, copies the sums back and launches buckets whose gradients never all arrived. With one rank it
-    does nothing. all_reduce_grads() is the same reduction without the overlap."""
+    """Gradient all-reduce (SUM) overlapped with the backward: one GradBucket per module. The backward of an encoder
+    is ONE autograd node (cvig_fov._EncoderFn), so all of its weight gradients appear together -- written by the wgrad
+    kernels directly into the bucket -- and that encoder's all-reduce is launched asynchronously the moment the node has
+    run: RCCL moves the 29 MB bucket over xGMI while the OTHER encoder's backward kernels run. Modules whose gradients come
+    through autograd's accumulation (in place, into the same views) launch from a post-accumulate-grad hook on their last
+    parameter instead. wait() (before optimizer.step()) joins the collectives and launches buckets whose gradients never all
+    arrived. With one rank nothing is sent. all_reduce_grads() is the same reduction without the overlap or the bucket."""
 
     def __init__(self, modules):
-        self.buckets = [[p for p in m.parameters() if p.requires_grad] for m in modules]
-        self.arrived = [0] * len(self.buckets)
+        self.modules = list(modules)
+        self.buckets = []
+        self.arrived = [0] * len(self.modules)
         self.inflight = {}
         self._hooks = []
-        for bi, ps in enumerate(self.buckets):
-            for p in ps:
+        for bi, m in enumerate(self.modules):
+            b = GradBucket([p for p in m.parameters() if p.requires_grad], on_ready=self._ready(bi))
+            self.buckets.append(b)
+            m._grad_bucket = b
+            for p in b.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._hook(bi)))
+
+    def _ready(self, bi):
+        def fn():
+            self.arrived[bi] = len(self.buckets[bi].params)
+            self._launch(bi)
+        return fn
 
     def _hook(self, bi):
         def fn(_p):
             self.arrived[bi] += 1
-            if self.arrived[bi] == len(self.buckets[bi]):
+            if self.arrived[bi] == len(self.buckets[bi].params):
+                self.buckets[bi].fresh = False
                 self._launch(bi)
         return fn
 
     def _launch(self, bi):
-        if world() == 1 or bi in self.inflight:
+        if world() == 1 or bi in self.inflight or not self.buckets[bi].params:
             return
-        grads = [p.grad for p in self.buckets[bi] if p.grad is not None]
-        if not grads:
-            return
-        flat = torch.cat([g.reshape(-1) for g in grads])
-        self.inflight[bi] = (grads, flat, dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True))
+        self.inflight[bi] = dist.all_reduce(self.buckets[bi].flat, op=dist.ReduceOp.SUM, async_op=True)
 
     def wait(self):
         """-> number of floats reduced."""
@@ -119,14 +170,9 @@ class OverlappedGradReducer:
             if self.arrived[bi] > 0:    # a bucket some of whose gradients never came (unused parameters) goes now
                 self._launch(bi)
         n = 0
-        for bi, (grads, flat, work) in sorted(self.inflight.items()):
+        for bi, work in sorted(self.inflight.items()):
             work.wait()
-            off = 0
-            for g in grads:
-                k = g.numel()
-                g.copy_(flat[off:off + k].view_as(g))
-                off += k
-            n += off
+            n += self.buckets[bi].flat.numel()
         self.inflight = {}
         self.arrived = [0] * len(self.buckets)
         return n
@@ -135,6 +181,10 @@ class OverlappedGradReducer:
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        for m, b in zip(self.modules, self.buckets):
+            b.release()
+            if getattr(m, '_grad_bucket', None) is b:
+                del m._grad_bucket
 
 
 class CapturedStep:
