@@ -126,7 +126,7 @@ def test_adam_matches_torch():
     d_ref, d_got = pr.detach() - p0, pg.detach().cpu() - p0
     tol = 3 * 1e-3 * lr + 2 * p0.abs() * 2.0 ** -23
     assert bool(((d_got - d_ref).abs() <= tol).all()), float((d_got - d_ref).abs().max())
-    assert bool((d_got[:10] == 0).all()) and float(d_ref[20:].abs().min()) > 0.5 * lr
+    assert bool((d_got[:10] == 0).all()) and float(d_ref.abs().max()) > lr and float(d_ref[20:].abs().median()) > 0.5 * lr
 
 
 def _gpu_gates(g, tag, enc, gates_out, layers=(17, 19, 21, 23, 25)):
