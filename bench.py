@@ -343,7 +343,7 @@ def main():
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL); gloo only for 1-GPU self-tests')
     ap.add_argument('--single-device', action='store_true', help='self-test: put every rank on cuda:0')
     ap.add_argument('--cpu-pairs', type=int, default=8)
-    ap.add_argument('--e2e-pairs', type=int, default=2048)
+    ap.add_argument('--e2e-pairs', type=int, default=4096)
     ap.add_argument('--workers', type=int, default=12, help='e2e: DataLoader workers (reference: 12, model/cvig_fov.py:402)')
     a = ap.parse_args()
 
@@ -421,6 +421,12 @@ def step_line(a, rank, world, device, cvig_fov, ops):
         out['config5_retrieval'] = retrieval_block(device, cvig_fov, ops, 125000, 10000, 10, 'dft')
         torch.cuda.empty_cache()
         out['config5_retrieval_direct'] = retrieval_block(device, cvig_fov, ops, 125000, 1024, 10, 'direct')
+        torch.cuda.empty_cache()
+        from witw_amd import e2e
+        e = e2e.bench(a, device, n_pairs=2048)
+        out['e2e_data_path'] = {k: e[k] for k in ('metric', 'value', 'unit', 'steady_state_pairs_per_s', 'pipeline_fill_s', 'stage_pairs_per_s',
+                                                  'limiting_stage', 'overlap_efficiency_steady_state')}
+        out['e2e_data_path']['workload'] = e['config']['workload']
         torch.cuda.empty_cache()
     if headline and rank == 0 and not a.no_cpu_baseline:      # last: nothing on the GPU waits behind the CPU leg
         out['cpu_baseline'] = cpu_baseline(a, *cpu_args)

@@ -302,6 +302,13 @@ int witw_exhaustive_triplet_loss_bwd(const float* e1, const float* e2, const flo
  *      PolarTransform (:156-209). NCHW fp32. mean/stdv: HOST arrays of C floats (NULL = resize only). */
 int witw_resize_bilinear_normalize(const float* x, float* y, int B, int C, int Hi, int Wi, int Ho, int Wo,
                                    const float* mean, const float* stdv, int n_div255, void* stream);
+/* Resize (+ normalise) a batch of images of INDIVIDUAL sizes in one launch (the DataLoader hands over raw images of any size,
+ * model/cvig_fov.py:393-403). desc: DEVICE array [B][5] of 64-bit words {device address of image b, H, W, start column, channels
+ * stored per pixel}; kind 0 = float32 planar CHW sources, 1 = uint8 interleaved HWC (decoder output). y [B,C,Ho,Wo] = the image
+ * resized to Ho x Wfull, columns start .. start+Wo-1 (mod Wfull) kept: the panorama crop of Resize (:118-128); Wfull == Wo and
+ * start == 0 give the plain resize. Same arithmetic as witw_resize_bilinear_normalize. */
+int witw_resize_bilinear_normalize_batched(const void* desc, float* y, int B, int C, int Ho, int Wo, int Wfull, int kind,
+                                           const float* mean, const float* stdv, int n_div255, void* stream);
 int witw_normalize(const float* x, float* y, int B, int C, int H, int W, const float* mean, const float* stdv, int n_div255,
                    void* stream);
 /* taps: int32 [Ho*Wo][4] flat offsets into a size*size plane; wts: fp32 [Ho*Wo][4]; both DEVICE tables

@@ -154,3 +154,61 @@ def test_sharded_ranks_single_rank_equals_ranks():
     thr = torch.diagonal(dist).contiguous()
     c = ops.rank_count_thresh(dist[:17].contiguous(), thr) + ops.rank_count_thresh(dist[17:].contiguous(), thr)
     np.testing.assert_array_equal(c.cpu().numpy().astype('int64'), a)
+
+
+def test_batched_preprocess_equals_the_per_sample_transforms(tmp_path):
+    """GpuPreprocess (3 launches per batch: batched resize + normalise over a descriptor table per side, one polar transform)
+    against the per-sample Compose[Resize, ImageNormalization, PolarTransform] (model/cvig_fov.py:393-397): BIT-identical, for
+    float CHW tensors on the host, tensors already on the GPU, and the decoder's uint8 bytes packed by collate_packed; images of
+    different sizes in one batch; panorama crops at per-sample offsets (wrapping) and the plain resize of the witw format."""
+    from witw_amd import cvig_fov
+    sizes = [((48, 80), (64, 64)), ((224, 224), (512, 512)), ((100, 333), (300, 200)), ((37, 51), (90, 77))]
+    raw = [(synth.images_u8(61, 2 * i, s + (3,)).astype(np.uint8), synth.images_u8(61, 2 * i + 1, o + (3,)).astype(np.uint8))
+           for i, (s, o) in enumerate(sizes)]
+    as_float = [{'idx': i, 'surface': torch.from_numpy(s.astype(np.float32).transpose(2, 0, 1).copy()),
+                 'overhead': torch.from_numpy(o.astype(np.float32).transpose(2, 0, 1).copy())} for i, (s, o) in enumerate(raw)]
+    as_bytes = [{'idx': i, 'surface': s, 'overhead': o} for i, (s, o) in enumerate(raw)]
+    starts = [0, 500, 17, 300]
+    for dataset, fov in (('cvusa', 70), ('cvusa', 360), ('witw', 70)):
+        prep = cvig_fov.GpuPreprocess(dataset, fov=fov, random_orientation=False)
+        rs, nm, pt = cvig_fov.Resize(dataset, fov, False), cvig_fov.ImageNormalization(), cvig_fov.PolarTransform()
+        ref_s, ref_p = [], []
+        for smp, st in zip(as_float, starts):
+            d = pt(nm(rs({'surface': smp['surface'].clone(), 'overhead': smp['overhead'].clone()}, start=st)))
+            ref_s.append(d['surface'])
+            ref_p.append(d['polar'])
+        ref_s, ref_p = torch.stack(ref_s), torch.stack(ref_p)
+        batches = {'host float': cvig_fov.collate_raw(as_float),
+                   'resident float': cvig_fov.collate_raw([{k: (v.cuda() if torch.is_tensor(v) else v) for k, v in smp.items()} for smp in as_float]),
+                   'packed bytes': cvig_fov.collate_packed(as_bytes), 'packed float': cvig_fov.collate_packed(as_float)}
+        assert batches['packed bytes']['surface_kind'] == 1 and batches['packed float']['surface_kind'] == 0
+        for name, batch in batches.items():
+            out = prep(batch, starts=starts)
+            assert out['idx'] == [0, 1, 2, 3]
+            assert torch.equal(out['surface'], ref_s), (dataset, fov, name)
+            assert torch.equal(out['polar'], ref_p), (dataset, fov, name)
+    # one batch ahead on a copy stream
+    ds_like = [cvig_fov.collate_packed(as_bytes[:2]), cvig_fov.collate_packed(as_bytes[2:])]
+    prep = cvig_fov.GpuPreprocess('witw', fov=70)
+    got = [prep(st)['surface'] for st in cvig_fov.DevicePrefetcher(ds_like, prep)]
+    assert torch.equal(torch.cat(got), ref_s)
+    # a grey-scale image cannot feed a 3-channel model
+    from witw_amd import _lib
+    with pytest.raises(_lib.WitwError):
+        prep(cvig_fov.collate_packed([{'surface': raw[0][0][:, :, :1], 'overhead': raw[0][1]}]))
+
+
+def test_raw_dataset_and_workers(tmp_path):
+    """ImagePairDataset(raw=True) + collate_packed through real DataLoader workers with pinned memory: the batch arrives as two
+    byte blocks, and the embeddings' inputs equal those of the reference-format (float CHW) dataset bit for bit."""
+    from witw_amd import cvig_fov
+    csv = _write_dataset(str(tmp_path), 5)
+    ds_raw, ds_ref = cvig_fov.ImagePairDataset('cvusa', csv, raw=True), cvig_fov.ImagePairDataset('cvusa', csv)
+    assert ds_raw[0]['surface'].dtype == np.uint8 and ds_raw[0]['surface'].shape == (48, 80, 3)
+    loader = torch.utils.data.DataLoader(ds_raw, batch_size=3, num_workers=2, collate_fn=cvig_fov.collate_packed, pin_memory=True)
+    prep = cvig_fov.GpuPreprocess('cvusa', fov=70, random_orientation=False)
+    outs = [prep(st) for st in cvig_fov.DevicePrefetcher(loader, prep)]
+    assert [o['surface'].shape[0] for o in outs] == [3, 2] and outs[0]['idx'] == [0, 1, 2]
+    ref = prep(cvig_fov.collate_raw([ds_ref[i] for i in range(5)]))
+    assert torch.equal(torch.cat([o['polar'] for o in outs]), ref['polar'])
+    assert torch.equal(torch.cat([o['surface'] for o in outs]), ref['surface'])

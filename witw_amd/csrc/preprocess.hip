@@ -53,6 +53,63 @@ __global__ void resize_bilinear_norm_kernel(const float* __restrict__ x, float* 
     }
 }
 
+// The same resize (+ normalisation) for a BATCH of images of different sizes in one launch: image b is described by
+// desc[b] = {address, H, W, start, pixel layout}; KIND 0 = float32 planar CHW (what ImagePairDataset returns, reference
+// model/cvig_fov.py:88-95), KIND 1 = uint8 interleaved HWC straight from the decoder (a quarter of the bytes over PCIe),
+// converted to float exactly (0..255). The panorama branch of Resize (:118-128: resize to Wfull columns, then keep Wo of them
+// from a per-sample start, wrapping) is the column map ox -> (ox + start) mod Wfull. Same arithmetic, operation for
+// operation, as resize_bilinear_norm_kernel.
+struct ImgDesc {
+    unsigned long long ptr;
+    long long H, W, start, cs;      // cs: channels stored per pixel (KIND 1) -- the first C are used
+};
+
+template <int KIND>
+__global__ void resize_batched_kernel(const ImgDesc* __restrict__ desc, float* __restrict__ y, int B, int C, int Ho, int Wo,
+                                      int Wfull, NormArgs na) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)B * Ho * Wo;
+    if (idx >= total) return;
+    const int ox = idx % Wo;
+    size_t t = idx / Wo;
+    const int oy = t % Ho;
+    const int b = (int)(t / Ho);
+    const ImgDesc d = desc[b];
+    const int Hi = (int)d.H, Wi = (int)d.W;
+    const float sh = (float)Hi / (float)Ho, sw = (float)Wi / (float)Wfull;
+    int cx = ox + (int)d.start;
+    if (cx >= Wfull) cx -= Wfull;
+    float fy = __fmaf_rn(sh, oy + 0.5f, -0.5f);
+    if (fy < 0.f) fy = 0.f;
+    float fx = __fmaf_rn(sw, cx + 0.5f, -0.5f);
+    if (fx < 0.f) fx = 0.f;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + ((y0 < Hi - 1) ? 1 : 0), x1 = x0 + ((x0 < Wi - 1) ? 1 : 0);
+    const float ly1 = fy - y0, lx1 = fx - x0;
+    const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+    for (int c = 0; c < C; ++c) {
+        float p00, p01, p10, p11;
+        if (KIND == 0) {
+            const float* p = reinterpret_cast<const float*>(d.ptr) + (size_t)c * Hi * Wi;
+            p00 = p[(size_t)y0 * Wi + x0]; p01 = p[(size_t)y0 * Wi + x1];
+            p10 = p[(size_t)y1 * Wi + x0]; p11 = p[(size_t)y1 * Wi + x1];
+        } else {
+            const unsigned char* p = reinterpret_cast<const unsigned char*>(d.ptr) + c;
+            const size_t cs = (size_t)d.cs;
+            p00 = (float)p[((size_t)y0 * Wi + x0) * cs]; p01 = (float)p[((size_t)y0 * Wi + x1) * cs];
+            p10 = (float)p[((size_t)y1 * Wi + x0) * cs]; p11 = (float)p[((size_t)y1 * Wi + x1) * cs];
+        }
+        const float top = lx0 * p00 + lx1 * p01;
+        const float bot = lx0 * p10 + lx1 * p11;
+        float v = ly0 * top + ly1 * bot;
+        if (na.enabled) {
+            if (c < na.n_div255) v = v / 255.f;
+            v = (v - na.mean[c]) / na.stdv[c];
+        }
+        y[(((size_t)b * C + c) * Ho + oy) * Wo + ox] = v;
+    }
+}
+
 __global__ void normalize_kernel(const float* __restrict__ x, float* __restrict__ y, int C, size_t hw, size_t total,
                                  NormArgs na) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -132,6 +189,30 @@ int witw_resize_bilinear_normalize(const float* x, float* y, int B, int C, int H
     hipLaunchKernelGGL(resize_bilinear_norm_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
                        y, B, C, Hi, Wi, Ho, Wo, (float)Hi / (float)Ho, (float)Wi / (float)Wo, na);
     WITW_CHECK_LAUNCH("resize_bilinear_normalize");
+    return WITW_OK;
+}
+
+// Resize (+ normalise) B images of individual sizes in ONE launch. desc: DEVICE array [B][5] of 64-bit words {device address of
+// the image, H, W, start column, channels stored per pixel}; kind 0 = float32 planar CHW sources, 1 = uint8 interleaved HWC.
+// Output [B,C,Ho,Wo]: the image resized to Ho x Wfull, of which the Wo columns from `start` on (wrapping) are kept
+// (Wfull == Wo, start == 0: a plain resize). mean / stdv as in witw_resize_bilinear_normalize.
+int witw_resize_bilinear_normalize_batched(const void* desc, float* y, int B, int C, int Ho, int Wo, int Wfull, int kind,
+                                           const float* mean, const float* stdv, int n_div255, void* stream) {
+    WITW_CHECK_ARG(desc && y, "resize_batched: null pointer");
+    WITW_CHECK_ARG(B > 0 && C > 0 && C <= 8 && Ho > 0 && Wo > 0 && Wfull >= Wo, "resize_batched: bad shape B=%d C=%d -> %dx%d of %d",
+                   B, C, Ho, Wo, Wfull);
+    WITW_CHECK_ARG(kind == 0 || kind == 1, "resize_batched: source kind %d unknown (0 float32 CHW, 1 uint8 HWC)", kind);
+    NormArgs na;
+    fill_norm(na, C, mean, stdv, n_div255);
+    const size_t total = (size_t)B * Ho * Wo;
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (kind == 0)
+        hipLaunchKernelGGL(resize_batched_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, (const ImgDesc*)desc, y, B, C, Ho, Wo,
+                           Wfull, na);
+    else
+        hipLaunchKernelGGL(resize_batched_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, (const ImgDesc*)desc, y, B, C, Ho, Wo,
+                           Wfull, na);
+    WITW_CHECK_LAUNCH("resize_bilinear_normalize_batched");
     return WITW_OK;
 }
 

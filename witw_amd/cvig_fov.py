@@ -1019,9 +1019,11 @@ class ImagePairDataset(torch.utils.data.Dataset):
     def _globals(cls):
         return Globals
 
-    def __init__(self, dataset, csv_path, base_path=None, transform=None):
+    def __init__(self, dataset, csv_path, base_path=None, transform=None, raw=False):
         import os
         import pandas as pd
+        self.raw = raw      # not in the reference: hand over the decoder's uint8 HWC arrays (collate_packed / GpuPreprocess convert
+        #                     them on the GPU, exactly); False = the reference's float32 CHW tensors
         self.csv_path = csv_path
         self.base_path = base_path if base_path is not None else os.path.dirname(csv_path)
         self.transform = transform
@@ -1043,9 +1045,19 @@ class ImagePairDataset(torch.utils.data.Dataset):
             a = a[:, :, None]
         return torch.from_numpy(a.astype(np.float32).transpose((2, 0, 1)).copy())
 
+    @staticmethod
+    def _read_raw(path):
+        import numpy as np
+        from PIL import Image
+        a = np.asarray(Image.open(path))
+        if a.ndim == 2:
+            a = a[:, :, None]
+        return a if a.dtype == np.uint8 else ImagePairDataset._read(path)
+
     def __getitem__(self, idx):
-        data = {'surface': self._read(self.file_paths.iloc[idx]['surface']),
-                'overhead': self._read(self.file_paths.iloc[idx]['overhead'])}
+        read = self._read_raw if self.raw else self._read
+        data = {'surface': read(self.file_paths.iloc[idx]['surface']),
+                'overhead': read(self.file_paths.iloc[idx]['overhead'])}
         if self._with_idx:
             data = dict(idx=idx, **data)
         if self.transform is not None:
@@ -1061,9 +1073,69 @@ def collate_raw(samples):
     return out
 
 
+def _pack_side(images):
+    """A batch of differently sized images -> ONE contiguous byte buffer + [B,4] int64 {byte offset, H, W, channels stored per
+    pixel}. All uint8 HWC (decoder output) -> kind 1, bytes as they are; anything else -> float32 planar CHW, kind 0."""
+    import numpy as np
+    raw = all(isinstance(a, np.ndarray) and a.dtype == np.uint8 and a.ndim == 3 for a in images)
+    parts, desc, off = [], [], 0
+    for a in images:
+        if raw:
+            h, w, cs = a.shape
+            flat = np.ascontiguousarray(a).reshape(-1)
+        else:
+            t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.asarray(a, dtype=np.float32).transpose((2, 0, 1)))
+            t = t.to(torch.float32).contiguous()
+            cs, h, w = t.shape
+            flat = t.reshape(-1).numpy().view(np.uint8)
+        desc.append((off, h, w, cs))
+        parts.append(flat)
+        off += (flat.size + 15) // 16 * 16                 # images start 16-byte aligned
+    buf = np.zeros((off,), dtype=np.uint8)
+    for (o, _h, _w, _c), f in zip(desc, parts):
+        buf[o:o + f.size] = f
+    return torch.from_numpy(buf), torch.tensor(desc, dtype=torch.int64), 1 if raw else 0
+
+
+def collate_packed(samples):
+    """collate_fn of the fast path (runs in the DataLoader worker): each side of the batch becomes one byte buffer + a
+    descriptor table, so that the batch crosses the process boundary, the pinning thread and PCIe as two large blocks
+    instead of 2 x B tensors."""
+    sb, sd, sk = _pack_side([s['surface'] for s in samples])
+    ob, od, ok = _pack_side([s['overhead'] for s in samples])
+    out = {'surface_bytes': sb, 'surface_desc': sd, 'surface_kind': sk, 'overhead_bytes': ob, 'overhead_desc': od,
+           'overhead_kind': ok, 'packed': True}
+    if samples and 'idx' in samples[0]:
+        out['idx'] = [s['idx'] for s in samples]
+    return out
+
+
+class StagedBatch(object):
+    """A batch whose images sit in device memory with their descriptor tables built (GpuPreprocess.stage)."""
+
+    def __init__(self):
+        self.keep = []          # tensors the descriptors point into
+        self.event = None       # recorded on the copy stream once everything has been queued there
+        self.n = 0
+        self.idx = None
+
+    def wait(self):
+        """Make the current stream wait for the staging copies and keep the allocator from recycling them early."""
+        if self.event is not None:
+            cur = torch.cuda.current_stream()
+            cur.wait_event(self.event)
+            for t in self.keep:
+                if t.is_cuda:
+                    t.record_stream(cur)
+        return self
+
+
 class GpuPreprocess(object):
-    """Compose[Resize, ImageNormalization, PolarTransform] (model/cvig_fov.py:393-397) over a batch of raw
-    images, on the GPU: -> {'surface' [B,3,128,Ws], 'overhead' [B,3,256,256], 'polar' [B,3,128,512]}."""
+    """Compose[Resize, ImageNormalization, PolarTransform] (model/cvig_fov.py:393-397) over a batch of raw images, on the
+    GPU: -> {'surface' [B,3,128,Ws], 'overhead' [B,3,256,256], 'polar' [B,3,128,512]} in THREE launches whatever the batch
+    size (one batched resize+normalise per side over a descriptor table of individually sized images, one polar transform).
+    stage() moves a batch to the device (one copy per side from pinned memory when the batch is packed) and may run on a
+    side stream ahead of time (DevicePrefetcher); __call__ accepts a raw batch or a staged one."""
 
     channels = 3
     normalization = None      # class used for the normalisation step (cvig_semantic overrides both)
@@ -1074,18 +1146,100 @@ class GpuPreprocess(object):
         self.polar = PolarTransform()
         self.device = device      # where host images go (train() / test() pass their module's `device`); None = cvig_fov.device
 
-    def __call__(self, batch):
-        s, o = [], []
-        c = self.channels
-        dev = self.device
-        for su, ov in zip(batch['surface'], batch['overhead']):
-            if dev is not None and not su.is_cuda:
-                su, ov = su.to(dev), ov.to(dev)
-            d = self.resize({'surface': su[:c], 'overhead': ov[:c]})
-            s.append(d['surface'])
-            o.append(d['overhead'])
-        data = {'idx': batch.get('idx'), 'surface': torch.stack(s), 'overhead': torch.stack(o)}
-        return self.polar(self.norm(data))
+    def _dev(self):
+        dev = self.device if self.device is not None else device
+        if dev.type != 'cuda':
+            raise _lib.WitwError('no gfx950 device: the WITW transforms run on the GPU only')
+        return dev
+
+    def _stage_side(self, st, dev, images=None, packed=None):
+        if packed is not None:
+            buf, desc, kind = packed
+        elif all(isinstance(t, torch.Tensor) and t.is_cuda for t in images):        # already resident: point at them
+            rows = []
+            for t in images:
+                t = t.to(torch.float32).contiguous()
+                st.keep.append(t)
+                rows.append((t.data_ptr(), t.shape[1], t.shape[2], 0, t.shape[0]))
+            return torch.tensor(rows, dtype=torch.int64).to(dev, non_blocking=True), 0
+        else:
+            buf, desc, kind = _pack_side([t.cpu() if isinstance(t, torch.Tensor) else t for t in images])
+        if not buf.is_pinned():
+            buf = buf.pin_memory()
+        dbuf = buf.to(dev, non_blocking=True)
+        st.keep += [dbuf, buf]
+        if int(desc[:, 3].min()) < self.channels:
+            raise _lib.WitwError('an image of the batch has %d channels, the model takes %d' % (int(desc[:, 3].min()), self.channels))
+        table = torch.empty((desc.shape[0], 5), dtype=torch.int64)
+        table[:, 0] = desc[:, 0] + dbuf.data_ptr()
+        table[:, 1:3] = desc[:, 1:3]
+        table[:, 3] = 0
+        table[:, 4] = desc[:, 3]
+        return table, kind
+
+    def stage(self, batch, starts=None):
+        dev = self._dev()
+        st = StagedBatch()
+        st.idx = batch.get('idx')
+        if batch.get('packed'):
+            s_tab, st.s_kind = self._stage_side(st, dev, packed=(batch['surface_bytes'], batch['surface_desc'], batch['surface_kind']))
+            o_tab, st.o_kind = self._stage_side(st, dev, packed=(batch['overhead_bytes'], batch['overhead_desc'], batch['overhead_kind']))
+        else:
+            s_tab, st.s_kind = self._stage_side(st, dev, images=batch['surface'])
+            o_tab, st.o_kind = self._stage_side(st, dev, images=batch['overhead'])
+        st.n = s_tab.shape[0]
+        if self.resize.panorama:      # random FoV crop offset per sample (reference: torch.randint per call, :121)
+            if starts is None:
+                starts = torch.randint(0, Globals.surface_width_max, (st.n,)) if self.resize.random_orientation else torch.zeros(st.n, dtype=torch.int64)
+            s_tab = s_tab.cpu() if s_tab.is_cuda else s_tab
+            s_tab[:, 3] = torch.as_tensor(starts, dtype=torch.int64)
+        st.s_desc = s_tab if s_tab.is_cuda else s_tab.pin_memory().to(dev, non_blocking=True)
+        st.o_desc = o_tab if o_tab.is_cuda else o_tab.pin_memory().to(dev, non_blocking=True)
+        st.keep += [st.s_desc, st.o_desc]
+        st.event = torch.cuda.Event()
+        st.event.record(torch.cuda.current_stream())
+        return st
+
+    def __call__(self, batch, starts=None):
+        st = batch if isinstance(batch, StagedBatch) else self.stage(batch, starts)
+        st.wait()
+        c, r = self.channels, self.resize
+        hs, wmax, so = Globals.surface_height_max, Globals.surface_width_max, Globals.overhead_size
+        nd = self.norm.n_div255
+        surface = ops.resize_batched(st.s_desc, st.n, c, (hs, r.surface_width), wfull=wmax if r.panorama else None, kind=st.s_kind,
+                                     mean=self.norm.mean, std=self.norm.std, n_div255=nd)
+        overhead = ops.resize_batched(st.o_desc, st.n, c, (so, so), kind=st.o_kind, mean=self.norm.mean, std=self.norm.std, n_div255=nd)
+        return self.polar({'idx': st.idx, 'surface': surface, 'overhead': overhead})
+
+
+class DevicePrefetcher(object):
+    """Iterates a DataLoader one batch ahead: batch n+1 is staged (H2D copies from the loader's pinned buffers, descriptor
+    tables) on a copy stream while the caller's kernels for batch n run on the compute stream. Yields StagedBatch."""
+
+    def __init__(self, loader, prep):
+        self.loader, self.prep = loader, prep
+        self.stream = torch.cuda.Stream()
+
+    def __len__(self):
+        return len(self.loader)
+
+    def _stage(self, raw):
+        with torch.cuda.stream(self.stream):
+            return self.prep.stage(raw)
+
+    def __iter__(self):
+        it = iter(self.loader)
+        try:
+            nxt = self._stage(next(it))
+        except StopIteration:
+            return
+        while nxt is not None:
+            cur = nxt
+            try:
+                nxt = self._stage(next(it))
+            except StopIteration:
+                nxt = None
+            yield cur
 
 
 def projector_dump(writer, surface, overhead, surface_embed, overhead_embed, global_step, tag, img_mean, img_std):
@@ -1212,7 +1366,7 @@ def train(dataset='cvusa', fov=360, val_quantity=1000, batch_size=64, num_worker
         else _NullWriter()
     csv_path = csv_path or Globals.dataset_paths[dataset]['train']
     prep = GpuPreprocess(dataset, fov, device=device)
-    trainval_set = ImagePairDataset(dataset=dataset, csv_path=csv_path)
+    trainval_set = ImagePairDataset(dataset=dataset, csv_path=csv_path, raw=True)      # decoder bytes; converted on the GPU
     split_gen = torch.Generator().manual_seed(seed) if world > 1 else None      # every rank must draw the same split
     train_set, val_set = torch.utils.data.random_split(trainval_set, [len(trainval_set) - val_quantity, val_quantity],
                                                        generator=split_gen)
@@ -1220,10 +1374,14 @@ def train(dataset='cvusa', fov=360, val_quantity=1000, batch_size=64, num_worker
     # every rank reads its own shard of each epoch and the loss still couples the whole global batch
     train_sampler = torch.utils.data.distributed.DistributedSampler(train_set, shuffle=True, drop_last=True) if world > 1 else None
     val_sampler = torch.utils.data.distributed.DistributedSampler(val_set, shuffle=False) if world > 1 else None
+    # workers decode and pack each batch into two byte blocks (collate_packed), the loader's pinning thread moves them to
+    # page-locked memory, DevicePrefetcher copies batch n+1 to the GPU on a side stream while batch n computes
     train_loader = torch.utils.data.DataLoader(train_set, batch_size=batch_size, shuffle=(world == 1), drop_last=True,
-                                               sampler=train_sampler, num_workers=num_workers, collate_fn=collate_raw)
+                                               sampler=train_sampler, num_workers=num_workers, collate_fn=collate_packed,
+                                               pin_memory=True)
     val_loader = torch.utils.data.DataLoader(val_set, batch_size=batch_size, shuffle=False, drop_last=False,
-                                             sampler=val_sampler, num_workers=num_workers, collate_fn=collate_raw)
+                                             sampler=val_sampler, num_workers=num_workers, collate_fn=collate_packed,
+                                             pin_memory=True)
     surface_encoder = FOV_DSM(circ_padding=False, seed=seed)
     overhead_encoder = FOV_DSM(circ_padding=True, seed=seed)
     if getattr(Globals, 'vgg16_weights', None):      # the reference's starting point (:256-272); else seeded synthetic weights
@@ -1251,7 +1409,7 @@ def train(dataset='cvusa', fov=360, val_quantity=1000, batch_size=64, num_worker
             loader = train_loader if phase == 'train' else val_loader
             surface_encoder.train(phase == 'train')
             overhead_encoder.train(phase == 'train')
-            for batch, raw in enumerate(loader):
+            for batch, raw in enumerate(DevicePrefetcher(loader, prep)):
                 data = prep(raw)
                 surface = data['surface']
                 overhead = data['polar']
@@ -1306,12 +1464,12 @@ def test(dataset='cvusa', fov=360, batch_size=64, num_workers=8, csv_path=None, 
     # the reference crops test panoramas at a random orientation too (:495-499); Globals.test_random_orientation = False
     # makes the evaluation repeatable
     prep = GpuPreprocess(dataset, fov, getattr(Globals, 'test_random_orientation', True), device=device)
-    test_set = ImagePairDataset(dataset=dataset, csv_path=csv_path)
+    test_set = ImagePairDataset(dataset=dataset, csv_path=csv_path, raw=True)
     # under torch.distributed every rank embeds a contiguous shard of the test set and keeps its gallery rows
     shard_begin, shard_end = parallel.shard_range(len(test_set))
     shard = torch.utils.data.Subset(test_set, range(shard_begin, shard_end)) if world > 1 else test_set
     test_loader = torch.utils.data.DataLoader(shard, batch_size=batch_size, shuffle=False, drop_last=False,
-                                              num_workers=num_workers, collate_fn=collate_raw)
+                                              num_workers=num_workers, collate_fn=collate_packed, pin_memory=True)
     surface_encoder = FOV_DSM(circ_padding=False).to(device)
     overhead_encoder = FOV_DSM(circ_padding=True).to(device)
     surface_encoder.precision = overhead_encoder.precision = Globals.precision
@@ -1321,7 +1479,7 @@ def test(dataset='cvusa', fov=360, batch_size=64, num_workers=8, csv_path=None, 
     overhead_encoder.eval()
     su_parts, ov_parts = [], []
     data = None
-    for raw in test_loader:
+    for raw in DevicePrefetcher(test_loader, prep):
         data = prep(raw)
         with torch.no_grad():
             su_parts.append(surface_encoder(data['surface']))

@@ -48,8 +48,8 @@ class ImagePairDataset(_fov.ImagePairDataset):
     def _globals(cls):
         return Globals
 
-    def __init__(self, dataset, csv_path, base_path=None, transform=None):
-        super().__init__(dataset, csv_path, base_path, transform)
+    def __init__(self, dataset, csv_path, base_path=None, transform=None, raw=False):
+        super().__init__(dataset, csv_path, base_path, transform, raw)
         self.semantic = Globals.dataset_paths[dataset]['semantic']
 
     @staticmethod
@@ -68,7 +68,8 @@ class ImagePairDataset(_fov.ImagePairDataset):
             data = {'idx': idx, 'surface': self._read_tiff(os.path.splitext(row['surface'])[0] + '.tif'),
                     'overhead': self._read_tiff(os.path.splitext(row['overhead'])[0] + '.tif')}
         else:
-            data = {'idx': idx, 'surface': self._read(row['surface']), 'overhead': self._read(row['overhead'])}
+            read = self._read_raw if self.raw else self._read
+            data = {'idx': idx, 'surface': read(row['surface']), 'overhead': read(row['overhead'])}
             cresi_path = os.path.join(self.base_path, 'cresi_uint8',
                                       os.path.splitext(os.path.basename(row['overhead']))[0] + '.tif')
             data['cresi'] = self._read_tiff(cresi_path)[[0, 1, 2, -1], :, :] if os.path.exists(cresi_path) else None

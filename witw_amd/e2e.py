@@ -1,0 +1,146 @@
+"""End-to-end data path of the cvig_fov drivers, measured: image files on disk -> ImagePairDataset in DataLoader worker
+processes (decode) -> collate_packed (one byte block per side) -> pinned memory -> PCIe on a copy stream (DevicePrefetcher)
+-> batched resize + normalise + polar on the GPU (GpuPreprocess, 3 launches) -> the two FOV_DSM encoders -> embeddings.
+
+The reference runs the transforms inside 12 DataLoader workers at about one second per sample (PolarTransform in numpy,
+model/cvig_fov.py:186-209, 393-403); here the workers only decode. `bench()` reports the disk -> embedding rate next to the
+rate of every stage on its own, and names the slowest."""
+import os
+import time
+
+import numpy as np
+import torch
+
+
+def _write_pair(args):
+    root, i, seed = args
+    from PIL import Image
+    g = np.random.Generator(np.random.Philox(key=[seed, i]))
+
+    def picture(h, w):
+        # band-limited noise: decodes like a photograph (pure noise would be the JPEG decoder's worst case, flat colour its best)
+        small = g.integers(0, 256, size=(h // 8 + 2, w // 8 + 2, 3), dtype=np.uint8)
+        img = np.asarray(Image.fromarray(small).resize((w + 16, h + 16), Image.BICUBIC))[8:8 + h, 8:8 + w]
+        fine = g.integers(-12, 13, size=(h, w, 3))
+        return np.clip(img.astype(np.int16) + fine, 0, 255).astype(np.uint8)
+    Image.fromarray(picture(512, 512)).save(os.path.join(root, 'ov_%05d.jpg' % i), quality=90)
+    Image.fromarray(picture(224, 224)).save(os.path.join(root, 'su_%05d.jpg' % i), quality=90)
+    return i
+
+
+def make_dataset(root, n_pairs, n_unique=512, seed=77, procs=8):
+    """A synthetic cvusa-format data set (CSV columns: overhead, surface; model/cvig_fov.py:38-44): n_pairs rows over
+    min(n_pairs, n_unique) distinct JPEG pairs (overhead 512x512, ground 224x224: the raw sizes of BASELINE.json)."""
+    import multiprocessing as mp
+    os.makedirs(root, exist_ok=True)
+    n_unique = min(n_pairs, n_unique)
+    with mp.get_context('spawn').Pool(procs) as pool:
+        pool.map(_write_pair, [(root, i, seed) for i in range(n_unique)], chunksize=16)
+    csv = os.path.join(root, 'pairs.csv')
+    with open(csv, 'w') as f:
+        for i in range(n_pairs):
+            f.write('ov_%05d.jpg,su_%05d.jpg\n' % (i % n_unique, i % n_unique))
+    size = sum(os.path.getsize(os.path.join(root, n)) for n in os.listdir(root) if n.endswith('.jpg'))
+    return csv, n_unique, size
+
+
+def bench(a, device, n_pairs=None, workers=None, keep_dir=None):
+    import tempfile
+    from . import cvig_fov, synth
+    n_pairs = n_pairs or a.e2e_pairs
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    workers = workers if workers is not None else max(1, min(a.workers, cores))
+    B, fov = a.batch, a.fov
+    tmp = tempfile.TemporaryDirectory(prefix='witw_e2e_')
+    root = keep_dir or tmp.name
+    t0 = time.perf_counter()
+    csv, n_unique, nbytes = make_dataset(root, n_pairs, procs=min(16, cores))
+    t_make = time.perf_counter() - t0
+
+    ds = cvig_fov.ImagePairDataset('cvusa', csv, raw=True)
+    loader = torch.utils.data.DataLoader(ds, batch_size=B, shuffle=False, drop_last=False, num_workers=workers,
+                                         collate_fn=cvig_fov.collate_packed, pin_memory=True,
+                                         prefetch_factor=4 if workers else None, persistent_workers=bool(workers))
+    prep = cvig_fov.GpuPreprocess('cvusa', fov, random_orientation=False, device=device)
+    wts = synth.fov_dsm_weights(1234)
+    se = cvig_fov.FOV_DSM(False, weights=wts).to(device).eval()
+    oe = cvig_fov.FOV_DSM(True, weights=wts).to(device).eval()
+
+    def embed(st):
+        with torch.no_grad():
+            data = prep(st)
+            return se(data['surface']), oe(data['polar'])
+
+    # ---- stage rates on their own
+    # (1) the loader alone: decode + pack in the workers, pinning thread; one untimed pass starts the workers / fills the page cache
+    first = None
+    for raw in loader:
+        first = first or raw
+    t0 = time.perf_counter()
+    n = 0
+    for raw in loader:
+        n += raw['surface_desc'].shape[0]
+    t_load = time.perf_counter() - t0
+    # (2) host -> device copy of one packed batch from pinned memory
+    blk = first['surface_bytes'].numel() + first['overhead_bytes'].numel()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        first['surface_bytes'].to(device, non_blocking=True)
+        first['overhead_bytes'].to(device, non_blocking=True)
+    torch.cuda.synchronize()
+    t_h2d = (time.perf_counter() - t0) / 5
+    # (3) the GPU side on a resident batch: 3 preprocessing launches + 2 encoders
+    st = prep.stage(first)
+    for _ in range(2):
+        embed(st)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        embed(st)
+    torch.cuda.synchronize()
+    t_gpu = (time.perf_counter() - t0) / 5
+    nb = st.n
+
+    # ---- end to end: every pair from disk to its two embeddings, prefetch one batch ahead
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    su_all, ov_all = [], []
+    t_first, n_first = None, 0
+    for st in cvig_fov.DevicePrefetcher(loader, prep):
+        su, ov = embed(st)
+        su_all.append(su)
+        ov_all.append(ov)
+        if t_first is None:          # the pipeline is full once the first batch is through: steady state counts from here
+            torch.cuda.synchronize()
+            t_first, n_first = time.perf_counter(), st.n
+    torch.cuda.synchronize()
+    t_end = time.perf_counter()
+    t_e2e = t_end - t0
+    su_all, ov_all = torch.cat(su_all), torch.cat(ov_all)
+    assert su_all.shape[0] == n_pairs and ov_all.shape[0] == n_pairs
+    del loader
+
+    rates = {'decode_and_pack (%d DataLoader workers)' % workers: n / t_load,
+             'host_to_device copy (pinned, %.1f MB per batch)' % (blk / 1e6): nb / t_h2d,
+             'gpu (batched resize+normalise+polar, 2 encoders; resident batch)': nb / t_gpu}
+    limiting = min(rates, key=rates.get)
+    out = {'metric': 'image-pairs/sec (disk -> embeddings)', 'value': round(n_pairs / t_e2e, 2), 'unit': 'pairs/s', 'n_gpus': 1,
+           'steps': (n_pairs + B - 1) // B, 'warmup': 0, 'ms_per_step': round(t_e2e / ((n_pairs + B - 1) // B) * 1e3, 3),
+           'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+           'config': {'workload': 'cvig_fov fov=%d, %d JPEG pairs on disk (%d distinct files pairs, overhead 512x512 + ground 224x224, %.1f MB) -> '
+                                  'ImagePairDataset(raw) in %d DataLoader workers -> collate_packed -> pinned -> copy stream -> GpuPreprocess '
+                                  '(3 launches per batch) -> 2x FOV_DSM -> embeddings' % (fov, n_pairs, n_unique, nbytes / 1e6, workers),
+                      'pairs_per_gpu': B, 'host_cores_available': cores, 'dataset_dir': 'tmpfs/disk under %s' % tempfile.gettempdir(),
+                      'reference_data_path': 'model/cvig_fov.py:393-403: transforms inside 12 DataLoader workers, ~1 s per sample '
+                                             '(SURVEY §6: PolarTransform 0.9-1.2 s)'},
+           'stage_pairs_per_s': {k: round(v, 1) for k, v in rates.items()},
+           'limiting_stage': limiting,
+           'steady_state_pairs_per_s': round((n_pairs - n_first) / max(1e-9, t_end - t_first), 1),
+           'pipeline_fill_s': round(t_first - t0, 3),
+           'note': 'value = the whole pass including the pipeline fill (a DataLoader worker decodes one whole batch: the first one '
+                   'arrives after ~batch x decode time); steady_state = from the first finished batch to the end',
+           'overlap_efficiency_steady_state': round(((n_pairs - n_first) / max(1e-9, t_end - t_first)) / min(rates.values()), 3),
+           'dataset_written_in_s': round(t_make, 1)}
+    tmp.cleanup()
+    return out

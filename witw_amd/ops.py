@@ -565,6 +565,27 @@ def resize_bilinear(x, size, mean=None, std=None, n_div255=None):
     return y
 
 
+def resize_batched(desc, batch, channels, size, wfull=None, kind=0, mean=None, std=None, n_div255=None):
+    """One launch for a batch of differently sized images. desc: int64 GPU tensor [B,5] = {device address, H, W, start column,
+    channels per stored pixel} per image; kind 0 = float32 CHW sources, 1 = uint8 HWC. -> [B,channels,Ho,Wo] (see
+    witw_resize_bilinear_normalize_batched for wfull / start)."""
+    import ctypes
+    lib = _lib.load()
+    if not (desc.is_cuda and desc.dtype == torch.int64 and desc.is_contiguous() and tuple(desc.shape) == (batch, 5)):
+        raise _lib.WitwError('resize_batched: desc must be a contiguous int64 GPU tensor [%d,5]' % batch)
+    Ho, Wo = size
+    y = torch.empty((batch, channels, Ho, Wo), dtype=torch.float32, device=desc.device)
+    m = s = None
+    if mean is not None:
+        m, s = _host_floats(mean), _host_floats(std)
+    nd = channels if n_div255 is None else n_div255
+    _lib.check(lib.witw_resize_bilinear_normalize_batched(desc.data_ptr(), y.data_ptr(), batch, channels, Ho, Wo, Wo if wfull is None else wfull,
+                                                          int(kind), ctypes.cast(m, ctypes.c_void_p) if m is not None else None,
+                                                          ctypes.cast(s, ctypes.c_void_p) if s is not None else None, nd, _stream()),
+               'witw_resize_bilinear_normalize_batched')
+    return y
+
+
 def normalize(x, mean, std, n_div255=None):
     import ctypes
     lib = _lib.load()
