@@ -55,7 +55,8 @@ int witw_conv3x3_fwd(const float* x, const float* wpk, const float* bias, const 
 /* First layer fast path: Conv2d(C<=4 -> 64, 3x3, pad 1)+ReLU straight from the NCHW fp32 image (features[0..1],
  * model/cvig_fov.py:256-260): wf = witw_conv3x3_first_pack(w [64][C][3][3]) (a 2560-float buffer; round_bf16 = 1
  * writes the bf16 MFMA kernel's filter image instead and goes with out_bf16 = 1), y = NHWC [B,H,W,64] fp32, or bf16
- * with bf16-rounded operands on v_mfma_f32_32x32x16_bf16 when out_bf16 = 1; out_bf16 = 2: fp32 arithmetic, split-fp16 output
+ * with bf16-rounded operands on v_mfma_f32_32x32x16_bf16 when out_bf16 = 1 (this form takes C <= 8: cvig_semantic's 5-channel
+ * first conv, model/cvig_semantic.py:301-303, at inference); out_bf16 = 2: fp32 arithmetic, split-fp16 output
  * [B,H,W,8,2,8] (hi / lo planes per 8 channels) for the fp16x3 path. */
 int witw_conv3x3_first_pack(const float* w, float* wf, int C, int round_bf16, void* stream);
 int witw_conv3x3_first_fwd(const float* x, const float* wf, const float* bias, void* y, int B, int C, int H, int W,

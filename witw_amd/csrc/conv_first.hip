@@ -8,6 +8,7 @@
 // three NCHW planes directly. The layer is bound by its output stream (64 channels per pixel), which leaves
 // through the same LDS-transposed 16-byte stores as the generic kernel, in fp32 or bf16.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -172,10 +173,17 @@ __global__ __launch_bounds__(FT, 2) void conv3x3_first_kernel(FirstArgs p) {
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
 
+// CW = bf16 values stored per pixel: 4 (C <= 4, 8 bytes: an MFMA operand = two taps, 3 MFMAs per tile) or 8 (cvig_semantic's
+// five channels, C <= 8, 16 bytes: an operand = one tap, lane half h of MFMA i holds tap 2i+h, 5 MFMAs per tile).
+template <int CW>
 __global__ __launch_bounds__(FT, 2) void conv3x3_first_bf16_kernel(FirstArgs p) {
-    __shared__ f32x4 smem[4096];                 // 64 KB: input tile (660 x 8 B), weights (384 x 16 B); slabs alias all of it
-    u32x2* in_s = reinterpret_cast<u32x2*>(smem);
-    u32x4v* w_s = reinterpret_cast<u32x4v*>(smem + 352);
+    static_assert(CW == 4 || CW == 8, "4 or 8 bf16 per pixel");
+    constexpr int NMF = (CW == 4) ? 3 : 5;                 // MFMAs per (M-tile, N-tile)
+    constexpr int IN_F4 = (CW == 4) ? 352 : 672;          // f32x4 slots reserved for the input tile (660 pixels)
+    typedef typename std::conditional<CW == 4, u32x2, u32x4v>::type pix_t;
+    __shared__ f32x4 smem[4096];                 // 64 KB: input tile, weights (NMF x 128 x 16 B); slabs alias all of it
+    pix_t* in_s = reinterpret_cast<pix_t*>(smem);
+    u32x4v* w_s = reinterpret_cast<u32x4v*>(smem + IN_F4);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hq = lane >> 5;
     int bid = blockIdx.x;
@@ -197,16 +205,18 @@ __global__ __launch_bounds__(FT, 2) void conv3x3_first_bf16_kernel(FirstArgs p) 
         } else {
             ok = ok && gc >= 0 && gc < p.W;
         }
-        __bf16 v[4] = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+        __bf16 v[CW];
+#pragma unroll
+        for (int ch = 0; ch < CW; ++ch) v[ch] = (__bf16)0.f;
         if (ok) {
             const float* src = p.x + (size_t)b * p.C * plane + (size_t)gr * p.W + gc;
 #pragma unroll
-            for (int ch = 0; ch < 4; ++ch)
+            for (int ch = 0; ch < CW; ++ch)
                 if (ch < p.C) v[ch] = (__bf16)src[ch * plane];
         }
-        in_s[s] = __builtin_bit_cast(u32x2, v);
+        in_s[s] = __builtin_bit_cast(pix_t, v);
     }
-    for (int s = tid; s < 384; s += FT) w_s[s] = reinterpret_cast<const u32x4v*>(p.wf)[s];
+    for (int s = tid; s < NMF * 128; s += FT) w_s[s] = reinterpret_cast<const u32x4v*>(p.wf)[s];
     __syncthreads();
 
     const int row0 = 2 * (wave >> 1), col0 = 32 * (wave & 1);
@@ -218,21 +228,28 @@ __global__ __launch_bounds__(FT, 2) void conv3x3_first_bf16_kernel(FirstArgs p) 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        // this lane's two taps of MFMA i; a tap past 8 reads tap 0's pixel and is zeroed
-        const int tA = 4 * i + 2 * hq, tB = tA + 1;
-        const int offA = (tA < 9) ? (tA / 3) * FIW + tA % 3 : 0;
-        const int offB = (tB < 9) ? (tB / 3) * FIW + tB % 3 : 0;
+    for (int i = 0; i < NMF; ++i) {
         u32x4v bw[2];
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) bw[nt] = w_s[(i * 2 + hq) * 64 + nt * 32 + l31];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             const int base = (row0 + mt) * FIW + col0 + l31;
-            u32x2 pa = in_s[base + offA], pb = in_s[base + offB];
-            if (tA >= 9) pa = (u32x2){0u, 0u};
-            if (tB >= 9) pb = (u32x2){0u, 0u};
-            const u32x4v av = {pa[0], pa[1], pb[0], pb[1]};
+            u32x4v av;
+            if constexpr (CW == 4) {
+                // this lane's two taps of MFMA i; a tap past 8 reads tap 0's pixel and is zeroed
+                const int tA = 4 * i + 2 * hq, tB = tA + 1;
+                const int offA = (tA < 9) ? (tA / 3) * FIW + tA % 3 : 0;
+                const int offB = (tB < 9) ? (tB / 3) * FIW + tB % 3 : 0;
+                u32x2 pa = in_s[base + offA], pb = in_s[base + offB];
+                if (tA >= 9) pa = (u32x2){0u, 0u};
+                if (tB >= 9) pb = (u32x2){0u, 0u};
+                av = (u32x4v){pa[0], pa[1], pb[0], pb[1]};
+            } else {
+                const int t = 2 * i + hq;                  // tap 9 does not exist: zeros (its filter slot is zero as well)
+                av = in_s[base + ((t < 9) ? (t / 3) * FIW + t % 3 : 0)];
+                if (t >= 9) av = (u32x4v){0u, 0u, 0u, 0u};
+            }
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bw[nt]),
@@ -277,14 +294,17 @@ __global__ __launch_bounds__(FT, 2) void conv3x3_first_bf16_kernel(FirstArgs p) 
 
 // bf16 filter image of conv3x3_first_bf16_kernel: slot [i][h][n] (16 B) = (w[n][0..3][tap 4i+2h], w[n][0..3][tap 4i+2h+1])
 // as bf16, zeros for taps >= 9 and channels >= C; 384 slots = 1536 floats of the 2560-float buffer.
+// C > 4 (the 8-values-per-pixel form): slot [i][h][n] = w[n][0..7][tap 2i+h], 640 slots = the whole 2560-float buffer.
 __global__ void pack_first_bf16_kernel(const float* __restrict__ w, unsigned short* __restrict__ wf, int C) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= 384) return;
+    const int slots = (C <= 4) ? 384 : 640;
+    if (idx >= slots) return;
     const int n = idx % 64, h = (idx / 64) % 2, i = idx / 128;
     __bf16 v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        const int tap = 4 * i + 2 * h + (e >> 2), ch = e & 3;
+        const int tap = (C <= 4) ? 4 * i + 2 * h + (e >> 2) : 2 * i + h;
+        const int ch = (C <= 4) ? (e & 3) : e;
         v[e] = (__bf16)((tap < 9 && ch < C) ? w[((size_t)n * C + ch) * 9 + tap] : 0.f);
     }
     reinterpret_cast<bf16x8*>(wf)[idx] = __builtin_bit_cast(bf16x8, v);
@@ -311,26 +331,26 @@ __global__ void pack_first_kernel(const float* __restrict__ w, float* __restrict
 
 extern "C" {
 
-// w: torch layout [64][C][3][3], C <= 4 -> wf: 2560 floats
+// w: torch layout [64][C][3][3], C <= 4 (bf16 image: C <= 8) -> wf: 2560 floats
 int witw_conv3x3_first_pack(const float* w, float* wf, int C, int round_bf16, void* stream) {
     WITW_CHECK_ARG(w && wf, "conv3x3_first_pack: null pointer");
-    WITW_CHECK_ARG(C >= 1 && C <= 4, "conv3x3_first_pack: C=%d outside [1,4]", C);
+    WITW_CHECK_ARG(C >= 1 && C <= (round_bf16 ? 8 : 4), "conv3x3_first_pack: C=%d outside [1,%d]", C, round_bf16 ? 8 : 4);
     if (round_bf16)     // the bf16 kernel's own filter image (see pack_first_bf16_kernel)
-        hipLaunchKernelGGL(pack_first_bf16_kernel, dim3(2), dim3(256), 0, (hipStream_t)stream, w, (unsigned short*)wf, C);
+        hipLaunchKernelGGL(pack_first_bf16_kernel, dim3(3), dim3(256), 0, (hipStream_t)stream, w, (unsigned short*)wf, C);
     else
         hipLaunchKernelGGL(pack_first_kernel, dim3(3), dim3(256), 0, (hipStream_t)stream, w, wf, C, round_bf16);
     WITW_CHECK_LAUNCH("conv3x3_first_pack");
     return WITW_OK;
 }
 
-// x NCHW fp32 [B,C,H,W] (C <= 4) -> y NHWC [B,H,W,64] (fp32, or bf16 if out_bf16; with out_bf16 the INPUT is
+// x NCHW fp32 [B,C,H,W] (C <= 4; C <= 8 with out_bf16 = 1) -> y NHWC [B,H,W,64] (fp32, or bf16 if out_bf16; with out_bf16 the INPUT is
 // rounded to bf16 on load so that the arithmetic equals the bf16 path's: bf16 operands, fp32 accumulate, and wf
 // must come from witw_conv3x3_first_pack(round_bf16 = 1), which writes the bf16 kernel's filter image). out_bf16 = 2: exact
 // fp32 arithmetic (wf packed with round_bf16 = 0) and a split-fp16 output [B,H,W,8,2,8] for the fp16x3 path.
 int witw_conv3x3_first_fwd(const float* x, const float* wf, const float* bias, void* y, int B, int C, int H, int W,
                            int pad_circular, int relu, int out_bf16, void* stream) {
     WITW_CHECK_ARG(x && wf && bias && y, "conv3x3_first_fwd: null pointer");
-    WITW_CHECK_ARG(B > 0 && C >= 1 && C <= 4 && H > 0 && W > 0, "conv3x3_first_fwd: bad shape B=%d C=%d H=%d W=%d", B, C, H, W);
+    WITW_CHECK_ARG(B > 0 && C >= 1 && C <= (out_bf16 == 1 ? 8 : 4) && H > 0 && W > 0, "conv3x3_first_fwd: bad shape B=%d C=%d H=%d W=%d", B, C, H, W);
     FirstArgs a;
     a.x = x; a.wf = wf; a.bias = bias; a.y = y;
     a.B = B; a.C = C; a.H = H; a.W = W;
@@ -338,8 +358,10 @@ int witw_conv3x3_first_fwd(const float* x, const float* wf, const float* bias, v
     a.circ = pad_circular; a.relu = relu; a.out_bf16 = out_bf16;
     const long long grid = (long long)B * a.tiles_x * a.tiles_y;
     WITW_CHECK_ARG(grid <= 0x7fffffffLL, "conv3x3_first_fwd: grid too large");
-    if (out_bf16 == 1)
-        hipLaunchKernelGGL(conv3x3_first_bf16_kernel, dim3((unsigned)grid), dim3(FT), 0, (hipStream_t)stream, a);
+    if (out_bf16 == 1 && C > 4)
+        hipLaunchKernelGGL(conv3x3_first_bf16_kernel<8>, dim3((unsigned)grid), dim3(FT), 0, (hipStream_t)stream, a);
+    else if (out_bf16 == 1)
+        hipLaunchKernelGGL(conv3x3_first_bf16_kernel<4>, dim3((unsigned)grid), dim3(FT), 0, (hipStream_t)stream, a);
     else
         hipLaunchKernelGGL(conv3x3_first_kernel, dim3((unsigned)grid), dim3(FT), 0, (hipStream_t)stream, a);
     WITW_CHECK_LAUNCH("conv3x3_first_fwd");

@@ -228,7 +228,7 @@ class FOV_DSM(torch.nn.Module):
         """The layer stack on the bf16 MFMA kernels (bf16 NHWC activations, fp32 accumulate, fp32 NCHW embedding).
         Returns (embedding, kept) with kept[idx] = (layer input, layer output, max-pool arg-max codes or None) bf16 NHWC
         for idx >= keep_from."""
-        fast0 = self.in_channels <= 4 and (keep_from is None or keep_from > 0)
+        fast0 = self.in_channels <= 8 and (keep_from is None or keep_from > 0)      # the bf16 first-layer kernel takes up to 8 channels
         h = x.contiguous() if fast0 else ops.nchw_to_nhwc_bf16(x.contiguous(), 16)
         last = self.layer_specs[-1][0]
         kept = {}
@@ -254,7 +254,7 @@ class FOV_DSM(torch.nn.Module):
         if self.training:
             raise _lib.WitwError('forward_bf16 is an inference path; call .eval()')
         with torch.no_grad():
-            fast0 = self.in_channels <= 4
+            fast0 = self.in_channels <= 8
             h = x.contiguous() if fast0 else ops.nchw_to_nhwc_bf16(x.contiguous(), 16)
             last = self.layer_specs[-1][0]
             for (idx, sh, relu, pool, drop) in self.layer_specs:

@@ -74,8 +74,8 @@ class PackedFirstConv:
     def __init__(self, weight, bias, bf16=False):
         lib = _lib.load()
         w = _dev_f32(weight.detach(), 'weight')
-        if w.shape[0] != 64 or w.shape[1] > 4:
-            raise _lib.WitwError('PackedFirstConv: expects a [64, C<=4, 3, 3] filter')
+        if w.shape[0] != 64 or w.shape[1] > (8 if bf16 else 4):
+            raise _lib.WitwError('PackedFirstConv: expects a [64, C<=4, 3, 3] filter (C<=8 with bf16=True)')
         self.cin, self.bf16 = w.shape[1], bool(bf16)
         self.wf = torch.empty(2560, dtype=torch.float32, device=w.device)
         _lib.check(lib.witw_conv3x3_first_pack(w.data_ptr(), self.wf.data_ptr(), self.cin, int(self.bf16), _stream()),
