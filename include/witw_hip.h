@@ -59,6 +59,13 @@ int witw_conv3x3_fwd(const float* x, const float* wpk, const float* bias, const 
  * first conv, model/cvig_semantic.py:301-303, at inference); out_bf16 = 2: fp32 arithmetic, split-fp16 output
  * [B,H,W,8,2,8] (hi / lo planes per 8 channels) for the fp16x3 path. */
 int witw_conv3x3_first_pack(const float* w, float* wf, int C, int round_bf16, void* stream);
+/* Layers 0 and 2 of the encoder fused, bf16 inference: x NCHW fp32 [B,C<=8,H,W] -> y NHWC bf16 [B,H/2,W/2,64] =
+ * MaxPool2d(2)(ReLU(conv 64->64 (ReLU(conv C->64 (x))))) (features[0..4], model/cvig_fov.py:256-260), the 64-channel map between
+ * the two convs never leaving the chip. wf0 / bias0: witw_conv3x3_first_pack(round_bf16 = 1) image and bias; wpk2 / bias2:
+ * witw_conv3x3_bf16_pack_weights image (64 -> 64) and bias. Bit-identical to witw_conv3x3_first_fwd(out_bf16 = 1) followed by
+ * witw_conv3x3_bf16_fwd(relu, pool). */
+int witw_conv_first2_bf16_fwd(const float* x, const void* wf0, const float* bias0, const void* wpk2, const float* bias2, void* y,
+                              int B, int C, int H, int W, int pad_circular, void* stream);
 int witw_conv3x3_first_fwd(const float* x, const float* wf, const float* bias, void* y, int B, int C, int H, int W,
                            int pad_circular, int relu, int out_bf16, void* stream);
 

@@ -89,3 +89,37 @@ def test_encoder_bf16_vs_emulation_and_fp32_goldens(golden_dir):
     assert _rel(e5, gs['embed5_circ1']) < 5e-2
     with pytest.raises(Exception):
         enc.train().forward_bf16(x360.cuda())
+
+
+@pytest.mark.parametrize('shape', [(2, 3, 128, 512), (3, 5, 128, 99), (2, 3, 20, 70), (1, 5, 9, 33), (2, 4, 64, 32), (1, 8, 16, 130)])
+def test_fused_first_two_layers_equal_the_separate_launches(shape):
+    """csrc/conv_first2_bf16.hip (layers 0 and 2 in one persistent kernel, layer 0 recomputed on each tile's halo, the
+    64-channel map between them never written) against conv3x3_first_fwd + conv3x3_bf16_fwd(pool): the same bits, both
+    padding modes, 3- / 5-channel inputs, sizes that are not multiples of the tile or of the pooling window."""
+    from witw_amd import ops
+    B, C, H, W = shape
+    g = np.random.Generator(np.random.Philox(key=[81, H * W + C]))
+    x = torch.from_numpy(g.standard_normal((B, C, H, W), dtype=np.float32)).cuda()
+    w0 = torch.from_numpy((g.standard_normal((64, C, 3, 3), dtype=np.float32) * 0.3).astype(np.float32)).cuda()
+    b0 = torch.from_numpy((g.standard_normal((64,), dtype=np.float32) * 0.2).astype(np.float32)).cuda()
+    w2 = torch.from_numpy((g.standard_normal((64, 64, 3, 3), dtype=np.float32) * 0.06).astype(np.float32)).cuda()
+    b2 = torch.from_numpy((g.standard_normal((64,), dtype=np.float32) * 0.2).astype(np.float32)).cuda()
+    pf, p2 = ops.PackedFirstConv(w0, b0, bf16=True), ops.PackedConvBf16(w2, b2)
+    for circ in (False, True):
+        mid = ops.conv3x3_first_fwd(x, pf, circular=circ, relu=True)
+        ref = ops.conv3x3_bf16_fwd(mid, p2, circular=circ, relu=True, pool=True)
+        got = ops.conv_first2_bf16(x, pf, p2, circular=circ)
+        assert got.shape == ref.shape == (B, H // 2, W // 2, 64)
+        assert torch.equal(got.view(torch.int16), ref.view(torch.int16)), (shape, circ, float((got.float() - ref.float()).abs().max()))
+
+
+def test_encoder_bf16_with_and_without_the_fused_launch():
+    from witw_amd import cvig_fov, cvig_semantic
+    for mod, c in ((cvig_fov, 3), (cvig_semantic, 5)):
+        w = synth.fov_dsm_weights(5, in_channels=c)
+        x = torch.from_numpy(synth.normalized_images(5, c, (2, c, 128, 512))).cuda()
+        enc = mod.FOV_DSM(circ_padding=True, weights=w).cuda().eval()
+        a = enc.forward_bf16(x)
+        enc.fuse_first2 = False
+        b = enc.forward_bf16(x)
+        assert torch.equal(a, b)

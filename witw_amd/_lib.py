@@ -93,6 +93,7 @@ SIGNATURES = {
     'witw_rank_count_band': (c_int, [c_void_p, c_void_p, c_float] + [c_void_p] * 4 + [c_int] * 3 + [c_void_p]),
     'witw_dropout2d_scales': (c_int, [c_void_p, ctypes.c_ulonglong, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint, c_void_p, c_int, c_int, c_int,
                                       c_float, c_void_p]),
+    'witw_conv_first2_bf16_fwd': (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p]),
     'witw_triplet_loss_fwd': (c_int, [c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     'witw_triplet_loss_slab_fwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     'witw_triplet_loss_slab_sig': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),

@@ -94,6 +94,7 @@ class FOV_DSM(torch.nn.Module):
     weights with load_state_dict. The unused VGG classifier of the reference is not kept.
     """
     in_channels = 3
+    fuse_first2 = True        # bf16 inference: layers 0 and 2 as one launch (False: the two separate kernels, same bits)
     _instances = 0            # encoders built so far: the id that keeps two encoders' Dropout2d masks independent
     dropout_seed = None       # None: torch.initial_seed()
     # 'fp32' = the reference's arithmetic on the fp32 MFMA kernels (parity path). 'bf16' = mixed precision on the bf16
@@ -257,7 +258,14 @@ class FOV_DSM(torch.nn.Module):
             fast0 = self.in_channels <= 8
             h = x.contiguous() if fast0 else ops.nchw_to_nhwc_bf16(x.contiguous(), 16)
             last = self.layer_specs[-1][0]
+            # layers 0 and 2 in one kernel (the 64-channel map between them stays on the chip): csrc/conv_first2_bf16.hip
+            fused = fast0 and self.fuse_first2 and self.layer_specs[0][:4] == (0, 1, True, False) and self.layer_specs[1][:4] == (2, 1, True, True)
             for (idx, sh, relu, pool, drop) in self.layer_specs:
+                if idx == 0 and fused:
+                    h = ops.conv_first2_bf16(h, self._pack_first(True), self._pack_bf16(2), circular=self.circ_padding)
+                    continue
+                if idx == 2 and fused:
+                    continue
                 if idx == 0 and fast0:
                     h = ops.conv3x3_first_fwd(h, self._pack_first(True), circular=self.circ_padding, relu=relu)
                     continue

@@ -110,6 +110,28 @@ def conv3x3_first_fwd(x_nchw, packed, circular=False, relu=True, split_f16=False
     return y
 
 
+def conv_first2_bf16(x_nchw, packed_first, packed_second, circular=False):
+    """Layers 0 and 2 fused (bf16 inference): x NCHW fp32 [B,C<=8,H,W] -> NHWC bf16 [B,H/2,W/2,64]; packed_first =
+    PackedFirstConv(bf16=True), packed_second = PackedConvBf16 of the 64 -> 64 conv."""
+    lib = _lib.load()
+    x = _dev_f32(x_nchw, 'x')
+    B, C, H, W = x.shape
+    if not packed_first.bf16 or C != packed_first.cin or packed_second.cin != 64 or packed_second.cout != 64:
+        raise _lib.WitwError('conv_first2_bf16: needs a bf16-packed C -> 64 first filter and a 64 -> 64 second one')
+    y = torch.empty((B, H // 2, W // 2, 64), dtype=torch.bfloat16, device=x.device)
+    prof = PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.check(lib.witw_conv_first2_bf16_fwd(x.data_ptr(), packed_first.wf.data_ptr(), packed_first.bias.data_ptr(),
+                                             packed_second.wpk.data_ptr(), packed_second.bias.data_ptr(), y.data_ptr(), B, C, H, W,
+                                             int(circular), _stream()), 'witw_conv_first2_bf16_fwd')
+    if prof is not None:
+        e1.record()
+        prof.append((('first2', True), 2.0 * (C + 64) * 64 * 9 * H * W * B, e0, e1))
+    return y
+
+
 def nchw_to_nhwc8(x):
     lib = _lib.load()
     x = _dev_f32(x, 'x')
