@@ -220,13 +220,16 @@ __global__ __launch_bounds__(FT, 2) void conv3x3_first_bf16_kernel(FirstArgs p) 
     __syncthreads();
 
     const int row0 = 2 * (wave >> 1), col0 = 32 * (wave & 1);
-    f32x16 acc[2][2];
+    float bv[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) bv[nt] = p.bias[nt * 32 + l31];
+    f32x16 acc[2][2];          // started from the bias (conv_first2_bf16.hip does the same: the two stay bit-identical)
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[a][c][r] = bv[c];
 #pragma unroll
     for (int i = 0; i < NMF; ++i) {
         u32x4v bw[2];
@@ -258,9 +261,6 @@ __global__ __launch_bounds__(FT, 2) void conv3x3_first_bf16_kernel(FirstArgs p) 
     }
     __syncthreads();     // every wave is done with the input / weight images before the slabs overwrite them
 
-    float bv[2];
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) bv[nt] = p.bias[nt * 32 + l31];
     float* slab = reinterpret_cast<float*>(smem) + wave * (32 * 64);
     const int prow = lane >> 3, pc8 = (lane & 7) * 8;
 #pragma unroll
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(FT, 2) void conv3x3_first_bf16_kernel(FirstArgs p) 
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float v = acc[mt][nt][r] + bv[nt];
+                float v = acc[mt][nt][r];
                 if (p.relu) v = fmaxf(v, 0.f);
                 slab[((r & 3) + 8 * (r >> 2) + 4 * hq) * 64 + nt * 32 + l31] = v;
             }

@@ -11,14 +11,18 @@
 //
 // Per tile (8 output rows x 32 columns x 64 channels, pooled 4 x 16 x 64):
 //   A  the 12 x 36 raw pixels (one per thread, prefetched during the previous tile) -> LDS as bf16 (r,g,b,0) / 8-channel slots
-//   B  layer 0 on the 10 x 34 positions of the layer-2 input tile: 11 M-tiles of 32 positions x 64 channels, MFMA with the
+//   B  layer 0 on the 10 x 34 positions of the layer-2 input tile: 11 M-tiles of 32 positions x 2 N-tiles of 32 channels (22
+//      units over the 8 waves), accumulators started from the bias, MFMA with the
 //      FILTER as the A operand so that a lane ends up with 4 consecutive channels of one position = one 8-byte LDS write into
 //      the layer-2 operand image [channel group of 8][position]; positions outside the picture are layer 2's zero padding
 //   C  layer 2: 4 K chunks x 9 taps of v_mfma_f32_32x32x16_bf16, M-tile = 2 rows x 16 columns (a 2x2 pooling window lies inside
-//      one lane's registers), operands by ds_read_b128 from the two resident images, same accumulation order as
+//      one lane's registers), one M-tile x 2 N-tiles per wave, operands by hand-issued ds_read_b128 three steps ahead with
+//      counted lgkmcnt waits, same accumulation order as
 //      conv3x3_nhwc_bf16_kernel (chunk-major, tap-minor): bit-identical to the unfused launches
 //   D  bias + ReLU + 2x2 max, through a wave-private 1 KB slab to 16-byte NHWC stores.
 #include "common.h"
+#include <stdio.h>
+#include <stdlib.h>
 #include <type_traits>
 
 namespace {
@@ -28,7 +32,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int F2T = 512;                 // 8 waves
+constexpr int F2T = 512;                 // 8 waves, two per SIMD (the layer-0 phase is VALU-heavy: two waves keep a SIMD's vector issue full)
 constexpr int TH2 = 8, TW2 = 32;         // layer-2 output tile
 constexpr int AH = TH2 + 2, AW = TW2 + 2;          // layer-2 input tile (layer-0 outputs): 10 x 34 positions
 constexpr int APITCH = 48;               // LDS row pitch of that tile in positions: a multiple of 16 keeps the two rows of an M-tile
@@ -36,6 +40,46 @@ constexpr int APITCH = 48;               // LDS row pitch of that tile in positi
 constexpr int APOS = AH * APITCH;        // 480 slots per channel group
 constexpr int RH = TH2 + 4, RW = TW2 + 4;          // raw tile: 12 x 36 pixels
 constexpr int NMT0 = (AH * AW + 31) / 32;          // 11 M-tiles of layer 0
+
+__device__ __forceinline__ unsigned lds_address(const void* p) {
+    return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)p;
+}
+__device__ __forceinline__ u32x4 lds_read128(unsigned addr) {
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
+// s_waitcnt lgkmcnt(n) that names the fragments it releases, so that the MFMAs reading them cannot be scheduled above it
+__device__ __forceinline__ void lds_wait(int n, u32x4& a) {
+    switch (n) {      // n is a constant once the caller's loop is unrolled
+    case 0: asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a)); break;
+    case 1: asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(a)); break;
+    case 2: asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a)); break;
+    case 3: asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(a)); break;
+    case 4: asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a)); break;
+    case 5: asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(a)); break;
+    case 6: asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(a)); break;
+    case 7: asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(a)); break;
+    case 8: asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(a)); break;
+    case 9: asm volatile("s_waitcnt lgkmcnt(9)" : "+v"(a)); break;
+    default: asm volatile("s_waitcnt lgkmcnt(10)" : "+v"(a)); break;
+    }
+}
+__device__ __forceinline__ void lds_wait(int n, u32x4& a, u32x4& b) {
+    switch (n) {
+    case 0: asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b)); break;
+    case 1: asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(a), "+v"(b)); break;
+    case 2: asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a), "+v"(b)); break;
+    case 3: asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(a), "+v"(b)); break;
+    case 4: asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a), "+v"(b)); break;
+    case 5: asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(a), "+v"(b)); break;
+    case 6: asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(a), "+v"(b)); break;
+    case 7: asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(a), "+v"(b)); break;
+    case 8: asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(a), "+v"(b)); break;
+    case 9: asm volatile("s_waitcnt lgkmcnt(9)" : "+v"(a), "+v"(b)); break;
+    default: asm volatile("s_waitcnt lgkmcnt(10)" : "+v"(a), "+v"(b)); break;
+    }
+}
 
 struct First2Args {
     const float* x;           // NCHW fp32 [B,C,H,W]
@@ -50,7 +94,9 @@ struct First2Args {
     int circ;
 };
 
-template <int CW>
+__device__ unsigned long long f2_stamps[2][8];       // WITW_F2_STAMPS=1 diagnostic: phase ticks of waves 0 and 7, third tile of workgroup 0
+
+template <int CW, bool REC>
 __global__ __launch_bounds__(F2T, 1) void conv_first2_bf16_kernel(First2Args p) {
     static_assert(CW == 4 || CW == 8, "4 or 8 bf16 per raw pixel");
     constexpr int NMF = (CW == 4) ? 3 : 5;
@@ -69,41 +115,49 @@ __global__ __launch_bounds__(F2T, 1) void conv_first2_bf16_kernel(First2Args p) 
     // ---- once per workgroup: layer-2 filter -> LDS, layer-0 filter fragments and layer-2 bias -> registers
     for (int s = tid; s < 4 * 9 * 2 * 64; s += F2T) w_s[s] = p.wpk2[s];
     if (tid < 64) b0_s[tid] = p.bias0[tid];
-    u32x4 aw[2][NMF];                               // layer-0 filter as the MFMA A operand: row = channel nt*32 + l31, k half = hq
+    // layer 0 is cut into 22 units (M-tile of 32 positions, N-tile of 32 channels); wave w takes units w, w+8, w+16, whose
+    // N-tile is w & 1 for all three: one N-tile's filter fragments and bias per wave
+    const int nt0 = wave & 1;
+    u32x4 aw[NMF];                                  // layer-0 filter as the MFMA A operand: row = channel nt0*32 + l31, k half = hq
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int i = 0; i < NMF; ++i) aw[nt][i] = p.wf0[(i * 2 + hq) * 64 + nt * 32 + l31];
+    for (int i = 0; i < NMF; ++i) aw[i] = p.wf0[(i * 2 + hq) * 64 + nt0 * 32 + l31];
     float b2[2];
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) b2[nt] = p.bias2[nt * 32 + l31];
+    f32x16 b0r;                                     // layer-0 bias of this lane's 16 channels (register 4j+e: channel nt0*32 + 8j + 4hq + e)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) b0r[r] = p.bias0[nt0 * 32 + 8 * (r >> 2) + 4 * hq + (r & 3)];
 
-    // raw pixel of this thread (tile-relative), fetched one tile ahead
-    const bool has_raw = tid < RH * RW;
-    const int rr = tid / RW, rc = tid - rr * RW;
-    float rv[CW];
+    // raw pixels of this thread (tile-relative; 432 pixels over 256 threads), fetched one tile ahead
+    constexpr int NRAW = (RH * RW + F2T - 1) / F2T;
+    float rv[NRAW][CW];
     auto fetch_raw = [&](long long tile) {
 #pragma unroll
-        for (int ch = 0; ch < CW; ++ch) rv[ch] = 0.f;
-        if (!has_raw || tile >= p.n_tiles) return;
-        const int tiles_img = p.tiles_x * p.tiles_y;
-        const int b = (int)(tile / tiles_img);
-        const int rem = (int)(tile - (long long)b * tiles_img);
-        const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
-        const int gr = ty * TH2 - 2 + rr;
-        int gc = tx * TW2 - 2 + rc;
-        bool ok = gr >= 0 && gr < p.H;
-        if (p.circ) {
-            gc %= p.W;
-            if (gc < 0) gc += p.W;
-        } else {
-            ok = ok && gc >= 0 && gc < p.W;
-        }
-        if (ok) {
-            const float* src = p.x + (size_t)b * p.C * plane + (size_t)gr * p.W + gc;
+        for (int k = 0; k < NRAW; ++k) {
 #pragma unroll
-            for (int ch = 0; ch < CW; ++ch)
-                if (ch < p.C) rv[ch] = src[ch * plane];
+            for (int ch = 0; ch < CW; ++ch) rv[k][ch] = 0.f;
+            const int s = tid + k * F2T;
+            if (s >= RH * RW || tile >= p.n_tiles) continue;
+            const int rr = s / RW, rc = s - rr * RW;
+            const int tiles_img = p.tiles_x * p.tiles_y;
+            const int b = (int)(tile / tiles_img);
+            const int rem = (int)(tile - (long long)b * tiles_img);
+            const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+            const int gr = ty * TH2 - 2 + rr;
+            int gc = tx * TW2 - 2 + rc;
+            bool ok = gr >= 0 && gr < p.H;
+            if (p.circ) {
+                gc %= p.W;
+                if (gc < 0) gc += p.W;
+            } else {
+                ok = ok && gc >= 0 && gc < p.W;
+            }
+            if (ok) {
+                const float* src = p.x + (size_t)b * p.C * plane + (size_t)gr * p.W + gc;
+#pragma unroll
+                for (int ch = 0; ch < CW; ++ch)
+                    if (ch < p.C) rv[k][ch] = src[ch * plane];
+            }
         }
     };
 
@@ -112,99 +166,150 @@ __global__ __launch_bounds__(F2T, 1) void conv_first2_bf16_kernel(First2Args p) 
     const int a_lane = ((2 * prow + (l31 >> 4)) * APITCH + 16 * chalf + (l31 & 15));      // + (kh * APITCH + kw) per tap
 
     fetch_raw(blockIdx.x);
-    for (long long tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
+    int iter = 0;
+    for (long long tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x, ++iter) {
+        const bool rec = REC && blockIdx.x == 0 && iter == 2 && lane == 0 && (wave == 0 || wave == 7);
+        auto stamp = [&](int k) { if (rec) f2_stamps[wave == 7][k] = __builtin_amdgcn_s_memtime(); };
+        stamp(0);
         const int tiles_img = p.tiles_x * p.tiles_y;
         const int b = (int)(tile / tiles_img);
         const int rem = (int)(tile - (long long)b * tiles_img);
         const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
         const int oy0 = ty * TH2, ox0 = tx * TW2;
+        const bool border = oy0 == 0 || oy0 + TH2 + 1 > p.H || (!p.circ && (ox0 == 0 || ox0 + TW2 + 1 > p.W));      // wave-uniform
 
         // ---- A: raw pixels -> LDS (bf16)
-        if (has_raw) {
-            __bf16 v[CW];
 #pragma unroll
-            for (int ch = 0; ch < CW; ++ch) v[ch] = (__bf16)rv[ch];
-            raw_s[tid] = __builtin_bit_cast(pix_t, v);
+        for (int k = 0; k < NRAW; ++k) {
+            const int s = tid + k * F2T;
+            if (s < RH * RW) {
+                __bf16 v[CW];
+#pragma unroll
+                for (int ch = 0; ch < CW; ++ch) v[ch] = (__bf16)rv[k][ch];
+                raw_s[s] = __builtin_bit_cast(pix_t, v);
+            }
         }
+        stamp(1);
         __syncthreads();          // raw tile visible; every wave has left the previous tile's layer-2 loop (a_s is free)
+        stamp(2);
         fetch_raw(tile + gridDim.x);
 
-        // ---- B: layer 0 on the 10 x 34 positions, 11 M-tiles over the 8 waves
-        for (int mt = wave; mt < NMT0; mt += 8) {
-            const int q = mt * 32 + l31;                    // position index in the 10 x 34 tile
-            const bool live = q < AH * AW;
-            const int qr = live ? q / AW : 0, qc = live ? q - qr * AW : 0;
-            const int rbase = qr * RW + qc;                 // raw pixel of tap (0,0)
-            f32x16 acc0[2];
+        // ---- B: layer 0 on the 10 x 34 positions: 11 M-tiles x 2 N-tiles = 22 units over the 8 waves, three per wave (the last
+        // one of waves 6 and 7 repeats unit 2 and is not written). All raw operands of the three units are read first, then the
+        // three accumulation chains advance in turn (one chain alone would wait out every MFMA's latency and every LDS read).
+        // The accumulator starts from the bias, as conv3x3_first_bf16_kernel's does: one max and half a convert per value.
+        {
+            constexpr int NU = 3;
+            int qr[NU], qc[NU];
+            bool live[NU];
+            u32x4 pv[NU][NMF];
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+            for (int k = 0; k < NU; ++k) {
+                const int mt = min((wave >> 1) + 4 * k, NMT0 - 1);
+                const int q = mt * 32 + l31;                // position index in the 10 x 34 tile
+                live[k] = q < AH * AW && (wave >> 1) + 4 * k < NMT0;
+                qr[k] = q < AH * AW ? q / AW : 0;
+                qc[k] = q < AH * AW ? q - qr[k] * AW : 0;
+                const int rbase = qr[k] * RW + qc[k];       // raw pixel of tap (0,0)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc0[nt][r] = 0.f;
-#pragma unroll
-            for (int i = 0; i < NMF; ++i) {
-                u32x4 pv;
-                if constexpr (CW == 4) {
-                    const int tA = 4 * i + 2 * hq, tB = tA + 1;
-                    u32x2 pa = raw_s[rbase + ((tA < 9) ? (tA / 3) * RW + tA % 3 : 0)];
-                    u32x2 pb = raw_s[rbase + ((tB < 9) ? (tB / 3) * RW + tB % 3 : 0)];
-                    if (tA >= 9) pa = (u32x2){0u, 0u};
-                    if (tB >= 9) pb = (u32x2){0u, 0u};
-                    pv = (u32x4){pa[0], pa[1], pb[0], pb[1]};
-                } else {
-                    const int t = 2 * i + hq;
-                    pv = raw_s[rbase + ((t < 9) ? (t / 3) * RW + t % 3 : 0)];
-                    if (t >= 9) pv = (u32x4){0u, 0u, 0u, 0u};
+                for (int i = 0; i < NMF; ++i) {
+                    if constexpr (CW == 4) {
+                        const int tA = 4 * i + 2 * hq, tB = tA + 1;
+                        u32x2 pa = raw_s[rbase + ((tA < 9) ? (tA / 3) * RW + tA % 3 : 0)];
+                        u32x2 pb = raw_s[rbase + ((tB < 9) ? (tB / 3) * RW + tB % 3 : 0)];
+                        if (tA >= 9) pa = (u32x2){0u, 0u};
+                        if (tB >= 9) pb = (u32x2){0u, 0u};
+                        pv[k][i] = (u32x4){pa[0], pa[1], pb[0], pb[1]};
+                    } else {
+                        const int t = 2 * i + hq;
+                        pv[k][i] = raw_s[rbase + ((t < 9) ? (t / 3) * RW + t % 3 : 0)];
+                        if (t >= 9) pv[k][i] = (u32x4){0u, 0u, 0u, 0u};
+                    }
                 }
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt)     // D[channel][position]: filter rows x pixel columns
-                    acc0[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aw[nt][i]), __builtin_bit_cast(bf16x8, pv),
-                                                                       acc0[nt], 0, 0, 0);
             }
-            // position inside the picture? (outside: layer 2's zero padding, or the wrapped column under circular padding)
-            const int gy = oy0 - 1 + qr;
-            int gx = ox0 - 1 + qc;
-            bool inside = live && gy >= 0 && gy < p.H;
-            if (!p.circ) inside = inside && gx >= 0 && gx < p.W;
-            if (live) {
-                unsigned char* dst = reinterpret_cast<unsigned char*>(a_s) + ((size_t)(qr * APITCH + qc)) * 16 + 8 * hq;
+            f32x16 acc0[NU];
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
+            for (int k = 0; k < NU; ++k) acc0[k] = b0r;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {           // registers 4j..4j+3 = channels nt*32 + 8j + 4hq + {0..3}
+            for (int i = 0; i < NMF; ++i)
+#pragma unroll
+                for (int k = 0; k < NU; ++k)       // D[channel][position]: filter rows x pixel columns
+                    acc0[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aw[i]), __builtin_bit_cast(bf16x8, pv[k][i]),
+                                                                      acc0[k], 0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < NU; ++k) {
+                // position inside the picture? (outside: layer 2's zero padding, or the wrapped column under circular padding);
+                // only tiles on the picture's edge need the test
+                bool outside = false;
+                if (border) {
+                    const int gy = oy0 - 1 + qr[k], gx = ox0 - 1 + qc[k];
+                    outside = gy < 0 || gy >= p.H;
+                    if (!p.circ) outside = outside || gx < 0 || gx >= p.W;
+                }
+                if (live[k]) {
+                    unsigned char* dst = reinterpret_cast<unsigned char*>(a_s) + ((size_t)(qr[k] * APITCH + qc[k])) * 16 + 8 * hq;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {           // registers 4j..4j+3 = channels nt0*32 + 8j + 4hq + {0..3}
                         bf16x4 o;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float v = acc0[nt][4 * j + e] + b0_s[nt * 32 + 8 * j + 4 * hq + e];
-                            v = fmaxf(v, 0.f);
-                            o[e] = (__bf16)(inside ? v : 0.f);
-                        }
-                        *reinterpret_cast<bf16x4*>(dst + (size_t)(nt * 4 + j) * (APOS * 16)) = o;
+                        for (int e = 0; e < 4; ++e) o[e] = (__bf16)fmaxf(acc0[k][4 * j + e], 0.f);
+                        u32x2 ob = __builtin_bit_cast(u32x2, o);
+                        if (outside) ob = (u32x2){0u, 0u};
+                        *reinterpret_cast<u32x2*>(dst + (size_t)(nt0 * 4 + j) * (APOS * 16)) = ob;
                     }
+                }
             }
         }
+        stamp(3);
         __syncthreads();          // layer-2 input tile complete
+        stamp(4);
 
-        // ---- C: layer 2, 36 (chunk, tap) steps
+        // ---- C: layer 2, 36 (chunk, tap) steps of 2 MFMAs per wave (1 M-tile x 2 N-tiles). Operand reads are inline asm (left to
+        // the scheduler each ds_read sinks to just in front of its MFMA and every MFMA pair waits on lgkmcnt(0)): asm volatile
+        // statements keep their order, reads are issued in the order their MFMAs need them (fa, fb0 -> MFMA 1; fb1 -> MFMA 2)
+        // PF steps ahead, and LDS returns in order, so an MFMA waits with lgkmcnt(reads issued after the last one it needs).
         f32x16 acc[2];
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+        constexpr int PF = 3, NB = PF + 1;
+        u32x4 fa[NB], fb[NB][2];
+        const unsigned abase = lds_address(a_s) + (unsigned)(hq * APOS + a_lane) * 16u;
+        const unsigned wbase = lds_address(w_s) + (unsigned)(hq * 64 + l31) * 16u;
+        auto a_addr = [&](int step) {
+            const int kc = step / 9, tap = step - kc * 9;
+            const int kh = tap / 3, kw = tap - kh * 3;
+            return abase + (unsigned)(2 * kc * APOS + kh * APITCH + kw) * 16u;
+        };
+        auto w_addr = [&](int step, int nt) { return wbase + (unsigned)(step * 128 + nt * 32) * 16u; };
+        int issued = 0;
+        auto issue = [&](int step, int which) {
+            const int bq = step % NB;
+            if (which == 0) fa[bq] = lds_read128(a_addr(step));
+            else fb[bq][which - 1] = lds_read128(w_addr(step, which - 1));
+            ++issued;
+        };
 #pragma unroll
-        for (int kc = 0; kc < 4; ++kc) {
+        for (int st = 0; st < PF; ++st)
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int kh = tap / 3, kw = tap - kh * 3;
-                const u32x4 fa = a_s[(2 * kc + hq) * APOS + a_lane + kh * APITCH + kw];
+            for (int which = 0; which < 3; ++which) issue(st, which);
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    const u32x4 fb = w_s[((kc * 9 + tap) * 2 + hq) * 64 + nt * 32 + l31];
-                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa), __builtin_bit_cast(bf16x8, fb),
-                                                                     acc[nt], 0, 0, 0);
-                }
+        for (int step = 0; step < 36; ++step) {
+            const int bq = step % NB;
+            const bool more = step + PF < 36;
+            lds_wait(issued - (3 * step + 2), fa[bq], fb[bq][0]);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[bq]), __builtin_bit_cast(bf16x8, fb[bq][0]), acc[0], 0, 0, 0);
+            if (more) {
+                issue(step + PF, 0);
+                issue(step + PF, 1);
             }
+            lds_wait(issued - (3 * step + 3), fb[bq][1]);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[bq]), __builtin_bit_cast(bf16x8, fb[bq][1]), acc[1], 0, 0, 0);
+            if (more) issue(step + PF, 2);
         }
 
+        stamp(5);
         // ---- D: bias + ReLU + 2x2 max-pool -> slab [pooled column 0..7][64 channels] bf16 -> 16-byte stores
         // register r <-> pixel m = (r&3) + 8*(r>>2) + 4*hq of the M-tile, m = 16*row + column: the window of pooled column
         // jp = (r&3)/2 + 4*((r>>2)&1) + 2*hq is registers {r, r+1, r+8, r+9} (r&3 in {0,2}, r < 8)
@@ -225,6 +330,7 @@ __global__ __launch_bounds__(F2T, 1) void conv_first2_bf16_kernel(First2Args p) 
             if (py < Hy && px < Wy)
                 __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p.y + (((size_t)b * Hy + py) * Wy + px) * 64 + c8));
         }
+        stamp(6);
     }
 }
 
@@ -254,10 +360,22 @@ int witw_conv_first2_bf16_fwd(const float* x, const void* wf0, const float* bias
         if (n_cu <= 0) n_cu = 256;
     }
     const unsigned grid = (unsigned)(a.n_tiles < n_cu ? a.n_tiles : n_cu);
-    if (C <= 4)
-        hipLaunchKernelGGL(conv_first2_bf16_kernel<4>, dim3(grid), dim3(F2T), 0, (hipStream_t)stream, a);
+    const bool rec = getenv("WITW_F2_STAMPS") != nullptr && a.n_tiles >= 3LL * grid;      // diagnostic, synchronous
+    if (rec && C > 4)
+        hipLaunchKernelGGL((conv_first2_bf16_kernel<8, true>), dim3(grid), dim3(F2T), 0, (hipStream_t)stream, a);
+    else if (C <= 4)
+        hipLaunchKernelGGL((conv_first2_bf16_kernel<4, false>), dim3(grid), dim3(F2T), 0, (hipStream_t)stream, a);
     else
-        hipLaunchKernelGGL(conv_first2_bf16_kernel<8>, dim3(grid), dim3(F2T), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((conv_first2_bf16_kernel<8, false>), dim3(grid), dim3(F2T), 0, (hipStream_t)stream, a);
+    if (rec && C > 4) {
+        (void)hipDeviceSynchronize();
+        unsigned long long h[2][8];
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(f2_stamps), sizeof(h)) == hipSuccess)
+            for (int w = 0; w < 2; ++w)
+                fprintf(stderr, "conv_first2 wave %d, third tile (ticks): raw->LDS %llu, barrier %llu, layer 0 %llu, barrier %llu, layer 2 %llu, "
+                                "pool+store %llu, total %llu\n", w ? 7 : 0, h[w][1] - h[w][0], h[w][2] - h[w][1], h[w][3] - h[w][2],
+                        h[w][4] - h[w][3], h[w][5] - h[w][4], h[w][6] - h[w][5], h[w][6] - h[w][0]);
+    }
     WITW_CHECK_LAUNCH("conv_first2_bf16");
     return WITW_OK;
 }
