@@ -65,7 +65,7 @@ def test_version_and_argument_errors_without_gpu():
     # the spectral match and the row-split top-k
     assert lib.witw_match_spectrum_floats(3) == 3 * 33 * 128
     assert lib.witw_match_dft_workspace_floats(5, 7) == 5 * 64 + 7 + 33 * 64
-    rc = lib.witw_match_spectrum(1, 1, 4, 65, None)
+    rc = lib.witw_match_spectrum(1, 1, 4, 65, 0, None)
     assert rc == -1 and b'bad shape' in lib.witw_last_error()
     rc = lib.witw_match_fwd_dft(1, 1, None, 1, 4, 4, 64, None, None, None, 1, None)
     assert rc == -1 and b'null' in lib.witw_last_error()

@@ -323,7 +323,7 @@ class SpectralCpuKernels(Fp64MatchKernels):
     SCORE_ROUNDING = 2e-4
 
     @staticmethod
-    def match_spectrum(emb):
+    def match_spectrum(emb, overhead=None):
         return emb
 
     @classmethod

@@ -16,7 +16,7 @@ gen = torch.Generator(device='cuda')
 gen.manual_seed(1)
 ov = torch.randn((16384, 16, 4, 64), generator=gen, device='cuda')
 su = torch.randn((4096, 16, 4, 64), generator=gen, device='cuda')
-sg, sq = ops.match_spectrum(ov), ops.match_spectrum(su)
+sg, sq = ops.match_spectrum(ov, overhead=True), ops.match_spectrum(su, overhead=False)
 for _ in range(2):
     ops.match_fwd_dft(ov, su, spec_ov=sg, spec_su=sq, want_orientation=False)
 torch.cuda.synchronize()

@@ -30,8 +30,8 @@ def main():
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / n, out
 
-    t_spec, spec_g = timed(lambda: ops.match_spectrum(ov))
-    t_specq, spec_q = timed(lambda: ops.match_spectrum(su))
+    t_spec, spec_g = timed(lambda: ops.match_spectrum(ov, overhead=True))
+    t_specq, spec_q = timed(lambda: ops.match_spectrum(su, overhead=False))
     t_dft, (ori1, d1) = timed(lambda: ops.match_fwd_dft(ov, su, spec_ov=spec_g, spec_su=spec_q))
     t_dir, (ori0, d0) = timed(lambda: ops.match_fwd(ov, su), n=1)
     pairs = G * Q

@@ -77,7 +77,7 @@ SIGNATURES = {
     'witw_match_workspace_floats': (c_longlong, [c_int, c_int]),
     'witw_match_fwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'witw_match_spectrum_floats': (c_longlong, [c_longlong]),
-    'witw_match_spectrum': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    'witw_match_spectrum': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'witw_match_dft_workspace_floats': (c_longlong, [c_int, c_int]),
     'witw_match_fwd_dft': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p]),

@@ -152,13 +152,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int j = (l31 & 3) + 4 * (l31 >> 3), part = (l31 >> 2) & 1;
     //   K < 64 (lines x re of the overhead):  Re row reads P, Im row reads Q (sign below);  K >= 64 (x im): Re row reads Q, Im row reads P
     // byte offsets in a stage of k-group 0; k-group u is at offset ^ (u << 4) (the swizzle: slot u ^ (row & 15))
-    const unsigned a_row = (unsigned)(par * 32 + team * 16 + j) * 512u + 8u * hk + ((unsigned)j << 4);
-    const unsigned a_off1 = a_row + (part ? 256u : 0u);
-    const unsigned a_off2 = a_row + (part ? 0u : 256u);
+    // 8-byte chunk of a 16-byte slot: ds_read_b64 serves lanes 0-31 and 32-63 in one LDS cycle each when their 32 x 8 bytes fall on
+    // 64 distinct banks. A surface's P and Q halves are 256 B apart (the same banks) and are read by the part-0 / part-1 lanes of
+    // one instruction, so the surface spectra are STORED with the two chunks of every Q slot exchanged (match_spectrum_kernel,
+    // role 0) and a lane reading Q takes chunk hk ^ 1: P readers sit on banks 4c+{0,1}, Q readers on 4c+{2,3}.
+    const unsigned a_row = (unsigned)(par * 32 + team * 16 + j) * 512u + ((unsigned)j << 4);
+    const unsigned a_off1 = a_row + (part ? 256u + 8u * (hk ^ 1) : 8u * hk);
+    const unsigned a_off2 = a_row + (part ? 8u * hk : 256u + 8u * (hk ^ 1));
     // the Im rows' minus sign (K < 64: -Q) is applied once per step: ca collects K < 64, cb K >= 64, and accumulator register r
     // holds Re C in lanes 0-31 and Im C in lanes 32-63, so C = cb + sg * ca with sg = -1 in the upper half-wave
     const float sg = hk ? -1.f : 1.f;
-    const unsigned b_off1 = (unsigned)(A_F + (par * 32 + l31) * ROW_F) * 4u + 8u * hk + ((unsigned)(l31 & 15) << 4);     // Q: + 256
+    // overheads: one instruction reads one half of 32 different rows; rows r and r + 16 share the slot swizzle, so the spectra of
+    // overheads with bit 4 of their index set are stored with the chunks of every slot exchanged (role 1) and read at hk ^ 1
+    const unsigned b_off1 = (unsigned)(A_F + (par * 32 + l31) * ROW_F) * 4u + 8u * (hk ^ (l31 >> 4)) + ((unsigned)(l31 & 15) << 4);     // Q: + 256
     for (int t = tid; t < (NSLOT + 1) * 64; t += 256) dt_s[t] = t < NSLOT * 64 ? p.dtab[t] : 0.f;
     // a global load here would sit at the end of every step with its whole latency exposed (measured: ~4.6k cycles per step)
     auto dcoef = [&](int step) { return dt_s[(2 * step + par) * 64 + lane]; };
@@ -299,7 +305,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
 // spec[e][t][0..63] = Re X_t(line), [64..127] = Im X_t(line) (0 for t = 0, 32), X_t = sum_k x[line][k] e^{-2 pi i t k / 64}; fp64
 // accumulation, rounded once to fp32. One workgroup per embedding [64 lines][W columns], W <= 64.
-__global__ __launch_bounds__(256) void match_spectrum_kernel(const float* __restrict__ emb, float* __restrict__ spec, int W) {
+// role: whose spectrum this is, which fixes the order of the two 8-byte chunks (float pairs) inside each 16-byte slot so that the
+// match kernel's ds_read_b64 are free of bank conflicts (see the operand roles there): 0 = surface (queries): the chunks of the
+// Q half exchanged; 1 = overhead (gallery): both halves' chunks exchanged for embeddings whose index has bit 4 set.
+__global__ __launch_bounds__(256) void match_spectrum_kernel(const float* __restrict__ emb, float* __restrict__ spec, int W, int role) {
     __shared__ float xs[64 * 65];
     __shared__ double cs[64], sn[64];
     const int tid = threadIdx.x, line = tid & 63, tq = tid >> 6;
@@ -319,8 +328,10 @@ __global__ __launch_bounds__(256) void match_spectrum_kernel(const float* __rest
             pr += xv * cs[idx];
             pi -= xv * sn[idx];
         }
-        out[t * 128 + line] = (float)pr;
-        out[t * 128 + 64 + line] = (t == 0 || t == 32) ? 0.f : (float)pi;
+        const int swap_p = (role == 1 && (blockIdx.x & 16)) ? 2 : 0;      // float index ^ 2 = the other 8-byte chunk of the slot
+        const int swap_q = (role == 0 || (blockIdx.x & 16)) ? 2 : 0;
+        out[t * 128 + (line ^ swap_p)] = (float)pr;
+        out[t * 128 + 64 + (line ^ swap_q)] = (t == 0 || t == 32) ? 0.f : (float)pi;
     }
 }
 
@@ -381,11 +392,14 @@ extern "C" {
 // floats of one embedding's row spectrum (33 slots x [64 re | 64 im])
 long long witw_match_spectrum_floats(long long n_embeddings) { return n_embeddings * (long long)SPEC; }
 
-// emb [B,64 lines,W] (an overhead embedding [B,16,4,64] or a surface embedding [B,16,4,We]) -> spec [B,33,128]
-int witw_match_spectrum(const float* emb, float* spec, int B, int W, void* stream) {
+// emb [B,64 lines,W] (an overhead embedding [B,16,4,64], role 1, or a surface embedding [B,16,4,We], role 0) -> spec [B,33,128]
+// in the chunk order the match kernel's operand reads expect of that side (an overhead's spectrum depends on its index & 16:
+// spectra of a gallery must be computed at the row numbering they are matched at, multiples of 32 apart)
+int witw_match_spectrum(const float* emb, float* spec, int B, int W, int role, void* stream) {
     WITW_CHECK_ARG(emb && spec, "match_spectrum: null pointer");
     WITW_CHECK_ARG(B > 0 && W >= 1 && W <= 64, "match_spectrum: bad shape B=%d W=%d", B, W);
-    hipLaunchKernelGGL(match_spectrum_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, emb, spec, W);
+    WITW_CHECK_ARG(role == 0 || role == 1, "match_spectrum: role %d (0 = surface / query side, 1 = overhead / gallery side)", role);
+    hipLaunchKernelGGL(match_spectrum_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, emb, spec, W, role);
     WITW_CHECK_LAUNCH("match_spectrum");
     return WITW_OK;
 }

@@ -812,7 +812,7 @@ def _retrieve_dft(overhead_shard, surface_all, k, shard_begin, query_chunk, kn, 
     n_q, n_g, we = surface_all.shape[0], overhead_shard.shape[0], surface_all.shape[3]
     kc = min(32, k + 6)                                  # local candidates per query, by spectral distance
     gallery = overhead_shard.contiguous()
-    spec_g = kn.match_spectrum(gallery) if n_g else None
+    spec_g = kn.match_spectrum(gallery, overhead=True) if n_g else None
     counts = torch.zeros((n_q,), dtype=torch.int32, device=dev)
     vals, idxs, sns = [], [], []
     wn = None

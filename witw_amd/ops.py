@@ -307,14 +307,17 @@ def match_fwd(overhead_embed, surface_embed, want_score=False, want_workspace=Fa
     return (ori, dist, score) if want_score else (ori, dist)
 
 
-def match_spectrum(embed):
-    """Row spectra of embeddings [B,16,4,W] (W = 64 overhead, W = We surface) -> f32 [B,33,128], the operand of match_fwd_dft."""
+def match_spectrum(embed, overhead=None):
+    """Row spectra of embeddings [B,16,4,W] (W = 64 overhead, W = We surface) -> f32 [B,33,128], the operand of match_fwd_dft.
+    overhead: which side the spectra are for (default: by width -- 64 columns = overhead); the two sides differ in the order
+    of the 8-byte chunks inside each 16-byte slot (csrc/match_dft.hip: conflict-free LDS operand reads)."""
     lib = _lib.load()
     e = _dev_f32(embed, 'embed')
     if e.dim() != 4 or e.shape[1] * e.shape[2] != 64 or not (1 <= e.shape[3] <= 64):
         raise _lib.WitwError('match_spectrum: embedding must be [B,16,4,W<=64], got %s' % (tuple(e.shape),))
+    role = int(e.shape[3] == 64) if overhead is None else int(bool(overhead))
     spec = torch.empty((e.shape[0], 33, 128), dtype=torch.float32, device=e.device)
-    _lib.check(lib.witw_match_spectrum(e.data_ptr(), spec.data_ptr(), e.shape[0], e.shape[3], _stream()), 'witw_match_spectrum')
+    _lib.check(lib.witw_match_spectrum(e.data_ptr(), spec.data_ptr(), e.shape[0], e.shape[3], role, _stream()), 'witw_match_spectrum')
     return spec
 
 
@@ -331,8 +334,8 @@ def match_fwd_dft(overhead_embed, surface_embed, spec_ov=None, spec_su=None, wan
     if su.shape[1] != ov.shape[1] or su.shape[2] != ov.shape[2]:
         raise _lib.WitwError('match_fwd_dft: surface embedding %s does not match overhead %s' % (tuple(su.shape), tuple(ov.shape)))
     Bo, Bs, We = ov.shape[0], su.shape[0], su.shape[3]
-    spec_ov = match_spectrum(ov) if spec_ov is None else spec_ov
-    spec_su = match_spectrum(su) if spec_su is None else spec_su
+    spec_ov = match_spectrum(ov, overhead=True) if spec_ov is None else spec_ov
+    spec_su = match_spectrum(su, overhead=False) if spec_su is None else spec_su
     for name, sp, n in (('spec_ov', spec_ov, Bo), ('spec_su', spec_su, Bs)):
         if not (sp.is_cuda and sp.dtype == torch.float32 and sp.is_contiguous() and tuple(sp.shape) == (n, 33, 128)):
             raise _lib.WitwError('match_fwd_dft: %s must be a contiguous float32 GPU tensor [%d,33,128]' % (name, n))
