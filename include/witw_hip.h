@@ -265,6 +265,18 @@ int witw_conv3x3_pack_weights_taps4(const float* w_kcrs, float* wpk, int cout, i
 int witw_conv3x3_fwd_taps4(const float* x, const float* wpk4, const float* bias, const float* gate, const float* post_scale,
                            const float* post_shift, float* y, int B, int H, int W, int Cin, int Cout, int relu,
                            float lrelu_slope, int tap_base, void* stream);
+/* The same convolution with two options for the deep, small-map layers of the encoder (model/cvig_baseline.py:240-252, conv5-7:
+ * 16x16 .. 4x4 maps with K = 4 taps x 2048 channels start far fewer workgroups than the chip has CUs):
+ *  ksplit > 1  split-K: y is a workspace of ksplit*B*H*W*Cout floats receiving the RAW partial sums of each K slice
+ *              ([ksplit][B,H,W,Cout]; no bias / activation / affine; gate must be NULL); witw_taps4_splitk_finish reduces them.
+ *              witw_conv3x3_taps4_ksplit returns the factor the library would pick (1 = the plain launch fills the chip).
+ *  s2d != 0    (ksplit == 1) y is written as the space-to-depth(2) image of the valid_h x valid_w region,
+ *              [B, ceil(valid_h/2), ceil(valid_w/2), 4*Cout], zeros outside it: the layout the next k=4,s=2 layer reads
+ *              (replaces a witw_space_to_depth2 pass over the activation). */
+int witw_conv3x3_taps4_ksplit(int B, int H, int W, int Cin, int Cout);
+int witw_conv3x3_fwd_taps4_ex(const float* x, const float* wpk4, const float* bias, const float* gate, const float* post_scale,
+                              const float* post_shift, float* y, int B, int H, int W, int Cin, int Cout, int relu,
+                              float lrelu_slope, int tap_base, int ksplit, int s2d, int valid_h, int valid_w, void* stream);
 int witw_conv3x3_wgrad_taps4(const float* x, const float* dz, float* dw, float* db, float* workspace, int B, int H, int W,
                              int Cin, int cin_real, int Cout, int accumulate, void* stream);
 
@@ -275,6 +287,14 @@ int witw_conv3x3_wgrad_taps4(const float* x, const float* dz, float* dw, float* 
  * train-mode BatchNorm applied on the fly (also accepted by witw_gem_pool). */
 int witw_space_to_depth2(const float* x, float* y, int B, int Hp, int Wp, int H, int W, int C, int Cpad, int in_nchw,
                          int normalize, const float* scale, const float* shift, void* stream);
+/* Mosaic space-to-depth: x NHWC [B,H,W,C] (C % 4 == 0) -> y [ceil(B/g^2), g*ceil(H/2), g*ceil(W/2), 4C]: image b is cell b % g^2
+ * (row-major) of mosaic image b / g^2. A k=4,s=2 layer over an n x n s2d map has (n-1)^2 valid outputs, so no valid window crosses
+ * a cell: conv6 / conv7 (8x8, 4x4 maps) run as g = 2 / 4 mosaics that fill the kernel's 16x16 tile. */
+int witw_space_to_depth2_mosaic(const float* x, float* y, int B, int H, int W, int C, int g, void* stream);
+/* Reduce the split-K partial sums ws [ksplit][ceil(B/g^2), g*h, g*w, C] in slice order and apply bias, activation (0 none, 1 ReLU,
+ * 2 LeakyReLU) and the optional per-channel affine: y [B,vh,vw,C] = the valid outputs of every image. */
+int witw_taps4_splitk_finish(const float* ws, int ksplit, const float* bias, int act, float lrelu_slope, const float* post_scale,
+                             const float* post_shift, float* y, int B, int g, int h, int w, int vh, int vw, int C, void* stream);
 /* f[b,col0+c] = (mean relu(x)^p)^(1/p) over the valid HxW region (:276-282); f has row length ldf. */
 int witw_gem_pool(const float* x, float* f, int B, int Hp, int Wp, int H, int W, int C, int ldf, int col0, float p,
                   const float* scale, const float* shift, void* stream);

@@ -192,3 +192,86 @@ def test_taps4_kernels_equal_the_zero_filled_3x3_form(case):
     w4, b4 = ops.conv3x3_wgrad(x, dz, Cin, taps4=True)
     assert torch.equal(w9[:, :, 1:, 1:], w4[:, :, 1:, 1:]) and torch.equal(b9, b4)
     assert float(w4[:, :, 0, :].abs().max()) == 0.0 and float(w4[:, :, :, 0].abs().max()) == 0.0
+
+
+def _taps4_case(B, H, W, Cin, Cout, seed=5):
+    import torch
+    from witw_amd import ops
+    g = np.random.Generator(np.random.Philox(key=[seed, Cin + Cout + H]))
+    dev = torch.device('cuda:0')
+    x = torch.from_numpy(g.standard_normal((B, H, W, Cin), dtype=np.float32)).to(dev)
+    k3 = torch.from_numpy(g.standard_normal((Cout, Cin, 3, 3), dtype=np.float32) * 0.05)
+    k3[:, :, 0, :] = 0
+    k3[:, :, :, 0] = 0
+    b = torch.from_numpy(g.standard_normal((Cout,), dtype=np.float32) * 0.1).to(dev)
+    sc = torch.from_numpy(1 + 0.1 * g.standard_normal((Cout,), dtype=np.float32)).to(dev)
+    sh = torch.from_numpy(0.1 * g.standard_normal((Cout,), dtype=np.float32)).to(dev)
+    return x, ops.PackedConv(k3.to(dev), b, taps4=True), sc, sh
+
+
+@pytest.mark.parametrize('case', [(2, 20, 70, 24, 128, (19, 69)), (1, 64, 64, 16, 64, (63, 63)), (3, 16, 16, 64, 192, (15, 15)),
+                                  (2, 9, 30, 64, 64, (8, 29)), (4, 256, 256, 16, 64, (255, 255)), (2, 32, 32, 8, 128, (30, 31))])
+def test_taps4_s2d_epilogue_equals_conv_then_space_to_depth(case):
+    """conv_taps4_s2d (the next block's space-to-depth input written by the conv epilogue) is BIT-identical to the conv followed
+    by the separate witw_space_to_depth2 pass, zeros outside the valid region included (wide 4- and 8-wave and narrow tiles)."""
+    import torch
+    from witw_amd import ops
+    B, H, W, Cin, Cout, valid = case
+    x, packed, sc, sh = _taps4_case(B, H, W, Cin, Cout)
+    y = ops.conv3x3_fwd(x, packed, relu=False, lrelu_slope=0.2, post_scale=sc, post_shift=sh)
+    want = ops.space_to_depth2(y, valid_hw=valid, cpad=4 * Cout)
+    got = ops.conv_taps4_s2d(x, packed, valid, lrelu_slope=0.2, post_scale=sc, post_shift=sh)
+    assert got.shape == want.shape and torch.equal(got, want)
+
+
+@pytest.mark.parametrize('case', [(5, 1, 16, 256, 128, None), (5, 2, 8, 256, 128, 3), (7, 4, 4, 512, 64, 5), (32, 4, 4, 2048, 512, None),
+                                  (3, 1, 12, 64, 64, 8), (16, 2, 8, 2048, 512, 32)])
+def test_taps4_splitk_mosaic_equals_plain_conv(case):
+    """Split-K over a g x g mosaic (what blocks 5-7 of the eval encoder run) against the plain taps4 conv per image: the K slices
+    are summed in a different order, so equality is to fp32 rounding of the K = 4*Cin sum; B not a multiple of g^2, uneven K
+    slices and the library's own ksplit choice are covered; the mosaic space-to-depth with g = 1 is the plain one bit for bit."""
+    import torch
+    from witw_amd import ops, _lib
+    B, g, h, Cin, Cout, ksplit = case
+    x, packed, sc, sh = _taps4_case(B, h, h, Cin, Cout, seed=9)
+    y = ops.conv3x3_fwd(x, packed, relu=False, lrelu_slope=0.2, post_scale=sc, post_shift=sh)[:, :h - 1, :h - 1].contiguous()
+    # build the mosaic of the INPUT maps by hand: image b -> cell (b % g^2) of mosaic b // g^2
+    Bm = (B + g * g - 1) // (g * g)
+    xm = torch.zeros((Bm, g * h, g * h, Cin), device=x.device)
+    for b in range(B):
+        bm, cell = divmod(b, g * g)
+        cy, cx = divmod(cell, g)
+        xm[bm, cy * h:(cy + 1) * h, cx * h:(cx + 1) * h] = x[b]
+    got = ops.conv_taps4_splitk(xm, packed, B, g, (h - 1, h - 1), lrelu_slope=0.2, post_scale=sc, post_shift=sh, ksplit=ksplit)
+    assert got.shape == y.shape
+    scale = float(y.abs().max())
+    assert float((got - y).abs().max()) <= 4e-6 * scale * max(1.0, (4 * Cin) ** 0.5 / 16)
+    if ksplit is None:
+        assert _lib.load().witw_conv3x3_taps4_ksplit(Bm, g * h, g * h, Cin, Cout) >= 1
+    # mosaic space-to-depth: cell b of the output is the plain space-to-depth image of y[b]
+    plain = ops.space_to_depth2(y, cpad=4 * Cout)
+    assert torch.equal(ops.space_to_depth2_mosaic(y, 1), plain)
+    mos = ops.space_to_depth2_mosaic(y, g)
+    h2 = plain.shape[1]
+    assert mos.shape == (Bm, g * h2, g * h2, 4 * Cout)
+    for b in range(B):
+        bm, cell = divmod(b, g * g)
+        cy, cx = divmod(cell, g)
+        assert torch.equal(mos[bm, cy * h2:(cy + 1) * h2, cx * h2:(cx + 1) * h2], plain[b])
+    for cell in range(B % (g * g) or g * g, g * g):       # cells without an image are zero
+        cy, cx = divmod(cell, g)
+        assert float(mos[Bm - 1, cy * h2:(cy + 1) * h2, cx * h2:(cx + 1) * h2].abs().max()) == 0.0
+
+
+def test_taps4_ex_rejects_bad_arguments():
+    import torch
+    from witw_amd import ops, _lib
+    x, packed, sc, sh = _taps4_case(2, 16, 16, 64, 64)
+    with pytest.raises(_lib.WitwError):
+        ops.conv_taps4_s2d(x, packed, (17, 15))                    # valid region outside the map
+    with pytest.raises(_lib.WitwError):
+        ops.conv_taps4_s2d(x, packed, (15, 16 + 1))
+    with pytest.raises(_lib.WitwError):
+        ops.conv_taps4_splitk(x, packed, 2, 1, (15, 15), ksplit=9)  # more slices than K-chunks (64 / 8 = 8)
+    with pytest.raises(_lib.WitwError):
+        ops.conv_taps4_splitk(x, packed, 9, 2, (7, 7))             # 9 images do not fit 2 mosaics of 2x2

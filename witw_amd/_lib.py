@@ -28,6 +28,8 @@ SIGNATURES = {
     'witw_conv3x3_packed_floats_taps4': (c_longlong, [c_int, c_int]),
     'witw_conv3x3_pack_weights_taps4': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'witw_conv3x3_fwd_taps4': (c_int, [c_void_p] * 7 + [c_int] * 6 + [c_float, c_int, c_void_p]),
+    'witw_conv3x3_taps4_ksplit': (c_int, [c_int] * 5),
+    'witw_conv3x3_fwd_taps4_ex': (c_int, [c_void_p] * 7 + [c_int] * 6 + [c_float] + [c_int] * 5 + [c_void_p]),
     'witw_conv3x3_wgrad_taps4': (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_void_p]),
     'witw_nchw_to_nhwc': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'witw_conv3x3_wgrad_splits': (c_int, [c_int] * 5),
@@ -61,6 +63,8 @@ SIGNATURES = {
     'witw_conv3x3_wgrad_f16x3_workspace_floats': (c_longlong, [c_int] * 6),
     'witw_conv3x3_wgrad_f16x3': (c_int, [c_void_p] * 6 + [c_int] * 9 + [c_void_p]),
     'witw_space_to_depth2': (c_int, [c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p, c_void_p]),
+    'witw_space_to_depth2_mosaic': (c_int, [c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]),
+    'witw_taps4_splitk_finish': (c_int, [c_void_p, c_int, c_void_p, c_int, c_float] + [c_void_p] * 3 + [c_int] * 7 + [c_void_p]),
     'witw_gem_pool': (c_int, [c_void_p, c_void_p] + [c_int] * 8 + [c_float, c_void_p, c_void_p, c_void_p]),
     'witw_bn_workspace_floats': (c_longlong, [c_int] * 4),
     'witw_bn_train_stats': (c_int, [c_void_p] + [c_int] * 6 + [c_void_p, c_void_p, c_float, c_float] + [c_void_p] * 8),

@@ -42,6 +42,69 @@ __global__ void space_to_depth2_kernel(const float* __restrict__ x, float* __res
     y[idx] = v;
 }
 
+// Mosaic space-to-depth: x NHWC [B,H,W,C] (all valid) -> y [ceil(B/g^2), g*H2, g*W2, 4C], H2 = ceil(H/2): image b sits in cell
+// (b % g^2) of mosaic image b / g^2, cells row-major, each the space-to-depth(2) image of x[b]; zeros where no source exists.
+// A k=4,s=2 layer over an H2 x W2 s2d map has (H2-1) x (W2-1) valid outputs, so no valid output's 2x2 window crosses a cell:
+// the deep cvig_baseline layers (8x8 and 4x4 maps) run as g = 2 / g = 4 mosaics that fill the conv kernel's 16x16 tile.
+__global__ void s2d_mosaic_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, int C, int g, size_t total4) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total4) return;
+    const int H2 = (H + 1) >> 1, W2 = (W + 1) >> 1;
+    const int C4 = C >> 2;
+    const int c4 = idx % C4;
+    size_t t = idx / C4;
+    const int q = t & 3;
+    t >>= 2;
+    const int X = t % (g * W2);
+    t /= (g * W2);
+    const int Y = t % (g * H2);
+    const int bm = (int)(t / (g * H2));
+    const int cy = Y / H2, y2 = Y - cy * H2, cx = X / W2, x2 = X - cx * W2;
+    const int b = (bm * g + cy) * g + cx;
+    const int h = 2 * y2 + (q >> 1), w = 2 * x2 + (q & 1);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (b < B && h < H && w < W) v = *reinterpret_cast<const f32x4*>(x + (((size_t)b * H + h) * W + w) * C + 4 * c4);
+    reinterpret_cast<f32x4*>(y)[idx] = v;
+}
+
+// Epilogue of a split-K taps4 convolution run over a g x g mosaic: ws [S][Bm, g*h, g*w, C] raw partial sums ->
+// y [B, vh, vw, C] (valid outputs of every image, compact), y = affine(lrelu(sum_s ws[s] + bias)); the S partials are added in
+// slice order (deterministic).
+__global__ void splitk_finish_kernel(const float* __restrict__ ws, int S, size_t stride, const float* __restrict__ bias, int act,
+                                     float slope, const float* __restrict__ post_scale, const float* __restrict__ post_shift,
+                                     float* __restrict__ y, int B, int g, int h, int w, int vh, int vw, int C, size_t total4) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total4) return;
+    const int C4 = C >> 2;
+    const int c4 = idx % C4;
+    size_t t = idx / C4;
+    const int xx = t % vw;
+    t /= vw;
+    const int yy = t % vh;
+    const int b = (int)(t / vh);
+    const int bm = b / (g * g), cell = b - bm * g * g, cy = cell / g, cx = cell - cy * g;
+    const size_t o = ((((size_t)bm * g * h + cy * h + yy) * (g * w)) + cx * w + xx) * C + 4 * c4;
+    f32x4 a = *reinterpret_cast<const f32x4*>(ws + o);
+    for (int s = 1; s < S; ++s) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(ws + (size_t)s * stride + o);
+        a += v;
+    }
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 4 * c4);
+    f32x4 ps = {1.f, 1.f, 1.f, 1.f}, pt = {0.f, 0.f, 0.f, 0.f};
+    if (post_scale != nullptr) {
+        ps = *reinterpret_cast<const f32x4*>(post_scale + 4 * c4);
+        pt = *reinterpret_cast<const f32x4*>(post_shift + 4 * c4);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float v = a[e] + bv[e];
+        if (act == 1) v = fmaxf(v, 0.f);
+        else if (act == 2) v = v > 0.f ? v : v * slope;
+        a[e] = v * ps[e] + pt[e];
+    }
+    reinterpret_cast<f32x4*>(y)[idx] = a;
+}
+
 // f[b, col0 + c] = (mean_{h<H,w<W} relu(x[b,h,w,c])^p)^(1/p); x NHWC [B,Hp,Wp,C]; one thread per (b,c).
 __global__ void gem_pool_kernel(const float* __restrict__ x, float* __restrict__ f, int B, int Hp, int Wp, int H, int W, int C,
                                 int ldf, int col0, float p, const float* __restrict__ scale, const float* __restrict__ shift) {
@@ -407,6 +470,36 @@ int witw_space_to_depth2(const float* x, float* y, int B, int Hp, int Wp, int H,
     hipLaunchKernelGGL(space_to_depth2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, B,
                        Hp, Wp, H, W, C, Cpad, in_nchw, normalize, total, scale, shift);
     WITW_CHECK_LAUNCH("space_to_depth2");
+    return WITW_OK;
+}
+
+int witw_space_to_depth2_mosaic(const float* x, float* y, int B, int H, int W, int C, int g, void* stream) {
+    WITW_CHECK_ARG(x && y, "space_to_depth2_mosaic: null pointer");
+    WITW_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0 && g >= 1 && g <= 64, "space_to_depth2_mosaic: bad shape");
+    const size_t total4 = (size_t)cdiv(B, g * g) * (g * ((H + 1) / 2)) * (g * ((W + 1) / 2)) * C;     // 4C / 4
+    WITW_CHECK_ARG((total4 + 255) / 256 <= 0x7fffffffULL, "space_to_depth2_mosaic: tensor too large");
+    hipLaunchKernelGGL(s2d_mosaic_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, B, H, W,
+                       C, g, total4);
+    WITW_CHECK_LAUNCH("space_to_depth2_mosaic");
+    return WITW_OK;
+}
+
+// ws: the [ksplit][Bm, g*h, g*w, C] partial sums witw_conv3x3_fwd_taps4_ex(ksplit > 1) wrote for B images laid out as g x g
+// mosaics of h x w maps (g = 1: plain batch); y [B, vh, vw, C] = the (vh, vw) valid outputs of every image after bias, activation
+// (0 none, 1 ReLU, 2 LeakyReLU) and the optional per-channel affine.
+int witw_taps4_splitk_finish(const float* ws, int ksplit, const float* bias, int act, float lrelu_slope, const float* post_scale,
+                             const float* post_shift, float* y, int B, int g, int h, int w, int vh, int vw, int C, void* stream) {
+    WITW_CHECK_ARG(ws && bias && y, "taps4_splitk_finish: null pointer");
+    WITW_CHECK_ARG(B > 0 && g >= 1 && h > 0 && w > 0 && vh > 0 && vw > 0 && vh <= h && vw <= w && C > 0 && (C & 3) == 0 && ksplit >= 1,
+                   "taps4_splitk_finish: bad shape B=%d g=%d map %dx%d valid %dx%d C=%d ksplit=%d", B, g, h, w, vh, vw, C, ksplit);
+    WITW_CHECK_ARG(act >= 0 && act <= 2, "taps4_splitk_finish: activation %d unknown", act);
+    WITW_CHECK_ARG((post_scale == nullptr) == (post_shift == nullptr), "taps4_splitk_finish: post_scale and post_shift go together");
+    const size_t stride = (size_t)cdiv(B, g * g) * (g * h) * (g * w) * C;
+    const size_t total4 = (size_t)B * vh * vw * (C / 4);
+    WITW_CHECK_ARG((total4 + 255) / 256 <= 0x7fffffffULL, "taps4_splitk_finish: tensor too large");
+    hipLaunchKernelGGL(splitk_finish_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ws, ksplit,
+                       stride, bias, act, lrelu_slope, post_scale, post_shift, y, B, g, h, w, vh, vw, C, total4);
+    WITW_CHECK_LAUNCH("taps4_splitk_finish");
     return WITW_OK;
 }
 

@@ -18,6 +18,7 @@
 // lanes 0-31 and channel j of quad 1 from lanes 32-63 (A and B agree on that order).
 #include "common.h"
 #include <stdlib.h>
+#include <algorithm>
 
 namespace {
 
@@ -47,6 +48,15 @@ struct ConvArgs {
     int force_geo;          // -1 = choose, 0 / 1 = force the wide / narrow tile geometry
     int dil_h;              // 1: input rows are zero-interleaved (row 2i = physical row i): dgrad of a stride-(2,1) conv
     int tap_base;           // TAPS == 4 only: the 2x2 taps are (tap_base + {0,1}, tap_base + {0,1}) of the 3x3 window
+    // TAPS == 4 only, split-K: ksplit > 1 launches grid.y = ksplit workgroups per tile, each reducing K-chunks
+    // [blockIdx.y * kc_per_split, ...) and writing its RAW partial sums (no bias / activation / affine) to
+    // y + blockIdx.y * split_stride; splitk_finish_kernel adds the partials in fixed order and applies the epilogue.
+    int ksplit, kc_per_split;
+    size_t split_stride;
+    // TAPS == 4 only: s2d != 0 writes the output as the space-to-depth(2) image the next k=4,s=2 layer reads,
+    // [B, s2d_h, s2d_w, 4*Cout] with channel ((y&1)*2 + (x&1))*Cout + c; outputs at y >= valid_h or x >= valid_w are
+    // written as 0 (the conv grid is padded to the tile; the next layer's window must read zeros there).
+    int s2d, s2d_h, s2d_w, valid_h, valid_w;
 #ifdef WITW_STAMPS
     unsigned long long* stamps;   // diagnostic build only (tools/conv_stamps.cpp)
 #endif
@@ -113,7 +123,14 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_f32_kernel(ConvArgs p) {
     const int oy0 = ty * TH;
     const int ox0 = tx * TW;
     const int n0 = ntile * TN;
-    const int nkc = p.Cin >> 3;
+    int nkc = p.Cin >> 3;      // K-chunks (8 input channels each) this workgroup reduces
+    int kc_lo = 0;             // ... starting at this one: split-K slices move the buffer bases, the loop stays 0 .. nkc
+    if constexpr (TAPS == 4) {
+        if (p.ksplit > 1) {
+            kc_lo = (int)blockIdx.y * p.kc_per_split;
+            nkc = min(nkc - kc_lo, p.kc_per_split);
+        }
+    }
 
     // ---- staging through buffer loads: one descriptor per image / per weight tile built from scalars, the
     // per-thread byte offset is fixed for the whole K loop and the K-chunk advance rides in the scalar
@@ -122,11 +139,11 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_f32_kernel(ConvArgs p) {
     constexpr unsigned OOR = 0x80000000u;
     const int Hp = p.dil_h ? (p.H - 1) / 2 + 1 : p.H;          // physical rows of the input
     const size_t img_floats = (size_t)Hp * p.W * p.Cin;
-    __amdgpu_buffer_rsrc_t in_rs =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)b * img_floats), 0, (unsigned)(img_floats * 4), 0x00020000);
+    __amdgpu_buffer_rsrc_t in_rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.x + (size_t)b * img_floats + (size_t)kc_lo * 8), 0, (unsigned)(img_floats * 4) - (unsigned)kc_lo * 32u, 0x00020000);
     const unsigned wtile_bytes = (unsigned)nkc * W_F4 * 16u;
     __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(reinterpret_cast<const f32x4*>(p.wpk) + (size_t)ntile * nkc * W_F4), 0, wtile_bytes, 0x00020000);
+        (void*)(reinterpret_cast<const f32x4*>(p.wpk) + ((size_t)ntile * (p.Cin >> 3) + kc_lo) * W_F4), 0, wtile_bytes, 0x00020000);
     unsigned gin[NIN];
 #pragma unroll
     for (int i = 0; i < NIN; ++i) {
@@ -362,15 +379,22 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_f32_kernel(ConvArgs p) {
     // ---- epilogue: bias, dropout scale, ReLU, optional 2x2 max pool, store
     float bv[WN], dm[WN], ps[WN], pt[WN];
     int nch[WN];
+    int act = p.relu;
+    bool has_post = p.post_scale != nullptr;
+    bool raw = false;          // split-K: the partial sums leave untouched (+0, *1, no activation), splitk_finish_kernel finishes
+    if constexpr (TAPS == 4) {
+        raw = p.ksplit > 1;
+        if (raw) { act = 0; has_post = false; }
+    }
 #pragma unroll
     for (int nt = 0; nt < WN; ++nt) {
         nch[nt] = n0 + wn * 64 + nt * 32 + l31;
-        bv[nt] = p.bias[nch[nt]];
+        bv[nt] = raw ? 0.f : p.bias[nch[nt]];
         dm[nt] = 1.f;
         if (p.dropmask != nullptr && nch[nt] < p.Cout) dm[nt] = p.dropmask[(size_t)b * p.Cout + nch[nt]];
         ps[nt] = 1.f;
         pt[nt] = 0.f;
-        if (p.post_scale != nullptr && nch[nt] < p.Cout) {
+        if (has_post && nch[nt] < p.Cout) {
             ps[nt] = p.post_scale[nch[nt]];
             pt[nt] = p.post_shift[nch[nt]];
         }
@@ -378,9 +402,9 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_f32_kernel(ConvArgs p) {
     // conv + bias -> Dropout2d scale -> activation -> per-channel affine
     auto fin = [&](float v, int nt) {
         v = (v + bv[nt]) * dm[nt];
-        if (p.relu == 1) v = fmaxf(v, 0.f);
-        else if (p.relu == 2) v = v > 0.f ? v : v * p.lrelu;
-        if (p.post_scale != nullptr) v = v * ps[nt] + pt[nt];
+        if (act == 1) v = fmaxf(v, 0.f);
+        else if (act == 2) v = v > 0.f ? v : v * p.lrelu;
+        if (has_post) v = v * ps[nt] + pt[nt];
         return v;
     };
     const int Hy = POOL ? (p.Ho >> 1) : p.Ho;
@@ -422,9 +446,19 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_f32_kernel(ConvArgs p) {
                 const f32x4 v = *reinterpret_cast<const f32x4*>(slab + m * 64 + pc4);
                 const int yy = oy0 + trow[mt] + m_row(m);
                 const int xx = ox0 + tcol[mt] + m_col(m);
-                if (yy < Hy && xx < Wy && nbase < p.Cout) {
-                    const size_t o = (((size_t)b * Hy + yy) * Wy + xx) * p.Cout + nbase;
-                    f32x4 w = v;
+                bool ok = yy < Hy && xx < Wy && nbase < p.Cout;
+                size_t o = (((size_t)b * Hy + yy) * Wy + xx) * p.Cout + nbase;
+                f32x4 w = v;
+                if constexpr (TAPS == 4) {
+                    if (p.ksplit > 1) {
+                        o += (size_t)blockIdx.y * p.split_stride;
+                    } else if (p.s2d) {
+                        ok = yy < 2 * p.s2d_h && xx < 2 * p.s2d_w && nbase < p.Cout;
+                        o = ((((size_t)b * p.s2d_h + (yy >> 1)) * p.s2d_w + (xx >> 1)) * 4 + (yy & 1) * 2 + (xx & 1)) * p.Cout + nbase;
+                        if (!(yy < p.valid_h && xx < p.valid_w)) w = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                }
+                if (ok) {
                     if (p.gate != nullptr) {
                         const f32x4 gt = *reinterpret_cast<const f32x4*>(p.gate + o);
 #pragma unroll
@@ -613,7 +647,8 @@ int launch_conv_nw(ConvArgs a, hipStream_t st) {
         return WITW_ERR_INVALID;
     }
     a.sp_total = (int)sp_total;
-    hipLaunchKernelGGL((conv3x3_nhwc_f32_kernel<TN, SH, POOL, NW, GEO, TAPS>), dim3((unsigned)grid), dim3(64 * NW), 0, st, a);
+    const unsigned gy = (TAPS == 4 && a.ksplit > 1) ? (unsigned)a.ksplit : 1u;
+    hipLaunchKernelGGL((conv3x3_nhwc_f32_kernel<TN, SH, POOL, NW, GEO, TAPS>), dim3((unsigned)grid, gy), dim3(64 * NW), 0, st, a);
     WITW_CHECK_LAUNCH("conv3x3_nhwc_f32");
     return WITW_OK;
 }
@@ -720,17 +755,57 @@ int witw_conv3x3_pack_weights_taps4(const float* w_kcrs, float* wpk, int cout, i
     return WITW_OK;
 }
 
+// workgroups the taps4 launcher would start for this shape (ksplit = 1)
+static long long taps4_workgroups(int B, int H, int W, int Cout) {
+    const int TN = witw_conv3x3_tile_n(Cout);
+    const long long nt = cdiv(Cout, TN);
+    if (choose_narrow(W, env_int("WITW_CONV_GEO", -1))) return nt * B * cdiv(H, 16) * cdiv(W, 16);
+    const int nw = choose_waves(B, H, W, Cout, env_int("WITW_CONV_NW", 0));
+    return nt * B * cdiv(H, nw) * cdiv(W, 64);
+}
+
+// Split-K factor the taps4 conv should run with: 1 when the plain launch already fills the chip (>= 2 workgroups per CU) or K
+// is short; otherwise enough K slices for ~4 workgroups per CU, each at least 32 K-chunks (256 input channels) long. The deep
+// cvig_baseline layers (16x16 .. 4x4 maps, K = 4 taps x 2048) start 8 .. 128 workgroups on 256 CUs without it.
+int witw_conv3x3_taps4_ksplit(int B, int H, int W, int Cin, int Cout) {
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return -1;
+    const int forced = env_int("WITW_CONV_KSPLIT", 0);
+    const int nkc = Cin >> 3;
+    const long long wg = taps4_workgroups(B, H, W, Cout);
+    int S = 1;
+    if (forced > 0) S = forced;
+    else if (wg < 512 && nkc >= 64) {
+        S = (int)std::min<long long>(32, (1024 + wg - 1) / wg);
+        S = std::min(S, nkc / 32);
+    }
+    S = std::max(1, std::min(S, nkc));
+    const int per = cdiv(nkc, S);
+    return cdiv(nkc, per);            // no empty slice
+}
+
 // y = act(conv over the 2x2 taps (tap_base + {0,1})^2 of the 3x3 window, zero padding 1) [* post_scale + post_shift],
 // gate as in witw_conv3x3_fwd_ex. tap_base = 1 with a forward-packed filter, 0 with a transpose_flip-packed one.
-int witw_conv3x3_fwd_taps4(const float* x, const float* wpk4, const float* bias, const float* gate, const float* post_scale,
-                           const float* post_shift, float* y, int B, int H, int W, int Cin, int Cout, int relu,
-                           float lrelu_slope, int tap_base, void* stream) {
+//   ksplit > 1: split-K. y is a workspace of ksplit * B*H*W*Cout floats that receives the RAW partial sums of each K slice
+//     ([ksplit][B,H,W,Cout]); bias / activation / affine are NOT applied (witw_taps4_splitk_finish does that), gate must be null.
+//   s2d != 0 (ksplit == 1): y is the space-to-depth(2) image of the valid region, [B, ceil(valid_h/2), ceil(valid_w/2), 4*Cout]
+//     with channel ((row&1)*2 + (col&1))*Cout + c and zeros outside the valid region: what the next k=4,s=2 layer reads.
+int witw_conv3x3_fwd_taps4_ex(const float* x, const float* wpk4, const float* bias, const float* gate, const float* post_scale,
+                              const float* post_shift, float* y, int B, int H, int W, int Cin, int Cout, int relu,
+                              float lrelu_slope, int tap_base, int ksplit, int s2d, int valid_h, int valid_w, void* stream) {
     WITW_CHECK_ARG(x && wpk4 && bias && y, "conv3x3_fwd_taps4: null pointer");
     WITW_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cout > 0, "conv3x3_fwd_taps4: bad shape B=%d H=%d W=%d Cout=%d", B, H, W, Cout);
     WITW_CHECK_ARG(Cin > 0 && (Cin % 8) == 0, "conv3x3_fwd_taps4: Cin=%d must be a positive multiple of 8", Cin);
     WITW_CHECK_ARG(relu >= 0 && relu <= 2, "conv3x3_fwd_taps4: activation %d unknown (0 none, 1 ReLU, 2 LeakyReLU)", relu);
     WITW_CHECK_ARG(tap_base == 0 || tap_base == 1, "conv3x3_fwd_taps4: tap_base=%d outside {0,1}", tap_base);
     WITW_CHECK_ARG((post_scale == nullptr) == (post_shift == nullptr), "conv3x3_fwd_taps4: post_scale and post_shift go together");
+    WITW_CHECK_ARG(ksplit >= 1 && ksplit <= 65535 && ksplit <= (Cin >> 3), "conv3x3_fwd_taps4: ksplit=%d outside [1, Cin/8]", ksplit);
+    WITW_CHECK_ARG(!(ksplit > 1 && (gate || s2d)), "conv3x3_fwd_taps4: split-K writes raw partial sums (no gate, no s2d output)");
+    WITW_CHECK_ARG(!((ksplit > 1 || s2d) && (Cout & 3)), "conv3x3_fwd_taps4: split-K / s2d output need Cout %% 4 == 0, got %d", Cout);
+    WITW_CHECK_ARG(!(s2d && gate), "conv3x3_fwd_taps4: s2d output with gate unsupported");
+    WITW_CHECK_ARG(!s2d || (valid_h > 0 && valid_w > 0 && valid_h <= H && valid_w <= W),
+                   "conv3x3_fwd_taps4: valid region %dx%d outside the %dx%d map", valid_h, valid_w, H, W);
+    WITW_CHECK_ARG(!s2d || (2 * ((valid_h + 1) / 2) <= H && 2 * ((valid_w + 1) / 2) <= W),
+                   "conv3x3_fwd_taps4: s2d output of an odd valid size needs one more computed row / column");
     ConvArgs a;
     a.x = x; a.wpk = wpk4; a.bias = bias; a.dropmask = nullptr; a.gate = gate; a.y = y;
     a.post_scale = post_scale; a.post_shift = post_shift; a.lrelu = lrelu_slope;
@@ -742,11 +817,25 @@ int witw_conv3x3_fwd_taps4(const float* x, const float* wpk4, const float* bias,
     a.force_geo = env_int("WITW_CONV_GEO", -1);
     a.xcd_map = env_int("WITW_CONV_XCD", 1) != 0;
     a.circ = 0; a.relu = relu; a.out_nchw = 0; a.dil_h = 0; a.tap_base = tap_base;
+    a.ksplit = ksplit;
+    a.kc_per_split = cdiv(Cin >> 3, ksplit);
+    WITW_CHECK_ARG((long long)(ksplit - 1) * a.kc_per_split < (Cin >> 3), "conv3x3_fwd_taps4: ksplit=%d leaves an empty K slice", ksplit);
+    a.split_stride = (size_t)B * H * W * Cout;
+    a.s2d = s2d ? 1 : 0;
+    a.valid_h = valid_h; a.valid_w = valid_w;
+    a.s2d_h = (valid_h + 1) / 2; a.s2d_w = (valid_w + 1) / 2;
 #ifdef WITW_STAMPS
     a.stamps = witw_conv_stamps_ptr;
 #endif
     hipStream_t st = (hipStream_t)stream;
     return witw_conv3x3_tile_n(Cout) == 128 ? launch_conv_taps4<128>(a, st) : launch_conv_taps4<64>(a, st);
+}
+
+int witw_conv3x3_fwd_taps4(const float* x, const float* wpk4, const float* bias, const float* gate, const float* post_scale,
+                           const float* post_shift, float* y, int B, int H, int W, int Cin, int Cout, int relu,
+                           float lrelu_slope, int tap_base, void* stream) {
+    return witw_conv3x3_fwd_taps4_ex(x, wpk4, bias, gate, post_scale, post_shift, y, B, H, W, Cin, Cout, relu, lrelu_slope,
+                                     tap_base, 1, 0, 0, 0, stream);
 }
 
 int witw_nchw_to_nhwc8(const float* x, float* y, int B, int C, int H, int W, void* stream) {
@@ -797,6 +886,7 @@ int witw_conv3x3_fwd_ex(const float* x, const float* wpk, const float* bias, con
     a.force_geo = env_int("WITW_CONV_GEO", -1);
     a.xcd_map = env_int("WITW_CONV_XCD", 1) != 0;      // 0: plain n-tile-major order (A/B timing)
     a.circ = pad_circular; a.relu = relu; a.out_nchw = out_nchw; a.dil_h = dilate_h; a.tap_base = 0;
+    a.ksplit = 1; a.kc_per_split = 0; a.split_stride = 0; a.s2d = 0; a.s2d_h = a.s2d_w = a.valid_h = a.valid_w = 0;
 #ifdef WITW_STAMPS
     a.stamps = witw_conv_stamps_ptr;
 #endif

@@ -220,14 +220,22 @@ class SurfaceEncoder(nn.Module):
             h = ops.space_to_depth2(x.contiguous(), in_nchw=True, normalize=True, cpad=self._layer(1)[3])   # :265-266
             f = torch.empty((B, 1536), dtype=torch.float32, device=x.device)
             vh, vw = H, W
+            g = 1                  # images per mosaic side of the current layer input h
             for i in range(1, 8):
                 packed, scale, shift, _cp = self._layer(i)
                 vh, vw = (vh - 4) // 2 + 1, (vw - 4) // 2 + 1
-                y = ops.conv3x3_fwd(h, packed, relu=False, lrelu_slope=0.2, post_scale=scale, post_shift=shift)
+                if i < 5 and 4 * packed.cout == self._layer(i + 1)[3]:
+                    # blocks 1-4: the epilogue writes the next block's space-to-depth input directly
+                    h = ops.conv_taps4_s2d(h, packed, (vh, vw), lrelu_slope=0.2, post_scale=scale, post_shift=shift)
+                    continue
+                # blocks 5-7 (maps of 16x16 and below, K = 4 x 2048): split-K over a mosaic that fills the 16x16 tile
+                y = ops.conv_taps4_splitk(h, packed, B, g, (vh, vw), lrelu_slope=0.2, post_scale=scale, post_shift=shift)
                 if i >= 5:
                     ops.gem_pool(y, (vh, vw), f, 512 * (i - 5), self.p)                                      # :276-282
                 if i < 7:
-                    h = ops.space_to_depth2(y, valid_hw=(vh, vw), cpad=self._layer(i + 1)[3])
+                    nh, nw = (vh + 1) // 2, (vw + 1) // 2
+                    g = max(1, min(16 // nh, 16 // nw))
+                    h = ops.space_to_depth2_mosaic(y, g)
             return ops.embed_normalize_(f)                                                                 # :283-284
 
 

@@ -206,6 +206,92 @@ def conv3x3_fwd(x_nhwc, packed, stride_h=1, circular=False, relu=True, pool=Fals
     return y
 
 
+def _taps4_args(x_nhwc, packed, lrelu_slope, post_scale, post_shift):
+    x = _dev_f32(x_nhwc, 'x')
+    if not getattr(packed, 'taps4', False):
+        raise _lib.WitwError('a taps4-packed filter is required')
+    if x.shape[3] != packed.cin_pad:
+        raise _lib.WitwError('conv taps4: input has %d channels, packed weights expect %d' % (x.shape[3], packed.cin_pad))
+    if post_scale is not None:
+        post_scale, post_shift = _dev_f32(post_scale, 'post_scale'), _dev_f32(post_shift, 'post_shift')
+        if post_scale.numel() != packed.cout or post_shift.numel() != packed.cout:
+            raise _lib.WitwError('post_scale/post_shift must have Cout entries')
+    act = 2 if lrelu_slope is not None else 0
+    return x, act, post_scale, post_shift
+
+
+def conv_taps4_s2d(x_nhwc, packed, valid_hw, lrelu_slope=None, post_scale=None, post_shift=None):
+    """2x2-tap convolution whose epilogue writes the space-to-depth(2) image of its (vh, vw) valid outputs, zeros elsewhere:
+    x [B,H,W,Cin_pad] -> [B, ceil(vh/2), ceil(vw/2), 4*Cout], the input layout of the next Conv2d(k=4, s=2) block
+    (model/cvig_baseline.py:236-252) without a separate pass over the activation."""
+    lib = _lib.load()
+    x, act, post_scale, post_shift = _taps4_args(x_nhwc, packed, lrelu_slope, post_scale, post_shift)
+    B, H, W, C = x.shape
+    vh, vw = valid_hw
+    y = torch.empty((B, (vh + 1) // 2, (vw + 1) // 2, 4 * packed.cout), dtype=torch.float32, device=x.device)
+    prof = PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.check(lib.witw_conv3x3_fwd_taps4_ex(x.data_ptr(), packed.wpk.data_ptr(), packed.bias.data_ptr(), None, _p(post_scale),
+                                             _p(post_shift), y.data_ptr(), B, H, W, C, packed.cout, act, float(lrelu_slope or 0.),
+                                             packed.tap_base, 1, 1, vh, vw, _stream()), 'witw_conv3x3_fwd_taps4_ex')
+    if prof is not None:
+        e1.record()
+        prof.append(((lib.witw_conv3x3_tile_n(packed.cout), 1, False, lib.witw_conv3x3_workgroup_waves(B, H, W, packed.cout, 1)),
+                     2.0 * packed.cin * packed.cout * 4 * vh * vw * B, e0, e1))
+    return y
+
+
+def conv_taps4_splitk(x_mosaic, packed, n_images, g, valid_hw, lrelu_slope=None, post_scale=None, post_shift=None, ksplit=None):
+    """Split-K 2x2-tap convolution over a g x g mosaic (g = 1: the plain batch): x [ceil(n/g^2), g*h, g*w, Cin_pad] ->
+    y [n_images, vh, vw, Cout] (the valid outputs, after bias / LeakyReLU / affine). ksplit None: the library's choice."""
+    lib = _lib.load()
+    x, act, post_scale, post_shift = _taps4_args(x_mosaic, packed, lrelu_slope, post_scale, post_shift)
+    Bm, H, W, C = x.shape
+    if H % g or W % g or Bm != (n_images + g * g - 1) // (g * g):
+        raise _lib.WitwError('conv_taps4_splitk: %s is not a %dx%d mosaic of %d images' % (tuple(x.shape), g, g, n_images))
+    h, w = H // g, W // g
+    vh, vw = valid_hw
+    S = ksplit or lib.witw_conv3x3_taps4_ksplit(Bm, H, W, C, packed.cout)
+    ws = torch.empty((S, Bm, H, W, packed.cout), dtype=torch.float32, device=x.device)
+    y = torch.empty((n_images, vh, vw, packed.cout), dtype=torch.float32, device=x.device)
+    prof = PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    if S > 1:
+        _lib.check(lib.witw_conv3x3_fwd_taps4_ex(x.data_ptr(), packed.wpk.data_ptr(), packed.bias.data_ptr(), None, None, None,
+                                                 ws.data_ptr(), Bm, H, W, C, packed.cout, 0, 0., packed.tap_base, S, 0, 0, 0,
+                                                 _stream()), 'witw_conv3x3_fwd_taps4_ex')
+        _lib.check(lib.witw_taps4_splitk_finish(ws.data_ptr(), S, packed.bias.data_ptr(), act, float(lrelu_slope or 0.),
+                                                _p(post_scale), _p(post_shift), y.data_ptr(), n_images, g, h, w, vh, vw,
+                                                packed.cout, _stream()), 'witw_taps4_splitk_finish')
+    else:       # one slice: the conv applies its own epilogue, the finish pass only gathers the valid outputs out of the mosaic
+        _lib.check(lib.witw_conv3x3_fwd_taps4_ex(x.data_ptr(), packed.wpk.data_ptr(), packed.bias.data_ptr(), None, _p(post_scale),
+                                                 _p(post_shift), ws.data_ptr(), Bm, H, W, C, packed.cout, act,
+                                                 float(lrelu_slope or 0.), packed.tap_base, 1, 0, 0, 0, _stream()),
+                   'witw_conv3x3_fwd_taps4_ex')
+        zero = torch.zeros((packed.cout,), dtype=torch.float32, device=x.device)
+        _lib.check(lib.witw_taps4_splitk_finish(ws.data_ptr(), 1, zero.data_ptr(), 0, 0., None, None, y.data_ptr(), n_images, g, h,
+                                                w, vh, vw, packed.cout, _stream()), 'witw_taps4_splitk_finish')
+    if prof is not None:
+        e1.record()
+        prof.append(((lib.witw_conv3x3_tile_n(packed.cout), 1, False, lib.witw_conv3x3_workgroup_waves(Bm, H, W, packed.cout, 1)),
+                     2.0 * packed.cin * packed.cout * 4 * vh * vw * n_images, e0, e1))
+    return y
+
+
+def space_to_depth2_mosaic(y_nhwc, g=1):
+    """y [B,H,W,C] -> [ceil(B/g^2), g*ceil(H/2), g*ceil(W/2), 4C]: g x g images per mosaic, each the space-to-depth(2) image."""
+    lib = _lib.load()
+    y = _dev_f32(y_nhwc, 'y')
+    B, H, W, C = y.shape
+    out = torch.empty(((B + g * g - 1) // (g * g), g * ((H + 1) // 2), g * ((W + 1) // 2), 4 * C), dtype=torch.float32, device=y.device)
+    _lib.check(lib.witw_space_to_depth2_mosaic(y.data_ptr(), out.data_ptr(), B, H, W, C, g, _stream()), 'witw_space_to_depth2_mosaic')
+    return out
+
+
 def maxpool2x2_bwd(dy, code, out_hw):
     """dy/code [B,Hp,Wp,C] -> dx [B,H,W,C] (gradient routed to the recorded arg-max position)."""
     lib = _lib.load()
