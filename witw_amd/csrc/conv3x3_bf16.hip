@@ -28,7 +28,7 @@ constexpr int IW = TW + 2;
 #define WITW_BF_DMA 1
 #endif
 #ifndef WITW_BF_SWAP
-#define WITW_BF_SWAP 2          // A/B builds: 1 = MFMA operands swapped (lane = pixel, register quad = 4 consecutive channels), the
+#define WITW_BF_SWAP 0          // A/B builds: 1 = MFMA operands swapped (lane = pixel, register quad = 4 consecutive channels), the
 #endif                          //     epilogue transposes through LDS with 8-byte writes (12 instead of 40 LDS instructions per M-tile).
                                 //     Parity-green, but measured SLOWER per tile (epilogue 9.1 k -> 11.9 k ticks)
 #ifndef WITW_BF_SPREAD
@@ -260,27 +260,12 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_bf16_kernel(ConvBfArgs p
     const int wbase = hq * TN + wn * 64 + l31;
 
     f32x16 acc[WM][WN];
-#if WITW_BF_SWAP >= 2
-    // the accumulators start from the bias (register quad g of n-tile nt = channels nt*32 + 8g + 4hq + {0..3} of this wave):
-    // the epilogue has no bias to fetch or add
-#pragma unroll
-    for (int nt = 0; nt < WN; ++nt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 bq0 = *reinterpret_cast<const f32x4*>(p.bias + n0 + wn * 64 + nt * 32 + 8 * g + 4 * hq);
-#pragma unroll
-            for (int mt = 0; mt < WM; ++mt)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[mt][nt][4 * g + j] = bq0[j];
-        }
-#else
 #pragma unroll
     for (int mt = 0; mt < WM; ++mt)
 #pragma unroll
         for (int nt = 0; nt < WN; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
-#endif
 
     u32x4 fa[2][WM], fb[2][WN];
     auto read_frags = [&](int set, const u32x4* in_s, const u32x4* w_s, int tap) {
@@ -373,12 +358,7 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_bf16_kernel(ConvBfArgs p
 #ifdef WITW_BF_STAMPS
     const unsigned long long t_loop1 = __builtin_amdgcn_s_memtime();
 #endif
-#if WITW_BF_SWAP >= 2
-    const bool direct_store = !p.out_nchw_f32 && (p.Cout & 7) == 0;      // the common case: no LDS in the epilogue at all
-    if (!direct_store) __syncthreads();
-#else
     __syncthreads();      // the slabs below reuse the stages
-#endif
 
 #if WITW_BF_SWAP
     // ---- epilogue, swapped-operand form. acc[mt][nt][r] = output of PIXEL m = l31 of M-tile mt, CHANNEL
@@ -393,20 +373,14 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_bf16_kernel(ConvBfArgs p
         // the bias of this lane's 8 channel quads is fetched once, up front (32 registers; fetching it where a quad is
         // finished put a global-load latency in front of every LDS write); the Dropout2d scale, present on three layers of
         // a training forward only, is fetched per quad
-#if WITW_BF_SWAP >= 2
-        f32x4 bq = {0.f, 0.f, 0.f, 0.f}, dq = {1.f, 1.f, 1.f, 1.f};
-#else
         f32x4 bv4[WN][4];
 #pragma unroll
         for (int nt = 0; nt < WN; ++nt)
 #pragma unroll
             for (int g = 0; g < 4; ++g) bv4[nt][g] = *reinterpret_cast<const f32x4*>(p.bias + cbase + nt * 32 + 8 * g + 4 * hq);
         f32x4 bq, dq = {1.f, 1.f, 1.f, 1.f};
-#endif
         auto load_quad = [&](int nt, int g) {
-#if WITW_BF_SWAP < 2
             bq = bv4[nt][g];
-#endif
             if (p.dropmask != nullptr) {
                 const int c = cbase + nt * 32 + 8 * g + 4 * hq;
 #pragma unroll
@@ -415,12 +389,7 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_bf16_kernel(ConvBfArgs p
         };
         auto fin = [&](float v, int nt, int g, int j) {      // conv + bias -> Dropout2d scale -> ReLU, after load_quad(nt, g)
             (void)nt; (void)g;
-#if WITW_BF_SWAP >= 2
-            (void)bq;
-            if (p.dropmask != nullptr) v *= dq[j];     // the bias is already inside the accumulator
-#else
             v = (v + bq[j]) * dq[j];
-#endif
             if (p.relu) v = fmaxf(v, 0.f);
             return v;
         };
@@ -452,119 +421,6 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_bf16_kernel(ConvBfArgs p
                 __builtin_nontemporal_store(o, reinterpret_cast<u16x8*>(reinterpret_cast<unsigned short*>(p.y) + off));
             }
         };
-#if WITW_BF_SWAP >= 2
-        // ---- direct store. A lane holds, per n-tile and register quad g, channels 8g + 4hq + {0..3} of its pixel; lanes l
-        // and l + 32 together hold the 8 channels of quad g. v_permlane32_swap_b32 on the packed quads g0 and g0 + 1 leaves
-        // lane l (< 32) with the 16 bytes of quad g0 and lane l + 32 with those of quad g0 + 1, i.e. 32 contiguous bytes per
-        // pixel and store instruction, 4 instructions per 128-byte line: no LDS transposition, and the stores drain while
-        // the wave (or the next workgroup on this CU) goes on.
-        typedef short s16x2 __attribute__((ext_vector_type(2)));
-        typedef short s16x8 __attribute__((ext_vector_type(8)));
-        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-        const bool has_drop = p.dropmask != nullptr;
-        const bool do_relu = p.relu != 0;
-        // two fp32 -> packed bf16 (RNE), Dropout2d scale before, ReLU after (on the packed pair: a negative bf16 is a negative int16)
-        auto pack2 = [&](float a, float b2, float da, float db) -> unsigned {
-            if (has_drop) { a *= da; b2 *= db; }
-            const bf16x2 q = {(__bf16)a, (__bf16)b2};
-            s16x2 r = __builtin_bit_cast(s16x2, q);
-            if (do_relu) r = __builtin_elementwise_max(r, (s16x2){0, 0});
-            return __builtin_bit_cast(unsigned, r);
-        };
-        // quads g0 / g0+1 (4 fp32 each) -> this lane's 16 bytes: channels 8*(g0 + hq) + {0..7} of its n-tile
-        auto octet = [&](const float* q0, const float* q1, f32x4 d0, f32x4 d1) -> u32x4 {
-            const unsigned X0 = pack2(q0[0], q0[1], d0[0], d0[1]), X1 = pack2(q0[2], q0[3], d0[2], d0[3]);
-            const unsigned Y0 = pack2(q1[0], q1[1], d1[0], d1[1]), Y1 = pack2(q1[2], q1[3], d1[2], d1[3]);
-            const u32x2 s0 = __builtin_amdgcn_permlane32_swap(X0, Y0, false, false);
-            const u32x2 s1 = __builtin_amdgcn_permlane32_swap(X1, Y1, false, false);
-            return u32x4{s0[0], s1[0], s0[1], s1[1]};
-        };
-        auto drop_quad = [&](int nt, int g) -> f32x4 {
-            f32x4 d = {1.f, 1.f, 1.f, 1.f};
-            if (has_drop) {
-                const int c = cbase + nt * 32 + 8 * g + 4 * hq;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) d[j] = (c + j < p.Cout) ? p.dropmask[(size_t)b * p.Cout + c + j] : 1.f;
-            }
-            return d;
-        };
-        auto store16 = [&](u32x4 o, int yy, int xx, int c0, bool lane_on) {
-            if (lane_on && yy < Hy && xx < Wy && c0 < p.Cout) {
-                const size_t off = (((size_t)b * Hy + yy) * Wy + xx) * p.Cout + c0;
-                if (p.gate != nullptr) {
-                    const s16x8 gt = *reinterpret_cast<const s16x8*>(p.gate + off);
-                    s16x8 v = __builtin_bit_cast(s16x8, o);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        if (!(gt[e] > 0)) v[e] = 0;          // a bf16 > 0 is a positive int16
-                    o = __builtin_bit_cast(u32x4, v);
-                }
-                *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(p.y) + off) = o;
-            }
-        };
-        if (direct_store && !POOL) {
-#pragma unroll
-            for (int mt = 0; mt < WM; ++mt) {
-                const int yy = oy0 + trow[mt], xx = ox0 + tcol[mt] + m;
-#pragma unroll
-                for (int nt = 0; nt < WN; ++nt)
-#pragma unroll
-                    for (int g0 = 0; g0 < 4; g0 += 2) {
-                        float q0[4], q1[4];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            q0[j] = acc[mt][nt][4 * g0 + j];
-                            q1[j] = acc[mt][nt][4 * g0 + 4 + j];
-                        }
-                        const u32x4 o = octet(q0, q1, drop_quad(nt, g0), drop_quad(nt, g0 + 1));
-                        store16(o, yy, xx, cbase + nt * 32 + 8 * (g0 + hq), true);
-                    }
-            }
-        } else if (direct_store) {
-            // fused 2x2 max-pool: vertical partner = the M-tile one row below (same lane), horizontal partner = lane ^ 1 (DPP
-            // quad_perm [1,0,3,2]); even lanes store pooled pixel m / 2
-            auto nb = [](float v) {
-                return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
-            };
-#pragma unroll
-            for (int pr = 0; pr < WM / 2; ++pr) {
-                const int mtA = (TN == 128) ? (pr & 1) : 0;
-                const int mtB = (TN == 128) ? (2 + (pr & 1)) : 1;
-                const int yy = (oy0 + trow[mtA]) >> 1;
-                const int xx = ((ox0 + tcol[mtA]) >> 1) + (m >> 1);
-#pragma unroll
-                for (int nt = 0; nt < WN; ++nt)
-#pragma unroll
-                    for (int g0 = 0; g0 < 4; g0 += 2) {
-                        float q[2][4];
-#pragma unroll
-                        for (int gg = 0; gg < 2; ++gg) {
-                            const int g = g0 + gg;
-                            unsigned code4 = 0;
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                const float a00 = acc[mtA][nt][4 * g + j], a10 = acc[mtB][nt][4 * g + j];
-                                const float v = fmaxf(a00, a10);
-                                const float mx = fmaxf(v, nb(v));
-                                q[gg][j] = mx;
-                                if (p.pool_code != nullptr) {
-                                    // first position attaining the max, scan order (0,0),(0,1),(1,0),(1,1) as torch's max_pool2d
-                                    const float a01 = nb(a00);
-                                    const unsigned code = (a00 == mx) ? 0u : (a01 == mx) ? 1u : (a10 == mx) ? 2u : 3u;
-                                    code4 |= code << (8 * j);
-                                }
-                            }
-                            const int c = cbase + nt * 32 + 8 * g + 4 * hq;
-                            if (p.pool_code != nullptr && !(m & 1) && yy < Hy && xx < Wy && c < p.Cout)
-                                *reinterpret_cast<unsigned*>(p.pool_code + (((size_t)b * Hy + yy) * Wy + xx) * p.Cout + c) = code4;
-                        }
-                        const u32x4 o = octet(q[0], q[1], drop_quad(nt, g0), drop_quad(nt, g0 + 1));
-                        store16(o, yy, xx, cbase + nt * 32 + 8 * (g0 + hq), !(m & 1));
-                    }
-            }
-        } else
-#endif
         if (p.out_nchw_f32 || (p.Cout & 7) != 0) {
             // fp32 NCHW embedding (last layer) or a ragged channel count: lanes are consecutive pixels of a row, so
             // every register is a coalesced run along x

@@ -19,7 +19,7 @@
 //      one lane's registers), one M-tile x 2 N-tiles per wave, operands by hand-issued ds_read_b128 three steps ahead with
 //      counted lgkmcnt waits, same accumulation order as
 //      conv3x3_nhwc_bf16_kernel (chunk-major, tap-minor): bit-identical to the unfused launches
-//   D  ReLU + 2x2 max (bias: accumulator start value), through a wave-private 1 KB slab to 16-byte NHWC stores.
+//   D  bias + ReLU + 2x2 max, through a wave-private 1 KB slab to 16-byte NHWC stores.
 #include "common.h"
 #include <stdio.h>
 #include <stdlib.h>
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(F2T, 1) void conv_first2_bf16_kernel(First2Args p) 
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[nt][r] = b2[nt];      // starts from the bias, as conv3x3_nhwc_bf16_kernel's does
+            for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
         constexpr int PF = 3, NB = PF + 1;
         u32x4 fa[NB], fb[NB][2];
         const unsigned abase = lds_address(a_s) + (unsigned)(hq * APOS + a_lane) * 16u;
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(F2T, 1) void conv_first2_bf16_kernel(First2Args p) 
         }
 
         stamp(5);
-        // ---- D: ReLU + 2x2 max-pool (the bias is in the accumulator) -> slab [pooled column 0..7][64 channels] bf16 -> 16-byte stores
+        // ---- D: bias + ReLU + 2x2 max-pool -> slab [pooled column 0..7][64 channels] bf16 -> 16-byte stores
         // register r <-> pixel m = (r&3) + 8*(r>>2) + 4*hq of the M-tile, m = 16*row + column: the window of pooled column
         // jp = (r&3)/2 + 4*((r>>2)&1) + 2*hq is registers {r, r+1, r+8, r+9} (r&3 in {0,2}, r < 8)
         __bf16* slab = reinterpret_cast<__bf16*>(slab_s + wave * 64);
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(F2T, 1) void conv_first2_bf16_kernel(First2Args p) 
                 const int r = (jj & 1) * 2 + (jj >> 1) * 4;
                 const float m4 = fmaxf(fmaxf(acc[nt][r], acc[nt][r + 1]), fmaxf(acc[nt][r + 8], acc[nt][r + 9]));
                 const int jp = (jj & 1) + 4 * (jj >> 1) + 2 * hq;
-                slab[jp * 64 + nt * 32 + l31] = (__bf16)fmaxf(m4, 0.f);
+                slab[jp * 64 + nt * 32 + l31] = (__bf16)fmaxf(m4 + b2[nt], 0.f);
             }
         {
             const int jp = lane >> 3, c8 = (lane & 7) * 8;
