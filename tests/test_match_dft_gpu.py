@@ -222,3 +222,25 @@ def test_evaluation_ranks_through_the_spectral_match():
     r_direct = cvig_fov.ranks(ov, su)
     r_dft = cvig_fov.retrieve(ov, su, k=5, method='dft')[0]
     np.testing.assert_array_equal(r_dft, r_direct)
+
+
+@pytest.mark.parametrize('we', [64, 24])
+def test_evaluation_ranks_auto_switches_to_the_spectral_pass(we, monkeypatch):
+    """cvig_fov.evaluation_ranks (what test() tabulates): 'auto' takes the direct kernel below SPECTRAL_FROM pairs and the
+    index-exact spectral pass from there on; all three settings give the same ranks, near-ties and duplicates included."""
+    from witw_amd import cvig_fov
+    n = 2500
+    gallery, queries = _planted(n, n, we, 6.0, 23)
+    r_direct = cvig_fov.evaluation_ranks(gallery, queries, method='direct')
+    np.testing.assert_array_equal(r_direct, cvig_fov.ranks(gallery, queries))
+    r_dft = cvig_fov.evaluation_ranks(gallery, queries, method='dft')
+    np.testing.assert_array_equal(r_dft, r_direct)
+    assert cvig_fov.retrieve.last_stats['method'] == 'dft'
+    cvig_fov.retrieve.last_stats = {}
+    np.testing.assert_array_equal(cvig_fov.evaluation_ranks(gallery, queries, method='auto'), r_direct)
+    assert cvig_fov.retrieve.last_stats == {}                     # below the switch: the direct kernel, retrieve() not involved
+    monkeypatch.setattr(cvig_fov, 'SPECTRAL_FROM', 2000)
+    np.testing.assert_array_equal(cvig_fov.evaluation_ranks(gallery, queries, method='auto'), r_direct)
+    assert cvig_fov.retrieve.last_stats.get('method') == 'dft'
+    with pytest.raises(Exception):
+        cvig_fov.evaluation_ranks(gallery, queries, method='fft')

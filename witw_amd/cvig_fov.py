@@ -40,6 +40,9 @@ class Globals:
     # not in the reference: arithmetic of the encoders built by train() / test() / the CLI (`--precision`).
     # 'fp32' = the reference's arithmetic (parity path); 'bf16' = bf16 MFMA operands, fp32 accumulate / weights / Adam.
     precision = 'fp32'
+    # not in the reference: how test() ranks the queries against the gallery. 'direct' = the reference's sum on every pair,
+    # 'dft' = the spectral pass with exact re-scoring (same ranks), 'auto' = 'dft' from cvig_fov.SPECTRAL_FROM pairs on.
+    match_method = 'auto'
 
 
 def _default_device():
@@ -684,6 +687,29 @@ def ranks(overhead_embed, surface_embed):
     return ops.rank_count(dist, 0).cpu().numpy().astype('int64')
 
 
+SPECTRAL_FROM = 8192      # evaluation sets from this many pairs on rank through the spectral pass under match_method 'auto'
+
+
+def evaluation_ranks(overhead_embed, surface_embed, shard_begin=0, world=1, method='auto'):
+    """The ranks test() tabulates (model/cvig_fov.py:543-552), int64 [N] on the host, identical on every rank. `overhead_embed` /
+    `surface_embed` are THIS rank's rows (world > 1: queries are replicated, gallery rows stay sharded). method:
+    'direct' = the fused correlation kernel on every (gallery, query) pair (2*64*E FLOP each); 'dft' = the spectral pass
+    (21 k FLOP per pair) with the exact re-scoring of retrieve(): the SAME ranks (index-exact, tests/test_match_dft_gpu.py) about
+    17x faster at retrieval sizes; 'auto' = 'dft' from SPECTRAL_FROM pairs on. 8,884 CVUSA test pairs: 0.55 s direct, 10^5 pairs:
+    36 s direct / 2 s spectral."""
+    from . import parallel
+    if method not in ('auto', 'direct', 'dft'):
+        raise _lib.WitwError("match_method must be 'auto', 'direct' or 'dft', got %r" % (method,))
+    surface_all = parallel.all_gather_ragged(surface_embed) if world > 1 else surface_embed
+    if method == 'auto':
+        method = 'dft' if surface_all.shape[0] >= SPECTRAL_FROM else 'direct'
+    if method == 'dft':
+        return retrieve(overhead_embed, surface_all, k=1, shard_begin=shard_begin, method='dft')[0]
+    if world > 1:
+        return sharded_ranks(overhead_embed, surface_all, shard_begin)
+    return ranks(overhead_embed, surface_embed)
+
+
 def sharded_ranks(overhead_shard, surface_all, shard_begin, query_chunk=4096, _match=None, _count=None):
     """Ranking with the GALLERY sharded by rows across ranks: this rank holds
     overhead_shard = gallery rows [shard_begin, shard_begin+n); queries (replicated) match gallery row
@@ -816,7 +842,7 @@ def _retrieve_dft(overhead_shard, surface_all, k, shard_begin, query_chunk, kn, 
     counts = torch.zeros((n_q,), dtype=torch.int32, device=dev)
     vals, idxs, sns = [], [], []
     wn = None
-    stats = {'pairs': float(n_g) * n_q, 'rescored_rank': 0, 'rescored_topk': 0, 'rescored_true': 0,
+    stats = {'method': 'dft', 'pairs': float(n_g) * n_q, 'rescored_rank': 0, 'rescored_topk': 0, 'rescored_true': 0,
              'rescored_orientation': 0, 'fallback_queries': 0}
     for q0 in range(0, n_q, query_chunk):
         q1 = min(n_q, q0 + query_chunk)
@@ -1500,10 +1526,7 @@ def test(dataset='cvusa', fov=360, batch_size=64, num_workers=8, csv_path=None, 
     if Globals.precision == 'fp16x3' and ops.f16x3_overflowed(surface_embed.device):
         raise _lib.WitwError("an activation left the fp16 range (|v| > 65504) on the fp16x3 kernels: evaluate these weights with "
                              "precision 'fp32'")
-    if world > 1:       # queries replicated, gallery rows stay sharded (SURVEY §8e retrieval partitioning)
-        rk = sharded_ranks(overhead_embed, parallel.all_gather_ragged(surface_embed), shard_begin)
-    else:
-        rk = ranks(overhead_embed, surface_embed)
+    rk = evaluation_ranks(overhead_embed, surface_embed, shard_begin, world, getattr(Globals, 'match_method', 'auto'))
     t = recall_table(rk)
     count = len(rk)
     if rank != 0:
