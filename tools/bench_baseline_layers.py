@@ -1,3 +1,4 @@
+"""Per-block timing of one cvig_baseline encoder (overhead, 32 x 512 x 512, eval path): run on the GPU box from the repo root."""
 import os, sys
 sys.path.insert(0, os.getcwd())
 import torch

@@ -1,3 +1,4 @@
+"""In-kernel phase stamps of conv_first2_bf16_kernel (WITW_F2_STAMPS=1 selects the recording instantiation): run on the GPU box from the repo root."""
 import os, sys
 sys.path.insert(0, os.getcwd())
 import torch
