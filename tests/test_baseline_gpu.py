@@ -51,10 +51,12 @@ def test_baseline_odd_sizes_vs_oracle():
     np.testing.assert_allclose(enc(x.cuda()).cpu().numpy(), ref, rtol=0, atol=1e-4)
 
 
-@pytest.mark.parametrize('shape', [(4, 512, 512), (8, 512, 512), (5, 500, 500), (32, 512, 512)])
+@pytest.mark.parametrize('shape', [(4, 512, 512), (8, 512, 512), (5, 500, 500), (32, 512, 512), (3, 382, 382), (7, 384, 640), (2, 768, 1024)])
 def test_baseline_encoder_config1_batches_vs_oracle(shape):
     """BASELINE config 1 shapes at batch sizes that pick the 8-wave workgroups (>= 4 images of 512 x 512): round 1 only ran 2
-    images here, and the 8-wave 64-channel 4-tap variant wrote two of its epilogue slabs past the end of the LDS buffer."""
+    images here, and the 8-wave 64-channel 4-tap variant wrote two of its epilogue slabs past the end of the LDS buffer. The
+    smallest legal input (382: block 7 has a single valid output), non-square maps (different mosaic factors per axis are not
+    allowed: the smaller one is taken) and maps too large for a mosaic in block 5 exercise the eval path's block 5-7 layouts."""
     from witw_amd import cvig_baseline
     B, H, W = shape
     enc = _load_encoder(cvig_baseline.OverheadEncoder, 4243)
