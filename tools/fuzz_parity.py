@@ -7,7 +7,7 @@ shapes through the C ABI, compared with torch CPU ops in the reference's op orde
 Covers: fp32 conv forward (stride, circular/zero padding, ReLU, fused pool, GEO / NW variants by shape), its dgrad
 form, fp32 wgrad (+ bias), the 4-tap forms, bf16 conv forward / wgrad, the fused match (orientation exact, distance
 1e-5) with ragged batch sizes and widths (direct and spectral forms), the fp16x3 conv forward / dgrad form (gate, Dropout2d scale, zero-interleaved
-rows) / wgrad against fp64. FUZZ_KINDS=10,11 restricts the sweep to the listed kinds. Prints one line per failure and a summary; exit code 1 on any failure.
+rows) / wgrad against fp64, the 4-tap conv's space-to-depth epilogue (bitwise) and its split-K mosaic form. FUZZ_KINDS=10,11 restricts the sweep to the listed kinds. Prints one line per failure and a summary; exit code 1 on any failure.
 """
 import os
 import sys
@@ -43,7 +43,7 @@ def main():
 
     while time.time() - t0 < budget:
         n += 1
-        kind = rng.integers(0, 14)
+        kind = rng.integers(0, 16)
         if os.environ.get('FUZZ_KINDS') and str(int(kind)) not in os.environ['FUZZ_KINDS'].split(','):
             continue
         B = int(rng.integers(1, 5))
@@ -97,6 +97,46 @@ def main():
                 a4, _ = ops.conv3x3_wgrad(xd, gy, cin, taps4=True)
                 if not torch.equal(a9[:, :, 1:, 1:], a4[:, :, 1:, 1:]):
                     check('taps4_wgrad', cfg, a4[:, :, 1:, 1:].cpu(), a9[:, :, 1:, 1:].cpu(), 0.0)
+            elif kind == 14 and H >= 2 and W >= 2 and cout % 4 == 0:    # 4-tap conv with the space-to-depth epilogue vs conv + separate pass
+                w4 = w.clone()
+                w4[:, :, 0, :] = 0
+                w4[:, :, :, 0] = 0
+                xd = nhwc(x).to(dev)
+                pk = ops.PackedConv(w4.to(dev), b.to(dev), taps4=True)
+                sc, shf = (1 + 0.1 * torch.randn(cout)).to(dev), (0.1 * torch.randn(cout)).to(dev)
+                vh = int(rng.integers(1, H + 1))
+                vw = int(rng.integers(1, W + 1))
+                vh -= (vh == H and H % 2 == 1)      # an odd valid size needs one more computed row / column
+                vw -= (vw == W and W % 2 == 1)
+                if vh >= 1 and vw >= 1:
+                    y = ops.conv3x3_fwd(xd, pk, relu=False, lrelu_slope=0.2, post_scale=sc, post_shift=shf)
+                    want = ops.space_to_depth2(y, valid_hw=(vh, vw), cpad=4 * cout)
+                    got = ops.conv_taps4_s2d(xd, pk, (vh, vw), lrelu_slope=0.2, post_scale=sc, post_shift=shf)
+                    if not torch.equal(got, want):
+                        check('taps4_s2d', cfg + (vh, vw), got.cpu(), want.cpu(), 0.0)
+            elif kind == 15 and cout % 4 == 0:    # split-K over a g x g mosaic vs the plain 4-tap conv per image
+                g = int(rng.choice([1, 2, 4]))
+                h = int(rng.choice([2, 3, 4, 8, 16])) if g > 1 else int(rng.integers(2, 20))
+                cin2 = int(rng.choice([64, 128, 256, 512]))
+                n_img = int(rng.integers(1, 12))
+                x2 = torch.randn(n_img, h, h, cin2)
+                w4 = torch.randn(cout, cin2, 3, 3) * (2.0 / (4 * cin2)) ** 0.5
+                w4[:, :, 0, :] = 0
+                w4[:, :, :, 0] = 0
+                pk = ops.PackedConv(w4.to(dev), b.to(dev), taps4=True)
+                y = ops.conv3x3_fwd(x2.to(dev), pk, relu=False, lrelu_slope=0.2)[:, :h - 1, :h - 1].contiguous()
+                bm = (n_img + g * g - 1) // (g * g)
+                xm = torch.zeros(bm, g * h, g * h, cin2)
+                for i in range(n_img):
+                    m_, cell = divmod(i, g * g)
+                    cy, cx = divmod(cell, g)
+                    xm[m_, cy * h:(cy + 1) * h, cx * h:(cx + 1) * h] = x2[i]
+                nkc = cin2 // 8
+                ks = int(rng.choice([0, 2, 3, 5, 8]))          # 0: the library's own choice
+                if ks == 0 or (ks - 1) * ((nkc + ks - 1) // ks) >= nkc:
+                    ks = None
+                got = ops.conv_taps4_splitk(xm.to(dev), pk, n_img, g, (h - 1, h - 1), lrelu_slope=0.2, ksplit=ks)
+                check('taps4_splitk', (n_img, g, h, cin2, cout, ks), got.cpu(), y.cpu(), 2e-5)
             elif kind == 3:     # bf16 forward vs emulation
                 cin16 = (cin + 15) // 16 * 16
                 x = torch.randn(B, cin16, H, W).bfloat16().float()
