@@ -192,6 +192,16 @@ def test_batched_preprocess_equals_the_per_sample_transforms(tmp_path):
     prep = cvig_fov.GpuPreprocess('witw', fov=70)
     got = [prep(st)['surface'] for st in cvig_fov.DevicePrefetcher(ds_like, prep)]
     assert torch.equal(torch.cat(got), ref_s)
+    # grouped: the loader hands out part batches, DevicePrefetcher(group=g) stages g of them as ONE batch (every part keeps its
+    # own device block; the descriptor tables are concatenated) -- same result as the whole batch, sample order kept
+    parts = [cvig_fov.collate_packed(as_bytes[:1]), cvig_fov.collate_packed(as_bytes[1:3]), cvig_fov.collate_packed(as_bytes[3:])]
+    staged = list(cvig_fov.DevicePrefetcher(parts, prep, group=3))
+    assert len(staged) == 1 and staged[0].n == 4 and staged[0].idx == [0, 1, 2, 3]
+    out = prep(staged[0])
+    assert torch.equal(out['surface'], ref_s) and torch.equal(out['polar'], ref_p)
+    two = list(cvig_fov.DevicePrefetcher(parts, prep, group=2))        # a short last group
+    assert [st.n for st in two] == [3, 1] and torch.equal(torch.cat([prep(st)['surface'] for st in two]), ref_s)
+    assert cvig_fov.loader_split(128, 12) == 4 and cvig_fov.loader_split(128, 0) == 1 and cvig_fov.loader_split(30, 4) == 1
     # a grey-scale image cannot feed a 3-channel model
     from witw_amd import _lib
     with pytest.raises(_lib.WitwError):

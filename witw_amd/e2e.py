@@ -58,7 +58,8 @@ def bench(a, device, n_pairs=None, workers=None, keep_dir=None):
     t_make = time.perf_counter() - t0
 
     ds = cvig_fov.ImagePairDataset('cvusa', csv, raw=True)
-    loader = torch.utils.data.DataLoader(ds, batch_size=B, shuffle=False, drop_last=False, num_workers=workers,
+    split = cvig_fov.loader_split(B, workers)      # workers decode quarter batches (as test() does): first batch 4x sooner
+    loader = torch.utils.data.DataLoader(ds, batch_size=B // split, shuffle=False, drop_last=False, num_workers=workers,
                                          collate_fn=cvig_fov.collate_packed, pin_memory=True,
                                          prefetch_factor=4 if workers else None, persistent_workers=bool(workers))
     prep = cvig_fov.GpuPreprocess('cvusa', fov, random_orientation=False, device=device)
@@ -73,25 +74,27 @@ def bench(a, device, n_pairs=None, workers=None, keep_dir=None):
 
     # ---- stage rates on their own
     # (1) the loader alone: decode + pack in the workers, pinning thread; one untimed pass starts the workers / fills the page cache
-    first = None
+    first = []                     # the parts of the first full batch
     for raw in loader:
-        first = first or raw
+        if len(first) < split:
+            first.append(raw)
     t0 = time.perf_counter()
     n = 0
     for raw in loader:
         n += raw['surface_desc'].shape[0]
     t_load = time.perf_counter() - t0
     # (2) host -> device copy of one packed batch from pinned memory
-    blk = first['surface_bytes'].numel() + first['overhead_bytes'].numel()
+    blk = sum(f['surface_bytes'].numel() + f['overhead_bytes'].numel() for f in first)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(5):
-        first['surface_bytes'].to(device, non_blocking=True)
-        first['overhead_bytes'].to(device, non_blocking=True)
+        for f in first:
+            f['surface_bytes'].to(device, non_blocking=True)
+            f['overhead_bytes'].to(device, non_blocking=True)
     torch.cuda.synchronize()
     t_h2d = (time.perf_counter() - t0) / 5
     # (3) the GPU side on a resident batch: 3 preprocessing launches + 2 encoders
-    st = prep.stage(first)
+    st = prep.stage(first if split > 1 else first[0])
     for _ in range(2):
         embed(st)
     torch.cuda.synchronize()
@@ -107,7 +110,7 @@ def bench(a, device, n_pairs=None, workers=None, keep_dir=None):
     t0 = time.perf_counter()
     su_all, ov_all = [], []
     t_first, n_first = None, 0
-    for st in cvig_fov.DevicePrefetcher(loader, prep):
+    for st in cvig_fov.DevicePrefetcher(loader, prep, group=split):
         su, ov = embed(st)
         su_all.append(su)
         ov_all.append(ov)
@@ -129,7 +132,7 @@ def bench(a, device, n_pairs=None, workers=None, keep_dir=None):
            'steps': (n_pairs + B - 1) // B, 'warmup': 0, 'ms_per_step': round(t_e2e / ((n_pairs + B - 1) // B) * 1e3, 3),
            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
            'config': {'workload': 'cvig_fov fov=%d, %d JPEG pairs on disk (%d distinct files pairs, overhead 512x512 + ground 224x224, %.1f MB) -> '
-                                  'ImagePairDataset(raw) in %d DataLoader workers -> collate_packed -> pinned -> copy stream -> GpuPreprocess '
+                                  'ImagePairDataset(raw) in %d DataLoader workers (quarter batches) -> collate_packed -> pinned -> copy stream -> GpuPreprocess '
                                   '(3 launches per batch) -> 2x FOV_DSM -> embeddings' % (fov, n_pairs, n_unique, nbytes / 1e6, workers),
                       'pairs_per_gpu': B, 'host_cores_available': cores, 'dataset_dir': 'tmpfs/disk under %s' % tempfile.gettempdir(),
                       'reference_data_path': 'model/cvig_fov.py:393-403: transforms inside 12 DataLoader workers, ~1 s per sample '
