@@ -33,6 +33,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 MFMA
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # same table, dense bf16 MFMA (no sparsity)
+PEAK_HBM_GBS = 8000.0           # same guide: HBM3E ~8 TB/s
 DOMINANT = (128, 1, False, 8)  # conv3x3_nhwc_f32_kernel<128,1,false,8,0,9> (TN, SH, POOL, NW, GEO, TAPS): layers 5,10,12,17,19,21 at B=128
 
 
@@ -391,6 +392,8 @@ def step_line(a, rank, world, device, cvig_fov, ops):
     side = headline and not a.no_side_blocks and a.model == 'fov' and a.fov == 360 and a.batch == 128
     if headline and not a.no_side_blocks:
         out['fp32_grade_on_fp16_mfma'] = fp16x3_block(sb, a.steps)
+        if not sb.semantic and a.fov == 360:
+            out['hbm_kernels'] = hbm_block(sb)
     cpu_args = (sb.ground_raw[:a.cpu_pairs].cpu(), sb.ov_raw[:a.cpu_pairs].cpu(), sb.wts, sb.semantic) if headline else None
     if side:
         del sb
@@ -431,6 +434,40 @@ def step_line(a, rank, world, device, cvig_fov, ops):
     if headline and rank == 0 and not a.no_cpu_baseline:      # last: nothing on the GPU waits behind the CPU leg
         out['cpu_baseline'] = cpu_baseline(a, *cpu_args)
     return out
+
+
+def hbm_block(sb):
+    """The HBM-bound kernels of the step, timed live with events on the stream they run on (20 launches each): algorithmic
+    bytes (read + written once) / duration against the HBM peak. They are 2 % of the step; the dominant kernel's roofline is
+    the MFMA one above."""
+    ops = sb.ops
+    B = sb.B
+    with torch.no_grad():
+        ov = ops.resize_bilinear(sb.ov_raw, (256, 256), sb.mean, sb.std, sb.ndiv)
+        polar = ops.polar_transform(ov)
+        packed = sb.oe._pack_first(False)
+
+        def timed(fn, n=20):
+            fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                fn()
+            e1.record()
+            e1.synchronize()
+            return e0.elapsed_time(e1) / n * 1e-3
+        c = polar.shape[1]
+        rows = {
+            'polar_kernel': (timed(lambda: ops.polar_transform(ov)), ov.numel() * 4 + polar.numel() * 4,
+                             '%d x %d x 256 x 256 fp32 in, %d x %d x 128 x 512 out' % (B, c, B, c)),
+            'resize_bilinear_norm_kernel (overhead 512 -> 256)': (timed(lambda: ops.resize_bilinear(sb.ov_raw, (256, 256), sb.mean, sb.std, sb.ndiv)),
+                                                                  sb.ov_raw.numel() * 4 + ov.numel() * 4, 'raw 512 x 512 in, 256 x 256 out'),
+            'conv3x3_first_kernel (3 -> 64 channels, NCHW in, NHWC out)': (timed(lambda: ops.conv3x3_first_fwd(polar, packed, circular=True, relu=True)),
+                                                                           polar.numel() * 4 + B * 128 * 512 * 64 * 4, '2.1 GB written per launch'),
+        }
+    return {'note': 'algorithmic bytes / HIP-event duration, 20 launches each, peak %.0f GB/s' % PEAK_HBM_GBS,
+            'kernels': {k: {'ms': round(t * 1e3, 4), 'GBps': round(nb / t / 1e9, 1), 'frac_of_hbm_peak': round(nb / t / 1e9 / PEAK_HBM_GBS, 3), 'what': w}
+                        for k, (t, nb, w) in rows.items()}}
 
 
 def fp16x3_block(sb, steps):
