@@ -117,8 +117,8 @@ __global__ __launch_bounds__(FT, 2) void conv3x3_first_kernel(FirstArgs p) {
                 const int m = g * 4 + prow;
                 const int xx = ox0 + col0 + m;
                 const f32x4 v = *reinterpret_cast<const f32x4*>(slab + m * 64 + pc4);
-                if (yy < p.H && xx < p.W)
-                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.y) + (((size_t)b * p.H + yy) * p.W + xx) * 64 + pc4) = v;
+                if (yy < p.H && xx < p.W)      // streaming store: 2.1 GB written once per launch (0.66 -> 0.55 ms against a plain store)
+                    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.y) + (((size_t)b * p.H + yy) * p.W + xx) * 64 + pc4));
             }
         } else if (p.out_bf16 == 2) {
             // split-fp16 output of the fp16x3 path (conv3x3_f16x3.hip): exact fp32 arithmetic here, then per pixel and 8
@@ -141,8 +141,8 @@ __global__ __launch_bounds__(FT, 2) void conv3x3_first_kernel(FirstArgs p) {
                 }
                 if (yy < p.H && xx < p.W) {
                     f16x8* dst = reinterpret_cast<f16x8*>(reinterpret_cast<_Float16*>(p.y) + ((((size_t)b * p.H + yy) * p.W + xx) * 64 + pc8) * 2);
-                    dst[0] = hi;
-                    dst[1] = lo;
+                    __builtin_nontemporal_store(hi, dst);
+                    __builtin_nontemporal_store(lo, dst + 1);
                 }
             }
         } else {
