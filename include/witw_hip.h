@@ -188,6 +188,11 @@ int witw_triplet_loss_bwd(const float* distance, const float* workspace, const f
 /* ---- bf16 inference path of the encoder (BASELINE config "cvig_semantic ... bf16 MFMA"): bf16 NHWC activations
  * (channels padded to 16) and packed bf16 filters, fp32 accumulate on v_mfma_f32_32x32x16_bf16, fp32 bias;
  * the last layer writes the fp32 NCHW embedding (out_nchw_f32). Pointers typed void* carry bf16 data. */
+/* MFMA shape of the bf16 inference forward where both kernels apply (Cout >= 128, stride 1, >= 512 workgroups of 8 waves,
+ * Cin % 32 == 0, bf16 NHWC out, no gate / Dropout2d scale / pool codes): 1 = v_mfma_f32_16x16x32_bf16 (default; two taps of a
+ * 16-channel chunk per MFMA, the ninth tap of an even chunk shares its MFMA with the ninth tap of the next chunk), 0 =
+ * v_mfma_f32_32x32x16_bf16. enable < 0 only queries; returns the previous setting. Results agree to one bf16 ulp. */
+int witw_conv3x3_bf16_mfma16(int enable);
 long long witw_conv3x3_bf16_packed_elems(int cout, int cin);
 int witw_conv3x3_bf16_pack_weights(const float* w_kcrs, void* wpk_bf16, int cout, int cin, void* stream);
 /* transpose_flip != 0: the dgrad filter of the source tensor [cin][cout][3][3] (cout, cin describe the packed filter) */

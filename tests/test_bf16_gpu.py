@@ -123,3 +123,42 @@ def test_encoder_bf16_with_and_without_the_fused_launch():
         enc.fuse_first2 = False
         b = enc.forward_bf16(x)
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('case', [(32, 32, 128, 128, 256, False, False), (32, 32, 128, 128, 256, True, True), (64, 16, 64, 512, 512, False, True),
+                                  (40, 64, 200, 64, 128, True, False), (24, 40, 70, 256, 384, False, False), (33, 24, 130, 256, 128, False, False),
+                                  (32, 32, 128, 48, 256, False, False)])
+def test_bf16_mfma16_kernel_matches_the_32x32_kernel(case):
+    """The 16x16x32 form of the bf16 inference forward (two taps of a 16-channel chunk per MFMA, the ninth tap of an even chunk
+    sharing its MFMA with the ninth tap of the next chunk) against the 32x32x16 kernel on layers large enough for the 8-wave tile:
+    the same products summed in fp32 in a different order, so outputs agree to one bf16 unit in the last place and almost all
+    are identical; ragged widths, circular and zero padding, the fused pool. The last two cases do not qualify (fewer than 512
+    workgroups; Cin % 32 != 0) and must be bit-identical whatever the switch says."""
+    import torch
+    from witw_amd import ops
+    B, H, W, cin, cout, pool, circ = case
+    g = torch.Generator(device='cuda')
+    g.manual_seed(cin + cout + W)
+    x = torch.randn((B, H, W, cin), generator=g, device='cuda').bfloat16()
+    w = torch.randn((cout, cin, 3, 3), generator=g, device='cuda') * (2.0 / (9 * cin)) ** 0.5
+    b = torch.randn((cout,), generator=g, device='cuda') * 0.1
+    pk = ops.PackedConvBf16(w, b)
+    prev = ops.bf16_mfma16(False)
+    try:
+        y32 = ops.conv3x3_bf16_fwd(x, pk, circular=circ, relu=True, pool=pool)
+        assert ops.bf16_mfma16(True) is False
+        y16 = ops.conv3x3_bf16_fwd(x, pk, circular=circ, relu=True, pool=pool)
+    finally:
+        ops.bf16_mfma16(prev)
+    qualifies = cin % 32 == 0 and cout >= 128 and H % 8 == 0 and ((cout + 127) // 128) * B * ((W + 63) // 64) * (H // 8) >= 512
+    a, c = y32.float(), y16.float()
+    if not qualifies:
+        assert torch.equal(a, c)
+        return
+    same = float((a == c).float().mean())
+    assert same > 0.999, same
+    # one unit in the last place of a bf16 number: 2^-7 relative (2^-8 mantissa step of the larger neighbour, doubled at a binade edge);
+    # next to zero (a pre-activation within fp32 summation rounding of the ReLU kink) the difference is that rounding itself
+    scale = float(a.abs().max())
+    assert bool(((a - c).abs() <= 2.0 ** -7 * torch.maximum(a.abs(), c.abs()) + 1e-5 * scale).all())
+    assert not torch.equal(a, c) or cin <= 64          # it really is the other kernel (a different summation order shows somewhere)

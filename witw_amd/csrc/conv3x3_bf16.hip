@@ -31,6 +31,9 @@ constexpr int IW = TW + 2;
 #define WITW_BF_SWAP 0          // A/B builds: 1 = MFMA operands swapped (lane = pixel, register quad = 4 consecutive channels), the
 #endif                          //     epilogue transposes through LDS with 8-byte writes (12 instead of 40 LDS instructions per M-tile).
                                 //     Parity-green, but measured SLOWER per tile (epilogue 9.1 k -> 11.9 k ticks)
+#ifndef WITW_BF_S16_SPREAD
+#define WITW_BF_S16_SPREAD 3    // half-units (of 8 per chunk) over which the 16x16x32 kernel issues the staging pieces of the next chunk
+#endif
 #ifndef WITW_BF_SPREAD
 #define WITW_BF_SPREAD 5        // taps over which the staging pieces of a chunk are issued (1 = all at tap 0)
 #endif
@@ -692,6 +695,324 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_bf16_kernel(ConvBfArgs p
 #endif
 }
 
+// Hand-issued fragment reads of the 16x16x32 kernel below: asm volatile keeps them where they are written (left to the scheduler,
+// refills are hoisted above the MFMAs that still read the old fragment and cost a second register set: 49 spills), the matching
+// s_waitcnt counts the reads issued after the one that is needed (LDS returns in order; extra LDS operations of the compiler
+// in the queue only make a wait stricter).
+__device__ __forceinline__ u32x4 s16_read(unsigned addr, int off) {      // off: a constant once the caller's loops are unrolled
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(off));
+    return v;
+}
+__device__ __forceinline__ void s16_wait(int n, u32x4& a) {
+    switch (n) {      // n is a constant once the caller's loops are unrolled
+    case 0: asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a)); break;
+    case 1: asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(a)); break;
+    case 2: asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a)); break;
+    case 3: asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(a)); break;
+    case 4: asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a)); break;
+    case 5: asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(a)); break;
+    case 6: asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(a)); break;
+    default: asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(a)); break;
+    }
+}
+__device__ __forceinline__ void s16_wait5(int n, u32x4& a, u32x4& b0, u32x4& b1, u32x4& b2, u32x4& b3) {
+    switch (n) {
+    case 0: asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3)); break;
+    case 1: asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(a), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3)); break;
+    default: asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3)); break;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The same convolution on v_mfma_f32_16x16x32_bf16 (inference forward of the 128-channel tile, 8 waves, stride 1, NHWC bf16 out,
+// no gate / Dropout2d scale / pool codes: everything else runs on the kernel above). Same workgroup tile, same LDS stages and
+// staging as above; what changes is the MFMA shape: the chip holds a higher clock on the 16x16x32 form (MI355X_MICROARCH.md,
+// 'DVFS give-back' item 7; a probe build of the kernel above with equal FLOPs and LDS reads ran the whole step +7 %).
+//   K = 32 of one MFMA = TWO taps of the 16-channel chunk: lane l holds 8 channels of pixel (l & 15) for k-group l >> 4 =
+//   (tap of the pair, channel group). A fragment = 16 pixels of one row x {tap a, tap b} x 2 groups = one ds_read_b128 whose
+//   lane address is base + (tap offset by lane), B fragment = 16 output channels likewise. A wave's 2 rows x 64 pixels x 64
+//   channels are 8 x 4 tiles of 16 x 16 (4 accumulation registers each: register r of lane l = pixel 4*(l>>4) + r, channel l & 15).
+//   The 9 taps of a chunk make 4 pairs + tap 8, whose partner half multiplies a zero slot (the padding slots of a stage).
+template <bool POOL>
+__global__ __launch_bounds__(512) void conv3x3_bf16_s16_kernel(ConvBfArgs p) {
+    constexpr int TN = 128, NW = 8, TH = 8, NTHREADS = 512;
+    constexpr int IH = TH + 2;
+    constexpr int IN_S = 2 * IH * IW;
+    constexpr int IN_P = (IN_S + 64 + 63) / 64 * 64;      // + 64 zero slots behind the tile (the partner half of tap 8 multiplies them)
+    constexpr int W_S = 9 * 2 * TN;
+    constexpr int STAGE_S = IN_P + W_S;
+    constexpr int NIN = (IN_S + NTHREADS - 1) / NTHREADS;
+    constexpr int NWT_D = (W_S / 64 + NW - 1) / NW;
+    constexpr unsigned OOR = 0x80000000u;
+    constexpr int SLAB_P = 68;      // floats per slab row: 64 channels + 4 (the four 16-lane groups of a write land on different banks)
+    static_assert(IN_P >= IN_S + 64, "the zero slots live in the padding of the input stage");
+    static_assert(STAGE_S * 16 >= (NW / 2) * 32 * SLAB_P * 4, "a stage must hold the epilogue slabs of half the waves");
+
+    __shared__ u32x4 stageA[STAGE_S];
+    __shared__ u32x4 stageB[STAGE_S + 1];
+    u32x4* const dummy_slot = stageB + STAGE_S;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave) & (NW - 1);
+    const int l15 = lane & 15, kg = lane >> 4;
+    const int sel = kg >> 1, grp = kg & 1;       // which tap of a pair / which 8-channel group this lane's k values are
+
+    int ntile, sp;
+    if (p.xcd_map) {
+        const int g = blockIdx.x >> 3;
+        ntile = g % p.n_tiles;
+        sp = (blockIdx.x & 7) * p.sp_per_xcd + g / p.n_tiles;
+        if (sp >= p.sp_total) return;
+    } else {
+        ntile = blockIdx.x / p.sp_total;
+        sp = blockIdx.x - ntile * p.sp_total;
+    }
+    const int tiles_img = p.tiles_x * p.tiles_y;
+    const int b = sp / tiles_img;
+    sp -= b * tiles_img;
+    const int ty = sp / p.tiles_x;
+    const int tx = sp - ty * p.tiles_x;
+    const int oy0 = ty * TH, ox0 = tx * TW, n0 = ntile * TN;
+    const int nkc = p.Cin >> 4;
+
+    // ---- staging: as in the kernel above (input tile through registers, weight slab by LDS-DMA)
+    const size_t img_elems = (size_t)p.H * p.W * p.Cin;
+    __amdgpu_buffer_rsrc_t in_rs =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)b * img_elems), 0, (unsigned)(img_elems * 2), 0x00020000);
+    const i32x4 w_rd = raw_rsrc(reinterpret_cast<const u32x4*>(p.wpk) + (size_t)ntile * nkc * W_S, (unsigned)nkc * W_S * 16u);
+    unsigned gin[NIN];
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) {
+        const int s = tid + i * NTHREADS;
+        const int pix = s >> 1, q = s & 1;
+        const int r = pix / IW, c = pix - r * IW;
+        const int gr = oy0 - 1 + r;
+        int gc = ox0 - 1 + c;
+        bool ok = s < IN_S && gr >= 0 && gr < p.H;
+        if (p.circ) {
+            gc %= p.W;
+            if (gc < 0) gc += p.W;
+        } else {
+            ok = ok && gc >= 0 && gc < p.W;
+        }
+        gin[i] = ok ? (unsigned)((((size_t)gr * p.W + gc) * p.Cin + q * 8) * 2) : OOR;
+    }
+    u32x4 rin[NIN];
+    const unsigned lane16 = (unsigned)lane * 16u;
+    constexpr int PIECES = NIN + NWT_D;
+    auto stage_piece = [&](int kc, u32x4* in_s, int pc) {
+        if (pc < NIN) {
+            rin[pc] = __builtin_amdgcn_raw_buffer_load_b128(in_rs, gin[pc], (unsigned)kc * 32u, 0);
+        } else {
+            const unsigned in_lds = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_address(in_s));
+            const int j = wave_u + NW * (pc - NIN);
+            if (NWT_D * NW == W_S / 64 || j < W_S / 64)
+                dma16(w_rd, in_lds + (unsigned)(IN_P + j * 64) * 16u, lane16, (unsigned)kc * W_S * 16u + (unsigned)j * 1024u);
+        }
+    };
+    auto stage_commit = [&](u32x4* in_s) {
+#pragma unroll
+        for (int i = 0; i < NIN; ++i) {
+            const int s = tid + i * NTHREADS;
+            u32x4* dst = (NIN * NTHREADS == IN_S || s < IN_S) ? in_s + (s & 1) * (IH * IW) + (s >> 1) : dummy_slot;
+            *dst = rin[i];
+        }
+    };
+    auto stage_wait = [&]() { __builtin_amdgcn_s_waitcnt(0x0F70); };      // vmcnt(0)
+
+    // ---- this wave's tiles: rows 2*wm, 2*wm + 1 of the workgroup's 8, all 64 columns; channels wn*64 .. +63
+    const int wm = wave >> 1, wn = wave & 1;
+    // pixel tile a (0..7): row 2*wm + (a >> 2), columns 16*(a & 3) ..+15. A-fragment slot of this lane for tap offset `off`:
+    //   grp*(IH*IW) + (2*wm + (a>>2))*IW + 16*(a&3) + l15 + off  =  a_lane + off + [(a>>2)*IW + 16*(a&3): immediate]
+    const int a_lane = grp * (IH * IW) + 2 * wm * IW + l15;
+    // channel tile bt (0..3): B-fragment slot = IN_P + tap*2*TN + grp*TN + wn*64 + 16*bt + l15 = w_lane + tap*2*TN + [16*bt]
+    const int w_lane = IN_P + grp * TN + wn * 64 + l15;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int bt = 0; bt < 4; ++bt) acc[a][bt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    u32x4 fa[4], fb[2][4];      // A: one set, refilled in place as soon as a tile's MFMAs are issued; B: one set per tap pair
+    auto tap_off = [](int t) { return (t / 3) * IW + t % 3; };
+    // Tap pairs are chosen so that the two taps of a pair differ by the same amount in most pairs and the lane-dependent part of
+    // an address is one of few registers: P0 = (0,1), P1 = (3,4), P2 = (6,7) (one column apart), P3 = (2,5) (one row apart),
+    // P4 = (8, zero weights).
+    // lane part of an address + stage base, per stage (index 0: stage A, 1: stage B): ten registers, every other part of an
+    // address is the immediate offset of the ds_read_b128
+    const unsigned ldsA = lds_address(stageA), ldsB = lds_address(stageB);
+    unsigned a_l1[2], a_lW[2], w_l1[2], w_l3[2], w_lZ[2];
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+        const unsigned base = st ? ldsB : ldsA;
+        a_l1[st] = base + (unsigned)(a_lane + sel) * 16u;
+        a_lW[st] = base + (unsigned)(a_lane + sel * IW) * 16u;
+        w_l1[st] = base + (unsigned)(w_lane + sel * 2 * TN) * 16u;
+        w_l3[st] = base + (unsigned)(w_lane + sel * 3 * 2 * TN) * 16u;
+        w_lZ[st] = base + (unsigned)(sel ? IN_S : w_lane + 8 * 2 * TN) * 16u;
+    }
+    // the shared pair [tap 8 of the even chunk (stage A) | tap 8 of the odd chunk (stage B)]: the stage is chosen by the lane
+    const unsigned a_lS = (sel ? ldsB : ldsA) + (unsigned)(a_lane + tap_off(8)) * 16u;
+    const unsigned w_lS = (sel ? ldsB : ldsA) + (unsigned)(w_lane + 8 * 2 * TN) * 16u;
+    // A fragment i of half-unit (pr, h) (tiles 4h..4h+3) out of stage st
+    auto read_a = [&](int st, int pr, int h, int i) -> u32x4 {      // st: 0 / 1 = a stage, 2 = the shared pair
+        const int a = 4 * h + i;
+        const int tile = (a >> 2) * IW + 16 * (a & 3);
+        if (st == 2) return s16_read(a_lS, tile * 16);
+        const int t0 = (pr == 0) ? 0 : (pr == 1) ? 3 : (pr == 2) ? 6 : (pr == 3) ? 2 : 8;
+        return s16_read((pr == 3) ? a_lW[st] : a_l1[st], (tap_off(t0) + tile) * 16);
+    };
+    auto read_b = [&](int st, int pr, int bt) -> u32x4 {
+        if (st == 2) return s16_read(w_lS, 16 * bt * 16);
+        if (pr == 4) return s16_read(w_lZ[st], 16 * bt * 16);
+        const int t0 = (pr == 0) ? 0 : (pr == 1) ? 3 : (pr == 2) ? 6 : 2;
+        return s16_read((pr == 3) ? w_l3[st] : w_l1[st], (t0 * 2 * TN + 16 * bt) * 16);
+    };
+
+    // the zero slots (never written by the staging: its masked-off stores go to dummy_slot)
+    if (tid < IN_P - IN_S) {
+        stageA[IN_S + tid] = u32x4{0u, 0u, 0u, 0u};
+        stageB[IN_S + tid] = u32x4{0u, 0u, 0u, 0u};
+    }
+#pragma unroll
+    for (int pc = 0; pc < PIECES; ++pc) stage_piece(0, stageA, pc);
+    stage_commit(stageA);
+    stage_wait();
+    __syncthreads();
+    // the reads of a second-half unit leave in the order A0 B0 B1 | A1 B2 B3 | A2 | A3; the prologue is such a unit
+    fa[0] = read_a(0, 0, 0, 0);
+    fb[0][0] = read_b(0, 0, 0);
+    fb[0][1] = read_b(0, 0, 1);
+    fa[1] = read_a(0, 0, 0, 1);
+    fb[0][2] = read_b(0, 0, 2);
+    fb[0][3] = read_b(0, 0, 3);
+    fa[2] = read_a(0, 0, 0, 2);
+    fa[3] = read_a(0, 0, 0, 3);
+
+    // Two K chunks (an even one in stage A, the odd one behind it in stage B) = 18 half-units of 16 MFMAs (4 pixel tiles x 4
+    // channel tiles): units 0-7 the four tap pairs of the even chunk, 8-9 the SHARED pair [tap 8 of the even chunk | tap 8 of the
+    // odd chunk] (no half-empty MFMA for the ninth tap), 10-17 the four pairs of the odd chunk. A tile's fragment is refilled for
+    // the next unit right behind its four MFMAs (12 MFMAs of lead), the next pair's B fragments are read behind the first two
+    // tiles of a pair's second half. Staging: the odd chunk leaves for stage B in units 0-4 (register part committed in unit 5),
+    // the next even chunk for stage A in units 10-14 (15). Barriers: in front of unit 7 (its refills read the shared pair: stage B
+    // must have landed), behind unit 9 (every wave has read tap 8 out of stage A before anyone overwrites it), in front of unit
+    // 17 (its refills read the next even chunk). q = B set of this pair of chunks' first tap pair (9 pairs: it flips every time).
+    auto chunk_pair = [&](int q, int kc) {
+        const int kn2 = (kc + 2 < nkc) ? kc + 2 : kc;      // behind the last pair the even stage is refilled with itself (never read)
+#pragma unroll
+        for (int u = 0; u < 18; ++u) {
+            // what unit u multiplies
+            const int h = u & 1;
+            const int pseq = u >> 1;                       // pair number in the sequence: 0-3 even chunk, 4 shared, 5-8 odd chunk
+            const int sb = (q + pseq) & 1;
+            // what unit u + 1 reads (u = 17: unit 0 of the next chunk pair, out of stage A)
+            const int un = (u + 1) % 18;
+            const int hn = un & 1, pseqn = un >> 1;
+            const int stn = (pseqn < 4) ? 0 : (pseqn == 4) ? 2 : 1;
+            const int prn = (pseqn < 4) ? pseqn : (pseqn == 4) ? 4 : pseqn - 5;
+            const int sbn = (u == 17) ? ((q + 9) & 1) : ((q + pseqn) & 1);
+            if (u == 7 || u == 17) {
+                stage_wait();
+                __syncthreads();
+            }
+#pragma unroll
+            for (int pc = 0; pc < PIECES; ++pc) {
+                if (pc * WITW_BF_S16_SPREAD / PIECES == u) stage_piece(kc + 1, stageB, pc);
+                if (pc * WITW_BF_S16_SPREAD / PIECES + 10 == u) stage_piece(kn2, stageA, pc);
+            }
+            if (u == 5) stage_commit(stageB);
+            if (u == 15) stage_commit(stageA);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (h == 0) {       // the previous unit issued A0 B0 B1 A1 B2 B3 A2 A3
+                    if (i == 0) s16_wait5(2, fa[0], fb[sb][0], fb[sb][1], fb[sb][2], fb[sb][3]);
+                    else s16_wait(i == 1 ? 5 : 3, fa[i]);
+                } else {            // the previous unit issued A0 A1 A2 A3
+                    s16_wait(i == 0 ? 3 : i == 1 ? 5 : 7, fa[i]);
+                }
+#pragma unroll
+                for (int bt = 0; bt < 4; ++bt)
+                    acc[4 * h + i][bt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[i]),
+                                                                                  __builtin_bit_cast(bf16x8, fb[sb][bt]), acc[4 * h + i][bt], 0, 0, 0);
+                fa[i] = read_a(stn, prn, hn, i);
+                if (h == 1 && i < 2) {
+                    fb[sbn][2 * i] = read_b(stn, prn, 2 * i);
+                    fb[sbn][2 * i + 1] = read_b(stn, prn, 2 * i + 1);
+                }
+            }
+            if (u == 9) __syncthreads();
+        }
+    };
+    for (int kc = 0; kc < nkc; kc += 4) {
+        chunk_pair(0, kc);
+        if (kc + 2 < nkc) chunk_pair(1, kc + 2);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the last unit's refills (never used) must have landed before the slabs
+    __syncthreads();      // the slabs below reuse the stages
+
+    // ---- epilogue: bias + ReLU (+ 2x2 max-pool) -> wave-private fp32 slab [pixel][64 channels] -> 8 bf16 channels (16 B) per lane
+    const int cb = n0 + wn * 64;
+    float bv[4];
+#pragma unroll
+    for (int bt = 0; bt < 4; ++bt) bv[bt] = p.bias[cb + 16 * bt + l15];
+    auto fin = [&](float v, int bt) {
+        v += bv[bt];
+        if (p.relu) v = fmaxf(v, 0.f);
+        return v;
+    };
+    const int Hy = POOL ? (p.Ho >> 1) : p.Ho;
+    const int Wy = POOL ? (p.Wo >> 1) : p.Wo;
+    float* slab = reinterpret_cast<float*>((wave & 1) ? stageB : stageA) + (wave >> 1) * (32 * SLAB_P);
+    const int prow = lane >> 3, pc8 = (lane & 7) * 8;      // read-back role: pixel row in a group of 8, channel octet
+    auto flush = [&](int yy, int xbase) {      // 32 slab rows -> 32 pixels xbase.. of output row yy
+        const int nbase = cb + pc8;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int m = g * 8 + prow;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(slab + m * SLAB_P + pc8);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(slab + m * SLAB_P + pc8 + 4);
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o[e] = (__bf16)v0[e];
+                o[4 + e] = (__bf16)v1[e];
+            }
+            const int xx = xbase + m;
+            if (yy < Hy && xx < Wy && nbase < p.Cout)
+                __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p.y) + (((size_t)b * Hy + yy) * Wy + xx) * p.Cout + nbase));
+        }
+    };
+    if (!POOL) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {          // tiles 2q, 2q+1: 32 consecutive pixels of one row
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int bt = 0; bt < 4; ++bt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        slab[(16 * i + 4 * kg + r) * SLAB_P + 16 * bt + l15] = fin(acc[2 * q + i][bt][r], bt);
+            flush(oy0 + 2 * wm + (q >> 1), ox0 + 32 * (q & 1));
+        }
+    } else {
+        // 2x2 max-pool: vertical partner = tile a + 4 (the row below, same lane and register), horizontal partner = register r ^ 1;
+        // the wave's 2 x 64 pixels become one row of 32 pooled pixels: pooled column 8*(a & 3) + 2*kg + e
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int bt = 0; bt < 4; ++bt)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float m4 = fmaxf(fmaxf(acc[a][bt][2 * e], acc[a][bt][2 * e + 1]), fmaxf(acc[a + 4][bt][2 * e], acc[a + 4][bt][2 * e + 1]));
+                    slab[(8 * a + 2 * kg + e) * SLAB_P + 16 * bt + l15] = fin(m4, bt);
+                }
+        flush((oy0 >> 1) + wm, ox0 >> 1);
+    }
+}
+
 // wpk[nt][kc][tap][g][n][0..7] (bf16) <- w[cout][cin][kh][kw] (fp32, torch KCRS); one thread per 16-B slot.
 // transpose_flip != 0 builds the dgrad filter instead: (Cout, Cin) describe the PACKED filter, the source tensor is
 // [Cin][Cout][3][3] and w'[co][ci][kh][kw] = w[ci][co][2-kh][2-kw].
@@ -777,9 +1098,42 @@ int launch_bf_nw(ConvBfArgs a, hipStream_t st) {
     return WITW_OK;
 }
 
+// 1: layers that qualify run on the 16x16x32 kernel (default; WITW_BF_S16=0 or witw_conv3x3_bf16_mfma16(0) turn it off)
+int g_bf16_mfma16 = -1;
+int bf16_mfma16() {
+    if (g_bf16_mfma16 < 0) {
+        const char* e = getenv("WITW_BF_S16");
+        g_bf16_mfma16 = e ? (atoi(e) != 0) : 1;
+    }
+    return g_bf16_mfma16;
+}
+
+template <bool POOL>
+int launch_bf_s16(ConvBfArgs a, hipStream_t st) {
+    a.tiles_y = cdiv(a.Ho, 8);
+    const long long sp_total = (long long)a.B * a.tiles_x * a.tiles_y;
+    a.n_tiles = cdiv(a.Cout, 128);
+    a.sp_per_xcd = (int)((sp_total + 7) / 8);
+    const long long grid = a.xcd_map ? 8LL * a.sp_per_xcd * a.n_tiles : sp_total * a.n_tiles;
+    if (grid <= 0 || grid > 0x7fffffffLL || sp_total > 0x7fffffffLL) {
+        witw_set_error("conv3x3_bf16: grid %lld out of range", grid);
+        return WITW_ERR_INVALID;
+    }
+    a.sp_total = (int)sp_total;
+    hipLaunchKernelGGL((conv3x3_bf16_s16_kernel<POOL>), dim3((unsigned)grid), dim3(512), 0, st, a);
+    WITW_CHECK_LAUNCH("conv3x3_bf16_s16");
+    return WITW_OK;
+}
+
 template <int TN, int SH, bool POOL>
 int launch_bf(const ConvBfArgs& a, hipStream_t st) {
     const long long big = (long long)cdiv(a.Cout, TN) * a.B * a.tiles_x * cdiv(a.Ho, 8);
+    if constexpr (TN == 128 && SH == 1) {
+        // the 16x16x32 form: plain inference forward (bf16 NHWC out) of layers large enough for the 8-wave tile
+        if (bf16_mfma16() && (a.Ho % 8) == 0 && big >= 512 && !a.gate && !a.dropmask && !a.pool_code && !a.out_nchw_f32 && !a.dil_h &&
+            (a.Cout & 7) == 0 && (a.Cin & 31) == 0)
+            return launch_bf_s16<POOL>(a, st);
+    }
     if ((a.Ho % 8) == 0 && big >= 512) return launch_bf_nw<TN, SH, POOL, 8>(a, st);
     return launch_bf_nw<TN, SH, POOL, 4>(a, st);
 }
@@ -791,6 +1145,16 @@ unsigned long long* witw_bf16_stamps_ptr = nullptr;
 #endif
 
 extern "C" {
+
+// Which MFMA shape the bf16 inference forward uses where both kernels apply (Cout >= 128, stride 1, >= 512 workgroups of 8
+// waves, Cin % 32 == 0, bf16 NHWC out, no gate / Dropout2d scale / pool codes): 1 = v_mfma_f32_16x16x32_bf16 (default: the chip
+// holds a higher clock on it), 0 = v_mfma_f32_32x32x16_bf16. enable < 0 only queries. Returns the previous setting. The two
+// kernels agree to one bf16 unit in the last place (different fp32 summation order).
+int witw_conv3x3_bf16_mfma16(int enable) {
+    const int prev = bf16_mfma16();
+    if (enable >= 0) g_bf16_mfma16 = enable != 0;
+    return prev;
+}
 
 long long witw_conv3x3_bf16_packed_elems(int cout, int cin) {
     if (cout <= 0 || cin <= 0) return -1;

@@ -873,6 +873,12 @@ def exhaustive_triplet_loss(D, soft_margin=False, alpha=10., margin=1.):
 
 
 # ----------------------------------------------------------------------------- bf16 inference path
+def bf16_mfma16(enable=None):
+    """MFMA shape of the bf16 inference forward where both kernels apply: True = 16x16x32 (default), False = 32x32x16; None only
+    queries. Returns the previous setting (witw_conv3x3_bf16_mfma16)."""
+    return bool(_lib.load().witw_conv3x3_bf16_mfma16(-1 if enable is None else int(bool(enable))))
+
+
 class PackedConvBf16:
     """bf16 filter packing of one 3x3 conv for the bf16 MFMA kernel + fp32 bias padded to the channel tile."""
 
