@@ -126,13 +126,14 @@ def test_encoder_bf16_with_and_without_the_fused_launch():
 
 
 @pytest.mark.parametrize('case', [(32, 32, 128, 128, 256, False, False), (32, 32, 128, 128, 256, True, True), (64, 16, 64, 512, 512, False, True),
-                                  (40, 64, 200, 64, 128, True, False), (24, 40, 70, 256, 384, False, False), (33, 24, 130, 256, 128, False, False),
+                                  (40, 64, 200, 64, 128, True, False), (24, 40, 70, 256, 384, False, False), (32, 32, 128, 96, 256, False, True),
+                                  (32, 32, 128, 160, 128, True, False), (33, 24, 130, 256, 128, False, False),
                                   (32, 32, 128, 48, 256, False, False)])
 def test_bf16_mfma16_kernel_matches_the_32x32_kernel(case):
     """The 16x16x32 form of the bf16 inference forward (two taps of a 16-channel chunk per MFMA, the ninth tap of an even chunk
     sharing its MFMA with the ninth tap of the next chunk) against the 32x32x16 kernel on layers large enough for the 8-wave tile:
     the same products summed in fp32 in a different order, so outputs agree to one bf16 unit in the last place and almost all
-    are identical; ragged widths, circular and zero padding, the fused pool. The last two cases do not qualify (fewer than 512
+    are identical; ragged widths, circular and zero padding, the fused pool, odd and even numbers of chunk pairs. The last two cases do not qualify (fewer than 512
     workgroups; Cin % 32 != 0) and must be bit-identical whatever the switch says."""
     import torch
     from witw_amd import ops

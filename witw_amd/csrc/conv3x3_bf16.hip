@@ -733,20 +733,20 @@ __device__ __forceinline__ void s16_wait5(int n, u32x4& a, u32x4& b0, u32x4& b1,
 //   (tap of the pair, channel group). A fragment = 16 pixels of one row x {tap a, tap b} x 2 groups = one ds_read_b128 whose
 //   lane address is base + (tap offset by lane), B fragment = 16 output channels likewise. A wave's 2 rows x 64 pixels x 64
 //   channels are 8 x 4 tiles of 16 x 16 (4 accumulation registers each: register r of lane l = pixel 4*(l>>4) + r, channel l & 15).
-//   The 9 taps of a chunk make 4 pairs + tap 8, whose partner half multiplies a zero slot (the padding slots of a stage).
+//   The taps 0..7 of a chunk make 4 pairs; tap 8 of an even chunk shares its MFMA with tap 8 of the odd chunk behind it (k-groups
+//   0,1 read stage A, k-groups 2,3 stage B), so no MFMA runs half empty: two chunks = 18 half-units of 16 MFMAs.
 template <bool POOL>
 __global__ __launch_bounds__(512) void conv3x3_bf16_s16_kernel(ConvBfArgs p) {
     constexpr int TN = 128, NW = 8, TH = 8, NTHREADS = 512;
     constexpr int IH = TH + 2;
     constexpr int IN_S = 2 * IH * IW;
-    constexpr int IN_P = (IN_S + 64 + 63) / 64 * 64;      // + 64 zero slots behind the tile (the partner half of tap 8 multiplies them)
+    constexpr int IN_P = (IN_S + 63) / 64 * 64;
     constexpr int W_S = 9 * 2 * TN;
     constexpr int STAGE_S = IN_P + W_S;
     constexpr int NIN = (IN_S + NTHREADS - 1) / NTHREADS;
     constexpr int NWT_D = (W_S / 64 + NW - 1) / NW;
     constexpr unsigned OOR = 0x80000000u;
     constexpr int SLAB_P = 68;      // floats per slab row: 64 channels + 4 (the four 16-lane groups of a write land on different banks)
-    static_assert(IN_P >= IN_S + 64, "the zero slots live in the padding of the input stage");
     static_assert(STAGE_S * 16 >= (NW / 2) * 32 * SLAB_P * 4, "a stage must hold the epilogue slabs of half the waves");
 
     __shared__ u32x4 stageA[STAGE_S];
@@ -839,12 +839,12 @@ __global__ __launch_bounds__(512) void conv3x3_bf16_s16_kernel(ConvBfArgs p) {
     u32x4 fa[4], fb[2][4];      // A: one set, refilled in place as soon as a tile's MFMAs are issued; B: one set per tap pair
     auto tap_off = [](int t) { return (t / 3) * IW + t % 3; };
     // Tap pairs are chosen so that the two taps of a pair differ by the same amount in most pairs and the lane-dependent part of
-    // an address is one of few registers: P0 = (0,1), P1 = (3,4), P2 = (6,7) (one column apart), P3 = (2,5) (one row apart),
-    // P4 = (8, zero weights).
+    // an address is one of few registers: P0 = (0,1), P1 = (3,4), P2 = (6,7) (one column apart), P3 = (2,5) (one row apart);
+    // tap 8 goes into the shared pair.
     // lane part of an address + stage base, per stage (index 0: stage A, 1: stage B): ten registers, every other part of an
     // address is the immediate offset of the ds_read_b128
     const unsigned ldsA = lds_address(stageA), ldsB = lds_address(stageB);
-    unsigned a_l1[2], a_lW[2], w_l1[2], w_l3[2], w_lZ[2];
+    unsigned a_l1[2], a_lW[2], w_l1[2], w_l3[2];
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
         const unsigned base = st ? ldsB : ldsA;
@@ -852,7 +852,6 @@ __global__ __launch_bounds__(512) void conv3x3_bf16_s16_kernel(ConvBfArgs p) {
         a_lW[st] = base + (unsigned)(a_lane + sel * IW) * 16u;
         w_l1[st] = base + (unsigned)(w_lane + sel * 2 * TN) * 16u;
         w_l3[st] = base + (unsigned)(w_lane + sel * 3 * 2 * TN) * 16u;
-        w_lZ[st] = base + (unsigned)(sel ? IN_S : w_lane + 8 * 2 * TN) * 16u;
     }
     // the shared pair [tap 8 of the even chunk (stage A) | tap 8 of the odd chunk (stage B)]: the stage is chosen by the lane
     const unsigned a_lS = (sel ? ldsB : ldsA) + (unsigned)(a_lane + tap_off(8)) * 16u;
@@ -862,21 +861,15 @@ __global__ __launch_bounds__(512) void conv3x3_bf16_s16_kernel(ConvBfArgs p) {
         const int a = 4 * h + i;
         const int tile = (a >> 2) * IW + 16 * (a & 3);
         if (st == 2) return s16_read(a_lS, tile * 16);
-        const int t0 = (pr == 0) ? 0 : (pr == 1) ? 3 : (pr == 2) ? 6 : (pr == 3) ? 2 : 8;
+        const int t0 = (pr == 0) ? 0 : (pr == 1) ? 3 : (pr == 2) ? 6 : 2;
         return s16_read((pr == 3) ? a_lW[st] : a_l1[st], (tap_off(t0) + tile) * 16);
     };
     auto read_b = [&](int st, int pr, int bt) -> u32x4 {
         if (st == 2) return s16_read(w_lS, 16 * bt * 16);
-        if (pr == 4) return s16_read(w_lZ[st], 16 * bt * 16);
         const int t0 = (pr == 0) ? 0 : (pr == 1) ? 3 : (pr == 2) ? 6 : 2;
         return s16_read((pr == 3) ? w_l3[st] : w_l1[st], (t0 * 2 * TN + 16 * bt) * 16);
     };
 
-    // the zero slots (never written by the staging: its masked-off stores go to dummy_slot)
-    if (tid < IN_P - IN_S) {
-        stageA[IN_S + tid] = u32x4{0u, 0u, 0u, 0u};
-        stageB[IN_S + tid] = u32x4{0u, 0u, 0u, 0u};
-    }
 #pragma unroll
     for (int pc = 0; pc < PIECES; ++pc) stage_piece(0, stageA, pc);
     stage_commit(stageA);
