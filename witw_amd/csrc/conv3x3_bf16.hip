@@ -31,6 +31,9 @@ constexpr int IW = TW + 2;
 #define WITW_BF_SWAP 0          // A/B builds: 1 = MFMA operands swapped (lane = pixel, register quad = 4 consecutive channels), the
 #endif                          //     epilogue transposes through LDS with 8-byte writes (12 instead of 40 LDS instructions per M-tile).
                                 //     Parity-green, but measured SLOWER per tile (epilogue 9.1 k -> 11.9 k ticks)
+#ifndef WITW_BF_S16_DMA
+#define WITW_BF_S16_DMA 0       // 16x16x32 kernel: 1 = the input tile moves by LDS-DMA as well (A/B builds)
+#endif
 #ifndef WITW_BF_S16_SPREAD
 #define WITW_BF_S16_SPREAD 3    // half-units (of 8 per chunk) over which the 16x16x32 kernel issues the staging pieces of the next chunk
 #endif
@@ -782,6 +785,31 @@ __global__ __launch_bounds__(512) void conv3x3_bf16_s16_kernel(ConvBfArgs p) {
     __amdgpu_buffer_rsrc_t in_rs =
         __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)b * img_elems), 0, (unsigned)(img_elems * 2), 0x00020000);
     const i32x4 w_rd = raw_rsrc(reinterpret_cast<const u32x4*>(p.wpk) + (size_t)ntile * nkc * W_S, (unsigned)nkc * W_S * 16u);
+#if WITW_BF_S16_DMA
+    // input tile by LDS-DMA too: slot s = instruction * 64 + lane IS the LDS position [group][pixel]; no register transit
+    constexpr int NIN_D = (IN_P / 64 + NW - 1) / NW;
+    const i32x4 in_rd = raw_rsrc(p.x + (size_t)b * img_elems, (unsigned)(img_elems * 2));
+    unsigned gin[NIN_D];
+#pragma unroll
+    for (int i = 0; i < NIN_D; ++i) {
+        const int s = (wave + NW * i) * 64 + lane;
+        const int q = s / (IH * IW);
+        const int pix = s - q * (IH * IW);
+        const int r = pix / IW, c = pix - r * IW;
+        const int gr = oy0 - 1 + r;
+        int gc = ox0 - 1 + c;
+        bool ok = s < IN_S && gr >= 0 && gr < p.H;
+        if (p.circ) {
+            gc %= p.W;
+            if (gc < 0) gc += p.W;
+        } else {
+            ok = ok && gc >= 0 && gc < p.W;
+        }
+        gin[i] = ok ? (unsigned)((((size_t)gr * p.W + gc) * p.Cin + q * 8) * 2) : OOR;
+    }
+    constexpr int P_IN = NIN_D;
+#else
+    constexpr int P_IN = NIN;
     unsigned gin[NIN];
 #pragma unroll
     for (int i = 0; i < NIN; ++i) {
@@ -800,25 +828,36 @@ __global__ __launch_bounds__(512) void conv3x3_bf16_s16_kernel(ConvBfArgs p) {
         gin[i] = ok ? (unsigned)((((size_t)gr * p.W + gc) * p.Cin + q * 8) * 2) : OOR;
     }
     u32x4 rin[NIN];
+#endif
     const unsigned lane16 = (unsigned)lane * 16u;
-    constexpr int PIECES = NIN + NWT_D;
+    constexpr int PIECES = P_IN + NWT_D;
     auto stage_piece = [&](int kc, u32x4* in_s, int pc) {
-        if (pc < NIN) {
+        if (pc < P_IN) {
+#if WITW_BF_S16_DMA
+            const unsigned in_lds = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_address(in_s));
+            const int j = wave_u + NW * pc;
+            if (NIN_D * NW == IN_P / 64 || j < IN_P / 64) dma16(in_rd, in_lds + (unsigned)j * 1024u, gin[pc], (unsigned)kc * 32u);
+#else
             rin[pc] = __builtin_amdgcn_raw_buffer_load_b128(in_rs, gin[pc], (unsigned)kc * 32u, 0);
+#endif
         } else {
             const unsigned in_lds = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_address(in_s));
-            const int j = wave_u + NW * (pc - NIN);
+            const int j = wave_u + NW * (pc - P_IN);
             if (NWT_D * NW == W_S / 64 || j < W_S / 64)
                 dma16(w_rd, in_lds + (unsigned)(IN_P + j * 64) * 16u, lane16, (unsigned)kc * W_S * 16u + (unsigned)j * 1024u);
         }
     };
     auto stage_commit = [&](u32x4* in_s) {
+#if WITW_BF_S16_DMA
+        (void)in_s; (void)dummy_slot;
+#else
 #pragma unroll
         for (int i = 0; i < NIN; ++i) {
             const int s = tid + i * NTHREADS;
             u32x4* dst = (NIN * NTHREADS == IN_S || s < IN_S) ? in_s + (s & 1) * (IH * IW) + (s >> 1) : dummy_slot;
             *dst = rin[i];
         }
+#endif
     };
     auto stage_wait = [&]() { __builtin_amdgcn_s_waitcnt(0x0F70); };      // vmcnt(0)
 
