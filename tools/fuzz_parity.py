@@ -7,7 +7,7 @@ shapes through the C ABI, compared with torch CPU ops in the reference's op orde
 Covers: fp32 conv forward (stride, circular/zero padding, ReLU, fused pool, GEO / NW variants by shape), its dgrad
 form, fp32 wgrad (+ bias), the 4-tap forms, bf16 conv forward / wgrad, the fused match (orientation exact, distance
 1e-5) with ragged batch sizes and widths (direct and spectral forms), the fp16x3 conv forward / dgrad form (gate, Dropout2d scale, zero-interleaved
-rows) / wgrad against fp64, the 4-tap conv's space-to-depth epilogue (bitwise) and its split-K mosaic form. FUZZ_KINDS=10,11 restricts the sweep to the listed kinds. Prints one line per failure and a summary; exit code 1 on any failure.
+rows) / wgrad against fp64, the 4-tap conv's space-to-depth epilogue (bitwise) and its split-K mosaic form, the bf16 16x16x32 kernel against the 32x32x16 kernel. FUZZ_KINDS=10,11 restricts the sweep to the listed kinds. Prints one line per failure and a summary; exit code 1 on any failure.
 """
 import os
 import sys
@@ -43,7 +43,7 @@ def main():
 
     while time.time() - t0 < budget:
         n += 1
-        kind = rng.integers(0, 16)
+        kind = rng.integers(0, 17)
         if os.environ.get('FUZZ_KINDS') and str(int(kind)) not in os.environ['FUZZ_KINDS'].split(','):
             continue
         B = int(rng.integers(1, 5))
@@ -137,6 +137,28 @@ def main():
                     ks = None
                 got = ops.conv_taps4_splitk(xm.to(dev), pk, n_img, g, (h - 1, h - 1), lrelu_slope=0.2, ksplit=ks)
                 check('taps4_splitk', (n_img, g, h, cin2, cout, ks), got.cpu(), y.cpu(), 2e-5)
+            elif kind == 16:    # bf16 forward: the 16x16x32 kernel against the 32x32x16 kernel on layers that take the 8-wave tile
+                cin2 = int(rng.choice([32, 64, 96, 128, 160, 256]))
+                cout2 = int(rng.choice([128, 144, 256, 384]))
+                H2 = 8 * int(rng.integers(1, 5))
+                W2 = int(rng.integers(1, 200))
+                nt = (cout2 + 127) // 128
+                B2 = (512 + nt * ((W2 + 63) // 64) * (H2 // 8) - 1) // (nt * ((W2 + 63) // 64) * (H2 // 8)) + int(rng.integers(0, 3))
+                if B2 * H2 * W2 * max(cin2, cout2) > 6e8:
+                    continue
+                pool = bool(rng.integers(0, 2)) and H2 >= 2 and W2 >= 2
+                x2 = torch.randn(B2, H2, W2, cin2, device=dev).bfloat16()
+                pk = ops.PackedConvBf16((torch.randn(cout2, cin2, 3, 3) * (2.0 / (9 * cin2)) ** 0.5).to(dev), (torch.randn(cout2) * 0.1).to(dev))
+                prev = ops.bf16_mfma16(False)
+                try:
+                    y32 = ops.conv3x3_bf16_fwd(x2, pk, circular=circ, relu=relu, pool=pool).float()
+                    ops.bf16_mfma16(True)
+                    y16 = ops.conv3x3_bf16_fwd(x2, pk, circular=circ, relu=relu, pool=pool).float()
+                finally:
+                    ops.bf16_mfma16(prev)
+                bad = (y32 - y16).abs() > 2.0 ** -7 * torch.maximum(y32.abs(), y16.abs()) + 1e-5 * float(y32.abs().max())
+                if bool(bad.any()):
+                    check('bf16_mfma16', (B2, H2, W2, cin2, cout2, circ, relu, pool), y16.cpu(), y32.cpu(), 0.0)
             elif kind == 3:     # bf16 forward vs emulation
                 cin16 = (cin + 15) // 16 * 16
                 x = torch.randn(B, cin16, H, W).bfloat16().float()
