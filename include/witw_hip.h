@@ -25,6 +25,10 @@ extern "C" {
 const char* witw_last_error(void);
 int witw_version(void);               /* major*10000 + minor*100 + patch */
 int witw_device_check(int device);    /* 0 iff `device` is a gfx950 part */
+/* name of the conv kernel instantiation the calling thread's last conv launcher picked, spelled as in rocprof kernel names
+ * (e.g. "conv3x3_bf16_s16_kernel<false>"); "" before the first launch. Parity tests assert on it so that a change of the
+ * launcher's thresholds cannot silently move a test onto another kernel. */
+const char* witw_last_kernel_variant(void);
 
 /* ---- FOV_DSM encoder: Conv2d(3x3,pad 1) [+HorizCircPadding] [+Dropout2d] [+ReLU] [+MaxPool2d(2)]
  *      reference: model/cvig_fov.py:212-231 (padding), :234-245 (dropout), :256-294 (layer stack).

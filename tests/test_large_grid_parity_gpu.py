@@ -1,0 +1,204 @@
+"""Large-grid kernel variants against the ORACLE (not against another HIP kernel).
+
+The conv launchers pick a different instantiation from 512 workgroups on (8-wave tiles; for the bf16 inference forward the
+16x16x32-MFMA kernel conv3x3_bf16_s16_kernel). Batches of 1-12 images never get there, so these cases use the batch sizes the
+benchmarks run (BASELINE configs[1] / configs[3]: 128 images, layers of model/cvig_fov.py:256-272 and
+model/cvig_semantic.py:275-325), compare a spread of images of the batch with the CPU oracle (images are independent, the
+kernel still sees the whole batch) and ASSERT WHICH KERNEL RAN through witw_last_kernel_variant(), so a change of the launcher's
+thresholds cannot silently move a case back onto the small-grid kernel.
+
+Tolerances: bf16 outputs within one bf16 unit in the last place of the oracle's conv on bf16-rounded operands (fp32
+accumulation, different summation order); fp32 kernels 3e-5 of the output scale; fp16x3 5e-6 against fp64."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cvig_fov_oracle as O
+from witw_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _layer(seed, B, H, W, cin, cout):
+    g = np.random.Generator(np.random.Philox(key=[seed, cin * 1000 + cout]))
+    x = torch.from_numpy(g.standard_normal((B, cin, H, W), dtype=np.float32))
+    w = torch.from_numpy(g.standard_normal((cout, cin, 3, 3), dtype=np.float32) * (2.0 / (9 * cin)) ** 0.5)
+    b = torch.from_numpy(g.standard_normal((cout,), dtype=np.float32) * 0.1)
+    return x, w, b
+
+
+def _pick(B):
+    """images of the batch the oracle is run on: both ends, the middle, one odd index (different XCDs / workgroup ranges)"""
+    return sorted({0, B // 3, B // 2 + 1, B - 1})
+
+
+def _ref(x, w, b, sh, circ, relu, pool):
+    r = O.conv3x3(x, w, b, sh, circ)
+    if relu:
+        r = torch.relu(r)
+    if pool:
+        r = torch.nn.functional.max_pool2d(r, 2, 2)
+    return r
+
+
+def _assert_bf16_ulp(got, ref):
+    r16 = ref.bfloat16().float()
+    bad = (got - r16).abs() > 2.0 ** -7 * torch.maximum(r16.abs(), got.abs()) + 1e-6
+    # an fp32 sum that lands within rounding of a bf16 tie may round to the neighbour: still one unit in the last place
+    assert not bool(bad.any()), (int(bad.sum()), float((got - r16).abs().max()))
+    assert float((got == r16).float().mean()) > 0.97
+
+
+# (B, H, W, Cin, Cout, stride_h, circular, pool, mfma16 switch, expected kernel)
+BF16_CASES = [
+    # the config-4 dominant kernel on the layer shapes the bench runs (layers 10/12, 17/19/21, 5, 7 of the encoder)
+    (32, 32, 128, 128, 256, 1, False, False, True, 'conv3x3_bf16_s16_kernel<false>'),
+    (32, 32, 128, 256, 256, 1, True, True, True, 'conv3x3_bf16_s16_kernel<true>'),
+    (64, 16, 64, 512, 512, 1, True, False, True, 'conv3x3_bf16_s16_kernel<false>'),
+    (64, 16, 64, 256, 512, 1, False, False, True, 'conv3x3_bf16_s16_kernel<false>'),
+    (16, 64, 256, 64, 128, 1, True, False, True, 'conv3x3_bf16_s16_kernel<false>'),
+    (16, 64, 256, 128, 128, 1, False, True, True, 'conv3x3_bf16_s16_kernel<true>'),
+    (44, 24, 100, 96, 144, 1, True, False, True, 'conv3x3_bf16_s16_kernel<false>'),      # ragged width / channels, odd chunk pairs
+    # the 8-wave 32x32x16 kernel: with the switch off, and where the 16x16x32 kernel does not apply
+    (32, 32, 128, 128, 256, 1, True, False, False, 'conv3x3_nhwc_bf16_kernel<128,1,false,8>'),
+    (32, 32, 128, 128, 256, 1, False, True, False, 'conv3x3_nhwc_bf16_kernel<128,1,true,8>'),
+    (32, 32, 128, 48, 256, 1, False, False, True, 'conv3x3_nhwc_bf16_kernel<128,1,false,8>'),     # Cin % 32 != 0
+    (128, 32, 64, 512, 256, 2, True, False, True, 'conv3x3_nhwc_bf16_kernel<128,2,false,8>'),     # stride (2,1) as layer 23
+    (16, 64, 256, 64, 64, 1, False, True, True, 'conv3x3_nhwc_bf16_kernel<64,1,true,8>'),         # layer 2 shape at half size
+    (16, 64, 256, 64, 64, 1, True, False, True, 'conv3x3_nhwc_bf16_kernel<64,1,false,8>'),
+]
+
+
+@pytest.mark.parametrize('case', BF16_CASES)
+def test_bf16_large_grid_kernels_vs_oracle(case):
+    from witw_amd import ops
+    B, H, W, cin, cout, sh, circ, pool, s16, want = case
+    x, w, b = _layer(31, B, H, W, cin, cout)
+    x = x.bfloat16().float()
+    dev = torch.device('cuda:0')
+    pk = ops.PackedConvBf16(w.to(dev), b.to(dev))
+    xd = x.to(dev).permute(0, 2, 3, 1).contiguous().bfloat16()
+    prev = ops.bf16_mfma16(s16)
+    try:
+        y = ops.conv3x3_bf16_fwd(xd, pk, stride_h=sh, circular=circ, relu=True, pool=pool)
+        assert ops.last_kernel_variant() == want, ops.last_kernel_variant()
+    finally:
+        ops.bf16_mfma16(prev)
+    sel = _pick(B)
+    ref = _ref(x[sel], w.bfloat16().float(), b, sh, circ, True, pool)
+    _assert_bf16_ulp(y[sel].float().cpu().permute(0, 3, 1, 2), ref)
+
+
+def test_bf16_large_grid_fp32_nchw_output_vs_oracle():
+    """the embedding layer's form (fp32 NCHW out, no ReLU) on an 8-wave grid: exact products, fp32 sums"""
+    from witw_amd import ops
+    B, H, W, cin, cout = 512, 8, 64, 64, 128
+    x, w, b = _layer(33, B, H, W, cin, cout)
+    x = x.bfloat16().float()
+    dev = torch.device('cuda:0')
+    y = ops.conv3x3_bf16_fwd(x.to(dev).permute(0, 2, 3, 1).contiguous().bfloat16(), ops.PackedConvBf16(w.to(dev), b.to(dev)),
+                             circular=True, relu=False, out_nchw_f32=True)
+    assert ops.last_kernel_variant() == 'conv3x3_nhwc_bf16_kernel<128,1,false,8>', ops.last_kernel_variant()
+    sel = _pick(B)
+    ref = _ref(x[sel], w.bfloat16().float(), b, 1, True, False, False)
+    np.testing.assert_allclose(y[sel].cpu().numpy(), ref.numpy(), rtol=0, atol=2e-5 * float(ref.abs().max()))
+
+
+F32_CASES = [
+    (32, 32, 128, 128, 256, 1, True, False, 'conv3x3_nhwc_f32_kernel<128,1,false,8,0,9>'),      # the headline's dominant kernel
+    (64, 16, 64, 256, 512, 1, False, False, 'conv3x3_nhwc_f32_kernel<128,1,false,8,0,9>'),
+    (16, 64, 256, 64, 128, 1, False, True, 'conv3x3_nhwc_f32_kernel<128,1,true,8,0,9>'),
+    (16, 64, 256, 64, 64, 1, True, True, 'conv3x3_nhwc_f32_kernel<64,1,true,8,0,9>'),
+    (128, 32, 64, 128, 256, 2, True, False, 'conv3x3_nhwc_f32_kernel<128,2,false,8,0,9>'),
+]
+
+
+@pytest.mark.parametrize('case', F32_CASES)
+def test_f32_large_grid_kernels_vs_oracle(case):
+    from witw_amd import ops
+    B, H, W, cin, cout, sh, circ, pool, want = case
+    x, w, b = _layer(35, B, H, W, cin, cout)
+    dev = torch.device('cuda:0')
+    y = ops.conv3x3_fwd(x.to(dev).permute(0, 2, 3, 1).contiguous(), ops.PackedConv(w.to(dev), b.to(dev)), stride_h=sh,
+                        circular=circ, relu=True, pool=pool)
+    assert ops.last_kernel_variant() == want, ops.last_kernel_variant()
+    sel = _pick(B)
+    ref = _ref(x[sel], w, b, sh, circ, True, pool)
+    np.testing.assert_allclose(y[sel].cpu().permute(0, 3, 1, 2).numpy(), ref.numpy(), rtol=0, atol=3e-5 * float(ref.abs().max()))
+
+
+F16X3_CASES = [
+    (32, 32, 128, 128, 256, 1, True, False, 'conv3x3_nhwc_f16x3_kernel<128,1,false,8>'),
+    (64, 16, 64, 256, 512, 1, False, False, 'conv3x3_nhwc_f16x3_kernel<128,1,false,8>'),
+    (16, 64, 256, 64, 128, 1, False, True, 'conv3x3_nhwc_f16x3_kernel<128,1,true,8>'),
+    (16, 64, 256, 64, 64, 1, True, True, 'conv3x3_nhwc_f16x3_kernel<64,1,true,8>'),
+]
+
+
+@pytest.mark.parametrize('case', F16X3_CASES)
+def test_f16x3_large_grid_kernels_vs_fp64_oracle(case):
+    from witw_amd import ops
+    B, H, W, cin, cout, sh, circ, pool, want = case
+    x, w, b = _layer(37, B, H, W, cin, cout)
+    dev = torch.device('cuda:0')
+    y = ops.conv3x3_f16x3_fwd(ops.nchw_to_split_f16(x.to(dev), cin), ops.PackedConvF16x3(w.to(dev), b.to(dev)), stride_h=sh,
+                              circular=circ, relu=True, pool=pool)
+    assert ops.last_kernel_variant() == want, ops.last_kernel_variant()
+    sel = _pick(B)
+    ref = _ref(x[sel].double(), w.double(), b.double(), sh, circ, True, pool).float()
+    got = ops.split_f16_to_f32(y[sel].contiguous()).cpu().permute(0, 3, 1, 2)
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=0, atol=5e-6 * max(1.0, float(ref.abs().max())))
+    assert not ops.f16x3_overflowed()
+
+
+def test_taps4_large_grid_kernel_vs_oracle():
+    """cvig_baseline's Conv2d(4,2,0) (model/cvig_baseline.py:236-252) as the 4-tap conv over space-to-depth channels, 8-wave
+    tile: against torch's conv2d with the 3x3 filter whose first row / column are zero."""
+    from witw_amd import ops
+    B, H, W, cin, cout = 128, 32, 64, 64, 128
+    x, w, b = _layer(39, B, H, W, cin, cout)
+    w[:, :, 0, :] = 0
+    w[:, :, :, 0] = 0
+    dev = torch.device('cuda:0')
+    y = ops.conv3x3_fwd(x.to(dev).permute(0, 2, 3, 1).contiguous(), ops.PackedConv(w.to(dev), b.to(dev), taps4=True), relu=True)
+    assert ops.last_kernel_variant() == 'conv3x3_nhwc_f32_kernel<128,1,false,8,0,4>', ops.last_kernel_variant()
+    sel = _pick(B)
+    ref = _ref(x[sel], w, b, 1, False, True, False)
+    np.testing.assert_allclose(y[sel].cpu().permute(0, 3, 1, 2).numpy(), ref.numpy(), rtol=0, atol=3e-5 * float(ref.abs().max()))
+
+
+@pytest.mark.parametrize('variant', ['semantic', 'fov'])
+def test_bf16_encoder_at_bench_batch_vs_emulation(variant, monkeypatch):
+    """The bf16 encoder at the batch size of BASELINE configs[3] (128: every layer from 5 to 21 on the large-grid kernels, as
+    in bench.py's config4_semantic_bf16 block) against the CPU emulation of 'fp32 algorithm + bf16 storage' on three images of
+    that batch, at the 1e-2 of tests/test_bf16_gpu.py. The kernels that ran are recorded per layer and asserted."""
+    from witw_amd import cvig_fov, cvig_semantic, ops
+    mod, c = (cvig_semantic, 5) if variant == 'semantic' else (cvig_fov, 3)
+    B, seed = 128, 21
+    w = synth.fov_dsm_weights(seed, in_channels=c)
+    wt = {k: (torch.from_numpy(a), torch.from_numpy(b)) for k, (a, b) in w.items()}
+    x = torch.from_numpy(synth.normalized_images(seed, 40 + c, (B, c, 128, 512)))
+    ran = []
+    real = ops.conv3x3_bf16_fwd
+
+    def recording(*a, **k):
+        out = real(*a, **k)
+        ran.append(ops.last_kernel_variant())
+        return out
+    monkeypatch.setattr(ops, 'conv3x3_bf16_fwd', recording)
+    for circ in (True, False):
+        del ran[:]
+        enc = mod.FOV_DSM(circ_padding=circ, weights=w).cuda().eval()
+        e = enc.forward_bf16(x.cuda()).cpu()
+        # layers 5,7 | 10,12,14 | 17,19,21 | 23 | 25, 27 (0 and 2 are the fused first-two-layers kernel)
+        assert ran == ['conv3x3_bf16_s16_kernel<false>', 'conv3x3_bf16_s16_kernel<true>',
+                       'conv3x3_bf16_s16_kernel<false>', 'conv3x3_bf16_s16_kernel<false>', 'conv3x3_bf16_s16_kernel<true>',
+                       'conv3x3_bf16_s16_kernel<false>', 'conv3x3_bf16_s16_kernel<false>', 'conv3x3_bf16_s16_kernel<false>',
+                       'conv3x3_nhwc_bf16_kernel<128,2,false,4>', 'conv3x3_nhwc_bf16_kernel<64,2,false,4>',
+                       'conv3x3_nhwc_bf16_kernel<64,1,false,4>'], ran
+        sel = [0, 77, 127]
+        with torch.no_grad():
+            emu = O.fov_dsm_forward_bf16_emulated(x[sel], wt, circ)
+        for i, s in enumerate(sel):
+            rel = float((e[s] - emu[i]).norm() / emu[i].norm())
+            assert rel < 1e-2, (variant, circ, s, rel)

@@ -25,10 +25,18 @@ def nhwc(t):
     return t.permute(0, 2, 3, 1).contiguous()
 
 
-def main():
-    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
-    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+N_KINDS = 17
+
+
+def run(budget=120.0, seed=0, rounds=None, kinds=None):
+    """Draw cases until `budget` seconds have passed (kinds at random), or — rounds given — exactly `rounds` cases of every
+    kind in `kinds` (default all) in a fixed order: the deterministic form tests/test_fuzz_gpu.py runs. Returns
+    (cases run per kind, list of failures)."""
     rng = np.random.default_rng(seed)
+    if kinds is None and os.environ.get('FUZZ_KINDS'):
+        kinds = [int(k) for k in os.environ['FUZZ_KINDS'].split(',')]
+    kinds = list(range(N_KINDS)) if kinds is None else list(kinds)
+    ran = {k: 0 for k in kinds}
     dev = torch.device('cuda:0')
     torch.manual_seed(seed)
     t0 = time.time()
@@ -41,11 +49,18 @@ def main():
             fails.append((name, cfg, err, scale))
             print('FAIL %s %s: max err %.3e (scale %.3e)' % (name, cfg, err, scale), flush=True)
 
-    while time.time() - t0 < budget:
+    def draw_kinds():
+        if rounds is not None:
+            for _ in range(rounds):
+                for k in kinds:
+                    yield k
+        else:
+            while time.time() - t0 < budget:
+                yield int(rng.choice(kinds))
+
+    for kind in draw_kinds():
         n += 1
-        kind = rng.integers(0, 17)
-        if os.environ.get('FUZZ_KINDS') and str(int(kind)) not in os.environ['FUZZ_KINDS'].split(','):
-            continue
+        ran[kind] += 1
         B = int(rng.integers(1, 5))
         H = int(rng.integers(1, 40))
         W = int(rng.integers(1, 140))
@@ -299,6 +314,13 @@ def main():
             fails.append(('exception', cfg, str(e)[:200], kind))
             print('EXC kind %d %s: %s' % (kind, cfg, str(e)[:300]), flush=True)
     print('fuzz_parity: %d cases in %.0f s, %d failures' % (n, time.time() - t0, len(fails)), flush=True)
+    return ran, fails
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    _, fails = run(budget, seed)
     sys.exit(1 if fails else 0)
 
 

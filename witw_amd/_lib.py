@@ -15,6 +15,7 @@ _LIB = None
 SIGNATURES = {
     'witw_last_error': (c_char_p, []),
     'witw_version': (c_int, []),
+    'witw_last_kernel_variant': (c_char_p, []),
     'witw_device_check': (c_int, [c_int]),
     'witw_conv3x3_tile_n': (c_int, [c_int]),
     'witw_conv3x3_workgroup_waves': (c_int, [c_int] * 5),

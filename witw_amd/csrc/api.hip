@@ -11,9 +11,22 @@ void witw_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+static thread_local char g_variant[128] = "";
+
+void witw_note_variant(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_variant, sizeof(g_variant), fmt, ap);
+    va_end(ap);
+}
+
 extern "C" {
 
 const char* witw_last_error(void) { return g_err; }
+
+// Name of the kernel instantiation the calling thread's most recent conv launcher picked (template arguments as in the
+// rocprof kernel names), "" before the first launch. Lets a parity test assert WHICH kernel it compared with the oracle.
+const char* witw_last_kernel_variant(void) { return g_variant; }
 
 int witw_version(void) { return 100; }  // 0.1.0
 

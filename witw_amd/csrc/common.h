@@ -18,6 +18,7 @@ enum {
 };
 
 void witw_set_error(const char* fmt, ...);
+void witw_note_variant(const char* fmt, ...);   // records the launched instantiation (witw_last_kernel_variant)
 
 #define WITW_CHECK_ARG(cond, ...)                \
     do {                                         \

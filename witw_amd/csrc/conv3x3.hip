@@ -650,6 +650,7 @@ int launch_conv_nw(ConvArgs a, hipStream_t st) {
     const unsigned gy = (TAPS == 4 && a.ksplit > 1) ? (unsigned)a.ksplit : 1u;
     hipLaunchKernelGGL((conv3x3_nhwc_f32_kernel<TN, SH, POOL, NW, GEO, TAPS>), dim3((unsigned)grid, gy), dim3(64 * NW), 0, st, a);
     WITW_CHECK_LAUNCH("conv3x3_nhwc_f32");
+    witw_note_variant("conv3x3_nhwc_f32_kernel<%d,%d,%s,%d,%d,%d>", TN, SH, POOL ? "true" : "false", NW, GEO, TAPS);
     return WITW_OK;
 }
 

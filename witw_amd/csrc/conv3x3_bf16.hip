@@ -1127,6 +1127,7 @@ int launch_bf_nw(ConvBfArgs a, hipStream_t st) {
     a.sp_total = (int)sp_total;
     hipLaunchKernelGGL((conv3x3_nhwc_bf16_kernel<TN, SH, POOL, NW>), dim3((unsigned)grid), dim3(64 * NW), 0, st, a);
     WITW_CHECK_LAUNCH("conv3x3_nhwc_bf16");
+    witw_note_variant("conv3x3_nhwc_bf16_kernel<%d,%d,%s,%d>", TN, SH, POOL ? "true" : "false", NW);
     return WITW_OK;
 }
 
@@ -1154,6 +1155,7 @@ int launch_bf_s16(ConvBfArgs a, hipStream_t st) {
     a.sp_total = (int)sp_total;
     hipLaunchKernelGGL((conv3x3_bf16_s16_kernel<POOL>), dim3((unsigned)grid), dim3(512), 0, st, a);
     WITW_CHECK_LAUNCH("conv3x3_bf16_s16");
+    witw_note_variant("conv3x3_bf16_s16_kernel<%s>", POOL ? "true" : "false");
     return WITW_OK;
 }
 

@@ -537,6 +537,7 @@ int launch_hx_nw(ConvHxArgs a, hipStream_t st) {
     a.sp_total = (int)sp_total;
     hipLaunchKernelGGL((conv3x3_nhwc_f16x3_kernel<TN, SH, POOL, NW>), dim3((unsigned)grid), dim3(64 * NW), 0, st, a);
     WITW_CHECK_LAUNCH("conv3x3_nhwc_f16x3");
+    witw_note_variant("conv3x3_nhwc_f16x3_kernel<%d,%d,%s,%d>", TN, SH, POOL ? "true" : "false", NW);
     return WITW_OK;
 }
 

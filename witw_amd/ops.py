@@ -872,6 +872,13 @@ def exhaustive_triplet_loss(D, soft_margin=False, alpha=10., margin=1.):
     return loss.reshape(())
 
 
+def last_kernel_variant():
+    """Name of the conv kernel instantiation the calling thread's last conv launcher picked (witw_last_kernel_variant), spelled
+    as in rocprof kernel names."""
+    v = _lib.load().witw_last_kernel_variant()
+    return v.decode() if v else ''
+
+
 # ----------------------------------------------------------------------------- bf16 inference path
 def bf16_mfma16(enable=None):
     """MFMA shape of the bf16 inference forward where both kernels apply: True = 16x16x32 (default), False = 32x32x16; None only
