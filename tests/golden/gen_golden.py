@@ -269,7 +269,7 @@ def main():
             print('  %-28s %8d bytes' % (f, os.path.getsize(os.path.join(HERE, f))))
 
 
-if __name__ == '__main__' and not any(a in sys.argv for a in ('--trainstep', '--trainstep-semantic', '--baseline', '--baseline-train')):
+if __name__ == '__main__' and not any(a in sys.argv for a in ('--trainstep', '--trainstep-semantic', '--baseline', '--baseline-train', '--augment', '--checkpoint-interop')):
     main()
 
 
@@ -569,3 +569,89 @@ def gen_baseline_train():
 
 if __name__ == '__main__' and '--baseline-train' in sys.argv:
     gen_baseline_train()
+
+
+AUGMENT_SHIFTS = (('pixels', 3), ('pixel', -2.5), ('p', 7.5), ('P', 40), ('fraction', 0.25), ('f', -0.4), ('Fractions', 1.7),
+                  ('degrees', 90), ('degree', 45.3), ('d', 359), ('D', -200.5), ('radians', 1.0), ('radian', -2.2), ('r', 6.5))
+
+
+def gen_augment():
+    """cvig_baseline's host-side augmentation helpers (model/cvig_baseline.py:97-128): horizontal_shift for every unit alias
+    and rounding case, quantized_rotation for factors -2..6, as computed by the reference."""
+    fov, sem, base = import_reference()
+    img = torch.arange(2 * 3 * 5 * 12, dtype=torch.float32).reshape(2, 3, 5, 12)
+    res = {'img': img.numpy(), 'units': np.array([u for u, _ in AUGMENT_SHIFTS]), 'shifts': np.array([s for _, s in AUGMENT_SHIFTS], dtype=np.float64)}
+    for i, (u, s) in enumerate(AUGMENT_SHIFTS):
+        res['shift_%d' % i] = base.horizontal_shift(img, s, unit=u).numpy()
+    try:
+        base.horizontal_shift(img, 1, unit='turns')
+        raise AssertionError('reference accepted an unknown unit')
+    except Exception as e:      # the reference raises a bare Exception with this text
+        res['bad_unit_message'] = np.array(str(e))
+    rect = torch.arange(3 * 4 * 6, dtype=torch.float32).reshape(3, 4, 6)
+    res['rect'] = rect.numpy()
+    for f in range(-2, 7):
+        res['rot_%d' % f] = base.quantized_rotation(rect, f).contiguous().numpy()
+    np.savez(os.path.join(HERE, 'augment.npz'), **res)
+    print('augment.npz written:', len(AUGMENT_SHIFTS), 'shifts, 9 rotations')
+
+
+if __name__ == '__main__' and '--augment' in sys.argv:
+    gen_augment()
+
+
+class FullVGG(FakeVGG):
+    """FakeVGG with torchvision's real classifier shapes: what a strict load of a reference-format checkpoint needs."""
+
+    def __init__(self, weights):
+        super().__init__(weights)
+        self.classifier = nn.Sequential(nn.Linear(25088, 4096), nn.ReLU(True), nn.Dropout(), nn.Linear(4096, 4096), nn.ReLU(True),
+                                        nn.Dropout(), nn.Linear(4096, 1000))
+
+
+def tensor_digest(t):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(t.detach().cpu().numpy()).tobytes()).hexdigest()[:16]
+
+
+INTEROP_SEED = SEED + 7
+
+
+def gen_checkpoint_interop():
+    """The proof that checkpoints written by witw_amd.cvig_fov.save_reference_state_dict are the reference's format: the file is
+    strict-loaded by the REFERENCE's FOV_DSM.load_state_dict (model/cvig_fov.py:511-512; a VGG16-shaped torch.hub stand-in with
+    other weights underneath, so every tensor that counts has to come from the file), and the reference then embeds seeded
+    inputs. Stored: the reference module's key list, per-tensor digests of its state after the load, its embeddings.
+    tests/test_checkpoints.py re-creates the file from the same seeds and compares."""
+    import tempfile
+    from witw_amd import cvig_fov as our_fov, cvig_semantic as our_sem
+    fov, sem, base = import_reference()
+    res = {'seed': INTEROP_SEED}
+    for tag, ours, ref_mod, circ, c, stream in (('surface', our_fov, fov, False, 3, 70), ('overhead', our_fov, fov, True, 3, 71),
+                                                ('semantic_overhead', our_sem, sem, True, 5, 72)):
+        w = synth.fov_dsm_weights(INTEROP_SEED, in_channels=c)
+        enc = ours.FOV_DSM(circ_padding=circ, weights=w)
+        with tempfile.TemporaryDirectory() as d:
+            path = os.path.join(d, 'ck.pth')
+            our_fov.save_reference_state_dict(enc, path)
+            res['file_bytes_' + tag] = os.path.getsize(path)
+            other = synth.fov_dsm_weights(INTEROP_SEED + 100, in_channels=3)
+            torch.hub.load = lambda *a, **k: FullVGG(other)
+            ref = ref_mod.FOV_DSM(circ_padding=circ)
+            out = ref.load_state_dict(torch.load(path, map_location='cpu'))          # strict (the default), as the reference calls it
+            assert not out.missing_keys and not out.unexpected_keys
+        ref.eval()
+        sd = ref.state_dict()
+        res['keys_' + tag] = np.array(list(sd.keys()))
+        res['digests_' + tag] = np.array([tensor_digest(v) for v in sd.values()])
+        res['shapes_' + tag] = np.array([','.join(str(n) for n in v.shape) for v in sd.values()])
+        x = torch.from_numpy(synth.normalized_images(INTEROP_SEED, stream, (2, c, 128, 512)))
+        with torch.no_grad():
+            res['embed_' + tag] = ref(x).numpy()
+        res['stream_' + tag] = stream
+        print(tag, 'strict load ok:', len(sd), 'tensors, file', res['file_bytes_' + tag], 'bytes')
+    np.savez_compressed(os.path.join(HERE, 'checkpoint_interop.npz'), **res)
+
+
+if __name__ == '__main__' and '--checkpoint-interop' in sys.argv:
+    gen_checkpoint_interop()

@@ -105,3 +105,33 @@ def test_reference_format_checkpoints(tmp_path, golden_dir):
     cvig_fov.save_reference_state_dict(enc, path)
     back = torch.load(path)
     assert float(back['model.classifier.3.weight'][0, 0]) == 4.0 and float(back['model.classifier.6.bias'][0]) == 8.0
+
+
+def test_reference_strict_loads_our_checkpoints(tmp_path, golden_dir):
+    """tests/golden/checkpoint_interop.npz (gen_golden.py --checkpoint-interop) records what the REFERENCE's FOV_DSM held after
+    `load_state_dict` (strict, model/cvig_fov.py:511-512; model/cvig_semantic.py:542-543) of a file written by
+    save_reference_state_dict, and the embeddings it then computed. Here the file is re-created from the same seeds: same key
+    order, shapes and per-tensor digests as the reference's loaded state, and the oracle on those weights reproduces the
+    reference's embeddings."""
+    import hashlib
+    from oracle import cvig_fov_oracle as O
+    g = np.load(os.path.join(golden_dir, 'checkpoint_interop.npz'))
+    seed = int(g['seed'])
+    for tag, mod, circ, c in (('surface', cvig_fov, False, 3), ('overhead', cvig_fov, True, 3), ('semantic_overhead', cvig_semantic, True, 5)):
+        w = synth.fov_dsm_weights(seed, in_channels=c)
+        enc = mod.FOV_DSM(circ_padding=circ, weights=w)
+        path = str(tmp_path / (tag + '.pth'))
+        cvig_fov.save_reference_state_dict(enc, path)
+        assert abs(os.path.getsize(path) - int(g['file_bytes_' + tag])) < 1e5       # the archive's member names carry the file name
+        back = torch.load(path, map_location='cpu')
+        assert sorted(back.keys()) == sorted(str(k) for k in g['keys_' + tag])
+        for k, shape, digest in zip(g['keys_' + tag], g['shapes_' + tag], g['digests_' + tag]):
+            t = back[str(k)]
+            assert ','.join(str(n) for n in t.shape) == str(shape), k
+            got = hashlib.sha256(np.ascontiguousarray(t.contiguous().numpy()).tobytes()).hexdigest()[:16]
+            assert got == str(digest), k                       # the reference held exactly these bytes after its strict load
+        x = torch.from_numpy(synth.normalized_images(seed, int(g['stream_' + tag]), (2, c, 128, 512)))
+        wt = {k: (torch.from_numpy(a), torch.from_numpy(b)) for k, (a, b) in w.items()}
+        with torch.no_grad():
+            e = O.fov_dsm_forward(x, wt, circ).numpy()
+        np.testing.assert_allclose(e, g['embed_' + tag], rtol=0, atol=1e-6)

@@ -91,12 +91,14 @@ def test_projector_dump_inverse_normalize_and_bilinear_interpolate(tmp_path, mon
     """The reference's TensorBoard embedding-projector dump (model/cvig_fov.py:474-479, :534-540) with a recording
     writer, inverse_normalize's verbatim semantics (:151-154) and bilinear_interpolate (:156-183) on free coordinates."""
     from witw_amd import cvig_fov
-    calls = []
+    calls, texts = [], []
 
     class Rec(object):
         def add_scalar(self, *a, **k):
             pass
-        add_text = add_scalar
+
+        def add_text(self, tag, text, global_step=None):
+            texts.append((tag, global_step))
 
         def add_embedding(self, mat, metadata=None, metadata_header=None, label_img=None, global_step=None, tag=None):
             calls.append((tuple(mat.shape), len(metadata), metadata_header, tuple(label_img.shape), global_step, tag))
@@ -104,7 +106,9 @@ def test_projector_dump_inverse_normalize_and_bilinear_interpolate(tmp_path, mon
     monkeypatch.setattr(cvig_fov, '_writer', lambda path: Rec())
     csv = _write_dataset(str(tmp_path), 6)
     monkeypatch.chdir(tmp_path)
-    cvig_fov.train(dataset='cvusa', fov=70, val_quantity=2, batch_size=2, num_workers=0, num_epochs=1, csv_path=csv)
+    cvig_fov.train(dataset='cvusa', fov=70, val_quantity=4, batch_size=2, num_workers=0, num_epochs=1, csv_path=csv)
+    # 'best_loss' is logged at the step of the last validation iteration, epoch * len(val loader) + batch = 0 * 2 + 1 (:487)
+    assert texts[0] == ('best_loss', 1), texts
     cvig_fov.test(dataset='cvusa', fov=70, batch_size=4, num_workers=0, csv_path=csv)
     e = 16 * 4 * 12
     assert calls[0] == ((4, e), 4, ['idx', 'type'], (4, 3, 128, 512), 1, 'val_embedding')

@@ -31,31 +31,27 @@ class Globals:
     }
 
 
+# how many units make one full turn of the panorama, per first letter of the unit name; None: the shift already is in pixels
+_FULL_TURN = {'p': None, 'f': 1., 'd': 360., 'r': 2 * math.pi}
+_UNIT_NAMES = {first + rest + plural for first, rest in (('p', 'ixel'), ('f', 'raction'), ('d', 'egree'), ('r', 'adian'))
+               for plural in ('', 's')} | set(_FULL_TURN)
+
+
 def horizontal_shift(img, shift, unit='pixels'):
-    """model/cvig_baseline.py:97-113 (host-side glue: a roll)."""
-    u = unit.lower()
-    if u in ['pixels', 'pixel', 'p']:
-        pix_shift = -round(shift)
-    elif u in ['fraction', 'fractions', 'f']:
-        pix_shift = -round(shift * img.size(-1))
-    elif u in ['degrees', 'degree', 'd']:
-        pix_shift = -round(shift * img.size(-1) / 360.)
-    elif u in ['radians', 'radian', 'r']:
-        pix_shift = -round(shift * img.size(-1) / (2 * math.pi))
-    else:
+    """Turn a 360-degree panorama by `shift` (the viewer turning clockwise = the columns moving left), behaviour of
+    model/cvig_baseline.py:97-113: units pixel(s)/p, fraction(s)/f, degree(s)/d, radian(s)/r in any case, the column count
+    rounded half-to-even, anything else raises. Pinned by tests/golden/augment.npz."""
+    name = unit.lower()
+    if name not in _UNIT_NAMES:
         raise Exception('! Invalid unit in horizontal_shift()')
-    return torch.roll(img, pix_shift, dims=-1)
+    turn = _FULL_TURN[name[0]]
+    columns = shift if turn is None else shift * img.size(-1) / turn
+    return img.roll(-round(columns), -1)
 
 
 def quantized_rotation(img, factor):
-    """model/cvig_baseline.py:116-128."""
-    if factor % 4 == 1:
-        img = img.transpose(-2, -1).flip(-1)
-    elif factor % 4 == 2:
-        img = img.flip(-2).flip(-1)
-    elif factor % 4 == 3:
-        img = img.transpose(-2, -1).flip(-2)
-    return img
+    """Quarter turns counter-clockwise (model/cvig_baseline.py:116-128); any integer factor, a view where torch allows."""
+    return torch.rot90(img, factor % 4, (-1, -2))
 
 
 class ImagePairDataset(_fov.ImagePairDataset):

@@ -1506,7 +1506,8 @@ def train(dataset='cvusa', fov=360, val_quantity=1000, batch_size=64, num_worker
                         save_reference_state_dict(enc, path)
                     else:
                         torch.save(enc.state_dict(), path)
-            writer.add_text('best_loss', 'new best loss: {}, epoch: {}'.format(best_loss, epoch + 1), epoch)
+            writer.add_text('best_loss', 'new best loss: {}, epoch: {}'.format(best_loss, epoch + 1),
+                            epoch * len(loader) + batch)        # the last validation iteration's step (:487)
     return best_loss
 
 
