@@ -338,12 +338,18 @@ def test_dropout2d_scales_are_the_counter_based_stream():
     torch.manual_seed(99)
     a = cvig_fov.FOV_DSM(False, weights=w).cuda().train()
     b = cvig_fov.FOV_DSM(False, weights=w).cuda().train()
+    b.dropout_stream = 5
     with torch.no_grad():
         a1, a2, b1 = a(x), a(x), b(x)
     assert not torch.equal(a1, a2) and not torch.equal(a1, b1)
     a._drop_step = 0
     with torch.no_grad():
         assert torch.equal(a(x), a1)
+    # the stream is a property of the side (0 surface, 1 overhead), not of how many encoders the process built before
+    c = cvig_fov.FOV_DSM(False, weights=w).cuda().train()
+    assert (a.dropout_stream, c.dropout_stream, cvig_fov.FOV_DSM(True, weights=w).dropout_stream) == (0, 0, 1)
+    with torch.no_grad():
+        assert torch.equal(c(x), a1)
 
 
 def test_grad_bucket_gradients_are_written_in_place():
@@ -386,8 +392,35 @@ def test_grad_bucket_gradients_are_written_in_place():
     out = enc(x, dropout_scales=drops)
     (out * out).sum().backward()
     assert torch.equal(bucket.flat, first)
+    # the encoder called TWICE in one step: two autograd nodes -> neither may overwrite the views, and the bucket goes to the
+    # all-reduce only after the second node's gradients have been accumulated
+    opt.zero_grad()
+    launches = []
+    red._launch = lambda bi: launches.append((bi, red.arrived[bi]))
+    o1 = enc(x, dropout_scales=drops)
+    o2 = enc(x, dropout_scales=drops)
+    assert bucket.nodes == 2
+    ((o1 * o1).sum() + (o2 * o2).sum()).backward()
+    assert launches == [(0, 2 * len(bucket.params))], launches
+    assert torch.allclose(bucket.flat, 2 * first, rtol=1e-6, atol=0)
+    del red._launch
+    opt.zero_grad()
+    out = enc(x, dropout_scales=drops)
+    (out * out).sum().backward()
     before = enc.model.features[27].layer.weight.detach().clone()
     opt.step()
     assert float((enc.model.features[27].layer.weight.detach() - before).abs().max()) > 0
     red.close()
     assert not hasattr(enc, '_grad_bucket') and enc.model.features[27].layer.weight.grad is None
+    # a bucket parameter that received no gradient in a step is skipped by Adam (torch skips .grad is None), not stepped with zeros
+    m = torch.nn.ModuleList([torch.nn.Linear(4, 4), torch.nn.Linear(4, 4)]).cuda()
+    red2 = parallel.OverlappedGradReducer([m])
+    opt2 = cvig_fov.Adam(list(m.parameters()), lr=1e-2)
+    for used in (1, 0):          # step 1 moves m[1] (its Adam moments become non-zero), step 2 must leave it alone
+        opt2.zero_grad()
+        m[used](torch.ones(2, 4, device='cuda')).sum().backward()
+        keep = [q.detach().clone() for q in m[1 - used].parameters()]
+        red2.wait()
+        opt2.step()
+        assert all(torch.equal(a, b.detach()) for a, b in zip(keep, m[1 - used].parameters()))
+    red2.close()

@@ -98,7 +98,6 @@ class FOV_DSM(torch.nn.Module):
     """
     in_channels = 3
     fuse_first2 = True        # bf16 inference: layers 0 and 2 as one launch (False: the two separate kernels, same bits)
-    _instances = 0            # encoders built so far: the id that keeps two encoders' Dropout2d masks independent
     dropout_seed = None       # None: torch.initial_seed()
     # 'fp32' = the reference's arithmetic on the fp32 MFMA kernels (parity path). 'bf16' = mixed precision on the bf16
     # MFMA kernels: bf16 activations / filters / activation gradients, fp32 accumulate, fp32 weight gradients, master
@@ -136,8 +135,11 @@ class FOV_DSM(torch.nn.Module):
         self.model = _VGGShell(torch.nn.Sequential(*mods))
         self.circ_padding = circ_padding
         self._packed = {}
-        FOV_DSM._instances += 1
-        self._encoder_id = FOV_DSM._instances & 0xFFFF
+        # Dropout2d mask stream of this encoder: a STABLE id per side (0 surface, 1 overhead), not the count of encoders the
+        # process has built (an encoder made earlier by test() / a bench block must not change a seeded run's masks); two
+        # encoders of one side in a process that need distinct masks set `dropout_stream` themselves. The step counter advances
+        # per training call; train() sets it from the global step so that a re-started run continues the mask sequence.
+        self.dropout_stream = 1 if circ_padding else 0
         self._drop_step = 0
 
     def _pack(self, idx):
@@ -174,7 +176,11 @@ class FOV_DSM(torch.nn.Module):
         seed = self.dropout_seed if self.dropout_seed is not None else torch.initial_seed()
         ch = _conv_of(self.model.features[layers[0]]).out_channels
         p = float(self.model.features[layers[0]].p)
-        sc = ops.dropout2d_scales(seed, self._encoder_id, self._drop_step, parallel.rank(), layers, x.shape[0], ch, p, x.device)
+        for idx in layers[1:]:      # one launch draws all layers: they have to agree on what is drawn
+            if _conv_of(self.model.features[idx]).out_channels != ch or float(self.model.features[idx].p) != p:
+                raise _lib.WitwError('Dropout2d layers of one encoder must share channel count and p (layer %d differs)' % idx)
+        sc = ops.dropout2d_scales(seed, self.dropout_stream & 0xFFFF, self._drop_step, parallel.rank(), layers, x.shape[0], ch, p,
+                                  x.device)
         self._drop_step += 1
         return {idx: sc[i] for i, idx in enumerate(layers)}
 
@@ -350,6 +356,9 @@ class FOV_DSM(torch.nn.Module):
             fn = _EncoderFnBf16 if self.precision == 'bf16' else _EncoderFnF16x3 if self.precision == 'fp16x3' else _EncoderFn
             # the dicts are read when the backward runs, so a caller may fill them between forward and backward
             self._bwd_override = ({} if relu_gates is None else relu_gates, {} if pool_codes is None else pool_codes)
+            bucket = getattr(self, '_grad_bucket', None)
+            if bucket is not None:      # parallel.GradBucket: how many backward nodes of this encoder the step will run
+                bucket.nodes += 1
             return fn.apply(x, self, scales, *params)
         if self.precision == 'fp16x3' and not self.training:
             return self.forward_f16x3(x)
@@ -385,7 +394,7 @@ class _EncoderFn(torch.autograd.Function):
         dz = ops.nchw_to_nhwc(grad_out.contiguous(), (cout_last + 7) // 8 * 8)   # layer 27 has no ReLU
         grads = {}
         bucket = getattr(enc, '_grad_bucket', None)      # parallel.GradBucket: the wgrad kernels write into its views
-        direct = bucket is not None and bucket.fresh
+        direct = bucket is not None and bucket.direct()
         for n in range(len(specs) - 1, -1, -1):
             idx, sh, relu, pool, drop = specs[n]
             x_in = kept[idx][0]
@@ -650,6 +659,9 @@ class Adam(object):
         for p in self.params:
             if p.grad is None:
                 continue
+            b = getattr(p, '_witw_bucket', None)
+            if b is not None and not b.received(p):      # its .grad view was only cleared: no gradient this step
+                continue
             st = self.state.get(p)
             if st is None:
                 st = self.state[p] = {'step': 0, 'exp_avg': torch.zeros_like(p), 'exp_avg_sq': torch.zeros_like(p)}
@@ -778,6 +790,12 @@ def retrieve(overhead_shard, surface_all, k=10, shard_begin=0, query_chunk=4096,
     direct kernel's: ranks and top-k INDICES equal method='direct' exactly (the listed distances agree to DISTANCE_EPS)."""
     from . import parallel
     kn = _kernels or ops
+    if method == 'dft' and k + DFT_MARGIN > 32:      # no room for the candidate margin in a 32-wide list: the top-k comes from the
+        ranks_dft = None                              # direct pass, the rank counts (no list involved) still from the spectral one
+        if _want_ranks:
+            ranks_dft = _retrieve_dft(overhead_shard, surface_all, 1, shard_begin, query_chunk, kn, True)[0]
+        _r, v, i = retrieve(overhead_shard, surface_all, k, shard_begin, query_chunk, 'direct', _kernels, _want_ranks=False)
+        return ranks_dft, v, i
     if method == 'dft':
         return _retrieve_dft(overhead_shard, surface_all, k, shard_begin, query_chunk, kn, _want_ranks)
     if method != 'direct':
@@ -828,6 +846,9 @@ def _sort_by_value_then_index(v, i):
     return torch.gather(v, 1, o2), torch.gather(i, 1, o2)
 
 
+DFT_MARGIN = 6      # candidates kept beyond place k by the spectral top-k (place k+1 must exist to decide place k)
+
+
 def _retrieve_dft(overhead_shard, surface_all, k, shard_begin, query_chunk, kn, want_ranks):
     """retrieve() on the spectral pass, index-exact (see retrieve). eps = ops.DISTANCE_EPS bounds |d_dft - d_direct| at full
     width; narrower surfaces (We < 64: the window norm, hence the distance, depends on the chosen shift) first have every pair
@@ -836,7 +857,8 @@ def _retrieve_dft(overhead_shard, surface_all, k, shard_begin, query_chunk, kn, 
     eps = float(getattr(kn, 'DISTANCE_EPS', ops.DISTANCE_EPS))
     dev = surface_all.device
     n_q, n_g, we = surface_all.shape[0], overhead_shard.shape[0], surface_all.shape[3]
-    kc = min(32, k + 6)                                  # local candidates per query, by spectral distance
+    kc = k + DFT_MARGIN                                  # local candidates per query, by spectral distance (retrieve: <= 32)
+    assert kc <= 32
     gallery = overhead_shard.contiguous()
     spec_g = kn.match_spectrum(gallery, overhead=True) if n_g else None
     counts = torch.zeros((n_q,), dtype=torch.int32, device=dev)
@@ -908,11 +930,13 @@ def _retrieve_dft(overhead_shard, surface_all, k, shard_begin, query_chunk, kn, 
     v = torch.where(i < 0, torch.full_like(v, float('inf')), v)
     v, i = _sort_by_value_then_index(v.contiguous(), i.contiguous())
     ncand = v.shape[1]
-    m = min(ncand, k + 6)                                # candidates re-scored for an undecided query
+    m = min(ncand, k + DFT_MARGIN)                       # candidates re-scored for an undecided query
     inf_col = torch.full((n_q, 1), float('inf'), dtype=torch.float32, device=dev)
     vp = torch.cat((v, inf_col), dim=1)
     gaps = vp[:, 1:k + 1] - vp[:, :k]                    # between places 1..k+1
     undecided = ((gaps <= 2 * eps) & torch.isfinite(vp[:, :k])).any(dim=1)
+    # a row outside every shard's list (spectral distance >= outsider) must not come within rounding of place k either
+    undecided |= torch.isfinite(vp[:, k - 1]) & (vp[:, k - 1] + 2 * eps >= outsider) & torch.isfinite(outsider)
     rows = torch.nonzero(undecided).squeeze(1)           # identical on every rank: computed from gathered data
     fallback = torch.zeros((0,), dtype=torch.int64, device=dev)
     if rows.numel():
@@ -1476,6 +1500,8 @@ def train(dataset='cvusa', fov=360, val_quantity=1000, batch_size=64, num_worker
                 data = prep(raw)
                 surface = data['surface']
                 overhead = data['polar']
+                if phase == 'train':      # Dropout2d masks keyed on the global step, not on how many calls this process made
+                    surface_encoder._drop_step = overhead_encoder._drop_step = epoch * len(loader) + batch
                 with torch.set_grad_enabled(phase == 'train'):
                     surface_embed = surface_encoder(surface)
                     overhead_embed = overhead_encoder(overhead)

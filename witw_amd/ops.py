@@ -393,18 +393,53 @@ def match_fwd(overhead_embed, surface_embed, want_score=False, want_workspace=Fa
     return (ori, dist, score) if want_score else (ori, dist)
 
 
-def match_spectrum(embed, overhead=None):
-    """Row spectra of embeddings [B,16,4,W] (W = 64 overhead, W = We surface) -> f32 [B,33,128], the operand of match_fwd_dft.
-    overhead: which side the spectra are for (default: by width -- 64 columns = overhead); the two sides differ in the order
-    of the 8-byte chunks inside each 16-byte slot (csrc/match_dft.hip: conflict-free LDS operand reads)."""
+SPECTRA_ALIGN = 32      # an overhead row's stored chunk order depends on bit 4 of its index (csrc/match_dft.hip:331)
+
+
+class Spectra(object):
+    """Row spectra of one side of the spectral match, f32 [B,33,128] in `data`, plus what the stored layout depends on: the
+    side (`overhead`: the two sides order the 8-byte chunks of every 16-byte slot differently) and, for the overhead side, each
+    row's index modulo 32 in the tensor the spectra were computed from. Slices (`rows`) and concatenations (`Spectra.cat`) are
+    therefore only defined at multiples of SPECTRA_ALIGN = 32 rows; match_fwd_dft refuses the wrong side or a misaligned view
+    instead of returning wrong distances."""
+
+    def __init__(self, data, overhead, base_row=0):
+        self.data, self.overhead, self.base_row = data, bool(overhead), int(base_row)
+
+    def __len__(self):
+        return self.data.shape[0]
+
+    def rows(self, start, count):
+        if self.overhead and start % SPECTRA_ALIGN:
+            raise _lib.WitwError('Spectra.rows: overhead spectra can only be sliced at multiples of %d rows (start %d)'
+                                 % (SPECTRA_ALIGN, start))
+        return Spectra(self.data[start:start + count], self.overhead, self.base_row + start)
+
+    @staticmethod
+    def cat(parts):
+        parts = list(parts)
+        if len({p.overhead for p in parts}) != 1:
+            raise _lib.WitwError('Spectra.cat: mixed sides')
+        if parts[0].overhead and any((p.base_row % SPECTRA_ALIGN) or (len(p) % SPECTRA_ALIGN and p is not parts[-1]) for p in parts):
+            raise _lib.WitwError('Spectra.cat: every overhead block but the last must hold a multiple of %d rows' % SPECTRA_ALIGN)
+        return Spectra(torch.cat([p.data for p in parts]), parts[0].overhead, 0)
+
+
+def match_spectrum(embed, overhead):
+    """Row spectra of embeddings [B,16,4,W] (overhead side W = 64, surface side W = We <= 64) -> Spectra over f32 [B,33,128], the
+    operand of match_fwd_dft. `overhead` (required: a fov-360 surface embedding is 64 columns wide too) names the side; the
+    sides differ in the order of the 8-byte chunks inside each 16-byte slot, and an overhead row's order also depends on
+    bit 4 of its index (csrc/match_dft.hip: conflict-free LDS operand reads) -- hence the 32-row alignment rule of Spectra."""
     lib = _lib.load()
     e = _dev_f32(embed, 'embed')
     if e.dim() != 4 or e.shape[1] * e.shape[2] != 64 or not (1 <= e.shape[3] <= 64):
         raise _lib.WitwError('match_spectrum: embedding must be [B,16,4,W<=64], got %s' % (tuple(e.shape),))
-    role = int(e.shape[3] == 64) if overhead is None else int(bool(overhead))
+    if overhead and e.shape[3] != 64:
+        raise _lib.WitwError('match_spectrum: an overhead embedding is 64 columns wide, got %d' % e.shape[3])
     spec = torch.empty((e.shape[0], 33, 128), dtype=torch.float32, device=e.device)
-    _lib.check(lib.witw_match_spectrum(e.data_ptr(), spec.data_ptr(), e.shape[0], e.shape[3], role, _stream()), 'witw_match_spectrum')
-    return spec
+    _lib.check(lib.witw_match_spectrum(e.data_ptr(), spec.data_ptr(), e.shape[0], e.shape[3], int(bool(overhead)), _stream()),
+               'witw_match_spectrum')
+    return Spectra(spec, overhead)
 
 
 def match_fwd_dft(overhead_embed, surface_embed, spec_ov=None, spec_su=None, want_score=False, want_orientation=True,
@@ -422,9 +457,18 @@ def match_fwd_dft(overhead_embed, surface_embed, spec_ov=None, spec_su=None, wan
     Bo, Bs, We = ov.shape[0], su.shape[0], su.shape[3]
     spec_ov = match_spectrum(ov, overhead=True) if spec_ov is None else spec_ov
     spec_su = match_spectrum(su, overhead=False) if spec_su is None else spec_su
-    for name, sp, n in (('spec_ov', spec_ov, Bo), ('spec_su', spec_su, Bs)):
-        if not (sp.is_cuda and sp.dtype == torch.float32 and sp.is_contiguous() and tuple(sp.shape) == (n, 33, 128)):
+    for name, sp, n, side in (('spec_ov', spec_ov, Bo, True), ('spec_su', spec_su, Bs, False)):
+        if not isinstance(sp, Spectra):
+            raise _lib.WitwError('match_fwd_dft: %s must be a Spectra (ops.match_spectrum), not a bare tensor' % name)
+        if sp.overhead != side:
+            raise _lib.WitwError('match_fwd_dft: %s holds %s-side spectra' % (name, 'overhead' if sp.overhead else 'surface'))
+        if side and sp.base_row % SPECTRA_ALIGN:
+            raise _lib.WitwError('match_fwd_dft: %s starts at row %d of its tensor; overhead spectra are laid out per index modulo %d'
+                                 % (name, sp.base_row, SPECTRA_ALIGN))
+        d = sp.data
+        if not (d.is_cuda and d.dtype == torch.float32 and d.is_contiguous() and tuple(d.shape) == (n, 33, 128)):
             raise _lib.WitwError('match_fwd_dft: %s must be a contiguous float32 GPU tensor [%d,33,128]' % (name, n))
+    spec_ov, spec_su = spec_ov.data, spec_su.data
     # want_orientation=False (retrieval: only distances are ranked) skips the int64 matrix, two thirds of the output bytes
     ori = torch.empty((Bo, Bs), dtype=torch.int64, device=ov.device) if want_orientation else None
     dist = torch.empty((Bo, Bs), dtype=torch.float32, device=ov.device)

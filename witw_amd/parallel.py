@@ -101,6 +101,8 @@ class GradBucket:
             p._witw_bucket = self
         self.fresh = True
         self.on_ready = on_ready
+        self.nodes = 0              # encoder autograd nodes built since zero() (cvig_fov._EncoderFn.forward counts them)
+        self.touched = set()        # id() of the parameters whose gradient was written since zero()
 
     def zero(self):
         self.flat.zero_()
@@ -108,12 +110,25 @@ class GradBucket:
             if p.grad is not v:
                 p.grad = v
         self.fresh = True
+        self.nodes = 0
+        self.touched = set()
+
+    def direct(self):
+        """May a backward WRITE the gradients into the views (and hand the bucket to the all-reduce at once)? Only when it is
+        the one autograd node of this module in the step: a second node (the encoder called twice before backward) has to
+        accumulate, and the reduction must wait for both."""
+        return self.fresh and self.nodes <= 1
 
     def notify(self):
         """All gradients of the bucket have been written in place (no autograd accumulation, hence no grad hooks)."""
         self.fresh = False
+        self.touched = {id(p) for p in self.params}
         if self.on_ready is not None:
             self.on_ready()
+
+    def received(self, p):
+        """Did p get a gradient since zero()? (Adam skips the others, as torch skips parameters whose .grad is None.)"""
+        return id(p) in self.touched
 
     def release(self):
         for p in self.params:
@@ -152,10 +167,13 @@ class OverlappedGradReducer:
         return fn
 
     def _hook(self, bi):
-        def fn(_p):
+        def fn(p):
+            b = self.buckets[bi]
             self.arrived[bi] += 1
-            if self.arrived[bi] == len(self.buckets[bi].params):
-                self.buckets[bi].fresh = False
+            b.touched.add(id(p))
+            b.fresh = False
+            # every parameter once per autograd node of the module (two encoder calls in one step = two rounds of hooks)
+            if self.arrived[bi] == len(b.params) * max(1, b.nodes):
                 self._launch(bi)
         return fn
 
