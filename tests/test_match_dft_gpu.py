@@ -244,3 +244,56 @@ def test_evaluation_ranks_auto_switches_to_the_spectral_pass(we, monkeypatch):
     assert cvig_fov.retrieve.last_stats.get('method') == 'dft'
     with pytest.raises(Exception):
         cvig_fov.evaluation_ranks(gallery, queries, method='fft')
+
+
+@pytest.mark.parametrize('k', [26, 27, 32])
+def test_dft_retrieve_large_k_equals_direct(k):
+    """k + DFT_MARGIN <= 32 keeps the candidate margin inside the 32-wide device list; beyond that (k = 27..32) the top-k comes
+    from the direct pass and only the rank counts from the spectral one. Planted near-ties around every place, so a query whose
+    place k+1 sits within rounding of place k cannot be decided from the list alone."""
+    from witw_amd import cvig_fov
+    gallery, queries = _planted(6000, 300, 64, 4.0, seed=300 + k)
+    # 40 one-ulp neighbours of each of the first 8 queries' true matches: near-ties at every place up to 40
+    for q in range(8):
+        rows = torch.arange(100 + 40 * q, 140 + 40 * q, device='cuda')
+        gallery[rows] = gallery[q]
+        gallery[rows[::2], 1, 1, :2] = torch.nextafter(gallery[rows[::2], 1, 1, :2], torch.full((20, 2), 10.0, device='cuda'))
+    r0, v0, i0 = cvig_fov.retrieve(gallery, queries, k=k, query_chunk=128)
+    r1, v1, i1 = cvig_fov.retrieve(gallery, queries, k=k, query_chunk=128, method='dft')
+    np.testing.assert_array_equal(r1, r0)
+    assert torch.equal(i1, i0)
+    assert float((v1 - v0).abs().max()) <= 1e-5
+
+
+def test_spectra_refuse_the_wrong_side_and_misaligned_slices():
+    """ops.Spectra records what the stored layout depends on (csrc/match_dft.hip:331: the side, and for overheads bit 4 of the
+    row index): a fov-360 surface embedding is 64 columns wide like an overhead and must not pass as one; slices of overhead
+    spectra are defined at multiples of 32 rows only."""
+    from witw_amd import _lib, ops
+    ov = torch.from_numpy(synth.embeddings(71, 1, (96, 16, 4, 64))).cuda()
+    su = torch.from_numpy(synth.embeddings(72, 1, (40, 16, 4, 64))).cuda()
+    s_ov, s_su = ops.match_spectrum(ov, overhead=True), ops.match_spectrum(su, overhead=False)
+    assert isinstance(s_ov, ops.Spectra) and s_ov.overhead and not s_su.overhead
+    ori, d = ops.match_fwd_dft(ov, su, spec_ov=s_ov, spec_su=s_su)
+    with pytest.raises(TypeError):
+        ops.match_spectrum(ov)                                     # the side is not guessed from the width
+    with pytest.raises(_lib.WitwError):
+        ops.match_fwd_dft(ov, su, spec_ov=s_ov.data, spec_su=s_su)          # a bare tensor carries no side
+    with pytest.raises(_lib.WitwError):
+        ops.match_fwd_dft(ov[:40], su, spec_ov=ops.match_spectrum(su, overhead=False), spec_su=s_su)      # surface spectra as gallery
+    with pytest.raises(_lib.WitwError):
+        ops.match_fwd_dft(su, ov, spec_ov=ops.match_spectrum(su, overhead=True), spec_su=s_ov)          # overhead spectra as queries
+    with pytest.raises(_lib.WitwError):
+        s_ov.rows(16, 32)
+    with pytest.raises(_lib.WitwError):
+        ops.Spectra.cat([s_ov.rows(0, 48), s_ov.rows(64, 32)])     # a 48-row block in front shifts the next rows' index & 16
+    # aligned slices and concatenations are the spectra of the same rows
+    part = s_ov.rows(32, 64)
+    o2, d2 = ops.match_fwd_dft(ov[32:96].contiguous(), su, spec_ov=part, spec_su=s_su)
+    assert torch.equal(o2, ori[32:96]) and torch.equal(d2, d[32:96])
+    both = ops.Spectra.cat([s_ov.rows(64, 32), s_ov.rows(0, 32)])
+    o3, d3 = ops.match_fwd_dft(torch.cat((ov[64:96], ov[0:32])).contiguous(), su, spec_ov=both, spec_su=s_su)
+    assert torch.equal(o3, torch.cat((ori[64:96], ori[0:32]))) and torch.equal(d3, torch.cat((d[64:96], d[0:32])))
+    # surface spectra have one layout whatever the row
+    o4, d4 = ops.match_fwd_dft(ov, su[7:30].contiguous(), spec_ov=s_ov, spec_su=s_su.rows(7, 23))
+    assert torch.equal(o4, ori[:, 7:30]) and torch.equal(d4, d[:, 7:30])

@@ -846,6 +846,14 @@ def _sort_by_value_then_index(v, i):
     return torch.gather(v, 1, o2), torch.gather(i, 1, o2)
 
 
+_RETRIEVE_TLS = __import__('threading').local()
+
+
+def last_retrieve_stats():
+    """Re-scoring statistics of the calling thread's last retrieve(method='dft') (retrieve.last_stats is process-wide)."""
+    return dict(getattr(_RETRIEVE_TLS, 'stats', None) or {})
+
+
 DFT_MARGIN = 6      # candidates kept beyond place k by the spectral top-k (place k+1 must exist to decide place k)
 
 
@@ -964,6 +972,7 @@ def _retrieve_dft(overhead_shard, surface_all, k, shard_begin, query_chunk, kn, 
         v[fallback, :k], i[fallback, :k] = fv, fi
     stats['eps'] = eps
     retrieve.last_stats = stats
+    _RETRIEVE_TLS.stats = stats
     return (counts.cpu().numpy().astype('int64') if want_ranks else None), v[:, :k].contiguous(), i[:, :k].contiguous()
 
 
