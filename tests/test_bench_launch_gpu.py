@@ -37,6 +37,34 @@ def test_bench_two_ranks_self_launched_infer():
     assert two['recall']['N'] == 16 and two['unit'] == 'pairs/s' and two['value'] > 0 and two['scaling'] == 'weak'
     assert one['n_gpus'] == 1 and one['recall']['N'] == 8
     assert np.isfinite(two['loss']) and two['roofline']['all_conv_launches_tflops'] > 0
+    # the line says what its process group was, from every rank
+    c = two['collectives']
+    assert c['world'] == 2 and c['ranks_seen'] == [0, 1] and c['backend'] == 'gloo' and c['all_reduce_of_ones'] == 2.0
+    assert [d['rank'] for d in c['devices']] == [0, 1] and c['devices'][0]['pid'] != c['devices'][1]['pid']
+    assert one['collectives']['world'] == 1 and one['collectives']['ranks_seen'] == [0]
+
+
+def test_bench_one_rank_under_the_launcher_equals_the_plain_run():
+    """The driver's N > 1 entry (python -m torch.distributed.run ... bench.py --gpus N) with N = 1: one rank, no process group,
+    the same step and the same numbers as `python bench.py --gpus 1`."""
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    args = ['--gpus', '1', '--steps', '2', '--warmup', '1', '--batch', '16', '--no-cpu-baseline', '--no-side-blocks']
+    p = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+                        '--master-port', str(port), os.path.join(ROOT, 'bench.py')] + args, env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, p.stdout
+    launched = json.loads(lines[0])
+    plain = _run_bench(*args)
+    assert launched['n_gpus'] == plain['n_gpus'] == 1 and launched['collectives']['world'] == 1
+    assert launched['loss'] == plain['loss'] and launched['recall'] == plain['recall']           # the same step, bit for bit
+    assert 0.5 < launched['value'] / plain['value'] < 2.0
 
 
 def test_bench_two_ranks_self_launched_train_and_retrieval():
