@@ -722,8 +722,8 @@ def cpu_model():
 def cpu_baseline(a, g, o, wts, semantic):
     """The oracle (CPU restatement of the reference, kind 'port') timed on this host on a bounded sample of the same workload:
     the first --cpu-pairs pairs (default 32, the batch SURVEY's CPU anchor and BASELINE configs[0] use) of the batch the GPU
-    step ran on, at two thread counts -- 8 (the survey container's core count) and every core of this
-    host -- with torch's own oneDNN / BLAS build. `value` is the better of the two, `cores` the threads it used."""
+    step ran on, at 8 threads (the survey container's core count) and 16 (the GPU box's CPU share)
+    with torch's own oneDNN / BLAS build. `value` is the better of the two, `cores` the threads it used."""
     from oracle import cvig_fov_oracle as O
     n = g.shape[0]
     w = {k: (torch.from_numpy(v[0]), torch.from_numpy(v[1])) for k, v in wts.items()}
@@ -745,7 +745,9 @@ def cpu_baseline(a, g, o, wts, semantic):
         return su, ov, ori, d, loss, ranks
 
     by_threads = {}
-    for threads in sorted({min(8, all_threads), all_threads}):
+    # 8 = the survey container; 16 = this box's CPU share per GPU (more threads than that only oversubscribe it: 128 -> 3.3 pairs/s
+    # against 5.8 at 8 on an EPYC 9575F box); every core as well when the host is small enough for that to be meaningful
+    for threads in sorted({min(8, all_threads), min(16, all_threads)} | ({all_threads} if all_threads <= 32 else set())):
         torch.set_num_threads(threads)
         cpu_step()
         times = []

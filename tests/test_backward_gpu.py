@@ -401,8 +401,9 @@ def test_grad_bucket_gradients_are_written_in_place():
     o2 = enc(x, dropout_scales=drops)
     assert bucket.nodes == 2
     ((o1 * o1).sum() + (o2 * o2).sum()).backward()
-    assert launches == [(0, 2 * len(bucket.params))], launches
-    assert torch.allclose(bucket.flat, 2 * first, rtol=1e-6, atol=0)
+    assert launches == [] and torch.allclose(bucket.flat, 2 * first, rtol=1e-6, atol=0)      # nothing sent during the backward
+    red.wait()
+    assert launches == [(0, len(bucket.params))], launches                                  # wait() hands the bucket over
     del red._launch
     opt.zero_grad()
     out = enc(x, dropout_scales=drops)

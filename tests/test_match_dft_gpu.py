@@ -256,7 +256,7 @@ def test_dft_retrieve_large_k_equals_direct(k):
     # 40 one-ulp neighbours of each of the first 8 queries' true matches: near-ties at every place up to 40
     for q in range(8):
         rows = torch.arange(100 + 40 * q, 140 + 40 * q, device='cuda')
-        gallery[rows] = gallery[q]
+        gallery[rows] = gallery[q].clone()
         gallery[rows[::2], 1, 1, :2] = torch.nextafter(gallery[rows[::2], 1, 1, :2], torch.full((20, 2), 10.0, device='cuda'))
     r0, v0, i0 = cvig_fov.retrieve(gallery, queries, k=k, query_chunk=128)
     r1, v1, i1 = cvig_fov.retrieve(gallery, queries, k=k, query_chunk=128, method='dft')

@@ -32,14 +32,19 @@ def _free_port():
     return p
 
 
-def fused_match(ov, su):
+def fused_match(ov, su, ori=None, want_gap=False):
     """correlation -> crop_overhead -> l2_distance (model/cvig_fov.py:297-363) without the [Bo,Bs,16,4,We] crop tensor
     (17 GB at B = 1024), in fp32 and differentiable: distance = 2 (1 - max score / (|window| |surface|)); checked against
-    the oracle's materialising form below."""
+    the oracle's materialising form below. ori: take these orientations instead of the arg-max (a score tie to fp32 rounding may
+    fall either way on another summation order; the distance and its gradient are then those of the shift taken)."""
     we, w = su.shape[3], ov.shape[3]
     x = torch.cat((ov, ov[:, :, :, :we - 1]), dim=3) if we > 1 else ov
     sc = F.conv2d(x, su).squeeze(-2)                                     # [Bo,Bs,64], the reference's own conv2d (:312)
-    ori = torch.argmax(sc.detach(), -1)
+    if want_gap:                                                         # best - runner-up score, relative to |ov| |su|
+        top = sc.detach().topk(2, dim=-1).values
+        scale = ov.detach().reshape(ov.shape[0], -1).norm(dim=1)[:, None] * su.detach().reshape(su.shape[0], -1).norm(dim=1)[None, :]
+        return torch.argmax(sc.detach(), -1), (top[..., 0] - top[..., 1]) / scale
+    ori = torch.argmax(sc.detach(), -1) if ori is None else ori
     col = (ov * ov).sum(dim=(1, 2))
     col2 = torch.cat((col, col[:, :we - 1]), dim=1) if we > 1 else col
     win = col2.unfold(1, we, 1)[:, :w].sum(-1)                           # [Bo,64] window energy per shift

@@ -43,11 +43,17 @@ def test_config3_sharded_match_loss_1024_over_8_rank_threads_on_hip():
     loss1 = cvig_fov.triplet_loss(d1)
     loss1.backward()
     # the oracle: the reference's arithmetic on the CPU (fused form of correlation / crop_overhead / l2_distance, triplet_loss)
+    # Orientation: the CPU's arg-max wherever its two best scores are further apart than fp32 summation rounding; on the handful
+    # of pairs inside that band either shift is a correct arg-max, and the distance / gradient comparison below takes the shift
+    # the HIP kernel took (one flipped pair moves 4096 gradient entries by its share of the loss, ~1e-3 of the largest entry).
     ovc, suc = ov.clone().requires_grad_(True), su.clone().requires_grad_(True)
-    ori_c, d_c = fused_match(ovc, suc)
+    ori_c, gap = fused_match(ov, su, want_gap=True)
+    clear_all = gap > 8e-6
+    assert float(clear_all.float().mean()) > 0.999 and torch.equal(ori1.cpu()[clear_all], ori_c[clear_all])
+    assert (ori_c.diagonal() == (5 * torch.arange(C3_B)) % 64).float().mean() > 0.9
+    _, d_c = fused_match(ovc, suc, ori=ori1.cpu())
     loss_c = O.triplet_loss(d_c)
     loss_c.backward()
-    assert (ori_c.diagonal() == (5 * torch.arange(C3_B)) % 64).float().mean() > 0.9
     assert abs(loss1.item() - loss_c.item()) <= 2e-6 * abs(loss_c.item())
     gov1, gsu1 = ov1.grad.cpu(), su1.grad.cpu()
     for rank, (loss, g_ov, g_su, ori, d) in enumerate(res):
@@ -56,9 +62,7 @@ def test_config3_sharded_match_loss_1024_over_8_rank_threads_on_hip():
         assert abs(loss - loss_c.item()) <= 2e-6 * abs(loss_c.item()), (rank, loss, loss_c.item())
         assert torch.equal(ori, ori1.cpu()[:, sl])                       # the slab kernel's choice = the full-matrix kernel's
         assert torch.equal(d, d1.detach().cpu()[:, sl])
-        clear = (ori == ori_c[:, sl])
-        assert float(clear.float().mean()) > 0.9999                     # vs the CPU: equal except at score near-ties
-        np.testing.assert_allclose(d[clear].numpy(), d_c.detach()[:, sl][clear].numpy(), rtol=0, atol=1e-5)
+        np.testing.assert_allclose(d.numpy(), d_c.detach()[:, sl].numpy(), rtol=0, atol=1e-5)
         for got, one, cpu in ((g_ov, gov1[sl], ovc.grad[sl]), (g_su, gsu1[sl], suc.grad[sl])):
             np.testing.assert_allclose(got.numpy(), one.numpy(), rtol=0, atol=1e-5 * float(one.abs().max()))
             np.testing.assert_allclose(got.numpy(), cpu.numpy(), rtol=0, atol=1e-5 * float(cpu.abs().max()))

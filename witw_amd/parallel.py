@@ -172,8 +172,9 @@ class OverlappedGradReducer:
             self.arrived[bi] += 1
             b.touched.add(id(p))
             b.fresh = False
-            # every parameter once per autograd node of the module (two encoder calls in one step = two rounds of hooks)
-            if self.arrived[bi] == len(b.params) * max(1, b.nodes):
+            # autograd sums a leaf's gradient over the nodes of ONE backward() before it accumulates (one round of hooks), but a
+            # module used by two nodes may also be driven by two backward() calls: the reduction of such a bucket waits for wait()
+            if b.nodes <= 1 and self.arrived[bi] == len(b.params):
                 self._launch(bi)
         return fn
 
