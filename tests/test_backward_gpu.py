@@ -396,7 +396,7 @@ def test_grad_bucket_gradients_are_written_in_place():
     # all-reduce only after the second node's gradients have been accumulated
     opt.zero_grad()
     launches = []
-    red._launch = lambda bi: launches.append((bi, red.arrived[bi]))
+    red._launch = lambda bi: launches.append((bi, red.buckets[bi].arrived))
     o1 = enc(x, dropout_scales=drops)
     o2 = enc(x, dropout_scales=drops)
     assert bucket.nodes == 2

@@ -43,7 +43,9 @@ def _ref(x, w, b, sh, circ, relu, pool):
 
 def _assert_bf16_ulp(got, ref):
     r16 = ref.bfloat16().float()
-    bad = (got - r16).abs() > 2.0 ** -7 * torch.maximum(r16.abs(), got.abs()) + 1e-6
+    # one bf16 unit in the last place, and next to zero the rounding of the fp32 sum itself (thousands of products of size ~1e-2:
+    # the CPU's fp32 conv is 2e-6 from the fp64 sum on these layers, tools/debug/bf16_s2.py), which is many units of a 3e-5 output
+    bad = (got - r16).abs() > 2.0 ** -7 * torch.maximum(r16.abs(), got.abs()) + 1e-5 * float(r16.abs().max())
     # an fp32 sum that lands within rounding of a bf16 tie may round to the neighbour: still one unit in the last place
     assert not bool(bad.any()), (int(bad.sum()), float((got - r16).abs().max()))
     assert float((got == r16).float().mean()) > 0.97

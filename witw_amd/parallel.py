@@ -101,6 +101,7 @@ class GradBucket:
             p._witw_bucket = self
         self.fresh = True
         self.on_ready = on_ready
+        self.arrived = 0            # gradients accumulated through autograd since zero() / the last reduction
         self.nodes = 0              # encoder autograd nodes built since zero() (cvig_fov._EncoderFn.forward counts them)
         self.touched = set()        # id() of the parameters whose gradient was written since zero()
 
@@ -110,6 +111,7 @@ class GradBucket:
             if p.grad is not v:
                 p.grad = v
         self.fresh = True
+        self.arrived = 0
         self.nodes = 0
         self.touched = set()
 
@@ -150,7 +152,6 @@ class OverlappedGradReducer:
     def __init__(self, modules):
         self.modules = list(modules)
         self.buckets = []
-        self.arrived = [0] * len(self.modules)
         self.inflight = {}
         self._hooks = []
         for bi, m in enumerate(self.modules):
@@ -162,19 +163,19 @@ class OverlappedGradReducer:
 
     def _ready(self, bi):
         def fn():
-            self.arrived[bi] = len(self.buckets[bi].params)
+            self.buckets[bi].arrived = len(self.buckets[bi].params)
             self._launch(bi)
         return fn
 
     def _hook(self, bi):
         def fn(p):
             b = self.buckets[bi]
-            self.arrived[bi] += 1
+            b.arrived += 1
             b.touched.add(id(p))
             b.fresh = False
             # autograd sums a leaf's gradient over the nodes of ONE backward() before it accumulates (one round of hooks), but a
             # module used by two nodes may also be driven by two backward() calls: the reduction of such a bucket waits for wait()
-            if b.nodes <= 1 and self.arrived[bi] == len(b.params):
+            if b.nodes <= 1 and b.arrived == len(b.params):
                 self._launch(bi)
         return fn
 
@@ -186,14 +187,15 @@ class OverlappedGradReducer:
     def wait(self):
         """-> number of floats reduced."""
         for bi in range(len(self.buckets)):
-            if self.arrived[bi] > 0:    # a bucket some of whose gradients never came (unused parameters) goes now
+            if self.buckets[bi].arrived > 0:    # a bucket some of whose gradients never came (unused parameters) goes now
                 self._launch(bi)
         n = 0
         for bi, work in sorted(self.inflight.items()):
             work.wait()
             n += self.buckets[bi].flat.numel()
         self.inflight = {}
-        self.arrived = [0] * len(self.buckets)
+        for b in self.buckets:
+            b.arrived = 0
         return n
 
     def close(self):
