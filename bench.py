@@ -159,7 +159,7 @@ class StepBench(object):
     def preprocess(self, g_raw, o_raw):
         ops = self.ops
         surface = ops.resize_bilinear(g_raw, (128, self.ws), self.mean, self.std, self.ndiv)
-        polar = ops.polar_transform(ops.resize_bilinear(o_raw, (256, 256), self.mean, self.std, self.ndiv))
+        polar = ops.polar_from_raw(o_raw, mean=self.mean, std=self.std, n_div255=self.ndiv)      # resize + normalise + polar: one launch
         return surface, polar
 
     def embed(self, surface, polar, precision=None):
@@ -462,10 +462,14 @@ def hbm_block(sb):
             return e0.elapsed_time(e1) / n * 1e-3
         c = polar.shape[1]
         rows = {
-            'polar_kernel': (timed(lambda: ops.polar_transform(ov)), ov.numel() * 4 + polar.numel() * 4,
-                             '%d x %d x 256 x 256 fp32 in, %d x %d x 128 x 512 out' % (B, c, B, c)),
-            'resize_bilinear_norm_kernel (overhead 512 -> 256)': (timed(lambda: ops.resize_bilinear(sb.ov_raw, (256, 256), sb.mean, sb.std, sb.ndiv)),
-                                                                  sb.ov_raw.numel() * 4 + ov.numel() * 4, 'raw 512 x 512 in, 256 x 256 out'),
+            'polar_from_raw_kernel (overhead side: resize 512 -> 256 + normalise + polar transform, one launch: what the step runs)': (
+                timed(lambda: ops.polar_from_raw(sb.ov_raw, mean=sb.mean, std=sb.std, n_div255=sb.ndiv)),
+                sb.ov_raw.numel() * 4 + polar.numel() * 4, 'raw %d x %d x 512 x 512 fp32 in, %d x %d x 128 x 512 out; the 256 x 256 image is never written' % (B, c, B, c)),
+            'resize_bilinear_norm_kernel (ground side 224 -> 128 x 512)': (timed(lambda: ops.resize_bilinear(sb.ground_raw, (128, sb.ws), sb.mean, sb.std, sb.ndiv)),
+                                                                          sb.ground_raw.numel() * 4 + B * c * 128 * sb.ws * 4, 'raw 224 x 224 in, 128 x %d out' % sb.ws),
+            'the former overhead side, two launches: resize_bilinear_norm_kernel 512 -> 256, then polar_kernel': (
+                timed(lambda: ops.polar_transform(ops.resize_bilinear(sb.ov_raw, (256, 256), sb.mean, sb.std, sb.ndiv))),
+                sb.ov_raw.numel() * 4 + polar.numel() * 4, 'same algorithmic bytes (raw in, polar out) as the fused launch'),
             'conv3x3_first_kernel (3 -> 64 channels, NCHW in, NHWC out)': (timed(lambda: ops.conv3x3_first_fwd(polar, packed, circular=True, relu=True)),
                                                                            polar.numel() * 4 + B * 128 * 512 * 64 * 4, '2.1 GB written per launch'),
         }

@@ -356,6 +356,18 @@ int witw_normalize(const float* x, float* y, int B, int C, int H, int W, const f
  * built on the host in fp64 exactly as model/cvig_fov.py:163-181,197-201. */
 int witw_polar_transform(const float* x, const int* taps, const float* wts, float* y, int B, int C, int size, int Ho, int Wo,
                          void* stream);
+/* Overhead side of Compose[Resize, ImageNormalization, PolarTransform] (model/cvig_fov.py:393-397, classes :100-209) in ONE
+ * launch: raw image -> bilinear size x size value -> (x/255 - mean)/std -> 4-tap polar gather -> y [B,C,Ho,Wo]; the size x size
+ * image is never written; bit-identical to witw_resize_bilinear_normalize(_batched) followed by witw_polar_transform.
+ * desc == NULL: src = fp32 [B,C,Hi,Wi]; else desc = the DEVICE table of witw_resize_bilinear_normalize_batched (kind 0 fp32
+ * CHW, 1 uint8 HWC). wts: the weights of witw_polar_transform's table; taps: its taps as offsets (row * box width + column)
+ * inside their tile's box. tiles: DEVICE int32 [n_tile][8] = {box x0, y0, width,
+ * height, first output row, first output column, rows, columns}: a partition of the Ho x Wo outputs into tiles of at most 256
+ * outputs, each with the bounding box (in the size x size plane) of all taps it reads, box width and height <= 64;
+ * max_box = the largest box width*height (-1 otherwise: use the separate launches). */
+int witw_polar_from_raw(const void* src, const void* desc, int kind, float* y, int B, int C, int Hi, int Wi, int size, int Ho,
+                        int Wo, const int* taps, const float* wts, const int* tiles, int n_tile, int max_box, const float* mean,
+                        const float* stdv, int n_div255, void* stream);
 /* bilinear_interpolate (model/cvig_fov.py:156-183) on arbitrary coordinates: the same 4-tap gather with a caller-built
  * table; taps = flat offsets into a plane of plane_in elements, n_out samples per plane: y [B,C,n_out]. */
 int witw_bilinear_gather(const float* x, const int* taps, const float* wts, float* y, int B, int C, long long plane_in,

@@ -191,6 +191,10 @@ def test_batched_preprocess_equals_the_per_sample_transforms(tmp_path):
             assert out['idx'] == [0, 1, 2, 3]
             assert torch.equal(out['surface'], ref_s), (dataset, fov, name)
             assert torch.equal(out['polar'], ref_p), (dataset, fov, name)
+            assert 'overhead' not in out              # the fused overhead launch never forms the 256 x 256 image
+        prep.keep_overhead = True                     # the reference's dict, overhead side as two launches
+        out = prep(batches['packed bytes'], starts=starts)
+        assert torch.equal(out['polar'], ref_p) and tuple(out['overhead'].shape) == (4, 3, 256, 256)
     # one batch ahead on a copy stream
     ds_like = [cvig_fov.collate_packed(as_bytes[:2]), cvig_fov.collate_packed(as_bytes[2:])]
     prep = cvig_fov.GpuPreprocess('witw', fov=70)

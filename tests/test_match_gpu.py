@@ -124,6 +124,48 @@ def test_polar_transform_bit_exact(golden_dir):
     np.testing.assert_array_equal(batched[1].numpy(), O.polar_transform(img * 2).numpy())
 
 
+def test_fused_resize_normalize_polar_equals_the_three_launches(golden_dir):
+    """witw_polar_from_raw (Resize -> ImageNormalization -> PolarTransform of the overhead side in one launch,
+    model/cvig_fov.py:117-209) against the separate launches: the same BITS for uniform fp32 batches of BASELINE's raw size, odd
+    sizes, 1 / 3 / 5 channels with cvig_semantic's normalisation, and no normalisation; and the reference golden of the polar
+    transform itself through the fused kernel (a 256 x 256 source resizes to itself exactly)."""
+    from witw_amd import ops
+    g = _g(golden_dir, 'polar.npz')
+    img = torch.from_numpy(synth.normalized_images(int(g['seed']), int(g['stream']), (3, 256, 256))).cuda()
+    out = ops.polar_from_raw(img.unsqueeze(0))[0].cpu()
+    np.testing.assert_array_equal(out[:, ::8, :].numpy(), g['polar_rows'])
+    assert out.double().sum().item() == float(g['polar_sum'])
+    mean, std = list(O.SEM_MEAN), list(O.SEM_STD)
+    for (B, C, Hi, Wi) in ((7, 3, 512, 512), (2, 5, 512, 512), (3, 3, 500, 470), (2, 1, 300, 777), (1, 3, 97, 64), (13, 3, 256, 256)):
+        x = torch.from_numpy(synth.images_u8(70 + C, Hi, (B, C, Hi, Wi))).cuda()
+        if C > 3:
+            x[:, 3:] /= 255.0
+        for norm in (True, False):
+            m, s_, nd = (mean[:C], std[:C], min(C, 3)) if norm else (None, None, None)
+            ref = ops.polar_transform(ops.resize_bilinear(x, (256, 256), m, s_, nd))
+            got = ops.polar_from_raw(x, mean=m, std=s_, n_div255=nd)
+            assert torch.equal(ref, got), (B, C, Hi, Wi, norm, float((ref - got).abs().max()))
+    # a polar geometry other than the model's (heat-map tiles): its own tile table
+    x = torch.from_numpy(synth.images_u8(75, 1, (2, 3, 200, 200))).cuda()
+    ref = ops.polar_transform(ops.resize_bilinear(x, (128, 128), mean[:3], std[:3]), 64, 256)
+    got = ops.polar_from_raw(x, mean=mean[:3], std=std[:3], size=128, h_s=64, w_s=256)
+    assert torch.equal(ref, got)
+
+
+def test_resize_normalisation_division_is_the_ieee_quotient():
+    """The resize kernels divide by 255 and by std through a reciprocal and two fma (csrc/preprocess.hip: div_exact); the result
+    must be the correctly rounded quotient, i.e. equal witw_normalize (true divisions) applied to the un-normalised resize --
+    the reference's own order of operations (Resize, then ImageNormalization: model/cvig_fov.py:117-149)."""
+    from witw_amd import ops
+    for C, mean, std, nd in ((3, [0.485, 0.456, 0.406], [0.229, 0.224, 0.225], 3), (5, list(O.SEM_MEAN), list(O.SEM_STD), 3),
+                             (2, [0.1, -3.0], [1.9999999, 7.0], 1)):        # 1.9999999 = all-ones significand: the true division
+        x = torch.from_numpy(synth.images_u8(80, C, (4, C, 224, 224))).cuda()
+        x = x + torch.rand_like(x)            # arbitrary significands, not only integers
+        a = ops.resize_bilinear(x, (128, 512), mean, std, nd)
+        b = ops.normalize(ops.resize_bilinear(x, (128, 512)), mean, std, nd)
+        assert torch.equal(a, b), (C, float((a - b).abs().max()))
+
+
 def test_normalization_bit_exact(golden_dir):
     from witw_amd import cvig_fov
     g = _g(golden_dir, 'normalize.npz')

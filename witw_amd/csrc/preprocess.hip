@@ -9,15 +9,31 @@
 // Compiled with -ffp-contract=off so products and sums round exactly like the reference's
 // separate elementwise torch ops (polar: wa*Ia + wb*Ib + wc*Ic + wd*Id, left to right).
 #include "common.h"
+#include <string.h>
 
 namespace {
 
 struct NormArgs {
     float mean[8];
     float stdv[8];
+    float rstd[8];  // RN(1/stdv[c]) where the three-operation division below is exact, else 0 (-> a true division)
     int n_div255;   // channels [0,n_div255) are divided by 255 first
     int enabled;
 };
+
+// a / b, correctly rounded, without the division sequence: with y = RN(1/b), q0 = RN(a y), r = a - b q0 (exact in one fma),
+// q1 = RN(q0 + r y) is the IEEE quotient (Markstein) for every finite a whose quotient is a normal number, unless b's
+// significand is all ones; fill_norm() hands out y only for divisors in [2^-10, 2^10] that pass that test, and
+// tools/debug/markstein.py compares 1.7e8 dividends per divisor of the two models with the true division: no difference.
+// y == 0 selects the true division.
+__device__ __forceinline__ float div_exact(float a, float b, float y) {
+    if (y == 0.f) return a / b;
+    const float q0 = a * y;
+    const float r = __fmaf_rn(-b, q0, a);
+    return __fmaf_rn(r, y, q0);
+}
+constexpr float RCP_255 = 0x1.010102p-8f;      // RN(1/255)
+
 
 // One thread per output pixel (b, y, x); loops over channels. Source index / lambda follow
 // ATen's area_pixel_compute_source_index (align_corners=False): src = scale*(dst+0.5)-0.5, <0 -> 0.
@@ -46,8 +62,8 @@ __global__ void resize_bilinear_norm_kernel(const float* __restrict__ x, float* 
         const float bot = lx0 * p[(size_t)y1 * Wi + x0] + lx1 * p[(size_t)y1 * Wi + x1];
         float v = ly0 * top + ly1 * bot;
         if (na.enabled) {
-            if (c < na.n_div255) v = v / 255.f;
-            v = (v - na.mean[c]) / na.stdv[c];
+            if (c < na.n_div255) v = div_exact(v, 255.f, RCP_255);
+            v = div_exact(v - na.mean[c], na.stdv[c], na.rstd[c]);
         }
         y[(((size_t)b * C + c) * Ho + oy) * Wo + ox] = v;
     }
@@ -103,10 +119,253 @@ __global__ void resize_batched_kernel(const ImgDesc* __restrict__ desc, float* _
         const float bot = lx0 * p10 + lx1 * p11;
         float v = ly0 * top + ly1 * bot;
         if (na.enabled) {
-            if (c < na.n_div255) v = v / 255.f;
-            v = (v - na.mean[c]) / na.stdv[c];
+            if (c < na.n_div255) v = div_exact(v, 255.f, RCP_255);
+            v = div_exact(v - na.mean[c], na.stdv[c], na.rstd[c]);
         }
         y[(((size_t)b * C + c) * Ho + oy) * Wo + ox] = v;
+    }
+}
+
+// ---- Resize -> ImageNormalization -> PolarTransform of the overhead image in ONE pass (model/cvig_fov.py:117-209, the
+// overhead branch of Compose[Resize, ImageNormalization, PolarTransform]): the size x size resized + normalised image is never
+// written. The output is cut into tiles of RH radii (rows) x AW angles (columns), RH * AW <= 256; a WAVE owns one tile for a run
+// of (image, channel) planes and never synchronises with another wave. Its sampling-table entries (4 outputs per lane) are
+// loaded ONCE into registers, the taps as offsets inside the tile's bounding box of the resized image; per plane the wave
+// (1) computes the resized + normalised pixels of that box from the raw image into its own LDS area -- operation for
+// operation resize_batched_kernel's arithmetic, the separable row / column terms (source offsets, second-tap weight) from
+// small LDS tables that are rebuilt only when the source size changes --, (2) gathers the four taps of every output from LDS
+// and combines them exactly as polar_kernel does. Bit-identical to the three launches. Waves are dealt so that the tiles of
+// one run of planes share an XCD: the boxes of neighbouring tiles overlap and the raw image crosses the fabric once.
+struct PolarTile {
+    int bx0, by0, bw, bh;     // bounding box in the size x size plane of every tap of the tile
+    int r0, c0, rh, aw;       // output rows [r0, r0+rh) x columns [c0, c0+aw)
+};
+
+struct PolarRawArgs {
+    const void* src;          // KIND 0: fp32 planar [B,C,Hi,Wi]; unused when desc != nullptr
+    const ImgDesc* desc;      // per-image {address, H, W, -, channels per stored pixel} or nullptr (uniform fp32 batch)
+    float* y;                 // [B,C,Ho,Wo]
+    const int4* taps;
+    const float4* wts;
+    const PolarTile* tile;
+    int B, C, Hi, Wi, size, Ho, Wo, n_tile, planes_per_wave, n_group, box_stride;
+    NormArgs na;
+};
+
+constexpr int PR_WAVES = 4;     // independent waves per workgroup
+constexpr int PR_OUT = 4;       // outputs per lane: rh * aw <= 64 * PR_OUT
+constexpr int PR_MAXE = 64;     // widest / tallest tile box
+
+// LDS traffic of ONE wave is processed in issue order, so a hand-over between its lanes needs no barrier: only the compiler has
+// to be kept from moving LDS accesses across this point, and the LDS counter drained. (A fence builtin would also wait for
+// vmcnt, i.e. for the previous plane's output STORES: ~2 us per plane with nothing to overlap them.)
+__device__ __forceinline__ void wave_lds_sync() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+#ifndef PR_OCC
+#define PR_OCC 4
+#endif
+typedef const __attribute__((address_space(1))) unsigned char* gmem_u8;
+typedef const __attribute__((address_space(1))) float* gmem_f32;
+
+#ifndef PR_NPL_N
+#define PR_NPL_N 1
+#endif
+// planes of equal source size a wave takes through one pass (shared index / address arithmetic). Measured 1 / 2 / 3: the same
+// 165 us at 128 x 3 x 512^2 (the pass is bound by the issue of its LDS + vector instructions, not by their count per plane);
+// 1 keeps the register count (100) and the LDS area per wave (4.5 KB) lowest.
+constexpr int PR_NPL = PR_NPL_N;
+
+struct PolarPlane {             // per-plane scalars (SGPRs)
+    gmem_u8 base;
+    float* y;
+    float mean, stdv, rstd;
+    bool div255;
+};
+
+// NPL planes of one tile: (1) their boxes of the resized + normalised image into LDS, (2) the tile's outputs from LDS.
+template <int KIND, int NPL>
+__device__ __forceinline__ void polar_planes(const PolarPlane (&pp)[PR_NPL], bool norm, int lane, float* bp, int box_stride, const unsigned* cx0,
+                                             const unsigned* cx1, const float* clx1, const unsigned* ry0, const unsigned* ry1,
+                                             const float* rly1, int bw, int n_box, float inv_bw, const unsigned (&o01)[PR_OUT],
+                                             const unsigned (&o23)[PR_OUT], const int (&dst)[PR_OUT], const float4 (&wt)[PR_OUT]) {
+    constexpr int MLP = NPL == 1 ? 6 : NPL == 2 ? 4 : 3;        // box pixels per lane whose 4 * NPL loads each are in flight together
+#ifndef WITW_PR_NOP1
+    for (int q0 = lane; q0 < n_box; q0 += 64 * MLP) {
+        float p00[NPL][MLP], p01[NPL][MLP], p10[NPL][MLP], p11[NPL][MLP], lx1[MLP], ly1[MLP];
+#pragma unroll
+        for (int k = 0; k < MLP; ++k) {
+            int q = q0 + 64 * k;
+            if (q >= n_box) q = n_box - 1;      // the tail repeats the last pixel (not stored)
+            const int ry = (int)(((float)q + 0.5f) * inv_bw), rx = q - ry * bw;
+#ifdef WITW_PR_NOTAB
+            const unsigned r0 = ry * 2048u, r1 = r0 + 2048u, x0 = rx * 8u, x1 = x0 + 4u;
+            ly1[k] = 0.5f; lx1[k] = 0.5f;
+#else
+            const unsigned r0 = ry0[ry], r1 = ry1[ry], x0 = cx0[rx], x1 = cx1[rx];
+            ly1[k] = rly1[ry];
+            lx1[k] = clx1[rx];
+#endif
+            const unsigned a00 = r0 + x0, a01 = r0 + x1, a10 = r1 + x0, a11 = r1 + x1;      // byte offsets, the same in every plane
+#pragma unroll
+            for (int j = 0; j < NPL; ++j) {
+                if (KIND == 0) {
+                    p00[j][k] = *reinterpret_cast<gmem_f32>(pp[j].base + a00); p01[j][k] = *reinterpret_cast<gmem_f32>(pp[j].base + a01);
+                    p10[j][k] = *reinterpret_cast<gmem_f32>(pp[j].base + a10); p11[j][k] = *reinterpret_cast<gmem_f32>(pp[j].base + a11);
+                } else {
+                    p00[j][k] = (float)pp[j].base[a00]; p01[j][k] = (float)pp[j].base[a01];
+                    p10[j][k] = (float)pp[j].base[a10]; p11[j][k] = (float)pp[j].base[a11];
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < MLP; ++k) {
+            const int q = q0 + 64 * k;
+            const float ly0 = 1.f - ly1[k], lx0 = 1.f - lx1[k];
+#pragma unroll
+            for (int j = 0; j < NPL; ++j) {
+                const float top = lx0 * p00[j][k] + lx1[k] * p01[j][k];
+                const float bot = lx0 * p10[j][k] + lx1[k] * p11[j][k];
+                float v = ly0 * top + ly1[k] * bot;
+                if (norm) {
+                    if (pp[j].div255) v = div_exact(v, 255.f, RCP_255);
+                    v = div_exact(v - pp[j].mean, pp[j].stdv, pp[j].rstd);
+                }
+#ifdef WITW_PR_NOWRITE
+                if (v == 12345.f) bp[j * box_stride + q] = v;
+#else
+                if (q < n_box) bp[j * box_stride + q] = v;
+#endif
+            }
+        }
+    }
+#endif
+    wave_lds_sync();
+#pragma unroll
+    for (int i = 0; i < PR_OUT; ++i) {
+#ifdef WITW_PR_NOP2
+        if (dst[i] == -7) pp[0].y[0] = wt[i].x + (float)(o01[i] + o23[i]);
+#else
+        if (dst[i] >= 0) {
+            const float4 ww = wt[i];
+            const unsigned a = o01[i] & 0xffffu, b = o01[i] >> 16, c = o23[i] & 0xffffu, d = o23[i] >> 16;
+#pragma unroll
+            for (int j = 0; j < NPL; ++j) {
+                const float* bj = bp + j * box_stride;
+                pp[j].y[dst[i]] = ((ww.x * bj[a] + ww.y * bj[b]) + ww.z * bj[c]) + ww.w * bj[d];
+            }
+        }
+#endif
+    }
+    wave_lds_sync();      // the next pass overwrites the boxes
+}
+
+#ifndef PR_OCC
+#define PR_OCC 4
+#endif
+template <int KIND>
+__global__ __launch_bounds__(64 * PR_WAVES, PR_OCC) void polar_from_raw_kernel(PolarRawArgs p) {
+    extern __shared__ float lds_all[];
+    // the wave index is the same in every lane: say so, or everything derived from it (tile, plane, base address, the
+    // normalisation constants) lives in vector registers and is fetched by vector loads
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int xcd = blockIdx.x & 7, slot = (blockIdx.x >> 3) * PR_WAVES + wave;
+    const int g = xcd + 8 * (slot / p.n_tile);
+    if (g >= p.n_group) return;
+    const PolarTile tl = p.tile[slot % p.n_tile];
+    const int bx0 = tl.bx0, by0 = tl.by0, bw = tl.bw, bh = tl.bh;
+    const int n_out = tl.rh * tl.aw;
+    float* bp = lds_all + wave * (PR_NPL * p.box_stride + 6 * PR_MAXE);      // this wave's boxes ...
+    float* tab = bp + PR_NPL * p.box_stride;                                 // ... and its separable-term tables
+    unsigned* cx0 = reinterpret_cast<unsigned*>(tab);
+    unsigned* cx1 = cx0 + PR_MAXE;
+    float* clx1 = tab + 2 * PR_MAXE;
+    unsigned* ry0 = reinterpret_cast<unsigned*>(tab + 3 * PR_MAXE);
+    unsigned* ry1 = ry0 + PR_MAXE;
+    float* rly1 = tab + 5 * PR_MAXE;
+    unsigned o01[PR_OUT], o23[PR_OUT];      // the four box offsets of an output, 16 bits each
+    int dst[PR_OUT];
+    float4 wt[PR_OUT];
+#pragma unroll
+    for (int i = 0; i < PR_OUT; ++i) {
+        const int j = lane + 64 * i;
+        dst[i] = -1;
+        o01[i] = o23[i] = 0;
+        wt[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (j < n_out) {
+            const int yy = j / tl.aw, xx = j - yy * tl.aw;
+            const int pix = (tl.r0 + yy) * p.Wo + tl.c0 + xx;
+            const int4 t = p.taps[pix];       // offsets inside the tile's box (built with the tile table)
+            wt[i] = p.wts[pix];
+            dst[i] = pix;
+            o01[i] = (unsigned)t.x | ((unsigned)t.y << 16);
+            o23[i] = (unsigned)t.z | ((unsigned)t.w << 16);
+        }
+    }
+    const int n_plane = p.B * p.C;
+    const int pl0 = g * p.planes_per_wave, pl1 = min(n_plane, pl0 + p.planes_per_wave);
+    const int n_box = bw * bh;
+    const float inv_bw = 1.0f / (float)bw;      // q / bw through the reciprocal: exact for q < 2^12, bw <= 64
+    int Hi_prev = -1, Wi_prev = -1, cs_prev = -1;
+    int pl = pl0;
+    while (pl < pl1) {
+        PolarPlane pp[PR_NPL];
+        int n = 0, Hi = 0, Wi = 0, cs = 1;
+        bool run = true;
+#pragma unroll
+        for (int j = 0; j < PR_NPL; ++j) {       // the run of planes with the first one's source size (constant j: registers)
+            const int plj = min(pl + j, pl1 - 1);
+            const int b = plj / p.C, c = plj - b * p.C;
+            int h = p.Hi, w = p.Wi, s = 1;
+            unsigned long long addr;
+            if (p.desc != nullptr) {
+                const ImgDesc d = p.desc[b];
+                h = (int)d.H; w = (int)d.W; s = (int)d.cs;
+                addr = d.ptr + (KIND == 0 ? (unsigned long long)c * h * w * 4 : (unsigned long long)c);
+            } else {
+                addr = (unsigned long long)p.src + ((unsigned long long)b * p.C + c) * h * w * 4;
+            }
+            if (j == 0) { Hi = h; Wi = w; cs = s; }
+            run = run && pl + j < pl1 && h == Hi && w == Wi && s == cs;
+            if (run) n = j + 1;
+            // the same in every lane: scalar registers (loads take the form base (SGPR pair) + 32-bit byte offset (VGPR))
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)addr), hi = __builtin_amdgcn_readfirstlane((unsigned)(addr >> 32));
+            pp[j].base = (gmem_u8)(((unsigned long long)hi << 32) | lo);
+            pp[j].y = p.y + (size_t)plj * p.Ho * p.Wo;
+            pp[j].mean = p.na.mean[c]; pp[j].stdv = p.na.stdv[c]; pp[j].rstd = p.na.rstd[c];
+            pp[j].div255 = c < p.na.n_div255;
+        }
+        if (Hi != Hi_prev || Wi != Wi_prev || cs != cs_prev) {       // wave-uniform
+            Hi_prev = Hi; Wi_prev = Wi; cs_prev = cs;
+            const float sh = (float)Hi / (float)p.size, sw = (float)Wi / (float)p.size;
+            const unsigned es = KIND == 0 ? 4u : (unsigned)cs;      // BYTES between neighbouring pixels of a row
+            wave_lds_sync();
+            if (lane < bw) {
+                float fx = __fmaf_rn(sw, (bx0 + lane) + 0.5f, -0.5f);
+                if (fx < 0.f) fx = 0.f;
+                const int x0 = (int)fx;
+                const int x1 = x0 + ((x0 < Wi - 1) ? 1 : 0);
+                cx0[lane] = (unsigned)x0 * es; cx1[lane] = (unsigned)x1 * es; clx1[lane] = fx - x0;
+            }
+            if (lane < bh) {
+                float fy = __fmaf_rn(sh, (by0 + lane) + 0.5f, -0.5f);
+                if (fy < 0.f) fy = 0.f;
+                const int y0 = (int)fy;
+                const int y1 = y0 + ((y0 < Hi - 1) ? 1 : 0);
+                ry0[lane] = (unsigned)y0 * (unsigned)Wi * es; ry1[lane] = (unsigned)y1 * (unsigned)Wi * es; rly1[lane] = fy - y0;
+            }
+            wave_lds_sync();
+        }
+        const bool norm = p.na.enabled != 0;
+        if (PR_NPL >= 3 && n == 3)
+            polar_planes<KIND, PR_NPL >= 3 ? 3 : 1>(pp, norm, lane, bp, p.box_stride, cx0, cx1, clx1, ry0, ry1, rly1, bw, n_box, inv_bw, o01, o23, dst, wt);
+        else if (PR_NPL >= 2 && n == 2)
+            polar_planes<KIND, PR_NPL >= 2 ? 2 : 1>(pp, norm, lane, bp, p.box_stride, cx0, cx1, clx1, ry0, ry1, rly1, bw, n_box, inv_bw, o01, o23, dst, wt);
+        else
+            polar_planes<KIND, 1>(pp, norm, lane, bp, p.box_stride, cx0, cx1, clx1, ry0, ry1, rly1, bw, n_box, inv_bw, o01, o23, dst, wt);
+        pl += n;
     }
 }
 
@@ -169,6 +428,12 @@ int fill_norm(NormArgs& na, int C, const float* mean, const float* stdv, int n_d
     for (int c = 0; c < 8; ++c) {
         na.mean[c] = (na.enabled && c < C) ? mean[c] : 0.f;
         na.stdv[c] = (na.enabled && c < C) ? stdv[c] : 1.f;
+        // reciprocal for div_exact: positive normal divisor of moderate size whose significand is not all ones
+        const float b = na.stdv[c];
+        unsigned bits;
+        memcpy(&bits, &b, 4);
+        const bool ok = b >= 0x1p-10f && b <= 0x1p10f && (bits & 0x7fffffu) != 0x7fffffu;
+        na.rstd[c] = ok ? (float)(1.0 / (double)b) : 0.f;
     }
     return 0;
 }
@@ -238,6 +503,45 @@ int witw_polar_transform(const float* x, const int* taps, const float* wts, floa
     hipLaunchKernelGGL(polar_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
                        (const int4*)taps, (const float4*)wts, y, B, C, size * size, Ho * Wo);
     WITW_CHECK_LAUNCH("polar_transform");
+    return WITW_OK;
+}
+
+// Overhead side of Compose[Resize, ImageNormalization, PolarTransform] (model/cvig_fov.py:393-397) in one launch: raw image ->
+// bilinear size x size value -> normalise -> 4-tap polar gather -> y [B,C,Ho,Wo]; bit-identical to
+// witw_resize_bilinear_normalize(_batched) + witw_polar_transform. Sources: desc == NULL: src = fp32 [B,C,Hi,Wi]; else desc = the
+// DEVICE table of witw_resize_bilinear_normalize_batched (kind 0 fp32 CHW, 1 uint8 HWC; start column unused). taps / wts: the
+// DEVICE sampling table of witw_polar_transform, the taps given as offsets (row * box width + column) inside their tile's
+// box; tiles: DEVICE int32 [n_tile][8] = {box x0, y0, width, height (bounding box in
+// the size x size plane of all taps of the tile), first output row, first output column, rows, columns}; the tiles partition the
+// Ho x Wo outputs, rows*columns <= 256, box width and height <= 64, max_box = the largest box width*height (the caller builds
+// the table with the sampling table), else -1.
+int witw_polar_from_raw(const void* src, const void* desc, int kind, float* y, int B, int C, int Hi, int Wi, int size, int Ho,
+                        int Wo, const int* taps, const float* wts, const int* tiles, int n_tile, int max_box, const float* mean,
+                        const float* stdv, int n_div255, void* stream) {
+    WITW_CHECK_ARG((src || desc) && y && taps && wts && tiles, "polar_from_raw: null pointer");
+    WITW_CHECK_ARG(kind == 0 || (kind == 1 && desc), "polar_from_raw: source kind %d (0 float32 CHW, 1 uint8 HWC through a descriptor table)", kind);
+    WITW_CHECK_ARG(B > 0 && C > 0 && C <= 8 && size > 0 && Ho > 0 && Wo > 0 && (desc || (Hi > 0 && Wi > 0)), "polar_from_raw: bad shape");
+    WITW_CHECK_ARG(n_tile > 0 && max_box > 0 && max_box <= 4096, "polar_from_raw: %d tiles, largest box %d pixels: does not fit the LDS",
+                   n_tile, max_box);
+    PolarRawArgs p;
+    p.src = src; p.desc = (const ImgDesc*)desc; p.y = y; p.taps = (const int4*)taps; p.wts = (const float4*)wts;
+    p.tile = (const PolarTile*)tiles;
+    p.B = B; p.C = C; p.Hi = Hi; p.Wi = Wi; p.size = size; p.Ho = Ho; p.Wo = Wo; p.n_tile = n_tile; p.box_stride = max_box;
+    const long long n_plane = (long long)B * C;
+    // about 32 waves per CU; a wave keeps its tile's table entries in registers over its run of planes
+    p.planes_per_wave = (int)((n_plane * n_tile + 8191) / 8192);
+    if (p.planes_per_wave < 1) p.planes_per_wave = 1;
+    if (n_plane >= PR_NPL) p.planes_per_wave = (p.planes_per_wave + PR_NPL - 1) / PR_NPL * PR_NPL;      // whole passes of PR_NPL planes
+    p.n_group = (int)((n_plane + p.planes_per_wave - 1) / p.planes_per_wave);
+    fill_norm(p.na, C, mean, stdv, n_div255);
+    const long long slots = (long long)((p.n_group + 7) / 8) * n_tile;       // (run of planes, tile) pairs per XCD
+    const unsigned grid = 8u * (unsigned)((slots + PR_WAVES - 1) / PR_WAVES);
+    const size_t lds = (size_t)PR_WAVES * (PR_NPL * max_box + 6 * PR_MAXE) * 4;
+    if (kind == 0)
+        hipLaunchKernelGGL(polar_from_raw_kernel<0>, dim3(grid), dim3(64 * PR_WAVES), lds, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL(polar_from_raw_kernel<1>, dim3(grid), dim3(64 * PR_WAVES), lds, (hipStream_t)stream, p);
+    WITW_CHECK_LAUNCH("polar_from_raw");
     return WITW_OK;
 }
 

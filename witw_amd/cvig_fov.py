@@ -1199,13 +1199,17 @@ class StagedBatch(object):
 
 class GpuPreprocess(object):
     """Compose[Resize, ImageNormalization, PolarTransform] (model/cvig_fov.py:393-397) over a batch of raw images, on the
-    GPU: -> {'surface' [B,3,128,Ws], 'overhead' [B,3,256,256], 'polar' [B,3,128,512]} in THREE launches whatever the batch
-    size (one batched resize+normalise per side over a descriptor table of individually sized images, one polar transform).
+    GPU: -> {'surface' [B,3,128,Ws], 'polar' [B,3,128,512]} in TWO launches whatever the batch size: one batched resize +
+    normalise of the ground side and one fused resize + normalise + polar transform of the overhead side, each over a descriptor
+    table of individually sized images (keep_overhead = True adds the reference's 'overhead' [B,3,256,256] entry and runs the
+    overhead side as two launches; the drivers never read it).
     stage() moves a batch to the device (one copy per side from pinned memory when the batch is packed) and may run on a
     side stream ahead of time (DevicePrefetcher); __call__ accepts a raw batch or a staged one."""
 
     channels = 3
     normalization = None      # class used for the normalisation step (cvig_semantic overrides both)
+    fused = True              # overhead side through witw_polar_from_raw (False: resize + polar transform as two launches)
+    keep_overhead = False     # True: also return the reference's 'overhead' entry (the resized + normalised image; two launches)
 
     def __init__(self, dataset, fov=360, random_orientation=True, device=None):
         self.resize = Resize(dataset, fov, random_orientation)
@@ -1292,6 +1296,12 @@ class GpuPreprocess(object):
         nd = self.norm.n_div255
         surface = ops.resize_batched(st.s_desc, st.n, c, (hs, r.surface_width), wfull=wmax if r.panorama else None, kind=st.s_kind,
                                      mean=self.norm.mean, std=self.norm.std, n_div255=nd)
+        if self.fused and not self.keep_overhead and ops.polar_tiles(st.o_desc.device, so, hs, wmax) is not None:
+            # Resize -> ImageNormalization -> PolarTransform of the overhead side in one launch (the same bits; the 256 x 256
+            # intermediate is never written)
+            polar = ops.polar_from_raw(desc=st.o_desc, kind=st.o_kind, batch=st.n, channels=c, mean=self.norm.mean, std=self.norm.std,
+                                       n_div255=nd, size=so, h_s=hs, w_s=wmax)
+            return {'idx': st.idx, 'surface': surface, 'polar': polar}
         overhead = ops.resize_batched(st.o_desc, st.n, c, (so, so), kind=st.o_kind, mean=self.norm.mean, std=self.norm.std, n_div255=nd)
         return self.polar({'idx': st.idx, 'surface': surface, 'overhead': overhead})
 

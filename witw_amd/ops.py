@@ -785,6 +785,83 @@ def polar_lut(device, size=256, h_s=128, w_s=512):
     return lut
 
 
+_POLAR_TILES = {}
+
+
+def polar_tiles(device, size=256, h_s=128, w_s=512):
+    """Tile decomposition of the polar sampling table for witw_polar_from_raw: the h_s x w_s outputs are cut into tiles of rh
+    radii x aw angles (powers of two, rh * aw <= 256: one wave's work) -- the shape whose boxes cover the least area in total -- each with the
+    bounding box {x0, y0, width, height} in the size x size plane of every tap it reads. -> (int32 GPU [n_tile,8], largest box
+    area, the sampling table's taps as offsets inside their tile's box: int32 GPU [h_s*w_s,4]) or None when no shape fits the kernel's limits (callers then use the separate launches)."""
+    import numpy as np
+    key = (str(device), size, h_s, w_s)
+    if key in _POLAR_TILES:
+        return _POLAR_TILES[key]
+    taps = polar_lut(device, size, h_s, w_s)[0].cpu().numpy().reshape(h_s, w_s, 4)
+    ty, tx = taps // size, taps % size
+    best = None
+    for aw in [2 ** k for k in range(9) if 2 ** k <= min(w_s, 256)]:
+        for rh in [2 ** k for k in range(9) if 2 ** k <= max(1, 256 // aw)]:
+            rh = min(rh, h_s)
+            rows = []
+            for r0 in range(0, h_s, rh):
+                for c0 in range(0, w_s, aw):
+                    sx, sy = tx[r0:r0 + rh, c0:c0 + aw], ty[r0:r0 + rh, c0:c0 + aw]
+                    rows.append((int(sx.min()), int(sy.min()), int(sx.max() - sx.min() + 1), int(sy.max() - sy.min() + 1),
+                                 r0, c0, sx.shape[0], sx.shape[1]))
+            t = np.asarray(rows, dtype=np.int32)
+            area = t[:, 2].astype(np.int64) * t[:, 3]
+            if int(t[:, 2].max()) > 64 or int(t[:, 3].max()) > 64:
+                continue
+            # total box area = pixels resized per plane; a few large tiles beat many small ones at equal area (table reuse)
+            score = (int(area.sum()), len(rows))
+            if best is None or score < best[0]:
+                best = (score, t, int(area.max()))
+    out = None
+    if best is not None:
+        t = best[1]
+        rel = np.zeros((h_s, w_s, 4), dtype=np.int32)       # every tap as an offset inside its tile's box
+        for (bx0, by0, bw, _bh, r0, c0, rh, aw) in t.tolist():
+            sl = (slice(r0, r0 + rh), slice(c0, c0 + aw))
+            rel[sl] = (ty[sl] - by0) * bw + (tx[sl] - bx0)
+        out = (torch.from_numpy(t).to(device), best[2], torch.from_numpy(rel.reshape(-1, 4)).to(device))
+    _POLAR_TILES[key] = out
+    return out
+
+
+def polar_from_raw(x=None, desc=None, kind=0, batch=None, channels=None, mean=None, std=None, n_div255=None, size=256, h_s=128,
+                   w_s=512):
+    """Resize(size x size) -> ImageNormalization -> PolarTransform of the overhead image in one launch (witw_polar_from_raw);
+    the same bits as resize_bilinear / resize_batched followed by polar_transform. x: fp32 [B,C,Hi,Wi] on the GPU, or desc /
+    kind / batch / channels as for resize_batched. -> [B,C,h_s,w_s]."""
+    import ctypes
+    lib = _lib.load()
+    if desc is None:
+        x = _dev_f32(x, 'x')
+        B, C, Hi, Wi = x.shape
+        dev = x.device
+    else:
+        if not (desc.is_cuda and desc.dtype == torch.int64 and desc.is_contiguous() and tuple(desc.shape) == (batch, 5)):
+            raise _lib.WitwError('polar_from_raw: desc must be a contiguous int64 GPU tensor [%d,5]' % batch)
+        B, C, Hi, Wi, dev = batch, channels, 0, 0, desc.device
+    tiles = polar_tiles(dev, size, h_s, w_s)
+    if tiles is None:
+        raise _lib.WitwError('polar_from_raw: a %dx%d polar table over a %d^2 image exceeds the fused kernel (use resize + polar_transform)'
+                             % (h_s, w_s, size))
+    tile_tab, max_box, taps = tiles
+    wts = polar_lut(dev, size, h_s, w_s)[1]
+    y = torch.empty((B, C, h_s, w_s), dtype=torch.float32, device=dev)
+    m = s = None
+    if mean is not None:
+        m, s = _host_floats(mean), _host_floats(std)
+    nd = C if n_div255 is None else n_div255
+    _lib.check(lib.witw_polar_from_raw(x.data_ptr() if desc is None else None, None if desc is None else desc.data_ptr(), int(kind),
+                                       y.data_ptr(), B, C, Hi, Wi, size, h_s, w_s, taps.data_ptr(), wts.data_ptr(), tile_tab.data_ptr(),
+                                       tile_tab.shape[0], max_box, ctypes.cast(m, ctypes.c_void_p) if m is not None else None,
+                                       ctypes.cast(s, ctypes.c_void_p) if s is not None else None, nd, _stream()), 'witw_polar_from_raw')
+    return y
+
+
 def bilinear_interpolate(im, x, y):
     """bilinear_interpolate(im, x, y) of model/cvig_fov.py:156-183 for arbitrary sample coordinates: im [C,H,W] (or
     [B,C,H,W]) on the GPU, x / y arrays of one shape (host, fp64 arithmetic as in the reference: indices clipped to the
