@@ -97,7 +97,7 @@ def test_dft_match_true_pairs_and_ties():
 
 
 @pytest.mark.parametrize('shape', [(7, 5, 64), (130, 257, 64), (1100, 260, 64), (1100, 260, 63), (1100, 300, 12), (1100, 300, 31),
-                                   (1100, 300, 40), (40, 9, 1), (2100, 70, 16)])
+                                   (1100, 300, 40), (40, 9, 1), (2100, 70, 16), (128, 128, 64), (128, 128, 12), (128, 128, 30), (100, 77, 64)])
 def test_match_pairs_bit_identical_to_match_fwd(shape):
     """witw_match_pairs re-scores single pairs with the arithmetic of the all-pairs kernels: orientation, score and distance
     carry the same BITS as witw_match_fwd's entries, whichever kernel variant the all-pairs launch dispatched to (generic,

@@ -52,7 +52,10 @@ def test_match_tie_break_first_index():
     assert torch.equal(torch.diagonal(ref), torch.full((3,), 5, dtype=torch.int64))
 
 
-@pytest.mark.parametrize('shape', [(1, 1, 64), (130, 257, 64), (3, 200, 1), (70, 5, 63), (1101, 130, 64), (1030, 129, 63)])
+# (128, 128, *), (100, 77, 64), (130, 257, 64): one minibatch -> match_kernel_nsplit<64 | 32 | 16> (a workgroup per overhead, the waves split
+# the shifts); the rest: the generic and the pipelined kernels
+@pytest.mark.parametrize('shape', [(1, 1, 64), (130, 257, 64), (3, 200, 1), (70, 5, 63), (1101, 130, 64), (1030, 129, 63), (128, 128, 64),
+                                   (128, 128, 12), (128, 128, 33), (128, 128, 17), (100, 77, 64), (128, 128, 1)])
 def test_match_ragged_shapes_vs_oracle(shape):
     from witw_amd import cvig_fov
     bo, bs, we = shape
@@ -66,7 +69,7 @@ def test_match_ragged_shapes_vs_oracle(shape):
     ori, dist = ori.cpu(), dist.cpu()
     assert torch.equal(ori[safe], ori_r[safe])
     np.testing.assert_allclose(dist[safe].numpy(), dist_r[safe].numpy(), rtol=0, atol=1e-5)
-    assert safe.float().mean() > 0.95
+    assert safe.float().mean() > (0.95 if we > 1 else 0.5)
 
 
 def test_triplet_loss_fwd_bwd(golden_dir):

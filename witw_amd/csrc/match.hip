@@ -153,6 +153,178 @@ __global__ __launch_bounds__(NT) void match_kernel(MatchArgs p) {
 }
 
 
+// ---- a single minibatch (128 x 128 pairs: the matching step of BASELINE configs[1] / configs[3]): match_kernel<1,1> makes 128
+// workgroups of 4 waves there, half a wave per SIMD of the chip. Here a workgroup is ONE overhead x 64 surfaces and its four waves
+// split surfaces (2 halves of 32) x SHIFTS (2 halves of 32): 256 workgroups, one wave on every SIMD, one accumulator tile per
+// wave. The two shift halves of a (surface, overhead) pair meet in the epilogue through LDS: larger score wins, the lower
+// half (smaller shift) on a tie -- the first-index rule of torch.argmax. Every score is the same k-ordered fma chain as in
+// match_kernel (K is not split), so orientation / score / distance carry the same bits.
+template <int WP>      // surface columns per row, zero-padded: 16, 32 or 64 (every k-loop fully unrolled)
+__global__ __launch_bounds__(NT) void match_kernel_nsplit(MatchArgs p) {
+    constexpr int MSB = 64;              // surfaces per block
+    constexpr int SU_F = MSB * SUS;
+    constexpr int RPW = MSB / 4;
+    constexpr int OV_F = 128;
+    __shared__ float smem[2 * (SU_F + OV_F)];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hk = lane >> 5;
+    const int s0 = blockIdx.x * MSB;
+    const int og = blockIdx.y;
+    const int We = p.We;
+    constexpr int Wp = WP;               // zero columns beyond We add exact zeros to every score: the same bits as K = We
+    const int wm = wave >> 1;            // surface half: rows [32*wm, 32*wm+32)
+    const int wn = wave & 1;             // shift half: shifts [32*wn, 32*wn+32)
+
+    // staging: the rows of the two embeddings travel global -> registers -> LDS, TWO rows ahead of the MFMAs (two register
+    // sets A / B): one row's MFMAs last 0.85 us at one wave per SIMD, less than a global load takes to come back. Buffer loads:
+    // the row offset is a scalar, lanes beyond We and surfaces beyond Bs carry an out-of-range offset and read 0 -- no VALU
+    // work or branch per load.
+    constexpr unsigned OOR = 0x80000000u;
+    const int rows_here = min(MSB, p.Bs - s0);
+    __amdgpu_buffer_rsrc_t su_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.su + (size_t)s0 * 64 * We), 0,
+                                                                     (unsigned)rows_here * 64u * We * 4u, 0x00020000);
+    __amdgpu_buffer_rsrc_t ov_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.ov + (size_t)og * 4096), 0, 4096u * 4u, 0x00020000);
+    unsigned suoff[RPW];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        const int row = wave + 4 * i;
+        suoff[i] = (lane < We && row < rows_here) ? ((unsigned)row * 64u * We + lane) * 4u : OOR;
+    }
+    const unsigned ovoff = (unsigned)lane * 4u;
+    float rsuA[RPW], rsuB[RPW];
+    float rovA, rovB;
+    auto load_A = [&](int r) {
+        const unsigned srow = (unsigned)r * We * 4u;
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) rsuA[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(su_rs, suoff[i], srow, 0));
+        rovA = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ov_rs, ovoff, (unsigned)r * 256u, 0));
+    };
+    auto load_B = [&](int r) {
+        const unsigned srow = (unsigned)r * We * 4u;
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) rsuB[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(su_rs, suoff[i], srow, 0));
+        rovB = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ov_rs, ovoff, (unsigned)r * 256u, 0));
+    };
+    auto store_A = [&](int buf) {
+        float* su_s = smem + buf * (SU_F + OV_F);
+        float* ov_s = su_s + SU_F;
+        if (lane < Wp) {
+#pragma unroll
+            for (int i = 0; i < RPW; ++i) su_s[(wave + 4 * i) * SUS + lane] = rsuA[i];
+        }
+        if (wave == 0) { ov_s[lane] = rovA; ov_s[64 + lane] = rovA; }
+    };
+    auto store_B = [&](int buf) {
+        float* su_s = smem + buf * (SU_F + OV_F);
+        float* ov_s = su_s + SU_F;
+        if (lane < Wp) {
+#pragma unroll
+            for (int i = 0; i < RPW; ++i) su_s[(wave + 4 * i) * SUS + lane] = rsuB[i];
+        }
+        if (wave == 0) { ov_s[lane] = rovB; ov_s[64 + lane] = rovB; }
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    load_A(0);
+    load_B(1);
+    store_A(0);
+    __syncthreads();
+
+    // a row's KS k-steps in four groups; the operands of group g+1 are read (one LDS read pair per MFMA) while group g
+    // multiplies, the row's barrier sits in front of the last group and the first group of the NEXT row is read behind it
+    constexpr int KS = Wp / 2, GS = KS / 4;
+    const int arow = (32 * wm + l31) * SUS + hk;
+    const int bcol = 32 * wn + l31 + hk;
+    float fa[2][GS], fb[2][GS];
+    auto read_group = [&](int set, int stage, int g) {
+        const float* su_s = smem + stage * (SU_F + OV_F);
+        const float* ov_s = su_s + SU_F;
+#pragma unroll
+        for (int j = 0; j < GS; ++j) {
+            fa[set][j] = su_s[arow + 2 * (GS * g + j)];
+            fb[set][j] = ov_s[bcol + 2 * (GS * g + j)];
+        }
+    };
+    auto mfma_group = [&](int set) {
+#pragma unroll
+        for (int j = 0; j < GS; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][j], fb[set][j], acc, 0, 0, 0);
+    };
+    // issue order inside a group: GS x (one MFMA, its two LDS reads for the next group), the group's global loads (mask 0x020)
+    // or LDS writes (0x200) spread evenly behind the MFMAs
+    constexpr int PER = (RPW + 1 + GS - 1) / GS;
+#define NSPLIT_INTERLEAVE(OTHER_MASK)                                                   \
+    _Pragma("unroll") for (int j = 0; j < GS; ++j) {                                     \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                               \
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                               \
+        if (OTHER_MASK) __builtin_amdgcn_sched_group_barrier(OTHER_MASK, PER, 0);        \
+    }
+    read_group(0, 0, 0);
+    for (int r = 0; r < 64; r += 2) {
+        // row r from stage 0; set B holds row r+1 (loaded one row ago), set A takes row r+2
+        load_A(min(r + 2, 63));
+        read_group(1, 0, 1); mfma_group(0); NSPLIT_INTERLEAVE(0x020)
+        read_group(0, 0, 2); store_B(1); mfma_group(1); NSPLIT_INTERLEAVE(0x200)
+        read_group(1, 0, 3); mfma_group(0); NSPLIT_INTERLEAVE(0)
+        __syncthreads();
+        read_group(0, 1, 0); mfma_group(1); NSPLIT_INTERLEAVE(0)
+        // row r+1 from stage 1; set A holds row r+2, set B takes row r+3
+        load_B(min(r + 3, 63));
+        read_group(1, 1, 1); mfma_group(0); NSPLIT_INTERLEAVE(0x020)
+        read_group(0, 1, 2); store_A(0); mfma_group(1); NSPLIT_INTERLEAVE(0x200)
+        read_group(1, 1, 3); mfma_group(0); NSPLIT_INTERLEAVE(0)
+        __syncthreads();
+        read_group(0, 0, 0); mfma_group(1); NSPLIT_INTERLEAVE(0)
+    }
+
+#undef NSPLIT_INTERLEAVE
+    // ---- epilogue: arg-max over this wave's 32 shifts, then across the two shift halves (LDS), first index wins ties
+    float* xv = smem;                                          // [2 surface halves][32 rows] best score of the upper shift half
+    int* xi = reinterpret_cast<int*>(smem + 64);               // ... and its shift
+    float bv[16];
+    int bi[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float v = acc[r];
+        int idx = 32 * wn + l31;
+#pragma unroll
+        for (int d = 1; d < 32; d <<= 1) {
+            const float vo = __shfl_xor(v, d, 64);
+            const int io = __shfl_xor(idx, d, 64);
+            if (vo > v || (vo == v && io < idx)) { v = vo; idx = io; }
+        }
+        bv[r] = v;
+        bi[r] = idx;
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hk;      // surface row inside this wave's half
+        if (wn == 1 && l31 == r) {
+            xv[32 * wm + row] = v;
+            xi[32 * wm + row] = idx;
+        }
+    }
+    __syncthreads();
+    if (wn == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * hk;
+            const int srow = s0 + 32 * wm + row;
+            if (l31 == r && srow < p.Bs) {
+                float v = bv[r];
+                int idx = bi[r];
+                const float v1 = xv[32 * wm + row];
+                if (v1 > v) { v = v1; idx = xi[32 * wm + row]; }
+                const size_t off = (size_t)og * p.Bs + srow;
+                if (p.orientation) p.orientation[off] = idx;
+                if (p.score) p.score[off] = v;
+                if (p.distance) p.distance[off] = 2.f * (1.f - v / (p.wn[(size_t)og * 64 + idx] * p.sn[srow]));
+            }
+        }
+    }
+}
+
+
 // ---- pipelined variant for full-width surfaces (We in {63,64}: 32 MFMA k-steps per embedding row), the
 // retrieval shape (BASELINE config C5). Same tiling as match_kernel<2> (4 overheads x 128 surfaces per
 // workgroup) but: staging uses buffer loads (row offset in a scalar, out-of-range rows/columns read 0: no
@@ -861,7 +1033,12 @@ int witw_match_fwd(const float* ov, const float* su, int Bo, int Bs, int We, lon
         hipLaunchKernelGGL((match_kernel<2, 2>), dim3(gx, cdiv(Bo, 4)), dim3(NT), 0, st, a);
     } else if ((long long)gx * cdiv(Bo, 2) >= 256) {
         hipLaunchKernelGGL((match_kernel<1, 2>), dim3(gx, cdiv(Bo, 2)), dim3(NT), 0, st, a);
-    } else {        // a single minibatch (128 x 128): 64-surface blocks double the workgroup count
+    } else if ((long long)cdiv(Bs, 64) * cdiv(Bo, 2) >= 96) {      // a single minibatch (128 x 128): one overhead per workgroup, the
+        const dim3 g2(cdiv(Bs, 64), Bo);                                       // waves split the shifts: a wave on every SIMD
+        if (We <= 16) hipLaunchKernelGGL(match_kernel_nsplit<16>, g2, dim3(NT), 0, st, a);
+        else if (We <= 32) hipLaunchKernelGGL(match_kernel_nsplit<32>, g2, dim3(NT), 0, st, a);
+        else hipLaunchKernelGGL(match_kernel_nsplit<64>, g2, dim3(NT), 0, st, a);
+    } else {        // smaller still: 64-surface blocks of two overheads
         hipLaunchKernelGGL((match_kernel<1, 1>), dim3(cdiv(Bs, 64), cdiv(Bo, 2)), dim3(NT), 0, st, a);
     }
     WITW_CHECK_LAUNCH("match_fwd");
