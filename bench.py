@@ -348,6 +348,9 @@ def main():
     ap.add_argument('--single-device', action='store_true', help='self-test: put every rank on cuda:0')
     ap.add_argument('--cpu-pairs', type=int, default=32, help='pairs of the batch the CPU oracle is timed on (cpu_baseline)')
     ap.add_argument('--e2e-pairs', type=int, default=4096)
+    ap.add_argument('--decode', choices=['device', 'host'], default='device',
+                    help="e2e: 'device' = DataLoader workers entropy-decode the JPEG files, the GPU does dequantisation / IDCT / upsampling / "
+                         "colour conversion (byte-identical to Pillow); 'host' = Pillow in the workers (the reference's arrangement)")
     ap.add_argument('--workers', type=int, default=12, help='e2e: DataLoader workers (reference: 12, model/cvig_fov.py:402)')
     a = ap.parse_args()
 

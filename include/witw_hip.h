@@ -377,6 +377,19 @@ int witw_bilinear_gather(const float* x, const int* taps, const float* wts, floa
  * fp32 [B][3][2]: per image the inverse rotation matrix divided by (W/2, H/2), row k = (x, y, 1) coefficient. */
 int witw_rotate_nearest(const float* x, const float* theta, float* y, int B, int C, int H, int W, void* stream);
 
+/* ---- JPEG back end on the device: what libjpeg does behind entropy decoding for the images the reference reads
+ *      (skimage.io.imread -> PIL -> libjpeg-turbo, model/cvig_fov.py:88-89, in the DataLoader workers of :402). The entropy
+ *      decoding stays on the host (witw_amd/csrc_host/jpeg_coef.cpp -> libwitw_jpeg.so: witw_jpeg_info, witw_jpeg_decode_coef).
+ *      Byte-identical to Pillow's decode (JDCT_ISLOW, fancy upsampling).
+ * witw_jpeg_idct: dequantisation + 'islow' integer inverse DCT. coef: DEVICE int16 [total_blocks][64] natural order; qt: DEVICE
+ * uint16 [tables][64]; planes: DEVICE int64 [n_planes][6] = {first block, table index, byte offset of the output plane, blocks
+ * wide, blocks high, blocks of all earlier planes}; out: the 8-bit component planes (bh*8 rows of bw*8 bytes). */
+int witw_jpeg_idct(const void* coef, const void* qt, const void* planes, int n_planes, long long total_blocks, void* out, void* stream);
+/* witw_jpeg_to_rgb: fancy chroma upsampling + YCbCr -> RGB. planes: the output above; images: DEVICE int64 [n_images][12] =
+ * {H, W, components (1 | 3), mode (0 none, 1 h2v1, 2 h2v2 fancy, 3 / 4 the same replicated: chroma planes of <= 2 columns), luma offset, luma stride, Cb offset, Cr offset, chroma stride, chroma
+ * rows, chroma columns (real samples), output offset}; out: H x W x components interleaved bytes per image. */
+int witw_jpeg_to_rgb(const void* planes, const void* images, int n_images, long long max_pixels, void* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,80 @@
+"""JPEG back end on the GPU (csrc/jpeg.hip: dequantisation, integer inverse DCT, fancy chroma upsampling, YCbCr -> RGB behind
+the host's entropy decoding) against Pillow, the decoder behind the reference's skimage.io.imread (model/cvig_fov.py:88-89):
+BYTE-identical images, on the committed fixtures, on freshly written files of BASELINE's raw sizes, and through the data path
+(ImagePairDataset(raw='jpeg') -> collate_packed -> GpuPreprocess) against the host-decoded path."""
+import io
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from witw_amd import jpeg
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'jpeg')
+
+
+def test_device_decode_equals_pillow_on_fixtures():
+    from PIL import Image
+    exp = np.load(os.path.join(HERE, 'expected.npz'))
+    names = sorted(n[:-4] for n in os.listdir(HERE) if n.endswith('.jpg'))
+    items = []
+    for n in names:
+        c = jpeg.read_coef(os.path.join(HERE, n + '.jpg'))
+        items.append(c if c is not None else np.asarray(Image.open(os.path.join(HERE, n + '.jpg'))))      # progressive: Pillow's bytes ride along
+    assert sum(isinstance(i, jpeg.JpegCoef) for i in items) == len(names) - 1
+    out = jpeg.decode(items, torch.device('cuda:0'))              # ONE batch: mixed sizes, layouts, a raw image
+    for n, o in zip(names, out):
+        e = exp[n] if exp[n].ndim == 3 else exp[n][:, :, None]
+        assert tuple(o.shape) == e.shape, n
+        np.testing.assert_array_equal(o.cpu().numpy(), e, err_msg=n)
+
+
+def test_device_decode_fresh_files():
+    from PIL import Image
+    g = np.random.Generator(np.random.Philox(key=[8, 3]))
+    items, refs = [], []
+    for (h, w) in ((512, 512), (224, 224), (750, 333), (8, 8), (100, 2)):
+        for sub, q, kw in ((2, 90, {}), (1, 70, {'optimize': True}), (0, 95, {}), (2, 40, {'restart_marker_blocks': 5})):
+            small = g.integers(0, 256, size=(h // 8 + 2, w // 8 + 2, 3), dtype=np.uint8)
+            a = np.asarray(Image.fromarray(small).resize((w + 16, h + 16), Image.BICUBIC))[8:8 + h, 8:8 + w]
+            a = np.clip(a.astype(np.int16) + g.integers(-15, 16, size=(h, w, 3)), 0, 255).astype(np.uint8)
+            bio = io.BytesIO()
+            Image.fromarray(a).save(bio, 'JPEG', quality=q, subsampling=sub, **kw)
+            items.append(jpeg.read_coef(bio.getvalue()))
+            refs.append(np.asarray(Image.open(io.BytesIO(bio.getvalue()))))
+    out = jpeg.decode(items, torch.device('cuda:0'))
+    for k, (o, r) in enumerate(zip(out, refs)):
+        np.testing.assert_array_equal(o.cpu().numpy(), r, err_msg=str(k))
+
+
+def test_data_path_with_device_decode_equals_host_decode(tmp_path):
+    """ImagePairDataset(raw='jpeg') hands out entropy-decoded files, collate_packed one block per side, GpuPreprocess decodes on
+    the device and goes on as before: the same 'surface' / 'polar' tensors, bit for bit, as with Pillow's bytes (raw=True)."""
+    from PIL import Image
+    from witw_amd import cvig_fov
+    g = np.random.Generator(np.random.Philox(key=[9, 9]))
+    root = str(tmp_path)
+    rows = []
+    for i, ((hs, ws), (ho, wo)) in enumerate([((224, 224), (512, 512)), ((100, 333), (300, 200)), ((48, 80), (64, 64)), ((224, 224), (512, 512))]):
+        for tag, (h, w) in (('su', (hs, ws)), ('ov', (ho, wo))):
+            a = g.integers(0, 256, size=(h // 4 + 1, w // 4 + 1, 3), dtype=np.uint8).repeat(4, 0).repeat(4, 1)[:h, :w]
+            Image.fromarray(a).save(os.path.join(root, '%s_%d.jpg' % (tag, i)), quality=88, progressive=(i == 2 and tag == 'ov'))
+        rows.append('ov_%d.jpg,su_%d.jpg' % (i, i))
+    csv = os.path.join(root, 'pairs.csv')
+    open(csv, 'w').write('\n'.join(rows) + '\n')
+    prep = cvig_fov.GpuPreprocess('cvusa', fov=360, random_orientation=False)
+    outs = {}
+    for mode in (True, 'jpeg'):
+        ds = cvig_fov.ImagePairDataset('cvusa', csv, raw=mode)
+        batch = cvig_fov.collate_packed([ds[i] for i in range(4)])
+        outs[mode] = prep(batch)
+        if mode == 'jpeg':
+            assert batch['overhead_kind'] == jpeg.KIND_JPEG and int(batch['overhead_desc'][:, 24].sum()) == 1      # the progressive file
+    assert torch.equal(outs[True]['surface'], outs['jpeg']['surface']) and torch.equal(outs[True]['polar'], outs['jpeg']['polar'])
+    # through a DataLoader with workers and the prefetcher
+    ds = cvig_fov.ImagePairDataset('cvusa', csv, raw='jpeg')
+    loader = torch.utils.data.DataLoader(ds, batch_size=2, shuffle=False, num_workers=2, collate_fn=cvig_fov.collate_packed, pin_memory=True)
+    got = [prep(st) for st in cvig_fov.DevicePrefetcher(loader, prep)]
+    assert torch.equal(torch.cat([d['polar'] for d in got]), outs[True]['polar'])

@@ -65,6 +65,34 @@ def _build_locked(verbose):
     return LIB
 
 
+HOST_SRC = os.path.join(HERE, 'csrc_host', 'jpeg_coef.cpp')
+HOST_LIB = os.path.join(HERE, 'libwitw_jpeg.so')
+
+
+def build_host(force=False, verbose=True):
+    """libwitw_jpeg.so: the host-only part of the data path (JPEG entropy decoding, csrc_host/jpeg_coef.cpp), plain g++ --
+    DataLoader workers load it without ever mapping the HIP runtime."""
+    if not force and os.path.exists(HOST_LIB) and os.path.getmtime(HOST_LIB) >= os.path.getmtime(HOST_SRC):
+        return HOST_LIB
+    import fcntl
+    os.makedirs(os.path.join(HERE, 'build'), exist_ok=True)
+    with open(os.path.join(HERE, 'build', '.lock_host'), 'w') as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if force or not os.path.exists(HOST_LIB) or os.path.getmtime(HOST_LIB) < os.path.getmtime(HOST_SRC):
+                tmp = HOST_LIB + '.tmp.%d' % os.getpid()
+                cmd = [os.environ.get('CXX', 'g++'), '-O3', '-fPIC', '-shared', '-std=c++17', '-Wall', '-o', tmp, HOST_SRC]
+                if verbose:
+                    print(' '.join(cmd), flush=True)
+                subprocess.check_call(cmd)
+                os.replace(tmp, HOST_LIB)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+    return HOST_LIB
+
+
 if __name__ == '__main__':
     build(force='--force' in sys.argv)
+    build_host(force='--force' in sys.argv)
     print(LIB)
+    print(HOST_LIB)

@@ -1,0 +1,292 @@
+// Host side of the on-device JPEG decode (the reference decodes on the host inside its DataLoader workers:
+// skimage.io.imread -> PIL -> libjpeg, model/cvig_fov.py:88-89, :402): ENTROPY decoding only -- marker parsing, Huffman decoding,
+// DC prediction, de-zigzag -- of baseline / extended-sequential 8-bit JFIF files into quantised DCT coefficient blocks. Everything
+// behind it (dequantisation, the integer 'islow' inverse DCT, chroma upsampling, YCbCr -> RGB) runs on the GPU
+// (csrc/jpeg.hip). Plain C ABI, no GPU runtime: DataLoader workers load this library, never libwitw_hip.so.
+//
+// Coefficient layout: component c holds bh[c] x bw[c] blocks (the MCU-padded block grid, raster order), each 64 int16 in NATURAL
+// (row-major) order; components follow one another. Quantisation tables: 64 uint16 per component, natural order.
+#include <stdint.h>
+#include <stddef.h>
+#include <string.h>
+
+namespace {
+
+const uint8_t ZZ[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                        41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                        30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+struct Huff {
+    uint8_t look_len[512];      // 9-bit prefix -> code length (0: longer than 9 bits)
+    uint8_t look_sym[512];
+    int32_t maxcode[18];        // largest code of each length (-1: none), [17] = sentinel
+    int32_t valoff[17];         // symbol index of the first code of each length minus that code
+    uint8_t sym[256];
+    bool present;
+};
+
+bool build_huff(Huff& h, const uint8_t* counts, const uint8_t* symbols, int nsym) {
+    memcpy(h.sym, symbols, nsym);
+    memset(h.look_len, 0, sizeof(h.look_len));
+    int code = 0, k = 0;
+    for (int len = 1; len <= 16; ++len) {
+        h.valoff[len] = k - code;
+        for (int i = 0; i < counts[len - 1]; ++i, ++k, ++code) {
+            if (len <= 9) {
+                const int first = code << (9 - len), n = 1 << (9 - len);
+                for (int j = 0; j < n; ++j) {
+                    h.look_len[first + j] = (uint8_t)len;
+                    h.look_sym[first + j] = symbols[k];
+                }
+            }
+        }
+        h.maxcode[len] = counts[len - 1] ? code - 1 : -1;
+        if (code > (1 << len)) return false;
+        code <<= 1;
+    }
+    h.maxcode[17] = 0x7fffffff;
+    h.present = true;
+    return k == nsym;
+}
+
+struct Bits {
+    const uint8_t* p;
+    const uint8_t* end;
+    uint64_t buf;       // bits left-aligned
+    int n;              // valid bits in buf
+    bool hit_marker;
+    void init(const uint8_t* a, const uint8_t* e) { p = a; end = e; buf = 0; n = 0; hit_marker = false; }
+    inline void fill() {
+        while (n <= 56) {
+            uint64_t b = 0;
+            if (!hit_marker && p < end) {
+                b = *p;
+                if (b == 0xFF) {
+                    if (p + 1 < end && p[1] == 0) p += 2;       // stuffed zero
+                    else { hit_marker = true; b = 0; }          // a marker: feed zeros from here on (as libjpeg does)
+                } else {
+                    ++p;
+                }
+            }
+            buf |= b << (56 - n);
+            n += 8;
+        }
+    }
+    inline int peek(int k) { return (int)(buf >> (64 - k)); }
+    inline void skip(int k) { buf <<= k; n -= k; }
+    inline int get(int k) { const int v = peek(k); skip(k); return v; }
+};
+
+inline int decode_sym(Bits& b, const Huff& h) {
+    if (b.n < 16) b.fill();
+    const int look = b.peek(9);
+    int len = h.look_len[look];
+    if (len) { b.skip(len); return h.look_sym[look]; }
+    len = 10;
+    int code = b.peek(10);
+    while (code > h.maxcode[len]) { ++len; if (len > 16) return -1; code = b.peek(len); }
+    b.skip(len);
+    return h.sym[(code + h.valoff[len]) & 255];
+}
+
+inline int extend(int v, int s) { return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v; }
+
+struct Comp { int id, h, v, tq, td, ta, bw, bh; int64_t off; int pred; };
+
+struct Parsed {
+    int H, W, ncomp, hmax, vmax, mcux, mcuy, restart;
+    Comp c[4];
+    uint16_t qt[4][64];
+    bool qt_present[4];
+    Huff dc[4], ac[4];
+    const uint8_t* scan;      // start of the entropy-coded segment
+    int scan_ncomp, scan_comp[4];
+    int status;               // 0 ok, < 0 see witw_jpeg_* below
+};
+
+inline int be16(const uint8_t* p) { return (p[0] << 8) | p[1]; }
+
+int parse(const uint8_t* d, size_t n, Parsed& P) {
+    memset(&P, 0, sizeof(P));
+    if (n < 4 || d[0] != 0xFF || d[1] != 0xD8) return -1;
+    size_t i = 2;
+    bool have_sof = false;
+    while (i + 4 <= n) {
+        if (d[i] != 0xFF) return -1;
+        while (i < n && d[i] == 0xFF) ++i;      // fill bytes
+        if (i >= n) return -1;
+        const int m = d[i++];
+        if (m == 0xD8 || (m >= 0xD0 && m <= 0xD7) || m == 0x01) continue;
+        if (m == 0xD9) return -1;               // EOI before a scan
+        if (i + 2 > n) return -1;
+        const int len = be16(d + i);
+        if (len < 2 || i + len > n) return -1;
+        const uint8_t* s = d + i + 2;
+        const int sl = len - 2;
+        if (m == 0xDB) {
+            int k = 0;
+            while (k < sl) {
+                const int pq = s[k] >> 4, tq = s[k] & 15;
+                ++k;
+                if (tq > 3 || pq > 1 || k + 64 * (pq + 1) > sl) return -1;
+                for (int j = 0; j < 64; ++j) {
+                    P.qt[tq][ZZ[j]] = (uint16_t)(pq ? be16(s + k + 2 * j) : s[k + j]);
+                }
+                P.qt_present[tq] = true;
+                k += 64 * (pq + 1);
+            }
+        } else if (m == 0xC0 || m == 0xC1) {
+            if (sl < 6 || s[0] != 8) return -2;                   // 8-bit samples only
+            P.H = be16(s + 1); P.W = be16(s + 3); P.ncomp = s[5];
+            if (P.H <= 0 || P.W <= 0 || (P.ncomp != 1 && P.ncomp != 3) || sl < 6 + 3 * P.ncomp) return -2;
+            for (int c = 0; c < P.ncomp; ++c) {
+                P.c[c].id = s[6 + 3 * c];
+                P.c[c].h = s[7 + 3 * c] >> 4; P.c[c].v = s[7 + 3 * c] & 15;
+                P.c[c].tq = s[8 + 3 * c];
+                if (P.c[c].h < 1 || P.c[c].h > 2 || P.c[c].v < 1 || P.c[c].v > 2 || P.c[c].tq > 3) return -2;
+            }
+            have_sof = true;
+        } else if (m == 0xC2 || (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) {
+            return -2;                                              // progressive / lossless / arithmetic: host decoder
+        } else if (m == 0xC4) {
+            int k = 0;
+            while (k < sl) {
+                if (k + 17 > sl) return -1;
+                const int tc = s[k] >> 4, th = s[k] & 15;
+                if (tc > 1 || th > 3) return -1;
+                int nsym = 0;
+                for (int j = 0; j < 16; ++j) nsym += s[k + 1 + j];
+                if (nsym > 256 || k + 17 + nsym > sl) return -1;
+                if (!build_huff(tc ? P.ac[th] : P.dc[th], s + k + 1, s + k + 17, nsym)) return -1;
+                k += 17 + nsym;
+            }
+        } else if (m == 0xDD) {
+            if (sl < 2) return -1;
+            P.restart = be16(s);
+        } else if (m == 0xDA) {
+            if (!have_sof || sl < 1) return -1;
+            const int ns = s[0];
+            if (ns != P.ncomp || sl < 1 + 2 * ns + 3) return -2;   // one interleaved scan with every component
+            for (int k = 0; k < ns; ++k) {
+                int ci = -1;
+                for (int c = 0; c < P.ncomp; ++c) if (P.c[c].id == s[1 + 2 * k]) ci = c;
+                if (ci < 0) return -1;
+                P.scan_comp[k] = ci;
+                P.c[ci].td = s[2 + 2 * k] >> 4; P.c[ci].ta = s[2 + 2 * k] & 15;
+                if (P.c[ci].td > 3 || P.c[ci].ta > 3) return -1;
+            }
+            if (s[1 + 2 * ns] != 0 || s[2 + 2 * ns] != 63 || s[3 + 2 * ns] != 0) return -2;
+            P.scan_ncomp = ns;
+            P.scan = d + i + len;
+            break;
+        }
+        i += len;
+    }
+    if (!P.scan) return -1;
+    P.hmax = P.vmax = 1;
+    for (int c = 0; c < P.ncomp; ++c) { if (P.c[c].h > P.hmax) P.hmax = P.c[c].h; if (P.c[c].v > P.vmax) P.vmax = P.c[c].v; }
+    if (P.ncomp == 1) { P.c[0].h = P.c[0].v = 1; P.hmax = P.vmax = 1; }      // a single-component scan is never interleaved
+    else if (P.c[1].h != 1 || P.c[1].v != 1 || P.c[2].h != 1 || P.c[2].v != 1 || P.c[0].h != P.hmax || P.c[0].v != P.vmax) return -2;
+    P.mcux = (P.W + 8 * P.hmax - 1) / (8 * P.hmax);
+    P.mcuy = (P.H + 8 * P.vmax - 1) / (8 * P.vmax);
+    int64_t off = 0;
+    for (int c = 0; c < P.ncomp; ++c) {
+        P.c[c].bw = P.mcux * P.c[c].h; P.c[c].bh = P.mcuy * P.c[c].v;
+        P.c[c].off = off;
+        off += (int64_t)P.c[c].bw * P.c[c].bh;
+        if (!P.qt_present[P.c[c].tq] || !P.dc[P.c[c].td].present || !P.ac[P.c[c].ta].present) return -1;
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+// info[0..]: H, W, ncomp, hmax, vmax, total blocks, then per component (4 slots): h, v, blocks wide, blocks high.
+// Returns 0; -1 = not a decodable JPEG stream; -2 = a JPEG this decoder leaves to the host library (progressive, arithmetic,
+// 12-bit, CMYK, non-interleaved scans, sampling factors other than 1 or 2 / chroma not 1x1).
+int witw_jpeg_info(const uint8_t* data, size_t n, int32_t* info /* 22 */) {
+    static thread_local Parsed P;
+    const int rc = parse(data, n, P);
+    if (rc) return rc;
+    info[0] = P.H; info[1] = P.W; info[2] = P.ncomp; info[3] = P.hmax; info[4] = P.vmax;
+    int64_t total = 0;
+    for (int c = 0; c < 4; ++c) {
+        const bool on = c < P.ncomp;
+        info[6 + 4 * c] = on ? P.c[c].h : 0; info[7 + 4 * c] = on ? P.c[c].v : 0;
+        info[8 + 4 * c] = on ? P.c[c].bw : 0; info[9 + 4 * c] = on ? P.c[c].bh : 0;
+        if (on) total += (int64_t)P.c[c].bw * P.c[c].bh;
+    }
+    info[5] = (int32_t)total;
+    return 0;
+}
+
+// coef: total blocks x 64 int16 (zero-filled here); qt: ncomp x 64 uint16. Returns 0 or a negative code as above; -3 = the
+// entropy-coded data ended early or holds an invalid code (the blocks decoded so far are kept, the rest stay zero).
+int witw_jpeg_decode_coef(const uint8_t* data, size_t n, int16_t* coef, uint16_t* qt) {
+    static thread_local Parsed P;
+    int rc = parse(data, n, P);
+    if (rc) return rc;
+    int64_t total = 0;
+    for (int c = 0; c < P.ncomp; ++c) {
+        total += (int64_t)P.c[c].bw * P.c[c].bh;
+        memcpy(qt + 64 * c, P.qt[P.c[c].tq], 128);
+        P.c[c].pred = 0;
+    }
+    memset(coef, 0, (size_t)total * 128);
+    Bits b;
+    b.init(P.scan, data + n);
+    int to_restart = P.restart, next_rst = 0;
+    for (int my = 0; my < P.mcuy; ++my)
+        for (int mx = 0; mx < P.mcux; ++mx) {
+            if (P.restart && to_restart == 0) {
+                // byte-align, expect RSTn
+                b.n = 0; b.buf = 0;
+                const uint8_t* q = b.p;
+                while (q + 1 < b.end && !(q[0] == 0xFF && q[1] >= 0xD0 && q[1] <= 0xD7)) ++q;
+                if (q + 1 >= b.end || q[1] != 0xD0 + next_rst) return -3;
+                b.p = q + 2;
+                b.hit_marker = false;
+                next_rst = (next_rst + 1) & 7;
+                to_restart = P.restart;
+                for (int c = 0; c < P.ncomp; ++c) P.c[c].pred = 0;
+            }
+            for (int k = 0; k < P.scan_ncomp; ++k) {
+                Comp& C = P.c[P.scan_comp[k]];
+                const Huff& hd = P.dc[C.td];
+                const Huff& ha = P.ac[C.ta];
+                for (int v = 0; v < C.v; ++v)
+                    for (int h = 0; h < C.h; ++h) {
+                        int16_t* blk = coef + (C.off + (int64_t)(my * C.v + v) * C.bw + (mx * C.h + h)) * 64;
+                        int s = decode_sym(b, hd);
+                        if (s < 0 || s > 15) return -3;
+                        if (s) {
+                            if (b.n < s) b.fill();
+                            C.pred += extend(b.get(s), s);
+                        }
+                        blk[0] = (int16_t)C.pred;
+                        for (int kk = 1; kk < 64;) {
+                            const int rs = decode_sym(b, ha);
+                            if (rs < 0) return -3;
+                            const int r = rs >> 4;
+                            s = rs & 15;
+                            if (s == 0) {
+                                if (r != 15) break;
+                                kk += 16;
+                                continue;
+                            }
+                            kk += r;
+                            if (kk > 63) return -3;
+                            if (b.n < s) b.fill();
+                            blk[ZZ[kk]] = (int16_t)extend(b.get(s), s);
+                            ++kk;
+                        }
+                    }
+            }
+            if (P.restart) --to_restart;
+        }
+    return 0;
+}
+
+}  // extern "C"

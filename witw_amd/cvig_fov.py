@@ -1089,8 +1089,9 @@ class ImagePairDataset(torch.utils.data.Dataset):
     def __init__(self, dataset, csv_path, base_path=None, transform=None, raw=False):
         import os
         import pandas as pd
-        self.raw = raw      # not in the reference: hand over the decoder's uint8 HWC arrays (collate_packed / GpuPreprocess convert
-        #                     them on the GPU, exactly); False = the reference's float32 CHW tensors
+        self.raw = raw      # not in the reference: True = hand over the decoder's uint8 HWC arrays (collate_packed / GpuPreprocess
+        #                     convert them on the GPU, exactly); 'jpeg' = hand over entropy-decoded JPEG files, the GPU does the
+        #                     rest of the decode too (same bytes); False = the reference's float32 CHW tensors
         self.csv_path = csv_path
         self.base_path = base_path if base_path is not None else os.path.dirname(csv_path)
         self.transform = transform
@@ -1121,8 +1122,20 @@ class ImagePairDataset(torch.utils.data.Dataset):
             a = a[:, :, None]
         return a if a.dtype == np.uint8 else ImagePairDataset._read(path)
 
+    @staticmethod
+    def _read_jpeg(path):
+        """raw='jpeg': a JPEG file is only ENTROPY-decoded here (witw_amd/jpeg.py: quantised DCT coefficient blocks); the GPU
+        finishes it into the bytes Pillow would have produced. Other formats, and JPEG flavours the device path leaves alone,
+        are decoded by Pillow as with raw=True."""
+        from . import jpeg
+        if str(path).lower().endswith(('.jpg', '.jpeg')):
+            c = jpeg.read_coef(path)
+            if c is not None:
+                return c
+        return ImagePairDataset._read_raw(path)
+
     def __getitem__(self, idx):
-        read = self._read_raw if self.raw else self._read
+        read = self._read_jpeg if self.raw == 'jpeg' else self._read_raw if self.raw else self._read
         data = {'surface': read(self.file_paths.iloc[idx]['surface']),
                 'overhead': read(self.file_paths.iloc[idx]['overhead'])}
         if self._with_idx:
@@ -1144,6 +1157,9 @@ def _pack_side(images):
     """A batch of differently sized images -> ONE contiguous byte buffer + [B,4] int64 {byte offset, H, W, channels stored per
     pixel}. All uint8 HWC (decoder output) -> kind 1, bytes as they are; anything else -> float32 planar CHW, kind 0."""
     import numpy as np
+    from . import jpeg
+    if any(isinstance(a, jpeg.JpegCoef) for a in images):      # entropy-decoded JPEG files (+ uint8 images of files left to Pillow)
+        return jpeg.pack(images)
     raw = all(isinstance(a, np.ndarray) and a.dtype == np.uint8 and a.ndim == 3 for a in images)
     parts, desc, off = [], [], 0
     for a in images:
@@ -1239,6 +1255,13 @@ class GpuPreprocess(object):
             buf = buf.pin_memory()
         dbuf = buf.to(dev, non_blocking=True)
         st.keep += [dbuf, buf]
+        if kind == 2:      # jpeg.KIND_JPEG: coefficient blocks -> dequantise, inverse DCT, upsample, colour-convert on the device
+            from . import jpeg
+            keep, table = jpeg.decode_packed(dbuf, desc)
+            st.keep += keep
+            if int(table[:, 4].min()) < self.channels:
+                raise _lib.WitwError('an image of the batch has %d channels, the model takes %d' % (int(table[:, 4].min()), self.channels))
+            return table, 1      # from here on: uint8 HWC images on the device
         if int(desc[:, 3].min()) < self.channels:
             raise _lib.WitwError('an image of the batch has %d channels, the model takes %d' % (int(desc[:, 3].min()), self.channels))
         table = torch.empty((desc.shape[0], 5), dtype=torch.int64)

@@ -44,9 +44,13 @@ def make_dataset(root, n_pairs, n_unique=512, seed=77, procs=8):
     return csv, n_unique, size
 
 
-def bench(a, device, n_pairs=None, workers=None, keep_dir=None):
+def bench(a, device, n_pairs=None, workers=None, keep_dir=None, decode=None, precision=None):
+    """decode: 'device' (workers entropy-decode, the GPU finishes the JPEG: witw_amd/jpeg.py) or 'host' (Pillow in the workers);
+    precision: 'fp32' | 'bf16' | 'fp16x3' encoders."""
     import tempfile
     from . import cvig_fov, synth
+    decode = decode or getattr(a, 'decode', 'device')
+    precision = precision or getattr(a, 'precision', 'fp32')
     n_pairs = n_pairs or a.e2e_pairs
     cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
     workers = workers if workers is not None else max(1, min(a.workers, cores))
@@ -57,7 +61,7 @@ def bench(a, device, n_pairs=None, workers=None, keep_dir=None):
     csv, n_unique, nbytes = make_dataset(root, n_pairs, procs=min(16, cores))
     t_make = time.perf_counter() - t0
 
-    ds = cvig_fov.ImagePairDataset('cvusa', csv, raw=True)
+    ds = cvig_fov.ImagePairDataset('cvusa', csv, raw='jpeg' if decode == 'device' else True)
     split = cvig_fov.loader_split(B, workers)      # workers decode quarter batches (as test() does): first batch 4x sooner
     loader = torch.utils.data.DataLoader(ds, batch_size=B // split, shuffle=False, drop_last=False, num_workers=workers,
                                          collate_fn=cvig_fov.collate_packed, pin_memory=True,
@@ -70,6 +74,10 @@ def bench(a, device, n_pairs=None, workers=None, keep_dir=None):
     def embed(st):
         with torch.no_grad():
             data = prep(st)
+            if precision == 'bf16':
+                return se.forward_bf16(data['surface']), oe.forward_bf16(data['polar'])
+            if precision == 'fp16x3':
+                return se.forward_f16x3(data['surface']), oe.forward_f16x3(data['polar'])
             return se(data['surface']), oe(data['polar'])
 
     # ---- stage rates on their own
@@ -93,14 +101,17 @@ def bench(a, device, n_pairs=None, workers=None, keep_dir=None):
             f['overhead_bytes'].to(device, non_blocking=True)
     torch.cuda.synchronize()
     t_h2d = (time.perf_counter() - t0) / 5
-    # (3) the GPU side on a resident batch: 3 preprocessing launches + 2 encoders
-    st = prep.stage(first if split > 1 else first[0])
+    # (3) the GPU side on a batch whose packed block is resident: [device decode: 2 launches] + 2 preprocessing launches + 2 encoders
+    def gpu_side():
+        st_ = prep.stage(first if split > 1 else first[0])      # H2D of pinned blocks (PCIe, counted in (2) as well) + device JPEG back end
+        embed(st_)
+        return st_
     for _ in range(2):
-        embed(st)
+        st = gpu_side()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(5):
-        embed(st)
+        st = gpu_side()
     torch.cuda.synchronize()
     t_gpu = (time.perf_counter() - t0) / 5
     nb = st.n
@@ -124,16 +135,19 @@ def bench(a, device, n_pairs=None, workers=None, keep_dir=None):
     assert su_all.shape[0] == n_pairs and ov_all.shape[0] == n_pairs
     del loader
 
-    rates = {'decode_and_pack (%d DataLoader workers)' % workers: n / t_load,
+    rates = {'%s (%d DataLoader workers)' % ('entropy-decode_and_pack' if decode == 'device' else 'decode_and_pack', workers): n / t_load,
              'host_to_device copy (pinned, %.1f MB per batch)' % (blk / 1e6): nb / t_h2d,
-             'gpu (batched resize+normalise+polar, 2 encoders; resident batch)': nb / t_gpu}
+             'gpu (%sbatched resize+normalise [+polar, fused], 2 %s encoders; staged from pinned memory)'
+             % ('JPEG back end: dequantise + IDCT + upsample + colour, ' if decode == 'device' else '', precision): nb / t_gpu}
     limiting = min(rates, key=rates.get)
     out = {'metric': 'image-pairs/sec (disk -> embeddings)', 'value': round(n_pairs / t_e2e, 2), 'unit': 'pairs/s', 'n_gpus': 1,
            'steps': (n_pairs + B - 1) // B, 'warmup': 0, 'ms_per_step': round(t_e2e / ((n_pairs + B - 1) // B) * 1e3, 3),
-           'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+           'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': {'fp32': 'f32'}.get(precision, precision), 'data': 'synthetic',
+           'jpeg_decode': 'device (host: entropy decoding only)' if decode == 'device' else 'host (Pillow)',
            'config': {'workload': 'cvig_fov fov=%d, %d JPEG pairs on disk (%d distinct files pairs, overhead 512x512 + ground 224x224, %.1f MB) -> '
-                                  'ImagePairDataset(raw) in %d DataLoader workers (quarter batches) -> collate_packed -> pinned -> copy stream -> GpuPreprocess '
-                                  '(3 launches per batch) -> 2x FOV_DSM -> embeddings' % (fov, n_pairs, n_unique, nbytes / 1e6, workers),
+                                  'ImagePairDataset(raw=%s) in %d DataLoader workers (quarter batches) -> collate_packed -> pinned -> copy stream -> %sGpuPreprocess '
+                                  '(2 launches per batch) -> 2x FOV_DSM (%s) -> embeddings' % (fov, n_pairs, n_unique, nbytes / 1e6, "'jpeg'" if decode == 'device' else 'True', workers,
+                                                                                                'JPEG back end on the GPU (2 launches) -> ' if decode == 'device' else '', precision),
                       'pairs_per_gpu': B, 'host_cores_available': cores, 'dataset_dir': 'tmpfs/disk under %s' % tempfile.gettempdir(),
                       'reference_data_path': 'model/cvig_fov.py:393-403: transforms inside 12 DataLoader workers, ~1 s per sample '
                                              '(SURVEY §6: PolarTransform 0.9-1.2 s)'},

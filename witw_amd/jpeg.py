@@ -1,0 +1,164 @@
+"""On-device JPEG decode for the data path: the reference decodes inside its DataLoader workers
+(skimage.io.imread -> PIL -> libjpeg, model/cvig_fov.py:88-89, :402). Here a worker only ENTROPY-decodes
+(libwitw_jpeg.so, csrc_host/jpeg_coef.cpp: Huffman decoding into quantised DCT coefficient blocks, about 40 % of libjpeg's
+decode time); the coefficient blocks of a batch cross PCIe as one block and the GPU does the rest (csrc/jpeg.hip:
+dequantisation, integer inverse DCT, fancy chroma upsampling, YCbCr -> RGB) into the same interleaved uint8 image Pillow
+produces, byte for byte. Files this decoder leaves alone (progressive, arithmetic-coded, CMYK, 12-bit, unusual sampling) are
+decoded by Pillow in the worker as before and travel as bytes in the same batch.
+
+Nothing here touches the GPU at import or in a worker: libwitw_jpeg.so is host-only C++."""
+import ctypes
+import os
+
+import numpy as np
+import torch
+
+from . import build as _build
+
+_HOST = None
+KIND_JPEG = 2          # packed-batch kind: coefficient blocks (+ raw uint8 images for the files left to Pillow)
+DESC_COLS = 26         # per image: coefficient byte offset, quantisation-table byte offset, 22 info ints, is_raw, channels
+
+
+def host_lib():
+    global _HOST
+    if _HOST is None:
+        path = _build.build_host(verbose=False)
+        lib = ctypes.CDLL(path)
+        lib.witw_jpeg_info.restype = ctypes.c_int
+        lib.witw_jpeg_info.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        lib.witw_jpeg_decode_coef.restype = ctypes.c_int
+        lib.witw_jpeg_decode_coef.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
+        _HOST = lib
+    return _HOST
+
+
+class JpegCoef(object):
+    """The entropy-decoded form of one JPEG file: info (the 22 ints of witw_jpeg_info), coef int16 [blocks, 64] (natural
+    order, components one after another), qt uint16 [components, 64]."""
+    __slots__ = ('info', 'coef', 'qt')
+
+    def __init__(self, info, coef, qt):
+        self.info, self.coef, self.qt = info, coef, qt
+
+    @property
+    def shape(self):          # of the decoded image, HWC
+        return (int(self.info[0]), int(self.info[1]), int(self.info[2]))
+
+
+def read_coef(src):
+    """src: a path or the bytes of a JPEG file -> JpegCoef, or None when the file is left to the host decoder."""
+    data = np.fromfile(src, dtype=np.uint8) if isinstance(src, (str, os.PathLike)) else np.frombuffer(src, dtype=np.uint8)
+    lib = host_lib()
+    info = np.zeros(22, dtype=np.int32)
+    if lib.witw_jpeg_info(data.ctypes.data, data.size, info.ctypes.data) != 0:
+        return None
+    coef = np.empty((int(info[5]), 64), dtype=np.int16)
+    qt = np.empty((int(info[2]), 64), dtype=np.uint16)
+    if lib.witw_jpeg_decode_coef(data.ctypes.data, data.size, coef.ctypes.data, qt.ctypes.data) != 0:
+        return None               # truncated / corrupt entropy data: let the host decoder say what it thinks of the file
+    return JpegCoef(info, coef, qt)
+
+
+def pack(images):
+    """A list of JpegCoef (and, for files left to Pillow, uint8 HWC arrays) -> (uint8 tensor, int64 [B, DESC_COLS], KIND_JPEG):
+    one contiguous block for the pinned copy, images 16-byte aligned, the quantisation tables behind the coefficient data."""
+    parts, desc, off = [], np.zeros((len(images), DESC_COLS), dtype=np.int64), 0
+    for i, a in enumerate(images):
+        if isinstance(a, JpegCoef):
+            flat = a.coef.reshape(-1).view(np.uint8)
+            desc[i, 2:24] = a.info
+        else:
+            a = np.ascontiguousarray(a)
+            if a.dtype != np.uint8 or a.ndim != 3:
+                raise ValueError('jpeg.pack takes JpegCoef objects and uint8 HWC arrays')
+            flat = a.reshape(-1)
+            desc[i, 2], desc[i, 3], desc[i, 24], desc[i, 25] = a.shape[0], a.shape[1], 1, a.shape[2]
+        desc[i, 0] = off
+        parts.append((off, flat))
+        off += (flat.size + 15) // 16 * 16
+    for i, a in enumerate(images):
+        if isinstance(a, JpegCoef):
+            flat = a.qt.reshape(-1).view(np.uint8)
+            desc[i, 1] = off
+            parts.append((off, flat))
+            off += (flat.size + 15) // 16 * 16
+    buf = np.zeros((off,), dtype=np.uint8)
+    for o, f in parts:
+        buf[o:o + f.size] = f
+    return torch.from_numpy(buf), torch.from_numpy(desc), KIND_JPEG
+
+
+def decode_packed(dbuf, desc):
+    """dbuf: the packed block on the GPU; desc: its HOST descriptor table -> (tensors to keep alive, int64 host table [B,5] =
+    {device address, H, W, 0, channels} of the decoded uint8 HWC images: the descriptor rows of
+    witw_resize_bilinear_normalize_batched / witw_polar_from_raw, kind 1). Two launches for the whole batch."""
+    from . import _lib, ops
+    d = desc.numpy() if isinstance(desc, torch.Tensor) else np.asarray(desc)
+    B = d.shape[0]
+    table = np.zeros((B, 5), dtype=np.int64)
+    keep = []
+    is_raw = d[:, 24] != 0
+    table[:, 1], table[:, 2] = d[:, 2], d[:, 3]
+    table[is_raw, 0] = dbuf.data_ptr() + d[is_raw, 0]
+    table[is_raw, 4] = d[is_raw, 25]
+    jp = np.nonzero(~is_raw)[0]
+    if jp.size:
+        planes, images = [], np.zeros((jp.size, 12), dtype=np.int64)
+        blk, pbytes, obytes = 0, 0, 0
+        qt_base = int(d[jp, 1].min())
+        for n, i in enumerate(jp):
+            H, W, ncomp, hmax, vmax = (int(v) for v in d[i, 2:7])
+            cb = int(d[i, 0]) // 128                      # coefficient blocks are 128 bytes
+            offs = []
+            for c in range(ncomp):
+                bw, bh = int(d[i, 10 + 4 * c]), int(d[i, 11 + 4 * c])
+                planes.append((cb, (int(d[i, 1]) - qt_base) // 128 + c, pbytes, bw, bh, blk))
+                offs.append((pbytes, bw * 8))
+                cb += bw * bh
+                blk += bw * bh
+                pbytes += bw * bh * 64
+            mode = 0 if (hmax, vmax) == (1, 1) else 1 if (hmax, vmax) == (2, 1) else 2 if (hmax, vmax) == (2, 2) else -1
+            if mode < 0:
+                raise _lib.WitwError('jpeg: sampling %dx%d reached the device path' % (hmax, vmax))
+            if mode and -(-W // hmax) <= 2:      # libjpeg replicates chroma planes of at most two columns instead of filtering them
+                mode += 2
+            images[n, :4] = (H, W, ncomp, mode)
+            images[n, 4], images[n, 5] = offs[0]
+            if ncomp == 3:
+                images[n, 6], images[n, 7], images[n, 8] = offs[1][0], offs[2][0], offs[1][1]
+                images[n, 9], images[n, 10] = -(-H * 1 // vmax), -(-W * 1 // hmax)
+            images[n, 11] = obytes
+            table[i, 4] = ncomp
+            obytes += (H * W * ncomp + 15) // 16 * 16
+        dev = dbuf.device
+        plane_t = torch.from_numpy(np.asarray(planes, dtype=np.int64)).pin_memory().to(dev, non_blocking=True)
+        image_t = torch.from_numpy(images).pin_memory().to(dev, non_blocking=True)
+        comp = torch.empty((pbytes,), dtype=torch.uint8, device=dev)
+        rgb = torch.empty((obytes,), dtype=torch.uint8, device=dev)
+        lib = _lib.load()
+        st = ops._stream()
+        _lib.check(lib.witw_jpeg_idct(dbuf.data_ptr(), dbuf.data_ptr() + qt_base, plane_t.data_ptr(), len(planes), blk, comp.data_ptr(), st),
+                   'witw_jpeg_idct')
+        _lib.check(lib.witw_jpeg_to_rgb(comp.data_ptr(), image_t.data_ptr(), int(jp.size), int((images[:, 0] * images[:, 1]).max()),
+                                        rgb.data_ptr(), st), 'witw_jpeg_to_rgb')
+        table[jp, 0] = rgb.data_ptr() + images[:, 11]
+        keep += [plane_t, image_t, comp, rgb]
+    return keep, torch.from_numpy(table)
+
+
+def decode(images, device):
+    """Decode a list of JpegCoef (or uint8 HWC arrays, passed through) on `device` -> list of uint8 HWC tensors (tests and
+    one-off use; the data path goes through pack / decode_packed inside GpuPreprocess)."""
+    buf, desc, _k = pack(images)
+    dbuf = buf.to(device)
+    keep, table = decode_packed(dbuf, desc)
+    torch.cuda.synchronize(device)
+    out = []
+    for i in range(len(images)):
+        H, W, C = int(table[i, 1]), int(table[i, 2]), int(table[i, 4])
+        src = next(t for t in [dbuf] + keep if t.dtype == torch.uint8 and t.data_ptr() <= int(table[i, 0]) < t.data_ptr() + max(1, t.numel())
+                   and int(table[i, 0]) + H * W * C <= t.data_ptr() + t.numel() and (t is dbuf) == bool(desc[i, 24]))
+        o = int(table[i, 0]) - src.data_ptr()
+        out.append(src[o:o + H * W * C].reshape(H, W, C).clone())
+    return out
