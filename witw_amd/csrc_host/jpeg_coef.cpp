@@ -16,24 +16,29 @@ const uint8_t ZZ[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 
                         41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
                         30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
+constexpr int FAST = 10;          // look-ahead bits of the decoding tables
+
 struct Huff {
-    uint8_t look_len[512];      // 9-bit prefix -> code length (0: longer than 9 bits)
-    uint8_t look_sym[512];
-    int32_t maxcode[18];        // largest code of each length (-1: none), [17] = sentinel
-    int32_t valoff[17];         // symbol index of the first code of each length minus that code
+    uint8_t look_len[1 << FAST];     // FAST-bit prefix -> code length (0: longer than FAST bits)
+    uint8_t look_sym[1 << FAST];
+    int32_t fast_ac[1 << FAST];      // AC tables: (value << 16) | (run << 8) | (code length + magnitude bits) when code AND magnitude
+                                     // bits fit the look-ahead, else 0 (the usual two-step path)
+    int32_t maxcode[18];             // largest code of each length (-1: none), [17] = sentinel
+    int32_t valoff[17];              // symbol index of the first code of each length minus that code
     uint8_t sym[256];
     bool present;
 };
 
-bool build_huff(Huff& h, const uint8_t* counts, const uint8_t* symbols, int nsym) {
+bool build_huff(Huff& h, const uint8_t* counts, const uint8_t* symbols, int nsym, bool ac) {
     memcpy(h.sym, symbols, nsym);
     memset(h.look_len, 0, sizeof(h.look_len));
+    memset(h.fast_ac, 0, sizeof(h.fast_ac));
     int code = 0, k = 0;
     for (int len = 1; len <= 16; ++len) {
         h.valoff[len] = k - code;
         for (int i = 0; i < counts[len - 1]; ++i, ++k, ++code) {
-            if (len <= 9) {
-                const int first = code << (9 - len), n = 1 << (9 - len);
+            if (len <= FAST) {
+                const int first = code << (FAST - len), n = 1 << (FAST - len);
                 for (int j = 0; j < n; ++j) {
                     h.look_len[first + j] = (uint8_t)len;
                     h.look_sym[first + j] = symbols[k];
@@ -46,44 +51,45 @@ bool build_huff(Huff& h, const uint8_t* counts, const uint8_t* symbols, int nsym
     }
     h.maxcode[17] = 0x7fffffff;
     h.present = true;
-    return k == nsym;
+    if (k != nsym) return false;
+    if (ac)
+        for (int i = 0; i < (1 << FAST); ++i) {
+            const int len = h.look_len[i];
+            if (!len) continue;
+            const int rs = h.look_sym[i], run = rs >> 4, mag = rs & 15;
+            if (mag == 0 || len + mag > FAST) continue;
+            int v = (i >> (FAST - len - mag)) & ((1 << mag) - 1);       // the magnitude bits behind the code
+            if (v < (1 << (mag - 1))) v -= (1 << mag) - 1;
+            h.fast_ac[i] = (int32_t)((uint32_t)v << 16) | (run << 8) | (len + mag);
+        }
+    return true;
 }
 
+// Bit reader over the UNSTUFFED entropy-coded bytes (FF 00 -> FF done once up front; 8 zero bytes behind the end)
 struct Bits {
     const uint8_t* p;
-    const uint8_t* end;
     uint64_t buf;       // bits left-aligned
     int n;              // valid bits in buf
-    bool hit_marker;
-    void init(const uint8_t* a, const uint8_t* e) { p = a; end = e; buf = 0; n = 0; hit_marker = false; }
-    inline void fill() {
-        while (n <= 56) {
-            uint64_t b = 0;
-            if (!hit_marker && p < end) {
-                b = *p;
-                if (b == 0xFF) {
-                    if (p + 1 < end && p[1] == 0) p += 2;       // stuffed zero
-                    else { hit_marker = true; b = 0; }          // a marker: feed zeros from here on (as libjpeg does)
-                } else {
-                    ++p;
-                }
-            }
-            buf |= b << (56 - n);
-            n += 8;
-        }
+    void init(const uint8_t* a) { p = a; buf = 0; n = 0; }
+    inline void fill() {      // tops up to at least 56 valid bits: one unaligned 8-byte load, whole bytes appended
+        uint64_t w;
+        memcpy(&w, p, 8);
+        buf |= __builtin_bswap64(w) >> n;
+        const int adv = (63 - n) >> 3;
+        p += adv;
+        n += adv << 3;
     }
-    inline int peek(int k) { return (int)(buf >> (64 - k)); }
+    inline int peek(int k) const { return (int)(buf >> (64 - k)); }
     inline void skip(int k) { buf <<= k; n -= k; }
     inline int get(int k) { const int v = peek(k); skip(k); return v; }
 };
 
-inline int decode_sym(Bits& b, const Huff& h) {
-    if (b.n < 16) b.fill();
-    const int look = b.peek(9);
+inline int decode_sym(Bits& b, const Huff& h) {      // caller has >= 16 valid bits
+    const int look = b.peek(FAST);
     int len = h.look_len[look];
     if (len) { b.skip(len); return h.look_sym[look]; }
-    len = 10;
-    int code = b.peek(10);
+    len = FAST + 1;
+    int code = b.peek(len);
     while (code > h.maxcode[len]) { ++len; if (len > 16) return -1; code = b.peek(len); }
     b.skip(len);
     return h.sym[(code + h.valoff[len]) & 255];
@@ -157,7 +163,7 @@ int parse(const uint8_t* d, size_t n, Parsed& P) {
                 int nsym = 0;
                 for (int j = 0; j < 16; ++j) nsym += s[k + 1 + j];
                 if (nsym > 256 || k + 17 + nsym > sl) return -1;
-                if (!build_huff(tc ? P.ac[th] : P.dc[th], s + k + 1, s + k + 17, nsym)) return -1;
+                if (!build_huff(tc ? P.ac[th] : P.dc[th], s + k + 1, s + k + 17, nsym, tc != 0)) return -1;
                 k += 17 + nsym;
             }
         } else if (m == 0xDD) {
@@ -235,19 +241,45 @@ int witw_jpeg_decode_coef(const uint8_t* data, size_t n, int16_t* coef, uint16_t
         P.c[c].pred = 0;
     }
     memset(coef, 0, (size_t)total * 128);
+    // ---- unstuff the entropy-coded segment once: FF 00 -> FF, RSTn markers dropped (their byte positions kept), any other
+    // marker ends the data; zeros behind the end so that the bit reader may run ahead
+    static thread_local uint8_t* clean = nullptr;
+    static thread_local size_t clean_cap = 0;
+    static thread_local uint32_t* rst_pos = nullptr;
+    static thread_local size_t rst_cap = 0;
+    const size_t seg = (size_t)(data + n - P.scan);
+    if (clean_cap < seg + 32) { delete[] clean; clean_cap = seg + 32 + seg / 4; clean = new uint8_t[clean_cap]; }
+    const size_t max_rst = P.restart ? (size_t)P.mcux * P.mcuy / P.restart + 2 : 1;
+    if (rst_cap < max_rst) { delete[] rst_pos; rst_cap = max_rst + max_rst / 4; rst_pos = new uint32_t[rst_cap]; }
+    size_t w = 0, n_rst = 0;
+    {
+        const uint8_t* q = P.scan;
+        const uint8_t* e = data + n;
+        while (q < e) {
+            const uint8_t* f = (const uint8_t*)memchr(q, 0xFF, (size_t)(e - q));
+            if (!f) { memcpy(clean + w, q, (size_t)(e - q)); w += (size_t)(e - q); break; }
+            memcpy(clean + w, q, (size_t)(f - q));
+            w += (size_t)(f - q);
+            if (f + 1 >= e) break;
+            const int m = f[1];
+            if (m == 0) { clean[w++] = 0xFF; q = f + 2; }
+            else if (m >= 0xD0 && m <= 0xD7) { if (n_rst < rst_cap) rst_pos[n_rst++] = (uint32_t)w | ((uint32_t)(m - 0xD0) << 29); q = f + 2; }
+            else if (m == 0xFF) { q = f + 1; }
+            else break;                                     // EOI or another marker: the entropy-coded data ends here
+        }
+    }
+    memset(clean + w, 0, 16);      // the reader loads 8 bytes at a time
     Bits b;
-    b.init(P.scan, data + n);
+    b.init(clean);
     int to_restart = P.restart, next_rst = 0;
+    size_t rst_i = 0;
+    const uint8_t* const limit = clean + w + 9;             // reading this far past the data means the stream was too short
     for (int my = 0; my < P.mcuy; ++my)
         for (int mx = 0; mx < P.mcux; ++mx) {
             if (P.restart && to_restart == 0) {
-                // byte-align, expect RSTn
-                b.n = 0; b.buf = 0;
-                const uint8_t* q = b.p;
-                while (q + 1 < b.end && !(q[0] == 0xFF && q[1] >= 0xD0 && q[1] <= 0xD7)) ++q;
-                if (q + 1 >= b.end || q[1] != 0xD0 + next_rst) return -3;
-                b.p = q + 2;
-                b.hit_marker = false;
+                if (rst_i >= n_rst || (int)(rst_pos[rst_i] >> 29) != next_rst) return -3;
+                b.init(clean + (rst_pos[rst_i] & 0x1fffffffu));
+                ++rst_i;
                 next_rst = (next_rst + 1) & 7;
                 to_restart = P.restart;
                 for (int c = 0; c < P.ncomp; ++c) P.c[c].pred = 0;
@@ -259,14 +291,21 @@ int witw_jpeg_decode_coef(const uint8_t* data, size_t n, int16_t* coef, uint16_t
                 for (int v = 0; v < C.v; ++v)
                     for (int h = 0; h < C.h; ++h) {
                         int16_t* blk = coef + (C.off + (int64_t)(my * C.v + v) * C.bw + (mx * C.h + h)) * 64;
+                        b.fill();                           // >= 56 bits: a code (<= 16) + its magnitude bits (<= 15), twice over
                         int s = decode_sym(b, hd);
                         if (s < 0 || s > 15) return -3;
-                        if (s) {
-                            if (b.n < s) b.fill();
-                            C.pred += extend(b.get(s), s);
-                        }
+                        if (s) C.pred += extend(b.get(s), s);
                         blk[0] = (int16_t)C.pred;
                         for (int kk = 1; kk < 64;) {
+                            if (b.n < 32) b.fill();
+                            const int32_t fa = ha.fast_ac[b.peek(FAST)];
+                            if (fa) {                       // code and value in one look-up
+                                kk += (fa >> 8) & 15;
+                                if (kk > 63) return -3;
+                                b.skip(fa & 255);
+                                blk[ZZ[kk++]] = (int16_t)(fa >> 16);
+                                continue;
+                            }
                             const int rs = decode_sym(b, ha);
                             if (rs < 0) return -3;
                             const int r = rs >> 4;
@@ -278,10 +317,10 @@ int witw_jpeg_decode_coef(const uint8_t* data, size_t n, int16_t* coef, uint16_t
                             }
                             kk += r;
                             if (kk > 63) return -3;
-                            if (b.n < s) b.fill();
                             blk[ZZ[kk]] = (int16_t)extend(b.get(s), s);
                             ++kk;
                         }
+                        if (b.p > limit) return -3;
                     }
             }
             if (P.restart) --to_restart;

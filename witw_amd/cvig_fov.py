@@ -1129,7 +1129,7 @@ class ImagePairDataset(torch.utils.data.Dataset):
         are decoded by Pillow as with raw=True."""
         from . import jpeg
         if str(path).lower().endswith(('.jpg', '.jpeg')):
-            c = jpeg.read_coef(path)
+            c = jpeg.open_file(path)      # header only; collate_packed entropy-decodes straight into the batch block
             if c is not None:
                 return c
         return ImagePairDataset._read_raw(path)
@@ -1159,7 +1159,7 @@ def _pack_side(images):
     import numpy as np
     from . import jpeg
     if any(isinstance(a, jpeg.JpegCoef) for a in images):      # entropy-decoded JPEG files (+ uint8 images of files left to Pillow)
-        return jpeg.pack(images)
+        return jpeg.pack(images, shared=torch.utils.data.get_worker_info() is not None)
     raw = all(isinstance(a, np.ndarray) and a.dtype == np.uint8 and a.ndim == 3 for a in images)
     parts, desc, off = [], [], 0
     for a in images:
@@ -1174,10 +1174,13 @@ def _pack_side(images):
         desc.append((off, h, w, cs))
         parts.append(flat)
         off += (flat.size + 15) // 16 * 16                 # images start 16-byte aligned
-    buf = np.zeros((off,), dtype=np.uint8)
+    # in a DataLoader worker the block is built in shared memory, where the parent reads it (no second copy when it is pickled);
+    # not zero-filled: the few alignment bytes between images are never read
+    t = jpeg._shared_bytes(off) if torch.utils.data.get_worker_info() is not None else torch.empty((off,), dtype=torch.uint8)
+    buf = t.numpy()
     for (o, _h, _w, _c), f in zip(desc, parts):
         buf[o:o + f.size] = f
-    return torch.from_numpy(buf), torch.tensor(desc, dtype=torch.int64), 1 if raw else 0
+    return t, torch.tensor(desc, dtype=torch.int64), 1 if raw else 0
 
 
 def collate_packed(samples):

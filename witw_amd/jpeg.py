@@ -46,6 +46,39 @@ class JpegCoef(object):
         return (int(self.info[0]), int(self.info[1]), int(self.info[2]))
 
 
+class JpegFile(JpegCoef):
+    """A JPEG file whose header has been parsed (info) but whose entropy-coded data is still to be decoded: pack() decodes it
+    straight into its place in the batch block (no array of its own, no copy). `coef` / `qt` decode on demand."""
+    __slots__ = ('data',)
+
+    def __init__(self, info, data):
+        self.info, self.data = info, data
+
+    def decode_into(self, coef, qt):
+        """coef int16 [blocks, 64], qt uint16 [components, 64]: views of the destination. -> False if the entropy data is bad."""
+        return host_lib().witw_jpeg_decode_coef(self.data.ctypes.data, self.data.size, coef.ctypes.data, qt.ctypes.data) == 0
+
+    def _decoded(self):
+        coef = np.empty((int(self.info[5]), 64), dtype=np.int16)
+        qt = np.empty((int(self.info[2]), 64), dtype=np.uint16)
+        if not self.decode_into(coef, qt):
+            raise ValueError('corrupt JPEG entropy data')
+        return coef, qt
+
+    coef = property(lambda self: self._decoded()[0])
+    qt = property(lambda self: self._decoded()[1])
+
+
+def open_file(src):
+    """src: a path or the bytes of a JPEG file -> JpegFile (header parsed, entropy decoding deferred to pack()), or None when the
+    file is left to the host decoder."""
+    data = np.fromfile(src, dtype=np.uint8) if isinstance(src, (str, os.PathLike)) else np.frombuffer(src, dtype=np.uint8)
+    info = np.zeros(22, dtype=np.int32)
+    if host_lib().witw_jpeg_info(data.ctypes.data, data.size, info.ctypes.data) != 0:
+        return None
+    return JpegFile(info, data)
+
+
 def read_coef(src):
     """src: a path or the bytes of a JPEG file -> JpegCoef, or None when the file is left to the host decoder."""
     data = np.fromfile(src, dtype=np.uint8) if isinstance(src, (str, os.PathLike)) else np.frombuffer(src, dtype=np.uint8)
@@ -60,33 +93,49 @@ def read_coef(src):
     return JpegCoef(info, coef, qt)
 
 
-def pack(images):
-    """A list of JpegCoef (and, for files left to Pillow, uint8 HWC arrays) -> (uint8 tensor, int64 [B, DESC_COLS], KIND_JPEG):
-    one contiguous block for the pinned copy, images 16-byte aligned, the quantisation tables behind the coefficient data."""
-    parts, desc, off = [], np.zeros((len(images), DESC_COLS), dtype=np.int64), 0
+def _shared_bytes(n):
+    """n bytes of shared memory as a uint8 tensor: a DataLoader worker's batch block is built in place where the parent process
+    will read it (torch would otherwise copy every tensor of a batch into shared memory when it pickles it)."""
+    return torch.empty((n,), dtype=torch.uint8).share_memory_() if n else torch.empty((0,), dtype=torch.uint8)
+
+
+def pack(images, shared=False):
+    """A list of JpegCoef / JpegFile (and, for files left to Pillow, uint8 HWC arrays) -> (uint8 tensor, int64 [B, DESC_COLS],
+    KIND_JPEG): one contiguous block for the pinned copy, images 16-byte aligned, the quantisation tables behind the coefficient
+    data. JpegFile entries are entropy-decoded HERE, straight into the block. shared: allocate the block in shared memory."""
+    desc, off, spans = np.zeros((len(images), DESC_COLS), dtype=np.int64), 0, []
     for i, a in enumerate(images):
         if isinstance(a, JpegCoef):
-            flat = a.coef.reshape(-1).view(np.uint8)
+            nbytes = int(a.info[5]) * 128
             desc[i, 2:24] = a.info
         else:
             a = np.ascontiguousarray(a)
             if a.dtype != np.uint8 or a.ndim != 3:
-                raise ValueError('jpeg.pack takes JpegCoef objects and uint8 HWC arrays')
-            flat = a.reshape(-1)
+                raise ValueError('jpeg.pack takes JpegCoef / JpegFile objects and uint8 HWC arrays')
+            nbytes = a.size
             desc[i, 2], desc[i, 3], desc[i, 24], desc[i, 25] = a.shape[0], a.shape[1], 1, a.shape[2]
         desc[i, 0] = off
-        parts.append((off, flat))
-        off += (flat.size + 15) // 16 * 16
+        spans.append((off, nbytes))
+        off += (nbytes + 15) // 16 * 16
     for i, a in enumerate(images):
         if isinstance(a, JpegCoef):
-            flat = a.qt.reshape(-1).view(np.uint8)
             desc[i, 1] = off
-            parts.append((off, flat))
-            off += (flat.size + 15) // 16 * 16
-    buf = np.zeros((off,), dtype=np.uint8)
-    for o, f in parts:
-        buf[o:o + f.size] = f
-    return torch.from_numpy(buf), torch.from_numpy(desc), KIND_JPEG
+            off += (int(a.info[2]) * 128 + 15) // 16 * 16
+    t = _shared_bytes(off) if shared else torch.empty((off,), dtype=torch.uint8)
+    buf = t.numpy()
+    for i, a in enumerate(images):
+        o, nbytes = spans[i]
+        if isinstance(a, JpegFile):
+            coef = buf[o:o + nbytes].view(np.int16).reshape(-1, 64)
+            qt = buf[int(desc[i, 1]):int(desc[i, 1]) + int(a.info[2]) * 128].view(np.uint16).reshape(-1, 64)
+            if not a.decode_into(coef, qt):
+                raise ValueError('corrupt JPEG entropy data in image %d of the batch' % i)
+        elif isinstance(a, JpegCoef):
+            buf[o:o + nbytes] = a.coef.reshape(-1).view(np.uint8)
+            buf[int(desc[i, 1]):int(desc[i, 1]) + a.qt.size * 2] = a.qt.reshape(-1).view(np.uint8)
+        else:
+            buf[o:o + nbytes] = np.ascontiguousarray(a).reshape(-1)
+    return t, torch.from_numpy(desc), KIND_JPEG
 
 
 def decode_packed(dbuf, desc):
