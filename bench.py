@@ -351,6 +351,7 @@ def main():
     ap.add_argument('--decode', choices=['device', 'host'], default='device',
                     help="e2e: 'device' = DataLoader workers entropy-decode the JPEG files, the GPU does dequantisation / IDCT / upsampling / "
                          "colour conversion (byte-identical to Pillow); 'host' = Pillow in the workers (the reference's arrangement)")
+    ap.add_argument('--no-ring', action='store_true', help='e2e: torch DataLoader staging (shared-memory pickling + pin_memory thread) instead of ring.PinnedRing')
     ap.add_argument('--workers', type=int, default=12, help='e2e: DataLoader workers (reference: 12, model/cvig_fov.py:402)')
     a = ap.parse_args()
 

@@ -1153,13 +1153,15 @@ def collate_raw(samples):
     return out
 
 
-def _pack_side(images):
+def _pack_side(images, alloc=None):
     """A batch of differently sized images -> ONE contiguous byte buffer + [B,4] int64 {byte offset, H, W, channels stored per
-    pixel}. All uint8 HWC (decoder output) -> kind 1, bytes as they are; anything else -> float32 planar CHW, kind 0."""
+    pixel}. All uint8 HWC (decoder output) -> kind 1, bytes as they are; anything else -> float32 planar CHW, kind 0.
+    alloc: build the block in caller-provided memory (ring.PinnedRing.allocator); the first result is then (offset, nbytes),
+    or the whole result None when the memory is too small."""
     import numpy as np
     from . import jpeg
     if any(isinstance(a, jpeg.JpegCoef) for a in images):      # entropy-decoded JPEG files (+ uint8 images of files left to Pillow)
-        return jpeg.pack(images, shared=torch.utils.data.get_worker_info() is not None)
+        return jpeg.pack(images, shared=torch.utils.data.get_worker_info() is not None, alloc=alloc)
     raw = all(isinstance(a, np.ndarray) and a.dtype == np.uint8 and a.ndim == 3 for a in images)
     parts, desc, off = [], [], 0
     for a in images:
@@ -1176,17 +1178,38 @@ def _pack_side(images):
         off += (flat.size + 15) // 16 * 16                 # images start 16-byte aligned
     # in a DataLoader worker the block is built in shared memory, where the parent reads it (no second copy when it is pickled);
     # not zero-filled: the few alignment bytes between images are never read
-    t = jpeg._shared_bytes(off) if torch.utils.data.get_worker_info() is not None else torch.empty((off,), dtype=torch.uint8)
-    buf = t.numpy()
+    if alloc is not None:
+        got = alloc(off)
+        if got is None:
+            return None
+        t, buf = (got[0], off), got[1]
+    else:
+        t = jpeg._shared_bytes(off) if torch.utils.data.get_worker_info() is not None else torch.empty((off,), dtype=torch.uint8)
+        buf = t.numpy()
     for (o, _h, _w, _c), f in zip(desc, parts):
         buf[o:o + f.size] = f
     return t, torch.tensor(desc, dtype=torch.int64), 1 if raw else 0
 
 
-def collate_packed(samples):
+def collate_packed(samples, ring=None):
     """collate_fn of the fast path (runs in the DataLoader worker): each side of the batch becomes one byte buffer + a
     descriptor table, so that the batch crosses the process boundary, the pinning thread and PCIe as two large blocks
-    instead of 2 x B tensors."""
+    instead of 2 x B tensors. ring (ring.PinnedRing, bound with functools.partial): the two blocks are built in a slot of the
+    parent's page-locked shared memory and only {slot, offsets} travel back -- no copy into shared memory, no pinning thread."""
+    if ring is not None:
+        slot = ring.acquire()
+        alloc = ring.allocator(slot)
+        s_side = _pack_side([s['surface'] for s in samples], alloc)
+        o_side = _pack_side([s['overhead'] for s in samples], alloc) if s_side is not None else None
+        if o_side is not None:
+            (s_off, s_len), sd, sk = s_side
+            (o_off, o_len), od, ok = o_side
+            out = {'ring': (slot, s_off, s_len, o_off, o_len), 'surface_desc': sd, 'surface_kind': sk, 'overhead_desc': od,
+                   'overhead_kind': ok, 'packed': True}
+            if samples and 'idx' in samples[0]:
+                out['idx'] = [s['idx'] for s in samples]
+            return out
+        ring.release(slot)          # the batch does not fit a slot: the ordinary blocks
     sb, sd, sk = _pack_side([s['surface'] for s in samples])
     ob, od, ok = _pack_side([s['overhead'] for s in samples])
     out = {'surface_bytes': sb, 'surface_desc': sd, 'surface_kind': sk, 'overhead_bytes': ob, 'overhead_desc': od,
@@ -1230,11 +1253,12 @@ class GpuPreprocess(object):
     fused = True              # overhead side through witw_polar_from_raw (False: resize + polar transform as two launches)
     keep_overhead = False     # True: also return the reference's 'overhead' entry (the resized + normalised image; two launches)
 
-    def __init__(self, dataset, fov=360, random_orientation=True, device=None):
+    def __init__(self, dataset, fov=360, random_orientation=True, device=None, ring=None):
         self.resize = Resize(dataset, fov, random_orientation)
         self.norm = (self.normalization or ImageNormalization)()
         self.polar = PolarTransform()
         self.device = device      # where host images go (train() / test() pass their module's `device`); None = cvig_fov.device
+        self.ring = ring          # ring.PinnedRing the loader's collate_packed builds its batch blocks in (None: ordinary blocks)
 
     def _dev(self):
         dev = self.device if self.device is not None else device
@@ -1242,7 +1266,7 @@ class GpuPreprocess(object):
             raise _lib.WitwError('no gfx950 device: the WITW transforms run on the GPU only')
         return dev
 
-    def _stage_side(self, st, dev, images=None, packed=None):
+    def _stage_side(self, st, dev, images=None, packed=None, pinned=False):
         if packed is not None:
             buf, desc, kind = packed
         elif all(isinstance(t, torch.Tensor) and t.is_cuda for t in images):        # already resident: point at them
@@ -1254,10 +1278,10 @@ class GpuPreprocess(object):
             return torch.tensor(rows, dtype=torch.int64).to(dev, non_blocking=True), 0
         else:
             buf, desc, kind = _pack_side([t.cpu() if isinstance(t, torch.Tensor) else t for t in images])
-        if not buf.is_pinned():
+        if not pinned and not buf.is_pinned():
             buf = buf.pin_memory()
         dbuf = buf.to(dev, non_blocking=True)
-        st.keep += [dbuf, buf]
+        st.keep += [dbuf] if pinned else [dbuf, buf]
         if kind == 2:      # jpeg.KIND_JPEG: coefficient blocks -> dequantise, inverse DCT, upsample, colour-convert on the device
             from . import jpeg
             keep, table = jpeg.decode_packed(dbuf, desc)
@@ -1284,8 +1308,20 @@ class GpuPreprocess(object):
         s_tabs, o_tabs, idx = [], [], []
         for part in parts:
             if part.get('packed'):
-                s_tab, s_kind = self._stage_side(st, dev, packed=(part['surface_bytes'], part['surface_desc'], part['surface_kind']))
-                o_tab, o_kind = self._stage_side(st, dev, packed=(part['overhead_bytes'], part['overhead_desc'], part['overhead_kind']))
+                ring_slot = None
+                if 'ring' in part:        # the blocks sit in a slot of the page-locked shared ring: DMA straight from there
+                    if self.ring is None:
+                        raise _lib.WitwError('a batch built in a PinnedRing reached a GpuPreprocess without `ring`')
+                    ring_slot, s_off, s_len, o_off, o_len = part['ring']
+                    part = dict(part, surface_bytes=self.ring.view(ring_slot, s_off, s_len), overhead_bytes=self.ring.view(ring_slot, o_off, o_len))
+                s_tab, s_kind = self._stage_side(st, dev, packed=(part['surface_bytes'], part['surface_desc'], part['surface_kind']),
+                                                 pinned=ring_slot is not None)
+                o_tab, o_kind = self._stage_side(st, dev, packed=(part['overhead_bytes'], part['overhead_desc'], part['overhead_kind']),
+                                                 pinned=ring_slot is not None)
+                if ring_slot is not None:
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream())
+                    self.ring.release_after(ring_slot, ev)
             else:
                 s_tab, s_kind = self._stage_side(st, dev, images=part['surface'])
                 o_tab, o_kind = self._stage_side(st, dev, images=part['overhead'])

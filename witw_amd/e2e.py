@@ -63,10 +63,20 @@ def bench(a, device, n_pairs=None, workers=None, keep_dir=None, decode=None, pre
 
     ds = cvig_fov.ImagePairDataset('cvusa', csv, raw='jpeg' if decode == 'device' else True)
     split = cvig_fov.loader_split(B, workers)      # workers decode quarter batches (as test() does): first batch 4x sooner
+    # batch blocks are built by the workers directly in page-locked shared memory (ring.PinnedRing): no pickling copy, no pinning
+    # thread; --no-ring: torch's own path (shared-memory pickling + pin_memory thread)
+    use_ring = bool(workers) and not getattr(a, 'no_ring', False)
+    ring = None
+    if use_ring:
+        import functools
+        from . import ring as ring_mod
+        per_part = (B // split) * int(1.25 * (3 * 512 * 512 + 3 * 224 * 224 + 4096))
+        ring = ring_mod.PinnedRing(slots=workers * 4 + 2 * split + 4, slot_bytes=per_part)
+    collate = functools.partial(cvig_fov.collate_packed, ring=ring) if use_ring else cvig_fov.collate_packed
     loader = torch.utils.data.DataLoader(ds, batch_size=B // split, shuffle=False, drop_last=False, num_workers=workers,
-                                         collate_fn=cvig_fov.collate_packed, pin_memory=True,
+                                         collate_fn=collate, pin_memory=not use_ring,
                                          prefetch_factor=4 if workers else None, persistent_workers=bool(workers))
-    prep = cvig_fov.GpuPreprocess('cvusa', fov, random_orientation=False, device=device)
+    prep = cvig_fov.GpuPreprocess('cvusa', fov, random_orientation=False, device=device, ring=ring)
     wts = synth.fov_dsm_weights(1234)
     se = cvig_fov.FOV_DSM(False, weights=wts).to(device).eval()
     oe = cvig_fov.FOV_DSM(True, weights=wts).to(device).eval()
@@ -82,14 +92,27 @@ def bench(a, device, n_pairs=None, workers=None, keep_dir=None, decode=None, pre
 
     # ---- stage rates on their own
     # (1) the loader alone: decode + pack in the workers, pinning thread; one untimed pass starts the workers / fills the page cache
+    def private_copy(raw):        # a batch kept beyond its slot's life: ordinary pinned blocks
+        if 'ring' not in raw:
+            return raw
+        slot, s_off, s_len, o_off, o_len = raw['ring']
+        out = {k: v for k, v in raw.items() if k != 'ring'}
+        out['surface_bytes'] = ring.view(slot, s_off, s_len).clone().pin_memory()
+        out['overhead_bytes'] = ring.view(slot, o_off, o_len).clone().pin_memory()
+        ring.release(slot)
+        return out
     first = []                     # the parts of the first full batch
     for raw in loader:
         if len(first) < split:
-            first.append(raw)
+            first.append(private_copy(raw))
+        elif 'ring' in raw:
+            ring.release(raw['ring'][0])
     t0 = time.perf_counter()
     n = 0
     for raw in loader:
         n += raw['surface_desc'].shape[0]
+        if 'ring' in raw:
+            ring.release(raw['ring'][0])
     t_load = time.perf_counter() - t0
     # (2) host -> device copy of one packed batch from pinned memory
     blk = sum(f['surface_bytes'].numel() + f['overhead_bytes'].numel() for f in first)
@@ -144,6 +167,8 @@ def bench(a, device, n_pairs=None, workers=None, keep_dir=None, decode=None, pre
            'steps': (n_pairs + B - 1) // B, 'warmup': 0, 'ms_per_step': round(t_e2e / ((n_pairs + B - 1) // B) * 1e3, 3),
            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': {'fp32': 'f32'}.get(precision, precision), 'data': 'synthetic',
            'jpeg_decode': 'device (host: entropy decoding only)' if decode == 'device' else 'host (Pillow)',
+           'staging': ('PinnedRing: %d slots x %.1f MB of page-locked shared memory, workers build the batch blocks in place' % (ring.slots, ring.slot_bytes / 1e6))
+           if ring is not None else 'torch: shared-memory pickling + pin_memory thread',
            'config': {'workload': 'cvig_fov fov=%d, %d JPEG pairs on disk (%d distinct files pairs, overhead 512x512 + ground 224x224, %.1f MB) -> '
                                   'ImagePairDataset(raw=%s) in %d DataLoader workers (quarter batches) -> collate_packed -> pinned -> copy stream -> %sGpuPreprocess '
                                   '(2 launches per batch) -> 2x FOV_DSM (%s) -> embeddings' % (fov, n_pairs, n_unique, nbytes / 1e6, "'jpeg'" if decode == 'device' else 'True', workers,
@@ -159,5 +184,7 @@ def bench(a, device, n_pairs=None, workers=None, keep_dir=None, decode=None, pre
                    'arrives after ~batch x decode time); steady_state = from the first finished batch to the end',
            'overlap_efficiency_steady_state': round(((n_pairs - n_first) / max(1e-9, t_end - t_first)) / min(rates.values()), 3),
            'dataset_written_in_s': round(t_make, 1)}
+    if ring is not None:
+        ring.close()
     tmp.cleanup()
     return out

@@ -99,10 +99,12 @@ def _shared_bytes(n):
     return torch.empty((n,), dtype=torch.uint8).share_memory_() if n else torch.empty((0,), dtype=torch.uint8)
 
 
-def pack(images, shared=False):
+def pack(images, shared=False, alloc=None):
     """A list of JpegCoef / JpegFile (and, for files left to Pillow, uint8 HWC arrays) -> (uint8 tensor, int64 [B, DESC_COLS],
     KIND_JPEG): one contiguous block for the pinned copy, images 16-byte aligned, the quantisation tables behind the coefficient
-    data. JpegFile entries are entropy-decoded HERE, straight into the block. shared: allocate the block in shared memory."""
+    data. JpegFile entries are entropy-decoded HERE, straight into the block. shared: allocate the block in shared memory;
+    alloc(nbytes) -> (offset, uint8 numpy view) or None: build the block in caller-provided memory (ring.PinnedRing), in which
+    case the first result is (offset, nbytes) instead of a tensor."""
     desc, off, spans = np.zeros((len(images), DESC_COLS), dtype=np.int64), 0, []
     for i, a in enumerate(images):
         if isinstance(a, JpegCoef):
@@ -121,8 +123,14 @@ def pack(images, shared=False):
         if isinstance(a, JpegCoef):
             desc[i, 1] = off
             off += (int(a.info[2]) * 128 + 15) // 16 * 16
-    t = _shared_bytes(off) if shared else torch.empty((off,), dtype=torch.uint8)
-    buf = t.numpy()
+    if alloc is not None:
+        got = alloc(off)
+        if got is None:
+            return None
+        t, buf = (got[0], off), got[1]
+    else:
+        t = _shared_bytes(off) if shared else torch.empty((off,), dtype=torch.uint8)
+        buf = t.numpy()
     for i, a in enumerate(images):
         o, nbytes = spans[i]
         if isinstance(a, JpegFile):

@@ -1,0 +1,73 @@
+"""Page-locked, shared staging memory between DataLoader workers and the GPU copy stream.
+
+torch's DataLoader moves a worker's batch three times on the host before the GPU sees it: the worker's tensors are copied into
+shared memory when the batch is pickled, the parent maps that (fresh) shared-memory file, and its pinning thread copies the batch
+once more into page-locked memory -- one thread, about 3.5 GB/s, which caps the cvig_fov data path at ~3.7 k pairs/s whatever
+the workers do. Here the parent owns ONE block of shared memory, page-locks it once (hipHostRegister) and hands slots of it to the
+workers through a queue: a worker builds its batch block directly in a slot (collate_packed(ring=...)) and sends back a few
+integers; the parent starts the host-to-device DMA straight from the slot and returns the slot when the copy's event has fired.
+The reference has no counterpart (its DataLoader hands float tensors to `.to(device)`, model/cvig_fov.py:402, :440-442)."""
+import multiprocessing as mp
+
+import torch
+
+
+class PinnedRing(object):
+    def __init__(self, slots, slot_bytes):
+        self.slots, self.slot_bytes = int(slots), int(slot_bytes)
+        self.mem = torch.empty((self.slots, self.slot_bytes), dtype=torch.uint8).share_memory_()
+        self.registered = False
+        if torch.cuda.is_available():
+            rc = torch.cuda.cudart().cudaHostRegister(self.mem.data_ptr(), self.slots * self.slot_bytes, 0)
+            if int(rc) != 0:
+                raise RuntimeError('hipHostRegister of %d MB failed (%s)' % (self.slots * self.slot_bytes >> 20, rc))
+            self.registered = True
+        self.free = mp.get_context('fork').Queue()      # workers are forked: they inherit the mapping and the queue
+        for i in range(self.slots):
+            self.free.put(i)
+        self.pending = []                                # parent: (event, slot) of copies still in flight
+
+    # ---- worker side
+    def acquire(self, timeout=600.0):
+        return self.free.get(timeout=timeout)
+
+    def allocator(self, slot):
+        """-> alloc(nbytes): consecutive 16-byte aligned uint8 views of the slot (numpy), None once the slot is full."""
+        row = self.mem[slot].numpy()
+        state = {'off': 0}
+
+        def alloc(nbytes):
+            o = state['off']
+            if o + nbytes > self.slot_bytes:
+                return None
+            state['off'] = (o + nbytes + 15) // 16 * 16
+            return o, row[o:o + nbytes]
+        return alloc
+
+    # ---- parent side
+    def view(self, slot, off, nbytes):
+        return self.mem[slot, off:off + nbytes]
+
+    def release_after(self, slot, event):
+        self.pending.append((event, slot))
+        self.reap()
+
+    def reap(self, wait=False):
+        still = []
+        for ev, slot in self.pending:
+            if wait:
+                ev.synchronize()
+            if wait or ev.query():
+                self.free.put(slot)
+            else:
+                still.append((ev, slot))
+        self.pending = still
+
+    def release(self, slot):
+        self.free.put(slot)
+
+    def close(self):
+        self.reap(wait=True)
+        if self.registered:
+            torch.cuda.cudart().cudaHostUnregister(self.mem.data_ptr())
+            self.registered = False
