@@ -79,23 +79,23 @@ def test_data_path_with_device_decode_equals_host_decode(tmp_path):
     got = [prep(st) for st in cvig_fov.DevicePrefetcher(loader, prep)]
     assert torch.equal(torch.cat([d['polar'] for d in got]), outs[True]['polar'])
     # the workers building their blocks in the parent's page-locked shared ring (no pickling copy, no pinning thread); both decoders;
-    # more batches than slots, so slots are recycled behind the copy events; a slot too small for a batch falls back to plain blocks
+    # 16 batches over 6 slots, so slots are recycled behind the copy events; a slot too small for a batch falls back to plain blocks
     import functools
     from witw_amd import ring as ring_mod
     for mode in ('jpeg', True):
         for slot_bytes in (4 << 20, 1 << 16):
-            ring = ring_mod.PinnedRing(slots=3, slot_bytes=slot_bytes)
+            ring = ring_mod.PinnedRing(slots=6, slot_bytes=slot_bytes)      # >= workers x prefetch_factor + 2 (see PinnedRing)
             assert ring.registered and ring.mem.is_shared()
             ds = cvig_fov.ImagePairDataset('cvusa', csv, raw=mode)
             prep_r = cvig_fov.GpuPreprocess('cvusa', fov=360, random_orientation=False, ring=ring)
-            loader = torch.utils.data.DataLoader(torch.utils.data.ConcatDataset([ds] * 3), batch_size=2, shuffle=False, num_workers=2,
+            loader = torch.utils.data.DataLoader(torch.utils.data.ConcatDataset([ds] * 8), batch_size=2, shuffle=False, num_workers=2,
                                                  collate_fn=functools.partial(cvig_fov.collate_packed, ring=ring))
             used_ring = 0
             polar = []
             for raw in loader:
                 used_ring += 'ring' in raw
                 polar.append(prep_r(raw)['polar'])
-            assert used_ring == (6 if slot_bytes > (1 << 20) else 0)
-            assert torch.equal(torch.cat(polar), torch.cat([outs[True]['polar']] * 3))
+            assert used_ring == (16 if slot_bytes > (1 << 20) else 0)
+            assert torch.equal(torch.cat(polar), torch.cat([outs[True]['polar']] * 8))
             ring.close()
-            assert ring.free.qsize() == 3
+            assert ring.free.qsize() == 6

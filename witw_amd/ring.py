@@ -13,6 +13,10 @@ import torch
 
 
 class PinnedRing(object):
+    """slots: at least num_workers x prefetch_factor + 2. A DataLoader hands batches out IN ORDER, so a worker that runs ahead
+    holds slots for batches the parent cannot take yet; with fewer slots than batches the workers may have in flight, the worker
+    that owes the NEXT batch can starve for a slot (deadlock). acquire() raises after `timeout` seconds instead of hanging."""
+
     def __init__(self, slots, slot_bytes):
         self.slots, self.slot_bytes = int(slots), int(slot_bytes)
         self.mem = torch.empty((self.slots, self.slot_bytes), dtype=torch.uint8).share_memory_()
