@@ -29,7 +29,7 @@ class PinnedRing(object):
         self.free = mp.get_context('fork').Queue()      # workers are forked: they inherit the mapping and the queue
         for i in range(self.slots):
             self.free.put(i)
-        self.pending = []                                # parent: (event, slot) of copies still in flight
+        self._reaper, self._todo = None, None           # parent: thread returning slots behind their copy events
 
     # ---- worker side
     def acquire(self, timeout=600.0):
@@ -53,25 +53,41 @@ class PinnedRing(object):
         return self.mem[slot, off:off + nbytes]
 
     def release_after(self, slot, event):
-        self.pending.append((event, slot))
-        self.reap()
+        """Return `slot` to the workers once `event` (recorded behind the host-to-device copies out of it) has fired. A small
+        reaper thread waits on the events: the parent's main thread may be blocked in the DataLoader waiting for exactly the
+        batch whose worker is waiting for this slot."""
+        import queue
+        import threading
+        if self._reaper is None:
+            self._todo = queue.Queue()
+
+            def run():
+                while True:
+                    item = self._todo.get()
+                    if item is None:
+                        return
+                    ev, sl = item
+                    ev.synchronize()
+                    self.free.put(sl)
+                    self._todo.task_done()
+            self._reaper = threading.Thread(target=run, name='witw-ring-reaper', daemon=True)
+            self._reaper.start()
+        self._todo.put((event, slot))
 
     def reap(self, wait=False):
-        still = []
-        for ev, slot in self.pending:
-            if wait:
-                ev.synchronize()
-            if wait or ev.query():
-                self.free.put(slot)
-            else:
-                still.append((ev, slot))
-        self.pending = still
+        """wait=True: block until every slot handed to release_after is back in the free queue."""
+        if wait and self._reaper is not None:
+            self._todo.join()
 
     def release(self, slot):
         self.free.put(slot)
 
     def close(self):
         self.reap(wait=True)
+        if self._reaper is not None:
+            self._todo.put(None)
+            self._reaper.join(5)
+            self._reaper = None
         if self.registered:
             torch.cuda.cudart().cudaHostUnregister(self.mem.data_ptr())
             self.registered = False
