@@ -40,6 +40,11 @@ class Globals:
     # not in the reference: arithmetic of the encoders built by train() / test() / the CLI (`--precision`).
     # 'fp32' = the reference's arithmetic (parity path); 'bf16' = bf16 MFMA operands, fp32 accumulate / weights / Adam.
     precision = 'fp32'
+    # not in the reference: the data path of train() / test(). device_jpeg: DataLoader workers only entropy-decode JPEG files and
+    # the GPU finishes them (byte-identical to Pillow, witw_amd/jpeg.py); pinned_ring: workers build their batches in page-locked
+    # shared memory (witw_amd/ring.py) instead of torch's pickling + pinning thread.
+    device_jpeg = True
+    pinned_ring = True
     # not in the reference: how test() ranks the queries against the gallery. 'direct' = the reference's sum on every pair,
     # 'dft' = the spectral pass with exact re-scoring (same ranks), 'auto' = 'dft' from cvig_fov.SPECTRAL_FROM pairs on.
     match_method = 'auto'
@@ -1404,6 +1409,26 @@ class DevicePrefetcher(object):
             yield cur
 
 
+def make_staging(dataset_obj, loader_batch, num_workers, n_loaders=1, prefetch_factor=2):
+    """How a driver's DataLoaders hand their batches to the GPU. With worker processes and Globals.pinned_ring: a ring.PinnedRing
+    sized from the first files of the data set (slots for every batch the workers can have in flight) -> (ring, collate_fn bound
+    to it, pin_memory=False); else torch's own path -> (None, collate_packed, pin_memory=True). A batch larger than a slot (files
+    much bigger than the sampled ones) falls back to ordinary blocks by itself."""
+    import functools
+    if not (num_workers > 0 and getattr(Globals, 'pinned_ring', True) and device.type == 'cuda' and len(dataset_obj) > 0):
+        return None, collate_packed, True
+    from . import ring as ring_mod
+    n = min(len(dataset_obj), 8)
+    probe = collate_packed([dataset_obj[i * (len(dataset_obj) // n)] for i in range(n)])
+    per_pair = (probe['surface_bytes'].numel() + probe['overhead_bytes'].numel()) / n
+    slot_bytes = int(1.5 * per_pair * loader_batch) + (1 << 16)
+    slots = n_loaders * num_workers * prefetch_factor + 4
+    if slots * slot_bytes > (8 << 30):          # do not lock more than 8 GB of host memory
+        return None, collate_packed, True
+    ring = ring_mod.PinnedRing(slots=slots, slot_bytes=slot_bytes)
+    return ring, functools.partial(collate_packed, ring=ring), False
+
+
 def loader_split(batch_size, num_workers):
     """Parts a batch is decoded in (DevicePrefetcher(group=...)): 4 for batches of 32 and more that divide evenly, when there
     are worker processes to decode them side by side; else 1."""
@@ -1533,8 +1558,9 @@ def train(dataset='cvusa', fov=360, val_quantity=1000, batch_size=64, num_worker
     writer = _writer('runs/{}/train/{}/{}'.format(dataset, fov, datetime.now().strftime("%Y%m%d-%H%M%S"))) if rank == 0 \
         else _NullWriter()
     csv_path = csv_path or Globals.dataset_paths[dataset]['train']
-    prep = GpuPreprocess(dataset, fov, device=device)
-    trainval_set = ImagePairDataset(dataset=dataset, csv_path=csv_path, raw=True)      # decoder bytes; converted on the GPU
+    # raw='jpeg': a worker only entropy-decodes JPEG files, the GPU finishes them (witw_amd/jpeg.py; the same bytes); True:
+    # Pillow's bytes; either way converted / resized / normalised on the GPU
+    trainval_set = ImagePairDataset(dataset=dataset, csv_path=csv_path, raw='jpeg' if getattr(Globals, 'device_jpeg', True) else True)
     split_gen = torch.Generator().manual_seed(seed) if world > 1 else None      # every rank must draw the same split
     train_set, val_set = torch.utils.data.random_split(trainval_set, [len(trainval_set) - val_quantity, val_quantity],
                                                        generator=split_gen)
@@ -1542,14 +1568,15 @@ def train(dataset='cvusa', fov=360, val_quantity=1000, batch_size=64, num_worker
     # every rank reads its own shard of each epoch and the loss still couples the whole global batch
     train_sampler = torch.utils.data.distributed.DistributedSampler(train_set, shuffle=True, drop_last=True) if world > 1 else None
     val_sampler = torch.utils.data.distributed.DistributedSampler(val_set, shuffle=False) if world > 1 else None
-    # workers decode and pack each batch into two byte blocks (collate_packed), the loader's pinning thread moves them to
-    # page-locked memory, DevicePrefetcher copies batch n+1 to the GPU on a side stream while batch n computes
+    # workers decode and pack each batch into two byte blocks (collate_packed) built in place in page-locked shared memory
+    # (make_staging / ring.PinnedRing; else the loader's pinning thread), DevicePrefetcher copies batch n+1 to the GPU on a side
+    # stream while batch n computes
+    ring, collate, pin = m.make_staging(trainval_set, batch_size, num_workers, n_loaders=2) if hasattr(m, 'make_staging') else (None, collate_packed, True)
+    prep = GpuPreprocess(dataset, fov, device=device, ring=ring)
     train_loader = torch.utils.data.DataLoader(train_set, batch_size=batch_size, shuffle=(world == 1), drop_last=True,
-                                               sampler=train_sampler, num_workers=num_workers, collate_fn=collate_packed,
-                                               pin_memory=True)
+                                               sampler=train_sampler, num_workers=num_workers, collate_fn=collate, pin_memory=pin)
     val_loader = torch.utils.data.DataLoader(val_set, batch_size=batch_size, shuffle=False, drop_last=False,
-                                             sampler=val_sampler, num_workers=num_workers, collate_fn=collate_packed,
-                                             pin_memory=True)
+                                             sampler=val_sampler, num_workers=num_workers, collate_fn=collate, pin_memory=pin)
     surface_encoder = FOV_DSM(circ_padding=False, seed=seed)
     overhead_encoder = FOV_DSM(circ_padding=True, seed=seed)
     if getattr(Globals, 'vgg16_weights', None):      # the reference's starting point (:256-272); else seeded synthetic weights
@@ -1615,6 +1642,9 @@ def train(dataset='cvusa', fov=360, val_quantity=1000, batch_size=64, num_worker
                         torch.save(enc.state_dict(), path)
             writer.add_text('best_loss', 'new best loss: {}, epoch: {}'.format(best_loss, epoch + 1),
                             epoch * len(loader) + batch)        # the last validation iteration's step (:487)
+    if ring is not None:
+        del train_loader, val_loader
+        ring.close()
     return best_loss
 
 
@@ -1634,14 +1664,15 @@ def test(dataset='cvusa', fov=360, batch_size=64, num_workers=8, csv_path=None, 
     csv_path = csv_path or Globals.dataset_paths[dataset]['test']
     # the reference crops test panoramas at a random orientation too (:495-499); Globals.test_random_orientation = False
     # makes the evaluation repeatable
-    prep = GpuPreprocess(dataset, fov, getattr(Globals, 'test_random_orientation', True), device=device)
-    test_set = ImagePairDataset(dataset=dataset, csv_path=csv_path, raw=True)
+    test_set = ImagePairDataset(dataset=dataset, csv_path=csv_path, raw='jpeg' if getattr(Globals, 'device_jpeg', True) else True)
     # under torch.distributed every rank embeds a contiguous shard of the test set and keeps its gallery rows
     shard_begin, shard_end = parallel.shard_range(len(test_set))
     shard = torch.utils.data.Subset(test_set, range(shard_begin, shard_end)) if world > 1 else test_set
     split = loader_split(batch_size, num_workers)      # workers decode quarter batches: the first batch arrives 4x sooner
+    ring, collate, pin = m.make_staging(test_set, batch_size // split, num_workers) if hasattr(m, 'make_staging') else (None, collate_packed, True)
+    prep = GpuPreprocess(dataset, fov, getattr(Globals, 'test_random_orientation', True), device=device, ring=ring)
     test_loader = torch.utils.data.DataLoader(shard, batch_size=batch_size // split, shuffle=False, drop_last=False,
-                                              num_workers=num_workers, collate_fn=collate_packed, pin_memory=True)
+                                              num_workers=num_workers, collate_fn=collate, pin_memory=pin)
     surface_encoder = FOV_DSM(circ_padding=False).to(device)
     overhead_encoder = FOV_DSM(circ_padding=True).to(device)
     surface_encoder.precision = overhead_encoder.precision = Globals.precision
@@ -1656,6 +1687,9 @@ def test(dataset='cvusa', fov=360, batch_size=64, num_workers=8, csv_path=None, 
         with torch.no_grad():
             su_parts.append(surface_encoder(data['surface']))
             ov_parts.append(overhead_encoder(data['polar']))
+    if ring is not None:
+        del test_loader
+        ring.close()
     if data is not None and getattr(m, 'PROJECTOR_DUMP', True):        # last batch -> embedding projector (:534-540)
         projector_dump(writer, data['surface'], data['polar'], su_parts[-1], ov_parts[-1], 0, 'test_embedding',
                        Globals.img_mean, Globals.img_std)
