@@ -54,13 +54,13 @@ def _assert_bf16_ulp(got, ref):
 # (B, H, W, Cin, Cout, stride_h, circular, pool, mfma16 switch, expected kernel)
 BF16_CASES = [
     # the config-4 dominant kernel on the layer shapes the bench runs (layers 10/12, 17/19/21, 5, 7 of the encoder)
-    (32, 32, 128, 128, 256, 1, False, False, True, 'conv3x3_bf16_s16_kernel<false>'),
-    (32, 32, 128, 256, 256, 1, True, True, True, 'conv3x3_bf16_s16_kernel<true>'),
-    (64, 16, 64, 512, 512, 1, True, False, True, 'conv3x3_bf16_s16_kernel<false>'),
-    (64, 16, 64, 256, 512, 1, False, False, True, 'conv3x3_bf16_s16_kernel<false>'),
-    (16, 64, 256, 64, 128, 1, True, False, True, 'conv3x3_bf16_s16_kernel<false>'),
-    (16, 64, 256, 128, 128, 1, False, True, True, 'conv3x3_bf16_s16_kernel<true>'),
-    (44, 24, 100, 96, 144, 1, True, False, True, 'conv3x3_bf16_s16_kernel<false>'),      # ragged width / channels, odd chunk pairs
+    (32, 32, 128, 128, 256, 1, False, False, True, 'conv3x3_bf16_s16_kernel<false,false>'),
+    (32, 32, 128, 256, 256, 1, True, True, True, 'conv3x3_bf16_s16_kernel<true,false>'),
+    (64, 16, 64, 512, 512, 1, True, False, True, 'conv3x3_bf16_s16_kernel<false,false>'),
+    (64, 16, 64, 256, 512, 1, False, False, True, 'conv3x3_bf16_s16_kernel<false,false>'),
+    (16, 64, 256, 64, 128, 1, True, False, True, 'conv3x3_bf16_s16_kernel<false,false>'),
+    (16, 64, 256, 128, 128, 1, False, True, True, 'conv3x3_bf16_s16_kernel<true,false>'),
+    (44, 24, 100, 96, 144, 1, True, False, True, 'conv3x3_bf16_s16_kernel<false,false>'),      # ragged width / channels, odd chunk pairs
     # the 8-wave 32x32x16 kernel: with the switch off, and where the 16x16x32 kernel does not apply
     (32, 32, 128, 128, 256, 1, True, False, False, 'conv3x3_nhwc_bf16_kernel<128,1,false,8>'),
     (32, 32, 128, 128, 256, 1, False, True, False, 'conv3x3_nhwc_bf16_kernel<128,1,true,8>'),
@@ -193,9 +193,9 @@ def test_bf16_encoder_at_bench_batch_vs_emulation(variant, monkeypatch):
         enc = mod.FOV_DSM(circ_padding=circ, weights=w).cuda().eval()
         e = enc.forward_bf16(x.cuda()).cpu()
         # layers 5,7 | 10,12,14 | 17,19,21 | 23 | 25, 27 (0 and 2 are the fused first-two-layers kernel)
-        assert ran == ['conv3x3_bf16_s16_kernel<false>', 'conv3x3_bf16_s16_kernel<true>',
-                       'conv3x3_bf16_s16_kernel<false>', 'conv3x3_bf16_s16_kernel<false>', 'conv3x3_bf16_s16_kernel<true>',
-                       'conv3x3_bf16_s16_kernel<false>', 'conv3x3_bf16_s16_kernel<false>', 'conv3x3_bf16_s16_kernel<false>',
+        assert ran == ['conv3x3_bf16_s16_kernel<false,false>', 'conv3x3_bf16_s16_kernel<true,false>',
+                       'conv3x3_bf16_s16_kernel<false,false>', 'conv3x3_bf16_s16_kernel<false,false>', 'conv3x3_bf16_s16_kernel<true,false>',
+                       'conv3x3_bf16_s16_kernel<false,false>', 'conv3x3_bf16_s16_kernel<false,false>', 'conv3x3_bf16_s16_kernel<false,false>',
                        'conv3x3_nhwc_bf16_kernel<128,2,false,4>', 'conv3x3_nhwc_bf16_kernel<64,2,false,4>',
                        'conv3x3_nhwc_bf16_kernel<64,1,false,4>'], ran
         sel = [0, 77, 127]
@@ -204,3 +204,59 @@ def test_bf16_encoder_at_bench_batch_vs_emulation(variant, monkeypatch):
         for i, s in enumerate(sel):
             rel = float((e[s] - emu[i]).norm() / emu[i].norm())
             assert rel < 1e-2, (variant, circ, s, rel)
+
+
+def test_bf16_s16_training_forms_vs_oracle():
+    """The forms a bf16 training step adds to the forward (model/cvig_fov.py:444-461 with Dropout2d :234-245 and the stride-(2,1)
+    layers :263-272), on the 16x16x32 kernel's TRAIN instantiation at a qualifying grid, each against the oracle: Dropout2d scale
+    before the ReLU; the ReLU gate of a dgrad launch (transposed filter, outputs zeroed where the forward's activation was <= 0);
+    zero-interleaved input rows (dgrad of a stride-(2,1) layer); the arg-max codes of the fused max-pool."""
+    from witw_amd import ops
+    dev = torch.device('cuda:0')
+    B, H, W, cin, cout = 64, 16, 64, 256, 512
+    x, w, b = _layer(41, B, H, W, cin, cout)
+    x = x.bfloat16().float()
+    xd = x.to(dev).permute(0, 2, 3, 1).contiguous().bfloat16()
+    g = np.random.Generator(np.random.Philox(key=[41, 7]))
+    sel = _pick(B)
+    # (1) Dropout2d scale
+    scale = torch.from_numpy((g.random((B, cout)) > 0.2).astype(np.float32) * 1.25)
+    pk = ops.PackedConvBf16(w.to(dev), b.to(dev))
+    y = ops.conv3x3_bf16_fwd(xd, pk, circular=True, relu=True, drop_scale=scale.to(dev))
+    assert ops.last_kernel_variant() == 'conv3x3_bf16_s16_kernel<false,true>', ops.last_kernel_variant()
+    ref = torch.relu(O.conv3x3(x[sel], w.bfloat16().float(), b, 1, True) * scale[sel][:, :, None, None])
+    _assert_bf16_ulp(y[sel].float().cpu().permute(0, 3, 1, 2), ref)
+    # (2) dgrad form: transposed + rotated filter, gate
+    dz = torch.from_numpy(g.standard_normal((B, cout, H, W), dtype=np.float32)).bfloat16().float()
+    gate = torch.from_numpy(g.standard_normal((B, cin, H, W), dtype=np.float32)).bfloat16()
+    pkt = ops.PackedConvBf16(w.to(dev), None, transpose_flip=True)
+    dx = ops.conv3x3_bf16_fwd(dz.to(dev).permute(0, 2, 3, 1).contiguous().bfloat16(), pkt, circular=False, relu=False,
+                              gate=gate.to(dev).permute(0, 2, 3, 1).contiguous())
+    assert ops.last_kernel_variant() == 'conv3x3_bf16_s16_kernel<false,true>', ops.last_kernel_variant()
+    wt = w.bfloat16().float().flip(2, 3).transpose(0, 1).contiguous()          # dgrad filter: [cin, cout, 3, 3], taps rotated
+    ref = O.conv3x3(dz[sel], wt, torch.zeros(cin), 1, False) * (gate[sel].float() > 0)
+    _assert_bf16_ulp(dx[sel].float().cpu().permute(0, 3, 1, 2), ref)
+    # (3) zero-interleaved rows: 8 physical rows stand for 16 logical ones (dgrad of a stride-(2,1) conv, Ho = 8 -> H = 16)
+    dz2 = dz[:, :, :8].contiguous()
+    dx2 = ops.conv3x3_bf16_fwd(dz2.to(dev).permute(0, 2, 3, 1).contiguous().bfloat16(), pkt, circular=True, relu=False, dilate_h=True, out_h=16)
+    assert ops.last_kernel_variant() == 'conv3x3_bf16_s16_kernel<false,true>', ops.last_kernel_variant()
+    up = torch.zeros((len(sel), cout, 16, W))
+    up[:, :, 0::2] = dz2[sel]
+    ref = O.conv3x3(up, wt, torch.zeros(cin), 1, True)
+    _assert_bf16_ulp(dx2[sel].float().cpu().permute(0, 3, 1, 2), ref)
+    # (4) fused max-pool with arg-max codes (cvig_semantic trains through the pooled layers, model/cvig_semantic.py:301-309)
+    B2, H2, W2, ci2, co2 = 32, 32, 128, 128, 256
+    x2, w2, b2 = _layer(43, B2, H2, W2, ci2, co2)
+    x2 = x2.bfloat16().float()
+    y2, code = ops.conv3x3_bf16_fwd(x2.to(dev).permute(0, 2, 3, 1).contiguous().bfloat16(), ops.PackedConvBf16(w2.to(dev), b2.to(dev)),
+                                    circular=True, relu=True, pool=True, want_pool_code=True)
+    assert ops.last_kernel_variant() == 'conv3x3_bf16_s16_kernel<true,true>', ops.last_kernel_variant()
+    sel2 = _pick(B2)
+    pre = O.conv3x3(x2[sel2], w2.bfloat16().float(), b2, 1, True)
+    ref2, idx = torch.nn.functional.max_pool2d(torch.relu(pre), 2, 2, return_indices=True)
+    _assert_bf16_ulp(y2[sel2].float().cpu().permute(0, 3, 1, 2), ref2)
+    # the recorded position must attain the window's maximum (ties and fp32 summation order may pick another of equal value)
+    win = pre.unfold(2, 2, 2).unfold(3, 2, 2).reshape(len(sel2), co2, H2 // 2, W2 // 2, 4)
+    picked = torch.gather(win, 4, code[sel2].cpu().permute(0, 3, 1, 2).long().unsqueeze(-1)).squeeze(-1)
+    assert int(code.max()) <= 3
+    assert bool(((win.max(-1).values - picked) <= 2e-5 * float(pre.abs().max())).all())

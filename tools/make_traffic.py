@@ -13,7 +13,7 @@ import sys
 from collections import defaultdict
 
 DOMINANT = ('conv3x3_nhwc_f32_kernel<128,1,false,8', 'conv3x3_nhwc_bf16_kernel<128,1,false,8', 'conv3x3_nhwc_f16x3_kernel<128,1,false,8',
-            'conv3x3_bf16_s16_kernel<false>')
+            'conv3x3_bf16_s16_kernel<false,false>')
 
 
 def per_kernel(path, counter):
@@ -21,7 +21,7 @@ def per_kernel(path, counter):
     for r in csv.DictReader(open(path)):
         if r['Counter_Name'] != counter:
             continue
-        k = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0]
+        k = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0].replace(' ', '')
         acc[k].append(float(r['Counter_Value']))
     return {k: (len(v), sum(v) / len(v)) for k, v in acc.items()}
 

@@ -738,7 +738,10 @@ __device__ __forceinline__ void s16_wait5(int n, u32x4& a, u32x4& b0, u32x4& b1,
 //   channels are 8 x 4 tiles of 16 x 16 (4 accumulation registers each: register r of lane l = pixel 4*(l>>4) + r, channel l & 15).
 //   The taps 0..7 of a chunk make 4 pairs; tap 8 of an even chunk shares its MFMA with tap 8 of the odd chunk behind it (k-groups
 //   0,1 read stage A, k-groups 2,3 stage B), so no MFMA runs half empty: two chunks = 18 half-units of 16 MFMAs.
-template <bool POOL>
+// TRAIN = the forms a training step needs on top of the plain forward: Dropout2d scale before the ReLU (dropmask), the ReLU gate of
+// a dgrad launch (gate), zero-interleaved input rows (dil_h: dgrad of a stride-(2,1) layer), arg-max codes of the fused max-pool
+// (pool_code). A template flag, so that the inference instantiations keep their register allocation (256 VGPRs, at the limit).
+template <bool POOL, bool TRAIN>
 __global__ __launch_bounds__(512) void conv3x3_bf16_s16_kernel(ConvBfArgs p) {
     constexpr int TN = 128, NW = 8, TH = 8, NTHREADS = 512;
     constexpr int IH = TH + 2;
@@ -781,7 +784,8 @@ __global__ __launch_bounds__(512) void conv3x3_bf16_s16_kernel(ConvBfArgs p) {
     const int nkc = p.Cin >> 4;
 
     // ---- staging: as in the kernel above (input tile through registers, weight slab by LDS-DMA)
-    const size_t img_elems = (size_t)p.H * p.W * p.Cin;
+    const int Hp = (TRAIN && p.dil_h) ? (p.H - 1) / 2 + 1 : p.H;      // physical rows of the input
+    const size_t img_elems = (size_t)Hp * p.W * p.Cin;
     __amdgpu_buffer_rsrc_t in_rs =
         __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)b * img_elems), 0, (unsigned)(img_elems * 2), 0x00020000);
     const i32x4 w_rd = raw_rsrc(reinterpret_cast<const u32x4*>(p.wpk) + (size_t)ntile * nkc * W_S, (unsigned)nkc * W_S * 16u);
@@ -796,9 +800,13 @@ __global__ __launch_bounds__(512) void conv3x3_bf16_s16_kernel(ConvBfArgs p) {
         const int q = s / (IH * IW);
         const int pix = s - q * (IH * IW);
         const int r = pix / IW, c = pix - r * IW;
-        const int gr = oy0 - 1 + r;
+        int gr = oy0 - 1 + r;
         int gc = ox0 - 1 + c;
         bool ok = s < IN_S && gr >= 0 && gr < p.H;
+        if (TRAIN && p.dil_h) {
+            ok = ok && !(gr & 1);
+            gr >>= 1;
+        }
         if (p.circ) {
             gc %= p.W;
             if (gc < 0) gc += p.W;
@@ -816,9 +824,13 @@ __global__ __launch_bounds__(512) void conv3x3_bf16_s16_kernel(ConvBfArgs p) {
         const int s = tid + i * NTHREADS;
         const int pix = s >> 1, q = s & 1;
         const int r = pix / IW, c = pix - r * IW;
-        const int gr = oy0 - 1 + r;
+        int gr = oy0 - 1 + r;
         int gc = ox0 - 1 + c;
         bool ok = s < IN_S && gr >= 0 && gr < p.H;
+        if (TRAIN && p.dil_h) {
+            ok = ok && !(gr & 1);
+            gr >>= 1;
+        }
         if (p.circ) {
             gc %= p.W;
             if (gc < 0) gc += p.W;
@@ -987,11 +999,15 @@ __global__ __launch_bounds__(512) void conv3x3_bf16_s16_kernel(ConvBfArgs p) {
 
     // ---- epilogue: bias + ReLU (+ 2x2 max-pool) -> wave-private fp32 slab [pixel][64 channels] -> 8 bf16 channels (16 B) per lane
     const int cb = n0 + wn * 64;
-    float bv[4];
+    float bv[4], dm[4] = {1.f, 1.f, 1.f, 1.f};
 #pragma unroll
-    for (int bt = 0; bt < 4; ++bt) bv[bt] = p.bias[cb + 16 * bt + l15];
-    auto fin = [&](float v, int bt) {
+    for (int bt = 0; bt < 4; ++bt) {
+        bv[bt] = p.bias[cb + 16 * bt + l15];
+        if (TRAIN && p.dropmask != nullptr && cb + 16 * bt + l15 < p.Cout) dm[bt] = p.dropmask[(size_t)b * p.Cout + cb + 16 * bt + l15];
+    }
+    auto fin = [&](float v, int bt) {      // conv + bias -> Dropout2d scale -> ReLU
         v += bv[bt];
+        if (TRAIN) v *= dm[bt];
         if (p.relu) v = fmaxf(v, 0.f);
         return v;
     };
@@ -1013,8 +1029,17 @@ __global__ __launch_bounds__(512) void conv3x3_bf16_s16_kernel(ConvBfArgs p) {
                 o[4 + e] = (__bf16)v1[e];
             }
             const int xx = xbase + m;
-            if (yy < Hy && xx < Wy && nbase < p.Cout)
-                __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p.y) + (((size_t)b * Hy + yy) * Wy + xx) * p.Cout + nbase));
+            if (yy < Hy && xx < Wy && nbase < p.Cout) {
+                const size_t off = (((size_t)b * Hy + yy) * Wy + xx) * p.Cout + nbase;
+                if (TRAIN && p.gate != nullptr) {      // ReLU backward of a dgrad launch: zero where the forward's output was <= 0
+                    typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+                    const u16x8 gt = *reinterpret_cast<const u16x8*>(p.gate + off);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if ((gt[e] & 0x7fffu) == 0 || (gt[e] & 0x8000u)) o[e] = (__bf16)0.f;
+                }
+                __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p.y) + off));
+            }
         }
     };
     if (!POOL) {
@@ -1038,8 +1063,16 @@ __global__ __launch_bounds__(512) void conv3x3_bf16_s16_kernel(ConvBfArgs p) {
             for (int bt = 0; bt < 4; ++bt)
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
-                    const float m4 = fmaxf(fmaxf(acc[a][bt][2 * e], acc[a][bt][2 * e + 1]), fmaxf(acc[a + 4][bt][2 * e], acc[a + 4][bt][2 * e + 1]));
+                    const float a00 = acc[a][bt][2 * e], a01 = acc[a][bt][2 * e + 1], a10 = acc[a + 4][bt][2 * e], a11 = acc[a + 4][bt][2 * e + 1];
+                    const float m4 = fmaxf(fmaxf(a00, a01), fmaxf(a10, a11));
                     slab[(8 * a + 2 * kg + e) * SLAB_P + 16 * bt + l15] = fin(m4, bt);
+                    if (TRAIN && p.pool_code != nullptr) {
+                        // first position attaining the max, scan order (0,0),(0,1),(1,0),(1,1) as torch's max_pool2d
+                        const int yy = (oy0 >> 1) + wm, xx = (ox0 >> 1) + 8 * a + 2 * kg + e, ch = cb + 16 * bt + l15;
+                        if (yy < Hy && xx < Wy && ch < p.Cout)
+                            p.pool_code[(((size_t)b * Hy + yy) * Wy + xx) * p.Cout + ch] =
+                                (unsigned char)((a00 == m4) ? 0 : (a01 == m4) ? 1 : (a10 == m4) ? 2 : 3);
+                    }
                 }
         flush((oy0 >> 1) + wm, ox0 >> 1);
     }
@@ -1141,7 +1174,7 @@ int bf16_mfma16() {
     return g_bf16_mfma16;
 }
 
-template <bool POOL>
+template <bool POOL, bool TRAIN>
 int launch_bf_s16(ConvBfArgs a, hipStream_t st) {
     a.tiles_y = cdiv(a.Ho, 8);
     const long long sp_total = (long long)a.B * a.tiles_x * a.tiles_y;
@@ -1153,9 +1186,9 @@ int launch_bf_s16(ConvBfArgs a, hipStream_t st) {
         return WITW_ERR_INVALID;
     }
     a.sp_total = (int)sp_total;
-    hipLaunchKernelGGL((conv3x3_bf16_s16_kernel<POOL>), dim3((unsigned)grid), dim3(512), 0, st, a);
+    hipLaunchKernelGGL((conv3x3_bf16_s16_kernel<POOL, TRAIN>), dim3((unsigned)grid), dim3(512), 0, st, a);
     WITW_CHECK_LAUNCH("conv3x3_bf16_s16");
-    witw_note_variant("conv3x3_bf16_s16_kernel<%s>", POOL ? "true" : "false");
+    witw_note_variant("conv3x3_bf16_s16_kernel<%s,%s>", POOL ? "true" : "false", TRAIN ? "true" : "false");
     return WITW_OK;
 }
 
@@ -1164,9 +1197,10 @@ int launch_bf(const ConvBfArgs& a, hipStream_t st) {
     const long long big = (long long)cdiv(a.Cout, TN) * a.B * a.tiles_x * cdiv(a.Ho, 8);
     if constexpr (TN == 128 && SH == 1) {
         // the 16x16x32 form: plain inference forward (bf16 NHWC out) of layers large enough for the 8-wave tile
-        if (bf16_mfma16() && (a.Ho % 8) == 0 && big >= 512 && !a.gate && !a.dropmask && !a.pool_code && !a.out_nchw_f32 && !a.dil_h &&
-            (a.Cout & 7) == 0 && (a.Cin & 31) == 0)
-            return launch_bf_s16<POOL>(a, st);
+        if (bf16_mfma16() && (a.Ho % 8) == 0 && big >= 512 && !a.out_nchw_f32 && (a.Cout & 7) == 0 && (a.Cin & 31) == 0) {
+            if (a.gate || a.dropmask || a.pool_code || a.dil_h) return launch_bf_s16<POOL, true>(a, st);      // training forms
+            return launch_bf_s16<POOL, false>(a, st);
+        }
     }
     if ((a.Ho % 8) == 0 && big >= 512) return launch_bf_nw<TN, SH, POOL, 8>(a, st);
     return launch_bf_nw<TN, SH, POOL, 4>(a, st);
