@@ -226,7 +226,9 @@ def test_bf16_s16_training_forms_vs_oracle():
     assert ops.last_kernel_variant() == 'conv3x3_bf16_s16_kernel<false,true>', ops.last_kernel_variant()
     ref = torch.relu(O.conv3x3(x[sel], w.bfloat16().float(), b, 1, True) * scale[sel][:, :, None, None])
     _assert_bf16_ulp(y[sel].float().cpu().permute(0, 3, 1, 2), ref)
-    # (2) dgrad form: transposed + rotated filter, gate
+    # (2) dgrad form: transposed + rotated filter, gate (a 512 -> 512 layer: 4 channel tiles x 64 images x 2 row tiles = 512 workgroups)
+    cin = 512
+    _x, w, _b = _layer(42, 1, 1, 1, cin, cout)
     dz = torch.from_numpy(g.standard_normal((B, cout, H, W), dtype=np.float32)).bfloat16().float()
     gate = torch.from_numpy(g.standard_normal((B, cin, H, W), dtype=np.float32)).bfloat16()
     pkt = ops.PackedConvBf16(w.to(dev), None, transpose_flip=True)
