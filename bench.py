@@ -434,10 +434,16 @@ def step_line(a, rank, world, device, cvig_fov, ops):
         out['config5_retrieval_direct'] = retrieval_block(device, cvig_fov, ops, 125000, 1024, 10, 'direct')
         torch.cuda.empty_cache()
         from witw_amd import e2e
-        e = e2e.bench(a, device, n_pairs=2048)
-        out['e2e_data_path'] = {k: e[k] for k in ('metric', 'value', 'unit', 'steady_state_pairs_per_s', 'pipeline_fill_s', 'stage_pairs_per_s',
-                                                  'limiting_stage', 'overlap_efficiency_steady_state')}
+        keys = ('metric', 'value', 'unit', 'dtype', 'jpeg_decode', 'staging', 'steady_state_pairs_per_s', 'pipeline_fill_s', 'stage_pairs_per_s',
+                'limiting_stage', 'overlap_efficiency_steady_state')
+        e = e2e.bench(a, device, n_pairs=2048)                       # the headline's fp32 encoders: the GPU is the limiting stage
+        out['e2e_data_path'] = {k: e[k] for k in keys}
         out['e2e_data_path']['workload'] = e['config']['workload']
+        torch.cuda.empty_cache()
+        # the bf16 encoders (configs[3] arithmetic) need 8x the images per second: JPEG back end on the GPU, page-locked ring
+        e = e2e.bench(a, device, n_pairs=8192, workers=16, precision='bf16')
+        out['e2e_data_path_bf16'] = {k: e[k] for k in keys}
+        out['e2e_data_path_bf16']['workload'] = e['config']['workload']
         torch.cuda.empty_cache()
     if headline and rank == 0 and not a.no_cpu_baseline:      # last: nothing on the GPU waits behind the CPU leg
         out['cpu_baseline'] = cpu_baseline(a, *cpu_args)
