@@ -377,6 +377,12 @@ int witw_bilinear_gather(const float* x, const int* taps, const float* wts, floa
  * fp32 [B][3][2]: per image the inverse rotation matrix divided by (W/2, H/2), row k = (x, y, 1) coefficient. */
 int witw_rotate_nearest(const float* x, const float* theta, float* y, int B, int C, int H, int W, void* stream);
 
+/* Conv2d(k=4, s=2) filter [co][ci][4][4] <-> the 3x3 filter over space-to-depth(2) channels [co][cpad][3][3] the taps4 kernels take
+ * (model/cvig_baseline.py:236-252; tap row 0 / column 0 zero, channel (dy*2+dx)*ci + c); the second call is the inverse gather for
+ * weight gradients. */
+int witw_conv4x4_to_k3(const float* w, float* k3, int co, int ci, int cpad, void* stream);
+int witw_k3_to_conv4x4(const float* k3, float* w, int co, int ci, int cpad, void* stream);
+
 /* ---- JPEG back end on the device: what libjpeg does behind entropy decoding for the images the reference reads
  *      (skimage.io.imread -> PIL -> libjpeg-turbo, model/cvig_fov.py:88-89, in the DataLoader workers of :402). The entropy
  *      decoding stays on the host (witw_amd/csrc_host/jpeg_coef.cpp -> libwitw_jpeg.so: witw_jpeg_info, witw_jpeg_decode_coef).

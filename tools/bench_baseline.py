@@ -17,7 +17,8 @@ def main():
     xo = torch.from_numpy(synth.images_u8(1, 2, (B, 3, 512, 512))).to(dev)
     se, oe = cb.SurfaceEncoder().to(dev), cb.OverheadEncoder().to(dev)
     flops = 2 * (6.64e9 + 7.17e9) * B          # MACs per image
-    for train in (False, True):
+    modes = {'eval': (False,), 'train': (True,)}.get(sys.argv[2] if len(sys.argv) > 2 else '', (False, True))
+    for train in modes:
         se.train(train)
         oe.train(train)
         opt = cvig_fov.Adam(list(se.parameters()) + list(oe.parameters()))

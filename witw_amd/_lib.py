@@ -111,6 +111,8 @@ SIGNATURES = {
     'witw_polar_transform': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]),
     'witw_polar_from_raw': (c_int, [c_void_p, c_void_p, c_int, c_void_p] + [c_int] * 7 + [c_void_p] * 3 + [c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     'witw_bilinear_gather': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_longlong, c_longlong, c_void_p]),
+    'witw_conv4x4_to_k3': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    'witw_k3_to_conv4x4': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'witw_jpeg_idct': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_longlong, c_void_p, c_void_p]),
     'witw_jpeg_to_rgb': (c_int, [c_void_p, c_void_p, c_int, c_longlong, c_void_p, c_void_p]),
     'witw_rotate_nearest': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),

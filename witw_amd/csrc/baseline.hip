@@ -278,17 +278,38 @@ __global__ __launch_bounds__(256) void channel_sums_rows_kernel(const float* __r
 
 // BatchNorm2d training statistics: mean / biased var -> scale = gamma*invstd, shift = beta - mean*scale, and the
 // running-stat update running = (1-m)*running + m*stat (unbiased variance), torch semantics.
-__global__ void bn_stats_finish_kernel(const float* __restrict__ part, int nparts, int C, float n, const float* __restrict__ gamma,
+// Second stage of the per-channel sums: part [nparts][2][C] -> two sums per channel. A workgroup takes 32 channels; its 8 groups of 32
+// lanes each add every 8th partial row (loads of a group: 128 contiguous bytes), then the 8 group sums are added in a fixed order
+// through LDS -- bit-reproducible, and 8x fewer dependent loads per thread than one thread per channel (the stage took 157 us of
+// pure load latency per call at 1024 partial rows).
+constexpr int BNF_CH = 32, BNF_LANES = 8;
+__device__ __forceinline__ bool bn_finish_sums(const float* __restrict__ part, int nparts, int C, int& c, float& s0, float& s1) {
+    __shared__ float red[2][BNF_LANES][BNF_CH];
+    const int cl = threadIdx.x % BNF_CH, pl = threadIdx.x / BNF_CH;
+    c = blockIdx.x * BNF_CH + cl;
+    float a0 = 0.f, a1 = 0.f;
+    if (c < C)
+        for (int k = pl; k < nparts; k += BNF_LANES) {
+            a0 += part[((size_t)k * 2 + 0) * C + c];
+            a1 += part[((size_t)k * 2 + 1) * C + c];
+        }
+    red[0][pl][cl] = a0;
+    red[1][pl][cl] = a1;
+    __syncthreads();
+    if (pl != 0 || c >= C) return false;
+    s0 = 0.f; s1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < BNF_LANES; ++j) { s0 += red[0][j][cl]; s1 += red[1][j][cl]; }
+    return true;
+}
+
+__global__ __launch_bounds__(BNF_CH * BNF_LANES) void bn_stats_finish_kernel(const float* __restrict__ part, int nparts, int C, float n, const float* __restrict__ gamma,
                                        const float* __restrict__ beta, float eps, float momentum, float* __restrict__ mean,
                                        float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift,
                                        float* __restrict__ running_mean, float* __restrict__ running_var) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float s0 = 0.f, s1 = 0.f;
-    for (int k = 0; k < nparts; ++k) {
-        s0 += part[((size_t)k * 2 + 0) * C + c];
-        s1 += part[((size_t)k * 2 + 1) * C + c];
-    }
+    int c;
+    float s0, s1;
+    if (!bn_finish_sums(part, nparts, C, c, s0, s1)) return;
     const float mu = s0 / n;
     const float var = fmaxf(s1 / n - mu * mu, 0.f);
     const float is = 1.f / sqrtf(var + eps);
@@ -303,15 +324,11 @@ __global__ void bn_stats_finish_kernel(const float* __restrict__ part, int npart
 }
 
 // sums[0][c] = sum dy, sums[1][c] = sum dy*xhat  (+ writes dgamma = sums[1], dbeta = sums[0])
-__global__ void bn_bwd_finish_kernel(const float* __restrict__ part, int nparts, int C, float* __restrict__ sums,
+__global__ __launch_bounds__(BNF_CH * BNF_LANES) void bn_bwd_finish_kernel(const float* __restrict__ part, int nparts, int C, float* __restrict__ sums,
                                      float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float s0 = 0.f, s1 = 0.f;
-    for (int k = 0; k < nparts; ++k) {
-        s0 += part[((size_t)k * 2 + 0) * C + c];
-        s1 += part[((size_t)k * 2 + 1) * C + c];
-    }
+    int c;
+    float s0, s1;
+    if (!bn_finish_sums(part, nparts, C, c, s0, s1)) return;
     sums[c] = s0;
     sums[C + c] = s1;
     dbeta[c] = s0;
@@ -457,6 +474,38 @@ __global__ __launch_bounds__(256) void sqdist_bwd_kernel(const float* __restrict
     }
 }
 
+
+// Conv2d(k=4, s=2) filter <-> the 3x3 filter over space-to-depth(2) channels the MFMA conv kernels take
+// (model/cvig_baseline.py:236-252: channel (dy*2+dx)*ci + c of the space-to-depth image is pixel (2y+dy, 2x+dx), so tap (a+1, b+1),
+// a, b in {0,1}, holds w[co][c][2a+dy][2b+dx]; tap row 0 and tap column 0 are zero). One launch each way instead of a zero fill and
+// four strided copies per layer and step.
+__global__ void conv4x4_to_k3_kernel(const float* __restrict__ w, float* __restrict__ k3, int ci, int cpad, size_t total) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int tap = idx % 9;
+    size_t t = idx / 9;
+    const int ch = t % cpad;
+    const size_t co = t / cpad;
+    const int kh = tap / 3, kw = tap % 3;
+    float v = 0.f;
+    if (kh >= 1 && kw >= 1 && ch < 4 * ci) {
+        const int d = ch / ci, c = ch - d * ci;
+        v = w[((co * ci + c) * 4 + 2 * (kh - 1) + (d >> 1)) * 4 + 2 * (kw - 1) + (d & 1)];
+    }
+    k3[idx] = v;
+}
+
+__global__ void k3_to_conv4x4_kernel(const float* __restrict__ k3, float* __restrict__ w, int ci, int cpad, size_t total) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int kx = idx & 3, ky = (idx >> 2) & 3;
+    const size_t t = idx >> 4;
+    const int c = t % ci;
+    const size_t co = t / ci;
+    const int ch = ((ky & 1) * 2 + (kx & 1)) * ci + c;
+    w[idx] = k3[((co * cpad + ch) * 3 + (ky >> 1) + 1) * 3 + (kx >> 1) + 1];
+}
+
 }  // namespace
 
 extern "C" {
@@ -586,7 +635,7 @@ int witw_bn_train_stats(const float* a, int B, int Hp, int Wp, int H, int W, int
     hipStream_t st = (hipStream_t)stream;
     const size_t npix = (size_t)B * H * W;
     const int nparts = bl_launch_sums(a, nullptr, nullptr, nullptr, workspace, B, Hp, Wp, H, W, C, st);
-    hipLaunchKernelGGL(bn_stats_finish_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, workspace, nparts, C, (float)npix, gamma, beta,
+    hipLaunchKernelGGL(bn_stats_finish_kernel, dim3(cdiv(C, BNF_CH)), dim3(BNF_CH * BNF_LANES), 0, st, workspace, nparts, C, (float)npix, gamma, beta,
                        eps, momentum, mean, invstd, scale, shift, running_mean, running_var);
     WITW_CHECK_LAUNCH("bn_train_stats");
     return WITW_OK;
@@ -602,7 +651,7 @@ int witw_bn_lrelu_bwd(const float* a, const float* dy, float* dz, float* dgamma,
     const size_t npix = (size_t)B * H * W;
     const int nparts = bl_launch_sums(a, dy, mean, invstd, workspace, B, Hp, Wp, H, W, C, st);
     float* sums = workspace + (size_t)nparts * 2 * C;
-    hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, workspace, nparts, C, sums, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3(cdiv(C, BNF_CH)), dim3(BNF_CH * BNF_LANES), 0, st, workspace, nparts, C, sums, dgamma, dbeta);
     const size_t total = (size_t)B * Hp * Wp * C;
     hipLaunchKernelGGL(bn_lrelu_bwd_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a, dy, dz, mean, invstd,
                        gamma, sums, Hp, Wp, H, W, C, (float)npix, slope, total);
@@ -651,6 +700,24 @@ int witw_exhaustive_triplet_loss_bwd(const float* e1, const float* e2, const flo
     hipLaunchKernelGGL(sqdist_bwd_kernel, dim3(B), dim3(256), 0, st, e1, e2, workspace, de1, B, n, 0);
     hipLaunchKernelGGL(sqdist_bwd_kernel, dim3(B), dim3(256), 0, st, e1, e2, workspace, de2, B, n, 1);
     WITW_CHECK_LAUNCH("exhaustive_triplet_loss_bwd");
+    return WITW_OK;
+}
+
+// w [co][ci][4][4] (torch layout of Conv2d(ci, co, 4, 2)) -> k3 [co][cpad][3][3], cpad >= 4*ci (extra channels zero)
+int witw_conv4x4_to_k3(const float* w, float* k3, int co, int ci, int cpad, void* stream) {
+    WITW_CHECK_ARG(w && k3 && co > 0 && ci > 0 && cpad >= 4 * ci, "conv4x4_to_k3: bad arguments");
+    const size_t total = (size_t)co * cpad * 9;
+    hipLaunchKernelGGL(conv4x4_to_k3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, k3, ci, cpad, total);
+    WITW_CHECK_LAUNCH("conv4x4_to_k3");
+    return WITW_OK;
+}
+
+// the inverse gather (a weight gradient in the k3 layout -> the Conv2d parameter's layout)
+int witw_k3_to_conv4x4(const float* k3, float* w, int co, int ci, int cpad, void* stream) {
+    WITW_CHECK_ARG(w && k3 && co > 0 && ci > 0 && cpad >= 4 * ci, "k3_to_conv4x4: bad arguments");
+    const size_t total = (size_t)co * ci * 16;
+    hipLaunchKernelGGL(k3_to_conv4x4_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, k3, w, ci, cpad, total);
+    WITW_CHECK_LAUNCH("k3_to_conv4x4");
     return WITW_OK;
 }
 

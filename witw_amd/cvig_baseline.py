@@ -162,35 +162,48 @@ class SurfaceEncoder(nn.Module):
             setattr(self, 'bn%d' % i, bn)
         self._packed = {}
 
-    def _layer(self, i):
+    def _layer(self, i, fold=True):
+        """-> (packed 2x2-tap filter, eval-mode BatchNorm scale, shift, padded input channels). fold=False (the training forward:
+        batch statistics) skips the scale / shift of the running statistics."""
         conv, bn = getattr(self, 'conv%d' % i), getattr(self, 'bn%d' % i)
         # torch's version counters see in-place torch ops; the C-ABI Adam bumps _witw_version instead
-        key = tuple(t._version for t in (conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var)) + \
-            tuple(getattr(t, '_witw_version', 0) for t in (conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var)) + \
+        wkey = tuple(t._version for t in (conv.weight, conv.bias)) + tuple(getattr(t, '_witw_version', 0) for t in (conv.weight, conv.bias)) + \
             (conv.weight.data_ptr(),)
         hit = self._packed.get(i)
-        if hit is None or hit[0] != key:
+        if hit is None or hit[0] != wkey:
             with torch.no_grad():
-                w = conv.weight                                     # [co, ci, 4, 4]
-                co, ci = w.shape[:2]
+                co, ci = conv.weight.shape[:2]
                 cpad = (4 * ci + 7) // 8 * 8
-                # 4x4/s2 filter -> 3x3 filter over space-to-depth channels (dy*2+dx)*ci+c; tap (kh,kw) in
-                # {1,2}^2 holds W[:, :, 2(kh-1)+dy, 2(kw-1)+dx], row/column 0 of taps stay zero
-                k3 = torch.zeros((co, cpad, 3, 3), dtype=torch.float32, device=w.device)
-                for a in range(2):
-                    for b in range(2):
-                        blk = w[:, :, 2 * a:2 * a + 2, 2 * b:2 * b + 2]                 # [co,ci,dy,dx]
-                        k3[:, :4 * ci, a + 1, b + 1] = blk.permute(0, 2, 3, 1).reshape(co, 4 * ci)
-                packed = ops.PackedConv(k3, conv.bias, taps4=True)      # only the 2x2 live taps are packed and multiplied
+                # 4x4/s2 filter -> 3x3 filter over space-to-depth channels (dy*2+dx)*ci+c; tap (kh,kw) in {1,2}^2 holds
+                # W[:, :, 2(kh-1)+dy, 2(kw-1)+dx], row / column 0 of the taps stay zero (witw_conv4x4_to_k3: one launch)
+                k3 = ops.conv4x4_to_k3(conv.weight, cpad)
+                packed = ops.PackedConv(k3, conv.bias, taps4=True, reuse=hit[1] if hit else None)      # only the 2x2 live taps
+            hit = [wkey, packed, cpad, k3, None]
+            self._packed[i] = hit
+        if not fold:
+            return hit[1], None, None, hit[2]
+        bkey = tuple(t._version for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var)) + \
+            tuple(getattr(t, '_witw_version', 0) for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var))
+        if hit[4] is None or hit[4][0] != bkey:
+            with torch.no_grad():
                 scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)               # eval-mode BatchNorm2d
                 shift = bn.bias - bn.running_mean * scale
-            hit = (key, packed, scale.contiguous(), shift.contiguous(), cpad, k3)
-            self._packed[i] = hit
-        return hit[1:5]
+            hit[4] = (bkey, scale.contiguous(), shift.contiguous())
+        return hit[1], hit[4][1], hit[4][2], hit[2]
 
     def _layer_k3(self, i):
-        self._layer(i)
-        return self._packed[i][5]
+        self._layer(i, fold=False)
+        return self._packed[i][3]
+
+    def _layer_t(self, i):
+        """the data-gradient filter of block i (transposed, taps rotated), re-packed in place when the weights have changed"""
+        self._layer(i, fold=False)
+        wkey, k3 = self._packed[i][0], self._packed[i][3]
+        hit = self._packed.get(('t', i))
+        if hit is None or hit[0] != wkey:
+            hit = (wkey, ops.PackedConv(k3, None, transpose_flip=True, taps4=True, reuse=hit[1] if hit else None))
+            self._packed[('t', i)] = hit
+        return hit[1]
 
     def train_params(self):
         out = []
@@ -239,6 +252,30 @@ class OverheadEncoder(SurfaceEncoder):
     pass
 
 
+def _mosaic_g(x):
+    """images per mosaic side for an NHWC batch of small maps: as many cells as fit a 16 x 16 tile"""
+    return max(1, min(16 // x.shape[1], 16 // x.shape[2]))
+
+
+def _to_mosaic(x, g):
+    """[B,h,w,C] -> [ceil(B/g^2), g*h, g*w, C]: g x g images side by side (missing images zero); pure data movement on maps of at
+    most 16 x 16 (the layout ops.space_to_depth2_mosaic writes directly on the eval path)"""
+    if g == 1:
+        return x
+    B, h, w, C = x.shape
+    Bm = (B + g * g - 1) // (g * g)
+    if Bm * g * g != B:
+        x = torch.cat((x, x.new_zeros((Bm * g * g - B, h, w, C))), 0)
+    return x.reshape(Bm, g, g, h, w, C).permute(0, 1, 3, 2, 4, 5).reshape(Bm, g * h, g * w, C).contiguous()
+
+
+def _pad_hw(y, H, W):
+    """[B,vh,vw,C] -> [B,H,W,C], zeros outside (the layout conv3x3_fwd gives an activation: its input's spatial size)"""
+    if y.shape[1] == H and y.shape[2] == W:
+        return y
+    return torch.nn.functional.pad(y, (0, 0, 0, W - y.shape[2], 0, H - y.shape[1]))
+
+
 class _BaselineEncoderFn(torch.autograd.Function):
     """Train-mode forward (BatchNorm2d batch statistics, running-stat update) and backward of one encoder call."""
 
@@ -246,15 +283,19 @@ class _BaselineEncoderFn(torch.autograd.Function):
     def forward(ctx, x, enc, *params):
         B, _c, H, W = x.shape
         with torch.no_grad():
-            h = ops.space_to_depth2(x.contiguous(), in_nchw=True, normalize=True, cpad=enc._layer(1)[3])
+            h = ops.space_to_depth2(x.contiguous(), in_nchw=True, normalize=True, cpad=enc._layer(1, fold=False)[3])
             g = torch.empty((B, 1536), dtype=torch.float32, device=x.device)
             vh, vw = H, W
             saved = []
             for i in range(1, 8):
-                packed, _es, _et, _cp = enc._layer(i)
+                packed, _es, _et, _cp = enc._layer(i, fold=False)
                 bn = getattr(enc, 'bn%d' % i)
                 vh, vw = (vh - 4) // 2 + 1, (vw - 4) // 2 + 1
-                a = ops.conv3x3_fwd(h, packed, relu=False, lrelu_slope=0.2)                  # LeakyReLU(conv), :267-275
+                if i >= 5:      # maps of 16 x 16 and below: split-K over a mosaic of g x g images, as the eval path (15 of 16 lanes of
+                    gm = _mosaic_g(h)                     # the narrow-geometry kernel idle otherwise); zero-padded to the input's size
+                    a = _pad_hw(ops.conv_taps4_splitk(_to_mosaic(h, gm), packed, B, gm, (vh, vw), lrelu_slope=0.2), h.shape[1], h.shape[2])
+                else:
+                    a = ops.conv3x3_fwd(h, packed, relu=False, lrelu_slope=0.2)              # LeakyReLU(conv), :267-275
                 mean, invstd, scale, shift = ops.bn_train_stats(a, (vh, vw), bn.weight, bn.bias, bn.running_mean,
                                                                 bn.running_var, bn.eps, bn.momentum)
                 bn.num_batches_tracked += 1
@@ -264,7 +305,7 @@ class _BaselineEncoderFn(torch.autograd.Function):
                 if i >= 5:
                     ops.gem_pool(a, (vh, vw), g, 512 * (i - 5), enc.p, scale, shift)
                 if i < 7:
-                    h = ops.space_to_depth2(a, valid_hw=(vh, vw), cpad=enc._layer(i + 1)[3], scale=scale, shift=shift)
+                    h = ops.space_to_depth2(a, valid_hw=(vh, vw), cpad=enc._layer(i + 1, fold=False)[3], scale=scale, shift=shift)
             f = ops.embed_normalize_(g.clone())
         ctx.enc, ctx.saved, ctx.g = enc, saved, g
         ctx.override = getattr(enc, '_bwd_override', {})
@@ -290,15 +331,16 @@ class _BaselineEncoderFn(torch.autograd.Function):
             dz, dgamma, dbeta = ops.bn_lrelu_bwd(ctx.override.get(i, a), dy, valid, mean, invstd, bn.weight, 0.2)
             k3 = enc._layer_k3(i)
             dk3, dbias = ops.conv3x3_wgrad(h, dz, k3.shape[1], stride_h=1, circular=False, taps4=True)
-            co, ci = conv.weight.shape[:2]
-            dw = torch.empty_like(conv.weight)
-            for ta in range(2):
-                for tb in range(2):     # tap (ta+1, tb+1) of the 3x3 filter holds W[:, :, 2ta+dy, 2tb+dx] as channel (dy,dx,c)
-                    blk = dk3[:, :4 * ci, ta + 1, tb + 1].reshape(co, 2, 2, ci).permute(0, 3, 1, 2)
-                    dw[:, :, 2 * ta:2 * ta + 2, 2 * tb:2 * tb + 2] = blk
+            # tap (ta+1, tb+1) of the 3x3 filter holds W[:, :, 2ta+dy, 2tb+dx] as channel (dy,dx,c): gathered back in one launch
+            dw = ops.k3_to_conv4x4(dk3, conv.weight.shape[1])
             grads[4 * (i - 1):4 * i] = [dw, dbias, dgamma, dbeta]
             if i > 1:
-                dx_s2d = ops.conv3x3_fwd(dz, ops.PackedConv(k3, None, transpose_flip=True, taps4=True), relu=False)
+                pk_t = enc._layer_t(i)
+                if i >= 5:      # the same small maps in the data gradient: mosaic + split-K (dz is zero outside its valid region,
+                    gm = _mosaic_g(dz)                    # so the last row / column of every cell is the zero border a window may touch)
+                    dx_s2d = ops.conv_taps4_splitk(_to_mosaic(dz, gm), pk_t, dz.shape[0], gm, (dz.shape[1], dz.shape[2]))
+                else:
+                    dx_s2d = ops.conv3x3_fwd(dz, pk_t, relu=False)
         ctx.saved = ctx.g = None
         return (None, None) + tuple(grads)
 

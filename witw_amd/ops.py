@@ -1314,6 +1314,24 @@ def conv3x3_wgrad_f16x3(x_split, dz_split, cin_real, stride_h=1, circular=False,
     return dw, db
 
 
+def conv4x4_to_k3(w, cpad):
+    """Conv2d(ci, co, 4, 2) weight [co,ci,4,4] -> the 3x3 filter over space-to-depth(2) channels [co,cpad,3,3] (one launch)."""
+    w = _dev_f32(w.detach(), 'weight')
+    co, ci = w.shape[:2]
+    k3 = torch.empty((co, cpad, 3, 3), dtype=torch.float32, device=w.device)
+    _lib.check(_lib.load().witw_conv4x4_to_k3(w.data_ptr(), k3.data_ptr(), co, ci, cpad, _stream()), 'witw_conv4x4_to_k3')
+    return k3
+
+
+def k3_to_conv4x4(dk3, ci):
+    """the inverse gather for a weight gradient: [co,cpad,3,3] -> [co,ci,4,4]"""
+    dk3 = _dev_f32(dk3, 'dk3')
+    co, cpad = dk3.shape[:2]
+    dw = torch.empty((co, ci, 4, 4), dtype=torch.float32, device=dk3.device)
+    _lib.check(_lib.load().witw_k3_to_conv4x4(dk3.data_ptr(), dw.data_ptr(), co, ci, cpad, _stream()), 'witw_k3_to_conv4x4')
+    return dw
+
+
 def bn_train_stats(a, valid_hw, gamma, beta, running_mean=None, running_var=None, eps=1e-5, momentum=0.1):
     """Batch statistics of BatchNorm2d over the valid region of a NHWC tensor -> (mean, invstd, scale, shift)."""
     lib = _lib.load()
