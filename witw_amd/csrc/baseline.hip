@@ -276,8 +276,6 @@ __global__ __launch_bounds__(256) void channel_sums_rows_kernel(const float* __r
     }
 }
 
-// BatchNorm2d training statistics: mean / biased var -> scale = gamma*invstd, shift = beta - mean*scale, and the
-// running-stat update running = (1-m)*running + m*stat (unbiased variance), torch semantics.
 // Second stage of the per-channel sums: part [nparts][2][C] -> two sums per channel. A workgroup takes 32 channels; its 8 groups of 32
 // lanes each add every 8th partial row (loads of a group: 128 contiguous bytes), then the 8 group sums are added in a fixed order
 // through LDS -- bit-reproducible, and 8x fewer dependent loads per thread than one thread per channel (the stage took 157 us of
@@ -303,6 +301,8 @@ __device__ __forceinline__ bool bn_finish_sums(const float* __restrict__ part, i
     return true;
 }
 
+// BatchNorm2d training statistics: mean / biased var -> scale = gamma*invstd, shift = beta - mean*scale, and the
+// running-stat update running = (1-m)*running + m*stat (unbiased variance), torch semantics.
 __global__ __launch_bounds__(BNF_CH * BNF_LANES) void bn_stats_finish_kernel(const float* __restrict__ part, int nparts, int C, float n, const float* __restrict__ gamma,
                                        const float* __restrict__ beta, float eps, float momentum, float* __restrict__ mean,
                                        float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift,
