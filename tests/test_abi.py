@@ -101,3 +101,24 @@ def test_product_refuses_cpu_tensors():
         ops.conv3x3_wgrad_bf16(torch.zeros(8, 4, 4, 16, dtype=torch.bfloat16), torch.zeros(8, 4, 4, 16, dtype=torch.bfloat16), 16)
     with pytest.raises(_lib.WitwError):
         ops.nhwc_bf16_to_octet(torch.zeros(8, 4, 4, 16, dtype=torch.bfloat16))
+
+
+def test_s16_register_allocation_guard(tmp_path, monkeypatch):
+    """build.py parses the resource usage hipcc reports for conv3x3_bf16_s16_kernel (hand-issued LDS reads with counted waits: valid
+    only for a register allocation the parity tests have seen) and leaves a marker when it differs from the validated table; the
+    loader then keeps the 32x32x16 kernel."""
+    from witw_amd import build
+    monkeypatch.setattr(build, 'S16_MARKER', str(tmp_path / 's16_unvalidated'))
+    good = ''
+    for inst, (v, sp, sc) in build.S16_VALIDATED.items():
+        good += ('remark: Function Name: _ZN12_GLOBAL__N_123conv3x3_bf16_s16_kernel%sEvNS_10ConvBfArgsE [-Rpass]\n'
+                 'remark:     VGPRs: %d [-R]\nremark:     ScratchSize [bytes/lane]: %d [-R]\nremark:     VGPRs Spill: %d [-R]\n'
+                 'remark: Function Name: other_kernel\nremark:     VGPRs: 7\n' % (inst, v, sc, sp))
+    build._check_s16(good)
+    assert not os.path.exists(build.S16_MARKER)
+    build._check_s16(good.replace('VGPRs Spill: 10', 'VGPRs Spill: 11'))
+    assert 'ILb0ELb0E' in open(build.S16_MARKER).read()
+    build._check_s16(good)
+    assert not os.path.exists(build.S16_MARKER)
+    build._check_s16('')               # a compiler that reports nothing is not a validated one
+    assert os.path.exists(build.S16_MARKER)

@@ -183,8 +183,10 @@ def embed_tiles(overhead_encoder, source, windows, batch_size=64):
     with torch.no_grad():
         for i in range(0, len(windows), batch_size):
             tiles = _cut_tiles(strip, source, windows[i:i + batch_size])
-            x = ops.resize_bilinear(tiles, (Globals.overhead_size, Globals.overhead_size), Globals.img_mean, Globals.img_std)
-            parts.append(overhead_encoder(ops.polar_transform(x, Globals.surface_height_max, Globals.surface_width_max)))
+            # resize + normalise + polar transform in one launch (witw_polar_from_raw: the same bits as the three transforms)
+            polar = ops.polar_from_raw(tiles, mean=Globals.img_mean, std=Globals.img_std, size=Globals.overhead_size,
+                                       h_s=Globals.surface_height_max, w_s=Globals.surface_width_max)
+            parts.append(overhead_encoder(polar))
     return torch.cat(parts, dim=0)
 
 
