@@ -18,6 +18,9 @@ namespace {
 constexpr int MS = 128;        // surfaces per block (4 M-tiles)
 constexpr int SUS = 65;        // LDS row stride of the surface tile (floats)
 constexpr int NT = 256;
+#ifndef NSPLIT_RPC
+#define NSPLIT_RPC 1           // match_kernel_nsplit: embedding rows per LDS stage (1: 33 KB of LDS; 2: 68 KB and half the barriers -- measured 94 against 92 us at 128 x 128)
+#endif
 
 struct MatchArgs {
     const float* ov;     // [Bo,64,64]
@@ -159,13 +162,14 @@ __global__ __launch_bounds__(NT) void match_kernel(MatchArgs p) {
 // wave. The two shift halves of a (surface, overhead) pair meet in the epilogue through LDS: larger score wins, the lower
 // half (smaller shift) on a tie -- the first-index rule of torch.argmax. Every score is the same k-ordered fma chain as in
 // match_kernel (K is not split), so orientation / score / distance carry the same bits.
-template <int WP>      // surface columns per row, zero-padded: 16, 32 or 64 (every k-loop fully unrolled)
+template <int WP, int RPC>      // WP: surface columns per row, zero-padded: 16, 32 or 64 (every k-loop fully unrolled); RPC: rows per LDS stage
 __global__ __launch_bounds__(NT) void match_kernel_nsplit(MatchArgs p) {
     constexpr int MSB = 64;              // surfaces per block
-    constexpr int SU_F = MSB * SUS;
+    constexpr int SUC = RPC * 64 + 1;    // LDS stride of a surface's RPC rows (odd: conflict-free ds_read_b32 down the surfaces)
+    constexpr int SU_F = MSB * SUC;
     constexpr int RPW = MSB / 4;
-    constexpr int OV_F = 128;
-    __shared__ float smem[2 * (SU_F + OV_F)];
+    constexpr int OV_F = RPC * 128;
+    extern __shared__ float smem[];      // 2 stages of SU_F + OV_F floats (68 KB at RPC = 2)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hk = lane >> 5;
@@ -176,10 +180,10 @@ __global__ __launch_bounds__(NT) void match_kernel_nsplit(MatchArgs p) {
     const int wm = wave >> 1;            // surface half: rows [32*wm, 32*wm+32)
     const int wn = wave & 1;             // shift half: shifts [32*wn, 32*wn+32)
 
-    // staging: the rows of the two embeddings travel global -> registers -> LDS, TWO rows ahead of the MFMAs (two register
-    // sets A / B): one row's MFMAs last 0.85 us at one wave per SIMD, less than a global load takes to come back. Buffer loads:
-    // the row offset is a scalar, lanes beyond We and surfaces beyond Bs carry an out-of-range offset and read 0 -- no VALU
-    // work or branch per load.
+    // staging: the rows of the two embeddings travel global -> registers -> LDS, TWO chunks (of RPC rows) ahead of the MFMAs (two
+    // register sets A / B): one row's MFMAs last 0.85 us at one wave per SIMD, less than a global load takes to come back. Buffer
+    // loads: the row offset is a scalar, lanes beyond We and surfaces beyond Bs carry an out-of-range offset and read 0 -- no
+    // VALU work or branch per load.
     constexpr unsigned OOR = 0x80000000u;
     const int rows_here = min(MSB, p.Bs - s0);
     __amdgpu_buffer_rsrc_t su_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.su + (size_t)s0 * 64 * We), 0,
@@ -192,37 +196,50 @@ __global__ __launch_bounds__(NT) void match_kernel_nsplit(MatchArgs p) {
         suoff[i] = (lane < We && row < rows_here) ? ((unsigned)row * 64u * We + lane) * 4u : OOR;
     }
     const unsigned ovoff = (unsigned)lane * 4u;
-    float rsuA[RPW], rsuB[RPW];
-    float rovA, rovB;
-    auto load_A = [&](int r) {
-        const unsigned srow = (unsigned)r * We * 4u;
+    constexpr int NCH = 64 / RPC;        // chunks
+    float rsuA[RPC][RPW], rsuB[RPC][RPW];
+    float rovA[RPC], rovB[RPC];
+    auto load_A = [&](int c) {
 #pragma unroll
-        for (int i = 0; i < RPW; ++i) rsuA[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(su_rs, suoff[i], srow, 0));
-        rovA = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ov_rs, ovoff, (unsigned)r * 256u, 0));
+        for (int rr = 0; rr < RPC; ++rr) {
+            const unsigned srow = (unsigned)(c * RPC + rr) * We * 4u;
+#pragma unroll
+            for (int i = 0; i < RPW; ++i) rsuA[rr][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(su_rs, suoff[i], srow, 0));
+            rovA[rr] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ov_rs, ovoff, (unsigned)(c * RPC + rr) * 256u, 0));
+        }
     };
-    auto load_B = [&](int r) {
-        const unsigned srow = (unsigned)r * We * 4u;
+    auto load_B = [&](int c) {
 #pragma unroll
-        for (int i = 0; i < RPW; ++i) rsuB[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(su_rs, suoff[i], srow, 0));
-        rovB = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ov_rs, ovoff, (unsigned)r * 256u, 0));
+        for (int rr = 0; rr < RPC; ++rr) {
+            const unsigned srow = (unsigned)(c * RPC + rr) * We * 4u;
+#pragma unroll
+            for (int i = 0; i < RPW; ++i) rsuB[rr][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(su_rs, suoff[i], srow, 0));
+            rovB[rr] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ov_rs, ovoff, (unsigned)(c * RPC + rr) * 256u, 0));
+        }
     };
     auto store_A = [&](int buf) {
         float* su_s = smem + buf * (SU_F + OV_F);
         float* ov_s = su_s + SU_F;
-        if (lane < Wp) {
 #pragma unroll
-            for (int i = 0; i < RPW; ++i) su_s[(wave + 4 * i) * SUS + lane] = rsuA[i];
+        for (int rr = 0; rr < RPC; ++rr) {
+            if (lane < Wp) {
+#pragma unroll
+                for (int i = 0; i < RPW; ++i) su_s[(wave + 4 * i) * SUC + rr * 64 + lane] = rsuA[rr][i];
+            }
+            if (wave == 0) { ov_s[rr * 128 + lane] = rovA[rr]; ov_s[rr * 128 + 64 + lane] = rovA[rr]; }
         }
-        if (wave == 0) { ov_s[lane] = rovA; ov_s[64 + lane] = rovA; }
     };
     auto store_B = [&](int buf) {
         float* su_s = smem + buf * (SU_F + OV_F);
         float* ov_s = su_s + SU_F;
-        if (lane < Wp) {
 #pragma unroll
-            for (int i = 0; i < RPW; ++i) su_s[(wave + 4 * i) * SUS + lane] = rsuB[i];
+        for (int rr = 0; rr < RPC; ++rr) {
+            if (lane < Wp) {
+#pragma unroll
+                for (int i = 0; i < RPW; ++i) su_s[(wave + 4 * i) * SUC + rr * 64 + lane] = rsuB[rr][i];
+            }
+            if (wave == 0) { ov_s[rr * 128 + lane] = rovB[rr]; ov_s[rr * 128 + 64 + lane] = rovB[rr]; }
         }
-        if (wave == 0) { ov_s[lane] = rovB; ov_s[64 + lane] = rovB; }
     };
 
     f32x16 acc;
@@ -234,10 +251,11 @@ __global__ __launch_bounds__(NT) void match_kernel_nsplit(MatchArgs p) {
     store_A(0);
     __syncthreads();
 
-    // a row's KS k-steps in four groups; the operands of group g+1 are read (one LDS read pair per MFMA) while group g
-    // multiplies, the row's barrier sits in front of the last group and the first group of the NEXT row is read behind it
-    constexpr int KS = Wp / 2, GS = KS / 4;
-    const int arow = (32 * wm + l31) * SUS + hk;
+    // a chunk's k-steps (row after row: the k-order of the other kernels) in four groups; the operands of group g+1 are read (one
+    // LDS read pair per MFMA) while group g multiplies, the chunk's barrier sits in front of the last group and the first group of
+    // the NEXT chunk is read behind it
+    constexpr int KS = Wp / 2, KSC = RPC * KS, GS = KSC / 4;
+    const int arow = (32 * wm + l31) * SUC + hk;
     const int bcol = 32 * wn + l31 + hk;
     float fa[2][GS], fb[2][GS];
     auto read_group = [&](int set, int stage, int g) {
@@ -245,8 +263,9 @@ __global__ __launch_bounds__(NT) void match_kernel_nsplit(MatchArgs p) {
         const float* ov_s = su_s + SU_F;
 #pragma unroll
         for (int j = 0; j < GS; ++j) {
-            fa[set][j] = su_s[arow + 2 * (GS * g + j)];
-            fb[set][j] = ov_s[bcol + 2 * (GS * g + j)];
+            const int kk = GS * g + j, rr = kk / KS, k = kk - rr * KS;
+            fa[set][j] = su_s[arow + rr * 64 + 2 * k];
+            fb[set][j] = ov_s[bcol + rr * 128 + 2 * k];
         }
     };
     auto mfma_group = [&](int set) {
@@ -255,7 +274,7 @@ __global__ __launch_bounds__(NT) void match_kernel_nsplit(MatchArgs p) {
     };
     // issue order inside a group: GS x (one MFMA, its two LDS reads for the next group), the group's global loads (mask 0x020)
     // or LDS writes (0x200) spread evenly behind the MFMAs
-    constexpr int PER = (RPW + 1 + GS - 1) / GS;
+    constexpr int PER = (RPC * (RPW + 1) + GS - 1) / GS;
 #define NSPLIT_INTERLEAVE(OTHER_MASK)                                                   \
     _Pragma("unroll") for (int j = 0; j < GS; ++j) {                                     \
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                               \
@@ -263,16 +282,16 @@ __global__ __launch_bounds__(NT) void match_kernel_nsplit(MatchArgs p) {
         if (OTHER_MASK) __builtin_amdgcn_sched_group_barrier(OTHER_MASK, PER, 0);        \
     }
     read_group(0, 0, 0);
-    for (int r = 0; r < 64; r += 2) {
-        // row r from stage 0; set B holds row r+1 (loaded one row ago), set A takes row r+2
-        load_A(min(r + 2, 63));
+    for (int c = 0; c < NCH; c += 2) {
+        // chunk c from stage 0; set B holds chunk c+1 (loaded one chunk ago), set A takes chunk c+2
+        load_A(min(c + 2, NCH - 1));
         read_group(1, 0, 1); mfma_group(0); NSPLIT_INTERLEAVE(0x020)
         read_group(0, 0, 2); store_B(1); mfma_group(1); NSPLIT_INTERLEAVE(0x200)
         read_group(1, 0, 3); mfma_group(0); NSPLIT_INTERLEAVE(0)
         __syncthreads();
         read_group(0, 1, 0); mfma_group(1); NSPLIT_INTERLEAVE(0)
-        // row r+1 from stage 1; set A holds row r+2, set B takes row r+3
-        load_B(min(r + 3, 63));
+        // chunk c+1 from stage 1; set A holds chunk c+2, set B takes chunk c+3
+        load_B(min(c + 3, NCH - 1));
         read_group(1, 1, 1); mfma_group(0); NSPLIT_INTERLEAVE(0x020)
         read_group(0, 1, 2); store_A(0); mfma_group(1); NSPLIT_INTERLEAVE(0x200)
         read_group(1, 1, 3); mfma_group(0); NSPLIT_INTERLEAVE(0)
@@ -1035,9 +1054,18 @@ int witw_match_fwd(const float* ov, const float* su, int Bo, int Bs, int We, lon
         hipLaunchKernelGGL((match_kernel<1, 2>), dim3(gx, cdiv(Bo, 2)), dim3(NT), 0, st, a);
     } else if ((long long)cdiv(Bs, 64) * cdiv(Bo, 2) >= 96) {      // a single minibatch (128 x 128): one overhead per workgroup, the
         const dim3 g2(cdiv(Bs, 64), Bo);                                       // waves split the shifts: a wave on every SIMD
-        if (We <= 16) hipLaunchKernelGGL(match_kernel_nsplit<16>, g2, dim3(NT), 0, st, a);
-        else if (We <= 32) hipLaunchKernelGGL(match_kernel_nsplit<32>, g2, dim3(NT), 0, st, a);
-        else hipLaunchKernelGGL(match_kernel_nsplit<64>, g2, dim3(NT), 0, st, a);
+        constexpr int RPC = NSPLIT_RPC;                                        // embedding rows per LDS stage and barrier
+        constexpr size_t lds = 2 * (64 * (RPC * 64 + 1) + RPC * 128) * sizeof(float);
+        static bool attr_set = false;
+        if (!attr_set && lds > 64 * 1024) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(match_kernel_nsplit<16, RPC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(match_kernel_nsplit<32, RPC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(match_kernel_nsplit<64, RPC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_set = true;
+        }
+        if (We <= 16) hipLaunchKernelGGL((match_kernel_nsplit<16, RPC>), g2, dim3(NT), lds, st, a);
+        else if (We <= 32) hipLaunchKernelGGL((match_kernel_nsplit<32, RPC>), g2, dim3(NT), lds, st, a);
+        else hipLaunchKernelGGL((match_kernel_nsplit<64, RPC>), g2, dim3(NT), lds, st, a);
     } else {        // smaller still: 64-surface blocks of two overheads
         hipLaunchKernelGGL((match_kernel<1, 1>), dim3(cdiv(Bs, 64), cdiv(Bo, 2)), dim3(NT), 0, st, a);
     }
