@@ -9,6 +9,7 @@
 // Compiled with -ffp-contract=off so products and sums round exactly like the reference's
 // separate elementwise torch ops (polar: wa*Ia + wb*Ib + wc*Ic + wd*Id, left to right).
 #include "common.h"
+#include <type_traits>
 #include <string.h>
 
 namespace {
@@ -186,32 +187,45 @@ struct PolarPlane {             // per-plane scalars (SGPRs)
 };
 
 // NPL planes of one tile: (1) their boxes of the resized + normalised image into LDS, (2) the tile's outputs from LDS.
-template <int KIND, int NPL>
+// HALF: the source is exactly twice the resized image in both directions (BASELINE's 512 x 512 -> 256 x 256): source pixel = 2 x
+// resized pixel, both weights 0.5 -- the same operations on the same operands as the general path (so the same bits), but no
+// term tables, and the two taps of a row arrive as one 8-byte load.
+template <int KIND, int NPL, bool HALF>
 __device__ __forceinline__ void polar_planes(const PolarPlane (&pp)[PR_NPL], bool norm, int lane, float* bp, int box_stride, const unsigned* cx0,
                                              const unsigned* cx1, const float* clx1, const unsigned* ry0, const unsigned* ry1,
                                              const float* rly1, int bw, int n_box, float inv_bw, const unsigned (&o01)[PR_OUT],
-                                             const unsigned (&o23)[PR_OUT], const int (&dst)[PR_OUT], const float4 (&wt)[PR_OUT]) {
-    constexpr int MLP = NPL == 1 ? 6 : NPL == 2 ? 4 : 3;        // box pixels per lane whose 4 * NPL loads each are in flight together
+                                             const unsigned (&o23)[PR_OUT], const int (&dst)[PR_OUT], const float4 (&wt)[PR_OUT],
+                                             int bx0, int by0, unsigned row_bytes, unsigned px_bytes) {
+    // box pixels in batches of MLP per lane (their 4 * NPL loads each in flight together): batches of 4 while 256 pixels remain, then
+    // batches of 2 -- a box of 375 pixels (the mean of the 16 x 16 tiles) costs 384 pixel slots, not 768
 #ifndef WITW_PR_NOP1
-    for (int q0 = lane; q0 < n_box; q0 += 64 * MLP) {
+    auto batch = [&](auto mlp_c, int q0) {
+        constexpr int MLP = decltype(mlp_c)::value;
         float p00[NPL][MLP], p01[NPL][MLP], p10[NPL][MLP], p11[NPL][MLP], lx1[MLP], ly1[MLP];
 #pragma unroll
         for (int k = 0; k < MLP; ++k) {
             int q = q0 + 64 * k;
             if (q >= n_box) q = n_box - 1;      // the tail repeats the last pixel (not stored)
             const int ry = (int)(((float)q + 0.5f) * inv_bw), rx = q - ry * bw;
-#ifdef WITW_PR_NOTAB
-            const unsigned r0 = ry * 2048u, r1 = r0 + 2048u, x0 = rx * 8u, x1 = x0 + 4u;
-            ly1[k] = 0.5f; lx1[k] = 0.5f;
-#else
-            const unsigned r0 = ry0[ry], r1 = ry1[ry], x0 = cx0[rx], x1 = cx1[rx];
-            ly1[k] = rly1[ry];
-            lx1[k] = clx1[rx];
-#endif
-            const unsigned a00 = r0 + x0, a01 = r0 + x1, a10 = r1 + x0, a11 = r1 + x1;      // byte offsets, the same in every plane
+            unsigned a00, a01, a10, a11;      // byte offsets of the four taps, the same in every plane
+            if (HALF) {
+                a00 = (unsigned)(2 * (by0 + ry)) * row_bytes + (unsigned)(2 * (bx0 + rx)) * px_bytes;
+                a01 = a00 + px_bytes; a10 = a00 + row_bytes; a11 = a10 + px_bytes;
+                ly1[k] = 0.5f; lx1[k] = 0.5f;
+            } else {
+                const unsigned r0 = ry0[ry], r1 = ry1[ry], x0 = cx0[rx], x1 = cx1[rx];
+                ly1[k] = rly1[ry];
+                lx1[k] = clx1[rx];
+                a00 = r0 + x0; a01 = r0 + x1; a10 = r1 + x0; a11 = r1 + x1;
+            }
 #pragma unroll
             for (int j = 0; j < NPL; ++j) {
-                if (KIND == 0) {
+                if (KIND == 0 && HALF) {          // neighbouring taps: one 8-byte load per source row
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+                    typedef const __attribute__((address_space(1))) f32x2* gmem_f32x2;
+                    const f32x2 t0 = *reinterpret_cast<gmem_f32x2>(pp[j].base + a00), t1 = *reinterpret_cast<gmem_f32x2>(pp[j].base + a10);
+                    p00[j][k] = t0[0]; p01[j][k] = t0[1]; p10[j][k] = t1[0]; p11[j][k] = t1[1];
+                } else if (KIND == 0) {
                     p00[j][k] = *reinterpret_cast<gmem_f32>(pp[j].base + a00); p01[j][k] = *reinterpret_cast<gmem_f32>(pp[j].base + a01);
                     p10[j][k] = *reinterpret_cast<gmem_f32>(pp[j].base + a10); p11[j][k] = *reinterpret_cast<gmem_f32>(pp[j].base + a11);
                 } else {
@@ -233,13 +247,15 @@ __device__ __forceinline__ void polar_planes(const PolarPlane (&pp)[PR_NPL], boo
                     if (pp[j].div255) v = div_exact(v, 255.f, RCP_255);
                     v = div_exact(v - pp[j].mean, pp[j].stdv, pp[j].rstd);
                 }
-#ifdef WITW_PR_NOWRITE
-                if (v == 12345.f) bp[j * box_stride + q] = v;
-#else
                 if (q < n_box) bp[j * box_stride + q] = v;
-#endif
             }
         }
+    };
+    {
+        constexpr int MB = NPL == 1 ? 4 : 2;      // the big batch
+        int base = 0;
+        for (; base + 64 * MB <= n_box; base += 64 * MB) batch(std::integral_constant<int, MB>(), base + lane);
+        for (; base < n_box; base += 64 * (MB / 2)) batch(std::integral_constant<int, MB / 2>(), base + lane);
     }
 #endif
     wave_lds_sync();
@@ -337,7 +353,10 @@ __global__ __launch_bounds__(64 * PR_WAVES, PR_OCC) void polar_from_raw_kernel(P
             pp[j].mean = p.na.mean[c]; pp[j].stdv = p.na.stdv[c]; pp[j].rstd = p.na.rstd[c];
             pp[j].div255 = c < p.na.n_div255;
         }
-        if (Hi != Hi_prev || Wi != Wi_prev || cs != cs_prev) {       // wave-uniform
+        // exactly 2:1 in both directions (and, for the 8-byte loads of fp32 sources, an even row length): the table-free path
+        const bool half = Hi == 2 * p.size && Wi == 2 * p.size;
+        const unsigned px_bytes = KIND == 0 ? 4u : (unsigned)cs, row_bytes = (unsigned)Wi * px_bytes;
+        if (!half && (Hi != Hi_prev || Wi != Wi_prev || cs != cs_prev)) {       // wave-uniform
             Hi_prev = Hi; Wi_prev = Wi; cs_prev = cs;
             const float sh = (float)Hi / (float)p.size, sw = (float)Wi / (float)p.size;
             const unsigned es = KIND == 0 ? 4u : (unsigned)cs;      // BYTES between neighbouring pixels of a row
@@ -359,12 +378,17 @@ __global__ __launch_bounds__(64 * PR_WAVES, PR_OCC) void polar_from_raw_kernel(P
             wave_lds_sync();
         }
         const bool norm = p.na.enabled != 0;
-        if (PR_NPL >= 3 && n == 3)
-            polar_planes<KIND, PR_NPL >= 3 ? 3 : 1>(pp, norm, lane, bp, p.box_stride, cx0, cx1, clx1, ry0, ry1, rly1, bw, n_box, inv_bw, o01, o23, dst, wt);
-        else if (PR_NPL >= 2 && n == 2)
-            polar_planes<KIND, PR_NPL >= 2 ? 2 : 1>(pp, norm, lane, bp, p.box_stride, cx0, cx1, clx1, ry0, ry1, rly1, bw, n_box, inv_bw, o01, o23, dst, wt);
-        else
-            polar_planes<KIND, 1>(pp, norm, lane, bp, p.box_stride, cx0, cx1, clx1, ry0, ry1, rly1, bw, n_box, inv_bw, o01, o23, dst, wt);
+#define PR_ARGS pp, norm, lane, bp, p.box_stride, cx0, cx1, clx1, ry0, ry1, rly1, bw, n_box, inv_bw, o01, o23, dst, wt, bx0, by0, row_bytes, px_bytes
+        if (half) {
+            if (PR_NPL >= 3 && n == 3) polar_planes<KIND, PR_NPL >= 3 ? 3 : 1, true>(PR_ARGS);
+            else if (PR_NPL >= 2 && n == 2) polar_planes<KIND, PR_NPL >= 2 ? 2 : 1, true>(PR_ARGS);
+            else { n = 1; polar_planes<KIND, 1, true>(PR_ARGS); }
+        } else {
+            if (PR_NPL >= 3 && n == 3) polar_planes<KIND, PR_NPL >= 3 ? 3 : 1, false>(PR_ARGS);
+            else if (PR_NPL >= 2 && n == 2) polar_planes<KIND, PR_NPL >= 2 ? 2 : 1, false>(PR_ARGS);
+            else { n = 1; polar_planes<KIND, 1, false>(PR_ARGS); }
+        }
+#undef PR_ARGS
         pl += n;
     }
 }
