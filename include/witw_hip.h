@@ -327,6 +327,11 @@ int witw_bn_train_stats(const float* a, int B, int Hp, int Wp, int H, int W, int
 int witw_bn_lrelu_bwd(const float* a, const float* dy, float* dz, float* dgamma, float* dbeta, const float* mean,
                       const float* invstd, const float* gamma, int B, int Hp, int Wp, int H, int W, int C, float slope,
                       float* workspace, void* stream);
+/* the same with dy still in the space-to-depth layout the next block's data-gradient conv wrote ([B, ceil(H/2), ceil(W/2), dy_s2d_cp],
+ * channel ((h&1)*2+(w&1))*C + c), read in place: saves the witw_depth_to_space2 pass; dy_s2d_cp = 0: dy is [B,Hp,Wp,C] */
+int witw_bn_lrelu_bwd_ex(const float* a, const float* dy, float* dz, float* dgamma, float* dbeta, const float* mean,
+                         const float* invstd, const float* gamma, int B, int Hp, int Wp, int H, int W, int C, float slope,
+                         int dy_s2d_cp, float* workspace, void* stream);
 /* inverse of witw_space_to_depth2 for gradients: g [B,ceil(H/2),ceil(W/2),Cpad] -> dx [B,Hp,Wp,C] (+ add, may be NULL) */
 int witw_depth_to_space2(const float* g, const float* add, float* dx, int B, int Hp, int Wp, int H, int W, int C, int Cpad,
                          void* stream);

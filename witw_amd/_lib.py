@@ -71,6 +71,7 @@ SIGNATURES = {
     'witw_bn_workspace_floats': (c_longlong, [c_int] * 4),
     'witw_bn_train_stats': (c_int, [c_void_p] + [c_int] * 6 + [c_void_p, c_void_p, c_float, c_float] + [c_void_p] * 8),
     'witw_bn_lrelu_bwd': (c_int, [c_void_p] * 8 + [c_int] * 6 + [c_float, c_void_p, c_void_p]),
+    'witw_bn_lrelu_bwd_ex': (c_int, [c_void_p] * 8 + [c_int] * 6 + [c_float, c_int, c_void_p, c_void_p]),
     'witw_depth_to_space2': (c_int, [c_void_p] * 3 + [c_int] * 7 + [c_void_p]),
     'witw_gem_pool_bwd': (c_int, [c_void_p] * 6 + [c_int] * 8 + [c_float, c_int, c_void_p]),
     'witw_embed_normalize_bwd': (c_int, [c_void_p] * 3 + [c_int, c_int, c_void_p]),

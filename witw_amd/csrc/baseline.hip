@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) void sum_finish_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void channel_sums_kernel(const float* __restrict__ a, const float* __restrict__ g,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
                                                             float* __restrict__ part, int Hp, int Wp, int H, int W, int C,
-                                                            size_t npix, int rows_per_block) {
+                                                            size_t npix, int rows_per_block, int g_cp) {
     __shared__ float sh[2][4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
     const size_t p0 = (size_t)blockIdx.y * rows_per_block, p1 = min(npix, p0 + (size_t)rows_per_block);
@@ -211,7 +211,9 @@ __global__ __launch_bounds__(256) void channel_sums_kernel(const float* __restri
             const size_t off = ((b * Hp + h) * Wp + w) * C + c;
             const float v = a[off];
             if (g) {
-                const float gv = g[off];
+                // g_cp > 0: the gradient is still in the space-to-depth layout the data-gradient conv wrote ([B,ceil(H/2),ceil(W/2),g_cp],
+                // channel ((h&1)*2+(w&1))*C + c): read in place, no depth-to-space pass
+                const float gv = g_cp ? g[((b * ((H + 1) >> 1) + (h >> 1)) * ((W + 1) >> 1) + (w >> 1)) * g_cp + ((h & 1) * 2 + (w & 1)) * C + c] : g[off];
                 s0 += gv;
                 s1 += gv * ((v - mu) * is);
             } else {
@@ -236,7 +238,7 @@ __global__ __launch_bounds__(256) void channel_sums_kernel(const float* __restri
 __global__ __launch_bounds__(256) void channel_sums_rows_kernel(const float* __restrict__ a, const float* __restrict__ g,
                                                                  const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                  float* __restrict__ part, int Hp, int Wp, int H, int W, int C,
-                                                                 int nrows, int rows_per_block) {
+                                                                 int nrows, int rows_per_block, int g_cp) {
     __shared__ f32x4 sh[2][256];
     const int Q = C >> 2, phases = 256 / Q;
     const int q = threadIdx.x % Q, ph = threadIdx.x / Q;
@@ -250,10 +252,11 @@ __global__ __launch_bounds__(256) void channel_sums_rows_kernel(const float* __r
     for (int r = r0; r < r1; ++r) {
         const int b = r / H, h = r - b * H;
         const size_t row = ((size_t)b * Hp + h) * Wp * C + 4 * q;
+        const size_t grow = ((size_t)b * ((H + 1) >> 1) + (h >> 1)) * ((W + 1) >> 1) * g_cp + (h & 1) * 2 * C + 4 * q;      // s2d layout (g_cp > 0)
         for (int w = ph; w < W; w += phases) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(a + row + (size_t)w * C);
             if (g) {
-                const f32x4 gv = *reinterpret_cast<const f32x4*>(g + row + (size_t)w * C);
+                const f32x4 gv = *reinterpret_cast<const f32x4*>(g_cp ? g + grow + (size_t)(w >> 1) * g_cp + (w & 1) * C : g + row + (size_t)w * C);
                 s0 += gv;
                 s1 += gv * ((v - mu) * is);
             } else {
@@ -339,7 +342,7 @@ __global__ __launch_bounds__(BNF_CH * BNF_LANES) void bn_bwd_finish_kernel(const
 __global__ void bn_lrelu_bwd_apply_kernel(const float* __restrict__ a, const float* __restrict__ dy, float* __restrict__ dz,
                                           const float* __restrict__ mean, const float* __restrict__ invstd,
                                           const float* __restrict__ gamma, const float* __restrict__ sums, int Hp, int Wp, int H,
-                                          int W, int C, float n, float slope, size_t total) {
+                                          int W, int C, float n, float slope, size_t total, int g_cp) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     const int c = idx % C;
@@ -351,7 +354,9 @@ __global__ void bn_lrelu_bwd_apply_kernel(const float* __restrict__ a, const flo
     if (h < H && w < W) {
         const float av = a[idx];
         const float xh = (av - mean[c]) * invstd[c];
-        const float da = gamma[c] * invstd[c] * (dy[idx] - sums[c] / n - xh * sums[C + c] / n);
+        const size_t b = t / Hp;
+        const float gy = g_cp ? dy[((b * ((H + 1) >> 1) + (h >> 1)) * ((W + 1) >> 1) + (w >> 1)) * g_cp + ((h & 1) * 2 + (w & 1)) * C + c] : dy[idx];
+        const float da = gamma[c] * invstd[c] * (gy - sums[c] / n - xh * sums[C + c] / n);
         out = av > 0.f ? da : da * slope;
     }
     dz[idx] = out;
@@ -602,17 +607,17 @@ static bool bl_wide(int C) { return (C % 4) == 0 && C >= 4 && C <= 1024 && (256 
 
 // launches the partial sums; returns the number of partials written
 static int bl_launch_sums(const float* a, const float* g, const float* mean, const float* invstd, float* part, int B, int Hp,
-                          int Wp, int H, int W, int C, hipStream_t st) {
+                          int Wp, int H, int W, int C, hipStream_t st, int g_cp = 0) {
     const size_t npix = (size_t)B * H * W;
     if (bl_wide(C)) {
         const int nrows = B * H, rpb = bl_rows_per_block(nrows), nparts = cdiv(nrows, rpb);
         hipLaunchKernelGGL(channel_sums_rows_kernel, dim3(nparts), dim3(256), 0, st, a, g, mean, invstd, part, Hp, Wp, H, W, C,
-                           nrows, rpb);
+                           nrows, rpb, g_cp);
         return nparts;
     }
     const int rows = bl_rows(npix), nparts = (int)((npix + rows - 1) / rows);
     hipLaunchKernelGGL(channel_sums_kernel, dim3(cdiv(C, 64), nparts), dim3(256), 0, st, a, g, mean, invstd, part, Hp, Wp, H, W, C,
-                       npix, rows);
+                       npix, rows, g_cp);
     return nparts;
 }
 
@@ -642,21 +647,30 @@ int witw_bn_train_stats(const float* a, int B, int Hp, int Wp, int H, int W, int
 }
 
 // Backward of y = BN_train(lrelu(z)) w.r.t. z, gamma, beta: a = lrelu(z) (saved), dy = gradient at y.
-int witw_bn_lrelu_bwd(const float* a, const float* dy, float* dz, float* dgamma, float* dbeta, const float* mean,
-                      const float* invstd, const float* gamma, int B, int Hp, int Wp, int H, int W, int C, float slope,
-                      float* workspace, void* stream) {
+// dy_s2d_cp > 0: dy is still the space-to-depth image the next block's data-gradient conv wrote ([B, ceil(H/2), ceil(W/2), dy_s2d_cp],
+// channel ((h&1)*2+(w&1))*C + c) and is read in place (no witw_depth_to_space2 pass); 0: dy is [B,Hp,Wp,C] like a.
+int witw_bn_lrelu_bwd_ex(const float* a, const float* dy, float* dz, float* dgamma, float* dbeta, const float* mean,
+                         const float* invstd, const float* gamma, int B, int Hp, int Wp, int H, int W, int C, float slope,
+                         int dy_s2d_cp, float* workspace, void* stream) {
     WITW_CHECK_ARG(a && dy && dz && dgamma && dbeta && mean && invstd && gamma && workspace, "bn_lrelu_bwd: null pointer");
     WITW_CHECK_ARG(B > 0 && C > 0 && H > 0 && W > 0 && H <= Hp && W <= Wp, "bn_lrelu_bwd: bad shape");
+    WITW_CHECK_ARG(dy_s2d_cp == 0 || (dy_s2d_cp >= 4 * C && (dy_s2d_cp % 4) == 0), "bn_lrelu_bwd: space-to-depth channel stride %d for C=%d", dy_s2d_cp, C);
     hipStream_t st = (hipStream_t)stream;
     const size_t npix = (size_t)B * H * W;
-    const int nparts = bl_launch_sums(a, dy, mean, invstd, workspace, B, Hp, Wp, H, W, C, st);
+    const int nparts = bl_launch_sums(a, dy, mean, invstd, workspace, B, Hp, Wp, H, W, C, st, dy_s2d_cp);
     float* sums = workspace + (size_t)nparts * 2 * C;
     hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3(cdiv(C, BNF_CH)), dim3(BNF_CH * BNF_LANES), 0, st, workspace, nparts, C, sums, dgamma, dbeta);
     const size_t total = (size_t)B * Hp * Wp * C;
     hipLaunchKernelGGL(bn_lrelu_bwd_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a, dy, dz, mean, invstd,
-                       gamma, sums, Hp, Wp, H, W, C, (float)npix, slope, total);
+                       gamma, sums, Hp, Wp, H, W, C, (float)npix, slope, total, dy_s2d_cp);
     WITW_CHECK_LAUNCH("bn_lrelu_bwd");
     return WITW_OK;
+}
+
+int witw_bn_lrelu_bwd(const float* a, const float* dy, float* dz, float* dgamma, float* dbeta, const float* mean,
+                      const float* invstd, const float* gamma, int B, int Hp, int Wp, int H, int W, int C, float slope,
+                      float* workspace, void* stream) {
+    return witw_bn_lrelu_bwd_ex(a, dy, dz, dgamma, dbeta, mean, invstd, gamma, B, Hp, Wp, H, W, C, slope, 0, workspace, stream);
 }
 
 int witw_depth_to_space2(const float* g, const float* add, float* dx, int B, int Hp, int Wp, int H, int W, int C, int Cpad,

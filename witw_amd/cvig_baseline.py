@@ -322,13 +322,15 @@ class _BaselineEncoderFn(torch.autograd.Function):
         for i in range(7, 0, -1):
             h, a, valid, mean, invstd, scale, shift = saved[i - 1]
             conv, bn = getattr(enc, 'conv%d' % i), getattr(enc, 'bn%d' % i)
+            s2d_grad = False
             if i == 7:
                 dy = ops.gem_pool_bwd(a, scale, shift, g, dg, valid, 1024, enc.p)
-            else:
+            elif i >= 5:
                 dy = ops.depth_to_space2(dx_s2d, a, valid)
-                if i >= 5:
-                    ops.gem_pool_bwd(a, scale, shift, g, dg, valid, 512 * (i - 5), enc.p, out=dy)
-            dz, dgamma, dbeta = ops.bn_lrelu_bwd(ctx.override.get(i, a), dy, valid, mean, invstd, bn.weight, 0.2)
+                ops.gem_pool_bwd(a, scale, shift, g, dg, valid, 512 * (i - 5), enc.p, out=dy)
+            else:       # blocks 1-4 (the large maps): the BatchNorm backward reads the space-to-depth gradient in place
+                dy, s2d_grad = dx_s2d, True
+            dz, dgamma, dbeta = ops.bn_lrelu_bwd(ctx.override.get(i, a), dy, valid, mean, invstd, bn.weight, 0.2, dy_s2d=s2d_grad)
             k3 = enc._layer_k3(i)
             dk3, dbias = ops.conv3x3_wgrad(h, dz, k3.shape[1], stride_h=1, circular=False, taps4=True)
             # tap (ta+1, tb+1) of the 3x3 filter holds W[:, :, 2ta+dy, 2tb+dx] as channel (dy,dx,c): gathered back in one launch

@@ -1347,19 +1347,25 @@ def bn_train_stats(a, valid_hw, gamma, beta, running_mean=None, running_var=None
     return out
 
 
-def bn_lrelu_bwd(a, dy, valid_hw, mean, invstd, gamma, slope=0.2):
-    """-> (dz, dgamma, dbeta) for y = BatchNorm_train(LeakyReLU(z)), a = LeakyReLU(z)."""
+def bn_lrelu_bwd(a, dy, valid_hw, mean, invstd, gamma, slope=0.2, dy_s2d=False):
+    """-> (dz, dgamma, dbeta) for y = BatchNorm_train(LeakyReLU(z)), a = LeakyReLU(z). dy_s2d: dy is the space-to-depth image
+    [B, ceil(H/2), ceil(W/2), >= 4C] the next block's data-gradient conv wrote, read in place (no depth_to_space2 pass)."""
     lib = _lib.load()
     a, dy = _dev_f32(a, 'a'), _dev_f32(dy, 'dy')
     B, Hp, Wp, C = a.shape
     H, W = valid_hw
+    cp = 0
+    if dy_s2d:
+        cp = dy.shape[3]
+        if tuple(dy.shape[:3]) != (B, (H + 1) // 2, (W + 1) // 2) or cp < 4 * C:
+            raise _lib.WitwError('bn_lrelu_bwd: space-to-depth gradient %s does not match activation %s valid %s' % (tuple(dy.shape), tuple(a.shape), (H, W)))
     dz = torch.empty_like(a)
     dg = torch.empty((C,), dtype=torch.float32, device=a.device)
     db = torch.empty((C,), dtype=torch.float32, device=a.device)
     ws = torch.empty(lib.witw_bn_workspace_floats(B, H, W, C), dtype=torch.float32, device=a.device)
-    _lib.check(lib.witw_bn_lrelu_bwd(a.data_ptr(), dy.data_ptr(), dz.data_ptr(), dg.data_ptr(), db.data_ptr(), mean.data_ptr(),
-                                     invstd.data_ptr(), gamma.data_ptr(), B, Hp, Wp, H, W, C, float(slope), ws.data_ptr(),
-                                     _stream()), 'witw_bn_lrelu_bwd')
+    _lib.check(lib.witw_bn_lrelu_bwd_ex(a.data_ptr(), dy.data_ptr(), dz.data_ptr(), dg.data_ptr(), db.data_ptr(), mean.data_ptr(),
+                                        invstd.data_ptr(), gamma.data_ptr(), B, Hp, Wp, H, W, C, float(slope), cp, ws.data_ptr(),
+                                        _stream()), 'witw_bn_lrelu_bwd_ex')
     return dz, dg, db
 
 
