@@ -248,7 +248,10 @@ int witw_jpeg_decode_coef(const uint8_t* data, size_t n, int16_t* coef, uint16_t
     static thread_local uint32_t* rst_pos = nullptr;
     static thread_local size_t rst_cap = 0;
     const size_t seg = (size_t)(data + n - P.scan);
-    if (clean_cap < seg + 32) { delete[] clean; clean_cap = seg + 32 + seg / 4; clean = new uint8_t[clean_cap]; }
+    // PAD zero bytes behind the data: a block of a corrupt stream can read at most 64 x (16 + 15) bits = 248 bytes past the end
+    // before the per-block check below stops the decode
+    constexpr size_t PAD = 512;
+    if (clean_cap < seg + PAD) { delete[] clean; clean_cap = seg + PAD + seg / 4; clean = new uint8_t[clean_cap]; }
     const size_t max_rst = P.restart ? (size_t)P.mcux * P.mcuy / P.restart + 2 : 1;
     if (rst_cap < max_rst) { delete[] rst_pos; rst_cap = max_rst + max_rst / 4; rst_pos = new uint32_t[rst_cap]; }
     size_t w = 0, n_rst = 0;
@@ -268,7 +271,7 @@ int witw_jpeg_decode_coef(const uint8_t* data, size_t n, int16_t* coef, uint16_t
             else break;                                     // EOI or another marker: the entropy-coded data ends here
         }
     }
-    memset(clean + w, 0, 16);      // the reader loads 8 bytes at a time
+    memset(clean + w, 0, PAD);     // the reader loads 8 bytes at a time and may run ahead by one block
     Bits b;
     b.init(clean);
     int to_restart = P.restart, next_rst = 0;
