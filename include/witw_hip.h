@@ -99,6 +99,10 @@ int witw_conv3x3_wgrad(const float* x, const float* dz, float* dw, float* db, fl
 /* torch.optim.Adam step (no weight decay / amsgrad), optimizer of model/cvig_fov.py:416-418. step counts from 1. */
 int witw_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr, float beta1,
                    float beta2, float eps, int step, void* stream);
+/* The same step for `count` parameter tensors in ceil(count / 48) launches: HOST arrays of device pointers, element counts and
+ * 1-based step numbers (the loop over optimizer.param_groups of torch.optim.Adam.step, model/cvig_fov.py:463). */
+int witw_adam_step_multi(float* const* param, const float* const* grad, float* const* exp_avg, float* const* exp_avg_sq,
+                         const long long* n, const int* step, int count, float lr, float beta1, float beta2, float eps, void* stream);
 
 /* ---- matching: correlation (:297-315) + crop_overhead (:318-343) + l2_distance (:346-363) fused.
  * ov [Bo,16,4,64], su [Bs,16,4,We] (NCHW embeddings). Outputs [Bo,Bs]; any of them may be NULL.

@@ -129,6 +129,30 @@ def test_adam_matches_torch():
     assert bool((d_got[:10] == 0).all()) and float(d_ref.abs().max()) > lr and float(d_ref[20:].abs().median()) > 0.5 * lr
 
 
+def test_adam_multi_tensor_launch_equals_one_launch_per_tensor():
+    """witw_adam_step_multi (one launch per 48 tensors, table in the kernel argument) against witw_adam_step tensor by tensor:
+    the same bits in parameter and both moments, with sizes that are not multiples of the workgroup, more tensors than one
+    table holds and different step numbers."""
+    from witw_amd import ops
+    sizes = [1, 255, 256, 257, 1000, 4096 + 3, 64 * 1024] * 8            # 56 tensors: two launches
+    state = []
+    for k, n in enumerate(sizes):
+        p, g = _rand(900 + k, (n,), 0.01).cuda(), _rand(1900 + k, (n,), 0.01).cuda()
+        m, v = (_rand(2900 + k, (n,), 0.001).cuda(), _rand(3900 + k, (n,), 0.001).cuda().abs())
+        state.append((p, g, m, v, 1 + (k % 5)))
+    one = [tuple(t.clone() for t in s[:4]) for s in state]
+    for (p, g, m, v), s in zip(one, state):
+        ops.adam_step(p, g, m, v, s[4], lr=1e-3)
+    many = [tuple(t.clone() for t in s[:4]) for s in state]
+    ops.adam_step_multi([t[0] for t in many], [t[1] for t in many], [t[2] for t in many], [t[3] for t in many],
+                        [s[4] for s in state], lr=1e-3)
+    for a, b, s in zip(one, many, state):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+        assert not torch.equal(a[0], s[0])
+    with pytest.raises(Exception):
+        ops.adam_step_multi([many[0][0]], [many[0][1], many[1][1]], [many[0][2]], [many[0][3]], [1])
+
+
 def _gpu_gates(g, tag, enc, gates_out, layers=(17, 19, 21, 23, 25)):
     """Reconcile the gates the GPU forward recorded (enc._last_kept) with the reference's (tests/test_trainstep_golden.py)
     and put them where the backward reads them. -> number of fragile positions where the GPU forward fell on the other side."""

@@ -277,3 +277,63 @@ def test_taps4_ex_rejects_bad_arguments():
         ops.conv_taps4_splitk(x, packed, 2, 1, (15, 15), ksplit=9)  # more slices than K-chunks (64 / 8 = 8)
     with pytest.raises(_lib.WitwError):
         ops.conv_taps4_splitk(x, packed, 9, 2, (7, 7))             # 9 images do not fit 2 mosaics of 2x2
+
+
+@pytest.mark.parametrize('case', [(2, 12, 10, (11, 9), 64), (1, 8, 8, (8, 8), 128), (3, 7, 9, (5, 9), 8)])
+def test_space_to_depth_quad_form_equals_the_scalar_form(case):
+    """witw_space_to_depth2 takes 16-byte accesses when C % 4 == 0 and Cpad == 4C; the scalar kernel (reached here through a
+    wider Cpad) must give the same bits, with and without the train-mode BatchNorm affine, and the plain re-layout must equal
+    an index-by-index copy."""
+    import torch
+    from witw_amd import ops
+    B, Hp, Wp, valid, C = case
+    g = np.random.Generator(np.random.Philox(key=[78, C + Hp]))
+    dev = torch.device('cuda:0')
+    x = torch.from_numpy(g.standard_normal((B, Hp, Wp, C), dtype=np.float32)).to(dev)
+    sc = torch.from_numpy(1 + 0.1 * g.standard_normal((C,), dtype=np.float32)).to(dev)
+    sh = torch.from_numpy(0.1 * g.standard_normal((C,), dtype=np.float32)).to(dev)
+    for kw in ({}, {'scale': sc, 'shift': sh}):
+        quad = ops.space_to_depth2(x, valid_hw=valid, cpad=4 * C, **kw)
+        scalar = ops.space_to_depth2(x, valid_hw=valid, cpad=4 * C + 8, **kw)
+        assert torch.equal(quad, scalar[..., :4 * C]) and float(scalar[..., 4 * C:].abs().max()) == 0.0
+    H, W = valid
+    xv = torch.zeros((B, 2 * ((H + 1) // 2), 2 * ((W + 1) // 2), C), device=dev)
+    xv[:, :H, :W] = x[:, :H, :W]
+    want = torch.cat([xv[:, dy::2, dx::2] for dy in (0, 1) for dx in (0, 1)], dim=3)
+    assert torch.equal(ops.space_to_depth2(x, valid_hw=valid, cpad=4 * C), want)
+
+
+@pytest.mark.parametrize('case', [(3, 10, 12, (9, 11), 64, False), (2, 8, 8, (7, 7), 128, True), (2, 6, 10, (6, 9), 6, False),
+                                  (4, 64, 64, (61, 61), 64, True)])
+def test_bn_lrelu_backward_against_autograd(case):
+    """witw_bn_lrelu_bwd(_ex) (channel-quad form for C % 4 == 0, scalar otherwise; gradient in place or in the space-to-depth
+    layout of the next block's data-gradient conv) against torch autograd through BatchNorm2d(train)(LeakyReLU(z)) in float64
+    over the valid region (model/cvig_baseline.py:267-275)."""
+    import torch
+    from witw_amd import ops
+    B, Hp, Wp, (H, W), C, s2d = case
+    g = np.random.Generator(np.random.Philox(key=[79, C + Hp]))
+    z = torch.from_numpy(g.standard_normal((B, Hp, Wp, C), dtype=np.float32))
+    gamma = torch.from_numpy(1 + 0.1 * g.standard_normal((C,), dtype=np.float32))
+    beta = torch.from_numpy(0.1 * g.standard_normal((C,), dtype=np.float32))
+    dy = torch.from_numpy(g.standard_normal((B, Hp, Wp, C), dtype=np.float32))
+    dy[:, H:] = 0
+    dy[:, :, W:] = 0
+    zr = z[:, :H, :W].double().permute(0, 3, 1, 2).clone().requires_grad_(True)
+    gr, br = gamma.double().clone().requires_grad_(True), beta.double().clone().requires_grad_(True)
+    y = torch.nn.functional.batch_norm(torch.nn.functional.leaky_relu(zr, 0.2), None, None, gr, br, True, 0.1, 1e-5)
+    y.backward(dy[:, :H, :W].double().permute(0, 3, 1, 2))
+    dev = torch.device('cuda:0')
+    a = torch.nn.functional.leaky_relu(z, 0.2).to(dev)
+    mean, invstd, _sc, _sh = ops.bn_train_stats(a, (H, W), gamma.to(dev), beta.to(dev))
+    dyd = dy.to(dev)
+    if s2d:
+        dyd = ops.space_to_depth2(dyd, valid_hw=(H, W), cpad=4 * C)
+    dz, dg, db = ops.bn_lrelu_bwd(a, dyd, (H, W), mean, invstd, gamma.to(dev), 0.2, dy_s2d=s2d)
+    want = zr.grad.permute(0, 2, 3, 1)
+    got = dz.cpu().double()
+    assert float(got[:, H:].abs().max() if H < Hp else 0) == 0.0 and float(got[:, :, W:].abs().max() if W < Wp else 0) == 0.0
+    scale = float(want.abs().max())
+    assert float((got[:, :H, :W] - want).abs().max()) <= 2e-5 * scale
+    assert float((dg.cpu().double() - gr.grad).abs().max()) <= 1e-5 * float(gr.grad.abs().max())
+    assert float((db.cpu().double() - br.grad).abs().max()) <= 1e-5 * float(br.grad.abs().max())

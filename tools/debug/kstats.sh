@@ -8,6 +8,6 @@ f=$(find $d -name "*kernel_stats.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
-for r in rows[:14]:
+for r in rows[:30]:
     print('%-90s calls %6s avg %9.1f us  total %8.2f ms' % (r['Name'][:90], r['Calls'], float(r['AverageNs']) / 1e3, float(r['TotalDurationNs']) / 1e6))
 PY

@@ -38,6 +38,7 @@ SIGNATURES = {
     'witw_conv3x3_wgrad': (c_int, [c_void_p] * 5 + [c_int] * 9 + [c_void_p]),
     'witw_adam_step': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_float, c_float, c_float, c_float, c_int,
                                c_void_p]),
+    'witw_adam_step_multi': (c_int, [c_void_p] * 6 + [c_int, c_float, c_float, c_float, c_float, c_void_p]),
     'witw_conv3x3_first_pack': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     'witw_conv3x3_first_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
     'witw_conv3x3_bf16_mfma16': (c_int, [c_int]),

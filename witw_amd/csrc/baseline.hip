@@ -42,6 +42,34 @@ __global__ void space_to_depth2_kernel(const float* __restrict__ x, float* __res
     y[idx] = v;
 }
 
+// The same for an NHWC source with C % 4 == 0 and Cp == 4C (every block but the first): one thread per channel quad, 16-byte
+// loads and stores, the same arithmetic per element.
+__global__ void space_to_depth2_quad_kernel(const float* __restrict__ x, float* __restrict__ y, int Hp, int Wp, int H, int W, int C,
+                                            size_t total4, const float* __restrict__ scale, const float* __restrict__ shift) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total4) return;
+    const int H2 = (H + 1) >> 1, W2 = (W + 1) >> 1, C4 = C >> 2;
+    const int c4 = idx % C4;
+    size_t t = idx / C4;
+    const int q = t & 3;
+    t >>= 2;
+    const int w2 = t % W2;
+    t /= W2;
+    const int h2 = t % H2;
+    const size_t b = t / H2;
+    const int h = 2 * h2 + (q >> 1), w = 2 * w2 + (q & 1);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (h < H && w < W) {
+        v = *reinterpret_cast<const f32x4*>(x + ((b * Hp + h) * Wp + w) * C + 4 * c4);
+        if (scale != nullptr) {
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + 4 * c4), sf = *reinterpret_cast<const f32x4*>(shift + 4 * c4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = v[j] * sc[j] + sf[j];
+        }
+    }
+    reinterpret_cast<f32x4*>(y)[idx] = v;
+}
+
 // Mosaic space-to-depth: x NHWC [B,H,W,C] (all valid) -> y [ceil(B/g^2), g*H2, g*W2, 4C], H2 = ceil(H/2): image b sits in cell
 // (b % g^2) of mosaic image b / g^2, cells row-major, each the space-to-depth(2) image of x[b]; zeros where no source exists.
 // A k=4,s=2 layer over an H2 x W2 s2d map has (H2-1) x (W2-1) valid outputs, so no valid output's 2x2 window crosses a cell:
@@ -279,17 +307,18 @@ __global__ __launch_bounds__(256) void channel_sums_rows_kernel(const float* __r
     }
 }
 
-// Second stage of the per-channel sums: part [nparts][2][C] -> two sums per channel. A workgroup takes 32 channels; its 8 groups of 32
-// lanes each add every 8th partial row (loads of a group: 128 contiguous bytes), then the 8 group sums are added in a fixed order
-// through LDS -- bit-reproducible, and 8x fewer dependent loads per thread than one thread per channel (the stage took 157 us of
-// pure load latency per call at 1024 partial rows).
-constexpr int BNF_CH = 32, BNF_LANES = 8;
+// Second stage of the per-channel sums: part [nparts][2][C] -> two sums per channel. A workgroup takes 32 channels; its 32 groups of 32
+// lanes each add every 32nd partial row (loads of a group: 128 contiguous bytes, 8 in flight), then the group sums are added in a
+// fixed order through LDS -- bit-reproducible, and 32x fewer dependent loads per thread than one thread per channel (the stage took
+// 157 us of pure load latency per call at 1024 partial rows; 25-40 us with 8 groups).
+constexpr int BNF_CH = 32, BNF_LANES = 32;
 __device__ __forceinline__ bool bn_finish_sums(const float* __restrict__ part, int nparts, int C, int& c, float& s0, float& s1) {
     __shared__ float red[2][BNF_LANES][BNF_CH];
     const int cl = threadIdx.x % BNF_CH, pl = threadIdx.x / BNF_CH;
     c = blockIdx.x * BNF_CH + cl;
     float a0 = 0.f, a1 = 0.f;
     if (c < C)
+#pragma unroll 8
         for (int k = pl; k < nparts; k += BNF_LANES) {
             a0 += part[((size_t)k * 2 + 0) * C + c];
             a1 += part[((size_t)k * 2 + 1) * C + c];
@@ -360,6 +389,38 @@ __global__ void bn_lrelu_bwd_apply_kernel(const float* __restrict__ a, const flo
         out = av > 0.f ? da : da * slope;
     }
     dz[idx] = out;
+}
+
+// The same for C % 4 == 0 (and g_cp % 4 == 0): one thread per channel quad, the same arithmetic per element.
+__global__ void bn_lrelu_bwd_apply_quad_kernel(const float* __restrict__ a, const float* __restrict__ dy, float* __restrict__ dz,
+                                               const float* __restrict__ mean, const float* __restrict__ invstd,
+                                               const float* __restrict__ gamma, const float* __restrict__ sums, int Hp, int Wp, int H,
+                                               int W, int C, float n, float slope, size_t total4, int g_cp) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total4) return;
+    const int C4 = C >> 2;
+    const int c = 4 * (int)(idx % C4);
+    size_t t = idx / C4;
+    const int w = t % Wp;
+    t /= Wp;
+    const int h = t % Hp;
+    f32x4 out = {0.f, 0.f, 0.f, 0.f};
+    if (h < H && w < W) {
+        const size_t b = t / Hp;
+        const f32x4 av = reinterpret_cast<const f32x4*>(a)[idx];
+        const f32x4 gy = *reinterpret_cast<const f32x4*>(
+            g_cp ? dy + ((b * ((H + 1) >> 1) + (h >> 1)) * ((W + 1) >> 1) + (w >> 1)) * g_cp + ((h & 1) * 2 + (w & 1)) * C + c : dy + 4 * idx);
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), is = *reinterpret_cast<const f32x4*>(invstd + c);
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c);
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(sums + c), s1 = *reinterpret_cast<const f32x4*>(sums + C + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float xh = (av[j] - mu[j]) * is[j];
+            const float da = ga[j] * is[j] * (gy[j] - s0[j] / n - xh * s1[j] / n);
+            out[j] = av[j] > 0.f ? da : da * slope;
+        }
+    }
+    reinterpret_cast<f32x4*>(dz)[idx] = out;
 }
 
 // depth-to-space(2) of the s2d-layout gradient: dx[b,h,w,c] = g[b,h/2,w/2,((h&1)*2+(w&1))*C+c] (+ add[b,h,w,c]) on
@@ -521,8 +582,12 @@ int witw_space_to_depth2(const float* x, float* y, int B, int Hp, int Wp, int H,
     WITW_CHECK_ARG(B > 0 && C > 0 && H > 0 && W > 0 && H <= Hp && W <= Wp && Cpad >= 4 * C, "space_to_depth2: bad shape");
     const size_t total = (size_t)B * ((H + 1) / 2) * ((W + 1) / 2) * Cpad;
     WITW_CHECK_ARG((total + 255) / 256 <= 0x7fffffffULL, "space_to_depth2: tensor too large");
-    hipLaunchKernelGGL(space_to_depth2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, B,
-                       Hp, Wp, H, W, C, Cpad, in_nchw, normalize, total, scale, shift);
+    if (!in_nchw && !normalize && (C & 3) == 0 && Cpad == 4 * C)
+        hipLaunchKernelGGL(space_to_depth2_quad_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+                           y, Hp, Wp, H, W, C, total / 4, scale, shift);
+    else
+        hipLaunchKernelGGL(space_to_depth2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, B,
+                           Hp, Wp, H, W, C, Cpad, in_nchw, normalize, total, scale, shift);
     WITW_CHECK_LAUNCH("space_to_depth2");
     return WITW_OK;
 }
@@ -661,8 +726,12 @@ int witw_bn_lrelu_bwd_ex(const float* a, const float* dy, float* dz, float* dgam
     float* sums = workspace + (size_t)nparts * 2 * C;
     hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3(cdiv(C, BNF_CH)), dim3(BNF_CH * BNF_LANES), 0, st, workspace, nparts, C, sums, dgamma, dbeta);
     const size_t total = (size_t)B * Hp * Wp * C;
-    hipLaunchKernelGGL(bn_lrelu_bwd_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a, dy, dz, mean, invstd,
-                       gamma, sums, Hp, Wp, H, W, C, (float)npix, slope, total, dy_s2d_cp);
+    if ((C & 3) == 0)
+        hipLaunchKernelGGL(bn_lrelu_bwd_apply_quad_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, st, a, dy, dz, mean,
+                           invstd, gamma, sums, Hp, Wp, H, W, C, (float)npix, slope, total / 4, dy_s2d_cp);
+    else
+        hipLaunchKernelGGL(bn_lrelu_bwd_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a, dy, dz, mean, invstd,
+                           gamma, sums, Hp, Wp, H, W, C, (float)npix, slope, total, dy_s2d_cp);
     WITW_CHECK_LAUNCH("bn_lrelu_bwd");
     return WITW_OK;
 }

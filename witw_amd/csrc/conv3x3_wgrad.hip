@@ -41,8 +41,13 @@ struct WgradArgs {
 
 // TAPS = 9: the full window. TAPS = 4: only the taps (kh, kw) in {1,2}^2 (cvig_baseline's Conv2d(k=4,s=2) as a 2x2
 // convolution over the space-to-depth image: the other five taps of its 3x3 form are structurally zero and get no gradient).
-template <int TAPS>
+// PACK (TAPS = 4, Cin <= 16: cvig_baseline's first block, 12 space-to-depth channels): the M dimension of the MFMA tile
+// holds (tap, ci) = 4 x 16 instead of 64 input channels of which 48 would be padding — one accumulator tile per wave
+// instead of four, a quarter of the MFMAs; every (tap, ci, co) sum runs over the same pixels in the same order.
+template <int TAPS, bool PACK = false>
 __global__ __launch_bounds__(WT, 2) void conv3x3_wgrad_kernel(WgradArgs p) {
+    static_assert(!PACK || TAPS == 4, "the packed form is the 2x2 sub-window over at most 16 channels");
+    constexpr int NACC = PACK ? 1 : TAPS;
     __shared__ float smem[X_F + DZ_F];
     float* x_s = smem;
     float* dz_s = smem + X_F;
@@ -53,9 +58,9 @@ __global__ __launch_bounds__(WT, 2) void conv3x3_wgrad_kernel(WgradArgs p) {
     const int c_begin = split * p.cps;
     const int c_end = min(p.chunks, c_begin + p.cps);
 
-    f32x16 acc[TAPS];
+    f32x16 acc[NACC];
 #pragma unroll
-    for (int t = 0; t < TAPS; ++t)
+    for (int t = 0; t < NACC; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     constexpr int R0 = (TAPS == 4) ? 1 : 0;      // first halo row that is read
@@ -133,17 +138,27 @@ __global__ __launch_bounds__(WT, 2) void conv3x3_wgrad_kernel(WgradArgs p) {
         // ---- 9 taps x ceil(npix/2) k-steps; lanes 0-31 take pixel 2k, lanes 32-63 pixel 2k+1
         const int npix = min(64, p.Wo - w0);
         const int ksteps = (npix + 1) >> 1;
-        const float* ap = x_s + (hk + 0) * 64 + mci;
         const float* bp = dz_s + hk * 64 + nco;
+        if constexpr (PACK) {       // A row m = (tap, ci): this wave's taps are (1 + (wave & 1), 1 + (l31 >> 4))
+            const float* ap = x_s + ((1 + (wave & 1)) * XCOLS + 1 + (l31 >> 4) + hk) * 64 + (l31 & 15);
+#pragma unroll 4
+            for (int k = 0; k < ksteps; ++k) {
+                const float bv = bp[k * 128];
+                if (do_bias) bsum += bv;
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[k * 128], bv, acc[0], 0, 0, 0);
+            }
+        } else {
+            const float* ap = x_s + (hk + 0) * 64 + mci;
 #pragma unroll 2
-        for (int k = 0; k < ksteps; ++k) {
-            const float bv = bp[k * 128];
-            if (do_bias) bsum += bv;
+            for (int k = 0; k < ksteps; ++k) {
+                const float bv = bp[k * 128];
+                if (do_bias) bsum += bv;
 #pragma unroll
-            for (int t = 0; t < TAPS; ++t) {
-                const int kh = (TAPS == 4) ? 1 + (t >> 1) : t / 3, kw = (TAPS == 4) ? 1 + (t & 1) : t - (t / 3) * 3;
-                const float av = ap[(kh * XCOLS + kw) * 64 + k * 128];
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+                for (int t = 0; t < TAPS; ++t) {
+                    const int kh = (TAPS == 4) ? 1 + (t >> 1) : t / 3, kw = (TAPS == 4) ? 1 + (t & 1) : t - (t / 3) * 3;
+                    const float av = ap[(kh * XCOLS + kw) * 64 + k * 128];
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+                }
             }
         }
     }
@@ -151,13 +166,22 @@ __global__ __launch_bounds__(WT, 2) void conv3x3_wgrad_kernel(WgradArgs p) {
     // ---- partial tile -> workspace [split][tap][ci][co]
     float* out = p.ws + (size_t)split * TAPS * p.Cin * p.Cout;
     const int co = co0 + nco;
-#pragma unroll
-    for (int t = 0; t < TAPS; ++t)
+    if constexpr (PACK) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int ci = ci0 + (wave & 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hk;
-            if (ci < p.Cin && co < p.Cout) out[((size_t)t * p.Cin + ci) * p.Cout + co] = acc[t][r];
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * hk;          // row of this wave's 32: (tap column, ci)
+            const int t = (wave & 1) * 2 + (m >> 4), ci = m & 15;
+            if (ci < p.Cin && co < p.Cout) out[((size_t)t * p.Cin + ci) * p.Cout + co] = acc[0][r];
         }
+    } else {
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = ci0 + (wave & 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hk;
+                if (ci < p.Cin && co < p.Cout) out[((size_t)t * p.Cin + ci) * p.Cout + co] = acc[t][r];
+            }
+    }
     if (do_bias) {                       // lanes l and l+32 hold the even / odd pixels of the same co
         bsum += __shfl_xor(bsum, 32, 64);
         if (hk == 0 && co < p.Cout) p.bias_part[(size_t)split * p.Cout + co] = bsum;
@@ -188,6 +212,48 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
     float s = 0.f;
     for (int k = 0; k < splits; ++k) s += ws[(size_t)k * n + idx];
     if (ci >= cin_real) return;   // zero-padded input channels have no weight
+    float* d = dw + ((size_t)co * cin_real + ci) * 9 + tap;
+    *d = accumulate ? (*d + s) : s;
+}
+
+// The same sums when there are many splits and few weights (first layers: one 64 x 64 tile, ~1000 splits — one thread per
+// element would walk them serially on a handful of workgroups): a workgroup owns 32 consecutive elements, its 8 groups of
+// 32 lanes each add every 8th split, and the group sums are added in group order. The order is fixed (reproducible), but
+// differs from wgrad_reduce_kernel's; the launcher chooses by `splits` alone.
+constexpr int RW_E = 32, RW_G = 8;
+__global__ __launch_bounds__(RW_E * RW_G) void wgrad_reduce_wide_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Cin,
+                                                                         int Cout, int splits, int accumulate, int cin_real, int taps,
+                                                                         const float* __restrict__ bias_part, float* __restrict__ db) {
+    __shared__ float part[RW_G][RW_E];
+    const size_t n = (size_t)taps * Cin * Cout;
+    const int e = threadIdx.x % RW_E, g = threadIdx.x / RW_E;
+    const size_t idx = (size_t)blockIdx.x * RW_E + e;         // weight elements, then (idx >= n) the bias elements
+    const bool is_w = idx < n;
+    const size_t co_b = idx - n;
+    const bool is_b = !is_w && db != nullptr && co_b < (size_t)Cout;
+    const float* src = is_w ? ws + idx : bias_part + co_b;
+    const size_t stride = is_w ? n : (size_t)Cout;
+    float s = 0.f;
+    if (is_w || is_b) {
+#pragma unroll 8
+        for (int k = g; k < splits; k += RW_G) s += src[(size_t)k * stride];
+    }
+    part[g][e] = s;
+    __syncthreads();
+    if (g != 0) return;
+#pragma unroll
+    for (int j = 1; j < RW_G; ++j) s += part[j][e];
+    if (is_b) {
+        db[co_b] = accumulate ? db[co_b] + s : s;
+        return;
+    }
+    if (!is_w) return;
+    const int co = idx % Cout;
+    const size_t t = idx / Cout;
+    const int ci = t % Cin;
+    int tap = (int)(t / Cin);
+    if (taps == 4) tap = (1 + (tap >> 1)) * 3 + 1 + (tap & 1);
+    if (ci >= cin_real) return;
     float* d = dw + ((size_t)co * cin_real + ci) * 9 + tap;
     *d = accumulate ? (*d + s) : s;
 }
@@ -226,6 +292,37 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     v[i] = vi;
     const float denom = sqrtf(vi) / bc2_sqrt + eps;
     p[i] = p[i] + (-(lr / bc1)) * (mi / denom);
+}
+
+// The same update for up to ADAM_MAX tensors in one launch (an optimizer step over a model is otherwise one launch of a few
+// microseconds per parameter tensor): the table travels as the kernel argument, a workgroup finds its tensor from the running
+// workgroup counts.
+constexpr int ADAM_MAX = 48;
+struct AdamTable {
+    float* p[ADAM_MAX];
+    const float* g[ADAM_MAX];
+    float* m[ADAM_MAX];
+    float* v[ADAM_MAX];
+    unsigned long long n[ADAM_MAX];
+    unsigned first_wg[ADAM_MAX + 1];      // workgroups of tensor k: [first_wg[k], first_wg[k+1])
+    float bc1[ADAM_MAX], bc2_sqrt[ADAM_MAX];
+    int count;
+};
+__global__ __launch_bounds__(256) void adam_multi_kernel(const AdamTable t, float lr, float b1, float b2, float eps) {
+    int k = 0;
+    while (k + 1 < t.count && blockIdx.x >= t.first_wg[k + 1]) ++k;
+    const size_t i = (size_t)(blockIdx.x - t.first_wg[k]) * 256 + threadIdx.x;
+    if (i >= t.n[k]) return;
+    float* p = t.p[k];
+    const float* g = t.g[k];
+    float *m = t.m[k], *v = t.v[k];
+    const float gi = g[i];
+    const float mi = m[i] * b1 + gi * (1.f - b1);
+    const float vi = v[i] * b2 + (gi * gi) * (1.f - b2);
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / t.bc2_sqrt[k] + eps;
+    p[i] = p[i] + (-(lr / t.bc1[k])) * (mi / denom);
 }
 
 }  // namespace
@@ -278,14 +375,21 @@ static int wgrad_launch(const float* x, const float* dz, float* dw, float* db, f
             witw_set_error("conv3x3_wgrad_taps4: memset failed");
             return WITW_ERR_LAUNCH;
         }
-        hipLaunchKernelGGL(conv3x3_wgrad_kernel<4>, grid, dim3(WT), 0, st, a);
+        if (Cin <= 16)
+            hipLaunchKernelGGL((conv3x3_wgrad_kernel<4, true>), grid, dim3(WT), 0, st, a);
+        else
+            hipLaunchKernelGGL((conv3x3_wgrad_kernel<4, false>), grid, dim3(WT), 0, st, a);
     } else {
-        hipLaunchKernelGGL(conv3x3_wgrad_kernel<9>, grid, dim3(WT), 0, st, a);
+        hipLaunchKernelGGL((conv3x3_wgrad_kernel<9, false>), grid, dim3(WT), 0, st, a);
     }
     WITW_CHECK_LAUNCH("conv3x3_wgrad");
     const size_t n = (size_t)taps * Cin * Cout;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + Cout + 255) / 256)), dim3(256), 0, st, workspace, dw, Cin, Cout,
-                       splits, accumulate, cin_real, taps, a.bias_part, db);
+    if (splits >= 32)
+        hipLaunchKernelGGL(wgrad_reduce_wide_kernel, dim3((unsigned)((n + Cout + RW_E - 1) / RW_E)), dim3(RW_E * RW_G), 0, st,
+                           workspace, dw, Cin, Cout, splits, accumulate, cin_real, taps, a.bias_part, db);
+    else
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + Cout + 255) / 256)), dim3(256), 0, st, workspace, dw, Cin, Cout,
+                           splits, accumulate, cin_real, taps, a.bias_part, db);
     WITW_CHECK_LAUNCH("wgrad_reduce");
     return WITW_OK;
 }
@@ -329,6 +433,36 @@ int witw_adam_step(float* param, const float* grad, float* exp_avg, float* exp_a
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
                        exp_avg_sq, (size_t)n, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2));
     WITW_CHECK_LAUNCH("adam_step");
+    return WITW_OK;
+}
+
+// witw_adam_step for `count` tensors (host arrays of device pointers, element counts and 1-based step numbers), ceil(count / 48)
+// launches; element for element the arithmetic of witw_adam_step.
+int witw_adam_step_multi(float* const* param, const float* const* grad, float* const* exp_avg, float* const* exp_avg_sq,
+                         const long long* n, const int* step, int count, float lr, float beta1, float beta2, float eps, void* stream) {
+    WITW_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && n && step && count > 0, "adam_step_multi: null pointer or count=%d", count);
+    for (int k = 0; k < count; ++k) {
+        WITW_CHECK_ARG(param[k] && grad[k] && exp_avg[k] && exp_avg_sq[k], "adam_step_multi: null pointer in tensor %d", k);
+        WITW_CHECK_ARG(n[k] > 0 && step[k] >= 1 && ((n[k] + 255) / 256) < 0x40000000LL, "adam_step_multi: bad n=%lld or step=%d in tensor %d", n[k], step[k], k);
+    }
+    for (int k0 = 0; k0 < count; k0 += ADAM_MAX) {
+        AdamTable t;
+        t.count = count - k0 < ADAM_MAX ? count - k0 : ADAM_MAX;
+        unsigned long long wgs = 0;
+        for (int j = 0; j < t.count; ++j) {
+            const int k = k0 + j;
+            t.p[j] = param[k]; t.g[j] = grad[k]; t.m[j] = exp_avg[k]; t.v[j] = exp_avg_sq[k];
+            t.n[j] = (unsigned long long)n[k];
+            t.first_wg[j] = (unsigned)wgs;
+            wgs += (unsigned long long)((n[k] + 255) / 256);
+            t.bc1[j] = (float)(1.0 - pow((double)beta1, step[k]));
+            t.bc2_sqrt[j] = (float)sqrt(1.0 - pow((double)beta2, step[k]));
+        }
+        WITW_CHECK_ARG(wgs < 0x7fffffffULL, "adam_step_multi: too many elements for one launch");
+        t.first_wg[t.count] = (unsigned)wgs;
+        hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, t, lr, beta1, beta2, eps);
+        WITW_CHECK_LAUNCH("adam_step_multi");
+    }
     return WITW_OK;
 }
 

@@ -642,8 +642,8 @@ def match(overhead_embed, surface_embed):
 
 class Adam(object):
     """torch.optim.Adam(params, lr) as used at model/cvig_fov.py:416-418 (defaults betas=(0.9,0.999),
-    eps=1e-8, no weight decay), one fused HIP launch per parameter. Parameters that never receive a
-    gradient (the frozen layers) are skipped, as torch does."""
+    eps=1e-8, no weight decay), one HIP launch per 48 parameter tensors (witw_adam_step_multi). Parameters that never
+    receive a gradient (the frozen layers) are skipped, as torch does."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
         self.params = [p for p in params]
@@ -661,6 +661,7 @@ class Adam(object):
                 b.zero()
 
     def step(self):
+        live, grads = [], []
         for p in self.params:
             if p.grad is None:
                 continue
@@ -671,9 +672,15 @@ class Adam(object):
             if st is None:
                 st = self.state[p] = {'step': 0, 'exp_avg': torch.zeros_like(p), 'exp_avg_sq': torch.zeros_like(p)}
             st['step'] += 1
-            with torch.no_grad():
-                ops.adam_step(p.data, p.grad.contiguous(), st['exp_avg'], st['exp_avg_sq'], st['step'], self.lr,
-                              self.betas[0], self.betas[1], self.eps)
+            live.append(p)
+            grads.append(p.grad.contiguous())
+        if not live:
+            return
+        with torch.no_grad():
+            states = [self.state[p] for p in live]
+            ops.adam_step_multi([p.data for p in live], grads, [s['exp_avg'] for s in states], [s['exp_avg_sq'] for s in states],
+                                [s['step'] for s in states], self.lr, self.betas[0], self.betas[1], self.eps)
+            for p in live:
                 p._witw_version = getattr(p, '_witw_version', 0) + 1   # packed-weight caches key on this
 
 

@@ -346,6 +346,26 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr=1e-3, beta1=0.9, beta2=
                'witw_adam_step')
 
 
+def adam_step_multi(params, grads, exp_avgs, exp_avg_sqs, steps, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8):
+    """adam_step over lists of tensors in ceil(len / 48) launches (same arithmetic per element)."""
+    import ctypes
+    lib = _lib.load()
+    k = len(params)
+    if not (k and len(grads) == k and len(exp_avgs) == k and len(exp_avg_sqs) == k and len(steps) == k):
+        raise _lib.WitwError('adam_step_multi: lists of different lengths')
+    for group, name in ((params, 'param'), (grads, 'grad'), (exp_avgs, 'exp_avg'), (exp_avg_sqs, 'exp_avg_sq')):
+        for t in group:
+            _dev_f32(t, name)
+    for p, g, m, v in zip(params, grads, exp_avgs, exp_avg_sqs):
+        if not (g.numel() == p.numel() and m.numel() == p.numel() and v.numel() == p.numel()):
+            raise _lib.WitwError('adam_step_multi: tensor sizes differ within a parameter')
+    ptrs = [(ctypes.c_void_p * k)(*[t.data_ptr() for t in group]) for group in (params, grads, exp_avgs, exp_avg_sqs)]
+    n = (ctypes.c_longlong * k)(*[p.numel() for p in params])
+    st = (ctypes.c_int * k)(*[int(s) for s in steps])
+    _lib.check(lib.witw_adam_step_multi(ptrs[0], ptrs[1], ptrs[2], ptrs[3], n, st, k, float(lr), float(beta1), float(beta2),
+                                        float(eps), _stream()), 'witw_adam_step_multi')
+
+
 # ----------------------------------------------------------------------------- matching
 def match_bwd(overhead_embed, surface_embed, orientation, score, workspace, grad_distance, need_ov=True, need_su=True):
     lib = _lib.load()
