@@ -572,6 +572,34 @@ def baseline_bench(a, device, full=True, B=32):
                         'achieved': round(tf, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tf / PEAK_F32_MFMA_TFLOPS, 4),
                         'launches': len(conv), 'avg_launch_ms': round(conv_ms / max(1, len(conv)), 4),
                         'note': 'algorithmic 2*Cin*Cout*16*Ho*Wo FLOP per launch; the conv launches take %.2f of the %.2f ms step' % (conv_ms / n, ms)}}
+    # the training step of the same batch (train-mode BatchNorm, backward through both encoders, Adam), model/cvig_baseline.py:373-387
+    from witw_amd import cvig_fov
+    se.train()
+    oe.train()
+    opt = cvig_fov.Adam(list(se.parameters()) + list(oe.parameters()), lr=1e-5)
+
+    def train_step():
+        es_t, eo_t = se(xs), oe(xo)
+        l = cb.exhaustive_minibatch_triplet_loss(es_t, eo_t)
+        opt.zero_grad()
+        l.backward()
+        opt.step()
+        return l
+    first = float(train_step().item())
+    for _ in range(2):
+        train_step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        tl = train_step()
+    torch.cuda.synchronize()
+    tms = (time.perf_counter() - t0) / n * 1e3
+    out['train_step'] = {'ms_per_step': round(tms, 3), 'value': round(B / tms * 1e3, 2), 'unit': 'pairs/s', 'steps': n, 'loss_first_step': first,
+                         'loss_last_step': float(tl.item()),       # one fixed batch of 32 random pairs is fitted within a few Adam steps (hinge -> 0)
+                         'what': 'forward with batch statistics + backward of both encoders + Adam on the same 32 pairs (round 2: 49.3 ms = 650 pairs/s); '
+                                 'parity: tests/test_baseline_gpu.py against tests/golden/baseline_train.npz'}
+    se.eval()
+    oe.eval()
     if full:
         from oracle import cvig_baseline_oracle as OB
         prm = [[dict((k, torch.from_numpy(np.asarray(v))) for k, v in q.items()) for q in p] for p in (prm_s, prm_o)]
