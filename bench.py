@@ -247,6 +247,7 @@ class StepBench(object):
         dom = [(fl, e0.elapsed_time(e1)) for (v, fl, e0, e1) in prof if v == dominant]
         allc = [(fl, e0.elapsed_time(e1)) for (v, fl, e0, e1) in prof if v[0] not in ('match', 'wgrad_bf16', 'wgrad_f16x3')]
         wg = [(fl, e0.elapsed_time(e1)) for (v, fl, e0, e1) in prof if v[0] == 'wgrad_bf16']
+        wres = [(fl, e0.elapsed_time(e1)) for (v, fl, e0, e1) in prof if v[0] == 'bf16_wres']      # layer 5 (64 input channels)
         dom_fl = sum(f for f, _ in dom) / max(1, len(dom))
         dom_ms = sum(m for _, m in dom) / max(1, len(dom))
         achieved = dom_fl / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
@@ -260,6 +261,11 @@ class StepBench(object):
                 'traffic': traffic, **({'traffic_source': tsrc} if tsrc else {}),
                 'launches': len(dom), 'avg_launch_ms': round(dom_ms, 4),
                 'avg_launch_gflop': round(dom_fl / 1e9, 2), 'all_conv_launches_tflops': round(conv_tf, 2),
+                **({'layer5_weight_resident_kernel': {'kernel': 'conv3x3_bf16_wres_kernel', 'launches': len(wres),
+                                                      'avg_launch_ms': round(sum(m for _, m in wres) / len(wres), 4),
+                                                      'tflops': round(sum(f for f, _ in wres) / (sum(m for _, m in wres) * 1e-3) / 1e12, 2),
+                                                      'note': 'not part of the dominant kernel\'s launches: 64 -> 128 channels, K = 576, the filter block stays in LDS'}}
+                   if wres else {}),
                 **({'wgrad_bf16_tflops_incl_layout_passes': round(sum(f for f, _ in wg) / (sum(m for _, m in wg) * 1e-3) / 1e12, 2)}
                    if wg else {}),
                 **({'note': 'achieved = fp32-equivalent FLOP/s (2*Cin*Cout*9 per output); peak = dense fp16 MFMA peak x 9/28 '

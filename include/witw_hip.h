@@ -201,6 +201,11 @@ int witw_triplet_loss_bwd(const float* distance, const float* workspace, const f
  * 16-channel chunk per MFMA, the ninth tap of an even chunk shares its MFMA with the ninth tap of the next chunk), 0 =
  * v_mfma_f32_32x32x16_bf16. enable < 0 only queries; returns the previous setting. Results agree to one bf16 ulp. */
 int witw_conv3x3_bf16_mfma16(int enable);
+/* 1 (default): plain bf16 forwards with 64 input channels (layer 5 of the trunk, model/cvig_fov.py:261-262) and H % 8 == 0,
+ * W % 32 == 0, Cout % 64 == 0, >= 4096 (8 x 32 tile, 64-channel block) units run on the kernel that keeps the filter block in
+ * LDS (csrc/conv3x3_bf16_wres.hip); 0: on the tiled kernels. enable < 0 only queries; returns the previous setting. Bit-identical
+ * to the 32x32x16 tiled kernel. */
+int witw_conv3x3_bf16_wres(int enable);
 long long witw_conv3x3_bf16_packed_elems(int cout, int cin);
 int witw_conv3x3_bf16_pack_weights(const float* w_kcrs, void* wpk_bf16, int cout, int cin, void* stream);
 /* transpose_flip != 0: the dgrad filter of the source tensor [cin][cout][3][3] (cout, cin describe the packed filter) */

@@ -91,6 +91,39 @@ def test_bf16_large_grid_kernels_vs_oracle(case):
     _assert_bf16_ulp(y[sel].float().cpu().permute(0, 3, 1, 2), ref)
 
 
+# (B, H, W, Cout, circular, relu): 64 input channels, >= 4096 (tile, channel block) units -> the weight-resident kernel
+WRES_CASES = [(64, 64, 256, 128, True, True), (32, 64, 256, 128, False, True), (64, 64, 256, 64, True, False), (22, 64, 256, 192, True, True),
+              (128, 32, 128, 128, False, True)]
+
+
+@pytest.mark.parametrize('case', WRES_CASES)
+def test_bf16_weight_resident_kernel_vs_oracle_and_tiled_kernel(case):
+    """conv3x3_bf16_wres_kernel (layer 5 of the trunk at bench batch sizes: the filter block stays in LDS, persistent workgroups)
+    against the oracle at one bf16 unit in the last place on a spread of images, and BITWISE against the 32x32x16 tiled kernel on
+    the whole batch (same products, same fp32 accumulation order)."""
+    from witw_amd import ops
+    B, H, W, cout, circ, relu = case
+    x, w, b = _layer(35, B, H, W, 64, cout)
+    x = x.bfloat16().float()
+    dev = torch.device('cuda:0')
+    pk = ops.PackedConvBf16(w.to(dev), b.to(dev))
+    xd = x.to(dev).permute(0, 2, 3, 1).contiguous().bfloat16()
+    assert ops.bf16_wres() is True
+    y = ops.conv3x3_bf16_fwd(xd, pk, circular=circ, relu=relu)
+    assert ops.last_kernel_variant() == 'conv3x3_bf16_wres_kernel', ops.last_kernel_variant()
+    prev_w, prev_s = ops.bf16_wres(False), ops.bf16_mfma16(False)
+    try:
+        tiled = ops.conv3x3_bf16_fwd(xd, pk, circular=circ, relu=relu)
+        assert ops.last_kernel_variant().startswith('conv3x3_nhwc_bf16_kernel<'), ops.last_kernel_variant()
+    finally:
+        ops.bf16_wres(prev_w)
+        ops.bf16_mfma16(prev_s)
+    assert torch.equal(y.view(torch.int16), tiled.view(torch.int16))
+    sel = _pick(B)
+    ref = _ref(x[sel], w.bfloat16().float(), b, 1, circ, relu, False)
+    _assert_bf16_ulp(y[sel].float().cpu().permute(0, 3, 1, 2), ref)
+
+
 def test_bf16_large_grid_fp32_nchw_output_vs_oracle():
     """the embedding layer's form (fp32 NCHW out, no ReLU) on an 8-wave grid: exact products, fp32 sums"""
     from witw_amd import ops
@@ -192,8 +225,9 @@ def test_bf16_encoder_at_bench_batch_vs_emulation(variant, monkeypatch):
         del ran[:]
         enc = mod.FOV_DSM(circ_padding=circ, weights=w).cuda().eval()
         e = enc.forward_bf16(x.cuda()).cpu()
-        # layers 5,7 | 10,12,14 | 17,19,21 | 23 | 25, 27 (0 and 2 are the fused first-two-layers kernel)
-        assert ran == ['conv3x3_bf16_s16_kernel<false,false>', 'conv3x3_bf16_s16_kernel<true,false>',
+        # layers 5,7 | 10,12,14 | 17,19,21 | 23 | 25, 27 (0 and 2 are the fused first-two-layers kernel; 5 = 64 input channels: the
+        # weight-resident kernel)
+        assert ran == ['conv3x3_bf16_wres_kernel', 'conv3x3_bf16_s16_kernel<true,false>',
                        'conv3x3_bf16_s16_kernel<false,false>', 'conv3x3_bf16_s16_kernel<false,false>', 'conv3x3_bf16_s16_kernel<true,false>',
                        'conv3x3_bf16_s16_kernel<false,false>', 'conv3x3_bf16_s16_kernel<false,false>', 'conv3x3_bf16_s16_kernel<false,false>',
                        'conv3x3_nhwc_bf16_kernel<128,2,false,4>', 'conv3x3_nhwc_bf16_kernel<64,2,false,4>',

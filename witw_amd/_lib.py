@@ -42,6 +42,7 @@ SIGNATURES = {
     'witw_conv3x3_first_pack': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     'witw_conv3x3_first_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
     'witw_conv3x3_bf16_mfma16': (c_int, [c_int]),
+    'witw_conv3x3_bf16_wres': (c_int, [c_int]),
     'witw_conv3x3_bf16_packed_elems': (c_longlong, [c_int, c_int]),
     'witw_conv3x3_bf16_pack_weights': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     'witw_conv3x3_bf16_pack_weights_ex': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

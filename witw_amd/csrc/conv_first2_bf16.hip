@@ -21,6 +21,7 @@
 //      conv3x3_nhwc_bf16_kernel (chunk-major, tap-minor): bit-identical to the unfused launches
 //   D  bias + ReLU + 2x2 max, through a wave-private 1 KB slab to 16-byte NHWC stores.
 #include "common.h"
+#include "lds_frag.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <type_traits>
@@ -30,7 +31,6 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int F2T = 512;                 // 8 waves, two per SIMD (the layer-0 phase is VALU-heavy: two waves keep a SIMD's vector issue full)
 constexpr int TH2 = 8, TW2 = 32;         // layer-2 output tile
@@ -40,46 +40,6 @@ constexpr int APITCH = 48;               // LDS row pitch of that tile in positi
 constexpr int APOS = AH * APITCH;        // 480 slots per channel group
 constexpr int RH = TH2 + 4, RW = TW2 + 4;          // raw tile: 12 x 36 pixels
 constexpr int NMT0 = (AH * AW + 31) / 32;          // 11 M-tiles of layer 0
-
-__device__ __forceinline__ unsigned lds_address(const void* p) {
-    return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)p;
-}
-__device__ __forceinline__ u32x4 lds_read128(unsigned addr) {
-    u32x4 v;
-    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
-    return v;
-}
-// s_waitcnt lgkmcnt(n) that names the fragments it releases, so that the MFMAs reading them cannot be scheduled above it
-__device__ __forceinline__ void lds_wait(int n, u32x4& a) {
-    switch (n) {      // n is a constant once the caller's loop is unrolled
-    case 0: asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a)); break;
-    case 1: asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(a)); break;
-    case 2: asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a)); break;
-    case 3: asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(a)); break;
-    case 4: asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a)); break;
-    case 5: asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(a)); break;
-    case 6: asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(a)); break;
-    case 7: asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(a)); break;
-    case 8: asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(a)); break;
-    case 9: asm volatile("s_waitcnt lgkmcnt(9)" : "+v"(a)); break;
-    default: asm volatile("s_waitcnt lgkmcnt(10)" : "+v"(a)); break;
-    }
-}
-__device__ __forceinline__ void lds_wait(int n, u32x4& a, u32x4& b) {
-    switch (n) {
-    case 0: asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b)); break;
-    case 1: asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(a), "+v"(b)); break;
-    case 2: asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a), "+v"(b)); break;
-    case 3: asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(a), "+v"(b)); break;
-    case 4: asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a), "+v"(b)); break;
-    case 5: asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(a), "+v"(b)); break;
-    case 6: asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(a), "+v"(b)); break;
-    case 7: asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(a), "+v"(b)); break;
-    case 8: asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(a), "+v"(b)); break;
-    case 9: asm volatile("s_waitcnt lgkmcnt(9)" : "+v"(a), "+v"(b)); break;
-    default: asm volatile("s_waitcnt lgkmcnt(10)" : "+v"(a), "+v"(b)); break;
-    }
-}
 
 struct First2Args {
     const float* x;           // NCHW fp32 [B,C,H,W]

@@ -1027,6 +1027,12 @@ def bf16_mfma16(enable=None):
     return bool(_lib.load().witw_conv3x3_bf16_mfma16(-1 if enable is None else int(bool(enable))))
 
 
+def bf16_wres(enable=None):
+    """Weight-resident kernel for the 64-input-channel bf16 forward (layer 5): True = on (default), False = tiled kernels; None
+    only queries. Returns the previous setting (witw_conv3x3_bf16_wres)."""
+    return bool(_lib.load().witw_conv3x3_bf16_wres(-1 if enable is None else int(bool(enable))))
+
+
 class PackedConvBf16:
     """bf16 filter packing of one 3x3 conv for the bf16 MFMA kernel + fp32 bias padded to the channel tile."""
 
@@ -1099,7 +1105,9 @@ def conv3x3_bf16_fwd(x_nhwc, packed, stride_h=1, circular=False, relu=True, pool
                'witw_conv3x3_bf16_fwd_ex')
     if prof is not None:
         e1.record()
-        prof.append((('bf16', lib.witw_conv3x3_tile_n(packed.cout), stride_h, bool(pool)),
+        # the 64-input-channel layer runs on its own kernel (csrc/conv3x3_bf16_wres.hip): its own launch class
+        kind = 'bf16_wres' if last_kernel_variant() == 'conv3x3_bf16_wres_kernel' else 'bf16'
+        prof.append(((kind, lib.witw_conv3x3_tile_n(packed.cout), stride_h, bool(pool)),
                      2.0 * packed.cin * packed.cout * 9 * Ho * W * B, e0, e1))
     if want_pool_code:
         return y, code
