@@ -42,4 +42,23 @@ bool witw_bf16_wres_applies(int B, int H, int W, int Cin, int Cout);
 int witw_bf16_wres_launch(const void* x, const void* wpk, const float* bias, void* y, int B, int H, int W, int Cout, int pad_circular,
                           int relu, void* stream);
 
+// ReLU on PACKED bf16 pairs: max as signed 16-bit integers against `floor2` -- a negative float is a negative integer (and -0
+// becomes +0), a positive one is itself; floor2 = 0 is the ReLU, 0x80008000 (the smallest integers) leaves the pair unchanged, so
+// a run-time "relu" flag costs no select. One v_pk_max_i16 per two values, after the conversion, instead of a v_max_f32 (two when
+// the operand has to be canonicalised first) and a select per value. Same bits as relu-then-round (rounding keeps the sign);
+// a NaN with the sign bit clear stays a NaN.
+#if defined(__HIPCC__)
+__device__ __forceinline__ unsigned witw_pack_bf16x2(float lo, float hi) {
+    // the instruction (__bf16)x compiles to (round to nearest even), written out: left to the compiler a pair that is then used as
+    // an integer is converted one value at a time and joined by a v_perm_b32
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ unsigned witw_relu_bf16x2(unsigned pair, unsigned floor2) {
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, pair), __builtin_bit_cast(s16x2, floor2)));
+}
+#endif
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

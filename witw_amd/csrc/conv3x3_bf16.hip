@@ -1005,12 +1005,12 @@ __global__ __launch_bounds__(512) void conv3x3_bf16_s16_kernel(ConvBfArgs p) {
         bv[bt] = p.bias[cb + 16 * bt + l15];
         if (TRAIN && p.dropmask != nullptr && cb + 16 * bt + l15 < p.Cout) dm[bt] = p.dropmask[(size_t)b * p.Cout + cb + 16 * bt + l15];
     }
-    auto fin = [&](float v, int bt) {      // conv + bias -> Dropout2d scale -> ReLU
+    auto fin = [&](float v, int bt) {      // conv + bias -> Dropout2d scale; the ReLU is applied to the packed bf16 pairs in flush()
         v += bv[bt];
         if (TRAIN) v *= dm[bt];
-        if (p.relu) v = fmaxf(v, 0.f);
         return v;
     };
+    const unsigned relu_floor = p.relu ? 0u : 0x80008000u;
     const int Hy = POOL ? (p.Ho >> 1) : p.Ho;
     const int Wy = POOL ? (p.Wo >> 1) : p.Wo;
     float* slab = reinterpret_cast<float*>((wave & 1) ? stageB : stageA) + (wave >> 1) * (32 * SLAB_P);
@@ -1022,12 +1022,12 @@ __global__ __launch_bounds__(512) void conv3x3_bf16_s16_kernel(ConvBfArgs p) {
             const int m = g * 8 + prow;
             const f32x4 v0 = *reinterpret_cast<const f32x4*>(slab + m * SLAB_P + pc8);
             const f32x4 v1 = *reinterpret_cast<const f32x4*>(slab + m * SLAB_P + pc8 + 4);
-            bf16x8 o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                o[e] = (__bf16)v0[e];
-                o[4 + e] = (__bf16)v1[e];
-            }
+            u32x4 ob;
+            ob[0] = witw_relu_bf16x2(witw_pack_bf16x2(v0[0], v0[1]), relu_floor);
+            ob[1] = witw_relu_bf16x2(witw_pack_bf16x2(v0[2], v0[3]), relu_floor);
+            ob[2] = witw_relu_bf16x2(witw_pack_bf16x2(v1[0], v1[1]), relu_floor);
+            ob[3] = witw_relu_bf16x2(witw_pack_bf16x2(v1[2], v1[3]), relu_floor);
+            bf16x8 o = __builtin_bit_cast(bf16x8, ob);
             const int xx = xbase + m;
             if (yy < Hy && xx < Wy && nbase < p.Cout) {
                 const size_t off = (((size_t)b * Hy + yy) * Wy + xx) * p.Cout + nbase;

@@ -135,7 +135,7 @@ __global__ __launch_bounds__(WRT, 1) void conv3x3_bf16_wres_kernel(WresArgs p) {
     const int prow = wave >> 1, chalf = wave & 1;
     const int a_lane = ((2 * prow + (l31 >> 4)) * WPITCH + 16 * chalf + (l31 & 15));
     unsigned char* slab = reinterpret_cast<unsigned char*>(slab_s) + wave * SLAB_BYTES;
-    const float floor_v = p.relu ? 0.f : -__builtin_inff();      // ReLU as max(v, 0), no ReLU as max(v, -inf)
+    const unsigned relu_floor = p.relu ? 0u : 0x80008000u;      // witw_relu_bf16x2
 
     // The first tile's input goes to LDS here, every later one at the bottom of the loop: ONE place inside the loop where the
     // prefetched registers are consumed, always behind the same sequence (6 loads, then the 4 output stores), so that its wait is
@@ -150,6 +150,10 @@ __global__ __launch_bounds__(WRT, 1) void conv3x3_bf16_wres_kernel(WresArgs p) {
     for (int k = 0; k < WNIN; ++k) fetch_one(k);
     to_lds();
     __syncthreads();                                // filter and first input tile in LDS
+    // everything loaded so far (filter fragments, biases) has landed: said with the builtin, so that the compiler's counter
+    // bookkeeping enters the loop clean -- otherwise the first use of such a register INSIDE the loop carries a vmcnt(0) in every
+    // iteration, i.e. a wait for the prefetch loads issued just before it
+    __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0), expcnt / lgkmcnt untouched
     int iter = 0;
     for (int t = t_first; t < p.n_sp; t += t_step, ++iter) {
         const bool rec = REC && blockIdx.x == 0 && iter == 2 && lane == 0 && (wave == 0 || wave == 7);
@@ -222,12 +226,10 @@ __global__ __launch_bounds__(WRT, 1) void conv3x3_bf16_wres_kernel(WresArgs p) {
                 for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        bf16x4 o;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            o[e] = (__bf16)fmaxf(acc[nt][4 * j + e] + bv[nt][4 * j + e], floor_v);
-                        }
-                        *reinterpret_cast<u32x2*>(dst + (nt * 32 + 8 * j) * 2) = __builtin_bit_cast(u32x2, o);
+                        u32x2 ob;
+                        ob[0] = witw_relu_bf16x2(witw_pack_bf16x2(acc[nt][4 * j] + bv[nt][4 * j], acc[nt][4 * j + 1] + bv[nt][4 * j + 1]), relu_floor);
+                        ob[1] = witw_relu_bf16x2(witw_pack_bf16x2(acc[nt][4 * j + 2] + bv[nt][4 * j + 2], acc[nt][4 * j + 3] + bv[nt][4 * j + 3]), relu_floor);
+                        *reinterpret_cast<u32x2*>(dst + (nt * 32 + 8 * j) * 2) = ob;
                     }
             }
             wres_wave_sync();

@@ -50,7 +50,7 @@ struct First2Args {
     unsigned short* y;        // NHWC bf16 [B,H/2,W/2,64]
     int B, C, H, W;
     int tiles_x, tiles_y;
-    long long n_tiles;
+    int n_tiles;
     int circ;
 };
 
@@ -88,57 +88,41 @@ __global__ __launch_bounds__(F2T, 1) void conv_first2_bf16_kernel(First2Args p) 
 #pragma unroll
     for (int r = 0; r < 16; ++r) b0r[r] = p.bias0[nt0 * 32 + 8 * (r >> 2) + 4 * hq + (r & 3)];
 
-    // raw pixels of this thread (tile-relative; 432 pixels over 256 threads), fetched one tile ahead
+    // raw pixels of this thread (tile-relative; 432 pixels, one per thread), fetched one tile ahead. Buffer loads over the image's C
+    // planes: a channel >= C, a row / column outside the picture and a tile past the end are out-of-range offsets or an empty
+    // descriptor (zeros) -- straight-line code, so the wait in front of the conversion below counts exactly these loads.
     constexpr int NRAW = (RH * RW + F2T - 1) / F2T;
+    constexpr unsigned OOR = 0xfffffff0u;
     float rv[NRAW][CW];
-    auto fetch_raw = [&](long long tile) {
+    const unsigned img_bytes = (unsigned)p.C * (unsigned)plane * 4u;       // < 2^31 (checked by the launcher)
+    const int tiles_img = p.tiles_x * p.tiles_y;
+    auto fetch_raw = [&](int tile) {
+        const bool any = tile < p.n_tiles;
+        const int tt = any ? tile : 0;
+        const int b = tt / tiles_img, rem = tt - b * tiles_img;
+        const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+        const unsigned char* img = reinterpret_cast<const unsigned char*>(p.x) + (size_t)b * img_bytes;
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)img, 0, any ? img_bytes : 0u, 0x00020000);
 #pragma unroll
         for (int k = 0; k < NRAW; ++k) {
-#pragma unroll
-            for (int ch = 0; ch < CW; ++ch) rv[k][ch] = 0.f;
             const int s = tid + k * F2T;
-            if (s >= RH * RW || tile >= p.n_tiles) continue;
             const int rr = s / RW, rc = s - rr * RW;
-            const int tiles_img = p.tiles_x * p.tiles_y;
-            const int b = (int)(tile / tiles_img);
-            const int rem = (int)(tile - (long long)b * tiles_img);
-            const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
             const int gr = ty * TH2 - 2 + rr;
             int gc = tx * TW2 - 2 + rc;
-            bool ok = gr >= 0 && gr < p.H;
+            bool ok = s < RH * RW && gr >= 0 && gr < p.H;
             if (p.circ) {
-                gc %= p.W;
-                if (gc < 0) gc += p.W;
+                if (p.W >= RW) gc = gc < 0 ? gc + p.W : (gc >= p.W ? gc - p.W : gc);      // gc in [-2, W + 33]: one wrap
+                else { gc %= p.W; if (gc < 0) gc += p.W; }
             } else {
                 ok = ok && gc >= 0 && gc < p.W;
             }
-            if (ok) {
-                const float* src = p.x + (size_t)b * p.C * plane + (size_t)gr * p.W + gc;
+            const unsigned off = ok ? (unsigned)(gr * p.W + gc) * 4u : OOR;
 #pragma unroll
-                for (int ch = 0; ch < CW; ++ch)
-                    if (ch < p.C) rv[k][ch] = src[ch * plane];
-            }
+            for (int ch = 0; ch < CW; ++ch)       // plane ch of the image; ch >= C lies behind the descriptor's end
+                rv[k][ch] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, (unsigned)ch * (unsigned)plane * 4u, 0));
         }
     };
-
-    // layer-2 roles: wave = (row pair, column half); M-tile = 2 rows x 16 columns, lane l31 -> (row l31 >> 4, column l31 & 15)
-    const int prow = wave >> 1, chalf = wave & 1;
-    const int a_lane = ((2 * prow + (l31 >> 4)) * APITCH + 16 * chalf + (l31 & 15));      // + (kh * APITCH + kw) per tap
-
-    fetch_raw(blockIdx.x);
-    int iter = 0;
-    for (long long tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x, ++iter) {
-        const bool rec = REC && blockIdx.x == 0 && iter == 2 && lane == 0 && (wave == 0 || wave == 7);
-        auto stamp = [&](int k) { if (rec) f2_stamps[wave == 7][k] = __builtin_amdgcn_s_memtime(); };
-        stamp(0);
-        const int tiles_img = p.tiles_x * p.tiles_y;
-        const int b = (int)(tile / tiles_img);
-        const int rem = (int)(tile - (long long)b * tiles_img);
-        const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
-        const int oy0 = ty * TH2, ox0 = tx * TW2;
-        const bool border = oy0 == 0 || oy0 + TH2 + 1 > p.H || (!p.circ && (ox0 == 0 || ox0 + TW2 + 1 > p.W));      // wave-uniform
-
-        // ---- A: raw pixels -> LDS (bf16)
+    auto raw_to_lds = [&]() {                       // phase A: this thread's raw pixel -> LDS as bf16
 #pragma unroll
         for (int k = 0; k < NRAW; ++k) {
             const int s = tid + k * F2T;
@@ -149,10 +133,36 @@ __global__ __launch_bounds__(F2T, 1) void conv_first2_bf16_kernel(First2Args p) 
                 raw_s[s] = __builtin_bit_cast(pix_t, v);
             }
         }
+    };
+
+    // layer-2 roles: wave = (row pair, column half); M-tile = 2 rows x 16 columns, lane l31 -> (row l31 >> 4, column l31 & 15)
+    const int prow = wave >> 1, chalf = wave & 1;
+    const int a_lane = ((2 * prow + (l31 >> 4)) * APITCH + 16 * chalf + (l31 & 15));      // + (kh * APITCH + kw) per tap
+
+    // Phase A of the first tile runs here, of every later tile behind its predecessor's layer-2 loop: one place inside the loop
+    // where the prefetched registers are consumed, always behind the same sequence of memory operations, so that its wait counts
+    // exactly the prefetch loads -- reached from two paths of different depth (loop top) it is vmcnt(0), which also waits for the
+    // previous tile's output store: a store round trip per tile.
+    fetch_raw(blockIdx.x);
+    raw_to_lds();
+    // everything loaded so far (filter fragments, biases) has landed: said with the builtin, so that the compiler's counter
+    // bookkeeping enters the loop clean -- otherwise the first use of such a register INSIDE the loop carries a vmcnt(0) in every
+    // iteration, i.e. a wait for the prefetch loads issued just before it
+    __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0), expcnt / lgkmcnt untouched
+    int iter = 0;
+    for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x, ++iter) {
+        const bool rec = REC && blockIdx.x == 0 && iter == 2 && lane == 0 && (wave == 0 || wave == 7);
+        auto stamp = [&](int k) { if (rec) f2_stamps[wave == 7][k] = __builtin_amdgcn_s_memtime(); };
+        stamp(0);
+        const int b = tile / tiles_img, rem = tile - b * tiles_img;
+        const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+        const int oy0 = ty * TH2, ox0 = tx * TW2;
+        const bool border = oy0 == 0 || oy0 + TH2 + 1 > p.H || (!p.circ && (ox0 == 0 || ox0 + TW2 + 1 > p.W));      // wave-uniform
+
         stamp(1);
         __syncthreads();          // raw tile visible; every wave has left the previous tile's layer-2 loop (a_s is free)
         stamp(2);
-        fetch_raw(tile + gridDim.x);
+        fetch_raw(tile + (int)gridDim.x);
 
         // ---- B: layer 0 on the 10 x 34 positions: 11 M-tiles x 2 N-tiles = 22 units over the 8 waves, three per wave (the last
         // one of waves 6 and 7 repeats unit 2 and is not written). All raw operands of the three units are read first, then the
@@ -210,10 +220,9 @@ __global__ __launch_bounds__(F2T, 1) void conv_first2_bf16_kernel(First2Args p) 
                     unsigned char* dst = reinterpret_cast<unsigned char*>(a_s) + ((size_t)(qr[k] * APITCH + qc[k])) * 16 + 8 * hq;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {           // registers 4j..4j+3 = channels nt0*32 + 8j + 4hq + {0..3}
-                        bf16x4 o;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = (__bf16)fmaxf(acc0[k][4 * j + e], 0.f);
-                        u32x2 ob = __builtin_bit_cast(u32x2, o);
+                        u32x2 ob;                               // ReLU on the packed pairs (common.h)
+                        ob[0] = witw_relu_bf16x2(witw_pack_bf16x2(acc0[k][4 * j], acc0[k][4 * j + 1]), 0u);
+                        ob[1] = witw_relu_bf16x2(witw_pack_bf16x2(acc0[k][4 * j + 2], acc0[k][4 * j + 3]), 0u);
                         if (outside) ob = (u32x2){0u, 0u};
                         *reinterpret_cast<u32x2*>(dst + (size_t)(nt0 * 4 + j) * (APOS * 16)) = ob;
                     }
@@ -270,6 +279,12 @@ __global__ __launch_bounds__(F2T, 1) void conv_first2_bf16_kernel(First2Args p) 
         }
 
         stamp(5);
+        // ---- A (next tile): raw_s was last read in phase B, a barrier ago. Before D, so that the tile's output store is issued
+        // AFTER these registers' loads have been waited for (the other way round the last wait is vmcnt(0): the store's round trip).
+        // The wait is stated here for every wave: inside raw_to_lds it sits behind a branch that the waves without a raw pixel
+        // skip, and a load left "pending" on that path costs a vmcnt(0) at the loop top, i.e. behind the store.
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        raw_to_lds();
         // ---- D: bias + ReLU + 2x2 max-pool -> slab [pooled column 0..7][64 channels] bf16 -> 16-byte stores
         // register r <-> pixel m = (r&3) + 8*(r>>2) + 4*hq of the M-tile, m = 16*row + column: the window of pooled column
         // jp = (r&3)/2 + 4*((r>>2)&1) + 2*hq is registers {r, r+1, r+8, r+9} (r&3 in {0,2}, r < 8)
@@ -310,7 +325,9 @@ int witw_conv_first2_bf16_fwd(const float* x, const void* wf0, const float* bias
     a.x = x; a.wf0 = (const u32x4*)wf0; a.bias0 = bias0; a.wpk2 = (const u32x4*)wpk2; a.bias2 = bias2; a.y = (unsigned short*)y;
     a.B = B; a.C = C; a.H = H; a.W = W;
     a.tiles_x = cdiv(W, TW2); a.tiles_y = cdiv(H, TH2);
-    a.n_tiles = (long long)B * a.tiles_x * a.tiles_y;
+    const long long n_tiles = (long long)B * a.tiles_x * a.tiles_y;
+    WITW_CHECK_ARG(n_tiles < 0x7fffffffLL && (unsigned long long)C * H * W * 4 < 0x80000000ull, "conv_first2_bf16: tensor too large");
+    a.n_tiles = (int)n_tiles;
     a.circ = pad_circular;
     static int n_cu = 0;        // persistent workgroups, one per CU (150 KB of LDS each)
     if (n_cu == 0) {
@@ -320,7 +337,7 @@ int witw_conv_first2_bf16_fwd(const float* x, const void* wf0, const float* bias
         if (n_cu <= 0) n_cu = 256;
     }
     const unsigned grid = (unsigned)(a.n_tiles < n_cu ? a.n_tiles : n_cu);
-    const bool rec = getenv("WITW_F2_STAMPS") != nullptr && a.n_tiles >= 3LL * grid;      // diagnostic, synchronous
+    const bool rec = getenv("WITW_F2_STAMPS") != nullptr && a.n_tiles >= 3 * (int)grid;      // diagnostic, synchronous
     if (rec && C > 4)
         hipLaunchKernelGGL((conv_first2_bf16_kernel<8, true>), dim3(grid), dim3(F2T), 0, (hipStream_t)stream, a);
     else if (C <= 4)
