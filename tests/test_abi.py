@@ -122,3 +122,21 @@ def test_s16_register_allocation_guard(tmp_path, monkeypatch):
     assert not os.path.exists(build.S16_MARKER)
     build._check_s16('')               # a compiler that reports nothing is not a validated one
     assert os.path.exists(build.S16_MARKER)
+
+
+def test_wres_register_allocation_guard(tmp_path, monkeypatch):
+    """the same guard for conv3x3_bf16_wres_kernel (layer 5 falls back to the tiled kernels when the allocation is not the validated
+    one), and the in-tree build must be a validated one: no marker next to the library the suite loads"""
+    from witw_amd import build
+    assert not os.path.exists(build.WRES_MARKER) and not os.path.exists(build.S16_MARKER)
+    monkeypatch.setattr(build, 'WRES_MARKER', str(tmp_path / 'wres_unvalidated'))
+    (v, sp, sc), = build.WRES_VALIDATED.values()
+    inst, = build.WRES_VALIDATED.keys()
+    good = ('remark: Function Name: _ZN12_GLOBAL__N_124conv3x3_bf16_wres_kernel%svNS_8WresArgsE [-Rpass]\nremark:     VGPRs: %d [-R]\n'
+            'remark:     ScratchSize [bytes/lane]: %d [-R]\nremark:     VGPRs Spill: %d [-R]\n' % (inst, v, sc, sp))
+    build._check_wres(good)
+    assert not os.path.exists(build.WRES_MARKER)
+    build._check_wres(good.replace('VGPRs Spill: 0', 'VGPRs Spill: 3'))
+    assert inst in open(build.WRES_MARKER).read()
+    build._check_wres(good)
+    assert not os.path.exists(build.WRES_MARKER)

@@ -155,6 +155,12 @@ def load():
                       '32x32x16 bf16 kernel. Re-run the bf16 parity tests with WITW_BF_S16=1 and update build.S16_VALIDATED.'
                       % open(_build.S16_MARKER).read().strip().replace('\n', '; '))
         lib.witw_conv3x3_bf16_mfma16(0)
+    if path == _build.LIB and os.path.exists(_build.WRES_MARKER) and 'WITW_BF_WRES' not in os.environ:
+        import warnings
+        warnings.warn('libwitw_hip: conv3x3_bf16_wres_kernel was compiled with an unvalidated register allocation (%s); layer 5 runs on '
+                      'the tiled bf16 kernels. Re-run tests/test_large_grid_parity_gpu.py with WITW_BF_WRES=1 and update build.WRES_VALIDATED.'
+                      % open(_build.WRES_MARKER).read().strip().replace('\n', '; '))
+        lib.witw_conv3x3_bf16_wres(0)
     return lib
 
 

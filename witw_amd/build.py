@@ -84,6 +84,47 @@ def _check_s16(remarks):
         os.remove(S16_MARKER)
 
 
+# The same for conv3x3_bf16_wres_kernel (hand-issued fragment reads of lds_frag.h): a different allocation switches layer 5 back to
+# the tiled kernels (witw_conv3x3_bf16_wres(0)) until tests/test_large_grid_parity_gpu.py (bitwise against the 32x32x16 kernel) has
+# been re-run and this entry updated; WITW_BF_WRES=1 forces the kernel.
+WRES_VALIDATED = {'ILb0EE': (256, 0, 0)}       # <REC = false>
+WRES_MARKER = os.path.join(HERE, 'build', 'wres_unvalidated')
+
+
+def _check_wres(remarks):
+    import re
+    found, cur = {}, None
+    for line in remarks.splitlines():
+        m = re.search(r'Function Name: \S*conv3x3_bf16_wres_kernel(ILb[01]EE)', line)
+        if m:
+            cur = m.group(1)
+            found[cur] = {}
+            continue
+        if 'Function Name:' in line:
+            cur = None
+        if cur is None:
+            continue
+        for key, pat in (('vgprs', r' VGPRs: (\d+)'), ('spill', r'VGPRs Spill: (\d+)'), ('scratch', r'ScratchSize \[bytes/lane\]: (\d+)')):
+            m = re.search(pat, line)
+            if m:
+                found[cur][key] = int(m.group(1))
+    bad = []
+    for inst, want in WRES_VALIDATED.items():
+        got = found.get(inst)
+        if not got or (got.get('vgprs'), got.get('spill'), got.get('scratch')) != want:
+            bad.append('%s: validated %s, this compiler %s' % (inst, want, got))
+    if bad:
+        with open(WRES_MARKER, 'w') as f:
+            f.write('\n'.join(bad) + '\n')
+        print('WARNING: conv3x3_bf16_wres_kernel compiled with a register allocation that has not been validated; layer 5 runs on the '
+              'tiled kernels instead (see witw_amd/build.py WRES_VALIDATED):\n  ' + '\n  '.join(bad), flush=True)
+    elif os.path.exists(WRES_MARKER):
+        os.remove(WRES_MARKER)
+
+
+CHECKED = {'conv3x3_bf16.hip': lambda r: _check_s16(r), 'conv3x3_bf16_wres.hip': lambda r: _check_wres(r)}
+
+
 def _build_locked(verbose):
     objs = []
     procs = []
@@ -92,12 +133,12 @@ def _build_locked(verbose):
         obj = os.path.join(HERE, 'build', os.path.basename(src)[:-4] + '.o')
         objs.append(obj)
         cmd = [HIPCC] + FLAGS + ['-c', src, '-o', obj]
-        checked = os.path.basename(src) == 'conv3x3_bf16.hip'
+        checked = CHECKED.get(os.path.basename(src))
         if checked:
             cmd.insert(-4, '-Rpass-analysis=kernel-resource-usage')
         if verbose:
             print(' '.join(cmd), flush=True)
-        procs.append((cmd, subprocess.Popen(cmd, stderr=subprocess.PIPE if checked else None, text=checked or None), checked))
+        procs.append((cmd, subprocess.Popen(cmd, stderr=subprocess.PIPE if checked else None, text=True if checked else None), checked))
     for cmd, p, checked in procs:
         err = p.communicate()[1] if checked else None
         if p.wait() != 0:
@@ -105,7 +146,7 @@ def _build_locked(verbose):
                 sys.stderr.write(err)
             raise RuntimeError('hipcc failed: ' + ' '.join(cmd))
         if checked:
-            _check_s16(err or '')
+            checked(err or '')
     tmp = LIB + '.tmp.%d' % os.getpid()
     cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', tmp] + objs
     if verbose:
