@@ -641,6 +641,9 @@ int launch_conv_nw(ConvArgs a, hipStream_t st) {
     const long long sp_total = (long long)a.B * a.tiles_x * a.tiles_y;
     a.n_tiles = cdiv(a.Cout, TN);
     a.sp_per_xcd = (int)((sp_total + 7) / 8);
+    // fewer spatial tiles than XCDs: the XCD-aware order would put every workgroup (all n tiles and K slices of a spatial tile) on
+    // sp_total of the 8 XCDs -- cvig_baseline's last block, 2 mosaics x 4 n tiles x 32 K slices, ran on 64 of the 256 CUs
+    if (sp_total < 8) a.xcd_map = 0;
     const long long grid = a.xcd_map ? 8LL * a.sp_per_xcd * a.n_tiles : sp_total * a.n_tiles;
     if (grid <= 0 || grid > 0x7fffffffLL || sp_total > 0x7fffffffLL) {
         witw_set_error("conv3x3: grid %lld out of range", grid);
@@ -777,7 +780,9 @@ int witw_conv3x3_taps4_ksplit(int B, int H, int W, int Cin, int Cout) {
     if (forced > 0) S = forced;
     else if (wg < 512 && nkc >= 64) {
         S = (int)std::min<long long>(32, (1024 + wg - 1) / wg);
-        S = std::min(S, nkc / 32);
+        // at least 32 chunks per slice -- 8 when the whole launch would not even reach one workgroup per CU otherwise (the 1 x 1 map of
+        // cvig_baseline's last block: 8 tiles; 8 slices of 32 chunks ran 125 us on 64 CUs)
+        S = std::min(S, wg * (nkc / 32) >= 256 ? nkc / 32 : nkc / 8);
     }
     S = std::max(1, std::min(S, nkc));
     const int per = cdiv(nkc, S);
