@@ -574,7 +574,7 @@ def baseline_bench(a, device, full=True, B=32):
            'value': round(B / ms * 1e3, 2), 'unit': 'pairs/s', 'ms_per_step': round(ms, 3), 'steps': n, 'dtype': 'f32', 'loss': float(loss.item()),
            'n_gpus': 1, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'data': 'synthetic',
            'recall': {'top1_pct': float((ranks <= 1).float().mean().item() * 100)},
-           'roofline': {'bound': 'mfma', 'kernel': 'conv3x3_nhwc_f32_kernel<...,TAPS=4> (Conv2d(4,2,0) as space-to-depth(2) + the 2x2 live taps), all 14 launches of a step',
+           'roofline': {'bound': 'mfma', 'kernel': 'conv3x3_nhwc_f32_kernel<...,TAPS=4> (Conv2d(4,2,0) as space-to-depth(2) + the 2x2 live taps) x 12 + conv4x4s2_first_kernel (block 1 from the raw image) x 2: all conv launches of a step',
                         'achieved': round(tf, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tf / PEAK_F32_MFMA_TFLOPS, 4),
                         'launches': len(conv), 'avg_launch_ms': round(conv_ms / max(1, len(conv)), 4),
                         'note': 'algorithmic 2*Cin*Cout*16*Ho*Wo FLOP per launch; the conv launches take %.2f of the %.2f ms step' % (conv_ms / n, ms)}}

@@ -303,6 +303,13 @@ int witw_conv3x3_wgrad_taps4(const float* x, const float* dz, float* dw, float* 
 /* x NHWC [B,Hp,Wp,C] (NCHW if in_nchw) with valid region HxW -> NHWC [B,ceil(H/2),ceil(W/2),Cpad], channel
  * (dy*2+dx)*C+c; normalize=1 applies x/255, -1+2x (:265-266); scale/shift (NULL or [C]): per-channel affine of a
  * train-mode BatchNorm applied on the fly (also accepted by witw_gem_pool). */
+/* The FIRST block of an encoder in one launch (model/cvig_baseline.py:236-240 conv1/bn1, :265-268 the in-model x/255, -1+2x,
+ * LeakyReLU, eval-mode BatchNorm): x NCHW fp32 [B,C<=5,H,W] -> y [B, ceil(vh/2), ceil(vw/2), 256], the space-to-depth(2) image of
+ * the vh x vw = ((H-4)/2+1) x ((W-4)/2+1) valid outputs (zeros elsewhere) that the second block reads. w: torch layout
+ * [64][C][4][4]; scale / shift [64] (both or neither). Replaces witw_space_to_depth2(in_nchw, normalize) +
+ * witw_conv3x3_fwd_taps4_ex(s2d = 1) for that block. */
+int witw_conv4x4s2_first_fwd(const float* x, const float* w, const float* bias, const float* scale, const float* shift, float* y,
+                             int B, int C, int H, int W, int normalize, float lrelu_slope, void* stream);
 int witw_space_to_depth2(const float* x, float* y, int B, int Hp, int Wp, int H, int W, int C, int Cpad, int in_nchw,
                          int normalize, const float* scale, const float* shift, void* stream);
 /* Mosaic space-to-depth: x NHWC [B,H,W,C] (C % 4 == 0) -> y [ceil(B/g^2), g*ceil(H/2), g*ceil(W/2), 4C]: image b is cell b % g^2

@@ -337,3 +337,58 @@ def test_bn_lrelu_backward_against_autograd(case):
     assert float((got[:, :H, :W] - want).abs().max()) <= 2e-5 * scale
     assert float((dg.cpu().double() - gr.grad).abs().max()) <= 1e-5 * float(gr.grad.abs().max())
     assert float((db.cpu().double() - br.grad).abs().max()) <= 1e-5 * float(br.grad.abs().max())
+
+
+@pytest.mark.parametrize('case', [(2, 3, 500, 500), (3, 5, 382, 390), (1, 3, 448, 611), (4, 1, 65, 130)])
+def test_first_block_in_one_launch_vs_float64_and_two_launch_form(case):
+    """witw_conv4x4s2_first_fwd (normalisation + Conv2d(k=4,s=2) + LeakyReLU + eval BatchNorm affine, written as the second block's
+    space-to-depth input; model/cvig_baseline.py:236-240, 265-268) against the same arithmetic in float64 (torch conv2d) and against
+    the library's two-launch form (space_to_depth2(normalize) + 2x2-tap conv with the s2d epilogue): same zeros outside the valid
+    outputs, values within fp32 rounding of each other (different summation order)."""
+    from witw_amd import ops
+    B, C, H, W = case
+    g = np.random.Generator(np.random.Philox(key=[81, C * 1000 + H]))
+    dev = torch.device('cuda:0')
+    x = torch.from_numpy(g.integers(0, 256, (B, C, H, W)).astype(np.float32))
+    w = torch.from_numpy(g.standard_normal((64, C, 4, 4), dtype=np.float32) * 0.1)
+    b = torch.from_numpy(g.standard_normal((64,), dtype=np.float32) * 0.1)
+    sc = torch.from_numpy(1 + 0.1 * g.standard_normal((64,), dtype=np.float32))
+    sh = torch.from_numpy(0.1 * g.standard_normal((64,), dtype=np.float32))
+    y = ops.conv4x4s2_first(x.to(dev), w.to(dev), b.to(dev), sc.to(dev), sh.to(dev))
+    assert ops.last_kernel_variant() == 'conv4x4s2_first_kernel<%d>' % C
+    vh, vw = (H - 4) // 2 + 1, (W - 4) // 2 + 1
+    xn = -1.0 + 2.0 * (x.double() / 255.0)
+    ref = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(xn, w.double(), b.double(), stride=2), 0.2)
+    ref = ref * sc.double()[None, :, None, None] + sh.double()[None, :, None, None]          # [B,64,vh,vw]
+    full = torch.zeros((B, 64, 2 * ((vh + 1) // 2), 2 * ((vw + 1) // 2)), dtype=torch.float64)
+    full[:, :, :vh, :vw] = ref
+    want = torch.cat([full[:, :, dy::2, dx::2] for dy in (0, 1) for dx in (0, 1)], dim=1).permute(0, 2, 3, 1)      # channel (dy*2+dx)*64 + n
+    got = y.cpu().double()
+    assert got.shape == want.shape
+    assert float((got - want).abs().max()) <= 2e-6 * float(want.abs().max())
+    outside = want == 0
+    assert bool((got[outside] == 0).all())
+    # the two-launch form of the same block
+    cpad = (4 * C + 7) // 8 * 8
+    k3 = ops.conv4x4_to_k3(w.to(dev), cpad)
+    packed = ops.PackedConv(k3, b.to(dev), taps4=True)
+    h = ops.space_to_depth2(x.to(dev), in_nchw=True, normalize=True, cpad=cpad)
+    two = ops.conv_taps4_s2d(h, packed, (vh, vw), lrelu_slope=0.2, post_scale=sc.to(dev), post_shift=sh.to(dev))
+    assert two.shape == y.shape
+    assert float((two - y).abs().max()) <= 2e-6 * float(want.abs().max())
+    assert bool(((two == 0) == (y == 0)).all()) or float(((two == 0) != (y == 0)).float().mean()) < 1e-6
+
+
+def test_baseline_eval_forward_with_and_without_the_fused_first_block():
+    """SurfaceEncoder's eval forward through witw_conv4x4s2_first_fwd equals the forward through the re-layout pass + 2x2-tap conv to
+    fp32 rounding (1e-5 of the embedding scale), for 3-band and 5-input (orientation) encoders."""
+    from witw_amd import cvig_baseline
+    for orientation, C in ((False, 3), (True, 5)):
+        torch.manual_seed(5)
+        enc = cvig_baseline.SurfaceEncoder(orientation=orientation).cuda().eval()
+        x = torch.from_numpy(synth.images_u8(11, 3, (3, C, 400, 420))).cuda()
+        enc.fused_first = True
+        a = enc(x)
+        enc.fused_first = False
+        b = enc(x)
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())

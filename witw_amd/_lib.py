@@ -66,6 +66,7 @@ SIGNATURES = {
     'witw_split_f16_to_octet': (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
     'witw_conv3x3_wgrad_f16x3_workspace_floats': (c_longlong, [c_int] * 6),
     'witw_conv3x3_wgrad_f16x3': (c_int, [c_void_p] * 6 + [c_int] * 9 + [c_void_p]),
+    'witw_conv4x4s2_first_fwd': (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_float, c_void_p]),
     'witw_space_to_depth2': (c_int, [c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p, c_void_p]),
     'witw_space_to_depth2_mosaic': (c_int, [c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]),
     'witw_taps4_splitk_finish': (c_int, [c_void_p, c_int, c_void_p, c_int, c_float] + [c_void_p] * 3 + [c_int] * 7 + [c_void_p]),

@@ -161,6 +161,7 @@ class SurfaceEncoder(nn.Module):
             setattr(self, 'conv%d' % i, conv)
             setattr(self, 'bn%d' % i, bn)
         self._packed = {}
+        self.fused_first = True       # eval forward: block 1 by witw_conv4x4s2_first_fwd (False: space-to-depth pass + 2x2-tap conv)
 
     def _layer(self, i, fold=True):
         """-> (packed 2x2-tap filter, eval-mode BatchNorm scale, shift, padded input channels). fold=False (the training forward:
@@ -226,13 +227,19 @@ class SurfaceEncoder(nn.Module):
             self._bwd_override = {} if lrelu_acts is None else lrelu_acts
             return _BaselineEncoderFn.apply(x, self, *self.train_params())
         with torch.no_grad():
-            h = ops.space_to_depth2(x.contiguous(), in_nchw=True, normalize=True, cpad=self._layer(1)[3])   # :265-266
             f = torch.empty((B, 1536), dtype=torch.float32, device=x.device)
             vh, vw = H, W
             g = 1                  # images per mosaic side of the current layer input h
+            # block 1 straight from the raw image (normalisation :265-266, conv1, LeakyReLU, bn1 in one launch) when the second
+            # block reads exactly its 4 x 64 space-to-depth channels; otherwise the re-layout pass + the generic 2x2-tap form
+            fused_first = self.fused_first and self._layer(2)[3] == 256 and self.inputs <= 5
+            h = None if fused_first else ops.space_to_depth2(x.contiguous(), in_nchw=True, normalize=True, cpad=self._layer(1)[3])
             for i in range(1, 8):
                 packed, scale, shift, _cp = self._layer(i)
                 vh, vw = (vh - 4) // 2 + 1, (vw - 4) // 2 + 1
+                if i == 1 and fused_first:
+                    h = ops.conv4x4s2_first(x.contiguous(), self.conv1.weight, self.conv1.bias, scale, shift, normalize=True, lrelu_slope=0.2)
+                    continue
                 if i < 5 and 4 * packed.cout == self._layer(i + 1)[3]:
                     # blocks 1-4: the epilogue writes the next block's space-to-depth input directly
                     h = ops.conv_taps4_s2d(h, packed, (vh, vw), lrelu_slope=0.2, post_scale=scale, post_shift=shift)

@@ -243,6 +243,34 @@ def conv_taps4_s2d(x_nhwc, packed, valid_hw, lrelu_slope=None, post_scale=None, 
     return y
 
 
+def conv4x4s2_first(x_nchw, weight, bias, post_scale=None, post_shift=None, normalize=True, lrelu_slope=0.2):
+    """First block of a cvig_baseline encoder in one launch: x NCHW fp32 [B,C,H,W] (raw 0..255 values when normalize) ->
+    [B, ceil(vh/2), ceil(vw/2), 256], the space-to-depth(2) input of the second block (model/cvig_baseline.py:236-240, 265-268).
+    weight [64,C,4,4] (torch layout), bias / post_scale / post_shift [64]."""
+    lib = _lib.load()
+    x = _dev_f32(x_nchw, 'x')
+    w, b = _dev_f32(weight.detach(), 'weight'), _dev_f32(bias.detach(), 'bias')
+    B, C, H, W = x.shape
+    if tuple(w.shape) != (64, C, 4, 4) or tuple(b.shape) != (64,):
+        raise _lib.WitwError('conv4x4s2_first: weight %s / bias %s do not fit a %d-channel input' % (tuple(w.shape), tuple(b.shape), C))
+    if (post_scale is None) != (post_shift is None):
+        raise _lib.WitwError('conv4x4s2_first: post_scale and post_shift come together')
+    if post_scale is not None:
+        post_scale, post_shift = _dev_f32(post_scale, 'post_scale'), _dev_f32(post_shift, 'post_shift')
+    vh, vw = (H - 4) // 2 + 1, (W - 4) // 2 + 1
+    y = torch.empty((B, (vh + 1) // 2, (vw + 1) // 2, 256), dtype=torch.float32, device=x.device)
+    prof = PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.check(lib.witw_conv4x4s2_first_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), _p(post_scale), _p(post_shift), y.data_ptr(),
+                                            B, C, H, W, int(bool(normalize)), float(lrelu_slope), _stream()), 'witw_conv4x4s2_first_fwd')
+    if prof is not None:
+        e1.record()
+        prof.append((('first4x4', 64, 2, False), 2.0 * C * 64 * 16 * vh * vw * B, e0, e1))
+    return y
+
+
 def conv_taps4_splitk(x_mosaic, packed, n_images, g, valid_hw, lrelu_slope=None, post_scale=None, post_shift=None, ksplit=None):
     """Split-K 2x2-tap convolution over a g x g mosaic (g = 1: the plain batch): x [ceil(n/g^2), g*h, g*w, Cin_pad] ->
     y [n_images, vh, vw, Cout] (the valid outputs, after bias / LeakyReLU / affine). ksplit None: the library's choice."""
