@@ -1017,6 +1017,20 @@ __global__ __launch_bounds__(512) void conv3x3_bf16_s16_kernel(ConvBfArgs p) {
     const int prow = lane >> 3, pc8 = (lane & 7) * 8;      // read-back role: pixel row in a group of 8, channel octet
     auto flush = [&](int yy, int xbase) {      // 32 slab rows -> 32 pixels xbase.. of output row yy
         const int nbase = cb + pc8;
+        typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+        // ReLU backward of a dgrad launch: the four gate octets of this flush are requested together, in front of its stores. Loaded
+        // one by one between the stores, each load was waited for with vmcnt(0) -- its own round trip plus the acknowledgement of the
+        // store just issued, 16 times per tile.
+        u16x8 gt[4];
+        if (TRAIN && p.gate != nullptr) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int xx = xbase + g * 8 + prow;
+                const bool ok = yy < Hy && xx < Wy && nbase < p.Cout;
+                const size_t off = ok ? (((size_t)b * Hy + yy) * Wy + xx) * p.Cout + nbase : 0;      // a pixel outside: any valid address, not used
+                gt[g] = *reinterpret_cast<const u16x8*>(p.gate + off);
+            }
+        }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int m = g * 8 + prow;
@@ -1031,12 +1045,10 @@ __global__ __launch_bounds__(512) void conv3x3_bf16_s16_kernel(ConvBfArgs p) {
             const int xx = xbase + m;
             if (yy < Hy && xx < Wy && nbase < p.Cout) {
                 const size_t off = (((size_t)b * Hy + yy) * Wy + xx) * p.Cout + nbase;
-                if (TRAIN && p.gate != nullptr) {      // ReLU backward of a dgrad launch: zero where the forward's output was <= 0
-                    typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
-                    const u16x8 gt = *reinterpret_cast<const u16x8*>(p.gate + off);
+                if (TRAIN && p.gate != nullptr) {      // zero where the forward's output was <= 0
 #pragma unroll
                     for (int e = 0; e < 8; ++e)
-                        if ((gt[e] & 0x7fffu) == 0 || (gt[e] & 0x8000u)) o[e] = (__bf16)0.f;
+                        if ((gt[g][e] & 0x7fffu) == 0 || (gt[g][e] & 0x8000u)) o[e] = (__bf16)0.f;
                 }
                 __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p.y) + off));
             }
