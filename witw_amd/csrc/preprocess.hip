@@ -9,6 +9,7 @@
 // Compiled with -ffp-contract=off so products and sums round exactly like the reference's
 // separate elementwise torch ops (polar: wa*Ia + wb*Ib + wc*Ic + wd*Id, left to right).
 #include "common.h"
+#include <stdlib.h>
 #include <type_traits>
 #include <string.h>
 
@@ -558,7 +559,10 @@ int witw_polar_from_raw(const void* src, const void* desc, int kind, float* y, i
     p.B = B; p.C = C; p.Hi = Hi; p.Wi = Wi; p.size = size; p.Ho = Ho; p.Wo = Wo; p.n_tile = n_tile; p.box_stride = max_box;
     const long long n_plane = (long long)B * C;
     // about 32 waves per CU; a wave keeps its tile's table entries in registers over its run of planes
-    p.planes_per_wave = (int)((n_plane * n_tile + 8191) / 8192);
+    // ~24 k (tile, run of planes) units, six rounds of the 4096 resident waves: the boxes of the tiles differ by 4x in area, and short
+    // runs let the dispatcher even that out (128 x 3 x 512^2, one box: runs of 24 / 12 / 8 / 4 / 3 planes: 152 / 139 / 131 / 128 / 131 us)
+    p.planes_per_wave = (int)((n_plane * n_tile + 24575) / 24576);
+    if (const char* e = getenv("WITW_PR_PPW")) p.planes_per_wave = atoi(e);      // diagnostic: planes a wave takes per tile
     if (p.planes_per_wave < 1) p.planes_per_wave = 1;
     if (n_plane >= PR_NPL) p.planes_per_wave = (p.planes_per_wave + PR_NPL - 1) / PR_NPL * PR_NPL;      // whole passes of PR_NPL planes
     p.n_group = (int)((n_plane + p.planes_per_wave - 1) / p.planes_per_wave);
