@@ -15,6 +15,7 @@ import time
 
 import numpy as np
 import torch
+import torch.nn.functional as F
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import cvig_fov_oracle as O  # noqa: E402
@@ -25,7 +26,7 @@ def nhwc(t):
     return t.permute(0, 2, 3, 1).contiguous()
 
 
-N_KINDS = 17
+N_KINDS = 20
 
 
 def run(budget=120.0, seed=0, rounds=None, kinds=None):
@@ -296,7 +297,57 @@ def run(budget=120.0, seed=0, rounds=None, kinds=None):
                         b0 = tuple(bad[0].tolist())
                         print('   bad', len(bad), bad[:5].tolist(), 'got', float(got[b0]), 'ref', float(ref[b0]), 'gate', float(gate[b0]),
                               'scale', float(scale[b0[0], b0[1]]), 'ungated', float(xr.grad[b0]), flush=True)
-            else:               # fused match (kinds 5 and above the list)
+            elif kind == 17:    # cvig_baseline block 1 in one launch vs float64 conv2d (normalisation, LeakyReLU, affine, s2d layout)
+                c = int(rng.choice([1, 3, 5]))
+                hh, ww = int(rng.integers(4, 140)), int(rng.integers(4, 200))
+                xr = torch.from_numpy(rng.integers(0, 256, (B, c, hh, ww)).astype(np.float32))
+                wf = torch.randn(64, c, 4, 4) * 0.1
+                bf = torch.randn(64) * 0.1
+                sc, shf = 1 + 0.1 * torch.randn(64), 0.1 * torch.randn(64)
+                yv = ops.conv4x4s2_first(xr.to(dev), wf.to(dev), bf.to(dev), sc.to(dev), shf.to(dev))
+                vh, vw = (hh - 4) // 2 + 1, (ww - 4) // 2 + 1
+                ref = F.leaky_relu(F.conv2d(-1.0 + 2.0 * (xr.double() / 255.0), wf.double(), bf.double(), stride=2), 0.2)
+                ref = ref * sc.double()[None, :, None, None] + shf.double()[None, :, None, None]
+                full = torch.zeros((B, 64, 2 * ((vh + 1) // 2), 2 * ((vw + 1) // 2)), dtype=torch.float64)
+                full[:, :, :vh, :vw] = ref
+                want = torch.cat([full[:, :, dy::2, dx::2] for dy in (0, 1) for dx in (0, 1)], dim=1).permute(0, 2, 3, 1)
+                check('first4x4', (B, c, hh, ww), yv.cpu().double(), want, 3e-6)
+            elif kind == 18:    # 2x2-tap weight gradient with few input channels (the packed (tap, channel) tile) vs float64 autograd
+                c4 = int(rng.choice([4, 8, 12, 16]))
+                co = int(rng.choice([8, 64, 72]))
+                hh, ww = int(rng.integers(2, 30)), int(rng.integers(2, 100))
+                xs = torch.randn(B, hh, ww, c4)
+                dz = torch.randn(B, hh, ww, co)
+                dw, db = ops.conv3x3_wgrad(xs.to(dev), dz.to(dev), c4, taps4=True)
+                wr = torch.zeros(co, c4, 3, 3, dtype=torch.float64, requires_grad=True)
+                yr = F.conv2d(xs.double().permute(0, 3, 1, 2), wr, None, padding=1)
+                yr.backward(dz.double().permute(0, 3, 1, 2))
+                check('wgrad_taps4_small_cin', (B, hh, ww, c4, co), dw.cpu().double()[:, :, 1:, 1:], wr.grad[:, :, 1:, 1:], 2e-5)
+                check('wgrad_taps4_bias', (B, hh, ww, c4, co), db.cpu().double(), dz.double().sum((0, 1, 2)), 2e-5)
+            elif kind == 19:    # GeM pooling (phases over pixels) and the channel-quad BatchNorm backward vs torch in float64
+                cc = int(rng.choice([8, 64, 72, 512]))
+                hh, ww = int(rng.integers(1, 20)), int(rng.integers(1, 20))
+                a = torch.rand(B, hh + 1, ww + 2, cc) + 0.05
+                fo = torch.zeros(B, cc + 8, device=dev)
+                ops.gem_pool(a.to(dev), (hh, ww), fo, 4, 3.0)
+                ref = a[:, :hh, :ww].double().clamp(min=0).pow(3.0).mean((1, 2)).pow(1.0 / 3.0)
+                check('gem_pool', (B, hh, ww, cc), fo[:, 4:4 + cc].cpu().double(), ref, 1e-5)
+                if B * hh * ww >= 8:       # a handful of values per channel: the normalisation amplifies fp32 rounding of mean / variance
+                    z = torch.randn(B, hh + 1, ww + 2, cc)
+                    gam, bet = 1 + 0.1 * torch.randn(cc), 0.1 * torch.randn(cc)
+                    dy = torch.randn(B, hh + 1, ww + 2, cc)
+                    dy[:, hh:] = 0
+                    dy[:, :, ww:] = 0
+                    zr = z[:, :hh, :ww].double().permute(0, 3, 1, 2).clone().requires_grad_(True)
+                    yb = F.batch_norm(F.leaky_relu(zr, 0.2), None, None, gam.double(), bet.double(), True, 0.1, 1e-5)
+                    yb.backward(dy[:, :hh, :ww].double().permute(0, 3, 1, 2))
+                    act = F.leaky_relu(z, 0.2).to(dev)
+                    mean, invstd, _s, _t = ops.bn_train_stats(act, (hh, ww), gam.to(dev), bet.to(dev))
+                    dzv, _dg, _db = ops.bn_lrelu_bwd(act, dy.to(dev), (hh, ww), mean, invstd, gam.to(dev), 0.2)
+                    var_ok = float(zr.detach().var(dim=(0, 2, 3), unbiased=False).min()) > 1e-2      # tiny variances amplify fp32 rounding
+                    if var_ok:
+                        check('bn_lrelu_bwd', (B, hh, ww, cc), dzv.cpu().double()[:, :hh, :ww], zr.grad.permute(0, 2, 3, 1), 5e-5)
+            else:               # fused match (kinds 5, 12, 13)
                 bo, bs, we = int(rng.integers(1, 40)), int(rng.integers(1, 150)), int(rng.integers(1, 65))
                 ov = torch.randn(bo, 16, 4, 64)
                 su = torch.randn(bs, 16, 4, we)
