@@ -140,3 +140,20 @@ def test_wres_register_allocation_guard(tmp_path, monkeypatch):
     assert inst in open(build.WRES_MARKER).read()
     build._check_wres(good)
     assert not os.path.exists(build.WRES_MARKER)
+
+
+def test_first2_register_allocation_guard(tmp_path, monkeypatch):
+    """and for conv_first2_bf16_kernel: the marker switches FOV_DSM.fuse_first2 off at import (the two separate kernels, same bits)"""
+    from witw_amd import build, cvig_fov
+    assert not os.path.exists(build.F2_MARKER) and cvig_fov.FOV_DSM.fuse_first2 is True
+    monkeypatch.setattr(build, 'F2_MARKER', str(tmp_path / 'first2_unvalidated'))
+    good = ''
+    for inst, (v, sp, sc) in build.F2_VALIDATED.items():
+        good += ('remark: Function Name: _ZN12_GLOBAL__N_123conv_first2_bf16_kernel%sEvNS_10First2ArgsE [-Rpass]\nremark:     VGPRs: %d [-R]\n'
+                 'remark:     ScratchSize [bytes/lane]: %d [-R]\nremark:     VGPRs Spill: %d [-R]\n' % (inst, v, sc, sp))
+    build._check_first2(good)
+    assert not os.path.exists(build.F2_MARKER)
+    build._check_first2(good.replace('VGPRs: 254', 'VGPRs: 250'))
+    assert 'ILi4ELb0EE' in open(build.F2_MARKER).read()
+    build._check_first2(good)
+    assert not os.path.exists(build.F2_MARKER)

@@ -122,7 +122,50 @@ def _check_wres(remarks):
         os.remove(WRES_MARKER)
 
 
-CHECKED = {'conv3x3_bf16.hip': lambda r: _check_s16(r), 'conv3x3_bf16_wres.hip': lambda r: _check_wres(r)}
+# conv_first2_bf16_kernel (same hand-issued reads in its layer-2 phase): FOV_DSM.fuse_first2 turns itself off (the two separate
+# kernels, same bits) when the marker exists; WITW_F2=1 forces the fused kernel.
+F2_VALIDATED = {'ILi4ELb0EE': (254, 0, 0), 'ILi8ELb0EE': (256, 0, 0)}      # <CW, REC = false>
+F2_MARKER = os.path.join(HERE, 'build', 'first2_unvalidated')
+
+
+def _check_table(remarks, kernel, table, marker, consequence):
+    """generic form of the two checks above: kernel-resource-usage remarks of `kernel`'s instantiations against `table`"""
+    import re
+    found, cur = {}, None
+    for line in remarks.splitlines():
+        m = re.search(r'Function Name: \S*%s(IL\w+?)EvNS' % kernel, line)
+        if m:
+            cur = m.group(1)
+            found[cur] = {}
+            continue
+        if 'Function Name:' in line:
+            cur = None
+        if cur is None:
+            continue
+        for key, pat in (('vgprs', r' VGPRs: (\d+)'), ('spill', r'VGPRs Spill: (\d+)'), ('scratch', r'ScratchSize \[bytes/lane\]: (\d+)')):
+            m = re.search(pat, line)
+            if m:
+                found[cur][key] = int(m.group(1))
+    bad = []
+    for inst, want in table.items():
+        got = found.get(inst)
+        if not got or (got.get('vgprs'), got.get('spill'), got.get('scratch')) != want:
+            bad.append('%s: validated %s, this compiler %s' % (inst, want, got))
+    if bad:
+        with open(marker, 'w') as f:
+            f.write('\n'.join(bad) + '\n')
+        print('WARNING: %s compiled with a register allocation that has not been validated; %s (see witw_amd/build.py):\n  %s'
+              % (kernel, consequence, '\n  '.join(bad)), flush=True)
+    elif os.path.exists(marker):
+        os.remove(marker)
+
+
+def _check_first2(remarks):
+    _check_table(remarks, 'conv_first2_bf16_kernel', F2_VALIDATED, F2_MARKER, 'layers 0 and 2 run as two launches instead')
+
+
+CHECKED = {'conv3x3_bf16.hip': lambda r: _check_s16(r), 'conv3x3_bf16_wres.hip': lambda r: _check_wres(r),
+           'conv_first2_bf16.hip': lambda r: _check_first2(r)}
 
 
 def _build_locked(verbose):
