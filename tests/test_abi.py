@@ -132,7 +132,7 @@ def test_wres_register_allocation_guard(tmp_path, monkeypatch):
     monkeypatch.setattr(build, 'WRES_MARKER', str(tmp_path / 'wres_unvalidated'))
     (v, sp, sc), = build.WRES_VALIDATED.values()
     inst, = build.WRES_VALIDATED.keys()
-    good = ('remark: Function Name: _ZN12_GLOBAL__N_124conv3x3_bf16_wres_kernel%svNS_8WresArgsE [-Rpass]\nremark:     VGPRs: %d [-R]\n'
+    good = ('remark: Function Name: _ZN12_GLOBAL__N_124conv3x3_bf16_wres_kernel%sEvNS_8WresArgsE [-Rpass]\nremark:     VGPRs: %d [-R]\n'
             'remark:     ScratchSize [bytes/lane]: %d [-R]\nremark:     VGPRs Spill: %d [-R]\n' % (inst, v, sc, sp))
     build._check_wres(good)
     assert not os.path.exists(build.WRES_MARKER)
@@ -143,9 +143,12 @@ def test_wres_register_allocation_guard(tmp_path, monkeypatch):
 
 
 def test_first2_register_allocation_guard(tmp_path, monkeypatch):
-    """and for conv_first2_bf16_kernel: the marker switches FOV_DSM.fuse_first2 off at import (the two separate kernels, same bits)"""
-    from witw_amd import build, cvig_fov
-    assert not os.path.exists(build.F2_MARKER) and cvig_fov.FOV_DSM.fuse_first2 is True
+    """and for conv_first2_bf16_kernel: the marker switches the fused launch of FOV_DSM.forward_bf16 off (the two separate kernels,
+    same bits) -- decided by _lib.load() AFTER the build, not when cvig_fov is imported (round-3 advisor finding)"""
+    from witw_amd import _lib, build, cvig_fov
+    assert not os.path.exists(build.F2_MARKER) and cvig_fov.FOV_DSM.fuse_first2 is None
+    g = _lib.guards()
+    assert set(g) == {'s16', 'wres', 'first2'} and all(v['hand_scheduled_kernel'] and not v['detail'] for v in g.values()), g
     monkeypatch.setattr(build, 'F2_MARKER', str(tmp_path / 'first2_unvalidated'))
     good = ''
     for inst, (v, sp, sc) in build.F2_VALIDATED.items():
@@ -155,5 +158,18 @@ def test_first2_register_allocation_guard(tmp_path, monkeypatch):
     assert not os.path.exists(build.F2_MARKER)
     build._check_first2(good.replace('VGPRs: 254', 'VGPRs: 250'))
     assert 'ILi4ELb0EE' in open(build.F2_MARKER).read()
+    # a marker written by a build that this very process triggers is seen by the load that follows it
+    monkeypatch.setattr(_lib, '_LIB', None)
+    monkeypatch.setattr(_lib, '_GUARDS', None)
+    monkeypatch.delenv('WITW_F2', raising=False)
+    with pytest.warns(UserWarning, match='first2'):
+        g = _lib.guards()
+    assert g['first2']['hand_scheduled_kernel'] is False and 'ILi4ELb0EE' in g['first2']['detail'] and g['s16']['hand_scheduled_kernel']
+    monkeypatch.setenv('WITW_F2', '1')
+    monkeypatch.setattr(_lib, '_LIB', None)
+    assert _lib.guards()['first2'] == {'hand_scheduled_kernel': True, 'forced': True, 'detail': ''}
     build._check_first2(good)
     assert not os.path.exists(build.F2_MARKER)
+    monkeypatch.setattr(_lib, '_LIB', None)
+    monkeypatch.delenv('WITW_F2', raising=False)
+    assert _lib.guards()['first2']['hand_scheduled_kernel'] is True

@@ -87,3 +87,139 @@ def test_pack_layout():
     o = int(desc[1, 0])
     assert desc[1, 24] == 1 and desc[1, 25] == 3 and list(desc[1, 2:4]) == [5, 6]
     np.testing.assert_array_equal(b[o:o + raw.size].reshape(5, 6, 3), raw)
+
+
+# ---- round 4: files the device path must leave to the host decoder, and hostile tables ------------------------------------------
+
+def _dht_segment(counts, nsym=None):
+    nsym = sum(counts) if nsym is None else nsym
+    body = bytes([0x00]) + bytes(counts) + bytes((i & 255) for i in range(nsym))
+    return b'\xff\xc4' + (len(body) + 2).to_bytes(2, 'big') + body
+
+
+@pytest.mark.parametrize('pos', range(16))
+def test_oversubscribed_huffman_table_is_refused_without_writing_past_the_tables(pos):
+    """a DHT whose code lengths over-subscribe the code space (255 codes of ONE length: the symbol count passes the <= 256 check)
+    used to be written into the look-up tables before it was rejected -- ~130 KB past them for length 1"""
+    counts = [0] * 16
+    counts[pos] = 255
+    for tail in (b'', b'\xff\xd9'):
+        assert jpeg.read_coef(b'\xff\xd8' + _dht_segment(counts) + tail) is None
+    counts = [2] + [0] * 15                              # exactly full at length 1, then one more code at length 2
+    counts[1] = 1
+    assert jpeg.read_coef(b'\xff\xd8' + _dht_segment(counts) + b'\xff\xd9') is None
+
+
+def _patch_sof(data, comp, hv):
+    """the sampling byte of component `comp` in the SOF0 segment"""
+    b = bytearray(data)
+    i = b.index(b'\xff\xc0')
+    b[i + 4 + 6 + 3 * comp + 1] = hv
+    return bytes(b)
+
+
+def test_440_sampling_is_left_to_the_host_decoder():
+    """h1v2 (4:4:0, e.g. a losslessly rotated 4:2:2 file): the device back end has no such upsampler"""
+    data = open(os.path.join(HERE, 's422_q50.jpg'), 'rb').read()
+    assert jpeg.open_file(data) is not None
+    assert jpeg.open_file(_patch_sof(data, 0, 0x12)) is None and jpeg.read_coef(_patch_sof(data, 0, 0x12)) is None
+    from PIL import Image
+    a = (np.arange(48 * 40 * 3, dtype=np.uint32).reshape(48, 40, 3) * 7 % 256).astype(np.uint8)
+    try:
+        bio = io.BytesIO()
+        Image.fromarray(a).save(bio, 'JPEG', quality=90, subsampling='4:4:0')
+    except (TypeError, ValueError, KeyError):
+        return                                           # this Pillow cannot write 4:4:0
+    assert jpeg.open_file(bio.getvalue()) is None
+
+
+def test_rgb_colourspace_files_are_left_to_the_host_decoder():
+    """libjpeg takes the colour space from the JFIF / Adobe markers and the component ids (jdapimin.c default_decompress_parms);
+    the device back end always converts YCbCr -> RGB, so files stored as RGB must not reach it"""
+    from PIL import Image
+    a = np.zeros((32, 40, 3), dtype=np.uint8)
+    a[..., 0], a[..., 1], a[..., 2] = 200, 40, 90
+    bio = io.BytesIO()
+    Image.fromarray(a).save(bio, 'JPEG', quality=95, subsampling=0, keep_rgb=True)
+    data = bio.getvalue()
+    ref = np.asarray(Image.open(io.BytesIO(data)))
+    assert abs(int(ref[5, 5, 0]) - 200) < 6 and abs(int(ref[5, 5, 1]) - 40) < 6      # Pillow reads it as RGB
+    assert jpeg.open_file(data) is None and jpeg.read_coef(data) is None
+    # an ordinary file: JFIF => YCbCr => ours
+    ycc = open(os.path.join(HERE, 's444_q100.jpg'), 'rb').read()
+    assert jpeg.open_file(ycc) is not None
+    # the same file behind an Adobe APP14 marker instead of JFIF: transform 1 = YCbCr (ours), 0 = RGB and 2 = YCCK (host decoder)
+    i = ycc.index(b'\xff\xe0')
+    ln = int.from_bytes(ycc[i + 2:i + 4], 'big')
+    for transform, ours in ((1, True), (0, False), (2, False)):
+        app14 = b'\xff\xee\x00\x0eAdobe\x00\x64\x00\x00\x00\x00' + bytes([transform])
+        f = ycc[:i] + app14 + ycc[i + 2 + ln:]
+        assert (jpeg.open_file(f) is not None) == ours, transform
+        if ours:
+            c = jpeg.read_coef(f)
+            np.testing.assert_array_equal(J.decode(c.info, c.coef, c.qt), np.asarray(Image.open(io.BytesIO(f))))
+    # no marker at all: the component ids decide
+    bare = ycc[:i] + ycc[i + 2 + ln:]
+    assert jpeg.open_file(bare) is not None
+    b = bytearray(bare)
+    j = b.index(b'\xff\xc0')
+    k = b.index(b'\xff\xda')
+    for c, ch in enumerate(b'RGB'):
+        b[j + 4 + 6 + 3 * c] = ch
+        b[k + 5 + 2 * c] = ch
+    assert jpeg.open_file(bytes(b)) is None
+
+
+def test_pack_hands_damaged_entropy_data_to_pillow_as_the_reference_would_read_it():
+    """open_file() sees only the header; a file whose entropy data turns out bad inside pack() is decoded by Pillow (libjpeg
+    reads truncated files with a warning -- so does the reference's imread) and travels as a raw image of the same batch"""
+    from PIL import Image, ImageFile
+    good = open(os.path.join(HERE, 's420_q90.jpg'), 'rb').read()
+    cut = good[:len(good) * 2 // 3]
+    f_good, f_cut = jpeg.open_file(good), jpeg.open_file(cut)
+    assert f_good is not None and f_cut is not None
+    old = ImageFile.LOAD_TRUNCATED_IMAGES
+    ImageFile.LOAD_TRUNCATED_IMAGES = True
+    try:
+        ref = np.asarray(Image.open(io.BytesIO(cut)))
+        buf, desc, kind = jpeg.pack([f_good, f_cut, f_good])
+    finally:
+        ImageFile.LOAD_TRUNCATED_IMAGES = old
+    d = desc.numpy()
+    assert kind == jpeg.KIND_JPEG and list(d[:, 24]) == [0, 1, 0] and int(d[1, 25]) == 3
+    assert (int(d[1, 2]), int(d[1, 3])) == ref.shape[:2]
+    o = int(d[1, 0])
+    np.testing.assert_array_equal(buf.numpy()[o:o + ref.size].reshape(ref.shape), ref)
+    # the neighbours are untouched coefficient entries
+    c = jpeg.read_coef(good)
+    for i in (0, 2):
+        o = int(d[i, 0])
+        np.testing.assert_array_equal(buf.numpy()[o:o + c.coef.size * 2].view(np.int16).reshape(-1, 64), c.coef)
+    # without Pillow's tolerance the batch fails as the reference's loader would: loudly, not silently
+    if not old:
+        with pytest.raises((OSError, ValueError)):
+            jpeg.pack([f_cut])
+
+
+def test_ring_slot_is_returned_when_a_batch_fails(monkeypatch):
+    from witw_amd import cvig_fov
+
+    class Ring(object):
+        def __init__(self):
+            self.out = 0
+
+        def acquire(self):
+            self.out += 1
+            return 0
+
+        def release(self, slot):
+            self.out -= 1
+
+        def allocator(self, slot):
+            return lambda n: None
+
+    r = Ring()
+    monkeypatch.setattr(cvig_fov, '_pack_side', lambda images, alloc=None: (_ for _ in ()).throw(ValueError('unreadable')))
+    with pytest.raises(ValueError):
+        cvig_fov.collate_packed([{'surface': 0, 'overhead': 0}], ring=r)
+    assert r.out == 0

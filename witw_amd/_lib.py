@@ -10,6 +10,7 @@ from ctypes import c_char_p, c_float, c_int, c_longlong, c_void_p
 from . import build as _build
 
 _LIB = None
+_GUARDS = None
 
 # name -> (restype, argtypes); mirrors include/witw_hip.h one-to-one
 SIGNATURES = {
@@ -149,20 +150,31 @@ def load():
         fn.restype = res
         fn.argtypes = args
     _LIB = lib
-    # the hand-scheduled 16x16x32 bf16 kernel is used only with a register allocation the parity tests have seen (build.py)
-    if path == _build.LIB and os.path.exists(_build.S16_MARKER) and 'WITW_BF_S16' not in os.environ:
-        import warnings
-        warnings.warn('libwitw_hip: conv3x3_bf16_s16_kernel was compiled with an unvalidated register allocation (%s); using the '
-                      '32x32x16 bf16 kernel. Re-run the bf16 parity tests with WITW_BF_S16=1 and update build.S16_VALIDATED.'
-                      % open(_build.S16_MARKER).read().strip().replace('\n', '; '))
+    # hand-scheduled kernels are used only with a register allocation the parity tests have seen (build.py); decided HERE, after the
+    # build, never at import time
+    global _GUARDS
+    _GUARDS = {}
+    for name, (marker, force) in _build.guard_markers().items():
+        tripped = path == _build.LIB and os.path.exists(marker) and force not in os.environ
+        _GUARDS[name] = {'hand_scheduled_kernel': not tripped, 'forced': force in os.environ,
+                         'detail': open(marker).read().strip().replace('\n', '; ') if tripped else ''}
+        if tripped:
+            import warnings
+            warnings.warn('libwitw_hip: guard %r tripped -- a hand-scheduled kernel was compiled with an unvalidated register allocation '
+                          '(%s); its compiler-scheduled replacement runs instead. Re-run the bf16 parity tests with %s=1 and update the '
+                          'table in witw_amd/build.py.' % (name, _GUARDS[name]['detail'], force))
+    if not _GUARDS['s16']['hand_scheduled_kernel']:
         lib.witw_conv3x3_bf16_mfma16(0)
-    if path == _build.LIB and os.path.exists(_build.WRES_MARKER) and 'WITW_BF_WRES' not in os.environ:
-        import warnings
-        warnings.warn('libwitw_hip: conv3x3_bf16_wres_kernel was compiled with an unvalidated register allocation (%s); layer 5 runs on '
-                      'the tiled bf16 kernels. Re-run tests/test_large_grid_parity_gpu.py with WITW_BF_WRES=1 and update build.WRES_VALIDATED.'
-                      % open(_build.WRES_MARKER).read().strip().replace('\n', '; '))
+    if not _GUARDS['wres']['hand_scheduled_kernel']:
         lib.witw_conv3x3_bf16_wres(0)
     return lib
+
+
+def guards():
+    """The register-allocation guards of build.py as this process sees them: name -> {'hand_scheduled_kernel': in use?, 'forced',
+    'detail'}. 's16' / 'wres' act inside the library (switches set by load()); 'first2' is read by FOV_DSM.forward_bf16."""
+    load()
+    return _GUARDS
 
 
 def check(rc, what):

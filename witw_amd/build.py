@@ -42,94 +42,26 @@ def build(force=False, verbose=True):
             fcntl.flock(lock, fcntl.LOCK_UN)
 
 
-# conv3x3_bf16_s16_kernel issues its LDS fragment reads by hand (asm volatile ds_read_b128 + counted s_waitcnt lgkmcnt): it is
-# correct only while the compiler keeps every fragment register untouched between a read and its wait. That was validated (parity
-# tests + fuzz against the oracle) for the register allocations below; a compiler that allocates differently gets the 32x32x16
-# kernel instead until the parity tests have been re-run and this table updated (WITW_BF_S16=1 forces the 16x16x32 kernel).
-S16_VALIDATED = {        # instantiation <POOL, TRAIN> -> (VGPRs, spilled VGPRs, scratch bytes per lane) under hipcc of ROCm 7.2.0
-    'ILb0ELb0E': (256, 10, 44), 'ILb1ELb0E': (256, 1, 8), 'ILb0ELb1E': (256, 10, 44), 'ILb1ELb1E': (256, 2, 12),
-}
+# Three kernels issue their LDS fragment reads by hand (asm volatile ds_read_b128 + counted s_waitcnt lgkmcnt): they are correct only
+# while the compiler keeps every fragment register untouched between a read and its wait. That was validated (parity tests + fuzz
+# against the oracle) for the register allocations below; a compiler that allocates differently gets the slower, compiler-scheduled
+# kernels instead until the parity tests have been re-run and the table updated. Each guard: the kernel-resource-usage remarks of
+# `kernel`'s instantiations (mangled template arguments -> (VGPRs, spilled VGPRs, scratch bytes per lane) under hipcc of ROCm 7.2.0)
+# are compared with `table` after every compile; a mismatch leaves `marker`, which _lib.load() reads AFTER the build (so a process
+# that triggers the build itself is covered) and reports through _lib.guards() / the bench line's `guards` field.
+#   s16:    conv3x3_bf16_s16_kernel<POOL, TRAIN> -> the 32x32x16 kernel (witw_conv3x3_bf16_mfma16(0));      force: WITW_BF_S16=1
+#   wres:   conv3x3_bf16_wres_kernel<REC>        -> layer 5 on the tiled kernels (witw_conv3x3_bf16_wres(0)); force: WITW_BF_WRES=1
+#   first2: conv_first2_bf16_kernel<CW, REC>     -> layers 0 and 2 as two launches (FOV_DSM.fuse_first2);     force: WITW_F2=1
+S16_VALIDATED = {'ILb0ELb0EE': (256, 10, 44), 'ILb1ELb0EE': (256, 1, 8), 'ILb0ELb1EE': (256, 10, 44), 'ILb1ELb1EE': (256, 2, 12)}
 S16_MARKER = os.path.join(HERE, 'build', 's16_unvalidated')
-
-
-def _check_s16(remarks):
-    """Parse -Rpass-analysis=kernel-resource-usage output of conv3x3_bf16.hip; write / clear the marker _lib.load() looks at."""
-    import re
-    found, cur = {}, None
-    for line in remarks.splitlines():
-        m = re.search(r'Function Name: \S*conv3x3_bf16_s16_kernel(ILb[01]ELb[01]E)', line)
-        if m:
-            cur = m.group(1)
-            found[cur] = {}
-            continue
-        if 'Function Name:' in line:
-            cur = None
-        if cur is None:
-            continue
-        for key, pat in (('vgprs', r' VGPRs: (\d+)'), ('spill', r'VGPRs Spill: (\d+)'), ('scratch', r'ScratchSize \[bytes/lane\]: (\d+)')):
-            m = re.search(pat, line)
-            if m:
-                found[cur][key] = int(m.group(1))
-    bad = []
-    for inst, want in S16_VALIDATED.items():
-        got = found.get(inst)
-        if not got or (got.get('vgprs'), got.get('spill'), got.get('scratch')) != want:
-            bad.append('%s: validated %s, this compiler %s' % (inst, want, got))
-    if bad:
-        with open(S16_MARKER, 'w') as f:
-            f.write('\n'.join(bad) + '\n')
-        print('WARNING: conv3x3_bf16_s16_kernel compiled with a register allocation that has not been validated; the 32x32x16 '
-              'kernel is used instead (see witw_amd/build.py S16_VALIDATED):\n  ' + '\n  '.join(bad), flush=True)
-    elif os.path.exists(S16_MARKER):
-        os.remove(S16_MARKER)
-
-
-# The same for conv3x3_bf16_wres_kernel (hand-issued fragment reads of lds_frag.h): a different allocation switches layer 5 back to
-# the tiled kernels (witw_conv3x3_bf16_wres(0)) until tests/test_large_grid_parity_gpu.py (bitwise against the 32x32x16 kernel) has
-# been re-run and this entry updated; WITW_BF_WRES=1 forces the kernel.
-WRES_VALIDATED = {'ILb0EE': (256, 0, 0)}       # <REC = false>
+WRES_VALIDATED = {'ILb0EE': (256, 0, 0)}
 WRES_MARKER = os.path.join(HERE, 'build', 'wres_unvalidated')
-
-
-def _check_wres(remarks):
-    import re
-    found, cur = {}, None
-    for line in remarks.splitlines():
-        m = re.search(r'Function Name: \S*conv3x3_bf16_wres_kernel(ILb[01]EE)', line)
-        if m:
-            cur = m.group(1)
-            found[cur] = {}
-            continue
-        if 'Function Name:' in line:
-            cur = None
-        if cur is None:
-            continue
-        for key, pat in (('vgprs', r' VGPRs: (\d+)'), ('spill', r'VGPRs Spill: (\d+)'), ('scratch', r'ScratchSize \[bytes/lane\]: (\d+)')):
-            m = re.search(pat, line)
-            if m:
-                found[cur][key] = int(m.group(1))
-    bad = []
-    for inst, want in WRES_VALIDATED.items():
-        got = found.get(inst)
-        if not got or (got.get('vgprs'), got.get('spill'), got.get('scratch')) != want:
-            bad.append('%s: validated %s, this compiler %s' % (inst, want, got))
-    if bad:
-        with open(WRES_MARKER, 'w') as f:
-            f.write('\n'.join(bad) + '\n')
-        print('WARNING: conv3x3_bf16_wres_kernel compiled with a register allocation that has not been validated; layer 5 runs on the '
-              'tiled kernels instead (see witw_amd/build.py WRES_VALIDATED):\n  ' + '\n  '.join(bad), flush=True)
-    elif os.path.exists(WRES_MARKER):
-        os.remove(WRES_MARKER)
-
-
-# conv_first2_bf16_kernel (same hand-issued reads in its layer-2 phase): FOV_DSM.fuse_first2 turns itself off (the two separate
-# kernels, same bits) when the marker exists; WITW_F2=1 forces the fused kernel.
-F2_VALIDATED = {'ILi4ELb0EE': (254, 0, 0), 'ILi8ELb0EE': (256, 0, 0)}      # <CW, REC = false>
+F2_VALIDATED = {'ILi4ELb0EE': (254, 0, 0), 'ILi8ELb0EE': (256, 0, 0)}
 F2_MARKER = os.path.join(HERE, 'build', 'first2_unvalidated')
 
 
 def _check_table(remarks, kernel, table, marker, consequence):
-    """generic form of the two checks above: kernel-resource-usage remarks of `kernel`'s instantiations against `table`"""
+    """kernel-resource-usage remarks of `kernel`'s instantiations against `table`; writes / clears `marker`"""
     import re
     found, cur = {}, None
     for line in remarks.splitlines():
@@ -160,12 +92,25 @@ def _check_table(remarks, kernel, table, marker, consequence):
         os.remove(marker)
 
 
+def _check_s16(remarks):
+    _check_table(remarks, 'conv3x3_bf16_s16_kernel', S16_VALIDATED, S16_MARKER, 'the 32x32x16 bf16 kernel is used instead')
+
+
+def _check_wres(remarks):
+    _check_table(remarks, 'conv3x3_bf16_wres_kernel', WRES_VALIDATED, WRES_MARKER, 'layer 5 runs on the tiled kernels instead')
+
+
 def _check_first2(remarks):
     _check_table(remarks, 'conv_first2_bf16_kernel', F2_VALIDATED, F2_MARKER, 'layers 0 and 2 run as two launches instead')
 
 
 CHECKED = {'conv3x3_bf16.hip': lambda r: _check_s16(r), 'conv3x3_bf16_wres.hip': lambda r: _check_wres(r),
            'conv_first2_bf16.hip': lambda r: _check_first2(r)}
+
+
+def guard_markers():
+    """name -> (marker path, environment variable that forces the hand-scheduled kernel); read at call time (tests repoint them)"""
+    return {'s16': (S16_MARKER, 'WITW_BF_S16'), 'wres': (WRES_MARKER, 'WITW_BF_WRES'), 'first2': (F2_MARKER, 'WITW_F2')}
 
 
 def _build_locked(verbose):

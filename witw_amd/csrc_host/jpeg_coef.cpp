@@ -33,9 +33,13 @@ bool build_huff(Huff& h, const uint8_t* counts, const uint8_t* symbols, int nsym
     memcpy(h.sym, symbols, nsym);
     memset(h.look_len, 0, sizeof(h.look_len));
     memset(h.fast_ac, 0, sizeof(h.fast_ac));
+    h.present = false;
     int code = 0, k = 0;
     for (int len = 1; len <= 16; ++len) {
         h.valoff[len] = k - code;
+        // an over-subscribed length (more codes than the code space has left) is rejected BEFORE anything is written: with
+        // code + count <= 2^len every look-up index below stays under 2^FAST and k stays under nsym <= 256
+        if (code + counts[len - 1] > (1 << len) || k + counts[len - 1] > nsym) return false;
         for (int i = 0; i < counts[len - 1]; ++i, ++k, ++code) {
             if (len <= FAST) {
                 const int first = code << (FAST - len), n = 1 << (FAST - len);
@@ -46,12 +50,11 @@ bool build_huff(Huff& h, const uint8_t* counts, const uint8_t* symbols, int nsym
             }
         }
         h.maxcode[len] = counts[len - 1] ? code - 1 : -1;
-        if (code > (1 << len)) return false;
         code <<= 1;
     }
     h.maxcode[17] = 0x7fffffff;
-    h.present = true;
     if (k != nsym) return false;
+    h.present = true;
     if (ac)
         for (int i = 0; i < (1 << FAST); ++i) {
             const int len = h.look_len[i];
@@ -107,6 +110,8 @@ struct Parsed {
     Huff dc[4], ac[4];
     const uint8_t* scan;      // start of the entropy-coded segment
     int scan_ncomp, scan_comp[4];
+    bool jfif, adobe;         // APP0 'JFIF' / APP14 'Adobe' seen (libjpeg picks the colour space from them, jdapimin.c)
+    int adobe_transform;
     int status;               // 0 ok, < 0 see witw_jpeg_* below
 };
 
@@ -166,6 +171,10 @@ int parse(const uint8_t* d, size_t n, Parsed& P) {
                 if (!build_huff(tc ? P.ac[th] : P.dc[th], s + k + 1, s + k + 17, nsym, tc != 0)) return -1;
                 k += 17 + nsym;
             }
+        } else if (m == 0xE0) {                                     // jdmarker.c examine_app0
+            if (sl >= 14 && !memcmp(s, "JFIF\0", 5)) P.jfif = true;
+        } else if (m == 0xEE) {                                     // jdmarker.c examine_app14
+            if (sl >= 12 && !memcmp(s, "Adobe", 5)) { P.adobe = true; P.adobe_transform = s[11]; }
         } else if (m == 0xDD) {
             if (sl < 2) return -1;
             P.restart = be16(s);
@@ -193,6 +202,15 @@ int parse(const uint8_t* d, size_t n, Parsed& P) {
     for (int c = 0; c < P.ncomp; ++c) { if (P.c[c].h > P.hmax) P.hmax = P.c[c].h; if (P.c[c].v > P.vmax) P.vmax = P.c[c].v; }
     if (P.ncomp == 1) { P.c[0].h = P.c[0].v = 1; P.hmax = P.vmax = 1; }      // a single-component scan is never interleaved
     else if (P.c[1].h != 1 || P.c[1].v != 1 || P.c[2].h != 1 || P.c[2].v != 1 || P.c[0].h != P.hmax || P.c[0].v != P.vmax) return -2;
+    // the device back end upsamples h1v1, h2v1 and h2v2 only: 4:4:0 (h1v2, e.g. a losslessly rotated 4:2:2 file) goes to the host decoder
+    if (P.hmax == 1 && P.vmax == 2) return -2;
+    // colour space as libjpeg's default_decompress_parms (jdapimin.c) decides it for three components: JFIF => YCbCr; else an
+    // Adobe marker's transform flag (0 = RGB, 1 = YCbCr); else the component ids ('R','G','B' = RGB). The device back end always
+    // applies YCbCr -> RGB, so every other case (and an unknown transform, which libjpeg warns about) is the host decoder's.
+    if (P.ncomp == 3 && !P.jfif) {
+        if (P.adobe) { if (P.adobe_transform != 1) return -2; }
+        else if (P.c[0].id == 'R' && P.c[1].id == 'G' && P.c[2].id == 'B') return -2;
+    }
     P.mcux = (P.W + 8 * P.hmax - 1) / (8 * P.hmax);
     P.mcuy = (P.H + 8 * P.vmax - 1) / (8 * P.vmax);
     int64_t off = 0;
@@ -205,15 +223,23 @@ int parse(const uint8_t* d, size_t n, Parsed& P) {
     return 0;
 }
 
+// one Parsed per thread, on the HEAP (not in the TLS block): a sanitizer build red-zones it, so an overrun of the tables is seen
+Parsed& parsed() {
+    static thread_local Parsed* p = nullptr;
+    if (!p) p = new Parsed;
+    return *p;
+}
+
 }  // namespace
 
 extern "C" {
 
 // info[0..]: H, W, ncomp, hmax, vmax, total blocks, then per component (4 slots): h, v, blocks wide, blocks high.
 // Returns 0; -1 = not a decodable JPEG stream; -2 = a JPEG this decoder leaves to the host library (progressive, arithmetic,
-// 12-bit, CMYK, non-interleaved scans, sampling factors other than 1 or 2 / chroma not 1x1).
+// 12-bit, CMYK, non-interleaved scans, sampling other than 4:4:4 / 4:2:2 (h2v1) / 4:2:0 / grey, RGB-colourspace files: Adobe
+// transform 0 or component ids 'R','G','B' without a JFIF marker).
 int witw_jpeg_info(const uint8_t* data, size_t n, int32_t* info /* 22 */) {
-    static thread_local Parsed P;
+    Parsed& P = parsed();
     const int rc = parse(data, n, P);
     if (rc) return rc;
     info[0] = P.H; info[1] = P.W; info[2] = P.ncomp; info[3] = P.hmax; info[4] = P.vmax;
@@ -231,7 +257,7 @@ int witw_jpeg_info(const uint8_t* data, size_t n, int32_t* info /* 22 */) {
 // coef: total blocks x 64 int16 (zero-filled here); qt: ncomp x 64 uint16. Returns 0 or a negative code as above; -3 = the
 // entropy-coded data ended early or holds an invalid code (the blocks decoded so far are kept, the rest stay zero).
 int witw_jpeg_decode_coef(const uint8_t* data, size_t n, int16_t* coef, uint16_t* qt) {
-    static thread_local Parsed P;
+    Parsed& P = parsed();
     int rc = parse(data, n, P);
     if (rc) return rc;
     int64_t total = 0;

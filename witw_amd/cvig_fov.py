@@ -104,9 +104,10 @@ class FOV_DSM(torch.nn.Module):
     weights with load_state_dict. The unused VGG classifier of the reference is not kept.
     """
     in_channels = 3
-    # bf16 inference: layers 0 and 2 as one launch (False: the two separate kernels, same bits). Off by itself when build.py found the
-    # fused kernel compiled with a register allocation the parity tests have not seen (hand-counted LDS waits), unless WITW_F2 is set
-    fuse_first2 = not os.path.exists(_build.F2_MARKER) or 'WITW_F2' in os.environ
+    # bf16 inference: layers 0 and 2 as one launch (False: the two separate kernels, same bits). None = decided at the first bf16
+    # forward, i.e. AFTER the library has been built and loaded: off when build.py found the fused kernel compiled with a register
+    # allocation the parity tests have not seen (hand-counted LDS waits), unless WITW_F2 is set (_lib.guards()['first2'])
+    fuse_first2 = None
     dropout_seed = None       # None: torch.initial_seed()
     # 'fp32' = the reference's arithmetic on the fp32 MFMA kernels (parity path). 'bf16' = mixed precision on the bf16
     # MFMA kernels: bf16 activations / filters / activation gradients, fp32 accumulate, fp32 weight gradients, master
@@ -277,7 +278,8 @@ class FOV_DSM(torch.nn.Module):
             h = x.contiguous() if fast0 else ops.nchw_to_nhwc_bf16(x.contiguous(), 16)
             last = self.layer_specs[-1][0]
             # layers 0 and 2 in one kernel (the 64-channel map between them stays on the chip): csrc/conv_first2_bf16.hip
-            fused = fast0 and self.fuse_first2 and self.layer_specs[0][:4] == (0, 1, True, False) and self.layer_specs[1][:4] == (2, 1, True, True)
+            fuse = _lib.guards()['first2']['hand_scheduled_kernel'] if self.fuse_first2 is None else self.fuse_first2
+            fused = fast0 and fuse and self.layer_specs[0][:4] == (0, 1, True, False) and self.layer_specs[1][:4] == (2, 1, True, True)
             for (idx, sh, relu, pool, drop) in self.layer_specs:
                 if idx == 0 and fused:
                     h = ops.conv_first2_bf16(h, self._pack_first(True), self._pack_bf16(2), circular=self.circ_padding)
@@ -1214,9 +1216,13 @@ def collate_packed(samples, ring=None):
     parent's page-locked shared memory and only {slot, offsets} travel back -- no copy into shared memory, no pinning thread."""
     if ring is not None:
         slot = ring.acquire()
-        alloc = ring.allocator(slot)
-        s_side = _pack_side([s['surface'] for s in samples], alloc)
-        o_side = _pack_side([s['overhead'] for s in samples], alloc) if s_side is not None else None
+        try:
+            alloc = ring.allocator(slot)
+            s_side = _pack_side([s['surface'] for s in samples], alloc)
+            o_side = _pack_side([s['overhead'] for s in samples], alloc) if s_side is not None else None
+        except BaseException:
+            ring.release(slot)      # an unreadable file must not cost the ring a slot for the rest of the epoch
+            raise
         if o_side is not None:
             (s_off, s_len), sd, sk = s_side
             (o_off, o_len), od, ok = o_side

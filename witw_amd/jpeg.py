@@ -58,6 +58,14 @@ class JpegFile(JpegCoef):
         """coef int16 [blocks, 64], qt uint16 [components, 64]: views of the destination. -> False if the entropy data is bad."""
         return host_lib().witw_jpeg_decode_coef(self.data.ctypes.data, self.data.size, coef.ctypes.data, qt.ctypes.data) == 0
 
+    def pillow(self):
+        """The host decoder's opinion of the file (what the reference's imread returns, model/cvig_fov.py:88-89): uint8 HWC.
+        pack() takes it when the entropy data does not decode cleanly here -- libjpeg reads many damaged files with a warning."""
+        import io
+        from PIL import Image
+        a = np.asarray(Image.open(io.BytesIO(self.data.tobytes())))
+        return a[:, :, None] if a.ndim == 2 else a
+
     def _decoded(self):
         coef = np.empty((int(self.info[5]), 64), dtype=np.int16)
         qt = np.empty((int(self.info[2]), 64), dtype=np.uint16)
@@ -137,7 +145,15 @@ def pack(images, shared=False, alloc=None):
             coef = buf[o:o + nbytes].view(np.int16).reshape(-1, 64)
             qt = buf[int(desc[i, 1]):int(desc[i, 1]) + int(a.info[2]) * 128].view(np.uint16).reshape(-1, 64)
             if not a.decode_into(coef, qt):
-                raise ValueError('corrupt JPEG entropy data in image %d of the batch' % i)
+                # damaged entropy data: the file goes to Pillow after all (as the reference and raw=True read it) and rides in the
+                # same span as a raw uint8 image -- the coefficient blocks of an image are never smaller than its pixels
+                px = np.ascontiguousarray(a.pillow())
+                if px.dtype != np.uint8 or px.size > nbytes:
+                    raise ValueError('image %d of the batch: JPEG entropy data is corrupt and the host decoder returned %s %s'
+                                     % (i, px.dtype, px.shape))
+                buf[o:o + px.size] = px.reshape(-1)
+                desc[i, 2:24] = 0
+                desc[i, 2], desc[i, 3], desc[i, 24], desc[i, 25] = px.shape[0], px.shape[1], 1, px.shape[2]
         elif isinstance(a, JpegCoef):
             buf[o:o + nbytes] = a.coef.reshape(-1).view(np.uint8)
             buf[int(desc[i, 1]):int(desc[i, 1]) + a.qt.size * 2] = a.qt.reshape(-1).view(np.uint8)
