@@ -171,24 +171,32 @@ class StepBench(object):
         return self.se(surface), self.oe(polar)
 
     def train_step(self):
-        with torch.no_grad():
+        phase = self.parallel.phase
+        with torch.no_grad(), phase('preprocess'):
             surface, polar = self.preprocess(self.ground_raw, self.ov_raw)
-        su = self.se(surface)
-        ov = self.oe(polar)
+        with phase('encoders_forward'):
+            su = self.se(surface)
+            ov = self.oe(polar)
         loss, ori, d = self.cvig_fov.sharded_match_loss(ov, su)     # global-batch loss from this rank's [B_global, B] slab
         self.optimizer.zero_grad()
-        loss.backward()          # each encoder's gradient all-reduce starts as soon as its backward node has run
+        with phase('backward_incl_its_collectives'):
+            loss.backward()      # each encoder's gradient all-reduce starts as soon as its backward node has run
         self.reducer.wait()
-        self.optimizer.step()
+        with phase('adam'):
+            self.optimizer.step()
         with torch.no_grad():
             ranks = self.ops.rank_count(d, self.rank * self.B)
         return loss.detach(), ranks, ori
 
     def infer_step(self):
+        phase = self.parallel.phase
         with torch.no_grad():
-            surface, polar = self.preprocess(self.ground_raw, self.ov_raw)
-            su, ov = self.embed(surface, polar)
-            ov_all = self.parallel._all_gather_cat(ov) if self.world > 1 else ov     # global gallery; surfaces stay local
+            with phase('preprocess'):
+                surface, polar = self.preprocess(self.ground_raw, self.ov_raw)
+            with phase('encoders_forward'):
+                su, ov = self.embed(surface, polar)
+            with phase('overhead_all_gather'):
+                ov_all = self.parallel._all_gather_cat(ov) if self.world > 1 else ov     # global gallery; surfaces stay local
             loss, ranks, ori, d = self.cvig_fov.evaluate_global_batch(ov_all, su, self.rank * self.B)
         return loss, ranks, ori
 
@@ -206,6 +214,9 @@ class StepBench(object):
             dist.barrier()
         torch.cuda.synchronize()
         ops.PROFILE = []
+        # per-phase device time of the step (HIP events on the launch stream, witw_amd/parallel.py PhaseTimer): what explains an
+        # N > 1 line -- the collectives' brackets, the stall of the gradient join -- and costs ~15 event records per step
+        timer = self.parallel.PHASES = None if self.graph else self.parallel.PhaseTimer()
         t0 = time.perf_counter()
         for _ in range(steps):
             loss, ranks, ori = self.step()
@@ -215,6 +226,8 @@ class StepBench(object):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         prof, ops.PROFILE = ops.PROFILE, None
+        self.parallel.PHASES = None
+        self.phases = timer.summary(steps) if timer is not None else {}
         if world > 1:
             t = torch.tensor([dt], device=device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -330,7 +343,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--batch', type=int, default=128, help='pairs per GPU (BASELINE.json configs[1]: bs=128)')
     ap.add_argument('--fov', type=int, default=360)
-    ap.add_argument('--mode', choices=['infer', 'train', 'retrieval', 'baseline', 'e2e'], default='infer',
+    ap.add_argument('--mode', choices=['infer', 'train', 'retrieval', 'baseline', 'e2e', 'sweep'], default='infer',
                     help='infer (headline): embedding + similarity; train: the full step of model/cvig_fov.py:444-461; '
                          'retrieval: BASELINE config 5, --gallery rows per GPU x --queries, ranks + top-k; baseline: BASELINE '
                          'config 1, cvig_baseline 32 pairs; e2e: disk -> embeddings through ImagePairDataset + DataLoader workers')
@@ -390,6 +403,8 @@ def main():
         out = baseline_bench(a, device, full=not a.no_cpu_baseline)
     elif a.mode == 'e2e':
         out = e2e_bench(a, device)
+    elif a.mode == 'sweep':
+        out = batch_sweep(a, rank, world, device, ops)
     else:
         out = step_line(a, rank, world, device, cvig_fov, ops)
     if rank == 0:
@@ -401,7 +416,8 @@ def main():
 def step_line(a, rank, world, device, cvig_fov, ops):
     sb = StepBench(a.model, a.mode, a.precision, a.batch, a.fov, rank, world, device, a.graph).run(a.steps, a.warmup)
     out = sb.line()
-    out['collectives'] = collectives_info(a, rank, world, device)          # every rank takes part; rank 0 prints
+    out['collectives'] = collectives_info(a, rank, world, device, sb.phases, sb.ms)          # every rank takes part; rank 0 prints
+    out['guards'] = guards_block(ops)
     headline = world == 1 and a.mode == 'infer' and a.precision == 'fp32' and not a.graph
     side = headline and not a.no_side_blocks and a.model == 'fov' and a.fov == 360 and a.batch == 128
     if headline and not a.no_side_blocks:
@@ -435,24 +451,67 @@ def step_line(a, rank, world, device, cvig_fov, ops):
         torch.cuda.empty_cache()
         out['config1_baseline'] = baseline_bench(a, device, full=not a.no_cpu_baseline)
         torch.cuda.empty_cache()
+        out['batch_sweep'] = batch_sweep(a, rank, world, device, ops)
+        torch.cuda.empty_cache()
         out['config5_retrieval'] = retrieval_block(device, cvig_fov, ops, 125000, 10000, 10, 'dft')
         torch.cuda.empty_cache()
         out['config5_retrieval_direct'] = retrieval_block(device, cvig_fov, ops, 125000, 1024, 10, 'direct')
         torch.cuda.empty_cache()
         from witw_amd import e2e
         keys = ('metric', 'value', 'unit', 'dtype', 'jpeg_decode', 'staging', 'steady_state_pairs_per_s', 'pipeline_fill_s', 'stage_pairs_per_s',
-                'limiting_stage', 'overlap_efficiency_steady_state')
+                'limiting_stage', 'overlap_efficiency_steady_state', 'gpu_stage_serialised_pairs_per_s', 'host_decode_pairs_per_s_per_core',
+                'host_decode_scaling')
         e = e2e.bench(a, device, n_pairs=2048)                       # the headline's fp32 encoders: the GPU is the limiting stage
-        out['e2e_data_path'] = {k: e[k] for k in keys}
+        out['e2e_data_path'] = {k: e[k] for k in keys if k in e}
         out['e2e_data_path']['workload'] = e['config']['workload']
         torch.cuda.empty_cache()
         # the bf16 encoders (configs[3] arithmetic) need 8x the images per second: JPEG back end on the GPU, page-locked ring
         e = e2e.bench(a, device, n_pairs=8192, workers=16, precision='bf16')
-        out['e2e_data_path_bf16'] = {k: e[k] for k in keys}
+        out['e2e_data_path_bf16'] = {k: e[k] for k in keys if k in e}
         out['e2e_data_path_bf16']['workload'] = e['config']['workload']
         torch.cuda.empty_cache()
     if headline and rank == 0 and not a.no_cpu_baseline:      # last: nothing on the GPU waits behind the CPU leg
         out['cpu_baseline'] = cpu_baseline(a, *cpu_args)
+    return out
+
+
+def batch_sweep(a, rank, world, device, ops):
+    """The reference's own default operating points (train / test batch_size 64: model/cvig_fov.py:385,490; cvig_semantic 32:
+    model/cvig_semantic.py:416; cvig_baseline 16) beside the B = 128 the headline is quoted on: the cvig_fov eval step at B = 16, 32, 64,
+    128 in fp32 and bf16, eager and -- where the step is launch-bound -- replayed as one hipGraph. Per point: pairs/s, and for the
+    conv kernel instantiation that takes the most time at that batch its FLOP/s against the MFMA peak (HIP events around every
+    launch, by kernel name), so that a kernel-selection cliff shows as a drop of `frac` against B = 128."""
+    out = {'what': 'cvig_fov fov=360 eval step (the headline workload) at the reference\'s default batch sizes', 'points': []}
+    for precision in ('fp32', 'bf16'):
+        peak = PEAK_BF16_MFMA_TFLOPS if precision == 'bf16' else PEAK_F32_MFMA_TFLOPS
+        for B in (16, 32, 64, 128):
+            sb = StepBench('fov', 'infer', precision, B, a.fov, rank, world, device)
+            k = 5 if precision == 'fp32' else 10
+            ops.PROFILE_BY_KERNEL = {}
+            sb.run(k, 2)
+            byk, ops.PROFILE_BY_KERNEL = ops.PROFILE_BY_KERNEL, None
+            agg = {n: (sum(f for f, _, _ in v), sum(e0.elapsed_time(e1) for _, e0, e1 in v), len(v)) for n, v in byk.items()}
+            top = max(agg, key=lambda n: agg[n][1])
+            conv_ms = sum(v[1] for v in agg.values()) / k
+            pt = {'precision': precision, 'pairs_per_gpu': B, 'value': round(sb.value, 1), 'unit': 'pairs/s', 'ms_per_step': round(sb.ms, 3),
+                  'dominant_kernel': top, 'dominant_kernel_tflops': round(agg[top][0] / (agg[top][1] * 1e-3) / 1e12, 1),
+                  'dominant_kernel_frac': round(agg[top][0] / (agg[top][1] * 1e-3) / 1e12 / peak, 4),
+                  'dominant_kernel_share_of_conv_time': round(agg[top][1] / max(1e-9, sum(v[1] for v in agg.values())), 3),
+                  'all_conv_launches_tflops': sb.roofline['all_conv_launches_tflops'],
+                  'all_conv_launches_frac': round(sb.roofline['all_conv_launches_tflops'] / peak, 4),
+                  'conv_launches_ms_per_step': round(conv_ms, 3),
+                  'kernels': {n: {'launches_per_step': agg[n][2] // k, 'ms_per_step': round(agg[n][1] / k, 4),
+                                  'tflops': round(agg[n][0] / (agg[n][1] * 1e-3) / 1e12, 1)} for n in sorted(agg, key=lambda n: -agg[n][1])}}
+            if sb.ms - conv_ms > 0.15 * sb.ms:        # a sixth of the step is not conv kernels: launch gaps matter -> one hipGraph
+                g = StepBench('fov', 'infer', precision, B, a.fov, rank, world, device, graph=True).run(k, 2)
+                pt['graph_replay'] = {'value': round(g.value, 1), 'ms_per_step': round(g.ms, 3)}
+                del g
+            out['points'].append(pt)
+            del sb
+            torch.cuda.empty_cache()
+    ref = {p['precision']: p for p in out['points'] if p['pairs_per_gpu'] == 128}
+    for p in out['points']:
+        p['all_conv_frac_vs_B128'] = round(p['all_conv_launches_frac'] / max(1e-9, ref[p['precision']]['all_conv_launches_frac']), 3)
     return out
 
 
@@ -615,15 +674,8 @@ def baseline_bench(a, device, full=True, B=32):
             with torch.no_grad():
                 es_r, eo_r = OB.encoder_forward(xs_c, prm[0]), OB.encoder_forward(xo_c, prm[1])
                 return es_r, eo_r, OB.exhaustive_minibatch_triplet_loss(es_r, eo_r), OB.ranks(eo_r, es_r)
-        cpu_step()
-        times = []
-        for _ in range(3):
-            t0 = time.perf_counter()
-            es_r, eo_r, loss_r, ranks_r = cpu_step()
-            times.append(time.perf_counter() - t0)
-        med = sorted(times)[1]
-        out['cpu_baseline'] = {'value': round(B / med, 3), 'unit': 'pairs/s', 'cores': torch.get_num_threads(), 'kind': 'port', 'cpu': cpu_model(),
-                               'sample': 'the same 32 pairs, full eval step, median of 3 after 1 warm-up, torch %s CPU ops' % torch.__version__}
+        es_r, eo_r, loss_r, ranks_r = cpu_step()
+        out['cpu_baseline'] = cpu_thread_sweep(cpu_step, B, 'the same 32 pairs, full eval step')
         out['parity'] = {'max_abs_embedding_diff_vs_oracle': max(float((es.cpu() - es_r).abs().max()), float((eo.cpu() - eo_r).abs().max())),
                          'loss_abs_diff_vs_oracle': abs(float(loss.item()) - float(loss_r)),
                          'ranks_equal_oracle': bool(np.array_equal(ranks.cpu().numpy().astype(np.int64), np.asarray(ranks_r).astype(np.int64))),
@@ -770,12 +822,10 @@ def cpu_model():
 def cpu_baseline(a, g, o, wts, semantic):
     """The oracle (CPU restatement of the reference, kind 'port') timed on this host on a bounded sample of the same workload:
     the first --cpu-pairs pairs (default 32, the batch SURVEY's CPU anchor and BASELINE configs[0] use) of the batch the GPU
-    step ran on, at 8 threads (the survey container's core count) and 16 (the GPU box's CPU share)
-    with torch's own oneDNN / BLAS build. `value` is the better of the two, `cores` the threads it used."""
+    step ran on, with torch's own oneDNN / BLAS build; thread counts and what is reported: cpu_thread_sweep."""
     from oracle import cvig_fov_oracle as O
     n = g.shape[0]
     w = {k: (torch.from_numpy(v[0]), torch.from_numpy(v[1])) for k, v in wts.items()}
-    all_threads = torch.get_num_threads()
     norm = O.image_normalization_semantic if semantic else O.image_normalization
 
     def cpu_step():
@@ -792,38 +842,69 @@ def cpu_baseline(a, g, o, wts, semantic):
             ranks = (d <= torch.diagonal(d)[None, :]).sum(0)
         return su, ov, ori, d, loss, ranks
 
+    return cpu_thread_sweep(cpu_step, n, '%d pairs of the same synthetic batch, full step (transforms+encoders+match+loss+ranks)' % n)
+
+
+def cpu_thread_sweep(fn, units, sample):
+    """ONE convention for every cpu_baseline of the line: the CPU port is timed at 8 threads (the survey
+    container's core count), 16 (this box's CPU share per GPU) and every core torch sees; `value` is the
+    best of them, `cores` the threads it used, all three are listed. One warm-up call, then best of 2 per thread count."""
+    all_threads = torch.get_num_threads()
     by_threads = {}
-    # 8 = the survey container; 16 = this box's CPU share per GPU (more threads than that only oversubscribe it: 128 -> 3.3 pairs/s
-    # against 5.8 at 8 on an EPYC 9575F box); every core as well when the host is small enough for that to be meaningful
-    for threads in sorted({min(8, all_threads), min(16, all_threads)} | ({all_threads} if all_threads <= 32 else set())):
+    fn()
+    for threads in sorted({min(8, all_threads), min(16, all_threads), all_threads}):
         torch.set_num_threads(threads)
-        cpu_step()
         times = []
         for _ in range(2):
             t0 = time.perf_counter()
-            cpu_step()
+            fn()
             times.append(time.perf_counter() - t0)
-        by_threads[threads] = round(n / min(times), 3)
+        by_threads[threads] = round(units / min(times), 3)
     torch.set_num_threads(all_threads)
     best = max(by_threads, key=lambda t: by_threads[t])
     return {'value': by_threads[best], 'unit': 'pairs/s', 'cores': best, 'kind': 'port', 'cpu': cpu_model(),
-            'pairs_per_s_by_threads': {str(t): v for t, v in by_threads.items()},
-            'sample': '%d pairs of the same synthetic batch, full step (transforms+encoders+match+loss+ranks), '
-                      'best of 2 after 1 warm-up per thread count, torch %s CPU ops (oneDNN / BLAS as built)' % (n, torch.__version__)}
+            'pairs_per_s_by_threads': {str(t): v for t, v in by_threads.items()}, 'threads_convention': '8, 16 and all (%d) threads; best reported' % all_threads,
+            'sample': sample + ', best of 2 after 1 warm-up, torch %s CPU ops (oneDNN / BLAS as built)' % torch.__version__}
 
 
-def collectives_info(a, rank, world, device):
+def guards_block(ops):
+    """Which hand-scheduled kernels this run used and which fell back (witw_amd/build.py's register-allocation guards, decided by
+    _lib.load() after the build): a tripped guard is a 6-30 % slower bf16 path, so the line says so itself."""
+    from witw_amd import _lib
+    g = _lib.guards()
+    return {'tripped': sorted(k for k, v in g.items() if not v['hand_scheduled_kernel']),
+            'forced_by_env': sorted(k for k, v in g.items() if v['forced']),
+            'detail': {k: v['detail'] for k, v in g.items() if v['detail']},
+            'bf16_16x16x32_kernel_on': bool(ops.bf16_mfma16()), 'bf16_weight_resident_kernel_on': bool(_lib.load().witw_conv3x3_bf16_wres(-1)),
+            'what': 's16: conv3x3_bf16_s16_kernel (else the 32x32x16 kernel); wres: conv3x3_bf16_wres_kernel for 64-input-channel layers '
+                    '(else the tiled kernels); first2: conv_first2_bf16_kernel (else layers 0 and 2 as two launches)'}
+
+
+def collectives_info(a, rank, world, device, phases=None, step_ms=None):
     """What the process group of this run really is, gathered from EVERY rank (so that an N-GPU line is self-evidencing):
-    backend, world size, RCCL version, which ranks answered and on which device each one ran."""
+    backend, world size, RCCL version, which ranks answered and on which device each one ran; per_phase_ms: device time per step
+    of each phase of the step on rank 0 and the largest value over the ranks (HIP events on the launch stream)."""
     mine = {'rank': rank, 'local_device': int(device.index or 0), 'pid': os.getpid(),
             'device_name': torch.cuda.get_device_name(device), 'pci_bus_id': None}
+    per_phase = None
+    if phases is not None:
+        allp = [phases]
+        if world > 1:
+            allp = [None] * world
+            dist.all_gather_object(allp, phases)
+        names = list(phases)
+        per_phase = {'rank0': phases, 'max_over_ranks': {n: max(p.get(n, 0.0) for p in allp) for n in names},
+                     'ms_per_step': None if step_ms is None else round(step_ms, 3),
+                     'how': 'HIP events on the launch stream around each phase, summed per step and averaged over the timed steps; a blocking '
+                            'collective\'s bracket includes its two stream hand-overs; grad_bucket*_issue_to_joined spans the other encoder\'s '
+                            'backward (overlap window), reducer_wait_stall is what the compute stream loses to the join'}
     try:
         mine['pci_bus_id'] = torch.cuda.get_device_properties(device).pci_bus_id
     except Exception:
         pass
     if world == 1:
         return {'backend': None, 'world': 1, 'rccl_version': None, 'ranks_seen': [0], 'devices': [mine],
-                'note': 'one rank: no process group, no collective on the path'}
+                'note': 'one rank: no process group, no collective on the path', **({'per_phase_ms': per_phase} if per_phase else {})}
     seen = [None] * world
     dist.all_gather_object(seen, mine)
     probe = torch.ones(1, device=device)
@@ -838,6 +919,7 @@ def collectives_info(a, rank, world, device):
             'rccl_version': ver, 'ranks_seen': sorted(d['rank'] for d in seen), 'all_reduce_of_ones': float(probe.item()),
             'devices': sorted(seen, key=lambda d: d['rank']),
             'distinct_devices': len({(d['pci_bus_id'], d['local_device']) for d in seen}),
+            **({'per_phase_ms': per_phase} if per_phase else {}),
             'per_step': 'all-gather of the overhead embeddings (2 MiB per rank at 128 pairs), all-gather of the diagonal, scalar loss '
                         'all-reduce' + ('; reduce-scatter of overhead-embedding gradients, all-reduce(SUM) of 2 x 7.24 M weight gradients'
                                         if a.mode == 'train' else '')}

@@ -42,6 +42,16 @@ def test_bench_two_ranks_self_launched_infer():
     assert c['world'] == 2 and c['ranks_seen'] == [0, 1] and c['backend'] == 'gloo' and c['all_reduce_of_ones'] == 2.0
     assert [d['rank'] for d in c['devices']] == [0, 1] and c['devices'][0]['pid'] != c['devices'][1]['pid']
     assert one['collectives']['world'] == 1 and one['collectives']['ranks_seen'] == [0]
+    # ... and where the step's device time went, phase by phase (HIP events), from every rank: the collectives' own brackets
+    pp = c['per_phase_ms']
+    for name in ('preprocess', 'encoders_forward', 'overhead_all_gather', 'slab_match', 'diagonal_all_gather', 'loss_partial_all_reduce'):
+        assert pp['rank0'][name] > 0 and pp['max_over_ranks'][name] >= pp['rank0'][name], (name, pp)
+    assert sum(pp['rank0'].values()) <= 1.05 * pp['ms_per_step'] + 0.5          # phases are disjoint parts of the step
+    assert set(one['collectives']['per_phase_ms']['rank0']) == set(pp['rank0'])
+    # ... and which register-allocation guards were active (none may have tripped on the validated toolchain)
+    for line in (one, two):
+        g = line['guards']
+        assert g['tripped'] == [] and g['bf16_16x16x32_kernel_on'] is True and g['bf16_weight_resident_kernel_on'] is True, g
 
 
 def test_bench_one_rank_under_the_launcher_equals_the_plain_run():
@@ -71,6 +81,12 @@ def test_bench_two_ranks_self_launched_train_and_retrieval():
     tr = _run_bench('--gpus', '2', '--backend', 'gloo', '--single-device', '--mode', 'train', '--steps', '1', '--warmup', '1',
                     '--batch', '8')
     assert tr['n_gpus'] == 2 and 'training step' in tr['metric'] and np.isfinite(tr['loss'])
+    pp = tr['collectives']['per_phase_ms']
+    for name in ('encoders_forward', 'overhead_all_gather', 'slab_match', 'diagonal_all_gather', 'loss_partial_all_reduce',
+                 'backward_incl_its_collectives', 'row_sigmoid_all_reduce', 'slab_match_backward', 'overhead_grad_reduce_scatter',
+                 'grad_bucket0_all_reduce_issue_to_joined', 'grad_bucket1_all_reduce_issue_to_joined', 'reducer_wait_stall', 'adam'):
+        assert pp['rank0'][name] > 0 and pp['max_over_ranks'][name] >= pp['rank0'][name], (name, pp)
+    assert tr['guards']['tripped'] == []
     rt = _run_bench('--gpus', '2', '--backend', 'gloo', '--single-device', '--mode', 'retrieval', '--gallery', '2000',
                     '--queries', '100', '--steps', '1', '--warmup', '1')
     assert rt['n_gpus'] == 2 and rt['recall']['N'] == 4000

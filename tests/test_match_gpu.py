@@ -155,6 +155,37 @@ def test_fused_resize_normalize_polar_equals_the_three_launches(golden_dir):
     assert torch.equal(ref, got)
 
 
+@pytest.mark.parametrize('B,C,Hi,Wi', [(3, 3, 512, 512), (2, 5, 512, 512), (2, 3, 500, 470), (1, 3, 256, 256)])
+def test_fused_resize_normalize_polar_against_the_oracle_directly(B, C, Hi, Wi):
+    """ops.polar_from_raw against the ORACLE's own composition O.polar_transform(normalise(O.resize_pair(...)[1])) -- not against
+    another HIP path -- at BASELINE's 512 -> 256 raw size (3 bands, and cvig_semantic's 5 bands with its normalisation,
+    model/cvig_semantic.py:167-176), an odd size on the general path and the identity resize. Tolerance: the resize restatement's
+    2e-4 on the 0..255 scale (tests above) carried through /255 and /std (<= 2e-4 / 255 / 0.22 = 3.6e-6) and the polar taps'
+    convex combination, plus fp32 rounding of the normalised values (|x| <= 2.7): 2e-5 absolute."""
+    from witw_amd import ops
+    x = torch.from_numpy(synth.images_u8(90 + C, Hi, (B, C, Hi, Wi)))
+    if C > 3:
+        x[:, 3:] /= 255.0
+    mean, std = (list(O.SEM_MEAN), list(O.SEM_STD)) if C == 5 else (list(O.IMG_MEAN), list(O.IMG_STD))
+    norm = O.image_normalization_semantic if C == 5 else O.image_normalization
+    got = ops.polar_from_raw(x.cuda(), mean=mean, std=std, n_div255=3).cpu()
+    assert got.shape == (B, C, 128, 512)
+    for i in range(B):
+        _s, ov = O.resize_pair(torch.zeros(C, 224, 224), x[i])
+        ref = O.polar_transform(norm(ov))
+        np.testing.assert_allclose(got[i].numpy(), ref.numpy(), rtol=0, atol=2e-5, err_msg=str((B, C, Hi, Wi, i)))
+    # the data path's call form (descriptor table of individually sized uint8 HWC images, GpuPreprocess) against the same oracle
+    if C == 3:
+        from witw_amd import cvig_fov
+        u8 = [x[i].permute(1, 2, 0).to(torch.uint8).numpy() for i in range(B)]
+        g8 = [np.zeros((224, 224, 3), dtype=np.uint8) for _ in range(B)]
+        prep = cvig_fov.GpuPreprocess('witw', 360, random_orientation=False, device=torch.device('cuda:0'))
+        out = prep(cvig_fov.collate_packed([{'surface': g8[i], 'overhead': u8[i]} for i in range(B)]))
+        for i in range(B):
+            ref = O.polar_transform(O.image_normalization(O.resize_pair(torch.zeros(3, 224, 224), x[i])[1]))
+            np.testing.assert_allclose(out['polar'][i].cpu().numpy(), ref.numpy(), rtol=0, atol=2e-5)
+
+
 def test_resize_normalisation_division_is_the_ieee_quotient():
     """The resize kernels divide by 255 and by std through a reciprocal and two fma (csrc/preprocess.hip: div_exact); the result
     must be the correctly rounded quotient, i.e. equal witw_normalize (true divisions) applied to the un-normalised resize --

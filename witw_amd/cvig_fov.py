@@ -1025,13 +1025,17 @@ class _ShardedMatchLossFn(torch.autograd.Function):
         from . import parallel
         b = surface_local.shape[0]
         col0 = parallel.rank() * b
-        ov_all = parallel._all_gather_cat(overhead_local.contiguous())
+        with parallel.phase('overhead_all_gather'):
+            ov_all = parallel._all_gather_cat(overhead_local.contiguous())
         su = surface_local.contiguous()
-        ori, dist, score, ws = k.match_fwd(ov_all, su, want_score=True, want_workspace=True)
+        with parallel.phase('slab_match'):
+            ori, dist, score, ws = k.match_fwd(ov_all, su, want_score=True, want_workspace=True)
         B = ov_all.shape[0]
-        diag = parallel._all_gather_cat(dist[col0:col0 + b].diagonal().contiguous())
-        part = k.triplet_loss_slab_fwd(dist, diag, col0, alpha)
-        parallel.all_reduce_sum_(part)
+        with parallel.phase('diagonal_all_gather'):
+            diag = parallel._all_gather_cat(dist[col0:col0 + b].diagonal().contiguous())
+        with parallel.phase('loss_partial_all_reduce'):
+            part = k.triplet_loss_slab_fwd(dist, diag, col0, alpha)
+            parallel.all_reduce_sum_(part)
         ctx.save_for_backward(ov_all, su, ori, score, ws, dist, diag)
         ctx.cfg = (col0, b, float(alpha), k)
         ctx.mark_non_differentiable(ori, dist)
@@ -1042,11 +1046,15 @@ class _ShardedMatchLossFn(torch.autograd.Function):
         from . import parallel
         ov_all, su, ori, score, ws, dist, diag = ctx.saved_tensors
         col0, b, alpha, k = ctx.cfg
-        rowsig, colsig = k.triplet_loss_slab_sig(dist, diag, col0, alpha)
-        parallel.all_reduce_sum_(rowsig)
-        g_dist = k.triplet_loss_slab_bwd(dist, diag, rowsig, colsig, g_loss.contiguous(), col0, alpha)
-        gov_all, gsu = k.match_bwd(ov_all, su, ori, score, ws, g_dist, True, True)
-        return parallel.reduce_scatter_rows(gov_all, b), gsu, None, None
+        with parallel.phase('row_sigmoid_all_reduce'):
+            rowsig, colsig = k.triplet_loss_slab_sig(dist, diag, col0, alpha)
+            parallel.all_reduce_sum_(rowsig)
+        with parallel.phase('slab_match_backward'):
+            g_dist = k.triplet_loss_slab_bwd(dist, diag, rowsig, colsig, g_loss.contiguous(), col0, alpha)
+            gov_all, gsu = k.match_bwd(ov_all, su, ori, score, ws, g_dist, True, True)
+        with parallel.phase('overhead_grad_reduce_scatter'):
+            gov = parallel.reduce_scatter_rows(gov_all, b)
+        return gov, gsu, None, None
 
 
 def sharded_match_loss(overhead_local, surface_local, alpha=10., _kernels=None):
@@ -1066,13 +1074,16 @@ def evaluate_global_batch(overhead_all, surface_local, col0, alpha=10.):
     the rank counts of its queries and its share of the global-batch loss need; the only exchanges are the
     diagonal (B floats) and the loss partial. -> (loss scalar tensor, ranks int32 [b], orientation [B,b], distance [B,b])."""
     from . import parallel
-    ori, dist = ops.match_fwd(overhead_all.contiguous(), surface_local.contiguous())
+    with parallel.phase('slab_match'):
+        ori, dist = ops.match_fwd(overhead_all.contiguous(), surface_local.contiguous())
     b = surface_local.shape[0]
     B = overhead_all.shape[0]
-    diag_local = dist[col0:col0 + b].diagonal().contiguous()
-    diag = parallel._all_gather_cat(diag_local) if parallel.world() > 1 else diag_local
-    part = ops.triplet_loss_slab_fwd(dist, diag, col0, alpha)
-    parallel.all_reduce_sum_(part)
+    with parallel.phase('diagonal_all_gather'):
+        diag_local = dist[col0:col0 + b].diagonal().contiguous()
+        diag = parallel._all_gather_cat(diag_local) if parallel.world() > 1 else diag_local
+    with parallel.phase('loss_partial_all_reduce'):
+        part = ops.triplet_loss_slab_fwd(dist, diag, col0, alpha)
+        parallel.all_reduce_sum_(part)
     loss = part / (2. * B * (B - 1))
     return loss.reshape(()), ops.rank_count(dist, col0), ori, dist
 

@@ -11,6 +11,7 @@ from . import _lib
 # When set to a list, every conv3x3 launch is bracketed by HIP events on the launch stream and
 # (variant, algorithmic FLOPs, start, end) is appended (bench.py's live roofline measurement).
 PROFILE = None
+PROFILE_BY_KERNEL = None      # bench.py batch sweep: {kernel instantiation (witw_last_kernel_variant): [(flop, start event, end event)]}
 
 
 def _stream():
@@ -129,6 +130,8 @@ def conv_first2_bf16(x_nchw, packed_first, packed_second, circular=False):
     if prof is not None:
         e1.record()
         prof.append((('first2', True), 2.0 * (C + 64) * 64 * 9 * H * W * B, e0, e1))
+        if PROFILE_BY_KERNEL is not None:
+            PROFILE_BY_KERNEL.setdefault('conv_first2_bf16_kernel', []).append((prof[-1][1], e0, e1))
     return y
 
 
@@ -201,6 +204,8 @@ def conv3x3_fwd(x_nhwc, packed, stride_h=1, circular=False, relu=True, pool=Fals
         variant = (lib.witw_conv3x3_tile_n(packed.cout), stride_h, bool(pool),
                    lib.witw_conv3x3_workgroup_waves(B, H, W, packed.cout, stride_h))
         prof.append((variant, 2.0 * packed.cin * packed.cout * (4 if getattr(packed, 'taps4', False) else 9) * Ho * W * B, e0, e1))
+        if PROFILE_BY_KERNEL is not None:
+            PROFILE_BY_KERNEL.setdefault(last_kernel_variant(), []).append((prof[-1][1], e0, e1))
     if want_pool_code:
         return y, code
     return y
@@ -1137,6 +1142,8 @@ def conv3x3_bf16_fwd(x_nhwc, packed, stride_h=1, circular=False, relu=True, pool
         kind = 'bf16_wres' if last_kernel_variant() == 'conv3x3_bf16_wres_kernel' else 'bf16'
         prof.append(((kind, lib.witw_conv3x3_tile_n(packed.cout), stride_h, bool(pool)),
                      2.0 * packed.cin * packed.cout * 9 * Ho * W * B, e0, e1))
+        if PROFILE_BY_KERNEL is not None:
+            PROFILE_BY_KERNEL.setdefault(last_kernel_variant(), []).append((prof[-1][1], e0, e1))
     if want_pool_code:
         return y, code
     return y

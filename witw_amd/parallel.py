@@ -27,6 +27,57 @@ def rank():
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
+class PhaseTimer:
+    """Per-phase device time of a step, for the bench line's `collectives.per_phase_ms`: HIP events recorded on the CURRENT
+    stream in front of and behind each named phase. A blocking torch.distributed collective makes the current stream wait for
+    the communication stream, so the bracket holds the collective plus its two stream hand-overs; for the asynchronous gradient
+    all-reduce the bracket runs from the launch to the point where wait() has joined it (an upper bound of the collective's own
+    duration: the other encoder's backward kernels run inside it) and `reducer_wait_stall` is what the compute stream really
+    loses. Off (PHASES is None) everywhere but in bench.py; CPU tensors (the gloo tests of the host logic) never record."""
+
+    def __init__(self):
+        self.rec = {}          # name -> [(start event, end event)]
+        self.order = []
+
+    def begin(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def end(self, name, e0):
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        if name not in self.rec:
+            self.rec[name] = []
+            self.order.append(name)
+        self.rec[name].append((e0, e1))
+
+    def summary(self, steps):
+        """-> {phase: ms per step} (call after a device synchronize); a phase that runs k times per step is summed"""
+        return {n: round(sum(a.elapsed_time(b) for a, b in self.rec[n]) / max(1, steps), 4) for n in self.order}
+
+
+PHASES = None       # bench.py: parallel.PHASES = parallel.PhaseTimer() for the timed region
+
+
+class phase:
+    """with phase('name'): ... -- a no-op unless PHASES is set"""
+    __slots__ = ('name', 'e0')
+
+    def __init__(self, name):
+        self.name, self.e0 = name, None
+
+    def __enter__(self):
+        if PHASES is not None:
+            self.e0 = PHASES.begin()
+        return self
+
+    def __exit__(self, *exc):
+        if self.e0 is not None and PHASES is not None:
+            PHASES.end(self.name, self.e0)
+        return False
+
+
 def _all_gather_cat(t):
     n = world()
     t = t.contiguous()
@@ -182,7 +233,8 @@ class OverlappedGradReducer:
     def _launch(self, bi):
         if world() == 1 or bi in self.inflight or not self.buckets[bi].params:
             return
-        self.inflight[bi] = dist.all_reduce(self.buckets[bi].flat, op=dist.ReduceOp.SUM, async_op=True)
+        e0 = PHASES.begin() if PHASES is not None and self.buckets[bi].flat.is_cuda else None
+        self.inflight[bi] = (dist.all_reduce(self.buckets[bi].flat, op=dist.ReduceOp.SUM, async_op=True), e0)
 
     def wait(self):
         """-> number of floats reduced."""
@@ -190,9 +242,12 @@ class OverlappedGradReducer:
             if self.buckets[bi].arrived > 0:    # a bucket some of whose gradients never came (unused parameters) goes now
                 self._launch(bi)
         n = 0
-        for bi, work in sorted(self.inflight.items()):
-            work.wait()
-            n += self.buckets[bi].flat.numel()
+        with phase('reducer_wait_stall'):
+            for bi, (work, e0) in sorted(self.inflight.items()):
+                work.wait()
+                if e0 is not None and PHASES is not None:
+                    PHASES.end('grad_bucket%d_all_reduce_issue_to_joined' % bi, e0)
+                n += self.buckets[bi].flat.numel()
         self.inflight = {}
         for b in self.buckets:
             b.arrived = 0
