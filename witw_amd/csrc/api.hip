@@ -20,6 +20,30 @@ void witw_note_variant(const char* fmt, ...) {
     va_end(ap);
 }
 
+// Compute units of the current device (256 on MI355X), looked up once; 256 when the query fails.
+int witw_cu_count() {
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                   ? prop.multiProcessorCount : 256;
+    }
+    return n_cu;
+}
+
+// Does a grid of `workgroups` one-per-CU workgroups (the 8-wave conv tiles: 256 registers per wave, one workgroup per CU) use the
+// chip well? Yes from two full rounds on (the tail is then at most a third of the launch), and below that when its LAST round is at
+// least 90 % full -- e.g. exactly one workgroup per CU: the 16 x 64 maps of the trunk at the reference's default batch of 32
+// (model/cvig_semantic.py:416), which round 3's ">= 512" rule sent to the 4-wave kernels.
+bool witw_fills_rounds(long long workgroups) {
+    const long long cu = witw_cu_count();
+    if (workgroups >= 2 * cu) return true;
+    if (workgroups <= 0) return false;
+    const long long rounds = (workgroups + cu - 1) / cu;
+    return 10 * workgroups >= 9 * cu * rounds;
+}
+
 extern "C" {
 
 const char* witw_last_error(void) { return g_err; }

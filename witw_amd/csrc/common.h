@@ -37,6 +37,9 @@ void witw_note_variant(const char* fmt, ...);   // records the launched instanti
         }                                                                  \
     } while (0)
 
+int witw_cu_count();                        // api.hip
+bool witw_fills_rounds(long long workgroups);
+
 // conv3x3_bf16_wres.hip: the weight-resident 64-input-channel bf16 forward, chosen by witw_conv3x3_bf16_fwd_ex
 bool witw_bf16_wres_applies(int B, int H, int W, int Cin, int Cout);
 int witw_bf16_wres_launch(const void* x, const void* wpk, const float* bias, void* y, int B, int H, int W, int Cout, int pad_circular,

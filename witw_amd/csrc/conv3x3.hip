@@ -657,12 +657,12 @@ int launch_conv_nw(ConvArgs a, hipStream_t st) {
     return WITW_OK;
 }
 
-// 8-wave workgroups (8-row tiles) when no rows are wasted and >= 2 workgroups per CU remain
+// 8-wave workgroups (8-row tiles) when no rows are wasted and the grid fills its rounds of one workgroup per CU (api.hip)
 int choose_waves(int B, int Ho, int Wo, int Cout, int force_nw) {
     const int TN = (Cout >= 128) ? 128 : 64;
     const long long big = (long long)cdiv(Cout, TN) * B * cdiv(Wo, TW_WIDE) * cdiv(Ho, 8);
     if (force_nw == 4) return 4;
-    return (force_nw == 8 || ((Ho % 8) == 0 && big >= 512)) ? 8 : 4;
+    return (force_nw == 8 || ((Ho % 8) == 0 && witw_fills_rounds(big))) ? 8 : 4;
 }
 
 // narrow geometry (2x16-pixel M-tiles, 16-column workgroup tiles) for maps of at most 32 columns

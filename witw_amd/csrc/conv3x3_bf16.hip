@@ -1209,12 +1209,12 @@ int launch_bf(const ConvBfArgs& a, hipStream_t st) {
     const long long big = (long long)cdiv(a.Cout, TN) * a.B * a.tiles_x * cdiv(a.Ho, 8);
     if constexpr (TN == 128 && SH == 1) {
         // the 16x16x32 form: plain inference forward (bf16 NHWC out) of layers large enough for the 8-wave tile
-        if (bf16_mfma16() && (a.Ho % 8) == 0 && big >= 512 && !a.out_nchw_f32 && (a.Cout & 7) == 0 && (a.Cin & 31) == 0) {
+        if (bf16_mfma16() && (a.Ho % 8) == 0 && witw_fills_rounds(big) && !a.out_nchw_f32 && (a.Cout & 7) == 0 && (a.Cin & 31) == 0) {
             if (a.gate || a.dropmask || a.pool_code || a.dil_h) return launch_bf_s16<POOL, true>(a, st);      // training forms
             return launch_bf_s16<POOL, false>(a, st);
         }
     }
-    if ((a.Ho % 8) == 0 && big >= 512) return launch_bf_nw<TN, SH, POOL, 8>(a, st);
+    if ((a.Ho % 8) == 0 && witw_fills_rounds(big)) return launch_bf_nw<TN, SH, POOL, 8>(a, st);
     return launch_bf_nw<TN, SH, POOL, 4>(a, st);
 }
 

@@ -5,19 +5,33 @@
 // and the per-tile prologue (first weight / input stage) + epilogue (accumulators -> LDS -> stores) take 40 % of its time
 // (0.38 of the matrix peak against 0.69 on the 512-channel layers). Here a persistent workgroup owns one block of 64 output
 // channels, keeps that block's whole filter (4 chunks x 9 taps x 64 channels x 16 bf16 = 73.7 KB) in LDS for all of its tiles
-// and only stages the 10 x 34 x 64 input tile of each 8 x 32 output tile -- the layer-2 phase of conv_first2_bf16.hip with the
-// input read from HBM instead of being recomputed. The workgroups of the other channel blocks walk the same tiles in the same
-// order on the same XCD, so the second read of an input tile is an L2 hit.
+// and only stages the input tile of each output tile -- the layer-2 phase of conv_first2_bf16.hip with the input read from HBM
+// instead of being recomputed. The workgroups of the other channel blocks walk the same tiles in the same order on the same XCD,
+// so the second read of an input tile is an L2 hit.
 //
-// Per tile: (1) the input tile, prefetched into registers during the previous tile, -> LDS [channel group of 8][row][pitch 48];
-// (2) 4 K chunks x 9 taps of v_mfma_f32_32x32x16_bf16 per wave (wave = row pair x column half: 32 pixels x 64 channels), the
-// FILTER as the A operand so that a lane ends up with 4 consecutive channels of one pixel, operands by hand-issued ds_read_b128
-// three steps ahead (lds_frag.h); accumulation order chunk-major, tap-minor as in conv3x3_nhwc_bf16_kernel: BIT-IDENTICAL to
-// that kernel; (3) bias + ReLU -> bf16 -> a wave-private slab [16 pixels][64 channels] (8-byte writes) -> 16-byte NHWC stores,
-// one row of the wave's two at a time.
+// Round 4: TWO TEAMS of four waves (one wave of each team per SIMD) on two 8 x 16 tiles half a tile apart in time, as in
+// conv_first2_bf16.hip. Round 3's form ran all eight waves through MFMA loop -> epilogue -> input-to-LDS together (stamps per 8 x 32
+// tile: MFMA loop 3.3 k cycles for the older wave of a SIMD and 5.5 k for the younger, epilogue 1.4-1.6 k, barriers and LDS fill
+// 1 k: 8.0 k against 4.6 k of matrix time). Now, between two workgroup barriers, one team is in its M phase (72 MFMAs per wave
+// back to back + the next tile's global loads, one between MFMA steps) while the other is in its V phase (prefetched input ->
+// LDS, then bias / ReLU / slab / stores of its previous tile).
+//
+// Per team and tile (8 x 16 pixels x 64 channels): V: the next tile's input, prefetched into registers during the previous M
+// phase, -> LDS [channel group of 8][row][pitch 24]; bias + ReLU -> bf16 -> a wave-private slab [8 pixels][64 channels] (8-byte
+// writes) -> 16-byte NHWC stores, one row of the wave's four at a time. M: 4 K chunks x 9 taps of v_mfma_f32_32x32x16_bf16 per
+// wave (M-tile = 4 rows x 8 columns: 32 pixels x 64 channels), the FILTER as the A operand so that a lane ends up with 4
+// consecutive channels of one pixel, operands by hand-issued ds_read_b128 three steps ahead (lds_frag.h); accumulation order
+// chunk-major, tap-minor as in conv3x3_nhwc_bf16_kernel: BIT-IDENTICAL to that kernel.
 #include "common.h"
 #include "lds_frag.h"
 #include <stdlib.h>
+
+#ifndef WITW_WRES_PF
+#define WITW_WRES_PF 3             // (chunk, tap) steps the layer-2 operand reads run ahead of their MFMAs
+#endif
+#ifndef WITW_WRES_PRIO
+#define WITW_WRES_PRIO 1        // s_setprio 1 for the M phase: the matrix-bound wave of a SIMD wins the issue arbitration
+#endif
 
 namespace {
 
@@ -25,15 +39,16 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int WRT = 512;                          // 8 waves, two per SIMD
-constexpr int WTH = 8, WTW = 32;                  // output tile
-constexpr int WAH = WTH + 2, WAW = WTW + 2;       // input tile: 10 x 34 positions
-constexpr int WPITCH = 48;                        // LDS row pitch in positions (conv_first2_bf16.hip: the two rows of an M-tile on disjoint banks)
-constexpr int WPOS = WAH * WPITCH + 1;            // 481 slots per channel group: the 8 groups of one pixel (8 neighbouring lanes of the staging
+constexpr int WRT = 512;                          // 8 waves: two teams of four
+constexpr int WTEAM = 256;
+constexpr int WTH = 8, WTW = 16;                  // output tile of a team
+constexpr int WAH = WTH + 2, WAW = WTW + 2;       // input tile: 10 x 18 positions
+constexpr int WPITCH = 24;                        // LDS row pitch in 16-byte slots (= 8 mod 16: the four rows of an M-tile on disjoint banks)
+constexpr int WPOS = WAH * WPITCH + 1;            // 241 slots per channel group: the 8 groups of one pixel (8 neighbouring lanes of the staging
                                                   // write) start 4 banks apart -- ds_write_b128 serves 8 contiguous lanes per cycle, bank (a/4) % 32
-constexpr int WNIN = (WAH * WAW * 8 + WRT - 1) / WRT;      // 16-byte input chunks per thread and tile (6)
+constexpr int WNIN = (WAH * WAW * 8 + WTEAM - 1) / WTEAM;      // 16-byte input chunks per thread and tile (6)
 constexpr int SLAB_PITCH = 144;                   // bytes per pixel of the output slab (128 + 16: 8-byte writes of 16 lanes on distinct banks)
-constexpr int SLAB_BYTES = 16 * SLAB_PITCH;
+constexpr int SLAB_BYTES = 16 * SLAB_PITCH;       // two rows of the M-tile: 16 pixels
 
 struct WresArgs {
     const u32x4* x;           // NHWC bf16 [B,H,W,64] as 16-byte channel groups
@@ -41,10 +56,10 @@ struct WresArgs {
     const float* bias;        // [>= Cout]
     unsigned short* y;        // NHWC bf16 [B,H,W,Cout]
     int B, H, W, Cout;
-    int tiles_x, tiles_y, n_sp;      // spatial tiles per row / column of an image, in all
+    int tiles_x, tiles_y, n_sp;      // spatial (team) tiles per row / column of an image, in all
     int n_cb;                 // blocks of 64 output channels
     int w_tn;                 // TN of the packing (64 or 128)
-    int q_per_xcd;            // tile walkers per XCD and channel block
+    int q_per_xcd;            // tile-pair walkers per XCD and channel block
     int circ, relu;
 };
 
@@ -53,21 +68,28 @@ __device__ __forceinline__ void wres_wave_sync() {      // one wave's LDS traffi
     __builtin_amdgcn_wave_barrier();
 }
 
-__device__ unsigned long long wres_stamps[2][8];     // WITW_WRES_STAMPS=1 diagnostic: phase ticks of waves 0 and 7, third tile of workgroup 0
+__device__ unsigned long long wres_stamps[2][8];     // WITW_WRES_STAMPS=1 diagnostic: phase ticks of waves 0 and 4 (one per team), third iteration of workgroup 0
 
 template <bool REC>
 __global__ __launch_bounds__(WRT, 1) void conv3x3_bf16_wres_kernel(WresArgs p) {
-    __shared__ u32x4 a_s[8 * WPOS];                 // 61,568 B: input tile
+    __shared__ u32x4 a_s[2 * 8 * WPOS];             // 61,696 B: per team the input tile
     __shared__ u32x4 w_s[4 * 9 * 2 * 64];           // 73,728 B: this channel block's filter
     __shared__ u32x4 slab_s[8 * SLAB_BYTES / 16];   // 18,432 B: one [16 pixels][64 channels] bf16 slab per wave
+    __shared__ f32x4 bias_s[16];                    // this channel block's bias
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int team = wave >> 2, wt = wave & 3, tt = tid & (WTEAM - 1);
     const int l31 = lane & 31, hq = lane >> 5;
+    u32x4* const a_t = a_s + team * (8 * WPOS);
 
     // workgroup -> (XCD, channel block, walker): block i runs on XCD i % 8; the n_cb workgroups of a walker share its tiles
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int cb = slot % p.n_cb, walker = slot / p.n_cb;
-    const int t_first = xcd + 8 * walker, t_step = 8 * p.q_per_xcd;
+    const int pair_first = xcd + 8 * walker, pair_step = 8 * p.q_per_xcd;
+    const int n_pairs = (p.n_sp + 1) >> 1;
+    const int n_it = pair_first < n_pairs ? (n_pairs - 1 - pair_first) / pair_step + 1 : 0;
+    auto tile_of = [&](int it) { return 2 * (pair_first + it * pair_step) + team; };
 
     // ---- once: filter block -> LDS, bias -> registers
     {
@@ -75,43 +97,38 @@ __global__ __launch_bounds__(WRT, 1) void conv3x3_bf16_wres_kernel(WresArgs p) {
         const u32x4* wsrc = p.wpk + (size_t)(cb / per_tile) * (4 * 9 * 2) * p.w_tn + (cb % per_tile) * 64;
         for (int s = tid; s < 4 * 9 * 2 * 64; s += WRT) w_s[s] = wsrc[(size_t)(s >> 6) * p.w_tn + (s & 63)];
     }
-    float bv[2][16];                                // register 4j+e of accumulator nt: channel cb*64 + nt*32 + 8j + 4hq + e
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) bv[nt][r] = p.bias[cb * 64 + nt * 32 + 8 * (r >> 2) + 4 * hq + (r & 3)];
+    if (tid < 64) reinterpret_cast<float*>(bias_s)[tid] = p.bias[cb * 64 + tid];      // read back by the epilogue (32 values per lane: kept out of the M phase's registers)
 
     // this thread's input chunks (tile-relative, the same for every tile): 8 lanes = the 128 bytes of one pixel, a wave = 8 neighbouring
-    // pixels of a row (whole cache lines, 1 KB contiguous inside a tile row). Per tile only a scalar base is added; the chunks on the
-    // tile's rim carry flags, and what a flag means for this tile (padding = out-of-range offset -> the load returns zeros; circular
-    // wrap = +-one row length) is decided on scalars: a dozen vector instructions per tile and thread, no branch.
+    // pixels of a row (whole cache lines). Per tile only a scalar base is added; the chunks on the tile's rim carry flags, and what
+    // a flag means for this tile (padding = out-of-range offset -> the load returns zeros; circular wrap = +-one row length) is
+    // decided on scalars: a dozen vector instructions per tile and thread, no branch.
     constexpr unsigned F_TOP = 1, F_BOT = 2, F_LEFT = 4, F_RIGHT = 8, F_DEAD = 16;
     constexpr unsigned OOR = 0xfffffff0u;           // a buffer offset outside any image
-    unsigned in_lds[WNIN];                          // slot in a_s
+    unsigned in_meta[WNIN];                         // slot in a_t (low 16 bits) | rim flags << 16
     unsigned in_rel[WNIN];                          // byte offset from the tile's first halo pixel (row -1, column -1)
-    unsigned in_flag[WNIN];
 #pragma unroll
     for (int k = 0; k < WNIN; ++k) {
-        const int s = tid + k * WRT;
+        const int s = tt + k * WTEAM;
         const int g = s & 7, pos = s >> 3;
         const bool live = pos < WAH * WAW;
         const int r = live ? pos / WAW : 0, c = live ? pos - r * WAW : 0;
-        in_lds[k] = (unsigned)(g * WPOS + r * WPITCH + c);
         in_rel[k] = ((unsigned)r * (unsigned)p.W + (unsigned)c) * 128u + (unsigned)g * 16u;
-        in_flag[k] = (live ? 0u : F_DEAD) | (r == 0 ? F_TOP : 0u) | (r == WAH - 1 ? F_BOT : 0u) | (c == 0 ? F_LEFT : 0u) | (c == WAW - 1 ? F_RIGHT : 0u);
+        in_meta[k] = (unsigned)(g * WPOS + r * WPITCH + c) |
+                     (((live ? 0u : F_DEAD) | (r == 0 ? F_TOP : 0u) | (r == WAH - 1 ? F_BOT : 0u) | (c == 0 ? F_LEFT : 0u) | (c == WAW - 1 ? F_RIGHT : 0u)) << 16);
     }
     const int tiles_img = p.tiles_x * p.tiles_y;
     const unsigned img_bytes = (unsigned)p.H * (unsigned)p.W * 128u;      // < 2^31 (checked by the caller)
     const unsigned row_bytes = (unsigned)p.W * 128u;
     u32x4 rv[WNIN];
     // Buffer loads, a tile past the end = empty descriptor: straight-line code, so the wait in front of the LDS write counts exactly
-    // these loads (see to_lds below)
+    // these loads
     __amdgpu_buffer_rsrc_t f_rs;
     unsigned f_base = 0, f_kill = 0, f_add_l = 0, f_add_r = 0;
     auto fetch_setup = [&](int t) {                 // wave-uniform part
         const bool any = t < p.n_sp;
-        const int tt = any ? t : 0;
-        const int b = tt / tiles_img, rem = tt - b * tiles_img;
+        const int tl = any ? t : 0;
+        const int b = tl / tiles_img, rem = tl - b * tiles_img;
         const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
         const unsigned char* img = reinterpret_cast<const unsigned char*>(p.x) + (size_t)b * img_bytes;
         f_rs = __builtin_amdgcn_make_buffer_rsrc((void*)img, 0, any ? img_bytes : 0u, 0x00020000);
@@ -125,133 +142,167 @@ __global__ __launch_bounds__(WRT, 1) void conv3x3_bf16_wres_kernel(WresArgs p) {
     };
     auto fetch_one = [&](int k) {
         unsigned off = f_base + in_rel[k];
-        off += (in_flag[k] & F_LEFT) ? f_add_l : 0u;
-        off += (in_flag[k] & F_RIGHT) ? f_add_r : 0u;
-        off = (in_flag[k] & f_kill) ? OOR : off;
+        off += (in_meta[k] & (F_LEFT << 16)) ? f_add_l : 0u;
+        off += (in_meta[k] & (F_RIGHT << 16)) ? f_add_r : 0u;
+        off = (in_meta[k] & (f_kill << 16)) ? OOR : off;
         rv[k] = __builtin_amdgcn_raw_buffer_load_b128(f_rs, off, 0, 0);
     };
-
-    // layer roles (conv_first2_bf16.hip): wave = (row pair, column half); lane l31 -> pixel (row l31 >> 4, column l31 & 15)
-    const int prow = wave >> 1, chalf = wave & 1;
-    const int a_lane = ((2 * prow + (l31 >> 4)) * WPITCH + 16 * chalf + (l31 & 15));
-    unsigned char* slab = reinterpret_cast<unsigned char*>(slab_s) + wave * SLAB_BYTES;
-    const unsigned relu_floor = p.relu ? 0u : 0x80008000u;      // witw_relu_bf16x2
-
-    // The first tile's input goes to LDS here, every later one at the bottom of the loop: ONE place inside the loop where the
-    // prefetched registers are consumed, always behind the same sequence (6 loads, then the 4 output stores), so that its wait is
-    // vmcnt(4..9) -- reached from two paths of different depth it would be vmcnt(0): a store round trip per tile.
     auto to_lds = [&]() {
 #pragma unroll
         for (int k = 0; k < WNIN; ++k)
-            if (!(in_flag[k] & F_DEAD)) a_s[in_lds[k]] = rv[k];
+            if (!(in_meta[k] & (F_DEAD << 16))) a_t[in_meta[k] & 0xffffu] = rv[k];
     };
-    fetch_setup(t_first);
-#pragma unroll
-    for (int k = 0; k < WNIN; ++k) fetch_one(k);
-    to_lds();
-    __syncthreads();                                // filter and first input tile in LDS
-    // everything loaded so far (filter fragments, biases) has landed: said with the builtin, so that the compiler's counter
-    // bookkeeping enters the loop clean -- otherwise the first use of such a register INSIDE the loop carries a vmcnt(0) in every
-    // iteration, i.e. a wait for the prefetch loads issued just before it
-    __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0), expcnt / lgkmcnt untouched
-    int iter = 0;
-    for (int t = t_first; t < p.n_sp; t += t_step, ++iter) {
-        const bool rec = REC && blockIdx.x == 0 && iter == 2 && lane == 0 && (wave == 0 || wave == 7);
-        auto stamp = [&](int k) { if (rec) wres_stamps[wave == 7][k] = __builtin_amdgcn_s_memtime(); };
-        stamp(0);
-        const int b = t / tiles_img, rem = t - b * tiles_img;
-        const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
-        const int oy0 = ty * WTH, ox0 = tx * WTW;
 
-        // ---- (1) the next tile's loads go out one at a time between the MFMA steps (all six at once queue up behind each other
-        // in the texture path and hold the wave at the issue of the last ones)
-        asm volatile("" ::: "memory");
-        fetch_setup(t + t_step);
-        stamp(1);
+    // roles inside a team (conv_first2_bf16.hip): wave wt = (row block wt >> 1, column block wt & 1); M-tile 4 rows x 8 columns,
+    // lane l31 -> pixel (row l31 >> 3, column l31 & 7)
+    const int mrow = wt >> 1, mcol = wt & 1;
+    const int a_lane = ((4 * mrow + (l31 >> 3)) * WPITCH + 8 * mcol + (l31 & 7));
+    unsigned char* const slab = reinterpret_cast<unsigned char*>(slab_s) + wave * SLAB_BYTES;
+    const unsigned relu_floor = p.relu ? 0u : 0x80008000u;      // witw_relu_bf16x2
 
-        // ---- (2) 36 (chunk, tap) steps of 2 MFMAs per wave
-        f32x16 acc[2];
+    f32x16 acc[2];
+    int pb = 0, poy0 = 0, pox0 = 0;                 // the tile whose accumulators are waiting for their epilogue
+    bool pvalid = false;
+    // ---- epilogue, D[channel][pixel]: lane = pixel l31, registers 4j..4j+3 of accumulator nt = channels nt*32 + 8j + 4hq + {0..3};
+    // one row (8 pixels) of the M-tile at a time through the slab: 8 x 128 bytes = 64 lanes x 16 bytes
+    auto epilogue = [&]() {
+        f32x4 bq[2][4];                             // bq[nt][j][e]: channel cb*64 + nt*32 + 8j + 4hq + e <-> register 4j+e of accumulator nt
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
-        constexpr int PF = 3, NB = PF + 1;
-        u32x4 fa[NB], fb[NB][2];
-        const unsigned abase = lds_address(a_s) + (unsigned)(hq * WPOS + a_lane) * 16u;
-        const unsigned wbase = lds_address(w_s) + (unsigned)(hq * 64 + l31) * 16u;
-        auto a_addr = [&](int step) {
-            const int kc = step / 9, tap = step - kc * 9;
-            const int kh = tap / 3, kw = tap - kh * 3;
-            return abase + (unsigned)(2 * kc * WPOS + kh * WPITCH + kw) * 16u;
-        };
-        auto w_addr = [&](int step, int nt) { return wbase + (unsigned)(step * 128 + nt * 32) * 16u; };
-        int issued = 0;
-        auto issue = [&](int step, int which) {
-            const int bq = step % NB;
-            if (which == 0) fa[bq] = lds_read128(a_addr(step));
-            else fb[bq][which - 1] = lds_read128(w_addr(step, which - 1));
-            ++issued;
-        };
+            for (int j = 0; j < 4; ++j) bq[nt][j] = reinterpret_cast<const f32x4*>(bias_s)[nt * 8 + 2 * j + hq];
+        // two rounds of two M-tile rows (16 pixels) through the slab. One wave's LDS operations execute in order, so neither the
+        // read-back behind the writes nor the second round's writes behind the first round's reads need a wait of their own: the
+        // only waits are the ones in front of the stores (the values' first use). (A first form synchronised four one-row rounds:
+        // eight LDS round trips in a row, 2.9 k cycles beside the other team's operand reads.)
+        u32x4 v[4];
 #pragma unroll
-        for (int st = 0; st < PF; ++st)
-#pragma unroll
-            for (int which = 0; which < 3; ++which) issue(st, which);
-#pragma unroll
-        for (int step = 0; step < 36; ++step) {
-            const int bq = step % NB;
-            const bool more = step + PF < 36;
-            lds_wait(issued - (3 * step + 2), fa[bq], fb[bq][0]);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb[bq][0]), __builtin_bit_cast(bf16x8, fa[bq]), acc[0], 0, 0, 0);
-            if (more) {
-                issue(step + PF, 0);
-                issue(step + PF, 1);
-            }
-            lds_wait(issued - (3 * step + 3), fb[bq][1]);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb[bq][1]), __builtin_bit_cast(bf16x8, fa[bq]), acc[1], 0, 0, 0);
-            if (more) issue(step + PF, 2);
-            if (step % 5 == 2 && step / 5 < WNIN) {
-                __builtin_amdgcn_sched_barrier(0);
-                fetch_one(step / 5);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-
-        stamp(2);
-        // ---- (3) D[channel][pixel]: lane = pixel l31, registers 4j..4j+3 of accumulator nt = channels nt*32 + 8j + 4hq + {0..3}
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            if ((l31 >> 4) == h) {
+        for (int rnd = 0; rnd < 2; ++rnd) {
+            if ((l31 >> 4) == rnd) {
                 unsigned char* dst = slab + (l31 & 15) * SLAB_PITCH + 8 * hq;
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         u32x2 ob;
-                        ob[0] = witw_relu_bf16x2(witw_pack_bf16x2(acc[nt][4 * j] + bv[nt][4 * j], acc[nt][4 * j + 1] + bv[nt][4 * j + 1]), relu_floor);
-                        ob[1] = witw_relu_bf16x2(witw_pack_bf16x2(acc[nt][4 * j + 2] + bv[nt][4 * j + 2], acc[nt][4 * j + 3] + bv[nt][4 * j + 3]), relu_floor);
+                        ob[0] = witw_relu_bf16x2(witw_pack_bf16x2(acc[nt][4 * j] + bq[nt][j][0], acc[nt][4 * j + 1] + bq[nt][j][1]), relu_floor);
+                        ob[1] = witw_relu_bf16x2(witw_pack_bf16x2(acc[nt][4 * j + 2] + bq[nt][j][2], acc[nt][4 * j + 3] + bq[nt][j][3]), relu_floor);
                         *reinterpret_cast<u32x2*>(dst + (nt * 32 + 8 * j) * 2) = ob;
                     }
             }
-            wres_wave_sync();
-            const int oy = oy0 + 2 * prow + h;
+            __builtin_amdgcn_wave_barrier();            // (compiler only: the other lanes' writes stay in front of the reads)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const int c = lane + 64 * i;
-                const int px = c >> 3, c8 = c & 7;
-                const u32x4 v = *reinterpret_cast<const u32x4*>(slab + px * SLAB_PITCH + c8 * 16);
-                const int ox = ox0 + 16 * chalf + px;
-                __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p.y + (((size_t)b * p.H + oy) * p.W + ox) * p.Cout + cb * 64 + c8 * 8));
+                const int c = lane + 64 * i;            // 16 pixels x 8 channel octets
+                v[2 * rnd + i] = *reinterpret_cast<const u32x4*>(slab + (c >> 3) * SLAB_PITCH + (c & 7) * 16);
             }
-            wres_wave_sync();
+            __builtin_amdgcn_wave_barrier();
         }
-        stamp(3);
-        __syncthreads();                            // every wave has left the MFMA loop: a_s may be overwritten
-        stamp(4);
-        to_lds();
-        stamp(5);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = lane + 64 * (k & 1);
+            const int px = c >> 3, c8 = c & 7;          // pixel 0..15 of the round: row px >> 3, column px & 7
+            const int oy = poy0 + 4 * mrow + 2 * (k >> 1) + (px >> 3), ox = pox0 + 8 * mcol + (px & 7);
+            if (pvalid)
+                __builtin_nontemporal_store(v[k], reinterpret_cast<u32x4*>(p.y + (((size_t)pb * p.H + oy) * p.W + ox) * p.Cout + cb * 64 + c8 * 8));
+        }
+    };
+
+    // the first tile's input goes to LDS here; inside the loop the registers prefetched during an M phase are consumed at ONE place
+    // (top of the next V phase), always behind the same sequence of memory operations
+    fetch_setup(tile_of(0));
+#pragma unroll
+    for (int k = 0; k < WNIN; ++k) fetch_one(k);
+    to_lds();
+    // everything loaded so far (filter, biases, the first input tile) has landed: said with the builtin, so that the compiler's
+    // counter bookkeeping enters the loop clean
+    __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0), expcnt / lgkmcnt untouched
+    __syncthreads();                                // filter and both teams' first input tiles in LDS
+    if (team) __syncthreads();                      // team 1 runs half a tile behind: its V phases meet team 0's M phases
+
+    for (int it = 0; it < n_it; ++it) {
+        const bool rec = REC && blockIdx.x == 0 && it == 2 && lane == 0 && wt == 0;
+        auto stamp = [&](int k) { if (rec) wres_stamps[team][k] = __builtin_amdgcn_s_memtime(); };
+        stamp(0);
+        const int t = tile_of(it);
+        const bool valid = t < p.n_sp;
+        const int tl = valid ? t : 0;
+        const int b = tl / tiles_img, rem = tl - b * tiles_img;
+        const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+
+        // ================= V phase (the other team is in its M phase) =================
+        if (WITW_WRES_PRIO) __builtin_amdgcn_s_setprio(WITW_WRES_PRIO == 2 ? 1 : 0);
+        if (it > 0) {
+            // the team's input tile was last read in the previous M phase, a barrier ago; the loads of this tile were issued there
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            to_lds();
+            stamp(1);
+            epilogue();
+        }
+        stamp(2);
         __syncthreads();
-        stamp(6);
+        stamp(3);
+
+        // ================= M phase (the other team is in its V phase) =================
+        if (WITW_WRES_PRIO) __builtin_amdgcn_s_setprio(WITW_WRES_PRIO == 2 ? 0 : 1);
+        // the next tile's loads go out one at a time between the MFMA steps (all six at once queue up behind each other in the
+        // texture path and hold the wave at the issue of the last ones)
+        asm volatile("" ::: "memory");
+        fetch_setup(tile_of(it + 1));
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+        {
+            constexpr int PF = WITW_WRES_PF, NB = PF + 1;
+            u32x4 fa[NB], fb[NB][2];
+            const unsigned abase = lds_address(a_t) + (unsigned)(hq * WPOS + a_lane) * 16u;
+            const unsigned wbase = lds_address(w_s) + (unsigned)(hq * 64 + l31) * 16u;
+            auto a_addr = [&](int step) {
+                const int kc = step / 9, tap = step - kc * 9;
+                const int kh = tap / 3, kw = tap - kh * 3;
+                return abase + (unsigned)(2 * kc * WPOS + kh * WPITCH + kw) * 16u;
+            };
+            auto w_addr = [&](int step, int nt) { return wbase + (unsigned)(step * 128 + nt * 32) * 16u; };
+            int issued = 0;
+            auto issue = [&](int step, int which) {
+                const int bq = step % NB;
+                if (which == 0) fa[bq] = lds_read128(a_addr(step));
+                else fb[bq][which - 1] = lds_read128(w_addr(step, which - 1));
+                ++issued;
+            };
+#pragma unroll
+            for (int st = 0; st < PF; ++st)
+#pragma unroll
+                for (int which = 0; which < 3; ++which) issue(st, which);
+#pragma unroll
+            for (int step = 0; step < 36; ++step) {
+                const int bq = step % NB;
+                const bool more = step + PF < 36;
+                lds_wait(issued - (3 * step + 2), fa[bq], fb[bq][0]);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb[bq][0]), __builtin_bit_cast(bf16x8, fa[bq]), acc[0], 0, 0, 0);
+                if (more) {
+                    issue(step + PF, 0);
+                    issue(step + PF, 1);
+                }
+                lds_wait(issued - (3 * step + 3), fb[bq][1]);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb[bq][1]), __builtin_bit_cast(bf16x8, fa[bq]), acc[1], 0, 0, 0);
+                if (more) issue(step + PF, 2);
+                if (step % 5 == 2 && step / 5 < WNIN) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    fetch_one(step / 5);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        pb = b; poy0 = ty * WTH; pox0 = tx * WTW; pvalid = valid;
+        stamp(4);
+        __syncthreads();
+        stamp(5);
     }
+    if (WITW_WRES_PRIO) __builtin_amdgcn_s_setprio(WITW_WRES_PRIO == 2 ? 1 : 0);
+    if (n_it > 0) epilogue();
+    if (!team) __syncthreads();                     // team 0 is half a tile ahead: the barrier team 1's last M phase ends on
 }
 
 }  // namespace
@@ -270,7 +321,7 @@ static int wres_enabled() {
 bool witw_bf16_wres_applies(int B, int H, int W, int Cin, int Cout) {
     if (!wres_enabled() || Cin != 64 || Cout < 64 || (Cout % 64) != 0 || (H % WTH) != 0 || (W % WTW) != 0) return false;
     const long long n_sp = (long long)B * (H / WTH) * (W / WTW);
-    return n_sp * (Cout / 64) >= 16 * 256 && n_sp < 0x7fffffffLL;
+    return n_sp * (Cout / 64) >= 32 * 256 && n_sp < 0x7fffffffLL;      // 16 tile pairs per workgroup pay for loading the filter block once
 }
 
 int witw_bf16_wres_launch(const void* x, const void* wpk, const float* bias, void* y, int B, int H, int W, int Cout, int pad_circular,
@@ -279,7 +330,7 @@ int witw_bf16_wres_launch(const void* x, const void* wpk, const float* bias, voi
     a.x = (const u32x4*)x; a.wpk = (const u32x4*)wpk; a.bias = bias; a.y = (unsigned short*)y;
     a.B = B; a.H = H; a.W = W; a.Cout = Cout;
     a.tiles_x = W / WTW; a.tiles_y = H / WTH;
-    a.n_sp = B * a.tiles_x * a.tiles_y;
+    a.n_sp = B * a.tiles_x * a.tiles_y;            // team tiles; a workgroup walks pairs of them
     a.n_cb = Cout / 64;
     a.w_tn = Cout >= 128 ? 128 : 64;
     a.circ = pad_circular; a.relu = relu;
@@ -294,16 +345,16 @@ int witw_bf16_wres_launch(const void* x, const void* wpk, const float* bias, voi
     if (q < 1) q = 1;
     a.q_per_xcd = q;
     const unsigned grid = 8u * (unsigned)(q * a.n_cb);
-    const bool rec = getenv("WITW_WRES_STAMPS") != nullptr && a.n_sp >= 3 * 8 * q;      // diagnostic, synchronous
+    const bool rec = getenv("WITW_WRES_STAMPS") != nullptr && (a.n_sp + 1) / 2 >= 3 * 8 * q;      // diagnostic, synchronous
     if (rec) {
         hipLaunchKernelGGL(conv3x3_bf16_wres_kernel<true>, dim3(grid), dim3(WRT), 0, (hipStream_t)stream, a);
         (void)hipDeviceSynchronize();
         unsigned long long h[2][8];
         if (hipMemcpyFromSymbol(h, HIP_SYMBOL(wres_stamps), sizeof(h)) == hipSuccess)
             for (int w = 0; w < 2; ++w)
-                fprintf(stderr, "conv3x3_bf16_wres wave %d, third tile (ticks): fetch issue %llu, MFMA loop %llu, epilogue %llu, barrier %llu, "
-                                "input->LDS %llu, barrier %llu, total %llu\n", w ? 7 : 0, h[w][1] - h[w][0], h[w][2] - h[w][1], h[w][3] - h[w][2],
-                        h[w][4] - h[w][3], h[w][5] - h[w][4], h[w][6] - h[w][5], h[w][6] - h[w][0]);
+                fprintf(stderr, "conv3x3_bf16_wres team %d (wave %d), third iteration (ticks): V input->LDS %llu, V epilogue %llu, barrier %llu, "
+                                "M MFMA loop %llu, barrier %llu, total %llu\n", w, 4 * w, h[w][1] - h[w][0], h[w][2] - h[w][1], h[w][3] - h[w][2],
+                        h[w][4] - h[w][3], h[w][5] - h[w][4], h[w][5] - h[w][0]);
     } else {
         hipLaunchKernelGGL(conv3x3_bf16_wres_kernel<false>, dim3(grid), dim3(WRT), 0, (hipStream_t)stream, a);
     }

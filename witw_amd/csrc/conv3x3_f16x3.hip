@@ -544,7 +544,7 @@ int launch_hx_nw(ConvHxArgs a, hipStream_t st) {
 template <int TN, int SH, bool POOL>
 int launch_hx(const ConvHxArgs& a, hipStream_t st) {
     const long long big = (long long)cdiv(a.Cout, TN) * a.B * a.tiles_x * cdiv(a.Ho, 8);
-    if ((a.Ho % 8) == 0 && big >= 512) return launch_hx_nw<TN, SH, POOL, 8>(a, st);
+    if ((a.Ho % 8) == 0 && witw_fills_rounds(big)) return launch_hx_nw<TN, SH, POOL, 8>(a, st);
     return launch_hx_nw<TN, SH, POOL, 4>(a, st);
 }
 

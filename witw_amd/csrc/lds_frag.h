@@ -19,6 +19,20 @@ __device__ __forceinline__ u32x4 lds_read128(unsigned addr) {
     asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
     return v;
 }
+typedef unsigned int u32x2_frag __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32x2_frag lds_read64(unsigned addr) {
+    u32x2_frag v;
+    asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
+// s_waitcnt lgkmcnt(0) over a whole array of fragments (everything this wave has in the LDS queue has landed)
+template <typename T, int N>
+__device__ __forceinline__ void lds_wait_all(T (&f)[N]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("" : "+v"(f[i]));      // the consumers of f[i] stay behind the wait
+}
+
 // s_waitcnt lgkmcnt(n) that names the fragments it releases, so that the MFMAs reading them cannot be scheduled above it
 __device__ __forceinline__ void lds_wait(int n, u32x4& a) {
     switch (n) {      // n is a constant once the caller's loop is unrolled
@@ -32,7 +46,12 @@ __device__ __forceinline__ void lds_wait(int n, u32x4& a) {
     case 7: asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(a)); break;
     case 8: asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(a)); break;
     case 9: asm volatile("s_waitcnt lgkmcnt(9)" : "+v"(a)); break;
-    default: asm volatile("s_waitcnt lgkmcnt(10)" : "+v"(a)); break;
+    case 10: asm volatile("s_waitcnt lgkmcnt(10)" : "+v"(a)); break;
+    case 11: asm volatile("s_waitcnt lgkmcnt(11)" : "+v"(a)); break;
+    case 12: asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(a)); break;
+    case 13: asm volatile("s_waitcnt lgkmcnt(13)" : "+v"(a)); break;
+    case 14: asm volatile("s_waitcnt lgkmcnt(14)" : "+v"(a)); break;
+    default: asm volatile("s_waitcnt lgkmcnt(15)" : "+v"(a)); break;      // the counter field has 4 bits: deeper queues wait here (conservative)
     }
 }
 __device__ __forceinline__ void lds_wait(int n, u32x4& a, u32x4& b) {
@@ -47,7 +66,12 @@ __device__ __forceinline__ void lds_wait(int n, u32x4& a, u32x4& b) {
     case 7: asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(a), "+v"(b)); break;
     case 8: asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(a), "+v"(b)); break;
     case 9: asm volatile("s_waitcnt lgkmcnt(9)" : "+v"(a), "+v"(b)); break;
-    default: asm volatile("s_waitcnt lgkmcnt(10)" : "+v"(a), "+v"(b)); break;
+    case 10: asm volatile("s_waitcnt lgkmcnt(10)" : "+v"(a), "+v"(b)); break;
+    case 11: asm volatile("s_waitcnt lgkmcnt(11)" : "+v"(a), "+v"(b)); break;
+    case 12: asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(a), "+v"(b)); break;
+    case 13: asm volatile("s_waitcnt lgkmcnt(13)" : "+v"(a), "+v"(b)); break;
+    case 14: asm volatile("s_waitcnt lgkmcnt(14)" : "+v"(a), "+v"(b)); break;
+    default: asm volatile("s_waitcnt lgkmcnt(15)" : "+v"(a), "+v"(b)); break;      // the counter field has 4 bits: deeper queues wait here (conservative)
     }
 }
 
