@@ -167,3 +167,28 @@ def test_first_layer_fast_path_matches_oracle(shape):
     refb = torch.relu(O.conv3x3(torch.from_numpy(x).bfloat16().float(), torch.from_numpy(w).bfloat16().float(),
                                 torch.from_numpy(b), 1, circ)).bfloat16().float()
     np.testing.assert_allclose(yb.float().cpu().permute(0, 3, 1, 2).numpy(), refb.numpy(), rtol=2 ** -7, atol=1e-6)
+
+
+@pytest.mark.parametrize('case', [(24, 3, 64, 512, True), (32, 3, 72, 200, False), (18, 4, 64, 520, True), (40, 1, 40, 330, False)])
+def test_first_layer_persistent_kernel_equals_the_tile_per_workgroup_kernel(case):
+    """conv3x3_first_persist_kernel (round 4: two persistent workgroups per CU, the next tile's pixels requested before the current
+    tile's MFMAs; taken from 4 x CUs tiles on, W >= 66) against conv3x3_first_kernel, which the same images take when they are
+    launched one at a time (fewer tiles than the threshold): the same products in the same order, so the same BITS; and against
+    the oracle on a spread of images. Ragged widths / heights, both paddings, 1 / 3 / 4 channels."""
+    from witw_amd import ops
+    B, C, H, W, circ = case
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    assert B * ((W + 63) // 64) * ((H + 7) // 8) >= 4 * n_cu and ((W + 63) // 64) * ((H + 7) // 8) < 4 * n_cu
+    g = np.random.Generator(np.random.Philox(key=[7, H * W + C]))
+    x = g.standard_normal((B, C, H, W), dtype=np.float32)
+    w = (g.standard_normal((64, C, 3, 3), dtype=np.float32) * 0.3).astype(np.float32)
+    b = (g.standard_normal((64,), dtype=np.float32) * 0.2).astype(np.float32)
+    dev = torch.device('cuda:0')
+    pk = ops.PackedFirstConv(torch.from_numpy(w).to(dev), torch.from_numpy(b).to(dev))
+    xd = torch.from_numpy(x).to(dev)
+    y = ops.conv3x3_first_fwd(xd, pk, circular=circ)
+    one = torch.cat([ops.conv3x3_first_fwd(xd[i:i + 1].contiguous(), pk, circular=circ) for i in range(B)])
+    assert torch.equal(y, one), float((y - one).abs().max())
+    sel = [0, B // 2, B - 1]
+    ref = O.conv3x3(torch.from_numpy(x[sel]), torch.from_numpy(w), torch.from_numpy(b), 1, circ).clamp_min(0)
+    np.testing.assert_allclose(y[sel].cpu().permute(0, 3, 1, 2).numpy(), ref.numpy(), rtol=0, atol=2e-5 * float(ref.abs().max()))

@@ -8,6 +8,7 @@
 // three NCHW planes directly. The layer is bound by its output stream (64 channels per pixel), which leaves
 // through the same LDS-transposed 16-byte stores as the generic kernel, in fp32 or bf16.
 #include "common.h"
+#include <stdlib.h>
 #include <type_traits>
 
 namespace {
@@ -163,6 +164,147 @@ __global__ __launch_bounds__(FT, 2) void conv3x3_first_kernel(FirstArgs p) {
                     *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p.y) + (((size_t)b * p.H + yy) * p.W + xx) * 64 + pc8) = o;
             }
         }
+    }
+}
+
+// fp32 output, PERSISTENT form (round 4). The kernel above is bound by its 2.1 GB output stream (B = 128) but ran at half the rate a
+// plain fill reaches on the same box (3.98 against 6.9 TB/s): a workgroup's life was input loads (their latency exposed: nothing
+// else to do) -> 60 MFMAs per wave -> slabs -> stores, and its successor started from scratch. Here two workgroups per CU walk the
+// tiles: the NEXT tile's pixels are requested before the MFMAs of the current one and written to the other half of a double-buffered
+// input image at the end of the iteration (one barrier per tile), the slabs no longer alias the operands (4 KB per wave, one
+// (M-tile, N-tile) at a time), so a workgroup's stores drain under its next tile's MFMAs and under the other workgroup's. Same
+// products, same accumulation order, same bits as conv3x3_first_kernel.
+constexpr int FIN = FIH * FIW;                 // 660 pixels of a tile's input image
+constexpr int FPX = (FIN + FT - 1) / FT;       // input pixels per thread (2)
+
+__global__ __launch_bounds__(FT, 2) void conv3x3_first_persist_kernel(FirstArgs p) {
+    __shared__ f32x4 in2_s[2 * FIN];             // 21,120 B
+    __shared__ f32x4 wp_s[640];                  // 10,240 B
+    __shared__ float slab_s[8 * 16 * 64];        // 32,768 B: one 16 pixel x 64 channel slab per wave
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hq = lane >> 5;
+    const int tiles_img = p.tiles_x * p.tiles_y;
+    const int n_tiles = p.B * tiles_img;
+    const size_t plane = (size_t)p.H * p.W;
+    const unsigned img_bytes = (unsigned)p.C * (unsigned)plane * 4u;       // < 2^31 (launcher)
+    constexpr unsigned OOR = 0xfffffff0u;
+
+    // this thread's input pixels: tile-relative (row, column), the same for every tile
+    int pr[FPX], pc[FPX];
+#pragma unroll
+    for (int k = 0; k < FPX; ++k) {
+        const int s = tid + k * FT;
+        pr[k] = s < FIN ? s / FIW : -100000;
+        pc[k] = s < FIN ? s - (s / FIW) * FIW : 0;
+    }
+    float rv[FPX][4];
+    auto fetch = [&](int tile) {                 // buffer loads: padding, missing channels and tiles past the end read zeros
+        const bool any = tile < n_tiles;
+        const int tl = any ? tile : 0;
+        const int b = tl / tiles_img, rem = tl - b * tiles_img;
+        const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+        const unsigned char* img = reinterpret_cast<const unsigned char*>(p.x) + (size_t)b * img_bytes;
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)img, 0, any ? img_bytes : 0u, 0x00020000);
+#pragma unroll
+        for (int k = 0; k < FPX; ++k) {
+            const int gr = ty * 8 - 1 + pr[k];
+            int gc = tx * 64 - 1 + pc[k];
+            bool ok = gr >= 0 && gr < p.H;
+            if (p.circ) {                        // gc in [-1, W + 64]: W >= 66 (launcher) -> one wrap
+                gc += gc < 0 ? p.W : 0;
+                gc -= gc >= p.W ? p.W : 0;
+            } else {
+                ok = ok && gc >= 0 && gc < p.W;
+            }
+            const unsigned off = ok ? (unsigned)(gr * p.W + gc) * 4u : OOR;
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch)       // plane ch; ch >= C lies behind the descriptor's end
+                rv[k][ch] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, (unsigned)ch * (unsigned)plane * 4u, 0));
+        }
+    };
+    auto to_lds = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < FPX; ++k)
+            if (tid + k * FT < FIN) in2_s[buf * FIN + tid + k * FT] = (f32x4){rv[k][0], rv[k][1], rv[k][2], rv[k][3]};
+    };
+
+    for (int s = tid; s < 640; s += FT) wp_s[s] = reinterpret_cast<const f32x4*>(p.wf)[s];
+    float bv[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) bv[nt] = p.bias[nt * 32 + l31];
+    const int row0 = 2 * (wave >> 1), col0 = 32 * (wave & 1);
+    float* slab = slab_s + wave * (16 * 64);
+
+    fetch(blockIdx.x);
+    to_lds(0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);          // everything loaded so far has landed (keeps vmcnt(0) out of the loop body)
+    int it = 0;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, ++it) {
+        const int b = tile / tiles_img, rem = tile - b * tiles_img;
+        const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+        const int oy0 = ty * 8, ox0 = tx * 64;
+        const f32x4* in_s = in2_s + (it & 1) * FIN;
+        __syncthreads();                         // this tile's input image is complete; the other half is free
+        fetch(tile + (int)gridDim.x);
+
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int tapA = 2 * i, tapB = (2 * i + 1 < 9) ? 2 * i + 1 : 0;     // tap 9 does not exist: zero weights
+            const int offA = (tapA / 3) * FIW + tapA % 3, offB = (tapB / 3) * FIW + tapB % 3;
+            const int off = hq ? offB : offA;
+            f32x4 av[2], bw[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) av[mt] = in_s[(row0 + mt) * FIW + col0 + l31 + off];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) bw[nt] = wp_s[(i * 2 + hq) * 64 + nt * 32 + l31];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (j == 3 && p.C < 4) break;       // RGB: the 4th channel of every slot is zero (uniform branch)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt][j], bw[nt][j], acc[mt][nt], 0, 0, 0);
+            }
+        }
+        // epilogue: half an M-tile (16 pixels x all 64 channels = registers 8h .. 8h+7 of both N-tiles) at a time through the wave's
+        // 4 KB slab -> 16-byte stores of 4 pixels x 256 bytes = 1 KB contiguous per wave instruction, as conv3x3_first_kernel's; a
+        // wave's LDS operations execute in order, so a round's writes need no wait for the previous round's reads
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int yy = oy0 + row0 + mt;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int r = 8 * h + q;            // pixel (r&3) + 8*(r>>2) + 4*hq = 16h + (q&3) + 8*(q>>2) + 4*hq
+                        float v = acc[mt][nt][r] + bv[nt];
+                        if (p.relu) v = fmaxf(v, 0.f);
+                        slab[((q & 3) + 8 * (q >> 2) + 4 * hq) * 64 + nt * 32 + l31] = v;
+                    }
+                __builtin_amdgcn_wave_barrier();
+                const int prow = lane >> 4, pc4 = (lane & 15) * 4;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int m = g * 4 + prow;             // pixel 0..15 of the half
+                    const int xx = ox0 + col0 + 16 * h + m;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(slab + m * 64 + pc4);
+                    if (yy < p.H && xx < p.W)
+                        __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.y) + (((size_t)b * p.H + yy) * p.W + xx) * 64 + pc4));
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        to_lds((it + 1) & 1);                    // the next tile's pixels (requested before the MFMAs) -> the free half
     }
 }
 
@@ -327,6 +469,15 @@ __global__ void pack_first_kernel(const float* __restrict__ w, float* __restrict
     reinterpret_cast<f32x4*>(wf)[idx] = v;
 }
 
+int first_persistent() {     // WITW_FIRST_PERSIST=0: the one-tile-per-workgroup kernel everywhere (A/B)
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("WITW_FIRST_PERSIST");
+        v = e ? atoi(e) != 0 : 1;
+    }
+    return v;
+}
+
 }  // namespace
 
 extern "C" {
@@ -362,7 +513,10 @@ int witw_conv3x3_first_fwd(const float* x, const float* wf, const float* bias, v
         hipLaunchKernelGGL(conv3x3_first_bf16_kernel<8>, dim3((unsigned)grid), dim3(FT), 0, (hipStream_t)stream, a);
     else if (out_bf16 == 1)
         hipLaunchKernelGGL(conv3x3_first_bf16_kernel<4>, dim3((unsigned)grid), dim3(FT), 0, (hipStream_t)stream, a);
-    else
+    else if (out_bf16 == 0 && W >= 66 && (unsigned long long)C * H * W * 4 < 0x80000000ull && grid >= 4LL * witw_cu_count() && first_persistent()) {
+        const unsigned g2 = 2u * (unsigned)witw_cu_count();      // two persistent workgroups per CU
+        hipLaunchKernelGGL(conv3x3_first_persist_kernel, dim3(g2), dim3(FT), 0, (hipStream_t)stream, a);
+    } else
         hipLaunchKernelGGL(conv3x3_first_kernel, dim3((unsigned)grid), dim3(FT), 0, (hipStream_t)stream, a);
     WITW_CHECK_LAUNCH("conv3x3_first_fwd");
     return WITW_OK;
