@@ -449,7 +449,11 @@ def step_line(a, rank, world, device, cvig_fov, ops):
         out['config4_semantic_bf16'] = blk
         del s, su_b, ov_b, su_f, ov_f, surface, polar
         torch.cuda.empty_cache()
-        out['config1_baseline'] = baseline_bench(a, device, full=not a.no_cpu_baseline)
+        baseline_cpu = None
+        if a.no_cpu_baseline:
+            out['config1_baseline'] = baseline_bench(a, device, full=False)
+        else:       # its CPU leg runs last, with the headline's
+            out['config1_baseline'], baseline_cpu = baseline_bench(a, device, full=True, defer_cpu=True)
         torch.cuda.empty_cache()
         out['batch_sweep'] = batch_sweep(a, rank, world, device, ops)
         torch.cuda.empty_cache()
@@ -472,6 +476,8 @@ def step_line(a, rank, world, device, cvig_fov, ops):
         torch.cuda.empty_cache()
     if headline and rank == 0 and not a.no_cpu_baseline:      # last: nothing on the GPU waits behind the CPU leg
         out['cpu_baseline'] = cpu_baseline(a, *cpu_args)
+        if side and baseline_cpu is not None:
+            baseline_cpu()
     return out
 
 
@@ -582,7 +588,7 @@ def fp16x3_block(sb, steps):
                     'held to the reference goldens at the same 1e-4 as the f32 kernels (tests/test_f16x3_gpu.py)'}
 
 
-def baseline_bench(a, device, full=True, B=32):
+def baseline_bench(a, device, full=True, B=32, defer_cpu=False):
     """BASELINE config 1: cvig_baseline, 32 pairs, ground 500x500 (SurfaceResize('witw'), model/cvig_baseline.py:219-221) /
     overhead 512x512, eval step = 2 encoders (7 x [Conv2d(4,2) -> LeakyReLU -> BatchNorm2d], 3 GeM pools) -> exhaustive
     minibatch triplet loss -> Euclidean rank counts (:228-315, :454-466). BASELINE calls this config CPU plumbing, so the
@@ -665,10 +671,14 @@ def baseline_bench(a, device, full=True, B=32):
                                  'parity: tests/test_baseline_gpu.py against tests/golden/baseline_train.npz'}
     se.eval()
     oe.eval()
-    if full:
+
+    def cpu_leg():
+        """the CPU port on the same 32 pairs + the in-bench parity check; defer_cpu: run by the caller at the very end of the line
+        (128 OpenMP threads started in this process in front of the e2e blocks cost their loaders a fifth of their rate)"""
         from oracle import cvig_baseline_oracle as OB
         prm = [[dict((k, torch.from_numpy(np.asarray(v))) for k, v in q.items()) for q in p] for p in (prm_s, prm_o)]
         xs_c, xo_c = xs.cpu(), xo.cpu()
+        es_h, eo_h, ranks_h = es.cpu(), eo.cpu(), ranks.cpu()
 
         def cpu_step():
             with torch.no_grad():
@@ -676,10 +686,15 @@ def baseline_bench(a, device, full=True, B=32):
                 return es_r, eo_r, OB.exhaustive_minibatch_triplet_loss(es_r, eo_r), OB.ranks(eo_r, es_r)
         es_r, eo_r, loss_r, ranks_r = cpu_step()
         out['cpu_baseline'] = cpu_thread_sweep(cpu_step, B, 'the same 32 pairs, full eval step')
-        out['parity'] = {'max_abs_embedding_diff_vs_oracle': max(float((es.cpu() - es_r).abs().max()), float((eo.cpu() - eo_r).abs().max())),
-                         'loss_abs_diff_vs_oracle': abs(float(loss.item()) - float(loss_r)),
-                         'ranks_equal_oracle': bool(np.array_equal(ranks.cpu().numpy().astype(np.int64), np.asarray(ranks_r).astype(np.int64))),
+        out['parity'] = {'max_abs_embedding_diff_vs_oracle': max(float((es_h - es_r).abs().max()), float((eo_h - eo_r).abs().max())),
+                         'loss_abs_diff_vs_oracle': abs(loss_h - float(loss_r)),
+                         'ranks_equal_oracle': bool(np.array_equal(ranks_h.numpy().astype(np.int64), np.asarray(ranks_r).astype(np.int64))),
                          'tolerance': 1e-4}
+    loss_h = float(loss.item())
+    if full and defer_cpu:
+        return out, cpu_leg
+    if full:
+        cpu_leg()
     else:
         out['parity'] = 'embeddings 1e-4 / ranks bit-exact vs the reference goldens (tests/test_baseline_gpu.py)'
     return out

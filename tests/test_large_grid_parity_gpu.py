@@ -1,7 +1,9 @@
 """Large-grid kernel variants against the ORACLE (not against another HIP kernel).
 
-The conv launchers pick a different instantiation from 512 workgroups on (8-wave tiles; for the bf16 inference forward the
-16x16x32-MFMA kernel conv3x3_bf16_s16_kernel). Batches of 1-12 images never get there, so these cases use the batch sizes the
+The conv launchers pick a different instantiation from 512 workgroups on, and (round 4, csrc/api.hip witw_fills_rounds) whenever the
+last round of one workgroup per CU is at least 90 % full, e.g. exactly 256 workgroups: the 16 x 64 maps at the reference's default
+batch of 32 (model/cvig_semantic.py:416) (8-wave tiles; for the bf16 inference forward the 16x16x32-MFMA kernel
+conv3x3_bf16_s16_kernel). Batches of 1-12 images never get there, so these cases use the batch sizes the
 benchmarks run (BASELINE configs[1] / configs[3]: 128 images, layers of model/cvig_fov.py:256-272 and
 model/cvig_semantic.py:275-325), compare a spread of images of the batch with the CPU oracle (images are independent, the
 kernel still sees the whole batch) and ASSERT WHICH KERNEL RAN through witw_last_kernel_variant(), so a change of the launcher's
@@ -61,6 +63,13 @@ BF16_CASES = [
     (16, 64, 256, 64, 128, 1, True, False, True, 'conv3x3_bf16_s16_kernel<false,false>'),
     (16, 64, 256, 128, 128, 1, False, True, True, 'conv3x3_bf16_s16_kernel<true,false>'),
     (44, 24, 100, 96, 144, 1, True, False, True, 'conv3x3_bf16_s16_kernel<false,false>'),      # ragged width / channels, odd chunk pairs
+    # round 4: exactly ONE round of workgroups (4 channel tiles x 32 images x 2 row tiles = 256 = one per CU): layers 17-21 at the
+    # reference's default batch of 32, and layer 23 (stride (2,1)) at the bench batch
+    (32, 16, 64, 512, 512, 1, True, False, True, 'conv3x3_bf16_s16_kernel<false,false>'),
+    (32, 16, 64, 256, 512, 1, False, False, True, 'conv3x3_bf16_s16_kernel<false,false>'),
+    (128, 16, 64, 512, 256, 2, True, False, True, 'conv3x3_nhwc_bf16_kernel<128,2,false,8>'),
+    (30, 16, 64, 512, 512, 1, True, False, True, 'conv3x3_bf16_s16_kernel<false,false>'),        # 240 workgroups: 94 % of a round
+    (27, 16, 64, 512, 512, 1, True, False, True, 'conv3x3_nhwc_bf16_kernel<128,1,false,4>'),    # 216: 84 % -> the 4-wave tiles
     # the 8-wave 32x32x16 kernel: with the switch off, and where the 16x16x32 kernel does not apply
     (32, 32, 128, 128, 256, 1, True, False, False, 'conv3x3_nhwc_bf16_kernel<128,1,false,8>'),
     (32, 32, 128, 128, 256, 1, False, True, False, 'conv3x3_nhwc_bf16_kernel<128,1,true,8>'),
@@ -145,6 +154,10 @@ F32_CASES = [
     (16, 64, 256, 64, 128, 1, False, True, 'conv3x3_nhwc_f32_kernel<128,1,true,8,0,9>'),
     (16, 64, 256, 64, 64, 1, True, True, 'conv3x3_nhwc_f32_kernel<64,1,true,8,0,9>'),
     (128, 32, 64, 128, 256, 2, True, False, 'conv3x3_nhwc_f32_kernel<128,2,false,8,0,9>'),
+    # round 4: one full round of 8-wave workgroups (the 16 x 64 maps at a batch of 32), and a grid just under it
+    (32, 16, 64, 256, 512, 1, True, False, 'conv3x3_nhwc_f32_kernel<128,1,false,8,0,9>'),
+    (128, 16, 64, 256, 256, 2, False, False, 'conv3x3_nhwc_f32_kernel<128,2,false,8,0,9>'),
+    (27, 16, 64, 256, 512, 1, True, False, 'conv3x3_nhwc_f32_kernel<128,1,false,4,0,9>'),
 ]
 
 

@@ -29,6 +29,9 @@
 #ifndef WITW_WRES_PF
 #define WITW_WRES_PF 3             // (chunk, tap) steps the layer-2 operand reads run ahead of their MFMAs
 #endif
+#ifndef WITW_WRES_DIAG
+#define WITW_WRES_DIAG 0        // diagnostic builds (wrong results): 1 = no waits on the operand reads, 2 = no operand reads, 4 = no V-phase work
+#endif
 #ifndef WITW_WRES_PRIO
 #define WITW_WRES_PRIO 1        // s_setprio 1 for the M phase: the matrix-bound wave of a SIMD wins the issue arbitration
 #endif
@@ -232,7 +235,7 @@ __global__ __launch_bounds__(WRT, 1) void conv3x3_bf16_wres_kernel(WresArgs p) {
 
         // ================= V phase (the other team is in its M phase) =================
         if (WITW_WRES_PRIO) __builtin_amdgcn_s_setprio(WITW_WRES_PRIO == 2 ? 1 : 0);
-        if (it > 0) {
+        if (it > 0 && !(WITW_WRES_DIAG & 4)) {
             // the team's input tile was last read in the previous M phase, a barrier ago; the loads of this tile were issued there
             __builtin_amdgcn_s_waitcnt(0x0F70);
             to_lds();
@@ -267,6 +270,7 @@ __global__ __launch_bounds__(WRT, 1) void conv3x3_bf16_wres_kernel(WresArgs p) {
             int issued = 0;
             auto issue = [&](int step, int which) {
                 const int bq = step % NB;
+                if (WITW_WRES_DIAG & 2) { ++issued; return; }
                 if (which == 0) fa[bq] = lds_read128(a_addr(step));
                 else fb[bq][which - 1] = lds_read128(w_addr(step, which - 1));
                 ++issued;
@@ -279,13 +283,13 @@ __global__ __launch_bounds__(WRT, 1) void conv3x3_bf16_wres_kernel(WresArgs p) {
             for (int step = 0; step < 36; ++step) {
                 const int bq = step % NB;
                 const bool more = step + PF < 36;
-                lds_wait(issued - (3 * step + 2), fa[bq], fb[bq][0]);
+                if (!(WITW_WRES_DIAG & 3)) lds_wait(issued - (3 * step + 2), fa[bq], fb[bq][0]);
                 acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb[bq][0]), __builtin_bit_cast(bf16x8, fa[bq]), acc[0], 0, 0, 0);
                 if (more) {
                     issue(step + PF, 0);
                     issue(step + PF, 1);
                 }
-                lds_wait(issued - (3 * step + 3), fb[bq][1]);
+                if (!(WITW_WRES_DIAG & 3)) lds_wait(issued - (3 * step + 3), fb[bq][1]);
                 acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb[bq][1]), __builtin_bit_cast(bf16x8, fa[bq]), acc[1], 0, 0, 0);
                 if (more) issue(step + PF, 2);
                 if (step % 5 == 2 && step / 5 < WNIN) {
