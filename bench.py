@@ -551,7 +551,7 @@ def hbm_block(sb):
             'the former overhead side, two launches: resize_bilinear_norm_kernel 512 -> 256, then polar_kernel': (
                 timed(lambda: ops.polar_transform(ops.resize_bilinear(sb.ov_raw, (256, 256), sb.mean, sb.std, sb.ndiv))),
                 sb.ov_raw.numel() * 4 + polar.numel() * 4, 'same algorithmic bytes (raw in, polar out) as the fused launch'),
-            'conv3x3_first_kernel (3 -> 64 channels, NCHW in, NHWC out)': (timed(lambda: ops.conv3x3_first_fwd(polar, packed, circular=True, relu=True)),
+            'conv3x3_first_persist_kernel (3 -> 64 channels, NCHW in, NHWC out; round 4: two persistent workgroups per CU, the next tile prefetched)': (timed(lambda: ops.conv3x3_first_fwd(polar, packed, circular=True, relu=True)),
                                                                            polar.numel() * 4 + B * 128 * 512 * 64 * 4, '2.1 GB written per launch'),
         }
     return {'note': 'algorithmic bytes / HIP-event duration, 20 launches each, peak %.0f GB/s' % PEAK_HBM_GBS,

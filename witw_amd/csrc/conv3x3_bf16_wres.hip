@@ -30,7 +30,7 @@
 #define WITW_WRES_PF 3             // (chunk, tap) steps the layer-2 operand reads run ahead of their MFMAs
 #endif
 #ifndef WITW_WRES_DIAG
-#define WITW_WRES_DIAG 0        // diagnostic builds (wrong results): 1 = no waits on the operand reads, 2 = no operand reads, 4 = no V-phase work
+#define WITW_WRES_DIAG 0        // diagnostic builds (wrong results): 1 = no waits on the operand reads, 2 = no operand reads, 4 = no V-phase work, 8 = no input -> LDS writes, 16 = no slab traffic in the epilogue
 #endif
 #ifndef WITW_WRES_PRIO
 #define WITW_WRES_PRIO 1        // s_setprio 1 for the M phase: the matrix-bound wave of a SIMD wins the issue arbitration
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(WRT, 1) void conv3x3_bf16_wres_kernel(WresArgs p) {
         u32x4 v[4];
 #pragma unroll
         for (int rnd = 0; rnd < 2; ++rnd) {
-            if ((l31 >> 4) == rnd) {
+            if ((l31 >> 4) == rnd && !(WITW_WRES_DIAG & 16)) {
                 unsigned char* dst = slab + (l31 & 15) * SLAB_PITCH + 8 * hq;
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
@@ -197,7 +197,8 @@ __global__ __launch_bounds__(WRT, 1) void conv3x3_bf16_wres_kernel(WresArgs p) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int c = lane + 64 * i;            // 16 pixels x 8 channel octets
-                v[2 * rnd + i] = *reinterpret_cast<const u32x4*>(slab + (c >> 3) * SLAB_PITCH + (c & 7) * 16);
+                if (WITW_WRES_DIAG & 16) v[2 * rnd + i] = (u32x4){__builtin_bit_cast(unsigned, acc[0][4 * rnd + i]), __builtin_bit_cast(unsigned, acc[1][4 * rnd + i]), 0u, 0u};
+                else v[2 * rnd + i] = *reinterpret_cast<const u32x4*>(slab + (c >> 3) * SLAB_PITCH + (c & 7) * 16);
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(WRT, 1) void conv3x3_bf16_wres_kernel(WresArgs p) {
         if (it > 0 && !(WITW_WRES_DIAG & 4)) {
             // the team's input tile was last read in the previous M phase, a barrier ago; the loads of this tile were issued there
             __builtin_amdgcn_s_waitcnt(0x0F70);
-            to_lds();
+            if (!(WITW_WRES_DIAG & 8)) to_lds();
             stamp(1);
             epilogue();
         }
