@@ -461,18 +461,22 @@ def step_line(a, rank, world, device, cvig_fov, ops):
         torch.cuda.empty_cache()
         out['config5_retrieval_direct'] = retrieval_block(device, cvig_fov, ops, 125000, 1024, 10, 'direct')
         torch.cuda.empty_cache()
-        from witw_amd import e2e
         keys = ('metric', 'value', 'unit', 'dtype', 'jpeg_decode', 'staging', 'steady_state_pairs_per_s', 'pipeline_fill_s', 'stage_pairs_per_s',
                 'limiting_stage', 'overlap_efficiency_steady_state', 'gpu_stage_serialised_pairs_per_s', 'host_decode_pairs_per_s_per_core',
                 'host_decode_scaling')
-        e = e2e.bench(a, device, n_pairs=2048)                       # the headline's fp32 encoders: the GPU is the limiting stage
-        out['e2e_data_path'] = {k: e[k] for k in keys if k in e}
-        out['e2e_data_path']['workload'] = e['config']['workload']
-        torch.cuda.empty_cache()
+        # The data-path blocks run as CHILD processes (`bench.py --mode e2e ...`, started here, never an exec of this process): inside
+        # this one -- 16 loader workers forked from a process that has built every other block -- the same pass measured a fifth
+        # slower (10.8 k against 13.6 k pairs/s) with every stage on its own unchanged; a driver's train() / test() is a fresh process.
+        # the headline's fp32 encoders: the GPU is the limiting stage
+        e = e2e_child(a, ['--e2e-pairs', '2048'])
+        if e is not None:
+            out['e2e_data_path'] = {k: e[k] for k in keys if k in e}
+            out['e2e_data_path']['workload'] = e['config']['workload']
         # the bf16 encoders (configs[3] arithmetic) need 8x the images per second: JPEG back end on the GPU, page-locked ring
-        e = e2e.bench(a, device, n_pairs=8192, workers=16, precision='bf16')
-        out['e2e_data_path_bf16'] = {k: e[k] for k in keys if k in e}
-        out['e2e_data_path_bf16']['workload'] = e['config']['workload']
+        e = e2e_child(a, ['--e2e-pairs', '8192', '--workers', '16', '--precision', 'bf16'])
+        if e is not None:
+            out['e2e_data_path_bf16'] = {k: e[k] for k in keys if k in e}
+            out['e2e_data_path_bf16']['workload'] = e['config']['workload']
         torch.cuda.empty_cache()
     if headline and rank == 0 and not a.no_cpu_baseline:      # last: nothing on the GPU waits behind the CPU leg
         out['cpu_baseline'] = cpu_baseline(a, *cpu_args)
@@ -938,6 +942,22 @@ def collectives_info(a, rank, world, device, phases=None, step_ms=None):
             'per_step': 'all-gather of the overhead embeddings (2 MiB per rank at 128 pairs), all-gather of the diagonal, scalar loss '
                         'all-reduce' + ('; reduce-scatter of overhead-embedding gradients, all-reduce(SUM) of 2 x 7.24 M weight gradients'
                                         if a.mode == 'train' else '')}
+
+
+def e2e_child(a, extra):
+    """`bench.py --mode e2e <extra>` as a child process on the same GPU (this process is idle meanwhile) -> its JSON line, or None"""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), '--mode', 'e2e', '--batch', str(a.batch), '--fov', str(a.fov)] + list(extra)
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    try:
+        p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    except subprocess.TimeoutExpired:
+        return None
+    for ln in p.stdout.splitlines():
+        if ln.startswith('{') and '"metric"' in ln:
+            return json.loads(ln)
+    sys.stderr.write('e2e child failed (%d): %s\n' % (p.returncode, p.stderr[-800:]))
+    return None
 
 
 def e2e_bench(a, device):

@@ -54,7 +54,7 @@ def build(force=False, verbose=True):
 #   first2: conv_first2_bf16_kernel<CW, REC>     -> layers 0 and 2 as two launches (FOV_DSM.fuse_first2);     force: WITW_F2=1
 S16_VALIDATED = {'ILb0ELb0EE': (256, 10, 44), 'ILb1ELb0EE': (256, 1, 8), 'ILb0ELb1EE': (256, 10, 44), 'ILb1ELb1EE': (256, 2, 12)}
 S16_MARKER = os.path.join(HERE, 'build', 's16_unvalidated')
-WRES_VALIDATED = {'ILb0EE': (238, 0, 0)}
+WRES_VALIDATED = {'ILb0EE': (209, 0, 0)}
 WRES_MARKER = os.path.join(HERE, 'build', 'wres_unvalidated')
 F2_VALIDATED = {'ILi4ELb0EE': (254, 0, 0), 'ILi8ELb0EE': (256, 0, 0)}
 F2_MARKER = os.path.join(HERE, 'build', 'first2_unvalidated')

@@ -29,6 +29,14 @@
 #ifndef WITW_WRES_PF
 #define WITW_WRES_PF 3             // (chunk, tap) steps the layer-2 operand reads run ahead of their MFMAs
 #endif
+#ifndef WITW_WRES_DMA
+#define WITW_WRES_DMA 1         // 1: the input tile by LDS-DMA into a pixel-major, XOR-swizzled image; 0: through registers + ds_write_b128
+#endif
+#ifndef WITW_WRES_DIRECT
+#define WITW_WRES_DIRECT 0      // 1: the epilogue stores from registers (v_permlane32_swap forms 16-byte channel octets); 0: through the LDS slab.
+                                // Measured (same box): in-kernel cycles per iteration 6.7 k -> 5.6 k, wall time 0.266-0.279 -> 0.270-0.275 ms with
+                                // plain stores (0.449 with non-temporal ones: the four 32-byte pieces of a line leave L2 one by one): no gain, off
+#endif
 #ifndef WITW_WRES_DIAG
 #define WITW_WRES_DIAG 0        // diagnostic builds (wrong results): 1 = no waits on the operand reads, 2 = no operand reads, 4 = no V-phase work, 8 = no input -> LDS writes, 16 = no slab traffic in the epilogue
 #endif
@@ -50,6 +58,16 @@ constexpr int WPITCH = 24;                        // LDS row pitch in 16-byte sl
 constexpr int WPOS = WAH * WPITCH + 1;            // 241 slots per channel group: the 8 groups of one pixel (8 neighbouring lanes of the staging
                                                   // write) start 4 banks apart -- ds_write_b128 serves 8 contiguous lanes per cycle, bank (a/4) % 32
 constexpr int WNIN = (WAH * WAW * 8 + WTEAM - 1) / WTEAM;      // 16-byte input chunks per thread and tile (6)
+// WITW_WRES_DMA: the team's input image is PIXEL-major -- pixel p = row * 18 + column holds its eight 16-byte channel groups in
+// slots 8p .. 8p+7, group g in slot 8p + (g ^ f), f = ((column >> 1) & 1) | ((row & 3) << 1) -- so that one LDS-DMA instruction copies
+// 1 KB of contiguous global memory (8 pixels x 128 bytes, whole cache lines; each lane fetches the 16 bytes that belong at its LDS
+// slot) and the MFMA operand reads (32 pixels of a 4 x 8 M-tile, one group) stay free of bank conflicts: within every 16-lane
+// group of ds_read_b128 the pairs (column parity, f) are distinct for all nine taps (checked exhaustively). No register transit,
+// no ds_write: the switch-off builds of the register form showed its 6 ds_write_b128 per wave and tile costing 12 % of the kernel
+// (they back the LDS queue up under the other team's operand reads).
+constexpr int DPIECES = (WAH * WAW * 128 + 1023) / 1024;      // 23 DMA pieces of 1 KB per tile
+constexpr int DIMG = DPIECES * 1024;                           // bytes of a team's image
+constexpr int DPW = (DPIECES + 3) / 4;                         // pieces per wave (6)
 constexpr int SLAB_PITCH = 144;                   // bytes per pixel of the output slab (128 + 16: 8-byte writes of 16 lanes on distinct banks)
 constexpr int SLAB_BYTES = 16 * SLAB_PITCH;       // two rows of the M-tile: 16 pixels
 
@@ -71,11 +89,20 @@ __device__ __forceinline__ void wres_wave_sync() {      // one wave's LDS traffi
     __builtin_amdgcn_wave_barrier();
 }
 
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+// global -> LDS, 16 B per lane, 1 KB of contiguous LDS per wave instruction at lds_addr (M0); out-of-range lanes write zeros
+__device__ __forceinline__ void wres_dma16(i32x4 rs, unsigned lds_addr, unsigned voff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                 :
+                 : "s"(lds_addr), "v"(voff), "s"(rs)
+                 : "memory");
+}
+
 __device__ unsigned long long wres_stamps[2][8];     // WITW_WRES_STAMPS=1 diagnostic: phase ticks of waves 0 and 4 (one per team), third iteration of workgroup 0
 
 template <bool REC>
 __global__ __launch_bounds__(WRT, 1) void conv3x3_bf16_wres_kernel(WresArgs p) {
-    __shared__ u32x4 a_s[2 * 8 * WPOS];             // 61,696 B: per team the input tile
+    __shared__ __attribute__((aligned(1024))) u32x4 a_s[WITW_WRES_DMA ? 2 * DIMG / 16 : 2 * 8 * WPOS];      // per team the input tile (47,104 B; register form 61,696)
     __shared__ u32x4 w_s[4 * 9 * 2 * 64];           // 73,728 B: this channel block's filter
     __shared__ u32x4 slab_s[8 * SLAB_BYTES / 16];   // 18,432 B: one [16 pixels][64 channels] bf16 slab per wave
     __shared__ f32x4 bias_s[16];                    // this channel block's bias
@@ -84,7 +111,7 @@ __global__ __launch_bounds__(WRT, 1) void conv3x3_bf16_wres_kernel(WresArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int team = wave >> 2, wt = wave & 3, tt = tid & (WTEAM - 1);
     const int l31 = lane & 31, hq = lane >> 5;
-    u32x4* const a_t = a_s + team * (8 * WPOS);
+    u32x4* const a_t = a_s + team * (WITW_WRES_DMA ? DIMG / 16 : 8 * WPOS);
 
     // workgroup -> (XCD, channel block, walker): block i runs on XCD i % 8; the n_cb workgroups of a walker share its tiles
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -124,6 +151,32 @@ __global__ __launch_bounds__(WRT, 1) void conv3x3_bf16_wres_kernel(WresArgs p) {
     const unsigned img_bytes = (unsigned)p.H * (unsigned)p.W * 128u;      // < 2^31 (checked by the caller)
     const unsigned row_bytes = (unsigned)p.W * 128u;
     u32x4 rv[WNIN];
+    // WITW_WRES_DMA: wave wt issues pieces wt * DPW .. of the team's image; lane -> slot s = 64 * piece + lane = pixel s >> 3, physical
+    // group slot s & 7, which holds channel group (s & 7) ^ f(pixel). dmeta = byte offset from the tile's first halo pixel | rim
+    // flags in the low 4 bits (the offset is a multiple of 16); bit 31 = no pixel (the image's tail) or no piece.
+    unsigned dmeta[DPW];
+#pragma unroll
+    for (int j = 0; j < DPW; ++j) {
+        const int piece = wt * DPW + j;
+        const int sl = piece * 64 + lane;
+        const int px = sl >> 3, k = sl & 7;
+        const bool live = piece < DPIECES && px < WAH * WAW;
+        const int r = live ? px / WAW : 0, c = live ? px - r * WAW : 0;
+        const int g = k ^ (((c >> 1) & 1) | ((r & 3) << 1));
+        dmeta[j] = live ? ((((unsigned)r * (unsigned)p.W + (unsigned)c) * 128u + (unsigned)g * 16u) |
+                           (r == 0 ? F_TOP : 0u) | (r == WAH - 1 ? F_BOT : 0u) | (c == 0 ? F_LEFT : 0u) | (c == WAW - 1 ? F_RIGHT : 0u))
+                        : 0x80000000u;
+    }
+    i32x4 d_rs = {0, 0, 0, 0x00020000};
+    auto dma_setup = [&](int t) {                   // the scalar part of fetch_setup with the descriptor as four SGPRs for the asm
+        const bool any = t < p.n_sp;
+        const int tl = any ? t : 0;
+        const int b = tl / tiles_img;
+        const unsigned long long a = (unsigned long long)(reinterpret_cast<const unsigned char*>(p.x) + (size_t)b * img_bytes);
+        d_rs[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+        d_rs[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)((a >> 32) & 0xffffu));
+        d_rs[2] = __builtin_amdgcn_readfirstlane(any ? (int)img_bytes : 0);
+    };
     // Buffer loads, a tile past the end = empty descriptor: straight-line code, so the wait in front of the LDS write counts exactly
     // these loads
     __amdgpu_buffer_rsrc_t f_rs;
@@ -156,6 +209,23 @@ __global__ __launch_bounds__(WRT, 1) void conv3x3_bf16_wres_kernel(WresArgs p) {
             if (!(in_meta[k] & (F_DEAD << 16))) a_t[in_meta[k] & 0xffffu] = rv[k];
     };
 
+    auto dma_tile = [&](int t) {                    // the whole input tile of tile t -> the team's image: DPW instructions per wave
+        fetch_setup(t);
+        dma_setup(t);
+        const unsigned lds_img = lds_address(a_t);
+#pragma unroll
+        for (int j = 0; j < DPW; ++j) {
+            if (wt * DPW + j < DPIECES) {           // wave-uniform
+                const unsigned m = dmeta[j];
+                unsigned off = f_base + (m & 0x7ffffff0u);
+                off += (m & F_LEFT) ? f_add_l : 0u;
+                off += (m & F_RIGHT) ? f_add_r : 0u;
+                off = ((m & (f_kill & 15u)) || (m >> 31)) ? OOR : off;
+                wres_dma16(d_rs, lds_img + (unsigned)(wt * DPW + j) * 1024u, off);
+            }
+        }
+    };
+
     // roles inside a team (conv_first2_bf16.hip): wave wt = (row block wt >> 1, column block wt & 1); M-tile 4 rows x 8 columns,
     // lane l31 -> pixel (row l31 >> 3, column l31 & 7)
     const int mrow = wt >> 1, mcol = wt & 1;
@@ -174,6 +244,37 @@ __global__ __launch_bounds__(WRT, 1) void conv3x3_bf16_wres_kernel(WresArgs p) {
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
             for (int j = 0; j < 4; ++j) bq[nt][j] = reinterpret_cast<const f32x4*>(bias_s)[nt * 8 + 2 * j + hq];
+        if (WITW_WRES_DIRECT) {
+            // straight from the registers: lane (pixel l31, half hq) holds channels 8j + 4hq .. + 3 of every octet j as one 8-byte pair;
+            // v_permlane32_swap exchanges the upper half-wave of octet j with the lower half-wave of octet j + 1, after which a lower
+            // lane holds all 8 channels of octet j of its pixel and the upper lane of the same pixel all 8 of octet j + 1: one 16-byte
+            // store each, 32 contiguous bytes per pixel and instruction, four instructions per wave -- and no LDS traffic under the
+            // other team's operand reads (the slab form's writes and read-backs cost 7 % of the kernel in the switch-off builds)
+            const int oy = poy0 + 4 * mrow + (l31 >> 3), ox = pox0 + 8 * mcol + (l31 & 7);
+            unsigned short* dst = p.y + (((size_t)pb * p.H + oy) * p.W + ox) * p.Cout + cb * 64 + 8 * hq;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int jp = 0; jp < 2; ++jp) {
+                    unsigned x[2][2];                   // [octet of the pair][dword]
+#pragma unroll
+                    for (int o = 0; o < 2; ++o) {
+                        const int j = 2 * jp + o;
+                        x[o][0] = witw_relu_bf16x2(witw_pack_bf16x2(acc[nt][4 * j] + bq[nt][j][0], acc[nt][4 * j + 1] + bq[nt][j][1]), relu_floor);
+                        x[o][1] = witw_relu_bf16x2(witw_pack_bf16x2(acc[nt][4 * j + 2] + bq[nt][j][2], acc[nt][4 * j + 3] + bq[nt][j][3]), relu_floor);
+                    }
+                    u32x4 v;
+#pragma unroll
+                    for (int d = 0; d < 2; ++d) {
+                        const auto sw = __builtin_amdgcn_permlane32_swap(x[0][d], x[1][d], false, false);
+                        v[d] = sw[0];
+                        v[2 + d] = sw[1];
+                    }
+                    // plain stores: the four 32-byte pieces of a pixel's 128-byte line must meet in L2 before the line leaves it
+                    if (pvalid) *reinterpret_cast<u32x4*>(dst + nt * 32 + 16 * jp) = v;
+                }
+            return;
+        }
         // two rounds of two M-tile rows (16 pixels) through the slab. One wave's LDS operations execute in order, so neither the
         // read-back behind the writes nor the second round's writes behind the first round's reads need a wait of their own: the
         // only waits are the ones in front of the stores (the values' first use). (A first form synchronised four one-row rounds:
@@ -214,13 +315,18 @@ __global__ __launch_bounds__(WRT, 1) void conv3x3_bf16_wres_kernel(WresArgs p) {
 
     // the first tile's input goes to LDS here; inside the loop the registers prefetched during an M phase are consumed at ONE place
     // (top of the next V phase), always behind the same sequence of memory operations
-    fetch_setup(tile_of(0));
+    if (WITW_WRES_DMA) {
+        dma_tile(tile_of(0));
+    } else {
+        fetch_setup(tile_of(0));
 #pragma unroll
-    for (int k = 0; k < WNIN; ++k) fetch_one(k);
-    to_lds();
+        for (int k = 0; k < WNIN; ++k) fetch_one(k);
+        to_lds();
+    }
     // everything loaded so far (filter, biases, the first input tile) has landed: said with the builtin, so that the compiler's
     // counter bookkeeping enters the loop clean
     __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0), expcnt / lgkmcnt untouched
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the DMA pieces are outside the compiler's bookkeeping)
     __syncthreads();                                // filter and both teams' first input tiles in LDS
     if (team) __syncthreads();                      // team 1 runs half a tile behind: its V phases meet team 0's M phases
 
@@ -237,11 +343,22 @@ __global__ __launch_bounds__(WRT, 1) void conv3x3_bf16_wres_kernel(WresArgs p) {
         // ================= V phase (the other team is in its M phase) =================
         if (WITW_WRES_PRIO) __builtin_amdgcn_s_setprio(WITW_WRES_PRIO == 2 ? 1 : 0);
         if (it > 0 && !(WITW_WRES_DIAG & 4)) {
-            // the team's input tile was last read in the previous M phase, a barrier ago; the loads of this tile were issued there
-            __builtin_amdgcn_s_waitcnt(0x0F70);
-            if (!(WITW_WRES_DIAG & 8)) to_lds();
-            stamp(1);
-            epilogue();
+            if (WITW_WRES_DMA) {
+                // the team's image was last read in the previous M phase, a barrier ago: this tile's pieces go out now and land under
+                // the epilogue; the wait counts the epilogue's four stores issued behind them (vector-memory operations retire in
+                // issue order), so it does not wait for those stores
+                if (!(WITW_WRES_DIAG & 8)) dma_tile(t);
+                stamp(1);
+                epilogue();
+                if (pvalid) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                // the team's input tile was last read in the previous M phase, a barrier ago; the loads of this tile were issued there
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+                if (!(WITW_WRES_DIAG & 8)) to_lds();
+                stamp(1);
+                epilogue();
+            }
         }
         stamp(2);
         __syncthreads();
@@ -252,7 +369,7 @@ __global__ __launch_bounds__(WRT, 1) void conv3x3_bf16_wres_kernel(WresArgs p) {
         // the next tile's loads go out one at a time between the MFMA steps (all six at once queue up behind each other in the
         // texture path and hold the wave at the issue of the last ones)
         asm volatile("" ::: "memory");
-        fetch_setup(tile_of(it + 1));
+        if (!WITW_WRES_DMA) fetch_setup(tile_of(it + 1));
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -261,10 +378,16 @@ __global__ __launch_bounds__(WRT, 1) void conv3x3_bf16_wres_kernel(WresArgs p) {
             constexpr int PF = WITW_WRES_PF, NB = PF + 1;
             u32x4 fa[NB], fb[NB][2];
             const unsigned abase = lds_address(a_t) + (unsigned)(hq * WPOS + a_lane) * 16u;
+            const unsigned dbase = lds_address(a_t);
             const unsigned wbase = lds_address(w_s) + (unsigned)(hq * 64 + l31) * 16u;
             auto a_addr = [&](int step) {
                 const int kc = step / 9, tap = step - kc * 9;
                 const int kh = tap / 3, kw = tap - kh * 3;
+                if (WITW_WRES_DMA) {                 // pixel-major swizzled image: slot 8 * pixel + (group ^ f(row, column))
+                    const int R = 4 * mrow + (l31 >> 3) + kh, C = 8 * mcol + (l31 & 7) + kw;
+                    const int f = ((C >> 1) & 1) | ((R & 3) << 1);
+                    return dbase + (unsigned)((R * WAW + C) * 8 + ((2 * kc + hq) ^ f)) * 16u;
+                }
                 return abase + (unsigned)(2 * kc * WPOS + kh * WPITCH + kw) * 16u;
             };
             auto w_addr = [&](int step, int nt) { return wbase + (unsigned)(step * 128 + nt * 32) * 16u; };
@@ -295,7 +418,7 @@ __global__ __launch_bounds__(WRT, 1) void conv3x3_bf16_wres_kernel(WresArgs p) {
                 if (more) issue(step + PF, 2);
                 if (step % 5 == 2 && step / 5 < WNIN) {
                     __builtin_amdgcn_sched_barrier(0);
-                    fetch_one(step / 5);
+                    if (!WITW_WRES_DMA) fetch_one(step / 5);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
