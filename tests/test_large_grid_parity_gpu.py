@@ -102,7 +102,10 @@ def test_bf16_large_grid_kernels_vs_oracle(case):
 
 # (B, H, W, Cout, circular, relu): 64 input channels, >= 4096 (tile, channel block) units -> the weight-resident kernel
 WRES_CASES = [(64, 64, 256, 128, True, True), (32, 64, 256, 128, False, True), (64, 64, 256, 64, True, False), (22, 64, 256, 192, True, True),
-              (128, 32, 128, 128, False, True)]
+              (128, 32, 128, 128, False, True),
+              # round 4 (two teams, LDS-DMA input): ONE 8 x 16 tile per image -- top and bottom rows padded, the left and right halo
+              # columns both wrapping onto the image itself -- and three tiles per row with an odd number of tile pairs per walker
+              (4096, 8, 16, 128, True, True), (4099, 8, 16, 128, False, True), (1400, 16, 48, 64, True, False)]
 
 
 @pytest.mark.parametrize('case', WRES_CASES)
