@@ -72,6 +72,29 @@ def test_garbage_and_truncated_streams_are_refused_not_crashed():
         jpeg.read_coef(bytes(b))
 
 
+def test_pack_keeps_coefficient_entries_on_the_128_byte_block_grid():
+    """the device back end addresses coefficients in 128-byte blocks from the start of the packed buffer: a raw image (a file left
+    to Pillow) of any size in front of a JPEG entry must not move it off that grid"""
+    c = jpeg.read_coef(os.path.join(HERE, 's420_odd.jpg'))
+    for shape in ((5, 6, 3), (7, 9, 3), (1, 1, 3), (33, 17, 1)):
+        raw = np.arange(int(np.prod(shape)), dtype=np.uint32).astype(np.uint8).reshape(shape)
+        buf, desc, _k = jpeg.pack([c, raw, c, raw, c])
+        d = desc.numpy()
+        assert not (d[:, 0] % 128).any(), d[:, 0]
+        planes, images, blk, pbytes, obytes, qt_base = jpeg.decode_tables(d[d[:, 24] == 0])
+        b = buf.numpy()
+        nb = [int(c.info[8 + 4 * k] * c.info[9 + 4 * k]) for k in range(int(c.info[2]))]      # blocks wide x blocks high per component
+        starts = [sum(nb[:k]) for k in range(len(nb))]
+        assert planes.shape[0] == 3 * len(nb)
+        for k, row in enumerate(planes):      # image-major, component-minor: the block the device reads first is the block the host wrote
+            got = b[int(row[0]) * 128:int(row[0]) * 128 + 128].view(np.int16)
+            np.testing.assert_array_equal(got, c.coef[starts[k % len(nb)]])
+    bad = d.copy()
+    bad[2, 0] += 16
+    with pytest.raises(ValueError):
+        jpeg.decode_tables(bad[bad[:, 24] == 0])
+
+
 def test_pack_layout():
     c = jpeg.read_coef(os.path.join(HERE, 's420_odd.jpg'))
     raw = np.arange(5 * 6 * 3, dtype=np.uint8).reshape(5, 6, 3)

@@ -31,6 +31,23 @@ def test_device_decode_equals_pillow_on_fixtures():
         np.testing.assert_array_equal(o.cpu().numpy(), e, err_msg=n)
 
 
+def test_device_decode_with_raw_images_of_any_size_in_the_same_batch():
+    """files left to Pillow travel as raw images in the batch block; their sizes must not move the coefficient data of the JPEG
+    entries behind them off the 128-byte block grid the device back end addresses (round 4: a 5 x 6 x 3 image in front of a JPEG
+    entry made it decode from 96 bytes too early)"""
+    exp = np.load(os.path.join(HERE, 'expected.npz'))
+    names = ['s420_odd', 's444_q10', 's422_q50', 'gray_q85']
+    g = np.random.Generator(np.random.Philox(key=[8, 4]))
+    items, want = [], []
+    for k, n in enumerate(names * 2):
+        raw = g.integers(0, 256, size=(3 + 2 * k, 5 + k, 3), dtype=np.uint8)
+        items += [raw, jpeg.read_coef(os.path.join(HERE, n + '.jpg'))]
+        want += [raw, exp[n] if exp[n].ndim == 3 else exp[n][:, :, None]]
+    out = jpeg.decode(items, torch.device('cuda:0'))
+    for k, (o, e) in enumerate(zip(out, want)):
+        np.testing.assert_array_equal(o.cpu().numpy(), e, err_msg=str(k))
+
+
 def test_device_decode_fresh_files():
     from PIL import Image
     g = np.random.Generator(np.random.Philox(key=[8, 3]))

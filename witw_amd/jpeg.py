@@ -109,7 +109,7 @@ def _shared_bytes(n):
 
 def pack(images, shared=False, alloc=None):
     """A list of JpegCoef / JpegFile (and, for files left to Pillow, uint8 HWC arrays) -> (uint8 tensor, int64 [B, DESC_COLS],
-    KIND_JPEG): one contiguous block for the pinned copy, images 16-byte aligned, the quantisation tables behind the coefficient
+    KIND_JPEG): one contiguous block for the pinned copy, images 128-byte aligned, the quantisation tables behind the coefficient
     data. JpegFile entries are entropy-decoded HERE, straight into the block. shared: allocate the block in shared memory;
     alloc(nbytes) -> (offset, uint8 numpy view) or None: build the block in caller-provided memory (ring.PinnedRing), in which
     case the first result is (offset, nbytes) instead of a tensor."""
@@ -126,7 +126,11 @@ def pack(images, shared=False, alloc=None):
             desc[i, 2], desc[i, 3], desc[i, 24], desc[i, 25] = a.shape[0], a.shape[1], 1, a.shape[2]
         desc[i, 0] = off
         spans.append((off, nbytes))
-        off += (nbytes + 15) // 16 * 16
+        # every entry starts on a 128-byte boundary: the device back end addresses coefficient data in 128-byte BLOCKS from the start
+        # of the buffer (decode_tables: first block = offset // 128), so a raw image of a file left to Pillow in front of a JPEG
+        # entry must not push it off that grid (round 4: it did -- 16-byte alignment -- and such a batch decoded its later JPEG
+        # entries from up to 112 bytes too early)
+        off += (nbytes + 127) // 128 * 128
     for i, a in enumerate(images):
         if isinstance(a, JpegCoef):
             desc[i, 1] = off
@@ -170,6 +174,8 @@ def decode_tables(d):
     offset}, blocks in all, component bytes, output bytes, byte offset of the first quantisation table). Whole-array numpy: a
     per-image Python loop here cost 8 ms per 128 pairs, as much as the bf16 encoders take for them."""
     n = d.shape[0]
+    if (d[:, 0] % 128).any():
+        raise ValueError('jpeg: a coefficient entry does not start on a 128-byte boundary of the packed block')
     H, W, ncomp, hmax, vmax = (d[:, k] for k in range(2, 7))
     qt_base = int(d[:, 1].min())
     bw, bh = d[:, [10, 14, 18]], d[:, [11, 15, 19]]
