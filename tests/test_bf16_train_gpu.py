@@ -225,3 +225,47 @@ def test_semantic_bf16_training_step_vs_fp32_path():
         # layer 0 sits behind 12 bf16-rounded layers and three arg-max routings (near-ties route differently)
         assert rel < (0.3 if 'features.0.' in name else 8e-2), (name, rel)
     print('semantic bf16 vs fp32 step: loss %.6f vs %.6f, worst gradient deviation %.3e (%s)' % (l16, l32, worst[1], worst[0]))
+
+
+def test_bf16_training_forward_with_the_fused_first_two_layers_is_bitwise_the_unfused_one():
+    """round 4: the bf16 TRAINING forward of cvig_fov (frozen trunk: nothing below layer 17 is kept for the backward) runs layers
+    0 and 2 on conv_first2_bf16_kernel, as the inference forward does -- the same bits and the same gradients as the two launches;
+    cvig_semantic (layer 0 trainable, model/cvig_semantic.py:301-309) keeps the unfused forward"""
+    from witw_amd import cvig_fov, cvig_semantic, ops
+    dev = torch.device('cuda:0')
+    w = synth.fov_dsm_weights(31)
+    x = torch.from_numpy(synth.normalized_images(32, 0, (4, 3, 128, 512))).to(dev)
+    drops = {i: torch.full((4, 512), 1.25, device=dev) for i in (17, 19, 21)}
+    outs, grads = [], []
+    for fuse in (None, False):
+        enc = cvig_fov.FOV_DSM(circ_padding=True, weights=w).to(dev).train()
+        enc.precision = 'bf16'
+        enc.fuse_first2 = fuse
+        ran = []
+        real = ops.conv_first2_bf16
+
+        def recording(*a, **k):
+            ran.append('first2')
+            return real(*a, **k)
+        ops.conv_first2_bf16 = recording
+        try:
+            e = enc(x, dropout_scales=drops)
+        finally:
+            ops.conv_first2_bf16 = real
+        assert (ran == ['first2']) == (fuse is None), (fuse, ran)
+        e.square().sum().backward()
+        outs.append(e.detach().clone())
+        grads.append([p.grad.clone() for p in enc.parameters() if p.grad is not None])
+    assert torch.equal(outs[0], outs[1])
+    assert len(grads[0]) == len(grads[1]) == 12 and all(torch.equal(a, b) for a, b in zip(*grads))
+    w5 = synth.fov_dsm_weights(31, in_channels=5)
+    enc5 = cvig_semantic.FOV_DSM(circ_padding=True, weights=w5).to(dev).train()
+    enc5.precision = 'bf16'
+    called = []
+    real = ops.conv_first2_bf16
+    ops.conv_first2_bf16 = lambda *a, **k: called.append(1) or real(*a, **k)
+    try:
+        enc5(torch.from_numpy(synth.normalized_images(33, 5, (2, 5, 128, 512))).to(dev))
+    finally:
+        ops.conv_first2_bf16 = real
+    assert not called

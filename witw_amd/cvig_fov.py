@@ -252,7 +252,17 @@ class FOV_DSM(torch.nn.Module):
         h = x.contiguous() if fast0 else ops.nchw_to_nhwc_bf16(x.contiguous(), 16)
         last = self.layer_specs[-1][0]
         kept = {}
+        # layers 0 and 2 in one kernel, as forward_bf16 runs them, when neither is kept for a backward (cvig_fov: the frozen trunk,
+        # model/cvig_fov.py:275-278 -- the backward starts at layer 17) nor carries a Dropout2d scale: the same bits as the two launches
+        fuse = _lib.guards()['first2']['hand_scheduled_kernel'] if self.fuse_first2 is None else self.fuse_first2
+        fused = (fast0 and fuse and (keep_from is None or keep_from > 2) and 0 not in scales and 2 not in scales and
+                 self.layer_specs[0][:4] == (0, 1, True, False) and self.layer_specs[1][:4] == (2, 1, True, True))
         for (idx, sh, relu, pool, drop) in self.layer_specs:
+            if idx == 0 and fused:
+                h = ops.conv_first2_bf16(h, self._pack_first(True), self._pack_bf16(2), circular=self.circ_padding)
+                continue
+            if idx == 2 and fused:
+                continue
             if idx == 0 and fast0:
                 h = ops.conv3x3_first_fwd(h, self._pack_first(True), circular=self.circ_padding, relu=relu)
                 continue
