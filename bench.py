@@ -34,6 +34,7 @@ sys.path.insert(0, ROOT)
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 MFMA
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # same table, dense bf16 MFMA (no sparsity)
 PEAK_HBM_GBS = 8000.0           # same guide: HBM3E ~8 TB/s
+LINE_BUDGET = 6144             # bytes of the one stdout line (the driver's record keeps the last 8 KB of stdout)
 DOMINANT = (128, 1, False, 8)  # conv3x3_nhwc_f32_kernel<128,1,false,8,0,9> (TN, SH, POOL, NW, GEO, TAPS): layers 5,10,12,17,19,21 at B=128
 
 
@@ -118,7 +119,8 @@ class StepBench(object):
     and the two encoders, times K steps between barrier + synchronize pairs, and derives the live roofline of the dominant
     kernel from HIP events recorded around every launch on the launch stream (ops.PROFILE)."""
 
-    def __init__(self, model, mode, precision, batch, fov, rank, world, device, graph=False):
+    def __init__(self, model, mode, precision, batch, fov, rank, world, device, graph=False, share=None):
+        """share: another StepBench of the same model / fov whose weights and first `batch` input pairs are reused (batch sweep)"""
         from witw_amd import cvig_fov, ops, synth, parallel
         self.cvig_fov, self.ops, self.synth, self.parallel = cvig_fov, ops, synth, parallel
         self.model, self.mode, self.precision, self.B, self.fov = model, mode, precision, batch, fov
@@ -133,7 +135,7 @@ class StepBench(object):
         seed = 1234
         self.train = mode == 'train'
         self.bf16, self.f16x3 = precision == 'bf16', precision == 'fp16x3'
-        self.wts = synth.fov_dsm_weights(seed, in_channels=self.channels)
+        self.wts = share.wts if share is not None else synth.fov_dsm_weights(seed, in_channels=self.channels)
         self.se = model_mod.FOV_DSM(circ_padding=False, weights=self.wts).to(device)
         self.oe = model_mod.FOV_DSM(circ_padding=True, weights=self.wts).to(device)
         if self.bf16 and self.train:
@@ -145,7 +147,11 @@ class StepBench(object):
         params = list(self.se.parameters()) + list(self.oe.parameters())
         self.optimizer = cvig_fov.Adam(params, lr=1.E-5) if self.train else None
         self.reducer = parallel.OverlappedGradReducer([self.se, self.oe]) if self.train else None
-        self.ground_raw, self.ov_raw = make_inputs(cvig_fov, ops, synth, batch, fov, seed + rank, device, self.channels)
+        if share is not None:
+            assert share.channels == self.channels and share.fov == fov and share.B >= batch
+            self.ground_raw, self.ov_raw = share.ground_raw[:batch].contiguous(), share.ov_raw[:batch].contiguous()
+        else:
+            self.ground_raw, self.ov_raw = make_inputs(cvig_fov, ops, synth, batch, fov, seed + rank, device, self.channels)
         self.ws = int(fov / 360 * 512)
         self.mean, self.std = model_mod.Globals.img_mean, model_mod.Globals.img_std
         self.ndiv = 3 if self.semantic else None      # only the RGB bands are /255 (model/cvig_semantic.py:172-176)
@@ -243,6 +249,12 @@ class StepBench(object):
         self.value = self.B * world * steps / dt
         self.ms = dt / steps * 1e3
         self.roofline = self._roofline(prof)
+        if self.fov == 360 and not self.f16x3:
+            # algorithmic conv FLOP of the WHOLE step (cvig_fov 75.51 GFLOP per pair eval, 124.15 train; cvig_semantic
+            # 2 x 18.953 GMAC eval, + 2 x 25.6 GMAC backward) over the wall-clock step, against the same peak: what the step as a
+            # whole reaches, launch gaps and every non-dominant kernel included
+            gf = ((2 * 2 * 18.953 + (2 * 2 * 25.6 if self.train else 0.0)) if self.semantic else (124.15 if self.train else 75.51))
+            self.roofline['whole_step_frac'] = round(gf * 1e9 * self.B / (self.ms * 1e-3) / 1e12 / self.roofline['peak'], 4)
         return self
 
     def _roofline(self, prof):
@@ -332,7 +344,7 @@ class StepBench(object):
                 'dtype': self.dtype(), 'loss': float(self.loss.item()),
                 'recall': {'top1_pct': float(np.mean(self.ranks_h <= 1) * 100), 'top5_pct': float(np.mean(self.ranks_h <= 5) * 100)},
                 'roofline': {k: r[k] for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'launches', 'avg_launch_ms',
-                                               'all_conv_launches_tflops') if k in r},
+                                               'all_conv_launches_tflops', 'whole_step_frac', 'wgrad_bf16_tflops_incl_layout_passes') if k in r},
                 'parity': parity}
 
 
@@ -343,7 +355,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--batch', type=int, default=128, help='pairs per GPU (BASELINE.json configs[1]: bs=128)')
     ap.add_argument('--fov', type=int, default=360)
-    ap.add_argument('--mode', choices=['infer', 'train', 'retrieval', 'baseline', 'e2e', 'sweep'], default='infer',
+    ap.add_argument('--mode', choices=['infer', 'train', 'retrieval', 'baseline', 'e2e', 'sweep', 'sides'], default='infer',
                     help='infer (headline): embedding + similarity; train: the full step of model/cvig_fov.py:444-461; '
                          'retrieval: BASELINE config 5, --gallery rows per GPU x --queries, ranks + top-k; baseline: BASELINE '
                          'config 1, cvig_baseline 32 pairs; e2e: disk -> embeddings through ImagePairDataset + DataLoader workers')
@@ -362,6 +374,10 @@ def main():
                     help='inference, one GPU: capture the whole step in a hipGraph (parallel.CapturedStep) and time replays; '
                          'pays off where the step is launch-bound (small --batch, bf16)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--detail-out', default=None,
+                    help='where the FULL record goes (default bench_detail.json beside bench.py): stdout carries one line of at most '
+                         '%d bytes -- headline, roofline, cpu_baseline and one compact entry per side config' % LINE_BUDGET)
+    ap.add_argument('--no-microbench', action='store_true', help='N > 1: skip the standalone timing of the step\'s collectives')
     ap.add_argument('--no-side-blocks', action='store_true', help='only the headline measurement (no blocks for the other BASELINE configs)')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL); gloo only for 1-GPU self-tests')
     ap.add_argument('--single-device', action='store_true', help='self-test: put every rank on cuda:0')
@@ -405,36 +421,98 @@ def main():
         out = e2e_bench(a, device)
     elif a.mode == 'sweep':
         out = batch_sweep(a, rank, world, device, ops)
+    elif a.mode == 'sides':
+        out = side_blocks(a, rank, world, device, cvig_fov, ops)
     else:
         out = step_line(a, rank, world, device, cvig_fov, ops)
+    bad = None
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        bad = emit(out, a)
     if world > 1:
         dist.destroy_process_group()
+    if bad:
+        sys.exit(bad)
+
+
+def stamp(what, t0=[None]):
+    """progress + where the run's wall time goes, on stderr (the driver's clock sees all of it)"""
+    now = time.perf_counter()
+    if t0[0] is None:
+        t0[0] = now
+    sys.stderr.write('[bench %7.1f s] %s\n' % (now - t0[0], what))
+    sys.stderr.flush()
 
 
 def step_line(a, rank, world, device, cvig_fov, ops):
+    """The headline line. Order: the headline measurement, then its cpu_baseline, and only then -- in a CHILD
+    process whose failure cannot lose either -- the blocks of the other single-GPU BASELINE configs. stdout gets the compact line
+    (<= LINE_BUDGET bytes), the full record goes to --detail-out and stderr."""
+    stamp('start (%s %s %s B=%d, %d rank(s))' % (a.model, a.mode, a.precision, a.batch, world))
     sb = StepBench(a.model, a.mode, a.precision, a.batch, a.fov, rank, world, device, a.graph).run(a.steps, a.warmup)
     out = sb.line()
+    stamp('headline: %.1f pairs/s, %.3f ms per step' % (sb.value, sb.ms))
     out['collectives'] = collectives_info(a, rank, world, device, sb.phases, sb.ms)          # every rank takes part; rank 0 prints
+    if world > 1 and not a.no_microbench:
+        out['collectives']['microbench'] = collectives_microbench(a, rank, world, device, sb.phases)
+        stamp('collectives microbench')
     out['guards'] = guards_block(ops)
     headline = world == 1 and a.mode == 'infer' and a.precision == 'fp32' and not a.graph
     side = headline and not a.no_side_blocks and a.model == 'fov' and a.fov == 360 and a.batch == 128
-    if headline and not a.no_side_blocks:
-        out['fp32_grade_on_fp16_mfma'] = fp16x3_block(sb, a.steps)
-        if not sb.semantic and a.fov == 360:
-            out['hbm_kernels'] = hbm_block(sb)
     cpu_args = (sb.ground_raw[:a.cpu_pairs].cpu(), sb.ov_raw[:a.cpu_pairs].cpu(), sb.wts, sb.semantic) if headline else None
+    del sb
+    torch.cuda.empty_cache()
+    if headline and rank == 0 and not a.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(a, *cpu_args)
+        stamp('cpu_baseline: %.2f pairs/s on %d threads' % (out['cpu_baseline']['value'], out['cpu_baseline']['cores']))
     if side:
-        del sb
+        out['_side_full'] = sides_child(a)       # this process is idle on the GPU meanwhile (its memory is released)
+        stamp('side blocks done')
+    return out
+
+
+SIDE_ORDER = ('train_step_fp32', 'config4_semantic_bf16', 'train_step_bf16', 'config1_baseline', 'config5_retrieval', 'config5_retrieval_direct',
+              'fp32_grade_on_fp16_mfma', 'hbm_kernels', 'batch_sweep', 'e2e_data_path', 'e2e_data_path_bf16')
+
+
+def side_blocks(a, rank, world, device, cvig_fov, ops):
+    """`--mode sides`: one block per other single-GPU BASELINE config (config 1 cvig_baseline, the config-2 training step in fp32 and
+    bf16, config 4 cvig_semantic on the bf16 MFMA, config 5 retrieval), the fp16x3 / HBM-kernel / batch-size / data-path blocks --
+    each measured here with its dominant kernel's live roofline. Run by the headline as a child; its stdout line is the full dict
+    (it is NOT bound by LINE_BUDGET: --detail-out takes it), and the dict is re-written to --detail-out after every block, so a
+    block that dies costs only itself."""
+    out = {}
+    k = max(2, min(a.steps, 5))
+
+    def done(name, blk):
+        out[name] = blk
+        stamp('side block %s' % name)
+        if a.detail_out:
+            tmp = a.detail_out + '.tmp'
+            with open(tmp, 'w') as f:
+                json.dump(out, f)
+            os.replace(tmp, a.detail_out)
+
+    def guarded(name, fn):
+        try:
+            done(name, fn())
+        except Exception as e:       # a failed block is reported as such; the others still run
+            import traceback
+            traceback.print_exc(file=sys.stderr)
+            done(name, {'error': '%s: %s' % (type(e).__name__, str(e)[:300])})
         torch.cuda.empty_cache()
-        k = max(2, min(a.steps, 5))
+
+    def train_fp32():
         t = StepBench('fov', 'train', 'fp32', a.batch, a.fov, rank, world, device).run(k, 2)
-        out['train_step_fp32'] = t.block('configs[1] shape (cvig_fov bs=128, fp32), the training step of model/cvig_fov.py:444-461',
-                                         'every trainable gradient within 1e-4 of its norm of the reference run with reconciled ReLU gates, '
-                                         'Adam update within 1e-3 lr (tests/test_backward_gpu.py::test_training_step_matches_reference_golden)')
-        del t
-        torch.cuda.empty_cache()
+        return t.block('configs[1] shape (cvig_fov bs=128, fp32), the training step of model/cvig_fov.py:444-461',
+                       'every trainable gradient within 1e-4 of its norm of the reference run with reconciled ReLU gates, '
+                       'Adam update within 1e-3 lr (tests/test_backward_gpu.py::test_training_step_matches_reference_golden)')
+
+    def train_bf16():
+        t = StepBench('fov', 'train', 'bf16', a.batch, a.fov, rank, world, device).run(k, 2)
+        return t.block('configs[1] shape on the configs[3] arithmetic: the cvig_fov training step with bf16 MFMA forward / dgrad / wgrad, '
+                       'fp32 accumulate, fp32 master weights and Adam', 'tests/test_bf16_train_gpu.py (wgrad vs autograd, step vs the fp32 path)')
+
+    def semantic_bf16():
         s = StepBench('semantic', 'infer', 'bf16', a.batch, a.fov, rank, world, device).run(k, 2)
         blk = s.block('configs[3]: cvig_semantic, bf16 MFMA, 1 GPU', None)
         with torch.no_grad():       # accuracy of this very step against the exact-fp32 kernels on the same inputs
@@ -446,56 +524,264 @@ def step_line(a, rank, world, device, cvig_fov, ops):
         blk['parity'] = {'embedding_rel_l2_vs_f32_kernels': rel, 'stated_tolerance': 5e-2,
                          'top1_pct_f32_kernels': float((r32 <= 1).float().mean().item() * 100),
                          'test': 'tests/test_bf16_gpu.py (vs CPU emulation of bf16 storage 1e-2, vs fp32 reference goldens 5e-2 of the norm)'}
-        out['config4_semantic_bf16'] = blk
-        del s, su_b, ov_b, su_f, ov_f, surface, polar
-        torch.cuda.empty_cache()
-        baseline_cpu = None
-        if a.no_cpu_baseline:
-            out['config1_baseline'] = baseline_bench(a, device, full=False)
-        else:       # its CPU leg runs last, with the headline's
-            out['config1_baseline'], baseline_cpu = baseline_bench(a, device, full=True, defer_cpu=True)
-        torch.cuda.empty_cache()
-        out['batch_sweep'] = batch_sweep(a, rank, world, device, ops)
-        torch.cuda.empty_cache()
-        out['config5_retrieval'] = retrieval_block(device, cvig_fov, ops, 125000, 10000, 10, 'dft')
-        torch.cuda.empty_cache()
-        out['config5_retrieval_direct'] = retrieval_block(device, cvig_fov, ops, 125000, 1024, 10, 'direct')
-        torch.cuda.empty_cache()
+        return blk
+
+    def fp32_blocks():
+        sb = StepBench('fov', 'infer', 'fp32', a.batch, a.fov, rank, world, device).run(2, 1)
+        done('fp32_grade_on_fp16_mfma', fp16x3_block(sb, k))
+        return hbm_block(sb)
+
+    def e2e(extra):
+        e = e2e_child(a, extra)
+        if 'error' in e:
+            return e
         keys = ('metric', 'value', 'unit', 'dtype', 'jpeg_decode', 'staging', 'steady_state_pairs_per_s', 'pipeline_fill_s', 'stage_pairs_per_s',
                 'limiting_stage', 'overlap_efficiency_steady_state', 'gpu_stage_serialised_pairs_per_s', 'host_decode_pairs_per_s_per_core',
                 'host_decode_scaling')
-        # The data-path blocks run as CHILD processes (`bench.py --mode e2e ...`, started here, never an exec of this process): inside
-        # this one -- 16 loader workers forked from a process that has built every other block -- the same pass measured a fifth
-        # slower (10.8 k against 13.6 k pairs/s) with every stage on its own unchanged; a driver's train() / test() is a fresh process.
-        # the headline's fp32 encoders: the GPU is the limiting stage
-        e = e2e_child(a, ['--e2e-pairs', '2048'])
-        if e is not None:
-            out['e2e_data_path'] = {k: e[k] for k in keys if k in e}
-            out['e2e_data_path']['workload'] = e['config']['workload']
-        # the bf16 encoders (configs[3] arithmetic) need 8x the images per second: JPEG back end on the GPU, page-locked ring
-        e = e2e_child(a, ['--e2e-pairs', '8192', '--workers', '16', '--precision', 'bf16'])
-        if e is not None:
-            out['e2e_data_path_bf16'] = {k: e[k] for k in keys if k in e}
-            out['e2e_data_path_bf16']['workload'] = e['config']['workload']
-        torch.cuda.empty_cache()
-    if headline and rank == 0 and not a.no_cpu_baseline:      # last: nothing on the GPU waits behind the CPU leg
-        out['cpu_baseline'] = cpu_baseline(a, *cpu_args)
-        if side and baseline_cpu is not None:
-            baseline_cpu()
+        blk = {kk: e[kk] for kk in keys if kk in e}
+        blk['workload'] = e['config']['workload']
+        return blk
+
+    guarded('train_step_fp32', train_fp32)
+    guarded('config4_semantic_bf16', semantic_bf16)
+    guarded('train_step_bf16', train_bf16)
+    cpu_leg = [None]
+
+    def baseline():      # its CPU leg runs at the very end, behind the data-path blocks (their loaders compete for the same cores)
+        if a.no_cpu_baseline:
+            return baseline_bench(a, device, full=False)
+        blk, cpu_leg[0] = baseline_bench(a, device, full=True, defer_cpu=True)
+        return blk
+    guarded('config1_baseline', baseline)
+    guarded('config5_retrieval', lambda: retrieval_block(device, cvig_fov, ops, 125000, 10000, 10, 'dft'))
+    guarded('config5_retrieval_direct', lambda: retrieval_block(device, cvig_fov, ops, 125000, 1024, 10, 'direct'))
+    guarded('hbm_kernels', fp32_blocks)
+    guarded('batch_sweep', lambda: batch_sweep(a, rank, world, device, ops, compact=True))
+    # The data-path blocks run as CHILD processes (`bench.py --mode e2e ...`): 16 loader workers forked from a process that has built
+    # every other block measured a fifth slower with every stage on its own unchanged; a driver's train() / test() is a fresh process.
+    # fp32 encoders: the GPU is the limiting stage; bf16 encoders (configs[3] arithmetic) need 8x the images per second
+    guarded('e2e_data_path', lambda: e2e(['--e2e-pairs', '2048']))
+    guarded('e2e_data_path_bf16', lambda: e2e(['--e2e-pairs', '8192', '--workers', '16', '--precision', 'bf16']))
+    if cpu_leg[0] is not None:
+        try:
+            cpu_leg[0]()                         # fills config1_baseline's cpu_baseline + parity in place
+            done('config1_baseline', out['config1_baseline'])
+        except Exception as e:
+            out['config1_baseline']['cpu_baseline'] = {'error': str(e)[:200]}
     return out
 
 
-def batch_sweep(a, rank, world, device, ops):
+def child_env():
+    """environment of a bench child: no launcher variables, and no profiler pre-load (a child under `rocprofv3 -- python3 bench.py`
+    would otherwise be measured with the tool attached and write into the parent's output directory)"""
+    drop = ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'LD_PRELOAD')
+    return {k: v for k, v in os.environ.items() if k not in drop and not k.startswith('ROCP') and not k.startswith('ROCPROF')}
+
+
+def run_child(cmd, timeout):
+    """cmd in its own session; on timeout the whole process group (loader workers, pools) is killed. -> (rc or None, stdout, stderr tail)"""
+    import signal
+    import subprocess
+    p = subprocess.Popen(cmd, env=child_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        so, se = p.communicate(timeout=timeout)
+        return p.returncode, so, se
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(p.pid, signal.SIGKILL)
+        except OSError:
+            pass
+        so, se = p.communicate()
+        return None, so, se
+
+
+def sides_child(a):
+    """`bench.py --mode sides` as a child -> {block: dict}; whatever it had finished when it failed or ran out of time is kept"""
+    import tempfile
+    fd, path = tempfile.mkstemp(prefix='witw_sides_', suffix='.json')
+    os.close(fd)
+    cmd = [sys.executable, os.path.abspath(__file__), '--mode', 'sides', '--batch', str(a.batch), '--fov', str(a.fov), '--steps', str(a.steps),
+           '--detail-out', path] + (['--no-cpu-baseline'] if a.no_cpu_baseline else [])
+    rc, so, se = run_child(cmd, 600)
+    sys.stderr.write(se)
+    blocks = {}
+    try:
+        blocks = json.load(open(path))
+    except Exception:
+        pass
+    for f in (path, path + '.tmp'):
+        if os.path.exists(f):
+            os.remove(f)
+    if rc != 0:
+        blocks['_child'] = {'error': 'timeout' if rc is None else 'exit status %d' % rc, 'stderr_tail': se[-400:]}
+    return blocks
+
+
+def short(s, n=120):
+    s = str(s)
+    return s if len(s) <= n else s[:n - 1] + '~'
+
+
+def compact_side(name, b):
+    """one side block -> the few keys the line carries: value, ms_per_step, dtype, the dominant kernel and its roofline fraction"""
+    if not isinstance(b, dict):
+        return None
+    if 'error' in b:
+        return {'error': short(b['error'], 80)}
+    c = {}
+    for k in ('value', 'unit', 'ms_per_step', 'dtype'):
+        if k in b:
+            c[k] = b[k]
+    r = b.get('roofline')
+    if isinstance(r, dict):
+        c['kernel'] = short(r.get('kernel', ''), 48)
+        c['frac'] = r.get('frac')
+        if r.get('bound') and r['bound'] != 'mfma':
+            c['bound'] = r['bound']
+    if name == 'config1_baseline':
+        if isinstance(b.get('train_step'), dict):
+            c['train_ms_per_step'] = b['train_step'].get('ms_per_step')
+        if isinstance(b.get('cpu_baseline'), dict):
+            c['cpu_pairs_per_s'] = b['cpu_baseline'].get('value')
+            c['cpu_cores'] = b['cpu_baseline'].get('cores')
+    if name.startswith('train_step') and isinstance(r, dict) and 'wgrad_bf16_tflops_incl_layout_passes' in r:
+        c['wgrad_tflops'] = r['wgrad_bf16_tflops_incl_layout_passes']
+    if name == 'hbm_kernels':
+        c = {'unit': 'frac of 8 TB/s', 'kernels': {short(k.split(' ')[0], 40): v['frac_of_hbm_peak'] for k, v in b.get('kernels', {}).items()}}
+    if name == 'batch_sweep':
+        c = {'unit': 'pairs/s', 'points': {'%s_B%d' % (p_['precision'], p_['pairs_per_gpu']):
+                                           [p_['value'], p_.get('graph_replay', {}).get('value')] for p_ in b.get('points', [])},
+             'what': '[eager, hipGraph replay or null]'}
+    if name.startswith('e2e'):
+        for k in ('steady_state_pairs_per_s', 'overlap_efficiency_steady_state'):
+            if k in b:
+                c[k] = b[k]
+        if 'limiting_stage' in b:
+            c['limiting_stage'] = short(b['limiting_stage'], 40)
+    if name == 'fp32_grade_on_fp16_mfma':
+        c['max_abs_embedding_diff_vs_f32_kernels'] = b.get('max_abs_embedding_diff_vs_f32_kernels')
+    if name == 'config5_retrieval' and isinstance(b.get('index_exact'), dict):
+        c['rescored_per_million'] = b['index_exact'].get('rescored_per_million')
+    return c
+
+
+def compact_line(full):
+    """The stdout line: headline keys in full, everything verbose trimmed, one compact entry per side config."""
+    line = {}
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data'):
+        if k in full:
+            line[k] = full[k] if k != 'dtype' else short(full[k], 40)
+    if isinstance(full.get('config'), dict):
+        line['config'] = {k: (short(v, 200) if isinstance(v, str) else v) for k, v in full['config'].items()}
+    for k in ('queries_per_sec', 'recall', 'loss', 'index_exact'):
+        if k in full:
+            line[k] = full[k]
+    r = full.get('roofline')
+    if isinstance(r, dict):
+        line['roofline'] = {k: (short(r[k], 100) if isinstance(r[k], str) else r[k]) for k in
+                            ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'launches', 'avg_launch_ms', 'avg_launch_gflop',
+                             'all_conv_launches_tflops', 'whole_step_frac', 'wgrad_bf16_tflops_incl_layout_passes') if k in r}
+        ts = r.get('traffic_source')
+        if isinstance(ts, dict):
+            line['roofline']['traffic_source'] = {'file': ts.get('file'), 'stale': ts.get('stale')}
+    c = full.get('cpu_baseline')
+    if isinstance(c, dict):
+        line['cpu_baseline'] = {k: (short(c[k], 160) if isinstance(c[k], str) else c[k]) for k in
+                                ('value', 'unit', 'cores', 'kind', 'cpu', 'pairs_per_s_by_threads', 'sample') if k in c}
+    g = full.get('guards')
+    if isinstance(g, dict):
+        line['guards'] = {k: g[k] for k in ('tripped', 'forced_by_env', 'bf16_16x16x32_kernel_on', 'bf16_weight_resident_kernel_on') if k in g}
+    c = full.get('collectives')
+    if isinstance(c, dict):
+        cc = {k: c[k] for k in ('backend', 'world', 'rccl_version', 'all_reduce_of_ones', 'distinct_devices', 'microbench') if k in c}
+        cc['ranks_seen'] = len(c.get('ranks_seen', []))
+        cc['devices'] = ['%d:%s' % (d['rank'], d.get('pci_bus_id') or d.get('local_device')) for d in c.get('devices', [])]
+        pp = c.get('per_phase_ms')
+        if isinstance(pp, dict):
+            cc['per_phase_ms_max_over_ranks'] = pp.get('max_over_ranks')
+        line['collectives'] = cc
+    sides = full.get('_side_full')
+    if isinstance(sides, dict):
+        line['side'] = {}
+        for name in list(SIDE_ORDER) + [k for k in sides if k not in SIDE_ORDER]:
+            if name in sides:
+                cs = compact_side(name, sides[name])
+                if cs is not None:
+                    line['side'][name] = cs
+    if isinstance(full.get('points'), list):        # --mode sweep: one row per point, the per-kernel tables stay in the detail record
+        line['points'] = [[p_['precision'], p_['pairs_per_gpu'], p_['value'], p_.get('all_conv_launches_frac'), p_.get('all_conv_frac_vs_B128'),
+                           p_.get('graph_replay', {}).get('value')] for p_ in full['points']]
+        line['points_columns'] = ['precision', 'pairs_per_gpu', 'pairs_per_s', 'all_conv_launches_frac', 'all_conv_frac_vs_B128', 'graph_replay_pairs_per_s']
+    for k in ('what', 'stage_pairs_per_s', 'limiting_stage', 'steady_state_pairs_per_s', 'overlap_efficiency_steady_state',
+              'jpeg_decode', 'train_step', 'parity', 'error'):          # the smaller modes' own keys (sweep, e2e, baseline)
+        if k in full and k not in line:
+            line[k] = full[k] if not isinstance(full[k], str) else short(full[k], 200)
+    return line
+
+
+def emit(full, a):
+    """Rank 0: full record -> --detail-out (default bench_detail.json beside bench.py) and stderr; compact line (< LINE_BUDGET bytes, or
+    optional parts are shed until it is) -> stdout, exactly one line. -> exit status to raise (None = fine)."""
+    path = a.detail_out or os.path.join(ROOT, 'bench_detail.json')
+    if a.mode == 'sides':                     # the child of a headline run: its parent compacts; the file was written block by block
+        print(json.dumps(full), flush=True)
+        return None
+    rec = dict(full)
+    sides = rec.pop('_side_full', None)
+    if sides:
+        rec.update(sides)
+    blob = json.dumps(rec)
+    try:
+        with open(path, 'w') as f:
+            f.write(blob + '\n')
+    except OSError as e:
+        sys.stderr.write('bench: could not write %s (%s)\n' % (path, e))
+        path = None
+    sys.stderr.write('BENCH_DETAIL ' + blob + '\n')
+    sys.stderr.flush()
+    line = compact_line(full)
+    line['detail'] = (os.path.relpath(path, ROOT) if path else None)
+    text = json.dumps(line, separators=(',', ':'))
+    for shed in ('side.batch_sweep', 'side.hbm_kernels', 'collectives.per_phase_ms_max_over_ranks', 'side', 'collectives.devices',
+                 'cpu_baseline.sample', 'config.workload'):
+        if len(text) < LINE_BUDGET:
+            break
+        d, keys = line, shed.split('.')
+        for k in keys[:-1]:
+            d = d.get(k, {})
+        if keys[-1] in d:
+            del d[keys[-1]]
+            line.setdefault('shed_to_fit', []).append(shed)
+        text = json.dumps(line, separators=(',', ':'))
+    if len(text) >= LINE_BUDGET:
+        sys.stderr.write('bench: line of %d bytes exceeds the budget of %d\n' % (len(text), LINE_BUDGET))
+    print(text, flush=True)
+    c = full.get('collectives') or {}
+    if c.get('world', 1) > 1:
+        # an N-GPU line that did not really run on N ranks / N devices is refused (exit status 3), after it has been printed
+        if c.get('all_reduce_of_ones') != float(c['world']) or len(c.get('ranks_seen', [])) != c['world']:
+            sys.stderr.write('bench: the process group did not count %d ranks\n' % c['world'])
+            return 3
+        if not a.single_device and c.get('distinct_devices') != c['world']:
+            sys.stderr.write('bench: %d ranks on %s distinct devices\n' % (c['world'], c.get('distinct_devices')))
+            return 3
+    return None
+
+
+def batch_sweep(a, rank, world, device, ops, compact=False):
     """The reference's own default operating points (train / test batch_size 64: model/cvig_fov.py:385,490; cvig_semantic 32:
     model/cvig_semantic.py:416; cvig_baseline 16) beside the B = 128 the headline is quoted on: the cvig_fov eval step at B = 16, 32, 64,
     128 in fp32 and bf16, eager and -- where the step is launch-bound -- replayed as one hipGraph. Per point: pairs/s, and for the
     conv kernel instantiation that takes the most time at that batch its FLOP/s against the MFMA peak (HIP events around every
-    launch, by kernel name), so that a kernel-selection cliff shows as a drop of `frac` against B = 128."""
+    launch, by kernel name), so that a kernel-selection cliff shows as a drop of `frac` against B = 128. compact (the default run's
+    side block): no per-kernel table; one synthetic batch of 128 pairs is built once and its first B pairs are every point's input."""
     out = {'what': 'cvig_fov fov=360 eval step (the headline workload) at the reference\'s default batch sizes', 'points': []}
+    base = None
     for precision in ('fp32', 'bf16'):
         peak = PEAK_BF16_MFMA_TFLOPS if precision == 'bf16' else PEAK_F32_MFMA_TFLOPS
-        for B in (16, 32, 64, 128):
-            sb = StepBench('fov', 'infer', precision, B, a.fov, rank, world, device)
+        for B in (128, 64, 32, 16):
+            sb = StepBench('fov', 'infer', precision, B, a.fov, rank, world, device, share=base)
+            base = base or sb
             k = 5 if precision == 'fp32' else 10
             ops.PROFILE_BY_KERNEL = {}
             sb.run(k, 2)
@@ -509,19 +795,22 @@ def batch_sweep(a, rank, world, device, ops):
                   'dominant_kernel_share_of_conv_time': round(agg[top][1] / max(1e-9, sum(v[1] for v in agg.values())), 3),
                   'all_conv_launches_tflops': sb.roofline['all_conv_launches_tflops'],
                   'all_conv_launches_frac': round(sb.roofline['all_conv_launches_tflops'] / peak, 4),
-                  'conv_launches_ms_per_step': round(conv_ms, 3),
-                  'kernels': {n: {'launches_per_step': agg[n][2] // k, 'ms_per_step': round(agg[n][1] / k, 4),
-                                  'tflops': round(agg[n][0] / (agg[n][1] * 1e-3) / 1e12, 1)} for n in sorted(agg, key=lambda n: -agg[n][1])}}
+                  'conv_launches_ms_per_step': round(conv_ms, 3)}
+            if not compact:
+                pt['kernels'] = {n: {'launches_per_step': agg[n][2] // k, 'ms_per_step': round(agg[n][1] / k, 4),
+                                     'tflops': round(agg[n][0] / (agg[n][1] * 1e-3) / 1e12, 1)} for n in sorted(agg, key=lambda n: -agg[n][1])}
             if sb.ms - conv_ms > 0.15 * sb.ms:        # a sixth of the step is not conv kernels: launch gaps matter -> one hipGraph
-                g = StepBench('fov', 'infer', precision, B, a.fov, rank, world, device, graph=True).run(k, 2)
+                g = StepBench('fov', 'infer', precision, B, a.fov, rank, world, device, graph=True, share=base).run(k, 2)
                 pt['graph_replay'] = {'value': round(g.value, 1), 'ms_per_step': round(g.ms, 3)}
                 del g
             out['points'].append(pt)
-            del sb
+            if sb is not base:
+                del sb
             torch.cuda.empty_cache()
     ref = {p['precision']: p for p in out['points'] if p['pairs_per_gpu'] == 128}
     for p in out['points']:
         p['all_conv_frac_vs_B128'] = round(p['all_conv_launches_frac'] / max(1e-9, ref[p['precision']]['all_conv_launches_frac']), 3)
+    out['points'].sort(key=lambda p: (p['precision'] != 'fp32', p['pairs_per_gpu']))
     return out
 
 
@@ -552,7 +841,7 @@ def hbm_block(sb):
                 sb.ov_raw.numel() * 4 + polar.numel() * 4, 'raw %d x %d x 512 x 512 fp32 in, %d x %d x 128 x 512 out; the 256 x 256 image is never written' % (B, c, B, c)),
             'resize_bilinear_norm_kernel (ground side 224 -> 128 x 512)': (timed(lambda: ops.resize_bilinear(sb.ground_raw, (128, sb.ws), sb.mean, sb.std, sb.ndiv)),
                                                                           sb.ground_raw.numel() * 4 + B * c * 128 * sb.ws * 4, 'raw 224 x 224 in, 128 x %d out' % sb.ws),
-            'the former overhead side, two launches: resize_bilinear_norm_kernel 512 -> 256, then polar_kernel': (
+            'resize_then_polar_two_launches (the former overhead side: resize_bilinear_norm_kernel 512 -> 256, then polar_kernel)': (
                 timed(lambda: ops.polar_transform(ops.resize_bilinear(sb.ov_raw, (256, 256), sb.mean, sb.std, sb.ndiv))),
                 sb.ov_raw.numel() * 4 + polar.numel() * 4, 'same algorithmic bytes (raw in, polar out) as the fused launch'),
             'conv3x3_first_persist_kernel (3 -> 64 channels, NCHW in, NHWC out; round 4: two persistent workgroups per CU, the next tile prefetched)': (timed(lambda: ops.conv3x3_first_fwd(polar, packed, circular=True, relu=True)),
@@ -865,25 +1154,26 @@ def cpu_baseline(a, g, o, wts, semantic):
 
 
 def cpu_thread_sweep(fn, units, sample):
-    """ONE convention for every cpu_baseline of the line: the CPU port is timed at 8 threads (the survey
-    container's core count), 16 (this box's CPU share per GPU) and every core torch sees; `value` is the
-    best of them, `cores` the threads it used, all three are listed. One warm-up call, then best of 2 per thread count."""
+    """ONE convention for every cpu_baseline of the line: the CPU port is timed at 16 threads (this box's CPU share per GPU; the
+    survey container had 8) and at every core torch sees; `value` is the better of the two, `cores` the
+    threads it used, both are listed. One warm-up call (at 16 threads), then ONE timed call per thread count: three passes over
+    the sample in all (rounds 3-4 made seven; the sample is sized so that the three stay within ~15 s)."""
     all_threads = torch.get_num_threads()
+    counts = sorted({min(16, all_threads), all_threads})
     by_threads = {}
+    torch.set_num_threads(counts[0])
     fn()
-    for threads in sorted({min(8, all_threads), min(16, all_threads), all_threads}):
+    for threads in counts:
         torch.set_num_threads(threads)
-        times = []
-        for _ in range(2):
-            t0 = time.perf_counter()
-            fn()
-            times.append(time.perf_counter() - t0)
-        by_threads[threads] = round(units / min(times), 3)
+        t0 = time.perf_counter()
+        fn()
+        by_threads[threads] = round(units / (time.perf_counter() - t0), 3)
     torch.set_num_threads(all_threads)
     best = max(by_threads, key=lambda t: by_threads[t])
     return {'value': by_threads[best], 'unit': 'pairs/s', 'cores': best, 'kind': 'port', 'cpu': cpu_model(),
-            'pairs_per_s_by_threads': {str(t): v for t, v in by_threads.items()}, 'threads_convention': '8, 16 and all (%d) threads; best reported' % all_threads,
-            'sample': sample + ', best of 2 after 1 warm-up, torch %s CPU ops (oneDNN / BLAS as built)' % torch.__version__}
+            'pairs_per_s_by_threads': {str(t): v for t, v in by_threads.items()},
+            'threads_convention': '16 and all (%d) threads; best reported' % all_threads,
+            'sample': sample + '; 1 warm-up + 1 timed pass per thread count, torch %s CPU ops (oneDNN / BLAS as built)' % torch.__version__}
 
 
 def guards_block(ops):
@@ -944,20 +1234,79 @@ def collectives_info(a, rank, world, device, phases=None, step_ms=None):
                                         if a.mode == 'train' else '')}
 
 
+XGMI_LINK_GBS = 153.0      # per point-to-point xGMI link (7 per GPU); SURVEY.md section 5 prices the collectives against it
+
+
+def collectives_microbench(a, rank, world, device, phases=None, iters=10):
+    """The three payloads the step really sends, each timed STANDALONE (nothing else on the device; HIP events on the launch
+    stream around `iters` back-to-back blocking calls, after 3 warm-up calls; max over ranks) -> microseconds per call, algorithm
+    bandwidth (payload bytes / time) and the fraction of the xGMI bound of a DIRECT (fully connected, all 7 links at once)
+    schedule, SURVEY.md section 5:
+      all-gather of the overhead embeddings  b x 16 KiB per rank    bound = payload_per_rank / link          (2 MiB -> ~14 us)
+      reduce-scatter of their gradients      world x b x 16 KiB     bound = (total / world) / link          (16 MiB -> ~14 us)
+      all-reduce (SUM) of one encoder's weight gradients, 7,236,432 fp32, x 2 encoders
+                                                                     bound = 2 phases x (bytes / world) / link   (2 x 29 MB -> ~95 us)
+    A ring schedule is bound by ONE link for (world - 1) hops: its figure is listed beside the direct one. In a training run
+    `overlap_hidden_ms` = what the asynchronous bucket all-reduces spent in flight (issue -> joined) minus what the compute stream
+    lost to the join (reducer_wait_stall): communication time that backward kernels covered. Reference semantics of the exchange:
+    nn.DataParallel, model/cvig_baseline.py:339-343; global-batch normaliser model/cvig_fov.py:380."""
+    from witw_amd import parallel
+    E = 16 * 4 * 64
+    b = a.batch
+    n_grad = 7236432
+    ov = torch.randn((b, E), device=device)
+    gall = torch.randn((world * b, E), device=device)
+    bucket = torch.randn((n_grad,), device=device)
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        dist.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        e1.synchronize()
+        t = torch.tensor([e0.elapsed_time(e1) / iters * 1e3], device=device, dtype=torch.float64)       # us per call
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    link = XGMI_LINK_GBS * 1e9
+    rows = (('all_gather_overhead_embeddings', lambda: parallel._all_gather_cat(ov), ov.numel() * 4, ov.numel() * 4 / link,
+             ov.numel() * 4 * (world - 1) / link),
+            ('reduce_scatter_overhead_grads', lambda: parallel.reduce_scatter_rows(gall, b), gall.numel() * 4, gall.numel() * 4 / world / link,
+             gall.numel() * 4 / world * (world - 1) / link),
+            ('all_reduce_weight_grads_one_encoder', lambda: dist.all_reduce(bucket, op=dist.ReduceOp.SUM), n_grad * 4,
+             2 * n_grad * 4 / world / link, 2 * n_grad * 4 / world * (world - 1) / link))
+    out = {}
+    for name, fn, nbytes, direct_s, ring_s in rows:
+        us = timed(fn)
+        out[name] = {'bytes': int(nbytes), 'us': round(us, 1), 'algbw_GBps': round(nbytes / (us * 1e-6) / 1e9, 2),
+                     'xgmi_direct_bound_us': round(direct_s * 1e6, 1), 'frac_of_direct_bound': round(direct_s * 1e6 / us, 4),
+                     'xgmi_ring_bound_us': round(ring_s * 1e6, 1)}
+    out['all_reduce_weight_grads_one_encoder']['per_step'] = 2
+    if phases and 'reducer_wait_stall' in phases:
+        inflight = sum(v for k, v in phases.items() if k.endswith('_all_reduce_issue_to_joined'))
+        out['overlap_hidden_ms'] = round(inflight - phases['reducer_wait_stall'], 4)
+    out['link_GBps'] = XGMI_LINK_GBS
+    out['how'] = 'standalone, %d calls after 3 warm-ups, HIP events, max over ranks; bounds: SURVEY.md section 5' % iters
+    return out
+
+
 def e2e_child(a, extra):
-    """`bench.py --mode e2e <extra>` as a child process on the same GPU (this process is idle meanwhile) -> its JSON line, or None"""
-    import subprocess
+    """`bench.py --mode e2e <extra>` as a child process on the same GPU (this process is idle meanwhile) -> its JSON line, or
+    {'error': ...}: a timeout kills the child's whole process group (loader workers, decode pool) and is reported, not dropped"""
     cmd = [sys.executable, os.path.abspath(__file__), '--mode', 'e2e', '--batch', str(a.batch), '--fov', str(a.fov)] + list(extra)
-    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
-    try:
-        p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
-    except subprocess.TimeoutExpired:
-        return None
-    for ln in p.stdout.splitlines():
+    rc, so, se = run_child(cmd, 300)
+    if rc is None:
+        return {'error': 'timeout after 300 s (process group killed)'}
+    for ln in so.splitlines():
         if ln.startswith('{') and '"metric"' in ln:
             return json.loads(ln)
-    sys.stderr.write('e2e child failed (%d): %s\n' % (p.returncode, p.stderr[-800:]))
-    return None
+    sys.stderr.write('e2e child failed (%d): %s\n' % (rc, se[-800:]))
+    return {'error': 'exit status %d: %s' % (rc, se[-200:])}
 
 
 def e2e_bench(a, device):

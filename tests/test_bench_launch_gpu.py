@@ -19,14 +19,28 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+LINE_BUDGET = 6144        # bench.LINE_BUDGET: the driver's record keeps the last 8 KB of stdout (round 4's 24 KB line was lost)
+
+
 def _run_bench(*args, timeout=900):
+    """-> the ONE stdout line (asserted to fit the budget), with the full record of --detail-out under '_detail'"""
+    import tempfile
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
-    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + list(args), env=env, stdout=subprocess.PIPE,
-                       stderr=subprocess.PIPE, text=True, timeout=timeout)
-    assert p.returncode == 0, p.stderr[-3000:]
-    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
-    assert len(lines) == 1, p.stdout                      # exactly ONE line on stdout
-    return json.loads(lines[0])
+    fd, detail = tempfile.mkstemp(prefix='witw_bench_detail_', suffix='.json')
+    os.close(fd)
+    try:
+        p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--detail-out', detail] + list(args), env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+        assert p.returncode == 0, p.stderr[-3000:]
+        lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+        assert len(lines) == 1, p.stdout                      # exactly ONE line on stdout
+        assert len(lines[0]) < LINE_BUDGET, len(lines[0])     # ... that the driver's capture holds whole
+        out = json.loads(lines[0])
+        out['_detail'] = json.load(open(detail))
+        assert 'BENCH_DETAIL ' in p.stderr                    # the full record also goes to stderr
+    finally:
+        os.remove(detail)
+    return out
 
 
 def test_bench_two_ranks_self_launched_infer():
@@ -39,15 +53,25 @@ def test_bench_two_ranks_self_launched_infer():
     assert np.isfinite(two['loss']) and two['roofline']['all_conv_launches_tflops'] > 0
     # the line says what its process group was, from every rank
     c = two['collectives']
-    assert c['world'] == 2 and c['ranks_seen'] == [0, 1] and c['backend'] == 'gloo' and c['all_reduce_of_ones'] == 2.0
-    assert [d['rank'] for d in c['devices']] == [0, 1] and c['devices'][0]['pid'] != c['devices'][1]['pid']
-    assert one['collectives']['world'] == 1 and one['collectives']['ranks_seen'] == [0]
+    assert c['world'] == 2 and c['ranks_seen'] == 2 and c['backend'] == 'gloo' and c['all_reduce_of_ones'] == 2.0 and len(c['devices']) == 2
+    cd = two['_detail']['collectives']
+    assert cd['ranks_seen'] == [0, 1] and [d['rank'] for d in cd['devices']] == [0, 1] and cd['devices'][0]['pid'] != cd['devices'][1]['pid']
+    assert one['collectives']['world'] == 1 and one['collectives']['ranks_seen'] == 1
     # ... and where the step's device time went, phase by phase (HIP events), from every rank: the collectives' own brackets
-    pp = c['per_phase_ms']
+    pp = cd['per_phase_ms']
     for name in ('preprocess', 'encoders_forward', 'overhead_all_gather', 'slab_match', 'diagonal_all_gather', 'loss_partial_all_reduce'):
         assert pp['rank0'][name] > 0 and pp['max_over_ranks'][name] >= pp['rank0'][name], (name, pp)
+        assert c['per_phase_ms_max_over_ranks'][name] == pp['max_over_ranks'][name]
     assert sum(pp['rank0'].values()) <= 1.05 * pp['ms_per_step'] + 0.5          # phases are disjoint parts of the step
-    assert set(one['collectives']['per_phase_ms']['rank0']) == set(pp['rank0'])
+    assert set(one['_detail']['collectives']['per_phase_ms']['rank0']) == set(pp['rank0'])
+    # ... and the comms roofline: the step's three payloads timed standalone against the xGMI bound (plumbing rehearsed over gloo)
+    mb = c['microbench']
+    assert mb['all_gather_overhead_embeddings']['bytes'] == 8 * 4096 * 4 and mb['reduce_scatter_overhead_grads']['bytes'] == 2 * 8 * 4096 * 4
+    assert mb['all_reduce_weight_grads_one_encoder']['bytes'] == 7236432 * 4 and mb['all_reduce_weight_grads_one_encoder']['per_step'] == 2
+    for name in ('all_gather_overhead_embeddings', 'reduce_scatter_overhead_grads', 'all_reduce_weight_grads_one_encoder'):
+        m = mb[name]
+        assert m['us'] > 0 and m['algbw_GBps'] > 0 and 0 < m['frac_of_direct_bound'] < 1.0 and m['xgmi_ring_bound_us'] >= m['xgmi_direct_bound_us']
+    assert 'microbench' not in one['collectives']
     # ... and which register-allocation guards were active (none may have tripped on the validated toolchain)
     for line in (one, two):
         g = line['guards']
@@ -81,7 +105,11 @@ def test_bench_two_ranks_self_launched_train_and_retrieval():
     tr = _run_bench('--gpus', '2', '--backend', 'gloo', '--single-device', '--mode', 'train', '--steps', '1', '--warmup', '1',
                     '--batch', '8')
     assert tr['n_gpus'] == 2 and 'training step' in tr['metric'] and np.isfinite(tr['loss'])
-    pp = tr['collectives']['per_phase_ms']
+    pp = tr['_detail']['collectives']['per_phase_ms']
+    mb = tr['collectives']['microbench']
+    stall = pp['max_over_ranks']['reducer_wait_stall']
+    assert abs(mb['overlap_hidden_ms'] - (pp['rank0']['grad_bucket0_all_reduce_issue_to_joined'] + pp['rank0']['grad_bucket1_all_reduce_issue_to_joined']
+                                          - pp['rank0']['reducer_wait_stall'])) < 1e-3 and stall > 0
     for name in ('encoders_forward', 'overhead_all_gather', 'slab_match', 'diagonal_all_gather', 'loss_partial_all_reduce',
                  'backward_incl_its_collectives', 'row_sigmoid_all_reduce', 'slab_match_backward', 'overhead_grad_reduce_scatter',
                  'grad_bucket0_all_reduce_issue_to_joined', 'grad_bucket1_all_reduce_issue_to_joined', 'reducer_wait_stall', 'adam'):

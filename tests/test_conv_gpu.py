@@ -192,3 +192,36 @@ def test_first_layer_persistent_kernel_equals_the_tile_per_workgroup_kernel(case
     sel = [0, B // 2, B - 1]
     ref = O.conv3x3(torch.from_numpy(x[sel]), torch.from_numpy(w), torch.from_numpy(b), 1, circ).clamp_min(0)
     np.testing.assert_allclose(y[sel].cpu().permute(0, 3, 1, 2).numpy(), ref.numpy(), rtol=0, atol=2e-5 * float(ref.abs().max()))
+
+
+@pytest.mark.parametrize('C', [1, 2, 3])
+def test_first_layer_missing_planes_read_zeros_not_the_next_image(C):
+    """the persistent first-layer kernels load plane ch of a pixel with the plane offset in the buffer load's
+    soffset, which the hardware range check does not see; for C < 4 (C < CW in the fused bf16 kernel) the planes ch >= C of image b
+    therefore ALIASED planes of image b + 1 -- finite data times zero weights, invisible to every bitwise test, NaN as soon as the
+    neighbour holds a NaN / Inf. Poison every image but the first: image 0's output must stay finite and equal, bit for bit, what it
+    gives when launched alone (the tile-per-workgroup kernel, which guards ch < C)."""
+    from witw_amd import ops
+    B, H, W = 16, 64, 512
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    assert B * (W // 64) * (H // 8) >= 4 * n_cu
+    g = np.random.Generator(np.random.Philox(key=[11, C]))
+    x = g.standard_normal((B, C, H, W), dtype=np.float32)
+    x[1:] = np.nan
+    w = (g.standard_normal((64, C, 3, 3), dtype=np.float32) * 0.3).astype(np.float32)
+    b = (g.standard_normal((64,), dtype=np.float32) * 0.2).astype(np.float32)
+    dev = torch.device('cuda:0')
+    xd = torch.from_numpy(x).to(dev)
+    pk = ops.PackedFirstConv(torch.from_numpy(w).to(dev), torch.from_numpy(b).to(dev))
+    y = ops.conv3x3_first_fwd(xd, pk, circular=True)
+    assert 'persist' in ops.last_kernel_variant(), ops.last_kernel_variant()
+    alone = ops.conv3x3_first_fwd(xd[:1].contiguous(), pk, circular=True)
+    assert bool(torch.isfinite(y[0]).all()) and torch.equal(y[0], alone[0])
+    # the fused layers 0 + 2 of the bf16 path (conv_first2_bf16_kernel, CW = 4 planes per pixel for C <= 4)
+    w2 = (g.standard_normal((64, 64, 3, 3), dtype=np.float32) * 0.05).astype(np.float32)
+    b2 = (g.standard_normal((64,), dtype=np.float32) * 0.1).astype(np.float32)
+    pkb = ops.PackedFirstConv(torch.from_numpy(w).to(dev), torch.from_numpy(b).to(dev), bf16=True)
+    pk2 = ops.PackedConvBf16(torch.from_numpy(w2).to(dev), torch.from_numpy(b2).to(dev))
+    yf = ops.conv_first2_bf16(xd, pkb, pk2, circular=True)
+    yf_alone = ops.conv_first2_bf16(xd[:1].contiguous(), pkb, pk2, circular=True)
+    assert bool(torch.isfinite(yf[0].float()).all()) and torch.equal(yf[0], yf_alone[0])

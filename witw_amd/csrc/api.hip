@@ -1,6 +1,7 @@
 // C-ABI plumbing shared by every entry point: thread-local error text, version, device probe.
 #include "common.h"
 #include <string.h>
+#include <atomic>
 
 static thread_local char g_err[512] = "";
 
@@ -20,16 +21,22 @@ void witw_note_variant(const char* fmt, ...) {
     va_end(ap);
 }
 
-// Compute units of the current device (256 on MI355X), looked up once; 256 when the query fails.
+// Compute units of the CURRENT device (256 on MI355X), looked up once PER DEVICE (a process may drive several: the
+// --single-device rehearsals, mixed parts); 256 when the query fails. The cache slots are relaxed atomics: two threads that
+// race on a slot both store the same value.
 int witw_cu_count() {
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-                   ? prop.multiProcessorCount : 256;
+    constexpr int MAXDEV = 64;
+    static std::atomic<int> cache[MAXDEV];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) return 256;
+    if (dev < MAXDEV) {
+        const int hit = cache[dev].load(std::memory_order_relaxed);
+        if (hit > 0) return hit;
     }
-    return n_cu;
+    hipDeviceProp_t prop;
+    const int n = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    if (dev < MAXDEV) cache[dev].store(n, std::memory_order_relaxed);
+    return n;
 }
 
 // Does a grid of `workgroups` one-per-CU workgroups (the 8-wave conv tiles: 256 registers per wave, one workgroup per CU) use the

@@ -92,6 +92,9 @@ __device__ __forceinline__ void wres_wave_sync() {      // one wave's LDS traffi
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 // global -> LDS, 16 B per lane, 1 KB of contiguous LDS per wave instruction at lds_addr (M0); out-of-range lanes write zeros
 __device__ __forceinline__ void wres_dma16(i32x4 rs, unsigned lds_addr, unsigned voff) {
+    // m0 is written here and is NOT on the clobber list: it is a reserved register for LLVM's AMDGPU back end (clang warns "clobber
+    // list contains reserved registers: m0 ... undefined behaviour" when it is listed), which keeps no value live in it across
+    // instructions and re-sets it right before each of its own uses (LDS-DMA builtins, movrel, sendmsg). ADVICE r04.
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
                  :
                  : "s"(lds_addr), "v"(voff), "s"(rs)
@@ -462,13 +465,7 @@ int witw_bf16_wres_launch(const void* x, const void* wpk, const float* bias, voi
     a.n_cb = Cout / 64;
     a.w_tn = Cout >= 128 ? 128 : 64;
     a.circ = pad_circular; a.relu = relu;
-    static int n_cu = 0;        // persistent workgroups, one per CU (150 KB of LDS each)
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-                   ? prop.multiProcessorCount : 256;
-    }
+    const int n_cu = witw_cu_count();        // persistent workgroups, one per CU (150 KB of LDS each)
     int q = n_cu / (8 * a.n_cb);
     if (q < 1) q = 1;
     a.q_per_xcd = q;
@@ -493,8 +490,8 @@ int witw_bf16_wres_launch(const void* x, const void* wpk, const float* bias, voi
 
 extern "C" {
 
-// 1 (default): 64-input-channel plain bf16 forwards with H % 8 == 0, W % 32 == 0, Cout % 64 == 0 and at least 4096 (tile, channel
-// block) units run on the weight-resident kernel; 0: on the tiled kernels. enable < 0 only queries. Returns the previous setting.
+// 1 (default): 64-input-channel plain bf16 forwards with H % WTH == 0, W % WTW == 0, Cout % 64 == 0 and at least 8192 (team tile,
+// channel block) units (witw_bf16_wres_applies) run on the weight-resident kernel; 0: on the tiled kernels. enable < 0 only queries. Returns the previous setting.
 // The results are bit-identical to the 32x32x16 tiled kernel's.
 int witw_conv3x3_bf16_wres(int enable) {
     const int prev = wres_enabled();

@@ -203,13 +203,7 @@ int witw_conv4x4s2_first_fwd(const float* x, const float* w, const float* bias, 
     const long long n_tiles = (long long)B * a.tiles_x * a.tiles_y;
     WITW_CHECK_ARG(n_tiles < 0x7fffffffLL, "conv4x4s2_first: too many tiles");
     a.n_tiles = (int)n_tiles;
-    static int n_cu = 0;        // persistent workgroups, a few per CU (28-35 KB of LDS, ~100 registers each)
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-                   ? prop.multiProcessorCount : 256;
-    }
+    const int n_cu = witw_cu_count();        // persistent workgroups, a few per CU (28-35 KB of LDS, ~100 registers each)
     const long long grid = n_tiles < 4LL * n_cu ? n_tiles : 4LL * n_cu;
     hipStream_t st = (hipStream_t)stream;
     switch (C) {

@@ -218,8 +218,10 @@ __global__ __launch_bounds__(FT, 2) void conv3x3_first_persist_kernel(FirstArgs 
             }
             const unsigned off = ok ? (unsigned)(gr * p.W + gc) * 4u : OOR;
 #pragma unroll
-            for (int ch = 0; ch < 4; ++ch)       // plane ch; ch >= C lies behind the descriptor's end
-                rv[k][ch] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, (unsigned)ch * (unsigned)plane * 4u, 0));
+            for (int ch = 0; ch < 4; ++ch)       // plane ch rides in soffset, which the range check does NOT cover (it sees voffset only):
+                // a missing plane (ch >= C, wave-uniform) is made out of range through the voffset, so that it reads zeros, not the next image
+                rv[k][ch] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, ch < p.C ? off : OOR,
+                                                                                           (unsigned)ch * (unsigned)plane * 4u, 0));
         }
     };
     auto to_lds = [&](int buf) {
@@ -509,15 +511,20 @@ int witw_conv3x3_first_fwd(const float* x, const float* wf, const float* bias, v
     a.circ = pad_circular; a.relu = relu; a.out_bf16 = out_bf16;
     const long long grid = (long long)B * a.tiles_x * a.tiles_y;
     WITW_CHECK_ARG(grid <= 0x7fffffffLL, "conv3x3_first_fwd: grid too large");
-    if (out_bf16 == 1 && C > 4)
+    if (out_bf16 == 1 && C > 4) {
         hipLaunchKernelGGL(conv3x3_first_bf16_kernel<8>, dim3((unsigned)grid), dim3(FT), 0, (hipStream_t)stream, a);
-    else if (out_bf16 == 1)
+        witw_note_variant("conv3x3_first_bf16_kernel<8>");
+    } else if (out_bf16 == 1) {
         hipLaunchKernelGGL(conv3x3_first_bf16_kernel<4>, dim3((unsigned)grid), dim3(FT), 0, (hipStream_t)stream, a);
-    else if (out_bf16 == 0 && W >= 66 && (unsigned long long)C * H * W * 4 < 0x80000000ull && grid >= 4LL * witw_cu_count() && first_persistent()) {
+        witw_note_variant("conv3x3_first_bf16_kernel<4>");
+    } else if (out_bf16 == 0 && W >= 66 && (unsigned long long)C * H * W * 4 < 0x80000000ull && grid >= 4LL * witw_cu_count() && first_persistent()) {
         const unsigned g2 = 2u * (unsigned)witw_cu_count();      // two persistent workgroups per CU
         hipLaunchKernelGGL(conv3x3_first_persist_kernel, dim3(g2), dim3(FT), 0, (hipStream_t)stream, a);
-    } else
+        witw_note_variant("conv3x3_first_persist_kernel");
+    } else {
         hipLaunchKernelGGL(conv3x3_first_kernel, dim3((unsigned)grid), dim3(FT), 0, (hipStream_t)stream, a);
+        witw_note_variant("conv3x3_first_kernel");
+    }
     WITW_CHECK_LAUNCH("conv3x3_first_fwd");
     return WITW_OK;
 }

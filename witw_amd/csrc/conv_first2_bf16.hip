@@ -118,8 +118,10 @@ __global__ __launch_bounds__(F2T, 1) void conv_first2_bf16_kernel(First2Args p) 
             }
             const unsigned off = ok ? (unsigned)(gr * p.W + gc) * 4u : OOR;
 #pragma unroll
-            for (int ch = 0; ch < CW; ++ch)       // plane ch of the image; ch >= C lies behind the descriptor's end
-                rv[k][ch] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, (unsigned)ch * (unsigned)plane * 4u, 0));
+            for (int ch = 0; ch < CW; ++ch)       // plane ch rides in soffset, which the range check does NOT cover (it sees voffset only):
+                // a missing plane (ch >= C, wave-uniform) is made out of range through the voffset, so that it reads zeros, not the next image
+                rv[k][ch] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, ch < p.C ? off : OOR,
+                                                                                           (unsigned)ch * (unsigned)plane * 4u, 0));
         }
     };
     auto raw_to_lds = [&]() {                       // phase A: this thread's raw pixel -> LDS as bf16
@@ -329,13 +331,7 @@ int witw_conv_first2_bf16_fwd(const float* x, const void* wf0, const float* bias
     WITW_CHECK_ARG(n_tiles < 0x7fffffffLL && (unsigned long long)C * H * W * 4 < 0x80000000ull, "conv_first2_bf16: tensor too large");
     a.n_tiles = (int)n_tiles;
     a.circ = pad_circular;
-    static int n_cu = 0;        // persistent workgroups, one per CU (150 KB of LDS each)
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-        if (n_cu <= 0) n_cu = 256;
-    }
+    const int n_cu = witw_cu_count();        // persistent workgroups, one per CU (150 KB of LDS each)
     const unsigned grid = (unsigned)(a.n_tiles < n_cu ? a.n_tiles : n_cu);
     const bool rec = getenv("WITW_F2_STAMPS") != nullptr && a.n_tiles >= 3 * (int)grid;      // diagnostic, synchronous
     if (rec && C > 4)

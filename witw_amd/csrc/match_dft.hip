@@ -425,13 +425,7 @@ static int match_fwd_dft_launch(const float* ov, const float* su, const float* s
     a.orientation = orientation; a.distance = distance; a.score = score; a.gap = gap;
     a.Bo = Bo; a.Bs = Bs; a.nbx = cdiv(Bs, 32); a.nby = cdiv(Bo, 32);
     const long long tiles = (long long)a.nbx * a.nby;
-    static int n_cu = 0;        // persistent workgroups, one per CU
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-        if (n_cu <= 0) n_cu = 256;
-    }
+    const int n_cu = witw_cu_count();        // persistent workgroups, one per CU
     const unsigned grid = (unsigned)(tiles < n_cu ? tiles : n_cu);
     // WITW_DFT_STAMPS=1 (diagnostic, synchronous): the first workgroups record s_memrealtime around the phases of their second
     // tile; printed to stderr

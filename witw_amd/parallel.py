@@ -33,20 +33,29 @@ class PhaseTimer:
     the communication stream, so the bracket holds the collective plus its two stream hand-overs; for the asynchronous gradient
     all-reduce the bracket runs from the launch to the point where wait() has joined it (an upper bound of the collective's own
     duration: the other encoder's backward kernels run inside it) and `reducer_wait_stall` is what the compute stream really
-    loses. Off (PHASES is None) everywhere but in bench.py; CPU tensors (the gloo tests of the host logic) never record."""
+    loses. Off (PHASES is None) everywhere but in bench.py. Every event of one timer is recorded on ONE stream -- the stream
+    that was current when the timer was made -- whichever thread calls begin() / end() (an autograd hook thread's current stream
+    need not be the step's; elapsed_time across streams means nothing). A timer made in a process that has no initialised GPU
+    (the gloo tests of the host logic) is disabled: begin() returns None, nothing touches the device."""
 
     def __init__(self):
         self.rec = {}          # name -> [(start event, end event)]
         self.order = []
+        self.enabled = torch.cuda.is_available() and torch.cuda.is_initialized()
+        self.stream = torch.cuda.current_stream() if self.enabled else None
 
     def begin(self):
+        if not self.enabled:
+            return None
         e = torch.cuda.Event(enable_timing=True)
-        e.record()
+        e.record(self.stream)
         return e
 
     def end(self, name, e0):
+        if e0 is None or not self.enabled:
+            return
         e1 = torch.cuda.Event(enable_timing=True)
-        e1.record()
+        e1.record(self.stream)
         if name not in self.rec:
             self.rec[name] = []
             self.order.append(name)
