@@ -386,6 +386,9 @@ def main():
     ap.add_argument('--decode', choices=['device', 'host'], default='device',
                     help="e2e: 'device' = DataLoader workers entropy-decode the JPEG files, the GPU does dequantisation / IDCT / upsampling / "
                          "colour conversion (byte-identical to Pillow); 'host' = Pillow in the workers (the reference's arrangement)")
+    ap.add_argument('--e2e-dir', default=None, help='e2e: directory of the synthetic JPEG data set (kept; files already there are reused)')
+    ap.add_argument('--no-decode-scaling', action='store_true', help='e2e: skip the host entropy-decode scaling sweep')
+    ap.add_argument('--decode-scaling-seconds', type=float, default=1.0)
     ap.add_argument('--no-ring', action='store_true', help='e2e: torch DataLoader staging (shared-memory pickling + pin_memory thread) instead of ring.PinnedRing')
     ap.add_argument('--workers', type=int, default=12, help='e2e: DataLoader workers (reference: 12, model/cvig_fov.py:402)')
     a = ap.parse_args()
@@ -560,8 +563,15 @@ def side_blocks(a, rank, world, device, cvig_fov, ops):
     # The data-path blocks run as CHILD processes (`bench.py --mode e2e ...`): 16 loader workers forked from a process that has built
     # every other block measured a fifth slower with every stage on its own unchanged; a driver's train() / test() is a fresh process.
     # fp32 encoders: the GPU is the limiting stage; bf16 encoders (configs[3] arithmetic) need 8x the images per second
-    guarded('e2e_data_path', lambda: e2e(['--e2e-pairs', '2048']))
-    guarded('e2e_data_path_bf16', lambda: e2e(['--e2e-pairs', '8192', '--workers', '16', '--precision', 'bf16']))
+    import shutil
+    import tempfile
+    jpegs = tempfile.mkdtemp(prefix='witw_e2e_')          # ONE synthetic data set for both blocks; the host-decode scaling sweep once
+    try:
+        guarded('e2e_data_path', lambda: e2e(['--e2e-pairs', '2048', '--e2e-dir', jpegs, '--no-decode-scaling']))
+        guarded('e2e_data_path_bf16', lambda: e2e(['--e2e-pairs', '8192', '--workers', '16', '--precision', 'bf16', '--e2e-dir', jpegs,
+                                                   '--decode-scaling-seconds', '0.5']))
+    finally:
+        shutil.rmtree(jpegs, ignore_errors=True)
     if cpu_leg[0] is not None:
         try:
             cpu_leg[0]()                         # fills config1_baseline's cpu_baseline + parity in place
@@ -1154,12 +1164,12 @@ def cpu_baseline(a, g, o, wts, semantic):
 
 
 def cpu_thread_sweep(fn, units, sample):
-    """ONE convention for every cpu_baseline of the line: the CPU port is timed at 16 threads (this box's CPU share per GPU; the
-    survey container had 8) and at every core torch sees; `value` is the better of the two, `cores` the
-    threads it used, both are listed. One warm-up call (at 16 threads), then ONE timed call per thread count: three passes over
-    the sample in all (rounds 3-4 made seven; the sample is sized so that the three stay within ~15 s)."""
+    """ONE convention for every cpu_baseline of the line: the CPU port is timed at 16 threads -- this box's CPU share per GPU (or every
+    core torch sees, if fewer; the survey container had 8). Rounds 2-5 also timed 8 threads and all 128: 16
+    won every time (r04: 5.7 / 7.5 / 3.6 pairs/s at 8 / 16 / 128; r05: 6.8 / 2.4 at 16 / 128 -- oversubscribed oneDNN convolutions),
+    so the other counts only cost the default run ~25 s. One warm-up call, then ONE timed call: ~10 s of CPU work on 32 pairs."""
     all_threads = torch.get_num_threads()
-    counts = sorted({min(16, all_threads), all_threads})
+    counts = [min(16, all_threads)]
     by_threads = {}
     torch.set_num_threads(counts[0])
     fn()
@@ -1172,7 +1182,7 @@ def cpu_thread_sweep(fn, units, sample):
     best = max(by_threads, key=lambda t: by_threads[t])
     return {'value': by_threads[best], 'unit': 'pairs/s', 'cores': best, 'kind': 'port', 'cpu': cpu_model(),
             'pairs_per_s_by_threads': {str(t): v for t, v in by_threads.items()},
-            'threads_convention': '16 and all (%d) threads; best reported' % all_threads,
+            'threads_convention': '%d threads (CPU share of one GPU on this box; %d visible)' % (counts[0], all_threads),
             'sample': sample + '; 1 warm-up + 1 timed pass per thread count, torch %s CPU ops (oneDNN / BLAS as built)' % torch.__version__}
 
 

@@ -271,6 +271,13 @@ int witw_nhwc_bf16_to_octet(const void* x_bf16, void* y_bf16, int B, int H, int 
 long long witw_conv3x3_wgrad_bf16_workspace_floats(int B, int H, int W, int Cin, int Cout, int stride_h);
 int witw_conv3x3_wgrad_bf16(const void* x_oct, const void* dz_oct, float* dw, float* db, float* workspace, int B, int H, int W,
                             int Cin, int cin_real, int Cout, int stride_h, int pad_circular, int accumulate, void* stream);
+/* Round 5: the same gradient straight from the NHWC bf16 tensors the forward / dgrad launches write (x [B][H][W][Cin], dz
+ * [B][Ho][W][Cout]) -- no re-layout pass: the MFMA's k index is the pixel, the [pixel][channel] LDS image is transposed on the
+ * way out by ds_read_b64_tr_b16 (replaces autograd through torch.nn.Conv2d in model/cvig_fov.py:447-460 like the entry above,
+ * and is what the bf16 training step now calls). Workspace of witw_conv3x3_wgrad_bf16_nhwc_workspace_floats floats. */
+long long witw_conv3x3_wgrad_bf16_nhwc_workspace_floats(int B, int H, int W, int Cin, int Cout, int stride_h);
+int witw_conv3x3_wgrad_bf16_nhwc(const void* x_nhwc, const void* dz_nhwc, float* dw, float* db, float* workspace, int B, int H, int W,
+                                 int Cin, int cin_real, int Cout, int stride_h, int pad_circular, int accumulate, void* stream);
 
 /* ---- 2x2 sub-window form of the 3x3 kernels: cvig_baseline's Conv2d(k=4,s=2,p=0) (model/cvig_baseline.py:236-252) is a
  * 2x2 convolution over the space-to-depth(2) image, i.e. a 3x3 window whose first tap row/column are zero (dgrad: last

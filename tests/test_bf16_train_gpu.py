@@ -34,11 +34,20 @@ WGRAD_CASES = [  # B, H, W, Cin, Cout, stride_h, circ
     (8, 8, 24, 72, 64, 2, False),        # stride (2,1), second ci tile mostly out of range
     (3, 7, 20, 16, 256, 2, True),        # odd height under stride 2, two co tiles
     (9, 5, 9, 128, 64, 1, False),        # odd width
+    (4, 16, 64, 256, 512, 1, True),      # layer 17's shape (16 tiles); two row groups of 8, four column segments, circular wrap
+    (2, 16, 64, 512, 256, 2, False),     # layer 23 (stride (2,1)): halo rows 2r .. 2r + 2, row groups of 4
+    (5, 19, 37, 40, 24, 1, True),        # nothing divides: 3 row groups (one ragged), 3 column segments (one ragged), partial tiles
+    (2, 32, 48, 8, 64, 1, False),        # 8 input channels (one 16-byte chunk per pixel): cvig_semantic's layer 0 is 5 -> padded
+    (3, 9, 16, 64, 64, 2, True),         # W == one column segment: both circular wraps inside one stage
 ]
 
 
+@pytest.mark.parametrize('layout', ['nhwc', 'octet'])
 @pytest.mark.parametrize('case', WGRAD_CASES)
-def test_wgrad_bf16_matches_autograd(case):
+def test_wgrad_bf16_matches_autograd(case, layout):
+    """Both bf16 weight-gradient kernels -- round 5's NHWC-direct one (pixels as the MFMA's k index, ds_read_b64_tr_b16; the one
+    the training step calls) and round 1's batch-octet one -- against CPU autograd through the oracle's conv on bf16-exact operands
+    (model/cvig_fov.py:447-460: autograd through torch.nn.Conv2d)."""
     from witw_amd import ops
     B, H, W, Cin, Cout, sh, circ = case
     x = _rand_bf16(1, (B, Cin, H, W))
@@ -53,13 +62,19 @@ def test_wgrad_bf16_matches_autograd(case):
     assert oct_.shape == ((B + 7) // 8, H, W, Cin, 8)
     back = oct_.permute(0, 4, 1, 2, 3).reshape(-1, H, W, Cin)          # [B8*8,H,W,C]
     assert torch.equal(back[:B], xd) and float(back[B:].float().abs().max() if back.shape[0] > B else 0.) == 0.
-    dw, db = ops.conv3x3_wgrad_bf16(xd, gyd, Cin, stride_h=sh, circular=circ)
+    dw, db = ops.conv3x3_wgrad_bf16(xd, gyd, Cin, stride_h=sh, circular=circ, layout=layout)
+    if layout == 'nhwc':
+        assert ops.last_kernel_variant() == 'conv3x3_wgrad_bf16_nhwc_kernel<%d,%d>' % (sh, 8 if sh == 1 else 4), ops.last_kernel_variant()
     assert dw.dtype == torch.float32 and dw.shape == (Cout, Cin, 3, 3)
     np.testing.assert_allclose(dw.cpu().numpy(), w.grad.numpy(), rtol=0, atol=2e-5 * max(1.0, float(w.grad.abs().max())))
     np.testing.assert_allclose(db.cpu().numpy(), b.grad.numpy(), rtol=0, atol=2e-5 * max(1.0, float(b.grad.abs().max())))
     # bitwise reproducible (fixed-order split-K reduction)
-    dw2, db2 = ops.conv3x3_wgrad_bf16(xd, gyd, Cin, stride_h=sh, circular=circ)
+    dw2, db2 = ops.conv3x3_wgrad_bf16(xd, gyd, Cin, stride_h=sh, circular=circ, layout=layout)
     assert torch.equal(dw, dw2) and torch.equal(db, db2)
+    # cin_real < Cin (a channel-padded input, as layer 0 of cvig_semantic: 5 of 16): the padded channels are dropped
+    if Cin >= 16:
+        dwp, _ = ops.conv3x3_wgrad_bf16(xd, gyd, Cin - 3, stride_h=sh, circular=circ, layout=layout, want_bias=False)
+        assert dwp.shape == (Cout, Cin - 3, 3, 3) and torch.equal(dwp, dw[:, :Cin - 3])
 
 
 DGRAD_CASES = [  # B, H (layer input rows), W, Cin, Cout, stride_h, circ

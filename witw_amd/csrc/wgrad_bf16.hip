@@ -289,6 +289,258 @@ __global__ void nhwc_to_octet_kernel(const unsigned short* __restrict__ x, unsig
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Round 5: the same weight gradient straight from the NHWC tensors the forward / dgrad kernels write -- no batch-octet copies
+// (nhwc_to_octet_kernel was 1.05 ms of the 15.0 ms bf16 training step, 2.5 ms of cvig_semantic's 29 ms; profiles/r05_*).
+//
+// The contraction index k of the MFMA is now the PIXEL: one k-step = 16 consecutive output columns of one row of one image
+// (lanes 0-31 take columns 0-7, lanes 32-63 columns 8-15). In NHWC a lane's 8 k values are 8 pixels = 8 far-apart 2-byte
+// elements; gfx950's ds_read_b64_tr_b16 does that transpose on the way out of the LDS: a group of 16 lanes reads a block of
+// 4 rows (pixels) x 16 columns (channels) and each lane receives one channel of the 4 pixels. Two such reads are one MFMA
+// operand. The LDS images are plain [pixel][channel] rows (X: 64 ci = 128 B per pixel, pitch XP = 24 pixels per halo row;
+// dZ: 128 co = 256 B per pixel), filled by LDS-DMA in 16-byte chunks. A DMA lane may fetch ANY global chunk, so the bank
+// swizzle costs nothing: LDS chunk position c of pixel p holds channel chunk c ^ (bit 1 of p << 2) (X) / c ^ ((p & 3) << 2)
+// (dZ), which makes every transposed read conflict-free (4 consecutive pixels x 64 B land on 64 distinct banks).
+// A filter tap is a pixel offset of the X read, as before. One stage = one image x R output rows x 16 columns: its
+// ((R-1)*SH+3) x 18 halo pixels of X and R x 16 pixels of dZ; zero padding / ragged edges = out-of-range DMA lanes (zeros).
+// Workgroup tile, wave roles, split-K workspace and the fixed-order reduction are those of the octet kernel above. The
+// workgroup -> (tile, split) map is XCD-aware: all tiles of one split share an XCD (blocks b and b + 8 do), so the X and dZ
+// slices a split streams are fetched from HBM once and re-used out of that XCD's L2 by the other ci / co tiles (the (x, y, z)
+// grid of the octet kernel put one ci tile per XCD: every XCD streamed all of dZ).
+struct WgradNhArgs {
+    const unsigned short* x;    // [B][H][W][Cin]    bf16 NHWC
+    const unsigned short* dz;   // [B][Ho][Wo][Cout] bf16 NHWC
+    float* ws;                  // [splits][9][Cin][Cout]
+    float* bias_part;           // nullptr, or [splits][Cout]
+    int B, H, W, Cin, Cout, Ho, Wo;
+    int circ;
+    int nseg, nrg, chunks, cps;
+    int tiles_ci, tiles_co, splits;
+};
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+constexpr int NH_P = 16;                // output columns per k-step
+constexpr int NH_XP = 24;               // pixel pitch of a halo row in the LDS (18 used: 3 DMA instructions of 8 pixels per row)
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {      // s_waitcnt vmcnt(N) only (expcnt / lgkmcnt left alone); N <= 63
+    __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | 0x0F70);
+}
+
+template <int SH, int R, int NS>
+__global__ __launch_bounds__(512) void conv3x3_wgrad_bf16_nhwc_kernel(WgradNhArgs p) {
+    constexpr int NW = 8;
+    constexpr int XR = (R - 1) * SH + 3;              // halo rows
+    constexpr int NXI = XR * 3;                       // X DMA instructions per stage (8 pixels x 128 B each)
+    constexpr int NZI = R * 4;                        // dZ DMA instructions per stage (4 pixels x 256 B each)
+    constexpr int X_B = NXI * 1024, Z_B = NZI * 1024; // bytes
+    constexpr int STAGE_B = X_B + Z_B;
+    static_assert(NS >= 2 && NS * STAGE_B <= 160 * 1024, "the stage ring must fit the LDS");
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[NS * STAGE_B];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6) & (NW - 1);
+    const int l31 = lane & 31, kg = lane >> 5;
+    const int wm = wave_u & 1, wn = wave_u >> 1;
+    // XCD-aware map: physical block b runs on XCD b % 8 (observed round-robin; speed only). Logical ids are dealt so that each XCD
+    // gets a CONTIGUOUS range of them, and logical id = split * tiles + tile: the tiles of a split share an XCD.
+    const int tiles = p.tiles_ci * p.tiles_co;
+    const int nblk = tiles * p.splits;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int logical = xcd * (nblk >> 3) + min(xcd, nblk & 7) + slot;
+    const int split = logical / tiles, tile = logical - split * tiles;
+    const int ci0 = (tile % p.tiles_ci) * WB_TM, co0 = (tile / p.tiles_ci) * WB_TN;
+    const int c_begin = split * p.cps;
+    const int c_end = min(p.chunks, c_begin + p.cps);
+
+    const i32x4 x_rs = raw_rsrc(p.x, (unsigned)((size_t)p.B * p.H * p.W * p.Cin * 2u));
+    const i32x4 z_rs = raw_rsrc(p.dz, (unsigned)((size_t)p.B * p.Ho * p.Wo * p.Cout * 2u));
+    // DMA lane roles. X instruction: 8 pixels x 8 chunks; lane -> pixel (lane >> 3) of the 8, LDS chunk position lane & 7, which
+    // holds channel chunk (lane & 7) ^ (bit 1 of the pixel's column index << 2); the column index of instruction part q is
+    // 8 q + (lane >> 3), whose bit 1 is that of (lane >> 3).
+    const int xpx = lane >> 3;
+    const int xchunk = (lane & 7) ^ (((xpx >> 1) & 1) << 2);
+    const bool x_ci_ok = ci0 + xchunk * 8 < p.Cin;
+    const unsigned x_lane_b = (unsigned)(ci0 + xchunk * 8) * 2u;
+    // dZ instruction: 4 pixels x 16 chunks; lane -> pixel (lane >> 4), LDS chunk position lane & 15 holding chunk ^ ((pixel & 3) << 2)
+    const int zpx = lane >> 4;
+    const int zchunk = (lane & 15) ^ (zpx << 2);
+    const bool z_co_ok = co0 + zchunk * 8 < p.Cout;
+    const unsigned z_lane_b = (unsigned)(zpx * p.Cout + co0 + zchunk * 8) * 2u;
+
+    auto stage = [&](int c, int buf) {
+        const unsigned base = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_address(lds)) + (unsigned)buf * STAGE_B;
+        const int seg = c % p.nseg;
+        const int t = c / p.nseg;
+        const int rg = t % p.nrg, b = t / p.nrg;
+        const int h0 = rg * R, w0 = seg * NH_P;
+#pragma unroll
+        for (int i = 0; i < (NXI + NW - 1) / NW; ++i) {
+            const int j = wave_u + NW * i;                       // wave-uniform
+            if (NXI % NW == 0 || j < NXI) {
+                const int r = j / 3, part = j - r * 3;
+                const int gr = h0 * SH - 1 + r;
+                const int col = part * 8 + xpx;                  // 0..23 (18 used)
+                int gc = w0 - 1 + col;
+                if (p.circ) {                                    // only columns -1 and W wrap; columns past W pair with zero dZ pixels
+                    if (gc < 0) gc += p.W;
+                    else if (gc == p.W) gc = 0;
+                }
+                const bool ok = x_ci_ok && col < NH_P + 2 && gc >= 0 && gc < p.W && gr >= 0 && gr < p.H;
+                const unsigned soff = (gr >= 0 && gr < p.H) ? (unsigned)(((size_t)b * p.H + gr) * p.W * p.Cin * 2u) : 0u;
+                dma16(x_rs, base + (unsigned)j * 1024u, ok ? (unsigned)(gc * p.Cin) * 2u + x_lane_b : OOR, soff);
+            }
+        }
+        static_assert(NZI % NW == 0 || NZI < NW, "dZ instructions split evenly over the waves");
+#pragma unroll
+        for (int i = 0; i < (NZI + NW - 1) / NW; ++i) {
+            const int j = wave_u + NW * i;
+            if (NZI % NW == 0 || j < NZI) {
+                const int r = j >> 2, c4 = (j & 3) * 4;
+                const int h = h0 + r, w = w0 + c4;               // this instruction's first pixel
+                const bool ok = z_co_ok && h < p.Ho && w + zpx < p.Wo;
+                const unsigned soff = (h < p.Ho && w < p.Wo) ? (unsigned)((((size_t)b * p.Ho + h) * p.Wo + w) * p.Cout * 2u) : 0u;
+                dma16(z_rs, base + (unsigned)(X_B + j * 1024), ok ? z_lane_b : OOR, soff);
+            }
+        }
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // transposed-read lane roles: group G = lane >> 4 (G & 1: channel half of the wave's 32, G >> 1 = kg: pixel half of the k-step),
+    // q = (lane >> 2) & 3: the pixel of the 4-row block whose address this lane supplies, pp = lane & 3: which 8 bytes of its 32
+    const int G = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    unsigned a_lane[3];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+        const int col = 8 * kg + q + kw;                                     // + 4 h per read half; bit 1 unaffected by 8 kg + 4 h
+        const int chunk = (4 * wm + 2 * (G & 1) + (pp >> 1)) ^ (((col >> 1) & 1) << 2);
+        a_lane[kw] = (unsigned)(col * 128 + chunk * 16 + 8 * (pp & 1));
+    }
+    const unsigned b_lane = (unsigned)(X_B + (8 * kg + q) * 256 + (((4 * wn + 2 * (G & 1) + (pp >> 1)) ^ (q << 2)) * 16) + 8 * (pp & 1));
+
+    const bool do_bias = p.bias_part != nullptr && ci0 == 0 && wm == 0;     // wave-uniform
+    f32x4 accb[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    u32x4 ones[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const unsigned v = ((lane & 15) == 0 && ((lane >> 4) & 1) == h) ? 0x3F803F80u : 0u;
+        ones[h] = (u32x4){v, v, v, v};
+    }
+
+    auto tr = [&](const unsigned char* sbase, unsigned off) -> s16x4 {
+        return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sbase + off));
+    };
+    auto frag = [&](const unsigned char* sbase, unsigned off) -> bf16x8 {       // 8 consecutive pixels of this lane's channel
+        const s16x4 lo = tr(sbase, off), hi = tr(sbase, off + 4 * 128);
+        return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    auto fragz = [&](const unsigned char* sbase, unsigned off) -> bf16x8 {
+        const s16x4 lo = tr(sbase, off), hi = tr(sbase, off + 4 * 256);
+        return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    // all MFMAs of one staged chunk: R k-steps (one per output row) x 9 taps. The X fragments of halo row j serve every output row
+    // whose window holds j (taps kh = j - r*SH): with SH = 1 an output row needs only ONE new halo row = 3 fragments (6 transposed
+    // reads) + its dZ fragment (2 reads) for 9 MFMAs, not 9 + 1 fragments. The unrolled loop names every halo row's fragments once
+    // (fx[j][kw]); those of the next output row are requested in front of the current row's MFMAs. Rows past Ho were staged as zeros
+    // (out-of-range DMA lanes) and are computed like the others.
+    auto compute = [&](int buf) {
+        const unsigned char* sb = lds + buf * STAGE_B;
+        bf16x8 fx[XR][3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) fx[j][kw] = frag(sb, a_lane[kw] + (unsigned)(j * NH_XP * 128));
+        bf16x8 fb = fragz(sb, b_lane);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            bf16x8 fbn = fb;
+            if (r + 1 < R) {
+                fbn = fragz(sb, b_lane + (unsigned)((r + 1) * NH_P * 256));
+#pragma unroll
+                for (int j = r * SH + 3; j < (r + 1) * SH + 3; ++j)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) fx[j][kw] = frag(sb, a_lane[kw] + (unsigned)(j * NH_XP * 128));
+            }
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fx[r * SH + t / 3][t % 3], fb, acc[t], 0, 0, 0);
+            if (do_bias) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    accb[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ones[h]), fb, accb[h], 0, 0, 0);
+            }
+            fb = fbn;
+        }
+    };
+
+    // Ring of NS stages, one barrier per chunk: chunk c + NS - 1 is requested into the buffer chunk c - 1 has just left, so a DMA
+    // has NS - 1 compute phases to land. This wave's own DMA instructions per stage: the waves share NXI and NZI unevenly.
+    constexpr int LO = NXI / NW + NZI / NW;                                  // instructions per stage of a wave ...
+    static_assert(NXI % NW == 0 || NZI % NW == 0, "at most one of the two instruction counts is uneven");
+    const bool extra = wave_u < NXI % NW || wave_u < NZI % NW;               // ... plus one for these waves
+    if (c_begin < c_end) {
+#pragma unroll
+        for (int s = 0; s < NS - 1; ++s)
+            if (c_begin + s < c_end) stage(c_begin + s, s);
+        int buf = 0;
+        for (int c = c_begin; c < c_end; ++c) {
+            // chunk c has landed when at most the NS - 2 younger stages' instructions of this wave are outstanding (in-order return)
+            if (NS > 2 && c + NS - 2 < c_end) {
+                if (extra) wait_vmcnt<(NS - 2) * (LO + 1)>();
+                else wait_vmcnt<(NS - 2) * LO>();
+            } else {
+                wait_vmcnt<0>();
+            }
+            __syncthreads();                         // ... everyone's has, and everyone is done reading chunk c - 1's buffer
+            if (c + NS - 1 < c_end) stage(c + NS - 1, buf == 0 ? NS - 1 : buf - 1);
+            compute(buf);
+            buf = buf + 1 == NS ? 0 : buf + 1;
+        }
+    }
+
+    // ---- partial tile -> workspace [split][tap][ci][co]
+    float* out = p.ws + (size_t)split * 9 * p.Cin * p.Cout;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int co = co0 + wn * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ci = ci0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+            if (ci < p.Cin && co < p.Cout) out[((size_t)t * p.Cin + ci) * p.Cout + co] = acc[t][r];
+        }
+    }
+    if (do_bias && lane < 16) {          // row 0 of the 16x16 results: lanes 0-15, register 0
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int co = co0 + wn * 32 + h * 16 + lane;
+            if (co < p.Cout) p.bias_part[(size_t)split * p.Cout + co] = accb[h][0];
+        }
+    }
+}
+
+// stage shape: R output rows per stage (8 rows x 16 columns of one image at stride 1: 8 k-steps = 72 MFMAs per wave between two
+// barriers; 4 at stride (2,1), whose halo is 9 rows). Two stages. Measured at the bench shapes (B = 128, layers 17-21, tools/
+// bench_wgrad_bf16.py, round 5): R = 4 with a ring of 3 or 4 stages was 7-9 % SLOWER than R = 8 with 2 (more barriers and halo
+// re-reads; the DMA latency is already covered by one 72-MFMA phase), so the ring stays generic in the kernel but only NS = 2
+// is instantiated.
+int wgrad_nh_rows(int stride_h) { return stride_h == 2 ? 4 : 8; }
+
+int wgrad_nh_splits(int B, int Ho, int Wo, int Cin, int Cout, int stride_h) {
+    const int tiles = cdiv(Cin, WB_TM) * cdiv(Cout, WB_TN);
+    const int chunks = B * cdiv(Ho, wgrad_nh_rows(stride_h)) * cdiv(Wo, NH_P);
+    int splits = cdiv(witw_cu_count(), tiles);       // one workgroup per CU; every extra split costs a 36*Cin*Cout-byte partial
+    if (splits > chunks) splits = chunks;
+    if (splits < 1) splits = 1;
+    return splits;
+}
+
 int wgrad_bf16_rows(int stride_h) { return stride_h == 2 ? 1 : 2; }
 
 int wgrad_bf16_splits(int B8, int Ho, int Wo, int Cin, int Cout, int stride_h) {
@@ -359,6 +611,54 @@ int witw_conv3x3_wgrad_bf16(const void* x_oct, const void* dz_oct, float* dw, fl
     hipLaunchKernelGGL(wgrad_bf16_reduce_kernel, dim3((unsigned)((n + Cout + 255) / 256)), dim3(256), 0, st, workspace, dw, Cin,
                        Cout, splits, accumulate, cin_real, a.bias_part, db);
     WITW_CHECK_LAUNCH("wgrad_bf16_reduce");
+    return WITW_OK;
+}
+
+
+long long witw_conv3x3_wgrad_bf16_nhwc_workspace_floats(int B, int H, int W, int Cin, int Cout, int stride_h) {
+    const int Ho = (H + 2 - 3) / stride_h + 1;
+    const long long splits = wgrad_nh_splits(B, Ho, W, Cin, Cout, stride_h);
+    return splits * 9 * Cin * Cout + splits * Cout;
+}
+
+// The same gradient from the NHWC tensors themselves: x [B][H][W][Cin], dz [B][Ho][W][Cout] bf16 (what the bf16 forward and
+// dgrad launches write) -- no re-layout pass. dw [Cout][cin_real][3][3] fp32, db [Cout] fp32 or NULL; workspace of
+// witw_conv3x3_wgrad_bf16_nhwc_workspace_floats floats. Bitwise reproducible (fixed split order), not bit-equal to the octet
+// entry (different summation order within a split).
+int witw_conv3x3_wgrad_bf16_nhwc(const void* x_nhwc, const void* dz_nhwc, float* dw, float* db, float* workspace, int B, int H, int W,
+                                 int Cin, int cin_real, int Cout, int stride_h, int pad_circular, int accumulate, void* stream) {
+    WITW_CHECK_ARG(x_nhwc && dz_nhwc && dw && workspace, "conv3x3_wgrad_bf16_nhwc: null pointer");
+    WITW_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv3x3_wgrad_bf16_nhwc: bad shape");
+    WITW_CHECK_ARG((Cin % 8) == 0 && (Cout % 8) == 0, "conv3x3_wgrad_bf16_nhwc: Cin=%d and Cout=%d must be multiples of 8", Cin, Cout);
+    WITW_CHECK_ARG(cin_real > 0 && cin_real <= Cin, "conv3x3_wgrad_bf16_nhwc: cin_real=%d outside (0,%d]", cin_real, Cin);
+    WITW_CHECK_ARG(stride_h == 1 || stride_h == 2, "conv3x3_wgrad_bf16_nhwc: stride_h=%d unsupported", stride_h);
+    const int Ho = (H + 2 - 3) / stride_h + 1;
+    WITW_CHECK_ARG((size_t)B * H * W * Cin * 2 < 0x80000000ull && (size_t)B * Ho * W * Cout * 2 < 0x80000000ull,
+                   "conv3x3_wgrad_bf16_nhwc: operand too large for one buffer descriptor");
+    hipStream_t st = (hipStream_t)stream;
+    WgradNhArgs a;
+    a.x = (const unsigned short*)x_nhwc; a.dz = (const unsigned short*)dz_nhwc; a.ws = workspace;
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.Ho = Ho; a.Wo = W;
+    a.circ = pad_circular;
+    const int R = wgrad_nh_rows(stride_h);
+    a.nseg = cdiv(a.Wo, NH_P);
+    a.nrg = cdiv(Ho, R);
+    a.chunks = B * a.nrg * a.nseg;
+    a.tiles_ci = cdiv(Cin, WB_TM); a.tiles_co = cdiv(Cout, WB_TN);
+    a.splits = wgrad_nh_splits(B, Ho, a.Wo, Cin, Cout, stride_h);
+    a.cps = cdiv(a.chunks, a.splits);
+    const size_t n = (size_t)9 * Cin * Cout;
+    a.bias_part = db ? workspace + (size_t)a.splits * n : nullptr;
+    const dim3 grid((unsigned)(a.tiles_ci * a.tiles_co * a.splits));
+    if (stride_h == 2)
+        hipLaunchKernelGGL((conv3x3_wgrad_bf16_nhwc_kernel<2, 4, 2>), grid, dim3(512), 0, st, a);
+    else
+        hipLaunchKernelGGL((conv3x3_wgrad_bf16_nhwc_kernel<1, 8, 2>), grid, dim3(512), 0, st, a);
+    WITW_CHECK_LAUNCH("conv3x3_wgrad_bf16_nhwc");
+    hipLaunchKernelGGL(wgrad_bf16_reduce_kernel, dim3((unsigned)((n + Cout + 255) / 256)), dim3(256), 0, st, workspace, dw, Cin,
+                       Cout, a.splits, accumulate, cin_real, a.bias_part, db);
+    WITW_CHECK_LAUNCH("wgrad_bf16_reduce");
+    witw_note_variant("conv3x3_wgrad_bf16_nhwc_kernel<%d,%d>", stride_h, R);
     return WITW_OK;
 }
 

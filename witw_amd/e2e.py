@@ -34,8 +34,11 @@ def make_dataset(root, n_pairs, n_unique=512, seed=77, procs=8):
     import multiprocessing as mp
     os.makedirs(root, exist_ok=True)
     n_unique = min(n_pairs, n_unique)
-    with mp.get_context('spawn').Pool(procs) as pool:
-        pool.map(_write_pair, [(root, i, seed) for i in range(n_unique)], chunksize=16)
+    todo = [(root, i, seed) for i in range(n_unique)
+            if not (os.path.exists(os.path.join(root, 'ov_%05d.jpg' % i)) and os.path.exists(os.path.join(root, 'su_%05d.jpg' % i)))]
+    if todo:            # a directory kept from an earlier block (bench.py --e2e-dir) already holds the files: same seed, same bytes
+        with mp.get_context('spawn').Pool(procs) as pool:
+            pool.map(_write_pair, todo, chunksize=16)
     csv = os.path.join(root, 'pairs.csv')
     with open(csv, 'w') as f:
         for i in range(n_pairs):
@@ -103,7 +106,7 @@ def bench(a, device, n_pairs=None, workers=None, keep_dir=None, decode=None, pre
     workers = workers if workers is not None else max(1, min(a.workers, cores))
     B, fov = a.batch, a.fov
     tmp = tempfile.TemporaryDirectory(prefix='witw_e2e_')
-    root = keep_dir or tmp.name
+    root = keep_dir or getattr(a, 'e2e_dir', None) or tmp.name
     t0 = time.perf_counter()
     csv, n_unique, nbytes = make_dataset(root, n_pairs, procs=min(16, cores))
     t_make = time.perf_counter() - t0
@@ -230,7 +233,8 @@ def bench(a, device, n_pairs=None, workers=None, keep_dir=None, decode=None, pre
              'gpu (%sbatched resize+normalise [+polar, fused], 2 %s encoders; the next batch staged on the copy stream meanwhile, as in the pipeline)'
              % ('JPEG back end: dequantise + IDCT + upsample + colour, ' if decode == 'device' else '', precision): nb / t_gpu}
     limiting = min(rates, key=rates.get)
-    scaling = decode_scaling(root, n_unique, cores, nb / t_gpu) if decode == 'device' else None
+    scaling = decode_scaling(root, n_unique, cores, nb / t_gpu, seconds=getattr(a, 'decode_scaling_seconds', 1.0)) \
+        if decode == 'device' and not getattr(a, 'no_decode_scaling', False) else None
     out = {'metric': 'image-pairs/sec (disk -> embeddings)', 'value': round(n_pairs / t_e2e, 2), 'unit': 'pairs/s', 'n_gpus': 1,
            'steps': (n_pairs + B - 1) // B, 'warmup': 0, 'ms_per_step': round(t_e2e / ((n_pairs + B - 1) // B) * 1e3, 3),
            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': {'fp32': 'f32'}.get(precision, precision), 'data': 'synthetic',

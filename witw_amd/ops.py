@@ -1174,13 +1174,18 @@ def nhwc_bf16_to_octet(x):
     return y
 
 
-def conv3x3_wgrad_bf16(x_nhwc, dz_nhwc, cin_real, stride_h=1, circular=False, want_bias=True, x_oct=None):
+def conv3x3_wgrad_bf16(x_nhwc, dz_nhwc, cin_real, stride_h=1, circular=False, want_bias=True, x_oct=None, layout='nhwc'):
     """bf16 MFMA weight gradient of one conv layer: x_nhwc [B,H,W,Cin] (its input), dz_nhwc [B,Ho,W,Cout] (gradient at
-    its output), both bf16 NHWC -> (dW [Cout,cin_real,3,3] fp32, db [Cout] fp32 or None)."""
+    its output), both bf16 NHWC -> (dW [Cout,cin_real,3,3] fp32, db [Cout] fp32 or None).
+    layout='nhwc' (round 5, default): witw_conv3x3_wgrad_bf16_nhwc reads the two tensors as they are (pixels are the MFMA's k
+    index, transposed LDS reads); layout='octet': the round-1 kernel on batch-octet copies of both operands (two
+    nhwc_to_octet passes per call). Same arithmetic (bf16 products, fp32 accumulation), different summation order."""
     lib = _lib.load()
     for t, n in ((x_nhwc, 'x'), (dz_nhwc, 'dz')):
         if not (t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous()):
             raise _lib.WitwError('conv3x3_wgrad_bf16: %s must be a contiguous bfloat16 GPU tensor' % n)
+    if layout not in ('nhwc', 'octet'):
+        raise _lib.WitwError("conv3x3_wgrad_bf16: layout must be 'nhwc' or 'octet'")
     B, H, W, Cin = x_nhwc.shape
     Ho = (H + 2 - 3) // stride_h + 1
     Cout = dz_nhwc.shape[3]
@@ -1191,16 +1196,23 @@ def conv3x3_wgrad_bf16(x_nhwc, dz_nhwc, cin_real, stride_h=1, circular=False, wa
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    if x_oct is None:
-        x_oct = nhwc_bf16_to_octet(x_nhwc)
-    dz_oct = nhwc_bf16_to_octet(dz_nhwc)
     dw = torch.empty((Cout, cin_real, 3, 3), dtype=torch.float32, device=x_nhwc.device)
     db = torch.empty((Cout,), dtype=torch.float32, device=x_nhwc.device) if want_bias else None
-    ws = torch.empty(lib.witw_conv3x3_wgrad_bf16_workspace_floats(B, H, W, Cin, Cout, stride_h), dtype=torch.float32,
-                     device=x_nhwc.device)
-    _lib.check(lib.witw_conv3x3_wgrad_bf16(x_oct.data_ptr(), dz_oct.data_ptr(), dw.data_ptr(), _p(db),
-                                           ws.data_ptr(), B, H, W, Cin, cin_real, Cout, stride_h, int(circular), 0, _stream()),
-               'witw_conv3x3_wgrad_bf16')
+    if layout == 'nhwc':
+        ws = torch.empty(lib.witw_conv3x3_wgrad_bf16_nhwc_workspace_floats(B, H, W, Cin, Cout, stride_h), dtype=torch.float32,
+                         device=x_nhwc.device)
+        _lib.check(lib.witw_conv3x3_wgrad_bf16_nhwc(x_nhwc.data_ptr(), dz_nhwc.data_ptr(), dw.data_ptr(), _p(db), ws.data_ptr(),
+                                                    B, H, W, Cin, cin_real, Cout, stride_h, int(circular), 0, _stream()),
+                   'witw_conv3x3_wgrad_bf16_nhwc')
+    else:
+        if x_oct is None:
+            x_oct = nhwc_bf16_to_octet(x_nhwc)
+        dz_oct = nhwc_bf16_to_octet(dz_nhwc)
+        ws = torch.empty(lib.witw_conv3x3_wgrad_bf16_workspace_floats(B, H, W, Cin, Cout, stride_h), dtype=torch.float32,
+                         device=x_nhwc.device)
+        _lib.check(lib.witw_conv3x3_wgrad_bf16(x_oct.data_ptr(), dz_oct.data_ptr(), dw.data_ptr(), _p(db),
+                                               ws.data_ptr(), B, H, W, Cin, cin_real, Cout, stride_h, int(circular), 0, _stream()),
+                   'witw_conv3x3_wgrad_bf16')
     if prof is not None:
         e1.record()
         prof.append((('wgrad_bf16', stride_h), 2.0 * cin_real * Cout * 9 * Ho * W * B, e0, e1))
