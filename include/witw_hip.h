@@ -210,6 +210,11 @@ long long witw_conv3x3_bf16_packed_elems(int cout, int cin);
 int witw_conv3x3_bf16_pack_weights(const float* w_kcrs, void* wpk_bf16, int cout, int cin, void* stream);
 /* transpose_flip != 0: the dgrad filter of the source tensor [cin][cout][3][3] (cout, cin describe the packed filter) */
 int witw_conv3x3_bf16_pack_weights_ex(const float* w_kcrs, void* wpk_bf16, int cout, int cin, int transpose_flip, void* stream);
+/* n filter images (and their biases) in one launch per 16 entries: what a bf16 training step re-packs after every Adam update
+ * (csrc/pack_multi.hip). Entry i as witw_conv3x3_bf16_pack_weights_ex(w[i], wpk[i], cout[i], cin[i], transpose[i]); bias[i] NULL
+ * or fp32 [cout[i]], copied to the first cout[i] floats of bias_dst[i]. Same bits as the one-at-a-time entry. */
+int witw_conv3x3_bf16_pack_weights_multi(const void* const* w, void* const* wpk, const void* const* bias, void* const* bias_dst,
+                                         const int* cout, const int* cin, const int* transpose, int n, void* stream);
 int witw_nchw_f32_to_nhwc_bf16(const float* x, void* y_bf16, int B, int C, int H, int W, int Cpad, void* stream);
 int witw_conv3x3_bf16_fwd(const void* x_bf16, const void* wpk_bf16, const float* bias, void* y, int B, int H, int W, int Cin,
                           int Cout, int stride_h, int pad_circular, int relu, int pool, int out_nchw_f32, void* stream);

@@ -39,6 +39,9 @@ WGRAD_CASES = [  # B, H, W, Cin, Cout, stride_h, circ
     (5, 19, 37, 40, 24, 1, True),        # nothing divides: 3 row groups (one ragged), 3 column segments (one ragged), partial tiles
     (2, 32, 48, 8, 64, 1, False),        # 8 input channels (one 16-byte chunk per pixel): cvig_semantic's layer 0 is 5 -> padded
     (3, 9, 16, 64, 64, 2, True),         # W == one column segment: both circular wraps inside one stage
+    (3, 12, 32, 16, 128, 1, True),       # wave roles 1 x 4 (one ci slab), two row blocks along k
+    (6, 10, 20, 24, 32, 1, False),       # wave roles 1 x 1: all 8 waves split the stage's rows
+    (4, 9, 24, 64, 16, 2, True),         # stride (2,1) with one co slab: roles 2 x 1, four row blocks
 ]
 
 
@@ -63,8 +66,9 @@ def test_wgrad_bf16_matches_autograd(case, layout):
     back = oct_.permute(0, 4, 1, 2, 3).reshape(-1, H, W, Cin)          # [B8*8,H,W,C]
     assert torch.equal(back[:B], xd) and float(back[B:].float().abs().max() if back.shape[0] > B else 0.) == 0.
     dw, db = ops.conv3x3_wgrad_bf16(xd, gyd, Cin, stride_h=sh, circular=circ, layout=layout)
-    if layout == 'nhwc':
-        assert ops.last_kernel_variant() == 'conv3x3_wgrad_bf16_nhwc_kernel<%d,%d>' % (sh, 8 if sh == 1 else 4), ops.last_kernel_variant()
+    if layout == 'nhwc':      # which instantiation ran: stride, rows per stage, wave roles (ci slabs x co slabs; the rest of the 8 waves along k)
+        nwm, nwn = (1 if Cin <= 32 and sh == 1 else 2), (1 if Cout <= 32 else 2 if Cout <= 64 else 4)
+        assert ops.last_kernel_variant() == 'conv3x3_wgrad_bf16_nhwc_kernel<%d,%d,%d,%d>' % (sh, 8 if sh == 1 else 4, nwm, nwn), ops.last_kernel_variant()
     assert dw.dtype == torch.float32 and dw.shape == (Cout, Cin, 3, 3)
     np.testing.assert_allclose(dw.cpu().numpy(), w.grad.numpy(), rtol=0, atol=2e-5 * max(1.0, float(w.grad.abs().max())))
     np.testing.assert_allclose(db.cpu().numpy(), b.grad.numpy(), rtol=0, atol=2e-5 * max(1.0, float(b.grad.abs().max())))
@@ -284,3 +288,34 @@ def test_bf16_training_forward_with_the_fused_first_two_layers_is_bitwise_the_un
     finally:
         ops.conv_first2_bf16 = real
     assert not called
+
+
+def test_batched_filter_packing_equals_one_at_a_time():
+    """ops.PackedConvBf16.batch (one launch for all of an encoder's stale filter images + bias copies: what the bf16 training step
+    calls after every Adam update) writes the same bits as the constructor image by image, forward and dgrad form, with and
+    without a buffer to reuse, across the 16-entries-per-launch boundary."""
+    from witw_amd import ops
+    dev = torch.device('cuda:0')
+    g = np.random.Generator(np.random.Philox(key=[77, 1]))
+    shapes = [(512, 256), (512, 512), (256, 512), (64, 256), (16, 64), (64, 5), (128, 64), (24, 40)]
+    items, singles = [], []
+    for n, (co, ci) in enumerate(shapes * 3):           # 24 entries: two launches
+        w = torch.from_numpy(g.standard_normal((co, ci, 3, 3), dtype=np.float32)).to(dev)
+        tf = n % 2 == 1
+        b = None if tf else torch.from_numpy(g.standard_normal((co,), dtype=np.float32)).to(dev)
+        items.append((w, b, tf, None))
+        singles.append(ops.PackedConvBf16(w, b, transpose_flip=tf))
+    batch = ops.PackedConvBf16.batch(items)
+    for one, many in zip(singles, batch):
+        assert (one.cout, one.cin, one.cin_pad) == (many.cout, many.cin, many.cin_pad)
+        assert torch.equal(one.wpk.view(torch.int16), many.wpk.view(torch.int16)) and torch.equal(one.bias, many.bias)
+    # re-packing into the same buffers after the weights changed (the training step's case)
+    items2 = []
+    for (w, b, tf, _r), pk in zip(items, batch):
+        w2 = w * 1.5 + 0.25
+        items2.append((w2, None if b is None else b - 1.0, tf, pk))
+    again = ops.PackedConvBf16.batch(items2)
+    for (w2, b2, tf, _r), pk, old in zip(items2, again, batch):
+        assert pk.wpk.data_ptr() == old.wpk.data_ptr() and pk.bias.data_ptr() == old.bias.data_ptr()
+        ref = ops.PackedConvBf16(w2, b2, transpose_flip=tf)
+        assert torch.equal(ref.wpk.view(torch.int16), pk.wpk.view(torch.int16)) and torch.equal(ref.bias, pk.bias)

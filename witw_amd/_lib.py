@@ -47,6 +47,7 @@ SIGNATURES = {
     'witw_conv3x3_bf16_packed_elems': (c_longlong, [c_int, c_int]),
     'witw_conv3x3_bf16_pack_weights': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     'witw_conv3x3_bf16_pack_weights_ex': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    'witw_conv3x3_bf16_pack_weights_multi': (c_int, [c_void_p] * 7 + [c_int, c_void_p]),
     'witw_nchw_f32_to_nhwc_bf16': (c_int, [c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]),
     'witw_conv3x3_bf16_fwd': (c_int, [c_void_p] * 4 + [c_int] * 10 + [c_void_p]),
     'witw_conv3x3_bf16_fwd_ex': (c_int, [c_void_p] * 7 + [c_int] * 11 + [c_void_p]),

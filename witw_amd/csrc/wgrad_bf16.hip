@@ -330,9 +330,17 @@ __device__ __forceinline__ void wait_vmcnt() {      // s_waitcnt vmcnt(N) only (
     __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | 0x0F70);
 }
 
-template <int SH, int R, int NS>
+// Wave roles: NWM x NWN waves cover the 32-channel slabs of the tile (ci x co) that EXIST -- a layer with Cin <= 32 has one ci slab
+// (NWM = 1), one with Cout <= 64 / <= 32 two / one co slabs -- and the remaining factor KS = 8 / (NWM * NWN) splits the stage's R
+// rows (k-steps) into KS contiguous blocks, one per wave group: every wave has MFMA work on its own rows instead of multiplying
+// zeros (cvig_semantic's layer 0, 5 -> 64 channels on 128 x 512 maps, ran 2 of 8 waves' worth of useful MFMAs and was MFMA-bound
+// where it should be HBM-bound). The wave groups' sums are added in the LDS at the end of the kernel (fixed order).
+template <int SH, int R, int NS, int NWM, int NWN>
 __global__ __launch_bounds__(512) void conv3x3_wgrad_bf16_nhwc_kernel(WgradNhArgs p) {
     constexpr int NW = 8;
+    constexpr int KS = NW / (NWM * NWN);              // wave groups along k (rows of the stage)
+    constexpr int RW = R / KS;                        // output rows per wave and stage
+    static_assert(NWM * NWN * KS == NW && RW * KS == R && RW >= 1, "8 waves = NWM x NWN x KS; the rows split evenly");
     constexpr int XR = (R - 1) * SH + 3;              // halo rows
     constexpr int NXI = XR * 3;                       // X DMA instructions per stage (8 pixels x 128 B each)
     constexpr int NZI = R * 4;                        // dZ DMA instructions per stage (4 pixels x 256 B each)
@@ -344,7 +352,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_bf16_nhwc_kernel(WgradNhArg
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6) & (NW - 1);
     const int l31 = lane & 31, kg = lane >> 5;
-    const int wm = wave_u & 1, wn = wave_u >> 1;
+    const int wm = wave_u % NWM, wn = (wave_u / NWM) % NWN, ks = wave_u / (NWM * NWN);
     // XCD-aware map: physical block b runs on XCD b % 8 (observed round-robin; speed only). Logical ids are dealt so that each XCD
     // gets a CONTIGUOUS range of them, and logical id = split * tiles + tile: the tiles of a split share an XCD.
     const int tiles = p.tiles_ci * p.tiles_co;
@@ -422,9 +430,10 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_bf16_nhwc_kernel(WgradNhArg
     for (int kw = 0; kw < 3; ++kw) {
         const int col = 8 * kg + q + kw;                                     // + 4 h per read half; bit 1 unaffected by 8 kg + 4 h
         const int chunk = (4 * wm + 2 * (G & 1) + (pp >> 1)) ^ (((col >> 1) & 1) << 2);
-        a_lane[kw] = (unsigned)(col * 128 + chunk * 16 + 8 * (pp & 1));
+        a_lane[kw] = (unsigned)(col * 128 + chunk * 16 + 8 * (pp & 1) + ks * RW * SH * NH_XP * 128);       // this wave group's first halo row
     }
-    const unsigned b_lane = (unsigned)(X_B + (8 * kg + q) * 256 + (((4 * wn + 2 * (G & 1) + (pp >> 1)) ^ (q << 2)) * 16) + 8 * (pp & 1));
+    const unsigned b_lane = (unsigned)(X_B + (8 * kg + q) * 256 + (((4 * wn + 2 * (G & 1) + (pp >> 1)) ^ (q << 2)) * 16) + 8 * (pp & 1) +
+                                       ks * RW * NH_P * 256);
 
     const bool do_bias = p.bias_part != nullptr && ci0 == 0 && wm == 0;     // wave-uniform
     f32x4 accb[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -453,16 +462,17 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_bf16_nhwc_kernel(WgradNhArg
     // (out-of-range DMA lanes) and are computed like the others.
     auto compute = [&](int buf) {
         const unsigned char* sb = lds + buf * STAGE_B;
-        bf16x8 fx[XR][3];
+        constexpr int XRW = (RW - 1) * SH + 3;      // halo rows of this wave's RW output rows
+        bf16x8 fx[XRW][3];
 #pragma unroll
         for (int j = 0; j < 3; ++j)
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) fx[j][kw] = frag(sb, a_lane[kw] + (unsigned)(j * NH_XP * 128));
         bf16x8 fb = fragz(sb, b_lane);
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
+        for (int r = 0; r < RW; ++r) {
             bf16x8 fbn = fb;
-            if (r + 1 < R) {
+            if (r + 1 < RW) {
                 fbn = fragz(sb, b_lane + (unsigned)((r + 1) * NH_P * 256));
 #pragma unroll
                 for (int j = r * SH + 3; j < (r + 1) * SH + 3; ++j)
@@ -505,6 +515,44 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_bf16_nhwc_kernel(WgradNhArg
         }
     }
 
+    // ---- the KS wave groups' sums of one slab pair are added in the LDS, group 1, 2, ... onto group 0 (a fixed order), one tap at
+    // a time (8 waves x 16 registers x 64 lanes x 4 B = 32 KB): the workspace keeps ONE partial per workgroup
+    if (KS > 1) {
+        float* red = reinterpret_cast<float*>(lds);
+#pragma unroll
+        for (int t = 0; t < 10; ++t) {                 // t = 9: the two bias tiles
+            __syncthreads();                           // the stage buffers / the previous tap's exchange have been read
+            if (ks > 0) {
+                if (t < 9) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) red[(wave_u * 16 + r) * 64 + lane] = acc[t][r];
+                } else {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) red[(wave_u * 16 + h * 4 + r) * 64 + lane] = accb[h][r];
+                }
+            }
+            __syncthreads();
+            if (ks == 0) {
+#pragma unroll 1
+                for (int k = 1; k < KS; ++k) {
+                    const int src = wave_u + k * (NWM * NWN);
+                    if (t < 9) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[t][r] += red[(src * 16 + r) * 64 + lane];
+                    } else {
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) accb[h][r] += red[(src * 16 + h * 4 + r) * 64 + lane];
+                    }
+                }
+            }
+        }
+        if (ks > 0) return;
+    }
+
     // ---- partial tile -> workspace [split][tap][ci][co]
     float* out = p.ws + (size_t)split * 9 * p.Cin * p.Cout;
 #pragma unroll
@@ -523,6 +571,18 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_bf16_nhwc_kernel(WgradNhArg
             if (co < p.Cout) p.bias_part[(size_t)split * p.Cout + co] = accb[h][0];
         }
     }
+}
+
+// wave roles for a layer (see the kernel): slabs that exist, the rest of the 8 waves along k
+void wgrad_nh_roles(int Cin, int Cout, int stride_h, int* nwm, int* nwn) {
+    *nwm = Cin <= 32 ? 1 : 2;
+    *nwn = Cout <= 32 ? 1 : Cout <= 64 ? 2 : 4;
+    if (stride_h == 2) *nwm = 2;         // instantiated at stride (2,1): (2,4), (2,2), (2,1) -- its layers have wide inputs
+}
+int wgrad_nh_ksplit(int Cin, int Cout, int stride_h) {
+    int nwm, nwn;
+    wgrad_nh_roles(Cin, Cout, stride_h, &nwm, &nwn);
+    return 8 / (nwm * nwn);
 }
 
 // stage shape: R output rows per stage (8 rows x 16 columns of one image at stride 1: 8 k-steps = 72 MFMAs per wave between two
@@ -648,17 +708,32 @@ int witw_conv3x3_wgrad_bf16_nhwc(const void* x_nhwc, const void* dz_nhwc, float*
     a.splits = wgrad_nh_splits(B, Ho, a.Wo, Cin, Cout, stride_h);
     a.cps = cdiv(a.chunks, a.splits);
     const size_t n = (size_t)9 * Cin * Cout;
-    a.bias_part = db ? workspace + (size_t)a.splits * n : nullptr;
+    int nwm, nwn;
+    wgrad_nh_roles(Cin, Cout, stride_h, &nwm, &nwn);
+    const int parts = a.splits;                          // partial tiles in the workspace
+    a.bias_part = db ? workspace + (size_t)parts * n : nullptr;
     const dim3 grid((unsigned)(a.tiles_ci * a.tiles_co * a.splits));
-    if (stride_h == 2)
-        hipLaunchKernelGGL((conv3x3_wgrad_bf16_nhwc_kernel<2, 4, 2>), grid, dim3(512), 0, st, a);
-    else
-        hipLaunchKernelGGL((conv3x3_wgrad_bf16_nhwc_kernel<1, 8, 2>), grid, dim3(512), 0, st, a);
+#define WITW_NH_LAUNCH(SH_, R_, NWM_, NWN_) \
+    hipLaunchKernelGGL((conv3x3_wgrad_bf16_nhwc_kernel<SH_, R_, 2, NWM_, NWN_>), grid, dim3(512), 0, st, a)
+    if (stride_h == 2) {
+        if (nwn == 4) WITW_NH_LAUNCH(2, 4, 2, 4);
+        else if (nwn == 2) WITW_NH_LAUNCH(2, 4, 2, 2);
+        else WITW_NH_LAUNCH(2, 4, 2, 1);
+    } else if (nwm == 2) {
+        if (nwn == 4) WITW_NH_LAUNCH(1, 8, 2, 4);
+        else if (nwn == 2) WITW_NH_LAUNCH(1, 8, 2, 2);
+        else WITW_NH_LAUNCH(1, 8, 2, 1);
+    } else {
+        if (nwn == 4) WITW_NH_LAUNCH(1, 8, 1, 4);
+        else if (nwn == 2) WITW_NH_LAUNCH(1, 8, 1, 2);
+        else WITW_NH_LAUNCH(1, 8, 1, 1);
+    }
+#undef WITW_NH_LAUNCH
     WITW_CHECK_LAUNCH("conv3x3_wgrad_bf16_nhwc");
     hipLaunchKernelGGL(wgrad_bf16_reduce_kernel, dim3((unsigned)((n + Cout + 255) / 256)), dim3(256), 0, st, workspace, dw, Cin,
-                       Cout, a.splits, accumulate, cin_real, a.bias_part, db);
+                       Cout, parts, accumulate, cin_real, a.bias_part, db);
     WITW_CHECK_LAUNCH("wgrad_bf16_reduce");
-    witw_note_variant("conv3x3_wgrad_bf16_nhwc_kernel<%d,%d>", stride_h, R);
+    witw_note_variant("conv3x3_wgrad_bf16_nhwc_kernel<%d,%d,%d,%d>", stride_h, R, nwm, nwn);
     return WITW_OK;
 }
 

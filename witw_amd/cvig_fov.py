@@ -244,6 +244,28 @@ class FOV_DSM(torch.nn.Module):
             self._packed[('t_bf16', idx)] = hit
         return hit[1]
 
+    def _refresh_packed_bf16(self, first):
+        """Every STALE bf16 filter image the step from layer `first` on will use -- forward images of all layers, dgrad images
+        (transposed, tap-rotated) of the layers behind `first` -- re-packed by one launch (ops.PackedConvBf16.batch) instead of one
+        launch + one bias copy per image as _pack_bf16 / _pack_t_bf16 would do them on first use: after an Adam update that is
+        11 images per encoder (model/cvig_fov.py:275-278: the trainable layers). The cache keys are those of the lazy methods."""
+        todo = []
+        for (idx, sh, relu, pool, drop) in self.layer_specs:
+            conv = _conv_of(self.model.features[idx])
+            fkey = (conv.weight.data_ptr(), conv.weight._version, conv.bias._version, getattr(conv.weight, '_witw_version', 0),
+                    getattr(conv.bias, '_witw_version', 0))
+            hit = self._packed.get(('bf16', idx))
+            if (hit is None or hit[0] != fkey) and not (idx == 0 and self.in_channels <= 8 and first > 0):     # frozen layer 0: _pack_first
+                todo.append((('bf16', idx), fkey, (conv.weight, conv.bias, False, hit[1] if hit else None)))
+            if idx > first:
+                tkey = (conv.weight.data_ptr(), conv.weight._version, getattr(conv.weight, '_witw_version', 0))
+                hit = self._packed.get(('t_bf16', idx))
+                if hit is None or hit[0] != tkey:
+                    todo.append((('t_bf16', idx), tkey, (conv.weight, None, True, hit[1] if hit else None)))
+        if len(todo) > 1:
+            for (slot, key, _item), pk in zip(todo, ops.PackedConvBf16.batch([t[2] for t in todo])):
+                self._packed[slot] = (key, pk)
+
     def _run_bf16(self, x, scales, keep_from=None):
         """The layer stack on the bf16 MFMA kernels (bf16 NHWC activations, fp32 accumulate, fp32 NCHW embedding).
         Returns (embedding, kept) with kept[idx] = (layer input, layer output, max-pool arg-max codes or None) bf16 NHWC
@@ -496,6 +518,7 @@ class _EncoderFnBf16(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, enc, scales, *params):
         first = min(i for i, _c in enc.trainable_convs())
+        enc._refresh_packed_bf16(first)
         out, kept = enc._run_bf16(x, scales, keep_from=first)
         ctx.enc, ctx.scales, ctx.kept, ctx.first = enc, scales, kept, first
         return out

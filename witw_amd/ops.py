@@ -1086,6 +1086,40 @@ class PackedConvBf16:
         if bias is not None:
             self.bias[:self.cout].copy_(bias.detach())
 
+    @classmethod
+    def batch(cls, items):
+        """items = [(weight, bias or None, transpose_flip, reuse or None)] -> [PackedConvBf16], all filter images and bias copies
+        written by ONE launch per 16 entries (witw_conv3x3_bf16_pack_weights_multi): what a bf16 training step re-packs after every
+        Adam update. The same bits as the constructor entry by entry."""
+        import ctypes
+        lib = _lib.load()
+        out, tab = [], []
+        for weight, bias, transpose_flip, reuse in items:
+            w = _dev_f32(weight.detach(), 'weight')
+            pk = cls.__new__(cls)
+            pk.cout, pk.cin = (w.shape[1], w.shape[0]) if transpose_flip else (w.shape[0], w.shape[1])
+            pk.cin_pad = (pk.cin + 15) // 16 * 16
+            n_pk = lib.witw_conv3x3_bf16_packed_elems(pk.cout, pk.cin)
+            if reuse is not None and not (reuse.wpk.numel() == n_pk and reuse.wpk.device == w.device and reuse.cout == pk.cout):
+                reuse = None
+            pk.wpk = reuse.wpk if reuse is not None else torch.empty(n_pk, dtype=torch.bfloat16, device=w.device)
+            pk.bias = reuse.bias if reuse is not None else \
+                torch.zeros(lib.witw_conv3x3_bias_floats(pk.cout), dtype=torch.float32, device=w.device)
+            b = None if bias is None else _dev_f32(bias.detach(), 'bias')
+            if b is not None and b.numel() != pk.cout:
+                raise _lib.WitwError('PackedConvBf16.batch: bias of %d elements for %d output channels' % (b.numel(), pk.cout))
+            tab.append((w, pk.wpk, b, pk.bias, pk.cout, pk.cin, int(bool(transpose_flip))))
+            out.append(pk)
+        k = len(tab)
+        if k:
+            vp = ctypes.c_void_p
+            _lib.check(lib.witw_conv3x3_bf16_pack_weights_multi(
+                (vp * k)(*[t[0].data_ptr() for t in tab]), (vp * k)(*[t[1].data_ptr() for t in tab]),
+                (vp * k)(*[None if t[2] is None else t[2].data_ptr() for t in tab]), (vp * k)(*[t[3].data_ptr() for t in tab]),
+                (ctypes.c_int * k)(*[t[4] for t in tab]), (ctypes.c_int * k)(*[t[5] for t in tab]),
+                (ctypes.c_int * k)(*[t[6] for t in tab]), k, _stream()), 'witw_conv3x3_bf16_pack_weights_multi')
+        return out
+
 
 def nchw_to_nhwc_bf16(x, cpad=16):
     lib = _lib.load()
