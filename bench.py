@@ -119,7 +119,7 @@ class StepBench(object):
     and the two encoders, times K steps between barrier + synchronize pairs, and derives the live roofline of the dominant
     kernel from HIP events recorded around every launch on the launch stream (ops.PROFILE)."""
 
-    def __init__(self, model, mode, precision, batch, fov, rank, world, device, graph=False, share=None):
+    def __init__(self, model, mode, precision, batch, fov, rank, world, device, graph=False, share=None, pair=True):
         """share: another StepBench of the same model / fov whose weights and first `batch` input pairs are reused (batch sweep)"""
         from witw_amd import cvig_fov, ops, synth, parallel
         self.cvig_fov, self.ops, self.synth, self.parallel = cvig_fov, ops, synth, parallel
@@ -156,6 +156,10 @@ class StepBench(object):
         self.mean, self.std = model_mod.Globals.img_mean, model_mod.Globals.img_std
         self.ndiv = 3 if self.semantic else None      # only the RGB bands are /255 (model/cvig_semantic.py:172-176)
         self.step = self.train_step if self.train else self.infer_step
+        self.pair = None
+        if pair and not self.train and precision in ('fp32', 'bf16') and batch <= 32:
+            self.se.precision = self.oe.precision = precision
+            self.pair = cvig_fov.PairEmbedder(self.se, self.oe)
         if graph:
             if self.train or world > 1:
                 sys.exit('--graph captures the single-GPU inference step only (no collectives, no optimizer)')
@@ -170,6 +174,10 @@ class StepBench(object):
 
     def embed(self, surface, polar, precision=None):
         p = precision or self.precision
+        if self.pair is not None and precision is None:
+            # the drivers' path at the reference's default batch sizes (cvig_fov.PairEmbedder: both encoders at once on two streams,
+            # the bf16 pair as one hipGraph); inside a whole-step capture only the two-stream form
+            return self.pair._dual(surface, polar) if torch.cuda.is_current_stream_capturing() or self.graph else self.pair(surface, polar)
         if p == 'fp16x3':
             return self.se.forward_f16x3(surface), self.oe.forward_f16x3(polar)
         if p == 'bf16':
@@ -790,7 +798,8 @@ def batch_sweep(a, rank, world, device, ops, compact=False):
     for precision in ('fp32', 'bf16'):
         peak = PEAK_BF16_MFMA_TFLOPS if precision == 'bf16' else PEAK_F32_MFMA_TFLOPS
         for B in (128, 64, 32, 16):
-            sb = StepBench('fov', 'infer', precision, B, a.fov, rank, world, device, share=base)
+            # the plain step (one stream, eager) gives the per-kernel table: HIP events around every launch, by instantiation
+            sb = StepBench('fov', 'infer', precision, B, a.fov, rank, world, device, share=base, pair=False)
             base = base or sb
             k = 5 if precision == 'fp32' else 10
             ops.PROFILE_BY_KERNEL = {}
@@ -809,6 +818,14 @@ def batch_sweep(a, rank, world, device, ops, compact=False):
             if not compact:
                 pt['kernels'] = {n: {'launches_per_step': agg[n][2] // k, 'ms_per_step': round(agg[n][1] / k, 4),
                                      'tflops': round(agg[n][0] / (agg[n][1] * 1e-3) / 1e12, 1)} for n in sorted(agg, key=lambda n: -agg[n][1])}
+            if B <= 32:
+                # what test() / the validation phase of train() run at this batch (cvig_fov.PairEmbedder: the two encoders on two
+                # streams, the bf16 pair as one hipGraph): THIS is `value`; the plain step stays listed beside it
+                dr = StepBench('fov', 'infer', precision, B, a.fov, rank, world, device, share=base, pair=True).run(k, 3)
+                pt['plain_one_stream_eager'] = {'value': pt['value'], 'ms_per_step': pt['ms_per_step']}
+                pt['value'], pt['ms_per_step'] = round(dr.value, 1), round(dr.ms, 3)
+                pt['pair_embedder'] = dict(dr.pair.stats)
+                del dr
             if sb.ms - conv_ms > 0.15 * sb.ms:        # a sixth of the step is not conv kernels: launch gaps matter -> one hipGraph
                 g = StepBench('fov', 'infer', precision, B, a.fov, rank, world, device, graph=True, share=base).run(k, 2)
                 pt['graph_replay'] = {'value': round(g.value, 1), 'ms_per_step': round(g.ms, 3)}

@@ -134,3 +134,61 @@ def test_step_replayed_as_a_hip_graph_equals_the_eager_step(bf16):
         ref = body(*x)
         for a, b in zip(got, ref):
             assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_pair_embedder_equals_the_plain_calls_bitwise(precision):
+    """cvig_fov.PairEmbedder (what test() and the validation phase of train() call: model/cvig_fov.py:524-527, :447-449) at the
+    reference's small default batches: the two encoders on two streams, the bf16 pair replayed as one hipGraph from the second
+    batch of a shape on -- always the same bits as calling the encoders one after the other; a weight update drops the stale
+    graph; a batch above the thresholds, a training-mode encoder and a gradient-recording call take the plain path."""
+    from witw_amd import cvig_fov
+    dev = torch.device('cuda:0')
+    w = synth.fov_dsm_weights(33)
+    se = cvig_fov.FOV_DSM(False, weights=w).to(dev).eval()
+    oe = cvig_fov.FOV_DSM(True, weights=w).to(dev).eval()
+    se.precision = oe.precision = precision
+    emb = cvig_fov.PairEmbedder(se, oe)
+
+    def batch(seed, B=16, ws=512):
+        return (torch.from_numpy(synth.normalized_images(seed, 1, (B, 3, 128, ws))).to(dev),
+                torch.from_numpy(synth.normalized_images(seed, 2, (B, 3, 128, 512))).to(dev))
+    with torch.no_grad():
+        for n, seed in enumerate((1, 2, 3, 4)):
+            s, p = batch(seed)
+            su, ov = emb(s, p)
+            ref_su, ref_ov = se(s), oe(p)
+            assert torch.equal(su, ref_su) and torch.equal(ov, ref_ov), (precision, n)
+        if precision == 'bf16':
+            assert emb.stats['captures'] == 1 and emb.stats['graph_replay'] == 3 and emb.stats['dual_stream'] == 1, emb.stats
+        else:
+            assert emb.stats['captures'] == 0 and emb.stats['dual_stream'] == 4, emb.stats
+        # another shape (the last, ragged batch of an epoch; a narrower field of view) has its own key
+        s, p = batch(5, B=5, ws=96)
+        su, ov = emb(s, p)
+        assert torch.equal(su, se(s)) and torch.equal(ov, oe(p))
+        # a weight update (validation after a training epoch): the stale graph must not be replayed
+        with torch.no_grad():
+            for enc in (se, oe):
+                c = cvig_fov._conv_of(enc.model.features[19])
+                c.weight.mul_(1.01)
+        before = dict(emb.stats)
+        for seed in (6, 7, 8):
+            s, p = batch(seed)
+            su, ov = emb(s, p)
+            assert torch.equal(su, se(s)) and torch.equal(ov, oe(p))
+        if precision == 'bf16':
+            assert emb.stats['captures'] == before['captures'] + 1 and emb.stats['graph_replay'] == before['graph_replay'] + 2
+        # above the thresholds: the plain path
+        s, p = batch(9, B=40)
+        n_eager = emb.stats['eager']
+        su, ov = emb(s, p)
+        assert emb.stats['eager'] == n_eager + 1 and torch.equal(su, se(s)) and torch.equal(ov, oe(p))
+    # gradient-recording call on training-mode encoders: plain path, autograd intact
+    se.train()
+    oe.train()
+    s, p = batch(10, B=4)
+    su, ov = emb(s, p)
+    assert su.requires_grad and ov.requires_grad
+    (su.sum() + ov.sum()).backward()
+    assert cvig_fov._conv_of(se.model.features[27]).weight.grad is not None

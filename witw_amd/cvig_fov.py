@@ -1101,6 +1101,81 @@ def sharded_match_loss(overhead_local, surface_local, alpha=10., _kernels=None):
     return _ShardedMatchLossFn.apply(overhead_local, surface_local, float(alpha), _kernels or ops)
 
 
+class PairEmbedder(object):
+    """The two encoders' EVAL forwards of one batch (model/cvig_fov.py:524-527 in test(), :447-449 in the validation phase), the
+    way that serves the reference's own default batch sizes (64 in cvig_fov :385,490; 32 in cvig_semantic :416) well:
+
+      * two streams: the surface and the overhead encoder share nothing, so up to `dual_max` pairs their launches are issued on
+        two HIP streams forked from the current one and joined behind it -- a layer whose grid leaves CUs idle at that batch (the
+        stride-(2,1) tail: 64 workgroups at 16 pairs; the first layers of a small batch) shares the chip with its twin;
+      * one hipGraph: up to `graph_max` pairs the bf16 step is bound by its ~35 launches, not by their kernels; once a (shape,
+        precision, weights) key has been seen twice its two forwards are captured (parallel.CapturedStep, both streams inside)
+        and later batches of that key replay the graph. A weight update (validation after a training epoch) changes the key:
+        the stale graph is dropped and a fresh one captured on the second batch.
+
+    Either way the kernels, their order within an encoder and therefore the BITS are those of calling the encoders one after
+    the other (tests/test_fullsize_properties_gpu.py). Gradient-recording calls and training-mode encoders take the plain path."""
+
+    def __init__(self, surface_encoder, overhead_encoder, graph_max=32, dual_max=32):
+        self.se, self.oe = surface_encoder, overhead_encoder
+        self.graph_max, self.dual_max = graph_max, dual_max
+        self._streams = None
+        self._seen = {}
+        self._graphs = {}
+        self.stats = {'eager': 0, 'dual_stream': 0, 'graph_replay': 0, 'captures': 0}
+
+    def _key(self, surface, polar):
+        sig = tuple((q.data_ptr(), q._version, getattr(q, '_witw_version', 0)) for enc in (self.se, self.oe) for q in enc.parameters())
+        return (tuple(surface.shape), tuple(polar.shape), surface.dtype, self.se.precision, self.oe.precision, hash(sig))
+
+    def _plain(self, surface, polar):
+        return self.se(surface), self.oe(polar)
+
+    def _dual(self, surface, polar):
+        cur = torch.cuda.current_stream()
+        if self._streams is None:
+            self._streams = (torch.cuda.Stream(), torch.cuda.Stream())
+        s1, s2 = self._streams
+        s1.wait_stream(cur)
+        s2.wait_stream(cur)
+        with torch.cuda.stream(s1):
+            su = self.se(surface)
+        with torch.cuda.stream(s2):
+            ov = self.oe(polar)
+        cur.wait_stream(s1)
+        cur.wait_stream(s2)
+        if not torch.cuda.is_current_stream_capturing():      # (a capture's pool is private to the graph)
+            for t in (su, ov):      # allocated on a side stream, consumed on the current one: keep the allocator from re-using them early
+                t.record_stream(cur)
+            surface.record_stream(s1)
+            polar.record_stream(s2)
+        return su, ov
+
+    def __call__(self, surface, polar):
+        from . import parallel
+        B = surface.shape[0]
+        plain = (torch.is_grad_enabled() or self.se.training or self.oe.training or not surface.is_cuda or B != polar.shape[0])
+        if plain or B > max(self.graph_max, self.dual_max):
+            self.stats['eager'] += 1
+            return self._plain(surface, polar)
+        dual = B <= self.dual_max
+        body = self._dual if dual else self._plain
+        if B <= self.graph_max and self.se.precision == 'bf16' and self.oe.precision == 'bf16':
+            key = self._key(surface, polar)
+            g = self._graphs.get(key)
+            if g is None and self._seen.get(key, 0) >= 1:
+                self._graphs = {k: v for k, v in self._graphs.items() if k[:5] != key[:5]}      # graphs of older weights of this shape
+                g = self._graphs[key] = parallel.CapturedStep(lambda a, b: body(a, b), [surface, polar], warmup=1)
+                self.stats['captures'] += 1
+            if g is not None:
+                su, ov = g(surface, polar)
+                self.stats['graph_replay'] += 1
+                return su.clone(), ov.clone()       # the graph's static outputs are overwritten by the next replay
+            self._seen = {key: self._seen.get(key, 0) + 1}
+        self.stats['dual_stream' if dual else 'eager'] += 1
+        return body(surface, polar)
+
+
 def evaluate_global_batch(overhead_all, surface_local, col0, alpha=10.):
     """Inference-time similarity for a minibatch sharded over ranks (no gradients): this rank matches ALL
     overhead embeddings of the global batch against its OWN surfaces (column slab [B, b]), which is all that
@@ -1649,6 +1724,7 @@ def train(dataset='cvusa', fov=360, val_quantity=1000, batch_size=64, num_worker
     all_params = list(surface_encoder.parameters()) + list(overhead_encoder.parameters())
     optimizer = Adam(all_params, lr=1.E-5)
     reducer = parallel.OverlappedGradReducer([surface_encoder, overhead_encoder])
+    embed = PairEmbedder(surface_encoder, overhead_encoder)
 
     def say(*a):
         if rank == 0:
@@ -1672,8 +1748,8 @@ def train(dataset='cvusa', fov=360, val_quantity=1000, batch_size=64, num_worker
                 if phase == 'train':      # Dropout2d masks keyed on the global step, not on how many calls this process made
                     surface_encoder._drop_step = overhead_encoder._drop_step = epoch * len(loader) + batch
                 with torch.set_grad_enabled(phase == 'train'):
-                    surface_embed = surface_encoder(surface)
-                    overhead_embed = overhead_encoder(overhead)
+                    # validation: PairEmbedder (small batches on two streams, bf16 as one hipGraph); training: the plain calls
+                    surface_embed, overhead_embed = embed(surface, overhead)
                     # correlation -> crop_overhead -> l2_distance -> triplet_loss (:450-454) over the GLOBAL batch
                     loss, orientation_estimate, distance = sharded_match_loss(overhead_embed, surface_embed)
                     if phase == 'train':
@@ -1743,11 +1819,13 @@ def test(dataset='cvusa', fov=360, batch_size=64, num_workers=8, csv_path=None, 
     overhead_encoder.eval()
     su_parts, ov_parts = [], []
     data = None
+    embed = PairEmbedder(surface_encoder, overhead_encoder)      # small batches: both encoders at once, bf16 as one hipGraph
     for raw in DevicePrefetcher(test_loader, prep, group=split):
         data = prep(raw)
         with torch.no_grad():
-            su_parts.append(surface_encoder(data['surface']))
-            ov_parts.append(overhead_encoder(data['polar']))
+            su, ov = embed(data['surface'], data['polar'])
+            su_parts.append(su)
+            ov_parts.append(ov)
     if ring is not None:
         del test_loader
         ring.close()
