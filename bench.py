@@ -275,7 +275,10 @@ class StepBench(object):
         # the bf16 inference forward runs its large layers on the 16x16x32 kernel (ops.bf16_mfma16); a bf16 training step mixes it
         # (frozen forward layers) with the 32x32x16 kernel (Dropout2d layers, dgrad) under the same launch class
         s16 = bf16 and not self.train and self.ops.bf16_mfma16()
-        kname = ('conv3x3_bf16_s16_kernel<false,false>' if s16 else 'conv3x3_nhwc_bf16_kernel<128,1,false,8>') if bf16 else \
+        s16t = bf16 and self.train and self.ops.bf16_mfma16()       # training: the same launch class on the TRAIN instantiation
+        kname = ('conv3x3_bf16_s16_kernel<false,false>' if s16 else
+                 'conv3x3_bf16_s16_kernel<false,true>' if s16t else      # Dropout2d forwards + dgrad launches (<false,false>: frozen layers)
+                 'conv3x3_nhwc_bf16_kernel<128,1,false,8>') if bf16 else \
             'conv3x3_nhwc_f16x3_kernel<128,1,false,8>' if f16x3 else 'conv3x3_nhwc_f32_kernel<128,1,false,8,0,9>'
         dom = [(fl, e0.elapsed_time(e1)) for (v, fl, e0, e1) in prof if v == dominant]
         allc = [(fl, e0.elapsed_time(e1)) for (v, fl, e0, e1) in prof if v[0] not in ('match', 'wgrad_bf16', 'wgrad_f16x3')]

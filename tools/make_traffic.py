@@ -13,7 +13,7 @@ import sys
 from collections import defaultdict
 
 DOMINANT = ('conv3x3_nhwc_f32_kernel<128,1,false,8', 'conv3x3_nhwc_bf16_kernel<128,1,false,8', 'conv3x3_nhwc_f16x3_kernel<128,1,false,8',
-            'conv3x3_bf16_s16_kernel<false,false>')
+            'conv3x3_bf16_s16_kernel<false,false>', 'conv3x3_bf16_s16_kernel<false,true>')
 
 
 def per_kernel(path, counter):
