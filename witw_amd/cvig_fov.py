@@ -532,13 +532,20 @@ class _EncoderFnBf16(torch.autograd.Function):
         cout_last = _conv_of(enc.model.features[last]).out_channels
         dz = ops.nchw_to_nhwc_bf16(grad_out.contiguous(), (cout_last + 15) // 16 * 16)   # layer 27 has no ReLU
         grads = {}
+        bucket = getattr(enc, '_grad_bucket', None)      # parallel.GradBucket: the wgrad kernels write into its views (as _EncoderFn)
+        # ... when no layer's gradient tensor carries padded output channels (bf16 activations are stored in multiples of 16)
+        direct = bucket is not None and bucket.direct() and all(c.out_channels % 16 == 0 for _i, c in enc.trainable_convs())
         for n in range(len(specs) - 1, -1, -1):
             idx, sh, relu, pool, drop = specs[n]
             x_in = kept[idx][0]
             conv = _conv_of(enc.model.features[idx])
             if conv.weight.requires_grad:
-                dw, db = ops.conv3x3_wgrad_bf16(x_in, dz, conv.in_channels, stride_h=sh, circular=circ)
-                grads[idx] = (dw[:conv.out_channels].contiguous(), db[:conv.out_channels].contiguous())
+                if direct:
+                    grads[idx] = ops.conv3x3_wgrad_bf16(x_in, dz, conv.in_channels, stride_h=sh, circular=circ,
+                                                        out=(conv.weight._witw_grad_view, conv.bias._witw_grad_view))
+                else:
+                    dw, db = ops.conv3x3_wgrad_bf16(x_in, dz, conv.in_channels, stride_h=sh, circular=circ)
+                    grads[idx] = (dw[:conv.out_channels].contiguous(), db[:conv.out_channels].contiguous())
             if n > 0:   # gradient at the previous layer's conv output
                 pidx, _psh, _prelu, ppool, _pdrop = specs[n - 1]
                 p_in, p_out, p_code = kept[pidx]
@@ -547,6 +554,9 @@ class _EncoderFnBf16(torch.autograd.Function):
                                           out_h=x_in.shape[1] if sh == 2 else None)
                 dz = ops.maxpool2x2_bwd_bf16(dy, p_code, (p_in.shape[1], p_in.shape[2])) if ppool else dy
         ctx.kept = None
+        if direct:      # the gradients already sit in the parameters' .grad views: nothing for autograd to accumulate
+            bucket.notify()
+            return (None, None, None) + (None,) * (2 * len(enc.trainable_convs()))
         flat = []
         for (idx, _c) in enc.trainable_convs():
             flat += [grads[idx][0], grads[idx][1]]

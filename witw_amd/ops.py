@@ -1208,12 +1208,13 @@ def nhwc_bf16_to_octet(x):
     return y
 
 
-def conv3x3_wgrad_bf16(x_nhwc, dz_nhwc, cin_real, stride_h=1, circular=False, want_bias=True, x_oct=None, layout='nhwc'):
+def conv3x3_wgrad_bf16(x_nhwc, dz_nhwc, cin_real, stride_h=1, circular=False, want_bias=True, x_oct=None, layout='nhwc', out=None):
     """bf16 MFMA weight gradient of one conv layer: x_nhwc [B,H,W,Cin] (its input), dz_nhwc [B,Ho,W,Cout] (gradient at
     its output), both bf16 NHWC -> (dW [Cout,cin_real,3,3] fp32, db [Cout] fp32 or None).
     layout='nhwc' (round 5, default): witw_conv3x3_wgrad_bf16_nhwc reads the two tensors as they are (pixels are the MFMA's k
     index, transposed LDS reads); layout='octet': the round-1 kernel on batch-octet copies of both operands (two
-    nhwc_to_octet passes per call). Same arithmetic (bf16 products, fp32 accumulation), different summation order."""
+    nhwc_to_octet passes per call). Same arithmetic (bf16 products, fp32 accumulation), different summation order.
+    out = (dW, db): write into these contiguous fp32 tensors (the .grad views of a parallel.GradBucket) instead of fresh ones."""
     lib = _lib.load()
     for t, n in ((x_nhwc, 'x'), (dz_nhwc, 'dz')):
         if not (t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous()):
@@ -1230,8 +1231,14 @@ def conv3x3_wgrad_bf16(x_nhwc, dz_nhwc, cin_real, stride_h=1, circular=False, wa
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    dw = torch.empty((Cout, cin_real, 3, 3), dtype=torch.float32, device=x_nhwc.device)
-    db = torch.empty((Cout,), dtype=torch.float32, device=x_nhwc.device) if want_bias else None
+    if out is not None:
+        dw, db = out
+        if not (dw.is_contiguous() and tuple(dw.shape) == (Cout, cin_real, 3, 3) and dw.dtype == torch.float32 and dw.is_cuda
+                and db is not None and db.is_contiguous() and db.numel() == Cout and db.dtype == torch.float32):
+            raise _lib.WitwError('conv3x3_wgrad_bf16: out must be contiguous float32 GPU tensors [%d,%d,3,3] and [%d]' % (Cout, cin_real, Cout))
+    else:
+        dw = torch.empty((Cout, cin_real, 3, 3), dtype=torch.float32, device=x_nhwc.device)
+        db = torch.empty((Cout,), dtype=torch.float32, device=x_nhwc.device) if want_bias else None
     if layout == 'nhwc':
         ws = torch.empty(lib.witw_conv3x3_wgrad_bf16_nhwc_workspace_floats(B, H, W, Cin, Cout, stride_h), dtype=torch.float32,
                          device=x_nhwc.device)
