@@ -5,12 +5,12 @@ cd /tmp && export TMPDIR=/tmp
 cd "$R"
 O=gpurun_out/r05b
 mkdir -p $O
-timeout -k 10 900 python3 -m pytest tests/test_fullsize_properties_gpu.py tests/test_drivers_gpu.py tests/test_drivers2_gpu.py -x -q -m gpu > $O/tests.log 2>&1 || { tail -40 $O/tests.log; exit 1; }
+timeout -k 10 900 python3 -m pytest tests/test_bf16_train_gpu.py -x -q -m gpu > $O/tests.log 2>&1 || { tail -40 $O/tests.log; exit 1; }
 tail -2 $O/tests.log
-timeout -k 10 600 python3 bench.py --mode sweep > $O/sweep.json 2> $O/sweep.err || { tail -20 $O/sweep.err; exit 1; }
+rocprofv3 --kernel-trace --stats -d $O/prof_wg -o p --output-format csv -- python3 tools/bench_wgrad_bf16.py --layers "L17,L19,L21,L23,L25,L27" > $O/wg.txt 2> $O/prof_wg.log
+grep -v amdgpu $O/wg.txt
 python3 - <<PY
-import json
-d=json.load(open('bench_detail.json'))
-for p in d['points']:
-    print(p['precision'], p['pairs_per_gpu'], p['value'], p['ms_per_step'], p.get('plain_one_stream_eager'), p.get('graph_replay'), p.get('pair_embedder'))
+import csv
+for r in list(csv.DictReader(open('$O/prof_wg/p_kernel_stats.csv')))[:12]:
+    print('%-90s calls %4s avg %8.1f us' % (r['Name'][:90], r['Calls'], float(r['AverageNs'])/1e3))
 PY
