@@ -281,6 +281,10 @@ int witw_conv3x3_wgrad_bf16(const void* x_oct, const void* dz_oct, float* dw, fl
  * way out by ds_read_b64_tr_b16 (replaces autograd through torch.nn.Conv2d in model/cvig_fov.py:447-460 like the entry above,
  * and is what the bf16 training step now calls). Workspace of witw_conv3x3_wgrad_bf16_nhwc_workspace_floats floats. */
 long long witw_conv3x3_wgrad_bf16_nhwc_workspace_floats(int B, int H, int W, int Cin, int Cout, int stride_h);
+/* 1: eligible layers (stride 1, Cin > 32, Cout > 64, W % 32 == 0) run it on v_mfma_f32_16x16x32_bf16; 0 (default; that form
+ * measured 3-9 % slower): v_mfma_f32_32x32x16_bf16. enable < 0 only queries; returns the previous setting. Set it BEFORE sizing the
+ * workspace. Same parity bar for both. */
+int witw_conv3x3_wgrad_bf16_mfma16(int enable);
 int witw_conv3x3_wgrad_bf16_nhwc(const void* x_nhwc, const void* dz_nhwc, float* dw, float* db, float* workspace, int B, int H, int W,
                                  int Cin, int cin_real, int Cout, int stride_h, int pad_circular, int accumulate, void* stream);
 

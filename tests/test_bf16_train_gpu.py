@@ -42,12 +42,38 @@ WGRAD_CASES = [  # B, H, W, Cin, Cout, stride_h, circ
     (3, 12, 32, 16, 128, 1, True),       # wave roles 1 x 4 (one ci slab), two row blocks along k
     (6, 10, 20, 24, 32, 1, False),       # wave roles 1 x 1: all 8 waves split the stage's rows
     (4, 9, 24, 64, 16, 2, True),         # stride (2,1) with one co slab: roles 2 x 1, four row blocks
+    # the 16x16x32 form (stride 1, W % 32 == 0, Cin > 32, Cout > 64): stages of 4 rows x 32 columns
+    (3, 6, 32, 72, 136, 1, True),        # one column segment (both circular wraps in one stage), ragged row group, partial ci and co tiles
+    (2, 9, 96, 64, 128, 1, False),       # three column segments, three row groups (one ragged)
+    (5, 4, 64, 128, 72, 1, True),        # second co block of the wave mostly out of range
 ]
+
+
+@pytest.fixture
+def wgrad_mfma16():
+    """the 16x16x32 form of the NHWC weight gradient (off by default: it measured slower), switched on for one test"""
+    from witw_amd import _lib
+    lib = _lib.load()
+    prev = lib.witw_conv3x3_wgrad_bf16_mfma16(1)
+    yield
+    lib.witw_conv3x3_wgrad_bf16_mfma16(prev)
+
+
+@pytest.mark.parametrize('case', [0])
+def test_wgrad_bf16_mfma16_form_matches_autograd(case, wgrad_mfma16):
+    """every eligible case of WGRAD_CASES on conv3x3_wgrad_bf16_nhwc16_kernel"""
+    n = 0
+    for c in WGRAD_CASES:
+        B, H, W, Cin, Cout, sh, circ = c
+        if sh == 1 and W % 32 == 0 and Cin > 32 and Cout > 64:
+            test_wgrad_bf16_matches_autograd(c, 'nhwc', mfma16=True)
+            n += 1
+    assert n >= 5
 
 
 @pytest.mark.parametrize('layout', ['nhwc', 'octet'])
 @pytest.mark.parametrize('case', WGRAD_CASES)
-def test_wgrad_bf16_matches_autograd(case, layout):
+def test_wgrad_bf16_matches_autograd(case, layout, mfma16=False):
     """Both bf16 weight-gradient kernels -- round 5's NHWC-direct one (pixels as the MFMA's k index, ds_read_b64_tr_b16; the one
     the training step calls) and round 1's batch-octet one -- against CPU autograd through the oracle's conv on bf16-exact operands
     (model/cvig_fov.py:447-460: autograd through torch.nn.Conv2d)."""
@@ -68,7 +94,10 @@ def test_wgrad_bf16_matches_autograd(case, layout):
     dw, db = ops.conv3x3_wgrad_bf16(xd, gyd, Cin, stride_h=sh, circular=circ, layout=layout)
     if layout == 'nhwc':      # which instantiation ran: stride, rows per stage, wave roles (ci slabs x co slabs; the rest of the 8 waves along k)
         nwm, nwn = (1 if Cin <= 32 and sh == 1 else 2), (1 if Cout <= 32 else 2 if Cout <= 64 else 4)
-        assert ops.last_kernel_variant() == 'conv3x3_wgrad_bf16_nhwc_kernel<%d,%d,%d,%d>' % (sh, 8 if sh == 1 else 4, nwm, nwn), ops.last_kernel_variant()
+        want = 'conv3x3_wgrad_bf16_nhwc_kernel<%d,%d,%d,%d>' % (sh, 8 if sh == 1 else 4, nwm, nwn)
+        if mfma16 and sh == 1 and W % 32 == 0 and Cin > 32 and Cout > 64:
+            want = 'conv3x3_wgrad_bf16_nhwc16_kernel<1,4>'          # the 16x16x32 MFMA form (witw_conv3x3_wgrad_bf16_mfma16(1))
+        assert ops.last_kernel_variant() == want, ops.last_kernel_variant()
     assert dw.dtype == torch.float32 and dw.shape == (Cout, Cin, 3, 3)
     np.testing.assert_allclose(dw.cpu().numpy(), w.grad.numpy(), rtol=0, atol=2e-5 * max(1.0, float(w.grad.abs().max())))
     np.testing.assert_allclose(db.cpu().numpy(), b.grad.numpy(), rtol=0, atol=2e-5 * max(1.0, float(b.grad.abs().max())))

@@ -57,6 +57,7 @@ SIGNATURES = {
     'witw_conv3x3_wgrad_bf16_workspace_floats': (c_longlong, [c_int] * 6),
     'witw_conv3x3_wgrad_bf16': (c_int, [c_void_p] * 5 + [c_int] * 9 + [c_void_p]),
     'witw_conv3x3_wgrad_bf16_nhwc_workspace_floats': (c_longlong, [c_int] * 6),
+    'witw_conv3x3_wgrad_bf16_mfma16': (c_int, [c_int]),
     'witw_conv3x3_wgrad_bf16_nhwc': (c_int, [c_void_p] * 5 + [c_int] * 9 + [c_void_p]),
     'witw_conv3x3_f16x3_packed_elems': (c_longlong, [c_int, c_int]),
     'witw_conv3x3_f16x3_pack_weights': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),

@@ -573,6 +573,226 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_bf16_nhwc_kernel(WgradNhArg
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The same kernel on v_mfma_f32_16x16x32_bf16 (round 5; full-width layers with Wo % 32 == 0: layers 17-23 of FOV_DSM). On random
+// bf16 data the chip holds a higher clock on the 16x16x32 shape than on 32x32x16 at equal FLOPs and operand traffic
+// (MI355X_MICROARCH.md, DVFS give-back (7): x1.12-1.15 in bare loops; conv3x3_bf16_s16_kernel gained 6.5 % of the step from it).
+//   k-step = 32 consecutive output columns of one row (k-group g = lane >> 4 takes columns 8 g .. 8 g + 7);
+//   stage  = one image x R rows x 32 columns: X halo ((R-1)*SH+3) x 34 pixels at a pitch of 40 (5 DMA instructions per row),
+//            dZ R x 32 pixels -- the same LDS bytes and DMA instruction counts as the 32x32x16 kernel's 8 x 16 stage;
+//   waves  = 4 (16 input channels each) x 2 (64 output channels each): a wave's 16 ci x 64 co x 9 taps are 9 x 4 accumulator
+//            tiles of 4 registers (144, as before); per k-step it reads one new halo row (3 fragments = 6 transposed reads) and
+//            four dZ fragments (8 reads) for 36 MFMAs;
+//   swizzles: a half-wave's transposed read now covers 8 pixels (p, p + 8 for four consecutive p), so bit 3 of the column joins the
+//            XOR: X chunk ^ (bit1(col) << 1 | bit3(col) << 2), dZ chunk ^ ((col & 3) << 1 | bit3(col) << 3) -- conflict-free.
+// Everything else (split-K map, workspace, reduction, bias through a ones operand) is the 32x32x16 kernel's.
+constexpr int N16_P = 32;               // output columns per k-step
+constexpr int N16_XP = 40;              // pixel pitch of a halo row (34 used)
+
+template <int SH, int R>
+__global__ __launch_bounds__(512) void conv3x3_wgrad_bf16_nhwc16_kernel(WgradNhArgs p) {
+    constexpr int NW = 8;
+    constexpr int XR = (R - 1) * SH + 3;
+    constexpr int NXI = XR * 5;                       // X DMA instructions per stage (8 pixels x 128 B each)
+    constexpr int NZI = R * 8;                        // dZ DMA instructions per stage (4 pixels x 256 B each)
+    constexpr int X_B = NXI * 1024, Z_B = NZI * 1024;
+    constexpr int STAGE_B = X_B + Z_B;
+    static_assert(2 * STAGE_B <= 160 * 1024, "two stages must fit the LDS");
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE_B];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6) & (NW - 1);
+    const int wm = wave_u & 3, wn = wave_u >> 2;
+    const int tiles = p.tiles_ci * p.tiles_co;
+    const int nblk = tiles * p.splits;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int logical = xcd * (nblk >> 3) + min(xcd, nblk & 7) + slot;
+    const int split = logical / tiles, tile = logical - split * tiles;
+    const int ci0 = (tile % p.tiles_ci) * WB_TM, co0 = (tile / p.tiles_ci) * WB_TN;
+    const int c_begin = split * p.cps;
+    const int c_end = min(p.chunks, c_begin + p.cps);
+
+    const i32x4 x_rs = raw_rsrc(p.x, (unsigned)((size_t)p.B * p.H * p.W * p.Cin * 2u));
+    const i32x4 z_rs = raw_rsrc(p.dz, (unsigned)((size_t)p.B * p.Ho * p.Wo * p.Cout * 2u));
+    const int xpx = lane >> 3;                        // pixel of an X instruction's 8
+    const int xc_l = (lane & 7) ^ (((xpx >> 1) & 1) << 1);      // channel chunk, lane part of the swizzle (bit 3 of the column: per instruction)
+    const int zpx = lane >> 4;                        // pixel of a dZ instruction's 4
+    const int zc_l = (lane & 15) ^ (zpx << 1);
+
+    auto stage = [&](int c, int buf) {
+        const unsigned base = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_address(lds)) + (unsigned)buf * STAGE_B;
+        const int seg = c % p.nseg;
+        const int t = c / p.nseg;
+        const int rg = t % p.nrg, b = t / p.nrg;
+        const int h0 = rg * R, w0 = seg * N16_P;
+#pragma unroll
+        for (int i = 0; i < (NXI + NW - 1) / NW; ++i) {
+            const int j = wave_u + NW * i;
+            if (NXI % NW == 0 || j < NXI) {
+                const int r = j / 5, part = j - r * 5;
+                const int gr = h0 * SH - 1 + r;
+                const int col = part * 8 + xpx;                  // 0..39 (34 used); bit 3 of col = bit 0 of part
+                const int chunk = xc_l ^ ((part & 1) << 2);
+                int gc = w0 - 1 + col;
+                if (p.circ) {
+                    if (gc < 0) gc += p.W;
+                    else if (gc == p.W) gc = 0;
+                }
+                const bool ok = ci0 + chunk * 8 < p.Cin && col < N16_P + 2 && gc >= 0 && gc < p.W && gr >= 0 && gr < p.H;
+                const unsigned soff = (gr >= 0 && gr < p.H) ? (unsigned)(((size_t)b * p.H + gr) * p.W * p.Cin * 2u) : 0u;
+                dma16(x_rs, base + (unsigned)j * 1024u, ok ? (unsigned)(gc * p.Cin + ci0 + chunk * 8) * 2u : OOR, soff);
+            }
+        }
+        static_assert(NZI % NW == 0, "dZ instructions split evenly over the waves");
+#pragma unroll
+        for (int i = 0; i < NZI / NW; ++i) {
+            const int j = wave_u + NW * i;
+            const int r = j >> 3, c4 = (j & 7) * 4;              // first pixel of the instruction: row r, column c4; bit 3 of the column = bit 1 of (j & 7)
+            const int chunk = zc_l ^ ((((j & 7) >> 1) & 1) << 3);
+            const int h = h0 + r, w = w0 + c4;
+            const bool ok = co0 + chunk * 8 < p.Cout && h < p.Ho && w + zpx < p.Wo;
+            const unsigned soff = (h < p.Ho && w < p.Wo) ? (unsigned)((((size_t)b * p.Ho + h) * p.Wo + w) * p.Cout * 2u) : 0u;
+            dma16(z_rs, base + (unsigned)(X_B + j * 1024), ok ? (unsigned)(zpx * p.Cout + co0 + chunk * 8) * 2u : OOR, soff);
+        }
+    };
+
+    f32x4 acc[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int bt = 0; bt < 4; ++bt) acc[t][bt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // transposed-read lane roles: G = lane >> 4 = k-group (columns 8 G ..), q = (lane >> 2) & 3: the pixel of the 4-pixel block whose
+    // address this lane supplies, pp = lane & 3: which 8 bytes of the block's 32
+    const int G = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    unsigned a_lane[3][2];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int col = 8 * G + 4 * h + q + kw;
+            const int chunk = (2 * wm + (pp >> 1)) ^ ((((col >> 1) & 1) << 1) | (((col >> 3) & 1) << 2));
+            a_lane[kw][h] = (unsigned)(col * 128 + chunk * 16 + 8 * (pp & 1));
+        }
+    unsigned b_lane[4];
+#pragma unroll
+    for (int bt = 0; bt < 4; ++bt) {
+        const int chunk = (8 * wn + 2 * bt + (pp >> 1)) ^ ((q << 1) | ((G & 1) << 3));
+        b_lane[bt] = (unsigned)(X_B + (8 * G + q) * 256 + chunk * 16 + 8 * (pp & 1));
+    }
+
+    // bias gradient db[co] = sum over pixels of dZ: the waves of the first ci tile that hold ci rows 0-15 add up the dZ fragments they
+    // read anyway on the VALU (8 bf16 -> fp32 adds per fragment: 32 per 36 MFMAs on a quarter of the waves of 1 / tiles_ci of the
+    // workgroups) -- one register per co block instead of an accumulator tile each; the four k-groups meet at the end
+    const bool do_bias = p.bias_part != nullptr && ci0 == 0 && wm == 0;     // wave-uniform
+    float accb[4] = {0.f, 0.f, 0.f, 0.f};
+
+    auto tr = [&](const unsigned char* sbase, unsigned off) -> s16x4 {
+        return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sbase + off));
+    };
+    auto bsum = [&](bf16x8 v) -> float {
+        const u32x4 u = __builtin_bit_cast(u32x4, v);
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s += __builtin_bit_cast(float, u[i] << 16) + __builtin_bit_cast(float, u[i] & 0xffff0000u);
+        return s;
+    };
+    auto compute = [&](int buf) {
+        const unsigned char* sb = lds + buf * STAGE_B;
+        bf16x8 fx[XR][3];
+        auto load_row = [&](int j) {
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const s16x4 lo = tr(sb, a_lane[kw][0] + (unsigned)(j * N16_XP * 128));
+                const s16x4 hi = tr(sb, a_lane[kw][1] + (unsigned)(j * N16_XP * 128));
+                fx[j][kw] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+        };
+        auto load_b = [&](int r, int bt) -> bf16x8 {
+            const s16x4 lo = tr(sb, b_lane[bt] + (unsigned)(r * N16_P * 256));
+            const s16x4 hi = tr(sb, b_lane[bt] + (unsigned)((r * N16_P + 4) * 256));
+            return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        };
+#pragma unroll
+        for (int j = 0; j < 3; ++j) load_row(j);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            // two co blocks at a time: their dZ fragments, 18 MFMAs; the next output row's halo row is requested under the second half
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const bf16x8 f0 = load_b(r, 2 * half), f1 = load_b(r, 2 * half + 1);
+                if (half == 1 && r + 1 < R) {
+#pragma unroll
+                    for (int j = r * SH + 3; j < (r + 1) * SH + 3; ++j) load_row(j);
+                }
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    acc[t][2 * half] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[r * SH + t / 3][t % 3], f0, acc[t][2 * half], 0, 0, 0);
+                    acc[t][2 * half + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[r * SH + t / 3][t % 3], f1, acc[t][2 * half + 1], 0, 0, 0);
+                }
+                if (do_bias) {
+                    accb[2 * half] += bsum(f0);
+                    accb[2 * half + 1] += bsum(f1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+
+    if (c_begin < c_end) {
+        stage(c_begin, 0);
+        for (int c = c_begin; c < c_end; ++c) {
+            const int buf = (c - c_begin) & 1;
+            wait_vmcnt<0>();                         // this wave's DMA of chunk c has landed
+            __syncthreads();                         // ... everyone's has, and everyone is done reading the other buffer
+            if (c + 1 < c_end) stage(c + 1, buf ^ 1);
+            compute(buf);
+        }
+    }
+
+    // ---- partial tile -> workspace [split][tap][ci][co]; 16x16 result: register r of lane l = (ci 4 (l >> 4) + r, co l & 15)
+    float* out = p.ws + (size_t)split * 9 * p.Cin * p.Cout;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int bt = 0; bt < 4; ++bt) {
+            const int co = co0 + wn * 64 + bt * 16 + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ci = ci0 + wm * 16 + 4 * (lane >> 4) + r;
+                if (ci < p.Cin && co < p.Cout) out[((size_t)t * p.Cin + ci) * p.Cout + co] = acc[t][bt][r];
+            }
+        }
+    if (do_bias) {                       // lanes l, l + 16, l + 32, l + 48 hold the four k-groups' sums of co (l & 15): fixed-order add
+#pragma unroll
+        for (int bt = 0; bt < 4; ++bt) {
+            float v = accb[bt];
+            v += __shfl_down(v, 32, 64);
+            v += __shfl_down(v, 16, 64);
+            const int co = co0 + wn * 64 + bt * 16 + lane;
+            if (lane < 16 && co < p.Cout) p.bias_part[(size_t)split * p.Cout + co] = v;
+        }
+    }
+}
+
+// Which layers CAN take the 16x16x32 kernel: stride 1, full wave roles (Cin > 32, Cout > 64), whole 32-column segments. OFF by
+// default: measured on the bench shapes (tools/bench_wgrad_bf16.py, B = 128, same box, alternating runs) it is 3-9 % SLOWER than the
+// 32x32x16 kernel (layers 17 / 19 / 21: 0.334 / 0.658 / 0.601 ms against 0.323 / 0.651 / 0.550 ms incl. the reduction) -- the clock
+// gain of the shape (MI355X_MICROARCH.md, DVFS give-back (7)) does not cover its 36 instead of 9 MFMA issues per k-step and the
+// four dZ fragments per k-step. witw_conv3x3_wgrad_bf16_mfma16(1) / WITW_WGRAD16=1 select it (parity-tested like the default).
+int g_wgrad16 = -1;
+int wgrad16_enabled() {
+    if (g_wgrad16 < 0) {
+        const char* e = getenv("WITW_WGRAD16");
+        g_wgrad16 = e ? (atoi(e) != 0) : 0;
+    }
+    return g_wgrad16;
+}
+bool wgrad_nh16_applies(int Wo, int Cin, int Cout, int stride_h) {
+    // stride (2,1): its 9-row halo keeps 60 fragment registers live beside the 144 accumulators: 220 bytes of scratch per lane, not instantiated
+    return wgrad16_enabled() && stride_h == 1 && (Wo % N16_P) == 0 && Cin > 32 && Cout > 64;
+}
+
 // wave roles for a layer (see the kernel): slabs that exist, the rest of the 8 waves along k
 void wgrad_nh_roles(int Cin, int Cout, int stride_h, int* nwm, int* nwn) {
     *nwm = Cin <= 32 ? 1 : 2;
@@ -594,7 +814,8 @@ int wgrad_nh_rows(int stride_h) { return stride_h == 2 ? 4 : 8; }
 
 int wgrad_nh_splits(int B, int Ho, int Wo, int Cin, int Cout, int stride_h) {
     const int tiles = cdiv(Cin, WB_TM) * cdiv(Cout, WB_TN);
-    const int chunks = B * cdiv(Ho, wgrad_nh_rows(stride_h)) * cdiv(Wo, NH_P);
+    const bool k16 = wgrad_nh16_applies(Wo, Cin, Cout, stride_h);      // stage = 4 rows x 32 columns instead of 8 x 16
+    const int chunks = k16 ? B * cdiv(Ho, 4) * cdiv(Wo, N16_P) : B * cdiv(Ho, wgrad_nh_rows(stride_h)) * cdiv(Wo, NH_P);
     int splits = cdiv(witw_cu_count(), tiles);       // one workgroup per CU; every extra split costs a 36*Cin*Cout-byte partial
     if (splits > chunks) splits = chunks;
     if (splits < 1) splits = 1;
@@ -675,6 +896,15 @@ int witw_conv3x3_wgrad_bf16(const void* x_oct, const void* dz_oct, float* dw, fl
 }
 
 
+// 1: stride-1 layers with Cin > 32, Cout > 64 and W % 32 == 0 run the NHWC weight gradient on v_mfma_f32_16x16x32_bf16
+// (conv3x3_wgrad_bf16_nhwc16_kernel); 0 (default: it measured slower, see above): on 32x32x16. enable < 0 only queries. Returns the
+// previous setting. Call it before sizing the workspace: the two forms split K differently.
+int witw_conv3x3_wgrad_bf16_mfma16(int enable) {
+    const int prev = wgrad16_enabled();
+    if (enable >= 0) g_wgrad16 = enable != 0;
+    return prev;
+}
+
 long long witw_conv3x3_wgrad_bf16_nhwc_workspace_floats(int B, int H, int W, int Cin, int Cout, int stride_h) {
     const int Ho = (H + 2 - 3) / stride_h + 1;
     const long long splits = wgrad_nh_splits(B, Ho, W, Cin, Cout, stride_h);
@@ -700,8 +930,9 @@ int witw_conv3x3_wgrad_bf16_nhwc(const void* x_nhwc, const void* dz_nhwc, float*
     a.x = (const unsigned short*)x_nhwc; a.dz = (const unsigned short*)dz_nhwc; a.ws = workspace;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.Ho = Ho; a.Wo = W;
     a.circ = pad_circular;
-    const int R = wgrad_nh_rows(stride_h);
-    a.nseg = cdiv(a.Wo, NH_P);
+    const bool k16 = wgrad_nh16_applies(a.Wo, Cin, Cout, stride_h);
+    const int R = k16 ? 4 : wgrad_nh_rows(stride_h);
+    a.nseg = cdiv(a.Wo, k16 ? N16_P : NH_P);
     a.nrg = cdiv(Ho, R);
     a.chunks = B * a.nrg * a.nseg;
     a.tiles_ci = cdiv(Cin, WB_TM); a.tiles_co = cdiv(Cout, WB_TN);
@@ -715,7 +946,9 @@ int witw_conv3x3_wgrad_bf16_nhwc(const void* x_nhwc, const void* dz_nhwc, float*
     const dim3 grid((unsigned)(a.tiles_ci * a.tiles_co * a.splits));
 #define WITW_NH_LAUNCH(SH_, R_, NWM_, NWN_) \
     hipLaunchKernelGGL((conv3x3_wgrad_bf16_nhwc_kernel<SH_, R_, 2, NWM_, NWN_>), grid, dim3(512), 0, st, a)
-    if (stride_h == 2) {
+    if (k16) {
+        hipLaunchKernelGGL((conv3x3_wgrad_bf16_nhwc16_kernel<1, 4>), grid, dim3(512), 0, st, a);
+    } else if (stride_h == 2) {
         if (nwn == 4) WITW_NH_LAUNCH(2, 4, 2, 4);
         else if (nwn == 2) WITW_NH_LAUNCH(2, 4, 2, 2);
         else WITW_NH_LAUNCH(2, 4, 2, 1);
@@ -733,7 +966,8 @@ int witw_conv3x3_wgrad_bf16_nhwc(const void* x_nhwc, const void* dz_nhwc, float*
     hipLaunchKernelGGL(wgrad_bf16_reduce_kernel, dim3((unsigned)((n + Cout + 255) / 256)), dim3(256), 0, st, workspace, dw, Cin,
                        Cout, parts, accumulate, cin_real, a.bias_part, db);
     WITW_CHECK_LAUNCH("wgrad_bf16_reduce");
-    witw_note_variant("conv3x3_wgrad_bf16_nhwc_kernel<%d,%d,%d,%d>", stride_h, R, nwm, nwn);
+    if (k16) witw_note_variant("conv3x3_wgrad_bf16_nhwc16_kernel<%d,%d>", stride_h, R);
+    else witw_note_variant("conv3x3_wgrad_bf16_nhwc_kernel<%d,%d,%d,%d>", stride_h, R, nwm, nwn);
     return WITW_OK;
 }
 
