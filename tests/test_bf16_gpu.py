@@ -168,3 +168,17 @@ def test_bf16_mfma16_kernel_matches_the_32x32_kernel(case):
     scale = float(a.abs().max())
     assert bool(((a - c).abs() <= 2.0 ** -7 * torch.maximum(a.abs(), c.abs()) + 1e-5 * scale).all())
     assert not torch.equal(a, c) or cin <= 64          # it really is the other kernel (a different summation order shows somewhere)
+
+
+@pytest.mark.parametrize('shape', [(3, 5, 33, 70, 16), (2, 3, 128, 512, 16), (4, 16, 9, 17, 16), (2, 21, 8, 24, 32), (1, 1, 5, 3, 16)])
+def test_nchw_f32_to_nhwc_bf16_is_exact(shape):
+    """witw_nchw_f32_to_nhwc_bf16 (cvig_semantic's training step converts its 5-channel inputs with it; round 5: one thread per
+    pixel and 8-channel group): round-to-nearest-even bf16 of every value in its NHWC place, zeros in the padding channels."""
+    from witw_amd import ops
+    B, C, H, W, cp = shape
+    g = np.random.Generator(np.random.Philox(key=[55, B * C * H * W]))
+    x = torch.from_numpy(g.standard_normal((B, C, H, W), dtype=np.float32) * 3.0)
+    y = ops.nchw_to_nhwc_bf16(x.cuda(), cp).cpu()
+    assert y.shape == (B, H, W, cp) and y.dtype == torch.bfloat16
+    assert torch.equal(y[..., :C], x.permute(0, 2, 3, 1).bfloat16())
+    assert float(y[..., C:].float().abs().max() if cp > C else 0.) == 0.

@@ -1119,15 +1119,26 @@ __global__ void pack_weights_bf16_kernel(const float* __restrict__ w, unsigned s
     reinterpret_cast<bf16x8*>(wpk)[idx] = v;
 }
 
-// NCHW fp32 [B,C,H,W] -> NHWC bf16 [B,H,W,Cp] (Cp % 16 == 0, extra channels zero)
+// NCHW fp32 [B,C,H,W] -> NHWC bf16 [B,H,W,Cp] (Cp % 16 == 0, extra channels zero). One thread per pixel and 8-channel group: 8
+// plane reads that coalesce across the wave (consecutive threads = consecutive pixels of a plane) and ONE 16-byte store -- the
+// element-per-thread form wrote 2 bytes per thread and read with a stride of a whole plane (cvig_semantic's training step converts
+// its 5 x 128 x 512 inputs with it: 340 us per call at 128 images, round 5: see docs/experiments.md).
 __global__ void nchw_f32_to_nhwc_bf16_kernel(const float* __restrict__ x, __bf16* __restrict__ y, int C, int Cp, size_t hw,
                                              size_t total) {
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;      // over (b, channel group, pixel): pixel fastest
     if (idx >= total) return;
-    const int c = idx % Cp;
-    const size_t t = idx / Cp;
-    const size_t b = t / hw, r = t - b * hw;
-    y[idx] = (__bf16)((c < C) ? x[(b * C + c) * hw + r] : 0.f);
+    const int ng = Cp >> 3;
+    const size_t r = idx % hw;
+    const size_t t = idx / hw;
+    const int g = (int)(t % ng);
+    const size_t b = t / ng;
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = g * 8 + j;
+        v[j] = (__bf16)((c < C) ? x[(b * C + c) * hw + r] : 0.f);
+    }
+    *reinterpret_cast<bf16x8*>(y + (b * hw + r) * Cp + (size_t)g * 8) = v;
 }
 
 // Backward of the fused MaxPool2d(2,2) on bf16 NHWC tensors: dy [B,Hp,Wp,C] is routed to the position the forward
@@ -1261,7 +1272,8 @@ int witw_conv3x3_bf16_pack_weights(const float* w_kcrs, void* wpk_bf16, int cout
 int witw_nchw_f32_to_nhwc_bf16(const float* x, void* y_bf16, int B, int C, int H, int W, int Cpad, void* stream) {
     WITW_CHECK_ARG(x && y_bf16, "nchw_f32_to_nhwc_bf16: null pointer");
     WITW_CHECK_ARG(B > 0 && C > 0 && H > 0 && W > 0 && Cpad >= C && (Cpad % 16) == 0, "nchw_f32_to_nhwc_bf16: bad shape");
-    const size_t total = (size_t)B * H * W * Cpad;
+    const size_t total = (size_t)B * H * W * (Cpad / 8);
+    WITW_CHECK_ARG((total + 255) / 256 <= 0x7fffffffull, "nchw_f32_to_nhwc_bf16: grid too large");
     hipLaunchKernelGGL(nchw_f32_to_nhwc_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
                        (__bf16*)y_bf16, C, Cpad, (size_t)H * W, total);
     WITW_CHECK_LAUNCH("nchw_f32_to_nhwc_bf16");

@@ -271,7 +271,11 @@ class FOV_DSM(torch.nn.Module):
         Returns (embedding, kept) with kept[idx] = (layer input, layer output, max-pool arg-max codes or None) bf16 NHWC
         for idx >= keep_from."""
         fast0 = self.in_channels <= 8 and (keep_from is None or keep_from > 0)      # the bf16 first-layer kernel takes up to 8 channels
-        h = x.contiguous() if fast0 else ops.nchw_to_nhwc_bf16(x.contiguous(), 16)
+        x_nchw = x.contiguous()
+        h = x_nchw if fast0 else ops.nchw_to_nhwc_bf16(x_nchw, 16)
+        sp0 = self.layer_specs[0]
+        first_direct = (not fast0 and self.in_channels <= 8 and sp0[0] == 0 and sp0[1] == 1 and not sp0[3] and 0 not in scales
+                        and keep_from is not None and keep_from <= 0)
         last = self.layer_specs[-1][0]
         kept = {}
         # layers 0 and 2 in one kernel, as forward_bf16 runs them, when neither is kept for a backward (cvig_fov: the frozen trunk,
@@ -289,6 +293,14 @@ class FOV_DSM(torch.nn.Module):
                 h = ops.conv3x3_first_fwd(h, self._pack_first(True), circular=self.circ_padding, relu=relu)
                 continue
             keep = keep_from is not None and idx >= keep_from
+            if idx == 0 and first_direct:
+                # a TRAINABLE layer 0 (cvig_semantic, model/cvig_semantic.py:301-309): its forward still runs on the first-layer kernel
+                # straight from the NCHW image (the generic kernel on the 16-channel NHWC copy is bound by that copy's pixel stride:
+                # 628 against ~300 us at 128 images); the NHWC bf16 copy h is only what the weight gradient reads
+                y = ops.conv3x3_first_fwd(x_nchw, self._pack_first(True), circular=self.circ_padding, relu=relu)
+                kept[idx] = (h, y, None)
+                h = y
+                continue
             out = ops.conv3x3_bf16_fwd(h, self._pack_bf16(idx), stride_h=sh, circular=self.circ_padding, relu=relu, pool=pool,
                                        out_nchw_f32=(idx == last), drop_scale=scales.get(idx), want_pool_code=(keep and pool))
             y, code = out if (keep and pool) else (out, None)
