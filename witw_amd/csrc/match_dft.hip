@@ -31,7 +31,11 @@ constexpr int ROW_F = 128;
 constexpr int A_F = 2 * 32 * ROW_F;    // [parity][32 surfaces]
 constexpr int B_F = 2 * 32 * ROW_F;    // [parity][32 overheads]
 constexpr int STAGE_F = A_F + B_F;     // 16384 floats
-constexpr int XCH = 128 * 33;          // exchange region of an epilogue round: 128 pairs x 32 shifts, row stride 33
+constexpr int XS = 36;                 // row stride of the exchange region in floats: 144 B = 9 x 16, so a pair's 32 shifts are read as
+                                       // 8 ds_read_b128 (round 5; stride 33 forced 32 ds_read_b32) and 16 consecutive rows start on 16
+                                       // different 4-bank groups (36 i mod 64 takes every multiple of 4 once): conflict-free; the
+                                       // b32 writes of a lane half go to 32 consecutive floats of one row: conflict-free as before
+constexpr int XCH = 128 * XS;          // exchange region of an epilogue round: 128 pairs x 32 shifts
 constexpr int LDS_F = STAGE_F + ((STAGE_F > 4 * XCH) ? STAGE_F : 4 * XCH);      // stage 0 | stage 1 / the epilogue exchange
 
 __device__ __forceinline__ unsigned lds_address(const void* p) {
@@ -265,19 +269,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int o = (q & 3) + 8 * (q >> 2) + 4 * hk;
-                mine[(o * 4 + rr) * 33 + l31] = acc2[4 * rd + rr][q];
+                mine[(o * 4 + rr) * XS + l31] = acc2[4 * rd + rr][q];
             }
         __syncthreads();
         {
             const int rl = tl & 3, o = tl >> 2;
-            const float* e = xe + tl * 33;       // row stride 33 -> conflict-free
-            const float* od = e + XCH;
+            const f32x4* e4 = reinterpret_cast<const f32x4*>(xe + tl * XS);
+            const f32x4* o4 = reinterpret_cast<const f32x4*>(xe + tl * XS + XCH);
             float vlo = -INFINITY, vhi = -INFINITY;
             float slo = -INFINITY, shi = -INFINITY;      // GAP: runner-up of each half
             int ilo = 0, ihi = 32;
-#pragma unroll 8
+#pragma unroll
             for (int sft = 0; sft < 32; ++sft) {
-                const float ev = e[sft], ov = od[sft];
+                const float ev = e4[sft >> 2][sft & 3], ov = o4[sft >> 2][sft & 3];       // 16-byte loads, 4 shifts each
                 const float lo = ev + ov, hi = ev - ov;
                 if (GAP) {                                // before the maxima move: max(second, min(x, best so far))
                     slo = fmaxf(slo, fminf(lo, vlo));
