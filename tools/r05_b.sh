@@ -1,13 +1,21 @@
 #!/bin/bash
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-cd /tmp && export TMPDIR=/tmp
 cd "$R"
 O=gpurun_out/r05b
 mkdir -p $O
-timeout -k 10 900 python3 -m pytest tests/test_match_dft_gpu.py tests/test_retrieval_fullsize_gpu.py -x -q -m gpu > $O/tests.log 2>&1 || { tail -40 $O/tests.log; exit 1; }
-tail -2 $O/tests.log
-for rep in 1 2 3; do
-  echo "base: $(WITW_LIB=tools/bin/lib_dft_base.so python3 tools/time_match_dft.py 2>&1 | grep 'dft    match')"
-  echo "new : $(python3 tools/time_match_dft.py 2>&1 | grep 'dft    match')"
-done
+FUZZ_KINDS=4 timeout -k 10 400 python3 tools/fuzz_parity.py 150 51 2>&1 | tail -6
+python3 - <<'PY'
+# the same sweep on the 16x16x32 form (off by default)
+import os, sys
+sys.path.insert(0, '.')
+from witw_amd import _lib
+_lib.load().witw_conv3x3_wgrad_bf16_mfma16(1)
+sys.argv = ['fuzz', '60', '52']
+os.environ['FUZZ_KINDS'] = '4'
+import runpy
+try:
+    runpy.run_path('tools/fuzz_parity.py', run_name='__main__')
+except SystemExit as e:
+    print('exit', e.code)
+PY
