@@ -3,7 +3,7 @@
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$R"
-O=gpurun_out/r05t
+O=gpurun_out/tests
 mkdir -p $O
 ( while true; do date >> $O/heartbeat.txt; sleep 60; done ) &
 HB=$!
