@@ -255,7 +255,7 @@ class FOV_DSM(torch.nn.Module):
             fkey = (conv.weight.data_ptr(), conv.weight._version, conv.bias._version, getattr(conv.weight, '_witw_version', 0),
                     getattr(conv.bias, '_witw_version', 0))
             hit = self._packed.get(('bf16', idx))
-            if (hit is None or hit[0] != fkey) and not (idx == 0 and self.in_channels <= 8 and first > 0):     # frozen layer 0: _pack_first
+            if (hit is None or hit[0] != fkey) and not (idx == 0 and self.in_channels <= 8):     # layer 0 runs on the first-layer kernels: _pack_first
                 todo.append((('bf16', idx), fkey, (conv.weight, conv.bias, False, hit[1] if hit else None)))
             if idx > first:
                 tkey = (conv.weight.data_ptr(), conv.weight._version, getattr(conv.weight, '_witw_version', 0))
