@@ -83,6 +83,10 @@ int witw_conv3x3_fwd_ex(const float* x, const float* wpk, const float* bias, con
                         const float* post_scale, const float* post_shift, float* y, unsigned char* pool_code, int B, int H,
                         int W, int Cin, int Cout, int stride_h, int pad_circular, int relu, float lrelu_slope, int pool,
                         int out_nchw, int dilate_h, void* stream);
+/* 1 (default): a zero-interleaved launch of witw_conv3x3_fwd_ex (dilate_h: the data gradient of a stride-(2,1) conv, model/cvig_fov.py:
+ * 263-272 through autograd) on the 8-wave 128-channel tile skips the products whose input rows are the interleaved zeros -- half the
+ * MFMAs, the same bits; 0: all products are issued. enable < 0 only queries; returns the previous setting. */
+int witw_conv3x3_dil_skip(int enable);
 /* backward of the fused MaxPool2d(2,2): pool_code (written by the forward when non-NULL: first arg-max position
  * dy*2+dx in torch's scan order) routes dy [B,Hp,Wp,C] into dx [B,H,W,C] (H>=2Hp, W>=2Wp). */
 int witw_maxpool2x2_bwd(const float* dy, const unsigned char* pool_code, float* dx, int B, int Hp, int Wp, int H, int W,

@@ -225,3 +225,42 @@ def test_first_layer_missing_planes_read_zeros_not_the_next_image(C):
     yf = ops.conv_first2_bf16(xd, pkb, pk2, circular=True)
     yf_alone = ops.conv_first2_bf16(xd[:1].contiguous(), pkb, pk2, circular=True)
     assert bool(torch.isfinite(yf[0].float()).all()) and torch.equal(yf[0], yf_alone[0])
+
+
+@pytest.mark.parametrize('circ', [False, True])
+def test_dilated_dgrad_launch_skips_the_zero_rows_bitwise(circ):
+    """The data gradient of a stride-(2,1) conv (layers 23 / 25, model/cvig_fov.py:263-272 through autograd) runs the forward kernel on a
+    zero-interleaved input (dilate_h). On the 8-wave 128-channel tile the launch (round 5: GEO = 2) does not issue the MFMAs whose input
+    rows are the interleaved zeros -- half of them. Same bits as the launch that multiplies them (witw_conv3x3_dil_skip(0)), and the
+    oracle's transposed convolution on a spread of images, gate and Dropout2d scale in the epilogue included."""
+    from witw_amd import _lib, ops
+    lib = _lib.load()
+    dev = torch.device('cuda:0')
+    B, Hp, W, cin, cout = 32, 8, 64, 32, 512          # dz [B,8,64,32] stands for 16 rows; 4 x 32 x 2 = 256 workgroups of 8 waves
+    g = np.random.Generator(np.random.Philox(key=[23, int(circ)]))
+    dz = torch.from_numpy(g.standard_normal((B, cin, Hp, W), dtype=np.float32))
+    w = torch.from_numpy(g.standard_normal((cin, cout, 3, 3), dtype=np.float32) * 0.1)      # the layer's filter [its cout = cin here][its cin = cout here]
+    gate = torch.from_numpy(g.standard_normal((B, cout, 16, W), dtype=np.float32))
+    scale = torch.from_numpy((g.random((B, cout)) > 0.2).astype(np.float32) * 1.25)
+    pkt = ops.PackedConv(w.to(dev), None, transpose_flip=True)
+    xd = dz.to(dev).permute(0, 2, 3, 1).contiguous()
+    gd = gate.to(dev).permute(0, 2, 3, 1).contiguous()
+
+    def run():
+        return ops.conv3x3_fwd(xd, pkt, stride_h=1, circular=circ, relu=False, drop_scale=scale.to(dev), gate=gd, dilate_h=True, out_h=16)
+    prev = lib.witw_conv3x3_dil_skip(1)
+    try:
+        y1 = run()
+        assert ops.last_kernel_variant() == 'conv3x3_nhwc_f32_kernel<128,1,false,8,2,9>', ops.last_kernel_variant()
+        lib.witw_conv3x3_dil_skip(0)
+        y0 = run()
+        assert ops.last_kernel_variant() == 'conv3x3_nhwc_f32_kernel<128,1,false,8,0,9>', ops.last_kernel_variant()
+    finally:
+        lib.witw_conv3x3_dil_skip(prev)
+    assert torch.equal(y1, y0)
+    sel = [0, 13, 31]
+    up = torch.zeros((len(sel), cin, 16, W))
+    up[:, :, 0::2] = dz[sel]
+    wt = w.flip(2, 3).transpose(0, 1).contiguous()            # [cout, cin, 3, 3], taps rotated
+    ref = O.conv3x3(up, wt, torch.zeros(cout), 1, circ) * scale[sel][:, :, None, None] * (gate[sel] > 0)
+    np.testing.assert_allclose(y1[sel].cpu().permute(0, 3, 1, 2).numpy(), ref.numpy(), rtol=0, atol=3e-5 * float(ref.abs().max()))

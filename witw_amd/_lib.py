@@ -26,6 +26,7 @@ SIGNATURES = {
     'witw_nchw_to_nhwc8': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'witw_conv3x3_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),
     'witw_conv3x3_fwd_ex': (c_int, [c_void_p] * 9 + [c_int] * 8 + [c_float] + [c_int] * 3 + [c_void_p]),
+    'witw_conv3x3_dil_skip': (c_int, [c_int]),
     'witw_maxpool2x2_bwd': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     'witw_conv3x3_packed_floats_taps4': (c_longlong, [c_int, c_int]),
     'witw_conv3x3_pack_weights_taps4': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

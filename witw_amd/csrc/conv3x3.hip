@@ -68,14 +68,22 @@ struct ConvArgs {
 // GEO = shape of one MFMA M-tile (32 output pixels): 0 = 1 row x 32 columns, workgroup tile NW rows x 64 columns
 // (wide maps); 1 = 2 rows x 16 columns, workgroup tile 4*NW rows x 16 columns (maps up to 32 columns wide, e.g. the
 // fov-70 ground branch whose widths are 24 and 12 in the deep layers: a 64-column tile would idle 63-81 % of it).
+// GEO = 2 (round 5) = geometry 0 for a ZERO-INTERLEAVED input (dil_h: the dgrad of a stride-(2,1) layer, model/cvig_fov.py:263-272): every
+// odd logical input row is zero, so an M-tile on an even output row only meets data under tap row kh = 1 and one on an odd output
+// row under kh = 0 and 2 -- the other (M-tile, tap) products multiply staged zeros. This instantiation issues neither those MFMAs nor
+// their fragment reads: half the matrix work of the launch, the same sums bit for bit (a skipped product adds +-0). 8-wave 128-channel
+// tile only (its M-tiles are whole rows of known parity: row 2 wm + (mt >> 1) of an 8-row tile).
 // TAPS = 9: the full 3x3 window. TAPS = 4: a 2x2 sub-window of it (rows/columns tap_base + {0,1}): the cvig_baseline
 // Conv2d(k=4, s=2, p=0) (model/cvig_baseline.py:236-252) is a 2x2 convolution over the space-to-depth(2) image, i.e. the
 // 3x3 window whose first tap row and column are zero (dgrad: last row and column) — 4 of 9 taps carry all the work.
 template <int TN, int SH, bool POOL, int NW, int GEO, int TAPS = 9>
 __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_f32_kernel(ConvArgs p) {
     static_assert(TAPS == 9 || TAPS == 4, "3x3 window or a 2x2 sub-window");
-    constexpr int TH = GEO ? 4 * NW : NW;
-    constexpr int TW = GEO ? 16 : 64;
+    constexpr bool NARROW = GEO == 1;
+    constexpr bool DIL = GEO == 2;              // zero-interleaved input rows: dead (M-tile, tap) products are not issued
+    static_assert(!DIL || (TN == 128 && NW == 8 && SH == 1 && TAPS == 9 && !POOL), "the dilated form exists for the 8-wave 128-channel tile");
+    constexpr int TH = NARROW ? 4 * NW : NW;
+    constexpr int TW = NARROW ? 16 : 64;
     constexpr int IW = TW + 2;
     constexpr int NTHREADS = 64 * NW;
     constexpr int IH = (TH - 1) * SH + 3;
@@ -203,7 +211,7 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_f32_kernel(ConvArgs p) {
     int trow[WM], tcol[WM];  // first tile row / column of each M-tile of this wave
 #pragma unroll
     for (int mt = 0; mt < WM; ++mt) {
-        if (GEO) {                       // M-tile t covers tile rows 2t, 2t+1 and all 16 columns
+        if (NARROW) {                    // M-tile t covers tile rows 2t, 2t+1 and all 16 columns
             trow[mt] = 2 * ((TN == 128 ? 4 : 2) * wm + mt);
             tcol[mt] = 0;
         } else if (TN == 128) {
@@ -215,8 +223,8 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_f32_kernel(ConvArgs p) {
         }
     }
     // pixel m (0..31) of an M-tile -> (row, column) offset inside it
-    auto m_row = [](int m) { return GEO ? (m >> 4) : 0; };
-    auto m_col = [](int m) { return GEO ? (m & 15) : m; };
+    auto m_row = [](int m) { return NARROW ? (m >> 4) : 0; };
+    auto m_col = [](int m) { return NARROW ? (m & 15) : m; };
     int abase[WM];
 #pragma unroll
     for (int mt = 0; mt < WM; ++mt)
@@ -238,22 +246,28 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_f32_kernel(ConvArgs p) {
     // first fragments of the next chunk are fetched behind tap 8's MFMAs: the matrix pipe only
     // idles for the barrier skew.
     f32x4 fa[2][WM], fb[2][WN];
+    // DIL: M-tile mt sits on output row 2 wm + (mt >> 1) of an 8-row tile at an even oy0: its input row under tap row kh is real
+    // (even) iff (mt >> 1) + kh is odd
+    auto live = [](int mt, int tap) { return !DIL || ((((mt >> 1) + tap / 3) & 1) == 1); };
     auto read_frags = [&](int set, const f32x4* in_s, const f32x4* w_s, int tap) {
         const int kh = (TAPS == 4) ? (tap >> 1) : tap / 3, kw = (TAPS == 4) ? (tap & 1) : tap - kh * 3;
 #pragma unroll
-        for (int mt = 0; mt < WM; ++mt) fa[set][mt] = in_s[abase[mt] + kh * IW + kw];
+        for (int mt = 0; mt < WM; ++mt)
+            if (live(mt, tap)) fa[set][mt] = in_s[abase[mt] + kh * IW + kw];
 #pragma unroll
         for (int nt = 0; nt < WN; ++nt) fb[set][nt] = w_s[tap * 2 * TN + wbase + nt * 32];
     };
-    auto mfma_tap = [&](int set) {
+    auto mfma_tap = [&](int set, int tap) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int mt = 0; mt < WM; ++mt)
+                if (live(mt, tap)) {
 #pragma unroll
-                for (int nt = 0; nt < WN; ++nt)
-                    acc[mt][nt] =
-                        __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][mt][j], fb[set][nt][j], acc[mt][nt], 0, 0, 0);
+                    for (int nt = 0; nt < WN; ++nt)
+                        acc[mt][nt] =
+                            __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][mt][j], fb[set][nt][j], acc[mt][nt], 0, 0, 0);
+                }
     };
 
 #ifdef WITW_STAMPS
@@ -274,8 +288,8 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_f32_kernel(ConvArgs p) {
     // Issue-order recipe for one tap (LLVM sched groups: 0x8 MFMA, 0x20 VMEM read, 0x100 DS read,
     // 0x200 DS write): every LDS / global instruction is issued alone between MFMAs so that it
     // hides in the shadow of a 64-cycle v_mfma_f32_32x32x2_f32 instead of stalling the pipe.
-    constexpr int MPT = 4 * WM * WN;   // MFMAs per tap
-    constexpr int RPT = WM + WN;       // fragment reads per tap
+    constexpr int MPT = 4 * (DIL ? WM / 2 : WM) * WN;   // MFMAs per tap (DIL: half the M-tiles are live under any tap)
+    constexpr int RPT = (DIL ? WM / 2 : WM) + WN;       // fragment reads per tap
 #define SG_PLAIN_TAP()                                                  \
     do {                                                                \
         _Pragma("unroll") for (int i_ = 0; i_ < RPT; ++i_) {            \
@@ -312,18 +326,18 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_f32_kernel(ConvArgs p) {
             const f32x4* in_n = smem + (cur ^ 1) * STAGE_F4;
             read_frags(1, in_s, w_s, 1);
             load_stage(kn);
-            mfma_tap(0);
+            mfma_tap(0, 0);
             SG_HEAVY_TAP(0x020, NIN + NWT);
             read_frags(0, in_s, w_s, 2);
-            mfma_tap(1);
+            mfma_tap(1, 1);
             SG_PLAIN_TAP();
             read_frags(1, in_s, w_s, 3);
             store_stage(cur ^ 1);
-            mfma_tap(0);
+            mfma_tap(0, 2);
             SG_HEAVY_TAP(0x200, NIN + NWT);
             __syncthreads();
             read_frags(0, in_n, in_n + IN_F4, 0);
-            mfma_tap(1);
+            mfma_tap(1, 3);
             SG_PLAIN_TAP();
         }
     } else {
@@ -338,12 +352,12 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_f32_kernel(ConvArgs p) {
 #ifndef WITW_DIAG_NOSTAGE
             load_stage(kn);
 #endif
-            mfma_tap(0);
+            mfma_tap(0, 0);
             SG_HEAVY_TAP(0x020, NIN + NWT);
 #pragma unroll
             for (int tap = 1; tap < 4; ++tap) {
                 read_frags((tap + 1) & 1, in_s, w_s, tap + 1);
-                mfma_tap(tap & 1);
+                mfma_tap(tap & 1, tap);
                 SG_PLAIN_TAP();
             }
             // tap 4 (+ LDS writes of the next chunk)
@@ -351,12 +365,12 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_f32_kernel(ConvArgs p) {
 #ifndef WITW_DIAG_NOSTAGE
             store_stage(cur ^ 1);
 #endif
-            mfma_tap(0);
+            mfma_tap(0, 4);
             SG_HEAVY_TAP(0x200, NIN + NWT);
 #pragma unroll
             for (int tap = 5; tap < 8; ++tap) {
                 read_frags((tap + 1) & 1, in_s, w_s, tap + 1);
-                mfma_tap(tap & 1);
+                mfma_tap(tap & 1, tap);
                 SG_PLAIN_TAP();
             }
 #ifndef WITW_DIAG_NOBARRIER
@@ -364,7 +378,7 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_f32_kernel(ConvArgs p) {
 #endif
             // tap 8, behind which the first fragments of the next chunk arrive
             read_frags(1, in_n, in_n + IN_F4, 0);
-            mfma_tap(0);
+            mfma_tap(0, 8);
             SG_PLAIN_TAP();
 #pragma unroll
             for (int mt = 0; mt < WM; ++mt) fa[0][mt] = fa[1][mt];
@@ -478,7 +492,7 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_nhwc_f32_kernel(ConvArgs p) {
                     const int m = (r & 3) + 8 * (r >> 2) + 4 * hq;
                     emit(acc[mt][nt][r], nt, oy0 + trow[mt] + m_row(m), ox0 + tcol[mt] + m_col(m));
                 }
-    } else if (GEO) {
+    } else if (NARROW) {
         // Narrow geometry: both rows of a pooling window sit in ONE M-tile (registers r and r+8), its two columns in
         // registers r and r+1: 8 pooled pixels (1 row x 8 columns) per M-tile, all in-lane.
 #pragma unroll
@@ -636,8 +650,8 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, float* __restri
 
 template <int TN, int SH, bool POOL, int NW, int GEO, int TAPS = 9>
 int launch_conv_nw(ConvArgs a, hipStream_t st) {
-    a.tiles_y = cdiv(a.Ho, GEO ? 4 * NW : NW);
-    a.tiles_x = cdiv(a.Wo, GEO ? 16 : 64);
+    a.tiles_y = cdiv(a.Ho, GEO == 1 ? 4 * NW : NW);
+    a.tiles_x = cdiv(a.Wo, GEO == 1 ? 16 : 64);
     const long long sp_total = (long long)a.B * a.tiles_x * a.tiles_y;
     a.n_tiles = cdiv(a.Cout, TN);
     a.sp_per_xcd = (int)((sp_total + 7) / 8);
@@ -673,12 +687,28 @@ int env_int(const char* name, int dflt) {
     return e ? atoi(e) : dflt;
 }
 
+// 1 (default): the dgrad of a stride-(2,1) layer on the 8-wave 128-channel tile skips the products with zero-interleaved rows
+// (GEO = 2); 0: it multiplies them like any other (WITW_CONV_DILSKIP=0 / witw_conv3x3_dil_skip(0): A/B runs, the bitwise test)
+int g_dil_skip = -1;
+int dil_skip() {
+    if (g_dil_skip < 0) {
+        const char* e = getenv("WITW_CONV_DILSKIP");
+        g_dil_skip = e ? (atoi(e) != 0) : 1;
+    }
+    return g_dil_skip;
+}
+
 template <int TN, int SH, bool POOL>
 int launch_conv(const ConvArgs& a, hipStream_t st) {
 #ifndef WITW_NO_NARROW
     if (choose_narrow(a.Wo, a.force_geo)) return launch_conv_nw<TN, SH, POOL, 4, 1>(a, st);
 #endif
-    if (choose_waves(a.B, a.Ho, a.Wo, a.Cout, a.force_nw) == 8) return launch_conv_nw<TN, SH, POOL, 8, 0>(a, st);
+    if (choose_waves(a.B, a.Ho, a.Wo, a.Cout, a.force_nw) == 8) {
+        if constexpr (TN == 128 && SH == 1 && !POOL) {
+            if (a.dil_h && dil_skip()) return launch_conv_nw<TN, SH, POOL, 8, 2>(a, st);      // dead (M-tile, tap) products not issued
+        }
+        return launch_conv_nw<TN, SH, POOL, 8, 0>(a, st);
+    }
     return launch_conv_nw<TN, SH, POOL, 4, 0>(a, st);
 }
 
@@ -904,6 +934,14 @@ int witw_conv3x3_fwd_ex(const float* x, const float* wpk, const float* bias, con
     }
     if (stride_h == 2) return launch_conv<64, 2, false>(a, st);
     return pool ? launch_conv<64, 1, true>(a, st) : launch_conv<64, 1, false>(a, st);
+}
+
+// 1 (default): a zero-interleaved launch (dilate_h) on the 8-wave 128-channel tile does not issue the MFMAs whose input rows are
+// the interleaved zeros (half of them; same bits); 0: it issues them all. enable < 0 only queries. Returns the previous setting.
+int witw_conv3x3_dil_skip(int enable) {
+    const int prev = dil_skip();
+    if (enable >= 0) g_dil_skip = enable != 0;
+    return prev;
 }
 
 int witw_conv3x3_fwd(const float* x, const float* wpk, const float* bias, const float* dropmask, float* y, int B, int H,
