@@ -49,7 +49,9 @@ $P -d $O/prof_sem_bf16_train -- python3 bench.py --model semantic --mode train -
 $P -d $O/prof_sem_bf16 -- python3 bench.py --model semantic --precision bf16 --steps 5 --warmup 2 --detail-out $O/d.json > $O/semantic_bf16_under_rocprof.json 2> $O/prof_sem_bf16.log
 $P -d $O/prof_baseline -- python3 bench.py --mode baseline --no-cpu-baseline --detail-out $O/d.json > $O/baseline_under_rocprof.json 2> $O/prof_baseline.log
 $P -d $O/prof_retr_dft -- python3 bench.py --mode retrieval --match dft --steps 2 --warmup 1 --detail-out $O/d.json > $O/retrieval_dft_under_rocprof.json 2> $O/prof_retr_dft.log
-$P -d $O/prof_e2e_bf16 -- python3 bench.py --mode e2e --precision bf16 --workers 16 --e2e-pairs 4096 --detail-out $O/d.json > $O/e2e_bf16_under_rocprof.json 2> $O/prof_e2e_bf16.log
+# the e2e data path under rocprofv3 (16 forked loader workers + a spawn pool with the profiler's preload) hung once for the whole call
+# limit on 2026-10-04 after two clean runs the same day: run it on its own, under a timeout, when that table is wanted:
+#   timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/prof_e2e_bf16 -o p --output-format csv -- python3 bench.py --mode e2e --precision bf16 --workers 16 --e2e-pairs 4096 --no-decode-scaling
 rm -f $O/d.json
 echo stats done
 fi

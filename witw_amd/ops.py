@@ -162,11 +162,15 @@ def conv3x3_fwd(x_nhwc, packed, stride_h=1, circular=False, relu=True, pool=Fals
     B, H, W, C = x.shape
     if C != packed.cin_pad:
         raise _lib.WitwError('conv3x3_fwd: input has %d channels, packed weights expect %d' % (C, packed.cin_pad))
+    h_phys = H
     if dilate_h:
         if out_h is None or (out_h - 1) // 2 + 1 != H:
             raise _lib.WitwError('conv3x3_fwd: dilate_h needs out_h with (out_h-1)//2+1 == %d physical rows' % H)
         H = out_h          # logical (zero-interleaved) height
     Ho = (H + 2 - 3) // stride_h + 1
+    # algorithmic rows of the launch's FLOP count: a zero-interleaved launch is the data gradient of a stride-(2,1) conv, whose
+    # multiply-adds are those of that conv's forward (one per real input row), not one per interleaved row
+    flop_rows = h_phys if dilate_h else Ho
     Hy, Wy = (Ho // 2, W // 2) if pool else (Ho, W)
     shape = (B, packed.cout, Hy, Wy) if out_nchw else (B, Hy, Wy, packed.cout)
     y = torch.empty(shape, dtype=torch.float32, device=x.device)
@@ -203,7 +207,7 @@ def conv3x3_fwd(x_nhwc, packed, stride_h=1, circular=False, relu=True, pool=Fals
         e1.record()
         variant = (lib.witw_conv3x3_tile_n(packed.cout), stride_h, bool(pool),
                    lib.witw_conv3x3_workgroup_waves(B, H, W, packed.cout, stride_h))
-        prof.append((variant, 2.0 * packed.cin * packed.cout * (4 if getattr(packed, 'taps4', False) else 9) * Ho * W * B, e0, e1))
+        prof.append((variant, 2.0 * packed.cin * packed.cout * (4 if getattr(packed, 'taps4', False) else 9) * flop_rows * W * B, e0, e1))
         if PROFILE_BY_KERNEL is not None:
             PROFILE_BY_KERNEL.setdefault(last_kernel_variant(), []).append((prof[-1][1], e0, e1))
     if want_pool_code:
@@ -1145,7 +1149,7 @@ def conv3x3_bf16_fwd(x_nhwc, packed, stride_h=1, circular=False, relu=True, pool
     if dilate_h:
         if out_h is None or (out_h - 1) // 2 + 1 != H:
             raise _lib.WitwError('conv3x3_bf16_fwd: dilate_h needs out_h with (out_h-1)//2+1 == %d physical rows' % H)
-        H = out_h          # logical (zero-interleaved) height
+        h_phys, H = H, out_h          # logical (zero-interleaved) height
     Ho = (H + 2 - 3) // stride_h + 1
     Hy, Wy = (Ho // 2, W // 2) if pool else (Ho, W)
     if out_nchw_f32:
@@ -1175,7 +1179,7 @@ def conv3x3_bf16_fwd(x_nhwc, packed, stride_h=1, circular=False, relu=True, pool
         # the 64-input-channel layer runs on its own kernel (csrc/conv3x3_bf16_wres.hip): its own launch class
         kind = 'bf16_wres' if last_kernel_variant() == 'conv3x3_bf16_wres_kernel' else 'bf16'
         prof.append(((kind, lib.witw_conv3x3_tile_n(packed.cout), stride_h, bool(pool)),
-                     2.0 * packed.cin * packed.cout * 9 * Ho * W * B, e0, e1))
+                     2.0 * packed.cin * packed.cout * 9 * (h_phys if dilate_h else Ho) * W * B, e0, e1))      # dilated: see conv3x3_fwd
         if PROFILE_BY_KERNEL is not None:
             PROFILE_BY_KERNEL.setdefault(last_kernel_variant(), []).append((prof[-1][1], e0, e1))
     if want_pool_code:
@@ -1342,7 +1346,7 @@ def conv3x3_f16x3_fwd(x_split, packed, stride_h=1, circular=False, relu=True, po
     if dilate_h:
         if out_h is None or (out_h - 1) // 2 + 1 != H:
             raise _lib.WitwError('conv3x3_f16x3_fwd: dilate_h needs out_h with (out_h-1)//2+1 == %d physical rows' % H)
-        H = out_h
+        h_phys, H = H, out_h
     Ho = (H + 2 - 3) // stride_h + 1
     Hy, Wy = (Ho // 2, W // 2) if pool else (Ho, W)
     if out_nchw_f32:
@@ -1370,7 +1374,7 @@ def conv3x3_f16x3_fwd(x_split, packed, stride_h=1, circular=False, relu=True, po
     if prof is not None:
         e1.record()
         prof.append((('f16x3', lib.witw_conv3x3_tile_n(packed.cout), stride_h, bool(pool)),
-                     2.0 * packed.cin * packed.cout * 9 * Ho * W * B, e0, e1))
+                     2.0 * packed.cin * packed.cout * 9 * (h_phys if dilate_h else Ho) * W * B, e0, e1))      # dilated: see conv3x3_fwd
     if want_pool_code:
         return y, code
     return y
