@@ -1313,8 +1313,8 @@ def collectives_microbench(a, rank, world, device, phases=None, iters=10):
     out = {}
     for name, fn, nbytes, direct_s, ring_s in rows:
         us = timed(fn)
-        out[name] = {'bytes': int(nbytes), 'us': round(us, 1), 'algbw_GBps': round(nbytes / (us * 1e-6) / 1e9, 2),
-                     'xgmi_direct_bound_us': round(direct_s * 1e6, 1), 'frac_of_direct_bound': round(direct_s * 1e6 / us, 4),
+        out[name] = {'bytes': int(nbytes), 'us': round(us, 1), 'algbw_GBps': round(nbytes / (us * 1e-6) / 1e9, 4),
+                     'xgmi_direct_bound_us': round(direct_s * 1e6, 1), 'frac_of_direct_bound': round(direct_s * 1e6 / us, 6),
                      'xgmi_ring_bound_us': round(ring_s * 1e6, 1)}
     out['all_reduce_weight_grads_one_encoder']['per_step'] = 2
     if phases and 'reducer_wait_stall' in phases:

@@ -70,7 +70,8 @@ def test_bench_two_ranks_self_launched_infer():
     assert mb['all_reduce_weight_grads_one_encoder']['bytes'] == 7236432 * 4 and mb['all_reduce_weight_grads_one_encoder']['per_step'] == 2
     for name in ('all_gather_overhead_embeddings', 'reduce_scatter_overhead_grads', 'all_reduce_weight_grads_one_encoder'):
         m = mb[name]
-        assert m['us'] > 0 and m['algbw_GBps'] > 0 and 0 < m['frac_of_direct_bound'] < 1.0 and m['xgmi_ring_bound_us'] >= m['xgmi_direct_bound_us']
+        # (over gloo on a loaded host a 128 KB all-gather can take tens of ms: the rounded figures may be tiny, never negative)
+        assert m['us'] > 0 and m['algbw_GBps'] >= 0 and 0 <= m['frac_of_direct_bound'] < 1.0 and m['xgmi_ring_bound_us'] >= m['xgmi_direct_bound_us']
     assert 'microbench' not in one['collectives']
     # ... and which register-allocation guards were active (none may have tripped on the validated toolchain)
     for line in (one, two):
