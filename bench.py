@@ -157,7 +157,7 @@ class StepBench(object):
         self.ndiv = 3 if self.semantic else None      # only the RGB bands are /255 (model/cvig_semantic.py:172-176)
         self.step = self.train_step if self.train else self.infer_step
         self.pair = None
-        if pair and not self.train and precision in ('fp32', 'bf16') and batch <= 32:
+        if pair and not self.train and precision in ('fp32', 'bf16') and batch <= 64:
             self.se.precision = self.oe.precision = precision
             self.pair = cvig_fov.PairEmbedder(self.se, self.oe)
         if graph:
@@ -177,7 +177,9 @@ class StepBench(object):
         if self.pair is not None and precision is None:
             # the drivers' path at the reference's default batch sizes (cvig_fov.PairEmbedder: both encoders at once on two streams,
             # the bf16 pair as one hipGraph); inside a whole-step capture only the two-stream form
-            return self.pair._dual(surface, polar) if torch.cuda.is_current_stream_capturing() or self.graph else self.pair(surface, polar)
+            if torch.cuda.is_current_stream_capturing() or self.graph:
+                return (self.pair._dual if self.pair.dual_for(surface.shape[0]) else self.pair._plain)(surface, polar)
+            return self.pair(surface, polar)
         if p == 'fp16x3':
             return self.se.forward_f16x3(surface), self.oe.forward_f16x3(polar)
         if p == 'bf16':
@@ -821,7 +823,7 @@ def batch_sweep(a, rank, world, device, ops, compact=False):
             if not compact:
                 pt['kernels'] = {n: {'launches_per_step': agg[n][2] // k, 'ms_per_step': round(agg[n][1] / k, 4),
                                      'tflops': round(agg[n][0] / (agg[n][1] * 1e-3) / 1e12, 1)} for n in sorted(agg, key=lambda n: -agg[n][1])}
-            if B <= 32:
+            if B <= 64:
                 # what test() / the validation phase of train() run at this batch (cvig_fov.PairEmbedder: the two encoders on two
                 # streams, the bf16 pair as one hipGraph): THIS is `value`; the plain step stays listed beside it
                 dr = StepBench('fov', 'infer', precision, B, a.fov, rank, world, device, share=base, pair=True).run(k, 3)

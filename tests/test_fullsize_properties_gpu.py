@@ -180,7 +180,7 @@ def test_pair_embedder_equals_the_plain_calls_bitwise(precision):
         if precision == 'bf16':
             assert emb.stats['captures'] == before['captures'] + 1 and emb.stats['graph_replay'] == before['graph_replay'] + 2
         # above the thresholds: the plain path
-        s, p = batch(9, B=40)
+        s, p = batch(9, B=72)
         n_eager = emb.stats['eager']
         su, ov = emb(s, p)
         assert emb.stats['eager'] == n_eager + 1 and torch.equal(su, se(s)) and torch.equal(ov, oe(p))

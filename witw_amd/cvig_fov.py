@@ -1134,13 +1134,17 @@ class PairEmbedder(object):
         precision, weights) key has been seen twice its two forwards are captured (parallel.CapturedStep, both streams inside)
         and later batches of that key replay the graph. A weight update (validation after a training epoch) changes the key:
         the stale graph is dropped and a fresh one captured on the second batch.
+    Thresholds as measured (whole eval step, same box; docs/experiments.md): two streams help up to 32 pairs with the bf16 encoders
+    and up to 64 with the fp32 ones (+1.2 % at 64; at 64 bf16 pairs they cost 2 % inside a graph); the graph helps bf16 up to 64 pairs
+    (+2.4 % at 64, without the second stream there), fp32 never (its kernels are long).
 
     Either way the kernels, their order within an encoder and therefore the BITS are those of calling the encoders one after
     the other (tests/test_fullsize_properties_gpu.py). Gradient-recording calls and training-mode encoders take the plain path."""
 
-    def __init__(self, surface_encoder, overhead_encoder, graph_max=32, dual_max=32):
+    def __init__(self, surface_encoder, overhead_encoder, graph_max=64, dual_max=None):
+        """dual_max None: 32 pairs with bf16 encoders, 64 with fp32 ones (decided per call from the encoders' precision)"""
         self.se, self.oe = surface_encoder, overhead_encoder
-        self.graph_max, self.dual_max = graph_max, dual_max
+        self.graph_max, self._dual_max = graph_max, dual_max
         self._streams = None
         self._seen = {}
         self._graphs = {}
@@ -1173,16 +1177,23 @@ class PairEmbedder(object):
             polar.record_stream(s2)
         return su, ov
 
+    def dual_for(self, B):
+        """two streams at this batch? (the measured thresholds, see the class comment)"""
+        bf16 = self.se.precision == 'bf16' and self.oe.precision == 'bf16'
+        return B <= (self._dual_max if self._dual_max is not None else (32 if bf16 else 64))
+
     def __call__(self, surface, polar):
         from . import parallel
         B = surface.shape[0]
         plain = (torch.is_grad_enabled() or self.se.training or self.oe.training or not surface.is_cuda or B != polar.shape[0])
-        if plain or B > max(self.graph_max, self.dual_max):
+        bf16 = self.se.precision == 'bf16' and self.oe.precision == 'bf16'
+        graph_max = self.graph_max if bf16 else 0
+        dual = self.dual_for(B)
+        if plain or (B > graph_max and not dual):
             self.stats['eager'] += 1
             return self._plain(surface, polar)
-        dual = B <= self.dual_max
         body = self._dual if dual else self._plain
-        if B <= self.graph_max and self.se.precision == 'bf16' and self.oe.precision == 'bf16':
+        if B <= graph_max:
             key = self._key(surface, polar)
             g = self._graphs.get(key)
             if g is None and self._seen.get(key, 0) >= 1:
