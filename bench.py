@@ -394,6 +394,9 @@ def main():
     ap.add_argument('--no-side-blocks', action='store_true', help='only the headline measurement (no blocks for the other BASELINE configs)')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL); gloo only for 1-GPU self-tests')
     ap.add_argument('--single-device', action='store_true', help='self-test: put every rank on cuda:0')
+    ap.add_argument('--pg-of-one', action='store_true',
+                    help='self-test on a one-GPU box: one rank, but inside a REAL process group of world size 1 (backend nccl = RCCL): the '
+                         'collectives block and its microbench run through RCCL (every collective is then the identity)')
     ap.add_argument('--cpu-pairs', type=int, default=32, help='pairs of the batch the CPU oracle is timed on (cpu_baseline)')
     ap.add_argument('--e2e-pairs', type=int, default=4096)
     ap.add_argument('--decode', choices=['device', 'host'], default='device',
@@ -425,6 +428,17 @@ def main():
             dist.init_process_group('nccl', device_id=device)
         else:
             dist.init_process_group(a.backend)
+    elif a.pg_of_one:
+        import socket
+        sk = socket.socket()
+        sk.bind(('127.0.0.1', 0))
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', str(sk.getsockname()[1]))
+        sk.close()
+        if a.backend == 'nccl':
+            dist.init_process_group('nccl', rank=0, world_size=1, device_id=device)
+        else:
+            dist.init_process_group(a.backend, rank=0, world_size=1)
 
     from witw_amd import _lib, cvig_fov, ops
     _lib.check(_lib.load().witw_device_check(local), 'witw_device_check')
@@ -444,7 +458,7 @@ def main():
     bad = None
     if rank == 0:
         bad = emit(out, a)
-    if world > 1:
+    if world > 1 or a.pg_of_one:
         dist.destroy_process_group()
     if bad:
         sys.exit(bad)
@@ -468,7 +482,7 @@ def step_line(a, rank, world, device, cvig_fov, ops):
     out = sb.line()
     stamp('headline: %.1f pairs/s, %.3f ms per step' % (sb.value, sb.ms))
     out['collectives'] = collectives_info(a, rank, world, device, sb.phases, sb.ms)          # every rank takes part; rank 0 prints
-    if world > 1 and not a.no_microbench:
+    if (world > 1 or a.pg_of_one) and not a.no_microbench:
         out['collectives']['microbench'] = collectives_microbench(a, rank, world, device, sb.phases)
         stamp('collectives microbench')
     out['guards'] = guards_block(ops)
@@ -1243,7 +1257,7 @@ def collectives_info(a, rank, world, device, phases=None, step_ms=None):
         mine['pci_bus_id'] = torch.cuda.get_device_properties(device).pci_bus_id
     except Exception:
         pass
-    if world == 1:
+    if world == 1 and not (dist.is_available() and dist.is_initialized()):
         return {'backend': None, 'world': 1, 'rccl_version': None, 'ranks_seen': [0], 'devices': [mine],
                 'note': 'one rank: no process group, no collective on the path', **({'per_phase_ms': per_phase} if per_phase else {})}
     seen = [None] * world

@@ -32,8 +32,12 @@ def _run_bench(*args, timeout=900):
         p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--detail-out', detail] + list(args), env=env,
                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
         assert p.returncode == 0, p.stderr[-3000:]
-        lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
-        assert len(lines) == 1, p.stdout                      # exactly ONE line on stdout
+        every = [ln for ln in p.stdout.splitlines() if ln.strip()]
+        lines = [ln for ln in every if ln.startswith('{')]
+        # exactly ONE JSON line, and it is the LAST line of stdout (RCCL prints a version banner of its own on stdout when a
+        # communicator is created: 'RCCL version : ...' -- in front of the line, never behind it)
+        assert len(lines) == 1 and every[-1] == lines[0], p.stdout
+        assert all(not ln.startswith('{') for ln in every[:-1])
         assert len(lines[0]) < LINE_BUDGET, len(lines[0])     # ... that the driver's capture holds whole
         out = json.loads(lines[0])
         out['_detail'] = json.load(open(detail))
@@ -174,3 +178,16 @@ def test_semantic_driver_two_ranks(tmp_path):
     assert res[0][2] == res[1][2]
     sd = torch.load(os.path.join(root, 'weights', 'fov_70_surface_best.pth'))
     assert sd['model.features.0.weight'].shape == (64, 5, 3, 3)
+
+
+def test_bench_collectives_block_through_rccl_in_a_world_of_one():
+    """`--pg-of-one`: the bench's collectives block and microbench inside a real process group on backend nccl = RCCL (one rank: a second
+    one cannot share the test box's GPU) -- the RCCL-only branches of the N > 1 line (device_id init, RCCL version, all_gather_into_tensor,
+    the counted all-reduce) execute on hardware before the first multi-GPU run does."""
+    one = _run_bench('--gpus', '1', '--pg-of-one', '--steps', '1', '--warmup', '1', '--batch', '8', '--no-cpu-baseline', '--no-side-blocks')
+    c = one['collectives']
+    assert c['backend'] == 'nccl (RCCL)' and c['world'] == 1 and c['rccl_version'] and c['all_reduce_of_ones'] == 1.0 and c['ranks_seen'] == 1
+    mb = c['microbench']
+    for name in ('all_gather_overhead_embeddings', 'all_reduce_weight_grads_one_encoder'):
+        assert mb[name]['us'] > 0 and mb[name]['bytes'] > 0
+    assert one['n_gpus'] == 1 and one['recall']['N'] == 8 and np.isfinite(one['loss'])
