@@ -422,6 +422,25 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
+    # RCCL prints a version banner ('RCCL version : ...', 5 lines) on STDOUT when its first communicator is created: that happens
+    # inside this block (init with device_id + one warm-up collective), with file descriptor 1 pointed at stderr meanwhile, so that
+    # rank 0's stdout carries the ONE JSON line and nothing else
+    sys.stdout.flush()
+    fd_out = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        init_group(a, world, device)
+    finally:
+        sys.stdout.flush()
+        os.dup2(fd_out, 1)
+        os.close(fd_out)
+
+    from witw_amd import _lib, cvig_fov, ops
+    _lib.check(_lib.load().witw_device_check(local), 'witw_device_check')
+    run_mode(a, rank, world, local, device, _lib, cvig_fov, ops)
+
+
+def init_group(a, world, device):
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if a.backend == 'nccl':
@@ -439,9 +458,13 @@ def main():
             dist.init_process_group('nccl', rank=0, world_size=1, device_id=device)
         else:
             dist.init_process_group(a.backend, rank=0, world_size=1)
+    if dist.is_available() and dist.is_initialized():
+        warm = torch.ones(1, device=device)
+        dist.all_reduce(warm)                       # creates the communicator (and prints RCCL's banner) here
+        torch.cuda.synchronize()
 
-    from witw_amd import _lib, cvig_fov, ops
-    _lib.check(_lib.load().witw_device_check(local), 'witw_device_check')
+
+def run_mode(a, rank, world, local, device, _lib, cvig_fov, ops):
 
     if a.mode == 'retrieval':
         out = retrieval(a, rank, world, device, cvig_fov, ops)
