@@ -14,10 +14,21 @@
 //          same (surface, overhead): exactly the A operand (32 overheads x K=2) of
 //   GEMM 2 (one 32x32x2 MFMA per surface and slot): [32 overheads x (Re,Im)] x [(cos,-sin) x 32 shifts], accumulated over the
 //          slots into 16 x f32x16 registers per wave (all 256 accumulation registers of the wave).
+//          Round 5: the coefficients are the A operand and C the B operand, so the accumulator holds [32 shifts x 32 overheads]:
+//          a lane owns ONE overhead and 16 of the 32 shifts in its 16 registers (the other 16 sit in lane ^ 32).
 // Even frequencies give E[shift], odd ones O[shift] for shift < 32; score[shift] = E + O, score[shift+32] = E - O. The two
-// waves of a team exchange E / O through LDS, every lane then scans the 64 shifts of two pairs (first maximum wins, as
-// torch.argmax) and writes orientation / score / distance like match.hip does.
+// waves of a team exchange HALF of their tiles register for register through LDS (the E wave finishes surfaces 0-7 of the
+// team, the O wave 8-15: 16-byte writes and reads, no transposition), every lane scans its 16 shifts x {+, -} of a pair in
+// registers, joins the other half-wave's result (first maximum wins, as torch.argmax) and writes
+// orientation / score / distance like match.hip does.
 #include "common.h"
+
+#ifndef WITW_DFT_ASMXOR
+#define WITW_DFT_ASMXOR 0
+#endif
+#ifndef WITW_DFT_DMA16
+#define WITW_DFT_DMA16 0
+#endif
 
 namespace {
 
@@ -31,12 +42,7 @@ constexpr int ROW_F = 128;
 constexpr int A_F = 2 * 32 * ROW_F;    // [parity][32 surfaces]
 constexpr int B_F = 2 * 32 * ROW_F;    // [parity][32 overheads]
 constexpr int STAGE_F = A_F + B_F;     // 16384 floats
-constexpr int XS = 36;                 // row stride of the exchange region in floats: 144 B = 9 x 16, so a pair's 32 shifts are read as
-                                       // 8 ds_read_b128 (round 5; stride 33 forced 32 ds_read_b32) and 16 consecutive rows start on 16
-                                       // different 4-bank groups (36 i mod 64 takes every multiple of 4 once): conflict-free; the
-                                       // b32 writes of a lane half go to 32 consecutive floats of one row: conflict-free as before
-constexpr int XCH = 128 * XS;          // exchange region of an epilogue round: 128 pairs x 32 shifts
-constexpr int LDS_F = STAGE_F + ((STAGE_F > 4 * XCH) ? STAGE_F : 4 * XCH);      // stage 0 | stage 1 / the epilogue exchange
+constexpr int LDS_F = 2 * STAGE_F;     // stage 0 | stage 1 / the epilogue exchange (4 waves x 16 KB per round)
 
 __device__ __forceinline__ unsigned lds_address(const void* p) {
     return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)p;
@@ -71,6 +77,25 @@ __device__ __forceinline__ f32x2 lds_read64(unsigned addr) {
     asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
     return v;
 }
+// operand address of k-group U: base ^ (U << 4) (the slot swizzle). As asm so that it is issued where it is written, in the shadow
+// of the group's MFMAs (left to the compiler, all 45 of a step were hoisted in front of the step's first MFMA: ~250 idle cycles)
+template <int IMM>
+__device__ __forceinline__ unsigned lds_xor(unsigned addr) {
+#if WITW_DFT_ASMXOR
+    unsigned v;
+    asm volatile("v_xor_b32 %0, %1, %2" : "=v"(v) : "n"(IMM), "v"(addr));
+    return v;
+#else
+    return addr ^ (unsigned)IMM;
+#endif
+}
+// the step's inverse-transform coefficient, by hand as well (issued in group 14, covered by group 15's lgkmcnt(0)): a
+// compiler-issued LDS read would be waited for with lgkmcnt(0) at its use, behind the next step's operand reads already in flight
+__device__ __forceinline__ float lds_read32(unsigned addr) {
+    float v;
+    asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
 template <int N>
 __device__ __forceinline__ void lds_wait(f32x2& a, f32x2& b, f32x2& c, f32x2& d) {
     asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
@@ -90,6 +115,52 @@ __device__ __forceinline__ void mfma_v0(f32x16& acc, float a, float b) {
 // 16-pass XDL write -> VALU read of the result: 18 wait states (CDNA3 ISA, manually inserted wait states)
 __device__ __forceinline__ void mfma_settle(f32x16& x, f32x16& y) {
     asm volatile("s_nop 15\n\ts_nop 3" : "+v"(x), "+v"(y));
+}
+
+// One pair's 16 shifts of a lane (register q = shift (q & 3) + 8 (q >> 2) + 4 hk; the 4 hk is added by the caller) x {E + O at
+// that shift, E - O at shift + 32}: the largest value, its index in torch.argmax order (smallest index among equal values) and,
+// GAP, the runner-up value. max(E + O, E - O) = E + |O| and a negative O puts it at shift + 32 (O = -0 cannot come out of an
+// MFMA sum that started at +0), so the scan looks at 16 values instead of 32. The index travels as (sign bit of O | shift),
+// ordered like the arg-max index under an unsigned minimum; no comparison of O, whose VCC result would cost two wait states
+// before the v_cndmask that reads it (gfx950).
+constexpr unsigned NOKEY = 0xffffffffu;
+__device__ __forceinline__ unsigned umin(unsigned a, unsigned b) { return a < b ? a : b; }      // (min() resolves to the int overload)
+// lo / hi = the lower / upper half-wave's x, in every lane: v_permlane32_swap exchanges the first operand's lanes 32-63 with the
+// second one's lanes 0-31 (tools/debug/permlane_probe.cpp)
+template <typename T>
+__device__ __forceinline__ void half_swap(T x, T& lo, T& hi) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, x), false, false);
+    const unsigned r0 = r[0], r1 = r[1];      // (a __builtin_bit_cast of the element expression r[1] itself reads element 0)
+    lo = __builtin_bit_cast(T, r0);
+    hi = __builtin_bit_cast(T, r1);
+}
+template <bool GAP>
+__device__ __forceinline__ void scan16(const f32x16& E, const f32x16& O, float& best, unsigned& key, float& second) {
+    float m[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) m[q] = E[q] + fabsf(O[q]);
+    float v = -INFINITY;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v = fmaxf(v, m[q]);
+    unsigned k = NOKEY;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const unsigned c = (unsigned)((q & 3) + 8 * (q >> 2));
+        const float oq = O[q];      // (a __builtin_bit_cast of the element expression O[q] itself reads element 0 for every q)
+        const unsigned kq = (__builtin_bit_cast(unsigned, oq) & 0x80000000u) | c;      // v_and + v_or (as asm v_bfi_b32: more moves)
+        k = umin(k, m[q] == v ? kq : NOKEY);
+    }
+    best = v;
+    key = k;
+    if (GAP) {      // second largest of the 32 values: E - |O| never is the largest of its pair
+        float t = -INFINITY, s2 = -INFINITY;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            s2 = fmaxf(fmaxf(s2, fminf(m[q], t)), E[q] - fabsf(O[q]));
+            t = fmaxf(t, m[q]);
+        }
+        second = s2;
+    }
 }
 
 struct DftArgs {
@@ -160,7 +231,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // 64 distinct banks. A surface's P and Q halves are 256 B apart (the same banks) and are read by the part-0 / part-1 lanes of
     // one instruction, so the surface spectra are STORED with the two chunks of every Q slot exchanged (match_spectrum_kernel,
     // role 0) and a lane reading Q takes chunk hk ^ 1: P readers sit on banks 4c+{0,1}, Q readers on 4c+{2,3}.
-    const unsigned a_row = (unsigned)(par * 32 + team * 16 + j) * 512u + ((unsigned)j << 4);
+    // the odd wave takes the team's surfaces in the order j ^ 8: its accumulator r then belongs to surface r ^ 8, and in the
+    // epilogue BOTH waves keep registers 0-7 (the E wave surfaces 0-7, the O wave 8-15) and send registers 8-15
+    const int jr = j ^ (par << 3);
+    const unsigned a_row = (unsigned)(par * 32 + team * 16 + jr) * 512u + ((unsigned)jr << 4);
     const unsigned a_off1 = a_row + (part ? 256u + 8u * (hk ^ 1) : 8u * hk);
     const unsigned a_off2 = a_row + (part ? 8u * hk : 256u + 8u * (hk ^ 1));
     // the Im rows' minus sign (K < 64: -Q) is applied once per step: ca collects K < 64, cb K >= 64, and accumulator register r
@@ -170,8 +244,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // overheads with bit 4 of their index set are stored with the chunks of every slot exchanged (role 1) and read at hk ^ 1
     const unsigned b_off1 = (unsigned)(A_F + (par * 32 + l31) * ROW_F) * 4u + 8u * (hk ^ (l31 >> 4)) + ((unsigned)(l31 & 15) << 4);     // Q: + 256
     for (int t = tid; t < (NSLOT + 1) * 64; t += 256) dt_s[t] = t < NSLOT * 64 ? p.dtab[t] : 0.f;
-    // a global load here would sit at the end of every step with its whole latency exposed (measured: ~4.6k cycles per step)
-    auto dcoef = [&](int step) { return dt_s[(2 * step + par) * 64 + lane]; };
+    // (a global load of the step's coefficient would sit at the end of every step with its whole latency exposed: ~4.6k cycles per step)
 
     int s0, o0;
     tile_origin(blockIdx.x, s0, o0);
@@ -179,75 +252,116 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int n = 0; n < 16; ++n) dma_rows(n, 0, 0);        // the first tile's first stage; later ones are issued in the epilogue
 
+    // the wave's 16 x 16 long-lived accumulation registers; zeroed here and again at the end of every epilogue (behind the norm
+    // loads of the output phase, whose latency that hides)
+    f32x16 acc2[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc2[r][q] = 0.f;
+    const int par_u = wv & 1;            // scalar copy of par: the epilogue's two roles are a uniform branch
+
     int iter = 0;
 #pragma clang loop unroll(disable)
     for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, ++iter) {
     const bool rec = REC && p.stamps && blockIdx.x < 4 && iter == 1 && tid == 0;      // a steady-state tile of the first workgroups
     auto stamp = [&](int k) { if (rec) p.stamps[blockIdx.x * 64 + k] = __builtin_amdgcn_s_memrealtime(); };
     stamp(0);
-    f32x16 acc2[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) acc2[r][q] = 0.f;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    float dval = dcoef(0);
     stamp(1);
 
-    // step i: 64 GEMM-1 MFMAs with the 16 DMA instructions of step i+1's rows issued one per MFMA group into the other stage
-    // (free since the barrier that ended step i-1), then the 16 GEMM-2 MFMAs; the DMAs land before the step's barrier
+    // step i: 64 GEMM-1 MFMAs with the 16 DMA instructions of step i+1's rows issued two per MFMA group in the first 8 groups into
+    // the other stage (free since the barrier of step i-1), barrier, then the 16 GEMM-2 MFMAs of step i behind the first operand
+    // reads and the coefficient read of step i+1: the barrier sits BETWEEN the two GEMMs, so GEMM 2 (registers only) hides the LDS
+    // latency of the next step's first reads and the drain of the last GEMM-1 MFMAs overlaps the barrier wait (round 5; before,
+    // every step began with a barrier followed by the address arithmetic and the exposed latency of its first reads).
+    // Operands as ds_read_b64: a lane holds k = 4u + 2hk and 4u + 2hk + 1 of its row, i.e. MFMA step 2u + e covers k = 4u + e
+    // (lanes 0-31) and 4u + 2 + e (lanes 32-63) -- the same K permutation on both operands. Reads run two groups ahead; the
+    // compiler would fuse neighbours into ds_read2_b64 (banked like ds_read_b32), hence the asm.
+    f32x2 qa1[3], qb1[3], qa2[3], qb2[3];
+    unsigned xa1, xb1, xa2;
+    const unsigned dt0 = lds_address(dt_s) + (unsigned)(par * 64 + lane) * 4u;      // + step * 512
+    // read addresses of the 16 k-groups: base ^ (U << 4) (the slot swizzle), 48 registers that live across the step. They are
+    // formed between the GEMM-2 MFMAs of the previous step (groups 0 and 1 at the step head): inside the groups the compiler
+    // forms each address in the register the read is about to overwrite, which an MFMA in flight still names as its operand,
+    // and the step ran 7 % slower (measured, same box).
+    unsigned XA[16], XB[16], XC[16];
+#define WITW_DFT_FETCH(U)                                              \
+        {                                                              \
+            qa1[(U) % 3] = lds_read64<0>(XA[U]);                       \
+            qb1[(U) % 3] = lds_read64<0>(XB[U]);                       \
+            qa2[(U) % 3] = lds_read64<0>(XC[U]);                       \
+            qb2[(U) % 3] = lds_read64<256>(XB[U]);                     \
+        }
+#define WITW_DFT_ADDR(U)                                               \
+        {                                                              \
+            XA[U] = lds_xor<((U) << 4)>(xa1);                          \
+            XB[U] = lds_xor<((U) << 4)>(xb1);                          \
+            XC[U] = lds_xor<((U) << 4)>(xa2);                          \
+        }
+#define WITW_DFT_STEP_HEAD(STEP)                                       \
+        {                                                              \
+            const unsigned sb = lds0 + (unsigned)((STEP) & 1) * (STAGE_F * 4u); \
+            xa1 = sb + a_off1; xb1 = sb + b_off1; xa2 = sb + a_off2;   \
+            WITW_DFT_ADDR(0)                                           \
+            WITW_DFT_ADDR(1)                                           \
+            WITW_DFT_FETCH(0)                                          \
+            WITW_DFT_FETCH(1)                                          \
+        }
+    WITW_DFT_STEP_HEAD(0)
+#pragma unroll
+    for (int u = 2; u < 16; ++u) {      // (again for every tile: 42 instructions, and the 48 registers are free during the epilogue)
+        XA[u] = xa1 ^ (unsigned)(u << 4);
+        XB[u] = xb1 ^ (unsigned)(u << 4);
+        XC[u] = xa2 ^ (unsigned)(u << 4);
+    }
 #pragma clang loop unroll(disable)
     for (int i = 0; i < NSTEP; ++i) {
-        const float* st = smem + (i & 1) * STAGE_F;
         const int bufn = (i + 1) & 1;
         const int inext = min(i + 1, NSTEP - 1);
         f32x16 ca, cb;      // the first MFMA of each chain starts from C = 0
-        // operands as ds_read_b64: a lane holds k = 4u + 2hk and 4u + 2hk + 1 of its row, i.e. MFMA step 2u + e covers
-        // k = 4u + e (lanes 0-31) and 4u + 2 + e (lanes 32-63) -- the same K permutation on both operands. Reads run two
-        // groups ahead; the compiler would fuse neighbours into ds_read2_b64 (banked like ds_read_b32), hence the asm.
-        const unsigned sb = lds_address(st);
-        const unsigned xa1 = sb + a_off1, xb1 = sb + b_off1, xa2 = sb + a_off2;
-        f32x2 qa1[3], qb1[3], qa2[3], qb2[3];
-#define WITW_DFT_FETCH(U)                                              \
-        {                                                              \
-            qa1[(U) % 3] = lds_read64<0>(xa1 ^ (unsigned)((U) << 4));  \
-            const unsigned xb = xb1 ^ (unsigned)((U) << 4);            \
-            qb1[(U) % 3] = lds_read64<0>(xb);                          \
-            qa2[(U) % 3] = lds_read64<0>(xa2 ^ (unsigned)((U) << 4));  \
-            qb2[(U) % 3] = lds_read64<256>(xb);                        \
-        }
+        float dval;
 #define WITW_DFT_GROUP(U)                                                                                                      \
         {                                                                                                                      \
             constexpr int d = (U) % 3;                                                                                         \
-            if ((U) + 2 < 16) WITW_DFT_FETCH(((U) + 2) % 16)                                                                   \
+            if ((U) + 2 < 16) WITW_DFT_FETCH((U) + 2 < 16 ? (U) + 2 : 0)                                                       \
             if ((U) + 2 < 16) lds_wait<8>(qa1[d], qb1[d], qa2[d], qb2[d]);                                                     \
             else if ((U) + 1 < 16) lds_wait<4>(qa1[d], qb1[d], qa2[d], qb2[d]);                                                \
-            else lds_wait<0>(qa1[d], qb1[d], qa2[d], qb2[d]);                                                                  \
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qa1[d]), "+v"(qb1[d]), "+v"(qa2[d]), "+v"(qb2[d]), "+v"(dval));     \
+            if ((U) == 14) dval = lds_read32(dt0 + (unsigned)i * 512u);      /* the step's coefficient: waited for by group 15 */ \
             if ((U) == 0) mfma_v0(ca, qa1[d][0], qb1[d][0]); else mfma_v(ca, qa1[d][0], qb1[d][0]);                            \
-            dma_rows((U), inext, bufn);                                                                                        \
+            if (WITW_DFT_DMA16) dma_rows((U), inext, bufn); else if ((U) < 8) dma_rows(2 * (U), inext, bufn);                  \
             if ((U) == 0) mfma_v0(cb, qa2[d][0], qb2[d][0]); else mfma_v(cb, qa2[d][0], qb2[d][0]);                            \
+            if (!WITW_DFT_DMA16 && (U) < 8) dma_rows(2 * (U) + 1, inext, bufn);                                                \
             mfma_v(ca, qa1[d][1], qb1[d][1]);                                                                                  \
             mfma_v(cb, qa2[d][1], qb2[d][1]);                                                                                  \
         }
-        WITW_DFT_FETCH(0)
-        WITW_DFT_FETCH(1)
         WITW_DFT_GROUP(0) WITW_DFT_GROUP(1) WITW_DFT_GROUP(2) WITW_DFT_GROUP(3)
         WITW_DFT_GROUP(4) WITW_DFT_GROUP(5) WITW_DFT_GROUP(6) WITW_DFT_GROUP(7)
         WITW_DFT_GROUP(8) WITW_DFT_GROUP(9) WITW_DFT_GROUP(10) WITW_DFT_GROUP(11)
         WITW_DFT_GROUP(12) WITW_DFT_GROUP(13) WITW_DFT_GROUP(14) WITW_DFT_GROUP(15)
 #undef WITW_DFT_GROUP
-#undef WITW_DFT_FETCH
         stamp(2 + 3 * i);
-        mfma_settle(ca, cb);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc2[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(fmaf(ca[r], sg, cb[r]), dval, acc2[r], 0, 0, 0);
-        dval = dcoef(inext);
-        stamp(3 + 3 * i);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        stamp(3 + 3 * i);
+        if (i + 1 < NSTEP) WITW_DFT_STEP_HEAD(i + 1)
+        mfma_settle(ca, cb);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            acc2[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(dval, fmaf(ca[r], sg, cb[r]), acc2[r], 0, 0, 0);      // [shift][overhead]
+            if (r >= 2) {      // the next step's read addresses, in the shadow of this MFMA (groups 0 and 1: at the step head)
+                XA[r] = xa1 ^ (unsigned)(r << 4);
+                XB[r] = xb1 ^ (unsigned)(r << 4);
+                XC[r] = xa2 ^ (unsigned)(r << 4);
+            }
+        }
         stamp(4 + 3 * i);
     }
+#undef WITW_DFT_STEP_HEAD
+#undef WITW_DFT_FETCH
+#undef WITW_DFT_ADDR
 
     // ---- the next tile's first stage goes into stage 0 (free since the last barrier) while this tile's epilogue runs in the
     // area of stage 1 (the last step's redundant DMA into it has landed: vmcnt(0) before that barrier)
@@ -258,50 +372,86 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int n = 0; n < 16; ++n) dma_rows(n, 0, 0);
     }
-    // ---- epilogue, four rounds of 4 surfaces per team: E and O tiles -> LDS [pair][shift], then one pair per lane
-    float* xe = smem + STAGE_F + team * (2 * XCH);       // this team's E region, O region behind it
-    float* mine = xe + par * XCH;
-    const int tl = par * 64 + lane;            // lane of the team (0..127) = pair of the round: overhead tl >> 2, surface tl & 3
+    // ---- epilogue. acc2[r][q] of lane (l31, hk) = E (even wave) or O (odd wave) of surface r of the team, overhead l31, shift
+    // (q & 3) + 8 (q >> 2) + 4 hk (the odd wave: surface r ^ 8). Two rounds h: a wave sends registers 8 + 4h .. +3 (the partner's
+    // surfaces) and receives the partner's tiles of its own surfaces, registers 4h .. +3; LDS [wave][surface of the round][register quad][lane] x 16 B (conflict-free both ways).
+    float* xw = smem + STAGE_F + wv * 4096 + lane * 4;
+    const float* xr = smem + STAGE_F + (wv ^ 1) * 4096 + lane * 4;
+    float rv[8], rs[8];
+    int rk[8];
 #pragma unroll
-    for (int rd = 0; rd < 4; ++rd) {
+    for (int h = 0; h < 2; ++h) {
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int o = (q & 3) + 8 * (q >> 2) + 4 * hk;
-                mine[(o * 4 + rr) * XS + l31] = acc2[4 * rd + rr][q];
+            for (int qq = 0; qq < 4; ++qq) {
+                const f32x4 t = {acc2[8 + 4 * h + rr][4 * qq], acc2[8 + 4 * h + rr][4 * qq + 1], acc2[8 + 4 * h + rr][4 * qq + 2], acc2[8 + 4 * h + rr][4 * qq + 3]};
+                *reinterpret_cast<f32x4*>(xw + (rr * 4 + qq) * 256) = t;
             }
         __syncthreads();
-        {
-            const int rl = tl & 3, o = tl >> 2;
-            const f32x4* e4 = reinterpret_cast<const f32x4*>(xe + tl * XS);
-            const f32x4* o4 = reinterpret_cast<const f32x4*>(xe + tl * XS + XCH);
-            float vlo = -INFINITY, vhi = -INFINITY;
-            float slo = -INFINITY, shi = -INFINITY;      // GAP: runner-up of each half
-            int ilo = 0, ihi = 32;
 #pragma unroll
-            for (int sft = 0; sft < 32; ++sft) {
-                const float ev = e4[sft >> 2][sft & 3], ov = o4[sft >> 2][sft & 3];       // 16-byte loads, 4 shifts each
-                const float lo = ev + ov, hi = ev - ov;
-                if (GAP) {                                // before the maxima move: max(second, min(x, best so far))
-                    slo = fmaxf(slo, fminf(lo, vlo));
-                    shi = fmaxf(shi, fminf(hi, vhi));
-                }
-                if (lo > vlo) { vlo = lo; ilo = sft; }
-                if (hi > vhi) { vhi = hi; ihi = 32 + sft; }
+        for (int rr = 0; rr < 4; ++rr) {
+            f32x16 got;
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(xr + (rr * 4 + qq) * 256);
+                got[4 * qq] = t[0]; got[4 * qq + 1] = t[1]; got[4 * qq + 2] = t[2]; got[4 * qq + 3] = t[3];
             }
-            const float v = vhi > vlo ? vhi : vlo;
-            const int idx = vhi > vlo ? ihi : ilo;
-            const int s = s0c + team * 16 + 4 * rd + rl, og = o0c + o;
-            if (s < p.Bs && og < p.Bo) {
-                const size_t off = (size_t)og * p.Bs + s;
-                if (p.orientation) p.orientation[off] = idx;
-                if (p.score) p.score[off] = v;
-                if (p.distance) p.distance[off] = 2.f * (1.f - v / (p.wn[(size_t)og * 64 + idx] * p.sn[s]));
-                if (GAP && p.gap) p.gap[off] = v - fmaxf(fmaxf(slo, shi), fminf(vlo, vhi));
+            float v, s2 = 0.f;
+            unsigned k;
+            if (par_u == 0) scan16<GAP>(acc2[4 * h + rr], got, v, k, s2);      // kept: E, received: O
+            else scan16<GAP>(got, acc2[4 * h + rr], v, k, s2);
+            // the other 16 shifts of the pair sit in lane ^ 32 (4 further on for the upper half-wave)
+            float v0, v1;
+            unsigned kl, ku0;
+            half_swap(v, v0, v1);
+            half_swap(k, kl, ku0);
+            const unsigned ku = ku0 == NOKEY ? NOKEY : ku0 + 4u;
+            const float vc = fmaxf(v0, v1);
+            const unsigned kb = umin(v0 == vc ? kl : NOKEY, v1 == vc ? ku : NOKEY);
+            const int kc = kb == NOKEY ? 0 : (int)((kb & 63u) + ((kb >> 31) << 5));      // no finite maximum (NaN scores): index 0
+            rv[4 * h + rr] = vc;
+            rk[4 * h + rr] = kc;
+            if (GAP) {
+                float s0, s1;
+                half_swap(s2, s0, s1);
+                rs[4 * h + rr] = fmaxf(fmaxf(s0, s1), fminf(v0, v1));
             }
         }
-        __syncthreads();
+        if (h == 0) __syncthreads();      // the partner has read round 0 before round 1 overwrites it
+    }
+    // ---- output: both half-waves hold the 8 results of overhead l31; the lower one writes surfaces 0-3, the upper one 4-7. The
+    // window-norm loads are issued first, the accumulators are zeroed for the next tile behind them
+    {
+        const int og = o0c + l31;
+        float wnv[4], snv[4], vv[4], gg[4];
+        int kk[4];
+        bool ok[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            vv[jj] = hk ? rv[4 + jj] : rv[jj];
+            kk[jj] = hk ? rk[4 + jj] : rk[jj];
+            if (GAP) gg[jj] = hk ? rs[4 + jj] : rs[jj];
+            const int s = s0c + team * 16 + par * 8 + 4 * hk + jj;
+            ok[jj] = s < p.Bs && og < p.Bo;
+            wnv[jj] = (ok[jj] && p.distance) ? p.wn[(size_t)og * 64 + kk[jj]] : 1.f;
+            snv[jj] = (ok[jj] && p.distance) ? p.sn[s] : 1.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc2[r][q] = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int s = s0c + team * 16 + par * 8 + 4 * hk + jj;
+            if (ok[jj]) {
+                const size_t off = (size_t)og * p.Bs + s;
+                if (p.orientation) p.orientation[off] = kk[jj];
+                if (p.score) p.score[off] = vv[jj];
+                if (p.distance) p.distance[off] = 2.f * (1.f - vv[jj] / (wnv[jj] * snv[jj]));
+                if (GAP && p.gap) p.gap[off] = vv[jj] - gg[jj];
+            }
+        }
     }
     stamp(53);
     }   // tiles
@@ -448,7 +598,7 @@ static int match_fwd_dft_launch(const float* ov, const float* su, const float* s
         (void)hipMemcpy(h, a.stamps, (size_t)nrec * 64 * 8, hipMemcpyDeviceToHost);
         for (int b = 0; b < nrec && b < 4; ++b) {
             const unsigned long long* t = h + (size_t)b * 64;
-            fprintf(stderr, "match_dft workgroup %d, second tile: first-stage wait %.2f us; steps (gemm1, gemm2, barrier) us:", b, (t[1] - t[0]) * 0.01);
+            fprintf(stderr, "match_dft workgroup %d, second tile: first-stage wait %.2f us; steps (gemm1, barrier, gemm2) us:", b, (t[1] - t[0]) * 0.01);
             for (int i = 0; i < 17; ++i)
                 fprintf(stderr, " [%.2f %.2f %.2f]", (t[2 + 3 * i] - (i ? t[1 + 3 * i] : t[1])) * 0.01, (t[3 + 3 * i] - t[2 + 3 * i]) * 0.01,
                         (t[4 + 3 * i] - t[3 + 3 * i]) * 0.01);
