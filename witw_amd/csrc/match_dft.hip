@@ -23,6 +23,20 @@
 // orientation / score / distance like match.hip does.
 #include "common.h"
 
+// WITW_DFT_DIAG (diagnostic builds, wrong results): 1 = no staging DMA inside the steps, 2 = no barrier / vmcnt wait per step,
+// 4 = no operand reads inside the groups, 8 = the tile loop ends before the epilogue
+#ifndef WITW_DFT_DIAG
+#define WITW_DFT_DIAG 0
+#endif
+// WITW_DFT_AHEAD: how many k-groups the operand reads run ahead of the MFMAs (2 or 3)
+#ifndef WITW_DFT_AHEAD
+#define WITW_DFT_AHEAD 2
+#endif
+// WITW_DFT_PHASES=1 (diagnostic build): with WITW_DFT_STAMPS=2 in the environment the product instantiation sums s_memrealtime
+// over the step loops and over the epilogues of a workgroup's tiles; printed to stderr
+#ifndef WITW_DFT_PHASES
+#define WITW_DFT_PHASES 0
+#endif
 #ifndef WITW_DFT_ASMXOR
 #define WITW_DFT_ASMXOR 0
 #endif
@@ -261,12 +275,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int q = 0; q < 16; ++q) acc2[r][q] = 0.f;
     const int par_u = wv & 1;            // scalar copy of par: the epilogue's two roles are a uniform branch
 
+#if WITW_DFT_PHASES
+    const unsigned long long ph_k0 = __builtin_amdgcn_s_memrealtime(), ph_c0 = __builtin_amdgcn_s_memtime();
+    unsigned long long ph_s[2] = {0, 0}, ph_last = 0;      // [0] barrier -> end of the next GEMM 1 (GEMM 2 + GEMM 1), [1] the wait + barrier
+    unsigned long long ph_steps = 0, ph_epi = 0, ph_t0 = 0, ph_t1 = 0, ph_e[6] = {0, 0, 0, 0, 0, 0}, ph_m[6];      // scalar: s_memrealtime sums over this workgroup's tiles
+#endif
     int iter = 0;
 #pragma clang loop unroll(disable)
     for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, ++iter) {
     const bool rec = REC && p.stamps && blockIdx.x < 4 && iter == 1 && tid == 0;      // a steady-state tile of the first workgroups
     auto stamp = [&](int k) { if (rec) p.stamps[blockIdx.x * 64 + k] = __builtin_amdgcn_s_memrealtime(); };
     stamp(0);
+#if WITW_DFT_PHASES
+    ph_t0 = __builtin_amdgcn_s_memrealtime();
+    ph_last = ph_t0;
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     stamp(1);
@@ -279,7 +302,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // Operands as ds_read_b64: a lane holds k = 4u + 2hk and 4u + 2hk + 1 of its row, i.e. MFMA step 2u + e covers k = 4u + e
     // (lanes 0-31) and 4u + 2 + e (lanes 32-63) -- the same K permutation on both operands. Reads run two groups ahead; the
     // compiler would fuse neighbours into ds_read2_b64 (banked like ds_read_b32), hence the asm.
-    f32x2 qa1[3], qb1[3], qa2[3], qb2[3];
+    constexpr int NQ = WITW_DFT_AHEAD + 1;      // register slots of the operand ring
+    f32x2 qa1[NQ], qb1[NQ], qa2[NQ], qb2[NQ];
     unsigned xa1, xb1, xa2;
     const unsigned dt0 = lds_address(dt_s) + (unsigned)(par * 64 + lane) * 4u;      // + step * 512
     // read addresses of the 16 k-groups: base ^ (U << 4) (the slot swizzle), 48 registers that live across the step. They are
@@ -289,10 +313,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     unsigned XA[16], XB[16], XC[16];
 #define WITW_DFT_FETCH(U)                                              \
         {                                                              \
-            qa1[(U) % 3] = lds_read64<0>(XA[U]);                       \
-            qb1[(U) % 3] = lds_read64<0>(XB[U]);                       \
-            qa2[(U) % 3] = lds_read64<0>(XC[U]);                       \
-            qb2[(U) % 3] = lds_read64<256>(XB[U]);                     \
+            qa1[(U) % NQ] = lds_read64<0>(XA[U]);                       \
+            qb1[(U) % NQ] = lds_read64<0>(XB[U]);                       \
+            qa2[(U) % NQ] = lds_read64<0>(XC[U]);                       \
+            qb2[(U) % NQ] = lds_read64<256>(XB[U]);                     \
         }
 #define WITW_DFT_ADDR(U)                                               \
         {                                                              \
@@ -308,6 +332,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             WITW_DFT_ADDR(1)                                           \
             WITW_DFT_FETCH(0)                                          \
             WITW_DFT_FETCH(1)                                          \
+            if (WITW_DFT_AHEAD == 3) { WITW_DFT_ADDR(2) WITW_DFT_FETCH(2) }  \
         }
     WITW_DFT_STEP_HEAD(0)
 #pragma unroll
@@ -324,16 +349,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         float dval;
 #define WITW_DFT_GROUP(U)                                                                                                      \
         {                                                                                                                      \
-            constexpr int d = (U) % 3;                                                                                         \
-            if ((U) + 2 < 16) WITW_DFT_FETCH((U) + 2 < 16 ? (U) + 2 : 0)                                                       \
-            if ((U) + 2 < 16) lds_wait<8>(qa1[d], qb1[d], qa2[d], qb2[d]);                                                     \
-            else if ((U) + 1 < 16) lds_wait<4>(qa1[d], qb1[d], qa2[d], qb2[d]);                                                \
+            constexpr int d = (U) % NQ;                                                                                        \
+            constexpr int AH = WITW_DFT_AHEAD;                                                                                 \
+            if ((U) + AH < 16 && !(WITW_DFT_DIAG & 4)) WITW_DFT_FETCH((U) + AH < 16 ? (U) + AH : 0)                            \
+            if ((U) + AH < 16) lds_wait<4 * AH>(qa1[d], qb1[d], qa2[d], qb2[d]);                                               \
+            else if ((U) + 1 < 16) lds_wait<4 * (15 - (U) < AH ? 15 - (U) : AH)>(qa1[d], qb1[d], qa2[d], qb2[d]);              \
             else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qa1[d]), "+v"(qb1[d]), "+v"(qa2[d]), "+v"(qb2[d]), "+v"(dval));     \
             if ((U) == 14) dval = lds_read32(dt0 + (unsigned)i * 512u);      /* the step's coefficient: waited for by group 15 */ \
             if ((U) == 0) mfma_v0(ca, qa1[d][0], qb1[d][0]); else mfma_v(ca, qa1[d][0], qb1[d][0]);                            \
-            if (WITW_DFT_DMA16) dma_rows((U), inext, bufn); else if ((U) < 8) dma_rows(2 * (U), inext, bufn);                  \
+            if (WITW_DFT_DIAG & 1) {} else if (WITW_DFT_DMA16) dma_rows((U), inext, bufn); else if ((U) < 8) dma_rows(2 * (U), inext, bufn); \
             if ((U) == 0) mfma_v0(cb, qa2[d][0], qb2[d][0]); else mfma_v(cb, qa2[d][0], qb2[d][0]);                            \
-            if (!WITW_DFT_DMA16 && (U) < 8) dma_rows(2 * (U) + 1, inext, bufn);                                                \
+            if (!(WITW_DFT_DIAG & 1) && !WITW_DFT_DMA16 && (U) < 8) dma_rows(2 * (U) + 1, inext, bufn);                        \
             mfma_v(ca, qa1[d][1], qb1[d][1]);                                                                                  \
             mfma_v(cb, qa2[d][1], qb2[d][1]);                                                                                  \
         }
@@ -343,26 +369,50 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         WITW_DFT_GROUP(12) WITW_DFT_GROUP(13) WITW_DFT_GROUP(14) WITW_DFT_GROUP(15)
 #undef WITW_DFT_GROUP
         stamp(2 + 3 * i);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+#if WITW_DFT_PHASES
+        const unsigned long long pa = __builtin_amdgcn_s_memrealtime();
+#endif
+        if (!(WITW_DFT_DIAG & 2)) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+#if WITW_DFT_PHASES
+        const unsigned long long pb = __builtin_amdgcn_s_memrealtime();
+        ph_s[0] += pa - ph_last; ph_s[1] += pb - pa; ph_last = pb;
+#endif
         stamp(3 + 3 * i);
         if (i + 1 < NSTEP) WITW_DFT_STEP_HEAD(i + 1)
         mfma_settle(ca, cb);
+        // C = cb + sg * ca into 16 DIFFERENT registers before the first GEMM-2 MFMA: left to the compiler every product went through
+        // one register, and a VALU write to a register that the MFMA in flight names as its operand waits for that MFMA -- each
+        // of the 16 GEMM-2 MFMAs then cost ~90 cycles instead of 64 (the same effect as the address registers above)
+        float cc[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cc[r] = fmaf(ca[r], sg, cb[r]);
+        asm volatile("" : "+v"(cc[0]), "+v"(cc[1]), "+v"(cc[2]), "+v"(cc[3]), "+v"(cc[4]), "+v"(cc[5]), "+v"(cc[6]), "+v"(cc[7]),
+                          "+v"(cc[8]), "+v"(cc[9]), "+v"(cc[10]), "+v"(cc[11]), "+v"(cc[12]), "+v"(cc[13]), "+v"(cc[14]), "+v"(cc[15]));
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            acc2[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(dval, fmaf(ca[r], sg, cb[r]), acc2[r], 0, 0, 0);      // [shift][overhead]
+            acc2[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(dval, cc[r], acc2[r], 0, 0, 0);      // [shift][overhead]
             if (r >= 2) {      // the next step's read addresses, in the shadow of this MFMA (groups 0 and 1: at the step head)
                 XA[r] = xa1 ^ (unsigned)(r << 4);
                 XB[r] = xb1 ^ (unsigned)(r << 4);
                 XC[r] = xa2 ^ (unsigned)(r << 4);
             }
         }
+        // the 16 operand registers stay live up to here: otherwise the address registers above are allocated on top of them
+        asm volatile("" :: "v"(cc[0]), "v"(cc[1]), "v"(cc[2]), "v"(cc[3]), "v"(cc[4]), "v"(cc[5]), "v"(cc[6]), "v"(cc[7]),
+                           "v"(cc[8]), "v"(cc[9]), "v"(cc[10]), "v"(cc[11]), "v"(cc[12]), "v"(cc[13]), "v"(cc[14]), "v"(cc[15]));
         stamp(4 + 3 * i);
     }
 #undef WITW_DFT_STEP_HEAD
 #undef WITW_DFT_FETCH
 #undef WITW_DFT_ADDR
 
+#if WITW_DFT_PHASES
+    ph_t1 = __builtin_amdgcn_s_memrealtime();
+    ph_steps += ph_t1 - ph_t0;
+#endif
     // ---- the next tile's first stage goes into stage 0 (free since the last barrier) while this tile's epilogue runs in the
     // area of stage 1 (the last step's redundant DMA into it has landed: vmcnt(0) before that barrier)
     const int s0c = s0, o0c = o0;
@@ -371,6 +421,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         rs = tile_rsrc(s0, o0);
 #pragma unroll
         for (int n = 0; n < 16; ++n) dma_rows(n, 0, 0);
+    }
+    if (WITW_DFT_DIAG & 8) {
+        float t = 0.f;      // every accumulator stays live
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) t += acc2[r][q];
+        if (t == 12345.f && p.score) p.score[tile] = t;
+        continue;
     }
     // ---- epilogue. acc2[r][q] of lane (l31, hk) = E (even wave) or O (odd wave) of surface r of the team, overhead l31, shift
     // (q & 3) + 8 (q >> 2) + 4 hk (the odd wave: surface r ^ 8). Two rounds h: a wave sends registers 8 + 4h .. +3 (the partner's
@@ -389,6 +448,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 *reinterpret_cast<f32x4*>(xw + (rr * 4 + qq) * 256) = t;
             }
         __syncthreads();
+#if WITW_DFT_PHASES
+        asm volatile("" ::: "memory");
+        ph_m[2 * h] = __builtin_amdgcn_s_memrealtime();
+#endif
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
             f32x16 got;
@@ -418,6 +481,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 rs[4 * h + rr] = fmaxf(fmaxf(s0, s1), fminf(v0, v1));
             }
         }
+#if WITW_DFT_PHASES
+        asm volatile("" :: "v"(rv[4 * h]), "v"(rv[4 * h + 1]), "v"(rv[4 * h + 2]), "v"(rv[4 * h + 3]), "v"(rk[4 * h + 3]) : "memory");
+        ph_m[2 * h + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
         if (h == 0) __syncthreads();      // the partner has read round 0 before round 1 overwrites it
     }
     // ---- output: both half-waves hold the 8 results of overhead l31; the lower one writes surfaces 0-3, the upper one 4-7. The
@@ -454,7 +521,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
     }
     stamp(53);
+#if WITW_DFT_PHASES
+    asm volatile("" ::: "memory");
+    {
+        const unsigned long long te = __builtin_amdgcn_s_memrealtime();
+        ph_epi += te - ph_t1;
+        ph_e[0] += ph_m[0] - ph_t1; ph_e[1] += ph_m[1] - ph_m[0]; ph_e[2] += ph_m[2] - ph_m[1]; ph_e[3] += ph_m[3] - ph_m[2]; ph_e[4] += te - ph_m[3];
+    }
+#endif
     }   // tiles
+#if WITW_DFT_PHASES
+    if (p.stamps && blockIdx.x < 4 && tid == 0) {
+        p.stamps[blockIdx.x * 64 + 0] = ph_steps;
+        p.stamps[blockIdx.x * 64 + 1] = ph_epi;
+        p.stamps[blockIdx.x * 64 + 2] = (unsigned long long)iter;
+        for (int e = 0; e < 5; ++e) p.stamps[blockIdx.x * 64 + 3 + e] = ph_e[e];
+        p.stamps[blockIdx.x * 64 + 10] = __builtin_amdgcn_s_memrealtime() - ph_k0;
+        p.stamps[blockIdx.x * 64 + 11] = __builtin_amdgcn_s_memtime() - ph_c0;
+        p.stamps[blockIdx.x * 64 + 8] = ph_s[0];
+        p.stamps[blockIdx.x * 64 + 9] = ph_s[1];
+    }
+#endif
 }
 
 // spec[e][t][0..63] = Re X_t(line), [64..127] = Im X_t(line) (0 for t = 0, 32), X_t = sum_k x[line][k] e^{-2 pi i t k / 64}; fp64
@@ -590,6 +677,24 @@ static int match_fwd_dft_launch(const float* ov, const float* su, const float* s
         else (void)hipMemset(a.stamps, 0, (size_t)nrec * 64 * 8);
     }
     if (gap) hipLaunchKernelGGL((match_dft_kernel<false, true>), dim3(grid), dim3(256), 0, st, a);
+    else if (a.stamps && WITW_DFT_PHASES && getenv("WITW_DFT_STAMPS")[0] == '2') {
+        hipLaunchKernelGGL((match_dft_kernel<false, false>), dim3(grid), dim3(256), 0, st, a);
+        (void)hipDeviceSynchronize();
+        unsigned long long h[4 * 64];
+        (void)hipMemcpy(h, a.stamps, sizeof(h), hipMemcpyDeviceToHost);
+        for (int b = 0; b < 4; ++b)
+            fprintf(stderr, "match_dft workgroup %d: %llu tiles, steps %.2f us per tile, epilogue %.2f us per tile (send 0 + barrier %.2f, scans 0 %.2f, "
+                    "barrier + send 1 + barrier %.2f, scans 1 %.2f, output + zeroing %.2f)\n", b, h[b * 64 + 2],
+                    h[b * 64] * 0.01 / (double)h[b * 64 + 2], h[b * 64 + 1] * 0.01 / (double)h[b * 64 + 2], h[b * 64 + 3] * 0.01 / (double)h[b * 64 + 2],
+                    h[b * 64 + 4] * 0.01 / (double)h[b * 64 + 2], h[b * 64 + 5] * 0.01 / (double)h[b * 64 + 2], h[b * 64 + 6] * 0.01 / (double)h[b * 64 + 2],
+                    h[b * 64 + 7] * 0.01 / (double)h[b * 64 + 2]);
+        for (int b = 0; b < 4; ++b)
+            fprintf(stderr, "match_dft workgroup %d: per step, previous barrier -> end of GEMM 1 %.3f us, vmcnt wait + barrier %.3f us; s_memtime ticks per us %.1f\n", b,
+                    h[b * 64 + 8] * 0.01 / (17.0 * (double)h[b * 64 + 2]), h[b * 64 + 9] * 0.01 / (17.0 * (double)h[b * 64 + 2]),
+                    (double)h[b * 64 + 11] / ((double)h[b * 64 + 10] * 0.01));
+        (void)hipFree(a.stamps);
+        a.stamps = nullptr;
+    }
     else if (a.stamps) hipLaunchKernelGGL((match_dft_kernel<true, false>), dim3(grid), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((match_dft_kernel<false, false>), dim3(grid), dim3(256), 0, st, a);
     if (a.stamps) {
