@@ -205,10 +205,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // Persistent workgroups (one per CU: the LDS admits one anyway): workgroup b ranks tiles b, b + gridDim.x, ... Tile numbering
     // in 16 x 16 windows: consecutive tiles walk 16 overhead tiles of one surface tile, then the next surface tile, so the
     // resident workgroups share 16 + 16 tile spectra per slot (L2-resident while the slots advance together).
-    const long long n_tiles = (long long)p.nbx * p.nby;
-    auto tile_origin = [&](long long tile, int& s0_, int& o0_) {
-        const int per_group = 16 * p.nbx;
-        const int g = (int)(tile / per_group), within = (int)(tile - (long long)g * per_group);
+    const unsigned n_tiles = (unsigned)p.nbx * (unsigned)p.nby;      // < 2^31 (checked by the launcher): 32-bit tile arithmetic
+    auto tile_origin = [&](unsigned tile, int& s0_, int& o0_) {
+        const unsigned per_group = 16u * (unsigned)p.nbx;
+        const int g = (int)(tile / per_group), within = (int)(tile - (unsigned)g * per_group);
         const int rows = min(16, p.nby - 16 * g);
         o0_ = (16 * g + within % rows) * 32;
         s0_ = (within / rows) * 32;
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #endif
     int iter = 0;
 #pragma clang loop unroll(disable)
-    for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, ++iter) {
+    for (unsigned tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, ++iter) {
     const bool rec = REC && p.stamps && blockIdx.x < 4 && iter == 1 && tid == 0;      // a steady-state tile of the first workgroups
     auto stamp = [&](int k) { if (rec) p.stamps[blockIdx.x * 64 + k] = __builtin_amdgcn_s_memrealtime(); };
     stamp(0);
@@ -447,6 +447,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 const f32x4 t = {acc2[8 + 4 * h + rr][4 * qq], acc2[8 + 4 * h + rr][4 * qq + 1], acc2[8 + 4 * h + rr][4 * qq + 2], acc2[8 + 4 * h + rr][4 * qq + 3]};
                 *reinterpret_cast<f32x4*>(xw + (rr * 4 + qq) * 256) = t;
             }
+        // the sent registers are zeroed for the next tile here, in front of the barrier wait
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc2[8 + 4 * h + rr][q] = 0.f;
         __syncthreads();
 #if WITW_DFT_PHASES
         asm volatile("" ::: "memory");
@@ -505,7 +510,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             snv[jj] = (ok[jj] && p.distance) ? p.sn[s] : 1.f;
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
+        for (int r = 0; r < 8; ++r)      // (registers 8-15: behind their sends)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc2[r][q] = 0.f;
 #pragma unroll
@@ -666,6 +671,7 @@ static int match_fwd_dft_launch(const float* ov, const float* su, const float* s
     a.orientation = orientation; a.distance = distance; a.score = score; a.gap = gap;
     a.Bo = Bo; a.Bs = Bs; a.nbx = cdiv(Bs, 32); a.nby = cdiv(Bo, 32);
     const long long tiles = (long long)a.nbx * a.nby;
+    WITW_CHECK_ARG(tiles < (1LL << 31), "match_fwd_dft: %lld tiles of 32 x 32 pairs (the kernel counts tiles in 32 bits)", tiles);
     const int n_cu = witw_cu_count();        // persistent workgroups, one per CU
     const unsigned grid = (unsigned)(tiles < n_cu ? tiles : n_cu);
     // WITW_DFT_STAMPS=1 (diagnostic, synchronous): the first workgroups record s_memrealtime around the phases of their second
