@@ -55,6 +55,11 @@ $P -d $O/prof_retr_dft -- python3 bench.py --mode retrieval --match dft --steps 
 rm -f $O/d.json
 echo stats done
 fi
+if [ $PART = dft ]; then      # the spectral match only (its kernel changed after the other parts were taken)
+python3 bench.py --mode retrieval --match dft --steps 2 --warmup 1 --detail-out $O/d.json > $O/bench_retrieval_dft.json 2> $O/bench_retrieval_dft.err
+rocprofv3 --kernel-trace --stats -o p --output-format csv -d $O/prof_retr_dft -- python3 bench.py --mode retrieval --match dft --steps 2 --warmup 1 --detail-out $O/d.json > $O/retrieval_dft_under_rocprof.json 2> $O/prof_retr_dft.log
+fi
+if [ $PART = pmc ] || [ $PART = dft ]; then
 if [ $PART = pmc ]; then
 for m in "infer:" "bf16:--precision bf16" "sem_bf16:--model semantic --precision bf16" "train:--mode train" "bf16_train:--mode train --precision bf16"; do
   tag=${m%%:*}; flags=${m#*:}
@@ -76,6 +81,7 @@ python3 tools/make_mfma_util.py infer:$O/pmc_mfma_infer/p_counter_collection.csv
   bf16_train:$O/pmc_mfma_bf16_train/p_counter_collection.csv > $O/mfma_util.json
 bash tools/debug/pmc_pp.sh > $O/weight_resident_pmc.txt 2>&1
 bash tools/debug/pmc_polar.sh > $O/polar_from_raw_pmc.txt 2>&1
+fi
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES -d $O/pmc_dft_lds -o p --output-format csv -- python3 tools/pmc_match_dft.py > /dev/null 2> $O/pmc_dft_lds.log
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES -d $O/pmc_dft_clk -o p --output-format csv -- python3 tools/pmc_match_dft.py > /dev/null 2> $O/pmc_dft_clk.log
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_dft_fetch -o p --output-format csv -- python3 tools/pmc_match_dft.py > /dev/null 2> $O/pmc_dft_fetch.log
