@@ -98,7 +98,7 @@ __device__ __forceinline__ void wres_dma16(i32x4 rs, unsigned lds_addr, unsigned
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
                  :
                  : "s"(lds_addr), "v"(voff), "s"(rs)
-                 : "memory", "m0");
+                 : "memory");
 }
 
 __device__ unsigned long long wres_stamps[2][8];     // WITW_WRES_STAMPS=1 diagnostic: phase ticks of waves 0 and 4 (one per team), third iteration of workgroup 0

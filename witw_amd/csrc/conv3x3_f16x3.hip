@@ -45,7 +45,7 @@ __device__ __forceinline__ void dma16(i32x4 rs, unsigned lds_addr, unsigned voff
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                  :
                  : "s"(lds_addr), "v"(voff), "s"(rs), "s"(soff)
-                 : "memory", "m0");
+                 : "memory");
 #endif
 }
 
