@@ -117,7 +117,7 @@ int witw_match_fwd(const float* ov, const float* su, int Bo, int Bs, int We, lon
 /* The same match through the row spectra (retrieval, BASELINE config 5: every gallery row against every query). The orientation
  * search is a circular cross-correlation along the 64 columns: with the 64-point DFT of every (channel,row) line of both sides it
  * costs 21k FLOP per pair instead of 524k. witw_match_spectrum: emb [B,64 lines,W] (overhead: W = 64; surface: W = We, zero-
- * padded) -> spec [B,33,128] (witw_match_spectrum_floats(B) floats; fp64 transform rounded once to fp32; the order of the two
+ * padded) -> spec [B,32,128] (witw_match_spectrum_floats(B) floats; fp64 transform rounded once to fp32; the order of the two
  * 8-byte chunks inside each 16-byte slot depends on the side -- `role` -- and, for overheads, on bit 4 of the embedding's index, so
  * that the match kernel's LDS operand reads are free of bank conflicts: a spectrum is only meaningful to witw_match_fwd_dft, on the
  * side and at the row numbering (mod 32) it was computed for). witw_match_fwd_dft:

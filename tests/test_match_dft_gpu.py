@@ -96,6 +96,30 @@ def test_dft_match_true_pairs_and_ties():
     assert (np.diagonal(ori) % 16 == 5).all()
 
 
+def test_dft_match_degenerate_inputs():
+    """All-zero embeddings (every shift ties at score 0: torch.argmax's first index, 0, as the direct kernel gives), a zero
+    surface against random overheads, and NaN embeddings (no finite maximum: index 0, nothing out of range is read)."""
+    from witw_amd import ops
+    rng = np.random.default_rng(11)
+    z_ov, z_su = torch.zeros((40, 16, 4, 64), device='cuda'), torch.zeros((70, 16, 4, 64), device='cuda')
+    ori = ops.match_fwd_dft(z_ov, z_su)[0]
+    assert torch.equal(ori, torch.zeros_like(ori)) and torch.equal(ori, ops.match_fwd(z_ov, z_su)[0])
+    ov = torch.from_numpy(rng.standard_normal((40, 16, 4, 64)).astype(np.float32)).cuda()
+    ori = ops.match_fwd_dft(ov, z_su)[0]
+    assert torch.equal(ori, torch.zeros_like(ori))
+    nan_su = torch.full((70, 16, 4, 64), float('nan'), device='cuda')
+    ori, dist = ops.match_fwd_dft(ov, nan_su)
+    torch.cuda.synchronize()
+    assert int(ori.min()) >= 0 and int(ori.max()) <= 63
+    # half of the surfaces NaN: the finite ones are untouched by their neighbours in the tile
+    su = torch.from_numpy(rng.standard_normal((70, 16, 4, 64)).astype(np.float32)).cuda()
+    mixed = su.clone()
+    mixed[::2] = float('nan')
+    o_ref, d_ref = ops.match_fwd_dft(ov, su)
+    o_mix, d_mix = ops.match_fwd_dft(ov, mixed)
+    assert torch.equal(o_mix[:, 1::2], o_ref[:, 1::2]) and torch.equal(d_mix[:, 1::2], d_ref[:, 1::2])
+
+
 @pytest.mark.parametrize('shape', [(7, 5, 64), (130, 257, 64), (1100, 260, 64), (1100, 260, 63), (1100, 300, 12), (1100, 300, 31),
                                    (1100, 300, 40), (40, 9, 1), (2100, 70, 16), (128, 128, 64), (128, 128, 12), (128, 128, 30), (100, 77, 64)])
 def test_match_pairs_bit_identical_to_match_fwd(shape):

@@ -5,7 +5,8 @@
 // over the 64 (channel,row) lines. With X_f = sum_k x[k] e^{-2 pi i f k/64} per line (su zero-padded to 64 columns):
 //   C_f[o,s]   = sum_ch OV_f[o,ch] * conj(SU_f[s,ch])                                  f = 0..32
 //   score[o,s,shift] = (1/64) [ C_0 + (-1)^shift C_32 + 2 sum_{f=1..31} (Re C_f cos(2 pi f shift/64) - Im C_f sin(..)) ]
-// 2*2*128*33 + 2*2*32*33 = 21k FLOP per pair instead of 2*64*4096 = 524k of the direct form (match.hip), both on the fp32 MFMA.
+// 2*2*128*33 + 2*2*32*33 = 21k FLOP per pair instead of 2*64*4096 = 524k of the direct form (match.hip), both on the fp32 MFMA
+// (the algorithmic count; the kernel runs 32 slots: the real spectra at f = 0 and f = 32 share one, see NSLOT).
 //
 // Kernel: persistent workgroups (one per CU), a tile = 32 surfaces x 32 overheads, 4 waves = 2 surface teams x {even, odd}
 // frequencies. Per frequency slot
@@ -46,9 +47,12 @@
 
 namespace {
 
-constexpr int NSLOT = 33;              // frequency slots 0..32 ([P(64 lines) | Q(64 lines)] each; Q = 0 for slots 0 and 32)
-constexpr int SPEC = NSLOT * 128;      // floats per embedding spectrum
-constexpr int NSTEP = 17;              // step i: even waves slot 2i, odd waves slot 2i+1 (slot 33 reads zeros)
+// Storage slots of a spectrum, [P(64 lines) | Q(64 lines)] each: slot t = 1..31 holds (Re, Im) of frequency t; the spectra at
+// frequencies 0 and 32 are real, and slot 0 holds BOTH: P = X_0, Q = X_32 (round 5: 33 -> 32 slots, 17 -> 16 steps per tile, and
+// no phantom 34th slot whose reads -- a neighbour's values times a zero coefficient -- let a NaN embedding reach the row before it)
+constexpr int NSLOT = 32;
+constexpr int SPEC = NSLOT * 128;      // floats per embedding spectrum (16 KB)
+constexpr int NSTEP = 16;              // step i: even waves slot 2i, odd waves slot 2i+1
 // LDS rows: 128 floats [P 64 | Q 64], unpadded (a 16-byte LDS-DMA writes 1 KB = two whole rows contiguously), with the 16-byte
 // slots of each half XOR-swizzled by (row & 15): logical slot c of row r sits at slot c ^ (r & 15). ds_read_b64 of one k-group
 // by 32 rows then touches every bank pair twice (rows r and r+16, and a surface's P and Q halves): 2-way, 4 LDS cycles.
@@ -178,9 +182,9 @@ __device__ __forceinline__ void scan16(const f32x16& E, const f32x16& O, float& 
 }
 
 struct DftArgs {
-    const float* spec_ov;    // [Bo][33][128]
-    const float* spec_su;    // [Bs][33][128]
-    const float* dtab;       // [33][64]: lane (hk, shift) -> inverse-transform coefficient of (Re | Im) at that shift
+    const float* spec_ov;    // [Bo][32][128]
+    const float* spec_su;    // [Bs][32][128]
+    const float* dtab;       // [32][64]: lane (hk, shift) -> inverse-transform coefficient of the slot's (Re | Im) at that shift
     const float* wn;         // [Bo,64] window norms per shift
     const float* sn;         // [Bs]    surface norms
     long long* orientation;  // [Bo,Bs] or null
@@ -197,7 +201,7 @@ struct DftArgs {
 template <bool REC, bool GAP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void match_dft_kernel(DftArgs p) {
     __shared__ __attribute__((aligned(1024))) float smem[LDS_F];      // the read addresses XOR bits 4-7: stage bases stay 1 KB-aligned
-    __shared__ float dt_s[(NSLOT + 1) * 64];      // inverse-transform coefficients; the extra slot (odd waves' 17th) is 0
+    __shared__ float dt_s[NSLOT * 64];      // inverse-transform coefficients
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hk = lane >> 5;
     const int team = wave >> 1, par = wave & 1;
@@ -251,13 +255,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const unsigned a_row = (unsigned)(par * 32 + team * 16 + jr) * 512u + ((unsigned)jr << 4);
     const unsigned a_off1 = a_row + (part ? 256u + 8u * (hk ^ 1) : 8u * hk);
     const unsigned a_off2 = a_row + (part ? 8u * hk : 256u + 8u * (hk ^ 1));
+    // slot 0 (the even waves' first step) holds two REAL spectra, P = X_0 and Q = X_32: there the Im rows read what the Re rows
+    // read, so that lanes 0-31 of the accumulators end up with C_0 + C_32 and lanes 32-63 (C = cb + sg * ca) with C_32 - C_0 --
+    // the coefficient table of slot 0 turns them into (C_0 + (-1)^shift C_32) / 64
+    const unsigned a_off1z = par ? a_off1 : a_row + 8u * hk;
+    const unsigned a_off2z = par ? a_off2 : a_row + 256u + 8u * (hk ^ 1);
     // the Im rows' minus sign (K < 64: -Q) is applied once per step: ca collects K < 64, cb K >= 64, and accumulator register r
     // holds Re C in lanes 0-31 and Im C in lanes 32-63, so C = cb + sg * ca with sg = -1 in the upper half-wave
     const float sg = hk ? -1.f : 1.f;
     // overheads: one instruction reads one half of 32 different rows; rows r and r + 16 share the slot swizzle, so the spectra of
     // overheads with bit 4 of their index set are stored with the chunks of every slot exchanged (role 1) and read at hk ^ 1
     const unsigned b_off1 = (unsigned)(A_F + (par * 32 + l31) * ROW_F) * 4u + 8u * (hk ^ (l31 >> 4)) + ((unsigned)(l31 & 15) << 4);     // Q: + 256
-    for (int t = tid; t < (NSLOT + 1) * 64; t += 256) dt_s[t] = t < NSLOT * 64 ? p.dtab[t] : 0.f;
+    for (int t = tid; t < NSLOT * 64; t += 256) dt_s[t] = p.dtab[t];
     // (a global load of the step's coefficient would sit at the end of every step with its whole latency exposed: ~4.6k cycles per step)
 
     int s0, o0;
@@ -324,17 +333,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             XB[U] = lds_xor<((U) << 4)>(xb1);                          \
             XC[U] = lds_xor<((U) << 4)>(xa2);                          \
         }
-#define WITW_DFT_STEP_HEAD(STEP)                                       \
+#define WITW_DFT_STEP_HEAD(STEP, SLOT0)                                \
         {                                                              \
             const unsigned sb = lds0 + (unsigned)((STEP) & 1) * (STAGE_F * 4u); \
-            xa1 = sb + a_off1; xb1 = sb + b_off1; xa2 = sb + a_off2;   \
+            xa1 = sb + ((SLOT0) ? a_off1z : a_off1); xb1 = sb + b_off1; xa2 = sb + ((SLOT0) ? a_off2z : a_off2); \
             WITW_DFT_ADDR(0)                                           \
             WITW_DFT_ADDR(1)                                           \
             WITW_DFT_FETCH(0)                                          \
             WITW_DFT_FETCH(1)                                          \
             if (WITW_DFT_AHEAD == 3) { WITW_DFT_ADDR(2) WITW_DFT_FETCH(2) }  \
         }
-    WITW_DFT_STEP_HEAD(0)
+    WITW_DFT_STEP_HEAD(0, true)
 #pragma unroll
     for (int u = 2; u < 16; ++u) {      // (again for every tile: 42 instructions, and the 48 registers are free during the epilogue)
         XA[u] = xa1 ^ (unsigned)(u << 4);
@@ -381,7 +390,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         ph_s[0] += pa - ph_last; ph_s[1] += pb - pa; ph_last = pb;
 #endif
         stamp(3 + 3 * i);
-        if (i + 1 < NSTEP) WITW_DFT_STEP_HEAD(i + 1)
+        if (i + 1 < NSTEP) WITW_DFT_STEP_HEAD(i + 1, false)
         mfma_settle(ca, cb);
         // C = cb + sg * ca into 16 DIFFERENT registers before the first GEMM-2 MFMA: left to the compiler every product went through
         // one register, and a VALU write to a register that the MFMA in flight names as its operand waits for that MFMA -- each
@@ -566,7 +575,7 @@ __global__ __launch_bounds__(256) void match_spectrum_kernel(const float* __rest
     }
     __syncthreads();
     float* out = spec + (size_t)blockIdx.x * SPEC;
-    for (int t = tq; t < NSLOT; t += 4) {
+    for (int t = tq; t <= 32; t += 4) {      // frequencies 0..32; X_0 and X_32 are real and share storage slot 0 (P = X_0, Q = X_32)
         double pr = 0.0, pi = 0.0;
         for (int k = 0; k < W; ++k) {
             const int idx = (t * k) & 63;
@@ -576,17 +585,21 @@ __global__ __launch_bounds__(256) void match_spectrum_kernel(const float* __rest
         }
         const int swap_p = (role == 1 && (blockIdx.x & 16)) ? 2 : 0;      // float index ^ 2 = the other 8-byte chunk of the slot
         const int swap_q = (role == 0 || (blockIdx.x & 16)) ? 2 : 0;
-        out[t * 128 + (line ^ swap_p)] = (float)pr;
-        out[t * 128 + 64 + (line ^ swap_q)] = (t == 0 || t == 32) ? 0.f : (float)pi;
+        if (t == 32) out[64 + (line ^ swap_q)] = (float)pr;
+        else {
+            out[t * 128 + (line ^ swap_p)] = (float)pr;
+            if (t != 0) out[t * 128 + 64 + (line ^ swap_q)] = (float)pi;
+        }
     }
 }
 
-// dtab[t][hk*32 + shift]: coefficient of Re C_t (hk = 0) / Im C_t (hk = 1) in score[shift], shift < 32
+// dtab[t][hk*32 + shift]: coefficient of lanes 0-31 (hk = 0) / 32-63 (hk = 1) of slot t's C in score[shift], shift < 32. Slots
+// 1..31: Re C_t / Im C_t. Slot 0: the kernel leaves C_0 + C_32 in lanes 0-31 and C_32 - C_0 in lanes 32-63, and
+// (C_0 + (-1)^shift C_32) / 64 is the former at even shifts and minus the latter at odd ones
 __global__ void match_dft_table_kernel(float* __restrict__ dtab) {
     const int t = blockIdx.x, lane = threadIdx.x, shift = lane & 31, hk = lane >> 5;
     double v;
-    if (t == 0) v = hk ? 0.0 : 1.0 / 64.0;
-    else if (t == 32) v = hk ? 0.0 : ((shift & 1) ? -1.0 : 1.0) / 64.0;
+    if (t == 0) v = hk ? ((shift & 1) ? -1.0 / 64.0 : 0.0) : ((shift & 1) ? 0.0 : 1.0 / 64.0);
     else {
         const double ang = (double)((t * shift) & 63) / 32.0;
         v = hk ? -sinpi(ang) / 32.0 : cospi(ang) / 32.0;
@@ -635,10 +648,10 @@ __global__ __launch_bounds__(256) void dft_row_norm_kernel(const float* __restri
 
 extern "C" {
 
-// floats of one embedding's row spectrum (33 slots x [64 re | 64 im])
+// floats of one embedding's row spectrum (32 slots x [64 re | 64 im]; slot 0: [X_0 | X_32])
 long long witw_match_spectrum_floats(long long n_embeddings) { return n_embeddings * (long long)SPEC; }
 
-// emb [B,64 lines,W] (an overhead embedding [B,16,4,64], role 1, or a surface embedding [B,16,4,We], role 0) -> spec [B,33,128]
+// emb [B,64 lines,W] (an overhead embedding [B,16,4,64], role 1, or a surface embedding [B,16,4,We], role 0) -> spec [B,32,128]
 // in the chunk order the match kernel's operand reads expect of that side (an overhead's spectrum depends on its index & 16:
 // spectra of a gallery must be computed at the row numbering they are matched at, multiples of 32 apart)
 int witw_match_spectrum(const float* emb, float* spec, int B, int W, int role, void* stream) {
@@ -696,7 +709,7 @@ static int match_fwd_dft_launch(const float* ov, const float* su, const float* s
                     h[b * 64 + 7] * 0.01 / (double)h[b * 64 + 2]);
         for (int b = 0; b < 4; ++b)
             fprintf(stderr, "match_dft workgroup %d: per step, previous barrier -> end of GEMM 1 %.3f us, vmcnt wait + barrier %.3f us; s_memtime ticks per us %.1f\n", b,
-                    h[b * 64 + 8] * 0.01 / (17.0 * (double)h[b * 64 + 2]), h[b * 64 + 9] * 0.01 / (17.0 * (double)h[b * 64 + 2]),
+                    h[b * 64 + 8] * 0.01 / ((double)NSTEP * (double)h[b * 64 + 2]), h[b * 64 + 9] * 0.01 / ((double)NSTEP * (double)h[b * 64 + 2]),
                     (double)h[b * 64 + 11] / ((double)h[b * 64 + 10] * 0.01));
         (void)hipFree(a.stamps);
         a.stamps = nullptr;
@@ -710,10 +723,10 @@ static int match_fwd_dft_launch(const float* ov, const float* su, const float* s
         for (int b = 0; b < nrec && b < 4; ++b) {
             const unsigned long long* t = h + (size_t)b * 64;
             fprintf(stderr, "match_dft workgroup %d, second tile: first-stage wait %.2f us; steps (gemm1, barrier, gemm2) us:", b, (t[1] - t[0]) * 0.01);
-            for (int i = 0; i < 17; ++i)
+            for (int i = 0; i < NSTEP; ++i)
                 fprintf(stderr, " [%.2f %.2f %.2f]", (t[2 + 3 * i] - (i ? t[1 + 3 * i] : t[1])) * 0.01, (t[3 + 3 * i] - t[2 + 3 * i]) * 0.01,
                         (t[4 + 3 * i] - t[3 + 3 * i]) * 0.01);
-            fprintf(stderr, "; epilogue %.2f us; total %.2f us\n", (t[53] - t[52]) * 0.01, (t[53] - t[0]) * 0.01);
+            fprintf(stderr, "; epilogue %.2f us; total %.2f us\n", (t[53] - t[1 + 3 * NSTEP]) * 0.01, (t[53] - t[0]) * 0.01);
         }
         free(h);
         (void)hipFree(a.stamps);

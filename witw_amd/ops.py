@@ -454,7 +454,7 @@ SPECTRA_ALIGN = 32      # an overhead row's stored chunk order depends on bit 4 
 
 
 class Spectra(object):
-    """Row spectra of one side of the spectral match, f32 [B,33,128] in `data`, plus what the stored layout depends on: the
+    """Row spectra of one side of the spectral match, f32 [B,32,128] in `data`, plus what the stored layout depends on: the
     side (`overhead`: the two sides order the 8-byte chunks of every 16-byte slot differently) and, for the overhead side, each
     row's index modulo 32 in the tensor the spectra were computed from. Slices (`rows`) and concatenations (`Spectra.cat`) are
     therefore only defined at multiples of SPECTRA_ALIGN = 32 rows; match_fwd_dft refuses the wrong side or a misaligned view
@@ -482,9 +482,15 @@ class Spectra(object):
         return Spectra(torch.cat([p.data for p in parts]), parts[0].overhead, 0)
 
 
+def spectrum_slots():
+    """storage slots of 128 floats per embedding spectrum, as the loaded library lays them out (32)"""
+    return int(_lib.load().witw_match_spectrum_floats(1)) // 128
+
+
 def match_spectrum(embed, overhead):
-    """Row spectra of embeddings [B,16,4,W] (overhead side W = 64, surface side W = We <= 64) -> Spectra over f32 [B,33,128], the
-    operand of match_fwd_dft. `overhead` (required: a fov-360 surface embedding is 64 columns wide too) names the side; the
+    """Row spectra of embeddings [B,16,4,W] (overhead side W = 64, surface side W = We <= 64) -> Spectra over f32 [B,32,128]
+    (slot t = 1..31: frequency t; slot 0: the real spectra at frequencies 0 and 32; the slot count is the library's:
+    witw_match_spectrum_floats), the operand of match_fwd_dft. `overhead` (required: a fov-360 surface embedding is 64 columns wide too) names the side; the
     sides differ in the order of the 8-byte chunks inside each 16-byte slot, and an overhead row's order also depends on
     bit 4 of its index (csrc/match_dft.hip: conflict-free LDS operand reads) -- hence the 32-row alignment rule of Spectra."""
     lib = _lib.load()
@@ -493,7 +499,7 @@ def match_spectrum(embed, overhead):
         raise _lib.WitwError('match_spectrum: embedding must be [B,16,4,W<=64], got %s' % (tuple(e.shape),))
     if overhead and e.shape[3] != 64:
         raise _lib.WitwError('match_spectrum: an overhead embedding is 64 columns wide, got %d' % e.shape[3])
-    spec = torch.empty((e.shape[0], 33, 128), dtype=torch.float32, device=e.device)
+    spec = torch.empty((e.shape[0], spectrum_slots(), 128), dtype=torch.float32, device=e.device)
     _lib.check(lib.witw_match_spectrum(e.data_ptr(), spec.data_ptr(), e.shape[0], e.shape[3], int(bool(overhead)), _stream()),
                'witw_match_spectrum')
     return Spectra(spec, overhead)
@@ -523,8 +529,8 @@ def match_fwd_dft(overhead_embed, surface_embed, spec_ov=None, spec_su=None, wan
             raise _lib.WitwError('match_fwd_dft: %s starts at row %d of its tensor; overhead spectra are laid out per index modulo %d'
                                  % (name, sp.base_row, SPECTRA_ALIGN))
         d = sp.data
-        if not (d.is_cuda and d.dtype == torch.float32 and d.is_contiguous() and tuple(d.shape) == (n, 33, 128)):
-            raise _lib.WitwError('match_fwd_dft: %s must be a contiguous float32 GPU tensor [%d,33,128]' % (name, n))
+        if not (d.is_cuda and d.dtype == torch.float32 and d.is_contiguous() and tuple(d.shape) == (n, spectrum_slots(), 128)):
+            raise _lib.WitwError('match_fwd_dft: %s must be a contiguous float32 GPU tensor [%d,%d,128]' % (name, n, spectrum_slots()))
     spec_ov, spec_su = spec_ov.data, spec_su.data
     # want_orientation=False (retrieval: only distances are ranked) skips the int64 matrix, two thirds of the output bytes
     ori = torch.empty((Bo, Bs), dtype=torch.int64, device=ov.device) if want_orientation else None
@@ -543,7 +549,7 @@ def match_fwd_dft(overhead_embed, surface_embed, spec_ov=None, spec_su=None, wan
     else:
         _lib.check(lib.witw_match_fwd_dft(ov.data_ptr(), su.data_ptr(), spec_ov.data_ptr(), spec_su.data_ptr(), Bo, Bs, We,
                                           _p(ori), dist.data_ptr(), _p(score), ws.data_ptr(), _stream()), 'witw_match_fwd_dft')
-    if prof is not None:      # FLOP of this form per pair: 33 slots x (2 rows x K=128 x 2 + 32 shifts x K=2 x 2) = 21,120
+    if prof is not None:      # FLOP of this form per pair: 33 frequencies x (2 rows x K=128 x 2 + 32 shifts x K=2 x 2) = 21,120 (algorithmic; the kernel runs 32 slots)
         e1.record()
         prof.append((('match_dft', We), 33.0 * (2 * 128 * 2 + 32 * 2 * 2) * Bo * Bs, e0, e1))
     if want_gap:            # best - runner-up score per pair (how far the chosen shift is from a tie), then the workspace
