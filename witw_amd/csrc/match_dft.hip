@@ -152,7 +152,9 @@ __device__ __forceinline__ void half_swap(T x, T& lo, T& hi) {
     lo = __builtin_bit_cast(T, r0);
     hi = __builtin_bit_cast(T, r1);
 }
-template <bool GAP>
+// VONLY: only the largest value is wanted (no orientation output and a full-width surface, whose window norm does not depend on
+// the shift): the index search -- two thirds of the scan's instructions -- is left out
+template <bool GAP, bool VONLY>
 __device__ __forceinline__ void scan16(const f32x16& E, const f32x16& O, float& best, unsigned& key, float& second) {
     float m[16];
 #pragma unroll
@@ -162,7 +164,7 @@ __device__ __forceinline__ void scan16(const f32x16& E, const f32x16& O, float& 
     for (int q = 0; q < 16; ++q) v = fmaxf(v, m[q]);
     unsigned k = NOKEY;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
+    for (int q = 0; q < (VONLY ? 0 : 16); ++q) {
         const unsigned c = (unsigned)((q & 3) + 8 * (q >> 2));
         const float oq = O[q];      // (a __builtin_bit_cast of the element expression O[q] itself reads element 0 for every q)
         const unsigned kq = (__builtin_bit_cast(unsigned, oq) & 0x80000000u) | c;      // v_and + v_or (as asm v_bfi_b32: more moves)
@@ -198,7 +200,7 @@ struct DftArgs {
 // REC: the diagnostic instantiation that records the in-kernel timeline (costs registers: the product launch uses REC = false)
 // GAP: the shift scan also tracks the runner-up score and writes best - runner-up (narrow surfaces: the caller re-scores the
 // pairs whose two best shifts tie to rounding, cvig_fov._dft_pass_narrow)
-template <bool REC, bool GAP>
+template <bool REC, bool GAP, bool VONLY>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void match_dft_kernel(DftArgs p) {
     __shared__ __attribute__((aligned(1024))) float smem[LDS_F];      // the read addresses XOR bits 4-7: stage bases stay 1 KB-aligned
     __shared__ float dt_s[NSLOT * 64];      // inverse-transform coefficients
@@ -299,7 +301,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     ph_t0 = __builtin_amdgcn_s_memrealtime();
     ph_last = ph_t0;
 #endif
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // vmcnt(0), said with the builtin: the staging DMA of the first stage has landed, AND the compiler's own counter bookkeeping
+    // enters the step loop clean. As asm only, the norm loads of the previous tile's epilogue stayed "pending" for the compiler; in
+    // the value-only instantiation their destination registers are the GEMM-1 accumulators, and it protected them with a
+    // vmcnt(0) inside the step loop, right behind the first staging DMA of every step: 244 -> 256 ms on configuration 5
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    asm volatile("" ::: "memory");
     __syncthreads();
     stamp(1);
 
@@ -476,17 +483,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
             float v, s2 = 0.f;
             unsigned k;
-            if (par_u == 0) scan16<GAP>(acc2[4 * h + rr], got, v, k, s2);      // kept: E, received: O
-            else scan16<GAP>(got, acc2[4 * h + rr], v, k, s2);
+            if (par_u == 0) scan16<GAP, VONLY>(acc2[4 * h + rr], got, v, k, s2);      // kept: E, received: O
+            else scan16<GAP, VONLY>(got, acc2[4 * h + rr], v, k, s2);
             // the other 16 shifts of the pair sit in lane ^ 32 (4 further on for the upper half-wave)
             float v0, v1;
             unsigned kl, ku0;
             half_swap(v, v0, v1);
-            half_swap(k, kl, ku0);
-            const unsigned ku = ku0 == NOKEY ? NOKEY : ku0 + 4u;
             const float vc = fmaxf(v0, v1);
-            const unsigned kb = umin(v0 == vc ? kl : NOKEY, v1 == vc ? ku : NOKEY);
-            const int kc = kb == NOKEY ? 0 : (int)((kb & 63u) + ((kb >> 31) << 5));      // no finite maximum (NaN scores): index 0
+            int kc = 0;
+            if (!VONLY) {
+                half_swap(k, kl, ku0);
+                const unsigned ku = ku0 == NOKEY ? NOKEY : ku0 + 4u;
+                const unsigned kb = umin(v0 == vc ? kl : NOKEY, v1 == vc ? ku : NOKEY);
+                kc = kb == NOKEY ? 0 : (int)((kb & 63u) + ((kb >> 31) << 5));      // no finite maximum (NaN scores): index 0
+            }
             rv[4 * h + rr] = vc;
             rk[4 * h + rr] = kc;
             if (GAP) {
@@ -695,9 +705,12 @@ static int match_fwd_dft_launch(const float* ov, const float* su, const float* s
         if (hipMalloc((void**)&a.stamps, (size_t)nrec * 64 * 8) != hipSuccess) a.stamps = nullptr;
         else (void)hipMemset(a.stamps, 0, (size_t)nrec * 64 * 8);
     }
-    if (gap) hipLaunchKernelGGL((match_dft_kernel<false, true>), dim3(grid), dim3(256), 0, st, a);
+    // value-only scan: no orientation wanted and the surface as wide as the overhead (fov 360: the window norm is the same sum for
+    // every shift, in another order -- the distance then uses shift 0's, within an ulp of any other's)
+    const bool vonly = !orientation && !gap && We == 64 && getenv("WITW_DFT_VONLY_OFF") == nullptr;
+    if (gap) hipLaunchKernelGGL((match_dft_kernel<false, true, false>), dim3(grid), dim3(256), 0, st, a);
     else if (a.stamps && WITW_DFT_PHASES && getenv("WITW_DFT_STAMPS")[0] == '2') {
-        hipLaunchKernelGGL((match_dft_kernel<false, false>), dim3(grid), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((match_dft_kernel<false, false, false>), dim3(grid), dim3(256), 0, st, a);
         (void)hipDeviceSynchronize();
         unsigned long long h[4 * 64];
         (void)hipMemcpy(h, a.stamps, sizeof(h), hipMemcpyDeviceToHost);
@@ -714,8 +727,9 @@ static int match_fwd_dft_launch(const float* ov, const float* su, const float* s
         (void)hipFree(a.stamps);
         a.stamps = nullptr;
     }
-    else if (a.stamps) hipLaunchKernelGGL((match_dft_kernel<true, false>), dim3(grid), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((match_dft_kernel<false, false>), dim3(grid), dim3(256), 0, st, a);
+    else if (a.stamps) hipLaunchKernelGGL((match_dft_kernel<true, false, false>), dim3(grid), dim3(256), 0, st, a);
+    else if (vonly) hipLaunchKernelGGL((match_dft_kernel<false, false, true>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((match_dft_kernel<false, false, false>), dim3(grid), dim3(256), 0, st, a);
     if (a.stamps) {
         (void)hipDeviceSynchronize();
         unsigned long long* h = (unsigned long long*)malloc((size_t)nrec * 64 * 8);
