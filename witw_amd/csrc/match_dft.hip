@@ -159,9 +159,13 @@ __device__ __forceinline__ void scan16(const f32x16& E, const f32x16& O, float& 
     float m[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) m[q] = E[q] + fabsf(O[q]);
-    float v = -INFINITY;
+    float v = -INFINITY, s2 = -INFINITY;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) v = fmaxf(v, m[q]);
+    for (int q = 0; q < 16; ++q) {
+        // GAP: the second largest of the 32 values rides along (E - |O| never is the largest of its pair)
+        if (GAP) s2 = fmaxf(fmaxf(s2, fminf(m[q], v)), E[q] - fabsf(O[q]));
+        v = fmaxf(v, m[q]);
+    }
     unsigned k = NOKEY;
 #pragma unroll
     for (int q = 0; q < (VONLY ? 0 : 16); ++q) {
@@ -172,15 +176,7 @@ __device__ __forceinline__ void scan16(const f32x16& E, const f32x16& O, float& 
     }
     best = v;
     key = k;
-    if (GAP) {      // second largest of the 32 values: E - |O| never is the largest of its pair
-        float t = -INFINITY, s2 = -INFINITY;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            s2 = fmaxf(fmaxf(s2, fminf(m[q], t)), E[q] - fabsf(O[q]));
-            t = fmaxf(t, m[q]);
-        }
-        second = s2;
-    }
+    if (GAP) second = s2;
 }
 
 struct DftArgs {
