@@ -63,8 +63,8 @@ def test_version_and_argument_errors_without_gpu():
     rc = lib.witw_maxpool2x2_bwd_bf16(1, 1, 1, 1, 2, 2, 3, 4, 8, None)
     assert rc == -1 and b'bad shape' in lib.witw_last_error()
     # the spectral match and the row-split top-k
-    assert lib.witw_match_spectrum_floats(3) == 3 * 33 * 128
-    assert lib.witw_match_dft_workspace_floats(5, 7) == 5 * 64 + 7 + 33 * 64
+    assert lib.witw_match_spectrum_floats(3) == 3 * 32 * 128      # 32 storage slots: frequencies 0 and 32 share slot 0
+    assert lib.witw_match_dft_workspace_floats(5, 7) == 5 * 64 + 7 + 32 * 64
     rc = lib.witw_match_spectrum(1, 1, 4, 65, 0, None)
     assert rc == -1 and b'bad shape' in lib.witw_last_error()
     rc = lib.witw_match_fwd_dft(1, 1, None, 1, 4, 4, 64, None, None, None, 1, None)
