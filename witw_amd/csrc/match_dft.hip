@@ -29,22 +29,11 @@
 #ifndef WITW_DFT_DIAG
 #define WITW_DFT_DIAG 0
 #endif
-// WITW_DFT_AHEAD: how many k-groups the operand reads run ahead of the MFMAs (2 or 3)
-#ifndef WITW_DFT_AHEAD
-#define WITW_DFT_AHEAD 2
-#endif
 // WITW_DFT_PHASES=1 (diagnostic build): with WITW_DFT_STAMPS=2 in the environment the product instantiation sums s_memrealtime
 // over the step loops and over the epilogues of a workgroup's tiles; printed to stderr
 #ifndef WITW_DFT_PHASES
 #define WITW_DFT_PHASES 0
 #endif
-#ifndef WITW_DFT_ASMXOR
-#define WITW_DFT_ASMXOR 0
-#endif
-#ifndef WITW_DFT_DMA16
-#define WITW_DFT_DMA16 0
-#endif
-
 namespace {
 
 // Storage slots of a spectrum, [P(64 lines) | Q(64 lines)] each: slot t = 1..31 holds (Re, Im) of frequency t; the spectra at
@@ -95,18 +84,9 @@ __device__ __forceinline__ f32x2 lds_read64(unsigned addr) {
     asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
     return v;
 }
-// operand address of k-group U: base ^ (U << 4) (the slot swizzle). As asm so that it is issued where it is written, in the shadow
-// of the group's MFMAs (left to the compiler, all 45 of a step were hoisted in front of the step's first MFMA: ~250 idle cycles)
+// operand address of k-group U: base ^ (U << 4) (the slot swizzle); formed in the GEMM-2 phase, see XA / XB / XC below
 template <int IMM>
-__device__ __forceinline__ unsigned lds_xor(unsigned addr) {
-#if WITW_DFT_ASMXOR
-    unsigned v;
-    asm volatile("v_xor_b32 %0, %1, %2" : "=v"(v) : "n"(IMM), "v"(addr));
-    return v;
-#else
-    return addr ^ (unsigned)IMM;
-#endif
-}
+__device__ __forceinline__ unsigned lds_xor(unsigned addr) { return addr ^ (unsigned)IMM; }
 // the step's inverse-transform coefficient, by hand as well (issued in group 14, covered by group 15's lgkmcnt(0)): a
 // compiler-issued LDS read would be waited for with lgkmcnt(0) at its use, behind the next step's operand reads already in flight
 __device__ __forceinline__ float lds_read32(unsigned addr) {
@@ -314,7 +294,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // Operands as ds_read_b64: a lane holds k = 4u + 2hk and 4u + 2hk + 1 of its row, i.e. MFMA step 2u + e covers k = 4u + e
     // (lanes 0-31) and 4u + 2 + e (lanes 32-63) -- the same K permutation on both operands. Reads run two groups ahead; the
     // compiler would fuse neighbours into ds_read2_b64 (banked like ds_read_b32), hence the asm.
-    constexpr int NQ = WITW_DFT_AHEAD + 1;      // register slots of the operand ring
+    constexpr int NQ = 3;      // register slots of the operand ring: reads run two k-groups ahead of the MFMAs (three: no gain)
     f32x2 qa1[NQ], qb1[NQ], qa2[NQ], qb2[NQ];
     unsigned xa1, xb1, xa2;
     const unsigned dt0 = lds_address(dt_s) + (unsigned)(par * 64 + lane) * 4u;      // + step * 512
@@ -344,7 +324,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             WITW_DFT_ADDR(1)                                           \
             WITW_DFT_FETCH(0)                                          \
             WITW_DFT_FETCH(1)                                          \
-            if (WITW_DFT_AHEAD == 3) { WITW_DFT_ADDR(2) WITW_DFT_FETCH(2) }  \
         }
     WITW_DFT_STEP_HEAD(0, true)
 #pragma unroll
@@ -362,16 +341,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define WITW_DFT_GROUP(U)                                                                                                      \
         {                                                                                                                      \
             constexpr int d = (U) % NQ;                                                                                        \
-            constexpr int AH = WITW_DFT_AHEAD;                                                                                 \
+            constexpr int AH = 2;                                                                                              \
             if ((U) + AH < 16 && !(WITW_DFT_DIAG & 4)) WITW_DFT_FETCH((U) + AH < 16 ? (U) + AH : 0)                            \
             if ((U) + AH < 16) lds_wait<4 * AH>(qa1[d], qb1[d], qa2[d], qb2[d]);                                               \
             else if ((U) + 1 < 16) lds_wait<4 * (15 - (U) < AH ? 15 - (U) : AH)>(qa1[d], qb1[d], qa2[d], qb2[d]);              \
             else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qa1[d]), "+v"(qb1[d]), "+v"(qa2[d]), "+v"(qb2[d]), "+v"(dval));     \
             if ((U) == 14) dval = lds_read32(dt0 + (unsigned)i * 512u);      /* the step's coefficient: waited for by group 15 */ \
             if ((U) == 0) mfma_v0(ca, qa1[d][0], qb1[d][0]); else mfma_v(ca, qa1[d][0], qb1[d][0]);                            \
-            if (WITW_DFT_DIAG & 1) {} else if (WITW_DFT_DMA16) dma_rows((U), inext, bufn); else if ((U) < 8) dma_rows(2 * (U), inext, bufn); \
+            if (!(WITW_DFT_DIAG & 1) && (U) < 8) dma_rows(2 * (U), inext, bufn);                                               \
             if ((U) == 0) mfma_v0(cb, qa2[d][0], qb2[d][0]); else mfma_v(cb, qa2[d][0], qb2[d][0]);                            \
-            if (!(WITW_DFT_DIAG & 1) && !WITW_DFT_DMA16 && (U) < 8) dma_rows(2 * (U) + 1, inext, bufn);                        \
+            if (!(WITW_DFT_DIAG & 1) && (U) < 8) dma_rows(2 * (U) + 1, inext, bufn);                                           \
             mfma_v(ca, qa1[d][1], qb1[d][1]);                                                                                  \
             mfma_v(cb, qa2[d][1], qb2[d][1]);                                                                                  \
         }
