@@ -318,13 +318,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
 #define WITW_DFT_STEP_HEAD(STEP, SLOT0)                                \
         {                                                              \
-            const unsigned sb = lds0 + (unsigned)((STEP) & 1) * (STAGE_F * 4u); \
+            const unsigned sb = lds0 + (unsigned)((STEP) & 1) * (STAGE_F * 4u) + tile_zero; \
             xa1 = sb + ((SLOT0) ? a_off1z : a_off1); xb1 = sb + b_off1; xa2 = sb + ((SLOT0) ? a_off2z : a_off2); \
             WITW_DFT_ADDR(0)                                           \
             WITW_DFT_ADDR(1)                                           \
             WITW_DFT_FETCH(0)                                          \
             WITW_DFT_FETCH(1)                                          \
         }
+    // tile_zero = 0 behind an empty asm: the 48 step-0 addresses below are the same for every tile, and the compiler would hoist
+    // them out of the tile loop and keep them across the epilogue (42 registers; the GAP instantiation then spilled 59, reloaded
+    // them behind the tile-top barrier and waited for the reloads -- i.e. for the staging DMA -- inside the step loop)
+    unsigned tile_zero = 0;
+    asm volatile("" : "+v"(tile_zero));
     WITW_DFT_STEP_HEAD(0, true)
 #pragma unroll
     for (int u = 2; u < 16; ++u) {      // (again for every tile: 42 instructions, and the 48 registers are free during the epilogue)
@@ -391,9 +396,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 XC[r] = xa2 ^ (unsigned)(r << 4);
             }
         }
-        // the 16 operand registers stay live up to here: otherwise the address registers above are allocated on top of them
-        asm volatile("" :: "v"(cc[0]), "v"(cc[1]), "v"(cc[2]), "v"(cc[3]), "v"(cc[4]), "v"(cc[5]), "v"(cc[6]), "v"(cc[7]),
-                           "v"(cc[8]), "v"(cc[9]), "v"(cc[10]), "v"(cc[11]), "v"(cc[12]), "v"(cc[13]), "v"(cc[14]), "v"(cc[15]));
+        // the 16 operand registers stay live up to here: otherwise the address registers above are allocated on top of them. The
+        // last accumulator is named as well: it ties this statement behind the last MFMA (an empty asm may move above the builtins)
+        asm volatile("" : "+a"(acc2[15]) : "v"(cc[0]), "v"(cc[1]), "v"(cc[2]), "v"(cc[3]), "v"(cc[4]), "v"(cc[5]), "v"(cc[6]), "v"(cc[7]),
+                           "v"(cc[8]), "v"(cc[9]), "v"(cc[10]), "v"(cc[11]), "v"(cc[12]), "v"(cc[13]), "v"(cc[14]), "v"(cc[15]), "v"(dval));
         stamp(4 + 3 * i);
     }
 #undef WITW_DFT_STEP_HEAD
@@ -484,20 +490,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         asm volatile("" :: "v"(rv[4 * h]), "v"(rv[4 * h + 1]), "v"(rv[4 * h + 2]), "v"(rv[4 * h + 3]), "v"(rk[4 * h + 3]) : "memory");
         ph_m[2 * h + 1] = __builtin_amdgcn_s_memrealtime();
 #endif
+        if (GAP) {
+            // this instantiation sits at the register limit: a round's four results are written at once (two surfaces per
+            // half-wave) instead of being carried to the end of the epilogue
+            const int og = o0c + l31;
+#pragma unroll
+            for (int j2 = 0; j2 < 2; ++j2) {
+                const float v = hk ? rv[4 * h + 2 + j2] : rv[4 * h + j2];
+                const int kx = hk ? rk[4 * h + 2 + j2] : rk[4 * h + j2];
+                const float g = hk ? rs[4 * h + 2 + j2] : rs[4 * h + j2];
+                const int s = s0c + team * 16 + par * 8 + 4 * h + 2 * hk + j2;
+                if (s < p.Bs && og < p.Bo) {
+                    const size_t off = (size_t)og * p.Bs + s;
+                    if (p.orientation) p.orientation[off] = kx;
+                    if (p.score) p.score[off] = v;
+                    if (p.distance) p.distance[off] = 2.f * (1.f - v / (p.wn[(size_t)og * 64 + kx] * p.sn[s]));
+                    if (p.gap) p.gap[off] = v - g;
+                }
+            }
+        }
         if (h == 0) __syncthreads();      // the partner has read round 0 before round 1 overwrites it
     }
     // ---- output: both half-waves hold the 8 results of overhead l31; the lower one writes surfaces 0-3, the upper one 4-7. The
     // window-norm loads are issued first, the accumulators are zeroed for the next tile behind them
-    {
+    if (GAP) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r)      // (registers 8-15: behind their sends)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc2[r][q] = 0.f;
+    } else {
         const int og = o0c + l31;
-        float wnv[4], snv[4], vv[4], gg[4];
+        float wnv[4], snv[4], vv[4];
         int kk[4];
         bool ok[4];
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
             vv[jj] = hk ? rv[4 + jj] : rv[jj];
             kk[jj] = hk ? rk[4 + jj] : rk[jj];
-            if (GAP) gg[jj] = hk ? rs[4 + jj] : rs[jj];
             const int s = s0c + team * 16 + par * 8 + 4 * hk + jj;
             ok[jj] = s < p.Bs && og < p.Bo;
             wnv[jj] = (ok[jj] && p.distance) ? p.wn[(size_t)og * 64 + kk[jj]] : 1.f;
@@ -515,7 +544,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 if (p.orientation) p.orientation[off] = kk[jj];
                 if (p.score) p.score[off] = vv[jj];
                 if (p.distance) p.distance[off] = 2.f * (1.f - vv[jj] / (wnv[jj] * snv[jj]));
-                if (GAP && p.gap) p.gap[off] = vv[jj] - gg[jj];
             }
         }
     }
