@@ -110,6 +110,12 @@ __device__ __forceinline__ void mfma_v(f32x16& acc, float a, float b) {
 __device__ __forceinline__ void mfma_v0(f32x16& acc, float a, float b) {
     asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=v"(acc) : "v"(a), "v"(b));
 }
+// 16 accumulation registers back to zero for the next tile, as ONE instruction on the matrix pipe, which is idle during the
+// epilogue (0 x 0 + 0), instead of 16 v_accvgpr_write on the vector pipe, which is the busy one there. asm: the builtin with
+// constant operands is folded back into the 16 writes
+__device__ __forceinline__ void mfma_zero(f32x16& acc, float zero) {
+    asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %1, 0" : "=a"(acc) : "v"(zero));
+}
 // 16-pass XDL write -> VALU read of the result: 18 wait states (CDNA3 ISA, manually inserted wait states)
 __device__ __forceinline__ void mfma_settle(f32x16& x, f32x16& y) {
     asm volatile("s_nop 15\n\ts_nop 3" : "+v"(x), "+v"(y));
@@ -261,6 +267,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc2[r][q] = 0.f;
     const int par_u = wv & 1;            // scalar copy of par: the epilogue's two roles are a uniform branch
+    float fzero = 0.f;                   // (behind an empty asm: a register, not a folded constant)
+    asm volatile("" : "+v"(fzero));
 
 #if WITW_DFT_PHASES
     const unsigned long long ph_k0 = __builtin_amdgcn_s_memrealtime(), ph_c0 = __builtin_amdgcn_s_memtime();
@@ -446,9 +454,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
         // the sent registers are zeroed for the next tile here, in front of the barrier wait
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) acc2[8 + 4 * h + rr][q] = 0.f;
+        for (int rr = 0; rr < 4; ++rr) mfma_zero(acc2[8 + 4 * h + rr], fzero);
         __syncthreads();
 #if WITW_DFT_PHASES
         asm volatile("" ::: "memory");
@@ -515,9 +521,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // window-norm loads are issued first, the accumulators are zeroed for the next tile behind them
     if (GAP) {
 #pragma unroll
-        for (int r = 0; r < 8; ++r)      // (registers 8-15: behind their sends)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) acc2[r][q] = 0.f;
+        for (int r = 0; r < 8; ++r) mfma_zero(acc2[r], fzero);      // (registers 8-15: behind their sends)
     } else {
         const int og = o0c + l31;
         float wnv[4], snv[4], vv[4];
@@ -533,9 +537,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             snv[jj] = (ok[jj] && p.distance) ? p.sn[s] : 1.f;
         }
 #pragma unroll
-        for (int r = 0; r < 8; ++r)      // (registers 8-15: behind their sends)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) acc2[r][q] = 0.f;
+        for (int r = 0; r < 8; ++r) mfma_zero(acc2[r], fzero);      // (registers 8-15: behind their sends)
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
             const int s = s0c + team * 16 + par * 8 + 4 * hk + jj;
