@@ -443,6 +443,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const float* xr = smem + STAGE_F + (wv ^ 1) * 4096 + lane * 4;
     float rv[8], rs[8];
     int rk[8];
+    // value-only: the norms of the output phase depend on no result (window norm of shift 0) -- loaded here, a whole epilogue ahead
+    float wn_e = 1.f, sn_e[4] = {1.f, 1.f, 1.f, 1.f};
+    if (VONLY && p.distance) {
+        const int og = o0c + l31;
+        if (og < p.Bo) wn_e = p.wn[(size_t)og * 64];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int s = s0c + team * 16 + par * 8 + 4 * hk + jj;
+            if (s < p.Bs) sn_e[jj] = p.sn[s];
+        }
+    }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -533,8 +544,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             kk[jj] = hk ? rk[4 + jj] : rk[jj];
             const int s = s0c + team * 16 + par * 8 + 4 * hk + jj;
             ok[jj] = s < p.Bs && og < p.Bo;
-            wnv[jj] = (ok[jj] && p.distance) ? p.wn[(size_t)og * 64 + kk[jj]] : 1.f;
-            snv[jj] = (ok[jj] && p.distance) ? p.sn[s] : 1.f;
+            wnv[jj] = VONLY ? wn_e : (ok[jj] && p.distance) ? p.wn[(size_t)og * 64 + kk[jj]] : 1.f;
+            snv[jj] = VONLY ? sn_e[jj] : (ok[jj] && p.distance) ? p.sn[s] : 1.f;
         }
 #pragma unroll
         for (int r = 0; r < 8; ++r) mfma_zero(acc2[r], fzero);      // (registers 8-15: behind their sends)
