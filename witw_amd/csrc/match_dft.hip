@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         return raw_rsrc(is_ov ? p.spec_ov + (size_t)o0_ * SPEC : p.spec_su + (size_t)s0_ * SPEC, (unsigned)rows_here * SPEC * 4u);
     };
     i32x4 rs;
-    auto dma_rows = [&](int n, int step, int buf) {      // n = row pair, compile-time after unrolling
+    auto dma_rows = [&](const i32x4& rs, int n, int step, int buf) {      // n = row pair, compile-time after unrolling
         const unsigned slot = (unsigned)(2 * step + srp);
         const unsigned soff = (unsigned)(2 * n) * (SPEC * 4u) + slot * 512u;
         const unsigned lds = lds0 + (unsigned)buf * (STAGE_F * 4u) + region + (unsigned)n * 1024u;
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     tile_origin(blockIdx.x, s0, o0);
     rs = tile_rsrc(s0, o0);
 #pragma unroll
-    for (int n = 0; n < 16; ++n) dma_rows(n, 0, 0);        // the first tile's first stage; later ones are issued in the epilogue
+    for (int n = 0; n < 16; ++n) dma_rows(rs, n, 0, 0);        // the first tile's first stage; a later one rides in the last step of the tile before it
 
     // the wave's 16 x 16 long-lived accumulation registers; zeroed here and again at the end of every epilogue (behind the norm
     // loads of the output phase, whose latency that hides)
@@ -278,6 +278,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     int iter = 0;
 #pragma clang loop unroll(disable)
     for (unsigned tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, ++iter) {
+    // the NEXT tile's origin and staging descriptor: its first stage is fetched by the staging DMA of this tile's last step (which
+    // has no step of its own to fetch for) into stage 0, free by then -- before, a block of 16 DMA instructions per wave in the
+    // epilogue (0.6 us per tile: outside the MFMAs' shadow a DMA instruction costs ~85 cycles of issue)
+    int s0n = 0, o0n = 0;
+    i32x4 rsn = raw_rsrc(p.spec_ov, 0u);      // no next tile: an empty descriptor (zeros)
+    if (tile + gridDim.x < n_tiles) {
+        tile_origin(tile + gridDim.x, s0n, o0n);
+        rsn = tile_rsrc(s0n, o0n);
+    }
     const bool rec = REC && p.stamps && blockIdx.x < 4 && iter == 1 && tid == 0;      // a steady-state tile of the first workgroups
     auto stamp = [&](int k) { if (rec) p.stamps[blockIdx.x * 64 + k] = __builtin_amdgcn_s_memrealtime(); };
     stamp(0);
@@ -348,7 +357,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma clang loop unroll(disable)
     for (int i = 0; i < NSTEP; ++i) {
         const int bufn = (i + 1) & 1;
-        const int inext = min(i + 1, NSTEP - 1);
+        const bool last_step = i + 1 == NSTEP;
+        const int inext = last_step ? 0 : i + 1;      // the last step stages step 0 of the next tile
+        i32x4 rsd;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rsd[e] = last_step ? rsn[e] : rs[e];
         f32x16 ca, cb;      // the first MFMA of each chain starts from C = 0
         float dval;
 #define WITW_DFT_GROUP(U)                                                                                                      \
@@ -361,9 +374,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qa1[d]), "+v"(qb1[d]), "+v"(qa2[d]), "+v"(qb2[d]), "+v"(dval));     \
             if ((U) == 14) dval = lds_read32(dt0 + (unsigned)i * 512u);      /* the step's coefficient: waited for by group 15 */ \
             if ((U) == 0) mfma_v0(ca, qa1[d][0], qb1[d][0]); else mfma_v(ca, qa1[d][0], qb1[d][0]);                            \
-            if (!(WITW_DFT_DIAG & 1) && (U) < 8) dma_rows(2 * (U), inext, bufn);                                               \
+            if (!(WITW_DFT_DIAG & 1) && (U) < 8) dma_rows(rsd, 2 * (U), inext, bufn);                                               \
             if ((U) == 0) mfma_v0(cb, qa2[d][0], qb2[d][0]); else mfma_v(cb, qa2[d][0], qb2[d][0]);                            \
-            if (!(WITW_DFT_DIAG & 1) && (U) < 8) dma_rows(2 * (U) + 1, inext, bufn);                                           \
+            if (!(WITW_DFT_DIAG & 1) && (U) < 8) dma_rows(rsd, 2 * (U) + 1, inext, bufn);                                           \
             mfma_v(ca, qa1[d][1], qb1[d][1]);                                                                                  \
             mfma_v(cb, qa2[d][1], qb2[d][1]);                                                                                  \
         }
@@ -418,15 +431,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     ph_t1 = __builtin_amdgcn_s_memrealtime();
     ph_steps += ph_t1 - ph_t0;
 #endif
-    // ---- the next tile's first stage goes into stage 0 (free since the last barrier) while this tile's epilogue runs in the
-    // area of stage 1 (the last step's redundant DMA into it has landed: vmcnt(0) before that barrier)
+    // ---- the epilogue runs in the area of stage 1; stage 0 already holds the next tile's first stage (fetched by the last step)
     const int s0c = s0, o0c = o0;
-    if (tile + gridDim.x < n_tiles) {
-        tile_origin(tile + gridDim.x, s0, o0);
-        rs = tile_rsrc(s0, o0);
-#pragma unroll
-        for (int n = 0; n < 16; ++n) dma_rows(n, 0, 0);
-    }
+    s0 = s0n; o0 = o0n; rs = rsn;      // the tile whose first stage is on its way
     if (WITW_DFT_DIAG & 8) {
         float t = 0.f;      // every accumulator stays live
 #pragma unroll
@@ -726,7 +733,8 @@ static int match_fwd_dft_launch(const float* ov, const float* su, const float* s
     const bool vonly = !orientation && !gap && We == 64 && getenv("WITW_DFT_VONLY_OFF") == nullptr;
     if (gap) hipLaunchKernelGGL((match_dft_kernel<false, true, false>), dim3(grid), dim3(256), 0, st, a);
     else if (a.stamps && WITW_DFT_PHASES && getenv("WITW_DFT_STAMPS")[0] == '2') {
-        hipLaunchKernelGGL((match_dft_kernel<false, false, false>), dim3(grid), dim3(256), 0, st, a);
+        if (vonly) hipLaunchKernelGGL((match_dft_kernel<false, false, true>), dim3(grid), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((match_dft_kernel<false, false, false>), dim3(grid), dim3(256), 0, st, a);
         (void)hipDeviceSynchronize();
         unsigned long long h[4 * 64];
         (void)hipMemcpy(h, a.stamps, sizeof(h), hipMemcpyDeviceToHost);
