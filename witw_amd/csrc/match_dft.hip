@@ -514,6 +514,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         asm volatile("" :: "v"(rv[4 * h]), "v"(rv[4 * h + 1]), "v"(rv[4 * h + 2]), "v"(rv[4 * h + 3]), "v"(rk[4 * h + 3]) : "memory");
         ph_m[2 * h + 1] = __builtin_amdgcn_s_memrealtime();
 #endif
+        // this round's kept accumulators are dead: back to zero on the matrix pipe while the vector pipe goes on
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) mfma_zero(acc2[4 * h + rr], fzero);
         if (GAP) {
             // this instantiation sits at the register limit: a round's four results are written at once (two surfaces per
             // half-wave) instead of being carried to the end of the epilogue
@@ -537,10 +540,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     // ---- output: both half-waves hold the 8 results of overhead l31; the lower one writes surfaces 0-3, the upper one 4-7. The
     // window-norm loads are issued first, the accumulators are zeroed for the next tile behind them
-    if (GAP) {
-#pragma unroll
-        for (int r = 0; r < 8; ++r) mfma_zero(acc2[r], fzero);      // (registers 8-15: behind their sends)
-    } else {
+    if (!GAP) {
         const int og = o0c + l31;
         float wnv[4], snv[4], vv[4];
         int kk[4];
@@ -554,8 +554,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             wnv[jj] = VONLY ? wn_e : (ok[jj] && p.distance) ? p.wn[(size_t)og * 64 + kk[jj]] : 1.f;
             snv[jj] = VONLY ? sn_e[jj] : (ok[jj] && p.distance) ? p.sn[s] : 1.f;
         }
-#pragma unroll
-        for (int r = 0; r < 8; ++r) mfma_zero(acc2[r], fzero);      // (registers 8-15: behind their sends)
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
             const int s = s0c + team * 16 + par * 8 + 4 * hk + jj;
