@@ -379,41 +379,55 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_bf16_nhwc_kernel(WgradNhArg
     const bool z_co_ok = co0 + zchunk * 8 < p.Cout;
     const unsigned z_lane_b = (unsigned)(zpx * p.Cout + co0 + zchunk * 8) * 2u;
 
-    auto stage = [&](int c, int buf) {
-        const unsigned base = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_address(lds)) + (unsigned)buf * STAGE_B;
+    // One stage = NXW + NZW DMA instructions of this wave ("slots"; waves past NXI % NW / NZI % NW have one less). stage_begin fixes
+    // the stage's scalars, stage_slot(k) issues slot k: the main loop spreads the slots of the NEXT stage over the first rows of the
+    // current stage's MFMAs (round 5, second half: issued as one block in front of the MFMAs, the 8 waves' 62 instructions queue at
+    // the texture path and every wave sits at its issue until they are taken -- outside an MFMA's shadow a DMA instruction costs
+    // far more than the ~10 cycles it costs inside one, as the spectral match's epilogue showed).
+    constexpr int NXW = (NXI + NW - 1) / NW, NZW = (NZI + NW - 1) / NW, NSLOT = NXW + NZW;
+    static_assert(NZI % NW == 0 || NZI < NW, "dZ instructions split evenly over the waves");
+    unsigned st_base = 0;
+    int st_b = 0, st_h0 = 0, st_w0 = 0;
+    auto stage_begin = [&](int c, int buf) {
+        st_base = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_address(lds)) + (unsigned)buf * STAGE_B;
         const int seg = c % p.nseg;
         const int t = c / p.nseg;
-        const int rg = t % p.nrg, b = t / p.nrg;
-        const int h0 = rg * R, w0 = seg * NH_P;
-#pragma unroll
-        for (int i = 0; i < (NXI + NW - 1) / NW; ++i) {
-            const int j = wave_u + NW * i;                       // wave-uniform
+        const int rg = t % p.nrg;
+        st_b = t / p.nrg;
+        st_h0 = rg * R;
+        st_w0 = seg * NH_P;
+    };
+    auto stage_slot = [&](int k) {      // k compile-time after unrolling
+        if (k < NXW) {
+            const int j = wave_u + NW * k;                       // wave-uniform
             if (NXI % NW == 0 || j < NXI) {
                 const int r = j / 3, part = j - r * 3;
-                const int gr = h0 * SH - 1 + r;
+                const int gr = st_h0 * SH - 1 + r;
                 const int col = part * 8 + xpx;                  // 0..23 (18 used)
-                int gc = w0 - 1 + col;
+                int gc = st_w0 - 1 + col;
                 if (p.circ) {                                    // only columns -1 and W wrap; columns past W pair with zero dZ pixels
                     if (gc < 0) gc += p.W;
                     else if (gc == p.W) gc = 0;
                 }
                 const bool ok = x_ci_ok && col < NH_P + 2 && gc >= 0 && gc < p.W && gr >= 0 && gr < p.H;
-                const unsigned soff = (gr >= 0 && gr < p.H) ? (unsigned)(((size_t)b * p.H + gr) * p.W * p.Cin * 2u) : 0u;
-                dma16(x_rs, base + (unsigned)j * 1024u, ok ? (unsigned)(gc * p.Cin) * 2u + x_lane_b : OOR, soff);
+                const unsigned soff = (gr >= 0 && gr < p.H) ? (unsigned)(((size_t)st_b * p.H + gr) * p.W * p.Cin * 2u) : 0u;
+                dma16(x_rs, st_base + (unsigned)j * 1024u, ok ? (unsigned)(gc * p.Cin) * 2u + x_lane_b : OOR, soff);
             }
-        }
-        static_assert(NZI % NW == 0 || NZI < NW, "dZ instructions split evenly over the waves");
-#pragma unroll
-        for (int i = 0; i < (NZI + NW - 1) / NW; ++i) {
-            const int j = wave_u + NW * i;
+        } else {
+            const int j = wave_u + NW * (k - NXW);
             if (NZI % NW == 0 || j < NZI) {
                 const int r = j >> 2, c4 = (j & 3) * 4;
-                const int h = h0 + r, w = w0 + c4;               // this instruction's first pixel
+                const int h = st_h0 + r, w = st_w0 + c4;         // this instruction's first pixel
                 const bool ok = z_co_ok && h < p.Ho && w + zpx < p.Wo;
-                const unsigned soff = (h < p.Ho && w < p.Wo) ? (unsigned)((((size_t)b * p.Ho + h) * p.Wo + w) * p.Cout * 2u) : 0u;
-                dma16(z_rs, base + (unsigned)(X_B + j * 1024), ok ? z_lane_b : OOR, soff);
+                const unsigned soff = (h < p.Ho && w < p.Wo) ? (unsigned)((((size_t)st_b * p.Ho + h) * p.Wo + w) * p.Cout * 2u) : 0u;
+                dma16(z_rs, st_base + (unsigned)(X_B + j * 1024), ok ? z_lane_b : OOR, soff);
             }
         }
+    };
+    auto stage = [&](int c, int buf) {      // a whole stage at once (the ring's first NS - 1 stages)
+        stage_begin(c, buf);
+#pragma unroll
+        for (int k = 0; k < NSLOT; ++k) stage_slot(k);
     };
 
     f32x16 acc[9];
@@ -460,7 +474,14 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_bf16_nhwc_kernel(WgradNhArg
     // reads) + its dZ fragment (2 reads) for 9 MFMAs, not 9 + 1 fragments. The unrolled loop names every halo row's fragments once
     // (fx[j][kw]); those of the next output row are requested in front of the current row's MFMAs. Rows past Ho were staged as zeros
     // (out-of-range DMA lanes) and are computed like the others.
-    auto compute = [&](int buf) {
+    constexpr int ROWS_PF = RW >= 4 ? RW / 2 : RW;                     // rows of a stage that carry the next stage's DMA slots ...
+    constexpr int PER_ROW = (NSLOT + ROWS_PF - 1) / ROWS_PF;            // ... this many each (with RW >= 4 the last one has RW / 2 rows to land)
+    constexpr int EVERY = PER_ROW <= 4 ? 2 : 1;                         // one slot behind every second MFMA of the row, or behind every one
+    static_assert(PER_ROW <= 9, "a row's 9 MFMAs carry at most 9 DMA slots");
+    // Spread only where every wave owns all R rows of the stage (KS = 1: the 128-channel layers, 2-3 % faster); where the waves split
+    // the rows (narrow layers: few MFMAs per wave and stage) the block in front of the MFMAs measured 2-7 % faster and is kept
+    constexpr bool SPREAD = KS == 1;
+    auto compute = [&](int buf, bool prefetch) {
         const unsigned char* sb = lds + buf * STAGE_B;
         constexpr int XRW = (RW - 1) * SH + 3;      // halo rows of this wave's RW output rows
         bf16x8 fx[XRW][3];
@@ -480,7 +501,13 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_bf16_nhwc_kernel(WgradNhArg
                     for (int kw = 0; kw < 3; ++kw) fx[j][kw] = frag(sb, a_lane[kw] + (unsigned)(j * NH_XP * 128));
             }
 #pragma unroll
-            for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fx[r * SH + t / 3][t % 3], fb, acc[t], 0, 0, 0);
+            for (int t = 0; t < 9; ++t) {
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fx[r * SH + t / 3][t % 3], fb, acc[t], 0, 0, 0);
+                // the next stage's DMA slots of this row, one behind every other MFMA
+                if (SPREAD && r < ROWS_PF && (t % EVERY) == EVERY - 1 && r * PER_ROW + t / EVERY < min(NSLOT, (r + 1) * PER_ROW)) {
+                    if (prefetch) stage_slot(r * PER_ROW + t / EVERY);
+                }
+            }
             if (do_bias) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
@@ -509,8 +536,12 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_bf16_nhwc_kernel(WgradNhArg
                 wait_vmcnt<0>();
             }
             __syncthreads();                         // ... everyone's has, and everyone is done reading chunk c - 1's buffer
-            if (c + NS - 1 < c_end) stage(c + NS - 1, buf == 0 ? NS - 1 : buf - 1);
-            compute(buf);
+            const bool prefetch = c + NS - 1 < c_end;
+            if (prefetch) {
+                if (SPREAD) stage_begin(c + NS - 1, buf == 0 ? NS - 1 : buf - 1);
+                else stage(c + NS - 1, buf == 0 ? NS - 1 : buf - 1);
+            }
+            compute(buf, prefetch);
             buf = buf + 1 == NS ? 0 : buf + 1;
         }
     }
