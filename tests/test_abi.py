@@ -130,13 +130,13 @@ def test_wres_register_allocation_guard(tmp_path, monkeypatch):
     from witw_amd import build
     assert not os.path.exists(build.WRES_MARKER) and not os.path.exists(build.S16_MARKER)
     monkeypatch.setattr(build, 'WRES_MARKER', str(tmp_path / 'wres_unvalidated'))
-    (v, sp, sc), = build.WRES_VALIDATED.values()
-    inst, = build.WRES_VALIDATED.keys()
-    good = ('remark: Function Name: _ZN12_GLOBAL__N_124conv3x3_bf16_wres_kernel%sEvNS_8WresArgsE [-Rpass]\nremark:     VGPRs: %d [-R]\n'
-            'remark:     ScratchSize [bytes/lane]: %d [-R]\nremark:     VGPRs Spill: %d [-R]\n' % (inst, v, sc, sp))
+    one = ('remark: Function Name: _ZN12_GLOBAL__N_124conv3x3_bf16_wres_kernel%sEvNS_8WresArgsE [-Rpass]\nremark:     VGPRs: %d [-R]\n'
+           'remark:     ScratchSize [bytes/lane]: %d [-R]\nremark:     VGPRs Spill: %d [-R]\n')
+    good = ''.join(one % (inst, v, sc, sp) for inst, (v, sp, sc) in build.WRES_VALIDATED.items())      # plain and gated instantiation
+    inst = next(iter(build.WRES_VALIDATED))
     build._check_wres(good)
     assert not os.path.exists(build.WRES_MARKER)
-    build._check_wres(good.replace('VGPRs Spill: 0', 'VGPRs Spill: 3'))
+    build._check_wres(good.replace('VGPRs Spill: 0', 'VGPRs Spill: 3', 1))
     assert inst in open(build.WRES_MARKER).read()
     build._check_wres(good)
     assert not os.path.exists(build.WRES_MARKER)

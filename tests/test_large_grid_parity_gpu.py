@@ -108,6 +108,41 @@ WRES_CASES = [(64, 64, 256, 128, True, True), (32, 64, 256, 128, False, True), (
               (4096, 8, 16, 128, True, True), (4099, 8, 16, 128, False, True), (1400, 16, 48, 64, True, False)]
 
 
+@pytest.mark.parametrize('case', [(8200, 8, 16, 64, True), (4099, 8, 16, 128, False), (2800, 16, 48, 64, True), (128, 128, 512, 64, True)])
+def test_bf16_weight_resident_kernel_gated_form_bitwise_vs_tiled_kernel(case):
+    """The dgrad form of conv3x3_bf16_wres_kernel (round 5: the ReLU gate of the previous layer applied to the 16-byte output octets;
+    cvig_semantic's layer-2 data gradient at 128 x 512, where layer 0 trains): BITWISE the tiled kernel's gated launch on the whole
+    batch -- same products, same accumulation order, and a gate is open exactly where the bf16 gate value is > 0 (zeros, negative
+    values and -0 close it)."""
+    from witw_amd import ops
+    B, H, W, cout, circ = case
+    if B * H * W * max(64, cout) * 2 > 3 * 2 ** 30:
+        pytest.skip('too large')
+    x, w, b = _layer(41, B if H < 100 else 8, H, W, 64, cout)
+    if H >= 100:      # the cvig_semantic shape: 8 distinct images repeated to the bench batch
+        x = x.repeat(B // 8, 1, 1, 1)
+    dev = torch.device('cuda:0')
+    pk = ops.PackedConvBf16(w.to(dev), torch.zeros_like(b).to(dev))
+    xd = x.to(dev).permute(0, 2, 3, 1).contiguous().bfloat16()
+    gen = torch.Generator(device='cuda')
+    gen.manual_seed(7)
+    gate = torch.randn((xd.shape[0], H, W, cout), generator=gen, device=dev).clamp_(min=0).bfloat16()      # a ReLU output: half zeros
+    gate[0, 0, 0, :8] = torch.tensor([0.0, -0.0, -1.0, 1e-38, 1.0, float('inf'), -float('inf'), 3.0]).bfloat16().to(dev)
+    assert ops.bf16_wres() is True
+    y = ops.conv3x3_bf16_fwd(xd, pk, circular=circ, relu=False, gate=gate)
+    assert ops.last_kernel_variant() == 'conv3x3_bf16_wres_kernel<gate>', ops.last_kernel_variant()
+    prev_w, prev_s = ops.bf16_wres(False), ops.bf16_mfma16(False)      # the 32x32x16 tiled kernel: the same accumulation order
+    try:
+        tiled = ops.conv3x3_bf16_fwd(xd, pk, circular=circ, relu=False, gate=gate)
+        assert ops.last_kernel_variant().startswith('conv3x3_nhwc_bf16_kernel<'), ops.last_kernel_variant()
+    finally:
+        ops.bf16_wres(prev_w)
+        ops.bf16_mfma16(prev_s)
+    assert torch.equal(y.view(torch.int16), tiled.view(torch.int16))
+    closed = ~(gate.float() > 0)
+    assert bool((y.float()[closed] == 0).all()) and float(y.float().abs().max()) > 0
+
+
 @pytest.mark.parametrize('case', WRES_CASES)
 def test_bf16_weight_resident_kernel_vs_oracle_and_tiled_kernel(case):
     """conv3x3_bf16_wres_kernel (layer 5 of the trunk at bench batch sizes: the filter block stays in LDS, persistent workgroups)

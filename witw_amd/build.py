@@ -50,11 +50,11 @@ def build(force=False, verbose=True):
 # are compared with `table` after every compile; a mismatch leaves `marker`, which _lib.load() reads AFTER the build (so a process
 # that triggers the build itself is covered) and reports through _lib.guards() / the bench line's `guards` field.
 #   s16:    conv3x3_bf16_s16_kernel<POOL, TRAIN> -> the 32x32x16 kernel (witw_conv3x3_bf16_mfma16(0));      force: WITW_BF_S16=1
-#   wres:   conv3x3_bf16_wres_kernel<REC>        -> layer 5 on the tiled kernels (witw_conv3x3_bf16_wres(0)); force: WITW_BF_WRES=1
+#   wres:   conv3x3_bf16_wres_kernel<REC, GATE>  -> layer 5 on the tiled kernels (witw_conv3x3_bf16_wres(0)); force: WITW_BF_WRES=1
 #   first2: conv_first2_bf16_kernel<CW, REC>     -> layers 0 and 2 as two launches (FOV_DSM.fuse_first2);     force: WITW_F2=1
 S16_VALIDATED = {'ILb0ELb0EE': (256, 10, 44), 'ILb1ELb0EE': (256, 1, 8), 'ILb0ELb1EE': (256, 10, 44), 'ILb1ELb1EE': (256, 2, 12)}
 S16_MARKER = os.path.join(HERE, 'build', 's16_unvalidated')
-WRES_VALIDATED = {'ILb0EE': (209, 0, 0)}
+WRES_VALIDATED = {'ILb0ELb0EE': (209, 0, 0), 'ILb0ELb1EE': (229, 0, 0)}      # <REC, GATE>: plain forward; gated (dgrad) form, round 5
 WRES_MARKER = os.path.join(HERE, 'build', 'wres_unvalidated')
 F2_VALIDATED = {'ILi4ELb0EE': (254, 0, 0), 'ILi8ELb0EE': (256, 0, 0)}
 F2_MARKER = os.path.join(HERE, 'build', 'first2_unvalidated')

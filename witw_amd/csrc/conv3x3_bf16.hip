@@ -1313,8 +1313,9 @@ int witw_conv3x3_bf16_fwd_ex(const void* x_bf16, const void* wpk_bf16, const flo
     a.xcd_map = e ? atoi(e) != 0 : 1;
     hipStream_t st = (hipStream_t)stream;
     // 64 input channels, plain forward: the kernel that keeps the filter in LDS (conv3x3_bf16_wres.hip; bit-identical to the 32x32x16 kernel)
-    if (stride_h == 1 && !pool && !out_nchw_f32 && !dropmask && !gate_bf16 && !dilate_h && witw_bf16_wres_applies(B, H, W, Cin, Cout))
-        return witw_bf16_wres_launch(x_bf16, wpk_bf16, bias, y, B, H, W, Cout, pad_circular, relu, stream);
+    // (round 5: also the gated form, i.e. the data gradient of a 64-channel layer -- cvig_semantic's layer 2, where layer 0 trains)
+    if (stride_h == 1 && !pool && !out_nchw_f32 && !dropmask && !dilate_h && witw_bf16_wres_applies(B, H, W, Cin, Cout))
+        return witw_bf16_wres_launch(x_bf16, wpk_bf16, bias, gate_bf16, y, B, H, W, Cout, pad_circular, relu, stream);
     if (Cout >= 128) {
         if (stride_h == 2) return launch_bf<128, 2, false>(a, st);
         return pool ? launch_bf<128, 1, true>(a, st) : launch_bf<128, 1, false>(a, st);

@@ -76,6 +76,7 @@ struct WresArgs {
     const u32x4* wpk;         // conv3x3_bf16 packing [n_tile][4 chunks][9 taps][2 groups][TN][8 bf16]
     const float* bias;        // [>= Cout]
     unsigned short* y;        // NHWC bf16 [B,H,W,Cout]
+    const unsigned short* gate;      // GATE instantiation: bf16 tensor shaped like y; outputs where gate <= 0 are zeroed (the ReLU backward of a dgrad launch)
     int B, H, W, Cout;
     int tiles_x, tiles_y, n_sp;      // spatial (team) tiles per row / column of an image, in all
     int n_cb;                 // blocks of 64 output channels
@@ -103,7 +104,7 @@ __device__ __forceinline__ void wres_dma16(i32x4 rs, unsigned lds_addr, unsigned
 
 __device__ unsigned long long wres_stamps[2][8];     // WITW_WRES_STAMPS=1 diagnostic: phase ticks of waves 0 and 4 (one per team), third iteration of workgroup 0
 
-template <bool REC>
+template <bool REC, bool GATE>
 __global__ __launch_bounds__(WRT, 1) void conv3x3_bf16_wres_kernel(WresArgs p) {
     __shared__ __attribute__((aligned(1024))) u32x4 a_s[WITW_WRES_DMA ? 2 * DIMG / 16 : 2 * 8 * WPOS];      // per team the input tile (47,104 B; register form 61,696)
     __shared__ u32x4 w_s[4 * 9 * 2 * 64];           // 73,728 B: this channel block's filter
@@ -237,6 +238,15 @@ __global__ __launch_bounds__(WRT, 1) void conv3x3_bf16_wres_kernel(WresArgs p) {
     const unsigned relu_floor = p.relu ? 0u : 0x80008000u;      // witw_relu_bf16x2
 
     f32x16 acc[2];
+    // GATE: the four 16-byte gate octets of this lane's four output stores, loaded at the START of the tile's M phase (the 36 MFMA
+    // steps hide them; in the V phase a compiler wait for them would also wait for the tile DMA issued behind them, which the
+    // compiler cannot see) and waited for with the builtin at the start of the V phase, in front of the DMA
+    u32x4 gt[4];
+    auto gate_mask = [](unsigned w) -> unsigned {      // 0xffff per bf16 half that is > 0 (conv3x3_bf16.hip: gate_open)
+        const unsigned lo = ((w & 0x7fffu) != 0u && !(w & 0x8000u)) ? 0x0000ffffu : 0u;
+        const unsigned hi = ((w & 0x7fff0000u) != 0u && !(w & 0x80000000u)) ? 0xffff0000u : 0u;
+        return lo | hi;
+    };
     int pb = 0, poy0 = 0, pox0 = 0;                 // the tile whose accumulators are waiting for their epilogue
     bool pvalid = false;
     // ---- epilogue, D[channel][pixel]: lane = pixel l31, registers 4j..4j+3 of accumulator nt = channels nt*32 + 8j + 4hq + {0..3};
@@ -311,6 +321,10 @@ __global__ __launch_bounds__(WRT, 1) void conv3x3_bf16_wres_kernel(WresArgs p) {
             const int c = lane + 64 * (k & 1);
             const int px = c >> 3, c8 = c & 7;          // pixel 0..15 of the round: row px >> 3, column px & 7
             const int oy = poy0 + 4 * mrow + 2 * (k >> 1) + (px >> 3), ox = pox0 + 8 * mcol + (px & 7);
+            if (GATE) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[k][e] &= gate_mask(gt[k][e]);
+            }
             if (pvalid)
                 __builtin_nontemporal_store(v[k], reinterpret_cast<u32x4*>(p.y + (((size_t)pb * p.H + oy) * p.W + ox) * p.Cout + cb * 64 + c8 * 8));
         }
@@ -350,6 +364,7 @@ __global__ __launch_bounds__(WRT, 1) void conv3x3_bf16_wres_kernel(WresArgs p) {
                 // the team's image was last read in the previous M phase, a barrier ago: this tile's pieces go out now and land under
                 // the epilogue; the wait counts the epilogue's four stores issued behind them (vector-memory operations retire in
                 // issue order), so it does not wait for those stores
+                if (GATE) __builtin_amdgcn_s_waitcnt(0x0F70);      // the gate octets (loaded an M phase ago): the compiler's bookkeeping is clean from here
                 if (!(WITW_WRES_DIAG & 8)) dma_tile(t);
                 stamp(1);
                 epilogue();
@@ -372,6 +387,15 @@ __global__ __launch_bounds__(WRT, 1) void conv3x3_bf16_wres_kernel(WresArgs p) {
         // the next tile's loads go out one at a time between the MFMA steps (all six at once queue up behind each other in the
         // texture path and hold the wave at the issue of the last ones)
         asm volatile("" ::: "memory");
+        if (GATE) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {           // the addresses of the epilogue's stores (below)
+                const int c = lane + 64 * (k & 1);
+                const int px = c >> 3, c8 = c & 7;
+                const int oy = ty * WTH + 4 * mrow + 2 * (k >> 1) + (px >> 3), ox = tx * WTW + 8 * mcol + (px & 7);
+                gt[k] = *reinterpret_cast<const u32x4*>(p.gate + (((size_t)b * p.H + oy) * p.W + ox) * p.Cout + cb * 64 + c8 * 8);
+            }
+        }
         if (!WITW_WRES_DMA) fetch_setup(tile_of(it + 1));
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
@@ -432,6 +456,7 @@ __global__ __launch_bounds__(WRT, 1) void conv3x3_bf16_wres_kernel(WresArgs p) {
         stamp(5);
     }
     if (WITW_WRES_PRIO) __builtin_amdgcn_s_setprio(WITW_WRES_PRIO == 2 ? 1 : 0);
+    if (GATE) __builtin_amdgcn_s_waitcnt(0x0F70);
     if (n_it > 0) epilogue();
     if (!team) __syncthreads();                     // team 0 is half a tile ahead: the barrier team 1's last M phase ends on
 }
@@ -455,10 +480,10 @@ bool witw_bf16_wres_applies(int B, int H, int W, int Cin, int Cout) {
     return n_sp * (Cout / 64) >= 32 * 256 && n_sp < 0x7fffffffLL;      // 16 tile pairs per workgroup pay for loading the filter block once
 }
 
-int witw_bf16_wres_launch(const void* x, const void* wpk, const float* bias, void* y, int B, int H, int W, int Cout, int pad_circular,
-                          int relu, void* stream) {
+int witw_bf16_wres_launch(const void* x, const void* wpk, const float* bias, const void* gate, void* y, int B, int H, int W, int Cout,
+                          int pad_circular, int relu, void* stream) {
     WresArgs a;
-    a.x = (const u32x4*)x; a.wpk = (const u32x4*)wpk; a.bias = bias; a.y = (unsigned short*)y;
+    a.x = (const u32x4*)x; a.wpk = (const u32x4*)wpk; a.bias = bias; a.y = (unsigned short*)y; a.gate = (const unsigned short*)gate;
     a.B = B; a.H = H; a.W = W; a.Cout = Cout;
     a.tiles_x = W / WTW; a.tiles_y = H / WTH;
     a.n_sp = B * a.tiles_x * a.tiles_y;            // team tiles; a workgroup walks pairs of them
@@ -470,9 +495,9 @@ int witw_bf16_wres_launch(const void* x, const void* wpk, const float* bias, voi
     if (q < 1) q = 1;
     a.q_per_xcd = q;
     const unsigned grid = 8u * (unsigned)(q * a.n_cb);
-    const bool rec = getenv("WITW_WRES_STAMPS") != nullptr && (a.n_sp + 1) / 2 >= 3 * 8 * q;      // diagnostic, synchronous
+    const bool rec = !gate && getenv("WITW_WRES_STAMPS") != nullptr && (a.n_sp + 1) / 2 >= 3 * 8 * q;      // diagnostic, synchronous
     if (rec) {
-        hipLaunchKernelGGL(conv3x3_bf16_wres_kernel<true>, dim3(grid), dim3(WRT), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((conv3x3_bf16_wres_kernel<true, false>), dim3(grid), dim3(WRT), 0, (hipStream_t)stream, a);
         (void)hipDeviceSynchronize();
         unsigned long long h[2][8];
         if (hipMemcpyFromSymbol(h, HIP_SYMBOL(wres_stamps), sizeof(h)) == hipSuccess)
@@ -480,11 +505,13 @@ int witw_bf16_wres_launch(const void* x, const void* wpk, const float* bias, voi
                 fprintf(stderr, "conv3x3_bf16_wres team %d (wave %d), third iteration (ticks): V input->LDS %llu, V epilogue %llu, barrier %llu, "
                                 "M MFMA loop %llu, barrier %llu, total %llu\n", w, 4 * w, h[w][1] - h[w][0], h[w][2] - h[w][1], h[w][3] - h[w][2],
                         h[w][4] - h[w][3], h[w][5] - h[w][4], h[w][5] - h[w][0]);
+    } else if (gate) {
+        hipLaunchKernelGGL((conv3x3_bf16_wres_kernel<false, true>), dim3(grid), dim3(WRT), 0, (hipStream_t)stream, a);
     } else {
-        hipLaunchKernelGGL(conv3x3_bf16_wres_kernel<false>, dim3(grid), dim3(WRT), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((conv3x3_bf16_wres_kernel<false, false>), dim3(grid), dim3(WRT), 0, (hipStream_t)stream, a);
     }
     WITW_CHECK_LAUNCH("conv3x3_bf16_wres");
-    witw_note_variant("conv3x3_bf16_wres_kernel");
+    witw_note_variant(gate ? "conv3x3_bf16_wres_kernel<gate>" : "conv3x3_bf16_wres_kernel");
     return WITW_OK;
 }
 

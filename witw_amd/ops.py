@@ -1183,7 +1183,7 @@ def conv3x3_bf16_fwd(x_nhwc, packed, stride_h=1, circular=False, relu=True, pool
     if prof is not None:
         e1.record()
         # the 64-input-channel layer runs on its own kernel (csrc/conv3x3_bf16_wres.hip): its own launch class
-        kind = 'bf16_wres' if last_kernel_variant() == 'conv3x3_bf16_wres_kernel' else 'bf16'
+        kind = 'bf16_wres' if last_kernel_variant().startswith('conv3x3_bf16_wres_kernel') else 'bf16'
         prof.append(((kind, lib.witw_conv3x3_tile_n(packed.cout), stride_h, bool(pool)),
                      2.0 * packed.cin * packed.cout * 9 * (h_phys if dilate_h else Ho) * W * B, e0, e1))      # dilated: see conv3x3_fwd
         if PROFILE_BY_KERNEL is not None:
