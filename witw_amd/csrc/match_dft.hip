@@ -205,8 +205,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // ---- staging: LDS-DMA, 16 B per lane: one instruction brings two whole rows (lanes 0-31 row 2n, lanes 32-63 row 2n+1)
     // with no register transit and no ds_write; a lane fetches the 16-byte slot that belongs at its LDS position under the
     // swizzle. Wave w owns the rows of one kind: w&1 = slot parity, w>>1 = 0 surfaces / 1 overheads; 16 instructions per
-    // step. Rows past the batch and the odd waves' 17th slot fall outside the descriptor (zeros) or read a neighbour's
-    // finite values whose coefficient is 0.
+    // step. Rows past the batch fall outside the descriptor (zeros); every slot a step reads exists (32 slots, 16 steps).
     const int wv = __builtin_amdgcn_readfirstlane(wave);
     const int srp = wv & 1, is_ov = wv >> 1;
     const unsigned region = (is_ov ? A_F + srp * 32 * ROW_F : srp * 32 * ROW_F) * 4u;
