@@ -114,6 +114,22 @@ def traffic_of(kname, batch, tag):
     return t.get('%s_bytes_per_launch_B%d%s' % (kname, batch, tag)), src
 
 
+def rocprof_avg_of(kname, tag):
+    """Average duration of `kname` in the committed rocprofv3 --kernel-trace --stats table of bench mode `tag`
+    (profiles/rocprof_kernel_avg.json, tools/make_rocprof_avg.py) -> (ms, csv path) or (None, None); withheld when any kernel
+    source changed since the table was taken (same rule as traffic_of)."""
+    try:
+        t = json.load(open(os.path.join(ROOT, 'profiles', 'rocprof_kernel_avg.json')))
+    except Exception:
+        return None, None
+    recorded = t.get('_kernel_sources_sha16', {})
+    if not recorded or any(sha16(os.path.join(ROOT, 'witw_amd', 'csrc', f)) != h for f, h in recorded.items()):
+        return None, None
+    blk = t.get(tag) or {}
+    k = (blk.get('kernels') or {}).get(kname.replace(' ', ''))
+    return (k['avg_ms'], blk.get('csv')) if k else (None, None)
+
+
 class StepBench(object):
     """One configuration of the cvig_fov / cvig_semantic step (model, mode, precision, batch, fov): builds the synthetic batch
     and the two encoders, times K steps between barrier + synchronize pairs, and derives the live roofline of the dominant
@@ -294,8 +310,17 @@ class StepBench(object):
         if self.fov == 360:      # the PMC passes were taken at fov 360 (other widths change the launch mix)
             tag = ('_bf16_train' if bf16 else '_train') if self.train else ''     # train modes average forward + dgrad launches
             traffic, tsrc = traffic_of(kname, self.B, tag)
+        # the same fraction on rocprofv3's clock: the committed --kernel-trace --stats table of this bench mode (same kernel sources),
+        # same FLOP per launch. Events bracket the launch on the stream, rocprof times the dispatch: they differ by 0.5 % on the fp32
+        # kernel and by up to 5 % on the bf16 ones, so the line carries both.
+        mode_tag = ('sem_' if self.semantic else '') + ('bf16' if bf16 else 'f16x3' if f16x3 else '') + ('_train' if self.train else '')
+        mode_tag = mode_tag.strip('_') or 'infer'
+        rp_ms, rp_csv = rocprof_avg_of(kname, mode_tag) if self.fov == 360 and self.B == 128 else (None, None)
+        clocks = {'frac_events': round(achieved / peak, 4)}
+        if rp_ms:
+            clocks.update(frac_rocprof=round(dom_fl / (rp_ms * 1e-3) / 1e12 / peak, 4), rocprof_avg_launch_ms=rp_ms, rocprof_csv=rp_csv)
         return {'bound': 'mfma', 'kernel': kname, 'achieved': round(achieved, 2),
-                'peak': peak, 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
+                'peak': peak, 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4), **clocks,
                 'traffic': traffic, **({'traffic_source': tsrc} if tsrc else {}),
                 'launches': len(dom), 'avg_launch_ms': round(dom_ms, 4),
                 'avg_launch_gflop': round(dom_fl / 1e9, 2), 'all_conv_launches_tflops': round(conv_tf, 2),
@@ -356,7 +381,7 @@ class StepBench(object):
                 'value': round(self.value, 2), 'unit': 'pairs/s', 'ms_per_step': round(self.ms, 3), 'steps': self.steps,
                 'dtype': self.dtype(), 'loss': float(self.loss.item()),
                 'recall': {'top1_pct': float(np.mean(self.ranks_h <= 1) * 100), 'top5_pct': float(np.mean(self.ranks_h <= 5) * 100)},
-                'roofline': {k: r[k] for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'launches', 'avg_launch_ms',
+                'roofline': {k: r[k] for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'frac_events', 'frac_rocprof', 'launches', 'avg_launch_ms',
                                                'all_conv_launches_tflops', 'whole_step_frac', 'wgrad_bf16_tflops_incl_layout_passes') if k in r},
                 'parity': parity}
 
@@ -391,6 +416,7 @@ def main():
                     help='where the FULL record goes (default bench_detail.json beside bench.py): stdout carries one line of at most '
                          '%d bytes -- headline, roofline, cpu_baseline and one compact entry per side config' % LINE_BUDGET)
     ap.add_argument('--no-microbench', action='store_true', help='N > 1: skip the standalone timing of the step\'s collectives')
+    ap.add_argument('--no-train-step', action='store_true', help='N > 1: skip the training step (BASELINE configs[2]) run behind the inference headline')
     ap.add_argument('--no-side-blocks', action='store_true', help='only the headline measurement (no blocks for the other BASELINE configs)')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL); gloo only for 1-GPU self-tests')
     ap.add_argument('--single-device', action='store_true', help='self-test: put every rank on cuda:0')
@@ -479,9 +505,19 @@ def run_mode(a, rank, world, local, device, _lib, cvig_fov, ops):
     else:
         out = step_line(a, rank, world, device, cvig_fov, ops)
     bad = None
+    after = out.pop('_after_group', None) if isinstance(out, dict) else None
+    if after is not None:
+        # every collective of the line is behind us: the group goes first, so that no rank sits in a collective (or its watchdog)
+        # while rank 0 spends ~40 s on the CPU port
+        dist.barrier()
+        dist.destroy_process_group()
+        try:
+            after()
+        except Exception as e:
+            out['cpu_baseline'] = {'error': '%s: %s' % (type(e).__name__, str(e)[:200])}
     if rank == 0:
         bad = emit(out, a)
-    if world > 1 or a.pg_of_one:
+    if (world > 1 or a.pg_of_one) and dist.is_initialized():
         dist.destroy_process_group()
     if bad:
         sys.exit(bad)
@@ -505,22 +541,61 @@ def step_line(a, rank, world, device, cvig_fov, ops):
     out = sb.line()
     stamp('headline: %.1f pairs/s, %.3f ms per step' % (sb.value, sb.ms))
     out['collectives'] = collectives_info(a, rank, world, device, sb.phases, sb.ms)          # every rank takes part; rank 0 prints
-    if (world > 1 or a.pg_of_one) and not a.no_microbench:
-        out['collectives']['microbench'] = collectives_microbench(a, rank, world, device, sb.phases)
-        stamp('collectives microbench')
-    out['guards'] = guards_block(ops)
-    headline = world == 1 and a.mode == 'infer' and a.precision == 'fp32' and not a.graph
-    side = headline and not a.no_side_blocks and a.model == 'fov' and a.fov == 360 and a.batch == 128
-    cpu_args = (sb.ground_raw[:a.cpu_pairs].cpu(), sb.ov_raw[:a.cpu_pairs].cpu(), sb.wts, sb.semantic) if headline else None
+    grouped = world > 1 or a.pg_of_one
+    headline = a.mode == 'infer' and a.precision == 'fp32' and not a.graph
+    cpu_args = (sb.ground_raw[:a.cpu_pairs].cpu(), sb.ov_raw[:a.cpu_pairs].cpu(), sb.wts, sb.semantic) if headline and rank == 0 else None
+    phases = sb.phases
     del sb
     torch.cuda.empty_cache()
-    if headline and rank == 0 and not a.no_cpu_baseline:
-        out['cpu_baseline'] = cpu_baseline(a, *cpu_args)
-        stamp('cpu_baseline: %.2f pairs/s on %d threads' % (out['cpu_baseline']['value'], out['cpu_baseline']['cores']))
+    if grouped and a.mode == 'infer' and not a.graph and not a.no_train_step:
+        # BASELINE configs[2] is a DDP TRAINING config (model/cvig_fov.py:444-461; nn.DataParallel, model/cvig_baseline.py:339-343): the
+        # N > 1 line therefore also runs the training step in the same process group -- the overhead-embedding all-gather, the
+        # reduce-scatter of their gradients and the two asynchronous bucket all-reduces inside a real step, not only standalone
+        k = max(1, min(a.steps, 5))
+        tb = StepBench(a.model, 'train', a.precision, a.batch, a.fov, rank, world, device).run(k, max(1, min(a.warmup, 2)))
+        out['train_step'], out['train_step_detail'] = train_step_entry(a, tb, rank, world, device)
+        phases = tb.phases
+        stamp('train step in the same group: %.1f pairs/s, %.3f ms per step' % (tb.value, tb.ms))
+        del tb
+        torch.cuda.empty_cache()
+    if grouped and not a.no_microbench:
+        out['collectives']['microbench'] = collectives_microbench(a, rank, world, device, phases)
+        stamp('collectives microbench')
+    out['guards'] = guards_block(ops)
+    side = world == 1 and headline and not a.no_side_blocks and a.model == 'fov' and a.fov == 360 and a.batch == 128
+    if headline and not a.no_cpu_baseline:
+        def cpu_leg():
+            if rank == 0:
+                out['cpu_baseline'] = cpu_baseline(a, *cpu_args)
+                stamp('cpu_baseline: %.2f pairs/s on %d threads' % (out['cpu_baseline']['value'], out['cpu_baseline']['cores']))
+        if world > 1:
+            out['_after_group'] = cpu_leg      # N > 1: rank 0 times the CPU port once the process group is gone (every rank takes this
+        else:                                  # branch, so that all of them leave the group together and none waits on rank 0)
+            cpu_leg()
     if side:
         out['_side_full'] = sides_child(a)       # this process is idle on the GPU meanwhile (its memory is released)
         stamp('side blocks done')
     return out
+
+
+def train_step_entry(a, tb, rank, world, device):
+    """The training step measured inside the N > 1 line -> (compact entry for the stdout line, full block for the detail record)"""
+    allp = [tb.phases]
+    if world > 1:
+        allp = [None] * world
+        dist.all_gather_object(allp, tb.phases)
+    mx = {n: round(max(p.get(n, 0.0) for p in allp), 3) for n in tb.phases}
+    inflight = sum(v for k, v in tb.phases.items() if k.endswith('_all_reduce_issue_to_joined'))
+    stall = tb.phases.get('reducer_wait_stall', 0.0)
+    r = tb.roofline
+    entry = {'baseline_config': 'configs[2]: DDP training step, %d pairs per GPU, global batch %d' % (tb.B, tb.B * world),
+             'value': round(tb.value, 2), 'unit': 'pairs/s', 'ms_per_step': round(tb.ms, 3), 'steps': tb.steps, 'warmup': tb.warmup,
+             'dtype': tb.dtype(), 'loss': float(tb.loss.item()),
+             'per_phase_ms_max_over_ranks': mx,
+             'bucket_inflight_ms': round(inflight, 4), 'reducer_wait_stall_ms': round(stall, 4), 'overlap_hidden_ms': round(inflight - stall, 4),
+             'frac': r.get('frac'), 'whole_step_frac': r.get('whole_step_frac')}
+    full = dict(tb.line(), per_phase_ms={'rank0': tb.phases, 'max_over_ranks': mx, 'every_rank': allp})
+    return entry, full
 
 
 SIDE_ORDER = ('train_step_fp32', 'config4_semantic_bf16', 'train_step_bf16', 'config1_baseline', 'config5_retrieval', 'config5_retrieval_direct',
@@ -589,10 +664,10 @@ def side_blocks(a, rank, world, device, cvig_fov, ops):
         if 'error' in e:
             return e
         keys = ('metric', 'value', 'unit', 'dtype', 'jpeg_decode', 'staging', 'steady_state_pairs_per_s', 'pipeline_fill_s', 'stage_pairs_per_s',
-                'limiting_stage', 'overlap_efficiency_steady_state', 'gpu_stage_serialised_pairs_per_s', 'host_decode_pairs_per_s_per_core',
-                'host_decode_scaling')
+                'limiting_stage', 'overlap_efficiency_steady_state', 'overlap_efficiency_raw', 'gpu_stage_serialised_pairs_per_s',
+                'host_decode_pairs_per_s_per_core', 'host_decode_scaling')
         blk = {kk: e[kk] for kk in keys if kk in e}
-        blk['workload'] = e['config']['workload']
+        blk['workload'] = (e.get('config') or {}).get('workload')
         return blk
 
     guarded('train_step_fp32', train_fp32)
@@ -696,6 +771,8 @@ def compact_side(name, b):
     if isinstance(r, dict):
         c['kernel'] = short(r.get('kernel', ''), 48)
         c['frac'] = r.get('frac')
+        if r.get('frac_rocprof') is not None:
+            c['frac_rocprof'] = r['frac_rocprof']
         if r.get('bound') and r['bound'] != 'mfma':
             c['bound'] = r['bound']
     if name == 'config1_baseline':
@@ -710,8 +787,11 @@ def compact_side(name, b):
         c = {'unit': 'frac of 8 TB/s', 'kernels': {short(k.split(' ')[0], 40): v['frac_of_hbm_peak'] for k, v in b.get('kernels', {}).items()}}
     if name == 'batch_sweep':
         c = {'unit': 'pairs/s', 'points': {'%s_B%d' % (p_['precision'], p_['pairs_per_gpu']):
-                                           [p_['value'], p_.get('graph_replay', {}).get('value')] for p_ in b.get('points', [])},
-             'what': '[eager, hipGraph replay or null]'}
+                                           [p_.get('plain_one_stream_eager', {}).get('value', p_['value']),
+                                            p_['value'] if 'plain_one_stream_eager' in p_ else None,
+                                            p_.get('graph_replay', {}).get('value')] for p_ in b.get('points', [])},
+             'what': '[plain step: one stream, eager; PairEmbedder (what test() runs at B <= 64: two streams, bf16 pair as a hipGraph) or null; '
+                     'whole step as one hipGraph or null]'}
     if name.startswith('e2e'):
         for k in ('steady_state_pairs_per_s', 'overlap_efficiency_steady_state'):
             if k in b:
@@ -739,15 +819,18 @@ def compact_line(full):
     r = full.get('roofline')
     if isinstance(r, dict):
         line['roofline'] = {k: (short(r[k], 100) if isinstance(r[k], str) else r[k]) for k in
-                            ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'launches', 'avg_launch_ms', 'avg_launch_gflop',
-                             'all_conv_launches_tflops', 'whole_step_frac', 'wgrad_bf16_tflops_incl_layout_passes') if k in r}
+                            ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'frac_events', 'frac_rocprof', 'rocprof_avg_launch_ms', 'traffic',
+                             'launches', 'avg_launch_ms', 'avg_launch_gflop', 'all_conv_launches_tflops', 'whole_step_frac',
+                             'wgrad_bf16_tflops_incl_layout_passes') if k in r}
         ts = r.get('traffic_source')
-        if isinstance(ts, dict):
-            line['roofline']['traffic_source'] = {'file': ts.get('file'), 'stale': ts.get('stale')}
+        if isinstance(ts, dict):      # `traffic` is NOT measured in this run: the committed PMC passes, tied to the kernel sources' hashes
+            line['roofline']['traffic_source'] = {'file': ts.get('file'), 'stale': ts.get('stale'),
+                                                  'what': 'lookup: committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, not this run'}
     c = full.get('cpu_baseline')
     if isinstance(c, dict):
         line['cpu_baseline'] = {k: (short(c[k], 160) if isinstance(c[k], str) else c[k]) for k in
-                                ('value', 'unit', 'cores', 'kind', 'cpu', 'pairs_per_s_by_threads', 'sample') if k in c}
+                                ('value', 'unit', 'cores', 'kind', 'cpu', 'passes', 'pass_pairs_per_s', 'train_pairs_per_s', 'rank_ms_per_query',
+                                 'sample') if k in c}
     g = full.get('guards')
     if isinstance(g, dict):
         line['guards'] = {k: g[k] for k in ('tripped', 'forced_by_env', 'bf16_16x16x32_kernel_on', 'bf16_weight_resident_kernel_on') if k in g}
@@ -803,7 +886,7 @@ def emit(full, a):
     line['detail'] = (os.path.relpath(path, ROOT) if path else None)
     text = json.dumps(line, separators=(',', ':'))
     for shed in ('side.batch_sweep', 'side.hbm_kernels', 'collectives.per_phase_ms_max_over_ranks', 'side', 'collectives.devices',
-                 'cpu_baseline.sample', 'config.workload'):
+                 'cpu_baseline.sample', 'train_step.baseline_config', 'config.workload', 'train_step.per_phase_ms_max_over_ranks'):
         if len(text) < LINE_BUDGET:
             break
         d, keys = line, shed.split('.')
@@ -1197,52 +1280,115 @@ def cpu_model():
 
 
 def cpu_baseline(a, g, o, wts, semantic):
-    """The oracle (CPU restatement of the reference, kind 'port') timed on this host on a bounded sample of the same workload:
-    the first --cpu-pairs pairs (default 32, the batch SURVEY's CPU anchor and BASELINE configs[0] use) of the batch the GPU
-    step ran on, with torch's own oneDNN / BLAS build; thread counts and what is reported: cpu_thread_sweep."""
+    """The oracle (CPU restatement of the reference, kind 'port') timed on this host on a bounded sample of the same workload, by the
+    protocol of BASELINE.md section 4: same seeded inputs and weights as the GPU run, 1 warm-up + the MEDIAN of 3 timed passes, three legs:
+      (i)   `value`: the full eval step (transforms + 2 encoders + match + loss + ranks) on the first --cpu-pairs pairs (default 32, the
+            batch SURVEY's CPU anchor and BASELINE configs[0] use) of the batch the GPU step ran on;
+      (ii)  `train_pairs_per_s`: the full training step (forward with Dropout2d -> match -> loss -> backward -> Adam, the loop body of
+            model/cvig_fov.py:439-465 = O.train_step) on 8 of those pairs (the survey's anchor batch);
+      (iii) `rank_ms_per_query`: the loop body of test() (model/cvig_fov.py:543-558 = O.ranks) against a gallery of N = 1000.
+    Thread counts and what is reported: cpu_thread_sweep."""
     from oracle import cvig_fov_oracle as O
     n = g.shape[0]
     w = {k: (torch.from_numpy(v[0]), torch.from_numpy(v[1])) for k, v in wts.items()}
     norm = O.image_normalization_semantic if semantic else O.image_normalization
 
-    def cpu_step():
+    def transforms(m):
+        su_in, ov_in = [], []
+        for i in range(m):
+            s, ov = O.resize_pair(g[i], o[i], fov=a.fov, panorama=False)
+            su_in.append(norm(s))
+            ov_in.append(O.polar_transform(norm(ov)))
+        return torch.stack(su_in), torch.stack(ov_in)
+
+    def cpu_step(m=n):
         with torch.no_grad():
-            su_in, ov_in = [], []
-            for i in range(n):
-                s, ov = O.resize_pair(g[i], o[i], fov=a.fov, panorama=False)
-                su_in.append(norm(s))
-                ov_in.append(O.polar_transform(norm(ov)))
-            su = O.fov_dsm_forward(torch.stack(su_in), w, False)
-            ov = O.fov_dsm_forward(torch.stack(ov_in), w, True)
+            su_in, ov_in = transforms(m)
+            su = O.fov_dsm_forward(su_in, w, False)
+            ov = O.fov_dsm_forward(ov_in, w, True)
             ori, d = O.match(ov, su)
             loss = O.triplet_loss(d)
             ranks = (d <= torch.diagonal(d)[None, :]).sum(0)
         return su, ov, ori, d, loss, ranks
 
-    return cpu_thread_sweep(cpu_step, n, '%d pairs of the same synthetic batch, full step (transforms+encoders+match+loss+ranks)' % n)
+    out = cpu_thread_sweep(cpu_step, n, '%d pairs of the same synthetic batch, full step (transforms+encoders+match+loss+ranks)' % n,
+                           all_threads_fn=lambda: cpu_step(min(n, 16)), all_threads_units=min(n, 16))
+    threads = out['cores']
+    all_threads = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    try:
+        # leg (ii): the training step on 8 pairs; fresh weight copies per pass (Adam updates them in place)
+        nt = min(n, 8)
+        with torch.no_grad():
+            su_in, ov_in = transforms(nt)
+        trainable = ((0,) + O.TRAINABLE) if semantic else None
+
+        def train_pass():
+            ws = {k: (v[0].clone(), v[1].clone()) for k, v in w.items()}
+            wo = {k: (v[0].clone(), v[1].clone()) for k, v in w.items()}
+            t0 = time.perf_counter()
+            O.train_step(su_in, ov_in, ws, wo, trainable=trainable)
+            return time.perf_counter() - t0
+        train_pass()
+        tt = sorted(train_pass() for _ in range(3))
+        out['train_pairs_per_s'] = round(nt / tt[1], 3)
+        out['train_sample'] = '%d pairs, O.train_step (fwd+match+loss+bwd+Adam), 1 warm-up + median of 3: %s s' % (nt, [round(t, 3) for t in tt])
+        # leg (iii): the ranking loop body per query against N = 1000 gallery rows (synthetic N(0,1) embeddings, fov 360 -> W_e = 64)
+        gen = torch.Generator().manual_seed(4321)
+        we = int(a.fov / 360 * 512) // 8
+        gal = torch.randn((1000, 16, 4, 64), generator=gen)
+        qry = torch.randn((1000, 16, 4, we), generator=gen)
+        nq = 8
+
+        def rank_pass():
+            t0 = time.perf_counter()
+            with torch.no_grad():
+                for idx in range(nq):            # O.ranks' loop body, model/cvig_fov.py:545-552, for the first nq queries
+                    _, d = O.match(gal, qry[idx:idx + 1])
+                    d = torch.squeeze(d, 1)
+                    torch.sum(torch.le(d, d[idx])).item()
+            return (time.perf_counter() - t0) / nq
+        rank_pass()
+        rt = sorted(rank_pass() for _ in range(3))
+        out['rank_ms_per_query'] = round(rt[1] * 1e3, 3)
+        out['rank_sample'] = 'N = 1000 gallery, %d queries per pass, 1 warm-up + median of 3: %s ms/query' % (nq, [round(t * 1e3, 2) for t in rt])
+    finally:
+        torch.set_num_threads(all_threads)
+    return out
 
 
-def cpu_thread_sweep(fn, units, sample):
+def cpu_thread_sweep(fn, units, sample, all_threads_fn=None, all_threads_units=None):
     """ONE convention for every cpu_baseline of the line: the CPU port is timed at 16 threads -- this box's CPU share per GPU (or every
     core torch sees, if fewer; the survey container had 8). Rounds 2-5 also timed 8 threads and all 128: 16
-    won every time (r04: 5.7 / 7.5 / 3.6 pairs/s at 8 / 16 / 128; r05: 6.8 / 2.4 at 16 / 128 -- oversubscribed oneDNN convolutions),
-    so the other counts only cost the default run ~25 s. One warm-up call, then ONE timed call: ~10 s of CPU work on 32 pairs."""
+    won every time (r04: 5.7 / 7.5 / 3.6 pairs/s at 8 / 16 / 128; r05: 6.8 / 2.4 at 16 / 128 -- oversubscribed oneDNN convolutions).
+    One warm-up call, then the MEDIAN of 3 timed calls ('1 warm-up + median of >= 3'; rounds 1-5 timed one pass and
+    spread 12 % across records). all_threads_fn: one more timed call with every visible thread (reported once per run as
+    `all_threads`, in the detail record) on a smaller sample."""
     all_threads = torch.get_num_threads()
-    counts = [min(16, all_threads)]
-    by_threads = {}
-    torch.set_num_threads(counts[0])
+    threads = min(16, all_threads)
+    torch.set_num_threads(threads)
     fn()
-    for threads in counts:
-        torch.set_num_threads(threads)
+    times = []
+    for _ in range(3):
         t0 = time.perf_counter()
         fn()
-        by_threads[threads] = round(units / (time.perf_counter() - t0), 3)
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    value = round(units / times[1], 3)
+    extra = {}
+    if all_threads_fn is not None and all_threads > threads:
+        torch.set_num_threads(all_threads)
+        t0 = time.perf_counter()
+        all_threads_fn()
+        extra['all_threads'] = {'threads': all_threads, 'pairs_per_s': round((all_threads_units or units) / (time.perf_counter() - t0), 3),
+                                'sample': '%d pairs, one pass, no warm-up at this thread count' % (all_threads_units or units)}
     torch.set_num_threads(all_threads)
-    best = max(by_threads, key=lambda t: by_threads[t])
-    return {'value': by_threads[best], 'unit': 'pairs/s', 'cores': best, 'kind': 'port', 'cpu': cpu_model(),
-            'pairs_per_s_by_threads': {str(t): v for t, v in by_threads.items()},
-            'threads_convention': '%d threads (CPU share of one GPU on this box; %d visible)' % (counts[0], all_threads),
-            'sample': sample + '; 1 warm-up + 1 timed pass per thread count, torch %s CPU ops (oneDNN / BLAS as built)' % torch.__version__}
+    return {'value': value, 'unit': 'pairs/s', 'cores': threads, 'kind': 'port', 'cpu': cpu_model(), 'passes': 3,
+            'pass_pairs_per_s': [round(units / t, 3) for t in times],
+            'pairs_per_s_by_threads': {str(threads): value},
+            'threads_convention': '%d threads (CPU share of one GPU on this box; %d visible)' % (threads, all_threads),
+            'sample': sample + '; 1 warm-up + median of 3 timed passes, torch %s CPU ops (oneDNN / BLAS as built)' % torch.__version__,
+            **extra}
 
 
 def guards_block(ops):
@@ -1365,17 +1511,30 @@ def collectives_microbench(a, rank, world, device, phases=None, iters=10):
 
 
 def e2e_child(a, extra):
-    """`bench.py --mode e2e <extra>` as a child process on the same GPU (this process is idle meanwhile) -> its JSON line, or
-    {'error': ...}: a timeout kills the child's whole process group (loader workers, decode pool) and is reported, not dropped"""
-    cmd = [sys.executable, os.path.abspath(__file__), '--mode', 'e2e', '--batch', str(a.batch), '--fov', str(a.fov)] + list(extra)
-    rc, so, se = run_child(cmd, 300)
-    if rc is None:
-        return {'error': 'timeout after 300 s (process group killed)'}
-    for ln in so.splitlines():
-        if ln.startswith('{') and '"metric"' in ln:
-            return json.loads(ln)
-    sys.stderr.write('e2e child failed (%d): %s\n' % (rc, se[-800:]))
-    return {'error': 'exit status %d: %s' % (rc, se[-200:])}
+    """`bench.py --mode e2e <extra>` as a child process on the same GPU (this process is idle meanwhile) -> its FULL record (the
+    child's stdout carries only the compact line: the record comes from a --detail-out file of its own, stdout is the fallback),
+    or {'error': ...}: a timeout kills the child's whole process group (loader workers, decode pool) and is reported, not dropped"""
+    import tempfile
+    fd, path = tempfile.mkstemp(prefix='witw_e2e_detail_', suffix='.json')
+    os.close(fd)
+    os.remove(path)
+    cmd = [sys.executable, os.path.abspath(__file__), '--mode', 'e2e', '--batch', str(a.batch), '--fov', str(a.fov), '--detail-out', path] + list(extra)
+    try:
+        rc, so, se = run_child(cmd, 300)
+        if rc is None:
+            return {'error': 'timeout after 300 s (process group killed)'}
+        try:
+            return json.load(open(path))
+        except (OSError, ValueError):
+            pass
+        for ln in so.splitlines():
+            if ln.startswith('{') and '"metric"' in ln:
+                return json.loads(ln)
+        sys.stderr.write('e2e child failed (%d): %s\n' % (rc, se[-800:]))
+        return {'error': 'exit status %d: %s' % (rc, se[-200:])}
+    finally:
+        if os.path.exists(path):
+            os.remove(path)
 
 
 def e2e_bench(a, device):

@@ -75,6 +75,57 @@ def test_train_then_test_drivers_bf16(tmp_path, monkeypatch, capsys):
     assert 1 <= t3['median'] <= 6
 
 
+def test_test_driver_bf16_with_loader_workers_captures_and_replays(tmp_path, monkeypatch, capsys):
+    """test() in bf16 with DataLoader WORKERS and four equal-shaped batches: PairEmbedder captures its hipGraph on the second batch
+    while the loader's worker / pinning / ring-reaper threads are alive (thread-local capture mode), replays it on the
+    others, and the table equals the one of the eager path (num_workers=0, graphs off)."""
+    from witw_amd import cvig_fov
+    csv = _write_dataset(str(tmp_path), 16)
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setattr(cvig_fov.Globals, 'precision', 'bf16')
+    monkeypatch.setattr(cvig_fov.Globals, 'test_random_orientation', False, raising=False)
+    cvig_fov.train(dataset='cvusa', fov=70, val_quantity=2, batch_size=2, num_workers=0, num_epochs=1, csv_path=csv)
+    made = []
+    real = cvig_fov.PairEmbedder
+
+    class Spy(real):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            made.append(self)
+    monkeypatch.setattr(cvig_fov, 'PairEmbedder', Spy)
+    t_workers = cvig_fov.test(dataset='cvusa', fov=70, batch_size=4, num_workers=2, csv_path=csv)
+    st = made[-1].stats
+    assert st['captures'] == 1 and st['graph_replay'] >= 2 and st['capture_failures'] == 0, st
+    # the eager path: no graph, no second stream
+    monkeypatch.setattr(cvig_fov, 'PairEmbedder', lambda se, oe: Spy(se, oe, graph_max=0, dual_max=0))
+    t_eager = cvig_fov.test(dataset='cvusa', fov=70, batch_size=4, num_workers=0, csv_path=csv)
+    assert made[-1].stats['graph_replay'] == 0 and made[-1].stats['eager'] == 4
+    assert t_workers == t_eager, (t_workers, t_eager)
+
+
+def test_pair_embedder_falls_back_to_eager_when_capture_fails(monkeypatch):
+    """A capture that raises costs the key its graph, not the evaluation: same bits from the eager path, counted in stats."""
+    from witw_amd import cvig_fov, parallel
+    dev = torch.device('cuda:0')
+    wts = synth.fov_dsm_weights(5)
+    se = cvig_fov.FOV_DSM(False, weights=wts).to(dev).eval()
+    oe = cvig_fov.FOV_DSM(True, weights=wts).to(dev).eval()
+    se.precision = oe.precision = 'bf16'
+    s = torch.from_numpy(synth.normalized_images(5, 0, (4, 3, 128, 99))).to(dev)
+    p_ = torch.from_numpy(synth.normalized_images(5, 1, (4, 3, 128, 512))).to(dev)
+
+    def boom(*a, **k):
+        raise RuntimeError('capture invalidated (simulated)')
+    monkeypatch.setattr(parallel, 'CapturedStep', boom)
+    pe = cvig_fov.PairEmbedder(se, oe)
+    with torch.no_grad(), pytest.warns(UserWarning, match='capture failed'):
+        outs = [pe(s, p_) for _ in range(3)]
+        ref = (se.forward_bf16(s), oe.forward_bf16(p_))
+    assert pe.stats['capture_failures'] == 1 and pe.stats['captures'] == 0 and pe.stats['graph_replay'] == 0
+    for su, ov in outs:
+        assert torch.equal(su, ref[0]) and torch.equal(ov, ref[1])
+
+
 def test_train_driver_on_f16x3(tmp_path, monkeypatch):
     """train() with Globals.precision = 'fp16x3': forward, dgrad and wgrad on the split-fp16 arithmetic, fp32 checkpoints."""
     from witw_amd import cvig_fov

@@ -79,7 +79,10 @@ def test_config5_full_per_gpu_gallery_direct_and_dft_vs_oracle_sample():
     np.testing.assert_allclose(t_gpu.numpy(), d_true[qs_t].cpu().numpy(), rtol=0, atol=0)
     outside = (d_ref - t_ref[None, :]).abs() > ops.DISTANCE_EPS
     assert torch.equal((d_gpu <= t_gpu[None, :])[outside], (d_ref <= t_ref[None, :])[outside])
-    assert float(outside.float().mean()) > 0.9
+    # the band holds each query's TRUE row (difference 0: 64 of the 256 x 64 sampled pairs) and at most a handful of near ties: the
+    # comparison above covers > 99.5 % of the sample (round 5 asserted > 90 %)
+    inside = int((~outside).sum())
+    assert len(qs) <= inside <= len(qs) + 0.001 * outside.numel(), (inside, outside.numel())
     # ... and the listed nearest rows of the sampled queries are the oracle's nearest among the sampled rows (each list's rows are in
     # the sample): same order wherever neighbours are further apart than the band
     for n, q in enumerate(qs):

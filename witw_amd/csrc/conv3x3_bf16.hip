@@ -34,6 +34,9 @@ constexpr int IW = TW + 2;
 #ifndef WITW_BF_S16_DMA
 #define WITW_BF_S16_DMA 0       // 16x16x32 kernel: 1 = the input tile moves by LDS-DMA as well (A/B builds)
 #endif
+#ifndef WITW_BF_S16_PLANE16
+#define WITW_BF_S16_PLANE16 1   // 16x16x32 kernel: channel-group planes of a stage at a pitch of 0 mod 16 slots (conflict-free A reads); 0 = round 2-5 layout
+#endif
 #ifndef WITW_BF_S16_SPREAD
 #define WITW_BF_S16_SPREAD 3    // half-units (of 8 per chunk) over which the 16x16x32 kernel issues the staging pieces of the next chunk
 #endif
@@ -745,7 +748,14 @@ template <bool POOL, bool TRAIN>
 __global__ __launch_bounds__(512) void conv3x3_bf16_s16_kernel(ConvBfArgs p) {
     constexpr int TN = 128, NW = 8, TH = 8, NTHREADS = 512;
     constexpr int IH = TH + 2;
-    constexpr int IN_S = 2 * IH * IW;
+    // Plane pitch of the two 8-channel groups of a stage. A fragment read (ds_read_b128) is served in four groups of 16 lanes
+    // ({0-3,12-15,20-27}, {4-11,16-19,28-31}, the same + 32); in this kernel lanes 16-31 / 48-63 of a wave read channel group 1, so a
+    // 16-lane group mixes pixels l15 of plane 0 with pixels l15' of plane 1 and is conflict-free only if the plane pitch is a
+    // multiple of 16 slots (64 banks): IH*IW = 660 = 4 mod 16 put pixels 12-15 of plane 0 on the banks of pixels 8-11 of plane 1 --
+    // every A read 2-way, 36-38 % of the LDS-active cycles (profiles/r05_bf16_train_lds_pmc.txt). 672 slots per plane: the stage
+    // keeps its size (2 * 672 = 1344 = the 64-slot round-up of 1320 it already had).
+    constexpr int PL = WITW_BF_S16_PLANE16 ? (IH * IW + 15) / 16 * 16 : IH * IW;
+    constexpr int IN_S = 2 * PL;
     constexpr int IN_P = (IN_S + 63) / 64 * 64;
     constexpr int W_S = 9 * 2 * TN;
     constexpr int STAGE_S = IN_P + W_S;
@@ -797,12 +807,12 @@ __global__ __launch_bounds__(512) void conv3x3_bf16_s16_kernel(ConvBfArgs p) {
 #pragma unroll
     for (int i = 0; i < NIN_D; ++i) {
         const int s = (wave + NW * i) * 64 + lane;
-        const int q = s / (IH * IW);
-        const int pix = s - q * (IH * IW);
+        const int q = s / PL;
+        const int pix = s - q * PL;
         const int r = pix / IW, c = pix - r * IW;
         int gr = oy0 - 1 + r;
         int gc = ox0 - 1 + c;
-        bool ok = s < IN_S && gr >= 0 && gr < p.H;
+        bool ok = s < IN_S && pix < IH * IW && gr >= 0 && gr < p.H;
         if (TRAIN && p.dil_h) {
             ok = ok && !(gr & 1);
             gr >>= 1;
@@ -826,7 +836,7 @@ __global__ __launch_bounds__(512) void conv3x3_bf16_s16_kernel(ConvBfArgs p) {
         const int r = pix / IW, c = pix - r * IW;
         int gr = oy0 - 1 + r;
         int gc = ox0 - 1 + c;
-        bool ok = s < IN_S && gr >= 0 && gr < p.H;
+        bool ok = s < IN_S && pix < IH * IW && gr >= 0 && gr < p.H;
         if (TRAIN && p.dil_h) {
             ok = ok && !(gr & 1);
             gr >>= 1;
@@ -866,7 +876,7 @@ __global__ __launch_bounds__(512) void conv3x3_bf16_s16_kernel(ConvBfArgs p) {
 #pragma unroll
         for (int i = 0; i < NIN; ++i) {
             const int s = tid + i * NTHREADS;
-            u32x4* dst = (NIN * NTHREADS == IN_S || s < IN_S) ? in_s + (s & 1) * (IH * IW) + (s >> 1) : dummy_slot;
+            u32x4* dst = (NIN * NTHREADS == IN_S || s < IN_S) ? in_s + (s & 1) * PL + (s >> 1) : dummy_slot;
             *dst = rin[i];
         }
 #endif
@@ -876,8 +886,8 @@ __global__ __launch_bounds__(512) void conv3x3_bf16_s16_kernel(ConvBfArgs p) {
     // ---- this wave's tiles: rows 2*wm, 2*wm + 1 of the workgroup's 8, all 64 columns; channels wn*64 .. +63
     const int wm = wave >> 1, wn = wave & 1;
     // pixel tile a (0..7): row 2*wm + (a >> 2), columns 16*(a & 3) ..+15. A-fragment slot of this lane for tap offset `off`:
-    //   grp*(IH*IW) + (2*wm + (a>>2))*IW + 16*(a&3) + l15 + off  =  a_lane + off + [(a>>2)*IW + 16*(a&3): immediate]
-    const int a_lane = grp * (IH * IW) + 2 * wm * IW + l15;
+    //   grp*PL + (2*wm + (a>>2))*IW + 16*(a&3) + l15 + off  =  a_lane + off + [(a>>2)*IW + 16*(a&3): immediate]
+    const int a_lane = grp * PL + 2 * wm * IW + l15;
     // channel tile bt (0..3): B-fragment slot = IN_P + tap*2*TN + grp*TN + wn*64 + 16*bt + l15 = w_lane + tap*2*TN + [16*bt]
     const int w_lane = IN_P + grp * TN + wn * 64 + l15;
 

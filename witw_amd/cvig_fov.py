@@ -1148,7 +1148,8 @@ class PairEmbedder(object):
         self._streams = None
         self._seen = {}
         self._graphs = {}
-        self.stats = {'eager': 0, 'dual_stream': 0, 'graph_replay': 0, 'captures': 0}
+        self._uncapturable = set()      # keys whose capture failed once: they stay on the eager path (same bits)
+        self.stats = {'eager': 0, 'dual_stream': 0, 'graph_replay': 0, 'captures': 0, 'capture_failures': 0}
 
     def _key(self, surface, polar):
         sig = tuple((q.data_ptr(), q._version, getattr(q, '_witw_version', 0)) for enc in (self.se, self.oe) for q in enc.parameters())
@@ -1196,10 +1197,24 @@ class PairEmbedder(object):
         if B <= graph_max:
             key = self._key(surface, polar)
             g = self._graphs.get(key)
-            if g is None and self._seen.get(key, 0) >= 1:
+            if g is None and self._seen.get(key, 0) >= 1 and key not in self._uncapturable:
                 self._graphs = {k: v for k, v in self._graphs.items() if k[:5] != key[:5]}      # graphs of older weights of this shape
-                g = self._graphs[key] = parallel.CapturedStep(lambda a, b: body(a, b), [surface, polar], warmup=1)
-                self.stats['captures'] += 1
+                # Other threads of a driver process make HIP calls meanwhile (ring.PinnedRing's reaper synchronises events, a
+                # DataLoader pin_memory thread allocates): the capture is thread-local so that they cannot invalidate it, and a
+                # capture that fails all the same costs this key its graph, not the evaluation -- the eager path gives the same bits
+                try:
+                    g = self._graphs[key] = parallel.CapturedStep(lambda a, b: body(a, b), [surface, polar], warmup=1,
+                                                                  capture_error_mode='thread_local')
+                    self.stats['captures'] += 1
+                except Exception as e:      # noqa: BLE001 -- whatever the runtime raises for a broken capture
+                    import warnings
+                    warnings.warn('PairEmbedder: hipGraph capture failed (%s: %s); this shape stays on the eager path'
+                                  % (type(e).__name__, str(e)[:200]))
+                    self._graphs.pop(key, None)
+                    self._uncapturable.add(key)
+                    self.stats['capture_failures'] += 1
+                    torch.cuda.synchronize()
+                    g = None
             if g is not None:
                 su, ov = g(surface, polar)
                 self.stats['graph_replay'] += 1

@@ -23,22 +23,46 @@ def _write_pair(args):
         img = np.asarray(Image.fromarray(small).resize((w + 16, h + 16), Image.BICUBIC))[8:8 + h, 8:8 + w]
         fine = g.integers(-12, 13, size=(h, w, 3))
         return np.clip(img.astype(np.int16) + fine, 0, 255).astype(np.uint8)
-    Image.fromarray(picture(512, 512)).save(os.path.join(root, 'ov_%05d.jpg' % i), quality=90)
-    Image.fromarray(picture(224, 224)).save(os.path.join(root, 'su_%05d.jpg' % i), quality=90)
+    for name, (h, w) in (('ov_%05d.jpg' % i, (512, 512)), ('su_%05d.jpg' % i, (224, 224))):
+        # written under a temporary name and renamed into place: a writer killed half way (bench.run_child's timeout) never leaves
+        # a truncated file under the name the next block would reuse
+        tmp = os.path.join(root, '.%s.%d.tmp' % (name, os.getpid()))
+        Image.fromarray(picture(h, w)).save(tmp, format='JPEG', quality=90)
+        os.replace(tmp, os.path.join(root, name))
     return i
 
 
 def make_dataset(root, n_pairs, n_unique=512, seed=77, procs=8):
     """A synthetic cvusa-format data set (CSV columns: overhead, surface; model/cvig_fov.py:38-44): n_pairs rows over
     min(n_pairs, n_unique) distinct JPEG pairs (overhead 512x512, ground 224x224: the raw sizes of BASELINE.json)."""
+    import json
     import multiprocessing as mp
     os.makedirs(root, exist_ok=True)
     n_unique = min(n_pairs, n_unique)
+    # A kept directory (bench.py --e2e-dir, shared by two blocks) is reused only for what its MANIFEST vouches for: the manifest is
+    # written LAST, names the generator (seed, sizes, quality) and how many pairs are complete; files of another seed / size, or of a
+    # run that died before its manifest, are written again.
+    want = {'generator': 'witw_amd.e2e._write_pair/1', 'seed': int(seed), 'overhead': [512, 512], 'ground': [224, 224], 'quality': 90}
+    mpath = os.path.join(root, 'manifest.json')
+    have = 0
+    try:
+        m = json.load(open(mpath))
+        if all(m.get(k) == v for k, v in want.items()):
+            have = int(m.get('pairs_complete', 0))
+    except (OSError, ValueError):
+        pass
     todo = [(root, i, seed) for i in range(n_unique)
-            if not (os.path.exists(os.path.join(root, 'ov_%05d.jpg' % i)) and os.path.exists(os.path.join(root, 'su_%05d.jpg' % i)))]
-    if todo:            # a directory kept from an earlier block (bench.py --e2e-dir) already holds the files: same seed, same bytes
+            if i >= have or not (os.path.exists(os.path.join(root, 'ov_%05d.jpg' % i)) and os.path.exists(os.path.join(root, 'su_%05d.jpg' % i)))]
+    if todo:
+        if os.path.exists(mpath):
+            os.remove(mpath)
         with mp.get_context('spawn').Pool(procs) as pool:
             pool.map(_write_pair, todo, chunksize=16)
+    if todo or have < n_unique:
+        tmp = mpath + '.%d.tmp' % os.getpid()
+        with open(tmp, 'w') as f:
+            json.dump(dict(want, pairs_complete=max(have, n_unique)), f)
+        os.replace(tmp, mpath)
     csv = os.path.join(root, 'pairs.csv')
     with open(csv, 'w') as f:
         for i in range(n_pairs):
@@ -254,7 +278,11 @@ def bench(a, device, n_pairs=None, workers=None, keep_dir=None, decode=None, pre
            'pipeline_fill_s': round(t_first - t0, 3),
            'note': 'value = the whole pass including the pipeline fill (a DataLoader worker decodes one whole batch: the first one '
                    'arrives after ~batch x decode time); steady_state = from the first finished batch to the end',
-           'overlap_efficiency_steady_state': round(((n_pairs - n_first) / max(1e-9, t_end - t_first)) / min(rates.values()), 3),
+           # steady state over the slowest stage's own rate. The stage rates are short separate measurements (8 pipelined iterations of
+           # ONE batch; one loader pass) and read 1-2 % low against the long pass, so the raw quotient can exceed 1: it is reported
+           # clamped, the raw value beside it
+           'overlap_efficiency_steady_state': round(min(1.0, ((n_pairs - n_first) / max(1e-9, t_end - t_first)) / min(rates.values())), 3),
+           'overlap_efficiency_raw': round(((n_pairs - n_first) / max(1e-9, t_end - t_first)) / min(rates.values()), 3),
            'gpu_stage_serialised_pairs_per_s': round(nb / t_gpu_serial, 1),      # staging and compute on one stream (the round-3 way of timing it)
            **({'host_decode_scaling': scaling, 'host_decode_pairs_per_s_per_core': scaling['host_decode_pairs_per_s_per_core']} if scaling else {}),
            'dataset_written_in_s': round(t_make, 1)}

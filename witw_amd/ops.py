@@ -207,6 +207,8 @@ def conv3x3_fwd(x_nhwc, packed, stride_h=1, circular=False, relu=True, pool=Fals
         e1.record()
         variant = (lib.witw_conv3x3_tile_n(packed.cout), stride_h, bool(pool),
                    lib.witw_conv3x3_workgroup_waves(B, H, W, packed.cout, stride_h))
+        if dilate_h:      # the zero-row-skipping instantiation (GEO = 2) is a launch class of its own: credited its real input rows
+            variant = variant + ('dil',)
         prof.append((variant, 2.0 * packed.cin * packed.cout * (4 if getattr(packed, 'taps4', False) else 9) * flop_rows * W * B, e0, e1))
         if PROFILE_BY_KERNEL is not None:
             PROFILE_BY_KERNEL.setdefault(last_kernel_variant(), []).append((prof[-1][1], e0, e1))
@@ -1184,7 +1186,7 @@ def conv3x3_bf16_fwd(x_nhwc, packed, stride_h=1, circular=False, relu=True, pool
         e1.record()
         # the 64-input-channel layer runs on its own kernel (csrc/conv3x3_bf16_wres.hip): its own launch class
         kind = 'bf16_wres' if last_kernel_variant().startswith('conv3x3_bf16_wres_kernel') else 'bf16'
-        prof.append(((kind, lib.witw_conv3x3_tile_n(packed.cout), stride_h, bool(pool)),
+        prof.append(((kind, lib.witw_conv3x3_tile_n(packed.cout), stride_h, bool(pool)) + (('dil',) if dilate_h else ()),
                      2.0 * packed.cin * packed.cout * 9 * (h_phys if dilate_h else Ho) * W * B, e0, e1))      # dilated: see conv3x3_fwd
         if PROFILE_BY_KERNEL is not None:
             PROFILE_BY_KERNEL.setdefault(last_kernel_variant(), []).append((prof[-1][1], e0, e1))
@@ -1379,7 +1381,7 @@ def conv3x3_f16x3_fwd(x_split, packed, stride_h=1, circular=False, relu=True, po
                'witw_conv3x3_f16x3_fwd_ex')
     if prof is not None:
         e1.record()
-        prof.append((('f16x3', lib.witw_conv3x3_tile_n(packed.cout), stride_h, bool(pool)),
+        prof.append((('f16x3', lib.witw_conv3x3_tile_n(packed.cout), stride_h, bool(pool)) + (('dil',) if dilate_h else ()),
                      2.0 * packed.cin * packed.cout * 9 * (h_phys if dilate_h else Ho) * W * B, e0, e1))      # dilated: see conv3x3_fwd
     if want_pool_code:
         return y, code

@@ -280,7 +280,7 @@ class CapturedStep:
     inputs; __call__ copies new inputs into those buffers and replays. At 8 pairs the bf16 inference step issues ~60
     kernels of 5-30 us each and is bound by their launches; the graph removes that bound."""
 
-    def __init__(self, fn, example_inputs, warmup=2):
+    def __init__(self, fn, example_inputs, warmup=2, capture_error_mode='global'):
         self.static_in = [t.clone() for t in example_inputs]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -290,7 +290,9 @@ class CapturedStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # capture_error_mode 'thread_local': HIP calls of OTHER host threads (loader / pinning / event-reaper threads of a driver)
+        # do not invalidate the capture; 'global' (torch's default) makes any such call an error
+        with torch.cuda.graph(self.graph, capture_error_mode=capture_error_mode):
             out = fn(*self.static_in)
         self.static_out = out
 
