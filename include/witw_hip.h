@@ -172,6 +172,15 @@ int witw_match_pairs(const float* ov, const float* su, const float* wn, const fl
                      int n_pairs, int Bo, int Bs, int We, long long* orientation, float* distance, float* score, void* stream);
 int witw_rank_count_band(const float* distance, const float* threshold, float eps, int* counts, int* pair_o, int* pair_s,
                          int* n_pairs, int capacity, int Bo, int Bs, void* stream);
+/* witw_rank_count_band's list resolved without reading its length back to the host (model/cvig_fov.py:547-552: the rank is a
+ * count of distances <= the true match's): re-scores the first min(*n_pairs_dev, capacity) pairs as witw_match_pairs does and
+ * adds 1 to counts[pair_s[i]] for every pair with exact distance <= threshold[pair_s[i]]. */
+int witw_match_pairs_count(const float* ov, const float* su, const float* wn, const float* sn, const int* pair_o, const int* pair_s,
+                           const int* n_pairs_dev, int capacity, int Bo, int Bs, int We, const float* threshold, int* counts, void* stream);
+/* which kernel witw_match_pairs runs: 1 = v_fma_f32 chain on the vector pipe, one lane per shift (default, round 6); 0 = the
+ * v_mfma_f32_32x32x2_f32 chain of rounds 4-5. Same bits (the f32 MFMA accumulates as a fused-multiply-add chain in k order).
+ * impl < 0 only queries; returns the previous setting. */
+int witw_match_pairs_impl(int impl);
 
 /* ---- Dropout2d masks (AddDropout, model/cvig_fov.py:234-245): out [n_layers][B][C] = 0 or 1/(1-p) per (sample, channel) from
  * Philox4x32-10 keyed on `seed`, counter (sample*C + channel, layers[i] | encoder << 16, step, rank) -- reproducible from those

@@ -106,6 +106,8 @@ SIGNATURES = {
     'witw_topk_smallest_ws': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_longlong, c_void_p, c_void_p]),
     'witw_rank_count_thresh': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     'witw_match_pairs': (c_int, [c_void_p] * 6 + [c_int] * 4 + [c_void_p] * 4),
+    'witw_match_pairs_impl': (c_int, [c_int]),
+    'witw_match_pairs_count': (c_int, [c_void_p] * 7 + [c_int] * 4 + [c_void_p] * 3),
     'witw_rank_count_band': (c_int, [c_void_p, c_void_p, c_float] + [c_void_p] * 4 + [c_int] * 3 + [c_void_p]),
     'witw_dropout2d_scales': (c_int, [c_void_p, ctypes.c_ulonglong, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint, c_void_p, c_int, c_int, c_int,
                                       c_float, c_void_p]),

@@ -42,8 +42,8 @@ bool witw_fills_rounds(long long workgroups);
 
 // conv3x3_bf16_wres.hip: the weight-resident 64-input-channel bf16 forward, chosen by witw_conv3x3_bf16_fwd_ex
 bool witw_bf16_wres_applies(int B, int H, int W, int Cin, int Cout);
-int witw_bf16_wres_launch(const void* x, const void* wpk, const float* bias, const void* gate, void* y, int B, int H, int W, int Cout,
-                          int pad_circular, int relu, void* stream);      // gate: null, or the dgrad launch's ReLU gate (a tensor shaped like y)
+int witw_bf16_wres_launch(const void* x, const void* wpk, const float* bias, const void* gate, const void* gate_bits, void* y, int B, int H,
+                          int W, int Cout, int pad_circular, int relu, void* stream);      // gate: null, or the dgrad launch's ReLU gate (a tensor shaped like y)
 
 // ReLU on PACKED bf16 pairs: max as signed 16-bit integers against `floor2` -- a negative float is a negative integer (and -0
 // becomes +0), a positive one is itself; floor2 = 0 is the ReLU, 0x80008000 (the smallest integers) leaves the pair unchanged, so

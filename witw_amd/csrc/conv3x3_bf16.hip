@@ -1325,13 +1325,30 @@ int witw_conv3x3_bf16_fwd_ex(const void* x_bf16, const void* wpk_bf16, const flo
     // 64 input channels, plain forward: the kernel that keeps the filter in LDS (conv3x3_bf16_wres.hip; bit-identical to the 32x32x16 kernel)
     // (round 5: also the gated form, i.e. the data gradient of a 64-channel layer -- cvig_semantic's layer 2, where layer 0 trains)
     if (stride_h == 1 && !pool && !out_nchw_f32 && !dropmask && !dilate_h && witw_bf16_wres_applies(B, H, W, Cin, Cout))
-        return witw_bf16_wres_launch(x_bf16, wpk_bf16, bias, gate_bf16, y, B, H, W, Cout, pad_circular, relu, stream);
+        return witw_bf16_wres_launch(x_bf16, wpk_bf16, bias, gate_bf16, nullptr, y, B, H, W, Cout, pad_circular, relu, stream);
     if (Cout >= 128) {
         if (stride_h == 2) return launch_bf<128, 2, false>(a, st);
         return pool ? launch_bf<128, 1, true>(a, st) : launch_bf<128, 1, false>(a, st);
     }
     if (stride_h == 2) return launch_bf<64, 2, false>(a, st);
     return pool ? launch_bf<64, 1, true>(a, st) : launch_bf<64, 1, false>(a, st);
+}
+
+// The data gradient of a 64-input-channel layer with the ReLU gate as ONE BIT per output (gate_bits [B,H,W,Cout/8] bytes: bit c & 7
+// of byte c >> 3 says whether channel c of that pixel passes; written by witw_conv_first2_bf16_fwd_train) instead of a bf16 tensor
+// shaped like y: cvig_semantic's layer 2 (model/cvig_semantic.py:301-309: layer 0 trains, so the gradient crosses layer 0's ReLU),
+// where the tensor form is the 1.07 GB layer-0 activation. Runs on the weight-resident kernel only: witw_conv3x3_bf16_gatebits_ok
+// says whether a shape qualifies (the caller keeps the tensor gate otherwise). Same bits as witw_conv3x3_bf16_fwd_ex with the tensor.
+int witw_conv3x3_bf16_gatebits_ok(int B, int H, int W, int Cin, int Cout) { return witw_bf16_wres_applies(B, H, W, Cin, Cout) ? 1 : 0; }
+
+int witw_conv3x3_bf16_fwd_gatebits(const void* x_bf16, const void* wpk_bf16, const float* bias, const void* gate_bits, void* y, int B, int H,
+                                   int W, int Cin, int Cout, int pad_circular, int relu, void* stream) {
+    WITW_CHECK_ARG(x_bf16 && wpk_bf16 && bias && gate_bits && y, "conv3x3_bf16_fwd_gatebits: null pointer");
+    WITW_CHECK_ARG(B > 0 && H > 0 && W > 0, "conv3x3_bf16_fwd_gatebits: bad shape");
+    WITW_CHECK_ARG(witw_bf16_wres_applies(B, H, W, Cin, Cout),
+                   "conv3x3_bf16_fwd_gatebits: B=%d H=%d W=%d Cin=%d Cout=%d does not run on the weight-resident kernel (witw_conv3x3_bf16_gatebits_ok)",
+                   B, H, W, Cin, Cout);
+    return witw_bf16_wres_launch(x_bf16, wpk_bf16, bias, nullptr, gate_bits, y, B, H, W, Cout, pad_circular, relu, stream);
 }
 
 int witw_maxpool2x2_bwd_bf16(const void* dy_bf16, const unsigned char* code, void* dx_bf16, int B, int Hp, int Wp, int H, int W,

@@ -77,6 +77,8 @@ struct WresArgs {
     const float* bias;        // [>= Cout]
     unsigned short* y;        // NHWC bf16 [B,H,W,Cout]
     const unsigned short* gate;      // GATE instantiation: bf16 tensor shaped like y; outputs where gate <= 0 are zeroed (the ReLU backward of a dgrad launch)
+    const unsigned char* gate_bits;  // GATE = 2: the same gate as ONE BIT per output, [B,H,W,Cout/8] bytes, bit c & 7 of byte c >> 3 = channel c passes
+                                     // (written by the training form of conv_first2_bf16_kernel: 67 MB instead of a 1.07 GB activation)
     int B, H, W, Cout;
     int tiles_x, tiles_y, n_sp;      // spatial (team) tiles per row / column of an image, in all
     int n_cb;                 // blocks of 64 output channels
@@ -104,7 +106,7 @@ __device__ __forceinline__ void wres_dma16(i32x4 rs, unsigned lds_addr, unsigned
 
 __device__ unsigned long long wres_stamps[2][8];     // WITW_WRES_STAMPS=1 diagnostic: phase ticks of waves 0 and 4 (one per team), third iteration of workgroup 0
 
-template <bool REC, bool GATE>
+template <bool REC, int GATE>      // GATE: 0 none, 1 = bf16 tensor shaped like y, 2 = one bit per output (gate_bits)
 __global__ __launch_bounds__(WRT, 1) void conv3x3_bf16_wres_kernel(WresArgs p) {
     __shared__ __attribute__((aligned(1024))) u32x4 a_s[WITW_WRES_DMA ? 2 * DIMG / 16 : 2 * 8 * WPOS];      // per team the input tile (47,104 B; register form 61,696)
     __shared__ u32x4 w_s[4 * 9 * 2 * 64];           // 73,728 B: this channel block's filter
@@ -242,6 +244,10 @@ __global__ __launch_bounds__(WRT, 1) void conv3x3_bf16_wres_kernel(WresArgs p) {
     // steps hide them; in the V phase a compiler wait for them would also wait for the tile DMA issued behind them, which the
     // compiler cannot see) and waited for with the builtin at the start of the V phase, in front of the DMA
     u32x4 gt[4];
+    unsigned gb[4] = {0u, 0u, 0u, 0u};               // GATE = 2: the byte (8 channels) of each of the four stores
+    auto bits_mask = [](unsigned byte, int e) -> unsigned {      // dword e of an octet = channels 2e, 2e + 1
+        return (((byte >> (2 * e)) & 1u) ? 0x0000ffffu : 0u) | (((byte >> (2 * e + 1)) & 1u) ? 0xffff0000u : 0u);
+    };
     auto gate_mask = [](unsigned w) -> unsigned {      // 0xffff per bf16 half that is > 0 (conv3x3_bf16.hip: gate_open)
         const unsigned lo = ((w & 0x7fffu) != 0u && !(w & 0x8000u)) ? 0x0000ffffu : 0u;
         const unsigned hi = ((w & 0x7fff0000u) != 0u && !(w & 0x80000000u)) ? 0xffff0000u : 0u;
@@ -321,9 +327,13 @@ __global__ __launch_bounds__(WRT, 1) void conv3x3_bf16_wres_kernel(WresArgs p) {
             const int c = lane + 64 * (k & 1);
             const int px = c >> 3, c8 = c & 7;          // pixel 0..15 of the round: row px >> 3, column px & 7
             const int oy = poy0 + 4 * mrow + 2 * (k >> 1) + (px >> 3), ox = pox0 + 8 * mcol + (px & 7);
-            if (GATE) {
+            if (GATE == 1) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[k][e] &= gate_mask(gt[k][e]);
+            }
+            if (GATE == 2) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[k][e] &= bits_mask(gb[k], e);
             }
             if (pvalid)
                 __builtin_nontemporal_store(v[k], reinterpret_cast<u32x4*>(p.y + (((size_t)pb * p.H + oy) * p.W + ox) * p.Cout + cb * 64 + c8 * 8));
@@ -393,7 +403,8 @@ __global__ __launch_bounds__(WRT, 1) void conv3x3_bf16_wres_kernel(WresArgs p) {
                 const int c = lane + 64 * (k & 1);
                 const int px = c >> 3, c8 = c & 7;
                 const int oy = ty * WTH + 4 * mrow + 2 * (k >> 1) + (px >> 3), ox = tx * WTW + 8 * mcol + (px & 7);
-                gt[k] = *reinterpret_cast<const u32x4*>(p.gate + (((size_t)b * p.H + oy) * p.W + ox) * p.Cout + cb * 64 + c8 * 8);
+                if (GATE == 1) gt[k] = *reinterpret_cast<const u32x4*>(p.gate + (((size_t)b * p.H + oy) * p.W + ox) * p.Cout + cb * 64 + c8 * 8);
+                if (GATE == 2) gb[k] = p.gate_bits[(((size_t)b * p.H + oy) * p.W + ox) * (p.Cout >> 3) + cb * 8 + c8];
             }
         }
         if (!WITW_WRES_DMA) fetch_setup(tile_of(it + 1));
@@ -480,10 +491,11 @@ bool witw_bf16_wres_applies(int B, int H, int W, int Cin, int Cout) {
     return n_sp * (Cout / 64) >= 32 * 256 && n_sp < 0x7fffffffLL;      // 16 tile pairs per workgroup pay for loading the filter block once
 }
 
-int witw_bf16_wres_launch(const void* x, const void* wpk, const float* bias, const void* gate, void* y, int B, int H, int W, int Cout,
-                          int pad_circular, int relu, void* stream) {
+int witw_bf16_wres_launch(const void* x, const void* wpk, const float* bias, const void* gate, const void* gate_bits, void* y, int B, int H,
+                          int W, int Cout, int pad_circular, int relu, void* stream) {
     WresArgs a;
     a.x = (const u32x4*)x; a.wpk = (const u32x4*)wpk; a.bias = bias; a.y = (unsigned short*)y; a.gate = (const unsigned short*)gate;
+    a.gate_bits = (const unsigned char*)gate_bits;
     a.B = B; a.H = H; a.W = W; a.Cout = Cout;
     a.tiles_x = W / WTW; a.tiles_y = H / WTH;
     a.n_sp = B * a.tiles_x * a.tiles_y;            // team tiles; a workgroup walks pairs of them
@@ -495,9 +507,9 @@ int witw_bf16_wres_launch(const void* x, const void* wpk, const float* bias, con
     if (q < 1) q = 1;
     a.q_per_xcd = q;
     const unsigned grid = 8u * (unsigned)(q * a.n_cb);
-    const bool rec = !gate && getenv("WITW_WRES_STAMPS") != nullptr && (a.n_sp + 1) / 2 >= 3 * 8 * q;      // diagnostic, synchronous
+    const bool rec = !gate && !gate_bits && getenv("WITW_WRES_STAMPS") != nullptr && (a.n_sp + 1) / 2 >= 3 * 8 * q;      // diagnostic, synchronous
     if (rec) {
-        hipLaunchKernelGGL((conv3x3_bf16_wres_kernel<true, false>), dim3(grid), dim3(WRT), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((conv3x3_bf16_wres_kernel<true, 0>), dim3(grid), dim3(WRT), 0, (hipStream_t)stream, a);
         (void)hipDeviceSynchronize();
         unsigned long long h[2][8];
         if (hipMemcpyFromSymbol(h, HIP_SYMBOL(wres_stamps), sizeof(h)) == hipSuccess)
@@ -505,13 +517,15 @@ int witw_bf16_wres_launch(const void* x, const void* wpk, const float* bias, con
                 fprintf(stderr, "conv3x3_bf16_wres team %d (wave %d), third iteration (ticks): V input->LDS %llu, V epilogue %llu, barrier %llu, "
                                 "M MFMA loop %llu, barrier %llu, total %llu\n", w, 4 * w, h[w][1] - h[w][0], h[w][2] - h[w][1], h[w][3] - h[w][2],
                         h[w][4] - h[w][3], h[w][5] - h[w][4], h[w][5] - h[w][0]);
+    } else if (gate_bits) {
+        hipLaunchKernelGGL((conv3x3_bf16_wres_kernel<false, 2>), dim3(grid), dim3(WRT), 0, (hipStream_t)stream, a);
     } else if (gate) {
-        hipLaunchKernelGGL((conv3x3_bf16_wres_kernel<false, true>), dim3(grid), dim3(WRT), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((conv3x3_bf16_wres_kernel<false, 1>), dim3(grid), dim3(WRT), 0, (hipStream_t)stream, a);
     } else {
-        hipLaunchKernelGGL((conv3x3_bf16_wres_kernel<false, false>), dim3(grid), dim3(WRT), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((conv3x3_bf16_wres_kernel<false, 0>), dim3(grid), dim3(WRT), 0, (hipStream_t)stream, a);
     }
     WITW_CHECK_LAUNCH("conv3x3_bf16_wres");
-    witw_note_variant(gate ? "conv3x3_bf16_wres_kernel<gate>" : "conv3x3_bf16_wres_kernel");
+    witw_note_variant(gate_bits ? "conv3x3_bf16_wres_kernel<gate_bits>" : gate ? "conv3x3_bf16_wres_kernel<gate>" : "conv3x3_bf16_wres_kernel");
     return WITW_OK;
 }
 

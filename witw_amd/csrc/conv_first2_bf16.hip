@@ -48,6 +48,8 @@ struct First2Args {
     const u32x4* wpk2;        // layer-2 filter, conv3x3_bf16 packing [4 chunks][9 taps][2 groups][64][8 bf16]
     const float* bias2;       // [64]
     unsigned short* y;        // NHWC bf16 [B,H/2,W/2,64]
+    unsigned char* pool_code; // TRAIN: arg-max codes of the fused max-pool, [B,H/2,W/2,64] (dy*2+dx, first maximum in scan order)
+    unsigned char* gate_bits; // TRAIN: layer 0's ReLU gate, one bit per output: [B,H,W,8] bytes, bit c & 7 of byte c >> 3 = channel c > 0
     int B, C, H, W;
     int tiles_x, tiles_y;
     int n_tiles;
@@ -56,7 +58,11 @@ struct First2Args {
 
 __device__ unsigned long long f2_stamps[2][8];       // WITW_F2_STAMPS=1 diagnostic: phase ticks of waves 0 and 7, third tile of workgroup 0
 
-template <int CW, bool REC>
+// TRAIN: what the backward of a training step needs instead of the two activations (cvig_semantic: layer 0 trains, so the gradient
+// goes back through both layers, model/cvig_semantic.py:301-309): the arg-max codes of the max-pool and layer 0's ReLU gate as one
+// bit per output (64 bits per pixel = 67 MB at 128 images against the 1.07 GB bf16 map), both produced in phase D -- the codes from
+// the accumulators, the bits from the layer-2 operand image, which stays in LDS until the next tile's phase B.
+template <int CW, bool REC, bool TRAIN>
 __global__ __launch_bounds__(F2T, 1) void conv_first2_bf16_kernel(First2Args p) {
     static_assert(CW == 4 || CW == 8, "4 or 8 bf16 per raw pixel");
     constexpr int NMF = (CW == 4) ? 3 : 5;
@@ -65,6 +71,7 @@ __global__ __launch_bounds__(F2T, 1) void conv_first2_bf16_kernel(First2Args p) 
     __shared__ u32x4 w_s[4 * 9 * 2 * 64];           // 73,728 B: layer-2 filter, resident for every tile of this workgroup
     __shared__ pix_t raw_s[RH * RW];                // 3.4 / 6.9 KB
     __shared__ u32x4 slab_s[8 * 64];                // 8 KB: one 1 KB output slab per wave
+    __shared__ unsigned char cslab_s[TRAIN ? 8 * 512 : 16];      // TRAIN: one 512-byte code slab per wave
     __shared__ float b0_s[64];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -291,6 +298,7 @@ __global__ __launch_bounds__(F2T, 1) void conv_first2_bf16_kernel(First2Args p) 
         // register r <-> pixel m = (r&3) + 8*(r>>2) + 4*hq of the M-tile, m = 16*row + column: the window of pooled column
         // jp = (r&3)/2 + 4*((r>>2)&1) + 2*hq is registers {r, r+1, r+8, r+9} (r&3 in {0,2}, r < 8)
         __bf16* slab = reinterpret_cast<__bf16*>(slab_s + wave * 64);
+        unsigned char* cslab = cslab_s + (TRAIN ? wave * 512 : 0);
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -299,13 +307,44 @@ __global__ __launch_bounds__(F2T, 1) void conv_first2_bf16_kernel(First2Args p) 
                 const float m4 = fmaxf(fmaxf(acc[nt][r], acc[nt][r + 1]), fmaxf(acc[nt][r + 8], acc[nt][r + 9]));
                 const int jp = (jj & 1) + 4 * (jj >> 1) + 2 * hq;
                 slab[jp * 64 + nt * 32 + l31] = (__bf16)fmaxf(m4 + b2[nt], 0.f);
+                if (TRAIN)      // first position attaining the max, scan order (0,0),(0,1),(1,0),(1,1) as torch's max_pool2d (conv3x3_bf16.hip)
+                    cslab[jp * 64 + nt * 32 + l31] = (unsigned char)((acc[nt][r] == m4) ? 0 : (acc[nt][r + 1] == m4) ? 1 : (acc[nt][r + 8] == m4) ? 2 : 3);
             }
+        if (TRAIN) __builtin_amdgcn_wave_barrier();      // (compiler only: the other lanes' slab writes stay in front of the reads)
         {
             const int jp = lane >> 3, c8 = (lane & 7) * 8;
             const u32x4 v = *reinterpret_cast<const u32x4*>(slab + jp * 64 + c8);
             const int py = (oy0 >> 1) + prow, px = (ox0 >> 1) + 8 * chalf + jp;
-            if (py < Hy && px < Wy)
+            if (py < Hy && px < Wy) {
                 __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p.y + (((size_t)b * Hy + py) * Wy + px) * 64 + c8));
+                if (TRAIN) {
+                    const u32x2 cv = *reinterpret_cast<const u32x2*>(cslab + jp * 64 + c8);
+                    *reinterpret_cast<u32x2*>(p.pool_code + (((size_t)b * Hy + py) * Wy + px) * 64 + c8) = cv;
+                }
+            }
+        }
+        if (TRAIN) {
+            // layer 0's ReLU gate of the tile's 8 x 32 interior positions out of the layer-2 operand image (a_s: post-ReLU bf16, 8
+            // channels per 16-byte slot, [group][row][pitch 48]): wave w takes row w, lane l31 column l31, the lower half-wave
+            // channel groups 0-3 and the upper one groups 4-7 (a ds_read_b128's 16-lane groups stay inside one half: 16 consecutive
+            // slots, conflict-free); the halves are joined by one cross-lane move and lanes 0-31 store 8 bytes each -- 256
+            // contiguous bytes per row. a_s is not written again before the next tile's first barrier.
+            unsigned wbits = 0;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const u32x4 sv = a_s[(4 * hq + g) * APOS + (wave + 1) * APITCH + (l31 + 1)];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned w = sv[e];
+                    const unsigned lo = ((w & 0x7fffu) != 0u && !(w & 0x8000u)) ? 1u : 0u;
+                    const unsigned hi = ((w & 0x7fff0000u) != 0u && !(w & 0x80000000u)) ? 1u : 0u;
+                    wbits |= (lo | (hi << 1)) << (8 * g + 2 * e);
+                }
+            }
+            const unsigned other = (unsigned)__shfl_xor((int)wbits, 32, 64);
+            const int oy = oy0 + wave, ox = ox0 + l31;
+            if (hq == 0 && oy < p.H && ox < p.W)
+                *reinterpret_cast<u32x2*>(p.gate_bits + (((size_t)b * p.H + oy) * p.W + ox) * 8) = (u32x2){wbits, other};
         }
         stamp(6);
     }
@@ -315,16 +354,12 @@ __global__ __launch_bounds__(F2T, 1) void conv_first2_bf16_kernel(First2Args p) 
 
 extern "C" {
 
-// x NCHW fp32 [B,C<=8,H,W] -> y NHWC bf16 [B,H/2,W/2,64] = MaxPool2(ReLU(conv2(ReLU(conv0(x))))), bf16 operands / fp32 accumulate.
-// wf0 / bias0: witw_conv3x3_first_pack(round_bf16 = 1) image and bias of the first conv; wpk2 / bias2: witw_conv3x3_bf16_pack_weights
-// image (64 -> 64) and bias of the second. Bit-identical to witw_conv3x3_first_fwd(out_bf16 = 1) followed by
-// witw_conv3x3_bf16_fwd(relu, pool).
-int witw_conv_first2_bf16_fwd(const float* x, const void* wf0, const float* bias0, const void* wpk2, const float* bias2, void* y,
-                              int B, int C, int H, int W, int pad_circular, void* stream) {
-    WITW_CHECK_ARG(x && wf0 && bias0 && wpk2 && bias2 && y, "conv_first2_bf16: null pointer");
-    WITW_CHECK_ARG(B > 0 && C >= 1 && C <= 8 && H >= 2 && W >= 2, "conv_first2_bf16: bad shape B=%d C=%d H=%d W=%d", B, C, H, W);
+static int first2_launch(const float* x, const void* wf0, const float* bias0, const void* wpk2, const float* bias2, void* y,
+                         unsigned char* pool_code, unsigned char* gate_bits, int B, int C, int H, int W, int pad_circular, void* stream) {
+    const bool train = pool_code != nullptr;
     First2Args a;
     a.x = x; a.wf0 = (const u32x4*)wf0; a.bias0 = bias0; a.wpk2 = (const u32x4*)wpk2; a.bias2 = bias2; a.y = (unsigned short*)y;
+    a.pool_code = pool_code; a.gate_bits = gate_bits;
     a.B = B; a.C = C; a.H = H; a.W = W;
     a.tiles_x = cdiv(W, TW2); a.tiles_y = cdiv(H, TH2);
     const long long n_tiles = (long long)B * a.tiles_x * a.tiles_y;
@@ -333,13 +368,17 @@ int witw_conv_first2_bf16_fwd(const float* x, const void* wf0, const float* bias
     a.circ = pad_circular;
     const int n_cu = witw_cu_count();        // persistent workgroups, one per CU (150 KB of LDS each)
     const unsigned grid = (unsigned)(a.n_tiles < n_cu ? a.n_tiles : n_cu);
-    const bool rec = getenv("WITW_F2_STAMPS") != nullptr && a.n_tiles >= 3 * (int)grid;      // diagnostic, synchronous
+    const bool rec = !train && getenv("WITW_F2_STAMPS") != nullptr && a.n_tiles >= 3 * (int)grid;      // diagnostic, synchronous
     if (rec && C > 4)
-        hipLaunchKernelGGL((conv_first2_bf16_kernel<8, true>), dim3(grid), dim3(F2T), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((conv_first2_bf16_kernel<8, true, false>), dim3(grid), dim3(F2T), 0, (hipStream_t)stream, a);
+    else if (train && C <= 4)
+        hipLaunchKernelGGL((conv_first2_bf16_kernel<4, false, true>), dim3(grid), dim3(F2T), 0, (hipStream_t)stream, a);
+    else if (train)
+        hipLaunchKernelGGL((conv_first2_bf16_kernel<8, false, true>), dim3(grid), dim3(F2T), 0, (hipStream_t)stream, a);
     else if (C <= 4)
-        hipLaunchKernelGGL((conv_first2_bf16_kernel<4, false>), dim3(grid), dim3(F2T), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((conv_first2_bf16_kernel<4, false, false>), dim3(grid), dim3(F2T), 0, (hipStream_t)stream, a);
     else
-        hipLaunchKernelGGL((conv_first2_bf16_kernel<8, false>), dim3(grid), dim3(F2T), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((conv_first2_bf16_kernel<8, false, false>), dim3(grid), dim3(F2T), 0, (hipStream_t)stream, a);
     if (rec && C > 4) {
         (void)hipDeviceSynchronize();
         unsigned long long h[2][8];
@@ -350,7 +389,32 @@ int witw_conv_first2_bf16_fwd(const float* x, const void* wf0, const float* bias
                         h[w][4] - h[w][3], h[w][5] - h[w][4], h[w][6] - h[w][5], h[w][6] - h[w][0]);
     }
     WITW_CHECK_LAUNCH("conv_first2_bf16");
+    witw_note_variant("conv_first2_bf16_kernel<%d,%s>", C <= 4 ? 4 : 8, train ? "train" : "infer");
     return WITW_OK;
+}
+
+// x NCHW fp32 [B,C<=8,H,W] -> y NHWC bf16 [B,H/2,W/2,64] = MaxPool2(ReLU(conv2(ReLU(conv0(x))))), bf16 operands / fp32 accumulate.
+// wf0 / bias0: witw_conv3x3_first_pack(round_bf16 = 1) image and bias of the first conv; wpk2 / bias2: witw_conv3x3_bf16_pack_weights
+// image (64 -> 64) and bias of the second. Bit-identical to witw_conv3x3_first_fwd(out_bf16 = 1) followed by
+// witw_conv3x3_bf16_fwd(relu, pool).
+int witw_conv_first2_bf16_fwd(const float* x, const void* wf0, const float* bias0, const void* wpk2, const float* bias2, void* y,
+                              int B, int C, int H, int W, int pad_circular, void* stream) {
+    WITW_CHECK_ARG(x && wf0 && bias0 && wpk2 && bias2 && y, "conv_first2_bf16: null pointer");
+    WITW_CHECK_ARG(B > 0 && C >= 1 && C <= 8 && H >= 2 && W >= 2, "conv_first2_bf16: bad shape B=%d C=%d H=%d W=%d", B, C, H, W);
+    return first2_launch(x, wf0, bias0, wpk2, bias2, y, nullptr, nullptr, B, C, H, W, pad_circular, stream);
+}
+
+// The training form: the same y, plus what the backward through both layers needs in place of the two activations -- pool_code
+// [B,H/2,W/2,64] (arg-max of each pooling window, dy*2+dx, as witw_conv3x3_bf16_fwd_ex writes them: input of
+// witw_maxpool2x2_bwd_bf16) and gate_bits [B,H,W,8] bytes (bit c & 7 of byte c >> 3: layer 0's output channel c at that pixel is
+// > 0: the gate of witw_conv3x3_bf16_fwd_gatebits). Layer 2's own ReLU gate is y > 0. H and W must be even.
+int witw_conv_first2_bf16_fwd_train(const float* x, const void* wf0, const float* bias0, const void* wpk2, const float* bias2, void* y,
+                                    unsigned char* pool_code, unsigned char* gate_bits, int B, int C, int H, int W, int pad_circular,
+                                    void* stream) {
+    WITW_CHECK_ARG(x && wf0 && bias0 && wpk2 && bias2 && y && pool_code && gate_bits, "conv_first2_bf16_train: null pointer");
+    WITW_CHECK_ARG(B > 0 && C >= 1 && C <= 8 && H >= 2 && W >= 2 && (H % 2) == 0 && (W % 2) == 0,
+                   "conv_first2_bf16_train: bad shape B=%d C=%d H=%d W=%d (H, W even)", B, C, H, W);
+    return first2_launch(x, wf0, bias0, wpk2, bias2, y, pool_code, gate_bits, B, C, H, W, pad_circular, stream);
 }
 
 }  // extern "C"

@@ -23,6 +23,7 @@
 // registers, joins the other half-wave's result (first maximum wins, as torch.argmax) and writes
 // orientation / score / distance like match.hip does.
 #include "common.h"
+#include "spectrum64_gen.h"
 
 // WITW_DFT_DIAG (diagnostic builds, wrong results): 1 = no staging DMA inside the steps, 2 = no barrier / vmcnt wait per step,
 // 4 = no operand reads inside the groups, 8 = the tile loop ends before the epilogue
@@ -623,6 +624,52 @@ __global__ __launch_bounds__(256) void match_spectrum_kernel(const float* __rest
     }
 }
 
+// The same spectra for full-width embeddings (W = 64: every gallery row, and the queries at fov 360) with the inner loop in
+// registers (round 6). The kernel above reads three LDS words per (line, frequency, k) -- the sample, cos and sin as doubles -- and
+// is bound by those reads: 125,000 gallery rows took 5 ms of the retrieval pass. Here a thread reads its line's samples (once per k from LDS), the 17 distinct twiddle magnitudes cos(2 pi m / 64), m = 0..16, are registers too, and because
+// a wave's frequencies are fixed (wave 0 the even t, wave 1 the odd t) every (t, k) names its magnitude and sign when the body is
+// generated: two v_fma_f64 per (line, t, k), one LDS word and one convert per (line, k). Same sums in the same k order, fp64, rounded once to fp32; products are fused here
+// (the kernel above rounds the product, then the sum), so single values may differ in the last fp32 bit -- inside the rounding
+// bound of the spectral scores that the index-exact re-scoring is built on (ops.SCORE_ROUNDING).
+struct Twiddle64 { double c[17]; };      // cos(2 pi m / 64), m = 0..16: kernel arguments, i.e. scalar registers
+
+// one workgroup = two waves per embedding: lane = line, wave = parity of the frequencies it sums; the body is generated
+// (tools/gen_spectrum64.py -> spectrum64_gen.h): straight-line code, every twiddle a named scalar with its sign
+__global__ __launch_bounds__(128) void match_spectrum64_kernel(const float* __restrict__ emb, float* __restrict__ spec, int role, Twiddle64 tw) {
+    __shared__ float xs[64 * 65];
+    const int tid = threadIdx.x, line = tid & 63;
+    const int par = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(emb + (size_t)blockIdx.x * 4096);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int q = tid + i * 128;              // float4 index: row q >> 4, columns 4 (q & 15) ..
+        const f32x4 v = x4[q];
+        float* d = xs + (q >> 4) * 65 + 4 * (q & 15);
+        d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+    }
+    const double c0 = tw.c[0], c1 = tw.c[1], c2 = tw.c[2], c3 = tw.c[3], c4 = tw.c[4], c5 = tw.c[5], c6 = tw.c[6], c7 = tw.c[7], c8 = tw.c[8],
+                 c9 = tw.c[9], c10 = tw.c[10], c11 = tw.c[11], c12 = tw.c[12], c13 = tw.c[13], c14 = tw.c[14], c15 = tw.c[15], c16 = tw.c[16];
+    __syncthreads();
+    float* out = spec + (size_t)blockIdx.x * SPEC;
+    const int swap_p = (role == 1 && (blockIdx.x & 16)) ? 2 : 0;      // as in match_spectrum_kernel
+    const int swap_q = (role == 0 || (blockIdx.x & 16)) ? 2 : 0;
+    const float* xrow = xs + line * 65;           // pitch 65: the wave's 64 lines read 64 different banks
+#define WITW_SPEC_STORE(T, PR, PI)                                            \
+    if ((T) == 32) out[64 + (line ^ swap_q)] = (float)(PR);                   \
+    else {                                                                    \
+        out[(T) * 128 + (line ^ swap_p)] = (float)(PR);                       \
+        if ((T) != 0) out[(T) * 128 + 64 + (line ^ swap_q)] = (float)(PI);    \
+    }
+    if (par == 0) {
+        WITW_SPECTRUM64_BODY_0(xrow);
+        WITW_SPECTRUM64_STORE_0(WITW_SPEC_STORE);
+    } else {
+        WITW_SPECTRUM64_BODY_1(xrow);
+        WITW_SPECTRUM64_STORE_1(WITW_SPEC_STORE);
+    }
+#undef WITW_SPEC_STORE
+}
+
 // dtab[t][hk*32 + shift]: coefficient of lanes 0-31 (hk = 0) / 32-63 (hk = 1) of slot t's C in score[shift], shift < 32. Slots
 // 1..31: Re C_t / Im C_t. Slot 0: the kernel leaves C_0 + C_32 in lanes 0-31 and C_32 - C_0 in lanes 32-63, and
 // (C_0 + (-1)^shift C_32) / 64 is the former at even shifts and minus the latter at odd ones
@@ -684,11 +731,20 @@ long long witw_match_spectrum_floats(long long n_embeddings) { return n_embeddin
 // emb [B,64 lines,W] (an overhead embedding [B,16,4,64], role 1, or a surface embedding [B,16,4,We], role 0) -> spec [B,32,128]
 // in the chunk order the match kernel's operand reads expect of that side (an overhead's spectrum depends on its index & 16:
 // spectra of a gallery must be computed at the row numbering they are matched at, multiples of 32 apart)
+static int g_spectrum_regs = getenv("WITW_SPECTRUM_LDS") == nullptr;      // WITW_SPECTRUM_LDS=1: the LDS-table kernel at every width (A/B)
+
 int witw_match_spectrum(const float* emb, float* spec, int B, int W, int role, void* stream) {
     WITW_CHECK_ARG(emb && spec, "match_spectrum: null pointer");
     WITW_CHECK_ARG(B > 0 && W >= 1 && W <= 64, "match_spectrum: bad shape B=%d W=%d", B, W);
     WITW_CHECK_ARG(role == 0 || role == 1, "match_spectrum: role %d (0 = surface / query side, 1 = overhead / gallery side)", role);
-    hipLaunchKernelGGL(match_spectrum_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, emb, spec, W, role);
+    if (W == 64 && g_spectrum_regs)
+        {
+        Twiddle64 tw;
+        for (int m = 0; m <= 16; ++m) tw.c[m] = m == 16 ? 0.0 : cos(2.0 * 3.14159265358979323846 * m / 64.0);
+        hipLaunchKernelGGL(match_spectrum64_kernel, dim3(B), dim3(128), 0, (hipStream_t)stream, emb, spec, role, tw);
+    }
+    else
+        hipLaunchKernelGGL(match_spectrum_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, emb, spec, W, role);
     WITW_CHECK_LAUNCH("match_spectrum");
     return WITW_OK;
 }

@@ -944,6 +944,7 @@ def _retrieve_dft(overhead_shard, surface_all, k, shard_begin, query_chunk, kn, 
     spec_g = kn.match_spectrum(gallery, overhead=True) if n_g else None
     counts = torch.zeros((n_q,), dtype=torch.int32, device=dev)
     vals, idxs, sns = [], [], []
+    band_checks = []
     wn = None
     stats = {'method': 'dft', 'pairs': float(n_g) * n_q, 'rescored_rank': 0, 'rescored_topk': 0, 'rescored_true': 0,
              'rescored_orientation': 0, 'fallback_queries': 0}
@@ -975,21 +976,29 @@ def _retrieve_dft(overhead_shard, surface_all, k, shard_begin, query_chunk, kn, 
             rounding = float(getattr(kn, 'SCORE_ROUNDING', ops.SCORE_ROUNDING))
             eps = max(eps, 1.25 * 4 * rounding * float(ratio.item()))
         if want_ranks:
-            qi = torch.arange(q0, q1, device=dev)
-            own = (qi >= shard_begin) & (qi < shard_begin + n_g)
+            # the queries of this chunk whose true row lives in this shard: a contiguous range, known on the host (no mask, no
+            # device round trip)
+            lo, hi = max(q0, shard_begin), min(q1, shard_begin + n_g)
             d_true = torch.zeros((nq,), dtype=torch.float32, device=dev)
-            if n_g and bool(own.any()):                  # the owner's EXACT distance of every true pair
-                po = (qi - shard_begin)[own].to(torch.int32).contiguous()
-                ps = (qi - q0)[own].to(torch.int32).contiguous()
-                d_true[own] = kn.match_pairs(gallery, su, wn, sn, po, ps, want_orientation=False)[1]
-                stats['rescored_true'] += int(po.numel())
+            if n_g and hi > lo:                          # the owner's EXACT distance of every true pair
+                po = torch.arange(lo - shard_begin, hi - shard_begin, dtype=torch.int32, device=dev)
+                ps = torch.arange(lo - q0, hi - q0, dtype=torch.int32, device=dev)
+                d_true[lo - q0:hi - q0] = kn.match_pairs(gallery, su, wn, sn, po, ps, want_orientation=False)[1]
+                stats['rescored_true'] += hi - lo
             parallel.all_reduce_sum_(d_true)
             if n_g:
-                c, po, ps = kn.rank_count_band(dist, d_true.contiguous(), eps)
-                if po.numel():
-                    d_x = kn.match_pairs(gallery, su, wn, sn, po, ps, want_orientation=False)[1]
-                    c.index_add_(0, ps.long(), (d_x <= d_true[ps.long()]).to(torch.int32))
-                    stats['rescored_rank'] += int(po.numel())
+                d_true = d_true.contiguous()
+                if hasattr(kn, 'rank_count_resolved'):
+                    # band list, exact re-scoring and the count update in one stream sequence; the list's length stays on the device
+                    # and is looked at once, behind the last chunk (band_checks)
+                    c, n_band, cap = kn.rank_count_resolved(dist, d_true, eps, gallery, su, wn, sn)
+                    band_checks.append((n_band, cap, q0, q1, dist if len(range(0, n_q, query_chunk)) == 1 else None, su, d_true, sn))
+                else:
+                    c, po, ps = kn.rank_count_band(dist, d_true, eps)
+                    if po.numel():
+                        d_x = kn.match_pairs(gallery, su, wn, sn, po, ps, want_orientation=False)[1]
+                        c.index_add_(0, ps.long(), (d_x <= d_true[ps.long()]).to(torch.int32))
+                        stats['rescored_rank'] += int(po.numel())
                 counts[q0:q1] = c
         if n_g:
             v, i = kn.topk_smallest(dist, kc, shard_begin)
@@ -998,6 +1007,22 @@ def _retrieve_dft(overhead_shard, surface_all, k, shard_begin, query_chunk, kn, 
             i = torch.full((nq, kc), -1, dtype=torch.int64, device=dev)
         vals.append(v)
         idxs.append(i)
+    if band_checks:
+        # one look at the band lists' lengths for the whole pass; a list that overflowed (more pairs within eps of a threshold than
+        # 1/4096 of the chunk: not seen on real or synthetic data) sends its chunk through the two-step form again
+        n_host = torch.cat([b[0] for b in band_checks]).tolist()
+        for got, (_n, cap, q0, q1, dist_kept, su, d_true, sn) in zip(n_host, band_checks):
+            stats['rescored_rank'] += min(int(got), cap)
+            if got > cap:
+                dist_c = dist_kept
+                if dist_c is None:
+                    dist_c = (_dft_pass_narrow(kn, gallery, su, spec_g)[0] if we < 64 else
+                              kn.match_fwd_dft(gallery, su, spec_ov=spec_g, want_orientation=False)[1])
+                c, po, ps = kn.rank_count_band(dist_c, d_true, eps)
+                d_x = kn.match_pairs(gallery, su, wn, sn, po, ps, want_orientation=False)[1]
+                c.index_add_(0, ps.long(), (d_x <= d_true[ps.long()]).to(torch.int32))
+                counts[q0:q1] = c
+        band_checks = []
     if want_ranks:
         parallel.all_reduce_sum_(counts)
     v, i, sn_all = torch.cat(vals), torch.cat(idxs), torch.cat(sns)

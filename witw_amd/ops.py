@@ -613,6 +613,34 @@ def rank_count_band(distance, threshold, eps):
         cap = got            # rare: more pairs in the band than the list holds -> once more with room for all
 
 
+def rank_count_resolved(distance, threshold, eps, overhead_embed, surface_embed, wn, sn):
+    """rank_count_band + the exact re-scoring of its band in ONE stream sequence without a host round trip: -> (counts int32 [Bs] =
+    #{o : exact distance[o][q] <= threshold[q]}, n int32 [1] on the device = pairs in the band, capacity). The result is complete iff
+    n <= capacity, which the caller checks once at the end of its pass (retrieve(method='dft')); beyond it the list overflowed and the
+    chunk has to be redone through rank_count_band."""
+    lib = _lib.load()
+    d = _dev_f32(distance, 'distance')
+    t = _dev_f32(threshold, 'threshold')
+    ov = _dev_f32(overhead_embed, 'overhead_embed')
+    su = _dev_f32(surface_embed, 'surface_embed')
+    Bo, Bs = d.shape
+    if t.numel() != Bs or ov.shape[0] != Bo or su.shape[0] != Bs:
+        raise _lib.WitwError('rank_count_resolved: distance [Bo,Bs], threshold [Bs] and the two embedding batches must agree')
+    if wn.numel() != Bo * 64 or sn.numel() != Bs:
+        raise _lib.WitwError('rank_count_resolved: wn / sn must hold [Bo,64] / [Bs] norms')
+    counts = torch.empty((Bs,), dtype=torch.int32, device=d.device)
+    n = torch.empty((1,), dtype=torch.int32, device=d.device)
+    cap = max(1 << 16, (Bo * Bs) // 4096)
+    po = torch.empty((cap,), dtype=torch.int32, device=d.device)
+    ps = torch.empty((cap,), dtype=torch.int32, device=d.device)
+    _lib.check(lib.witw_rank_count_band(d.data_ptr(), t.data_ptr(), float(eps), counts.data_ptr(), po.data_ptr(), ps.data_ptr(),
+                                        n.data_ptr(), cap, Bo, Bs, _stream()), 'witw_rank_count_band')
+    _lib.check(lib.witw_match_pairs_count(ov.data_ptr(), su.data_ptr(), _dev_f32(wn, 'wn').data_ptr(), _dev_f32(sn, 'sn').data_ptr(),
+                                          po.data_ptr(), ps.data_ptr(), n.data_ptr(), cap, Bo, Bs, su.shape[3], t.data_ptr(),
+                                          counts.data_ptr(), _stream()), 'witw_match_pairs_count')
+    return counts, n, cap
+
+
 def crop_overhead(overhead_embed, orientation, surface_width):
     lib = _lib.load()
     ov = _dev_f32(overhead_embed, 'overhead_embed')
