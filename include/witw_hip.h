@@ -70,6 +70,19 @@ int witw_conv3x3_first_pack(const float* w, float* wf, int C, int round_bf16, vo
  * witw_conv3x3_bf16_fwd(relu, pool). */
 int witw_conv_first2_bf16_fwd(const float* x, const void* wf0, const float* bias0, const void* wpk2, const float* bias2, void* y,
                               int B, int C, int H, int W, int pad_circular, void* stream);
+/* The training form (cvig_semantic trains layer 0, model/cvig_semantic.py:301-309, so the backward crosses both layers): the same
+ * y, plus pool_code [B,H/2,W/2,64] (arg-max of each 2x2 window, dy*2+dx: the input of witw_maxpool2x2_bwd_bf16) and gate_bits
+ * [B,H,W,8] bytes (bit c & 7 of byte c >> 3 = layer 0's output channel c at that pixel is > 0) instead of the two 64-channel
+ * activations. Layer 2's own ReLU gate is y > 0. H and W even. */
+int witw_conv_first2_bf16_fwd_train(const float* x, const void* wf0, const float* bias0, const void* wpk2, const float* bias2, void* y,
+                                    unsigned char* pool_code, unsigned char* gate_bits, int B, int C, int H, int W, int pad_circular,
+                                    void* stream);
+/* Data gradient of a 64-input-channel stride-1 layer whose upstream ReLU gate is given as ONE BIT per output (gate_bits
+ * [B,H,W,Cout/8] bytes as above) instead of a bf16 tensor: same bits as witw_conv3x3_bf16_fwd_ex(gate = the activation). Runs on the
+ * weight-resident kernel only: witw_conv3x3_bf16_gatebits_ok tells whether a shape qualifies (1) or the tensor gate has to be kept (0). */
+int witw_conv3x3_bf16_gatebits_ok(int B, int H, int W, int Cin, int Cout);
+int witw_conv3x3_bf16_fwd_gatebits(const void* x_bf16, const void* wpk_bf16, const float* bias, const void* gate_bits, void* y, int B, int H,
+                                   int W, int Cin, int Cout, int pad_circular, int relu, void* stream);
 int witw_conv3x3_first_fwd(const float* x, const float* wf, const float* bias, void* y, int B, int C, int H, int W,
                            int pad_circular, int relu, int out_bf16, void* stream);
 

@@ -157,14 +157,14 @@ def test_first2_register_allocation_guard(tmp_path, monkeypatch):
     build._check_first2(good)
     assert not os.path.exists(build.F2_MARKER)
     build._check_first2(good.replace('VGPRs: 254', 'VGPRs: 250'))
-    assert 'ILi4ELb0EE' in open(build.F2_MARKER).read()
+    assert 'ILi4ELb0ELb0EE' in open(build.F2_MARKER).read()
     # a marker written by a build that this very process triggers is seen by the load that follows it
     monkeypatch.setattr(_lib, '_LIB', None)
     monkeypatch.setattr(_lib, '_GUARDS', None)
     monkeypatch.delenv('WITW_F2', raising=False)
     with pytest.warns(UserWarning, match='first2'):
         g = _lib.guards()
-    assert g['first2']['hand_scheduled_kernel'] is False and 'ILi4ELb0EE' in g['first2']['detail'] and g['s16']['hand_scheduled_kernel']
+    assert g['first2']['hand_scheduled_kernel'] is False and 'ILi4ELb0ELb0EE' in g['first2']['detail'] and g['s16']['hand_scheduled_kernel']
     monkeypatch.setenv('WITW_F2', '1')
     monkeypatch.setattr(_lib, '_LIB', None)
     assert _lib.guards()['first2'] == {'hand_scheduled_kernel': True, 'forced': True, 'detail': ''}

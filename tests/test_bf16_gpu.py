@@ -113,6 +113,60 @@ def test_fused_first_two_layers_equal_the_separate_launches(shape):
         assert torch.equal(got.view(torch.int16), ref.view(torch.int16)), (shape, circ, float((got.float() - ref.float()).abs().max()))
 
 
+@pytest.mark.parametrize('shape', [(2, 5, 128, 512), (3, 5, 128, 98), (2, 3, 20, 70), (1, 5, 10, 34), (2, 4, 64, 32), (1, 8, 16, 130)])
+def test_fused_first_two_layers_training_form(shape):
+    """The training form of csrc/conv_first2_bf16.hip (round 6: cvig_semantic trains layer 0, model/cvig_semantic.py:301-309, so the
+    backward crosses both layers): the same y bits as the inference form, the max-pool arg-max codes of the two-launch path
+    (conv3x3_bf16_fwd(pool, want_pool_code)) and layer 0's ReLU gate as one bit per output = (layer-0 activation > 0), both padding
+    modes, sizes that are not multiples of the tile."""
+    from witw_amd import _lib, ops
+    B, C, H, W = shape
+    g = np.random.Generator(np.random.Philox(key=[82, H * W + C]))
+    x = torch.from_numpy(g.standard_normal((B, C, H, W), dtype=np.float32)).cuda()
+    w0 = torch.from_numpy((g.standard_normal((64, C, 3, 3), dtype=np.float32) * 0.3).astype(np.float32)).cuda()
+    b0 = torch.from_numpy((g.standard_normal((64,), dtype=np.float32) * 0.2).astype(np.float32)).cuda()
+    w2 = torch.from_numpy((g.standard_normal((64, 64, 3, 3), dtype=np.float32) * 0.06).astype(np.float32)).cuda()
+    b2 = torch.from_numpy((g.standard_normal((64,), dtype=np.float32) * 0.2).astype(np.float32)).cuda()
+    pf, p2 = ops.PackedFirstConv(w0, b0, bf16=True), ops.PackedConvBf16(w2, b2)
+    for circ in (False, True):
+        mid = ops.conv3x3_first_fwd(x, pf, circular=circ, relu=True)                      # [B,H,W,64] bf16
+        ref, ref_code = ops.conv3x3_bf16_fwd(mid, p2, circular=circ, relu=True, pool=True, want_pool_code=True)
+        y, code, bits = ops.conv_first2_bf16_train(x, pf, p2, circular=circ)
+        assert ops.last_kernel_variant() == 'conv_first2_bf16_kernel<%d,train>' % (4 if C <= 4 else 8)
+        assert torch.equal(y.view(torch.int16), ref.view(torch.int16)), (shape, circ)
+        assert torch.equal(y.view(torch.int16), ops.conv_first2_bf16(x, pf, p2, circular=circ).view(torch.int16))
+        assert torch.equal(code, ref_code), (shape, circ, int((code != ref_code).sum()))
+        want = (mid.float() > 0).reshape(B, H, W, 8, 8)                                    # channel c = 8 * byte + bit
+        want = (want.to(torch.int32) << torch.arange(8, device=x.device, dtype=torch.int32)).sum(-1).to(torch.uint8)
+        assert bits.shape == (B, H, W, 8) and torch.equal(bits, want), (shape, circ, int((bits != want).sum()))
+    with pytest.raises(_lib.WitwError):
+        ops.conv_first2_bf16_train(x[:, :, :H - 1], pf, p2)                                # odd height
+
+
+@pytest.mark.parametrize('circ', [False, True])
+def test_gate_bits_dgrad_equals_the_tensor_gate(circ):
+    """conv3x3_bf16_wres_kernel<gate_bits> (round 6: the data gradient of cvig_semantic's layer 2 with layer 0's ReLU gate as one bit
+    per output) against the same launch with the bf16 activation as the gate: the same bits, both on the weight-resident kernel."""
+    from witw_amd import _lib, ops
+    B, H, W = 16, 128, 512
+    assert ops.gatebits_dgrad_ok(B, H, W, 64, 64) and not ops.gatebits_dgrad_ok(2, H, W, 64, 64)
+    g = np.random.Generator(np.random.Philox(key=[83, int(circ)]))
+    dev = torch.device('cuda:0')
+    dz = torch.from_numpy(g.standard_normal((B, H, W, 64), dtype=np.float32)).to(dev).bfloat16()
+    act = torch.from_numpy(g.standard_normal((B, H, W, 64), dtype=np.float32)).to(dev).clamp_min(0).bfloat16()      # a post-ReLU map: half zeros
+    w2 = torch.from_numpy((g.standard_normal((64, 64, 3, 3), dtype=np.float32) * 0.06).astype(np.float32)).to(dev)
+    pt = ops.PackedConvBf16(w2, None, transpose_flip=True)
+    ref = ops.conv3x3_bf16_fwd(dz, pt, circular=circ, relu=False, gate=act)
+    assert ops.last_kernel_variant() == 'conv3x3_bf16_wres_kernel<gate>'
+    bits = ((act.float() > 0).reshape(B, H, W, 8, 8).to(torch.int32) << torch.arange(8, device=dev, dtype=torch.int32)).sum(-1).to(torch.uint8)
+    got = ops.conv3x3_bf16_dgrad_gatebits(dz, pt, bits.contiguous(), circular=circ)
+    assert ops.last_kernel_variant() == 'conv3x3_bf16_wres_kernel<gate_bits>'
+    assert torch.equal(got.view(torch.int16), ref.view(torch.int16)), float((got.float() - ref.float()).abs().max())
+    assert float(ref.float().abs().max()) > 0 and float((ref == 0).float().mean()) > 0.4
+    with pytest.raises(_lib.WitwError):
+        ops.conv3x3_bf16_dgrad_gatebits(dz[:2].contiguous(), pt, bits[:2].contiguous(), circular=circ)      # too small for the weight-resident kernel
+
+
 def test_encoder_bf16_with_and_without_the_fused_launch():
     from witw_amd import cvig_fov, cvig_semantic
     for mod, c in ((cvig_fov, 3), (cvig_semantic, 5)):

@@ -319,6 +319,40 @@ def test_bf16_training_forward_with_the_fused_first_two_layers_is_bitwise_the_un
     assert not called
 
 
+def test_semantic_training_step_with_the_fused_first_two_layers_is_bitwise_the_unfused_one():
+    """round 6: cvig_semantic's bf16 training step (layer 0 trains, model/cvig_semantic.py:301-309) runs layers 0 and 2 forward on the
+    TRAINING form of conv_first2_bf16_kernel from 16 images on (the batch at which layer 2's data gradient runs on the kernel that
+    reads one-bit gates): arg-max codes + one gate bit per layer-0 output instead of the two activations. Same embedding bits and
+    the same bits in every gradient (layer 0's included) as the unfused step; smaller batches keep the two launches."""
+    from witw_amd import cvig_semantic, ops
+    dev = torch.device('cuda:0')
+    w5 = synth.fov_dsm_weights(31, in_channels=5)
+    for B, expect_fused in ((16, True), (2, False)):
+        x = torch.from_numpy(synth.normalized_images(34, 5, (B, 5, 128, 512))).to(dev)
+        drops = {i: torch.full((B, 512), 1.25, device=dev) for i in (17, 19, 21)}
+        outs, grads = [], []
+        for fuse in (None, False):
+            enc = cvig_semantic.FOV_DSM(circ_padding=True, weights=w5).to(dev).train()
+            enc.precision = 'bf16'
+            enc.fuse_first2 = fuse
+            ran = []
+            real_f, real_g = ops.conv_first2_bf16_train, ops.conv3x3_bf16_dgrad_gatebits
+            ops.conv_first2_bf16_train = lambda *a, **k: ran.append('first2_train') or real_f(*a, **k)
+            ops.conv3x3_bf16_dgrad_gatebits = lambda *a, **k: ran.append('gatebits') or real_g(*a, **k)
+            try:
+                e = enc(x, dropout_scales=drops)
+                e.square().sum().backward()
+            finally:
+                ops.conv_first2_bf16_train, ops.conv3x3_bf16_dgrad_gatebits = real_f, real_g
+            assert (ran == ['first2_train', 'gatebits']) == (fuse is None and expect_fused), (B, fuse, ran)
+            outs.append(e.detach().clone())
+            grads.append({n: p.grad.clone() for n, p in enc.named_parameters() if p.grad is not None})
+        assert torch.equal(outs[0], outs[1])
+        assert len(grads[0]) == len(grads[1]) == 14 and any('features.0.' in n for n in grads[0])
+        for n in grads[0]:
+            assert torch.equal(grads[0][n], grads[1][n]), (B, n, float((grads[0][n] - grads[1][n]).abs().max()))
+
+
 def test_batched_filter_packing_equals_one_at_a_time():
     """ops.PackedConvBf16.batch (one launch for all of an encoder's stale filter images + bias copies: what the bf16 training step
     calls after every Adam update) writes the same bits as the constructor image by image, forward and dgrad form, with and

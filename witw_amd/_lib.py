@@ -112,6 +112,9 @@ SIGNATURES = {
     'witw_dropout2d_scales': (c_int, [c_void_p, ctypes.c_ulonglong, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint, c_void_p, c_int, c_int, c_int,
                                       c_float, c_void_p]),
     'witw_conv_first2_bf16_fwd': (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p]),
+    'witw_conv_first2_bf16_fwd_train': (c_int, [c_void_p] * 8 + [c_int] * 5 + [c_void_p]),
+    'witw_conv3x3_bf16_gatebits_ok': (c_int, [c_int] * 5),
+    'witw_conv3x3_bf16_fwd_gatebits': (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_void_p]),
     'witw_triplet_loss_fwd': (c_int, [c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     'witw_triplet_loss_slab_fwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     'witw_triplet_loss_slab_sig': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),

@@ -51,12 +51,14 @@ def build(force=False, verbose=True):
 # that triggers the build itself is covered) and reports through _lib.guards() / the bench line's `guards` field.
 #   s16:    conv3x3_bf16_s16_kernel<POOL, TRAIN> -> the 32x32x16 kernel (witw_conv3x3_bf16_mfma16(0));      force: WITW_BF_S16=1
 #   wres:   conv3x3_bf16_wres_kernel<REC, GATE>  -> layer 5 on the tiled kernels (witw_conv3x3_bf16_wres(0)); force: WITW_BF_WRES=1
-#   first2: conv_first2_bf16_kernel<CW, REC>     -> layers 0 and 2 as two launches (FOV_DSM.fuse_first2);     force: WITW_F2=1
+#   first2: conv_first2_bf16_kernel<CW, REC, TRAIN> -> layers 0 and 2 as two launches (FOV_DSM.fuse_first2); force: WITW_F2=1
 S16_VALIDATED = {'ILb0ELb0EE': (256, 10, 44), 'ILb1ELb0EE': (256, 1, 8), 'ILb0ELb1EE': (256, 10, 44), 'ILb1ELb1EE': (256, 2, 12)}
 S16_MARKER = os.path.join(HERE, 'build', 's16_unvalidated')
-WRES_VALIDATED = {'ILb0ELb0EE': (209, 0, 0), 'ILb0ELb1EE': (229, 0, 0)}      # <REC, GATE>: plain forward; gated (dgrad) form, round 5
+WRES_VALIDATED = {'ILb0ELi0EE': (209, 0, 0), 'ILb0ELi1EE': (229, 0, 0),      # <REC, GATE>: plain forward; gated (dgrad) form, round 5;
+                  'ILb0ELi2EE': (221, 0, 0)}                                # gate as one bit per output (round 6)
 WRES_MARKER = os.path.join(HERE, 'build', 'wres_unvalidated')
-F2_VALIDATED = {'ILi4ELb0EE': (254, 0, 0), 'ILi8ELb0EE': (256, 0, 0)}
+F2_VALIDATED = {'ILi4ELb0ELb0EE': (254, 0, 0), 'ILi8ELb0ELb0EE': (256, 0, 0),      # <CW, REC, TRAIN>: the two inference forms;
+                'ILi8ELb0ELb1EE': (256, 0, 0)}                                     # the training form of cvig_semantic (round 6)
 F2_MARKER = os.path.join(HERE, 'build', 'first2_unvalidated')
 
 

@@ -1344,13 +1344,24 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ D, 
     };
     if (q < Bs) {
         int o = r0 + wave;
-        for (; o + 28 < r1; o += 32) {             // eight independent loads in flight per thread
+        // eight independent loads per batch, and the NEXT batch requested before this one is ranked: with the loads of one batch
+        // only, a wave's memory round trip and its ranking alternate and the scan ran at 1.5 TB/s of the 2 GB matrix
+        float dn[8];
+        if (o + 28 < r1) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) dn[u] = D[(size_t)(o + 4 * u) * Bs + q];
+        }
+        for (; o + 28 < r1; o += 32) {
             float d[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                d[u] = D[(size_t)(o + 4 * u) * Bs + q];
-                if (d[u] != d[u]) d[u] = __builtin_inff();
+            for (int u = 0; u < 8; ++u) d[u] = dn[u];
+            if (o + 32 + 28 < r1) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) dn[u] = D[(size_t)(o + 32 + 4 * u) * Bs + q];
             }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (d[u] != d[u]) d[u] = __builtin_inff();
             // A wave executes an insertion (16 compare-exchange steps) whenever ANY of its 64 queries takes a row; offered one by
             // one, nearly every row of the first few thousand triggers one (64 K / n per row at row n of a query's stream). Per
             // batch of eight rows each lane instead inserts its SMALLEST admissible candidate, and the wave repeats only while some

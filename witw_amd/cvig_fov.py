@@ -283,11 +283,25 @@ class FOV_DSM(torch.nn.Module):
         fuse = _lib.guards()['first2']['hand_scheduled_kernel'] if self.fuse_first2 is None else self.fuse_first2
         fused = (fast0 and fuse and (keep_from is None or keep_from > 2) and 0 not in scales and 2 not in scales and
                  self.layer_specs[0][:4] == (0, 1, True, False) and self.layer_specs[1][:4] == (2, 1, True, True))
+        # ... and when the backward DOES cross both layers (layer 0 trains: cvig_semantic, model/cvig_semantic.py:301-309) the training
+        # form of the same kernel: neither 64-channel activation is written -- the backward gets the max-pool's arg-max codes, layer
+        # 2's gate is its pooled output, layer 0's gate one bit per output (67 MB instead of the 1.07 GB map at 128 images). Needs
+        # the data gradient of layer 2 on the weight-resident kernel (the one that reads bit gates); smaller batches keep the two launches.
+        B_, _C, H_, W_ = x_nchw.shape
+        fused_train = (first_direct and fuse and keep_from == 0 and 2 not in scales and H_ % 2 == 0 and W_ % 2 == 0 and
+                       self.layer_specs[0][:4] == (0, 1, True, False) and self.layer_specs[1][:4] == (2, 1, True, True) and
+                       not _conv_of(self.model.features[2]).weight.requires_grad and ops.gatebits_dgrad_ok(B_, H_, W_, 64, 64))
         for (idx, sh, relu, pool, drop) in self.layer_specs:
             if idx == 0 and fused:
                 h = ops.conv_first2_bf16(h, self._pack_first(True), self._pack_bf16(2), circular=self.circ_padding)
                 continue
-            if idx == 2 and fused:
+            if idx == 2 and (fused or fused_train):
+                continue
+            if idx == 0 and fused_train:
+                y2, code2, bits0 = ops.conv_first2_bf16_train(x_nchw, self._pack_first(True), self._pack_bf16(2), circular=self.circ_padding)
+                kept[0] = (h, _GateBits(bits0), None)                      # h: the NHWC bf16 image, what layer 0's weight gradient reads
+                kept[2] = (_ShapeOnly((B_, H_, W_, 64)), y2, code2)         # layer 2 is frozen: nobody reads its input
+                h = y2
                 continue
             if idx == 0 and fast0:
                 h = ops.conv3x3_first_fwd(h, self._pack_first(True), circular=self.circ_padding, relu=relu)
@@ -519,6 +533,22 @@ class _EncoderFnF16x3(torch.autograd.Function):
         return (None, None, None) + tuple(flat)
 
 
+class _GateBits(object):
+    """A ReLU gate kept as one bit per output (ops.conv_first2_bf16_train) in the place of the activation tensor"""
+    __slots__ = ('bits',)
+
+    def __init__(self, bits):
+        self.bits = bits
+
+
+class _ShapeOnly(object):
+    """Stands for a kept activation of which the backward only asks the shape"""
+    __slots__ = ('shape',)
+
+    def __init__(self, shape):
+        self.shape = tuple(shape)
+
+
 class _EncoderFnBf16(torch.autograd.Function):
     """_EncoderFn on the bf16 MFMA kernels (FOV_DSM.precision = 'bf16'): mixed-precision training step with bf16
     activations / filters / activation gradients, fp32 accumulation, fp32 weight gradients (the fp32 master weights and
@@ -561,9 +591,12 @@ class _EncoderFnBf16(torch.autograd.Function):
             if n > 0:   # gradient at the previous layer's conv output
                 pidx, _psh, _prelu, ppool, _pdrop = specs[n - 1]
                 p_in, p_out, p_code = kept[pidx]
-                dy = ops.conv3x3_bf16_fwd(dz, enc._pack_t_bf16(idx), stride_h=1, circular=circ, relu=False, pool=False,
-                                          drop_scale=scales.get(pidx), gate=p_out, dilate_h=(sh == 2),
-                                          out_h=x_in.shape[1] if sh == 2 else None)
+                if isinstance(p_out, _GateBits):      # the fused first-two-layers forward kept this gate as bits
+                    dy = ops.conv3x3_bf16_dgrad_gatebits(dz, enc._pack_t_bf16(idx), p_out.bits, circular=circ)
+                else:
+                    dy = ops.conv3x3_bf16_fwd(dz, enc._pack_t_bf16(idx), stride_h=1, circular=circ, relu=False, pool=False,
+                                              drop_scale=scales.get(pidx), gate=p_out, dilate_h=(sh == 2),
+                                              out_h=x_in.shape[1] if sh == 2 else None)
                 dz = ops.maxpool2x2_bwd_bf16(dy, p_code, (p_in.shape[1], p_in.shape[2])) if ppool else dy
         ctx.kept = None
         if direct:      # the gradients already sit in the parameters' .grad views: nothing for autograd to accumulate

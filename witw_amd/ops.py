@@ -135,6 +135,71 @@ def conv_first2_bf16(x_nchw, packed_first, packed_second, circular=False):
     return y
 
 
+def conv_first2_bf16_train(x_nchw, packed_first, packed_second, circular=False):
+    """conv_first2_bf16 for a training step whose backward crosses both layers (cvig_semantic: layer 0 trains): -> (y NHWC bf16
+    [B,H/2,W/2,64], pool codes uint8 of y's shape, gate_bits uint8 [B,H,W,8]: layer 0's ReLU gate, bit c & 7 of byte c >> 3 = channel
+    c of that pixel is > 0). Neither 64-channel activation is written: the backward routes the pooled gradient with the codes
+    (maxpool2x2_bwd_bf16), gates layer 2 with y > 0 and layer 0 with the bits (conv3x3_bf16_dgrad_gatebits)."""
+    lib = _lib.load()
+    x = _dev_f32(x_nchw, 'x')
+    B, C, H, W = x.shape
+    if not packed_first.bf16 or C != packed_first.cin or packed_second.cin != 64 or packed_second.cout != 64:
+        raise _lib.WitwError('conv_first2_bf16_train: needs a bf16-packed C -> 64 first filter and a 64 -> 64 second one')
+    if H % 2 or W % 2:
+        raise _lib.WitwError('conv_first2_bf16_train: H and W must be even, got %d x %d' % (H, W))
+    y = torch.empty((B, H // 2, W // 2, 64), dtype=torch.bfloat16, device=x.device)
+    code = torch.empty((B, H // 2, W // 2, 64), dtype=torch.uint8, device=x.device)
+    bits = torch.empty((B, H, W, 8), dtype=torch.uint8, device=x.device)
+    prof = PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.check(lib.witw_conv_first2_bf16_fwd_train(x.data_ptr(), packed_first.wf.data_ptr(), packed_first.bias.data_ptr(),
+                                                   packed_second.wpk.data_ptr(), packed_second.bias.data_ptr(), y.data_ptr(),
+                                                   code.data_ptr(), bits.data_ptr(), B, C, H, W, int(circular), _stream()),
+               'witw_conv_first2_bf16_fwd_train')
+    if prof is not None:
+        e1.record()
+        prof.append((('first2', True), 2.0 * (C + 64) * 64 * 9 * H * W * B, e0, e1))
+        if PROFILE_BY_KERNEL is not None:
+            PROFILE_BY_KERNEL.setdefault('conv_first2_bf16_kernel<train>', []).append((prof[-1][1], e0, e1))
+    return y, code, bits
+
+
+def gatebits_dgrad_ok(B, H, W, cin, cout):
+    """can conv3x3_bf16_dgrad_gatebits run this shape? (the weight-resident kernel must apply and be switched on)"""
+    return bool(_lib.load().witw_conv3x3_bf16_gatebits_ok(B, H, W, cin, cout))
+
+
+def conv3x3_bf16_dgrad_gatebits(dz_nhwc, packed_t, gate_bits, circular=False):
+    """Data gradient of a 64-input-channel stride-1 layer with the ReLU gate of the layer in front as one bit per output
+    (conv_first2_bf16_train's gate_bits): dz NHWC bf16 [B,H,W,64 (padded cout of the layer)] -> NHWC bf16 [B,H,W,Cout_t], zero
+    where the bit is clear. Same bits as conv3x3_bf16_fwd(dz, packed_t, relu=False, gate=<the bf16 activation>)."""
+    lib = _lib.load()
+    if not (dz_nhwc.is_cuda and dz_nhwc.dtype == torch.bfloat16 and dz_nhwc.is_contiguous() and dz_nhwc.dim() == 4):
+        raise _lib.WitwError('conv3x3_bf16_dgrad_gatebits: dz must be a contiguous bfloat16 NHWC GPU tensor')
+    B, H, W, C = dz_nhwc.shape
+    if C != packed_t.cin_pad:
+        raise _lib.WitwError('conv3x3_bf16_dgrad_gatebits: dz has %d channels, the packed filter expects %d' % (C, packed_t.cin_pad))
+    if not (gate_bits.is_cuda and gate_bits.dtype == torch.uint8 and gate_bits.is_contiguous()
+            and tuple(gate_bits.shape) == (B, H, W, packed_t.cout // 8)):
+        raise _lib.WitwError('conv3x3_bf16_dgrad_gatebits: gate_bits must be uint8 [%d,%d,%d,%d]' % (B, H, W, packed_t.cout // 8))
+    y = torch.empty((B, H, W, packed_t.cout), dtype=torch.bfloat16, device=dz_nhwc.device)
+    prof = PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.check(lib.witw_conv3x3_bf16_fwd_gatebits(dz_nhwc.data_ptr(), packed_t.wpk.data_ptr(), packed_t.bias.data_ptr(), gate_bits.data_ptr(),
+                                                  y.data_ptr(), B, H, W, C, packed_t.cout, int(circular), 0, _stream()),
+               'witw_conv3x3_bf16_fwd_gatebits')
+    if prof is not None:
+        e1.record()
+        prof.append((('bf16_wres', lib.witw_conv3x3_tile_n(packed_t.cout), 1, False), 2.0 * packed_t.cin * packed_t.cout * 9 * H * W * B, e0, e1))
+        if PROFILE_BY_KERNEL is not None:
+            PROFILE_BY_KERNEL.setdefault(last_kernel_variant(), []).append((prof[-1][1], e0, e1))
+    return y
+
+
 def nchw_to_nhwc8(x):
     lib = _lib.load()
     x = _dev_f32(x, 'x')
