@@ -290,3 +290,138 @@ def test_decode_tables_vectorised_form_equals_the_per_image_loop():
     bad[0, 5], bad[0, 6] = 1, 2
     with pytest.raises(ValueError):
         jpeg.decode_tables(bad)
+
+
+# ---- entropy decoding on the device (round 6): what the HOST contributes is the plan; its layout is checked here with a plain-Python
+# rendering of the kernel's algorithm (csrc/jpeg.hip jpeg_huffman_kernel): tables from the DHT counts, a bit reader that unstuffs
+# FF 00 and stops at a marker, one independent decode per restart interval
+def _decode_from_plan(data, plan, n_blocks):
+    ZZ = [0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28, 35, 42, 49, 56,
+          57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63]
+    h = np.frombuffer(plan[:128].tobytes(), dtype=np.int32)
+    assert h[0] == 0x3157504A
+    n_int, restart, mcux, mcuy, ncomp = (int(v) for v in h[1:6])
+    tabs = []
+    for t in range(4):
+        d = plan[128 + 32 * t:128 + 32 * t + 32] if t < 2 else plan[192 + 272 * (t - 2):192 + 272 * (t - 2) + 272]
+        codes, code, k = {}, 0, 0
+        for ln in range(1, 17):
+            for _ in range(int(d[ln - 1])):
+                codes[(ln, code)] = int(d[16 + k])
+                code += 1
+                k += 1
+            code <<= 1
+        tabs.append(codes)
+    ioff = np.frombuffer(plan[736:736 + 4 * n_int].tobytes(), dtype=np.uint32)
+    coef = np.zeros((n_blocks, 64), dtype=np.int16)
+    for iv in range(n_int):
+        pos, end = int(ioff[iv]), (int(ioff[iv + 1]) if iv + 1 < n_int else int(h[27]))
+        bits = []
+        while pos < end:
+            b = int(data[pos])
+            if b == 0xFF:
+                if pos + 1 < end and data[pos + 1] == 0:
+                    pos += 2
+                else:
+                    break
+            else:
+                pos += 1
+            bits.extend((b >> (7 - j)) & 1 for j in range(8))
+        bits.extend([0] * 64)
+        bp = 0
+
+        def sym(tab):
+            nonlocal bp
+            code = 0
+            for ln in range(1, 17):
+                code = (code << 1) | bits[bp + ln - 1]
+                if (ln, code) in tab:
+                    bp += ln
+                    return tab[(ln, code)]
+            raise AssertionError('invalid code')
+
+        def recv(s):
+            nonlocal bp
+            v = 0
+            for _ in range(s):
+                v = (v << 1) | bits[bp]
+                bp += 1
+            return v if v >= (1 << (s - 1)) else v - (1 << s) + 1
+        pred = [0, 0, 0]
+        for m in range(iv * restart, min((iv + 1) * restart, mcux * mcuy)):
+            my, mx = divmod(m, mcux)
+            for k in range(ncomp):
+                c = int(h[28 + k])
+                ch, cv, cbw, _cbh, coff, dcs, acs = (int(v) for v in h[6 + 7 * c:13 + 7 * c])
+                for v in range(cv):
+                    for hh in range(ch):
+                        blk = coef[coff + (my * cv + v) * cbw + mx * ch + hh]
+                        s = sym(tabs[dcs])
+                        if s:
+                            pred[c] += recv(s)
+                        blk[0] = pred[c]
+                        kk = 1
+                        while kk < 64:
+                            rs = sym(tabs[2 + acs])
+                            r, s = rs >> 4, rs & 15
+                            if s == 0:
+                                if r != 15:
+                                    break
+                                kk += 16
+                                continue
+                            kk += r
+                            blk[ZZ[kk]] = recv(s)
+                            kk += 1
+    return coef
+
+
+def test_entropy_plan_describes_the_restart_intervals():
+    import io
+    from PIL import Image
+    g = np.random.Generator(np.random.Philox(key=[12, 1]))
+    files = [open(os.path.join(HERE, n), 'rb').read() for n in ('s420_rst.jpg', 's422_rst.jpg')]
+    for (hh, ww, sub, kw) in ((40, 56, 2, {'restart_marker_rows': 1}), (33, 17, 0, {'restart_marker_blocks': 2}),
+                              (64, 48, 1, {'restart_marker_blocks': 3, 'optimize': True}), (24, 24, 2, {'restart_marker_blocks': 100})):
+        a = g.integers(0, 256, size=(hh, ww, 3), dtype=np.uint8)
+        bio = io.BytesIO()
+        Image.fromarray(a).save(bio, 'JPEG', quality=85, subsampling=sub, **kw)
+        files.append(bio.getvalue())
+    for raw in files:
+        f = jpeg.open_file(raw)
+        pl = f.entropy_plan()
+        assert pl is not None
+        plan, qt = pl
+        ref = jpeg.read_coef(raw)
+        np.testing.assert_array_equal(qt, ref.qt)
+        hdr = np.frombuffer(plan[:128].tobytes(), dtype=np.int32)
+        n_int = int(hdr[1])
+        assert n_int == -(-int(hdr[3]) * int(hdr[4]) // int(hdr[2])) and plan.size == 736 + 4 * n_int
+        off = np.frombuffer(plan[736:].tobytes(), dtype=np.uint32)
+        data = np.frombuffer(raw, dtype=np.uint8)
+        for i in range(1, n_int):        # every interval but the first starts right behind its RSTn marker, numbered in sequence
+            assert data[off[i] - 2] == 0xFF and data[off[i] - 1] == 0xD0 + ((i - 1) & 7)
+        np.testing.assert_array_equal(_decode_from_plan(data, plan, int(f.info[5])), ref.coef)
+    # no restart markers -> no plan (the host's Huffman decoder keeps the file); markers out of sequence -> no plan either
+    assert jpeg.open_file(os.path.join(HERE, 's420_q90.jpg')).entropy_plan() is None
+    bad = bytearray(files[0])
+    p = bad.find(b'\xff\xd1')
+    bad[p + 1] = 0xD5
+    assert jpeg.open_file(bytes(bad)).entropy_plan() is None
+
+
+def test_pack_ships_file_bytes_for_restart_marker_files(monkeypatch):
+    raw = open(os.path.join(HERE, 's420_rst.jpg'), 'rb').read()
+    plain = open(os.path.join(HERE, 's420_q90.jpg'), 'rb').read()
+    items = [jpeg.open_file(raw), jpeg.open_file(plain), jpeg.open_file(raw)]
+    buf, desc, kind = jpeg.pack(items)
+    d = desc.numpy()
+    assert kind == jpeg.KIND_JPEG and list(d[:, 26]) == [1, 0, 1] and list(d[:, 28]) == [len(raw), 0, len(raw)]
+    b = buf.numpy()
+    for i in (0, 2):
+        assert d[i, 0] % 128 == 0 and d[i, 27] % 16 == 0 and bytes(b[d[i, 0]:d[i, 0] + len(raw)]) == raw
+        assert b[d[i, 27]:d[i, 27] + 4].view(np.int32)[0] == 0x3157504A
+    # the host-decoded entry is laid out as before
+    np.testing.assert_array_equal(b[d[1, 0]:d[1, 0] + int(d[1, 7]) * 128].view(np.int16).reshape(-1, 64), jpeg.read_coef(plain).coef)
+    monkeypatch.setattr(jpeg, 'DEVICE_ENTROPY', False)
+    _b, desc2, _k = jpeg.pack([jpeg.open_file(raw)])
+    assert int(desc2[0, 26]) == 0

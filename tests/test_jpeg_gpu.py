@@ -116,3 +116,120 @@ def test_data_path_with_device_decode_equals_host_decode(tmp_path):
             assert torch.equal(torch.cat(polar), torch.cat([outs[True]['polar']] * 8))
             ring.close()
             assert ring.free.qsize() == 6
+
+
+def _fresh(g, h, w, sub, q, **kw):
+    from PIL import Image
+    small = g.integers(0, 256, size=(h // 8 + 2, w // 8 + 2, 3), dtype=np.uint8)
+    a = np.asarray(Image.fromarray(small).resize((w + 16, h + 16), Image.BICUBIC))[8:8 + h, 8:8 + w]
+    a = np.clip(a.astype(np.int16) + g.integers(-15, 16, size=(h, w, 3)), 0, 255).astype(np.uint8)
+    bio = io.BytesIO()
+    Image.fromarray(a).save(bio, 'JPEG', quality=q, subsampling=sub, **kw)
+    return bio.getvalue()
+
+
+def test_device_entropy_decode_equals_the_host_coefficients():
+    """round 6: files with restart markers are Huffman-decoded ON THE DEVICE (csrc/jpeg.hip jpeg_huffman_kernel, one thread per restart
+    interval, the host only scans for the markers): the coefficient blocks are those of witw_jpeg_decode_coef bit for bit -- fixtures,
+    fresh files of BASELINE's raw sizes, every sampling, optimised (per-file) Huffman tables, one / several / partial MCU rows per
+    interval, more intervals than the 64 lanes of a wave."""
+    from witw_amd import _lib, ops
+    dev = torch.device('cuda:0')
+    g = np.random.Generator(np.random.Philox(key=[13, 1]))
+    files = [open(os.path.join(HERE, n), 'rb').read() for n in ('s420_rst.jpg', 's422_rst.jpg')]
+    for (h, w, sub, q, kw) in ((512, 512, 2, 90, {'restart_marker_rows': 1}), (224, 224, 2, 90, {'restart_marker_rows': 1}),
+                               (750, 333, 1, 70, {'restart_marker_blocks': 7, 'optimize': True}), (100, 2, 0, 95, {'restart_marker_blocks': 1}),
+                               (8, 8, 2, 40, {'restart_marker_rows': 1}), (640, 640, 0, 99, {'restart_marker_blocks': 16}),
+                               (300, 300, 2, 5, {'restart_marker_rows': 2})):
+        files.append(_fresh(g, h, w, sub, q, **kw))
+    items = [jpeg.open_file(f) for f in files]
+    plans = [it.entropy_plan() for it in items]
+    assert all(p is not None for p in plans)
+    blocks = np.array([int(it.info[5]) for it in items], dtype=np.int64)
+    first = np.cumsum(blocks) - blocks
+    coef = torch.zeros((int(blocks.sum()), 64), dtype=torch.int16, device=dev)
+    keep, rows = [], []
+    for it, (plan, _qt), f0 in zip(items, plans, first):
+        raw = np.zeros((it.data.size + 8 + 7) // 8 * 8, dtype=np.uint8)
+        raw[:it.data.size] = it.data
+        rb, pb = torch.from_numpy(raw).to(dev), torch.from_numpy(np.concatenate([plan, np.zeros(16, np.uint8)])).to(dev)
+        keep += [rb, pb]
+        assert rb.data_ptr() % 8 == 0 and pb.data_ptr() % 4 == 0
+        rows.append((rb.data_ptr(), pb.data_ptr(), coef.data_ptr() + int(f0) * 128, it.data.size))
+    files_t = torch.tensor(rows, dtype=torch.int64, device=dev)
+    errors = torch.zeros((len(items),), dtype=torch.int32, device=dev)
+    _lib.check(_lib.load().witw_jpeg_huffman(files_t.data_ptr(), len(items), errors.data_ptr(), ops._stream()), 'witw_jpeg_huffman')
+    torch.cuda.synchronize()
+    assert int(errors.abs().sum()) == 0
+    got = coef.cpu().numpy()
+    for k, (raw, f0, nb) in enumerate(zip(files, first, blocks)):
+        np.testing.assert_array_equal(got[f0:f0 + nb], jpeg.read_coef(raw).coef, err_msg='file %d' % k)
+    # a damaged interval is flagged, the others of the file still decode, nothing is written outside the file's area
+    bad = bytearray(files[2])
+    p = bad.find(b'\xff\xd3')
+    bad[p + 8:p + 40] = b'\xff' * 32
+    it = jpeg.open_file(bytes(bad))
+    plan = it.entropy_plan()
+    if plan is not None:
+        raw = np.zeros((it.data.size + 15) // 8 * 8, dtype=np.uint8)
+        raw[:it.data.size] = it.data
+        rb, pb = torch.from_numpy(raw).to(dev), torch.from_numpy(plan[0]).to(dev)
+        c2 = torch.zeros((int(it.info[5]) + 8, 64), dtype=torch.int16, device=dev)
+        e2 = torch.zeros((1,), dtype=torch.int32, device=dev)
+        row = torch.tensor([[rb.data_ptr(), pb.data_ptr(), c2.data_ptr(), it.data.size]], dtype=torch.int64, device=dev)
+        _lib.check(_lib.load().witw_jpeg_huffman(row.data_ptr(), 1, e2.data_ptr(), ops._stream()), 'witw_jpeg_huffman')
+        torch.cuda.synchronize()
+        assert int(e2.item()) == 1 and int(c2[int(it.info[5]):].abs().sum()) == 0
+
+
+def test_device_entropy_path_gives_pillows_bytes_in_mixed_batches():
+    """pack() ships the FILE BYTES of restart-marker files (descriptor column 26) and decode_packed entropy-decodes them on the
+    device in front of the usual back end; files without markers (host Huffman), a progressive file (Pillow's bytes) and a raw array
+    ride in the same batch: every image equals Pillow's decode byte for byte, and nothing was flagged."""
+    from PIL import Image
+    g = np.random.Generator(np.random.Philox(key=[13, 2]))
+    raws = [_fresh(g, 512, 512, 2, 90, restart_marker_rows=1), _fresh(g, 224, 224, 2, 90), _fresh(g, 224, 224, 2, 90, restart_marker_rows=1),
+            open(os.path.join(HERE, 'prog_q85.jpg'), 'rb').read(), _fresh(g, 97, 131, 1, 60, restart_marker_blocks=3, optimize=True),
+            open(os.path.join(HERE, 's422_rst.jpg'), 'rb').read(), _fresh(g, 64, 64, 0, 80)]
+    items, refs = [], []
+    for r in raws:
+        it = jpeg.open_file(r)
+        ref = np.asarray(Image.open(io.BytesIO(r)))
+        items.append(it if it is not None else ref)
+        refs.append(ref)
+    items.insert(2, g.integers(0, 256, size=(7, 9, 3), dtype=np.uint8))
+    refs.insert(2, items[2])
+    buf, desc, _k = jpeg.pack(items)
+    assert list(desc[:, 26].numpy()) == [1, 0, 0, 1, 0, 1, 1, 0] and int(desc[4, 24]) == 1
+    out = jpeg.decode(items, torch.device('cuda:0'))
+    for k, (o, r) in enumerate(zip(out, refs)):
+        np.testing.assert_array_equal(o.cpu().numpy(), r if r.ndim == 3 else r[:, :, None], err_msg=str(k))
+    assert jpeg.entropy_errors() == 0
+
+
+def test_data_path_with_restart_marker_files_equals_host_decode(tmp_path):
+    """The drivers' data path on a data set written with restart markers: DataLoader workers only scan for the markers, the GPU does
+    Huffman decoding, IDCT, upsampling, colour conversion and the transforms -- the same 'surface' / 'polar' bits as Pillow's decode."""
+    from PIL import Image
+    from witw_amd import cvig_fov
+    g = np.random.Generator(np.random.Philox(key=[13, 3]))
+    root = str(tmp_path)
+    rows = []
+    for i in range(6):
+        for tag, (h, w) in (('su', (224, 224)), ('ov', (512, 512))):
+            open(os.path.join(root, '%s_%d.jpg' % (tag, i)), 'wb').write(_fresh(g, h, w, 2, 90, restart_marker_rows=1))
+        rows.append('ov_%d.jpg,su_%d.jpg' % (i, i))
+    csv = os.path.join(root, 'pairs.csv')
+    open(csv, 'w').write('\n'.join(rows) + '\n')
+    prep = cvig_fov.GpuPreprocess('cvusa', fov=360, random_orientation=False)
+    ref = prep(cvig_fov.collate_packed([cvig_fov.ImagePairDataset('cvusa', csv, raw=True)[i] for i in range(6)]))
+    ds = cvig_fov.ImagePairDataset('cvusa', csv, raw='jpeg')
+    batch = cvig_fov.collate_packed([ds[i] for i in range(6)])
+    assert int(batch['overhead_desc'][:, 26].sum()) == 6 and int(batch['surface_desc'][:, 26].sum()) == 6
+    # the block that crosses PCIe holds file bytes, not coefficient blocks: an order of magnitude smaller
+    assert batch['overhead_bytes'].numel() < 6 * 512 * 512 * 3 // 4
+    got = prep(batch)
+    assert torch.equal(got['surface'], ref['surface']) and torch.equal(got['polar'], ref['polar'])
+    loader = torch.utils.data.DataLoader(ds, batch_size=3, shuffle=False, num_workers=2, collate_fn=cvig_fov.collate_packed, pin_memory=True)
+    outs = [prep(st) for st in cvig_fov.DevicePrefetcher(loader, prep)]
+    assert torch.equal(torch.cat([d['polar'] for d in outs]), ref['polar']) and jpeg.entropy_errors() == 0

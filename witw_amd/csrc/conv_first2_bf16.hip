@@ -329,17 +329,24 @@ __global__ __launch_bounds__(F2T, 1) void conv_first2_bf16_kernel(First2Args p) 
             // channel groups 0-3 and the upper one groups 4-7 (a ds_read_b128's 16-lane groups stay inside one half: 16 consecutive
             // slots, conflict-free); the halves are joined by one cross-lane move and lanes 0-31 store 8 bytes each -- 256
             // contiguous bytes per row. a_s is not written again before the next tile's first barrier.
+            // the image holds post-ReLU values (witw_relu_bf16x2: every half is in [0x0000, 0x7fff]), so "> 0" is "!= 0": a packed
+            // unsigned min with 1 turns a dword into its two gate bits (positions 0 and 16), shift-ors gather a group's four
+            // dwords (positions 0,2,4,6 / 16,18,20,22) and one shift folds the upper ones in between: ~10 vector instructions per
+            // 8 channels (the compare-and-select form took 32)
+            // (v_pk_min_u16 by hand: written as __builtin_elementwise_min on a 2 x u16 view of sv[e], hipcc 7.2 folded the four
+            // dwords of a slot into its first one -- a one-dword load and t = m | m << 2 | m << 4 | m << 6)
+            const unsigned one2 = 0x00010001u;
             unsigned wbits = 0;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const u32x4 sv = a_s[(4 * hq + g) * APOS + (wave + 1) * APITCH + (l31 + 1)];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const unsigned w = sv[e];
-                    const unsigned lo = ((w & 0x7fffu) != 0u && !(w & 0x8000u)) ? 1u : 0u;
-                    const unsigned hi = ((w & 0x7fff0000u) != 0u && !(w & 0x80000000u)) ? 1u : 0u;
-                    wbits |= (lo | (hi << 1)) << (8 * g + 2 * e);
-                }
+                unsigned m0, m1, m2, m3;
+                asm("v_pk_min_u16 %0, %1, %2" : "=v"(m0) : "v"(sv[0]), "v"(one2));
+                asm("v_pk_min_u16 %0, %1, %2" : "=v"(m1) : "v"(sv[1]), "v"(one2));
+                asm("v_pk_min_u16 %0, %1, %2" : "=v"(m2) : "v"(sv[2]), "v"(one2));
+                asm("v_pk_min_u16 %0, %1, %2" : "=v"(m3) : "v"(sv[3]), "v"(one2));
+                const unsigned t = m0 | (m1 << 2) | (m2 << 4) | (m3 << 6);
+                wbits |= ((t & 0x55u) | ((t >> 15) & 0xAAu)) << (8 * g);
             }
             const unsigned other = (unsigned)__shfl_xor((int)wbits, 32, 64);
             const int oy = oy0 + wave, ox = ox0 + l31;

@@ -158,9 +158,215 @@ __global__ __launch_bounds__(256) void jpeg_to_rgb_kernel(const unsigned char* _
     o[0] = (unsigned char)r; o[1] = (unsigned char)g; o[2] = (unsigned char)b;
 }
 
+// ---- entropy decoding on the device (round 6; SURVEY 8(f)3 'decode ... entirely on device'), step one: files that carry RESTART
+// MARKERS. A restart interval starts byte-aligned with the DC predictors reset, so intervals decode independently: ONE THREAD PER
+// INTERVAL (a 512 x 512 4:2:0 file written with a marker per MCU row has 32 of them, a batch of 128 pairs ~5,900), one wave per
+// file. The host's share shrinks to a byte scan for the markers (csrc_host/jpeg_coef.cpp, witw_jpeg_entropy_plan: the plan layout is
+// described there) and the FILE BYTES cross PCIe instead of the coefficient blocks (~80 KB instead of 786 KB per overhead image).
+// Integer / byte work, latency-bound per thread (a table look-up and a few shifts per symbol); nothing here is MFMA- or
+// HBM-shaped. Same coefficients, bit for bit, as witw_jpeg_decode_coef (tests/test_jpeg_gpu.py).
+struct HuffLds {
+    unsigned short look[512];      // 9-bit prefix -> (code length << 8) | symbol; 0: the code is longer than 9 bits
+    int maxcode[18];               // largest code of each length (-1: none), [17] = sentinel
+    int valoff[17];                // symbol index of the first code of a length minus that code
+    unsigned char sym[256];
+};
+
+struct JpegFileDev {               // int64 x 4 per file
+    long long bytes;               // address of the file bytes (8-byte aligned, at least 8 readable bytes behind the end)
+    long long plan;                // address of the plan (witw_jpeg_entropy_plan)
+    long long coef;                // address of the file's coefficient area: int16 [blocks][64], ZERO-FILLED by the caller
+    long long n_bytes;             // file length
+};
+
+__constant__ unsigned char kZigZag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                                          41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                                          30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+struct BitReader {                 // over the STUFFED bytes of one restart interval: FF 00 -> FF on the fly, any other FF xx ends the data
+    const unsigned long long* words;
+    unsigned pos, end;             // byte offsets in the file
+    unsigned long long cache;      // the aligned 8 bytes that hold byte `pos`
+    unsigned cidx;                 // which 8-byte word `cache` is (0xffffffff: none)
+    unsigned long long buf;        // bits, left-aligned
+    int n;                         // valid bits in buf
+    int starved;                   // zero bytes fed behind the end of the data
+
+    __device__ __forceinline__ unsigned raw(unsigned p) {
+        if ((p >> 3) != cidx) { cidx = p >> 3; cache = words[cidx]; }
+        return (unsigned)(cache >> (8 * (p & 7))) & 0xffu;
+    }
+    __device__ __forceinline__ void fill() {      // tops up to more than 56 valid bits
+        while (n <= 56) {
+            unsigned b = 0;
+            if (pos < end) {
+                b = raw(pos);
+                if (b == 0xffu) {
+                    const unsigned b2 = pos + 1 < end ? raw(pos + 1) : 0xd9u;
+                    if (b2 == 0u) pos += 2;                    // a stuffed FF
+                    else { end = pos; b = 0; ++starved; }      // a marker (the next interval's RSTn, or EOI): the data ends here
+                } else {
+                    ++pos;
+                }
+            } else {
+                ++starved;
+            }
+            buf |= (unsigned long long)b << (56 - n);
+            n += 8;
+        }
+    }
+    __device__ __forceinline__ int get(int k) {    // k in 1..16, caller has >= 32 valid bits
+        const int v = (int)(buf >> (64 - k));
+        buf <<= k;
+        n -= k;
+        return v;
+    }
+};
+
+__device__ __forceinline__ int huff_decode(BitReader& b, const HuffLds& h) {      // caller has >= 32 valid bits; -1: invalid code
+    const unsigned e = h.look[(unsigned)(b.buf >> 55)];
+    if (e) {
+        const int len = (int)(e >> 8);
+        b.buf <<= len;
+        b.n -= len;
+        return (int)(e & 255u);
+    }
+    int len = 10;
+    int code = (int)(b.buf >> 54);
+    while (code > h.maxcode[len]) {
+        ++len;
+        if (len > 16) return -1;
+        code = (int)(b.buf >> (64 - len));
+    }
+    b.buf <<= len;
+    b.n -= len;
+    return h.sym[(code + h.valoff[len]) & 255];
+}
+
+__device__ __forceinline__ int jpeg_extend(int v, int s) { return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v; }
+
+__global__ __launch_bounds__(64) void jpeg_huffman_kernel(const JpegFileDev* __restrict__ files, int* __restrict__ errors) {
+    __shared__ HuffLds tab[4];                    // DC slot 0, 1, AC slot 0, 1
+    __shared__ int hdr[32];
+    const int lane = threadIdx.x;
+    const JpegFileDev f = files[blockIdx.x];
+    const unsigned char* plan = reinterpret_cast<const unsigned char*>(f.plan);
+    if (lane < 32) hdr[lane] = reinterpret_cast<const int*>(plan)[lane];
+    // ---- the four decoding tables from the DHT counts / symbols: lanes 0-3 assign the canonical codes of one table each (16
+    // lengths), then all lanes fill the 9-bit look-ups
+    if (lane < 4) {
+        const unsigned char* d = lane < 2 ? plan + 128 + 32 * lane : plan + 192 + 272 * (lane - 2);
+        HuffLds& h = tab[lane];
+        int code = 0, k = 0;
+        for (int len = 1; len <= 16; ++len) {
+            h.valoff[len] = k - code;
+            const int cnt = d[len - 1];
+            k += cnt;
+            code += cnt;
+            h.maxcode[len] = cnt ? code - 1 : -1;
+            code <<= 1;
+        }
+        h.maxcode[17] = 0x7fffffff;
+        h.maxcode[0] = -1;
+        h.valoff[0] = 0;
+        const int nsym = lane < 2 ? (k < 16 ? k : 16) : (k < 256 ? k : 256);
+        for (int i = 0; i < 256; ++i) h.sym[i] = i < nsym ? d[16 + i] : 0;
+    }
+    __syncthreads();
+    for (int e = lane; e < 4 * 512; e += 64) {
+        const int t = e >> 9, i = e & 511;
+        const unsigned char* d = t < 2 ? plan + 128 + 32 * t : plan + 192 + 272 * (t - 2);
+        const HuffLds& h = tab[t];
+        unsigned short v = 0;
+        for (int len = 1; len <= 9; ++len) {
+            const int code = i >> (9 - len);
+            const int cnt = d[len - 1];
+            if (cnt && code <= h.maxcode[len] && code > h.maxcode[len] - cnt) {
+                v = (unsigned short)((len << 8) | h.sym[(code + h.valoff[len]) & 255]);
+                break;
+            }
+        }
+        tab[t].look[i] = v;
+    }
+    __syncthreads();
+    if (hdr[0] != 0x3157504A) {
+        if (lane == 0) errors[blockIdx.x] = 2;
+        return;
+    }
+    const int n_int = hdr[1], restart = hdr[2], mcux = hdr[3], mcuy = hdr[4], ncomp = hdr[5];
+    const unsigned end_all = (unsigned)hdr[27];
+    const unsigned* ioff = reinterpret_cast<const unsigned*>(plan + 736);
+    short* coef = reinterpret_cast<short*>(f.coef);
+    const long long mcus = (long long)mcux * mcuy;
+    bool bad = false;
+    for (int iv = lane; iv < n_int; iv += 64) {
+        BitReader b;
+        b.words = reinterpret_cast<const unsigned long long*>(f.bytes);
+        b.pos = ioff[iv];
+        b.end = iv + 1 < n_int ? ioff[iv + 1] : end_all;      // (the RSTn marker in front of the next interval stops the reader earlier)
+        if (b.end > (unsigned)f.n_bytes) b.end = (unsigned)f.n_bytes;
+        b.cidx = 0xffffffffu; b.cache = 0; b.buf = 0; b.n = 0; b.starved = 0;
+        int pred[3] = {0, 0, 0};
+        const long long m0 = (long long)iv * restart;
+        const long long m1 = m0 + restart < mcus ? m0 + restart : mcus;
+        for (long long m = m0; m < m1 && !bad; ++m) {
+            const int my = (int)(m / mcux), mx = (int)(m - (long long)my * mcux);
+            for (int k = 0; k < ncomp && !bad; ++k) {
+                const int c = hdr[28 + k];
+                const int* q = hdr + 6 + 7 * c;
+                const int ch = q[0], cv = q[1], cbw = q[2];
+                const long long coff = q[4];
+                const HuffLds& hd = tab[q[5] & 1];
+                const HuffLds& ha = tab[2 + (q[6] & 1)];
+                for (int v = 0; v < cv && !bad; ++v)
+                    for (int hh = 0; hh < ch && !bad; ++hh) {
+                        short* blk = coef + (coff + (long long)(my * cv + v) * cbw + (mx * ch + hh)) * 64;
+                        b.fill();
+                        int s = huff_decode(b, hd);
+                        if (s < 0 || s > 15) { bad = true; break; }
+                        if (s) pred[c] += jpeg_extend(b.get(s), s);
+                        blk[0] = (short)pred[c];
+                        for (int kk = 1; kk < 64;) {
+                            if (b.n < 32) b.fill();
+                            const int rs = huff_decode(b, ha);
+                            if (rs < 0) { bad = true; break; }
+                            const int r = rs >> 4;
+                            s = rs & 15;
+                            if (s == 0) {
+                                if (r != 15) break;
+                                kk += 16;
+                                continue;
+                            }
+                            kk += r;
+                            if (kk > 63) { bad = true; break; }
+                            blk[kZigZag[kk]] = (short)jpeg_extend(b.get(s), s);
+                            ++kk;
+                        }
+                        if (b.starved > 9) bad = true;      // the data ended inside the interval (witw_jpeg_decode_coef: -3)
+                    }
+            }
+        }
+    }
+    if (bad) errors[blockIdx.x] = 1;
+}
+
 }  // namespace
 
 extern "C" {
+
+// Entropy decoding of n_files JPEG files WITH RESTART MARKERS on the device, one thread per restart interval: files = DEVICE int64
+// [n_files][4] = {address of the file bytes (8-byte aligned, 8 readable bytes behind the end), address of the file's plan
+// (witw_jpeg_entropy_plan, 4-byte aligned), address of its coefficient area int16 [blocks][64] (zero-filled by the caller), file
+// length}; errors = DEVICE int32 [n_files], zeroed by the caller: 1 where the entropy-coded data of a file is damaged (its
+// coefficients are then incomplete: witw_jpeg_decode_coef returns -3 for such a file), 2 for a bad plan. The coefficients are the
+// bits witw_jpeg_decode_coef writes; witw_jpeg_idct / witw_jpeg_to_rgb take it from there (model/cvig_fov.py:88-89).
+int witw_jpeg_huffman(const void* files, int n_files, int* errors, void* stream) {
+    WITW_CHECK_ARG(files && errors, "jpeg_huffman: null pointer");
+    WITW_CHECK_ARG(n_files > 0, "jpeg_huffman: %d files", n_files);
+    hipLaunchKernelGGL(jpeg_huffman_kernel, dim3((unsigned)n_files), dim3(64), 0, (hipStream_t)stream, (const JpegFileDev*)files, errors);
+    WITW_CHECK_LAUNCH("jpeg_huffman");
+    return WITW_OK;
+}
 
 // coef: DEVICE int16 [total_blocks][64] (natural order, as witw_jpeg_decode_coef writes them); qt: DEVICE uint16 [n_tables][64];
 // planes: DEVICE int64 [n_planes][6] = {first block, table index, byte offset of the output plane, blocks wide, blocks high,

@@ -26,11 +26,15 @@ struct Huff {
     int32_t maxcode[18];             // largest code of each length (-1: none), [17] = sentinel
     int32_t valoff[17];              // symbol index of the first code of each length minus that code
     uint8_t sym[256];
+    uint8_t counts[16];              // codes per length as the DHT segment gives them (witw_jpeg_entropy_plan hands them to the device)
+    int nsym;
     bool present;
 };
 
 bool build_huff(Huff& h, const uint8_t* counts, const uint8_t* symbols, int nsym, bool ac) {
     memcpy(h.sym, symbols, nsym);
+    memcpy(h.counts, counts, 16);
+    h.nsym = nsym;
     memset(h.look_len, 0, sizeof(h.look_len));
     memset(h.fast_ac, 0, sizeof(h.fast_ac));
     h.present = false;
@@ -355,6 +359,95 @@ int witw_jpeg_decode_coef(const uint8_t* data, size_t n, int16_t* coef, uint16_t
             if (P.restart) --to_restart;
         }
     return 0;
+}
+
+// ---- entropy decoding ON THE DEVICE for files that carry restart markers (csrc/jpeg.hip, jpeg_huffman_kernel: one GPU thread per
+// restart interval). What is left for the host is a byte scan: the header, and the positions of the RSTn markers in the entropy-coded
+// segment (memchr over ~80 KB per 512 x 512 image instead of decoding ~60 k Huffman symbols). The plan written here is what the
+// kernel reads beside the FILE BYTES themselves (it unstuffs FF 00 on the fly):
+//   int32[0] magic 'JPW1', [1] intervals, [2] MCUs per interval, [3] MCUs per row, [4] MCU rows, [5] components,
+//   [6 + 7c ..] component c < 3: h, v, blocks wide, blocks high, first block (within the file's coefficient area), DC slot, AC slot,
+//   [27] end of the entropy-coded data (byte offset in the file), [28..30] component of scan position k, [31] 0;
+//   byte 128: DC tables of slots 0, 1 (16 counts + 16 symbols each), byte 192: AC tables of slots 0, 1 (16 counts + 256 symbols each);
+//   byte 736: uint32 [intervals]: byte offset in the file of each interval's first entropy-coded byte.
+// Files without restart markers, with more than two DC or AC tables in use, or whose markers are out of sequence return -2 / -3 and
+// take the host path (witw_jpeg_decode_coef) as before.
+enum { WITW_JPEG_PLAN_FIXED = 736 };
+
+long long witw_jpeg_entropy_plan_bytes(const uint8_t* data, size_t n) {      // 0: no restart markers (or not a file for this decoder)
+    Parsed& P = parsed();
+    if (parse(data, n, P) || P.restart <= 0) return 0;
+    const long long mcus = (long long)P.mcux * P.mcuy;
+    return WITW_JPEG_PLAN_FIXED + 4 * ((mcus + P.restart - 1) / P.restart);
+}
+
+// plan: plan_cap bytes (witw_jpeg_entropy_plan_bytes); qt: ncomp x 64 uint16 (as witw_jpeg_decode_coef writes them).
+// Returns the plan's size in bytes, or -1 / -2 as witw_jpeg_info, -2 also for files without restart markers or with more than two
+// Huffman tables of a kind in use, -3 when the restart markers found do not number intervals - 1 in sequence.
+long long witw_jpeg_entropy_plan(const uint8_t* data, size_t n, uint8_t* plan, size_t plan_cap, uint16_t* qt) {
+    Parsed& P = parsed();
+    const int rc = parse(data, n, P);
+    if (rc) return rc;
+    if (P.restart <= 0) return -2;
+    const long long mcus = (long long)P.mcux * P.mcuy;
+    const long long n_int = (mcus + P.restart - 1) / P.restart;
+    const long long need = WITW_JPEG_PLAN_FIXED + 4 * n_int;
+    if ((long long)plan_cap < need || n_int > 0x7fffffff) return -1;
+    memset(plan, 0, (size_t)need);
+    int32_t* h = reinterpret_cast<int32_t*>(plan);
+    h[0] = 0x3157504A;      // 'JPW1'
+    h[1] = (int32_t)n_int; h[2] = P.restart; h[3] = P.mcux; h[4] = P.mcuy; h[5] = P.ncomp;
+    int dc_slot[4] = {-1, -1, -1, -1}, ac_slot[4] = {-1, -1, -1, -1}, n_dc = 0, n_ac = 0;
+    for (int c = 0; c < P.ncomp; ++c) {
+        if (dc_slot[P.c[c].td] < 0) { if (n_dc == 2) return -2; dc_slot[P.c[c].td] = n_dc++; }
+        if (ac_slot[P.c[c].ta] < 0) { if (n_ac == 2) return -2; ac_slot[P.c[c].ta] = n_ac++; }
+        int32_t* q = h + 6 + 7 * c;
+        q[0] = P.c[c].h; q[1] = P.c[c].v; q[2] = P.c[c].bw; q[3] = P.c[c].bh; q[4] = (int32_t)P.c[c].off;
+        q[5] = dc_slot[P.c[c].td]; q[6] = ac_slot[P.c[c].ta];
+        memcpy(qt + 64 * c, P.qt[P.c[c].tq], 128);
+    }
+    for (int k = 0; k < P.scan_ncomp && k < 3; ++k) h[28 + k] = P.scan_comp[k];
+    for (int t = 0; t < 4; ++t) {
+        if (dc_slot[t] >= 0) {
+            const Huff& hf = P.dc[t];
+            if (hf.nsym > 16) return -2;                              // a DC table holds at most 12 categories (16 leaves room)
+            uint8_t* d = plan + 128 + 32 * dc_slot[t];
+            memcpy(d, hf.counts, 16);
+            memcpy(d + 16, hf.sym, (size_t)hf.nsym);
+        }
+        if (ac_slot[t] >= 0) {
+            const Huff& hf = P.ac[t];
+            uint8_t* d = plan + 192 + 272 * ac_slot[t];
+            memcpy(d, hf.counts, 16);
+            memcpy(d + 16, hf.sym, (size_t)hf.nsym);
+        }
+    }
+    uint32_t* off = reinterpret_cast<uint32_t*>(plan + WITW_JPEG_PLAN_FIXED);
+    const uint8_t* q = P.scan;
+    const uint8_t* e = data + n;
+    long long found = 0;
+    off[0] = (uint32_t)(P.scan - data);
+    int next_rst = 0;
+    const uint8_t* end = e;
+    while (q < e) {
+        const uint8_t* f = (const uint8_t*)memchr(q, 0xFF, (size_t)(e - q));
+        if (!f || f + 1 >= e) break;
+        const int m = f[1];
+        if (m == 0) { q = f + 2; continue; }                           // a stuffed FF
+        if (m == 0xFF) { q = f + 1; continue; }                        // fill byte
+        if (m >= 0xD0 && m <= 0xD7) {
+            if (m - 0xD0 != next_rst || found + 1 >= n_int) return -3;
+            next_rst = (next_rst + 1) & 7;
+            off[++found] = (uint32_t)(f + 2 - data);
+            q = f + 2;
+            continue;
+        }
+        end = f;                                                       // EOI or another marker: the entropy-coded data ends here
+        break;
+    }
+    if (found != n_int - 1) return -3;
+    h[27] = (int32_t)(end - data);
+    return need;
 }
 
 }  // extern "C"

@@ -17,7 +17,13 @@ from . import build as _build
 
 _HOST = None
 KIND_JPEG = 2          # packed-batch kind: coefficient blocks (+ raw uint8 images for the files left to Pillow)
-DESC_COLS = 26         # per image: coefficient byte offset, quantisation-table byte offset, 22 info ints, is_raw, channels
+DESC_COLS = 30         # per image: coefficient byte offset, quantisation-table byte offset, 22 info ints, is_raw, channels,
+#                        entropy decoding on the device (1: column 0 is then the offset of the FILE BYTES), plan byte offset, file length, 0
+# Files that carry restart markers are entropy-decoded ON THE DEVICE (csrc/jpeg.hip jpeg_huffman_kernel, one GPU thread per restart
+# interval; round 6): the worker only scans for the markers and the file bytes cross PCIe instead of the coefficient blocks.
+# WITW_JPEG_DEVICE_ENTROPY=0 (or jpeg.DEVICE_ENTROPY = False) keeps every file on the host's Huffman decoder.
+DEVICE_ENTROPY = os.environ.get('WITW_JPEG_DEVICE_ENTROPY', '1') != '0'
+_ERRORS = []           # error flags (device int32 tensors) of the last batches decoded on the device: entropy_errors() sums them
 
 
 def host_lib():
@@ -29,6 +35,10 @@ def host_lib():
         lib.witw_jpeg_info.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
         lib.witw_jpeg_decode_coef.restype = ctypes.c_int
         lib.witw_jpeg_decode_coef.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
+        lib.witw_jpeg_entropy_plan_bytes.restype = ctypes.c_longlong
+        lib.witw_jpeg_entropy_plan_bytes.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+        lib.witw_jpeg_entropy_plan.restype = ctypes.c_longlong
+        lib.witw_jpeg_entropy_plan.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
         _HOST = lib
     return _HOST
 
@@ -57,6 +67,21 @@ class JpegFile(JpegCoef):
     def decode_into(self, coef, qt):
         """coef int16 [blocks, 64], qt uint16 [components, 64]: views of the destination. -> False if the entropy data is bad."""
         return host_lib().witw_jpeg_decode_coef(self.data.ctypes.data, self.data.size, coef.ctypes.data, qt.ctypes.data) == 0
+
+    def entropy_plan(self):
+        """What the DEVICE needs to entropy-decode this file itself (csrc_host/jpeg_coef.cpp witw_jpeg_entropy_plan: header fields,
+        Huffman tables, the byte offset of every restart interval) -> (plan uint8 array, qt uint16 [components, 64]), or None for a
+        file without restart markers (or one this scheme leaves to the host: more than two tables of a kind, markers out of
+        sequence). A byte scan of the file, no Huffman decoding."""
+        lib = host_lib()
+        n = int(lib.witw_jpeg_entropy_plan_bytes(self.data.ctypes.data, self.data.size))
+        if n <= 0:
+            return None
+        plan = np.empty((n,), dtype=np.uint8)
+        qt = np.empty((int(self.info[2]), 64), dtype=np.uint16)
+        if lib.witw_jpeg_entropy_plan(self.data.ctypes.data, self.data.size, plan.ctypes.data, n, qt.ctypes.data) != n:
+            return None
+        return plan, qt
 
     def pillow(self):
         """The host decoder's opinion of the file (what the reference's imread returns, model/cvig_fov.py:88-89): uint8 HWC.
@@ -114,8 +139,18 @@ def pack(images, shared=False, alloc=None):
     alloc(nbytes) -> (offset, uint8 numpy view) or None: build the block in caller-provided memory (ring.PinnedRing), in which
     case the first result is (offset, nbytes) instead of a tensor."""
     desc, off, spans = np.zeros((len(images), DESC_COLS), dtype=np.int64), 0, []
+    plans = {}
     for i, a in enumerate(images):
-        if isinstance(a, JpegCoef):
+        if DEVICE_ENTROPY and isinstance(a, JpegFile):
+            pl = a.entropy_plan()
+            if pl is not None:
+                plans[i] = pl
+        if i in plans:
+            # entropy decoding on the device: the FILE BYTES travel (8 readable bytes behind the end for the kernel's 8-byte loads)
+            nbytes = int(a.data.size) + 8
+            desc[i, 2:24] = a.info
+            desc[i, 26], desc[i, 28] = 1, int(a.data.size)
+        elif isinstance(a, JpegCoef):
             nbytes = int(a.info[5]) * 128
             desc[i, 2:24] = a.info
         else:
@@ -135,6 +170,9 @@ def pack(images, shared=False, alloc=None):
         if isinstance(a, JpegCoef):
             desc[i, 1] = off
             off += (int(a.info[2]) * 128 + 15) // 16 * 16
+    for i in plans:
+        desc[i, 27] = off
+        off += (plans[i][0].size + 15) // 16 * 16
     if alloc is not None:
         got = alloc(off)
         if got is None:
@@ -145,7 +183,13 @@ def pack(images, shared=False, alloc=None):
         buf = t.numpy()
     for i, a in enumerate(images):
         o, nbytes = spans[i]
-        if isinstance(a, JpegFile):
+        if i in plans:
+            plan, qt = plans[i]
+            buf[o:o + a.data.size] = a.data
+            buf[o + a.data.size:o + nbytes] = 0
+            buf[int(desc[i, 27]):int(desc[i, 27]) + plan.size] = plan
+            buf[int(desc[i, 1]):int(desc[i, 1]) + qt.size * 2] = qt.reshape(-1).view(np.uint8)
+        elif isinstance(a, JpegFile):
             coef = buf[o:o + nbytes].view(np.int16).reshape(-1, 64)
             qt = buf[int(desc[i, 1]):int(desc[i, 1]) + int(a.info[2]) * 128].view(np.uint16).reshape(-1, 64)
             if not a.decode_into(coef, qt):
@@ -205,40 +249,74 @@ def decode_tables(d):
     return planes, images, int(flat.sum()), int(flat.sum()) * 64, int(ob.sum()), qt_base
 
 
+def _decode_group(dbuf, d, coef_ptr, qt_ptr):
+    """dequantisation + inverse DCT + upsampling + colour conversion of the JPEG entries d (descriptor rows whose column 0 is the
+    byte offset of their coefficient blocks from coef_ptr) -> (tensors to keep alive, device address of every decoded image,
+    components per image). Two launches."""
+    from . import _lib, ops
+    try:
+        planes, images, blk, pbytes, obytes, qt_base = decode_tables(d)
+    except ValueError as e:
+        raise _lib.WitwError(str(e))
+    dev = dbuf.device
+    plane_t = torch.from_numpy(planes).pin_memory().to(dev, non_blocking=True)
+    image_t = torch.from_numpy(images).pin_memory().to(dev, non_blocking=True)
+    comp = torch.empty((pbytes,), dtype=torch.uint8, device=dev)
+    rgb = torch.empty((obytes,), dtype=torch.uint8, device=dev)
+    lib = _lib.load()
+    st = ops._stream()
+    _lib.check(lib.witw_jpeg_idct(coef_ptr, qt_ptr + qt_base, plane_t.data_ptr(), planes.shape[0], blk, comp.data_ptr(), st), 'witw_jpeg_idct')
+    _lib.check(lib.witw_jpeg_to_rgb(comp.data_ptr(), image_t.data_ptr(), int(d.shape[0]), int((images[:, 0] * images[:, 1]).max()),
+                                    rgb.data_ptr(), st), 'witw_jpeg_to_rgb')
+    return [plane_t, image_t, comp, rgb], rgb.data_ptr() + images[:, 11], images[:, 2]
+
+
 def decode_packed(dbuf, desc):
     """dbuf: the packed block on the GPU; desc: its HOST descriptor table -> (tensors to keep alive, int64 host table [B,5] =
     {device address, H, W, 0, channels} of the decoded uint8 HWC images: the descriptor rows of
-    witw_resize_bilinear_normalize_batched / witw_polar_from_raw, kind 1). Two launches for the whole batch."""
+    witw_resize_bilinear_normalize_batched / witw_polar_from_raw, kind 1). Two launches for the entries whose coefficient blocks
+    came from the host; for the entries that travelled as file bytes (restart markers: DEVICE_ENTROPY) one more launch in front
+    entropy-decodes them into a coefficient buffer on the device."""
     from . import _lib, ops
     d = desc.numpy() if isinstance(desc, torch.Tensor) else np.asarray(desc)
     B = d.shape[0]
     table = np.zeros((B, 5), dtype=np.int64)
     keep = []
     is_raw = d[:, 24] != 0
+    on_dev = (d[:, 26] != 0) & ~is_raw if d.shape[1] > 26 else np.zeros((B,), dtype=bool)
     table[:, 1], table[:, 2] = d[:, 2], d[:, 3]
     table[is_raw, 0] = dbuf.data_ptr() + d[is_raw, 0]
     table[is_raw, 4] = d[is_raw, 25]
-    jp = np.nonzero(~is_raw)[0]
+    jp = np.nonzero(~is_raw & ~on_dev)[0]
     if jp.size:
-        try:
-            planes, images, blk, pbytes, obytes, qt_base = decode_tables(d[jp])
-        except ValueError as e:
-            raise _lib.WitwError(str(e))
-        table[jp, 4] = images[:, 2]
+        k, addr, ncomp = _decode_group(dbuf, d[jp], dbuf.data_ptr(), dbuf.data_ptr())
+        keep += k
+        table[jp, 0], table[jp, 4] = addr, ncomp
+    dv = np.nonzero(on_dev)[0]
+    if dv.size:
         dev = dbuf.device
-        plane_t = torch.from_numpy(planes).pin_memory().to(dev, non_blocking=True)
-        image_t = torch.from_numpy(images).pin_memory().to(dev, non_blocking=True)
-        comp = torch.empty((pbytes,), dtype=torch.uint8, device=dev)
-        rgb = torch.empty((obytes,), dtype=torch.uint8, device=dev)
-        lib = _lib.load()
-        st = ops._stream()
-        _lib.check(lib.witw_jpeg_idct(dbuf.data_ptr(), dbuf.data_ptr() + qt_base, plane_t.data_ptr(), planes.shape[0], blk, comp.data_ptr(), st),
-                   'witw_jpeg_idct')
-        _lib.check(lib.witw_jpeg_to_rgb(comp.data_ptr(), image_t.data_ptr(), int(jp.size), int((images[:, 0] * images[:, 1]).max()),
-                                        rgb.data_ptr(), st), 'witw_jpeg_to_rgb')
-        table[jp, 0] = rgb.data_ptr() + images[:, 11]
-        keep += [plane_t, image_t, comp, rgb]
+        blocks = d[dv, 7]                                        # info[5]: coefficient blocks of the file
+        first = np.cumsum(blocks) - blocks
+        coef = torch.zeros((int(blocks.sum()) * 64,), dtype=torch.int16, device=dev)
+        files = np.stack([dbuf.data_ptr() + d[dv, 0], dbuf.data_ptr() + d[dv, 27], coef.data_ptr() + first * 128, d[dv, 28]], axis=1).astype(np.int64)
+        files_t = torch.from_numpy(files).pin_memory().to(dev, non_blocking=True)
+        errors = torch.zeros((int(dv.size),), dtype=torch.int32, device=dev)
+        _lib.check(_lib.load().witw_jpeg_huffman(files_t.data_ptr(), int(dv.size), errors.data_ptr(), ops._stream()), 'witw_jpeg_huffman')
+        dd = d[dv].copy()
+        dd[:, 0] = first * 128                                   # where each file's coefficient blocks sit in `coef`
+        k, addr, ncomp = _decode_group(dbuf, dd, coef.data_ptr(), dbuf.data_ptr())
+        keep += k + [coef, files_t, errors]
+        table[dv, 0], table[dv, 4] = addr, ncomp
+        _ERRORS.append(errors)
+        del _ERRORS[:-64]
     return keep, torch.from_numpy(table)
+
+
+def entropy_errors():
+    """Files of the last (up to 64) device-entropy-decoded batches whose entropy-coded data was damaged (the host path hands such a
+    file to Pillow; on the device it decodes with zeros from the damage on and is counted here). Synchronises."""
+    n = sum(int((e != 0).sum().item()) for e in _ERRORS)
+    return n
 
 
 def decode(images, device):
