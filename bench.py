@@ -429,6 +429,10 @@ def main():
                     help="e2e: 'device' = DataLoader workers entropy-decode the JPEG files, the GPU does dequantisation / IDCT / upsampling / "
                          "colour conversion (byte-identical to Pillow); 'host' = Pillow in the workers (the reference's arrangement)")
     ap.add_argument('--e2e-dir', default=None, help='e2e: directory of the synthetic JPEG data set (kept; files already there are reused)')
+    ap.add_argument('--jpeg-restart-rows', type=int, default=0,
+                    help='e2e: write the synthetic JPEG files with a restart marker every N MCU rows (0: none, as Pillow / libjpeg write by '
+                         'default); files with restart markers are entropy-decoded on the GPU, one thread per restart interval')
+    ap.add_argument('--jpeg-restart-blocks', type=int, default=0, help='e2e: ... or a restart marker every N MCUs (jpegtran -restart NB)')
     ap.add_argument('--no-decode-scaling', action='store_true', help='e2e: skip the host entropy-decode scaling sweep')
     ap.add_argument('--decode-scaling-seconds', type=float, default=1.0)
     ap.add_argument('--no-ring', action='store_true', help='e2e: torch DataLoader staging (shared-memory pickling + pin_memory thread) instead of ring.PinnedRing')
@@ -598,8 +602,8 @@ def train_step_entry(a, tb, rank, world, device):
     return entry, full
 
 
-SIDE_ORDER = ('train_step_fp32', 'config4_semantic_bf16', 'train_step_bf16', 'config1_baseline', 'config5_retrieval', 'config5_retrieval_direct',
-              'fp32_grade_on_fp16_mfma', 'hbm_kernels', 'batch_sweep', 'e2e_data_path', 'e2e_data_path_bf16')
+SIDE_ORDER = ('train_step_fp32', 'config4_semantic_bf16', 'config4_semantic_bf16_train', 'train_step_bf16', 'config1_baseline', 'config5_retrieval', 'config5_retrieval_direct',
+              'fp32_grade_on_fp16_mfma', 'hbm_kernels', 'batch_sweep', 'e2e_data_path', 'e2e_data_path_bf16', 'e2e_data_path_bf16_device_entropy')
 
 
 def side_blocks(a, rank, world, device, cvig_fov, ops):
@@ -663,15 +667,22 @@ def side_blocks(a, rank, world, device, cvig_fov, ops):
         e = e2e_child(a, extra)
         if 'error' in e:
             return e
-        keys = ('metric', 'value', 'unit', 'dtype', 'jpeg_decode', 'staging', 'steady_state_pairs_per_s', 'pipeline_fill_s', 'stage_pairs_per_s',
+        keys = ('metric', 'value', 'unit', 'dtype', 'jpeg_decode', 'pcie_bytes_per_pair', 'staging', 'steady_state_pairs_per_s', 'pipeline_fill_s', 'stage_pairs_per_s',
                 'limiting_stage', 'overlap_efficiency_steady_state', 'overlap_efficiency_raw', 'gpu_stage_serialised_pairs_per_s',
                 'host_decode_pairs_per_s_per_core', 'host_decode_scaling')
         blk = {kk: e[kk] for kk in keys if kk in e}
         blk['workload'] = (e.get('config') or {}).get('workload')
         return blk
 
+    def semantic_bf16_train():
+        t = StepBench('semantic', 'train', 'bf16', a.batch, a.fov, rank, world, device).run(k, 2)
+        return t.block('configs[3] training: cvig_semantic (layer 0 trains, model/cvig_semantic.py:301-309) on the bf16 MFMA -- forward, data '
+                       'gradient through all 13 layers, weight gradients of layers 0 and 17-27, fp32 master weights and Adam',
+                       'tests/test_bf16_train_gpu.py (semantic cases: vs the fp32 step; fused first-two-layers forward bitwise the unfused one)')
+
     guarded('train_step_fp32', train_fp32)
     guarded('config4_semantic_bf16', semantic_bf16)
+    guarded('config4_semantic_bf16_train', semantic_bf16_train)
     guarded('train_step_bf16', train_bf16)
     cpu_leg = [None]
 
@@ -695,6 +706,14 @@ def side_blocks(a, rank, world, device, cvig_fov, ops):
         guarded('e2e_data_path', lambda: e2e(['--e2e-pairs', '2048', '--e2e-dir', jpegs, '--no-decode-scaling']))
         guarded('e2e_data_path_bf16', lambda: e2e(['--e2e-pairs', '8192', '--workers', '16', '--precision', 'bf16', '--e2e-dir', jpegs,
                                                    '--decode-scaling-seconds', '0.5']))
+    finally:
+        shutil.rmtree(jpegs, ignore_errors=True)
+    # the same bf16 pass on files that carry restart markers: Huffman decoding moves to the GPU and FOUR workers (marker scan +
+    # packing) feed it -- the data path no longer scales with the host's cores
+    jpegs = tempfile.mkdtemp(prefix='witw_e2e_rst_')
+    try:
+        guarded('e2e_data_path_bf16_device_entropy', lambda: e2e(['--e2e-pairs', '8192', '--workers', '4', '--precision', 'bf16', '--e2e-dir', jpegs,
+                                                                  '--jpeg-restart-blocks', '2']))
     finally:
         shutil.rmtree(jpegs, ignore_errors=True)
     if cpu_leg[0] is not None:
@@ -781,7 +800,7 @@ def compact_side(name, b):
         if isinstance(b.get('cpu_baseline'), dict):
             c['cpu_pairs_per_s'] = b['cpu_baseline'].get('value')
             c['cpu_cores'] = b['cpu_baseline'].get('cores')
-    if name.startswith('train_step') and isinstance(r, dict) and 'wgrad_bf16_tflops_incl_layout_passes' in r:
+    if (name.startswith('train_step') or name.endswith('_train')) and isinstance(r, dict) and 'wgrad_bf16_tflops_incl_layout_passes' in r:
         c['wgrad_tflops'] = r['wgrad_bf16_tflops_incl_layout_passes']
     if name == 'hbm_kernels':
         c = {'unit': 'frac of 8 TB/s', 'kernels': {short(k.split(' ')[0], 40): v['frac_of_hbm_peak'] for k, v in b.get('kernels', {}).items()}}

@@ -173,7 +173,7 @@ struct HuffLds {
 };
 
 struct JpegFileDev {               // int64 x 4 per file
-    long long bytes;               // address of the file bytes (8-byte aligned, at least 8 readable bytes behind the end)
+    long long bytes;               // address of the file bytes (8-byte aligned, at least 24 readable bytes behind the end)
     long long plan;                // address of the plan (witw_jpeg_entropy_plan)
     long long coef;                // address of the file's coefficient area: int16 [blocks][64], ZERO-FILLED by the caller
     long long n_bytes;             // file length
@@ -187,13 +187,20 @@ struct BitReader {                 // over the STUFFED bytes of one restart inte
     const unsigned long long* words;
     unsigned pos, end;             // byte offsets in the file
     unsigned long long cache;      // the aligned 8 bytes that hold byte `pos`
+    unsigned long long ahead;      // ... and the 8 bytes behind them, requested when `cache` was taken (the stream is read in order:
+                                   // the load's round trip runs under the decoding of the current word instead of in front of the next)
     unsigned cidx;                 // which 8-byte word `cache` is (0xffffffff: none)
     unsigned long long buf;        // bits, left-aligned
     int n;                         // valid bits in buf
     int starved;                   // zero bytes fed behind the end of the data
 
     __device__ __forceinline__ unsigned raw(unsigned p) {
-        if ((p >> 3) != cidx) { cidx = p >> 3; cache = words[cidx]; }
+        if ((p >> 3) != cidx) {
+            const unsigned w = p >> 3;
+            cache = (w == cidx + 1u) ? ahead : words[w];
+            cidx = w;
+            ahead = words[w + 1u];
+        }
         return (unsigned)(cache >> (8 * (p & 7))) & 0xffu;
     }
     __device__ __forceinline__ void fill() {      // tops up to more than 56 valid bits
@@ -251,6 +258,9 @@ __global__ __launch_bounds__(64) void jpeg_huffman_kernel(const JpegFileDev* __r
     const int lane = threadIdx.x;
     const JpegFileDev f = files[blockIdx.x];
     const unsigned char* plan = reinterpret_cast<const unsigned char*>(f.plan);
+    // blockIdx.y: which 64 intervals of the file this wave decodes (a thread's chain of symbols is what bounds the kernel: files with
+    // short intervals spread over several waves); waves past the file's last interval leave before building tables
+    if ((int)blockIdx.y * 64 >= reinterpret_cast<const int*>(plan)[1] && reinterpret_cast<const int*>(plan)[0] == 0x3157504A) return;
     if (lane < 32) hdr[lane] = reinterpret_cast<const int*>(plan)[lane];
     // ---- the four decoding tables from the DHT counts / symbols: lanes 0-3 assign the canonical codes of one table each (16
     // lengths), then all lanes fill the 9-bit look-ups
@@ -290,7 +300,7 @@ __global__ __launch_bounds__(64) void jpeg_huffman_kernel(const JpegFileDev* __r
     }
     __syncthreads();
     if (hdr[0] != 0x3157504A) {
-        if (lane == 0) errors[blockIdx.x] = 2;
+        if (lane == 0 && blockIdx.y == 0) errors[blockIdx.x] = 2;
         return;
     }
     const int n_int = hdr[1], restart = hdr[2], mcux = hdr[3], mcuy = hdr[4], ncomp = hdr[5];
@@ -299,13 +309,13 @@ __global__ __launch_bounds__(64) void jpeg_huffman_kernel(const JpegFileDev* __r
     short* coef = reinterpret_cast<short*>(f.coef);
     const long long mcus = (long long)mcux * mcuy;
     bool bad = false;
-    for (int iv = lane; iv < n_int; iv += 64) {
+    for (int iv = (int)blockIdx.y * 64 + lane; iv < n_int; iv += 64 * (int)gridDim.y) {
         BitReader b;
         b.words = reinterpret_cast<const unsigned long long*>(f.bytes);
         b.pos = ioff[iv];
         b.end = iv + 1 < n_int ? ioff[iv + 1] : end_all;      // (the RSTn marker in front of the next interval stops the reader earlier)
         if (b.end > (unsigned)f.n_bytes) b.end = (unsigned)f.n_bytes;
-        b.cidx = 0xffffffffu; b.cache = 0; b.buf = 0; b.n = 0; b.starved = 0;
+        b.cidx = 0xfffffff0u; b.cache = 0; b.ahead = 0; b.buf = 0; b.n = 0; b.starved = 0;
         int pred[3] = {0, 0, 0};
         const long long m0 = (long long)iv * restart;
         const long long m1 = m0 + restart < mcus ? m0 + restart : mcus;
@@ -355,15 +365,19 @@ __global__ __launch_bounds__(64) void jpeg_huffman_kernel(const JpegFileDev* __r
 extern "C" {
 
 // Entropy decoding of n_files JPEG files WITH RESTART MARKERS on the device, one thread per restart interval: files = DEVICE int64
-// [n_files][4] = {address of the file bytes (8-byte aligned, 8 readable bytes behind the end), address of the file's plan
+// [n_files][4] = {address of the file bytes (8-byte aligned, 24 readable bytes behind the end), address of the file's plan
 // (witw_jpeg_entropy_plan, 4-byte aligned), address of its coefficient area int16 [blocks][64] (zero-filled by the caller), file
-// length}; errors = DEVICE int32 [n_files], zeroed by the caller: 1 where the entropy-coded data of a file is damaged (its
+// length}; max_intervals = the largest number of restart intervals of a file of the launch (sizes the grid: one wave per 64
+// intervals of a file); errors = DEVICE int32 [n_files], zeroed by the caller: 1 where the entropy-coded data of a file is damaged (its
 // coefficients are then incomplete: witw_jpeg_decode_coef returns -3 for such a file), 2 for a bad plan. The coefficients are the
 // bits witw_jpeg_decode_coef writes; witw_jpeg_idct / witw_jpeg_to_rgb take it from there (model/cvig_fov.py:88-89).
-int witw_jpeg_huffman(const void* files, int n_files, int* errors, void* stream) {
+int witw_jpeg_huffman(const void* files, int n_files, int max_intervals, int* errors, void* stream) {
     WITW_CHECK_ARG(files && errors, "jpeg_huffman: null pointer");
-    WITW_CHECK_ARG(n_files > 0, "jpeg_huffman: %d files", n_files);
-    hipLaunchKernelGGL(jpeg_huffman_kernel, dim3((unsigned)n_files), dim3(64), 0, (hipStream_t)stream, (const JpegFileDev*)files, errors);
+    WITW_CHECK_ARG(n_files > 0 && max_intervals > 0, "jpeg_huffman: %d files, %d intervals", n_files, max_intervals);
+    int waves = (max_intervals + 63) / 64;      // per file; at most 64 (a file with more than 4096 intervals loops)
+    if (waves > 64) waves = 64;
+    hipLaunchKernelGGL(jpeg_huffman_kernel, dim3((unsigned)n_files, (unsigned)waves), dim3(64), 0, (hipStream_t)stream,
+                       (const JpegFileDev*)files, errors);
     WITW_CHECK_LAUNCH("jpeg_huffman");
     return WITW_OK;
 }

@@ -13,7 +13,7 @@ import torch
 
 
 def _write_pair(args):
-    root, i, seed = args
+    root, i, seed, restart_rows, restart_blocks = args
     from PIL import Image
     g = np.random.Generator(np.random.Philox(key=[seed, i]))
 
@@ -27,12 +27,17 @@ def _write_pair(args):
         # written under a temporary name and renamed into place: a writer killed half way (bench.run_child's timeout) never leaves
         # a truncated file under the name the next block would reuse
         tmp = os.path.join(root, '.%s.%d.tmp' % (name, os.getpid()))
-        Image.fromarray(picture(h, w)).save(tmp, format='JPEG', quality=90)
+        # restart_rows > 0: a restart marker every that many MCU rows (libjpeg's -restart N; 1.3 % larger files at one row) -- such
+        # files are entropy-decoded on the GPU, one thread per restart interval (witw_amd/jpeg.py DEVICE_ENTROPY)
+        # restart_blocks > 0: a marker every that many MCUs (-restart NB): the shorter an interval, the shorter the sequential chain of
+        # the GPU thread that decodes it (8 MCUs: +0.4 % file size)
+        kw = {'restart_marker_blocks': restart_blocks} if restart_blocks else {'restart_marker_rows': restart_rows} if restart_rows else {}
+        Image.fromarray(picture(h, w)).save(tmp, format='JPEG', quality=90, **kw)
         os.replace(tmp, os.path.join(root, name))
     return i
 
 
-def make_dataset(root, n_pairs, n_unique=512, seed=77, procs=8):
+def make_dataset(root, n_pairs, n_unique=512, seed=77, procs=8, restart_rows=0, restart_blocks=0):
     """A synthetic cvusa-format data set (CSV columns: overhead, surface; model/cvig_fov.py:38-44): n_pairs rows over
     min(n_pairs, n_unique) distinct JPEG pairs (overhead 512x512, ground 224x224: the raw sizes of BASELINE.json)."""
     import json
@@ -42,7 +47,8 @@ def make_dataset(root, n_pairs, n_unique=512, seed=77, procs=8):
     # A kept directory (bench.py --e2e-dir, shared by two blocks) is reused only for what its MANIFEST vouches for: the manifest is
     # written LAST, names the generator (seed, sizes, quality) and how many pairs are complete; files of another seed / size, or of a
     # run that died before its manifest, are written again.
-    want = {'generator': 'witw_amd.e2e._write_pair/1', 'seed': int(seed), 'overhead': [512, 512], 'ground': [224, 224], 'quality': 90}
+    want = {'generator': 'witw_amd.e2e._write_pair/2', 'seed': int(seed), 'overhead': [512, 512], 'ground': [224, 224], 'quality': 90,
+            'restart_marker_rows': int(restart_rows), 'restart_marker_blocks': int(restart_blocks)}
     mpath = os.path.join(root, 'manifest.json')
     have = 0
     try:
@@ -51,7 +57,7 @@ def make_dataset(root, n_pairs, n_unique=512, seed=77, procs=8):
             have = int(m.get('pairs_complete', 0))
     except (OSError, ValueError):
         pass
-    todo = [(root, i, seed) for i in range(n_unique)
+    todo = [(root, i, seed, int(restart_rows), int(restart_blocks)) for i in range(n_unique)
             if i >= have or not (os.path.exists(os.path.join(root, 'ov_%05d.jpg' % i)) and os.path.exists(os.path.join(root, 'su_%05d.jpg' % i)))]
     if todo:
         if os.path.exists(mpath):
@@ -132,7 +138,10 @@ def bench(a, device, n_pairs=None, workers=None, keep_dir=None, decode=None, pre
     tmp = tempfile.TemporaryDirectory(prefix='witw_e2e_')
     root = keep_dir or getattr(a, 'e2e_dir', None) or tmp.name
     t0 = time.perf_counter()
-    csv, n_unique, nbytes = make_dataset(root, n_pairs, procs=min(16, cores))
+    restart_rows, restart_blocks = int(getattr(a, 'jpeg_restart_rows', 0) or 0), int(getattr(a, 'jpeg_restart_blocks', 0) or 0)
+    csv, n_unique, nbytes = make_dataset(root, n_pairs, procs=min(16, cores), restart_rows=restart_rows, restart_blocks=restart_blocks)
+    from . import jpeg as jpeg_mod
+    dev_entropy = decode == 'device' and (restart_rows > 0 or restart_blocks > 0) and jpeg_mod.DEVICE_ENTROPY
     t_make = time.perf_counter() - t0
 
     ds = cvig_fov.ImagePairDataset('cvusa', csv, raw='jpeg' if decode == 'device' else True)
@@ -252,17 +261,24 @@ def bench(a, device, n_pairs=None, workers=None, keep_dir=None, decode=None, pre
     assert su_all.shape[0] == n_pairs and ov_all.shape[0] == n_pairs
     del loader
 
-    rates = {'%s (%d DataLoader workers)' % ('entropy-decode_and_pack' if decode == 'device' else 'decode_and_pack', workers): n / t_load,
+    rates = {'%s (%d DataLoader workers)' % ('restart-marker-scan_and_pack (entropy decoding on the GPU)' if dev_entropy else
+                                             'entropy-decode_and_pack' if decode == 'device' else 'decode_and_pack', workers): n / t_load,
              'host_to_device copy (pinned, %.1f MB per batch)' % (blk / 1e6): nb / t_h2d,
              'gpu (%sbatched resize+normalise [+polar, fused], 2 %s encoders; the next batch staged on the copy stream meanwhile, as in the pipeline)'
-             % ('JPEG back end: dequantise + IDCT + upsample + colour, ' if decode == 'device' else '', precision): nb / t_gpu}
+             % (('JPEG on the GPU: Huffman decoding (one thread per restart interval) + dequantise + IDCT + upsample + colour, ' if dev_entropy else
+                 'JPEG back end: dequantise + IDCT + upsample + colour, ') if decode == 'device' else '', precision): nb / t_gpu}
     limiting = min(rates, key=rates.get)
     scaling = decode_scaling(root, n_unique, cores, nb / t_gpu, seconds=getattr(a, 'decode_scaling_seconds', 1.0)) \
-        if decode == 'device' and not getattr(a, 'no_decode_scaling', False) else None
+        if decode == 'device' and not dev_entropy and not getattr(a, 'no_decode_scaling', False) else None
+    entropy_errors = jpeg_mod.entropy_errors() if dev_entropy else None
     out = {'metric': 'image-pairs/sec (disk -> embeddings)', 'value': round(n_pairs / t_e2e, 2), 'unit': 'pairs/s', 'n_gpus': 1,
            'steps': (n_pairs + B - 1) // B, 'warmup': 0, 'ms_per_step': round(t_e2e / ((n_pairs + B - 1) // B) * 1e3, 3),
            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': {'fp32': 'f32'}.get(precision, precision), 'data': 'synthetic',
-           'jpeg_decode': 'device (host: entropy decoding only)' if decode == 'device' else 'host (Pillow)',
+           'jpeg_decode': ('device, entropy decoding included (files with a restart marker per %s: host = marker scan only); damaged files '
+                           'flagged in the last batches: %d' % ('%d MCUs' % restart_blocks if restart_blocks else '%d MCU row(s)' % restart_rows,
+                                                                entropy_errors)) if dev_entropy else
+                          'device (host: entropy decoding only)' if decode == 'device' else 'host (Pillow)',
+           'pcie_bytes_per_pair': int(blk / max(1, nb)),
            'staging': ('PinnedRing: %d slots x %.1f MB of page-locked shared memory, workers build the batch blocks in place' % (ring.slots, ring.slot_bytes / 1e6))
            if ring is not None else 'torch: shared-memory pickling + pin_memory thread',
            'config': {'workload': 'cvig_fov fov=%d, %d JPEG pairs on disk (%d distinct files pairs, overhead 512x512 + ground 224x224, %.1f MB) -> '

@@ -18,7 +18,8 @@ from . import build as _build
 _HOST = None
 KIND_JPEG = 2          # packed-batch kind: coefficient blocks (+ raw uint8 images for the files left to Pillow)
 DESC_COLS = 30         # per image: coefficient byte offset, quantisation-table byte offset, 22 info ints, is_raw, channels,
-#                        entropy decoding on the device (1: column 0 is then the offset of the FILE BYTES), plan byte offset, file length, 0
+#                        entropy decoding on the device (1: column 0 is then the offset of the FILE BYTES), plan byte offset, file length,
+#                        restart intervals
 # Files that carry restart markers are entropy-decoded ON THE DEVICE (csrc/jpeg.hip jpeg_huffman_kernel, one GPU thread per restart
 # interval; round 6): the worker only scans for the markers and the file bytes cross PCIe instead of the coefficient blocks.
 # WITW_JPEG_DEVICE_ENTROPY=0 (or jpeg.DEVICE_ENTROPY = False) keeps every file on the host's Huffman decoder.
@@ -146,10 +147,12 @@ def pack(images, shared=False, alloc=None):
             if pl is not None:
                 plans[i] = pl
         if i in plans:
-            # entropy decoding on the device: the FILE BYTES travel (8 readable bytes behind the end for the kernel's 8-byte loads)
-            nbytes = int(a.data.size) + 8
+            # entropy decoding on the device: the FILE BYTES travel (24 readable bytes behind the end: the kernel reads aligned 8-byte
+            # words one ahead of the one it decodes)
+            nbytes = int(a.data.size) + 24
             desc[i, 2:24] = a.info
             desc[i, 26], desc[i, 28] = 1, int(a.data.size)
+            desc[i, 29] = int(plans[i][0][4:8].view(np.int32)[0])      # restart intervals of the file (grid sizing of the device decoder)
         elif isinstance(a, JpegCoef):
             nbytes = int(a.info[5]) * 128
             desc[i, 2:24] = a.info
@@ -301,7 +304,8 @@ def decode_packed(dbuf, desc):
         files = np.stack([dbuf.data_ptr() + d[dv, 0], dbuf.data_ptr() + d[dv, 27], coef.data_ptr() + first * 128, d[dv, 28]], axis=1).astype(np.int64)
         files_t = torch.from_numpy(files).pin_memory().to(dev, non_blocking=True)
         errors = torch.zeros((int(dv.size),), dtype=torch.int32, device=dev)
-        _lib.check(_lib.load().witw_jpeg_huffman(files_t.data_ptr(), int(dv.size), errors.data_ptr(), ops._stream()), 'witw_jpeg_huffman')
+        _lib.check(_lib.load().witw_jpeg_huffman(files_t.data_ptr(), int(dv.size), int(d[dv, 29].max()), errors.data_ptr(), ops._stream()),
+                   'witw_jpeg_huffman')
         dd = d[dv].copy()
         dd[:, 0] = first * 128                                   # where each file's coefficient blocks sit in `coef`
         k, addr, ncomp = _decode_group(dbuf, dd, coef.data_ptr(), dbuf.data_ptr())
