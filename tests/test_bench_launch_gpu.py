@@ -76,6 +76,18 @@ def test_bench_two_ranks_self_launched_infer():
         # (over gloo on a loaded host a 128 KB all-gather can take tens of ms: the rounded figures may be tiny, never negative)
         assert m['us'] > 0 and m['algbw_GBps'] >= 0 and 0 <= m['frac_of_direct_bound'] < 1.0 and m['xgmi_ring_bound_us'] >= m['xgmi_direct_bound_us']
     assert 'microbench' not in one['collectives']
+    # ... and BASELINE configs[2] as what it is, a DDP TRAINING config (round 6): behind the inference headline the N > 1 line runs the
+    # training step in the same process group -- all-gather, reduce-scatter and the two bucket all-reduces inside a real step
+    ts = two['train_step']
+    assert ts['value'] > 0 and ts['ms_per_step'] > 0 and ts['steps'] == 1 and np.isfinite(ts['loss']) and 'configs[2]' in ts['baseline_config']
+    for name in ('encoders_forward', 'overhead_all_gather', 'slab_match', 'backward_incl_its_collectives', 'overhead_grad_reduce_scatter',
+                 'grad_bucket0_all_reduce_issue_to_joined', 'grad_bucket1_all_reduce_issue_to_joined', 'reducer_wait_stall', 'adam'):
+        assert ts['per_phase_ms_max_over_ranks'][name] > 0, (name, ts)
+    assert abs(ts['overlap_hidden_ms'] - (ts['bucket_inflight_ms'] - ts['reducer_wait_stall_ms'])) < 1e-3
+    assert abs(mb['overlap_hidden_ms'] - ts['overlap_hidden_ms']) < 1e-3          # the microbench block quotes the TRAINING step's overlap
+    td = two['_detail']['train_step_detail']
+    assert len(td['per_phase_ms']['every_rank']) == 2 and 'training step' in td['metric']
+    assert 'train_step' not in one
     # ... and which register-allocation guards were active (none may have tripped on the validated toolchain)
     for line in (one, two):
         g = line['guards']
@@ -190,3 +202,17 @@ def test_bench_collectives_block_through_rccl_in_a_world_of_one():
     for name in ('all_gather_overhead_embeddings', 'all_reduce_weight_grads_one_encoder'):
         assert mb[name]['us'] > 0 and mb[name]['bytes'] > 0
     assert one['n_gpus'] == 1 and one['recall']['N'] == 8 and np.isfinite(one['loss'])
+    # the training step of the N > 1 line ran through RCCL too (one rank: every collective is the identity)
+    ts = one['train_step']
+    assert ts['value'] > 0 and ts['per_phase_ms_max_over_ranks']['adam'] > 0 and 'overlap_hidden_ms' in ts
+
+
+def test_bench_two_ranks_with_the_cpu_baseline_behind_the_group():
+    """N > 1 with the cpu_baseline on: rank 0 times the CPU port AFTER every rank has left the process group (no rank sits in a
+    collective meanwhile); the line carries the three legs of BASELINE.md section 4."""
+    two = _run_bench('--gpus', '2', '--backend', 'gloo', '--single-device', '--steps', '1', '--warmup', '1', '--batch', '4',
+                     '--cpu-pairs', '2', '--no-microbench')
+    c = two['cpu_baseline']
+    assert c['kind'] == 'port' and c['passes'] == 3 and len(c['pass_pairs_per_s']) == 3 and c['value'] > 0
+    assert c['train_pairs_per_s'] > 0 and c['rank_ms_per_query'] > 0
+    assert two['n_gpus'] == 2 and two['collectives']['ranks_seen'] == 2 and two['train_step']['value'] > 0

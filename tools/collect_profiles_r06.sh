@@ -1,0 +1,113 @@
+#!/bin/bash
+# Round-6 judged artefacts under profiles/ (run through gpurun from the repo root, one part per call: a call is limited to 20
+# minutes): plain bench lines, rocprofv3 --kernel-trace --stats summaries of the same commands, PMC passes (FETCH_SIZE /
+# WRITE_SIZE / matrix-pipe busy / LDS conflicts; each in its own run, no trace domain besides --kernel-trace).
+# Only summaries come back; tools/install_profiles_r06.sh copies them to profiles/.
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+cd /tmp && export TMPDIR=/tmp
+cd "$R"
+O=gpurun_out/final6
+mkdir -p $O
+( while true; do date >> $O/heartbeat.txt; sleep 60; done ) &
+HB=$!
+trap "kill $HB 2>/dev/null" EXIT
+PART=${1:-bench}
+if [ $PART = bench ]; then
+S=$(date +%s)
+python3 bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
+echo "default run: $(( $(date +%s) - S )) s wall, line $(wc -c < $O/bench.json) bytes" | tee $O/bench_default_run.txt
+grep "^\[bench" $O/bench.err >> $O/bench_default_run.txt
+cp bench_detail.json $O/bench_detail.json
+python3 bench.py --mode train --detail-out $O/bench_train_detail.json > $O/bench_train.json 2> $O/bench_train.err
+python3 bench.py --precision bf16 --detail-out $O/d.json > $O/bench_bf16.json 2> $O/bench_bf16.err
+python3 bench.py --model semantic --precision bf16 --detail-out $O/d.json > $O/bench_semantic_bf16.json 2> $O/bench_semantic_bf16.err
+python3 bench.py --mode train --precision bf16 --detail-out $O/d.json > $O/bench_bf16_train.json 2> $O/bench_bf16_train.err
+python3 bench.py --model semantic --mode train --precision bf16 --detail-out $O/d.json > $O/bench_semantic_bf16_train.json 2> $O/bench_semantic_bf16_train.err
+python3 bench.py --mode retrieval --match dft --steps 2 --warmup 1 --detail-out $O/d.json > $O/bench_retrieval_dft.json 2> $O/bench_retrieval_dft.err
+python3 bench.py --mode retrieval --steps 1 --warmup 1 --detail-out $O/d.json > $O/bench_retrieval.json 2> $O/bench_retrieval.err
+python3 bench.py --mode e2e --detail-out $O/bench_e2e_detail.json > $O/bench_e2e.json 2> $O/bench_e2e.err
+python3 bench.py --mode e2e --precision bf16 --workers 16 --e2e-pairs 8192 --detail-out $O/bench_e2e_bf16_detail.json > $O/bench_e2e_bf16.json 2> $O/bench_e2e_bf16.err
+python3 bench.py --mode baseline --detail-out $O/bench_baseline_detail.json > $O/bench_baseline.json 2> $O/bench_baseline.err
+python3 bench.py --mode sweep --detail-out $O/bench_sweep_detail.json > $O/bench_sweep.json 2> $O/bench_sweep.err
+python3 tools/bench_layers.py --bf16 --iters 10 > $O/bf16_layers.txt 2>&1
+python3 tools/bench_layers.py --iters 5 > $O/f32_layers.txt 2>&1
+python3 tools/bench_wgrad_bf16.py 2>&1 | grep -v amdgpu.ids > $O/wgrad_bf16_layers.txt
+python3 tools/bench_hbm.py > $O/hbm_kernels.txt 2>&1
+python3 tools/debug/hbm_calib.py >> $O/hbm_kernels.txt 2>&1
+tools/bin/hbm_yardstick 2048 > $O/hbm_yardstick.txt 2>&1
+for a in "1 0" "0 8" "0 4" "0 2"; do python3 tools/debug/jpeg_huff_bench.py $a 2>&1 | grep -v amdgpu.ids >> $O/jpeg_huffman_intervals.txt; done
+python3 bench.py --mode e2e --precision bf16 --workers 4 --e2e-pairs 8192 --jpeg-restart-blocks 2 --detail-out $O/bench_e2e_bf16_device_entropy_detail.json > $O/bench_e2e_bf16_device_entropy.json 2> $O/bench_e2e_bf16_device_entropy.err
+python3 tools/bench_f2_wres.py > $O/weight_resident_kernels.txt 2>&1
+rm -f $O/d.json
+echo benches done
+fi
+if [ $PART = stats ]; then
+P="rocprofv3 --kernel-trace --stats -o p --output-format csv"
+$P -d $O/prof -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-side-blocks --detail-out $O/d.json > $O/bench_under_rocprof.json 2> $O/prof.log
+$P -d $O/prof_all -- python3 bench.py --mode sides --steps 5 --no-cpu-baseline > /dev/null 2> $O/prof_all.log
+$P -d $O/prof_train -- python3 bench.py --mode train --steps 5 --warmup 2 --detail-out $O/d.json > $O/train_under_rocprof.json 2> $O/prof_train.log
+$P -d $O/prof_bf16_train -- python3 bench.py --mode train --precision bf16 --steps 5 --warmup 2 --detail-out $O/d.json > $O/bf16_train_under_rocprof.json 2> $O/prof_bf16_train.log
+$P -d $O/prof_sem_bf16_train -- python3 bench.py --model semantic --mode train --precision bf16 --steps 5 --warmup 2 --detail-out $O/d.json > $O/sem_bf16_train_under_rocprof.json 2> $O/prof_sem_bf16_train.log
+$P -d $O/prof_sem_bf16 -- python3 bench.py --model semantic --precision bf16 --steps 5 --warmup 2 --detail-out $O/d.json > $O/semantic_bf16_under_rocprof.json 2> $O/prof_sem_bf16.log
+$P -d $O/prof_baseline -- python3 bench.py --mode baseline --no-cpu-baseline --detail-out $O/d.json > $O/baseline_under_rocprof.json 2> $O/prof_baseline.log
+$P -d $O/prof_retr_dft -- python3 bench.py --mode retrieval --match dft --steps 2 --warmup 1 --detail-out $O/d.json > $O/retrieval_dft_under_rocprof.json 2> $O/prof_retr_dft.log
+# the e2e data path under rocprofv3 (16 forked loader workers + a spawn pool with the profiler's preload) hung once for the whole call
+# limit on 2026-10-04 after two clean runs the same day: run it on its own, under a timeout, when that table is wanted:
+#   timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/prof_e2e_bf16 -o p --output-format csv -- python3 bench.py --mode e2e --precision bf16 --workers 16 --e2e-pairs 4096 --no-decode-scaling
+rm -f $O/d.json
+echo stats done
+fi
+if [ $PART = dft ]; then      # the spectral match only (its kernel changed after the other parts were taken)
+python3 bench.py --mode retrieval --match dft --steps 2 --warmup 1 --detail-out $O/d.json > $O/bench_retrieval_dft.json 2> $O/bench_retrieval_dft.err
+rocprofv3 --kernel-trace --stats -o p --output-format csv -d $O/prof_retr_dft -- python3 bench.py --mode retrieval --match dft --steps 2 --warmup 1 --detail-out $O/d.json > $O/retrieval_dft_under_rocprof.json 2> $O/prof_retr_dft.log
+fi
+if [ $PART = pmc ] || [ $PART = dft ]; then
+if [ $PART = pmc ]; then
+for m in "infer:" "bf16:--precision bf16" "sem_bf16:--model semantic --precision bf16" "train:--mode train" "bf16_train:--mode train --precision bf16"; do
+  tag=${m%%:*}; flags=${m#*:}
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch_$tag -o p --output-format csv -- python3 bench.py $flags --steps 2 --warmup 1 --no-cpu-baseline --no-side-blocks --detail-out $O/d.json > $O/pmc_fetch_$tag.json 2> $O/pmc_fetch_$tag.log
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write_$tag -o p --output-format csv -- python3 bench.py $flags --steps 2 --warmup 1 --no-cpu-baseline --no-side-blocks --detail-out $O/d.json > $O/pmc_write_$tag.json 2> $O/pmc_write_$tag.log
+  rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/pmc_mfma_$tag -o p --output-format csv -- python3 bench.py $flags --steps 2 --warmup 1 --no-cpu-baseline --no-side-blocks --detail-out $O/d.json > $O/pmc_mfma_$tag.json 2> $O/pmc_mfma_$tag.log
+  echo pmc $tag done
+done
+# the bf16 training step's LDS side (the NHWC weight-gradient kernel's transposed reads)
+rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAVE_CYCLES -d $O/pmc_lds_bf16_train -o p --output-format csv -- python3 bench.py --mode train --precision bf16 --steps 2 --warmup 1 --detail-out $O/d.json > /dev/null 2> $O/pmc_lds_bf16_train.log
+python3 tools/pmc_summary.py $O/pmc_lds_bf16_train/p_counter_collection.csv > $O/bf16_train_lds_pmc.txt 2>&1
+python3 tools/make_traffic.py 128 infer:$O/pmc_fetch_infer/p_counter_collection.csv:$O/pmc_write_infer/p_counter_collection.csv \
+  train:$O/pmc_fetch_train/p_counter_collection.csv:$O/pmc_write_train/p_counter_collection.csv \
+  bf16:$O/pmc_fetch_bf16/p_counter_collection.csv:$O/pmc_write_bf16/p_counter_collection.csv \
+  sem_bf16:$O/pmc_fetch_sem_bf16/p_counter_collection.csv:$O/pmc_write_sem_bf16/p_counter_collection.csv \
+  bf16_train:$O/pmc_fetch_bf16_train/p_counter_collection.csv:$O/pmc_write_bf16_train/p_counter_collection.csv > $O/traffic.json
+python3 tools/make_mfma_util.py infer:$O/pmc_mfma_infer/p_counter_collection.csv train:$O/pmc_mfma_train/p_counter_collection.csv \
+  bf16:$O/pmc_mfma_bf16/p_counter_collection.csv sem_bf16:$O/pmc_mfma_sem_bf16/p_counter_collection.csv \
+  bf16_train:$O/pmc_mfma_bf16_train/p_counter_collection.csv > $O/mfma_util.json
+bash tools/debug/pmc_pp.sh > $O/weight_resident_pmc.txt 2>&1
+bash tools/debug/pmc_polar.sh > $O/polar_from_raw_pmc.txt 2>&1
+fi
+rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES -d $O/pmc_dft_lds -o p --output-format csv -- python3 tools/pmc_match_dft.py > /dev/null 2> $O/pmc_dft_lds.log
+rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES -d $O/pmc_dft_clk -o p --output-format csv -- python3 tools/pmc_match_dft.py > /dev/null 2> $O/pmc_dft_clk.log
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_dft_fetch -o p --output-format csv -- python3 tools/pmc_match_dft.py > /dev/null 2> $O/pmc_dft_fetch.log
+python3 - > $O/match_dft_pmc.json <<PY
+import csv, json, collections
+out = {'_note': 'rocprofv3 --kernel-trace --pmc <counters> (separate passes) over tools/pmc_match_dft.py: match_dft_kernel at 16384 x 4096, averages over its 2 dispatches'}
+for d in ('pmc_dft_lds', 'pmc_dft_clk', 'pmc_dft_fetch'):
+    acc, dur = collections.defaultdict(list), []
+    for r in csv.DictReader(open('$O/%s/p_counter_collection.csv' % d)):
+        if 'match_dft_kernel' in r['Kernel_Name']:
+            acc[r['Counter_Name']].append(float(r['Counter_Value']))
+            dur.append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
+    for k, v in acc.items():
+        out[k] = sum(v) / len(v)
+    out['avg_us_' + d] = sum(dur) / max(1, len(dur)) / 1e3 / max(1, len(acc))
+if 'SQ_LDS_IDX_ACTIVE' in out:
+    out['lds_bank_conflict_share'] = out['SQ_LDS_BANK_CONFLICT'] / out['SQ_LDS_IDX_ACTIVE']
+if 'GRBM_GUI_ACTIVE' in out and 'SQ_VALU_MFMA_BUSY_CYCLES' in out:
+    out['mfma_util'] = out['SQ_VALU_MFMA_BUSY_CYCLES'] / (out['GRBM_GUI_ACTIVE'] / 8 * 1024)
+print(json.dumps(out, indent=1))
+PY
+rm -f $O/d.json
+echo pmc done
+fi
+rm -f $O/pmc_*/p_counter_collection.csv $O/pmc_*/p_kernel_trace.csv $O/prof*/p_kernel_trace.csv
+ls $O | head -100

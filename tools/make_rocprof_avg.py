@@ -23,8 +23,12 @@ def main():
     csrc = os.path.join(ROOT, 'witw_amd', 'csrc')
     out = {'_note': 'rocprofv3 --kernel-trace --stats over `bench.py [mode flags] --steps 5 --warmup 2 --no-cpu-baseline --no-side-blocks`: '
                     'AverageNs per kernel instantiation; bench.py quotes a figure only while the kernel sources hash as below',
+           # the sources of the convolution kernels (the dominant kernels of every StepBench mode): a change to the matching / JPEG /
+           # preprocessing sources does not touch them
            '_kernel_sources_sha16': {f: hashlib.sha256(open(os.path.join(csrc, f), 'rb').read()).hexdigest()[:16]
-                                     for f in sorted(os.listdir(csrc)) if f.endswith(('.hip', '.h'))}}
+                                     for f in ('common.h', 'lds_frag.h', 'conv3x3.hip', 'conv3x3_bf16.hip', 'conv3x3_bf16_wres.hip',
+                                               'conv3x3_f16x3.hip', 'conv3x3_wgrad.hip', 'conv_first.hip', 'conv_first2_bf16.hip',
+                                               'wgrad_bf16.hip', 'wgrad_f16x3.hip')}}
     for spec in sys.argv[1:]:
         parts = spec.split(':')
         tag, path = parts[0], parts[1]
