@@ -624,7 +624,11 @@ def side_blocks(a, rank, world, device, cvig_fov, ops):
                 json.dump(out, f)
             os.replace(tmp, a.detail_out)
 
+    only = [n for n in os.environ.get('WITW_SIDES_ONLY', '').split(',') if n]      # diagnostic: run only these side blocks
+
     def guarded(name, fn):
+        if only and name not in only:
+            return
         try:
             done(name, fn())
         except Exception as e:       # a failed block is reported as such; the others still run

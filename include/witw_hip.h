@@ -467,6 +467,14 @@ int witw_jpeg_to_rgb(const void* planes, const void* images, int n_images, long 
  * caller, 1 where a file's entropy-coded data is damaged, 2 for a bad plan. Coefficients bit-identical to the host decoder's
  * (witw_jpeg_decode_coef); witw_jpeg_idct / witw_jpeg_to_rgb take it from there. */
 int witw_jpeg_huffman(const void* files, int n_files, int max_intervals, int* errors, void* stream);
+/* The same for files WITHOUT restart markers (their plan holds ONE interval: the whole scan): a self-synchronising decode, one
+ * workgroup of 1024 threads per file -- the scan is unstuffed and cut into 1024 subsequences, every thread decodes its own from a
+ * guessed state, then from its neighbour's exit state, round after round until no entry state changes (Huffman codes fall into step
+ * after a few dozen symbols; thread 0 starts at the true state, so the fixed point is the true decoding); a prefix sum numbers the
+ * blocks, a last pass writes the coefficients and a per-component prefix sum turns DC differences into DC values. files: DEVICE int64
+ * [n_files][6] = {file bytes, plan, coefficient area (zero-filled), file length, scratch of file length + 32 bytes (8-byte aligned),
+ * 0}. Coefficients bit-identical to the host decoder's. */
+int witw_jpeg_huffman_selfsync(const void* files, int n_files, int* errors, void* stream);
 
 #ifdef __cplusplus
 }

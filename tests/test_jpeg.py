@@ -193,10 +193,12 @@ def test_rgb_colourspace_files_are_left_to_the_host_decoder():
     assert jpeg.open_file(bytes(b)) is None
 
 
-def test_pack_hands_damaged_entropy_data_to_pillow_as_the_reference_would_read_it():
+def test_pack_hands_damaged_entropy_data_to_pillow_as_the_reference_would_read_it(monkeypatch):
     """open_file() sees only the header; a file whose entropy data turns out bad inside pack() is decoded by Pillow (libjpeg
-    reads truncated files with a warning -- so does the reference's imread) and travels as a raw image of the same batch"""
+    reads truncated files with a warning -- so does the reference's imread) and travels as a raw image of the same batch
+    (the host-entropy path; with the device decoder the flags come back from the GPU: tests/test_jpeg_gpu.py)"""
     from PIL import Image, ImageFile
+    monkeypatch.setattr(jpeg, 'DEVICE_ENTROPY', False)
     good = open(os.path.join(HERE, 's420_q90.jpg'), 'rb').read()
     cut = good[:len(good) * 2 // 3]
     f_good, f_cut = jpeg.open_file(good), jpeg.open_file(cut)
@@ -401,27 +403,35 @@ def test_entropy_plan_describes_the_restart_intervals():
         for i in range(1, n_int):        # every interval but the first starts right behind its RSTn marker, numbered in sequence
             assert data[off[i] - 2] == 0xFF and data[off[i] - 1] == 0xD0 + ((i - 1) & 7)
         np.testing.assert_array_equal(_decode_from_plan(data, plan, int(f.info[5])), ref.coef)
-    # no restart markers -> no plan (the host's Huffman decoder keeps the file); markers out of sequence -> no plan either
-    assert jpeg.open_file(os.path.join(HERE, 's420_q90.jpg')).entropy_plan() is None
+    # no restart markers -> a plan of ONE interval (the self-synchronising kernel's input); markers out of sequence -> no plan
+    raw = open(os.path.join(HERE, 's420_q90.jpg'), 'rb').read()
+    f = jpeg.open_file(raw)
+    plan, _qt = f.entropy_plan()
+    hdr = np.frombuffer(plan[:128].tobytes(), dtype=np.int32)
+    assert hdr[1] == 1 and hdr[2] == hdr[3] * hdr[4] and plan.size == 740
+    np.testing.assert_array_equal(_decode_from_plan(np.frombuffer(raw, dtype=np.uint8), plan, int(f.info[5])), jpeg.read_coef(raw).coef)
     bad = bytearray(files[0])
     p = bad.find(b'\xff\xd1')
     bad[p + 1] = 0xD5
     assert jpeg.open_file(bytes(bad)).entropy_plan() is None
 
 
-def test_pack_ships_file_bytes_for_restart_marker_files(monkeypatch):
+def test_pack_ships_file_bytes_for_device_entropy_decoding(monkeypatch):
     raw = open(os.path.join(HERE, 's420_rst.jpg'), 'rb').read()
     plain = open(os.path.join(HERE, 's420_q90.jpg'), 'rb').read()
     items = [jpeg.open_file(raw), jpeg.open_file(plain), jpeg.open_file(raw)]
     buf, desc, kind = jpeg.pack(items)
     d = desc.numpy()
-    assert kind == jpeg.KIND_JPEG and list(d[:, 26]) == [1, 0, 1] and list(d[:, 28]) == [len(raw), 0, len(raw)]
+    assert kind == jpeg.KIND_JPEG and list(d[:, 26]) == [1, 1, 1] and list(d[:, 28]) == [len(raw), len(plain), len(raw)]
+    assert list(d[:, 29]) == [int(np.frombuffer(buf.numpy()[d[0, 27] + 4:d[0, 27] + 8].tobytes(), dtype=np.int32)[0]), 1, d[0, 29]] and d[0, 29] > 1
     b = buf.numpy()
     for i in (0, 2):
         assert d[i, 0] % 128 == 0 and d[i, 27] % 16 == 0 and bytes(b[d[i, 0]:d[i, 0] + len(raw)]) == raw
         assert b[d[i, 27]:d[i, 27] + 4].view(np.int32)[0] == 0x3157504A
-    # the host-decoded entry is laid out as before
-    np.testing.assert_array_equal(b[d[1, 0]:d[1, 0] + int(d[1, 7]) * 128].view(np.int16).reshape(-1, 64), jpeg.read_coef(plain).coef)
+    assert bytes(b[d[1, 0]:d[1, 0] + len(plain)]) == plain
+    # with the device decoder off every file is Huffman-decoded here, laid out as before
     monkeypatch.setattr(jpeg, 'DEVICE_ENTROPY', False)
-    _b, desc2, _k = jpeg.pack([jpeg.open_file(raw)])
-    assert int(desc2[0, 26]) == 0
+    b2, desc2, _k = jpeg.pack([jpeg.open_file(raw), jpeg.open_file(plain)])
+    d2 = desc2.numpy()
+    assert list(d2[:, 26]) == [0, 0]
+    np.testing.assert_array_equal(b2.numpy()[d2[1, 0]:d2[1, 0] + int(d2[1, 7]) * 128].view(np.int16).reshape(-1, 64), jpeg.read_coef(plain).coef)

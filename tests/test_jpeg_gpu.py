@@ -185,9 +185,10 @@ def test_device_entropy_decode_equals_the_host_coefficients():
 
 
 def test_device_entropy_path_gives_pillows_bytes_in_mixed_batches():
-    """pack() ships the FILE BYTES of restart-marker files (descriptor column 26) and decode_packed entropy-decodes them on the
-    device in front of the usual back end; files without markers (host Huffman), a progressive file (Pillow's bytes) and a raw array
-    ride in the same batch: every image equals Pillow's decode byte for byte, and nothing was flagged."""
+    """pack() ships the FILE BYTES (descriptor column 26) and decode_packed entropy-decodes them on the device in front of the usual
+    back end -- restart-marker files on the interval kernel, marker-less ones on the self-synchronising kernel (the small one on a
+    single thread of the interval kernel); a progressive file (Pillow's bytes) and a raw array ride in the same batch: every image
+    equals Pillow's decode byte for byte, and nothing was flagged."""
     from PIL import Image
     g = np.random.Generator(np.random.Philox(key=[13, 2]))
     raws = [_fresh(g, 512, 512, 2, 90, restart_marker_rows=1), _fresh(g, 224, 224, 2, 90), _fresh(g, 224, 224, 2, 90, restart_marker_rows=1),
@@ -202,7 +203,8 @@ def test_device_entropy_path_gives_pillows_bytes_in_mixed_batches():
     items.insert(2, g.integers(0, 256, size=(7, 9, 3), dtype=np.uint8))
     refs.insert(2, items[2])
     buf, desc, _k = jpeg.pack(items)
-    assert list(desc[:, 26].numpy()) == [1, 0, 0, 1, 0, 1, 1, 0] and int(desc[4, 24]) == 1
+    assert list(desc[:, 26].numpy()) == [1, 1, 0, 1, 0, 1, 1, 1] and int(desc[4, 24]) == 1
+    assert list(desc[:, 29].numpy())[1] == 1 and list(desc[:, 29].numpy())[0] > 1      # no markers: one interval (self-synchronising kernel)
     out = jpeg.decode(items, torch.device('cuda:0'))
     for k, (o, r) in enumerate(zip(out, refs)):
         np.testing.assert_array_equal(o.cpu().numpy(), r if r.ndim == 3 else r[:, :, None], err_msg=str(k))
@@ -235,3 +237,75 @@ def test_data_path_with_restart_marker_files_equals_host_decode(tmp_path):
     loader = torch.utils.data.DataLoader(ds, batch_size=3, shuffle=False, num_workers=2, collate_fn=cvig_fov.collate_packed, pin_memory=True)
     outs = [prep(st) for st in cvig_fov.DevicePrefetcher(loader, prep)]
     assert torch.equal(torch.cat([d['polar'] for d in outs]), ref['polar']) and jpeg.entropy_errors() == 0
+
+
+def test_selfsync_decode_equals_the_host_coefficients():
+    """round 6, step two: files WITHOUT restart markers on jpeg_selfsync_kernel (one workgroup per file: unstuff, synchronise the 1024
+    subsequences round by round, number the blocks, write, DC prefix sums): coefficient blocks bit for bit those of
+    witw_jpeg_decode_coef -- every fixture this decoder takes, fresh files of BASELINE's raw sizes, all samplings, optimised tables,
+    very low and very high quality (long runs of EOB-only blocks / long codes), grey, sizes that are not multiples of the MCU."""
+    from witw_amd import _lib, ops
+    dev = torch.device('cuda:0')
+    g = np.random.Generator(np.random.Philox(key=[14, 1]))
+    files = [open(os.path.join(HERE, n), 'rb').read() for n in sorted(os.listdir(HERE)) if n.endswith('.jpg') and 'rst' not in n and 'prog' not in n]
+    for (h, w, sub, q, kw) in ((512, 512, 2, 90, {}), (224, 224, 2, 90, {}), (750, 333, 1, 70, {'optimize': True}), (640, 640, 0, 99, {}),
+                               (300, 300, 2, 3, {}), (1024, 768, 2, 85, {}), (97, 131, 1, 60, {'optimize': True}), (33, 999, 0, 50, {})):
+        files.append(_fresh(g, h, w, sub, q, **kw))
+    from PIL import Image
+    bio = io.BytesIO()
+    Image.fromarray(g.integers(0, 256, size=(200, 120), dtype=np.uint8)).save(bio, 'JPEG', quality=80)      # grey: one component
+    files.append(bio.getvalue())
+    items = [jpeg.open_file(f) for f in files]
+    plans = [it.entropy_plan() for it in items]
+    assert all(p is not None and int(np.frombuffer(p[0][4:8].tobytes(), dtype=np.int32)[0]) == 1 for p in plans)
+    blocks = np.array([int(it.info[5]) for it in items], dtype=np.int64)
+    first = np.cumsum(blocks) - blocks
+    coef = torch.zeros((int(blocks.sum()), 64), dtype=torch.int16, device=dev)
+    keep, rows = [], []
+    for it, (plan, _qt), f0 in zip(items, plans, first):
+        raw = np.zeros((it.data.size + 24 + 7) // 8 * 8, dtype=np.uint8)
+        raw[:it.data.size] = it.data
+        rb, pb = torch.from_numpy(raw).to(dev), torch.from_numpy(np.concatenate([plan, np.zeros(16, np.uint8)])).to(dev)
+        sc = torch.empty(((it.data.size + 32 + 7) // 8 * 8,), dtype=torch.uint8, device=dev)
+        keep += [rb, pb, sc]
+        rows.append((rb.data_ptr(), pb.data_ptr(), coef.data_ptr() + int(f0) * 128, it.data.size, sc.data_ptr(), 0))
+    files_t = torch.tensor(rows, dtype=torch.int64, device=dev)
+    errors = torch.zeros((len(items),), dtype=torch.int32, device=dev)
+    _lib.check(_lib.load().witw_jpeg_huffman_selfsync(files_t.data_ptr(), len(items), errors.data_ptr(), ops._stream()), 'witw_jpeg_huffman_selfsync')
+    torch.cuda.synchronize()
+    assert int(errors.abs().sum()) == 0, errors
+    got = coef.cpu().numpy()
+    for k, (raw, f0, nb) in enumerate(zip(files, first, blocks)):
+        ref = jpeg.read_coef(raw).coef
+        bad = np.nonzero((got[f0:f0 + nb] != ref).any(axis=1))[0]
+        assert bad.size == 0, 'file %d (%d bytes): %d of %d blocks differ, first %s' % (k, len(raw), bad.size, nb, bad[:5])
+
+
+def test_device_flags_damaged_files_and_the_data_path_hands_them_to_pillow(tmp_path):
+    """a truncated file: the device decoder flags it (its block count does not come out), the staging step looks at the flags and lets
+    Pillow decode the flagged file from the bytes still in the host block -- the image the host path (and the reference's imread with
+    libjpeg's tolerance) produces; the other files of the batch are untouched"""
+    from PIL import Image, ImageFile
+    from witw_amd import cvig_fov
+    g = np.random.Generator(np.random.Philox(key=[14, 2]))
+    good = [_fresh(g, 224, 224, 2, 90), _fresh(g, 224, 224, 2, 90, restart_marker_rows=1), _fresh(g, 224, 224, 2, 90)]
+    cut = good[2][:len(good[2]) * 2 // 3]
+    old = ImageFile.LOAD_TRUNCATED_IMAGES
+    ImageFile.LOAD_TRUNCATED_IMAGES = True
+    try:
+        refs = [np.asarray(Image.open(io.BytesIO(b))) for b in (good[0], good[1], cut)]
+        items = [jpeg.open_file(good[0]), jpeg.open_file(good[1]), jpeg.open_file(cut)]
+        buf, desc, _k = jpeg.pack(items)
+        assert list(desc[:, 26].numpy()) == [1, 1, 1]
+        before = jpeg.REPAIRED[0]
+        dbuf = buf.to('cuda:0')
+        keep, table = jpeg.decode_packed(dbuf, desc, host_buf=buf)
+        torch.cuda.synchronize()
+    finally:
+        ImageFile.LOAD_TRUNCATED_IMAGES = old
+    assert jpeg.REPAIRED[0] == before + 1
+    for i, r in enumerate(refs):
+        H, W, C = int(table[i, 1]), int(table[i, 2]), int(table[i, 4])
+        src = next(t for t in keep if t.dtype == torch.uint8 and t.data_ptr() <= int(table[i, 0]) < t.data_ptr() + max(1, t.numel()))
+        o = int(table[i, 0]) - src.data_ptr()
+        np.testing.assert_array_equal(src.reshape(-1)[o:o + H * W * C].reshape(H, W, C).cpu().numpy(), r, err_msg=str(i))

@@ -9,6 +9,7 @@
 // the byte layout PIL hands the reference (and witw_resize_bilinear_normalize_batched kind 1 / witw_polar_from_raw read).
 // Byte-identical to Pillow's decode: tests/test_jpeg*.py (fixtures under tests/golden/jpeg/ + files written at test time).
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -183,7 +184,9 @@ __constant__ unsigned char kZigZag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24
                                           41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
                                           30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
-struct BitReader {                 // over the STUFFED bytes of one restart interval: FF 00 -> FF on the fly, any other FF xx ends the data
+template <bool STUFFED>
+struct BitReaderT {                // STUFFED: over the file's bytes of one restart interval: FF 00 -> FF on the fly, any other FF xx ends the
+                                   // data; !STUFFED: over an unstuffed copy (jpeg_selfsync_kernel), positions are plain bit indices
     const unsigned long long* words;
     unsigned pos, end;             // byte offsets in the file
     unsigned long long cache;      // the aligned 8 bytes that hold byte `pos`
@@ -208,7 +211,7 @@ struct BitReader {                 // over the STUFFED bytes of one restart inte
             unsigned b = 0;
             if (pos < end) {
                 b = raw(pos);
-                if (b == 0xffu) {
+                if (STUFFED && b == 0xffu) {
                     const unsigned b2 = pos + 1 < end ? raw(pos + 1) : 0xd9u;
                     if (b2 == 0u) pos += 2;                    // a stuffed FF
                     else { end = pos; b = 0; ++starved; }      // a marker (the next interval's RSTn, or EOI): the data ends here
@@ -228,9 +231,18 @@ struct BitReader {                 // over the STUFFED bytes of one restart inte
         n -= k;
         return v;
     }
+    __device__ __forceinline__ void start(const void* base, unsigned byte_pos, unsigned byte_end) {
+        words = reinterpret_cast<const unsigned long long*>(base);
+        pos = byte_pos; end = byte_end;
+        cidx = 0xfffffff0u; cache = 0; ahead = 0; buf = 0; n = 0; starved = 0;
+    }
+    // !STUFFED: index of the next unread bit (zero bytes fed behind the end of the data count as read: the position keeps advancing)
+    __device__ __forceinline__ unsigned bit_pos() const { return (pos + (unsigned)starved) * 8u - (unsigned)n; }
 };
+typedef BitReaderT<true> BitReader;
 
-__device__ __forceinline__ int huff_decode(BitReader& b, const HuffLds& h) {      // caller has >= 32 valid bits; -1: invalid code
+template <typename BR>
+__device__ __forceinline__ int huff_decode(BR& b, const HuffLds& h) {      // caller has >= 32 valid bits; -1: invalid code
     const unsigned e = h.look[(unsigned)(b.buf >> 55)];
     if (e) {
         const int len = (int)(e >> 8);
@@ -252,18 +264,9 @@ __device__ __forceinline__ int huff_decode(BitReader& b, const HuffLds& h) {    
 
 __device__ __forceinline__ int jpeg_extend(int v, int s) { return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v; }
 
-__global__ __launch_bounds__(64) void jpeg_huffman_kernel(const JpegFileDev* __restrict__ files, int* __restrict__ errors) {
-    __shared__ HuffLds tab[4];                    // DC slot 0, 1, AC slot 0, 1
-    __shared__ int hdr[32];
-    const int lane = threadIdx.x;
-    const JpegFileDev f = files[blockIdx.x];
-    const unsigned char* plan = reinterpret_cast<const unsigned char*>(f.plan);
-    // blockIdx.y: which 64 intervals of the file this wave decodes (a thread's chain of symbols is what bounds the kernel: files with
-    // short intervals spread over several waves); waves past the file's last interval leave before building tables
-    if ((int)blockIdx.y * 64 >= reinterpret_cast<const int*>(plan)[1] && reinterpret_cast<const int*>(plan)[0] == 0x3157504A) return;
-    if (lane < 32) hdr[lane] = reinterpret_cast<const int*>(plan)[lane];
-    // ---- the four decoding tables from the DHT counts / symbols: lanes 0-3 assign the canonical codes of one table each (16
-    // lengths), then all lanes fill the 9-bit look-ups
+// The four decoding tables (DC slot 0, 1, AC slot 0, 1) from the DHT counts / symbols of the plan: threads 0-3 assign the canonical codes
+// of one table each (16 lengths), then all threads fill the 9-bit look-ups. Ends with a workgroup barrier.
+__device__ __forceinline__ void build_huff_tables(HuffLds (&tab)[4], const unsigned char* plan, int lane, int nthreads) {
     if (lane < 4) {
         const unsigned char* d = lane < 2 ? plan + 128 + 32 * lane : plan + 192 + 272 * (lane - 2);
         HuffLds& h = tab[lane];
@@ -283,7 +286,7 @@ __global__ __launch_bounds__(64) void jpeg_huffman_kernel(const JpegFileDev* __r
         for (int i = 0; i < 256; ++i) h.sym[i] = i < nsym ? d[16 + i] : 0;
     }
     __syncthreads();
-    for (int e = lane; e < 4 * 512; e += 64) {
+    for (int e = lane; e < 4 * 512; e += nthreads) {
         const int t = e >> 9, i = e & 511;
         const unsigned char* d = t < 2 ? plan + 128 + 32 * t : plan + 192 + 272 * (t - 2);
         const HuffLds& h = tab[t];
@@ -299,6 +302,19 @@ __global__ __launch_bounds__(64) void jpeg_huffman_kernel(const JpegFileDev* __r
         tab[t].look[i] = v;
     }
     __syncthreads();
+}
+
+__global__ __launch_bounds__(64) void jpeg_huffman_kernel(const JpegFileDev* __restrict__ files, int* __restrict__ errors) {
+    __shared__ HuffLds tab[4];                    // DC slot 0, 1, AC slot 0, 1
+    __shared__ int hdr[32];
+    const int lane = threadIdx.x;
+    const JpegFileDev f = files[blockIdx.x];
+    const unsigned char* plan = reinterpret_cast<const unsigned char*>(f.plan);
+    // blockIdx.y: which 64 intervals of the file this wave decodes (a thread's chain of symbols is what bounds the kernel: files with
+    // short intervals spread over several waves); waves past the file's last interval leave before building tables
+    if ((int)blockIdx.y * 64 >= reinterpret_cast<const int*>(plan)[1] && reinterpret_cast<const int*>(plan)[0] == 0x3157504A) return;
+    if (lane < 32) hdr[lane] = reinterpret_cast<const int*>(plan)[lane];
+    build_huff_tables(tab, plan, lane, 64);
     if (hdr[0] != 0x3157504A) {
         if (lane == 0 && blockIdx.y == 0) errors[blockIdx.x] = 2;
         return;
@@ -311,11 +327,9 @@ __global__ __launch_bounds__(64) void jpeg_huffman_kernel(const JpegFileDev* __r
     bool bad = false;
     for (int iv = (int)blockIdx.y * 64 + lane; iv < n_int; iv += 64 * (int)gridDim.y) {
         BitReader b;
-        b.words = reinterpret_cast<const unsigned long long*>(f.bytes);
-        b.pos = ioff[iv];
-        b.end = iv + 1 < n_int ? ioff[iv + 1] : end_all;      // (the RSTn marker in front of the next interval stops the reader earlier)
-        if (b.end > (unsigned)f.n_bytes) b.end = (unsigned)f.n_bytes;
-        b.cidx = 0xfffffff0u; b.cache = 0; b.ahead = 0; b.buf = 0; b.n = 0; b.starved = 0;
+        unsigned iend = iv + 1 < n_int ? ioff[iv + 1] : end_all;      // (the RSTn marker in front of the next interval stops the reader earlier)
+        if (iend > (unsigned)f.n_bytes) iend = (unsigned)f.n_bytes;
+        b.start(reinterpret_cast<const void*>(f.bytes), ioff[iv], iend);
         int pred[3] = {0, 0, 0};
         const long long m0 = (long long)iv * restart;
         const long long m1 = m0 + restart < mcus ? m0 + restart : mcus;
@@ -360,9 +374,241 @@ __global__ __launch_bounds__(64) void jpeg_huffman_kernel(const JpegFileDev* __r
     if (bad) errors[blockIdx.x] = 1;
 }
 
+// ---- step two: files WITHOUT restart markers. The scan is one long bit string; a decoder dropped into the middle of it, with a
+// wrong idea of where symbols start and which block / coefficient it is in, falls into step with the true decoding after a few dozen
+// symbols (Huffman codes self-synchronise; Klein & Wiseman 2003, Weissenberger & Schmidt 2018 for JPEG on GPUs). One workgroup of
+// 1024 threads per file:
+//   1 unstuff: the entropy-coded bytes minus the 00 behind every FF -> a clean copy (block-wide prefix sum of the kept bytes);
+//   2 synchronise: the clean bit string is cut into 1024 equal subsequences. Thread s decodes from its ENTRY state (bit position,
+//     block within the MCU, zig-zag index) to the first symbol that starts in the next subsequence and publishes that as its EXIT
+//     state with the number of blocks it completed. Round 0 enters every subsequence at its first bit in state (block 0, DC); in
+//     later rounds thread s enters at thread s - 1's exit and decodes again only if that entry changed. Thread 0's entry is the true
+//     start, so a fixed point (no entry changed) IS the true decoding: reached after a handful of rounds, at worst after 1024;
+//   3 an exclusive prefix sum of the completed-block counts numbers every thread's first block; the threads decode once more, now
+//     WRITING: AC coefficients to their place, DC DIFFERENCES to slot 0 of their block;
+//   4 per component a prefix sum over its blocks in scan order turns the differences into DC values.
+// Bit-identical to witw_jpeg_decode_coef on valid files (tests/test_jpeg_gpu.py); a file whose block count does not come out as
+// MCUs x blocks per MCU is flagged in `errors`.
+constexpr int SS_T = 1024;
+
+struct JpegSyncDev {               // int64 x 6 per file
+    long long bytes, plan, coef, n_bytes;      // as JpegFileDev
+    long long clean;               // address of a scratch buffer of n_bytes + 32 bytes, 8-byte aligned (the unstuffed copy)
+    long long reserved;
+};
+
+struct SyncState { unsigned p; unsigned short b, k; };      // next unread bit, block within the MCU, zig-zag index (0: at the DC symbol)
+
+__device__ __forceinline__ int block_scan_excl(int v, int* wave_tot, int tid, int& total) {      // 1024 threads; ends with a barrier
+    const int lane = tid & 63, wave = tid >> 6;
+    int x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int y = __shfl_up(x, d, 64);
+        if (lane >= d) x += y;
+    }
+    if (lane == 63) wave_tot[wave] = x;
+    __syncthreads();
+    int base = 0, tot = 0;
+    for (int w = 0; w < SS_T / 64; ++w) {
+        const int t = wave_tot[w];
+        if (w < wave) base += t;
+        tot += t;
+    }
+    total = tot;
+    __syncthreads();
+    return base + x - v;
+}
+
+__global__ __launch_bounds__(SS_T) void jpeg_selfsync_kernel(const JpegSyncDev* __restrict__ files, int* __restrict__ errors) {
+    __shared__ HuffLds tab[4];
+    __shared__ int hdr[32];
+    __shared__ SyncState exit_s[SS_T];
+    __shared__ unsigned short nblk_s[SS_T];
+    __shared__ int wave_tot[SS_T / 64];
+    __shared__ int changed;
+    __shared__ unsigned char mcu_comp[16], mcu_v[16], mcu_h[16];      // block j of an MCU: component, row / column inside the MCU
+    const int tid = threadIdx.x;
+    const JpegSyncDev f = files[blockIdx.x];
+    const unsigned char* plan = reinterpret_cast<const unsigned char*>(f.plan);
+    if (tid < 32) hdr[tid] = reinterpret_cast<const int*>(plan)[tid];
+    build_huff_tables(tab, plan, tid, SS_T);
+    if (hdr[0] != 0x3157504A || hdr[1] != 1) {
+        if (tid == 0) errors[blockIdx.x] = 2;
+        return;
+    }
+    const int mcux = hdr[3], mcuy = hdr[4], ncomp = hdr[5];
+    int nb = 0;                                    // blocks per MCU
+    for (int k = 0; k < ncomp; ++k) nb += hdr[6 + 7 * hdr[28 + k]] * hdr[7 + 7 * hdr[28 + k]];
+    if (tid == 0) {
+        int j = 0;
+        for (int k = 0; k < ncomp; ++k) {
+            const int c = hdr[28 + k];
+            for (int v = 0; v < hdr[7 + 7 * c]; ++v)
+                for (int h = 0; h < hdr[6 + 7 * c]; ++h, ++j)
+                    if (j < 16) { mcu_comp[j] = (unsigned char)c; mcu_v[j] = (unsigned char)v; mcu_h[j] = (unsigned char)h; }
+        }
+    }
+    if (nb > 16) {
+        if (tid == 0) errors[blockIdx.x] = 2;
+        return;
+    }
+    // ---- 1: unstuff [start, end) -> clean
+    const unsigned char* src = reinterpret_cast<const unsigned char*>(f.bytes);
+    unsigned char* clean = reinterpret_cast<unsigned char*>(f.clean);
+    const unsigned s0 = reinterpret_cast<const unsigned*>(plan + 736)[0];
+    unsigned s1 = (unsigned)hdr[27];
+    if (s1 > (unsigned)f.n_bytes) s1 = (unsigned)f.n_bytes;
+    const unsigned len = s1 > s0 ? s1 - s0 : 0u;
+    const unsigned chunk = (len + SS_T - 1) / SS_T;
+    const unsigned c0 = s0 + min(len, (unsigned)tid * chunk), c1 = s0 + min(len, ((unsigned)tid + 1u) * chunk);
+    int kept = 0;
+    for (unsigned i = c0; i < c1; ++i) kept += !(src[i] == 0 && i > s0 && src[i - 1] == 0xff);
+    int n_clean = 0;
+    unsigned w = (unsigned)block_scan_excl(kept, wave_tot, tid, n_clean);
+    for (unsigned i = c0; i < c1; ++i) {
+        const unsigned char v = src[i];
+        if (!(v == 0 && i > s0 && src[i - 1] == 0xff)) clean[w++] = v;
+    }
+    if (tid < 32) clean[n_clean + tid] = 0;      // the reader runs up to two 8-byte words ahead
+    __syncthreads();
+    const unsigned total_bits = (unsigned)n_clean * 8u;
+    // subsequence length in bits: equal parts, at least 64 (a symbol with its value bits is at most 32)
+    unsigned L = (total_bits + SS_T - 1) / SS_T;
+    if (L < 64u) L = 64u;
+    const unsigned my_lo = min(total_bits, (unsigned)tid * L), my_hi = min(total_bits, ((unsigned)tid + 1u) * L);
+
+    // decode from `st` to the first symbol that starts at or behind `limit`; WRITE: store coefficients, first block = blk0
+    auto run = [&](SyncState st, unsigned limit, auto write_c, long long blk0) -> SyncState {
+        constexpr bool WRITE = decltype(write_c)::value;
+        BitReaderT<false> b;
+        b.start(clean, st.p >> 3, (unsigned)n_clean);
+        b.fill();
+        if (st.p & 7u) { b.buf <<= (st.p & 7u); b.n -= (int)(st.p & 7u); }
+        unsigned bq = st.b, kq = st.k;
+        int done = 0;
+        short* coef = reinterpret_cast<short*>(f.coef);
+        short* blk = nullptr;
+        const long long total_blocks = (long long)mcux * mcuy * nb;
+        auto locate = [&](long long bi) -> short* {      // block number in scan order -> its 64 coefficients (nullptr: past the image)
+            if (bi >= total_blocks) return nullptr;
+            const long long m = bi / nb;
+            const int j = (int)(bi - m * nb);
+            const int c = mcu_comp[j];
+            const int* q = hdr + 6 + 7 * c;
+            const int my = (int)(m / mcux), mx = (int)(m - (long long)my * mcux);
+            return coef + ((long long)q[4] + (long long)(my * q[1] + mcu_v[j]) * q[2] + (mx * q[0] + mcu_h[j])) * 64;
+        };
+        if (WRITE) blk = locate(blk0);
+        while (b.bit_pos() < limit) {
+            if (b.n < 32) b.fill();
+            const int c = mcu_comp[bq];
+            const int* q = hdr + 6 + 7 * c;
+            bool finished = false;
+            if (kq == 0) {
+                const int sdc = huff_decode(b, tab[q[5] & 1]);
+                if (sdc < 0 || sdc > 15) { b.buf <<= 1; b.n -= 1; continue; }      // not a code (only ever out of step): slide one bit on
+                int diff = 0;
+                if (sdc) diff = jpeg_extend(b.get(sdc), sdc);
+                if (WRITE && blk) blk[0] = (short)diff;
+                kq = 1;
+            } else {
+                const int rs = huff_decode(b, tab[2 + (q[6] & 1)]);
+                if (rs < 0) { b.buf <<= 1; b.n -= 1; continue; }
+                const int r = rs >> 4, sz = rs & 15;
+                if (sz == 0) {
+                    if (r == 15) kq += 16; else finished = true;
+                } else {
+                    kq += r;
+                    const int v = jpeg_extend(b.get(sz), sz);
+                    if (WRITE && blk && kq < 64) blk[kZigZag[kq]] = (short)v;
+                    ++kq;
+                }
+                if (kq >= 64) finished = true;
+            }
+            if (finished) {
+                ++done;
+                kq = 0;
+                bq = (bq + 1 == (unsigned)nb) ? 0 : bq + 1;
+                if (WRITE) blk = locate(blk0 + done);
+            }
+        }
+        SyncState e;
+        e.p = b.bit_pos(); e.b = (unsigned short)bq; e.k = (unsigned short)kq;
+        nblk_s[tid] = (unsigned short)(done > 65535 ? 65535 : done);
+        return e;
+    };
+
+    // ---- 2: rounds until no entry changes
+    SyncState entry;
+    entry.p = my_lo; entry.b = 0; entry.k = 0;
+    exit_s[tid] = run(entry, my_hi, std::false_type(), 0);
+    __syncthreads();
+    for (int round = 0; round < SS_T + 1; ++round) {
+        if (tid == 0) changed = 0;
+        SyncState want = entry;
+        if (tid > 0) want = exit_s[tid - 1];
+        __syncthreads();                        // everybody has read its neighbour's exit of the last round
+        const bool differs = want.p != entry.p || want.b != entry.b || want.k != entry.k;
+        if (differs) {
+            entry = want;
+            // (an entry behind this subsequence's end: the neighbour's last symbol reached across all of it -- nothing starts here)
+            if (entry.p >= my_hi) { exit_s[tid] = entry; nblk_s[tid] = 0; }
+            else exit_s[tid] = run(entry, my_hi, std::false_type(), 0);
+            changed = 1;
+        }
+        __syncthreads();
+        if (!changed) break;
+        __syncthreads();
+    }
+    // ---- 3: number the blocks, decode once more and write
+    int total_done = 0;
+    const int first = block_scan_excl((int)nblk_s[tid], wave_tot, tid, total_done);
+    if (entry.p < my_hi) run(entry, my_hi, std::true_type(), (long long)first);
+    __syncthreads();
+    const long long total_blocks = (long long)mcux * mcuy * nb;
+    if (tid == 0 && (long long)total_done < total_blocks) errors[blockIdx.x] = 1;      // the data ended early (a trailing partial block of padding bits may add one)
+    // ---- 4: DC differences -> DC values, per component over its blocks in scan order
+    short* coef = reinterpret_cast<short*>(f.coef);
+    for (int k = 0; k < ncomp; ++k) {
+        const int c = hdr[28 + k];
+        const int* q = hdr + 6 + 7 * c;
+        const int per_mcu = q[0] * q[1];
+        const long long n_c = (long long)mcux * mcuy * per_mcu;
+        const long long per_t = (n_c + SS_T - 1) / SS_T;
+        const long long i0 = min(n_c, (long long)tid * per_t), i1 = min(n_c, ((long long)tid + 1) * per_t);
+        auto at = [&](long long i) -> short* {      // i-th block of the component in scan order
+            const long long m = i / per_mcu;
+            const int j = (int)(i - m * per_mcu), v = j / q[0], h = j - v * q[0];
+            const int my = (int)(m / mcux), mx = (int)(m - (long long)my * mcux);
+            return coef + ((long long)q[4] + (long long)(my * q[1] + v) * q[2] + (mx * q[0] + h)) * 64;
+        };
+        int sum = 0;
+        for (long long i = i0; i < i1; ++i) sum += *at(i);
+        int dummy = 0;
+        int pred = block_scan_excl(sum, wave_tot, tid, dummy);
+        for (long long i = i0; i < i1; ++i) {
+            short* d = at(i);
+            pred += *d;
+            *d = (short)pred;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+// The same for files WITHOUT restart markers (plans of ONE interval): self-synchronising decode, one workgroup of 1024 threads per file.
+// files: DEVICE int64 [n_files][6] = {file bytes, plan, coefficient area (zero-filled), file length, scratch of file length + 32
+// bytes (8-byte aligned), 0}; errors as above. Coefficients bit-identical to witw_jpeg_decode_coef.
+int witw_jpeg_huffman_selfsync(const void* files, int n_files, int* errors, void* stream) {
+    WITW_CHECK_ARG(files && errors, "jpeg_huffman_selfsync: null pointer");
+    WITW_CHECK_ARG(n_files > 0, "jpeg_huffman_selfsync: %d files", n_files);
+    hipLaunchKernelGGL(jpeg_selfsync_kernel, dim3((unsigned)n_files), dim3(SS_T), 0, (hipStream_t)stream, (const JpegSyncDev*)files, errors);
+    WITW_CHECK_LAUNCH("jpeg_huffman_selfsync");
+    return WITW_OK;
+}
 
 // Entropy decoding of n_files JPEG files WITH RESTART MARKERS on the device, one thread per restart interval: files = DEVICE int64
 // [n_files][4] = {address of the file bytes (8-byte aligned, 24 readable bytes behind the end), address of the file's plan

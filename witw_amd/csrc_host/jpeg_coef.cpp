@@ -370,26 +370,33 @@ int witw_jpeg_decode_coef(const uint8_t* data, size_t n, int16_t* coef, uint16_t
 //   [27] end of the entropy-coded data (byte offset in the file), [28..30] component of scan position k, [31] 0;
 //   byte 128: DC tables of slots 0, 1 (16 counts + 16 symbols each), byte 192: AC tables of slots 0, 1 (16 counts + 256 symbols each);
 //   byte 736: uint32 [intervals]: byte offset in the file of each interval's first entropy-coded byte.
-// Files without restart markers, with more than two DC or AC tables in use, or whose markers are out of sequence return -2 / -3 and
-// take the host path (witw_jpeg_decode_coef) as before.
+// A file without restart markers gets a plan of ONE interval (the whole scan): the device decodes it with the self-synchronising
+// kernel. Files with more than two DC or AC tables in use, or whose markers are out of sequence, return -2 / -3 and take the host
+// path (witw_jpeg_decode_coef) as before.
 enum { WITW_JPEG_PLAN_FIXED = 736 };
 
-long long witw_jpeg_entropy_plan_bytes(const uint8_t* data, size_t n) {      // 0: no restart markers (or not a file for this decoder)
+long long witw_jpeg_entropy_plan_bytes(const uint8_t* data, size_t n) {      // 0: not a file for this decoder
     Parsed& P = parsed();
-    if (parse(data, n, P) || P.restart <= 0) return 0;
+    if (parse(data, n, P)) return 0;
+    if (P.restart <= 0) return WITW_JPEG_PLAN_FIXED + 4;      // no restart markers: ONE interval, decoded by the self-synchronising kernel
     const long long mcus = (long long)P.mcux * P.mcuy;
     return WITW_JPEG_PLAN_FIXED + 4 * ((mcus + P.restart - 1) / P.restart);
 }
 
 // plan: plan_cap bytes (witw_jpeg_entropy_plan_bytes); qt: ncomp x 64 uint16 (as witw_jpeg_decode_coef writes them).
-// Returns the plan's size in bytes, or -1 / -2 as witw_jpeg_info, -2 also for files without restart markers or with more than two
-// Huffman tables of a kind in use, -3 when the restart markers found do not number intervals - 1 in sequence.
+// Returns the plan's size in bytes, or -1 / -2 as witw_jpeg_info, -2 also for files with more than two Huffman tables of a kind in
+// use, -3 when the restart markers found do not number intervals - 1 in sequence.
 long long witw_jpeg_entropy_plan(const uint8_t* data, size_t n, uint8_t* plan, size_t plan_cap, uint16_t* qt) {
     Parsed& P = parsed();
     const int rc = parse(data, n, P);
     if (rc) return rc;
-    if (P.restart <= 0) return -2;
+    // no restart markers: the whole scan is ONE interval ([2] = every MCU of the image); the device finds its way into the middle of
+    // it by self-synchronisation (csrc/jpeg.hip, jpeg_selfsync_kernel)
     const long long mcus = (long long)P.mcux * P.mcuy;
+    if (P.restart <= 0) {
+        if (mcus > 0x7fffffff) return -2;
+        P.restart = (int)mcus;
+    }
     const long long n_int = (mcus + P.restart - 1) / P.restart;
     const long long need = WITW_JPEG_PLAN_FIXED + 4 * n_int;
     if ((long long)plan_cap < need || n_int > 0x7fffffff) return -1;

@@ -1531,7 +1531,7 @@ class GpuPreprocess(object):
         st.keep += [dbuf] if pinned else [dbuf, buf]
         if kind == 2:      # jpeg.KIND_JPEG: coefficient blocks -> dequantise, inverse DCT, upsample, colour-convert on the device
             from . import jpeg
-            keep, table = jpeg.decode_packed(dbuf, desc)
+            keep, table = jpeg.decode_packed(dbuf, desc, host_buf=buf)
             st.keep += keep
             if int(table[:, 4].min()) < self.channels:
                 raise _lib.WitwError('an image of the batch has %d channels, the model takes %d' % (int(table[:, 4].min()), self.channels))

@@ -20,10 +20,16 @@ KIND_JPEG = 2          # packed-batch kind: coefficient blocks (+ raw uint8 imag
 DESC_COLS = 30         # per image: coefficient byte offset, quantisation-table byte offset, 22 info ints, is_raw, channels,
 #                        entropy decoding on the device (1: column 0 is then the offset of the FILE BYTES), plan byte offset, file length,
 #                        restart intervals
-# Files that carry restart markers are entropy-decoded ON THE DEVICE (csrc/jpeg.hip jpeg_huffman_kernel, one GPU thread per restart
-# interval; round 6): the worker only scans for the markers and the file bytes cross PCIe instead of the coefficient blocks.
+# Baseline / extended-sequential Huffman files are entropy-decoded ON THE DEVICE (round 6; csrc/jpeg.hip): with restart markers one GPU
+# thread per restart interval (jpeg_huffman_kernel), without them a self-synchronising decode, one workgroup per file
+# (jpeg_selfsync_kernel). The worker only parses the header and scans for markers; the file bytes cross PCIe instead of the
+# coefficient blocks.
 # WITW_JPEG_DEVICE_ENTROPY=0 (or jpeg.DEVICE_ENTROPY = False) keeps every file on the host's Huffman decoder.
 DEVICE_ENTROPY = os.environ.get('WITW_JPEG_DEVICE_ENTROPY', '1') != '0'
+CHECK_ERRORS = True    # decode_packed(host_buf=...) re-decodes files the device flagged as damaged with Pillow (as the host path does)
+REPAIRED = [0]         # how many files that happened to
+SELFSYNC_MIN_BLOCKS = 96   # a marker-less file of at most this many blocks is decoded by ONE thread of the interval kernel (a 1024-thread
+#                            workgroup would find nothing to split)
 _ERRORS = []           # error flags (device int32 tensors) of the last batches decoded on the device: entropy_errors() sums them
 
 
@@ -274,7 +280,7 @@ def _decode_group(dbuf, d, coef_ptr, qt_ptr):
     return [plane_t, image_t, comp, rgb], rgb.data_ptr() + images[:, 11], images[:, 2]
 
 
-def decode_packed(dbuf, desc):
+def decode_packed(dbuf, desc, host_buf=None):
     """dbuf: the packed block on the GPU; desc: its HOST descriptor table -> (tensors to keep alive, int64 host table [B,5] =
     {device address, H, W, 0, channels} of the decoded uint8 HWC images: the descriptor rows of
     witw_resize_bilinear_normalize_batched / witw_polar_from_raw, kind 1). Two launches for the entries whose coefficient blocks
@@ -301,18 +307,53 @@ def decode_packed(dbuf, desc):
         blocks = d[dv, 7]                                        # info[5]: coefficient blocks of the file
         first = np.cumsum(blocks) - blocks
         coef = torch.zeros((int(blocks.sum()) * 64,), dtype=torch.int16, device=dev)
-        files = np.stack([dbuf.data_ptr() + d[dv, 0], dbuf.data_ptr() + d[dv, 27], coef.data_ptr() + first * 128, d[dv, 28]], axis=1).astype(np.int64)
-        files_t = torch.from_numpy(files).pin_memory().to(dev, non_blocking=True)
         errors = torch.zeros((int(dv.size),), dtype=torch.int32, device=dev)
-        _lib.check(_lib.load().witw_jpeg_huffman(files_t.data_ptr(), int(dv.size), int(d[dv, 29].max()), errors.data_ptr(), ops._stream()),
-                   'witw_jpeg_huffman')
+        # files with restart markers: one thread per interval; files without (ONE interval of more than SELFSYNC_MIN_BLOCKS blocks):
+        # the self-synchronising kernel, one workgroup per file
+        sync = (d[dv, 29] == 1) & (blocks > SELFSYNC_MIN_BLOCKS)
+        rows = np.stack([dbuf.data_ptr() + d[dv, 0], dbuf.data_ptr() + d[dv, 27], coef.data_ptr() + first * 128, d[dv, 28]], axis=1).astype(np.int64)
+        ir = np.nonzero(~sync)[0]
+        if ir.size:
+            files_t = torch.from_numpy(np.ascontiguousarray(rows[ir])).pin_memory().to(dev, non_blocking=True)
+            e_r = torch.zeros((int(ir.size),), dtype=torch.int32, device=dev)
+            _lib.check(_lib.load().witw_jpeg_huffman(files_t.data_ptr(), int(ir.size), int(d[dv[ir], 29].max()), e_r.data_ptr(), ops._stream()),
+                       'witw_jpeg_huffman')
+            errors[torch.from_numpy(ir).to(dev)] = e_r
+            keep += [files_t, e_r]
+        isy = np.nonzero(sync)[0]
+        if isy.size:
+            sizes = (d[dv[isy], 28] + 32 + 7) // 8 * 8
+            soff = np.cumsum(sizes) - sizes
+            scratch = torch.empty((int(sizes.sum()),), dtype=torch.uint8, device=dev)
+            srows = np.concatenate([rows[isy], (scratch.data_ptr() + soff)[:, None], np.zeros((isy.size, 1), np.int64)], axis=1).astype(np.int64)
+            files_s = torch.from_numpy(np.ascontiguousarray(srows)).pin_memory().to(dev, non_blocking=True)
+            e_s = torch.zeros((int(isy.size),), dtype=torch.int32, device=dev)
+            _lib.check(_lib.load().witw_jpeg_huffman_selfsync(files_s.data_ptr(), int(isy.size), e_s.data_ptr(), ops._stream()),
+                       'witw_jpeg_huffman_selfsync')
+            errors[torch.from_numpy(isy).to(dev)] = e_s
+            keep += [files_s, e_s, scratch]
         dd = d[dv].copy()
         dd[:, 0] = first * 128                                   # where each file's coefficient blocks sit in `coef`
         k, addr, ncomp = _decode_group(dbuf, dd, coef.data_ptr(), dbuf.data_ptr())
-        keep += k + [coef, files_t, errors]
+        keep += k + [coef, errors]
         table[dv, 0], table[dv, 4] = addr, ncomp
         _ERRORS.append(errors)
         del _ERRORS[:-64]
+        if host_buf is not None and CHECK_ERRORS:
+            # A file whose entropy-coded data is damaged is read by the reference through libjpeg, which recovers what it can (with
+            # a warning); the host path hands such a file to Pillow inside pack(). Here the damage shows only once the kernel has
+            # run: look at the flags (a 4-byte-per-file copy; it waits for THIS stream's staging work, which the drivers run on the
+            # copy stream one batch ahead of the encoders) and let Pillow decode the flagged files from the bytes that are still in
+            # the host block -- the same image, by the same decoder, as on the host path.
+            flagged = np.nonzero(errors.cpu().numpy())[0]
+            hb = host_buf.numpy() if isinstance(host_buf, torch.Tensor) else np.asarray(host_buf)
+            for j in flagged:
+                i = int(dv[j])
+                px = np.ascontiguousarray(JpegFile(None, hb[int(d[i, 0]):int(d[i, 0]) + int(d[i, 28])]).pillow())
+                t = torch.from_numpy(px).to(dev)
+                keep.append(t)
+                table[i] = (t.data_ptr(), px.shape[0], px.shape[1], 0, px.shape[2])
+                REPAIRED[0] += 1
     return keep, torch.from_numpy(table)
 
 
