@@ -432,6 +432,9 @@ def main():
     ap.add_argument('--jpeg-restart-rows', type=int, default=0,
                     help='e2e: write the synthetic JPEG files with a restart marker every N MCU rows (0: none, as Pillow / libjpeg write by '
                          'default); files with restart markers are entropy-decoded on the GPU, one thread per restart interval')
+    ap.add_argument('--device-entropy', choices=['off', 'restart', 'all'], default=None,
+                    help="e2e: which JPEG files are Huffman-decoded on the GPU (witw_amd/jpeg.py DEVICE_ENTROPY; default 'restart': those "
+                         "with restart markers; 'all' adds the self-synchronising decode of marker-less files)")
     ap.add_argument('--jpeg-restart-blocks', type=int, default=0, help='e2e: ... or a restart marker every N MCUs (jpegtran -restart NB)')
     ap.add_argument('--no-decode-scaling', action='store_true', help='e2e: skip the host entropy-decode scaling sweep')
     ap.add_argument('--decode-scaling-seconds', type=float, default=1.0)

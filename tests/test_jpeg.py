@@ -420,6 +420,10 @@ def test_pack_ships_file_bytes_for_device_entropy_decoding(monkeypatch):
     raw = open(os.path.join(HERE, 's420_rst.jpg'), 'rb').read()
     plain = open(os.path.join(HERE, 's420_q90.jpg'), 'rb').read()
     items = [jpeg.open_file(raw), jpeg.open_file(plain), jpeg.open_file(raw)]
+    assert jpeg.DEVICE_ENTROPY == 'restart'                     # the default: only restart-marker files go to the device decoder
+    _b, desc_r, _k = jpeg.pack(items)
+    assert list(desc_r[:, 26].numpy()) == [1, 0, 1]
+    monkeypatch.setattr(jpeg, 'DEVICE_ENTROPY', 'all')
     buf, desc, kind = jpeg.pack(items)
     d = desc.numpy()
     assert kind == jpeg.KIND_JPEG and list(d[:, 26]) == [1, 1, 1] and list(d[:, 28]) == [len(raw), len(plain), len(raw)]

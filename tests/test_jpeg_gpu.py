@@ -184,12 +184,13 @@ def test_device_entropy_decode_equals_the_host_coefficients():
         assert int(e2.item()) == 1 and int(c2[int(it.info[5]):].abs().sum()) == 0
 
 
-def test_device_entropy_path_gives_pillows_bytes_in_mixed_batches():
+def test_device_entropy_path_gives_pillows_bytes_in_mixed_batches(monkeypatch):
     """pack() ships the FILE BYTES (descriptor column 26) and decode_packed entropy-decodes them on the device in front of the usual
     back end -- restart-marker files on the interval kernel, marker-less ones on the self-synchronising kernel (the small one on a
     single thread of the interval kernel); a progressive file (Pillow's bytes) and a raw array ride in the same batch: every image
     equals Pillow's decode byte for byte, and nothing was flagged."""
     from PIL import Image
+    monkeypatch.setattr(jpeg, 'DEVICE_ENTROPY', 'all')
     g = np.random.Generator(np.random.Philox(key=[13, 2]))
     raws = [_fresh(g, 512, 512, 2, 90, restart_marker_rows=1), _fresh(g, 224, 224, 2, 90), _fresh(g, 224, 224, 2, 90, restart_marker_rows=1),
             open(os.path.join(HERE, 'prog_q85.jpg'), 'rb').read(), _fresh(g, 97, 131, 1, 60, restart_marker_blocks=3, optimize=True),
@@ -281,12 +282,13 @@ def test_selfsync_decode_equals_the_host_coefficients():
         assert bad.size == 0, 'file %d (%d bytes): %d of %d blocks differ, first %s' % (k, len(raw), bad.size, nb, bad[:5])
 
 
-def test_device_flags_damaged_files_and_the_data_path_hands_them_to_pillow(tmp_path):
+def test_device_flags_damaged_files_and_the_data_path_hands_them_to_pillow(tmp_path, monkeypatch):
     """a truncated file: the device decoder flags it (its block count does not come out), the staging step looks at the flags and lets
     Pillow decode the flagged file from the bytes still in the host block -- the image the host path (and the reference's imread with
     libjpeg's tolerance) produces; the other files of the batch are untouched"""
     from PIL import Image, ImageFile
     from witw_amd import cvig_fov
+    monkeypatch.setattr(jpeg, 'DEVICE_ENTROPY', 'all')
     g = np.random.Generator(np.random.Philox(key=[14, 2]))
     good = [_fresh(g, 224, 224, 2, 90), _fresh(g, 224, 224, 2, 90, restart_marker_rows=1), _fresh(g, 224, 224, 2, 90)]
     cut = good[2][:len(good[2]) * 2 // 3]
@@ -309,3 +311,29 @@ def test_device_flags_damaged_files_and_the_data_path_hands_them_to_pillow(tmp_p
         src = next(t for t in keep if t.dtype == torch.uint8 and t.data_ptr() <= int(table[i, 0]) < t.data_ptr() + max(1, t.numel()))
         o = int(table[i, 0]) - src.data_ptr()
         np.testing.assert_array_equal(src.reshape(-1)[o:o + H * W * C].reshape(H, W, C).cpu().numpy(), r, err_msg=str(i))
+
+
+def test_data_path_with_selfsync_mode_equals_host_decode(tmp_path, monkeypatch):
+    """jpeg.DEVICE_ENTROPY = 'all': ordinary files (no restart markers) are Huffman-decoded by the self-synchronising kernel inside the
+    drivers' data path -- loader workers included -- with the same 'surface' / 'polar' bits as Pillow's decode."""
+    from witw_amd import cvig_fov
+    monkeypatch.setattr(jpeg, 'DEVICE_ENTROPY', 'all')
+    g = np.random.Generator(np.random.Philox(key=[15, 1]))
+    root = str(tmp_path)
+    rows = []
+    for i in range(4):
+        for tag, (h, w) in (('su', (224, 224)), ('ov', (512, 512))):
+            open(os.path.join(root, '%s_%d.jpg' % (tag, i)), 'wb').write(_fresh(g, h, w, 2, 90))
+        rows.append('ov_%d.jpg,su_%d.jpg' % (i, i))
+    csv = os.path.join(root, 'pairs.csv')
+    open(csv, 'w').write('\n'.join(rows) + '\n')
+    prep = cvig_fov.GpuPreprocess('cvusa', fov=360, random_orientation=False)
+    ref = prep(cvig_fov.collate_packed([cvig_fov.ImagePairDataset('cvusa', csv, raw=True)[i] for i in range(4)]))
+    ds = cvig_fov.ImagePairDataset('cvusa', csv, raw='jpeg')
+    batch = cvig_fov.collate_packed([ds[i] for i in range(4)])
+    assert int(batch['overhead_desc'][:, 26].sum()) == 4 and list(batch['overhead_desc'][:, 29].numpy()) == [1, 1, 1, 1]
+    got = prep(batch)
+    assert torch.equal(got['surface'], ref['surface']) and torch.equal(got['polar'], ref['polar'])
+    loader = torch.utils.data.DataLoader(ds, batch_size=2, shuffle=False, num_workers=2, collate_fn=cvig_fov.collate_packed, pin_memory=True)
+    outs = [prep(st) for st in cvig_fov.DevicePrefetcher(loader, prep)]
+    assert torch.equal(torch.cat([d['polar'] for d in outs]), ref['polar']) and jpeg.entropy_errors() == 0

@@ -141,7 +141,9 @@ def bench(a, device, n_pairs=None, workers=None, keep_dir=None, decode=None, pre
     restart_rows, restart_blocks = int(getattr(a, 'jpeg_restart_rows', 0) or 0), int(getattr(a, 'jpeg_restart_blocks', 0) or 0)
     csv, n_unique, nbytes = make_dataset(root, n_pairs, procs=min(16, cores), restart_rows=restart_rows, restart_blocks=restart_blocks)
     from . import jpeg as jpeg_mod
-    dev_entropy = decode == 'device' and (restart_rows > 0 or restart_blocks > 0) and jpeg_mod.DEVICE_ENTROPY
+    if getattr(a, 'device_entropy', None):
+        jpeg_mod.DEVICE_ENTROPY = False if a.device_entropy == 'off' else a.device_entropy      # (loader workers are forked below: they inherit it)
+    dev_entropy = decode == 'device' and bool(jpeg_mod.DEVICE_ENTROPY) and (restart_rows > 0 or restart_blocks > 0 or jpeg_mod.DEVICE_ENTROPY == 'all')
     t_make = time.perf_counter() - t0
 
     ds = cvig_fov.ImagePairDataset('cvusa', csv, raw='jpeg' if decode == 'device' else True)
@@ -261,7 +263,7 @@ def bench(a, device, n_pairs=None, workers=None, keep_dir=None, decode=None, pre
     assert su_all.shape[0] == n_pairs and ov_all.shape[0] == n_pairs
     del loader
 
-    rates = {'%s (%d DataLoader workers)' % ('restart-marker-scan_and_pack (entropy decoding on the GPU)' if dev_entropy else
+    rates = {'%s (%d DataLoader workers)' % ('header-parse_marker-scan_and_pack (entropy decoding on the GPU)' if dev_entropy else
                                              'entropy-decode_and_pack' if decode == 'device' else 'decode_and_pack', workers): n / t_load,
              'host_to_device copy (pinned, %.1f MB per batch)' % (blk / 1e6): nb / t_h2d,
              'gpu (%sbatched resize+normalise [+polar, fused], 2 %s encoders; the next batch staged on the copy stream meanwhile, as in the pipeline)'
@@ -274,8 +276,10 @@ def bench(a, device, n_pairs=None, workers=None, keep_dir=None, decode=None, pre
     out = {'metric': 'image-pairs/sec (disk -> embeddings)', 'value': round(n_pairs / t_e2e, 2), 'unit': 'pairs/s', 'n_gpus': 1,
            'steps': (n_pairs + B - 1) // B, 'warmup': 0, 'ms_per_step': round(t_e2e / ((n_pairs + B - 1) // B) * 1e3, 3),
            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': {'fp32': 'f32'}.get(precision, precision), 'data': 'synthetic',
-           'jpeg_decode': ('device, entropy decoding included (files with a restart marker per %s: host = marker scan only); damaged files '
-                           'flagged in the last batches: %d' % ('%d MCUs' % restart_blocks if restart_blocks else '%d MCU row(s)' % restart_rows,
+           'jpeg_decode': ('device, entropy decoding included (%s: host = header parse + marker scan only); damaged files '
+                           'flagged in the last batches: %d' % ('files with a restart marker per %d MCUs, one GPU thread per interval' % restart_blocks if restart_blocks else
+                                                                'files with a restart marker per %d MCU row(s), one GPU thread per interval' % restart_rows if restart_rows else
+                                                                'files without restart markers, self-synchronising decode, one workgroup per file',
                                                                 entropy_errors)) if dev_entropy else
                           'device (host: entropy decoding only)' if decode == 'device' else 'host (Pillow)',
            'pcie_bytes_per_pair': int(blk / max(1, nb)),

@@ -24,8 +24,14 @@ DESC_COLS = 30         # per image: coefficient byte offset, quantisation-table 
 # thread per restart interval (jpeg_huffman_kernel), without them a self-synchronising decode, one workgroup per file
 # (jpeg_selfsync_kernel). The worker only parses the header and scans for markers; the file bytes cross PCIe instead of the
 # coefficient blocks.
-# WITW_JPEG_DEVICE_ENTROPY=0 (or jpeg.DEVICE_ENTROPY = False) keeps every file on the host's Huffman decoder.
-DEVICE_ENTROPY = os.environ.get('WITW_JPEG_DEVICE_ENTROPY', '1') != '0'
+# Modes: 'restart' (default) = only files with restart markers go to the device decoder (0.7 + 0.5 ms per 128 pairs at a marker every
+# 2 MCUs: the bf16 data path keeps its rate with 4 loader workers instead of 16); 'all' = marker-less files too, on the self-synchronising
+# kernel (2.6 + 1.9 ms per 128 pairs standalone, and a 1024-thread workgroup per file competes with the encoders' workgroups for whole
+# CUs: worth it where the GPU stage has room -- the fp32 encoders, 67 ms per batch -- or the host has no cores to spare; with the bf16
+# encoders 16 host workers are faster: 14.6 k against 5.3 k pairs/s, docs/experiments.md); 'off' / False = host Huffman decoding.
+# WITW_JPEG_DEVICE_ENTROPY = 0 | off | restart | 1 | all.
+_mode = os.environ.get('WITW_JPEG_DEVICE_ENTROPY', 'restart').lower()
+DEVICE_ENTROPY = False if _mode in ('0', 'off', 'false') else 'all' if _mode in ('all', '2') else 'restart'
 CHECK_ERRORS = True    # decode_packed(host_buf=...) re-decodes files the device flagged as damaged with Pillow (as the host path does)
 REPAIRED = [0]         # how many files that happened to
 SELFSYNC_MIN_BLOCKS = 96   # a marker-less file of at most this many blocks is decoded by ONE thread of the interval kernel (a 1024-thread
@@ -150,7 +156,8 @@ def pack(images, shared=False, alloc=None):
     for i, a in enumerate(images):
         if DEVICE_ENTROPY and isinstance(a, JpegFile):
             pl = a.entropy_plan()
-            if pl is not None:
+            # (a plan of ONE interval = a file without restart markers: the self-synchronising kernel, mode 'all' only)
+            if pl is not None and (DEVICE_ENTROPY in ('all', True) or int(pl[0][4:8].view(np.int32)[0]) > 1):
                 plans[i] = pl
         if i in plans:
             # entropy decoding on the device: the FILE BYTES travel (24 readable bytes behind the end: the kernel reads aligned 8-byte
