@@ -9,6 +9,7 @@
 // the byte layout PIL hands the reference (and witw_resize_bilinear_normalize_batched kind 1 / witw_polar_from_raw read).
 // Byte-identical to Pillow's decode: tests/test_jpeg*.py (fixtures under tests/golden/jpeg/ + files written at test time).
 #include "common.h"
+#include <stdlib.h>
 #include <type_traits>
 
 namespace {
@@ -377,7 +378,7 @@ __global__ __launch_bounds__(64) void jpeg_huffman_kernel(const JpegFileDev* __r
 // ---- step two: files WITHOUT restart markers. The scan is one long bit string; a decoder dropped into the middle of it, with a
 // wrong idea of where symbols start and which block / coefficient it is in, falls into step with the true decoding after a few dozen
 // symbols (Huffman codes self-synchronise; Klein & Wiseman 2003, Weissenberger & Schmidt 2018 for JPEG on GPUs). One workgroup of
-// 1024 threads per file:
+// SS_T (256 / 512 / 1024) threads per file:
 //   1 unstuff: the entropy-coded bytes minus the 00 behind every FF -> a clean copy (block-wide prefix sum of the kept bytes);
 //   2 synchronise: the clean bit string is cut into 1024 equal subsequences. Thread s decodes from its ENTRY state (bit position,
 //     block within the MCU, zig-zag index) to the first symbol that starts in the next subsequence and publishes that as its EXIT
@@ -389,7 +390,6 @@ __global__ __launch_bounds__(64) void jpeg_huffman_kernel(const JpegFileDev* __r
 //   4 per component a prefix sum over its blocks in scan order turns the differences into DC values.
 // Bit-identical to witw_jpeg_decode_coef on valid files (tests/test_jpeg_gpu.py); a file whose block count does not come out as
 // MCUs x blocks per MCU is flagged in `errors`.
-constexpr int SS_T = 1024;
 
 struct JpegSyncDev {               // int64 x 6 per file
     long long bytes, plan, coef, n_bytes;      // as JpegFileDev
@@ -399,7 +399,8 @@ struct JpegSyncDev {               // int64 x 6 per file
 
 struct SyncState { unsigned p; unsigned short b, k; };      // next unread bit, block within the MCU, zig-zag index (0: at the DC symbol)
 
-__device__ __forceinline__ int block_scan_excl(int v, int* wave_tot, int tid, int& total) {      // 1024 threads; ends with a barrier
+template <int SS_T>
+__device__ __forceinline__ int block_scan_excl(int v, int* wave_tot, int tid, int& total) {      // SS_T threads; ends with a barrier
     const int lane = tid & 63, wave = tid >> 6;
     int x = v;
 #pragma unroll
@@ -420,10 +421,11 @@ __device__ __forceinline__ int block_scan_excl(int v, int* wave_tot, int tid, in
     return base + x - v;
 }
 
+template <int SS_T>      // threads per file: 256 (a workgroup that fits beside others on a CU; a thread's subsequence is 4 x longer) .. 1024
 __global__ __launch_bounds__(SS_T) void jpeg_selfsync_kernel(const JpegSyncDev* __restrict__ files, int* __restrict__ errors) {
     __shared__ HuffLds tab[4];
     __shared__ int hdr[32];
-    __shared__ SyncState exit_s[SS_T];
+    __shared__ SyncState exit_s[SS_T];      // (SS_T is the template parameter here)
     __shared__ unsigned short nblk_s[SS_T];
     __shared__ int wave_tot[SS_T / 64];
     __shared__ int changed;
@@ -465,7 +467,7 @@ __global__ __launch_bounds__(SS_T) void jpeg_selfsync_kernel(const JpegSyncDev* 
     int kept = 0;
     for (unsigned i = c0; i < c1; ++i) kept += !(src[i] == 0 && i > s0 && src[i - 1] == 0xff);
     int n_clean = 0;
-    unsigned w = (unsigned)block_scan_excl(kept, wave_tot, tid, n_clean);
+    unsigned w = (unsigned)block_scan_excl<SS_T>(kept, wave_tot, tid, n_clean);
     for (unsigned i = c0; i < c1; ++i) {
         const unsigned char v = src[i];
         if (!(v == 0 && i > s0 && src[i - 1] == 0xff)) clean[w++] = v;
@@ -563,7 +565,7 @@ __global__ __launch_bounds__(SS_T) void jpeg_selfsync_kernel(const JpegSyncDev* 
     }
     // ---- 3: number the blocks, decode once more and write
     int total_done = 0;
-    const int first = block_scan_excl((int)nblk_s[tid], wave_tot, tid, total_done);
+    const int first = block_scan_excl<SS_T>((int)nblk_s[tid], wave_tot, tid, total_done);
     if (entry.p < my_hi) run(entry, my_hi, std::true_type(), (long long)first);
     __syncthreads();
     const long long total_blocks = (long long)mcux * mcuy * nb;
@@ -586,7 +588,7 @@ __global__ __launch_bounds__(SS_T) void jpeg_selfsync_kernel(const JpegSyncDev* 
         int sum = 0;
         for (long long i = i0; i < i1; ++i) sum += *at(i);
         int dummy = 0;
-        int pred = block_scan_excl(sum, wave_tot, tid, dummy);
+        int pred = block_scan_excl<SS_T>(sum, wave_tot, tid, dummy);
         for (long long i = i0; i < i1; ++i) {
             short* d = at(i);
             pred += *d;
@@ -605,7 +607,13 @@ extern "C" {
 int witw_jpeg_huffman_selfsync(const void* files, int n_files, int* errors, void* stream) {
     WITW_CHECK_ARG(files && errors, "jpeg_huffman_selfsync: null pointer");
     WITW_CHECK_ARG(n_files > 0, "jpeg_huffman_selfsync: %d files", n_files);
-    hipLaunchKernelGGL(jpeg_selfsync_kernel, dim3((unsigned)n_files), dim3(SS_T), 0, (hipStream_t)stream, (const JpegSyncDev*)files, errors);
+    static const int threads = [] { const char* e = getenv("WITW_SELFSYNC_THREADS"); const int t = e ? atoi(e) : 256; return t; }();
+    if (threads >= 1024)
+        hipLaunchKernelGGL(jpeg_selfsync_kernel<1024>, dim3((unsigned)n_files), dim3(1024), 0, (hipStream_t)stream, (const JpegSyncDev*)files, errors);
+    else if (threads >= 512)
+        hipLaunchKernelGGL(jpeg_selfsync_kernel<512>, dim3((unsigned)n_files), dim3(512), 0, (hipStream_t)stream, (const JpegSyncDev*)files, errors);
+    else
+        hipLaunchKernelGGL(jpeg_selfsync_kernel<256>, dim3((unsigned)n_files), dim3(256), 0, (hipStream_t)stream, (const JpegSyncDev*)files, errors);
     WITW_CHECK_LAUNCH("jpeg_huffman_selfsync");
     return WITW_OK;
 }
