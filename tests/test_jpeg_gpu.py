@@ -191,6 +191,7 @@ def test_device_entropy_path_gives_pillows_bytes_in_mixed_batches(monkeypatch):
     equals Pillow's decode byte for byte, and nothing was flagged."""
     from PIL import Image
     monkeypatch.setattr(jpeg, 'DEVICE_ENTROPY', 'all')
+    del jpeg._ERRORS[:]
     g = np.random.Generator(np.random.Philox(key=[13, 2]))
     raws = [_fresh(g, 512, 512, 2, 90, restart_marker_rows=1), _fresh(g, 224, 224, 2, 90), _fresh(g, 224, 224, 2, 90, restart_marker_rows=1),
             open(os.path.join(HERE, 'prog_q85.jpg'), 'rb').read(), _fresh(g, 97, 131, 1, 60, restart_marker_blocks=3, optimize=True),
@@ -226,6 +227,7 @@ def test_data_path_with_restart_marker_files_equals_host_decode(tmp_path):
         rows.append('ov_%d.jpg,su_%d.jpg' % (i, i))
     csv = os.path.join(root, 'pairs.csv')
     open(csv, 'w').write('\n'.join(rows) + '\n')
+    del jpeg._ERRORS[:]
     prep = cvig_fov.GpuPreprocess('cvusa', fov=360, random_orientation=False)
     ref = prep(cvig_fov.collate_packed([cvig_fov.ImagePairDataset('cvusa', csv, raw=True)[i] for i in range(6)]))
     ds = cvig_fov.ImagePairDataset('cvusa', csv, raw='jpeg')
@@ -318,6 +320,7 @@ def test_data_path_with_selfsync_mode_equals_host_decode(tmp_path, monkeypatch):
     drivers' data path -- loader workers included -- with the same 'surface' / 'polar' bits as Pillow's decode."""
     from witw_amd import cvig_fov
     monkeypatch.setattr(jpeg, 'DEVICE_ENTROPY', 'all')
+    del jpeg._ERRORS[:]                                    # (flags of earlier tests' batches, e.g. the deliberately damaged file)
     g = np.random.Generator(np.random.Philox(key=[15, 1]))
     root = str(tmp_path)
     rows = []

@@ -607,7 +607,7 @@ extern "C" {
 int witw_jpeg_huffman_selfsync(const void* files, int n_files, int* errors, void* stream) {
     WITW_CHECK_ARG(files && errors, "jpeg_huffman_selfsync: null pointer");
     WITW_CHECK_ARG(n_files > 0, "jpeg_huffman_selfsync: %d files", n_files);
-    static const int threads = [] { const char* e = getenv("WITW_SELFSYNC_THREADS"); const int t = e ? atoi(e) : 256; return t; }();
+    static const int threads = [] { const char* e = getenv("WITW_SELFSYNC_THREADS"); const int t = e ? atoi(e) : 512; return t; }();      // 256 / 512 / 1024 measured: 5.2 / 4.5 / 4.4 ms per 128 pairs alone, 512 best beside the encoders
     if (threads >= 1024)
         hipLaunchKernelGGL(jpeg_selfsync_kernel<1024>, dim3((unsigned)n_files), dim3(1024), 0, (hipStream_t)stream, (const JpegSyncDev*)files, errors);
     else if (threads >= 512)

@@ -26,9 +26,9 @@ DESC_COLS = 30         # per image: coefficient byte offset, quantisation-table 
 # coefficient blocks.
 # Modes: 'restart' (default) = only files with restart markers go to the device decoder (0.7 + 0.5 ms per 128 pairs at a marker every
 # 2 MCUs: the bf16 data path keeps its rate with 4 loader workers instead of 16); 'all' = marker-less files too, on the self-synchronising
-# kernel (2.6 + 1.9 ms per 128 pairs standalone, and a 1024-thread workgroup per file competes with the encoders' workgroups for whole
-# CUs: worth it where the GPU stage has room -- the fp32 encoders, 67 ms per batch -- or the host has no cores to spare; with the bf16
-# encoders 16 host workers are faster: 14.6 k against 5.3 k pairs/s, docs/experiments.md); 'off' / False = host Huffman decoding.
+# kernel (4.5 ms per 128 pairs standalone, and its workgroups -- 512 threads with barriers, one per file -- share the chip badly with
+# the encoders' persistent workgroups: beside the bf16 encoders the pass runs at 5.1 k pairs/s where 16 host workers give 14.6 k, beside
+# the fp32 ones at 1,660 against 1,820-1,860: for hosts with no cores to spare; docs/experiments.md); 'off' / False = host Huffman decoding.
 # WITW_JPEG_DEVICE_ENTROPY = 0 | off | restart | 1 | all.
 _mode = os.environ.get('WITW_JPEG_DEVICE_ENTROPY', 'restart').lower()
 DEVICE_ENTROPY = False if _mode in ('0', 'off', 'false') else 'all' if _mode in ('all', '2') else 'restart'
