@@ -356,7 +356,7 @@ def decode_packed(dbuf, desc, host_buf=None):
             hb = host_buf.numpy() if isinstance(host_buf, torch.Tensor) else np.asarray(host_buf)
             for j in flagged:
                 i = int(dv[j])
-                px = np.ascontiguousarray(JpegFile(None, hb[int(d[i, 0]):int(d[i, 0]) + int(d[i, 28])]).pillow())
+                px = np.array(JpegFile(None, hb[int(d[i, 0]):int(d[i, 0]) + int(d[i, 28])]).pillow())      # a writable copy (from_numpy warns on Pillow's read-only view)
                 t = torch.from_numpy(px).to(dev)
                 keep.append(t)
                 table[i] = (t.data_ptr(), px.shape[0], px.shape[1], 0, px.shape[2])
