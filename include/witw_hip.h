@@ -463,7 +463,7 @@ int witw_jpeg_to_rgb(const void* planes, const void* images, int n_images, long 
  * (8-byte aligned, 24 readable bytes behind the end), address of the file's plan (host side: witw_jpeg_entropy_plan in
  * libwitw_jpeg.so -- header fields, Huffman tables, byte offset of every interval; a byte scan, no Huffman decoding), address of the
  * file's coefficient area int16 [blocks][64] (zero-filled by the caller), file length}; max_intervals: the largest interval count of a
- * file of the launch (grid sizing: one wave per 64 intervals of a file); errors: DEVICE int32 [n_files], zeroed by the
+ * file of the launch (grid sizing: one workgroup per 256 intervals of a file); errors: DEVICE int32 [n_files], zeroed by the
  * caller, 1 where a file's entropy-coded data is damaged, 2 for a bad plan. Coefficients bit-identical to the host decoder's
  * (witw_jpeg_decode_coef); witw_jpeg_idct / witw_jpeg_to_rgb take it from there. */
 int witw_jpeg_huffman(const void* files, int n_files, int max_intervals, int* errors, void* stream);

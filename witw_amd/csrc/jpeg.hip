@@ -162,16 +162,19 @@ __global__ __launch_bounds__(256) void jpeg_to_rgb_kernel(const unsigned char* _
 
 // ---- entropy decoding on the device (round 6; SURVEY 8(f)3 'decode ... entirely on device'), step one: files that carry RESTART
 // MARKERS. A restart interval starts byte-aligned with the DC predictors reset, so intervals decode independently: ONE THREAD PER
-// INTERVAL (a 512 x 512 4:2:0 file written with a marker per MCU row has 32 of them, a batch of 128 pairs ~5,900), one wave per
-// file. The host's share shrinks to a byte scan for the markers (csrc_host/jpeg_coef.cpp, witw_jpeg_entropy_plan: the plan layout is
+// INTERVAL (a 512 x 512 4:2:0 file written with a marker per MCU row has 32 of them, with one per 2 MCUs 512), one workgroup per 256
+// intervals of a file. The host's share shrinks to a byte scan for the markers (csrc_host/jpeg_coef.cpp, witw_jpeg_entropy_plan: the plan layout is
 // described there) and the FILE BYTES cross PCIe instead of the coefficient blocks (~80 KB instead of 786 KB per overhead image).
 // Integer / byte work, latency-bound per thread (a table look-up and a few shifts per symbol); nothing here is MFMA- or
-// HBM-shaped. Same coefficients, bit for bit, as witw_jpeg_decode_coef (tests/test_jpeg_gpu.py).
+// HBM-shaped. A wave pays for every path ANY of its 64 lanes takes, so the rare paths are kept short: four input bytes at a time while
+// no FF is among them, codes longer than the look-up by seven compares instead of a loop, the zig-zag order from the LDS. Same coefficients, bit for bit, as witw_jpeg_decode_coef (tests/test_jpeg_gpu.py).
 struct HuffLds {
     unsigned short look[512];      // 9-bit prefix -> (code length << 8) | symbol; 0: the code is longer than 9 bits
     int maxcode[18];               // largest code of each length (-1: none), [17] = sentinel
     int valoff[17];                // symbol index of the first code of a length minus that code
     unsigned char sym[256];
+    unsigned lim[8];               // codes longer than 9 bits: lim[j] = the first 16-bit left-aligned value ABOVE every code of length
+                                   // <= 10 + j (non-decreasing; a length without codes repeats its predecessor's), [7] unused
 };
 
 struct JpegFileDev {               // int64 x 4 per file
@@ -185,11 +188,18 @@ __constant__ unsigned char kZigZag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24
                                           41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
                                           30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
-template <bool STUFFED>
+// Addresses that arrive as integers (descriptor rows) carry no address space: dereferenced as plain pointers they become FLAT accesses,
+// which count on the LDS counter as well as on the memory counter. The Huffman kernels name the space of everything they touch.
+#define WITW_AS_GLOBAL __attribute__((address_space(1)))
+#define WITW_AS_LDS __attribute__((address_space(3)))
+typedef const WITW_AS_GLOBAL unsigned long long* GlobalWords;
+typedef const WITW_AS_LDS unsigned long long* LdsWords;      // a copy of the bytes in the LDS (jpeg_huffman_kernel)
+
+template <bool STUFFED, typename WP = GlobalWords>
 struct BitReaderT {                // STUFFED: over the file's bytes of one restart interval: FF 00 -> FF on the fly, any other FF xx ends the
                                    // data; !STUFFED: over an unstuffed copy (jpeg_selfsync_kernel), positions are plain bit indices
-    const unsigned long long* words;
-    unsigned pos, end;             // byte offsets in the file
+    WP words;
+    unsigned pos, end;             // byte offsets from `words`
     unsigned long long cache;      // the aligned 8 bytes that hold byte `pos`
     unsigned long long ahead;      // ... and the 8 bytes behind them, requested when `cache` was taken (the stream is read in order:
                                    // the load's round trip runs under the decoding of the current word instead of in front of the next)
@@ -207,8 +217,29 @@ struct BitReaderT {                // STUFFED: over the file's bytes of one rest
         }
         return (unsigned)(cache >> (8 * (p & 7))) & 0xffu;
     }
-    __device__ __forceinline__ void fill() {      // tops up to more than 56 valid bits
-        while (n <= 56) {
+    // Tops up to at least 32 valid bits (!STUFFED: to more than 56). STUFFED, called with n <= 32: the next FOUR bytes at once
+    // when none of them is an FF (no stuffing, no marker) -- in a wave of 64 readers the byte-wise loop otherwise runs on nearly every
+    // symbol for the one lane that needs it.
+    __device__ __forceinline__ void fill() {
+        if (STUFFED && n <= 32 && pos + 4u <= end) {
+            const unsigned w = pos >> 3;
+            if (w != cidx) {
+                cache = (w == cidx + 1u) ? ahead : words[w];
+                cidx = w;
+                ahead = words[w + 1u];
+            }
+            const unsigned s = (pos & 7u) * 8u;
+            unsigned w32 = (unsigned)(cache >> s);
+            if (s > 32u) w32 |= (unsigned)(ahead << (64u - s));
+            const unsigned x = ~w32;
+            if ((((x - 0x01010101u) & w32) & 0x80808080u) == 0u) {      // no byte of x is zero: no FF among the four
+                buf |= (unsigned long long)__builtin_bswap32(w32) << (32 - n);
+                n += 32;
+                pos += 4u;
+                return;
+            }
+        }
+        while (n <= (STUFFED ? 31 : 56)) {      // (STUFFED: the four-byte step takes over again as soon as it can)
             unsigned b = 0;
             if (pos < end) {
                 b = raw(pos);
@@ -232,18 +263,18 @@ struct BitReaderT {                // STUFFED: over the file's bytes of one rest
         n -= k;
         return v;
     }
-    __device__ __forceinline__ void start(const void* base, unsigned byte_pos, unsigned byte_end) {
-        words = reinterpret_cast<const unsigned long long*>(base);
+    __device__ __forceinline__ void start(WP base, unsigned byte_pos, unsigned byte_end) {
+        words = base;
         pos = byte_pos; end = byte_end;
         cidx = 0xfffffff0u; cache = 0; ahead = 0; buf = 0; n = 0; starved = 0;
     }
     // !STUFFED: index of the next unread bit (zero bytes fed behind the end of the data count as read: the position keeps advancing)
     __device__ __forceinline__ unsigned bit_pos() const { return (pos + (unsigned)starved) * 8u - (unsigned)n; }
 };
-typedef BitReaderT<true> BitReader;
 
-template <typename BR>
-__device__ __forceinline__ int huff_decode(BR& b, const HuffLds& h) {      // caller has >= 32 valid bits; -1: invalid code
+template <typename BR, typename HP>      // HP: pointer to a HuffLds (jpeg_huffman_kernel: typed as an LDS pointer -- a pointer the compiler cannot place becomes a flat access)
+__device__ __forceinline__ int huff_decode(BR& b, HP hp) {      // caller has >= 32 valid bits; -1: invalid code
+    auto& h = *hp;
     const unsigned e = h.look[(unsigned)(b.buf >> 55)];
     if (e) {
         const int len = (int)(e >> 8);
@@ -251,25 +282,35 @@ __device__ __forceinline__ int huff_decode(BR& b, const HuffLds& h) {      // ca
         b.n -= len;
         return (int)(e & 255u);
     }
-    int len = 10;
-    int code = (int)(b.buf >> 54);
-    while (code > h.maxcode[len]) {
-        ++len;
-        if (len > 16) return -1;
-        code = (int)(b.buf >> (64 - len));
+    // longer than 9 bits (a few per cent of the symbols -- but of 64 lanes one nearly always): the length by comparing against the
+    // limits of the lengths 10..16, no loop
+    const unsigned c16 = (unsigned)(b.buf >> 48);
+    int len = 10, vo = h.valoff[10];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const bool above = c16 >= h.lim[j];
+        len += above ? 1 : 0;
+        vo = above ? h.valoff[11 + j] : vo;
     }
+    if (c16 >= h.lim[6]) return -1;
+    const int code = (int)(c16 >> (16 - len));
     b.buf <<= len;
     b.n -= len;
-    return h.sym[(code + h.valoff[len]) & 255];
+    return h.sym[(code + vo) & 255];
 }
 
 __device__ __forceinline__ int jpeg_extend(int v, int s) { return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v; }
 
 // The four decoding tables (DC slot 0, 1, AC slot 0, 1) from the DHT counts / symbols of the plan: threads 0-3 assign the canonical codes
 // of one table each (16 lengths), then all threads fill the 9-bit look-ups. Ends with a workgroup barrier.
-__device__ __forceinline__ void build_huff_tables(HuffLds (&tab)[4], const unsigned char* plan, int lane, int nthreads) {
+template <typename PP>      // PP: pointer to the plan's bytes
+__device__ __forceinline__ void build_huff_tables(HuffLds (&tab)[4], PP plan, int lane, int nthreads) {
+    for (int e = lane; e < 4 * 256; e += nthreads) {      // the symbols (a DC table has at most 16; nothing past a table's count is ever indexed)
+        const int t = e >> 8, i = e & 255;
+        tab[t].sym[i] = t < 2 ? (i < 16 ? plan[128 + 32 * t + 16 + i] : 0) : plan[192 + 272 * (t - 2) + 16 + i];
+    }
     if (lane < 4) {
-        const unsigned char* d = lane < 2 ? plan + 128 + 32 * lane : plan + 192 + 272 * (lane - 2);
+        const PP d = lane < 2 ? plan + 128 + 32 * lane : plan + 192 + 272 * (lane - 2);
         HuffLds& h = tab[lane];
         int code = 0, k = 0;
         for (int len = 1; len <= 16; ++len) {
@@ -278,24 +319,24 @@ __device__ __forceinline__ void build_huff_tables(HuffLds (&tab)[4], const unsig
             k += cnt;
             code += cnt;
             h.maxcode[len] = cnt ? code - 1 : -1;
+            if (len >= 10) h.lim[len - 10] = (unsigned)code << (16 - len);
             code <<= 1;
         }
         h.maxcode[17] = 0x7fffffff;
         h.maxcode[0] = -1;
         h.valoff[0] = 0;
-        const int nsym = lane < 2 ? (k < 16 ? k : 16) : (k < 256 ? k : 256);
-        for (int i = 0; i < 256; ++i) h.sym[i] = i < nsym ? d[16 + i] : 0;
+        h.lim[7] = 0x10000u;
     }
     __syncthreads();
+    // 9-bit look-ups. Canonical codes: the first length whose largest code is not below the prefix holds it (a prefix below that
+    // length's first code would have matched a shorter length already)
     for (int e = lane; e < 4 * 512; e += nthreads) {
         const int t = e >> 9, i = e & 511;
-        const unsigned char* d = t < 2 ? plan + 128 + 32 * t : plan + 192 + 272 * (t - 2);
         const HuffLds& h = tab[t];
         unsigned short v = 0;
         for (int len = 1; len <= 9; ++len) {
             const int code = i >> (9 - len);
-            const int cnt = d[len - 1];
-            if (cnt && code <= h.maxcode[len] && code > h.maxcode[len] - cnt) {
+            if (code <= h.maxcode[len]) {
                 v = (unsigned short)((len << 8) | h.sym[(code + h.valoff[len]) & 255]);
                 break;
             }
@@ -305,72 +346,132 @@ __device__ __forceinline__ void build_huff_tables(HuffLds (&tab)[4], const unsig
     __syncthreads();
 }
 
-__global__ __launch_bounds__(64) void jpeg_huffman_kernel(const JpegFileDev* __restrict__ files, int* __restrict__ errors) {
+constexpr int HUFF_T = 256;         // threads per workgroup of jpeg_huffman_kernel: the four tables are built once for 256 intervals
+constexpr int HUFF_STAGE = 10 * 1024;      // bytes of LDS per wave for the entropy-coded bytes of its 64 intervals (a marker per MCU at
+                                           // quality 90: ~7 KB). 46 KB per workgroup: three of them per CU -- a wave's chain of symbols is pure
+                                           // latency, so the kernel's rate is the number of waves a SIMD can interleave
+
+struct HuffCtx {                    // what decoding an interval needs besides its reader (uniform over the workgroup)
+    const WITW_AS_LDS HuffLds* tab;
+    const WITW_AS_LDS int* hdr;
+    const WITW_AS_LDS unsigned char* zz;
+    WITW_AS_GLOBAL short* coef;
+    int mcux, ncomp;
+};
+
+// One restart interval: MCUs m0 .. m1 - 1 from the reader's position. False: damaged data.
+template <typename WP>
+__device__ __forceinline__ bool huff_interval(BitReaderT<true, WP>& b, const HuffCtx& x, long long m0, long long m1) {
+    int pred[3] = {0, 0, 0};
+    int my = (int)(m0 / x.mcux), mx = (int)(m0 - (long long)my * x.mcux);
+    for (long long m = m0; m < m1; ++m) {
+        for (int k = 0; k < x.ncomp; ++k) {
+            const int c = x.hdr[28 + k];
+            const WITW_AS_LDS int* q = x.hdr + 6 + 7 * c;
+            const int ch = q[0], cv = q[1], cbw = q[2];
+            const long long coff = q[4];
+            const WITW_AS_LDS HuffLds* hd = x.tab + (q[5] & 1);
+            const WITW_AS_LDS HuffLds* ha = x.tab + 2 + (q[6] & 1);
+            for (int v = 0; v < cv; ++v)
+                for (int hh = 0; hh < ch; ++hh) {
+                    WITW_AS_GLOBAL short* blk = x.coef + (coff + (long long)(my * cv + v) * cbw + (mx * ch + hh)) * 64;
+                    if (b.n < 32) b.fill();
+                    int s = huff_decode(b, hd);
+                    if (s < 0 || s > 15) return false;
+                    if (s) pred[c] += jpeg_extend(b.get(s), s);
+                    blk[0] = (short)pred[c];
+                    for (int kk = 1; kk < 64;) {
+                        if (b.n < 32) b.fill();
+                        const int rs = huff_decode(b, ha);
+                        if (rs < 0) return false;
+                        const int r = rs >> 4;
+                        s = rs & 15;
+                        if (s == 0) {
+                            if (r != 15) break;
+                            kk += 16;
+                            continue;
+                        }
+                        kk += r;
+                        if (kk > 63) return false;
+                        blk[x.zz[kk]] = (short)jpeg_extend(b.get(s), s);
+                        ++kk;
+                    }
+                    // bits consumed that were never in the interval (zero bytes fed behind its end): the data ended inside it
+                    // (witw_jpeg_decode_coef: -3)
+                    if (b.starved * 8 > b.n) return false;
+                }
+        }
+        if (++mx == x.mcux) { mx = 0; ++my; }
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(HUFF_T) void jpeg_huffman_kernel(const JpegFileDev* __restrict__ files, int* __restrict__ errors) {
     __shared__ HuffLds tab[4];                    // DC slot 0, 1, AC slot 0, 1
     __shared__ int hdr[32];
-    const int lane = threadIdx.x;
+    __shared__ unsigned char zz[64];
+    __shared__ __attribute__((aligned(16))) unsigned long long stage[HUFF_T / 64][HUFF_STAGE / 8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const JpegFileDev f = files[blockIdx.x];
-    const unsigned char* plan = reinterpret_cast<const unsigned char*>(f.plan);
-    // blockIdx.y: which 64 intervals of the file this wave decodes (a thread's chain of symbols is what bounds the kernel: files with
-    // short intervals spread over several waves); waves past the file's last interval leave before building tables
-    if ((int)blockIdx.y * 64 >= reinterpret_cast<const int*>(plan)[1] && reinterpret_cast<const int*>(plan)[0] == 0x3157504A) return;
-    if (lane < 32) hdr[lane] = reinterpret_cast<const int*>(plan)[lane];
-    build_huff_tables(tab, plan, lane, 64);
+    const WITW_AS_GLOBAL unsigned char* plan = (const WITW_AS_GLOBAL unsigned char*)f.plan;
+    // blockIdx.y: which 256 intervals of the file this workgroup decodes (a thread's chain of symbols is what bounds the kernel: files
+    // with short intervals spread over several workgroups); workgroups past the file's last interval leave before building tables
+    if ((int)blockIdx.y * HUFF_T >= ((const WITW_AS_GLOBAL int*)plan)[1] && ((const WITW_AS_GLOBAL int*)plan)[0] == 0x3157504A) return;
+    if (tid < 32) hdr[tid] = ((const WITW_AS_GLOBAL int*)plan)[tid];
+    if (tid >= 64 && tid < 128) zz[tid - 64] = kZigZag[tid - 64];
+    build_huff_tables(tab, plan, tid, HUFF_T);
     if (hdr[0] != 0x3157504A) {
-        if (lane == 0 && blockIdx.y == 0) errors[blockIdx.x] = 2;
+        if (tid == 0 && blockIdx.y == 0) errors[blockIdx.x] = 2;
         return;
     }
-    const int n_int = hdr[1], restart = hdr[2], mcux = hdr[3], mcuy = hdr[4], ncomp = hdr[5];
-    const unsigned end_all = (unsigned)hdr[27];
-    const unsigned* ioff = reinterpret_cast<const unsigned*>(plan + 736);
-    short* coef = reinterpret_cast<short*>(f.coef);
-    const long long mcus = (long long)mcux * mcuy;
+    const int n_int = hdr[1], restart = hdr[2], mcuy = hdr[4];
+    const unsigned n_bytes = (unsigned)f.n_bytes;
+    const unsigned end_all = min((unsigned)hdr[27], n_bytes);
+    const WITW_AS_GLOBAL unsigned* ioff = (const WITW_AS_GLOBAL unsigned*)(plan + 736);
+    HuffCtx x;
+    x.tab = (const WITW_AS_LDS HuffLds*)tab; x.hdr = (const WITW_AS_LDS int*)hdr; x.zz = (const WITW_AS_LDS unsigned char*)zz;
+    x.coef = (WITW_AS_GLOBAL short*)f.coef; x.mcux = hdr[3]; x.ncomp = hdr[5];
+    const long long mcus = (long long)x.mcux * mcuy;
     bool bad = false;
-    for (int iv = (int)blockIdx.y * 64 + lane; iv < n_int; iv += 64 * (int)gridDim.y) {
-        BitReader b;
-        unsigned iend = iv + 1 < n_int ? ioff[iv + 1] : end_all;      // (the RSTn marker in front of the next interval stops the reader earlier)
-        if (iend > (unsigned)f.n_bytes) iend = (unsigned)f.n_bytes;
-        b.start(reinterpret_cast<const void*>(f.bytes), ioff[iv], iend);
-        int pred[3] = {0, 0, 0};
-        const long long m0 = (long long)iv * restart;
-        const long long m1 = m0 + restart < mcus ? m0 + restart : mcus;
-        for (long long m = m0; m < m1 && !bad; ++m) {
-            const int my = (int)(m / mcux), mx = (int)(m - (long long)my * mcux);
-            for (int k = 0; k < ncomp && !bad; ++k) {
-                const int c = hdr[28 + k];
-                const int* q = hdr + 6 + 7 * c;
-                const int ch = q[0], cv = q[1], cbw = q[2];
-                const long long coff = q[4];
-                const HuffLds& hd = tab[q[5] & 1];
-                const HuffLds& ha = tab[2 + (q[6] & 1)];
-                for (int v = 0; v < cv && !bad; ++v)
-                    for (int hh = 0; hh < ch && !bad; ++hh) {
-                        short* blk = coef + (coff + (long long)(my * cv + v) * cbw + (mx * ch + hh)) * 64;
-                        b.fill();
-                        int s = huff_decode(b, hd);
-                        if (s < 0 || s > 15) { bad = true; break; }
-                        if (s) pred[c] += jpeg_extend(b.get(s), s);
-                        blk[0] = (short)pred[c];
-                        for (int kk = 1; kk < 64;) {
-                            if (b.n < 32) b.fill();
-                            const int rs = huff_decode(b, ha);
-                            if (rs < 0) { bad = true; break; }
-                            const int r = rs >> 4;
-                            s = rs & 15;
-                            if (s == 0) {
-                                if (r != 15) break;
-                                kk += 16;
-                                continue;
-                            }
-                            kk += r;
-                            if (kk > 63) { bad = true; break; }
-                            blk[kZigZag[kk]] = (short)jpeg_extend(b.get(s), s);
-                            ++kk;
-                        }
-                        if (b.starved > 9) bad = true;      // the data ended inside the interval (witw_jpeg_decode_coef: -3)
-                    }
+    for (int base = (int)blockIdx.y * HUFF_T; base < n_int; base += HUFF_T * (int)gridDim.y) {      // (one pass unless the file has > 16,384 intervals)
+        // The entropy-coded bytes of this wave's 64 consecutive intervals are one contiguous piece of the file: copied to the LDS with
+        // coalesced loads when they fit, so that no global load (and no wait for the coefficient stores in flight: loads and stores
+        // share the wave's memory counter) sits in any lane's chain of symbols. Longer intervals are read from global memory.
+        const int iv0 = base + wave * 64, iv = iv0 + lane;
+        const int iv_last = min(iv0 + 64, n_int);
+        unsigned r0 = 0, r1 = 0;
+        if (iv0 < n_int) {
+            r0 = min(ioff[iv0], n_bytes) & ~7u;
+            r1 = iv_last < n_int ? min(ioff[iv_last], n_bytes) : end_all;
+        }
+        const bool staged = r1 > r0 && r1 - r0 + 24u <= (unsigned)HUFF_STAGE;
+        if (staged) {      // up to 16 bytes behind r1 are read ahead (the file has 24 readable bytes behind its end)
+            const WITW_AS_GLOBAL unsigned char* src = (const WITW_AS_GLOBAL unsigned char*)f.bytes + r0;
+            for (unsigned o = (unsigned)lane * 16u; o < r1 - r0 + 16u; o += 1024u) {
+                const unsigned long long lo = *(GlobalWords)(src + o);
+                const unsigned long long hi = *(GlobalWords)(src + o + 8);
+                stage[wave][o >> 3] = lo;
+                stage[wave][(o >> 3) + 1] = hi;
             }
         }
+        __syncthreads();
+        if (iv < n_int && !bad) {
+            unsigned i0 = min(ioff[iv], n_bytes);
+            unsigned i1 = iv + 1 < n_int ? min(ioff[iv + 1], n_bytes) : end_all;      // (the RSTn marker in front of the next interval stops the reader earlier)
+            if (i1 < i0) i1 = i0;
+            const long long m0 = (long long)iv * restart;
+            const long long m1 = m0 + restart < mcus ? m0 + restart : mcus;
+            if (staged && i0 >= r0 && i1 <= r1) {
+                BitReaderT<true, LdsWords> b;
+                b.start((LdsWords)&stage[wave][0], i0 - r0, i1 - r0);
+                bad = !huff_interval(b, x, m0, m1);
+            } else {
+                BitReaderT<true, GlobalWords> b;
+                b.start((GlobalWords)f.bytes, i0, i1);
+                bad = !huff_interval(b, x, m0, m1);
+            }
+        }
+        __syncthreads();
     }
     if (bad) errors[blockIdx.x] = 1;
 }
@@ -484,7 +585,7 @@ __global__ __launch_bounds__(SS_T) void jpeg_selfsync_kernel(const JpegSyncDev* 
     auto run = [&](SyncState st, unsigned limit, auto write_c, long long blk0) -> SyncState {
         constexpr bool WRITE = decltype(write_c)::value;
         BitReaderT<false> b;
-        b.start(clean, st.p >> 3, (unsigned)n_clean);
+        b.start((GlobalWords)clean, st.p >> 3, (unsigned)n_clean);
         b.fill();
         if (st.p & 7u) { b.buf <<= (st.p & 7u); b.n -= (int)(st.p & 7u); }
         unsigned bq = st.b, kq = st.k;
@@ -508,14 +609,14 @@ __global__ __launch_bounds__(SS_T) void jpeg_selfsync_kernel(const JpegSyncDev* 
             const int* q = hdr + 6 + 7 * c;
             bool finished = false;
             if (kq == 0) {
-                const int sdc = huff_decode(b, tab[q[5] & 1]);
+                const int sdc = huff_decode(b, &tab[q[5] & 1]);
                 if (sdc < 0 || sdc > 15) { b.buf <<= 1; b.n -= 1; continue; }      // not a code (only ever out of step): slide one bit on
                 int diff = 0;
                 if (sdc) diff = jpeg_extend(b.get(sdc), sdc);
                 if (WRITE && blk) blk[0] = (short)diff;
                 kq = 1;
             } else {
-                const int rs = huff_decode(b, tab[2 + (q[6] & 1)]);
+                const int rs = huff_decode(b, &tab[2 + (q[6] & 1)]);
                 if (rs < 0) { b.buf <<= 1; b.n -= 1; continue; }
                 const int r = rs >> 4, sz = rs & 15;
                 if (sz == 0) {
@@ -621,16 +722,16 @@ int witw_jpeg_huffman_selfsync(const void* files, int n_files, int* errors, void
 // Entropy decoding of n_files JPEG files WITH RESTART MARKERS on the device, one thread per restart interval: files = DEVICE int64
 // [n_files][4] = {address of the file bytes (8-byte aligned, 24 readable bytes behind the end), address of the file's plan
 // (witw_jpeg_entropy_plan, 4-byte aligned), address of its coefficient area int16 [blocks][64] (zero-filled by the caller), file
-// length}; max_intervals = the largest number of restart intervals of a file of the launch (sizes the grid: one wave per 64
+// length}; max_intervals = the largest number of restart intervals of a file of the launch (sizes the grid: one workgroup per 256
 // intervals of a file); errors = DEVICE int32 [n_files], zeroed by the caller: 1 where the entropy-coded data of a file is damaged (its
 // coefficients are then incomplete: witw_jpeg_decode_coef returns -3 for such a file), 2 for a bad plan. The coefficients are the
 // bits witw_jpeg_decode_coef writes; witw_jpeg_idct / witw_jpeg_to_rgb take it from there (model/cvig_fov.py:88-89).
 int witw_jpeg_huffman(const void* files, int n_files, int max_intervals, int* errors, void* stream) {
     WITW_CHECK_ARG(files && errors, "jpeg_huffman: null pointer");
     WITW_CHECK_ARG(n_files > 0 && max_intervals > 0, "jpeg_huffman: %d files, %d intervals", n_files, max_intervals);
-    int waves = (max_intervals + 63) / 64;      // per file; at most 64 (a file with more than 4096 intervals loops)
-    if (waves > 64) waves = 64;
-    hipLaunchKernelGGL(jpeg_huffman_kernel, dim3((unsigned)n_files, (unsigned)waves), dim3(64), 0, (hipStream_t)stream,
+    int groups = (max_intervals + HUFF_T - 1) / HUFF_T;      // per file; at most 64 (a file with more than 16,384 intervals loops)
+    if (groups > 64) groups = 64;
+    hipLaunchKernelGGL(jpeg_huffman_kernel, dim3((unsigned)n_files, (unsigned)groups), dim3(HUFF_T), 0, (hipStream_t)stream,
                        (const JpegFileDev*)files, errors);
     WITW_CHECK_LAUNCH("jpeg_huffman");
     return WITW_OK;

@@ -1513,37 +1513,53 @@ class GpuPreprocess(object):
             raise _lib.WitwError('no gfx950 device: the WITW transforms run on the GPU only')
         return dev
 
-    def _stage_side(self, st, dev, images=None, packed=None, pinned=False):
-        if packed is not None:
-            buf, desc, kind = packed
-        elif all(isinstance(t, torch.Tensor) and t.is_cuda for t in images):        # already resident: point at them
+    def _copy_side(self, st, dev, packed, pinned=False):
+        """one packed block: pinned (unless it sits in the ring already) and queued for the device -> (dbuf, desc, kind, host block)"""
+        buf, desc, kind = packed
+        if not pinned and not buf.is_pinned():
+            buf = buf.pin_memory()
+        dbuf = buf.to(dev, non_blocking=True)
+        st.keep += [dbuf] if pinned else [dbuf, buf]
+        return dbuf, desc, kind, buf
+
+    def _table_side(self, st, copied):
+        """copied: the _copy_side results of ONE side of a batch (one per part) -> (descriptor table over all parts, image kind, finish).
+        JPEG parts (jpeg.KIND_JPEG: file bytes or coefficient blocks -> [Huffman decoding,] dequantise, inverse DCT, upsample,
+        colour-convert on the device) are decoded by launches that cover every part; finish (None or a callable) must run before the
+        table is used: it reads the device decoder's damage flags and patches the rows of re-decoded files."""
+        kinds = set(c[2] for c in copied)
+        if kinds == {2}:
+            from . import jpeg
+            keep, table, finish = jpeg.decode_packed_multi([(dbuf, desc, buf) for dbuf, desc, _k, buf in copied], defer=True)
+            st.keep += keep
+            if int(table[:, 4].min()) < self.channels:
+                raise _lib.WitwError('an image of the batch has %d channels, the model takes %d' % (int(table[:, 4].min()), self.channels))
+            return table, 1, finish      # from here on: uint8 HWC images on the device
+        if len(kinds) > 1:
+            raise _lib.WitwError('the parts of a grouped batch hold different image kinds (fp32 CHW / u8 HWC)')
+        tables = []
+        for dbuf, desc, kind, _buf in copied:
+            if int(desc[:, 3].min()) < self.channels:
+                raise _lib.WitwError('an image of the batch has %d channels, the model takes %d' % (int(desc[:, 3].min()), self.channels))
+            table = torch.empty((desc.shape[0], 5), dtype=torch.int64)
+            table[:, 0] = desc[:, 0] + dbuf.data_ptr()
+            table[:, 1:3] = desc[:, 1:3]
+            table[:, 3] = 0
+            table[:, 4] = desc[:, 3]
+            tables.append(table)
+        return (tables[0] if len(tables) == 1 else torch.cat(tables)), copied[0][2], None
+
+    def _stage_side(self, st, dev, images):
+        """a list of images (resident tensors, or host tensors / JpegCoef / JpegFile objects to pack here) -> (table, kind, finish)"""
+        if all(isinstance(t, torch.Tensor) and t.is_cuda for t in images):        # already resident: point at them
             rows = []
             for t in images:
                 t = t.to(torch.float32).contiguous()
                 st.keep.append(t)
                 rows.append((t.data_ptr(), t.shape[1], t.shape[2], 0, t.shape[0]))
-            return torch.tensor(rows, dtype=torch.int64).to(dev, non_blocking=True), 0
-        else:
-            buf, desc, kind = _pack_side([t.cpu() if isinstance(t, torch.Tensor) else t for t in images])
-        if not pinned and not buf.is_pinned():
-            buf = buf.pin_memory()
-        dbuf = buf.to(dev, non_blocking=True)
-        st.keep += [dbuf] if pinned else [dbuf, buf]
-        if kind == 2:      # jpeg.KIND_JPEG: coefficient blocks -> dequantise, inverse DCT, upsample, colour-convert on the device
-            from . import jpeg
-            keep, table = jpeg.decode_packed(dbuf, desc, host_buf=buf)
-            st.keep += keep
-            if int(table[:, 4].min()) < self.channels:
-                raise _lib.WitwError('an image of the batch has %d channels, the model takes %d' % (int(table[:, 4].min()), self.channels))
-            return table, 1      # from here on: uint8 HWC images on the device
-        if int(desc[:, 3].min()) < self.channels:
-            raise _lib.WitwError('an image of the batch has %d channels, the model takes %d' % (int(desc[:, 3].min()), self.channels))
-        table = torch.empty((desc.shape[0], 5), dtype=torch.int64)
-        table[:, 0] = desc[:, 0] + dbuf.data_ptr()
-        table[:, 1:3] = desc[:, 1:3]
-        table[:, 3] = 0
-        table[:, 4] = desc[:, 3]
-        return table, kind
+            return torch.tensor(rows, dtype=torch.int64).to(dev, non_blocking=True), 0, None
+        packed = _pack_side([t.cpu() if isinstance(t, torch.Tensor) else t for t in images])
+        return self._table_side(st, [self._copy_side(st, dev, packed)])
 
     def stage(self, batch, starts=None):
         """batch: one raw / packed batch, or a LIST of them that become ONE staged batch (DevicePrefetcher(group=g): the loader
@@ -1553,6 +1569,7 @@ class GpuPreprocess(object):
         st = StagedBatch()
         parts = batch if isinstance(batch, (list, tuple)) else [batch]
         s_tabs, o_tabs, idx = [], [], []
+        s_copied, o_copied, ring_slots, finishers = [], [], [], []
         for part in parts:
             if part.get('packed'):
                 ring_slot = None
@@ -1561,26 +1578,39 @@ class GpuPreprocess(object):
                         raise _lib.WitwError('a batch built in a PinnedRing reached a GpuPreprocess without `ring`')
                     ring_slot, s_off, s_len, o_off, o_len = part['ring']
                     part = dict(part, surface_bytes=self.ring.view(ring_slot, s_off, s_len), overhead_bytes=self.ring.view(ring_slot, o_off, o_len))
-                s_tab, s_kind = self._stage_side(st, dev, packed=(part['surface_bytes'], part['surface_desc'], part['surface_kind']),
-                                                 pinned=ring_slot is not None)
-                o_tab, o_kind = self._stage_side(st, dev, packed=(part['overhead_bytes'], part['overhead_desc'], part['overhead_kind']),
-                                                 pinned=ring_slot is not None)
-                if ring_slot is not None:
-                    ev = torch.cuda.Event()
-                    ev.record(torch.cuda.current_stream())
-                    self.ring.release_after(ring_slot, ev)
+                    ring_slots.append(ring_slot)
+                # every part's blocks are queued for the device first; the decode launches below then cover all parts at once
+                s_copied.append(self._copy_side(st, dev, (part['surface_bytes'], part['surface_desc'], part['surface_kind']), pinned=ring_slot is not None))
+                o_copied.append(self._copy_side(st, dev, (part['overhead_bytes'], part['overhead_desc'], part['overhead_kind']), pinned=ring_slot is not None))
             else:
-                s_tab, s_kind = self._stage_side(st, dev, images=part['surface'])
-                o_tab, o_kind = self._stage_side(st, dev, images=part['overhead'])
-            if s_tabs and (s_kind != st.s_kind or o_kind != st.o_kind):
-                raise _lib.WitwError('the parts of a grouped batch hold different image kinds (fp32 CHW / u8 HWC)')
-            st.s_kind, st.o_kind = s_kind, o_kind
-            s_tabs.append(s_tab)
-            o_tabs.append(o_tab)
+                if s_copied:
+                    raise _lib.WitwError('the parts of a grouped batch are packed and unpacked')
+                s_tab, s_kind, f1 = self._stage_side(st, dev, part['surface'])
+                o_tab, o_kind, f2 = self._stage_side(st, dev, part['overhead'])
+                finishers += [f for f in (f1, f2) if f is not None]
+                if s_tabs and (s_kind != st.s_kind or o_kind != st.o_kind):
+                    raise _lib.WitwError('the parts of a grouped batch hold different image kinds (fp32 CHW / u8 HWC)')
+                st.s_kind, st.o_kind = s_kind, o_kind
+                s_tabs.append(s_tab)
+                o_tabs.append(o_tab)
             if part.get('idx') is not None:
                 idx += list(part['idx'])
+        if s_copied:
+            if s_tabs:
+                raise _lib.WitwError('the parts of a grouped batch are packed and unpacked')
+            s_tab, st.s_kind, f1 = self._table_side(st, s_copied)
+            o_tab, st.o_kind, f2 = self._table_side(st, o_copied)
+            finishers += [f for f in (f1, f2) if f is not None]
+            s_tabs, o_tabs = [s_tab], [o_tab]
+        for f in finishers:      # the device decoder's damage flags: ONE host wait per batch, behind every launch of the staging
+            f()
+        if ring_slots:           # (the host blocks were still needed for files Pillow re-decodes)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            for slot in ring_slots:
+                self.ring.release_after(slot, ev)
         st.idx = idx if idx else None
-        if len(parts) == 1:
+        if len(s_tabs) == 1:
             s_tab, o_tab = s_tabs[0], o_tabs[0]
         else:
             s_tab, o_tab = torch.cat(s_tabs), torch.cat(o_tabs)

@@ -265,16 +265,15 @@ def decode_tables(d):
     return planes, images, int(flat.sum()), int(flat.sum()) * 64, int(ob.sum()), qt_base
 
 
-def _decode_group(dbuf, d, coef_ptr, qt_ptr):
+def _decode_group(dev, d, coef_ptr, qt_ptr):
     """dequantisation + inverse DCT + upsampling + colour conversion of the JPEG entries d (descriptor rows whose column 0 is the
-    byte offset of their coefficient blocks from coef_ptr) -> (tensors to keep alive, device address of every decoded image,
-    components per image). Two launches."""
+    byte offset of their coefficient blocks from coef_ptr, column 1 that of their quantisation tables from qt_ptr) -> (tensors to keep
+    alive, device address of every decoded image, components per image). Two launches."""
     from . import _lib, ops
     try:
         planes, images, blk, pbytes, obytes, qt_base = decode_tables(d)
     except ValueError as e:
         raise _lib.WitwError(str(e))
-    dev = dbuf.device
     plane_t = torch.from_numpy(planes).pin_memory().to(dev, non_blocking=True)
     image_t = torch.from_numpy(images).pin_memory().to(dev, non_blocking=True)
     comp = torch.empty((pbytes,), dtype=torch.uint8, device=dev)
@@ -287,30 +286,49 @@ def _decode_group(dbuf, d, coef_ptr, qt_ptr):
     return [plane_t, image_t, comp, rgb], rgb.data_ptr() + images[:, 11], images[:, 2]
 
 
-def decode_packed(dbuf, desc, host_buf=None):
-    """dbuf: the packed block on the GPU; desc: its HOST descriptor table -> (tensors to keep alive, int64 host table [B,5] =
-    {device address, H, W, 0, channels} of the decoded uint8 HWC images: the descriptor rows of
-    witw_resize_bilinear_normalize_batched / witw_polar_from_raw, kind 1). Two launches for the entries whose coefficient blocks
-    came from the host; for the entries that travelled as file bytes (restart markers: DEVICE_ENTROPY) one more launch in front
-    entropy-decodes them into a coefficient buffer on the device."""
+def decode_packed_multi(parts, defer=False):
+    """parts: [(dbuf, desc, host_buf or None), ...] = the packed blocks of ONE side of a batch, each on the GPU with its HOST descriptor
+    table (a batch arrives in pieces when the loader hands out quarter batches: DevicePrefetcher(group=4)) -> (tensors to keep alive,
+    int64 host table [sum B, 5] = {device address, H, W, 0, channels} of the decoded uint8 HWC images in part order: the descriptor
+    rows of witw_resize_bilinear_normalize_batched / witw_polar_from_raw, kind 1, finish).
+    EVERY LAUNCH COVERS THE FILES OF ALL PARTS (the descriptor rows carry addresses, so the blocks need not be one allocation): two
+    launches for the entries whose coefficient blocks came from the host; for the entries that travelled as file bytes (DEVICE_ENTROPY)
+    one or two more in front entropy-decode them into a coefficient buffer on the device -- a thread's chain of symbols bounds
+    jpeg_huffman_kernel, so four launches over 32 files each take four times as long as one over 128.
+    finish: None, or (defer=True, some part came with its host block) a callable that reads the damage flags of the device decoder --
+    the one host wait of the call -- and lets Pillow re-decode flagged files, patching `table` in place; with defer=False that has
+    happened on return."""
     from . import _lib, ops
-    d = desc.numpy() if isinstance(desc, torch.Tensor) else np.asarray(desc)
+    dev = parts[0][0].device
+    ref = min(int(p[0].data_ptr()) for p in parts)      # offsets of every part are re-based to the lowest block (allocations are 512-byte aligned)
+    ds, part_of, off0 = [], [], []
+    for k, (dbuf, desc, _hb) in enumerate(parts):
+        dk = np.array(desc.numpy() if isinstance(desc, torch.Tensor) else desc, dtype=np.int64, copy=True)
+        delta = int(dbuf.data_ptr()) - ref
+        off0.append(dk[:, 0].copy())
+        dk[:, 0] += delta
+        dk[:, 1] += delta
+        if dk.shape[1] > 27:
+            dk[:, 27] += delta
+        ds.append(dk)
+        part_of.append(np.full((dk.shape[0],), k, dtype=np.int64))
+    d, part_of, off0 = np.concatenate(ds), np.concatenate(part_of), np.concatenate(off0)
     B = d.shape[0]
     table = np.zeros((B, 5), dtype=np.int64)
     keep = []
+    finish = None
     is_raw = d[:, 24] != 0
     on_dev = (d[:, 26] != 0) & ~is_raw if d.shape[1] > 26 else np.zeros((B,), dtype=bool)
     table[:, 1], table[:, 2] = d[:, 2], d[:, 3]
-    table[is_raw, 0] = dbuf.data_ptr() + d[is_raw, 0]
+    table[is_raw, 0] = ref + d[is_raw, 0]
     table[is_raw, 4] = d[is_raw, 25]
     jp = np.nonzero(~is_raw & ~on_dev)[0]
     if jp.size:
-        k, addr, ncomp = _decode_group(dbuf, d[jp], dbuf.data_ptr(), dbuf.data_ptr())
+        k, addr, ncomp = _decode_group(dev, d[jp], ref, ref)
         keep += k
         table[jp, 0], table[jp, 4] = addr, ncomp
     dv = np.nonzero(on_dev)[0]
     if dv.size:
-        dev = dbuf.device
         blocks = d[dv, 7]                                        # info[5]: coefficient blocks of the file
         first = np.cumsum(blocks) - blocks
         coef = torch.zeros((int(blocks.sum()) * 64,), dtype=torch.int16, device=dev)
@@ -318,14 +336,15 @@ def decode_packed(dbuf, desc, host_buf=None):
         # files with restart markers: one thread per interval; files without (ONE interval of more than SELFSYNC_MIN_BLOCKS blocks):
         # the self-synchronising kernel, one workgroup per file
         sync = (d[dv, 29] == 1) & (blocks > SELFSYNC_MIN_BLOCKS)
-        rows = np.stack([dbuf.data_ptr() + d[dv, 0], dbuf.data_ptr() + d[dv, 27], coef.data_ptr() + first * 128, d[dv, 28]], axis=1).astype(np.int64)
+        rows = np.stack([ref + d[dv, 0], ref + d[dv, 27], coef.data_ptr() + first * 128, d[dv, 28]], axis=1).astype(np.int64)
         ir = np.nonzero(~sync)[0]
         if ir.size:
             files_t = torch.from_numpy(np.ascontiguousarray(rows[ir])).pin_memory().to(dev, non_blocking=True)
-            e_r = torch.zeros((int(ir.size),), dtype=torch.int32, device=dev)
+            e_r = errors if ir.size == dv.size else torch.zeros((int(ir.size),), dtype=torch.int32, device=dev)
             _lib.check(_lib.load().witw_jpeg_huffman(files_t.data_ptr(), int(ir.size), int(d[dv[ir], 29].max()), e_r.data_ptr(), ops._stream()),
                        'witw_jpeg_huffman')
-            errors[torch.from_numpy(ir).to(dev)] = e_r
+            if e_r is not errors:
+                errors[torch.from_numpy(ir).to(dev)] = e_r
             keep += [files_t, e_r]
         isy = np.nonzero(sync)[0]
         if isy.size:
@@ -334,34 +353,54 @@ def decode_packed(dbuf, desc, host_buf=None):
             scratch = torch.empty((int(sizes.sum()),), dtype=torch.uint8, device=dev)
             srows = np.concatenate([rows[isy], (scratch.data_ptr() + soff)[:, None], np.zeros((isy.size, 1), np.int64)], axis=1).astype(np.int64)
             files_s = torch.from_numpy(np.ascontiguousarray(srows)).pin_memory().to(dev, non_blocking=True)
-            e_s = torch.zeros((int(isy.size),), dtype=torch.int32, device=dev)
+            e_s = errors if isy.size == dv.size else torch.zeros((int(isy.size),), dtype=torch.int32, device=dev)
             _lib.check(_lib.load().witw_jpeg_huffman_selfsync(files_s.data_ptr(), int(isy.size), e_s.data_ptr(), ops._stream()),
                        'witw_jpeg_huffman_selfsync')
-            errors[torch.from_numpy(isy).to(dev)] = e_s
+            if e_s is not errors:
+                errors[torch.from_numpy(isy).to(dev)] = e_s
             keep += [files_s, e_s, scratch]
         dd = d[dv].copy()
         dd[:, 0] = first * 128                                   # where each file's coefficient blocks sit in `coef`
-        k, addr, ncomp = _decode_group(dbuf, dd, coef.data_ptr(), dbuf.data_ptr())
+        k, addr, ncomp = _decode_group(dev, dd, coef.data_ptr(), ref)
         keep += k + [coef, errors]
         table[dv, 0], table[dv, 4] = addr, ncomp
         _ERRORS.append(errors)
         del _ERRORS[:-64]
-        if host_buf is not None and CHECK_ERRORS:
+        if CHECK_ERRORS and any(p[2] is not None for p in parts):
             # A file whose entropy-coded data is damaged is read by the reference through libjpeg, which recovers what it can (with
             # a warning); the host path hands such a file to Pillow inside pack(). Here the damage shows only once the kernel has
             # run: look at the flags (a 4-byte-per-file copy; it waits for THIS stream's staging work, which the drivers run on the
             # copy stream one batch ahead of the encoders) and let Pillow decode the flagged files from the bytes that are still in
             # the host block -- the same image, by the same decoder, as on the host path.
-            flagged = np.nonzero(errors.cpu().numpy())[0]
-            hb = host_buf.numpy() if isinstance(host_buf, torch.Tensor) else np.asarray(host_buf)
-            for j in flagged:
-                i = int(dv[j])
-                px = np.array(JpegFile(None, hb[int(d[i, 0]):int(d[i, 0]) + int(d[i, 28])]).pillow())      # a writable copy (from_numpy warns on Pillow's read-only view)
-                t = torch.from_numpy(px).to(dev)
-                keep.append(t)
-                table[i] = (t.data_ptr(), px.shape[0], px.shape[1], 0, px.shape[2])
-                REPAIRED[0] += 1
-    return keep, torch.from_numpy(table)
+            flags_host = torch.empty((int(dv.size),), dtype=torch.int32).pin_memory()
+            flags_host.copy_(errors, non_blocking=True)
+            flags_ready = torch.cuda.Event()
+            flags_ready.record(torch.cuda.current_stream(dev))
+
+            def finish():
+                flags_ready.synchronize()
+                for j in np.nonzero(flags_host.numpy())[0]:
+                    i = int(dv[j])
+                    hb = parts[int(part_of[i])][2]
+                    if hb is None:
+                        continue
+                    hb = hb.numpy() if isinstance(hb, torch.Tensor) else np.asarray(hb)
+                    px = np.array(JpegFile(None, hb[int(off0[i]):int(off0[i]) + int(d[i, 28])]).pillow())      # a writable copy (from_numpy warns on Pillow's read-only view)
+                    t = torch.from_numpy(px).to(dev)
+                    keep.append(t)
+                    table[i] = (t.data_ptr(), px.shape[0], px.shape[1], 0, px.shape[2])
+                    REPAIRED[0] += 1
+    if finish is not None and not defer:
+        finish()
+        finish = None
+    return keep, torch.from_numpy(table), finish
+
+
+def decode_packed(dbuf, desc, host_buf=None):
+    """One packed block: decode_packed_multi([(dbuf, desc, host_buf)]) -> (tensors to keep alive, table); damaged files repaired on
+    return."""
+    keep, table, _f = decode_packed_multi([(dbuf, desc, host_buf)])
+    return keep, table
 
 
 def entropy_errors():
