@@ -217,33 +217,47 @@ struct BitReaderT {                // STUFFED: over the file's bytes of one rest
         }
         return (unsigned)(cache >> (8 * (p & 7))) & 0xffu;
     }
-    // Tops up to at least 32 valid bits (!STUFFED: to more than 56). STUFFED, called with n <= 32: the next FOUR bytes at once
-    // when none of them is an FF (no stuffing, no marker) -- in a wave of 64 readers the byte-wise loop otherwise runs on nearly every
-    // symbol for the one lane that needs it.
+    __device__ __forceinline__ unsigned window32() {      // the four bytes at `pos`, first byte lowest
+        const unsigned w = pos >> 3;
+        if (w != cidx) {
+            cache = (w == cidx + 1u) ? ahead : words[w];
+            cidx = w;
+            ahead = words[w + 1u];
+        }
+        const unsigned s = (pos & 7u) * 8u;
+        unsigned w32 = (unsigned)(cache >> s);
+        if (s > 32u) w32 |= (unsigned)(ahead << (64u - s));
+        return w32;
+    }
+    // Called with fewer than 32 valid bits, tops up to at least 32. In a wave of 64 readers every path ANY lane takes is paid by all, on
+    // nearly every symbol, so the common step is short and branch-free: up to FOUR bytes at once.
+    //   !STUFFED: always four (behind the end of the copy lie zero bytes; the position simply runs on);
+    //   STUFFED: the bytes in front of the first FF of the four (all four when there is none), never past `end`; only an FF at the very
+    //   position -- a stuffed FF 00 or a marker -- and the end of the data go byte by byte.
     __device__ __forceinline__ void fill() {
-        if (STUFFED && n <= 32 && pos + 4u <= end) {
-            const unsigned w = pos >> 3;
-            if (w != cidx) {
-                cache = (w == cidx + 1u) ? ahead : words[w];
-                cidx = w;
-                ahead = words[w + 1u];
-            }
-            const unsigned s = (pos & 7u) * 8u;
-            unsigned w32 = (unsigned)(cache >> s);
-            if (s > 32u) w32 |= (unsigned)(ahead << (64u - s));
-            const unsigned x = ~w32;
-            if ((((x - 0x01010101u) & w32) & 0x80808080u) == 0u) {      // no byte of x is zero: no FF among the four
-                buf |= (unsigned long long)__builtin_bswap32(w32) << (32 - n);
-                n += 32;
-                pos += 4u;
-                return;
+        if (!STUFFED) {
+            buf |= (unsigned long long)__builtin_bswap32(window32()) << (32 - n);
+            n += 32;
+            pos += 4u;
+            return;
+        }
+        if (pos < end) {
+            const unsigned w32 = window32();
+            const unsigned ff = ((~w32 - 0x01010101u) & w32) & 0x80808080u;      // bit 7 of every FF byte (exact for the lowest one)
+            unsigned k = ff ? (unsigned)__builtin_ctz(ff) >> 3 : 4u;
+            k = min(k, end - pos);
+            if (k) {
+                const unsigned v = __builtin_bswap32(w32) >> (32u - 8u * k);
+                buf |= (unsigned long long)v << (64 - n - 8 * (int)k);
+                n += 8 * (int)k;
+                pos += k;
             }
         }
-        while (n <= (STUFFED ? 31 : 56)) {      // (STUFFED: the four-byte step takes over again as soon as it can)
+        while (n < 32) {
             unsigned b = 0;
             if (pos < end) {
                 b = raw(pos);
-                if (STUFFED && b == 0xffu) {
+                if (b == 0xffu) {
                     const unsigned b2 = pos + 1 < end ? raw(pos + 1) : 0xd9u;
                     if (b2 == 0u) pos += 2;                    // a stuffed FF
                     else { end = pos; b = 0; ++starved; }      // a marker (the next interval's RSTn, or EOI): the data ends here
@@ -531,10 +545,12 @@ __global__ __launch_bounds__(SS_T) void jpeg_selfsync_kernel(const JpegSyncDev* 
     __shared__ int wave_tot[SS_T / 64];
     __shared__ int changed;
     __shared__ unsigned char mcu_comp[16], mcu_v[16], mcu_h[16];      // block j of an MCU: component, row / column inside the MCU
+    __shared__ unsigned char zz[64];
     const int tid = threadIdx.x;
     const JpegSyncDev f = files[blockIdx.x];
-    const unsigned char* plan = reinterpret_cast<const unsigned char*>(f.plan);
-    if (tid < 32) hdr[tid] = reinterpret_cast<const int*>(plan)[tid];
+    const WITW_AS_GLOBAL unsigned char* plan = (const WITW_AS_GLOBAL unsigned char*)f.plan;
+    if (tid < 32) hdr[tid] = ((const WITW_AS_GLOBAL int*)plan)[tid];
+    if (tid >= 64 && tid < 128) zz[tid - 64] = kZigZag[tid - 64];
     build_huff_tables(tab, plan, tid, SS_T);
     if (hdr[0] != 0x3157504A || hdr[1] != 1) {
         if (tid == 0) errors[blockIdx.x] = 2;
@@ -557,9 +573,9 @@ __global__ __launch_bounds__(SS_T) void jpeg_selfsync_kernel(const JpegSyncDev* 
         return;
     }
     // ---- 1: unstuff [start, end) -> clean
-    const unsigned char* src = reinterpret_cast<const unsigned char*>(f.bytes);
-    unsigned char* clean = reinterpret_cast<unsigned char*>(f.clean);
-    const unsigned s0 = reinterpret_cast<const unsigned*>(plan + 736)[0];
+    const WITW_AS_GLOBAL unsigned char* src = (const WITW_AS_GLOBAL unsigned char*)f.bytes;
+    WITW_AS_GLOBAL unsigned char* clean = (WITW_AS_GLOBAL unsigned char*)f.clean;
+    const unsigned s0 = ((const WITW_AS_GLOBAL unsigned*)(plan + 736))[0];
     unsigned s1 = (unsigned)hdr[27];
     if (s1 > (unsigned)f.n_bytes) s1 = (unsigned)f.n_bytes;
     const unsigned len = s1 > s0 ? s1 - s0 : 0u;
@@ -590,10 +606,10 @@ __global__ __launch_bounds__(SS_T) void jpeg_selfsync_kernel(const JpegSyncDev* 
         if (st.p & 7u) { b.buf <<= (st.p & 7u); b.n -= (int)(st.p & 7u); }
         unsigned bq = st.b, kq = st.k;
         int done = 0;
-        short* coef = reinterpret_cast<short*>(f.coef);
-        short* blk = nullptr;
+        WITW_AS_GLOBAL short* coef = (WITW_AS_GLOBAL short*)f.coef;
+        WITW_AS_GLOBAL short* blk = nullptr;
         const long long total_blocks = (long long)mcux * mcuy * nb;
-        auto locate = [&](long long bi) -> short* {      // block number in scan order -> its 64 coefficients (nullptr: past the image)
+        auto locate = [&](long long bi) -> WITW_AS_GLOBAL short* {      // block number in scan order -> its 64 coefficients (nullptr: past the image)
             if (bi >= total_blocks) return nullptr;
             const long long m = bi / nb;
             const int j = (int)(bi - m * nb);
@@ -624,7 +640,7 @@ __global__ __launch_bounds__(SS_T) void jpeg_selfsync_kernel(const JpegSyncDev* 
                 } else {
                     kq += r;
                     const int v = jpeg_extend(b.get(sz), sz);
-                    if (WRITE && blk && kq < 64) blk[kZigZag[kq]] = (short)v;
+                    if (WRITE && blk && kq < 64) blk[zz[kq]] = (short)v;
                     ++kq;
                 }
                 if (kq >= 64) finished = true;
@@ -672,7 +688,7 @@ __global__ __launch_bounds__(SS_T) void jpeg_selfsync_kernel(const JpegSyncDev* 
     const long long total_blocks = (long long)mcux * mcuy * nb;
     if (tid == 0 && (long long)total_done < total_blocks) errors[blockIdx.x] = 1;      // the data ended early (a trailing partial block of padding bits may add one)
     // ---- 4: DC differences -> DC values, per component over its blocks in scan order
-    short* coef = reinterpret_cast<short*>(f.coef);
+    WITW_AS_GLOBAL short* coef = (WITW_AS_GLOBAL short*)f.coef;
     for (int k = 0; k < ncomp; ++k) {
         const int c = hdr[28 + k];
         const int* q = hdr + 6 + 7 * c;
@@ -680,7 +696,7 @@ __global__ __launch_bounds__(SS_T) void jpeg_selfsync_kernel(const JpegSyncDev* 
         const long long n_c = (long long)mcux * mcuy * per_mcu;
         const long long per_t = (n_c + SS_T - 1) / SS_T;
         const long long i0 = min(n_c, (long long)tid * per_t), i1 = min(n_c, ((long long)tid + 1) * per_t);
-        auto at = [&](long long i) -> short* {      // i-th block of the component in scan order
+        auto at = [&](long long i) -> WITW_AS_GLOBAL short* {      // i-th block of the component in scan order
             const long long m = i / per_mcu;
             const int j = (int)(i - m * per_mcu), v = j / q[0], h = j - v * q[0];
             const int my = (int)(m / mcux), mx = (int)(m - (long long)my * mcux);
@@ -691,7 +707,7 @@ __global__ __launch_bounds__(SS_T) void jpeg_selfsync_kernel(const JpegSyncDev* 
         int dummy = 0;
         int pred = block_scan_excl<SS_T>(sum, wave_tot, tid, dummy);
         for (long long i = i0; i < i1; ++i) {
-            short* d = at(i);
+            WITW_AS_GLOBAL short* d = at(i);
             pred += *d;
             *d = (short)pred;
         }
