@@ -433,8 +433,9 @@ def main():
                     help='e2e: write the synthetic JPEG files with a restart marker every N MCU rows (0: none, as Pillow / libjpeg write by '
                          'default); files with restart markers are entropy-decoded on the GPU, one thread per restart interval')
     ap.add_argument('--device-entropy', choices=['off', 'restart', 'all'], default=None,
-                    help="e2e: which JPEG files are Huffman-decoded on the GPU (witw_amd/jpeg.py DEVICE_ENTROPY; default 'restart': those "
-                         "with restart markers; 'all' adds the self-synchronising decode of marker-less files)")
+                    help="e2e: which JPEG files are Huffman-decoded on the GPU (witw_amd/jpeg.py DEVICE_ENTROPY; default 'all': files with "
+                         "restart markers one thread per interval, the others by the self-synchronising decode; 'restart': only the former; "
+                         "'off': Huffman decoding in the loader workers)")
     ap.add_argument('--jpeg-restart-blocks', type=int, default=0, help='e2e: ... or a restart marker every N MCUs (jpegtran -restart NB)')
     ap.add_argument('--no-decode-scaling', action='store_true', help='e2e: skip the host entropy-decode scaling sweep')
     ap.add_argument('--decode-scaling-seconds', type=float, default=1.0)
@@ -606,7 +607,7 @@ def train_step_entry(a, tb, rank, world, device):
 
 
 SIDE_ORDER = ('train_step_fp32', 'config4_semantic_bf16', 'config4_semantic_bf16_train', 'train_step_bf16', 'config1_baseline', 'config5_retrieval', 'config5_retrieval_direct',
-              'fp32_grade_on_fp16_mfma', 'hbm_kernels', 'batch_sweep', 'e2e_data_path', 'e2e_data_path_bf16', 'e2e_data_path_bf16_device_entropy')
+              'fp32_grade_on_fp16_mfma', 'hbm_kernels', 'batch_sweep', 'e2e_data_path', 'e2e_data_path_bf16', 'e2e_data_path_bf16_device_entropy_all', 'e2e_data_path_bf16_device_entropy')
 
 
 def side_blocks(a, rank, world, device, cvig_fov, ops):
@@ -710,13 +711,17 @@ def side_blocks(a, rank, world, device, cvig_fov, ops):
     import tempfile
     jpegs = tempfile.mkdtemp(prefix='witw_e2e_')          # ONE synthetic data set for both blocks; the host-decode scaling sweep once
     try:
+        # (the files carry no restart markers, as Pillow / libjpeg write them. fp32 block: the library's default data path -- Huffman
+        # decoding on the GPU, self-synchronising; bf16: the host-Huffman path with 16 workers, then the device path with FOUR)
         guarded('e2e_data_path', lambda: e2e(['--e2e-pairs', '2048', '--e2e-dir', jpegs, '--no-decode-scaling']))
         guarded('e2e_data_path_bf16', lambda: e2e(['--e2e-pairs', '8192', '--workers', '16', '--precision', 'bf16', '--e2e-dir', jpegs,
-                                                   '--decode-scaling-seconds', '0.5']))
+                                                   '--device-entropy', 'off', '--decode-scaling-seconds', '0.5']))
+        guarded('e2e_data_path_bf16_device_entropy_all', lambda: e2e(['--e2e-pairs', '8192', '--workers', '4', '--precision', 'bf16', '--e2e-dir', jpegs,
+                                                                      '--device-entropy', 'all']))
     finally:
         shutil.rmtree(jpegs, ignore_errors=True)
-    # the same bf16 pass on files that carry restart markers: Huffman decoding moves to the GPU and FOUR workers (marker scan +
-    # packing) feed it -- the data path no longer scales with the host's cores
+    # the same bf16 pass on files that carry restart markers (one GPU thread per restart interval instead of the self-synchronising
+    # decode): FOUR workers (marker scan + packing) feed it -- the data path no longer scales with the host's cores
     jpegs = tempfile.mkdtemp(prefix='witw_e2e_rst_')
     try:
         guarded('e2e_data_path_bf16_device_entropy', lambda: e2e(['--e2e-pairs', '8192', '--workers', '4', '--precision', 'bf16', '--e2e-dir', jpegs,

@@ -420,7 +420,8 @@ def test_pack_ships_file_bytes_for_device_entropy_decoding(monkeypatch):
     raw = open(os.path.join(HERE, 's420_rst.jpg'), 'rb').read()
     plain = open(os.path.join(HERE, 's420_q90.jpg'), 'rb').read()
     items = [jpeg.open_file(raw), jpeg.open_file(plain), jpeg.open_file(raw)]
-    assert jpeg.DEVICE_ENTROPY == 'restart'                     # the default: only restart-marker files go to the device decoder
+    assert jpeg.DEVICE_ENTROPY == 'all'                         # the default: every baseline Huffman file goes to the device decoder
+    monkeypatch.setattr(jpeg, 'DEVICE_ENTROPY', 'restart')      # only files with restart markers
     _b, desc_r, _k = jpeg.pack(items)
     assert list(desc_r[:, 26].numpy()) == [1, 0, 1]
     monkeypatch.setattr(jpeg, 'DEVICE_ENTROPY', 'all')

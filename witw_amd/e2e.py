@@ -267,7 +267,7 @@ def bench(a, device, n_pairs=None, workers=None, keep_dir=None, decode=None, pre
                                              'entropy-decode_and_pack' if decode == 'device' else 'decode_and_pack', workers): n / t_load,
              'host_to_device copy (pinned, %.1f MB per batch)' % (blk / 1e6): nb / t_h2d,
              'gpu (%sbatched resize+normalise [+polar, fused], 2 %s encoders; the next batch staged on the copy stream meanwhile, as in the pipeline)'
-             % (('JPEG on the GPU: Huffman decoding (one thread per restart interval) + dequantise + IDCT + upsample + colour, ' if dev_entropy else
+             % (('JPEG on the GPU: Huffman decoding (%s) + dequantise + IDCT + upsample + colour, ' % ('one thread per restart interval' if restart_rows or restart_blocks else 'self-synchronising, one workgroup per file') if dev_entropy else
                  'JPEG back end: dequantise + IDCT + upsample + colour, ') if decode == 'device' else '', precision): nb / t_gpu}
     limiting = min(rates, key=rates.get)
     scaling = decode_scaling(root, n_unique, cores, nb / t_gpu, seconds=getattr(a, 'decode_scaling_seconds', 1.0)) \

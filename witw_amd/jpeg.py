@@ -23,15 +23,14 @@ DESC_COLS = 30         # per image: coefficient byte offset, quantisation-table 
 # Baseline / extended-sequential Huffman files are entropy-decoded ON THE DEVICE (round 6; csrc/jpeg.hip): with restart markers one GPU
 # thread per restart interval (jpeg_huffman_kernel), without them a self-synchronising decode, one workgroup per file
 # (jpeg_selfsync_kernel). The worker only parses the header and scans for markers; the file bytes cross PCIe instead of the
-# coefficient blocks.
-# Modes: 'restart' (default) = only files with restart markers go to the device decoder (0.7 + 0.5 ms per 128 pairs at a marker every
-# 2 MCUs: the bf16 data path keeps its rate with 4 loader workers instead of 16); 'all' = marker-less files too, on the self-synchronising
-# kernel (4.5 ms per 128 pairs standalone, and its workgroups -- 512 threads with barriers, one per file -- share the chip badly with
-# the encoders' persistent workgroups: beside the bf16 encoders the pass runs at 5.1 k pairs/s where 16 host workers give 14.6 k, beside
-# the fp32 ones at 1,660 against 1,820-1,860: for hosts with no cores to spare; docs/experiments.md); 'off' / False = host Huffman decoding.
+# coefficient blocks, and every launch covers all the files of a batch side (decode_packed_multi).
+# Modes: 'all' (default) = every such file; disk -> embeddings with the bf16 encoders and FOUR loader workers: 14.5 k pairs/s on files
+# with a restart marker every 1-2 MCUs, 14.1 k on ordinary files without markers -- what 16 workers reach with host Huffman decoding
+# (14.5 k), the encoders alone run at 15.1 k; fp32 encoders 1,802 against 1,822. 'restart' = only files with restart markers go to
+# the device decoder, the others are Huffman-decoded in the worker; 'off' / False = host Huffman decoding for all.
 # WITW_JPEG_DEVICE_ENTROPY = 0 | off | restart | 1 | all.
-_mode = os.environ.get('WITW_JPEG_DEVICE_ENTROPY', 'restart').lower()
-DEVICE_ENTROPY = False if _mode in ('0', 'off', 'false') else 'all' if _mode in ('all', '2') else 'restart'
+_mode = os.environ.get('WITW_JPEG_DEVICE_ENTROPY', 'all').lower()
+DEVICE_ENTROPY = False if _mode in ('0', 'off', 'false') else 'restart' if _mode in ('restart', '1') else 'all'
 CHECK_ERRORS = True    # decode_packed(host_buf=...) re-decodes files the device flagged as damaged with Pillow (as the host path does)
 REPAIRED = [0]         # how many files that happened to
 SELFSYNC_MIN_BLOCKS = 96   # a marker-less file of at most this many blocks is decoded by ONE thread of the interval kernel (a 1024-thread
