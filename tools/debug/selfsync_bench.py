@@ -25,4 +25,4 @@ for (h, w) in ((512, 512), (224, 224)):
     for _ in range(5): keep, table = jpeg.decode_packed(dbuf, desc)
     e1.record(); torch.cuda.synchronize()
     print('threads/file %s  %dx%d: host parse+pack %.2f ms, device decode (self-sync huffman + idct + rgb) %.3f ms per batch of 128, errors %d'
-          % (os.environ.get('WITW_SELFSYNC_THREADS', '256'), h, w, t_pack * 1e3, e0.elapsed_time(e1) / 5, jpeg.entropy_errors()))
+          % (os.environ.get('WITW_SELFSYNC_THREADS', '512'), h, w, t_pack * 1e3, e0.elapsed_time(e1) / 5, jpeg.entropy_errors()))

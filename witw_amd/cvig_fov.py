@@ -1598,8 +1598,16 @@ class GpuPreprocess(object):
         if s_copied:
             if s_tabs:
                 raise _lib.WitwError('the parts of a grouped batch are packed and unpacked')
-            s_tab, st.s_kind, f1 = self._table_side(st, s_copied)
-            o_tab, st.o_kind, f2 = self._table_side(st, o_copied)
+            if all(c[2] == 2 for c in s_copied + o_copied):
+                # JPEG on both sides: ONE set of decode launches for the ground and the overhead files of every part (the device
+                # Huffman decoders are bound by a thread's chain of symbols, not by how many files a launch holds)
+                both, _kind, f1 = self._table_side(st, s_copied + o_copied)
+                n_s = sum(int(c[1].shape[0]) for c in s_copied)
+                s_tab, o_tab, f2 = both[:n_s], both[n_s:], None      # (views: a re-decoded file's row is patched in place)
+                st.s_kind = st.o_kind = 1
+            else:
+                s_tab, st.s_kind, f1 = self._table_side(st, s_copied)
+                o_tab, st.o_kind, f2 = self._table_side(st, o_copied)
             finishers += [f for f in (f1, f2) if f is not None]
             s_tabs, o_tabs = [s_tab], [o_tab]
         for f in finishers:      # the device decoder's damage flags: ONE host wait per batch, behind every launch of the staging
