@@ -468,7 +468,7 @@ int witw_jpeg_to_rgb(const void* planes, const void* images, int n_images, long 
  * (witw_jpeg_decode_coef); witw_jpeg_idct / witw_jpeg_to_rgb take it from there. */
 int witw_jpeg_huffman(const void* files, int n_files, int max_intervals, int* errors, void* stream);
 /* The same for files WITHOUT restart markers (their plan holds ONE interval: the whole scan): a self-synchronising decode, one
- * workgroup of 1024 threads per file -- the scan is unstuffed and cut into 1024 subsequences, every thread decodes its own from a
+ * workgroup of 512 threads per file (WITW_SELFSYNC_THREADS = 256 | 512 | 1024) -- the scan is unstuffed and cut into as many subsequences, every thread decodes its own from a
  * guessed state, then from its neighbour's exit state, round after round until no entry state changes (Huffman codes fall into step
  * after a few dozen symbols; thread 0 starts at the true state, so the fixed point is the true decoding); a prefix sum numbers the
  * blocks, a last pass writes the coefficients and a per-component prefix sum turns DC differences into DC values. files: DEVICE int64

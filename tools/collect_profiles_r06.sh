@@ -42,6 +42,44 @@ python3 tools/bench_f2_wres.py > $O/weight_resident_kernels.txt 2>&1
 rm -f $O/d.json
 echo benches done
 fi
+if [ $PART = jpeg ]; then      # the device JPEG decoders and the data path on ONE box (their kernels changed after the other parts were taken)
+rm -f $O/jpeg_huffman_intervals.txt $O/jpeg_selfsync.txt
+for a in "1 0" "0 8" "0 4" "0 2" "0 1"; do python3 tools/debug/jpeg_huff_bench.py $a 2>&1 | grep -v amdgpu.ids >> $O/jpeg_huffman_intervals.txt; done
+for t in 256 512 1024; do WITW_SELFSYNC_THREADS=$t python3 tools/debug/selfsync_bench.py 2>&1 | grep -v amdgpu.ids >> $O/jpeg_selfsync.txt; done
+for bl in 2 1; do
+rocprofv3 --kernel-trace --stats -o p --output-format csv -d $O/prof_huff$bl -- python3 tools/debug/jpeg_huff_bench.py 0 $bl > /dev/null 2> $O/prof_huff$bl.log
+done
+rocprofv3 --kernel-trace --stats -o p --output-format csv -d $O/prof_selfsync -- python3 tools/debug/selfsync_bench.py > /dev/null 2> $O/prof_selfsync.log
+D=$(mktemp -d /tmp/witw_e2e_XXXX)
+python3 bench.py --mode e2e --e2e-dir $D --detail-out $O/bench_e2e_detail.json > $O/bench_e2e.json 2> $O/bench_e2e.err
+python3 bench.py --mode e2e --e2e-dir $D --workers 16 --device-entropy off --no-decode-scaling --detail-out $O/d.json > $O/bench_e2e_host.json 2> $O/bench_e2e_host.err
+python3 bench.py --mode e2e --precision bf16 --workers 16 --e2e-pairs 8192 --e2e-dir $D --device-entropy off --detail-out $O/bench_e2e_bf16_detail.json > $O/bench_e2e_bf16.json 2> $O/bench_e2e_bf16.err
+python3 bench.py --mode e2e --precision bf16 --workers 4 --e2e-pairs 8192 --e2e-dir $D --device-entropy off --no-decode-scaling --detail-out $O/d.json > $O/bench_e2e_bf16_host_w4.json 2> $O/bench_e2e_bf16_host_w4.err
+python3 bench.py --mode e2e --precision bf16 --workers 4 --e2e-pairs 8192 --e2e-dir $D --device-entropy all --detail-out $O/d.json > $O/bench_e2e_bf16_device_entropy_all.json 2> $O/bench_e2e_bf16_device_entropy_all.err
+rm -rf $D
+for bl in 2 1; do
+D=$(mktemp -d /tmp/witw_e2e_XXXX)
+python3 bench.py --mode e2e --precision bf16 --workers 4 --e2e-pairs 8192 --e2e-dir $D --jpeg-restart-blocks $bl --detail-out $O/d.json > $O/bench_e2e_bf16_device_entropy_rst$bl.json 2> $O/bench_e2e_bf16_device_entropy_rst$bl.err
+rm -rf $D
+done
+cp $O/bench_e2e_bf16_device_entropy_rst2.json $O/bench_e2e_bf16_device_entropy.json
+python3 - <<PY
+import json
+out = {}
+for k, f in (('fp32_default_device_entropy_all_w12', 'bench_e2e'), ('fp32_host_entropy_w16', 'bench_e2e_host'), ('bf16_host_entropy_w16', 'bench_e2e_bf16'),
+             ('bf16_host_entropy_w4', 'bench_e2e_bf16_host_w4'), ('bf16_device_entropy_all_w4', 'bench_e2e_bf16_device_entropy_all'),
+             ('bf16_device_entropy_restart2_w4', 'bench_e2e_bf16_device_entropy_rst2'), ('bf16_device_entropy_restart1_w4', 'bench_e2e_bf16_device_entropy_rst1')):
+    try:
+        d = json.loads(open('$O/%s.json' % f).read().strip().splitlines()[-1])
+        out[k] = {q: d.get(q) for q in ('value', 'unit', 'steady_state_pairs_per_s', 'stage_pairs_per_s', 'limiting_stage', 'jpeg_decode', 'pcie_bytes_per_pair', 'dtype')}
+    except Exception as e:
+        out[k] = {'error': str(e)}
+json.dump(out, open('$O/e2e_device_entropy_dev.json', 'w'), indent=1)
+for k, v in out.items(): print(k, v.get('value'), v.get('steady_state_pairs_per_s'))
+PY
+rm -f $O/d.json
+echo jpeg done
+fi
 if [ $PART = stats ]; then
 P="rocprofv3 --kernel-trace --stats -o p --output-format csv"
 $P -d $O/prof -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-side-blocks --detail-out $O/d.json > $O/bench_under_rocprof.json 2> $O/prof.log

@@ -35,6 +35,12 @@ c $O/weight_resident_pmc.txt profiles/${R}_weight_resident_pmc.txt
 c $O/hbm_yardstick.txt profiles/${R}_hbm_yardstick.txt
 c $O/jpeg_huffman_intervals.txt profiles/${R}_jpeg_huffman_intervals.txt
 c $O/bench_e2e_bf16_device_entropy.json profiles/${R}_bench_e2e_bf16_device_entropy.json
+c $O/bench_e2e_bf16_device_entropy_all.json profiles/${R}_bench_e2e_bf16_device_entropy_all.json
+c $O/e2e_device_entropy_dev.json profiles/${R}_e2e_device_entropy_dev.json
+c $O/jpeg_selfsync.txt profiles/${R}_jpeg_selfsync.txt
+c $O/prof_huff2/p_kernel_stats.csv profiles/${R}_jpeg_huffman_rst2_kernel_stats.csv
+c $O/prof_huff1/p_kernel_stats.csv profiles/${R}_jpeg_huffman_rst1_kernel_stats.csv
+c $O/prof_selfsync/p_kernel_stats.csv profiles/${R}_jpeg_selfsync_kernel_stats.csv
 # both clocks of the dominant kernels: the rocprof tables of this round, keyed by the kernel sources' hashes (bench.py: frac_rocprof)
 python3 tools/make_rocprof_avg.py infer:$O/prof/p_kernel_stats.csv:profiles/${R}_bench_kernel_stats.csv \
   train:$O/prof_train/p_kernel_stats.csv:profiles/${R}_train_kernel_stats.csv \

@@ -718,7 +718,8 @@ __global__ __launch_bounds__(SS_T) void jpeg_selfsync_kernel(const JpegSyncDev* 
 
 extern "C" {
 
-// The same for files WITHOUT restart markers (plans of ONE interval): self-synchronising decode, one workgroup of 1024 threads per file.
+// The same for files WITHOUT restart markers (plans of ONE interval): self-synchronising decode, one workgroup of 512 threads per file
+// (WITW_SELFSYNC_THREADS = 256 | 512 | 1024).
 // files: DEVICE int64 [n_files][6] = {file bytes, plan, coefficient area (zero-filled), file length, scratch of file length + 32
 // bytes (8-byte aligned), 0}; errors as above. Coefficients bit-identical to witw_jpeg_decode_coef.
 int witw_jpeg_huffman_selfsync(const void* files, int n_files, int* errors, void* stream) {
