@@ -340,3 +340,73 @@ def test_data_path_with_selfsync_mode_equals_host_decode(tmp_path, monkeypatch):
     loader = torch.utils.data.DataLoader(ds, batch_size=2, shuffle=False, num_workers=2, collate_fn=cvig_fov.collate_packed, pin_memory=True)
     outs = [prep(st) for st in cvig_fov.DevicePrefetcher(loader, prep)]
     assert torch.equal(torch.cat([d['polar'] for d in outs]), ref['polar']) and jpeg.entropy_errors() == 0
+
+
+def test_one_set_of_launches_over_the_parts_of_a_batch_equals_part_by_part_decoding(monkeypatch):
+    """decode_packed_multi: the blocks of a batch that arrived in pieces (separate allocations) are decoded by launches that cover all
+    of them -- same images as decoding every block by itself, rows in part order; a damaged file in the SECOND part is re-decoded by
+    Pillow from that part's host block and only its row is patched (deferred: nothing is read back before finish())."""
+    from PIL import Image, ImageFile
+    monkeypatch.setattr(jpeg, 'DEVICE_ENTROPY', 'all')
+    g = np.random.Generator(np.random.Philox(key=[16, 3]))
+    a = [_fresh(g, 224, 224, 2, 90, restart_marker_blocks=2), _fresh(g, 97, 131, 1, 60), g.integers(0, 256, size=(9, 7, 3), dtype=np.uint8)]
+    whole = _fresh(g, 224, 224, 2, 85)
+    b = [open(os.path.join(HERE, 'prog_q85.jpg'), 'rb').read(), whole[:len(whole) * 3 // 5], _fresh(g, 512, 512, 2, 90, restart_marker_blocks=1),
+         _fresh(g, 64, 64, 0, 80)]
+    old = ImageFile.LOAD_TRUNCATED_IMAGES
+    ImageFile.LOAD_TRUNCATED_IMAGES = True
+    try:
+        def item(r):
+            if isinstance(r, np.ndarray):
+                return r, r
+            ref = np.asarray(Image.open(io.BytesIO(r)))
+            it = jpeg.open_file(r)
+            return (it if it is not None else ref), (ref if ref.ndim == 3 else ref[:, :, None])
+        parts, refs = [], []
+        for raws in (a, b):
+            items = [item(r) for r in raws]
+            refs += [r for _i, r in items]
+            buf, desc, _k = jpeg.pack([i for i, _r in items])
+            parts.append((buf.to('cuda:0'), desc, buf))
+        before = jpeg.REPAIRED[0]
+        keep, table, finish = jpeg.decode_packed_multi(parts, defer=True)
+        assert finish is not None and jpeg.REPAIRED[0] == before and table.shape[0] == len(refs)
+        finish()
+        torch.cuda.synchronize()
+        assert jpeg.REPAIRED[0] == before + 1
+    finally:
+        ImageFile.LOAD_TRUNCATED_IMAGES = old
+    pool = [p[0] for p in parts] + keep
+    for i, r in enumerate(refs):
+        H, W, C = int(table[i, 1]), int(table[i, 2]), int(table[i, 4])
+        assert (H, W, C) == r.shape, i
+        src = next(t for t in pool if t.dtype == torch.uint8 and t.data_ptr() <= int(table[i, 0]) and int(table[i, 0]) + H * W * C <= t.data_ptr() + t.numel())
+        o = int(table[i, 0]) - src.data_ptr()
+        np.testing.assert_array_equal(src.reshape(-1)[o:o + H * W * C].reshape(H, W, C).cpu().numpy(), r, err_msg=str(i))
+
+
+def test_grouped_prefetcher_decodes_both_sides_of_all_parts_together(tmp_path, monkeypatch):
+    """DevicePrefetcher(group=2) over loader batches of 2: GpuPreprocess.stage queues the four blocks and decodes ground and overhead files
+    of both parts with one set of launches -- the 'surface' / 'polar' bits of Pillow's decode, in loader order."""
+    from witw_amd import cvig_fov
+    monkeypatch.setattr(jpeg, 'DEVICE_ENTROPY', 'all')
+    del jpeg._ERRORS[:]
+    g = np.random.Generator(np.random.Philox(key=[17, 1]))
+    root = str(tmp_path)
+    rows = []
+    for i in range(4):
+        for tag, (h, w) in (('su', (224, 224)), ('ov', (512, 512))):
+            kw = {'restart_marker_blocks': 2} if i % 2 else {}
+            open(os.path.join(root, '%s_%d.jpg' % (tag, i)), 'wb').write(_fresh(g, h, w, 2, 90, **kw))
+        rows.append('ov_%d.jpg,su_%d.jpg' % (i, i))
+    csv = os.path.join(root, 'pairs.csv')
+    open(csv, 'w').write('\n'.join(rows) + '\n')
+    prep = cvig_fov.GpuPreprocess('cvusa', fov=360, random_orientation=False)
+    ref = prep(cvig_fov.collate_packed([cvig_fov.ImagePairDataset('cvusa', csv, raw=True)[i] for i in range(4)]))
+    ds = cvig_fov.ImagePairDataset('cvusa', csv, raw='jpeg')
+    loader = torch.utils.data.DataLoader(ds, batch_size=2, shuffle=False, num_workers=0, collate_fn=cvig_fov.collate_packed)
+    n_launch = len(jpeg._ERRORS)
+    outs = [prep(st) for st in cvig_fov.DevicePrefetcher(loader, prep, group=2)]
+    assert len(outs) == 1 and outs[0]['surface'].shape[0] == 4
+    assert len(jpeg._ERRORS) == n_launch + 1                  # ONE device-entropy decode for the 8 files
+    assert torch.equal(outs[0]['surface'], ref['surface']) and torch.equal(outs[0]['polar'], ref['polar']) and jpeg.entropy_errors() == 0
