@@ -190,6 +190,9 @@ __constant__ unsigned char kZigZag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24
 
 // Addresses that arrive as integers (descriptor rows) carry no address space: dereferenced as plain pointers they become FLAT accesses,
 // which count on the LDS counter as well as on the memory counter. The Huffman kernels name the space of everything they touch.
+#ifndef WITW_SS_DIAG
+#define WITW_SS_DIAG 0          // 1: jpeg_selfsync_kernel stops behind its rounds and reports (rounds << 20 | re-decoded subsequences) per file in `errors`
+#endif
 #define WITW_AS_GLOBAL __attribute__((address_space(1)))
 #define WITW_AS_LDS __attribute__((address_space(3)))
 typedef const WITW_AS_GLOBAL unsigned long long* GlobalWords;
@@ -544,6 +547,10 @@ __global__ __launch_bounds__(SS_T) void jpeg_selfsync_kernel(const JpegSyncDev* 
     __shared__ unsigned short nblk_s[SS_T];
     __shared__ int wave_tot[SS_T / 64];
     __shared__ int changed;
+#if WITW_SS_DIAG
+    __shared__ int diag_rounds, diag_changed;
+    if (threadIdx.x == 0) { diag_rounds = 0; diag_changed = 0; }
+#endif
     __shared__ unsigned char mcu_comp[16], mcu_v[16], mcu_h[16];      // block j of an MCU: component, row / column inside the MCU
     __shared__ unsigned char zz[64];
     const int tid = threadIdx.x;
@@ -677,9 +684,18 @@ __global__ __launch_bounds__(SS_T) void jpeg_selfsync_kernel(const JpegSyncDev* 
             changed = 1;
         }
         __syncthreads();
+#if WITW_SS_DIAG
+        if (differs) atomicAdd(&diag_changed, 1);
+        if (tid == 0) ++diag_rounds;
+#endif
         if (!changed) break;
         __syncthreads();
     }
+#if WITW_SS_DIAG
+    __syncthreads();
+    if (tid == 0) errors[blockIdx.x] = (diag_rounds << 20) | diag_changed;      // DIAGNOSTIC BUILD: rounds, re-decoded subsequences in all
+    return;
+#endif
     // ---- 3: number the blocks, decode once more and write
     int total_done = 0;
     const int first = block_scan_excl<SS_T>((int)nblk_s[tid], wave_tot, tid, total_done);
