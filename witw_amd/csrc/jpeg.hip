@@ -168,13 +168,14 @@ __global__ __launch_bounds__(256) void jpeg_to_rgb_kernel(const unsigned char* _
 // Integer / byte work, latency-bound per thread (a table look-up and a few shifts per symbol); nothing here is MFMA- or
 // HBM-shaped. A wave pays for every path ANY of its 64 lanes takes, so the rare paths are kept short: four input bytes at a time while
 // no FF is among them, codes longer than the look-up by seven compares instead of a loop, the zig-zag order from the LDS. Same coefficients, bit for bit, as witw_jpeg_decode_coef (tests/test_jpeg_gpu.py).
+constexpr int HUFF_LOOK = 11;       // bits of the first-step look-up: 4 KB per table. Codes longer than that are a fraction of a per cent of the
+                                    // symbols of a photograph -- with 9 bits (2-3 %) one of a wave's 64 lanes needed the second step on most symbols
 struct HuffLds {
-    unsigned short look[512];      // 9-bit prefix -> (code length << 8) | symbol; 0: the code is longer than 9 bits
-    int maxcode[18];               // largest code of each length (-1: none), [17] = sentinel
+    unsigned short look[1 << HUFF_LOOK];      // prefix -> (code length << 8) | symbol; 0: the code is longer than HUFF_LOOK bits
     int valoff[17];                // symbol index of the first code of a length minus that code
+    unsigned lim[17];              // lim[L] = the first 16-bit left-aligned value ABOVE every code of length <= L (non-decreasing; a length
+                                   // without codes repeats its predecessor's; lim[0] = 0): a code's length is 1 + the number of limits it reaches
     unsigned char sym[256];
-    unsigned lim[8];               // codes longer than 9 bits: lim[j] = the first 16-bit left-aligned value ABOVE every code of length
-                                   // <= 10 + j (non-decreasing; a length without codes repeats its predecessor's), [7] unused
 };
 
 struct JpegFileDev {               // int64 x 4 per file
@@ -292,24 +293,23 @@ struct BitReaderT {                // STUFFED: over the file's bytes of one rest
 template <typename BR, typename HP>      // HP: pointer to a HuffLds (jpeg_huffman_kernel: typed as an LDS pointer -- a pointer the compiler cannot place becomes a flat access)
 __device__ __forceinline__ int huff_decode(BR& b, HP hp) {      // caller has >= 32 valid bits; -1: invalid code
     auto& h = *hp;
-    const unsigned e = h.look[(unsigned)(b.buf >> 55)];
+    const unsigned e = h.look[(unsigned)(b.buf >> (64 - HUFF_LOOK))];
     if (e) {
         const int len = (int)(e >> 8);
         b.buf <<= len;
         b.n -= len;
         return (int)(e & 255u);
     }
-    // longer than 9 bits (a few per cent of the symbols -- but of 64 lanes one nearly always): the length by comparing against the
-    // limits of the lengths 10..16, no loop
+    // longer than the look-up: the length by comparing against the limits of the remaining lengths, no loop
     const unsigned c16 = (unsigned)(b.buf >> 48);
-    int len = 10, vo = h.valoff[10];
+    int len = HUFF_LOOK + 1, vo = h.valoff[HUFF_LOOK + 1];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        const bool above = c16 >= h.lim[j];
+    for (int L = HUFF_LOOK + 1; L < 16; ++L) {
+        const bool above = c16 >= h.lim[L];
         len += above ? 1 : 0;
-        vo = above ? h.valoff[11 + j] : vo;
+        vo = above ? h.valoff[L + 1] : vo;
     }
-    if (c16 >= h.lim[6]) return -1;
+    if (c16 >= h.lim[16]) return -1;
     const int code = (int)(c16 >> (16 - len));
     b.buf <<= len;
     b.n -= len;
@@ -330,34 +330,28 @@ __device__ __forceinline__ void build_huff_tables(HuffLds (&tab)[4], PP plan, in
         const PP d = lane < 2 ? plan + 128 + 32 * lane : plan + 192 + 272 * (lane - 2);
         HuffLds& h = tab[lane];
         int code = 0, k = 0;
-        for (int len = 1; len <= 16; ++len) {
+        h.lim[0] = 0u;
+        h.valoff[0] = 0;
+        for (int len = 1; len <= 16; ++len) {      // (the host rejected tables with code + count > 2^len: every limit is at most 0x10000)
             h.valoff[len] = k - code;
             const int cnt = d[len - 1];
             k += cnt;
             code += cnt;
-            h.maxcode[len] = cnt ? code - 1 : -1;
-            if (len >= 10) h.lim[len - 10] = (unsigned)code << (16 - len);
+            h.lim[len] = (unsigned)code << (16 - len);
             code <<= 1;
         }
-        h.maxcode[17] = 0x7fffffff;
-        h.maxcode[0] = -1;
-        h.valoff[0] = 0;
-        h.lim[7] = 0x10000u;
     }
     __syncthreads();
-    // 9-bit look-ups. Canonical codes: the first length whose largest code is not below the prefix holds it (a prefix below that
-    // length's first code would have matched a shorter length already)
-    for (int e = lane; e < 4 * 512; e += nthreads) {
-        const int t = e >> 9, i = e & 511;
+    // the look-ups, one entry per thread and step: the length of the code an entry starts with = 1 + the limits its prefix reaches
+    for (int e = lane; e < 4 * (1 << HUFF_LOOK); e += nthreads) {
+        const int t = e >> HUFF_LOOK, i = e & ((1 << HUFF_LOOK) - 1);
         const HuffLds& h = tab[t];
+        const unsigned c16 = (unsigned)i << (16 - HUFF_LOOK);
+        int len = 1;
+#pragma unroll
+        for (int L = 1; L < HUFF_LOOK; ++L) len += c16 >= h.lim[L] ? 1 : 0;
         unsigned short v = 0;
-        for (int len = 1; len <= 9; ++len) {
-            const int code = i >> (9 - len);
-            if (code <= h.maxcode[len]) {
-                v = (unsigned short)((len << 8) | h.sym[(code + h.valoff[len]) & 255]);
-                break;
-            }
-        }
+        if (c16 < h.lim[HUFF_LOOK]) v = (unsigned short)((len << 8) | h.sym[((int)(c16 >> (16 - len)) + h.valoff[len]) & 255]);
         tab[t].look[i] = v;
     }
     __syncthreads();
@@ -365,8 +359,8 @@ __device__ __forceinline__ void build_huff_tables(HuffLds (&tab)[4], PP plan, in
 
 constexpr int HUFF_T = 256;         // threads per workgroup of jpeg_huffman_kernel: the four tables are built once for 256 intervals
 constexpr int HUFF_STAGE = 10 * 1024;      // bytes of LDS per wave for the entropy-coded bytes of its 64 intervals (a marker per MCU at
-                                           // quality 90: ~7 KB). 46 KB per workgroup: three of them per CU -- a wave's chain of symbols is pure
-                                           // latency, so the kernel's rate is the number of waves a SIMD can interleave
+                                           // quality 90: ~7 KB). 57 KB per workgroup with the tables: two of them per CU -- a wave's chain of symbols
+                                           // is pure latency, so the kernel's rate is the number of waves a SIMD can interleave
 
 struct HuffCtx {                    // what decoding an interval needs besides its reader (uniform over the workgroup)
     const WITW_AS_LDS HuffLds* tab;
@@ -626,20 +620,27 @@ __global__ __launch_bounds__(SS_T) void jpeg_selfsync_kernel(const JpegSyncDev* 
             return coef + ((long long)q[4] + (long long)(my * q[1] + mcu_v[j]) * q[2] + (mx * q[0] + mcu_h[j])) * 64;
         };
         if (WRITE) blk = locate(blk0);
+        // the two tables of the block at hand, looked up when the block changes (not per symbol: component -> header -> table is a chain
+        // of LDS reads in front of every look-up otherwise)
+        int tdc = 0, tac = 2;
+        auto tables_of = [&](unsigned j) {
+            const int* q = hdr + 6 + 7 * mcu_comp[j];
+            tdc = q[5] & 1;
+            tac = 2 + (q[6] & 1);
+        };
+        tables_of(bq);
         while (b.bit_pos() < limit) {
             if (b.n < 32) b.fill();
-            const int c = mcu_comp[bq];
-            const int* q = hdr + 6 + 7 * c;
             bool finished = false;
             if (kq == 0) {
-                const int sdc = huff_decode(b, &tab[q[5] & 1]);
+                const int sdc = huff_decode(b, &tab[tdc]);
                 if (sdc < 0 || sdc > 15) { b.buf <<= 1; b.n -= 1; continue; }      // not a code (only ever out of step): slide one bit on
                 int diff = 0;
                 if (sdc) diff = jpeg_extend(b.get(sdc), sdc);
                 if (WRITE && blk) blk[0] = (short)diff;
                 kq = 1;
             } else {
-                const int rs = huff_decode(b, &tab[2 + (q[6] & 1)]);
+                const int rs = huff_decode(b, &tab[tac]);
                 if (rs < 0) { b.buf <<= 1; b.n -= 1; continue; }
                 const int r = rs >> 4, sz = rs & 15;
                 if (sz == 0) {
@@ -656,6 +657,7 @@ __global__ __launch_bounds__(SS_T) void jpeg_selfsync_kernel(const JpegSyncDev* 
                 ++done;
                 kq = 0;
                 bq = (bq + 1 == (unsigned)nb) ? 0 : bq + 1;
+                tables_of(bq);
                 if (WRITE) blk = locate(blk0 + done);
             }
         }
