@@ -275,6 +275,12 @@ struct BitReaderT {                // STUFFED: over the file's bytes of one rest
             n += 8;
         }
     }
+    __device__ __forceinline__ int take(int k) {   // k in 0..16 (0: nothing, returns 0), caller has >= 32 valid bits
+        const int v = (int)((buf >> 1) >> (63 - k));
+        buf <<= k;
+        n -= k;
+        return v;
+    }
     __device__ __forceinline__ int get(int k) {    // k in 1..16, caller has >= 32 valid bits
         const int v = (int)(buf >> (64 - k));
         buf <<= k;
@@ -317,6 +323,7 @@ __device__ __forceinline__ int huff_decode(BR& b, HP hp) {      // caller has >=
 }
 
 __device__ __forceinline__ int jpeg_extend(int v, int s) { return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v; }
+__device__ __forceinline__ int jpeg_extend0(int v, int s) { return v < ((1 << s) >> 1) ? v - (1 << s) + 1 : v; }      // the same, and 0 for s = 0 (v = 0)
 
 // The four decoding tables (DC slot 0, 1, AC slot 0, 1) from the DHT counts / symbols of the plan: threads 0-3 assign the canonical codes
 // of one table each (16 lengths), then all threads fill the 9-bit look-ups. Ends with a workgroup barrier.
@@ -387,29 +394,28 @@ __device__ __forceinline__ bool huff_interval(BitReaderT<true, WP>& b, const Huf
                 for (int hh = 0; hh < ch; ++hh) {
                     WITW_AS_GLOBAL short* blk = x.coef + (coff + (long long)(my * cv + v) * cbw + (mx * ch + hh)) * 64;
                     if (b.n < 32) b.fill();
-                    int s = huff_decode(b, hd);
-                    if (s < 0 || s > 15) return false;
-                    if (s) pred[c] += jpeg_extend(b.get(s), s);
+                    const int sdc = huff_decode(b, hd);
+                    bool bad = sdc < 0 || sdc > 15;
+                    const int sd = bad ? 0 : sdc;
+                    pred[c] += jpeg_extend0(b.take(sd), sd);
                     blk[0] = (short)pred[c];
-                    for (int kk = 1; kk < 64;) {
+                    // One straight line for the three kinds of AC symbol -- a coefficient (size > 0: skip `run` zeros, store), ZRL (15 / 0:
+                    // skip 16), EOB (0 / 0: the block ends) -- and ONE loop exit: a wave runs every path any of its lanes takes, and
+                    // each `break` / `continue` / `return` in the loop was another region the other lanes sat through.
+                    int kk = bad ? 64 : 1;
+                    while (kk < 64) {
                         if (b.n < 32) b.fill();
                         const int rs = huff_decode(b, ha);
-                        if (rs < 0) return false;
-                        const int r = rs >> 4;
-                        s = rs & 15;
-                        if (s == 0) {
-                            if (r != 15) break;
-                            kk += 16;
-                            continue;
-                        }
-                        kk += r;
-                        if (kk > 63) return false;
-                        blk[x.zz[kk]] = (short)jpeg_extend(b.get(s), s);
-                        ++kk;
+                        const int r = (rs >> 4) & 15, sz = rs < 0 ? 0 : rs & 15;
+                        const int at = kk + r;
+                        const int v = jpeg_extend0(b.take(sz), sz);
+                        bad = bad || rs < 0 || (sz && at > 63);
+                        if (sz && at <= 63) blk[x.zz[at]] = (short)v;
+                        kk = bad ? 64 : sz ? at + 1 : (r == 15 ? kk + 16 : 64);
                     }
                     // bits consumed that were never in the interval (zero bytes fed behind its end): the data ended inside it
                     // (witw_jpeg_decode_coef: -3)
-                    if (b.starved * 8 > b.n) return false;
+                    if (bad || b.starved * 8 > b.n) return false;
                 }
         }
         if (++mx == x.mcux) { mx = 0; ++my; }
@@ -629,33 +635,23 @@ __global__ __launch_bounds__(SS_T) void jpeg_selfsync_kernel(const JpegSyncDev* 
             tac = 2 + (q[6] & 1);
         };
         tables_of(bq);
+        // ONE decode site and one straight line for the DC symbol and the three kinds of AC symbol (coefficient, ZRL, EOB): the 64 lanes of
+        // a wave are in different blocks at different zig-zag positions, and the wave runs every path one of them takes
         while (b.bit_pos() < limit) {
             if (b.n < 32) b.fill();
-            bool finished = false;
-            if (kq == 0) {
-                const int sdc = huff_decode(b, &tab[tdc]);
-                if (sdc < 0 || sdc > 15) { b.buf <<= 1; b.n -= 1; continue; }      // not a code (only ever out of step): slide one bit on
-                int diff = 0;
-                if (sdc) diff = jpeg_extend(b.get(sdc), sdc);
-                if (WRITE && blk) blk[0] = (short)diff;
-                kq = 1;
-            } else {
-                const int rs = huff_decode(b, &tab[tac]);
-                if (rs < 0) { b.buf <<= 1; b.n -= 1; continue; }
-                const int r = rs >> 4, sz = rs & 15;
-                if (sz == 0) {
-                    if (r == 15) kq += 16; else finished = true;
-                } else {
-                    kq += r;
-                    const int v = jpeg_extend(b.get(sz), sz);
-                    if (WRITE && blk && kq < 64) blk[zz[kq]] = (short)v;
-                    ++kq;
-                }
-                if (kq >= 64) finished = true;
-            }
+            const bool dc = kq == 0;
+            const int rs = huff_decode(b, &tab[dc ? tdc : tac]);
+            const bool inval = rs < 0 || (dc && rs > 15);      // not a code (only ever out of step): slide one bit on
+            const int r = dc ? 0 : (rs >> 4) & 15, sz = inval ? 0 : (dc ? rs : rs & 15);
+            if (inval) { b.buf <<= 1; b.n -= 1; }
+            const unsigned at = kq + (unsigned)r;
+            const int v = jpeg_extend0(b.take(sz), sz);
+            if (WRITE && blk && !inval && (dc || (sz && at < 64u))) blk[dc ? 0 : zz[at]] = (short)v;
+            const unsigned nk = inval ? kq : dc ? 1u : sz ? at + 1u : (r == 15 ? kq + 16u : 64u);
+            const bool finished = nk >= 64u;
+            kq = finished ? 0u : nk;
             if (finished) {
                 ++done;
-                kq = 0;
                 bq = (bq + 1 == (unsigned)nb) ? 0 : bq + 1;
                 tables_of(bq);
                 if (WRITE) blk = locate(blk0 + done);
