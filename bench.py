@@ -958,9 +958,18 @@ def batch_sweep(a, rank, world, device, ops, compact=False):
             sb = StepBench('fov', 'infer', precision, B, a.fov, rank, world, device, share=base, pair=False)
             base = base or sb
             k = 5 if precision == 'fp32' else 10
-            ops.PROFILE_BY_KERNEL = {}
-            sb.run(k, 2)
-            byk, ops.PROFILE_BY_KERNEL = ops.PROFILE_BY_KERNEL, None
+            # (a timed window of 10-20 ms at the small batches: one host hiccup of 60 ms read as a fifth of the rate in two committed
+            # records, at a different point each time -- below B = 128 every figure is the better of two windows)
+            reps = 1 if B >= 128 else 2
+            byk = None
+            for _rep in range(reps):
+                ops.PROFILE_BY_KERNEL = {}
+                before = getattr(sb, 'ms', None)
+                sb.run(k, 2)
+                got, ops.PROFILE_BY_KERNEL = ops.PROFILE_BY_KERNEL, None
+                if before is None or sb.ms <= before:
+                    byk, best = got, (sb.value, sb.ms, sb.roofline)
+            sb.value, sb.ms, sb.roofline = best
             agg = {n: (sum(f for f, _, _ in v), sum(e0.elapsed_time(e1) for _, e0, e1 in v), len(v)) for n, v in byk.items()}
             top = max(agg, key=lambda n: agg[n][1])
             conv_ms = sum(v[1] for v in agg.values()) / k
@@ -978,12 +987,20 @@ def batch_sweep(a, rank, world, device, ops, compact=False):
                 # what test() / the validation phase of train() run at this batch (cvig_fov.PairEmbedder: the two encoders on two
                 # streams, the bf16 pair as one hipGraph): THIS is `value`; the plain step stays listed beside it
                 dr = StepBench('fov', 'infer', precision, B, a.fov, rank, world, device, share=base, pair=True).run(k, 3)
+                first = (dr.value, dr.ms)
+                dr.run(k, 1)
+                if first[1] < dr.ms:
+                    dr.value, dr.ms = first
                 pt['plain_one_stream_eager'] = {'value': pt['value'], 'ms_per_step': pt['ms_per_step']}
                 pt['value'], pt['ms_per_step'] = round(dr.value, 1), round(dr.ms, 3)
                 pt['pair_embedder'] = dict(dr.pair.stats)
                 del dr
             if sb.ms - conv_ms > 0.15 * sb.ms:        # a sixth of the step is not conv kernels: launch gaps matter -> one hipGraph
                 g = StepBench('fov', 'infer', precision, B, a.fov, rank, world, device, graph=True, share=base).run(k, 2)
+                first = (g.value, g.ms)
+                g.run(k, 1)
+                if first[1] < g.ms:
+                    g.value, g.ms = first
                 pt['graph_replay'] = {'value': round(g.value, 1), 'ms_per_step': round(g.ms, 3)}
                 del g
             out['points'].append(pt)
