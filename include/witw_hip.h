@@ -475,6 +475,9 @@ int witw_jpeg_huffman(const void* files, int n_files, int max_intervals, int* er
  * [n_files][6] = {file bytes, plan, coefficient area (zero-filled), file length, scratch of file length + 32 bytes (8-byte aligned),
  * 0}. Coefficients bit-identical to the host decoder's. */
 int witw_jpeg_huffman_selfsync(const void* files, int n_files, int* errors, void* stream);
+/* The same with the threads per file chosen by the caller (256, 512 or 1024; jpeg.decode_packed_multi: 1024 when the launch holds a file
+ * of 48 KB or more, else 512 -- larger files gain from shorter subsequences, smaller ones lose to the extra rounds). */
+int witw_jpeg_huffman_selfsync_threads(const void* files, int n_files, int threads, int* errors, void* stream);
 
 #ifdef __cplusplus
 }

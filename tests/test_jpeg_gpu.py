@@ -242,9 +242,10 @@ def test_data_path_with_restart_marker_files_equals_host_decode(tmp_path):
     assert torch.equal(torch.cat([d['polar'] for d in outs]), ref['polar']) and jpeg.entropy_errors() == 0
 
 
-def test_selfsync_decode_equals_the_host_coefficients():
-    """round 6, step two: files WITHOUT restart markers on jpeg_selfsync_kernel (one workgroup per file: unstuff, synchronise the 1024
-    subsequences round by round, number the blocks, write, DC prefix sums): coefficient blocks bit for bit those of
+@pytest.mark.parametrize('threads', [512, 256, 1024])
+def test_selfsync_decode_equals_the_host_coefficients(threads):
+    """round 6, step two: files WITHOUT restart markers on jpeg_selfsync_kernel (one workgroup of `threads` threads per file: unstuff,
+    synchronise as many subsequences round by round, number the blocks, write, DC prefix sums): coefficient blocks bit for bit those of
     witw_jpeg_decode_coef -- every fixture this decoder takes, fresh files of BASELINE's raw sizes, all samplings, optimised tables,
     very low and very high quality (long runs of EOB-only blocks / long codes), grey, sizes that are not multiples of the MCU."""
     from witw_amd import _lib, ops
@@ -274,7 +275,8 @@ def test_selfsync_decode_equals_the_host_coefficients():
         rows.append((rb.data_ptr(), pb.data_ptr(), coef.data_ptr() + int(f0) * 128, it.data.size, sc.data_ptr(), 0))
     files_t = torch.tensor(rows, dtype=torch.int64, device=dev)
     errors = torch.zeros((len(items),), dtype=torch.int32, device=dev)
-    _lib.check(_lib.load().witw_jpeg_huffman_selfsync(files_t.data_ptr(), len(items), errors.data_ptr(), ops._stream()), 'witw_jpeg_huffman_selfsync')
+    _lib.check(_lib.load().witw_jpeg_huffman_selfsync_threads(files_t.data_ptr(), len(items), threads, errors.data_ptr(), ops._stream()),
+               'witw_jpeg_huffman_selfsync_threads')
     torch.cuda.synchronize()
     assert int(errors.abs().sum()) == 0, errors
     got = coef.cpu().numpy()

@@ -132,6 +132,7 @@ SIGNATURES = {
     'witw_jpeg_to_rgb': (c_int, [c_void_p, c_void_p, c_int, c_longlong, c_void_p, c_void_p]),
     'witw_jpeg_huffman': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'witw_jpeg_huffman_selfsync': (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    'witw_jpeg_huffman_selfsync_threads': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'witw_rotate_nearest': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
 }
 

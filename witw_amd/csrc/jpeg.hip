@@ -780,18 +780,29 @@ extern "C" {
 // (WITW_SELFSYNC_THREADS = 256 | 512 | 1024).
 // files: DEVICE int64 [n_files][6] = {file bytes, plan, coefficient area (zero-filled), file length, scratch of file length + 32
 // bytes (8-byte aligned), 0}; errors as above. Coefficients bit-identical to witw_jpeg_decode_coef.
-int witw_jpeg_huffman_selfsync(const void* files, int n_files, int* errors, void* stream) {
+int witw_jpeg_huffman_selfsync_threads(const void* files, int n_files, int threads, int* errors, void* stream) {
     WITW_CHECK_ARG(files && errors, "jpeg_huffman_selfsync: null pointer");
     WITW_CHECK_ARG(n_files > 0, "jpeg_huffman_selfsync: %d files", n_files);
-    static const int threads = [] { const char* e = getenv("WITW_SELFSYNC_THREADS"); const int t = e ? atoi(e) : 512; return t; }();      // 256 / 512 / 1024 measured: 5.2 / 4.5 / 4.4 ms per 128 pairs alone, 512 best beside the encoders
-    if (threads >= 1024)
+    WITW_CHECK_ARG(threads == 256 || threads == 512 || threads == 1024, "jpeg_huffman_selfsync: %d threads per file (256, 512 or 1024)", threads);
+    if (threads == 1024)
         hipLaunchKernelGGL(jpeg_selfsync_kernel<1024>, dim3((unsigned)n_files), dim3(1024), 0, (hipStream_t)stream, (const JpegSyncDev*)files, errors);
-    else if (threads >= 512)
+    else if (threads == 512)
         hipLaunchKernelGGL(jpeg_selfsync_kernel<512>, dim3((unsigned)n_files), dim3(512), 0, (hipStream_t)stream, (const JpegSyncDev*)files, errors);
     else
         hipLaunchKernelGGL(jpeg_selfsync_kernel<256>, dim3((unsigned)n_files), dim3(256), 0, (hipStream_t)stream, (const JpegSyncDev*)files, errors);
     WITW_CHECK_LAUNCH("jpeg_huffman_selfsync");
     return WITW_OK;
+}
+
+// ... with 512 threads per file (WITW_SELFSYNC_THREADS = 256 | 512 | 1024 overrides). More threads = shorter subsequences but more rounds:
+// 113 KB files 1.7 / 1.4 / 1.3 ms per 128 files at 256 / 512 / 1024 threads, 22 KB files 0.79 / 0.76 / 0.89 (incl. IDCT + colour).
+int witw_jpeg_huffman_selfsync(const void* files, int n_files, int* errors, void* stream) {
+    static const int threads = [] {
+        const char* e = getenv("WITW_SELFSYNC_THREADS");
+        const int t = e ? atoi(e) : 512;
+        return t >= 1024 ? 1024 : t >= 512 ? 512 : 256;
+    }();
+    return witw_jpeg_huffman_selfsync_threads(files, n_files, threads, errors, stream);
 }
 
 // Entropy decoding of n_files JPEG files WITH RESTART MARKERS on the device, one thread per restart interval: files = DEVICE int64

@@ -35,6 +35,7 @@ CHECK_ERRORS = True    # decode_packed(host_buf=...) re-decodes files the device
 REPAIRED = [0]         # how many files that happened to
 SELFSYNC_MIN_BLOCKS = 96   # a marker-less file of at most this many blocks is decoded by ONE thread of the interval kernel (a 1024-thread
 #                            workgroup would find nothing to split)
+SELFSYNC_WIDE_BYTES = 48 * 1024   # a launch of the self-synchronising kernel that holds a file this large runs 1024 threads per file, else 512
 _ERRORS = []           # error flags (device int32 tensors) of the last batches decoded on the device: entropy_errors() sums them
 
 
@@ -353,8 +354,13 @@ def decode_packed_multi(parts, defer=False):
             srows = np.concatenate([rows[isy], (scratch.data_ptr() + soff)[:, None], np.zeros((isy.size, 1), np.int64)], axis=1).astype(np.int64)
             files_s = torch.from_numpy(np.ascontiguousarray(srows)).pin_memory().to(dev, non_blocking=True)
             e_s = errors if isy.size == dv.size else torch.zeros((int(isy.size),), dtype=torch.int32, device=dev)
-            _lib.check(_lib.load().witw_jpeg_huffman_selfsync(files_s.data_ptr(), int(isy.size), e_s.data_ptr(), ops._stream()),
-                       'witw_jpeg_huffman_selfsync')
+            # threads per file: 1024 when the launch holds a large file (shorter subsequences: 113 KB files 1.3 against 1.4 ms per 128 at
+            # 512 threads), 512 otherwise (22 KB files: 0.76 against 0.89 ms -- more rounds than the shorter subsequences save)
+            env_t = os.environ.get('WITW_SELFSYNC_THREADS')
+            threads = (1024 if int(env_t) >= 1024 else 512 if int(env_t) >= 512 else 256) if env_t else \
+                (1024 if int(d[dv[isy], 28].max()) >= SELFSYNC_WIDE_BYTES else 512)
+            _lib.check(_lib.load().witw_jpeg_huffman_selfsync_threads(files_s.data_ptr(), int(isy.size), threads, e_s.data_ptr(), ops._stream()),
+                       'witw_jpeg_huffman_selfsync_threads')
             if e_s is not errors:
                 errors[torch.from_numpy(isy).to(dev)] = e_s
             keep += [files_s, e_s, scratch]
