@@ -24,9 +24,9 @@ DESC_COLS = 30         # per image: coefficient byte offset, quantisation-table 
 # thread per restart interval (jpeg_huffman_kernel), without them a self-synchronising decode, one workgroup per file
 # (jpeg_selfsync_kernel). The worker only parses the header and scans for markers; the file bytes cross PCIe instead of the
 # coefficient blocks, and every launch covers all the files of a batch side (decode_packed_multi).
-# Modes: 'all' (default) = every such file; disk -> embeddings with the bf16 encoders and FOUR loader workers: 15.4-15.7 k pairs/s on files
-# with a restart marker every 1-2 MCUs, 14.6 k on ordinary files without markers -- 16 workers with host Huffman decoding reach 11.5-15.0 k
-# by box, the encoders alone 16.0-16.2 k; fp32 encoders 1,865 against 1,859 (profiles/r06_e2e_device_entropy_dev.json). 'restart' = only files with restart markers go to
+# Modes: 'all' (default) = every such file; disk -> embeddings with the bf16 encoders and FOUR loader workers: 16.1-16.4 k pairs/s on files
+# with a restart marker every 1-2 MCUs, 14.9 k on ordinary files without markers -- 16 workers with host Huffman decoding reach 14.8 k on
+# that box (11.5-15.0 k by box), the encoders alone 16.1-16.2 k; fp32 encoders 1,867 against 1,865 (profiles/r06_e2e_device_entropy_dev.json). 'restart' = only files with restart markers go to
 # the device decoder, the others are Huffman-decoded in the worker; 'off' / False = host Huffman decoding for all.
 # WITW_JPEG_DEVICE_ENTROPY = 0 | off | restart | 1 | all.
 _mode = os.environ.get('WITW_JPEG_DEVICE_ENTROPY', 'all').lower()
