@@ -1312,7 +1312,8 @@ namespace {
 template <int K>
 __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ D, float* __restrict__ vals,
                                                    long long* __restrict__ idx, int Bo, int Bs, int k, long long row_offset,
-                                                   int rps, float* __restrict__ pv, int* __restrict__ pi) {
+                                                   int rps, float* __restrict__ pv, int* __restrict__ pi,
+                                                   const float* __restrict__ tau, int tau_stride) {
     __shared__ float sv[4][K][64];
     __shared__ int si[4][K][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1325,9 +1326,14 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ D, 
         bv[j] = __builtin_inff();
         bi[j] = 0x7fffffff;
     }
+    // tau (optional): per query an UPPER BOUND of its k-th smallest distance -- the k-th smallest of the gallery's first rows, from a
+    // pass over those alone. Rows above it cannot be among the k best (ties at the bound still can) and are dropped by one compare:
+    // without it every split starts from empty lists and nearly every batch of its first thousand rows triggers an insertion
+    // (1.3 TB/s over the 2 GB matrix); with it the scan is loads and compares.
+    const float tq = (tau != nullptr && q < Bs) ? tau[(size_t)q * tau_stride] : __builtin_inff();
     auto offer = [&](float d, int o) {
         if (d != d) d = __builtin_inff();          // NaN sorts last
-        if (d < bv[K - 1] || (d == bv[K - 1] && o < bi[K - 1])) {
+        if (d <= tq && (d < bv[K - 1] || (d == bv[K - 1] && o < bi[K - 1]))) {
             float cv = d;
             int ci = o;
 #pragma unroll
@@ -1373,7 +1379,7 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ D, 
                 int cu = -1;
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {      // smallest admissible (distance, row) among the rows not yet dealt with
-                    const bool adm = ((live >> u) & 1u) && (d[u] < bv[K - 1] || (d[u] == bv[K - 1] && o + 4 * u < bi[K - 1]));
+                    const bool adm = ((live >> u) & 1u) && d[u] <= tq && (d[u] < bv[K - 1] || (d[u] == bv[K - 1] && o + 4 * u < bi[K - 1]));
                     if (!adm) live &= ~(1u << u);
                     if (adm && (cu < 0 || d[u] < cv)) { cv = d[u]; cu = u; }      // equal distances: the lower row (lower u) stays
                 }
@@ -1470,6 +1476,8 @@ __global__ __launch_bounds__(64) void topk_merge_kernel(const float* __restrict_
 
 }  // namespace
 
+constexpr int TOPK_SAMPLE = 1024;      // rows of the threshold pass of long galleries (witw_topk_smallest_ws)
+
 static int topk_splits(int Bo, int Bs) {
     // enough (query tile, split) workgroups to fill the chip several times over, at least 512 rows per split
     int s = cdiv(2048, cdiv(Bs, 64));
@@ -1483,14 +1491,22 @@ static void topk_launch(const float* D, float* values, long long* indices, int B
     const int splits = workspace ? topk_splits(Bo, Bs) : 1;
     if (splits <= 1) {
         hipLaunchKernelGGL((topk_kernel<K>), dim3(cdiv(Bs, 64)), dim3(256), 0, st, D, values, indices, Bo, Bs, k, row_offset, Bo,
-                           (float*)nullptr, (int*)nullptr);
+                           (float*)nullptr, (int*)nullptr, (const float*)nullptr, 0);
         return;
     }
     float* pv = (float*)workspace;
     int* pi = (int*)(pv + (size_t)splits * k * Bs);
     const int rps = cdiv(Bo, splits);
+    // long galleries: the k best of the first TOPK_SAMPLE rows first (into `values`, which the merge overwrites at the end); their k-th
+    // distance bounds every query's k-th distance over all rows and is the main pass's admission threshold
+    const float* tau = nullptr;
+    if (Bo >= 16 * TOPK_SAMPLE) {
+        hipLaunchKernelGGL((topk_kernel<K>), dim3(cdiv(Bs, 64)), dim3(256), 0, st, D, values, indices, TOPK_SAMPLE, Bs, k, row_offset,
+                           TOPK_SAMPLE, (float*)nullptr, (int*)nullptr, (const float*)nullptr, 0);
+        tau = values + (k - 1);
+    }
     hipLaunchKernelGGL((topk_kernel<K>), dim3(cdiv(Bs, 64), splits), dim3(256), 0, st, D, values, indices, Bo, Bs, k, row_offset,
-                       rps, pv, pi);
+                       rps, pv, pi, tau, k);
     hipLaunchKernelGGL((topk_merge_kernel<K>), dim3(cdiv(Bs, 64)), dim3(64), 0, st, pv, pi, values, indices, Bs, k, splits, row_offset);
 }
 
