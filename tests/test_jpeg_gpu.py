@@ -412,3 +412,48 @@ def test_grouped_prefetcher_decodes_both_sides_of_all_parts_together(tmp_path, m
     assert len(outs) == 1 and outs[0]['surface'].shape[0] == 4
     assert len(jpeg._ERRORS) == n_launch + 1                  # ONE device-entropy decode for the 8 files
     assert torch.equal(outs[0]['surface'], ref['surface']) and torch.equal(outs[0]['polar'], ref['polar']) and jpeg.entropy_errors() == 0
+
+
+@pytest.mark.parametrize('seed', [5, 6, 7])
+def test_device_decode_of_randomly_parametrised_files_equals_pillow(seed):
+    """the default data path (every baseline Huffman file entropy-decoded on the device) over 96 files whose size (8..700, mostly not a
+    multiple of the MCU), sampling (4:4:4 / 4:2:2 / 4:2:0 / grey), quality (1..100), Huffman tables (standard / optimised) and restart
+    interval (none, 1..5 MCU rows, 1..40 MCUs) are drawn at random: every image byte for byte Pillow's, nothing flagged. One batch, one set
+    of launches -- interval kernel and self-synchronising kernel side by side."""
+    from PIL import Image
+    assert jpeg.DEVICE_ENTROPY == 'all'
+    del jpeg._ERRORS[:]
+    g = np.random.Generator(np.random.Philox(key=[18, seed]))
+    raws = []
+    for i in range(96):
+        h, w = int(g.integers(8, 701)), int(g.integers(8, 701))
+        if i % 7 == 0:
+            h, w = int(g.integers(8, 40)), int(g.integers(8, 40))      # a few tiny ones (a single MCU or two)
+        sub = int(g.integers(0, 4))
+        kw = {'optimize': True} if g.integers(0, 2) else {}
+        r = int(g.integers(0, 3))
+        if r == 1:
+            kw['restart_marker_rows'] = int(g.integers(1, 6))
+        elif r == 2:
+            kw['restart_marker_blocks'] = int(g.integers(1, 41))
+        q = int(g.integers(1, 101))
+        if sub == 3:      # grey
+            small = g.integers(0, 256, size=(h // 8 + 2, w // 8 + 2), dtype=np.uint8)
+            a = np.asarray(Image.fromarray(small).resize((w, h), Image.BICUBIC))
+            a = np.clip(a.astype(np.int16) + g.integers(-15, 16, size=(h, w)), 0, 255).astype(np.uint8)
+            bio = io.BytesIO()
+            Image.fromarray(a).save(bio, 'JPEG', quality=q, **kw)
+            raws.append(bio.getvalue())
+        else:
+            raws.append(_fresh(g, h, w, sub, q, **kw))
+    items = [jpeg.open_file(r) for r in raws]
+    assert all(it is not None for it in items)
+    buf, desc, _k = jpeg.pack(items)
+    d = desc.numpy()
+    assert int(d[:, 26].sum()) == len(raws)                     # all of them travel as file bytes
+    assert (d[:, 29] > 1).any() and (d[:, 29] == 1).any()       # both kernels have work
+    out = jpeg.decode(items, torch.device('cuda:0'))
+    for k, (o, r) in enumerate(zip(out, raws)):
+        ref = np.asarray(Image.open(io.BytesIO(r)))
+        np.testing.assert_array_equal(o.cpu().numpy(), ref if ref.ndim == 3 else ref[:, :, None], err_msg='file %d' % k)
+    assert jpeg.entropy_errors() == 0
