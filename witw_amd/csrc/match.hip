@@ -1497,6 +1497,7 @@ __global__ __launch_bounds__(64) void topk_merge_kernel(const float* __restrict_
 }  // namespace
 
 constexpr int TOPK_SAMPLE = 1024;      // rows of the threshold pass of long galleries (witw_topk_smallest_ws)
+constexpr int TOPK_SAMPLE_SPLITS = 8;  // ... ranked in this many row splits
 
 static int topk_splits(int Bo, int Bs) {
     // enough (query tile, split) workgroups to fill the chip several times over, at least 512 rows per split
@@ -1520,9 +1521,11 @@ static void topk_launch(const float* D, float* values, long long* indices, int B
     // long galleries: the k best of the first TOPK_SAMPLE rows first (into `values`, which the merge overwrites at the end); their k-th
     // distance bounds every query's k-th distance over all rows and is the main pass's admission threshold
     const float* tau = nullptr;
-    if (Bo >= 16 * TOPK_SAMPLE) {
-        hipLaunchKernelGGL((topk_kernel<K>), dim3(cdiv(Bs, 64)), dim3(256), 0, st, D, values, indices, TOPK_SAMPLE, Bs, k, row_offset,
-                           TOPK_SAMPLE, (float*)nullptr, (int*)nullptr, (const float*)nullptr, 0);
+    if (Bo >= 16 * TOPK_SAMPLE && splits >= TOPK_SAMPLE_SPLITS) {      // (the sample is ranked in row splits too: the workspace is free until the main pass)
+        hipLaunchKernelGGL((topk_kernel<K>), dim3(cdiv(Bs, 64), TOPK_SAMPLE_SPLITS), dim3(256), 0, st, D, values, indices, TOPK_SAMPLE, Bs, k,
+                           row_offset, TOPK_SAMPLE / TOPK_SAMPLE_SPLITS, pv, pi, (const float*)nullptr, 0);
+        hipLaunchKernelGGL((topk_merge_kernel<K>), dim3(cdiv(Bs, 64)), dim3(64), 0, st, pv, pi, values, indices, Bs, k, TOPK_SAMPLE_SPLITS,
+                           row_offset);
         tau = values + (k - 1);
     }
     hipLaunchKernelGGL((topk_kernel<K>), dim3(cdiv(Bs, 64), splits), dim3(256), 0, st, D, values, indices, Bo, Bs, k, row_offset,
